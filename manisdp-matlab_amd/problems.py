@@ -1,0 +1,450 @@
+"""Instance readers and generators that feed the three ManiSDP entry points.
+
+These are the callers' side of the hot path: they emit
+exactly the SeDuMi-format data ``(At, b, c, K)`` / sparse ``C`` that the
+reference entry points consume.  Each function cites the reference file it
+restates.  Nothing here touches the GPU.
+
+Conventions
+-----------
+* ``At`` is ``scipy.sparse.csc_matrix`` of shape ``(n*n, m)``; column ``k`` is the
+  column-major ``vec`` of the symmetric constraint matrix ``A_k``
+  (reference: src/basicfunction/bqpmom.m:91, example/example_theta.m:39).
+* ``b`` is a dense ``(m,)`` float64 vector, ``c`` a dense ``(n*n,)`` vector or a
+  sparse ``(n*n, 1)`` matrix, ``K = {"s": n}``.
+"""
+from __future__ import annotations
+
+import gzip
+import io
+import os
+import re
+from itertools import combinations
+from math import comb
+
+import numpy as np
+import scipy.sparse as sp
+
+__all__ = [
+    "read_gset", "gset_laplacian", "maxcut_cost_matrix", "toroidal_grid_maxcut",
+    "from_sdpa", "get_basis", "bqpmom", "qsmom", "theta_problem",
+    "dense_unitdiag_cost", "vec_index",
+]
+
+
+def _open_text(path):
+    if str(path).endswith(".gz"):
+        return io.TextIOWrapper(gzip.open(path, "rb"))
+    return open(path, "r")
+
+
+# --------------------------------------------------------------------------- Gset
+def read_gset(path):
+    """Read a Gset graph file: header ``nv ne`` then ``i j w`` lines, 1-based.
+
+    Reference: src/basicfunction/Laplacian.m:2-4 (``readmatrix``)."""
+    with _open_text(path) as fh:
+        head = fh.readline().split()
+        nv, ne = int(head[0]), int(head[1])
+        edges = np.loadtxt(fh, ndmin=2, max_rows=ne)
+    i = edges[:, 0].astype(np.int64) - 1
+    j = edges[:, 1].astype(np.int64) - 1
+    w = edges[:, 2].astype(np.float64)
+    return nv, i, j, w
+
+
+def gset_laplacian(path):
+    """Graph Laplacian with the reference's semantics (Laplacian.m:5-11):
+    off-diagonals are *assigned* ``-w`` (a repeated edge overwrites), the
+    diagonal accumulates ``+w`` for every listed edge."""
+    nv, i, j, w = read_gset(path)
+    # "last assignment wins" for repeated (i,j): keep the last occurrence
+    lo, hi = np.minimum(i, j), np.maximum(i, j)
+    key = lo * nv + hi
+    _, last = np.unique(key[::-1], return_index=True)
+    last = len(key) - 1 - last
+    oi, oj, ow = i[last], j[last], w[last]
+    diag = np.zeros(nv)
+    np.add.at(diag, i, w)
+    np.add.at(diag, j, w)
+    rows = np.concatenate([oi, oj, np.arange(nv)])
+    cols = np.concatenate([oj, oi, np.arange(nv)])
+    vals = np.concatenate([-ow, -ow, diag])
+    L = sp.coo_matrix((vals, (rows, cols)), shape=(nv, nv)).tocsr()
+    return L
+
+
+def maxcut_cost_matrix(path):
+    """``C = -L/4`` as in example/example_maxcut.m:10-11 (sparse CSR, symmetric).
+
+    Explicit zeros on the diagonal are dropped, as MATLAB's ``sparse`` does."""
+    C = (-0.25 * gset_laplacian(path)).tocsr()
+    C.eliminate_zeros()
+    C.sort_indices()
+    return C
+
+
+def toroidal_grid_maxcut(rows, cols, seed=0):
+    """Synthetic G81-shaped instance: 2-D toroidal grid, every vertex of degree 4,
+    i.i.d. +-1 edge weights (Gset G81 is the 100 x 200 instance of this family).
+    Returns ``C = -L/4``."""
+    rng = np.random.default_rng(seed)
+    n = rows * cols
+    idx = np.arange(n).reshape(rows, cols)
+    right = np.roll(idx, -1, axis=1)
+    down = np.roll(idx, -1, axis=0)
+    i = np.concatenate([idx.ravel(), idx.ravel()])
+    j = np.concatenate([right.ravel(), down.ravel()])
+    w = rng.choice([-1.0, 1.0], size=i.size)
+    diag = np.zeros(n)
+    np.add.at(diag, i, w)
+    np.add.at(diag, j, w)
+    r = np.concatenate([i, j, np.arange(n)])
+    c = np.concatenate([j, i, np.arange(n)])
+    v = np.concatenate([-w, -w, diag])
+    C = (-0.25 * sp.coo_matrix((v, (r, c)), shape=(n, n))).tocsr()
+    C.eliminate_zeros()
+    C.sort_indices()
+    return C
+
+
+# --------------------------------------------------------------------------- SDPA
+def from_sdpa(path):
+    """SDPA sparse format -> SeDuMi ``(At, b, c, K)`` for a single PSD block.
+
+    Restates src/basicfunction/fromsdpa.m:40-155 for the case the three entry
+    points accept (one semidefinite block, ``K.s = n``): ``c = -vec(F0)``
+    (:127-130), matrices ``1..m`` become the columns of ``At`` (:141-144), both
+    symmetrised from the upper triangle."""
+    with _open_text(path) as fh:
+        lines = [ln for ln in fh.read().splitlines()]
+    # skip comment lines (start with " or *)
+    lines = [ln for ln in lines if ln.strip() and ln.lstrip()[0] not in '"*']
+    m = int(re.split(r"[\s=]+", lines[0].strip())[0])
+    nblocks = int(re.split(r"[\s=]+", lines[1].strip())[0])
+    dims = [int(t) for t in re.sub(r"[\.\,(){}]", " ", lines[2]).split()[:nblocks]]
+    if nblocks != 1 or dims[0] <= 1:
+        raise ValueError("from_sdpa: only a single semidefinite block is supported "
+                         "(the three ManiSDP entry points take K.s = n)")
+    n = dims[0]
+    b = np.array([float(t) for t in re.sub(r"[\,(){}]", " ", lines[3]).split()[:m]])
+    if b.size != m:
+        raise ValueError("from_sdpa: right-hand side has the wrong dimension")
+    E = np.loadtxt(io.StringIO("\n".join(lines[4:])), ndmin=2)
+    matno = E[:, 0].astype(np.int64)
+    ii = E[:, 2].astype(np.int64) - 1
+    jj = E[:, 3].astype(np.int64) - 1
+    vv = E[:, 4].astype(np.float64)
+    off = ii != jj
+    # column-major vec index of (i, j): i + j*n ; mirror entry for off-diagonals
+    r = np.concatenate([ii + jj * n, (jj + ii * n)[off]])
+    k = np.concatenate([matno, matno[off]])
+    v = np.concatenate([vv, vv[off]])
+    obj = k == 0
+    c = -sp.coo_matrix((v[obj], (r[obj], np.zeros(obj.sum(), dtype=np.int64))),
+                       shape=(n * n, 1)).tocsc()
+    At = sp.coo_matrix((v[~obj], (r[~obj], k[~obj] - 1)), shape=(n * n, m)).tocsc()
+    At.eliminate_zeros()
+    c.eliminate_zeros()
+    return At, b, c, {"s": n}
+
+
+# ------------------------------------------------------------------ monomial bases
+def get_basis(n, d):
+    """All exponent vectors of degree <= d in n variables, as columns, in the
+    reference's order (src/basicfunction/get_basis.m:1-33; order relation
+    comp.m:1-23): graded; inside one degree ascending in
+    ``(a_n, a_{n-1}, ..., a_1)``.  Returned as an ``(n, L)`` int8 array."""
+    cols = []
+    for deg in range(d + 1):
+        # enumerate multisets of size deg over variables; sort by the comp order
+        block = []
+        for combo in _multisets(n, deg):
+            a = np.zeros(n, dtype=np.int8)
+            for v in combo:
+                a[v] += 1
+            block.append(a)
+        block.sort(key=lambda a: tuple(a[::-1]))
+        cols.extend(block)
+    return np.array(cols, dtype=np.int8).T.reshape(n, -1)
+
+
+def _multisets(n, k):
+    from itertools import combinations_with_replacement
+    return combinations_with_replacement(range(n), k)
+
+
+def _get_basis_literal(n, d):
+    """Line-by-line restatement of get_basis.m:1-33 (used by the tests to pin
+    :func:`get_basis`'s ordering against the reference's own iteration)."""
+    lb = comb(n + d, d)
+    basis = np.zeros((n, lb), dtype=np.int64)
+    i = 0
+    t = 0  # 0-based column of "t" (MATLAB t = 1)
+    while i < d + 1:
+        t += 1
+        if t >= lb:
+            # MATLAB grows the array by one zero column here and leaves the loop
+            # right after (i reaches d+1); we simply stop.
+            if basis[n - 1, t - 1] == i:
+                i += 1
+                continue
+            raise AssertionError("get_basis: ran past the expected length")
+        if basis[n - 1, t - 1] == i:
+            if i < d:
+                basis[0, t] = i + 1
+            i += 1
+        else:
+            j = 0
+            while basis[j, t - 1] == 0:
+                j += 1
+            basis[:, t] = basis[:, t - 1]
+            if j == 0:
+                basis[0, t] -= 1
+                basis[1, t] += 1
+            else:
+                basis[0, t] = basis[j, t] - 1
+                basis[j, t] = 0
+                basis[j + 1, t] += 1
+    return basis
+
+
+def vec_index(i, j, n):
+    """0-based column-major linear index of entry (i, j) of an n x n matrix."""
+    return i + j * n
+
+
+def _mono_key(vars_sorted):
+    return tuple(vars_sorted)
+
+
+def _sp_order_key(mono, n):
+    """Sort key implementing comp.m for a monomial given as a sorted variable
+    multiset: (degree, a_n, ..., a_1)."""
+    a = [0] * n
+    for v in mono:
+        a[v] += 1
+    return (len(mono),) + tuple(a[::-1])
+
+
+def bqpmom(n, Q, e):
+    """Second-order moment relaxation of ``min x'Qx + e'x, x_i^2 = 1`` in SeDuMi
+    format.  Restates src/basicfunction/bqpmom.m:6-117 (same basis order, same
+    constraint order, same coefficients).  Returns ``(At, b, c, K)`` with ``c``
+    sparse ``(mb^2, 1)`` like the reference (:114-115)."""
+    Q = np.asarray(Q, dtype=np.float64)
+    e = np.asarray(e, dtype=np.float64).ravel()
+    # basis: multilinear monomials of degree <= 2 (bqpmom.m:7-15), in get_basis order
+    basis = [()] + [(k,) for k in range(n)]
+    # degree 2, ordered by (a_n..a_1): for i=1..n-1 (0-based second var), j<i
+    basis += [(j, i) for i in range(1, n) for j in range(i)]
+    mb = len(basis)
+    assert mb == 1 + n + n * (n - 1) // 2
+    # sp: monomials of degree <= 4, exponents <= 2, at least one odd exponent (:16-23)
+    sp_list = []
+    for deg in range(1, 5):
+        for combo in _multisets(n, deg):
+            cnt = {}
+            for v in combo:
+                cnt[v] = cnt.get(v, 0) + 1
+            if max(cnt.values()) > 2:
+                continue
+            if all(c % 2 == 0 for c in cnt.values()):
+                continue
+            sp_list.append(combo)
+    sp_list.sort(key=lambda mno: _sp_order_key(mno, n))
+    lsp = len(sp_list)
+    sp_index = {mno: k for k, mno in enumerate(sp_list)}
+    # mm{ind}: pairs (i<j) of basis elements whose product is sp(ind) (:25-32)
+    mm = [[] for _ in range(lsp)]
+    for i in range(mb):
+        bi = basis[i]
+        for j in range(i + 1, mb):
+            mono = tuple(sorted(bi + basis[j]))
+            mm[sp_index[mono]].append((i, j))
+    ncons = mb * (mb + 1) // 2 - lsp + n * (mb - 1) - mb + 1
+    rows, cols, vals = [0], [0], [1.0]
+    b = np.zeros(ncons)
+    b[0] = 1.0
+    # X11/2 - Xii/2 = 0 for the degree-1 diagonal (:39-43)
+    for i in range(1, n + 1):
+        rows += [0, i * mb + i]
+        cols += [i, i]
+        vals += [0.5, -0.5]
+    l = n + 1
+    # two diagonal ties per degree-2 basis element (:46-52)
+    for i in range(n + 1, mb):
+        c1, c2 = basis[i][0] + 1, basis[i][1] + 1
+        rows += [c1 * mb + c1, i * mb + i, c2 * mb + c2, i * mb + i]
+        cols += [l, l, l + 1, l + 1]
+        vals += [0.5, -0.5, 0.5, -0.5]
+        l += 2
+    # loa{i}: linear indices of both orientations of every pair (:53-59)
+    loa = []
+    for k in range(lsp):
+        arr = []
+        for (i, j) in mm[k]:
+            arr += [j * mb + i, i * mb + j]
+        loa.append(arr)
+    # x_k^2 * x^alpha == x^alpha (:60-78)
+    for k in range(n):
+        for i in range(1, mb):
+            if k not in basis[i]:
+                ind1 = sp_index[tuple(sorted(basis[i] + (k, k)))]
+                ind2 = sp_index[basis[i]]
+                l1, l2 = len(loa[ind1]), len(loa[ind2])
+                rows += loa[ind1] + loa[ind2]
+                cols += [l] * (l1 + l2)
+                if l1 < l2:
+                    vals += [1.0] * l1 + [-l1 / l2] * l2
+                else:
+                    vals += [l2 / l1] * l1 + [-1.0] * l2
+                l += 1
+    # equal-monomial ties inside each class (:80-90)
+    for k in range(lsp):
+        firsts = [pr[0] for pr in mm[k]]
+        idx = int(np.argmax(firsts))  # first maximum, like MATLAB's max
+        for j in range(len(mm[k])):
+            if j != idx:
+                rows += loa[k][2 * idx:2 * idx + 2] + loa[k][2 * j:2 * j + 2]
+                cols += [l, l, l, l]
+                vals += [0.5, 0.5, -0.5, -0.5]
+                l += 1
+    assert l == ncons, (l, ncons)
+    At = sp.coo_matrix((np.array(vals), (np.array(rows), np.array(cols))),
+                       shape=(mb * mb, ncons)).tocsc()
+    # objective (:93-114)
+    rows = list(range(1, n + 1))
+    cols = list(range(1, n + 1))
+    vals = list(np.diag(Q))
+    for i in range(n):
+        for (a, bb) in mm[i]:
+            rows += [a, bb]
+            cols += [bb, a]
+        vals += [e[i] / (2 * len(mm[i]))] * (2 * len(mm[i]))
+    ind = n
+    for i in range(1, n):
+        for j in range(i):
+            for (a, bb) in mm[ind]:
+                rows += [a, bb]
+                cols += [bb, a]
+            vals += [Q[j, i] / len(mm[ind])] * (2 * len(mm[ind]))
+            ind += 1
+    C = sp.coo_matrix((np.array(vals), (np.array(rows), np.array(cols))), shape=(mb, mb)).tocsc()
+    c = C.reshape((mb * mb, 1), order="F").tocsc()
+    return At, b, c, {"s": mb}
+
+
+def qsmom(n, coe):
+    """Second-order moment relaxation of ``min coe'[x]_4, |x|^2 = 1`` in SeDuMi
+    format.  Restates src/basicfunction/qsmom.m:6-116.  The moment matrix has
+    constant trace 3 (README.md:82)."""
+    coe = np.asarray(coe, dtype=np.float64).ravel()
+    basis_arr = get_basis(n, 2)
+    mb = basis_arr.shape[1]
+    basis = [tuple(v for v in range(n) for _ in range(int(basis_arr[v, k]))) for k in range(mb)]
+    sp_arr = get_basis(n, 4)
+    lsp = sp_arr.shape[1]
+    sp_list = [tuple(v for v in range(n) for _ in range(int(sp_arr[v, k]))) for k in range(lsp)]
+    sp_index = {mno: k for k, mno in enumerate(sp_list)}
+    if coe.size != lsp:
+        raise ValueError(f"qsmom: coe must have length C(n+4,4) = {lsp}")
+    mm = [[] for _ in range(lsp)]
+    for i in range(mb):
+        for j in range(i, mb):
+            mm[sp_index[tuple(sorted(basis[i] + basis[j]))]].append((i, j))
+    ncons = mb * (mb + 1) // 2 - lsp + mb + 1
+    rows, cols, vals = [0], [0], [1.0]
+    b = np.zeros(ncons)
+    b[0] = 1.0
+    l = 1
+    loa = []
+    for k in range(lsp):
+        arr = []
+        for (i, j) in mm[k]:
+            arr += [j * mb + i, i * mb + j]
+        loa.append(arr)
+
+    def class_rows(ind):
+        out = []
+        for t, (i, j) in enumerate(mm[ind]):
+            if i == j:
+                out.append(loa[ind][2 * t + 1])
+            else:
+                out += loa[ind][2 * t:2 * t + 2]
+        return out
+
+    # sphere constraint times every basis element (:33-65)
+    for i in range(mb):
+        for k in range(n):
+            r1 = class_rows(sp_index[tuple(sorted(basis[i] + (k, k)))])
+            rows += r1
+            cols += [l] * len(r1)
+            vals += [1.0 / len(r1)] * len(r1)
+        r2 = class_rows(sp_index[basis[i]])
+        rows += r2
+        cols += [l] * len(r2)
+        vals += [-1.0 / len(r2)] * len(r2)
+        l += 1
+    # equal-monomial ties (:67-92)
+    for k in range(lsp):
+        firsts = [pr[0] for pr in mm[k]]
+        idx = int(np.argmax(firsts))
+        for j in range(len(mm[k])):
+            if j == idx:
+                continue
+            if mm[k][idx][0] == mm[k][idx][1]:
+                rows += [loa[k][2 * idx + 1]]; cols += [l]; vals += [1.0]
+            else:
+                rows += loa[k][2 * idx:2 * idx + 2]; cols += [l, l]; vals += [0.5, 0.5]
+            if mm[k][j][0] == mm[k][j][1]:
+                rows += [loa[k][2 * j + 1]]; cols += [l]; vals += [-1.0]
+            else:
+                rows += loa[k][2 * j:2 * j + 2]; cols += [l, l]; vals += [-0.5, -0.5]
+            l += 1
+    assert l == ncons, (l, ncons)
+    At = sp.coo_matrix((np.array(vals), (np.array(rows), np.array(cols))),
+                       shape=(mb * mb, ncons)).tocsc()
+    rows, cols, vals = [], [], []
+    for k in range(lsp):
+        s = 0
+        for (i, j) in mm[k]:
+            if i == j:
+                rows.append(i); cols.append(j); s += 1
+            else:
+                rows += [i, j]; cols += [j, i]; s += 2
+        vals += [coe[k] / s] * s
+    C = sp.coo_matrix((np.array(vals), (np.array(rows), np.array(cols))), shape=(mb, mb)).tocsc()
+    c = C.reshape((mb * mb, 1), order="F").tocsc()
+    return At, b, c, {"s": mb}
+
+
+# -------------------------------------------------------------------------- theta
+def theta_problem(n, ndraws=None, seed=1):
+    """Lovasz-theta-like unit-trace SDP of example/example_theta.m:2-39:
+    random edge set Omega (i<j, de-duplicated, sorted by rows), ``C = -ones``,
+    constraints ``X_ij + X_ji = 0`` on Omega and ``tr X = 1`` as the LAST column,
+    ``b = [0 ... 0 1]``.  (NumPy RNG replaces MATLAB's ``randi``.)"""
+    rng = np.random.default_rng(seed)
+    if ndraws is None:
+        ndraws = 10 * n
+    om = rng.integers(0, n, size=(ndraws, 2))
+    om = om[om[:, 0] < om[:, 1]]
+    om = np.unique(om, axis=0)
+    m = om.shape[0]
+    i, j = om[:, 0], om[:, 1]
+    rows = np.concatenate([i * n + j, j * n + i, np.arange(n) * n + np.arange(n)])
+    cols = np.concatenate([np.arange(m), np.arange(m), np.full(n, m)])
+    vals = np.ones(rows.size)
+    At = sp.coo_matrix((vals, (rows, cols)), shape=(n * n, m + 1)).tocsc()
+    b = np.zeros(m + 1)
+    b[m] = 1.0
+    c = -np.ones(n * n)
+    return At, b, c, {"s": n}
+
+
+def dense_unitdiag_cost(n, seed=0):
+    """Random dense symmetric cost ``C = (G + G')/(2 sqrt(n))``."""
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((n, n))
+    return (G + G.T) / (2.0 * np.sqrt(n))
