@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- tCG Hess-vec throughput of the device-resident RTR/tCG hot path.
+
+Workload (BASELINE.json configs[1]): MaxCut SDP of Gset G81 (n = 20000, 92 644 stored
+nonzeros in C = -L/4) through the ManiSDP_onlyunitdiag path, oblique manifold, p = 32.
+A *step* is one complete ``trustregions(problem, Y, opts)`` call (reference defaults
+TR_maxiter = 40, TR_maxinner = 100) from the same seeded start point with all problem
+data and the factor already resident in HBM.  ``value`` = Hess-vec products executed by
+all ranks' job / wall time, i.e. whole-tCG throughput (Hess-vec + every vector update,
+retraction and cost evaluation of the solve).
+
+N > 1 (one process per GPU, RCCL): rows of the factor are sharded over the ranks with an
+all-gather of the thin n x p direction before every S*U and an all-reduce of the partial
+sums; the instance is the same toroidal-grid family scaled to n = 20000 * N rows so the
+per-GPU work is fixed ("weak" scaling); value counts 20000-row-equivalent Hess-vecs.
+
+One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(C, Y0, budget_s=20.0):
+    """Oracle ("port") timed on the host: the same RTR call, bounded to ~budget_s."""
+    from oracle import manisdp_ref, manopt_rtr
+    n, p = Y0.shape
+    prob = manisdp_ref._OnlyUnitDiagProblem(C, n, p, q1="correct")
+    # size the sample: one TR iteration = up to 100 Hess-vecs; add iterations until the budget is used
+    t0 = time.time()
+    hv = 0
+    Y = Y0.copy()
+    iters = 0
+    while time.time() - t0 < budget_s and iters < 40:
+        Y, _, info = manopt_rtr.trustregions(prob, Y, 1, 100, 1e-8)
+        hv += info.hessvecs
+        iters += 1
+        if info.gradnorm < 1e-8:
+            break
+    dt = time.time() - t0
+    return {"value": hv / dt, "unit": "Hess-vec/s", "cores": 1, "kind": "port",
+            "sample": f"{iters} TR iterations ({hv} Hess-vecs, tCG + retraction + cost) of the same G81 p=32 "
+                      f"RTR call in the NumPy/SciPy oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--p", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kkt", action="store_true", help="also time the full G81 solve to KKT 1e-8")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    N = args.gpus
+    if world != N and N > 1:
+        raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    _lib.set_device(local_rank)
+
+    dist = None
+    if N > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    p = args.p
+    g81 = os.path.join(ROOT, "tests", "golden", "G81.txt.gz")
+    if N == 1 and os.path.exists(g81):
+        C = problems.maxcut_cost_matrix(g81)
+        workload = "Gset G81 MaxCut, ManiSDP_onlyunitdiag RTR call, n=20000, p=%d" % p
+        data_kind = "Gset G81 (public instance shipped with the reference; fixture copy)"
+    else:
+        C = problems.toroidal_grid_maxcut(100 * N, 200, seed=81)
+        workload = "G81-family toroidal grid MaxCut (%dx200, +-1 weights), n=%d, p=%d, rows sharded over %d GPUs" % (
+            100 * N, 20000 * N, p, N)
+        data_kind = "synthetic"
+    n = C.shape[0]
+    rng = np.random.default_rng(0)
+    Y0 = rng.standard_normal((n, p))
+    Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+
+    h = _lib.Handle.onlyunitdiag(C, pcap=p)
+    if N > 1:
+        import torch
+        uid = [_lib.Handle.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        h.comm_init(N, rank, uid[0])
+    opts = _lib.default_opts(maxiter=40, maxinner=100, tolgradnorm=1e-8)
+
+    def step():
+        h.set_point(Y0)          # device-side reset of the resident point (untimed cost is tiny vs the solve)
+        return h.rtr(opts)
+
+    def sync():
+        if N > 1:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    hv = 0
+    rtr_s = 0.0
+    for _ in range(args.steps):
+        st = step()
+        hv += st.hessvecs
+        rtr_s += st.seconds
+    sync()
+    dt = time.perf_counter() - t0
+    if N > 1:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel: the Hess-vec (S*U) kernel, timed with HIP events on the library's stream
+    h.set_point(Y0)
+    ms, abytes, aflops = h.bench_hessvec(200)
+    trip_ms = h.bench_tcg_trip(200)
+    achieved = abytes / (ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "tCG Hess-vec prods/sec (n,p), G81 MaxCut",
+        "value": hv * N / dt,
+        "unit": "Hess-vec/s",
+        "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": data_kind,
+        "config": {"workload": workload, "n": n, "p": p, "nnz_C": int(C.nnz),
+                   "TR_maxiter": 40, "TR_maxinner": 100, "hessvecs_per_step": hv / args.steps,
+                   "parallelism": "rows%d" % N},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_hess_sparse_obl", "kernel_us": ms * 1e3,
+                     "algorithmic_bytes_per_launch": abytes},
+        "tcg_trip_us": trip_ms * 1e3,
+        "hessvec_per_s_in_rtr": hv / rtr_s if rtr_s > 0 else None,
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(C, Y0) if N == 1 else None
+    if args.kkt and N == 1 and rank == 0:
+        from manisdp_matlab_amd import solvers
+        t1 = time.perf_counter()
+        _, obj, data = solvers.ManiSDP_onlyunitdiag(C, {"p0": 2}, verbose=False)
+        out["g81_time_to_kkt_s"] = time.perf_counter() - t1
+        out["g81_obj"] = obj
+        out["g81_dinf"] = data["dinf"]
+    h.close()
+    if N > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

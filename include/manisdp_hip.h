@@ -1,0 +1,197 @@
+/*
+ * manisdp_hip.h -- C ABI of libmanisdp_hip.so, the MI355X (gfx950) hot path of
+ * ManiSDP's three primal entry points.
+ *
+ * The reference (wangjie212/ManiSDP-matlab) has no FFI on this path: its operator
+ * interface is Manopt's problem struct consumed by trustregions()
+ *   problem.cost / problem.grad / problem.hess / problem.M.*
+ *   (src/primal/ManiSDP_onlyunitdiag.m:28-30,39,43; ManiSDP_unitdiag.m:41-43,53,57;
+ *    ManiSDP_unittrace.m:42-44,53,57).
+ * This library is cut AT the trustregions() call: the factor Y stays resident in
+ * HBM for the whole Riemannian trust-region solve and never crosses PCIe inside
+ * tCG.  The only native-call precedent in the reference is the MEX gateway of
+ * src/C-files/<fn>.cpp (plain double* via mxGetPr, errors via mexErrMsgIdAndTxt);
+ * the MEX shim in manisdp-matlab_amd/matlab/manisdp_mex.cpp binds exactly the
+ * entry points declared here.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative MSDP_E* code otherwise;
+ *    msdp_last_error() returns a human-readable message (no exceptions cross the ABI);
+ *  - all floating-point data is IEEE double (the reference is fp64 throughout);
+ *  - sparse inputs are MATLAB-style compressed columns with 64-bit indices
+ *    (mwIndex Jc/Ir, 0-based);
+ *  - factor layout at the boundary is the reference's own:
+ *      oblique entry points (onlyunitdiag, unitdiag): Y is p x n column-major
+ *        (each point's p-vector contiguous; ManiSDP_unitdiag.m:59 X = Y'*Y);
+ *      unittrace: Y is n x p column-major (ManiSDP_unittrace.m:59 X = Y*Y');
+ *  - the library is single-caller per handle (MATLAB's interpreter thread).
+ */
+#ifndef MANISDP_HIP_H
+#define MANISDP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSDP_OK              0
+#define MSDP_EINVAL         -1   /* bad argument                                 */
+#define MSDP_EHIP           -2   /* HIP runtime error                            */
+#define MSDP_ENOMEM         -3   /* device or host allocation failed             */
+#define MSDP_ESTATE         -4   /* call order violated (e.g. no point resident) */
+#define MSDP_ECOMM          -5   /* RCCL error                                   */
+#define MSDP_EUNSUPPORTED   -6
+
+typedef struct msdp_handle_s* msdp_handle;
+
+/* Problem kinds (which reference entry point the handle serves). */
+#define MSDP_KIND_ONLYUNITDIAG 1   /* src/primal/ManiSDP_onlyunitdiag.m */
+#define MSDP_KIND_UNITDIAG     2   /* src/primal/ManiSDP_unitdiag.m     */
+#define MSDP_KIND_UNITTRACE    3   /* src/primal/ManiSDP_unittrace.m    */
+
+/* Options of one Riemannian trust-region solve: the fields ManiSDP sets
+ * (ManiSDP_unitdiag.m:44-47) plus Manopt's defaults that are in force
+ * (manopt7.0/manopt/solvers/trustregions/trustregions.m:340-351,363-372).
+ * Delta_bar <= 0 / Delta0 <= 0 select the reference's defaults
+ * (M.typicaldist(), Delta_bar/8). */
+typedef struct {
+    int32_t maxiter;          /* opts.maxiter  = options.TR_maxiter            */
+    int32_t maxinner;         /* opts.maxinner = options.TR_maxinner           */
+    int32_t mininner;         /* Manopt default 1                              */
+    int32_t reserved0;
+    double  tolgradnorm;      /* opts.tolgradnorm                              */
+    double  kappa;            /* 0.1                                           */
+    double  theta;            /* 1.0                                           */
+    double  rho_prime;        /* 0.1                                           */
+    double  rho_regularization; /* 1e3                                         */
+    double  Delta_bar;        /* <=0: typicaldist                              */
+    double  Delta0;           /* <=0: Delta_bar/8                              */
+} msdp_rtr_opts;
+
+/* What the AL loop reads back from trustregions(): info(end).gradnorm and the
+ * cost, plus the counters the reference does not report. */
+typedef struct {
+    double  cost;             /* f at the returned point                       */
+    double  gradnorm;         /* info(end).gradnorm                            */
+    double  Delta;            /* final trust-region radius                     */
+    double  seconds;          /* wall-clock of the solve (host timer)          */
+    int32_t iters;            /* TR iterations performed                       */
+    int32_t hessvecs;         /* sum(info.numinner)                            */
+    int32_t accepted;
+    int32_t rejected;
+    int32_t cost_evals;
+    int32_t last_stop_inner;  /* tCG stop code 1..6 of the last TR iteration   */
+    int32_t reserved[2];
+} msdp_rtr_stats;
+
+void msdp_rtr_default_opts(msdp_rtr_opts* o);
+
+/* ---------------------------------------------------------------- life cycle */
+
+/* Select the HIP device of the calling thread (one process per GPU: LOCAL_RANK). */
+int msdp_set_device(int32_t device);
+int msdp_device_count(int32_t* count);
+
+/* min <C,X>, diag X = 1 with sparse symmetric C (n x n) given as MATLAB CSC
+ * (= CSR by symmetry).  Replaces the closures of ManiSDP_onlyunitdiag.m:117-130.
+ * pcap: initial capacity for the factor width (grown on demand). */
+int msdp_create_onlyunitdiag_csc(int64_t n, const int64_t* jc, const int64_t* ir,
+                                 const double* pr, int32_t pcap, msdp_handle* out);
+
+/* Same with a dense symmetric C (n x n, column-major == row-major). */
+int msdp_create_onlyunitdiag_dense(int64_t n, const double* C, int32_t pcap,
+                                   msdp_handle* out);
+
+/* min <C,X>, A(X) = b, diag X = 1 (kind = MSDP_KIND_UNITDIAG;
+ * ManiSDP_unitdiag.m:152-171) or tr X = 1 (kind = MSDP_KIND_UNITTRACE;
+ * ManiSDP_unittrace.m:156-177).  At is n^2 x m CSC (column k = vec(A_k)),
+ * b dense m, c dense n^2 (the shim densifies a sparse c). */
+int msdp_create_affine(int32_t kind, int64_t n, int64_t m,
+                       const int64_t* at_jc, const int64_t* at_ir, const double* at_pr,
+                       const double* b, const double* c, int32_t pcap, msdp_handle* out);
+
+int msdp_destroy(msdp_handle h);
+
+/* AL state that changes between trustregions() calls: y and sigma
+ * (ManiSDP_unitdiag.m:64,108-112).  No-op error for onlyunitdiag handles. */
+int msdp_set_multipliers(msdp_handle h, const double* y, double sigma);
+
+/* ------------------------------------------------------- resident point I/O */
+
+/* Upload the current point in the reference layout (see header comment). */
+int msdp_set_point(msdp_handle h, int32_t p, const double* Y);
+int msdp_get_point(msdp_handle h, double* Y);
+int msdp_get_p(msdp_handle h, int32_t* p);
+
+/* ------------------------------------------------------------------ hot path */
+
+/* [Y, ~, info] = trustregions(problem, Y, opts) on the resident point: the whole
+ * RTR/tCG loop (trustregions.m:441-767, tCG.m:160-289) runs on the device. */
+int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats* stats);
+
+/* Convenience: set_point + rtr + get_point. */
+int msdp_rtr_host(msdp_handle h, int32_t p, double* Y_inout,
+                  const msdp_rtr_opts* opts, msdp_rtr_stats* stats);
+
+/* Fine-grained operators at the resident point (parity tests; reference layout).
+ *   cost   : problem.cost(Y)                       -> *f
+ *   rgrad  : problem.grad(Y) (after cost)          -> G
+ *   hessvec: problem.hess(Y, U)                    -> H
+ *   proj   : problem.M.proj(Y, U)                  -> V
+ *   retr   : problem.M.retr(Y, U)                  -> Z (does not move the point) */
+int msdp_cost(msdp_handle h, double* f);
+int msdp_rgrad(msdp_handle h, double* G);
+int msdp_hessvec(msdp_handle h, const double* U, double* H);
+int msdp_proj(msdp_handle h, const double* U, double* V);
+int msdp_retr(msdp_handle h, const double* U, double* Z);
+
+/* Per-point vector the AL step needs after RTR without recomputing it on the host:
+ * onlyunitdiag: z = sum((Y*C).*Y) (ManiSDP_onlyunitdiag.m:46-47), length n. */
+int msdp_get_z(msdp_handle h, double* z);
+
+/* co(Y) of the line search (ManiSDP_onlyunitdiag.m:99-101, ManiSDP_unitdiag.m:131-136,
+ * ManiSDP_unittrace.m:135-140) evaluated at the retraction of Y + alpha*U, U given in
+ * the reference layout; used by line_search(). alpha = 0 evaluates co(Y). */
+int msdp_linesearch_cost(msdp_handle h, const double* U, double alpha, double* val);
+/* Adopt the trial point of the last msdp_linesearch_cost call (nY of line_search)
+ * as the resident point. */
+int msdp_linesearch_accept(msdp_handle h);
+
+/* ----------------------------------------------------------------- escape */
+
+/* Few-eigenvector saddle escape (replaces eig(S) of ManiSDP_onlyunitdiag.m:50,
+ * ManiSDP_unitdiag.m:68, ManiSDP_unittrace.m:68 for large n): the k smallest
+ * eigenpairs and the largest eigenvalue of the dual slack S at the resident point,
+ * by block Lanczos / LOBPCG on the device re-using the S*U kernel.
+ * lam_min[k] ascending, V is n x k column-major, *lam_max the top eigenvalue. */
+int msdp_escape_eigs(msdp_handle h, int32_t k, double tol, int32_t maxit,
+                     double* lam_min, double* V, double* lam_max, int32_t* iters);
+
+/* ------------------------------------------------------------- multi-GPU */
+
+/* Row sharding: call on every rank right after create, before any
+ * point is set.  unique_id is the 128-byte RCCL id produced on rank 0 by
+ * msdp_comm_unique_id and broadcast by the host launcher. */
+int msdp_comm_unique_id(void* id128);
+int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const void* id128);
+/* Local row range [row0, row1) of this rank. */
+int msdp_local_rows(msdp_handle h, int64_t* row0, int64_t* row1);
+
+/* ------------------------------------------------------------ measurement */
+
+/* Launch the Hess-vec kernel `reps` times on the library's stream between two
+ * HIP events and return the average device time per launch (ms) together with
+ * the algorithmic bytes/flops of one launch (SURVEY.md 8d formulas). */
+int msdp_bench_hessvec(msdp_handle h, int32_t reps, double* avg_ms,
+                       double* algo_bytes, double* algo_flops);
+/* Same for one whole tCG trip (Hess-vec + the vector updates), exits disabled. */
+int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms);
+
+const char* msdp_last_error(void);
+const char* msdp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MANISDP_HIP_H */

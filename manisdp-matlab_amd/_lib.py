@@ -1,0 +1,297 @@
+"""ctypes binding of ``include/manisdp_hip.h`` (libmanisdp_hip.so).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is
+visible, every entry point raises.  The library is looked up in-tree
+(``manisdp-matlab_amd/lib/libmanisdp_hip.so``) so the GPU box loads exactly the
+file that ``__graft_entry__.build()`` produced.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmanisdp_hip.so")
+
+KIND_ONLYUNITDIAG, KIND_UNITDIAG, KIND_UNITTRACE = 1, 2, 3
+
+
+class RtrOpts(C.Structure):
+    _fields_ = [("maxiter", C.c_int32), ("maxinner", C.c_int32), ("mininner", C.c_int32),
+                ("reserved0", C.c_int32), ("tolgradnorm", C.c_double), ("kappa", C.c_double),
+                ("theta", C.c_double), ("rho_prime", C.c_double), ("rho_regularization", C.c_double),
+                ("Delta_bar", C.c_double), ("Delta0", C.c_double)]
+
+
+class RtrStats(C.Structure):
+    _fields_ = [("cost", C.c_double), ("gradnorm", C.c_double), ("Delta", C.c_double),
+                ("seconds", C.c_double), ("iters", C.c_int32), ("hessvecs", C.c_int32),
+                ("accepted", C.c_int32), ("rejected", C.c_int32), ("cost_evals", C.c_int32),
+                ("last_stop_inner", C.c_int32), ("reserved", C.c_int32 * 2)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class MsdpError(RuntimeError):
+    pass
+
+
+_P = C.POINTER
+_dp = _P(C.c_double)
+_i64p = _P(C.c_int64)
+
+# name -> (restype, argtypes); this table is also what tests/test_cabi_symbols.py
+# checks against the declarations in include/manisdp_hip.h.
+SIGNATURES = {
+    "msdp_rtr_default_opts": (None, [_P(RtrOpts)]),
+    "msdp_set_device": (C.c_int, [C.c_int32]),
+    "msdp_device_count": (C.c_int, [_P(C.c_int32)]),
+    "msdp_create_onlyunitdiag_csc": (C.c_int, [C.c_int64, _i64p, _i64p, _dp, C.c_int32, _P(C.c_void_p)]),
+    "msdp_create_onlyunitdiag_dense": (C.c_int, [C.c_int64, _dp, C.c_int32, _P(C.c_void_p)]),
+    "msdp_create_affine": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp,
+                                     C.c_int32, _P(C.c_void_p)]),
+    "msdp_destroy": (C.c_int, [C.c_void_p]),
+    "msdp_set_multipliers": (C.c_int, [C.c_void_p, _dp, C.c_double]),
+    "msdp_set_point": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
+    "msdp_get_point": (C.c_int, [C.c_void_p, _dp]),
+    "msdp_get_p": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "msdp_rtr": (C.c_int, [C.c_void_p, _P(RtrOpts), _P(RtrStats)]),
+    "msdp_rtr_host": (C.c_int, [C.c_void_p, C.c_int32, _dp, _P(RtrOpts), _P(RtrStats)]),
+    "msdp_cost": (C.c_int, [C.c_void_p, _dp]),
+    "msdp_rgrad": (C.c_int, [C.c_void_p, _dp]),
+    "msdp_hessvec": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "msdp_proj": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "msdp_retr": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "msdp_get_z": (C.c_int, [C.c_void_p, _dp]),
+    "msdp_linesearch_cost": (C.c_int, [C.c_void_p, _dp, C.c_double, _dp]),
+    "msdp_linesearch_accept": (C.c_int, [C.c_void_p]),
+    "msdp_escape_eigs": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, _dp, _dp, _dp, _P(C.c_int32)]),
+    "msdp_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "msdp_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "msdp_local_rows": (C.c_int, [C.c_void_p, _i64p, _i64p]),
+    "msdp_bench_hessvec": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
+    "msdp_bench_tcg_trip": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
+    "msdp_last_error": (C.c_char_p, []),
+    "msdp_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmanisdp_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MsdpError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(or `make -C manisdp-matlab_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MsdpError(f"libmanisdp_hip error {rc}: {load().msdp_last_error().decode()}")
+
+
+def _dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def set_device(dev):
+    _check(load().msdp_set_device(int(dev)))
+
+
+def device_count():
+    n = C.c_int32()
+    _check(load().msdp_device_count(C.byref(n)))
+    return n.value
+
+
+def default_opts(**kw):
+    o = RtrOpts()
+    load().msdp_rtr_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class Handle:
+    """Owning wrapper of an ``msdp_handle``.  Factors cross this boundary in the
+    reference layout: (n, p) C-contiguous NumPy arrays for the oblique kinds (the
+    bytes of MATLAB's p x n column-major Y), (n, p) arrays for unittrace as well
+    (converted to MATLAB's n x p column-major, i.e. Fortran order, on the way in)."""
+
+    def __init__(self, ptr, kind, n):
+        self._h = C.c_void_p(ptr)
+        self.kind = kind
+        self.n = n
+        self.p = 0
+        self._lib = load()
+
+    # ---- construction
+    @classmethod
+    def onlyunitdiag(cls, Cmat, pcap=32):
+        import scipy.sparse as sp
+        lib = load()
+        out = C.c_void_p()
+        n = Cmat.shape[0]
+        if sp.issparse(Cmat):
+            Cc = Cmat.tocsc()
+            Cc.sort_indices()
+            jc = np.ascontiguousarray(Cc.indptr, dtype=np.int64)
+            ir = np.ascontiguousarray(Cc.indices, dtype=np.int64)
+            pr = np.ascontiguousarray(Cc.data, dtype=np.float64)
+            _check(lib.msdp_create_onlyunitdiag_csc(n, jc.ctypes.data_as(_i64p), ir.ctypes.data_as(_i64p),
+                                                    _dptr(pr), pcap, C.byref(out)))
+        else:
+            Cd = np.ascontiguousarray(Cmat, dtype=np.float64)
+            _check(lib.msdp_create_onlyunitdiag_dense(n, _dptr(Cd), pcap, C.byref(out)))
+        return cls(out.value, KIND_ONLYUNITDIAG, n)
+
+    @classmethod
+    def affine(cls, kind, At, b, c, n, pcap=32):
+        lib = load()
+        out = C.c_void_p()
+        Atc = At.tocsc()
+        Atc.sort_indices()
+        jc = np.ascontiguousarray(Atc.indptr, dtype=np.int64)
+        ir = np.ascontiguousarray(Atc.indices, dtype=np.int64)
+        pr = np.ascontiguousarray(Atc.data, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        _check(lib.msdp_create_affine(kind, n, Atc.shape[1], jc.ctypes.data_as(_i64p), ir.ctypes.data_as(_i64p),
+                                      _dptr(pr), _dptr(b), _dptr(c), pcap, C.byref(out)))
+        return cls(out.value, kind, n)
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._lib.msdp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- layout helpers
+    def _to_boundary(self, Y):
+        Y = np.asarray(Y, dtype=np.float64)
+        if self.kind == KIND_UNITTRACE:
+            return np.asfortranarray(Y)           # MATLAB n x p column-major
+        return np.ascontiguousarray(Y)            # bytes of MATLAB p x n column-major
+
+    def _empty(self):
+        if self.kind == KIND_UNITTRACE:
+            return np.empty((self.n, self.p), dtype=np.float64, order="F")
+        return np.empty((self.n, self.p), dtype=np.float64, order="C")
+
+    # ---- point I/O
+    def set_point(self, Y):
+        Yb = self._to_boundary(Y)
+        assert Yb.shape[0] == self.n
+        self.p = Yb.shape[1]
+        _check(self._lib.msdp_set_point(self._h, self.p, _dptr(Yb)))
+
+    def get_point(self):
+        out = self._empty()
+        _check(self._lib.msdp_get_point(self._h, _dptr(out)))
+        return np.ascontiguousarray(out)
+
+    def set_multipliers(self, y, sigma):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        _check(self._lib.msdp_set_multipliers(self._h, _dptr(y), float(sigma)))
+
+    # ---- hot path
+    def rtr(self, opts):
+        st = RtrStats()
+        _check(self._lib.msdp_rtr(self._h, C.byref(opts), C.byref(st)))
+        return st
+
+    # ---- fine-grained
+    def cost(self):
+        f = C.c_double()
+        _check(self._lib.msdp_cost(self._h, C.byref(f)))
+        return f.value
+
+    def rgrad(self):
+        out = self._empty()
+        _check(self._lib.msdp_rgrad(self._h, _dptr(out)))
+        return np.ascontiguousarray(out)
+
+    def _vec_op(self, fn, U):
+        Ub = self._to_boundary(U)
+        out = self._empty()
+        _check(fn(self._h, _dptr(Ub), _dptr(out)))
+        return np.ascontiguousarray(out)
+
+    def hessvec(self, U):
+        return self._vec_op(self._lib.msdp_hessvec, U)
+
+    def proj(self, U):
+        return self._vec_op(self._lib.msdp_proj, U)
+
+    def retr(self, U):
+        return self._vec_op(self._lib.msdp_retr, U)
+
+    def get_z(self):
+        z = np.empty(self.n)
+        _check(self._lib.msdp_get_z(self._h, _dptr(z)))
+        return z
+
+    def linesearch_cost(self, U, alpha):
+        v = C.c_double()
+        if U is None:
+            _check(self._lib.msdp_linesearch_cost(self._h, None, 0.0, C.byref(v)))
+        else:
+            Ub = self._to_boundary(U)
+            _check(self._lib.msdp_linesearch_cost(self._h, _dptr(Ub), float(alpha), C.byref(v)))
+        return v.value
+
+    def linesearch_accept(self):
+        _check(self._lib.msdp_linesearch_accept(self._h))
+
+    def escape_eigs(self, k, tol=1e-10, maxit=500):
+        lam = np.empty(k)
+        V = np.empty((self.n, k), order="F")
+        lmax = C.c_double()
+        its = C.c_int32()
+        _check(self._lib.msdp_escape_eigs(self._h, k, tol, maxit, _dptr(lam), _dptr(V), C.byref(lmax), C.byref(its)))
+        return lam, np.ascontiguousarray(V), lmax.value, its.value
+
+    # ---- multi-GPU
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_char * 128)()
+        _check(load().msdp_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, uid):
+        buf = (C.c_char * 128).from_buffer_copy(uid)
+        _check(self._lib.msdp_comm_init(self._h, nranks, rank, C.cast(buf, C.c_void_p)))
+
+    def local_rows(self):
+        a, b = C.c_int64(), C.c_int64()
+        _check(self._lib.msdp_local_rows(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # ---- measurement
+    def bench_hessvec(self, reps):
+        ms, by, fl = C.c_double(), C.c_double(), C.c_double()
+        _check(self._lib.msdp_bench_hessvec(self._h, reps, C.byref(ms), C.byref(by), C.byref(fl)))
+        return ms.value, by.value, fl.value
+
+    def bench_tcg_trip(self, reps):
+        ms = C.c_double()
+        _check(self._lib.msdp_bench_tcg_trip(self._h, reps, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,741 @@
+// msdp_api.hip -- C ABI of libmanisdp_hip.so (include/manisdp_hip.h): handle life
+// cycle, resident-point I/O, the host side of the device-resident RTR/tCG driver,
+// the fine-grained parity entry points, RCCL sharding and measurement hooks.
+#include "msdp_common.h"
+#include <rccl/rccl.h>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+static thread_local char g_err[1024] = "";
+void msdp_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* msdp_last_error(void) { return g_err; }
+extern "C" const char* msdp_version(void) { return "manisdp_hip 0.1.0 (gfx950)"; }
+
+// kernels.hip wrappers
+int msdp_k_pack(msdp_handle h, const double* src, double* dst, int n, int p, int ld, bool colmajor);
+int msdp_k_unpack(msdp_handle h, const double* src, double* dst, int n, int p, int ld, bool colmajor);
+int msdp_k_proj_obl(msdp_handle h, const double* Y, const double* U, double* V);
+int msdp_k_retr_obl(msdp_handle h, const double* Y, const double* U, double* Z, double alpha);
+int msdp_k_set_active(msdp_handle h, int active);
+int msdp_k_sum_to(msdp_handle h, int which, double* out);
+int msdp_sphere_proj(msdp_handle h, const double* Y, const double* U, double* V);
+int msdp_sphere_retr(msdp_handle h, const double* Y, const double* U, double* Z, double alpha);
+int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const double* pr,
+                      const double* b, const double* c);
+int msdp_affine_set_multipliers(msdp_handle h, const double* y, double sigma);
+int msdp_affine_linesearch_cost(msdp_handle h, const double* Yt, double* val);
+int msdp_dense_setup(msdp_handle h, const double* C);
+int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam, double* V, double* lmax, int* iters);
+
+#define CHECK_H(h)                                          \
+    if (!(h)) { msdp_set_error("null handle"); return MSDP_EINVAL; }
+
+template <typename T>
+static int dev_alloc(msdp_handle h, T** out, size_t count) {
+    void* p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(&p, count * sizeof(T));
+    if (e != hipSuccess) {
+        msdp_set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return MSDP_ENOMEM;
+    }
+    h->allocs.push_back(p);
+    *out = (T*)p;
+    return 0;
+}
+int msdp_dev_alloc_bytes(msdp_handle h, void** out, size_t bytes) {
+    char* p = nullptr;
+    int rc = dev_alloc<char>(h, &p, bytes);
+    *out = p;
+    return rc;
+}
+static void dev_free(msdp_handle h, void* p) {
+    if (!p) return;
+    for (size_t i = 0; i < h->allocs.size(); ++i)
+        if (h->allocs[i] == p) { h->allocs.erase(h->allocs.begin() + i); break; }
+    (void)hipFree(p);
+}
+
+static bool boundary_colmajor(msdp_handle h) { return h->kind == MSDP_KIND_UNITTRACE; }
+
+static int rows_capacity(msdp_handle h) {
+    // equal per-rank row count so the all-gather is one uniform RCCL call
+    return (h->d.n + h->nranks - 1) / h->nranks;
+}
+
+static void choose_grid(msdp_handle h) {
+    Dev& d = h->d;
+    int half = d.ld / 2, lpr = 1;
+    while (lpr < half && lpr < 64) lpr <<= 1;
+    const int rows_per_step = 4 * (64 / lpr);
+    int want = (rows_capacity(h) + rows_per_step - 1) / rows_per_step;
+    int gmax = 256;
+    if (const char* e = getenv("MSDP_GRID")) { int v = atoi(e); if (v >= 8) gmax = v; }
+    if (gmax > MSDP_MAX_GRID) gmax = MSDP_MAX_GRID;
+    int G = ((want + 7) / 8) * 8;
+    if (G < 8) G = 8;
+    if (G > gmax) G = (gmax / 8) * 8;
+    d.G = G;
+}
+
+// (Re)allocate every n_loc x ld vector for factor widths up to pcap.
+int msdp_alloc_vectors(msdp_handle h, int pcap) {
+    Dev& d = h->d;
+    const int ldcap = ((pcap + 1) / 2) * 2;
+    const size_t rows = (size_t)rows_capacity(h);
+    const size_t cnt = rows * (size_t)ldcap;
+    double** vecs[] = {&d.Y[0], &d.Y[1], &d.Gr[0], &d.Gr[1], &d.eta[0], &d.eta[1], &d.Heta[0], &d.Heta[1],
+                       &d.r, &d.md, &d.Hmd, &d.W0, &d.W1};
+    if (h->nranks > 1 && d.full) dev_free(h, d.full);
+    d.full = nullptr;
+    for (double** v : vecs) {
+        if (*v) dev_free(h, *v);
+        *v = nullptr;
+        int rc = dev_alloc<double>(h, v, cnt);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(*v, 0, cnt * sizeof(double), h->stream));
+    }
+    if (h->nranks > 1) {
+        int rc = dev_alloc<double>(h, &d.full, cnt * (size_t)h->nranks);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(d.full, 0, cnt * h->nranks * sizeof(double), h->stream));
+    }
+    h->pcap = pcap;
+    h->ldcap = ldcap;
+    return 0;
+}
+
+static int alloc_common(msdp_handle h) {
+    Dev& d = h->d;
+    int rc;
+    if ((rc = dev_alloc<Ctl>(h, &d.ctl, 1))) return rc;
+    if ((rc = dev_alloc<Frame>(h, &d.F, 2))) return rc;
+    if ((rc = dev_alloc<double>(h, &d.P, (size_t)MSDP_NPART * MSDP_MAX_GRID))) return rc;
+    HIPCHK(hipMemset(d.ctl, 0, sizeof(Ctl)));
+    HIPCHK(hipMemset(d.F, 0, 2 * sizeof(Frame)));
+    HIPCHK(hipMemset(d.P, 0, (size_t)MSDP_NPART * MSDP_MAX_GRID * sizeof(double)));
+    const size_t rows = (size_t)rows_capacity(h);
+    for (int s = 0; s < 2; ++s) {
+        if (d.eG[s]) dev_free(h, d.eG[s]);
+        if ((rc = dev_alloc<double>(h, &d.eG[s], rows))) return rc;
+        HIPCHK(hipMemset(d.eG[s], 0, rows * sizeof(double)));
+    }
+    return 0;
+}
+
+static int new_handle(int kind, int64_t n, msdp_handle* out) {
+    if (!out) { msdp_set_error("out handle pointer is null"); return MSDP_EINVAL; }
+    if (n <= 0 || n > 0x7fffffff) { msdp_set_error("matrix order n = %lld out of range", (long long)n); return MSDP_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        msdp_set_error("no HIP device visible: libmanisdp_hip has no CPU fallback");
+        return MSDP_EHIP;
+    }
+    msdp_handle h = new msdp_handle_s();
+    h->kind = kind;
+    h->d.n = (int)n;
+    h->d.n_loc = (int)n;
+    h->d.row0 = 0;
+    h->d.manifold = (kind == MSDP_KIND_UNITTRACE) ? MANI_SPHERE : MANI_OBLIQUE;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_ctl, sizeof(Ctl), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_frame, 2 * sizeof(Frame), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        msdp_set_error("stream/event/pinned setup failed: %s", hipGetErrorString(e));
+        delete h;
+        return MSDP_EHIP;
+    }
+    *out = h;
+    return 0;
+}
+
+// Upload the CSR rows [row0, row0+n_loc) of the host copy.
+static int upload_sparse_rows(msdp_handle h) {
+    Dev& d = h->d;
+    const int r0 = d.row0, r1 = d.row0 + d.n_loc;
+    const int base = h->h_rowptr[r0];
+    const int64_t nnz = h->h_rowptr[r1] - base;
+    std::vector<int> rp((size_t)rows_capacity(h) + 1);
+    for (int i = 0; i <= d.n_loc; ++i) rp[i] = h->h_rowptr[r0 + i] - base;
+    for (size_t i = d.n_loc + 1; i < rp.size(); ++i) rp[i] = rp[d.n_loc];
+    if (h->d_rowptr) dev_free(h, h->d_rowptr);
+    if (h->d_colind) dev_free(h, h->d_colind);
+    if (h->d_cval) dev_free(h, h->d_cval);
+    int rc;
+    if ((rc = dev_alloc<int>(h, &h->d_rowptr, rp.size()))) return rc;
+    if ((rc = dev_alloc<int>(h, &h->d_colind, (size_t)nnz))) return rc;
+    if ((rc = dev_alloc<double>(h, &h->d_cval, (size_t)nnz))) return rc;
+    HIPCHK(hipMemcpy(h->d_rowptr, rp.data(), rp.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (nnz) {
+        HIPCHK(hipMemcpy(h->d_colind, h->h_colind.data() + base, nnz * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_cval, h->h_cval.data() + base, nnz * sizeof(double), hipMemcpyHostToDevice));
+    }
+    d.rowptr = h->d_rowptr; d.colind = h->d_colind; d.cval = h->d_cval; d.nnz = nnz;
+    return 0;
+}
+
+extern "C" int msdp_set_device(int32_t device) {
+    HIPCHK(hipSetDevice(device));
+    return 0;
+}
+extern "C" int msdp_device_count(int32_t* count) {
+    if (!count) return MSDP_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return 0;
+}
+
+extern "C" void msdp_rtr_default_opts(msdp_rtr_opts* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->maxiter = 1000; o->maxinner = 100; o->mininner = 1;
+    o->tolgradnorm = 1e-6; o->kappa = 0.1; o->theta = 1.0; o->rho_prime = 0.1;
+    o->rho_regularization = 1e3; o->Delta_bar = -1.0; o->Delta0 = -1.0;
+}
+
+extern "C" int msdp_create_onlyunitdiag_csc(int64_t n, const int64_t* jc, const int64_t* ir,
+                                            const double* pr, int32_t pcap, msdp_handle* out) {
+    if (!jc || (!ir && jc[n] > 0) || (!pr && jc[n] > 0)) { msdp_set_error("null sparse arrays"); return MSDP_EINVAL; }
+    msdp_handle h = nullptr;
+    int rc = new_handle(MSDP_KIND_ONLYUNITDIAG, n, &h);
+    if (rc) return rc;
+    const int64_t nnz = jc[n];
+    if (nnz > 0x7fffffff) { msdp_set_error("nnz(C) too large"); msdp_destroy(h); return MSDP_EINVAL; }
+    h->h_rowptr.resize(n + 1);
+    h->h_colind.resize(nnz);
+    h->h_cval.assign(pr, pr + nnz);
+    for (int64_t i = 0; i <= n; ++i) h->h_rowptr[i] = (int)jc[i];
+    for (int64_t k = 0; k < nnz; ++k) {
+        if (ir[k] < 0 || ir[k] >= n) { msdp_set_error("row index out of range"); msdp_destroy(h); return MSDP_EINVAL; }
+        h->h_colind[k] = (int)ir[k];
+    }
+    h->d.costkind = COST_SPARSE;
+    if ((rc = alloc_common(h)) || (rc = upload_sparse_rows(h)) || (rc = msdp_alloc_vectors(h, pcap > 0 ? pcap : 32))) {
+        msdp_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" int msdp_create_onlyunitdiag_dense(int64_t n, const double* C, int32_t pcap, msdp_handle* out) {
+    if (!C) { msdp_set_error("null C"); return MSDP_EINVAL; }
+    msdp_handle h = nullptr;
+    int rc = new_handle(MSDP_KIND_ONLYUNITDIAG, n, &h);
+    if (rc) return rc;
+    h->d.costkind = COST_DENSE;
+    if ((rc = alloc_common(h)) || (rc = msdp_dense_setup(h, C)) || (rc = msdp_alloc_vectors(h, pcap > 0 ? pcap : 32))) {
+        msdp_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" int msdp_create_affine(int32_t kind, int64_t n, int64_t m, const int64_t* at_jc, const int64_t* at_ir,
+                                  const double* at_pr, const double* b, const double* c, int32_t pcap,
+                                  msdp_handle* out) {
+    if (kind != MSDP_KIND_UNITDIAG && kind != MSDP_KIND_UNITTRACE) { msdp_set_error("bad kind %d", kind); return MSDP_EINVAL; }
+    if (!at_jc || !b || !c || m <= 0) { msdp_set_error("null/empty affine data"); return MSDP_EINVAL; }
+    msdp_handle h = nullptr;
+    int rc = new_handle(kind, n, &h);
+    if (rc) return rc;
+    h->d.costkind = COST_AFFINE;
+    h->d.m = m;
+    if ((rc = alloc_common(h)) || (rc = msdp_affine_setup(h, at_jc, at_ir, at_pr, b, c)) ||
+        (rc = msdp_alloc_vectors(h, pcap > 0 ? pcap : 32))) {
+        msdp_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" int msdp_destroy(msdp_handle h) {
+    if (!h) return 0;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm) (void)ncclCommDestroy((ncclComm_t)h->comm);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+    if (h->h_frame) (void)hipHostFree(h->h_frame);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+extern "C" int msdp_set_multipliers(msdp_handle h, const double* y, double sigma) {
+    CHECK_H(h);
+    if (h->d.costkind != COST_AFFINE) { msdp_set_error("set_multipliers: handle has no affine constraints"); return MSDP_ESTATE; }
+    h->state_valid = false;
+    return msdp_affine_set_multipliers(h, y, sigma);
+}
+
+// ------------------------------------------------------------------ point I/O
+static int host_cur(msdp_handle h) { return h->h_ctl->cur; }
+
+// Stage a boundary-layout host matrix (local rows) into a device vector.
+static int upload_rows(msdp_handle h, const double* host, double* dst) {
+    Dev& d = h->d;
+    const size_t cnt = (size_t)d.n_loc * d.p;
+    double* stage = nullptr;
+    hipError_t e = hipMalloc((void**)&stage, (cnt ? cnt : 1) * sizeof(double));
+    if (e != hipSuccess) { msdp_set_error("staging alloc failed"); return MSDP_ENOMEM; }
+    int rc = 0;
+    if (boundary_colmajor(h)) {
+        // n x p column-major; each rank reads its row block of every column
+        if (h->nranks == 1) {
+            e = hipMemcpyAsync(stage, host, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream);
+        } else {
+            e = hipMemcpy2DAsync(stage, (size_t)d.n_loc * sizeof(double), host + d.row0, (size_t)d.n * sizeof(double),
+                                 (size_t)d.n_loc * sizeof(double), d.p, hipMemcpyHostToDevice, h->stream);
+        }
+    } else {
+        e = hipMemcpyAsync(stage, host + (size_t)d.row0 * d.p, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    }
+    if (e != hipSuccess) { msdp_set_error("H2D copy failed: %s", hipGetErrorString(e)); rc = MSDP_EHIP; }
+    if (!rc) rc = msdp_k_pack(h, stage, dst, d.n_loc, d.p, d.ld, boundary_colmajor(h));
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(stage);
+    return rc;
+}
+
+static int download_rows(msdp_handle h, const double* src, double* host) {
+    Dev& d = h->d;
+    const size_t cnt = (size_t)d.n_loc * d.p;
+    double* stage = nullptr;
+    hipError_t e = hipMalloc((void**)&stage, (cnt ? cnt : 1) * sizeof(double));
+    if (e != hipSuccess) { msdp_set_error("staging alloc failed"); return MSDP_ENOMEM; }
+    int rc = msdp_k_unpack(h, src, stage, d.n_loc, d.p, d.ld, boundary_colmajor(h));
+    if (!rc) {
+        if (boundary_colmajor(h) && h->nranks > 1)
+            e = hipMemcpy2DAsync(host + d.row0, (size_t)d.n * sizeof(double), stage, (size_t)d.n_loc * sizeof(double),
+                                 (size_t)d.n_loc * sizeof(double), d.p, hipMemcpyDeviceToHost, h->stream);
+        else
+            e = hipMemcpyAsync(host + (boundary_colmajor(h) ? 0 : (size_t)d.row0 * d.p), stage, cnt * sizeof(double),
+                               hipMemcpyDeviceToHost, h->stream);
+        if (e != hipSuccess) { msdp_set_error("D2H copy failed: %s", hipGetErrorString(e)); rc = MSDP_EHIP; }
+    }
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(stage);
+    return rc;
+}
+
+extern "C" int msdp_set_point(msdp_handle h, int32_t p, const double* Y) {
+    CHECK_H(h);
+    if (p < 1 || !Y) { msdp_set_error("set_point: p = %d, Y = %p", p, (const void*)Y); return MSDP_EINVAL; }
+    if (p > 512) { msdp_set_error("factor width p = %d exceeds the supported maximum of 512", p); return MSDP_EUNSUPPORTED; }
+    Dev& d = h->d;
+    if (p > h->pcap) {
+        int rc = msdp_alloc_vectors(h, p + 16);
+        if (rc) return rc;
+    }
+    d.p = p;
+    d.ld = ((p + 1) / 2) * 2;
+    if (h->nranks == 1) d.full = d.md;     // overwritten per launch by allgather_rows
+    choose_grid(h);
+    h->h_ctl->cur = 0;
+    // zero the slot so pad columns and pad rows are exactly zero
+    HIPCHK(hipMemsetAsync(d.Y[0], 0, (size_t)rows_capacity(h) * h->ldcap * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(d.Y[1], 0, (size_t)rows_capacity(h) * h->ldcap * sizeof(double), h->stream));
+    int rc = upload_rows(h, Y, d.Y[0]);
+    if (rc) return rc;
+    h->have_point = true;
+    h->state_valid = false;
+    return 0;
+}
+
+extern "C" int msdp_get_point(msdp_handle h, double* Y) {
+    CHECK_H(h);
+    if (!h->have_point) { msdp_set_error("no resident point"); return MSDP_ESTATE; }
+    return download_rows(h, h->d.Y[host_cur(h)], Y);
+}
+
+extern "C" int msdp_get_p(msdp_handle h, int32_t* p) {
+    CHECK_H(h);
+    if (!p) return MSDP_EINVAL;
+    *p = h->d.p;
+    return 0;
+}
+
+// ------------------------------------------------------------------ collectives
+int msdp_allreduce_partials(msdp_handle h, int first, int count) {
+    if (h->nranks == 1) return 0;
+    double* buf = h->d.P + (size_t)first * MSDP_MAX_GRID;
+    ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count * MSDP_MAX_GRID, ncclDouble, ncclSum,
+                                   (ncclComm_t)h->comm, h->stream);
+    if (r != ncclSuccess) { msdp_set_error("ncclAllReduce failed: %s", ncclGetErrorString(r)); return MSDP_ECOMM; }
+    return 0;
+}
+
+// Make all rows of a row-sharded vector visible to the gather kernels: one RCCL
+// all-gather of the thin n x p factor (each rank sends its slab to its 7 peers,
+// one message per xGMI link).  With one rank the local buffer is used directly.
+int msdp_allgather_rows(msdp_handle h, const double* local_rows) {
+    if (h->nranks == 1) {
+        h->d.full = const_cast<double*>(local_rows);
+        return 0;
+    }
+    const size_t cnt = (size_t)rows_capacity(h) * h->d.ld;
+    // slabs are packed with the CURRENT ld so the full buffer is n_pad x ld row-major
+    ncclResult_t r = ncclAllGather(local_rows, h->d.full, cnt, ncclDouble, (ncclComm_t)h->comm, h->stream);
+    if (r != ncclSuccess) { msdp_set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return MSDP_ECOMM; }
+    return 0;
+}
+
+extern "C" int msdp_comm_unique_id(void* id128) {
+    if (!id128) return MSDP_EINVAL;
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) { msdp_set_error("ncclGetUniqueId failed: %s", ncclGetErrorString(r)); return MSDP_ECOMM; }
+    static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+    memcpy(id128, &id, 128);
+    return 0;
+}
+
+extern "C" int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const void* id128) {
+    CHECK_H(h);
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id128) { msdp_set_error("bad comm arguments"); return MSDP_EINVAL; }
+    if (h->have_point) { msdp_set_error("comm_init must precede set_point"); return MSDP_ESTATE; }
+    if (h->d.costkind == COST_AFFINE && nranks > 1) {
+        msdp_set_error("row sharding of the affine (A-operator) kinds is not implemented yet");
+        return MSDP_EUNSUPPORTED;
+    }
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclComm_t comm;
+    ncclResult_t r = ncclCommInitRank(&comm, nranks, id, rank);
+    if (r != ncclSuccess) { msdp_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r)); return MSDP_ECOMM; }
+    h->comm = comm;
+    h->nranks = nranks;
+    h->rank = rank;
+    const int cap = rows_capacity(h);
+    h->d.row0 = rank * cap;
+    int r1 = h->d.row0 + cap;
+    if (r1 > h->d.n) r1 = h->d.n;
+    h->d.n_loc = r1 > h->d.row0 ? r1 - h->d.row0 : 0;
+    int rc = alloc_common(h);
+    if (rc) return rc;
+    if (h->d.costkind == COST_SPARSE && (rc = upload_sparse_rows(h))) return rc;
+    if (h->d.costkind == COST_DENSE) {
+        msdp_set_error("dense C must be created per shard (msdp_create_onlyunitdiag_dense_shard)");
+        return MSDP_EUNSUPPORTED;
+    }
+    return msdp_alloc_vectors(h, h->pcap);
+}
+
+extern "C" int msdp_local_rows(msdp_handle h, int64_t* row0, int64_t* row1) {
+    CHECK_H(h);
+    if (row0) *row0 = h->d.row0;
+    if (row1) *row1 = h->d.row0 + h->d.n_loc;
+    return 0;
+}
+
+// ------------------------------------------------------------------ RTR driver
+static int push_ctl(msdp_handle h) {
+    HIPCHK(hipMemcpyAsync(h->d.ctl, h->h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+static int pull_ctl(msdp_handle h) {
+    HIPCHK(hipMemcpyAsync(h->h_ctl, h->d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static void fill_ctl(msdp_handle h, const msdp_rtr_opts* o) {
+    Ctl* c = h->h_ctl;
+    const int cur = c->cur;
+    const double sigma = c->sigma;
+    const double z0 = c->z_sphere[0], z1 = c->z_sphere[1];
+    memset(c, 0, sizeof(Ctl));
+    c->cur = cur; c->sigma = sigma; c->z_sphere[0] = z0; c->z_sphere[1] = z1;
+    c->maxiter = o->maxiter; c->maxinner = o->maxinner; c->mininner = o->mininner;
+    c->tolgradnorm = o->tolgradnorm; c->kappa = o->kappa; c->theta = o->theta;
+    c->rho_prime = o->rho_prime; c->rho_reg = o->rho_regularization;
+    // trustregions.m:363-372; typicaldist: pi*sqrt(n) (ManiSDP_onlyunitdiag.m:137) or pi (spherefactory.m:111)
+    const double typical = (h->d.manifold == MANI_OBLIQUE) ? M_PI * sqrt((double)h->d.n) : M_PI;
+    c->Delta_bar = (o->Delta_bar > 0) ? o->Delta_bar : typical;
+    c->Delta0 = (o->Delta0 > 0) ? o->Delta0 : c->Delta_bar / 8.0;
+}
+
+static int tcg_chunk() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MSDP_TCG_CHUNK"); v = e ? atoi(e) : 8; if (v < 1) v = 1; }
+    return v;
+}
+
+extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats* stats) {
+    CHECK_H(h);
+    if (!opts) { msdp_set_error("rtr: null options"); return MSDP_EINVAL; }
+    if (!h->have_point) { msdp_set_error("rtr: no resident point (call msdp_set_point)"); return MSDP_ESTATE; }
+    if (opts->rho_prime >= 0.25) { msdp_set_error("options.rho_prime must be strictly smaller than 1/4"); return MSDP_EINVAL; }
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    fill_ctl(h, opts);
+    h->last_opts = *opts;
+    if ((rc = push_ctl(h))) return rc;
+    int cur = h->h_ctl->cur;
+    if ((rc = msdp_launch_costgrad(h, cur))) return rc;          // trustregions.m:405
+    if ((rc = msdp_launch_rtr_begin(h))) return rc;
+    if ((rc = pull_ctl(h))) return rc;
+    const int CH = tcg_chunk();
+    while (!h->h_ctl->done) {                                     // trustregions.m:441
+        cur = h->h_ctl->cur;
+        if ((rc = msdp_launch_tcg_init(h))) return rc;            // :484-496
+        int j = 0;
+        while (j < opts->maxinner) {
+            const int cnt = std::min(CH, opts->maxinner - j);
+            for (int t = 0; t < cnt; ++t) {
+                if ((rc = msdp_launch_hess(h))) return rc;        // tCG.m:163
+                if ((rc = msdp_launch_upd1(h))) return rc;        // tCG.m:166-241
+                if ((rc = msdp_launch_upd2(h))) return rc;        // tCG.m:249-287
+            }
+            j += cnt;
+            if (j < opts->maxinner) {
+                HIPCHK(hipMemcpyAsync(&h->h_ctl->tcg_running, &h->d.ctl->tcg_running, sizeof(int),
+                                      hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                if (!h->h_ctl->tcg_running) break;
+            }
+        }
+        if ((rc = msdp_launch_retract(h))) return rc;             // trustregions.m:540
+        if ((rc = msdp_launch_costgrad(h, cur ^ 1))) return rc;   // :544
+        if ((rc = msdp_launch_rtr_decide(h))) return rc;          // :548-729
+        if ((rc = pull_ctl(h))) return rc;
+    }
+    h->state_valid = true;
+    if (stats) {
+        const Ctl* c = h->h_ctl;
+        memset(stats, 0, sizeof(*stats));
+        stats->cost = c->fx; stats->gradnorm = c->norm_grad; stats->Delta = c->Delta;
+        stats->iters = c->k; stats->hessvecs = c->hessvecs; stats->accepted = c->accepted;
+        stats->rejected = c->rejected; stats->cost_evals = c->cost_evals;
+        stats->last_stop_inner = c->last_stop_inner;
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
+}
+
+extern "C" int msdp_rtr_host(msdp_handle h, int32_t p, double* Y, const msdp_rtr_opts* opts, msdp_rtr_stats* stats) {
+    int rc = msdp_set_point(h, p, Y);
+    if (rc) return rc;
+    if ((rc = msdp_rtr(h, opts, stats))) return rc;
+    return msdp_get_point(h, Y);
+}
+
+// ------------------------------------------------------------------ fine-grained ops
+static int ensure_state(msdp_handle h) {
+    if (!h->have_point) { msdp_set_error("no resident point"); return MSDP_ESTATE; }
+    if (h->state_valid) return 0;
+    h->h_ctl->done = 0;
+    h->h_ctl->bench_mode = 0;
+    int rc = push_ctl(h);
+    if (rc) return rc;
+    if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
+    h->state_valid = true;
+    return 0;
+}
+
+extern "C" int msdp_cost(msdp_handle h, double* f) {
+    CHECK_H(h);
+    if (!f) return MSDP_EINVAL;
+    int rc = ensure_state(h);
+    if (rc) return rc;
+    // re-run the reduction of the stored partials only if they are still those of the
+    // resident point; simplest is to recompute the cost
+    h->h_ctl->done = 0;
+    if ((rc = push_ctl(h))) return rc;
+    if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
+    if ((rc = msdp_k_sum_to(h, P_F, &h->d.ctl->fx))) return rc;
+    double v = 0.0;
+    HIPCHK(hipMemcpyAsync(&v, &h->d.ctl->fx, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *f = v;
+    return 0;
+}
+
+extern "C" int msdp_rgrad(msdp_handle h, double* G) {
+    CHECK_H(h);
+    int rc = ensure_state(h);
+    if (rc) return rc;
+    return download_rows(h, h->d.Gr[host_cur(h)], G);
+}
+
+extern "C" int msdp_hessvec(msdp_handle h, const double* U, double* H) {
+    CHECK_H(h);
+    int rc = ensure_state(h);
+    if (rc) return rc;
+    if ((rc = upload_rows(h, U, h->d.md))) return rc;
+    if ((rc = msdp_k_set_active(h, 1))) return rc;
+    if ((rc = msdp_launch_hess(h))) return rc;
+    if ((rc = msdp_k_set_active(h, 0))) return rc;
+    return download_rows(h, h->d.Hmd, H);
+}
+
+extern "C" int msdp_proj(msdp_handle h, const double* U, double* V) {
+    CHECK_H(h);
+    if (!h->have_point) { msdp_set_error("no resident point"); return MSDP_ESTATE; }
+    int rc = upload_rows(h, U, h->d.W0);
+    if (rc) return rc;
+    if (h->d.manifold == MANI_OBLIQUE) rc = msdp_k_proj_obl(h, h->d.Y[host_cur(h)], h->d.W0, h->d.W1);
+    else rc = msdp_sphere_proj(h, h->d.Y[host_cur(h)], h->d.W0, h->d.W1);
+    if (rc) return rc;
+    return download_rows(h, h->d.W1, V);
+}
+
+extern "C" int msdp_retr(msdp_handle h, const double* U, double* Z) {
+    CHECK_H(h);
+    if (!h->have_point) { msdp_set_error("no resident point"); return MSDP_ESTATE; }
+    int rc = upload_rows(h, U, h->d.W0);
+    if (rc) return rc;
+    if (h->d.manifold == MANI_OBLIQUE) rc = msdp_k_retr_obl(h, h->d.Y[host_cur(h)], h->d.W0, h->d.W1, 1.0);
+    else rc = msdp_sphere_retr(h, h->d.Y[host_cur(h)], h->d.W0, h->d.W1, 1.0);
+    if (rc) return rc;
+    return download_rows(h, h->d.W1, Z);
+}
+
+extern "C" int msdp_get_z(msdp_handle h, double* z) {
+    CHECK_H(h);
+    if (h->kind != MSDP_KIND_ONLYUNITDIAG) { msdp_set_error("get_z: only for onlyunitdiag handles"); return MSDP_EUNSUPPORTED; }
+    int rc = ensure_state(h);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(z + h->d.row0, h->d.eG[host_cur(h)], (size_t)h->d.n_loc * sizeof(double),
+                          hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// co() of the line search at retr(Y + alpha*U): for onlyunitdiag co = sum((Y*C).*Y) = 2 f.
+extern "C" int msdp_linesearch_cost(msdp_handle h, const double* U, double alpha, double* val) {
+    CHECK_H(h);
+    if (!h->have_point || !val) { msdp_set_error("linesearch_cost: no point / null out"); return MSDP_ESTATE; }
+    int rc;
+    const int cur = host_cur(h);
+    Dev& d = h->d;
+    if (U && alpha != 0.0) {
+        if ((rc = upload_rows(h, U, d.W0))) return rc;
+        if (d.manifold == MANI_OBLIQUE) rc = msdp_k_retr_obl(h, d.Y[cur], d.W0, d.Y[cur ^ 1], alpha);
+        else rc = msdp_sphere_retr(h, d.Y[cur], d.W0, d.Y[cur ^ 1], alpha);
+        if (rc) return rc;
+    } else {
+        HIPCHK(hipMemcpyAsync(d.Y[cur ^ 1], d.Y[cur], (size_t)rows_capacity(h) * d.ld * sizeof(double),
+                              hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (d.costkind == COST_AFFINE) return msdp_affine_linesearch_cost(h, d.Y[cur ^ 1], val);
+    h->h_ctl->done = 0;
+    if ((rc = push_ctl(h))) return rc;
+    if ((rc = msdp_launch_costgrad(h, cur ^ 1))) return rc;
+    if ((rc = msdp_k_sum_to(h, P_F, &d.ctl->fx_prop))) return rc;
+    double v = 0.0;
+    HIPCHK(hipMemcpyAsync(&v, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *val = 2.0 * v;
+    return 0;
+}
+
+// Adopt the retraction of Y + alpha*U as the new resident point (result of line_search).
+extern "C" int msdp_linesearch_accept(msdp_handle h) {
+    CHECK_H(h);
+    h->h_ctl->cur ^= 1;
+    h->state_valid = false;
+    return 0;
+}
+
+extern "C" int msdp_escape_eigs(msdp_handle h, int32_t k, double tol, int32_t maxit, double* lam_min, double* V,
+                                double* lam_max, int32_t* iters) {
+    CHECK_H(h);
+    int rc = ensure_state(h);
+    if (rc) return rc;
+    return msdp_escape_impl(h, k, tol, maxit, lam_min, V, lam_max, iters);
+}
+
+// ------------------------------------------------------------------ measurement
+static void algo_cost(msdp_handle h, double* bytes, double* flops) {
+    const Dev& d = h->d;
+    const double n = d.n_loc, p = d.p;
+    if (d.costkind == COST_SPARSE) {
+        // nnz*(8+4) + (n+1)*4 + 3*8*n*p + 8*n ; 2*nnz*p + 5*n*p
+        *bytes = (double)d.nnz * 12.0 + (n + 1) * 4.0 + 24.0 * n * p + 8.0 * n;
+        *flops = 2.0 * (double)d.nnz * p + 5.0 * n * p;
+    } else if (d.costkind == COST_DENSE) {
+        *bytes = 8.0 * n * (double)d.n + 24.0 * n * p;
+        *flops = 2.0 * n * (double)d.n * p;
+    } else {
+        *bytes = 0.0; *flops = 0.0;
+    }
+}
+
+extern "C" int msdp_bench_hessvec(msdp_handle h, int32_t reps, double* avg_ms, double* algo_bytes, double* algo_flops) {
+    CHECK_H(h);
+    if (reps < 1 || !avg_ms) return MSDP_EINVAL;
+    int rc = ensure_state(h);
+    if (rc) return rc;
+    // direction: the Riemannian gradient at the resident point
+    HIPCHK(hipMemcpyAsync(h->d.md, h->d.Gr[host_cur(h)], (size_t)rows_capacity(h) * h->d.ld * sizeof(double),
+                          hipMemcpyDeviceToDevice, h->stream));
+    if ((rc = msdp_k_set_active(h, 1))) return rc;
+    for (int i = 0; i < 3; ++i) if ((rc = msdp_launch_hess(h))) return rc;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < reps; ++i) if ((rc = msdp_launch_hess(h))) return rc;
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *avg_ms = (double)ms / reps;
+    if ((rc = msdp_k_set_active(h, 0))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double b, f;
+    algo_cost(h, &b, &f);
+    if (algo_bytes) *algo_bytes = b;
+    if (algo_flops) *algo_flops = f;
+    return 0;
+}
+
+extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms) {
+    CHECK_H(h);
+    if (reps < 1 || !avg_ms) return MSDP_EINVAL;
+    int rc = ensure_state(h);
+    if (rc) return rc;
+    msdp_rtr_opts o;
+    msdp_rtr_default_opts(&o);
+    o.maxinner = 0x7ffffff0; o.maxiter = 1;
+    fill_ctl(h, &o);
+    h->h_ctl->bench_mode = 1;
+    if ((rc = push_ctl(h))) return rc;
+    if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
+    if ((rc = msdp_launch_rtr_begin(h))) return rc;
+    h->h_ctl->done = 0;
+    if ((rc = msdp_launch_tcg_init(h))) return rc;
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = msdp_launch_hess(h)) || (rc = msdp_launch_upd1(h)) || (rc = msdp_launch_upd2(h))) return rc;
+    }
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < reps; ++i) {
+        if ((rc = msdp_launch_hess(h)) || (rc = msdp_launch_upd1(h)) || (rc = msdp_launch_upd2(h))) return rc;
+    }
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *avg_ms = (double)ms / reps;
+    h->h_ctl->bench_mode = 0;
+    h->h_ctl->done = 0;
+    if ((rc = push_ctl(h))) return rc;
+    if ((rc = msdp_k_set_active(h, 0))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->state_valid = false;
+    return 0;
+}

@@ -1,0 +1,128 @@
+// msdp_common.h -- internal structures shared by the HIP translation units of
+// libmanisdp_hip.so.  gfx950 only (wave64, 256 CUs in 8 XCDs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/manisdp_hip.h"
+
+#define MSDP_BLOCK 256            // threads per workgroup (4 waves)
+#define MSDP_MAX_GRID 512         // <= 512 partial sums per reduction (2 per CU)
+#define MSDP_NPART 8              // number of partial-sum arrays
+
+void msdp_set_error(const char* fmt, ...);
+
+#define HIPCHK(expr)                                                              \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            msdp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                           __FILE__, __LINE__);                                   \
+            return MSDP_EHIP;                                                     \
+        }                                                                         \
+    } while (0)
+
+// RTR-level scalars; written only by single-workgroup kernels that run alone
+// between vector kernels (no intra-launch hazards).
+struct Ctl {
+    double fx, fx_prop, gg, gg_prop, norm_grad, Delta, Delta_bar, Delta0;
+    double tolgradnorm, kappa, theta, rho_prime, rho_reg;
+    double rho, rhonum, rhoden;
+    double z_sphere[2];          // unittrace: store.z per slot
+    double sigma;                // AL penalty (affine kinds)
+    int maxiter, maxinner, mininner;
+    int k, cur, done, stop_reason;
+    int hessvecs, accepted, rejected, cost_evals, last_stop_inner;
+    int bench_mode;              // 1: tCG exits disabled (throughput measurement)
+    int tcg_running;             // mirror of Frame.active for host polling
+};
+
+// tCG scalars (tCG.m:102-157, 286-287); two frames, each kernel reads one frame and
+// writes the other so no workgroup ever reads a word another workgroup writes in
+// the same launch.
+struct Frame {
+    double z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha, beta;
+    int active, j, stop, eta_idx;
+};
+
+// Partial-sum array ids
+enum { P_F = 0, P_GG = 1, P_DHD = 2, P_S1 = 3, P_S2 = 4, P_S3 = 5, P_RD = 6, P_AUX = 7 };
+
+enum { MANI_OBLIQUE = 0, MANI_SPHERE = 1 };
+enum { COST_SPARSE = 0, COST_DENSE = 1, COST_AFFINE = 2 };
+
+// Everything a kernel needs, passed by value.
+struct Dev {
+    int n;            // global number of points (matrix order)
+    int n_loc;        // rows owned by this rank
+    int row0;         // global index of local row 0
+    int p;            // current factor width
+    int ld;           // row stride in doubles (even, >= p; pad columns are zero)
+    int G;            // workgroups per row-parallel launch (multiple of 8, <= MSDP_MAX_GRID)
+    int manifold;     // MANI_*
+    int costkind;     // COST_*
+    Ctl* ctl;
+    Frame* F;         // F[0], F[1]
+    double* P;        // MSDP_NPART arrays of MSDP_MAX_GRID doubles
+    double* Y[2];     // point per slot            (n_loc x ld)
+    double* Gr[2];    // Riemannian gradient / slot (n_loc x ld)
+    double* eG[2];    // per-row scalar / slot: eG (onlyunitdiag), YeG (unitdiag)  (n_loc)
+    double* eta[2];
+    double* Heta[2];
+    double* r;
+    double* md;       // mdelta, local rows
+    double* Hmd;
+    double* full;     // gather source of n x ld (== local buffer when nranks == 1)
+    double* W0;       // scratch n_loc x ld
+    double* W1;
+    // sparse C (local rows, global column indices)
+    const int* rowptr;
+    const int* colind;
+    const double* cval;
+    int64_t nnz;
+    // dense C / eS (n_loc x n row-major) per slot for affine kinds
+    double* Cd;       // dense cost matrix rows (COST_DENSE) or c reshaped (COST_AFFINE)
+    double* eS[2];    // affine kinds: eS per slot (n_loc x n)
+    double* AyU;      // affine kinds: A'(A(.)) scratch (n_loc x n)
+    // affine operator: At in CSC (by constraint) and CSR (by matrix entry)
+    int64_t m;
+    const int64_t* at_jc; const int64_t* at_ir; const double* at_pr;     // CSC n^2 x m
+    const int64_t* a_rp;  const int* a_ci;  const double* a_v;           // CSR by entry (n^2 rows)
+    const double* b; double* yv; double* Axb[2]; double* w;              // length m
+    double* Pm;       // partial sums for m-length reductions
+};
+
+struct msdp_handle_s {
+    int kind = 0;
+    Dev d{};
+    int pcap = 0;
+    int ldcap = 0;
+    bool have_point = false;
+    bool state_valid = false;      // cost/grad state computed at the resident point
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Ctl* h_ctl = nullptr;          // pinned host mirror
+    Frame* h_frame = nullptr;
+    std::vector<void*> allocs;     // everything to hipFree
+    // host copies needed for re-allocation / sharding
+    int nranks = 1, rank = 0;
+    void* comm = nullptr;          // ncclComm_t
+    std::vector<int> h_rowptr; std::vector<int> h_colind; std::vector<double> h_cval;
+    // device-side sparse arrays owned by the handle
+    int* d_rowptr = nullptr; int* d_colind = nullptr; double* d_cval = nullptr;
+    msdp_rtr_opts last_opts{};
+};
+
+// --- launchers implemented in the .hip units (all asynchronous on h->stream) ---
+int msdp_launch_costgrad(msdp_handle h, int slot);            // Y[slot] -> Gr[slot], eG[slot], P_F, P_GG
+int msdp_launch_hess(msdp_handle h);                          // md -> Hmd, P_DHD (oblique sparse/dense)
+int msdp_launch_tcg_init(msdp_handle h);
+int msdp_launch_upd1(msdp_handle h);
+int msdp_launch_upd2(msdp_handle h);
+int msdp_launch_retract(msdp_handle h);                       // Y[cur]+eta -> Y[1-cur], P_RD
+int msdp_launch_rtr_begin(msdp_handle h);
+int msdp_launch_rtr_decide(msdp_handle h);
+int msdp_alloc_vectors(msdp_handle h, int pcap);
+int msdp_allreduce_partials(msdp_handle h, int first, int count);   // no-op when nranks == 1
+int msdp_allgather_rows(msdp_handle h, const double* local_rows);   // local -> d.full

@@ -1,0 +1,636 @@
+// msdp_kernels.hip -- row-tiled fp64 kernels of the oblique sparse-C path and the
+// manifold-generic tCG / RTR bookkeeping kernels.  gfx950 (wave64) only.
+//
+// Data layout: every n x p factor / tangent vector is row-major with row stride
+// ld (even, pad columns identically zero) -- byte-identical to MATLAB's p x n
+// column-major Y when ld == p.  A row is served by LPR = pow2 >= ld/2 lanes, each
+// lane owning one double2 (16 B: the coalescing sweet spot), so a wave covers
+// 64/LPR rows and the per-row dot products are LPR-lane shuffles.
+//
+// Reference expressions reproduced here:
+//   cost/grad  ManiSDP_onlyunitdiag.m:117-125   YC=Y*C; eG=sum(YC.*Y); f=.5*sum(eG); G=YC-Y.*eG
+//   hess       ManiSDP_onlyunitdiag.m:127-130   eH=U*C; H=eH-Y.*sum(Y.*eH)-U.*eG
+//   manifold   ManiSDP_onlyunitdiag.m:132-156   proj/tangent, retr
+//   tCG        manopt7.0/manopt/solvers/trustregions/tCG.m:160-289
+//   RTR        manopt7.0/manopt/solvers/trustregions/trustregions.m:405-409,540-729
+#include "msdp_device.h"
+#include <math.h>
+
+// ------------------------------------------------------------------ sparse gather
+// acc[ch] += sum_k C[row,k] * X[k, cols of this lane]; the LPR lanes of a row each
+// fetch one (col,val) pair of the CSR row (coalesced) and broadcast it by shuffle.
+template <int LPR, int NCH>
+__device__ __forceinline__ void spmm_row(const Dev& d, int row, int sub, const double* __restrict__ X,
+                                         double2 (&acc)[NCH]) {
+    const int start = d.rowptr[row], end = d.rowptr[row + 1];
+    for (int base = start; base < end; base += LPR) {
+        const int my = base + sub;
+        int ci = 0;
+        double cv = 0.0;
+        if (my < end) { ci = d.colind[my]; cv = d.cval[my]; }
+        const int cnt = min(LPR, end - base);
+        for (int t = 0; t < cnt; ++t) {
+            const int c = __shfl(ci, t, LPR);
+            const double v = __shfl(cv, t, LPR);
+            const double* src = X + (int64_t)c * d.ld + 2 * sub;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (2 * sub + ch * 2 * LPR < d.ld) {
+                    const double2 x = ld2(src + ch * 2 * LPR);
+                    acc[ch].x = fma(v, x.x, acc[ch].x);
+                    acc[ch].y = fma(v, x.y, acc[ch].y);
+                }
+            }
+        }
+    }
+}
+
+// cost + Riemannian gradient at Y[slot] (gather source: d.full holds all rows of Y[slot]).
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_costgrad_sparse_obl(Dev d, int slot) {
+    __shared__ double sh[8];
+    if (d.ctl->done) return;
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RPW = 64 / LPR;
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    const double* __restrict__ Yl = d.Y[slot];
+    const double* __restrict__ Xf = d.full;
+    double* __restrict__ Gr = d.Gr[slot];
+    double* __restrict__ eG = d.eG[slot];
+    double pf = 0.0, pgg = 0.0;
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += 4 * RPW) {
+        const int row = row0 + rsub;
+        if (row < hi) {
+            double2 acc[NCH];
+            double2 y[NCH];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                acc[ch] = make_double2(0.0, 0.0);
+                const int col = 2 * sub + ch * 2 * LPR;
+                y[ch] = (col < d.ld) ? ld2(Yl + (int64_t)row * d.ld + col) : make_double2(0.0, 0.0);
+            }
+            spmm_row<LPR, NCH>(d, row, sub, Xf, acc);
+            double dot = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) dot += acc[ch].x * y[ch].x + acc[ch].y * y[ch].y;
+            dot = msdp_group_sum<LPR>(dot);          // eG(row) = sum(YC.*Y)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int col = 2 * sub + ch * 2 * LPR;
+                if (col < d.ld) {
+                    double2 g;
+                    g.x = acc[ch].x - y[ch].x * dot;  // G = YC - Y.*eG
+                    g.y = acc[ch].y - y[ch].y * dot;
+                    st2(Gr + (int64_t)row * d.ld + col, g);
+                    pgg += g.x * g.x + g.y * g.y;
+                }
+            }
+            if (sub == 0) { eG[row] = dot; pf += 0.5 * dot; }
+        }
+    }
+    msdp_put_partial(d.P, P_F, pf, sh);
+    msdp_put_partial(d.P, P_GG, pgg, sh);
+}
+
+// Hess-vec: Hmd = proj-fused (C*md - Y.*rowdot(Y, C*md) - md.*eG), partial <md, Hmd>.
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_hess_sparse_obl(Dev d) {
+    __shared__ double sh[8];
+    if (!d.F[0].active) return;
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RPW = 64 / LPR;
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    const int cur = d.ctl->cur;
+    const double* __restrict__ Yl = d.Y[cur];
+    const double* __restrict__ eG = d.eG[cur];
+    const double* __restrict__ Uf = d.full;
+    const double* __restrict__ Ul = d.md;
+    double* __restrict__ H = d.Hmd;
+    double pd = 0.0;
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += 4 * RPW) {
+        const int row = row0 + rsub;
+        if (row < hi) {
+            double2 acc[NCH], y[NCH], u[NCH];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                acc[ch] = make_double2(0.0, 0.0);
+                const int col = 2 * sub + ch * 2 * LPR;
+                const bool ok = col < d.ld;
+                y[ch] = ok ? ld2(Yl + (int64_t)row * d.ld + col) : make_double2(0.0, 0.0);
+                u[ch] = ok ? ld2(Ul + (int64_t)row * d.ld + col) : make_double2(0.0, 0.0);
+            }
+            const double eg = eG[row];
+            spmm_row<LPR, NCH>(d, row, sub, Uf, acc);
+            double dot = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) dot += acc[ch].x * y[ch].x + acc[ch].y * y[ch].y;
+            dot = msdp_group_sum<LPR>(dot);          // sum(Y.*eH)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int col = 2 * sub + ch * 2 * LPR;
+                if (col < d.ld) {
+                    double2 h;
+                    h.x = acc[ch].x - y[ch].x * dot - u[ch].x * eg;
+                    h.y = acc[ch].y - y[ch].y * dot - u[ch].y * eg;
+                    st2(H + (int64_t)row * d.ld + col, h);
+                    pd += u[ch].x * h.x + u[ch].y * h.y;
+                }
+            }
+        }
+    }
+    msdp_put_partial(d.P, P_DHD, pd, sh);
+}
+
+// ------------------------------------------------------------------ tCG kernels
+// tCG.m:102-157: eta=0, Heta=0, r=grad, mdelta=r, scalars.
+__global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_init(Dev d) {
+    const Ctl* c = d.ctl;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        Frame f;
+        f.z_r = c->gg; f.d_Pd = c->gg; f.e_Pd = 0.0; f.e_Pe = 0.0; f.model_value = 0.0;
+        f.norm_r0 = sqrt(c->gg); f.alpha = 0.0; f.beta = 0.0;
+        f.active = c->done ? 0 : 1; f.j = 0; f.stop = 5; f.eta_idx = 0;
+        d.F[0] = f;
+        d.F[1] = f;
+        d.ctl->tcg_running = f.active;
+    }
+    if (c->done) return;
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const double* __restrict__ g = d.Gr[c->cur];
+    const int64_t e0 = (int64_t)lo * d.ld, e1 = (int64_t)hi * d.ld;
+    const double2 z = make_double2(0.0, 0.0);
+    for (int64_t i = e0 + 2 * threadIdx.x; i < e1; i += 2 * MSDP_BLOCK) {
+        const double2 gv = ld2(g + i);
+        st2(d.r + i, gv);
+        st2(d.md + i, gv);
+        st2(d.eta[0] + i, z);
+        st2(d.Heta[0] + i, z);
+    }
+}
+
+// tCG.m:166-241 (everything between the Hess-vec and the residual norm).
+__global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd1(Dev d) {
+    __shared__ double sh[8];
+    const Frame f0 = d.F[0];
+    if (!f0.active) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) d.F[1] = f0;
+        return;
+    }
+    const Ctl* c = d.ctl;
+    const bool bench = c->bench_mode != 0;
+    const double d_Hd = msdp_sum_partials(d.P, P_DHD, d.G, sh);       // :166
+    const double alpha = f0.z_r / d_Hd;                                 // :170
+    const double e_Pe_new = f0.e_Pe + 2.0 * alpha * f0.e_Pd + alpha * alpha * f0.d_Pd;  // :173
+    const double Delta = c->Delta;
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const int64_t e0 = (int64_t)lo * d.ld, e1 = (int64_t)hi * d.ld;
+    const int ix = f0.eta_idx;
+    const double* __restrict__ eta = d.eta[ix];
+    const double* __restrict__ Heta = d.Heta[ix];
+    double* __restrict__ neta = d.eta[ix ^ 1];
+    double* __restrict__ nHeta = d.Heta[ix ^ 1];
+    if (!bench && (d_Hd <= 0.0 || e_Pe_new >= Delta * Delta)) {         // :183
+        const double tau = (-f0.e_Pd + sqrt(f0.e_Pd * f0.e_Pd + f0.d_Pd * (Delta * Delta - f0.e_Pe))) / f0.d_Pd;  // :188
+        for (int64_t i = e0 + 2 * threadIdx.x; i < e1; i += 2 * MSDP_BLOCK) {
+            const double2 e = ld2(eta + i), he = ld2(Heta + i), m = ld2(d.md + i), hm = ld2(d.Hmd + i);
+            st2(neta + i, make_double2(e.x - tau * m.x, e.y - tau * m.y));       // :192
+            st2(nHeta + i, make_double2(he.x - tau * hm.x, he.y - tau * hm.y));  // :198
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            Frame f = f0;
+            f.active = 0; f.stop = (d_Hd <= 0.0) ? 1 : 2; f.eta_idx = ix ^ 1; f.j = f0.j + 1;
+            d.F[1] = f;
+        }
+        return;
+    }
+    const double* __restrict__ g = d.Gr[c->cur];
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int64_t i = e0 + 2 * threadIdx.x; i < e1; i += 2 * MSDP_BLOCK) {
+        const double2 e = ld2(eta + i), he = ld2(Heta + i), m = ld2(d.md + i), hm = ld2(d.Hmd + i);
+        const double2 rr = ld2(d.r + i), gv = ld2(g + i);
+        const double2 ne = make_double2(e.x - alpha * m.x, e.y - alpha * m.y);         // :215
+        const double2 nh = make_double2(he.x - alpha * hm.x, he.y - alpha * hm.y);     // :220
+        const double2 nr = make_double2(rr.x - alpha * hm.x, rr.y - alpha * hm.y);     // :238
+        st2(neta + i, ne);
+        st2(nHeta + i, nh);
+        st2(d.r + i, nr);
+        s1 += ne.x * gv.x + ne.y * gv.y;      // <new_eta, grad>     :227
+        s2 += ne.x * nh.x + ne.y * nh.y;      // <new_eta, new_Heta>
+        s3 += nr.x * nr.x + nr.y * nr.y;      // r_r                 :241
+    }
+    msdp_put_partial(d.P, P_S1, s1, sh);
+    msdp_put_partial(d.P, P_S2, s2, sh);
+    msdp_put_partial(d.P, P_S3, s3, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        Frame f = f0;
+        f.alpha = alpha; f.e_Pe = e_Pe_new;      // :214
+        d.F[1] = f;
+    }
+}
+
+// tCG.m:227-287: model check, convergence test, new direction + tangent re-projection.
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd2_obl(Dev d) {
+    __shared__ double sh[8];
+    const Frame f1 = d.F[1];
+    if (!f1.active) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { d.F[0] = f1; d.ctl->tcg_running = 0; }
+        return;
+    }
+    const Ctl* c = d.ctl;
+    const bool bench = c->bench_mode != 0;
+    const double s1 = msdp_sum_partials(d.P, P_S1, d.G, sh);
+    const double s2 = msdp_sum_partials(d.P, P_S2, d.G, sh);
+    const double r_r = msdp_sum_partials(d.P, P_S3, d.G, sh);
+    const double new_model = s1 + 0.5 * s2;                 // :227
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    Frame f = f1;
+    f.j = f1.j + 1;
+    if (!bench && new_model >= f1.model_value) {            // :228
+        f.active = 0; f.stop = 6;
+        if (lead) { d.F[0] = f; d.ctl->tcg_running = 0; }
+        return;
+    }
+    f.eta_idx = f1.eta_idx ^ 1;                             // :233-235 commit new_eta/new_Heta
+    f.model_value = new_model;
+    const double norm_r = sqrt(r_r);
+    if (!bench && f.j >= c->mininner &&
+        norm_r <= f1.norm_r0 * fmin(pow(f1.norm_r0, c->theta), c->kappa)) {   // :249
+        f.active = 0; f.stop = (c->kappa < pow(f1.norm_r0, c->theta)) ? 3 : 4;
+        if (lead) { d.F[0] = f; d.ctl->tcg_running = 0; }
+        return;
+    }
+    if (f.j >= c->maxinner) {                               // loop bound :160 (stop stays 5)
+        f.active = 0;
+        if (lead) { d.F[0] = f; d.ctl->tcg_running = 0; }
+        return;
+    }
+    const double beta = r_r / f1.z_r;                       // :272
+    f.beta = beta;
+    f.e_Pd = beta * (f1.e_Pd + f1.alpha * f1.d_Pd);         // :286
+    f.d_Pd = r_r + beta * beta * f1.d_Pd;                   // :287
+    f.z_r = r_r;
+    if (lead) d.F[0] = f;
+    // mdelta = tangent(z + beta*mdelta), z = r   :273,283
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RPW = 64 / LPR;
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    const double* __restrict__ Yl = d.Y[c->cur];
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += 4 * RPW) {
+        const int row = row0 + rsub;
+        if (row < hi) {
+            double2 v[NCH], y[NCH];
+            double dot = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int col = 2 * sub + ch * 2 * LPR;
+                if (col < d.ld) {
+                    const int64_t o = (int64_t)row * d.ld + col;
+                    const double2 rr = ld2(d.r + o), m = ld2(d.md + o);
+                    y[ch] = ld2(Yl + o);
+                    v[ch] = make_double2(rr.x + beta * m.x, rr.y + beta * m.y);
+                    dot += v[ch].x * y[ch].x + v[ch].y * y[ch].y;
+                } else { v[ch] = make_double2(0.0, 0.0); y[ch] = v[ch]; }
+            }
+            dot = msdp_group_sum<LPR>(dot);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int col = 2 * sub + ch * 2 * LPR;
+                if (col < d.ld)
+                    st2(d.md + (int64_t)row * d.ld + col,
+                        make_double2(v[ch].x - y[ch].x * dot, v[ch].y - y[ch].y * dot));
+            }
+        }
+    }
+}
+
+// x_prop = retr(x, eta) (ManiSDP_onlyunitdiag.m:142-145) into the other slot, and the
+// partial of <eta, grad + .5*Heta> (trustregions.m:549-550).
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_retract_obl(Dev d) {
+    __shared__ double sh[8];
+    const Ctl* c = d.ctl;
+    if (c->done) return;
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RPW = 64 / LPR;
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    const int cur = c->cur, ix = d.F[0].eta_idx;
+    const double* __restrict__ Yl = d.Y[cur];
+    const double* __restrict__ g = d.Gr[cur];
+    const double* __restrict__ eta = d.eta[ix];
+    const double* __restrict__ Heta = d.Heta[ix];
+    double* __restrict__ Yp = d.Y[cur ^ 1];
+    double prd = 0.0;
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += 4 * RPW) {
+        const int row = row0 + rsub;
+        if (row < hi) {
+            double2 x[NCH];
+            double nn = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int col = 2 * sub + ch * 2 * LPR;
+                if (col < d.ld) {
+                    const int64_t o = (int64_t)row * d.ld + col;
+                    const double2 y = ld2(Yl + o), e = ld2(eta + o), he = ld2(Heta + o), gv = ld2(g + o);
+                    x[ch] = make_double2(y.x + e.x, y.y + e.y);
+                    nn += x[ch].x * x[ch].x + x[ch].y * x[ch].y;
+                    prd += e.x * (gv.x + 0.5 * he.x) + e.y * (gv.y + 0.5 * he.y);
+                } else x[ch] = make_double2(0.0, 0.0);
+            }
+            nn = sqrt(msdp_group_sum<LPR>(nn));
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int col = 2 * sub + ch * 2 * LPR;
+                if (col < d.ld)
+                    st2(Yp + (int64_t)row * d.ld + col, make_double2(x[ch].x / nn, x[ch].y / nn));
+            }
+        }
+    }
+    msdp_put_partial(d.P, P_RD, prd, sh);
+}
+
+// ------------------------------------------------------------------ RTR scalars
+// trustregions.m:405-409 after the first cost/grad.
+__global__ __launch_bounds__(MSDP_BLOCK) void k_rtr_begin(Dev d) {
+    __shared__ double sh[8];
+    const double f = msdp_sum_partials(d.P, P_F, d.G, sh);
+    const double gg = msdp_sum_partials(d.P, P_GG, d.G, sh);
+    if (threadIdx.x == 0) {
+        Ctl* c = d.ctl;
+        c->fx = f; c->gg = gg; c->norm_grad = sqrt(gg);
+        c->Delta = c->Delta0;
+        c->k = 0; c->hessvecs = 0; c->accepted = 0; c->rejected = 0; c->cost_evals = 1;
+        c->last_stop_inner = 0;
+        c->done = (c->norm_grad < c->tolgradnorm) || (c->k >= c->maxiter);   // stoppingcriterion.m:51-72
+        c->tcg_running = 0;
+    }
+}
+
+// trustregions.m:548-729: rho, radius update, accept/reject, stopping test.
+__global__ __launch_bounds__(MSDP_BLOCK) void k_rtr_decide(Dev d) {
+    __shared__ double sh[8];
+    if (d.ctl->done) return;
+    const double fp = msdp_sum_partials(d.P, P_F, d.G, sh);
+    const double ggp = msdp_sum_partials(d.P, P_GG, d.G, sh);
+    const double rd = msdp_sum_partials(d.P, P_RD, d.G, sh);
+    if (threadIdx.x == 0) {
+        Ctl* c = d.ctl;
+        const Frame f = d.F[0];
+        double rhonum = c->fx - fp;                                          // :548
+        double rhoden = -rd;                                                 // :550
+        const double rho_reg = fmax(1.0, fabs(c->fx)) * 2.220446049250313e-16 * c->rho_reg;   // :579
+        rhonum += rho_reg;
+        rhoden += rho_reg;
+        const bool model_decreased = rhoden >= 0.0;                          // :614
+        const double rho = rhonum / rhoden;                                  // :621
+        if (rho < 0.25 || !model_decreased || isnan(rho)) {                  // :653
+            c->Delta = c->Delta / 4.0;
+        } else if (rho > 0.75 && (f.stop == 1 || f.stop == 2)) {             // :669
+            c->Delta = fmin(2.0 * c->Delta, c->Delta_bar);
+        }
+        if (model_decreased && rho > c->rho_prime) {                         // :688
+            c->cur ^= 1;
+            c->fx = fp; c->gg = ggp; c->norm_grad = sqrt(ggp);
+            c->accepted++;
+        } else {
+            c->rejected++;
+        }
+        c->rho = rho; c->rhonum = rhonum; c->rhoden = rhoden; c->fx_prop = fp; c->gg_prop = ggp;
+        c->k++;                                                              // :729
+        c->hessvecs += f.j;
+        c->cost_evals++;
+        c->last_stop_inner = f.stop;
+        c->done = (c->norm_grad < c->tolgradnorm) || (c->k >= c->maxiter);
+    }
+}
+
+// ------------------------------------------------------------------ utilities
+// Reference layout (row stride p) <-> device layout (row stride ld, zero pad).
+__global__ void k_pack_rows(const double* __restrict__ src, double* __restrict__ dst, int n, int p, int ld) {
+    const int64_t tot = (int64_t)n * ld;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / ld;
+        const int col = (int)(i - row * ld);
+        dst[i] = (col < p) ? src[row * p + col] : 0.0;
+    }
+}
+__global__ void k_unpack_rows(const double* __restrict__ src, double* __restrict__ dst, int n, int p, int ld) {
+    const int64_t tot = (int64_t)n * p;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / p;
+        const int col = (int)(i - row * p);
+        dst[i] = src[row * ld + col];
+    }
+}
+// Same for the n x p column-major boundary layout of unittrace.
+__global__ void k_pack_cols(const double* __restrict__ src, double* __restrict__ dst, int n, int p, int ld) {
+    const int64_t tot = (int64_t)n * ld;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / ld;
+        const int col = (int)(i - row * ld);
+        dst[i] = (col < p) ? src[(int64_t)col * n + row] : 0.0;
+    }
+}
+__global__ void k_unpack_cols(const double* __restrict__ src, double* __restrict__ dst, int n, int p, int ld) {
+    const int64_t tot = (int64_t)n * p;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t col = i / n;
+        const int64_t row = i - col * n;
+        dst[i] = src[row * ld + col];
+    }
+}
+
+// V = U - Y.*rowdot(Y,U) (M.proj, ManiSDP_onlyunitdiag.m:138); flat one-thread-per-row
+// version for the test-only fine-grained entry point.
+__global__ void k_proj_obl_simple(const double* __restrict__ Y, const double* __restrict__ U,
+                                  double* __restrict__ V, int n, int ld) {
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x) {
+        double dot = 0.0;
+        for (int c = 0; c < ld; ++c) dot += Y[(int64_t)row * ld + c] * U[(int64_t)row * ld + c];
+        for (int c = 0; c < ld; ++c) V[(int64_t)row * ld + c] = U[(int64_t)row * ld + c] - Y[(int64_t)row * ld + c] * dot;
+    }
+}
+__global__ void k_retr_obl_simple(const double* __restrict__ Y, const double* __restrict__ U,
+                                  double* __restrict__ Z, double alpha, int n, int ld) {
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x) {
+        double nn = 0.0;
+        for (int c = 0; c < ld; ++c) {
+            const double x = Y[(int64_t)row * ld + c] + alpha * U[(int64_t)row * ld + c];
+            nn += x * x;
+        }
+        nn = sqrt(nn);
+        for (int c = 0; c < ld; ++c)
+            Z[(int64_t)row * ld + c] = (Y[(int64_t)row * ld + c] + alpha * U[(int64_t)row * ld + c]) / nn;
+    }
+}
+__global__ void k_set_frame_active(Dev d, int active) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        d.F[0].active = active; d.F[1].active = active; d.ctl->done = 0;
+    }
+}
+__global__ void k_sum_to(Dev d, int which, double* out) {
+    __shared__ double sh[8];
+    const double s = msdp_sum_partials(d.P, which, d.G, sh);
+    if (threadIdx.x == 0) *out = s;
+}
+
+// ------------------------------------------------------------------ launchers
+static inline void lpr_for(int ld, int& lpr, int& nch) {
+    int half = ld / 2;
+    lpr = 1;
+    while (lpr < half && lpr < 64) lpr <<= 1;
+    nch = (half + lpr - 1) / lpr;
+    if (nch < 1) nch = 1;
+}
+
+#define DISPATCH_LPR(KERNEL, h, ...)                                                                 \
+    do {                                                                                             \
+        int lpr, nch;                                                                                \
+        lpr_for((h)->d.ld, lpr, nch);                                                                \
+        dim3 grid((h)->d.G), block(MSDP_BLOCK);                                                      \
+        if (nch == 1) {                                                                              \
+            switch (lpr) {                                                                           \
+                case 1:  hipLaunchKernelGGL((KERNEL<1, 1>),  grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 2:  hipLaunchKernelGGL((KERNEL<2, 1>),  grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 4:  hipLaunchKernelGGL((KERNEL<4, 1>),  grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 8:  hipLaunchKernelGGL((KERNEL<8, 1>),  grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 16: hipLaunchKernelGGL((KERNEL<16, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 32: hipLaunchKernelGGL((KERNEL<32, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                default: hipLaunchKernelGGL((KERNEL<64, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+            }                                                                                        \
+        } else if (nch == 2) {                                                                       \
+            hipLaunchKernelGGL((KERNEL<64, 2>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
+        } else if (nch <= 4) {                                                                       \
+            hipLaunchKernelGGL((KERNEL<64, 4>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
+        } else {                                                                                     \
+            msdp_set_error("factor width p = %d exceeds the supported maximum of 512", (h)->d.p);    \
+            return MSDP_EUNSUPPORTED;                                                                \
+        }                                                                                            \
+    } while (0)
+
+int msdp_dense_costgrad(msdp_handle h, int slot);   // msdp_dense.hip
+int msdp_dense_hess(msdp_handle h);
+int msdp_affine_costgrad(msdp_handle h, int slot);  // msdp_affine.hip
+int msdp_affine_hess(msdp_handle h);
+int msdp_sphere_upd2(msdp_handle h);
+int msdp_sphere_retract(msdp_handle h);
+
+int msdp_launch_costgrad(msdp_handle h, int slot) {
+    // gather source: all rows of Y[slot]
+    int rc = msdp_allgather_rows(h, h->d.Y[slot]);
+    if (rc) return rc;
+    if (h->d.costkind == COST_SPARSE) {
+        DISPATCH_LPR(k_costgrad_sparse_obl, h, h->d, slot);
+    } else if (h->d.costkind == COST_DENSE) {
+        rc = msdp_dense_costgrad(h, slot);
+        if (rc) return rc;
+    } else {
+        rc = msdp_affine_costgrad(h, slot);
+        if (rc) return rc;
+    }
+    HIPCHK(hipGetLastError());
+    return msdp_allreduce_partials(h, P_F, 2);
+}
+
+int msdp_launch_hess(msdp_handle h) {
+    int rc = msdp_allgather_rows(h, h->d.md);
+    if (rc) return rc;
+    if (h->d.costkind == COST_SPARSE) {
+        DISPATCH_LPR(k_hess_sparse_obl, h, h->d);
+    } else if (h->d.costkind == COST_DENSE) {
+        rc = msdp_dense_hess(h);
+        if (rc) return rc;
+    } else {
+        rc = msdp_affine_hess(h);
+        if (rc) return rc;
+    }
+    HIPCHK(hipGetLastError());
+    return msdp_allreduce_partials(h, P_DHD, 1);
+}
+
+int msdp_launch_tcg_init(msdp_handle h) {
+    hipLaunchKernelGGL(k_tcg_init, dim3(h->d.G), dim3(MSDP_BLOCK), 0, h->stream, h->d);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int msdp_launch_upd1(msdp_handle h) {
+    hipLaunchKernelGGL(k_tcg_upd1, dim3(h->d.G), dim3(MSDP_BLOCK), 0, h->stream, h->d);
+    HIPCHK(hipGetLastError());
+    return msdp_allreduce_partials(h, P_S1, 3);
+}
+
+int msdp_launch_upd2(msdp_handle h) {
+    if (h->d.manifold == MANI_OBLIQUE) {
+        DISPATCH_LPR(k_tcg_upd2_obl, h, h->d);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    return msdp_sphere_upd2(h);
+}
+
+int msdp_launch_retract(msdp_handle h) {
+    if (h->d.manifold == MANI_OBLIQUE) {
+        DISPATCH_LPR(k_retract_obl, h, h->d);
+        HIPCHK(hipGetLastError());
+        return msdp_allreduce_partials(h, P_RD, 1);
+    }
+    return msdp_sphere_retract(h);
+}
+
+int msdp_launch_rtr_begin(msdp_handle h) {
+    hipLaunchKernelGGL(k_rtr_begin, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, h->d);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int msdp_launch_rtr_decide(msdp_handle h) {
+    hipLaunchKernelGGL(k_rtr_decide, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, h->d);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- small launch wrappers used by the API unit ----
+int msdp_k_pack(msdp_handle h, const double* src, double* dst, int n, int p, int ld, bool colmajor) {
+    const int grid = 1024;
+    if (colmajor) hipLaunchKernelGGL(k_pack_cols, dim3(grid), dim3(256), 0, h->stream, src, dst, n, p, ld);
+    else hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, h->stream, src, dst, n, p, ld);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int msdp_k_unpack(msdp_handle h, const double* src, double* dst, int n, int p, int ld, bool colmajor) {
+    const int grid = 1024;
+    if (colmajor) hipLaunchKernelGGL(k_unpack_cols, dim3(grid), dim3(256), 0, h->stream, src, dst, n, p, ld);
+    else hipLaunchKernelGGL(k_unpack_rows, dim3(grid), dim3(256), 0, h->stream, src, dst, n, p, ld);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int msdp_k_proj_obl(msdp_handle h, const double* Y, const double* U, double* V) {
+    hipLaunchKernelGGL(k_proj_obl_simple, dim3(256), dim3(256), 0, h->stream, Y, U, V, h->d.n_loc, h->d.ld);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int msdp_k_retr_obl(msdp_handle h, const double* Y, const double* U, double* Z, double alpha) {
+    hipLaunchKernelGGL(k_retr_obl_simple, dim3(256), dim3(256), 0, h->stream, Y, U, Z, alpha, h->d.n_loc, h->d.ld);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int msdp_k_set_active(msdp_handle h, int active) {
+    hipLaunchKernelGGL(k_set_frame_active, dim3(1), dim3(64), 0, h->stream, h->d, active);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int msdp_k_sum_to(msdp_handle h, int which, double* out) {
+    hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, h->d, which, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

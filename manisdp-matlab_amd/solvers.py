@@ -1,0 +1,331 @@
+"""Host-side mirrors of the reference's three primal entry points.
+
+Same names, option names, defaults, printed protocol and ``data`` fields as
+``src/primal/ManiSDP_onlyunitdiag.m``, ``ManiSDP_unitdiag.m`` and
+``ManiSDP_unittrace.m``.  The augmented-Lagrangian loop and the bookkeeping
+(multiplier / sigma updates, KKT residues, rank cut, escape set-up) stay on the
+host exactly as in the reference; every ``trustregions(problem, Y, opts)`` call
+(``ManiSDP_onlyunitdiag.m:43``, ``ManiSDP_unitdiag.m:57``, ``ManiSDP_unittrace.m:57``)
+is replaced by ``msdp_rtr`` on the HIP library, with the factor resident in HBM.
+
+Factors are NumPy ``(n, p)`` arrays (for the oblique kinds the bytes of MATLAB's
+``p x n`` column-major ``Y``).  Returned ``X`` is the factor ``Y`` (``X = Y Y'``);
+``data['X']`` holds the dense matrix only when ``n <= options['dense_X_max']``.
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+
+__all__ = ["ManiSDP_onlyunitdiag", "ManiSDP_unitdiag", "ManiSDP_unittrace"]
+
+
+def _say(verbose, msg):
+    if verbose:
+        print(msg, flush=True)
+
+
+def _rtr_opts(o):
+    return _lib.default_opts(maxiter=int(o["TR_maxiter"]), maxinner=int(o["TR_maxinner"]),
+                             tolgradnorm=float(o["tolgradnorm"]))
+
+
+def _thin_svd_rank(Y, theta):
+    """svd(Y) and r = sum(e >= theta*e(1)) (ManiSDP_onlyunitdiag.m:52-54) through the
+    p x p Gram matrix: never forms the n x n V of the reference."""
+    G = Y.T @ Y
+    w, Q = np.linalg.eigh(G)
+    order = np.argsort(w)[::-1]
+    w = np.maximum(w[order], 0.0)
+    Q = Q[:, order]
+    e = np.sqrt(w)
+    r = int(np.sum(e >= theta * e[0]))
+    return Q, e, r
+
+
+def _rank_cut(Y, Q, e, r):
+    """Y = V(:,1:r)'.*e(1:r): with Y = V diag(e) Q', V(:,k) e_k = Y Q(:,k)."""
+    return Y @ Q[:, :r]
+
+
+def _extreme_eigs_host(S, k, dense_max):
+    """lambda_min side (k smallest eigenpairs) and lambda_max of S on the host.
+    n <= dense_max: LAPACK like the reference's eig(full(S)) (ManiSDP_onlyunitdiag.m:50)."""
+    n = S.shape[0]
+    if n <= dense_max:
+        Sd = S.toarray() if sp.issparse(S) else np.asarray(S)
+        dS, vS = np.linalg.eigh(Sd)
+        return dS, vS, int(np.sum(dS < 0))
+    raise RuntimeError("host eigensolver limit exceeded; use the device escape (options['eig'] = 'device')")
+
+
+# =============================================================== onlyunitdiag
+def ManiSDP_onlyunitdiag(C, options=None, verbose=True, rng=None):
+    """``[X, obj, data] = ManiSDP_onlyunitdiag(C, options)`` (reference
+    src/primal/ManiSDP_onlyunitdiag.m:6).  Extra, optional option fields that the
+    reference does not have: ``Y0`` (start point instead of ``randn``), ``eig``
+    (``'host'`` dense LAPACK | ``'device'`` few-eigenvector escape; default by size),
+    ``dense_X_max``."""
+    o = dict(options or {})
+    o.setdefault("p0", 2); o.setdefault("AL_maxiter", 20); o.setdefault("tol", 1e-8)
+    o.setdefault("theta", 1e-1); o.setdefault("delta", 8); o.setdefault("alpha", 0.5)
+    o.setdefault("tolgradnorm", 1e-8); o.setdefault("TR_maxinner", 100); o.setdefault("TR_maxiter", 40)
+    o.setdefault("line_search", 0)
+    dense_max = int(o.get("dense_eig_max", 3000))
+    dense_X_max = int(o.get("dense_X_max", 4000))
+    rng = rng or np.random.default_rng(0)
+
+    _say(verbose, "ManiSDP is starting...")
+    n = C.shape[0]
+    _say(verbose, f"SDP size: n = {n}, m = {n}")
+    Csp = C.tocsr() if sp.issparse(C) else np.asarray(C, dtype=np.float64)
+    eig_mode = o.get("eig", "host" if n <= dense_max else "device")
+    h = _lib.Handle.onlyunitdiag(Csp, pcap=max(32, int(o["p0"]) + 2 * int(o["delta"])))
+    topts = _rtr_opts(o)
+    p = int(o["p0"])
+    Y = o.get("Y0", None)
+    if Y is None:                                          # trustregions.m:390-392 -> M.rand()
+        Y = rng.standard_normal((n, p))
+        Y /= np.sqrt(np.sum(Y * Y, axis=1, keepdims=True))
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    U = None
+    data = {"status": 0, "hessvecs": 0, "cost_evals": 0, "rejected": 0, "rtr_seconds": 0.0,
+            "eig_seconds": 0.0, "log": []}
+    t0 = time.time()
+    dinf0 = None
+    obj = dinf = gradnorm = None
+    z = S = None
+    try:
+        for it in range(1, int(o["AL_maxiter"]) + 1):      # :38
+            h.set_point(Y)
+            if U is not None:                              # :40-42 line_search
+                _line_search(h, U)
+            st = h.rtr(topts)                              # :43
+            data["rtr_seconds"] += st.seconds
+            data["hessvecs"] += st.hessvecs
+            data["cost_evals"] += st.cost_evals
+            data["rejected"] += st.rejected
+            gradnorm = st.gradnorm                         # :44
+            Y = h.get_point()
+            z = h.get_z()                                  # :46-47  z = sum((Y*C).*Y)
+            obj = float(np.sum(z))                         # :48
+            t1 = time.time()
+            if eig_mode == "host":
+                S = (Csp - sp.diags(z)) if sp.issparse(Csp) else (Csp - np.diag(z))   # :49
+                dS, vS, nneg = _extreme_eigs_host(S, int(o["delta"]), dense_max)     # :50
+                lam_min, lam_max = dS[0], dS[-1]
+            else:
+                k = int(o["delta"])
+                lam, vS, lam_max, _ = h.escape_eigs(k, tol=float(o.get("eig_tol", 1e-9)),
+                                                    maxit=int(o.get("eig_maxit", 2000)))
+                lam_min = lam[0]
+                nneg = int(np.sum(lam < 0))
+                S = None
+            data["eig_seconds"] += time.time() - t1
+            dinf = max(0.0, -lam_min) / (1.0 + lam_max)    # :51
+            Q, e, r = _thin_svd_rank(Y, float(o["theta"]))  # :52-54
+            _say(verbose, "Iter %d, obj:%0.8f, dinf:%0.1e, r:%d, p:%d, time:%0.2fs"
+                 % (it, obj, dinf, r, p, time.time() - t0))
+            data["log"].append((it, obj, dinf, r, p, time.time() - t0, st.hessvecs))
+            data["iters"] = it
+            if dinf < o["tol"]:                            # :57-60
+                _say(verbose, "Optimality is reached!")
+                break
+            if it % 20 == 0:                               # :61-69
+                if it > 50 and dinf > dinf0:
+                    data["status"] = 2
+                    _say(verbose, "Slow progress!")
+                    break
+                dinf0 = dinf
+            if r <= p - 1:                                 # :70-73
+                Y = _rank_cut(Y, Q, e, r)
+                p = r
+            nne = max(min(nneg, int(o["delta"])), 1)       # :74
+            if o["line_search"] == 1:                      # :75-77
+                U = np.hstack([np.zeros((n, p)), vS[:, :nne]])
+            p = p + nne                                    # :78
+            if o["line_search"] == 1:
+                Y = np.hstack([Y, np.zeros((n, nne))])     # :80
+            else:
+                Y = np.hstack([Y, o["alpha"] * vS[:, :nne]])   # :82
+                Y = Y / np.sqrt(np.sum(Y * Y, axis=1, keepdims=True))   # :83
+            Y = np.ascontiguousarray(Y)
+    finally:
+        h.close()
+    data.update({"Y": Y, "S": S, "z": z, "dinf": dinf, "gradnorm": gradnorm,
+                 "time": time.time() - t0, "p": Y.shape[1]})
+    if n <= dense_X_max:
+        data["X"] = Y @ Y.T                                # :45,86
+    if data["status"] == 0 and dinf > o["tol"]:            # :92-95
+        data["status"] = 1
+        _say(verbose, "Iteration maximum is reached!")
+    _say(verbose, "ManiSDP: optimum = %0.8f, time = %0.2fs" % (obj, time.time() - t0))
+    return Y, obj, data
+
+
+def _line_search(h, U):
+    """line_search(Y, U) (ManiSDP_onlyunitdiag.m:103-115, ManiSDP_unitdiag.m:138-150,
+    ManiSDP_unittrace.m:142-154) with every co() evaluated on the device; leaves the
+    accepted trial point resident."""
+    alpha = 1.0
+    cost0 = h.linesearch_cost(None, 0.0)
+    i = 1
+    val = h.linesearch_cost(U, alpha)
+    while i <= 15 and val - cost0 > -1e-3:
+        alpha = 0.8 * alpha
+        val = h.linesearch_cost(U, alpha)
+        i += 1
+    h.linesearch_accept()
+
+
+# =================================================================== unitdiag
+def _dense_vec(v):
+    if sp.issparse(v):
+        return np.asarray(v.todense()).ravel()
+    return np.asarray(v, dtype=np.float64).ravel()
+
+
+def _affine_common(kind, At, b, c, K, options, verbose, rng, defaults):
+    o = dict(options or {})
+    for k, v in defaults.items():
+        o.setdefault(k, v)
+    n = int(K["s"])
+    rng = rng or np.random.default_rng(0)
+    b = _dense_vec(b)
+    c = _dense_vec(c)
+    Atc = sp.csc_matrix(At)
+    A = Atc.T.tocsr()
+    sphere = kind == _lib.KIND_UNITTRACE
+    _say(verbose, "ManiSDP is starting...")
+    _say(verbose, f"SDP size: n = {n}, m = {b.size}")
+    h = _lib.Handle.affine(kind, Atc, b, c, n, pcap=max(32, int(o["p0"]) + 2 * int(o["delta"])))
+    topts = _rtr_opts(o)
+    p = int(o["p0"])
+    sigma = float(o["sigma0"])
+    gama = float(o["gama"])
+    y = np.zeros(b.size)
+    normb = 1.0 + np.linalg.norm(b)
+    Y = o.get("Y0", None)
+    if Y is None:
+        Y = rng.standard_normal((n, p))
+        if sphere:
+            Y /= np.linalg.norm(Y)                         # spherefactory.m:249-254
+        else:
+            Y /= np.sqrt(np.sum(Y * Y, axis=1, keepdims=True))
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    U = None
+    fac_size = []
+    data = {"status": 0, "hessvecs": 0, "cost_evals": 0, "rejected": 0, "rtr_seconds": 0.0,
+            "eig_seconds": 0.0, "log": []}
+    t0 = time.time()
+    gap0 = pinf0 = dinf0 = None
+    obj = gap = pinf = dinf = gradnorm = eta_kkt = None
+    S = z = None
+    slow_every, slow_after = (20, 50) if sphere else (50, 100)
+    try:
+        for it in range(1, int(o["AL_maxiter"]) + 1):
+            fac_size.append(p)
+            h.set_multipliers(y, sigma)
+            h.set_point(Y)
+            if U is not None:
+                _line_search(h, U)
+            st = h.rtr(topts)
+            data["rtr_seconds"] += st.seconds
+            data["hessvecs"] += st.hessvecs
+            data["cost_evals"] += st.cost_evals
+            data["rejected"] += st.rejected
+            gradnorm = st.gradnorm
+            Y = h.get_point()
+            X = Y @ Y.T                                    # unitdiag :59 / unittrace :59
+            x = X.ravel(order="F")
+            obj = float(c @ x)                             # :61
+            Axb = A @ x - b                                # :62
+            pinf = float(np.linalg.norm(Axb)) / normb      # :63
+            y = y - sigma * Axb                            # :64
+            eS = (c - Atc @ y).reshape((n, n), order="F")  # :65
+            t1 = time.time()
+            if sphere:
+                z = float(np.sum(eS * X))                  # unittrace :66
+                S = eS - z * np.eye(n)                     # :67
+                by = float(b @ y) + z                      # :70
+            else:
+                z = np.sum(X * eS, axis=0)                 # unitdiag :66
+                S = eS - np.diag(z)                        # :67
+                by = float(b @ y) + float(np.sum(z))       # :70
+            dS, vS = np.linalg.eigh(S)                     # :68
+            data["eig_seconds"] += time.time() - t1
+            dinf = max(0.0, -dS[0]) / (1.0 + dS[-1])       # :69
+            gap = abs(obj - by) / (abs(by) + abs(obj) + 1.0)   # :71
+            Q, e, r = _thin_svd_rank(Y, float(o["theta"]))     # :72-74
+            _say(verbose, "Iter %d, obj:%0.8f, gap:%0.1e, pinf:%0.1e, dinf:%0.1e, gradnorm:%0.1e, r:%d, p:%d, sigma:%0.3f, time:%0.2fs"
+                 % (it, obj, gap, pinf, dinf, gradnorm, r, p, sigma, time.time() - t0))
+            data["log"].append((it, obj, gap, pinf, dinf, gradnorm, r, p, sigma, time.time() - t0))
+            eta_kkt = max(gap, pinf, dinf)                 # :77
+            data["iters"] = it
+            if eta_kkt < o["tol"]:
+                _say(verbose, "Optimality is reached!")
+                break
+            if it % slow_every == 0:                       # unitdiag :82-92 / unittrace :86-96
+                if it > slow_after and gap > gap0 and pinf > pinf0 and dinf > dinf0:
+                    data["status"] = 2
+                    _say(verbose, "Slow progress!")
+                    break
+                gap0, pinf0, dinf0 = gap, pinf, dinf
+            if r <= p - 1:                                 # :93-96
+                Y = _rank_cut(Y, Q, e, r)
+                p = r
+            nneg = int(np.sum(dS < 0))
+            if sphere:
+                nne = min(nneg, int(o["delta"]))           # unittrace :101
+            else:
+                nne = max(min(nneg, int(o["delta"])), 1)   # unitdiag :97
+            if o["line_search"] == 1:
+                U = np.hstack([np.zeros((n, p)), vS[:, :nne]])
+            p = p + nne
+            if o["line_search"] == 1:
+                Y = np.hstack([Y, np.zeros((n, nne))])
+            else:
+                Y = np.hstack([Y, o["alpha"] * vS[:, :nne]])
+                if sphere:
+                    Y = Y / np.linalg.norm(Y)              # unittrace :110
+                else:
+                    Y = Y / np.sqrt(np.sum(Y * Y, axis=1, keepdims=True))   # unitdiag :106
+            Y = np.ascontiguousarray(Y)
+            if pinf < o["tau1"] * gradnorm:                # :108-112
+                sigma = max(sigma / gama, o["sigma_min"])
+            elif pinf > o["tau2"] * gradnorm:
+                sigma = min(sigma * gama, o["sigma_max"])
+    finally:
+        h.close()
+    data.update({"Y": Y, "X": Y @ Y.T, "y": y, "S": S, "z": z, "gap": gap, "pinf": pinf, "dinf": dinf,
+                 "gradnorm": gradnorm, "time": time.time() - t0, "sigma": sigma})
+    if not sphere:
+        data["fac_size"] = fac_size
+    if data["status"] == 0 and eta_kkt > o["tol"]:
+        data["status"] = 1
+        _say(verbose, "Iteration maximum is reached!")
+    _say(verbose, "ManiSDP: optimum = %0.8f, time = %0.2fs" % (obj, time.time() - t0))
+    return Y, obj, data
+
+
+def ManiSDP_unitdiag(At, b, c, K, options=None, verbose=True, rng=None):
+    """``[X, obj, data] = ManiSDP_unitdiag(At, b, c, K, options)`` (reference
+    src/primal/ManiSDP_unitdiag.m:7; defaults :10-26)."""
+    defaults = dict(p0=2, AL_maxiter=300, gama=2, sigma0=1e-3, sigma_min=1e-2, sigma_max=1e7, tol=1e-8,
+                    theta=1e-3, delta=8, alpha=0.1, tolgradnorm=1e-8, TR_maxinner=20, TR_maxiter=4,
+                    tau1=1, tau2=1, line_search=0)
+    return _affine_common(_lib.KIND_UNITDIAG, At, b, c, K, options, verbose, rng, defaults)
+
+
+def ManiSDP_unittrace(At, b, c, K, options=None, verbose=True, rng=None):
+    """``[X, obj, data] = ManiSDP_unittrace(At, b, c, K, options)`` (reference
+    src/primal/ManiSDP_unittrace.m:7; defaults :10-25)."""
+    defaults = dict(p0=1, AL_maxiter=1000, gama=2, sigma0=1e1, sigma_min=1e2, sigma_max=1e7, tol=1e-8,
+                    theta=1e-2, delta=8, alpha=0.05, tolgradnorm=1e-8, TR_maxinner=40, TR_maxiter=3,
+                    tau1=1e-5, tau2=1e-4, line_search=1)
+    return _affine_common(_lib.KIND_UNITTRACE, At, b, c, K, options, verbose, rng, defaults)
