@@ -185,6 +185,9 @@ int msdp_local_rows(msdp_handle h, int64_t* row0, int64_t* row1);
  * the algorithmic bytes/flops of one launch (SURVEY.md 8d formulas). */
 int msdp_bench_hessvec(msdp_handle h, int32_t reps, double* avg_ms,
                        double* algo_bytes, double* algo_flops);
+/* One kernel of the tCG trip in isolation: which = 0 Hess-vec, 1 upd1 (tCG.m:166-241),
+ * 2 upd2 (tCG.m:249-287); average device time per launch in ms. */
+int msdp_bench_kernel(msdp_handle h, int32_t which, int32_t reps, double* avg_ms);
 /* Same for one whole tCG trip (Hess-vec + the vector updates), exits disabled. */
 int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms);
 

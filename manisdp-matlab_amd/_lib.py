@@ -74,6 +74,7 @@ SIGNATURES = {
     "msdp_local_rows": (C.c_int, [C.c_void_p, _i64p, _i64p]),
     "msdp_bench_hessvec": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
     "msdp_bench_tcg_trip": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
+    "msdp_bench_kernel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
     "msdp_last_error": (C.c_char_p, []),
     "msdp_version": (C.c_char_p, []),
 }
@@ -290,6 +291,11 @@ class Handle:
         ms, by, fl = C.c_double(), C.c_double(), C.c_double()
         _check(self._lib.msdp_bench_hessvec(self._h, reps, C.byref(ms), C.byref(by), C.byref(fl)))
         return ms.value, by.value, fl.value
+
+    def bench_kernel(self, which, reps):
+        ms = C.c_double()
+        _check(self._lib.msdp_bench_kernel(self._h, which, reps, C.byref(ms)))
+        return ms.value
 
     def bench_tcg_trip(self, reps):
         ms = C.c_double()

@@ -76,9 +76,9 @@ static void choose_grid(msdp_handle h) {
     Dev& d = h->d;
     int half = d.ld / 2, lpr = 1;
     while (lpr < half && lpr < 64) lpr <<= 1;
-    const int rows_per_step = 4 * (64 / lpr);
+    const int rows_per_step = MSDP_WAVES * (64 / lpr);
     int want = (rows_capacity(h) + rows_per_step - 1) / rows_per_step;
-    int gmax = 256;
+    int gmax = 512;
     if (const char* e = getenv("MSDP_GRID")) { int v = atoi(e); if (v >= 8) gmax = v; }
     if (gmax > MSDP_MAX_GRID) gmax = MSDP_MAX_GRID;
     int G = ((want + 7) / 8) * 8;
@@ -146,11 +146,19 @@ static int new_handle(int kind, int64_t n, msdp_handle* out) {
     h->d.n_loc = (int)n;
     h->d.row0 = 0;
     h->d.manifold = (kind == MSDP_KIND_UNITTRACE) ? MANI_SPHERE : MANI_OBLIQUE;
+    if (const char* ev = getenv("MSDP_VARIANT")) h->d.variant = atoi(ev);
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_ctl, sizeof(Ctl), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_frame, 2 * sizeof(Frame), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_status, 64, hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *h->h_status = 0;
+        void* dp = nullptr;
+        e = hipHostGetDevicePointer(&dp, (void*)h->h_status, 0);
+        h->d.status = (unsigned long long*)dp;
+    }
     if (e != hipSuccess) {
         msdp_set_error("stream/event/pinned setup failed: %s", hipGetErrorString(e));
         delete h;
@@ -270,6 +278,8 @@ extern "C" int msdp_destroy(msdp_handle h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
     if (h->h_frame) (void)hipHostFree(h->h_frame);
+    if (h->h_status) (void)hipHostFree((void*)h->h_status);
+    if (h->chunk_exec) (void)hipGraphExecDestroy(h->chunk_exec);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -476,42 +486,133 @@ static int tcg_chunk() {
     if (v < 0) { const char* e = getenv("MSDP_TCG_CHUNK"); v = e ? atoi(e) : 8; if (v < 1) v = 1; }
     return v;
 }
+static bool use_graphs() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MSDP_NO_GRAPH"); v = (e && atoi(e)) ? 0 : 1; }
+    return v != 0;
+}
+
+static int enqueue_trips(msdp_handle h, int cnt) {
+    int rc;
+    for (int t = 0; t < cnt; ++t) {
+        if ((rc = msdp_launch_hess(h))) return rc;        // tCG.m:163
+        if ((rc = msdp_launch_upd1(h))) return rc;        // tCG.m:166-241
+        if ((rc = msdp_launch_upd2(h))) return rc;        // tCG.m:249-287
+    }
+    return 0;
+}
+
+// One hipGraph of CH tCG trips (3*CH kernel nodes).  All kernel arguments are the Dev
+// struct by value and all run-time state lives in device memory, so the same executable
+// graph is replayed for every chunk until the Dev struct changes (new p / reallocation).
+// Kernels of a finished tCG exit at their first instruction, so replaying a whole chunk
+// past the end of the solve is safe.
+static int ensure_chunk_graph(msdp_handle h, int CH) {
+    h->d.full = h->d.md;
+    if (h->chunk_exec && h->chunk_len == CH && memcmp(&h->chunk_sig, &h->d, sizeof(Dev)) == 0) return 0;
+    if (h->chunk_exec) { (void)hipGraphExecDestroy(h->chunk_exec); h->chunk_exec = nullptr; }
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_trips(h, CH);
+    hipError_t e = hipStreamEndCapture(h->stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) { msdp_set_error("graph capture failed: %s", hipGetErrorString(e)); return MSDP_EHIP; }
+    e = hipGraphInstantiate(&h->chunk_exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { msdp_set_error("graph instantiate failed: %s", hipGetErrorString(e)); h->chunk_exec = nullptr; return MSDP_EHIP; }
+    h->chunk_sig = h->d;
+    h->chunk_len = CH;
+    return 0;
+}
+
+static int launch_chunk(msdp_handle h, int CH, bool graph) {
+    if (graph) { HIPCHK(hipGraphLaunch(h->chunk_exec, h->stream)); return 0; }
+    return enqueue_trips(h, CH);
+}
+
+// Run the tCG inner loop of the current TR iteration: chunks of CH trips are enqueued one
+// ahead of the device (so the graph-launch latency is hidden) while the host polls the
+// host-mapped progress word the lead thread of k_tcg_upd2 publishes every trip.
+static int run_tcg(msdp_handle h, int maxinner, int k) {
+    const int CH = tcg_chunk();
+    const bool graph = use_graphs() && h->nranks == 1;
+    int rc;
+    static int nopub = -1;
+    if (nopub < 0) { const char* e = getenv("MSDP_NO_PUBLISH"); nopub = (e && atoi(e)) ? 1 : 0; }
+    if (nopub) {
+        // blocking variant: one stream sync per chunk, no host-mapped progress word
+        h->d.status = nullptr;
+        if (graph && (rc = ensure_chunk_graph(h, CH))) return rc;
+        if ((rc = msdp_launch_tcg_init(h))) return rc;
+        for (int j = 0; j < maxinner; j += CH) {
+            if ((rc = launch_chunk(h, CH, graph))) return rc;
+            HIPCHK(hipMemcpyAsync(&h->h_ctl->tcg_running, &h->d.ctl->tcg_running, sizeof(int),
+                                  hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (!h->h_ctl->tcg_running) break;
+        }
+        return 0;
+    }
+    if (graph && (rc = ensure_chunk_graph(h, CH))) return rc;
+    if ((rc = msdp_launch_tcg_init(h))) return rc;                // trustregions.m:484-496
+    int enq = 0;
+    if ((rc = launch_chunk(h, CH, graph))) return rc;
+    enq = 1;
+    if (enq * CH < maxinner) { if ((rc = launch_chunk(h, CH, graph))) return rc; enq = 2; }
+    const unsigned long long want = (unsigned long long)(unsigned)(k + 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    for (;;) {
+        const unsigned long long s = *h->h_status;
+        if ((s >> 32) == want) {
+            const int active = (int)(s & 1ULL);
+            const int j = (int)((s & 0xffffffffULL) >> 1);
+            if (!active) break;
+            if (enq * CH < maxinner && j >= (enq - 1) * CH) {
+                if ((rc = launch_chunk(h, CH, graph))) return rc;
+                ++enq;
+                continue;
+            }
+        }
+        if ((++spins & 0xfff) == 0) {
+            if (hipStreamQuery(h->stream) == hipSuccess) {
+                // everything enqueued has run: the final status must be visible now
+                const unsigned long long s2 = *h->h_status;
+                if ((s2 >> 32) == want && !(s2 & 1ULL)) break;
+                if (enq * CH >= maxinner || (s2 >> 32) != want) {
+                    msdp_set_error("tCG progress word inconsistent (status %llx, TR iteration %d)", s2, k);
+                    return MSDP_EHIP;
+                }
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+                msdp_set_error("tCG made no progress for 120 s");
+                return MSDP_EHIP;
+            }
+        }
+    }
+    return 0;
+}
 
 extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats* stats) {
     CHECK_H(h);
     if (!opts) { msdp_set_error("rtr: null options"); return MSDP_EINVAL; }
     if (!h->have_point) { msdp_set_error("rtr: no resident point (call msdp_set_point)"); return MSDP_ESTATE; }
     if (opts->rho_prime >= 0.25) { msdp_set_error("options.rho_prime must be strictly smaller than 1/4"); return MSDP_EINVAL; }
+    if (opts->maxinner < 1 || opts->maxiter < 0) { msdp_set_error("rtr: maxinner >= 1 and maxiter >= 0 required"); return MSDP_EINVAL; }
     const auto t0 = std::chrono::steady_clock::now();
     int rc;
     fill_ctl(h, opts);
     h->last_opts = *opts;
+    *h->h_status = 0;
     if ((rc = push_ctl(h))) return rc;
     int cur = h->h_ctl->cur;
     if ((rc = msdp_launch_costgrad(h, cur))) return rc;          // trustregions.m:405
     if ((rc = msdp_launch_rtr_begin(h))) return rc;
     if ((rc = pull_ctl(h))) return rc;
-    const int CH = tcg_chunk();
     while (!h->h_ctl->done) {                                     // trustregions.m:441
         cur = h->h_ctl->cur;
-        if ((rc = msdp_launch_tcg_init(h))) return rc;            // :484-496
-        int j = 0;
-        while (j < opts->maxinner) {
-            const int cnt = std::min(CH, opts->maxinner - j);
-            for (int t = 0; t < cnt; ++t) {
-                if ((rc = msdp_launch_hess(h))) return rc;        // tCG.m:163
-                if ((rc = msdp_launch_upd1(h))) return rc;        // tCG.m:166-241
-                if ((rc = msdp_launch_upd2(h))) return rc;        // tCG.m:249-287
-            }
-            j += cnt;
-            if (j < opts->maxinner) {
-                HIPCHK(hipMemcpyAsync(&h->h_ctl->tcg_running, &h->d.ctl->tcg_running, sizeof(int),
-                                      hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(hipStreamSynchronize(h->stream));
-                if (!h->h_ctl->tcg_running) break;
-            }
-        }
-        if ((rc = msdp_launch_retract(h))) return rc;             // trustregions.m:540
+        if ((rc = run_tcg(h, opts->maxinner, h->h_ctl->k))) return rc;   // :495
+        if ((rc = msdp_launch_retract(h))) return rc;             // :540
         if ((rc = msdp_launch_costgrad(h, cur ^ 1))) return rc;   // :544
         if ((rc = msdp_launch_rtr_decide(h))) return rc;          // :548-729
         if ((rc = pull_ctl(h))) return rc;
@@ -688,10 +789,31 @@ extern "C" int msdp_bench_hessvec(msdp_handle h, int32_t reps, double* avg_ms, d
                           hipMemcpyDeviceToDevice, h->stream));
     if ((rc = msdp_k_set_active(h, 1))) return rc;
     for (int i = 0; i < 3; ++i) if ((rc = msdp_launch_hess(h))) return rc;
+    // replay a graph of 50 back-to-back launches so the host launch path is not what is timed
+    const int per = 50;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    const bool graph = use_graphs() && h->nranks == 1;
+    if (graph) {
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < per && !rc; ++i) rc = msdp_launch_hess(h);
+        hipError_t e = hipStreamEndCapture(h->stream, &g);
+        if (rc) return rc;
+        if (e != hipSuccess) { msdp_set_error("graph capture failed: %s", hipGetErrorString(e)); return MSDP_EHIP; }
+        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        HIPCHK(hipGraphLaunch(ge, h->stream));
+    }
+    const int nrep = (reps + per - 1) / per;
+    reps = nrep * per;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    for (int i = 0; i < reps; ++i) if ((rc = msdp_launch_hess(h))) return rc;
+    for (int i = 0; i < nrep; ++i) {
+        if (graph) { HIPCHK(hipGraphLaunch(ge, h->stream)); }
+        else for (int t = 0; t < per; ++t) if ((rc = msdp_launch_hess(h))) return rc;
+    }
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));
+    if (ge) (void)hipGraphExecDestroy(ge);
+    if (g) (void)hipGraphDestroy(g);
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *avg_ms = (double)ms / reps;
@@ -701,6 +823,56 @@ extern "C" int msdp_bench_hessvec(msdp_handle h, int32_t reps, double* avg_ms, d
     algo_cost(h, &b, &f);
     if (algo_bytes) *algo_bytes = b;
     if (algo_flops) *algo_flops = f;
+    return 0;
+}
+
+// Time ONE kernel of the tCG trip in isolation (graph of 50 back-to-back launches):
+// which = 0 hess, 1 upd1, 2 upd2.  Exits are disabled (bench mode).
+extern "C" int msdp_bench_kernel(msdp_handle h, int32_t which, int32_t reps, double* avg_ms) {
+    CHECK_H(h);
+    if (reps < 1 || !avg_ms || which < 0 || which > 2) return MSDP_EINVAL;
+    int rc = ensure_state(h);
+    if (rc) return rc;
+    msdp_rtr_opts o;
+    msdp_rtr_default_opts(&o);
+    o.maxinner = 0x7ffffff0; o.maxiter = 1;
+    fill_ctl(h, &o);
+    h->h_ctl->bench_mode = 1;
+    if ((rc = push_ctl(h))) return rc;
+    if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
+    if ((rc = msdp_launch_rtr_begin(h))) return rc;
+    if ((rc = msdp_launch_tcg_init(h))) return rc;
+    for (int i = 0; i < 2; ++i)
+        if ((rc = msdp_launch_hess(h)) || (rc = msdp_launch_upd1(h)) || (rc = msdp_launch_upd2(h))) return rc;
+    if ((rc = msdp_launch_hess(h))) return rc;
+    if (which == 2 && (rc = msdp_launch_upd1(h))) return rc;      // upd2 reads frame 1
+    const int per = 50;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < per && !rc; ++i)
+        rc = which == 0 ? msdp_launch_hess(h) : (which == 1 ? msdp_launch_upd1(h) : msdp_launch_upd2(h));
+    hipError_t e = hipStreamEndCapture(h->stream, &g);
+    if (rc) return rc;
+    if (e != hipSuccess) { msdp_set_error("graph capture failed: %s", hipGetErrorString(e)); return MSDP_EHIP; }
+    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    HIPCHK(hipGraphLaunch(ge, h->stream));
+    const int nrep = (reps + per - 1) / per;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < nrep; ++i) HIPCHK(hipGraphLaunch(ge, h->stream));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    (void)hipGraphExecDestroy(ge);
+    (void)hipGraphDestroy(g);
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *avg_ms = (double)ms / (nrep * per);
+    h->h_ctl->bench_mode = 0;
+    h->h_ctl->done = 0;
+    if ((rc = push_ctl(h))) return rc;
+    if ((rc = msdp_k_set_active(h, 0))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->state_valid = false;
     return 0;
 }
 
@@ -722,10 +894,13 @@ extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms) 
     for (int i = 0; i < 2; ++i) {
         if ((rc = msdp_launch_hess(h)) || (rc = msdp_launch_upd1(h)) || (rc = msdp_launch_upd2(h))) return rc;
     }
+    const int CH = tcg_chunk();
+    const bool graph = use_graphs() && h->nranks == 1;
+    if (graph && (rc = ensure_chunk_graph(h, CH))) return rc;
+    const int nchunks = (reps + CH - 1) / CH;
+    reps = nchunks * CH;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    for (int i = 0; i < reps; ++i) {
-        if ((rc = msdp_launch_hess(h)) || (rc = msdp_launch_upd1(h)) || (rc = msdp_launch_upd2(h))) return rc;
-    }
+    for (int i = 0; i < nchunks; ++i) if ((rc = launch_chunk(h, CH, graph))) return rc;
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));
     float ms = 0.f;

@@ -7,7 +7,8 @@
 #include <vector>
 #include "../../include/manisdp_hip.h"
 
-#define MSDP_BLOCK 256            // threads per workgroup (4 waves)
+#define MSDP_BLOCK 1024           // threads per workgroup (16 waves: one row step per wave, latency hidden by occupancy)
+#define MSDP_WAVES (MSDP_BLOCK / 64)
 #define MSDP_MAX_GRID 512         // <= 512 partial sums per reduction (2 per CU)
 #define MSDP_NPART 8              // number of partial-sum arrays
 
@@ -91,6 +92,8 @@ struct Dev {
     const int64_t* a_rp;  const int* a_ci;  const double* a_v;           // CSR by entry (n^2 rows)
     const double* b; double* yv; double* Axb[2]; double* w;              // length m
     double* Pm;       // partial sums for m-length reductions
+    int variant;      // experiment switch (MSDP_VARIANT), 0 in production
+    unsigned long long* status;   // host-mapped progress word: (TR iteration+1) << 32 | tCG j << 1 | active
 };
 
 struct msdp_handle_s {
@@ -112,6 +115,11 @@ struct msdp_handle_s {
     // device-side sparse arrays owned by the handle
     int* d_rowptr = nullptr; int* d_colind = nullptr; double* d_cval = nullptr;
     msdp_rtr_opts last_opts{};
+    // tCG chunk graph (CH x {hess, upd1, upd2}) and its validity signature
+    hipGraphExec_t chunk_exec = nullptr;
+    Dev chunk_sig{};
+    int chunk_len = 0;
+    volatile unsigned long long* h_status = nullptr;   // host view of Dev::status
 };
 
 // --- launchers implemented in the .hip units (all asynchronous on h->stream) ---

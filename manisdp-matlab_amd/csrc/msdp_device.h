@@ -1,4 +1,9 @@
 // msdp_device.h -- device-side helpers shared by the kernel translation units.
+//
+// Reductions use DPP (data-parallel primitives on the VALU) instead of __shfl:
+// on gfx950 a __shfl_xor of a double is two ds_bpermute round trips through the
+// LDS pipe per step (measured: three workgroup sums added 4 us to a 6.8 us
+// streaming kernel); the DPP forms are plain VALU moves.
 #pragma once
 #include "msdp_common.h"
 
@@ -6,28 +11,60 @@
 // dispatch, observed; a pure speed heuristic), so XCD x gets the contiguous
 // chunk range [x*G/8, (x+1)*G/8): its L2 then serves one contiguous 1/8 of the
 // rows of every vector.  G is a multiple of 8.
-__device__ __forceinline__ void msdp_chunk_rows(int n_loc, int G, int& lo, int& hi) {
+__device__ __forceinline__ void msdp_chunk_rows(int n_loc, int G, int& lo, int& hi, int plain = 0) {
     const int b = blockIdx.x;
-    const int c = (b & 7) * (G >> 3) + (b >> 3);
+    const int c = plain ? b : (b & 7) * (G >> 3) + (b >> 3);
     lo = (int)(((int64_t)n_loc * c) / G);
     hi = (int)(((int64_t)n_loc * (c + 1)) / G);
 }
 
-__device__ __forceinline__ double msdp_wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// v moved by a DPP control (both halves of the double).
+template <int CTRL>
+__device__ __forceinline__ double msdp_dpp(double v) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+#define MSDP_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define MSDP_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define MSDP_DPP_HALF_MIRROR 0x141  // lane i <-> 7-i inside each 8 lanes
+#define MSDP_DPP_MIRROR 0x140       // lane i <-> 15-i inside each 16-lane row
+
+__device__ __forceinline__ double msdp_readlane(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
 
+// Sum over the LPR consecutive lanes that serve one row; valid in every lane of the
+// group.  All lanes of a group must be active together (they are: a group = a row).
 template <int LPR>
 __device__ __forceinline__ double msdp_group_sum(double v) {
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPR);
+    if (LPR >= 2) v += msdp_dpp<MSDP_DPP_XOR1>(v);
+    if (LPR >= 4) v += msdp_dpp<MSDP_DPP_XOR2>(v);
+    if (LPR >= 8) v += msdp_dpp<MSDP_DPP_HALF_MIRROR>(v);
+    if (LPR >= 16) v += msdp_dpp<MSDP_DPP_MIRROR>(v);
+    if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    if (LPR >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 
-// Deterministic workgroup sum; result valid in every thread.
-__device__ __forceinline__ double msdp_block_sum(double v, double* sh /* >= 8 doubles */) {
+// Full-wave sum (all 64 lanes active), same value in every lane, fixed order.
+__device__ __forceinline__ double msdp_wave_sum(double v) {
+    v += msdp_dpp<MSDP_DPP_XOR1>(v);
+    v += msdp_dpp<MSDP_DPP_XOR2>(v);
+    v += msdp_dpp<MSDP_DPP_HALF_MIRROR>(v);
+    v += msdp_dpp<MSDP_DPP_MIRROR>(v);
+    const double r0 = msdp_readlane(v, 0), r1 = msdp_readlane(v, 16);
+    const double r2 = msdp_readlane(v, 32), r3 = msdp_readlane(v, 48);
+    return ((r0 + r1) + r2) + r3;
+}
+
+// Deterministic workgroup sum; result valid in every thread (one barrier pair).
+__device__ __forceinline__ double msdp_block_sum(double v, double* sh /* >= MSDP_WAVES doubles */) {
     v = msdp_wave_sum(v);
     const int w = threadIdx.x >> 6;
     __syncthreads();
@@ -39,21 +76,69 @@ __device__ __forceinline__ double msdp_block_sum(double v, double* sh /* >= 8 do
     return s;
 }
 
-// Write this workgroup's partial sum.
+// Up to three per-workgroup partial sums with ONE barrier.  sh (>= 3*MSDP_WAVES
+// doubles) must not be in use by another phase of the kernel.
+__device__ __forceinline__ void msdp_put_partials3(double* P, int w0, double a, int w1, double b, int w2, double c,
+                                                   double* sh) {
+    a = msdp_wave_sum(a);
+    if (w1 >= 0) b = msdp_wave_sum(b);
+    if (w2 >= 0) c = msdp_wave_sum(c);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[w] = a; sh[MSDP_WAVES + w] = b; sh[2 * MSDP_WAVES + w] = c; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int which = threadIdx.x == 0 ? w0 : (threadIdx.x == 1 ? w1 : w2);
+        if (which >= 0) {
+            double s = 0.0;
+            const int nw = blockDim.x >> 6;
+            for (int i = 0; i < nw; ++i) s += sh[threadIdx.x * MSDP_WAVES + i];
+            P[which * MSDP_MAX_GRID + blockIdx.x] = s;
+        }
+    }
+}
 __device__ __forceinline__ void msdp_put_partial(double* P, int which, double v, double* sh) {
-    const double s = msdp_block_sum(v, sh);
-    if (threadIdx.x == 0) P[which * MSDP_MAX_GRID + blockIdx.x] = s;
+    msdp_put_partials3(P, which, v, -1, 0.0, -1, 0.0, sh);
 }
 
-// Every workgroup re-reduces the <= 512 partials of the previous launch in the
-// same fixed order, so all workgroups (and all ranks) take identical decisions
-// without atomics or fences.
-__device__ __forceinline__ double msdp_sum_partials(const double* P, int which, int G, double* sh) {
+// Every WAVE re-reduces the <= 512 partials of the previous launch in the same fixed
+// order (no LDS, no barrier): all waves, workgroups and ranks obtain bit-identical
+// sums and therefore take identical decisions without atomics or fences.
+__device__ __forceinline__ double msdp_sum_partials(const double* P, int which, int G) {
     const double* a = P + which * MSDP_MAX_GRID;
+    const int lane = threadIdx.x & 63;
     double v = 0.0;
-    for (int i = threadIdx.x; i < G; i += blockDim.x) v += a[i];
-    return msdp_block_sum(v, sh);
+    for (int i = lane; i < G; i += 64) v += a[i];
+    return msdp_wave_sum(v);
+}
+
+// Block-level variant: wave 0 re-reduces, everyone reads the result from LDS (one barrier);
+// 16x fewer same-address requests to the L2 channels that hold the partials.
+__device__ __forceinline__ double msdp_sum_partials_block(const double* P, int which, int G, double* shb) {
+    if (threadIdx.x < 64) {
+        const double s = msdp_sum_partials(P, which, G);
+        if (threadIdx.x == 0) shb[0] = s;
+    }
+    __syncthreads();
+    return shb[0];
+}
+__device__ __forceinline__ void msdp_sum_partials3_block(const double* P, int w0, int w1, int w2, int G, double* shb,
+                                                         double& s0, double& s1, double& s2) {
+    if (threadIdx.x < 64) {
+        const double a = msdp_sum_partials(P, w0, G), b = msdp_sum_partials(P, w1, G), c = msdp_sum_partials(P, w2, G);
+        if (threadIdx.x == 0) { shb[0] = a; shb[1] = b; shb[2] = c; }
+    }
+    __syncthreads();
+    s0 = shb[0]; s1 = shb[1]; s2 = shb[2];
 }
 
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 __device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
+
+// Publish tCG progress to the host-mapped status word (one relaxed system-scope store by
+// the lead thread): the host polls it to decide whether to enqueue another chunk.
+__device__ __forceinline__ void msdp_publish(const Dev& d, int k, int j, int active) {
+    if (!d.status) return;
+    const unsigned long long v = ((unsigned long long)(unsigned)(k + 1) << 32) |
+                                 ((unsigned long long)(unsigned)j << 1) | (unsigned long long)(active & 1);
+    __hip_atomic_store(d.status, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}

@@ -22,24 +22,23 @@
 template <int LPR, int NCH>
 __device__ __forceinline__ void spmm_row(const Dev& d, int row, int sub, const double* __restrict__ X,
                                          double2 (&acc)[NCH]) {
+    // All LPR lanes of a row read the same (col,val) pair: one L1 line per row serves the
+    // whole group, the loads are independent of each other (no shuffle in the chain) and
+    // the compiler can keep 4 neighbour rows in flight per lane.
     const int start = d.rowptr[row], end = d.rowptr[row + 1];
-    for (int base = start; base < end; base += LPR) {
-        const int my = base + sub;
-        int ci = 0;
-        double cv = 0.0;
-        if (my < end) { ci = d.colind[my]; cv = d.cval[my]; }
-        const int cnt = min(LPR, end - base);
-        for (int t = 0; t < cnt; ++t) {
-            const int c = __shfl(ci, t, LPR);
-            const double v = __shfl(cv, t, LPR);
-            const double* src = X + (int64_t)c * d.ld + 2 * sub;
+    const int* __restrict__ ci = d.colind;
+    const double* __restrict__ cv = d.cval;
+#pragma unroll 4
+    for (int k = start; k < end; ++k) {
+        const int c = ci[k];
+        const double v = cv[k];
+        const double* src = X + (int64_t)c * d.ld + 2 * sub;
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                if (2 * sub + ch * 2 * LPR < d.ld) {
-                    const double2 x = ld2(src + ch * 2 * LPR);
-                    acc[ch].x = fma(v, x.x, acc[ch].x);
-                    acc[ch].y = fma(v, x.y, acc[ch].y);
-                }
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (2 * sub + ch * 2 * LPR < d.ld) {
+                const double2 x = ld2(src + ch * 2 * LPR);
+                acc[ch].x = fma(v, x.x, acc[ch].x);
+                acc[ch].y = fma(v, x.y, acc[ch].y);
             }
         }
     }
@@ -48,19 +47,19 @@ __device__ __forceinline__ void spmm_row(const Dev& d, int row, int sub, const d
 // cost + Riemannian gradient at Y[slot] (gather source: d.full holds all rows of Y[slot]).
 template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_costgrad_sparse_obl(Dev d, int slot) {
-    __shared__ double sh[8];
+    __shared__ double sh[3 * MSDP_WAVES];
     if (d.ctl->done) return;
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RPW = 64 / LPR;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
-    const double* __restrict__ Yl = d.Y[slot];
+    const double* __restrict__ Yl = slot ? d.Y[1] : d.Y[0];
     const double* __restrict__ Xf = d.full;
-    double* __restrict__ Gr = d.Gr[slot];
-    double* __restrict__ eG = d.eG[slot];
+    double* __restrict__ Gr = slot ? d.Gr[1] : d.Gr[0];
+    double* __restrict__ eG = slot ? d.eG[1] : d.eG[0];
     double pf = 0.0, pgg = 0.0;
-    for (int row0 = lo + wave * RPW; row0 < hi; row0 += 4 * RPW) {
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
         const int row = row0 + rsub;
         if (row < hi) {
             double2 acc[NCH];
@@ -90,28 +89,27 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_costgrad_sparse_obl(Dev d, int s
             if (sub == 0) { eG[row] = dot; pf += 0.5 * dot; }
         }
     }
-    msdp_put_partial(d.P, P_F, pf, sh);
-    msdp_put_partial(d.P, P_GG, pgg, sh);
+    msdp_put_partials3(d.P, P_F, pf, P_GG, pgg, -1, 0.0, sh);
 }
 
 // Hess-vec: Hmd = proj-fused (C*md - Y.*rowdot(Y, C*md) - md.*eG), partial <md, Hmd>.
 template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_hess_sparse_obl(Dev d) {
-    __shared__ double sh[8];
+    __shared__ double sh[3 * MSDP_WAVES];
     if (!d.F[0].active) return;
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RPW = 64 / LPR;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
     const int cur = d.ctl->cur;
-    const double* __restrict__ Yl = d.Y[cur];
-    const double* __restrict__ eG = d.eG[cur];
+    const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
+    const double* __restrict__ eG = cur ? d.eG[1] : d.eG[0];
     const double* __restrict__ Uf = d.full;
     const double* __restrict__ Ul = d.md;
     double* __restrict__ H = d.Hmd;
     double pd = 0.0;
-    for (int row0 = lo + wave * RPW; row0 < hi; row0 += 4 * RPW) {
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
         const int row = row0 + rsub;
         if (row < hi) {
             double2 acc[NCH], y[NCH], u[NCH];
@@ -145,23 +143,32 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_hess_sparse_obl(Dev d) {
     msdp_put_partial(d.P, P_DHD, pd, sh);
 }
 
+// Frame fields are read one by one into scalars and written field by field by the lead
+// thread: a by-value Frame copy is lowered through per-thread LDS/scratch by hipcc and
+// cost 10 us per launch (measured: 19.3 -> 9.4 us for k_tcg_upd1).
+__device__ __forceinline__ void frame_store(Frame* o, double z_r, double d_Pd, double e_Pd, double e_Pe,
+                                            double model_value, double norm_r0, double alpha, double beta,
+                                            int active, int j, int stop, int eta_idx) {
+    o->z_r = z_r; o->d_Pd = d_Pd; o->e_Pd = e_Pd; o->e_Pe = e_Pe; o->model_value = model_value;
+    o->norm_r0 = norm_r0; o->alpha = alpha; o->beta = beta;
+    o->active = active; o->j = j; o->stop = stop; o->eta_idx = eta_idx;
+}
+
 // ------------------------------------------------------------------ tCG kernels
 // tCG.m:102-157: eta=0, Heta=0, r=grad, mdelta=r, scalars.
 __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_init(Dev d) {
     const Ctl* c = d.ctl;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        Frame f;
-        f.z_r = c->gg; f.d_Pd = c->gg; f.e_Pd = 0.0; f.e_Pe = 0.0; f.model_value = 0.0;
-        f.norm_r0 = sqrt(c->gg); f.alpha = 0.0; f.beta = 0.0;
-        f.active = c->done ? 0 : 1; f.j = 0; f.stop = 5; f.eta_idx = 0;
-        d.F[0] = f;
-        d.F[1] = f;
-        d.ctl->tcg_running = f.active;
+        const int act = c->done ? 0 : 1;
+        frame_store(&d.F[0], c->gg, c->gg, 0.0, 0.0, 0.0, sqrt(c->gg), 0.0, 0.0, act, 0, 5, 0);
+        frame_store(&d.F[1], c->gg, c->gg, 0.0, 0.0, 0.0, sqrt(c->gg), 0.0, 0.0, act, 0, 5, 0);
+        d.ctl->tcg_running = act;
+        msdp_publish(d, c->k, 0, act);
     }
     if (c->done) return;
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
-    const double* __restrict__ g = d.Gr[c->cur];
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
+    const double* __restrict__ g = c->cur ? d.Gr[1] : d.Gr[0];
     const int64_t e0 = (int64_t)lo * d.ld, e1 = (int64_t)hi * d.ld;
     const double2 z = make_double2(0.0, 0.0);
     for (int64_t i = e0 + 2 * threadIdx.x; i < e1; i += 2 * MSDP_BLOCK) {
@@ -175,43 +182,48 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_init(Dev d) {
 
 // tCG.m:166-241 (everything between the Hess-vec and the residual norm).
 __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd1(Dev d) {
-    __shared__ double sh[8];
-    const Frame f0 = d.F[0];
-    if (!f0.active) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) d.F[1] = f0;
+    __shared__ double sh[3 * MSDP_WAVES];
+    __shared__ double shb[2];
+    const Frame* fi = &d.F[0];
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    const int active = fi->active;
+    const double z_r = fi->z_r, d_Pd = fi->d_Pd, e_Pd = fi->e_Pd, e_Pe = fi->e_Pe;
+    const double model_value = fi->model_value, norm_r0 = fi->norm_r0, beta0 = fi->beta, alpha0 = fi->alpha;
+    const int j = fi->j, stop0 = fi->stop, ix = fi->eta_idx;
+    if (!active) {
+        if (lead) frame_store(&d.F[1], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha0, beta0, 0, j, stop0, ix);
         return;
     }
     const Ctl* c = d.ctl;
     const bool bench = c->bench_mode != 0;
-    const double d_Hd = msdp_sum_partials(d.P, P_DHD, d.G, sh);       // :166
-    const double alpha = f0.z_r / d_Hd;                                 // :170
-    const double e_Pe_new = f0.e_Pe + 2.0 * alpha * f0.e_Pd + alpha * alpha * f0.d_Pd;  // :173
     const double Delta = c->Delta;
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
     const int64_t e0 = (int64_t)lo * d.ld, e1 = (int64_t)hi * d.ld;
-    const int ix = f0.eta_idx;
-    const double* __restrict__ eta = d.eta[ix];
-    const double* __restrict__ Heta = d.Heta[ix];
-    double* __restrict__ neta = d.eta[ix ^ 1];
-    double* __restrict__ nHeta = d.Heta[ix ^ 1];
+    const double* __restrict__ eta = ix ? d.eta[1] : d.eta[0];
+    const double* __restrict__ Heta = ix ? d.Heta[1] : d.Heta[0];
+    double* __restrict__ neta = ix ? d.eta[0] : d.eta[1];
+    double* __restrict__ nHeta = ix ? d.Heta[0] : d.Heta[1];
+    const double* __restrict__ g = c->cur ? d.Gr[1] : d.Gr[0];
+    const int64_t i0 = e0 + 2 * threadIdx.x;
+    const double d_Hd = (d.variant & 64) ? msdp_sum_partials(d.P, P_DHD, d.G)
+                                         : msdp_sum_partials_block(d.P, P_DHD, d.G, shb);       // :166
+    const double alpha = z_r / d_Hd;                                 // :170
+    const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;  // :173
     if (!bench && (d_Hd <= 0.0 || e_Pe_new >= Delta * Delta)) {         // :183
-        const double tau = (-f0.e_Pd + sqrt(f0.e_Pd * f0.e_Pd + f0.d_Pd * (Delta * Delta - f0.e_Pe))) / f0.d_Pd;  // :188
-        for (int64_t i = e0 + 2 * threadIdx.x; i < e1; i += 2 * MSDP_BLOCK) {
+        const double tau = (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta * Delta - e_Pe))) / d_Pd;  // :188
+        for (int64_t i = i0; i < e1; i += 2 * MSDP_BLOCK) {
             const double2 e = ld2(eta + i), he = ld2(Heta + i), m = ld2(d.md + i), hm = ld2(d.Hmd + i);
             st2(neta + i, make_double2(e.x - tau * m.x, e.y - tau * m.y));       // :192
             st2(nHeta + i, make_double2(he.x - tau * hm.x, he.y - tau * hm.y));  // :198
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            Frame f = f0;
-            f.active = 0; f.stop = (d_Hd <= 0.0) ? 1 : 2; f.eta_idx = ix ^ 1; f.j = f0.j + 1;
-            d.F[1] = f;
-        }
+        if (lead)
+            frame_store(&d.F[1], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha0, beta0, 0, j + 1,
+                        (d_Hd <= 0.0) ? 1 : 2, ix ^ 1);
         return;
     }
-    const double* __restrict__ g = d.Gr[c->cur];
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int64_t i = e0 + 2 * threadIdx.x; i < e1; i += 2 * MSDP_BLOCK) {
+    for (int64_t i = i0; i < e1; i += 2 * MSDP_BLOCK) {
         const double2 e = ld2(eta + i), he = ld2(Heta + i), m = ld2(d.md + i), hm = ld2(d.Hmd + i);
         const double2 rr = ld2(d.r + i), gv = ld2(g + i);
         const double2 ne = make_double2(e.x - alpha * m.x, e.y - alpha * m.y);         // :215
@@ -224,67 +236,83 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd1(Dev d) {
         s2 += ne.x * nh.x + ne.y * nh.y;      // <new_eta, new_Heta>
         s3 += nr.x * nr.x + nr.y * nr.y;      // r_r                 :241
     }
-    msdp_put_partial(d.P, P_S1, s1, sh);
-    msdp_put_partial(d.P, P_S2, s2, sh);
-    msdp_put_partial(d.P, P_S3, s3, sh);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        Frame f = f0;
-        f.alpha = alpha; f.e_Pe = e_Pe_new;      // :214
-        d.F[1] = f;
-    }
+    msdp_put_partials3(d.P, P_S1, s1, P_S2, s2, P_S3, s3, sh);
+    if (lead)   // :214
+        frame_store(&d.F[1], z_r, d_Pd, e_Pd, e_Pe_new, model_value, norm_r0, alpha, beta0, 1, j, stop0, ix);
 }
 
 // tCG.m:227-287: model check, convergence test, new direction + tangent re-projection.
 template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd2_obl(Dev d) {
-    __shared__ double sh[8];
-    const Frame f1 = d.F[1];
-    if (!f1.active) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { d.F[0] = f1; d.ctl->tcg_running = 0; }
+    __shared__ double shb[4];
+    const Frame* fi = &d.F[1];
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    const int active = fi->active;
+    const double z_r = fi->z_r, d_Pd = fi->d_Pd, e_Pd = fi->e_Pd, e_Pe = fi->e_Pe;
+    const double model_value = fi->model_value, norm_r0 = fi->norm_r0, beta0 = fi->beta, alpha = fi->alpha;
+    const int j0 = fi->j, stop0 = fi->stop, ix = fi->eta_idx;
+    if (!active) {
+        if (lead) {
+            frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha, beta0, 0, j0, stop0, ix);
+            d.ctl->tcg_running = 0;
+            msdp_publish(d, d.ctl->k, j0, 0);
+        }
         return;
     }
     const Ctl* c = d.ctl;
     const bool bench = c->bench_mode != 0;
-    const double s1 = msdp_sum_partials(d.P, P_S1, d.G, sh);
-    const double s2 = msdp_sum_partials(d.P, P_S2, d.G, sh);
-    const double r_r = msdp_sum_partials(d.P, P_S3, d.G, sh);
-    const double new_model = s1 + 0.5 * s2;                 // :227
-    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
-    Frame f = f1;
-    f.j = f1.j + 1;
-    if (!bench && new_model >= f1.model_value) {            // :228
-        f.active = 0; f.stop = 6;
-        if (lead) { d.F[0] = f; d.ctl->tcg_running = 0; }
-        return;
-    }
-    f.eta_idx = f1.eta_idx ^ 1;                             // :233-235 commit new_eta/new_Heta
-    f.model_value = new_model;
-    const double norm_r = sqrt(r_r);
-    if (!bench && f.j >= c->mininner &&
-        norm_r <= f1.norm_r0 * fmin(pow(f1.norm_r0, c->theta), c->kappa)) {   // :249
-        f.active = 0; f.stop = (c->kappa < pow(f1.norm_r0, c->theta)) ? 3 : 4;
-        if (lead) { d.F[0] = f; d.ctl->tcg_running = 0; }
-        return;
-    }
-    if (f.j >= c->maxinner) {                               // loop bound :160 (stop stays 5)
-        f.active = 0;
-        if (lead) { d.F[0] = f; d.ctl->tcg_running = 0; }
-        return;
-    }
-    const double beta = r_r / f1.z_r;                       // :272
-    f.beta = beta;
-    f.e_Pd = beta * (f1.e_Pd + f1.alpha * f1.d_Pd);         // :286
-    f.d_Pd = r_r + beta * beta * f1.d_Pd;                   // :287
-    f.z_r = r_r;
-    if (lead) d.F[0] = f;
-    // mdelta = tangent(z + beta*mdelta), z = r   :273,283
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RPW = 64 / LPR;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
-    const double* __restrict__ Yl = d.Y[c->cur];
-    for (int row0 = lo + wave * RPW; row0 < hi; row0 += 4 * RPW) {
+    const double* __restrict__ Yl = c->cur ? d.Y[1] : d.Y[0];
+    double s1, s2, r_r;
+    if (!(d.variant & 64)) {
+        msdp_sum_partials3_block(d.P, P_S1, P_S2, P_S3, d.G, shb, s1, s2, r_r);
+    } else {
+        s1 = msdp_sum_partials(d.P, P_S1, d.G);
+        s2 = msdp_sum_partials(d.P, P_S2, d.G);
+        r_r = msdp_sum_partials(d.P, P_S3, d.G);
+    }
+    const double new_model = s1 + 0.5 * s2;                 // :227
+    const int j = j0 + 1;
+    if (!bench && new_model >= model_value) {               // :228
+        if (lead) {
+            frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha, beta0, 0, j, 6, ix);
+            d.ctl->tcg_running = 0;
+            msdp_publish(d, c->k, j, 0);
+        }
+        return;
+    }
+    const int nix = ix ^ 1;                                 // :233-235 commit new_eta/new_Heta
+    const double norm_r = sqrt(r_r);
+    const double nr0t = (c->theta == 1.0) ? norm_r0 : pow(norm_r0, c->theta);   // norm_r0^theta
+    if (!bench && j >= c->mininner && norm_r <= norm_r0 * fmin(nr0t, c->kappa)) {   // :249
+        if (lead) {
+            frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, new_model, norm_r0, alpha, beta0, 0, j,
+                        (c->kappa < nr0t) ? 3 : 4, nix);
+            d.ctl->tcg_running = 0;
+            msdp_publish(d, c->k, j, 0);
+        }
+        return;
+    }
+    if (j >= c->maxinner) {                                 // loop bound :160 (stop stays 5)
+        if (lead) {
+            frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, new_model, norm_r0, alpha, beta0, 0, j, stop0, nix);
+            d.ctl->tcg_running = 0;
+            msdp_publish(d, c->k, j, 0);
+        }
+        return;
+    }
+    const double beta = r_r / z_r;                          // :272
+    if (lead) {
+        frame_store(&d.F[0], r_r, r_r + beta * beta * d_Pd /* :287 */, beta * (e_Pd + alpha * d_Pd) /* :286 */, e_Pe,
+                    new_model, norm_r0, alpha, beta, 1, j, stop0, nix);
+        msdp_publish(d, c->k, j, 1);
+    }
+    // mdelta = tangent(z + beta*mdelta), z = r   :273,283
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
         const int row = row0 + rsub;
         if (row < hi) {
             double2 v[NCH], y[NCH];
@@ -316,22 +344,22 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd2_obl(Dev d) {
 // partial of <eta, grad + .5*Heta> (trustregions.m:549-550).
 template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_retract_obl(Dev d) {
-    __shared__ double sh[8];
+    __shared__ double sh[3 * MSDP_WAVES];
     const Ctl* c = d.ctl;
     if (c->done) return;
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RPW = 64 / LPR;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
     const int cur = c->cur, ix = d.F[0].eta_idx;
-    const double* __restrict__ Yl = d.Y[cur];
-    const double* __restrict__ g = d.Gr[cur];
-    const double* __restrict__ eta = d.eta[ix];
-    const double* __restrict__ Heta = d.Heta[ix];
-    double* __restrict__ Yp = d.Y[cur ^ 1];
+    const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
+    const double* __restrict__ g = cur ? d.Gr[1] : d.Gr[0];
+    const double* __restrict__ eta = ix ? d.eta[1] : d.eta[0];
+    const double* __restrict__ Heta = ix ? d.Heta[1] : d.Heta[0];
+    double* __restrict__ Yp = cur ? d.Y[0] : d.Y[1];
     double prd = 0.0;
-    for (int row0 = lo + wave * RPW; row0 < hi; row0 += 4 * RPW) {
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
         const int row = row0 + rsub;
         if (row < hi) {
             double2 x[NCH];
@@ -362,9 +390,9 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_retract_obl(Dev d) {
 // ------------------------------------------------------------------ RTR scalars
 // trustregions.m:405-409 after the first cost/grad.
 __global__ __launch_bounds__(MSDP_BLOCK) void k_rtr_begin(Dev d) {
-    __shared__ double sh[8];
-    const double f = msdp_sum_partials(d.P, P_F, d.G, sh);
-    const double gg = msdp_sum_partials(d.P, P_GG, d.G, sh);
+    __shared__ double sh[3 * MSDP_WAVES];
+    const double f = msdp_sum_partials(d.P, P_F, d.G);
+    const double gg = msdp_sum_partials(d.P, P_GG, d.G);
     if (threadIdx.x == 0) {
         Ctl* c = d.ctl;
         c->fx = f; c->gg = gg; c->norm_grad = sqrt(gg);
@@ -378,14 +406,14 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_rtr_begin(Dev d) {
 
 // trustregions.m:548-729: rho, radius update, accept/reject, stopping test.
 __global__ __launch_bounds__(MSDP_BLOCK) void k_rtr_decide(Dev d) {
-    __shared__ double sh[8];
+    __shared__ double sh[3 * MSDP_WAVES];
     if (d.ctl->done) return;
-    const double fp = msdp_sum_partials(d.P, P_F, d.G, sh);
-    const double ggp = msdp_sum_partials(d.P, P_GG, d.G, sh);
-    const double rd = msdp_sum_partials(d.P, P_RD, d.G, sh);
+    const double fp = msdp_sum_partials(d.P, P_F, d.G);
+    const double ggp = msdp_sum_partials(d.P, P_GG, d.G);
+    const double rd = msdp_sum_partials(d.P, P_RD, d.G);
     if (threadIdx.x == 0) {
         Ctl* c = d.ctl;
-        const Frame f = d.F[0];
+        const int f_stop = d.F[0].stop, f_j = d.F[0].j;
         double rhonum = c->fx - fp;                                          // :548
         double rhoden = -rd;                                                 // :550
         const double rho_reg = fmax(1.0, fabs(c->fx)) * 2.220446049250313e-16 * c->rho_reg;   // :579
@@ -395,7 +423,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_rtr_decide(Dev d) {
         const double rho = rhonum / rhoden;                                  // :621
         if (rho < 0.25 || !model_decreased || isnan(rho)) {                  // :653
             c->Delta = c->Delta / 4.0;
-        } else if (rho > 0.75 && (f.stop == 1 || f.stop == 2)) {             // :669
+        } else if (rho > 0.75 && (f_stop == 1 || f_stop == 2)) {             // :669
             c->Delta = fmin(2.0 * c->Delta, c->Delta_bar);
         }
         if (model_decreased && rho > c->rho_prime) {                         // :688
@@ -407,9 +435,9 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_rtr_decide(Dev d) {
         }
         c->rho = rho; c->rhonum = rhonum; c->rhoden = rhoden; c->fx_prop = fp; c->gg_prop = ggp;
         c->k++;                                                              // :729
-        c->hessvecs += f.j;
+        c->hessvecs += f_j;
         c->cost_evals++;
-        c->last_stop_inner = f.stop;
+        c->last_stop_inner = f_stop;
         c->done = (c->norm_grad < c->tolgradnorm) || (c->k >= c->maxiter);
     }
 }
@@ -479,8 +507,8 @@ __global__ void k_set_frame_active(Dev d, int active) {
     }
 }
 __global__ void k_sum_to(Dev d, int which, double* out) {
-    __shared__ double sh[8];
-    const double s = msdp_sum_partials(d.P, which, d.G, sh);
+    __shared__ double sh[3 * MSDP_WAVES];
+    const double s = msdp_sum_partials(d.P, which, d.G);
     if (threadIdx.x == 0) *out = s;
 }
 

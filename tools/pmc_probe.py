@@ -1,0 +1,14 @@
+"""Few plain launches of each tCG kernel (no graphs) for rocprofv3 --pmc passes."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MSDP_NO_GRAPH"] = "1"
+import numpy as np
+from manisdp_matlab_amd import _lib, problems
+p = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+C = problems.maxcut_cost_matrix(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "G81.txt.gz"))
+n = C.shape[0]
+rng = np.random.default_rng(0)
+Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+h = _lib.Handle.onlyunitdiag(C, pcap=p)
+h.set_point(Y)
+print(h.bench_tcg_trip(8) * 1e3)
