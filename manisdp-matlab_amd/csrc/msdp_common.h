@@ -120,6 +120,8 @@ struct msdp_handle_s {
     Dev chunk_sig{};
     int chunk_len = 0;
     volatile unsigned long long* h_status = nullptr;   // host view of Dev::status
+    double* slab = nullptr;        // split-K partial slabs of the dense MFMA path
+    size_t slab_cap = 0;
 };
 
 // --- launchers implemented in the .hip units (all asynchronous on h->stream) ---

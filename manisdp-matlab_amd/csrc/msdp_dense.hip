@@ -1,0 +1,355 @@
+// msdp_dense.hip -- fp64 MFMA path for the dense tall-skinny contraction S*U.
+//
+//   onlyunitdiag, dense C :  eH = C*U                       (ManiSDP_onlyunitdiag.m:128, dense C)
+//   unitdiag              :  eH = 2*eS*U + 4*sigma*AyU*Y    (ManiSDP_unitdiag.m:169)
+//   unittrace             :  H  = 2*eS*U + 4*sigma*AyU*Y    (ManiSDP_unittrace.m:174)
+//
+// Every matrix is stored row-major with a padded leading dimension nS = roundup(n,16)
+// (zero pad columns), so the k-loop has no tail and every A-fragment load is a 16-byte
+// aligned global_load_dwordx4.  The matrix is symmetric, so "row-major rows" are also the
+// columns the reference's U*C touches.
+//
+// Kernel 1 (k_dense_partial): one wave owns 16 rows x all p columns as NT accumulator
+// tiles of v_mfma_f64_16x16x4_f64; the matrix is streamed from HBM exactly once straight
+// into the MFMA A layout (lane (g = lane>>4, i = lane&15) holds S[row0+i][k0+4g+t], t=0..3,
+// two dwordx4 per 16 k -- each matrix row contributes a full 128-byte line per step); the
+// thin panel tile U[k0:k0+KT, :] is staged through LDS once per workgroup and read as the
+// B operand with a row stride = 4 (mod 8) doubles, which places the four k-groups of a
+// wave on disjoint bank halves (conflict-free ds_read_b64).  The K range is split over
+// blockIdx.y so that >= 2 workgroups per CU exist even for n = 5000; each slice writes a
+// partial slab with plain stores (deterministic, no fp64 atomics).
+// Kernel 2 (row-tiled epilogue): sums the slabs and applies the fused projection.
+#include "msdp_device.h"
+#include <math.h>
+#include <cstring>
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define DENSE_KT 32              // k extent of one LDS panel tile
+#define DENSE_WAVES 4            // waves per workgroup (64 matrix rows)
+
+struct DenseOp {
+    const double* M[2];          // n_loc x nS row-major matrices (rows = local rows)
+    const double* X[2];          // n x ld panels (all rows)
+    double scale[2];
+    int nmat;
+    int n;                       // true matrix order (panel rows)
+    int nS;                      // padded leading dimension / k extent per matrix
+    int n_loc, ld, ldl;          // rows, panel stride, LDS row stride
+    int SK;                      // k slices
+    int kslice;                  // k extent per slice (multiple of DENSE_KT) over the concatenated K = nmat*nS
+    double* slab;                // SK x n_loc_cap x ld
+    int64_t slab_stride;         // doubles between slabs
+};
+
+template <int NT>
+__global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial(DenseOp op, const int* active_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // DENSE_KT x ldl
+    if (active_flag && !*active_flag) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int row0 = (blockIdx.x * DENSE_WAVES + wave) * 16;
+    const int arow = min(row0 + i, op.n_loc - 1);            // clamp: pad rows are never stored
+    const int64_t Ktot = (int64_t)op.nmat * op.nS;
+    const int64_t kbeg = (int64_t)blockIdx.y * op.kslice;
+    int64_t kend = kbeg + op.kslice;
+    if (kend > Ktot) kend = Ktot;
+    double4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int ld = op.ld, ldl = op.ldl;
+    const int half = ld >> 1;                                  // double2 per panel row
+    for (int64_t k0 = kbeg; k0 < kend; k0 += DENSE_KT) {
+        // which matrix does this tile belong to (tiles never straddle: nS % DENSE_KT == 0 is not
+        // required, only nS % 16 == 0, so resolve per 16-k step below; the panel tile is staged per step pair)
+        __syncthreads();
+        // stage panel tile rows k0 .. k0+KT-1 (concatenated K index -> matrix m, local k)
+        for (int e = threadIdx.x; e < DENSE_KT * half; e += DENSE_WAVES * 64) {
+            const int r = e / half, c2 = e - r * half;
+            const int64_t kk = k0 + r;
+            double2 v = make_double2(0.0, 0.0);
+            if (kk < kend) {
+                const int m = (kk >= op.nS) ? 1 : 0;
+                const int64_t kl = kk - (int64_t)m * op.nS;
+                if (kl < op.n) v = ld2(op.X[m] + kl * ld + 2 * c2);
+            }
+            *reinterpret_cast<double2*>(&lds[r * ldl + 2 * c2]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < DENSE_KT / 16; ++s) {
+            const int64_t ks = k0 + 16 * s;
+            if (ks >= kend) break;
+            const int m = (ks >= op.nS) ? 1 : 0;               // a 16-step never straddles (nS % 16 == 0)
+            const int64_t kl = ks - (int64_t)m * op.nS;
+            const double* ap = op.M[m] + (int64_t)arow * op.nS + kl + 4 * g;
+            const double2 a01 = ld2(ap), a23 = ld2(ap + 2);
+            const double sc = op.scale[m];
+            const double a[4] = {a01.x * sc, a01.y * sc, a23.x * sc, a23.y * sc};
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const double* brow = &lds[(16 * s + 4 * g + t4) * ldl + i];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const double b = (16 * t + i < ld) ? brow[16 * t] : 0.0;
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t4], b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
+    double* out = op.slab + (int64_t)blockIdx.y * op.slab_stride;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = 16 * t + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + g + 4 * r;
+            if (row < op.n_loc && col < ld) out[(int64_t)row * ld + col] = acc[t][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- epilogues (oblique)
+// eH(row) = sum of the SK slabs; then ManiSDP_onlyunitdiag.m:129 / ManiSDP_unitdiag.m:170.
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_dense_hess_epi_obl(Dev d, const double* slab, int64_t slab_stride, int SK) {
+    __shared__ double sh[3 * MSDP_WAVES];
+    if (!d.F[0].active) return;
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RPW = 64 / LPR;
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    const int cur = d.ctl->cur;
+    const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
+    const double* __restrict__ eG = cur ? d.eG[1] : d.eG[0];
+    double pd = 0.0;
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
+        const int row = row0 + rsub;
+        if (row < hi) {
+            double2 acc[NCH], y[NCH], u[NCH];
+            double dot = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int col = 2 * sub + ch * 2 * LPR;
+                acc[ch] = make_double2(0.0, 0.0); y[ch] = acc[ch]; u[ch] = acc[ch];
+                if (col < d.ld) {
+                    const int64_t o = (int64_t)row * d.ld + col;
+                    for (int s = 0; s < SK; ++s) {
+                        const double2 v = ld2(slab + s * slab_stride + o);
+                        acc[ch].x += v.x; acc[ch].y += v.y;
+                    }
+                    y[ch] = ld2(Yl + o); u[ch] = ld2(d.md + o);
+                    dot += acc[ch].x * y[ch].x + acc[ch].y * y[ch].y;
+                }
+            }
+            dot = msdp_group_sum<LPR>(dot);
+            const double eg = eG[row];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int col = 2 * sub + ch * 2 * LPR;
+                if (col < d.ld) {
+                    double2 h;
+                    h.x = acc[ch].x - y[ch].x * dot - u[ch].x * eg;
+                    h.y = acc[ch].y - y[ch].y * dot - u[ch].y * eg;
+                    st2(d.Hmd + (int64_t)row * d.ld + col, h);
+                    pd += u[ch].x * h.x + u[ch].y * h.y;
+                }
+            }
+        }
+    }
+    msdp_put_partial(d.P, P_DHD, pd, sh);
+}
+
+// cost/grad epilogue for dense-C onlyunitdiag: YC = sum slabs; eG, G, f, |G|^2
+// (ManiSDP_onlyunitdiag.m:118-124).
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_dense_costgrad_epi_obl(Dev d, int slot, const double* slab,
+                                                                     int64_t slab_stride, int SK) {
+    __shared__ double sh[3 * MSDP_WAVES];
+    if (d.ctl->done) return;
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RPW = 64 / LPR;
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    const double* __restrict__ Yl = slot ? d.Y[1] : d.Y[0];
+    double* __restrict__ Gr = slot ? d.Gr[1] : d.Gr[0];
+    double* __restrict__ eG = slot ? d.eG[1] : d.eG[0];
+    double pf = 0.0, pgg = 0.0;
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
+        const int row = row0 + rsub;
+        if (row < hi) {
+            double2 acc[NCH], y[NCH];
+            double dot = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int col = 2 * sub + ch * 2 * LPR;
+                acc[ch] = make_double2(0.0, 0.0); y[ch] = acc[ch];
+                if (col < d.ld) {
+                    const int64_t o = (int64_t)row * d.ld + col;
+                    for (int s = 0; s < SK; ++s) {
+                        const double2 v = ld2(slab + s * slab_stride + o);
+                        acc[ch].x += v.x; acc[ch].y += v.y;
+                    }
+                    y[ch] = ld2(Yl + o);
+                    dot += acc[ch].x * y[ch].x + acc[ch].y * y[ch].y;
+                }
+            }
+            dot = msdp_group_sum<LPR>(dot);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int col = 2 * sub + ch * 2 * LPR;
+                if (col < d.ld) {
+                    double2 gq;
+                    gq.x = acc[ch].x - y[ch].x * dot;
+                    gq.y = acc[ch].y - y[ch].y * dot;
+                    st2(Gr + (int64_t)row * d.ld + col, gq);
+                    pgg += gq.x * gq.x + gq.y * gq.y;
+                }
+            }
+            if (sub == 0) { eG[row] = dot; pf += 0.5 * dot; }
+        }
+    }
+    msdp_put_partials3(d.P, P_F, pf, P_GG, pgg, -1, 0.0, sh);
+}
+
+// ---------------------------------------------------------------- host side
+int msdp_dev_alloc_bytes(msdp_handle h, void** out, size_t bytes);
+
+static int ensure_slab(msdp_handle h, size_t need) {
+    if (h->slab_cap >= need) return 0;
+    if (h->slab) {
+        for (size_t i = 0; i < h->allocs.size(); ++i)
+            if (h->allocs[i] == h->slab) { h->allocs.erase(h->allocs.begin() + i); break; }
+        (void)hipFree(h->slab);
+        h->slab = nullptr;
+        h->slab_cap = 0;
+    }
+    void* p = nullptr;
+    int rc = msdp_dev_alloc_bytes(h, &p, need * sizeof(double));
+    if (rc) return rc;
+    h->slab = (double*)p;
+    h->slab_cap = need;
+    return 0;
+}
+
+int msdp_dense_nS(int n) { return ((n + 15) / 16) * 16; }
+
+// Launch the partial GEMM for up to two (matrix, panel, scale) pairs; returns slab info.
+int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const double* const* X, const double* scale,
+                    const int* active_flag, const double** slab_out, int64_t* stride_out, int* SK_out) {
+    Dev& d = h->d;
+    DenseOp op;
+    memset(&op, 0, sizeof(op));
+    op.nmat = nmat;
+    for (int m = 0; m < nmat; ++m) { op.M[m] = M[m]; op.X[m] = X[m]; op.scale[m] = scale[m]; }
+    if (nmat == 1) { op.M[1] = M[0]; op.X[1] = X[0]; op.scale[1] = 0.0; }
+    op.n = d.n;
+    op.nS = msdp_dense_nS(d.n);
+    op.n_loc = d.n_loc;
+    op.ld = d.ld;
+    int ldl = d.ld;
+    while ((ldl & 7) != 4) ldl += 2;                    // ldl = 4 (mod 8): conflict-free B reads
+    op.ldl = ldl;
+    const int row_blocks = (d.n_loc + DENSE_WAVES * 16 - 1) / (DENSE_WAVES * 16);
+    const int64_t Ktot = (int64_t)nmat * op.nS;
+    int SK = (1024 + row_blocks - 1) / row_blocks;      // aim at ~4 workgroups per CU
+    const int maxSK = (int)((Ktot + 4 * DENSE_KT - 1) / (4 * DENSE_KT));
+    if (SK > maxSK) SK = maxSK;
+    if (SK > 32) SK = 32;
+    if (SK < 1) SK = 1;
+    int64_t kslice = (Ktot + SK - 1) / SK;
+    kslice = ((kslice + DENSE_KT - 1) / DENSE_KT) * DENSE_KT;
+    SK = (int)((Ktot + kslice - 1) / kslice);
+    op.SK = SK;
+    op.kslice = (int)kslice;
+    const int64_t cap_rows = (d.n + h->nranks - 1) / h->nranks;
+    op.slab_stride = cap_rows * (int64_t)d.ld;
+    int rc = ensure_slab(h, (size_t)SK * op.slab_stride);
+    if (rc) return rc;
+    op.slab = h->slab;
+    const int NT = (d.ld + 15) / 16;
+    if (NT > 8) { msdp_set_error("dense path supports p <= 128 (got ld = %d)", d.ld); return MSDP_EUNSUPPORTED; }
+    dim3 grid(row_blocks, SK), block(DENSE_WAVES * 64);
+    const size_t shmem = (size_t)DENSE_KT * ldl * sizeof(double);
+    switch (NT) {
+        case 1: hipLaunchKernelGGL((k_dense_partial<1>), grid, block, shmem, h->stream, op, active_flag); break;
+        case 2: hipLaunchKernelGGL((k_dense_partial<2>), grid, block, shmem, h->stream, op, active_flag); break;
+        case 3: hipLaunchKernelGGL((k_dense_partial<3>), grid, block, shmem, h->stream, op, active_flag); break;
+        case 4: hipLaunchKernelGGL((k_dense_partial<4>), grid, block, shmem, h->stream, op, active_flag); break;
+        case 5: hipLaunchKernelGGL((k_dense_partial<5>), grid, block, shmem, h->stream, op, active_flag); break;
+        case 6: hipLaunchKernelGGL((k_dense_partial<6>), grid, block, shmem, h->stream, op, active_flag); break;
+        case 7: hipLaunchKernelGGL((k_dense_partial<7>), grid, block, shmem, h->stream, op, active_flag); break;
+        default: hipLaunchKernelGGL((k_dense_partial<8>), grid, block, shmem, h->stream, op, active_flag); break;
+    }
+    HIPCHK(hipGetLastError());
+    *slab_out = h->slab;
+    *stride_out = op.slab_stride;
+    *SK_out = SK;
+    return 0;
+}
+
+#define DISPATCH_LPR_D(KERNEL, h, ...)                                                               \
+    do {                                                                                             \
+        int half = (h)->d.ld / 2, lpr = 1;                                                           \
+        while (lpr < half && lpr < 64) lpr <<= 1;                                                    \
+        int nch = (half + lpr - 1) / lpr; if (nch < 1) nch = 1;                                      \
+        dim3 grid((h)->d.G), block(MSDP_BLOCK);                                                      \
+        if (nch == 1) {                                                                              \
+            switch (lpr) {                                                                           \
+                case 1:  hipLaunchKernelGGL((KERNEL<1, 1>),  grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 2:  hipLaunchKernelGGL((KERNEL<2, 1>),  grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 4:  hipLaunchKernelGGL((KERNEL<4, 1>),  grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 8:  hipLaunchKernelGGL((KERNEL<8, 1>),  grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 16: hipLaunchKernelGGL((KERNEL<16, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 32: hipLaunchKernelGGL((KERNEL<32, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                default: hipLaunchKernelGGL((KERNEL<64, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+            }                                                                                        \
+        } else {                                                                                     \
+            msdp_set_error("dense path supports p <= 128");                                          \
+            return MSDP_EUNSUPPORTED;                                                                \
+        }                                                                                            \
+    } while (0)
+
+// Upload a dense symmetric n x n matrix (host, column-major == row-major) with the padded
+// leading dimension nS.
+int msdp_dense_setup(msdp_handle h, const double* C) {
+    Dev& d = h->d;
+    const int nS = msdp_dense_nS(d.n);
+    void* p = nullptr;
+    int rc = msdp_dev_alloc_bytes(h, &p, (size_t)d.n * nS * sizeof(double));
+    if (rc) return rc;
+    d.Cd = (double*)p;
+    HIPCHK(hipMemset(d.Cd, 0, (size_t)d.n * nS * sizeof(double)));
+    HIPCHK(hipMemcpy2D(d.Cd, (size_t)nS * sizeof(double), C, (size_t)d.n * sizeof(double), (size_t)d.n * sizeof(double),
+                       d.n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int msdp_dense_costgrad(msdp_handle h, int slot) {
+    Dev& d = h->d;
+    const double* M[1] = {d.Cd};
+    const double* X[1] = {d.full};
+    const double sc[1] = {1.0};
+    const double* slab; int64_t stride; int SK;
+    int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
+    if (rc) return rc;
+    DISPATCH_LPR_D(k_dense_costgrad_epi_obl, h, d, slot, slab, stride, SK);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int msdp_dense_hess(msdp_handle h) {
+    Dev& d = h->d;
+    const double* M[1] = {d.Cd};
+    const double* X[1] = {d.full};
+    const double sc[1] = {1.0};
+    const double* slab; int64_t stride; int SK;
+    int rc = msdp_dense_gemm(h, 1, M, X, sc, &d.F[0].active, &slab, &stride, &SK);
+    if (rc) return rc;
+    DISPATCH_LPR_D(k_dense_hess_epi_obl, h, d, slab, stride, SK);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

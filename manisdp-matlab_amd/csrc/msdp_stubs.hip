@@ -1,9 +1,6 @@
 // Temporary: entry points of units not built yet.
 #include "msdp_common.h"
 #define UNSUP(name) { msdp_set_error(name ": not implemented in this build"); return MSDP_EUNSUPPORTED; }
-int msdp_dense_costgrad(msdp_handle, int) UNSUP("dense costgrad")
-int msdp_dense_hess(msdp_handle) UNSUP("dense hess")
-int msdp_dense_setup(msdp_handle, const double*) UNSUP("dense setup")
 int msdp_affine_costgrad(msdp_handle, int) UNSUP("affine costgrad")
 int msdp_affine_hess(msdp_handle) UNSUP("affine hess")
 int msdp_affine_setup(msdp_handle, const int64_t*, const int64_t*, const double*, const double*, const double*) UNSUP("affine setup")
