@@ -1,0 +1,504 @@
+// msdp_affine.hip -- the sparse A(.) / A'(.) operators and the cost / gradient / Hess-vec
+// of the two affine entry points, on the oblique (unitdiag) and sphere (unittrace) manifolds.
+//
+// Reference expressions (Y, U are n x p row-major here = MATLAB's p x n for unitdiag):
+//   cost   ManiSDP_unitdiag.m:152-157   X=Y'*Y; Axb=A*x-b-y/sigma; f=c'*x+.5*sigma*(Axb'*Axb)
+//   grad   ManiSDP_unitdiag.m:159-164   eS=reshape(c+sigma*At*Axb,n,n); eG=2*Y*eS; YeG=sum(Y.*eG); G=eG-Y.*YeG
+//   hess   ManiSDP_unitdiag.m:166-171   YU=Y'*U; AyU=reshape(A'*(At'*YU(:)),n,n); eH=2*U*eS+4*sigma*(Y*AyU);
+//                                       H=eH-Y.*sum(Y.*eH)-U.*YeG
+//   cost   ManiSDP_unittrace.m:156-165  ... z=sum(X.*eS,'all'); G=2*eS*Y-2*z*Y
+//   hess   ManiSDP_unittrace.m:171-177  H=2*eS*U+4*sigma*(AyU*Y); H=H-trace(H*Y')*Y-2*z*U
+//
+// The n x n matrices X, YU are never formed: A(Ya Yb') is an SDDMM over the pattern of At
+// (one LPR-lane group per constraint column, p-wide row panels gathered from L2), A'(w) is a
+// CSR-by-entry SpMV that writes the dense n x nS matrix the MFMA kernel then contracts.
+// The constraint matrices A_k and C are symmetric (SeDuMi data), so row-major == column-major.
+#include "msdp_device.h"
+#include <math.h>
+#include <cstring>
+#include <vector>
+
+int msdp_dev_alloc_bytes(msdp_handle h, void** out, size_t bytes);
+int msdp_dense_nS(int n);
+int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const double* const* X, const double* scale,
+                    const int* active_flag, const double** slab_out, int64_t* stride_out, int* SK_out);
+
+struct AffineDev {
+    int n, nS, p, ld;
+    int64_t m;
+    const int* cjc;        // m+1 column pointers (CSC by constraint)
+    const int* ci;         // row i of each nonzero
+    const int* cj;         // col j of each nonzero
+    const double* cv;
+    const int64_t* rp;     // n*n+1 row pointers (CSR by matrix entry r = i*n + j)
+    const int* rk;         // constraint index
+    const double* rv;
+    const double* b;
+    const double* y;
+    double* w;             // A(.) result, length m
+    double* Axb[2];        // per slot
+};
+
+// w_k = sum_{(i,j) in A_k} val * <Ya_i, Yb_j>; mode 0: store w.  mode 1 (cost): Axb = w - b - y/sigma into
+// axb_out, partial sum of Axb^2 -> P_AUX.
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm(AffineDev a, const double* __restrict__ Ya,
+                                                    const double* __restrict__ Yb, int mode, double* axb_out,
+                                                    double sigma, double* P, int G, const int* skip_flag,
+                                                    int skip_when) {
+    __shared__ double sh[3 * MSDP_WAVES];
+    if (skip_flag && *skip_flag == skip_when) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int CPW = 64 / LPR;                       // constraints per wave
+    const int sub = lane & (LPR - 1), csub = lane / LPR;
+    double pss = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * MSDP_WAVES * CPW;
+    for (int64_t k = ((int64_t)blockIdx.x * MSDP_WAVES + wave) * CPW + csub; k < a.m; k += stride) {
+        const int s0 = a.cjc[k], s1 = a.cjc[k + 1];
+        double acc = 0.0;
+        for (int t = s0; t < s1; ++t) {
+            const int i = a.ci[t], j = a.cj[t];
+            const double v = a.cv[t];
+            const double* ya = Ya + (int64_t)i * a.ld + 2 * sub;
+            const double* yb = Yb + (int64_t)j * a.ld + 2 * sub;
+            double dd = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (2 * sub + ch * 2 * LPR < a.ld) {
+                    const double2 x = ld2(ya + ch * 2 * LPR), z = ld2(yb + ch * 2 * LPR);
+                    dd += x.x * z.x + x.y * z.y;
+                }
+            }
+            acc = fma(v, dd, acc);
+        }
+        acc = msdp_group_sum<LPR>(acc);
+        if (sub == 0) {
+            if (mode == 0) a.w[k] = acc;
+            else {
+                const double r = acc - a.b[k] - a.y[k] / sigma;
+                a.w[k] = acc;
+                axb_out[k] = r;
+                pss += r * r;
+            }
+        }
+    }
+    if (mode == 1) msdp_put_partial(P, P_AUX, pss, sh);
+}
+
+// out[i][j] = (base ? base[i][j] : 0) + scale * sum_k At[(i,j),k] * vec[k]   (dense n x nS, zero pad)
+__global__ void k_adjoint_dense(AffineDev a, const double* __restrict__ base, const double* __restrict__ vec,
+                                double scale, double* __restrict__ out, const int* skip_flag, int skip_when) {
+    if (skip_flag && *skip_flag == skip_when) return;
+    const int64_t tot = (int64_t)a.n * a.nS;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / a.nS), j = (int)(e - (int64_t)i * a.nS);
+        double v = 0.0;
+        if (j < a.n) {
+            const int64_t r = (int64_t)i * a.n + j;
+            const int64_t s0 = a.rp[r], s1 = a.rp[r + 1];
+            double acc = 0.0;
+            for (int64_t t = s0; t < s1; ++t) acc = fma(a.rv[t], vec[a.rk[t]], acc);
+            v = (base ? base[e] : 0.0) + scale * acc;
+        }
+        out[e] = v;
+    }
+}
+
+// rows: t_i = <S_i, Y_i> where S = sum of slabs (S = M*Y); writes optional S to dst and partial sum -> P[which]
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_rowdot_slabs(Dev d, const double* __restrict__ Yl, const double* slab,
+                                                           int64_t slab_stride, int SK, double scale_out,
+                                                           double* dst, double* rowdot_out, int which) {
+    __shared__ double sh[3 * MSDP_WAVES];
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RPW = 64 / LPR;
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    double ps = 0.0;
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
+        const int row = row0 + rsub;
+        if (row < hi) {
+            double dot = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int col = 2 * sub + ch * 2 * LPR;
+                if (col < d.ld) {
+                    const int64_t o = (int64_t)row * d.ld + col;
+                    double2 acc = make_double2(0.0, 0.0);
+                    for (int s = 0; s < SK; ++s) {
+                        const double2 v = ld2(slab + s * slab_stride + o);
+                        acc.x += v.x; acc.y += v.y;
+                    }
+                    const double2 y = ld2(Yl + o);
+                    dot += acc.x * y.x + acc.y * y.y;
+                    if (dst) st2(dst + o, make_double2(scale_out * acc.x, scale_out * acc.y));
+                }
+            }
+            dot = msdp_group_sum<LPR>(dot);
+            if (sub == 0) { if (rowdot_out) rowdot_out[row] = scale_out * dot; ps += dot; }
+        }
+    }
+    msdp_put_partial(d.P, which, ps, sh);
+}
+
+// unitdiag gradient finish: eG (n x ld, = 2*eS*Y) in Gr, YeG rows known -> G = eG - Y.*YeG, |G|^2; and f.
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_obl_grad_finish(Dev d, int slot, double sigma) {
+    __shared__ double sh[3 * MSDP_WAVES + 8];
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RPW = 64 / LPR;
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    const double* __restrict__ Yl = slot ? d.Y[1] : d.Y[0];
+    double* __restrict__ Gr = slot ? d.Gr[1] : d.Gr[0];
+    const double* __restrict__ YeG = slot ? d.eG[1] : d.eG[0];
+    double pgg = 0.0;
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
+        const int row = row0 + rsub;
+        if (row < hi) {
+            const double t = YeG[row];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int col = 2 * sub + ch * 2 * LPR;
+                if (col < d.ld) {
+                    const int64_t o = (int64_t)row * d.ld + col;
+                    const double2 e = ld2(Gr + o), y = ld2(Yl + o);
+                    const double2 gq = make_double2(e.x - y.x * t, e.y - y.y * t);
+                    st2(Gr + o, gq);
+                    pgg += gq.x * gq.x + gq.y * gq.y;
+                }
+            }
+        }
+    }
+    // f = c'x + .5*sigma*|Axb|^2 : c'x partial sums are in P_S1 (sum <C*Y, Y>), |Axb|^2 in P_AUX
+    const double cx = msdp_sum_partials_block(d.P, P_S1, d.G, sh);
+    __syncthreads();
+    const double ss = msdp_sum_partials_block(d.P, P_AUX, d.G, sh);
+    __syncthreads();
+    double pf = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) pf = cx + 0.5 * sigma * ss;
+    msdp_put_partials3(d.P, P_F, pf, P_GG, pgg, -1, 0.0, sh + 8);
+}
+
+// sphere gradient finish: Gr holds 2*eS*Y, z = <eS*Y, Y> partials in P_S2: G = 2 eS Y - 2 z Y.
+__global__ __launch_bounds__(MSDP_BLOCK) void k_sph_grad_finish(Dev d, int slot, double sigma) {
+    __shared__ double sh[3 * MSDP_WAVES + 8];
+    const double z = msdp_sum_partials_block(d.P, P_S2, d.G, sh);
+    __syncthreads();
+    const double cx = msdp_sum_partials_block(d.P, P_S1, d.G, sh);
+    __syncthreads();
+    const double ss = msdp_sum_partials_block(d.P, P_AUX, d.G, sh);
+    __syncthreads();
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const double* __restrict__ Yl = slot ? d.Y[1] : d.Y[0];
+    double* __restrict__ Gr = slot ? d.Gr[1] : d.Gr[0];
+    const int64_t e0 = (int64_t)lo * d.ld, e1 = (int64_t)hi * d.ld;
+    double pgg = 0.0;
+    for (int64_t i = e0 + 2 * threadIdx.x; i < e1; i += 2 * MSDP_BLOCK) {
+        const double2 e = ld2(Gr + i), y = ld2(Yl + i);
+        const double2 gq = make_double2(e.x - 2.0 * z * y.x, e.y - 2.0 * z * y.y);
+        st2(Gr + i, gq);
+        pgg += gq.x * gq.x + gq.y * gq.y;
+    }
+    double pf = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { pf = cx + 0.5 * sigma * ss; d.ctl->z_sphere[slot] = z; }
+    msdp_put_partials3(d.P, P_F, pf, P_GG, pgg, -1, 0.0, sh + 8);
+}
+
+// sphere Hess-vec finish (ManiSDP_unittrace.m:176): Hmd holds H_raw, t = <H_raw, Y> partials in P_AUX
+__global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_finish(Dev d) {
+    __shared__ double sh[3 * MSDP_WAVES + 8];
+    if (!d.F[0].active) return;
+    const double t = msdp_sum_partials_block(d.P, P_AUX, d.G, sh);
+    __syncthreads();
+    const int cur = d.ctl->cur;
+    const double z = d.ctl->z_sphere[cur];
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
+    const int64_t e0 = (int64_t)lo * d.ld, e1 = (int64_t)hi * d.ld;
+    double pd = 0.0;
+    for (int64_t i = e0 + 2 * threadIdx.x; i < e1; i += 2 * MSDP_BLOCK) {
+        const double2 hr = ld2(d.Hmd + i), y = ld2(Yl + i), u = ld2(d.md + i);
+        const double2 hq = make_double2(hr.x - t * y.x - 2.0 * z * u.x, hr.y - t * y.y - 2.0 * z * u.y);
+        st2(d.Hmd + i, hq);
+        pd += u.x * hq.x + u.y * hq.y;
+    }
+    msdp_put_partial(d.P, P_DHD, pd, sh + 8);
+}
+
+__global__ void k_cost_only(Dev d, double sigma, double* out) {
+    __shared__ double sh[8];
+    const double cx = msdp_sum_partials_block(d.P, P_S1, d.G, sh);
+    __syncthreads();
+    const double ss = msdp_sum_partials_block(d.P, P_AUX, d.G, sh);
+    if (threadIdx.x == 0) *out = cx + 0.5 * sigma * ss;
+}
+
+// ------------------------------------------------------------------ host side
+struct AffineState {
+    AffineDev a{};
+    double sigma = 1.0;
+    double* Cdense = nullptr;      // n x nS
+    double* d_y = nullptr;
+};
+static std::vector<std::pair<msdp_handle, AffineState*>> g_aff;
+static AffineState* astate(msdp_handle h) {
+    for (auto& pr : g_aff) if (pr.first == h) return pr.second;
+    return nullptr;
+}
+void msdp_affine_release(msdp_handle h) {
+    for (size_t i = 0; i < g_aff.size(); ++i)
+        if (g_aff[i].first == h) { delete g_aff[i].second; g_aff.erase(g_aff.begin() + i); return; }
+}
+
+template <typename T>
+static int up(msdp_handle h, const std::vector<T>& v, const T** out) {
+    void* p = nullptr;
+    int rc = msdp_dev_alloc_bytes(h, &p, v.size() * sizeof(T));
+    if (rc) return rc;
+    if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return 0;
+}
+
+int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const double* pr, const double* b,
+                      const double* c) {
+    Dev& d = h->d;
+    const int n = d.n;
+    const int64_t m = d.m;
+    const int64_t nnz = jc[m];
+    if (nnz > 0x7fffffff) { msdp_set_error("nnz(At) too large"); return MSDP_EINVAL; }
+    AffineState* st = new AffineState();
+    g_aff.push_back({h, st});
+    AffineDev& a = st->a;
+    a.n = n; a.nS = msdp_dense_nS(n); a.m = m;
+    std::vector<int> cjc(m + 1), ci(nnz), cj(nnz);
+    std::vector<double> cv(pr, pr + nnz);
+    for (int64_t k = 0; k <= m; ++k) cjc[k] = (int)jc[k];
+    const int64_t nn = (int64_t)n * n;
+    std::vector<int64_t> rp(nn + 1, 0);
+    for (int64_t t = 0; t < nnz; ++t) {
+        const int64_t e = ir[t];
+        if (e < 0 || e >= nn) { msdp_set_error("At row index out of range"); return MSDP_EINVAL; }
+        const int i = (int)(e % n), j = (int)(e / n);      // column-major vec index (bqpmom.m:57, example_theta.m:20)
+        ci[t] = i; cj[t] = j;
+        rp[(int64_t)i * n + j + 1]++;
+    }
+    for (int64_t r = 0; r < nn; ++r) rp[r + 1] += rp[r];
+    std::vector<int> rk(nnz);
+    std::vector<double> rv(nnz);
+    {
+        std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
+        for (int64_t k = 0; k < m; ++k)
+            for (int64_t t = jc[k]; t < jc[k + 1]; ++t) {
+                const int64_t r = (int64_t)ci[t] * n + cj[t];
+                const int64_t pos = fill[r]++;
+                rk[pos] = (int)k; rv[pos] = pr[t];
+            }
+    }
+    int rc;
+    if ((rc = up(h, cjc, &a.cjc)) || (rc = up(h, ci, &a.ci)) || (rc = up(h, cj, &a.cj)) || (rc = up(h, cv, &a.cv)) ||
+        (rc = up(h, rp, &a.rp)) || (rc = up(h, rk, &a.rk)) || (rc = up(h, rv, &a.rv)))
+        return rc;
+    std::vector<double> bv(b, b + m);
+    if ((rc = up(h, bv, &a.b))) return rc;
+    void* p = nullptr;
+    if ((rc = msdp_dev_alloc_bytes(h, &p, m * sizeof(double)))) return rc;
+    st->d_y = (double*)p; a.y = st->d_y;
+    HIPCHK(hipMemset(st->d_y, 0, m * sizeof(double)));
+    if ((rc = msdp_dev_alloc_bytes(h, &p, m * sizeof(double)))) return rc;
+    a.w = (double*)p;
+    for (int s = 0; s < 2; ++s) {
+        if ((rc = msdp_dev_alloc_bytes(h, &p, m * sizeof(double)))) return rc;
+        a.Axb[s] = (double*)p;
+    }
+    // dense C (n x nS) from the column-major vector c (symmetric)
+    const size_t msz = (size_t)n * a.nS * sizeof(double);
+    if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
+    st->Cdense = (double*)p; d.Cd = st->Cdense;
+    HIPCHK(hipMemset(st->Cdense, 0, msz));
+    HIPCHK(hipMemcpy2D(st->Cdense, (size_t)a.nS * sizeof(double), c, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n,
+                       hipMemcpyHostToDevice));
+    for (int s = 0; s < 2; ++s) {
+        if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
+        d.eS[s] = (double*)p;
+        HIPCHK(hipMemset(d.eS[s], 0, msz));
+    }
+    if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
+    d.AyU = (double*)p;
+    HIPCHK(hipMemset(d.AyU, 0, msz));
+    h->h_ctl->sigma = 1.0;
+    return 0;
+}
+
+int msdp_affine_set_multipliers(msdp_handle h, const double* y, double sigma) {
+    AffineState* st = astate(h);
+    if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
+    if (!(sigma > 0)) { msdp_set_error("sigma must be positive"); return MSDP_EINVAL; }
+    HIPCHK(hipMemcpyAsync(st->d_y, y, st->a.m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    st->sigma = sigma;
+    h->h_ctl->sigma = sigma;
+    return 0;
+}
+
+#define DISPATCH_LPR_A(KERNEL, h, GRID, ...)                                                         \
+    do {                                                                                             \
+        int half = (h)->d.ld / 2, lpr = 1;                                                           \
+        while (lpr < half && lpr < 64) lpr <<= 1;                                                    \
+        int nch = (half + lpr - 1) / lpr; if (nch < 1) nch = 1;                                      \
+        dim3 grid(GRID), block(MSDP_BLOCK);                                                          \
+        if (nch == 1) {                                                                              \
+            switch (lpr) {                                                                           \
+                case 1:  hipLaunchKernelGGL((KERNEL<1, 1>),  grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 2:  hipLaunchKernelGGL((KERNEL<2, 1>),  grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 4:  hipLaunchKernelGGL((KERNEL<4, 1>),  grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 8:  hipLaunchKernelGGL((KERNEL<8, 1>),  grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 16: hipLaunchKernelGGL((KERNEL<16, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                case 32: hipLaunchKernelGGL((KERNEL<32, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+                default: hipLaunchKernelGGL((KERNEL<64, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
+            }                                                                                        \
+        } else {                                                                                     \
+            msdp_set_error("affine path supports p <= 128");                                         \
+            return MSDP_EUNSUPPORTED;                                                                \
+        }                                                                                            \
+    } while (0)
+
+int msdp_dense_hess_epilogue_obl(msdp_handle h, const double* slab, int64_t stride, int SK);   // msdp_dense.hip
+int msdp_sphere_hess_raw(msdp_handle h, const double* slab, int64_t stride, int SK);           // below
+
+static int adjoint_grid(const AffineDev& a) {
+    int64_t tot = (int64_t)a.n * a.nS;
+    int64_t g = (tot + 255) / 256;
+    if (g > 4096) g = 4096;
+    return (int)g;
+}
+
+// cost + gradient state at Y[slot]:  w = A(YY'), Axb, eS, eS*Y, C*Y  (see header comment)
+int msdp_affine_costgrad(msdp_handle h, int slot) {
+    AffineState* st = astate(h);
+    if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
+    Dev& d = h->d;
+    AffineDev a = st->a;
+    a.p = d.p; a.ld = d.ld;
+    const double sigma = st->sigma;
+    const double* Ys = d.Y[slot];
+    const int* done = &d.ctl->done;
+    DISPATCH_LPR_A(k_sddmm, h, d.G, a, Ys, Ys, 1, a.Axb[slot], sigma, d.P, d.G, done, 1);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_adjoint_dense, dim3(adjoint_grid(a)), dim3(256), 0, h->stream, a, d.Cd, a.Axb[slot], sigma,
+                       d.eS[slot], done, 1);
+    HIPCHK(hipGetLastError());
+    // c'x = <C*Y, Y>
+    const double* slab; int64_t stride; int SK;
+    {
+        const double* M[1] = {d.Cd}; const double* X[1] = {Ys}; const double sc[1] = {1.0};
+        int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
+        if (rc) return rc;
+        DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 1.0, (double*)nullptr, (double*)nullptr, P_S1);
+        HIPCHK(hipGetLastError());
+    }
+    // eG = 2*eS*Y -> Gr[slot]; row dots (YeG = sum(Y.*eG)) and their total (2z)
+    {
+        const double* M[1] = {d.eS[slot]}; const double* X[1] = {Ys}; const double sc[1] = {1.0};
+        int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
+        if (rc) return rc;
+        DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 2.0, d.Gr[slot], d.eG[slot], P_S2);
+        HIPCHK(hipGetLastError());
+    }
+    if (d.manifold == MANI_OBLIQUE) {
+        DISPATCH_LPR_A(k_obl_grad_finish, h, d.G, d, slot, sigma);
+    } else {
+        hipLaunchKernelGGL(k_sph_grad_finish, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, d, slot, sigma);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int msdp_affine_hess(msdp_handle h) {
+    AffineState* st = astate(h);
+    if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
+    Dev& d = h->d;
+    AffineDev a = st->a;
+    a.p = d.p; a.ld = d.ld;
+    const double sigma = st->sigma;
+    const int cur = h->h_ctl->cur;
+    const int* act = &d.F[0].active;
+    // w = A(Y U') ; AyU = A'(w)
+    DISPATCH_LPR_A(k_sddmm, h, d.G, a, d.Y[cur], d.md, 0, (double*)nullptr, sigma, d.P, d.G, act, 0);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_adjoint_dense, dim3(adjoint_grid(a)), dim3(256), 0, h->stream, a, (const double*)nullptr, a.w, 1.0,
+                       d.AyU, act, 0);
+    HIPCHK(hipGetLastError());
+    const double* M[2] = {d.eS[cur], d.AyU};
+    const double* X[2] = {d.md, d.Y[cur]};
+    const double sc[2] = {2.0, 4.0 * sigma};
+    const double* slab; int64_t stride; int SK;
+    int rc = msdp_dense_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK);
+    if (rc) return rc;
+    if (d.manifold == MANI_OBLIQUE) return msdp_dense_hess_epilogue_obl(h, slab, stride, SK);
+    return msdp_sphere_hess_raw(h, slab, stride, SK);
+}
+
+// sphere: H_raw = sum slabs -> Hmd, partial <H_raw, Y> -> P_AUX; then the finish kernel.
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_raw(Dev d, const double* slab, int64_t slab_stride, int SK) {
+    __shared__ double sh[3 * MSDP_WAVES];
+    if (!d.F[0].active) return;
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const int cur = d.ctl->cur;
+    const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
+    const int64_t e0 = (int64_t)lo * d.ld, e1 = (int64_t)hi * d.ld;
+    double pt = 0.0;
+    for (int64_t i = e0 + 2 * threadIdx.x; i < e1; i += 2 * MSDP_BLOCK) {
+        double2 acc = make_double2(0.0, 0.0);
+        for (int s = 0; s < SK; ++s) {
+            const double2 v = ld2(slab + s * slab_stride + i);
+            acc.x += v.x; acc.y += v.y;
+        }
+        const double2 y = ld2(Yl + i);
+        st2(d.Hmd + i, acc);
+        pt += acc.x * y.x + acc.y * y.y;
+    }
+    msdp_put_partial(d.P, P_AUX, pt, sh);
+}
+
+int msdp_sphere_hess_raw(msdp_handle h, const double* slab, int64_t stride, int SK) {
+    Dev& d = h->d;
+    hipLaunchKernelGGL((k_sph_hess_raw<1, 1>), dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, d, slab, stride, SK);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_sph_hess_finish, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, d);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// co(Y) of the line search at the trial point Yt (device, n x ld): c'x + sigma/2 |A x - b - y/sigma|^2
+int msdp_affine_linesearch_cost(msdp_handle h, const double* Yt, double* val) {
+    AffineState* st = astate(h);
+    if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
+    Dev& d = h->d;
+    AffineDev a = st->a;
+    a.p = d.p; a.ld = d.ld;
+    const double sigma = st->sigma;
+    const int other = h->h_ctl->cur ^ 1;
+    DISPATCH_LPR_A(k_sddmm, h, d.G, a, Yt, Yt, 1, a.Axb[other], sigma, d.P, d.G, (const int*)nullptr, 0);
+    HIPCHK(hipGetLastError());
+    const double* slab; int64_t stride; int SK;
+    const double* M[1] = {d.Cd}; const double* X[1] = {Yt}; const double sc[1] = {1.0};
+    int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
+    if (rc) return rc;
+    DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Yt, slab, stride, SK, 1.0, (double*)nullptr, (double*)nullptr, P_S1);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_cost_only, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, d, sigma, &d.ctl->fx_prop);
+    HIPCHK(hipGetLastError());
+    double v = 0.0;
+    HIPCHK(hipMemcpyAsync(&v, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *val = v;
+    return 0;
+}

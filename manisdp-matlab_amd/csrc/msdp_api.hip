@@ -34,6 +34,8 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
 int msdp_affine_set_multipliers(msdp_handle h, const double* y, double sigma);
 int msdp_affine_linesearch_cost(msdp_handle h, const double* Yt, double* val);
 int msdp_dense_setup(msdp_handle h, const double* C);
+int msdp_dense_reserve(msdp_handle h, int nmat);
+void msdp_affine_release(msdp_handle h);
 int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam, double* V, double* lmax, int* iters);
 
 #define CHECK_H(h)                                          \
@@ -280,6 +282,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     if (h->h_frame) (void)hipHostFree(h->h_frame);
     if (h->h_status) (void)hipHostFree((void*)h->h_status);
     if (h->chunk_exec) (void)hipGraphExecDestroy(h->chunk_exec);
+    msdp_affine_release(h);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -357,6 +360,10 @@ extern "C" int msdp_set_point(msdp_handle h, int32_t p, const double* Y) {
     d.ld = ((p + 1) / 2) * 2;
     if (h->nranks == 1) d.full = d.md;     // overwritten per launch by allgather_rows
     choose_grid(h);
+    if (d.costkind != COST_SPARSE) {
+        int rc = msdp_dense_reserve(h, d.costkind == COST_AFFINE ? 2 : 1);
+        if (rc) return rc;
+    }
     h->h_ctl->cur = 0;
     // zero the slot so pad columns and pad rows are exactly zero
     HIPCHK(hipMemsetAsync(d.Y[0], 0, (size_t)rows_capacity(h) * h->ldcap * sizeof(double), h->stream));
@@ -509,7 +516,7 @@ static int enqueue_trips(msdp_handle h, int cnt) {
 // past the end of the solve is safe.
 static int ensure_chunk_graph(msdp_handle h, int CH) {
     h->d.full = h->d.md;
-    if (h->chunk_exec && h->chunk_len == CH && memcmp(&h->chunk_sig, &h->d, sizeof(Dev)) == 0) return 0;
+    if (h->chunk_exec && h->chunk_len == CH && h->chunk_cur == h->h_ctl->cur && memcmp(&h->chunk_sig, &h->d, sizeof(Dev)) == 0) return 0;
     if (h->chunk_exec) { (void)hipGraphExecDestroy(h->chunk_exec); h->chunk_exec = nullptr; }
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
@@ -522,6 +529,7 @@ static int ensure_chunk_graph(msdp_handle h, int CH) {
     if (e != hipSuccess) { msdp_set_error("graph instantiate failed: %s", hipGetErrorString(e)); h->chunk_exec = nullptr; return MSDP_EHIP; }
     h->chunk_sig = h->d;
     h->chunk_len = CH;
+    h->chunk_cur = h->h_ctl->cur;
     return 0;
 }
 

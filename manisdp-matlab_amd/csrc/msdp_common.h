@@ -119,6 +119,7 @@ struct msdp_handle_s {
     hipGraphExec_t chunk_exec = nullptr;
     Dev chunk_sig{};
     int chunk_len = 0;
+    int chunk_cur = -1;            // slot the graph was captured for (affine kinds bake slot pointers in)
     volatile unsigned long long* h_status = nullptr;   // host view of Dev::status
     double* slab = nullptr;        // split-K partial slabs of the dense MFMA path
     size_t slab_cap = 0;

@@ -237,6 +237,31 @@ static int ensure_slab(msdp_handle h, size_t need) {
 
 int msdp_dense_nS(int n) { return ((n + 15) / 16) * 16; }
 
+static void dense_plan(msdp_handle h, int nmat, int* row_blocks_out, int* SK_out, int64_t* kslice_out) {
+    const Dev& d = h->d;
+    const int nS = msdp_dense_nS(d.n);
+    const int row_blocks = (d.n_loc + DENSE_WAVES * 16 - 1) / (DENSE_WAVES * 16);
+    const int64_t Ktot = (int64_t)nmat * nS;
+    int SK = (1024 + row_blocks - 1) / row_blocks;      // aim at ~4 workgroups per CU
+    const int maxSK = (int)((Ktot + 4 * DENSE_KT - 1) / (4 * DENSE_KT));
+    if (SK > maxSK) SK = maxSK;
+    if (SK > 32) SK = 32;
+    if (SK < 1) SK = 1;
+    int64_t kslice = (Ktot + SK - 1) / SK;
+    kslice = ((kslice + DENSE_KT - 1) / DENSE_KT) * DENSE_KT;
+    SK = (int)((Ktot + kslice - 1) / kslice);
+    *row_blocks_out = row_blocks; *SK_out = SK; *kslice_out = kslice;
+}
+
+// Reserve the split-K slab for the current p BEFORE any graph capture (hipMalloc is illegal
+// while a stream is capturing).
+int msdp_dense_reserve(msdp_handle h, int nmat) {
+    int SK, row_blocks; int64_t kslice;
+    dense_plan(h, nmat, &row_blocks, &SK, &kslice);
+    const int64_t cap_rows = (h->d.n + h->nranks - 1) / h->nranks;
+    return ensure_slab(h, (size_t)SK * cap_rows * (size_t)h->d.ld);
+}
+
 // Launch the partial GEMM for up to two (matrix, panel, scale) pairs; returns slab info.
 int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const double* const* X, const double* scale,
                     const int* active_flag, const double** slab_out, int64_t* stride_out, int* SK_out) {
@@ -253,16 +278,8 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
     int ldl = d.ld;
     while ((ldl & 7) != 4) ldl += 2;                    // ldl = 4 (mod 8): conflict-free B reads
     op.ldl = ldl;
-    const int row_blocks = (d.n_loc + DENSE_WAVES * 16 - 1) / (DENSE_WAVES * 16);
-    const int64_t Ktot = (int64_t)nmat * op.nS;
-    int SK = (1024 + row_blocks - 1) / row_blocks;      // aim at ~4 workgroups per CU
-    const int maxSK = (int)((Ktot + 4 * DENSE_KT - 1) / (4 * DENSE_KT));
-    if (SK > maxSK) SK = maxSK;
-    if (SK > 32) SK = 32;
-    if (SK < 1) SK = 1;
-    int64_t kslice = (Ktot + SK - 1) / SK;
-    kslice = ((kslice + DENSE_KT - 1) / DENSE_KT) * DENSE_KT;
-    SK = (int)((Ktot + kslice - 1) / kslice);
+    int SK; int64_t kslice; int row_blocks;
+    dense_plan(h, nmat, &row_blocks, &SK, &kslice);
     op.SK = SK;
     op.kslice = (int)kslice;
     const int64_t cap_rows = (d.n + h->nranks - 1) / h->nranks;
@@ -349,6 +366,13 @@ int msdp_dense_hess(msdp_handle h) {
     const double* slab; int64_t stride; int SK;
     int rc = msdp_dense_gemm(h, 1, M, X, sc, &d.F[0].active, &slab, &stride, &SK);
     if (rc) return rc;
+    DISPATCH_LPR_D(k_dense_hess_epi_obl, h, d, slab, stride, SK);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int msdp_dense_hess_epilogue_obl(msdp_handle h, const double* slab, int64_t stride, int SK) {
+    Dev& d = h->d;
     DISPATCH_LPR_D(k_dense_hess_epi_obl, h, d, slab, stride, SK);
     HIPCHK(hipGetLastError());
     return 0;

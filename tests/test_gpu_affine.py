@@ -1,0 +1,170 @@
+"""GPU parity tests for the two affine entry points (ManiSDP_unitdiag / ManiSDP_unittrace):
+operators through the C-ABI against the oracle closures on seeded inputs (1e-11 relative:
+fp64, SDDMM + MFMA summation orders differ from SciPy/BLAS), then solver-level known answers
+from the SDPLIB table the reference ships (tolerance = accuracy the solve certifies)."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _relerr(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from manisdp_matlab_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def _bqp(d):
+    from manisdp_matlab_amd import problems
+    Q = np.loadtxt(golden_path(f"bqp_Q_{d}_1.txt.gz"), delimiter=",")
+    e = np.loadtxt(golden_path(f"bqp_e_{d}_1.txt.gz"), delimiter=",")
+    At, b, c, K = problems.bqpmom(d, Q, e)
+    c = np.asarray(c.todense()).ravel()
+    return At, b, c / np.abs(c).max(), K
+
+
+@pytest.mark.parametrize("case,p", [("gpp100", 2), ("gpp100", 7), ("bqp10", 5), ("bqp20", 16), ("gpp124-1", 33)])
+def test_unitdiag_operators(lib, case, p):
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R
+    if case.startswith("bqp"):
+        At, b, c, K = _bqp(int(case[3:]))
+    else:
+        At, b, c, K = problems.from_sdpa(golden_path(case + ".dat-s.gz"))
+        c = np.asarray(c.todense()).ravel()
+    n = K["s"]
+    rng = np.random.default_rng(p)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    y = rng.standard_normal(b.size) * 0.1
+    sigma = 0.37
+    prob = R._UnitDiagProblem(At, np.asarray(b, float), c, n, p)
+    prob.y, prob.sigma = y, sigma
+    f_ref = prob.cost(Y); G_ref = prob.grad(Y); H_ref = prob.hess(Y, U)
+    h = lib.Handle.affine(lib.KIND_UNITDIAG, At, b, c, n)
+    h.set_multipliers(y, sigma)
+    h.set_point(Y)
+    assert abs(h.cost() - f_ref) <= 1e-11 * max(1.0, abs(f_ref))
+    assert _relerr(h.rgrad(), G_ref) < 1e-11
+    assert _relerr(h.hessvec(U), H_ref) < 1e-11
+    # co() of the line search at a retracted trial point
+    Z = prob.M.retr(Y, 0.5 * U)
+    assert abs(h.linesearch_cost(U, 0.5) - prob.cost(Z)) <= 1e-11 * max(1.0, abs(prob.cost(Z)))
+    h.close()
+
+
+@pytest.mark.parametrize("case,p", [("theta1", 1), ("theta1", 6), ("theta2", 20)])
+def test_unittrace_operators(lib, case, p):
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R
+    At, b, c, K = problems.from_sdpa(golden_path(case + ".dat-s.gz"))
+    c = np.asarray(c.todense()).ravel()
+    n = K["s"]
+    rng = np.random.default_rng(p)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y)
+    U = rng.standard_normal((n, p))
+    y = rng.standard_normal(b.size) * 0.1
+    sigma = 12.5
+    prob = R._UnitTraceProblem(At, np.asarray(b, float), c, n, p)
+    prob.y, prob.sigma = y, sigma
+    f_ref = prob.cost(Y); G_ref = prob.grad(Y); H_ref = prob.hess(Y, U)
+    h = lib.Handle.affine(lib.KIND_UNITTRACE, At, b, c, n)
+    h.set_multipliers(y, sigma)
+    h.set_point(Y)
+    assert abs(h.cost() - f_ref) <= 1e-11 * max(1.0, abs(f_ref))
+    assert _relerr(h.rgrad(), G_ref) < 1e-11
+    assert _relerr(h.hessvec(U), H_ref) < 1e-11
+    assert _relerr(h.proj(U), prob.M.proj(Y, U)) < 1e-13
+    assert _relerr(h.retr(U), prob.M.retr(Y, U)) < 1e-13
+    assert _relerr(h.get_point(), Y) == 0.0
+    h.close()
+
+
+def test_unitdiag_rtr_single_tcg(lib):
+    """maxiter = 1: one tCG; Hess-vec count, stop code and cost agree with the oracle."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R, manopt_rtr
+    At, b, c, K = _bqp(10)
+    n, p = K["s"], 4
+    rng = np.random.default_rng(3)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    y = np.zeros(b.size); sigma = 1e-3
+    h = lib.Handle.affine(lib.KIND_UNITDIAG, At, b, c, n)
+    h.set_multipliers(y, sigma)
+    for maxinner in (1, 5, 20):
+        h.set_point(Y)
+        st = h.rtr(lib.default_opts(maxiter=1, maxinner=maxinner, tolgradnorm=1e-8))
+        prob = R._UnitDiagProblem(At, np.asarray(b, float), c, n, p)
+        prob.y, prob.sigma = y, sigma
+        _, f_ref, info = manopt_rtr.trustregions(prob, Y.copy(), 1, maxinner, 1e-8)
+        assert st.hessvecs == info.hessvecs
+        assert st.last_stop_inner == info.stop_inner[-1]
+        assert abs(st.cost - f_ref) < 1e-10 * max(1.0, abs(f_ref))
+    h.close()
+
+
+def test_unittrace_rtr_single_tcg(lib):
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R, manopt_rtr
+    At, b, c, K = problems.from_sdpa(golden_path("theta1.dat-s.gz"))
+    c = np.asarray(c.todense()).ravel()
+    n, p = K["s"], 3
+    rng = np.random.default_rng(3)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y)
+    y = np.zeros(b.size); sigma = 10.0
+    h = lib.Handle.affine(lib.KIND_UNITTRACE, At, b, c, n)
+    h.set_multipliers(y, sigma)
+    for maxinner in (1, 5, 40):
+        h.set_point(Y)
+        st = h.rtr(lib.default_opts(maxiter=1, maxinner=maxinner, tolgradnorm=1e-8))
+        prob = R._UnitTraceProblem(At, np.asarray(b, float), c, n, p)
+        prob.y, prob.sigma = y, sigma
+        _, f_ref, info = manopt_rtr.trustregions(prob, Y.copy(), 1, maxinner, 1e-8)
+        assert st.hessvecs == info.hessvecs
+        assert st.last_stop_inner == info.stop_inner[-1]
+        assert abs(st.cost - f_ref) < 1e-10 * max(1.0, abs(f_ref))
+    h.close()
+
+
+def test_solver_bqp_matches_oracle(lib):
+    from manisdp_matlab_amd import solvers
+    from oracle import manisdp_ref as R
+    At, b, c, K = _bqp(10)
+    n = K["s"]
+    rng = np.random.default_rng(0)
+    Y0 = rng.standard_normal((n, 2)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    Y, obj, data = solvers.ManiSDP_unitdiag(At, b, c, K, {"Y0": Y0}, verbose=False)
+    Yr, objr, datar = R.ManiSDP_unitdiag(At, b, c, K, {"Y0": Y0})
+    assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-8 and data["status"] == 0
+    assert abs(obj - objr) < 1e-6 * max(1.0, abs(objr))
+
+
+def test_solver_gpp100_known_answer(lib):
+    from manisdp_matlab_amd import problems, solvers
+    known = json.load(open(golden_path("known_answers.json")))
+    At, b, c, K = problems.from_sdpa(golden_path("gpp100.dat-s.gz"))
+    opts = dict(sigma0=1e-1, sigma_min=1e-1, tau1=1e-2, tau2=1e-1, TR_maxinner=40, TR_maxiter=6)
+    Y, obj, data = solvers.ManiSDP_unitdiag(At, b, c, K, opts, verbose=False)
+    eta = max(data["gap"], data["pinf"], data["dinf"])
+    assert eta < 1e-6
+    assert abs(-obj - known["gpp100"]) < 2e-5 * abs(known["gpp100"])      # README prints 6 digits
+
+
+def test_solver_theta1_known_answer(lib):
+    from manisdp_matlab_amd import problems, solvers
+    known = json.load(open(golden_path("known_answers.json")))
+    At, b, c, K = problems.from_sdpa(golden_path("theta1.dat-s.gz"))
+    opts = dict(tol=1e-6, sigma0=1e5, sigma_max=1e8)            # example/example_theta.m:50-53
+    Y, obj, data = solvers.ManiSDP_unittrace(At, b, c, K, opts, verbose=False)
+    eta = max(data["gap"], data["pinf"], data["dinf"])
+    assert eta < 1e-5
+    assert abs(-obj - known["theta1"]) < 1e-5 * known["theta1"]
