@@ -337,8 +337,8 @@ def bqpmom(n, Q, e):
 
 def qsmom(n, coe):
     """Second-order moment relaxation of ``min coe'[x]_4, |x|^2 = 1`` in SeDuMi
-    format.  Restates src/basicfunction/qsmom.m:6-116.  The moment matrix has
-    constant trace 3 (README.md:82)."""
+    format.  Restates src/basicfunction/qsmom.m:6-116 (the reference's own example solves it
+    with the generic ManiSDP, example/example_qsphere.m:18-27)."""
     coe = np.asarray(coe, dtype=np.float64).ravel()
     basis_arr = get_basis(n, 2)
     mb = basis_arr.shape[1]

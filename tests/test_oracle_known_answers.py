@@ -1,0 +1,83 @@
+"""CPU tests (no GPU): pin the oracle against every known answer the reference ships for this
+path (data/sdplib/README:39-51,71-88,98-105 -> tests/golden/known_answers.json) and against the
+SURVEY.md probe value for G1.  These are what make the oracle trustworthy as the GPU checker."""
+import json
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import golden_path
+from manisdp_matlab_amd import problems
+from oracle import manisdp_ref as R
+
+KNOWN = json.load(open(golden_path("known_answers.json")))
+
+
+def _mcp(name):
+    At, b, c, K = problems.from_sdpa(golden_path(name + ".dat-s.gz"))
+    n = K["s"]
+    return sp.csr_matrix(c.toarray().reshape(n, n, order="F"))
+
+
+@pytest.mark.parametrize("name", ["mcp100", "mcp124-1", "mcp250-1"])
+def test_onlyunitdiag_sdplib_mcp(name):
+    """max <F0,X>, X_ii = 1  ->  ManiSDP_onlyunitdiag with C = -F0 returns -value (7 printed digits)."""
+    Y, obj, data = R.ManiSDP_onlyunitdiag(_mcp(name), {})
+    assert data["status"] == 0 and data["dinf"] < 1e-8
+    assert abs(-obj - KNOWN[name]) < 1e-6 * abs(KNOWN[name])
+    assert np.allclose(np.linalg.norm(Y, axis=1), 1.0, atol=1e-12)
+
+
+def test_onlyunitdiag_gset():
+    """maxG11 == Gset G11 with C = -L/4 (example_maxcut.m:10-11); G1 against the survey probe."""
+    Y, obj, data = R.ManiSDP_onlyunitdiag(problems.maxcut_cost_matrix(golden_path("G11.txt.gz")), {})
+    assert data["dinf"] < 1e-8
+    assert abs(-obj - KNOWN["maxG11"]) < 1e-6 * KNOWN["maxG11"]
+    Y, obj, data = R.ManiSDP_onlyunitdiag(problems.maxcut_cost_matrix(golden_path("G1.txt.gz")), {})
+    assert data["dinf"] < 1e-8
+    assert abs(obj - (-12083.19765455)) < 1e-6 * 12083.2
+
+
+def test_quirk_q1_variants_agree_at_optimum():
+    """Reference behaviour (stale eG after a rejected step) and per-point state reach the same optimum."""
+    C = problems.maxcut_cost_matrix(golden_path("G11.txt.gz"))
+    rng = np.random.default_rng(1)
+    Y0 = rng.standard_normal((C.shape[0], 2)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    _, o1, d1 = R.ManiSDP_onlyunitdiag(C, {"Y0": Y0}, q1="reference")
+    _, o2, d2 = R.ManiSDP_onlyunitdiag(C, {"Y0": Y0}, q1="correct")
+    assert d1["dinf"] < 1e-8 and d2["dinf"] < 1e-8
+    assert abs(o1 - o2) < 1e-7 * abs(o1)
+
+
+def test_unitdiag_gpp100():
+    """gpp100 through fromsdpa: constraint 1 is <J,X> = 0, the rest X_ii = 1; README gives 6 digits.
+    Option set of SURVEY.md section 4 (the defaults are tuned for BQP)."""
+    At, b, c, K = problems.from_sdpa(golden_path("gpp100.dat-s.gz"))
+    opts = dict(sigma0=1e-1, sigma_min=1e-1, tau1=1e-2, tau2=1e-1, TR_maxinner=40, TR_maxiter=6)
+    Y, obj, data = R.ManiSDP_unitdiag(At, b, c, K, opts)
+    assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-6
+    assert abs(-obj - KNOWN["gpp100"]) < 2e-5 * abs(KNOWN["gpp100"])
+
+
+def test_unitdiag_bqp_kkt_self_certification():
+    """BQP instances have no stored optimum: KKT residues below tol certify the value."""
+    Q = np.loadtxt(golden_path("bqp_Q_10_1.txt.gz"), delimiter=",")
+    e = np.loadtxt(golden_path("bqp_e_10_1.txt.gz"), delimiter=",")
+    At, b, c, K = problems.bqpmom(10, Q, e)
+    c = np.asarray(c.todense()).ravel()
+    Y, obj, data = R.ManiSDP_unitdiag(At, b, c / np.abs(c).max(), K, {})
+    assert data["status"] == 0
+    assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
+    X = Y @ Y.T
+    assert np.allclose(np.diag(X), 1.0, atol=1e-12)
+    assert np.linalg.norm(At.T @ X.ravel(order="F") - b) / (1 + np.linalg.norm(b)) < 1e-8
+
+
+def test_unittrace_theta1():
+    """theta1: constraint 1 is tr X = 1, F0 = J; options of example/example_theta.m:50-53."""
+    At, b, c, K = problems.from_sdpa(golden_path("theta1.dat-s.gz"))
+    Y, obj, data = R.ManiSDP_unittrace(At, b, c, K, dict(tol=1e-6, sigma0=1e5, sigma_max=1e8))
+    assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-5
+    assert abs(-obj - KNOWN["theta1"]) < 1e-5 * KNOWN["theta1"]
+    assert abs(np.linalg.norm(Y) - 1.0) < 1e-12

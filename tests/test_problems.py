@@ -1,0 +1,90 @@
+"""CPU tests of the instance readers / generators against facts stated in the reference tree."""
+import numpy as np
+import scipy.sparse as sp
+
+from conftest import golden_path
+from manisdp_matlab_amd import problems as P
+
+
+def test_gset_sizes():
+    C = P.maxcut_cost_matrix(golden_path("G1.txt.gz"))
+    assert C.shape == (800, 800) and C.nnz == 39152            # K1
+    C = P.maxcut_cost_matrix(golden_path("G81.txt.gz"))
+    assert C.shape == (20000, 20000) and C.nnz == 92644        # K2 (zero diagonals dropped)
+    assert abs(C - C.T).max() == 0
+
+
+def test_laplacian_assignment_semantics(tmp_path):
+    """Laplacian.m:7-10: off-diagonals are ASSIGNED (last wins), the diagonal accumulates."""
+    f = tmp_path / "g.txt"
+    f.write_text("3 3\n1 2 1\n1 2 5\n2 3 2\n")
+    L = P.gset_laplacian(str(f)).toarray()
+    assert L[0, 1] == -5 and L[1, 0] == -5
+    assert L[0, 0] == 6 and L[1, 1] == 8 and L[2, 2] == 2
+
+
+def test_get_basis_order_matches_reference_iteration():
+    for n, d in [(2, 2), (3, 2), (3, 4), (4, 3), (5, 4)]:
+        assert (P.get_basis(n, d) == P._get_basis_literal(n, d)).all()
+    # n=3, d=2 within degree 2: 200,110,020,101,011,002
+    b = P.get_basis(3, 2)[:, 4:]
+    assert [tuple(c) for c in b.T] == [(2, 0, 0), (1, 1, 0), (0, 2, 0), (1, 0, 1), (0, 1, 1), (0, 0, 2)]
+
+
+def test_bqpmom_sizes_match_reference_log():
+    """data/bqp_result.txt:3-8: d -> (n, m)."""
+    for d, (n, m) in {10: (56, 1256), 20: (211, 16361)}.items():
+        Q = np.loadtxt(golden_path(f"bqp_Q_{d}_1.txt.gz"), delimiter=",")
+        e = np.loadtxt(golden_path(f"bqp_e_{d}_1.txt.gz"), delimiter=",")
+        At, b, c, K = P.bqpmom(d, Q, e)
+        assert K["s"] == n and At.shape == (n * n, m) and b[0] == 1 and np.count_nonzero(b) == 1
+        # every constraint matrix is symmetric
+        k = m // 2
+        Ak = At[:, k].toarray().reshape(n, n, order="F")
+        assert np.array_equal(Ak, Ak.T)
+        # objective reproduces x'Qx + e'x on a +-1 point lifted to the moment matrix
+        rng = np.random.default_rng(d)
+        x = rng.choice([-1.0, 1.0], size=d)
+        v = np.concatenate([[1.0], x, [x[j] * x[i] for i in range(1, d) for j in range(i)]])
+        X = np.outer(v, v)
+        C = c.toarray().reshape(n, n, order="F")
+        assert abs(np.sum(C * X) - (x @ Q @ x + e @ x)) < 1e-9
+        assert np.linalg.norm(At.T @ X.ravel(order="F") - b) < 1e-9      # feasible for every constraint
+
+
+def test_qsmom_feasible_moment_matrix():
+    coe = np.loadtxt(golden_path("qs_c_10_1.txt.gz"), delimiter=",")
+    At, b, c, K = P.qsmom(10, coe)
+    n = K["s"]
+    assert n == 66 and At.shape[1] == n * (n + 1) // 2 - 1001 + n + 1
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(10); x /= np.linalg.norm(x)
+    basis = P.get_basis(10, 2)
+    v = np.prod(x[:, None] ** basis, axis=0)
+    X = np.outer(v, v)
+    assert np.linalg.norm(At.T @ X.ravel(order="F") - b) < 1e-9
+
+
+def test_from_sdpa_structure():
+    At, b, c, K = P.from_sdpa(golden_path("gpp100.dat-s.gz"))
+    n = K["s"]
+    assert n == 100 and At.shape == (10000, 101) and b[0] == 0 and (b[1:] == 1).all()
+    A1 = At[:, 0].toarray().reshape(n, n, order="F")
+    assert (A1 == 1).all()                                      # <J, X> = 0
+    A2 = At[:, 1].toarray().reshape(n, n, order="F")
+    assert A2[0, 0] == 1 and A2.sum() == 1                      # X_11 = 1
+    At, b, c, K = P.from_sdpa(golden_path("theta1.dat-s.gz"))
+    n = K["s"]
+    A1 = At[:, 0].toarray().reshape(n, n, order="F")
+    assert np.array_equal(A1, np.eye(n)) and b[0] == 1          # trace constraint
+    assert (c.toarray() == -1).all()                            # F0 = J -> c = -vec(J)
+
+
+def test_theta_generator():
+    At, b, c, K = P.theta_problem(40, seed=1)
+    n = K["s"]
+    assert b[-1] == 1 and (b[:-1] == 0).all()
+    last = At[:, -1].toarray().reshape(n, n, order="F")
+    assert np.array_equal(last, np.eye(n))
+    A0 = At[:, 0].toarray().reshape(n, n, order="F")
+    assert np.array_equal(A0, A0.T) and A0.sum() == 2

@@ -1,0 +1,78 @@
+"""CPU test of the N > 1 data path with two gloo processes: the row partition, the uniform
+all-gather of the thin direction before S*U and the all-reduce of the partial sums reproduce
+the single-process Hess-vec of the oracle bit for bit in structure (allclose to 1e-14)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from manisdp_matlab_amd import problems, sharding
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_rows, n_cols, p, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    C = problems.toroidal_grid_maxcut(n_rows, n_cols, seed=7)
+    n = C.shape[0]
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    r0, r1 = sharding.row_range(n, world, rank)
+    Cl = sharding.shard_rows_csr(C, n, world, rank)
+    Yl, Ul = Y[r0:r1], U[r0:r1]
+
+    def allgather(local):
+        slab = torch.from_numpy(sharding.pad_slab(local, n, world))
+        outs = [torch.empty_like(slab) for _ in range(world)]
+        dist.all_gather(outs, slab)
+        return sharding.unpad_gathered([o.numpy() for o in outs], n)
+
+    # cost state: eG rows need all of Y (ManiSDP_onlyunitdiag.m:118-119)
+    Yfull = allgather(Yl)
+    eG = np.sum((Cl @ Yfull) * Yl, axis=1, keepdims=True)
+    # Hess-vec rows need all of U (:128-129); projections are row-local
+    Ufull = allgather(Ul)
+    eH = Cl @ Ufull
+    Hl = eH - Yl * np.sum(Yl * eH, axis=1, keepdims=True) - Ul * eG
+    part = torch.tensor([float(np.sum(Ul * Hl))], dtype=torch.float64)
+    dist.all_reduce(part)
+    Hfull = allgather(Hl)
+    if rank == 0:
+        np.save(out, np.concatenate([Hfull.ravel(), [part.item()]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape,p", [((10, 13), 4), ((9, 7), 3)])
+def test_two_rank_hessvec_matches_single_process(tmp_path, shape, p):
+    from oracle import manisdp_ref as R
+    out = str(tmp_path / "h.npy")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, shape[0], shape[1], p, out), nprocs=2, join=True)
+    got = np.load(out)
+    C = problems.toroidal_grid_maxcut(shape[0], shape[1], seed=7)
+    n = C.shape[0]
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    H = R.hessvec_onlyunitdiag(C, Y, U)
+    assert np.allclose(got[:-1].reshape(n, p), H, rtol=0, atol=1e-13)
+    assert abs(got[-1] - np.sum(U * H)) < 1e-11 * abs(np.sum(U * H))
+
+
+def test_partition_properties():
+    for n, w in [(20000, 8), (100000, 8), (17, 4), (5, 8), (64, 1)]:
+        cap = sharding.row_capacity(n, w)
+        ranges = [sharding.row_range(n, w, r) for r in range(w)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        assert all(r1 - r0 <= cap for r0, r1 in ranges)
