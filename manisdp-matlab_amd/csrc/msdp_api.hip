@@ -372,6 +372,7 @@ extern "C" int msdp_set_point(msdp_handle h, int32_t p, const double* Y) {
     if (rc) return rc;
     h->have_point = true;
     h->state_valid = false;
+    h->gradnorm_valid = false;
     return 0;
 }
 
@@ -626,6 +627,7 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
         if ((rc = pull_ctl(h))) return rc;
     }
     h->state_valid = true;
+    h->gradnorm_valid = true;
     if (stats) {
         const Ctl* c = h->h_ctl;
         memset(stats, 0, sizeof(*stats));
@@ -760,6 +762,7 @@ extern "C" int msdp_linesearch_accept(msdp_handle h) {
     CHECK_H(h);
     h->h_ctl->cur ^= 1;
     h->state_valid = false;
+    h->gradnorm_valid = false;
     return 0;
 }
 
@@ -768,6 +771,21 @@ extern "C" int msdp_escape_eigs(msdp_handle h, int32_t k, double tol, int32_t ma
     CHECK_H(h);
     int rc = ensure_state(h);
     if (rc) return rc;
+    if (!h->gradnorm_valid) {
+        // |S*Y|_F and f at the resident point (decides whether span(Y) may be deflated)
+        h->h_ctl->done = 0;
+        if ((rc = push_ctl(h))) return rc;
+        if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
+        if ((rc = msdp_k_sum_to(h, P_GG, &h->d.ctl->gg_prop))) return rc;
+        if ((rc = msdp_k_sum_to(h, P_F, &h->d.ctl->fx_prop))) return rc;
+        double v[2] = {0.0, 0.0};
+        HIPCHK(hipMemcpyAsync(&v[0], &h->d.ctl->gg_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(&v[1], &h->d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->h_ctl->norm_grad = sqrt(v[0] > 0 ? v[0] : 0.0);
+        h->h_ctl->fx = v[1];
+        h->gradnorm_valid = true;
+    }
     return msdp_escape_impl(h, k, tol, maxit, lam_min, V, lam_max, iters);
 }
 
