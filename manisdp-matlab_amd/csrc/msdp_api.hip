@@ -281,7 +281,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
     if (h->h_frame) (void)hipHostFree(h->h_frame);
     if (h->h_status) (void)hipHostFree((void*)h->h_status);
-    if (h->chunk_exec) (void)hipGraphExecDestroy(h->chunk_exec);
+    for (int s2 = 0; s2 < 2; ++s2) if (h->chunk_execs[s2]) (void)hipGraphExecDestroy(h->chunk_execs[s2]);
     msdp_affine_release(h);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -294,6 +294,7 @@ extern "C" int msdp_set_multipliers(msdp_handle h, const double* y, double sigma
     CHECK_H(h);
     if (h->d.costkind != COST_AFFINE) { msdp_set_error("set_multipliers: handle has no affine constraints"); return MSDP_ESTATE; }
     h->state_valid = false;
+    h->chunk_len = 0;      // sigma is baked into the captured launches: force a re-capture
     return msdp_affine_set_multipliers(h, y, sigma);
 }
 
@@ -517,20 +518,27 @@ static int enqueue_trips(msdp_handle h, int cnt) {
 // past the end of the solve is safe.
 static int ensure_chunk_graph(msdp_handle h, int CH) {
     h->d.full = h->d.md;
-    if (h->chunk_exec && h->chunk_len == CH && h->chunk_cur == h->h_ctl->cur && memcmp(&h->chunk_sig, &h->d, sizeof(Dev)) == 0) return 0;
-    if (h->chunk_exec) { (void)hipGraphExecDestroy(h->chunk_exec); h->chunk_exec = nullptr; }
-    hipGraph_t g = nullptr;
-    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_trips(h, CH);
-    hipError_t e = hipStreamEndCapture(h->stream, &g);
-    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-    if (e != hipSuccess) { msdp_set_error("graph capture failed: %s", hipGetErrorString(e)); return MSDP_EHIP; }
-    e = hipGraphInstantiate(&h->chunk_exec, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    if (e != hipSuccess) { msdp_set_error("graph instantiate failed: %s", hipGetErrorString(e)); h->chunk_exec = nullptr; return MSDP_EHIP; }
-    h->chunk_sig = h->d;
-    h->chunk_len = CH;
-    h->chunk_cur = h->h_ctl->cur;
+    // The affine kinds bake the current slot's pointers (eS[cur], Y[cur]) into the launches on the host, so
+    // they keep one executable graph per slot; the other kinds read `cur` on the device.
+    const int slot = (h->d.costkind == COST_AFFINE) ? h->h_ctl->cur : 0;
+    if (h->chunk_len != CH || memcmp(&h->chunk_sig, &h->d, sizeof(Dev)) != 0) {
+        for (int s = 0; s < 2; ++s)
+            if (h->chunk_execs[s]) { (void)hipGraphExecDestroy(h->chunk_execs[s]); h->chunk_execs[s] = nullptr; }
+        h->chunk_sig = h->d;
+        h->chunk_len = CH;
+    }
+    if (!h->chunk_execs[slot]) {
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_trips(h, CH);
+        hipError_t e = hipStreamEndCapture(h->stream, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) { msdp_set_error("graph capture failed: %s", hipGetErrorString(e)); return MSDP_EHIP; }
+        e = hipGraphInstantiate(&h->chunk_execs[slot], g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) { msdp_set_error("graph instantiate failed: %s", hipGetErrorString(e)); h->chunk_execs[slot] = nullptr; return MSDP_EHIP; }
+    }
+    h->chunk_exec = h->chunk_execs[slot];
     return 0;
 }
 
@@ -618,14 +626,25 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
     if ((rc = msdp_launch_costgrad(h, cur))) return rc;          // trustregions.m:405
     if ((rc = msdp_launch_rtr_begin(h))) return rc;
     if ((rc = pull_ctl(h))) return rc;
+    static int timing = -1;
+    if (timing < 0) { const char* e = getenv("MSDP_TIMING"); timing = (e && atoi(e)) ? 1 : 0; }
+    double t_tcg = 0.0, t_rest = 0.0;
     while (!h->h_ctl->done) {                                     // trustregions.m:441
         cur = h->h_ctl->cur;
+        const auto ta = std::chrono::steady_clock::now();
         if ((rc = run_tcg(h, opts->maxinner, h->h_ctl->k))) return rc;   // :495
+        const auto tb = std::chrono::steady_clock::now();
         if ((rc = msdp_launch_retract(h))) return rc;             // :540
         if ((rc = msdp_launch_costgrad(h, cur ^ 1))) return rc;   // :544
         if ((rc = msdp_launch_rtr_decide(h))) return rc;          // :548-729
         if ((rc = pull_ctl(h))) return rc;
+        const auto tc = std::chrono::steady_clock::now();
+        t_tcg += std::chrono::duration<double>(tb - ta).count();
+        t_rest += std::chrono::duration<double>(tc - tb).count();
     }
+    if (timing)
+        fprintf(stderr, "[msdp_rtr] k=%d hessvecs=%d  tCG phase %.3f ms  (retract+cost+decide+sync) %.3f ms\n",
+                h->h_ctl->k, h->h_ctl->hessvecs, t_tcg * 1e3, t_rest * 1e3);
     h->state_valid = true;
     h->gradnorm_valid = true;
     if (stats) {

@@ -117,10 +117,10 @@ struct msdp_handle_s {
     int* d_rowptr = nullptr; int* d_colind = nullptr; double* d_cval = nullptr;
     msdp_rtr_opts last_opts{};
     // tCG chunk graph (CH x {hess, upd1, upd2}) and its validity signature
-    hipGraphExec_t chunk_exec = nullptr;
+    hipGraphExec_t chunk_exec = nullptr;          // the one to launch now (alias into chunk_execs)
+    hipGraphExec_t chunk_execs[2] = {nullptr, nullptr};
     Dev chunk_sig{};
     int chunk_len = 0;
-    int chunk_cur = -1;            // slot the graph was captured for (affine kinds bake slot pointers in)
     volatile unsigned long long* h_status = nullptr;   // host view of Dev::status
     double* slab = nullptr;        // split-K partial slabs of the dense MFMA path
     size_t slab_cap = 0;

@@ -119,10 +119,20 @@ def ManiSDP_onlyunitdiag(C, options=None, verbose=True, rng=None):
                 S = (Csp - sp.diags(z)) if sp.issparse(Csp) else (Csp - np.diag(z))   # :49
                 dS, vS, nneg = _extreme_eigs_host(S, int(o["delta"]), dense_max)     # :50
                 lam_min, lam_max = dS[0], dS[-1]
+            elif eig_mode == "host_sparse":
+                # diagnostic: ARPACK shift-invert on the host (sparse LU of S - sigma I), k bottom eigenpairs
+                import scipy.sparse.linalg as spla
+                S = (Csp - sp.diags(z)).tocsc()
+                k = int(o["delta"])
+                lam_max = float(spla.eigsh(S, k=1, which="LA", return_eigenvectors=False, tol=1e-6)[0])
+                lam, vS = spla.eigsh(S, k=k, sigma=-1e-3 - 0.0 * lam_max, which="LM", tol=1e-12)
+                order = np.argsort(lam); lam = lam[order]; vS = vS[:, order]
+                lam_min = lam[0]
+                nneg = int(np.sum(lam < 0))
             else:
                 k = int(o["delta"])
                 lam, vS, lam_max, _ = h.escape_eigs(k, tol=float(o.get("eig_tol", 1e-9)),
-                                                    maxit=int(o.get("eig_maxit", 2000)))
+                                                    maxit=int(o.get("eig_maxit", 60000)))
                 lam_min = lam[0]
                 nneg = int(np.sum(lam < 0))
                 S = None
