@@ -97,7 +97,7 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
     const size_t cnt = rows * (size_t)ldcap;
     double** vecs[] = {&d.Y[0], &d.Y[1], &d.Gr[0], &d.Gr[1], &d.eta[0], &d.eta[1], &d.Heta[0], &d.Heta[1],
                        &d.r, &d.md, &d.Hmd, &d.W0, &d.W1};
-    if (h->nranks > 1 && d.full) dev_free(h, d.full);
+    if (h->use_comm && d.full) dev_free(h, d.full);
     d.full = nullptr;
     for (double** v : vecs) {
         if (*v) dev_free(h, *v);
@@ -106,7 +106,7 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(*v, 0, cnt * sizeof(double), h->stream));
     }
-    if (h->nranks > 1) {
+    if (h->use_comm) {
         int rc = dev_alloc<double>(h, &d.full, cnt * (size_t)h->nranks);
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(d.full, 0, cnt * h->nranks * sizeof(double), h->stream));
@@ -359,7 +359,7 @@ extern "C" int msdp_set_point(msdp_handle h, int32_t p, const double* Y) {
     }
     d.p = p;
     d.ld = ((p + 1) / 2) * 2;
-    if (h->nranks == 1) d.full = d.md;     // overwritten per launch by allgather_rows
+    if (!h->use_comm) d.full = d.md;       // overwritten per launch by allgather_rows
     choose_grid(h);
     if (d.costkind != COST_SPARSE) {
         int rc = msdp_dense_reserve(h, d.costkind == COST_AFFINE ? 2 : 1);
@@ -392,7 +392,7 @@ extern "C" int msdp_get_p(msdp_handle h, int32_t* p) {
 
 // ------------------------------------------------------------------ collectives
 int msdp_allreduce_partials(msdp_handle h, int first, int count) {
-    if (h->nranks == 1) return 0;
+    if (!h->use_comm) return 0;
     double* buf = h->d.P + (size_t)first * MSDP_MAX_GRID;
     ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count * MSDP_MAX_GRID, ncclDouble, ncclSum,
                                    (ncclComm_t)h->comm, h->stream);
@@ -404,7 +404,7 @@ int msdp_allreduce_partials(msdp_handle h, int first, int count) {
 // all-gather of the thin n x p factor (each rank sends its slab to its 7 peers,
 // one message per xGMI link).  With one rank the local buffer is used directly.
 int msdp_allgather_rows(msdp_handle h, const double* local_rows) {
-    if (h->nranks == 1) {
+    if (!h->use_comm) {
         h->d.full = const_cast<double*>(local_rows);
         return 0;
     }
@@ -441,6 +441,7 @@ extern "C" int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const
     h->comm = comm;
     h->nranks = nranks;
     h->rank = rank;
+    h->use_comm = true;      // also with nranks == 1: a size-1 communicator exercises the same RCCL calls
     const int cap = rows_capacity(h);
     h->d.row0 = rank * cap;
     int r1 = h->d.row0 + cap;
@@ -552,12 +553,14 @@ static int launch_chunk(msdp_handle h, int CH, bool graph) {
 // host-mapped progress word the lead thread of k_tcg_upd2 publishes every trip.
 static int run_tcg(msdp_handle h, int maxinner, int k) {
     const int CH = tcg_chunk();
-    const bool graph = use_graphs() && h->nranks == 1;
+    const bool graph = use_graphs() && !h->use_comm;
     int rc;
     static int nopub = -1;
     if (nopub < 0) { const char* e = getenv("MSDP_NO_PUBLISH"); nopub = (e && atoi(e)) ? 1 : 0; }
-    if (nopub) {
-        // blocking variant: one stream sync per chunk, no host-mapped progress word
+    if (nopub || h->use_comm) {
+        // blocking variant: one stream sync per chunk, no host-mapped progress word.  Mandatory with RCCL:
+        // every rank must enqueue the SAME number of collectives, so the chunk count may only depend on
+        // device state that is identical on all ranks (the frames are), never on host timing.
         h->d.status = nullptr;
         if (graph && (rc = ensure_chunk_graph(h, CH))) return rc;
         if ((rc = msdp_launch_tcg_init(h))) return rc;
@@ -838,7 +841,7 @@ extern "C" int msdp_bench_hessvec(msdp_handle h, int32_t reps, double* avg_ms, d
     const int per = 50;
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
-    const bool graph = use_graphs() && h->nranks == 1;
+    const bool graph = use_graphs() && !h->use_comm;
     if (graph) {
         HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         for (int i = 0; i < per && !rc; ++i) rc = msdp_launch_hess(h);
@@ -940,7 +943,7 @@ extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms) 
         if ((rc = msdp_launch_hess(h)) || (rc = msdp_launch_upd1(h)) || (rc = msdp_launch_upd2(h))) return rc;
     }
     const int CH = tcg_chunk();
-    const bool graph = use_graphs() && h->nranks == 1;
+    const bool graph = use_graphs() && !h->use_comm;
     if (graph && (rc = ensure_chunk_graph(h, CH))) return rc;
     const int nchunks = (reps + CH - 1) / CH;
     reps = nchunks * CH;

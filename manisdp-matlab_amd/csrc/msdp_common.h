@@ -112,6 +112,7 @@ struct msdp_handle_s {
     // host copies needed for re-allocation / sharding
     int nranks = 1, rank = 0;
     void* comm = nullptr;          // ncclComm_t
+    bool use_comm = false;         // route the exchanges through RCCL (set by msdp_comm_init, any nranks)
     std::vector<int> h_rowptr; std::vector<int> h_colind; std::vector<double> h_cval;
     // device-side sparse arrays owned by the handle
     int* d_rowptr = nullptr; int* d_colind = nullptr; double* d_cval = nullptr;

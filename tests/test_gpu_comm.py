@@ -1,0 +1,36 @@
+"""GPU test of the RCCL data path on ONE GPU: a size-1 communicator routes every exchange through the same
+ncclAllGather / ncclAllReduce calls the 8-GPU run uses (all-gather of the thin direction into the gather
+buffer before S*U, all-reduce of the partial-sum arrays, chunked tCG without host-timing dependence).
+Results must be bit-identical to the communicator-free path."""
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+
+
+def test_size1_communicator_is_bit_identical():
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    C = problems.maxcut_cost_matrix(golden_path("G1.txt.gz"))
+    n, p = C.shape[0], 12
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    res = []
+    for use_comm in (False, True):
+        h = _lib.Handle.onlyunitdiag(C)
+        if use_comm:
+            h.comm_init(1, 0, _lib.Handle.comm_unique_id())
+            assert h.local_rows() == (0, n)
+        h.set_point(Y)
+        H = h.hessvec(U)
+        G = h.rgrad()
+        st = h.rtr(_lib.default_opts(maxiter=10, maxinner=30, tolgradnorm=1e-8))
+        res.append((H, G, st.cost, st.gradnorm, st.hessvecs, st.accepted, h.get_point()))
+        h.close()
+    a, b = res
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and a[5] == b[5]
+    assert np.array_equal(a[6], b[6])
