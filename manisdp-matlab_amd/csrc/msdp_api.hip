@@ -3,6 +3,7 @@
 // the fine-grained parity entry points, RCCL sharding and measurement hooks.
 #include "msdp_common.h"
 #include <rccl/rccl.h>
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -78,13 +79,18 @@ static void choose_grid(msdp_handle h) {
     Dev& d = h->d;
     int half = d.ld / 2, lpr = 1;
     while (lpr < half && lpr < 64) lpr <<= 1;
+    if (const char* e = getenv("MSDP_LPR_SHIFT")) for (int s2 = 0; s2 < atoi(e) && lpr > 1; ++s2) lpr >>= 1;
     const int rows_per_step = MSDP_WAVES * (64 / lpr);
     int want = (rows_capacity(h) + rows_per_step - 1) / rows_per_step;
+    // One or two workgroups per CU, never a fraction in between: with 256 < G < 512 some CUs get two
+    // 1024-thread workgroups and the launch waits for them (measured on G81 p=32: G=320 -> 27.4 us per tCG
+    // trip, G=256 -> 24.1 us).
     int gmax = 512;
     if (const char* e = getenv("MSDP_GRID")) { int v = atoi(e); if (v >= 8) gmax = v; }
     if (gmax > MSDP_MAX_GRID) gmax = MSDP_MAX_GRID;
     int G = ((want + 7) / 8) * 8;
     if (G < 8) G = 8;
+    if (G > 256 && G < 512) G = 256;
     if (G > gmax) G = (gmax / 8) * 8;
     d.G = G;
 }
@@ -192,6 +198,31 @@ static int upload_sparse_rows(msdp_handle h) {
         HIPCHK(hipMemcpy(h->d_cval, h->h_cval.data() + base, nnz * sizeof(double), hipMemcpyHostToDevice));
     }
     d.rowptr = h->d_rowptr; d.colind = h->d_colind; d.cval = h->d_cval; d.nnz = nnz;
+    // ELL copy when every row is short (fixed-degree graphs such as G81: W = 5)
+    int W = 0;
+    for (int i = 0; i < d.n_loc; ++i) W = std::max(W, rp[i + 1] - rp[i]);
+    d.ellW = 0; d.ellc = nullptr; d.ellv = nullptr;
+    const char* noell = getenv("MSDP_NO_ELL");
+    if (W >= 1 && W <= 8 && !(noell && atoi(noell))) {
+        const size_t cap = (size_t)rows_capacity(h);
+        std::vector<int> ec((size_t)W * cap);
+        std::vector<double> ev((size_t)W * cap, 0.0);
+        for (int w = 0; w < W; ++w)
+            for (size_t i = 0; i < cap; ++i) ec[(size_t)w * cap + i] = (int)std::min<size_t>(i, d.n_loc ? d.n_loc - 1 : 0) + d.row0;
+        for (int i = 0; i < d.n_loc; ++i)
+            for (int t = rp[i]; t < rp[i + 1]; ++t) {
+                const int w = t - rp[i];
+                ec[(size_t)w * cap + i] = h->h_colind[base + t];
+                ev[(size_t)w * cap + i] = h->h_cval[base + t];
+            }
+        if (h->d_ellc) dev_free(h, h->d_ellc);
+        if (h->d_ellv) dev_free(h, h->d_ellv);
+        if ((rc = dev_alloc<int>(h, &h->d_ellc, ec.size()))) return rc;
+        if ((rc = dev_alloc<double>(h, &h->d_ellv, ev.size()))) return rc;
+        HIPCHK(hipMemcpy(h->d_ellc, ec.data(), ec.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_ellv, ev.data(), ev.size() * sizeof(double), hipMemcpyHostToDevice));
+        d.ellW = W; d.ell_stride = (int64_t)cap; d.ellc = h->d_ellc; d.ellv = h->d_ellv;
+    }
     return 0;
 }
 

@@ -82,6 +82,11 @@ struct Dev {
     const int* colind;
     const double* cval;
     int64_t nnz;
+    // optional ELL copy of the same rows (max row length <= 8): [w][row] slices
+    int ellW;
+    int64_t ell_stride;
+    const int* ellc;
+    const double* ellv;
     // dense C / eS (n_loc x n row-major) per slot for affine kinds
     double* Cd;       // dense cost matrix rows (COST_DENSE) or c reshaped (COST_AFFINE)
     double* eS[2];    // affine kinds: eS per slot (n_loc x n)
@@ -116,6 +121,7 @@ struct msdp_handle_s {
     std::vector<int> h_rowptr; std::vector<int> h_colind; std::vector<double> h_cval;
     // device-side sparse arrays owned by the handle
     int* d_rowptr = nullptr; int* d_colind = nullptr; double* d_cval = nullptr;
+    int* d_ellc = nullptr; double* d_ellv = nullptr;
     msdp_rtr_opts last_opts{};
     // tCG chunk graph (CH x {hess, upd1, upd2}) and its validity signature
     hipGraphExec_t chunk_exec = nullptr;          // the one to launch now (alias into chunk_execs)

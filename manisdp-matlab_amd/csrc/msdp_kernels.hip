@@ -15,14 +15,44 @@
 //   RTR        manopt7.0/manopt/solvers/trustregions/trustregions.m:405-409,540-729
 #include "msdp_device.h"
 #include <math.h>
+#include <cstdlib>
 
 // ------------------------------------------------------------------ sparse gather
 // acc[ch] += sum_k C[row,k] * X[k, cols of this lane]; the LPR lanes of a row each
 // fetch one (col,val) pair of the CSR row (coalesced) and broadcast it by shuffle.
-template <int LPR, int NCH>
+#define MSDP_ELL_MAXW 8
+template <int LPR, int NCH, bool ELL>
 __device__ __forceinline__ void spmm_row(const Dev& d, int row, int sub, const double* __restrict__ X,
                                          double2 (&acc)[NCH]) {
-    // All LPR lanes of a row read the same (col,val) pair: one L1 line per row serves the
+    if (ELL) {
+        // ELL slices ([w][row], padded with (row, 0.0)): no rowptr in the dependency chain, all (col,val)
+        // loads of a row are independent and coalesced across the rows of a wave, and all W neighbour-row
+        // gathers are in flight together: two dependent memory round trips instead of three.
+        int c[MSDP_ELL_MAXW];
+        double v[MSDP_ELL_MAXW];
+#pragma unroll
+        for (int w = 0; w < MSDP_ELL_MAXW; ++w) {
+            const bool ok = w < d.ellW;
+            c[w] = ok ? d.ellc[(int64_t)w * d.ell_stride + row] : row;
+            v[w] = ok ? d.ellv[(int64_t)w * d.ell_stride + row] : 0.0;
+        }
+#pragma unroll
+        for (int w = 0; w < MSDP_ELL_MAXW; ++w) {
+            if (w < d.ellW) {
+                const double* src = X + (int64_t)c[w] * d.ld + 2 * sub;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    if (2 * sub + ch * 2 * LPR < d.ld) {
+                        const double2 x = ld2(src + ch * 2 * LPR);
+                        acc[ch].x = fma(v[w], x.x, acc[ch].x);
+                        acc[ch].y = fma(v[w], x.y, acc[ch].y);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // CSR: all LPR lanes of a row read the same (col,val) pair: one L1 line per row serves the
     // whole group, the loads are independent of each other (no shuffle in the chain) and
     // the compiler can keep 4 neighbour rows in flight per lane.
     const int start = d.rowptr[row], end = d.rowptr[row + 1];
@@ -45,8 +75,8 @@ __device__ __forceinline__ void spmm_row(const Dev& d, int row, int sub, const d
 }
 
 // cost + Riemannian gradient at Y[slot] (gather source: d.full holds all rows of Y[slot]).
-template <int LPR, int NCH>
-__global__ __launch_bounds__(MSDP_BLOCK) void k_costgrad_sparse_obl(Dev d, int slot) {
+template <int LPR, int NCH, bool ELL>
+__device__ __forceinline__ void costgrad_sparse_obl_body(const Dev& d, int slot) {
     __shared__ double sh[3 * MSDP_WAVES];
     if (d.ctl->done) return;
     int lo, hi;
@@ -70,7 +100,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_costgrad_sparse_obl(Dev d, int s
                 const int col = 2 * sub + ch * 2 * LPR;
                 y[ch] = (col < d.ld) ? ld2(Yl + (int64_t)row * d.ld + col) : make_double2(0.0, 0.0);
             }
-            spmm_row<LPR, NCH>(d, row, sub, Xf, acc);
+            spmm_row<LPR, NCH, ELL>(d, row, sub, Xf, acc);
             double dot = 0.0;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) dot += acc[ch].x * y[ch].x + acc[ch].y * y[ch].y;
@@ -93,8 +123,8 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_costgrad_sparse_obl(Dev d, int s
 }
 
 // Hess-vec: Hmd = proj-fused (C*md - Y.*rowdot(Y, C*md) - md.*eG), partial <md, Hmd>.
-template <int LPR, int NCH>
-__global__ __launch_bounds__(MSDP_BLOCK) void k_hess_sparse_obl(Dev d) {
+template <int LPR, int NCH, bool ELL>
+__device__ __forceinline__ void hess_sparse_obl_body(const Dev& d) {
     __shared__ double sh[3 * MSDP_WAVES];
     if (!d.F[0].active) return;
     int lo, hi;
@@ -122,7 +152,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_hess_sparse_obl(Dev d) {
                 u[ch] = ok ? ld2(Ul + (int64_t)row * d.ld + col) : make_double2(0.0, 0.0);
             }
             const double eg = eG[row];
-            spmm_row<LPR, NCH>(d, row, sub, Uf, acc);
+            spmm_row<LPR, NCH, ELL>(d, row, sub, Uf, acc);
             double dot = 0.0;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) dot += acc[ch].x * y[ch].x + acc[ch].y * y[ch].y;
@@ -142,6 +172,15 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_hess_sparse_obl(Dev d) {
     }
     msdp_put_partial(d.P, P_DHD, pd, sh);
 }
+
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_costgrad_sparse_obl(Dev d, int slot) { costgrad_sparse_obl_body<LPR, NCH, false>(d, slot); }
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK, 8) void k_costgrad_ell_obl(Dev d, int slot) { costgrad_sparse_obl_body<LPR, NCH, true>(d, slot); }
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_hess_sparse_obl(Dev d) { hess_sparse_obl_body<LPR, NCH, false>(d); }
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK, 8) void k_hess_ell_obl(Dev d) { hess_sparse_obl_body<LPR, NCH, true>(d); }
 
 // Frame fields are read one by one into scalars and written field by field by the lead
 // thread: a by-value Frame copy is lowered through per-thread LDS/scratch by hipcc and
@@ -517,6 +556,9 @@ static inline void lpr_for(int ld, int& lpr, int& nch) {
     int half = ld / 2;
     lpr = 1;
     while (lpr < half && lpr < 64) lpr <<= 1;
+    static int shift = -1;
+    if (shift < 0) { const char* e = getenv("MSDP_LPR_SHIFT"); shift = e ? atoi(e) : 0; }
+    for (int s2 = 0; s2 < shift && lpr > 1; ++s2) lpr >>= 1;      // experiment: fewer lanes per row, more columns per lane
     nch = (half + lpr - 1) / lpr;
     if (nch < 1) nch = 1;
 }
@@ -536,9 +578,13 @@ static inline void lpr_for(int ld, int& lpr, int& nch) {
                 case 32: hipLaunchKernelGGL((KERNEL<32, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
                 default: hipLaunchKernelGGL((KERNEL<64, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
             }                                                                                        \
-        } else if (nch == 2) {                                                                       \
+        } else if (nch == 2 && lpr == 8) {                                                           \
+            hipLaunchKernelGGL((KERNEL<8, 2>), grid, block, 0, (h)->stream, __VA_ARGS__);            \
+        } else if (nch == 4 && lpr == 4) {                                                           \
+            hipLaunchKernelGGL((KERNEL<4, 4>), grid, block, 0, (h)->stream, __VA_ARGS__);            \
+        } else if (nch == 2 && lpr == 64) {                                                          \
             hipLaunchKernelGGL((KERNEL<64, 2>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
-        } else if (nch <= 4) {                                                                       \
+        } else if (nch <= 4 && lpr == 64) {                                                          \
             hipLaunchKernelGGL((KERNEL<64, 4>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
         } else {                                                                                     \
             msdp_set_error("factor width p = %d exceeds the supported maximum of 512", (h)->d.p);    \
@@ -558,7 +604,8 @@ int msdp_launch_costgrad(msdp_handle h, int slot) {
     int rc = msdp_allgather_rows(h, h->d.Y[slot]);
     if (rc) return rc;
     if (h->d.costkind == COST_SPARSE) {
-        DISPATCH_LPR(k_costgrad_sparse_obl, h, h->d, slot);
+        if (h->d.ellW > 0) DISPATCH_LPR(k_costgrad_ell_obl, h, h->d, slot);
+        else DISPATCH_LPR(k_costgrad_sparse_obl, h, h->d, slot);
     } else if (h->d.costkind == COST_DENSE) {
         rc = msdp_dense_costgrad(h, slot);
         if (rc) return rc;
@@ -574,7 +621,8 @@ int msdp_launch_hess(msdp_handle h) {
     int rc = msdp_allgather_rows(h, h->d.md);
     if (rc) return rc;
     if (h->d.costkind == COST_SPARSE) {
-        DISPATCH_LPR(k_hess_sparse_obl, h, h->d);
+        if (h->d.ellW > 0) DISPATCH_LPR(k_hess_ell_obl, h, h->d);
+        else DISPATCH_LPR(k_hess_sparse_obl, h, h->d);
     } else if (h->d.costkind == COST_DENSE) {
         rc = msdp_dense_hess(h);
         if (rc) return rc;
