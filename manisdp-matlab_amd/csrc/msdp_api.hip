@@ -102,7 +102,7 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
     const size_t rows = (size_t)rows_capacity(h);
     const size_t cnt = rows * (size_t)ldcap;
     double** vecs[] = {&d.Y[0], &d.Y[1], &d.Gr[0], &d.Gr[1], &d.eta[0], &d.eta[1], &d.Heta[0], &d.Heta[1],
-                       &d.r, &d.md, &d.Hmd, &d.W0, &d.W1};
+                       &d.r, &d.md, &d.md2, &d.Hmd, &d.W0, &d.W1};
     if (h->use_comm && d.full) dev_free(h, d.full);
     d.full = nullptr;
     for (double** v : vecs) {
@@ -533,8 +533,24 @@ static bool use_graphs() {
     return v != 0;
 }
 
+static bool fused_enabled(msdp_handle h) {
+    // Opt-in (MSDP_FUSED=1): the fused two-launch trip is correct (tests/test_gpu_onlyunitdiag.py runs it) but
+    // measured SLOWER on G81 p=32 (26.0 us vs 24.6 us per trip): recomputing the neighbours' directions costs
+    // 15 row loads + 5 group reductions per row, more than the launch and the 2 vectors of traffic it saves.
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MSDP_FUSED"); v = (e && atoi(e)) ? 1 : 0; }
+    return v && h->d.costkind == COST_SPARSE && h->d.manifold == MANI_OBLIQUE && !h->use_comm;
+}
+
 static int enqueue_trips(msdp_handle h, int cnt) {
     int rc;
+    if (h->d.fused) {
+        for (int t = 0; t < cnt; ++t) {
+            if ((rc = msdp_launch_hess_fused(h))) return rc;  // tCG.m:227-287 of the previous trip + :163
+            if ((rc = msdp_launch_upd1(h))) return rc;        // tCG.m:166-241
+        }
+        return 0;
+    }
     for (int t = 0; t < cnt; ++t) {
         if ((rc = msdp_launch_hess(h))) return rc;        // tCG.m:163
         if ((rc = msdp_launch_upd1(h))) return rc;        // tCG.m:166-241
@@ -654,6 +670,7 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
     int rc;
     fill_ctl(h, opts);
     h->last_opts = *opts;
+    h->d.fused = fused_enabled(h) ? 1 : 0;
     *h->h_status = 0;
     if ((rc = push_ctl(h))) return rc;
     int cur = h->h_ctl->cur;
@@ -917,6 +934,7 @@ extern "C" int msdp_bench_kernel(msdp_handle h, int32_t which, int32_t reps, dou
     o.maxinner = 0x7ffffff0; o.maxiter = 1;
     fill_ctl(h, &o);
     h->h_ctl->bench_mode = 1;
+    h->d.fused = 0;                      // the three classic kernels, one at a time
     if ((rc = push_ctl(h))) return rc;
     if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
     if ((rc = msdp_launch_rtr_begin(h))) return rc;
@@ -965,14 +983,13 @@ extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms) 
     o.maxinner = 0x7ffffff0; o.maxiter = 1;
     fill_ctl(h, &o);
     h->h_ctl->bench_mode = 1;
+    h->d.fused = fused_enabled(h) ? 1 : 0;
     if ((rc = push_ctl(h))) return rc;
     if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
     if ((rc = msdp_launch_rtr_begin(h))) return rc;
     h->h_ctl->done = 0;
     if ((rc = msdp_launch_tcg_init(h))) return rc;
-    for (int i = 0; i < 2; ++i) {
-        if ((rc = msdp_launch_hess(h)) || (rc = msdp_launch_upd1(h)) || (rc = msdp_launch_upd2(h))) return rc;
-    }
+    if ((rc = enqueue_trips(h, 2))) return rc;
     const int CH = tcg_chunk();
     const bool graph = use_graphs() && !h->use_comm;
     if (graph && (rc = ensure_chunk_graph(h, CH))) return rc;

@@ -45,6 +45,8 @@ struct Ctl {
 struct Frame {
     double z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha, beta;
     int active, j, stop, eta_idx;
+    int md_idx;       // which of md / md2 holds the current direction (fused trips ping-pong it)
+    int fresh;        // 1 right after k_tcg_init: the direction is the gradient, no update step yet
 };
 
 // Partial-sum array ids
@@ -73,6 +75,8 @@ struct Dev {
     double* Heta[2];
     double* r;
     double* md;       // mdelta, local rows
+    double* md2;      // second direction buffer (fused two-launch trips)
+    int fused;        // 1: trips are {k_hess_fused, k_tcg_upd1}; the final frame is F[1]
     double* Hmd;
     double* full;     // gather source of n x ld (== local buffer when nranks == 1)
     double* W0;       // scratch n_loc x ld
@@ -135,7 +139,8 @@ struct msdp_handle_s {
 
 // --- launchers implemented in the .hip units (all asynchronous on h->stream) ---
 int msdp_launch_costgrad(msdp_handle h, int slot);            // Y[slot] -> Gr[slot], eG[slot], P_F, P_GG
-int msdp_launch_hess(msdp_handle h);                          // md -> Hmd, P_DHD (oblique sparse/dense)
+int msdp_launch_hess(msdp_handle h);
+int msdp_launch_hess_fused(msdp_handle h);                          // md -> Hmd, P_DHD (oblique sparse/dense)
 int msdp_launch_tcg_init(msdp_handle h);
 int msdp_launch_upd1(msdp_handle h);
 int msdp_launch_upd2(msdp_handle h);

@@ -145,3 +145,24 @@ def test_solver_G1_matches_oracle(lib):
     Y, obj11, d11 = solvers.ManiSDP_onlyunitdiag(problems.maxcut_cost_matrix(golden_path("G11.txt.gz")), {}, verbose=False)
     known = json.load(open(golden_path("known_answers.json")))
     assert abs(-obj11 - known["maxG11"]) < 1e-6 * known["maxG11"]
+
+
+def test_fused_trip_matches_classic(lib, monkeypatch):
+    """MSDP_FUSED=1 (two launches per tCG trip: the direction update is recomputed inside the Hess-vec kernel)
+    must reproduce the classic three-launch trip bit for bit: same arithmetic in the same order."""
+    import subprocess, sys, os, json
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r);"
+        "from manisdp_matlab_amd import _lib, problems;"
+        "C = problems.toroidal_grid_maxcut(30, 40, seed=2); n = C.shape[0]; rng = np.random.default_rng(1);"
+        "Y = rng.standard_normal((n, 10)); Y /= np.linalg.norm(Y, axis=1, keepdims=True);"
+        "h = _lib.Handle.onlyunitdiag(C); h.set_point(Y);"
+        "st = h.rtr(_lib.default_opts(maxiter=12, maxinner=40, tolgradnorm=1e-9));"
+        "print(json.dumps([st.cost, st.gradnorm, st.hessvecs, st.accepted, st.rejected, float(np.sum(h.get_point()))]))"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for fused in ("0", "1"):
+        env = dict(os.environ, MSDP_FUSED=fused)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True)
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
