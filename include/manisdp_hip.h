@@ -103,6 +103,15 @@ int msdp_create_onlyunitdiag_csc(int64_t n, const int64_t* jc, const int64_t* ir
 int msdp_create_onlyunitdiag_dense(int64_t n, const double* C, int32_t pcap,
                                    msdp_handle* out);
 
+/* Pre-sharded synthetic dense problem (BASELINE config 5: n = 100000, p = 64 over 8 GPUs; the full C would be
+ * 80 GB): rank `rank` of `nranks` fills ITS rows of a dense symmetric C on the device from a counter-based
+ * generator; msdp_synthetic_dense_entry is the same generator on the host (parity tests). */
+int msdp_create_onlyunitdiag_dense_synthetic(int64_t n, uint64_t seed, int32_t nranks, int32_t rank,
+                                             int32_t pcap, msdp_handle* out);
+double msdp_synthetic_dense_entry(int64_t n, int64_t i, int64_t j, uint64_t seed);
+/* Test-only: stand in for the all-gather on a communicator-free shard (one process = rank r of N). */
+int msdp_debug_set_full_rows(msdp_handle h, const double* rows_host);
+
 /* min <C,X>, A(X) = b, diag X = 1 (kind = MSDP_KIND_UNITDIAG;
  * ManiSDP_unitdiag.m:152-171) or tr X = 1 (kind = MSDP_KIND_UNITTRACE;
  * ManiSDP_unittrace.m:156-177).  At is n^2 x m CSC (column k = vec(A_k)),

@@ -51,6 +51,10 @@ SIGNATURES = {
     "msdp_device_count": (C.c_int, [_P(C.c_int32)]),
     "msdp_create_onlyunitdiag_csc": (C.c_int, [C.c_int64, _i64p, _i64p, _dp, C.c_int32, _P(C.c_void_p)]),
     "msdp_create_onlyunitdiag_dense": (C.c_int, [C.c_int64, _dp, C.c_int32, _P(C.c_void_p)]),
+    "msdp_create_onlyunitdiag_dense_synthetic": (C.c_int, [C.c_int64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32,
+                                                          _P(C.c_void_p)]),
+    "msdp_synthetic_dense_entry": (C.c_double, [C.c_int64, C.c_int64, C.c_int64, C.c_uint64]),
+    "msdp_debug_set_full_rows": (C.c_int, [C.c_void_p, _dp]),
     "msdp_create_affine": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp,
                                      C.c_int32, _P(C.c_void_p)]),
     "msdp_destroy": (C.c_int, [C.c_void_p]),
@@ -158,6 +162,18 @@ class Handle:
             Cd = np.ascontiguousarray(Cmat, dtype=np.float64)
             _check(lib.msdp_create_onlyunitdiag_dense(n, _dptr(Cd), pcap, C.byref(out)))
         return cls(out.value, KIND_ONLYUNITDIAG, n)
+
+    @classmethod
+    def dense_synthetic(cls, n, seed, nranks=1, rank=0, pcap=32):
+        """Pre-sharded synthetic dense-C problem (rank `rank` of `nranks` holds its rows only)."""
+        lib = load()
+        out = C.c_void_p()
+        _check(lib.msdp_create_onlyunitdiag_dense_synthetic(n, seed, nranks, rank, pcap, C.byref(out)))
+        return cls(out.value, KIND_ONLYUNITDIAG, n)
+
+    def debug_set_full_rows(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        _check(self._lib.msdp_debug_set_full_rows(self._h, _dptr(rows)))
 
     @classmethod
     def affine(cls, kind, At, b, c, n, pcap=32):

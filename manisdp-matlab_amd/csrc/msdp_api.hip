@@ -36,6 +36,7 @@ int msdp_affine_set_multipliers(msdp_handle h, const double* y, double sigma);
 int msdp_affine_linesearch_cost(msdp_handle h, const double* Yt, double* val);
 int msdp_dense_setup(msdp_handle h, const double* C);
 int msdp_dense_reserve(msdp_handle h, int nmat);
+int msdp_dense_setup_synthetic(msdp_handle h, uint64_t seed);
 void msdp_affine_release(msdp_handle h);
 int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam, double* V, double* lmax, int* iters);
 
@@ -103,7 +104,8 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
     const size_t cnt = rows * (size_t)ldcap;
     double** vecs[] = {&d.Y[0], &d.Y[1], &d.Gr[0], &d.Gr[1], &d.eta[0], &d.eta[1], &d.Heta[0], &d.Heta[1],
                        &d.r, &d.md, &d.md2, &d.Hmd, &d.W0, &d.W1};
-    if (h->use_comm && d.full) dev_free(h, d.full);
+    if (h->full_buf) dev_free(h, h->full_buf);
+    h->full_buf = nullptr;
     d.full = nullptr;
     for (double** v : vecs) {
         if (*v) dev_free(h, *v);
@@ -112,10 +114,11 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(*v, 0, cnt * sizeof(double), h->stream));
     }
-    if (h->use_comm) {
-        int rc = dev_alloc<double>(h, &d.full, cnt * (size_t)h->nranks);
+    if (h->use_comm || h->nranks > 1) {
+        int rc = dev_alloc<double>(h, &h->full_buf, cnt * (size_t)h->nranks);
         if (rc) return rc;
-        HIPCHK(hipMemsetAsync(d.full, 0, cnt * h->nranks * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(h->full_buf, 0, cnt * h->nranks * sizeof(double), h->stream));
+        d.full = h->full_buf;
     }
     h->pcap = pcap;
     h->ldcap = ldcap;
@@ -285,6 +288,47 @@ extern "C" int msdp_create_onlyunitdiag_dense(int64_t n, const double* C, int32_
     return 0;
 }
 
+extern "C" int msdp_create_onlyunitdiag_dense_synthetic(int64_t n, uint64_t seed, int32_t nranks, int32_t rank,
+                                                       int32_t pcap, msdp_handle* out) {
+    if (nranks < 1 || rank < 0 || rank >= nranks) { msdp_set_error("bad shard (%d of %d)", rank, nranks); return MSDP_EINVAL; }
+    msdp_handle h = nullptr;
+    int rc = new_handle(MSDP_KIND_ONLYUNITDIAG, n, &h);
+    if (rc) return rc;
+    h->d.costkind = COST_DENSE;
+    h->nranks = nranks;
+    h->rank = rank;
+    h->presharded = true;
+    const int cap = rows_capacity(h);
+    h->d.row0 = std::min<int64_t>(n, (int64_t)rank * cap);
+    h->d.n_loc = (int)std::min<int64_t>(cap, n - h->d.row0);
+    if ((rc = alloc_common(h)) || (rc = msdp_dense_setup_synthetic(h, seed)) ||
+        (rc = msdp_alloc_vectors(h, pcap > 0 ? pcap : 32))) {
+        msdp_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+// Test-only: fill the gather buffer of a pre-sharded handle that has NO communicator (a single process
+// standing in for rank r of N) with all n rows of a host matrix, so that the non-square shard kernels can be
+// checked against a full-size reference on one GPU.  With a communicator the all-gather does this.
+extern "C" int msdp_debug_set_full_rows(msdp_handle h, const double* rows_host) {
+    CHECK_H(h);
+    if (!h->presharded || h->use_comm || !h->d.p) { msdp_set_error("debug_set_full_rows: pre-sharded, communicator-free handle with a point"); return MSDP_ESTATE; }
+    Dev& d = h->d;
+    const size_t cnt = (size_t)d.n * d.p;
+    double* stage = nullptr;
+    if (hipMalloc((void**)&stage, cnt * sizeof(double)) != hipSuccess) { msdp_set_error("staging alloc failed"); return MSDP_ENOMEM; }
+    hipError_t e = hipMemcpyAsync(stage, rows_host, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    int rc = 0;
+    if (e != hipSuccess) { msdp_set_error("H2D failed"); rc = MSDP_EHIP; }
+    if (!rc) rc = msdp_k_pack(h, stage, h->full_buf, d.n, d.p, d.ld, false);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(stage);
+    return rc;
+}
+
 extern "C" int msdp_create_affine(int32_t kind, int64_t n, int64_t m, const int64_t* at_jc, const int64_t* at_ir,
                                   const double* at_pr, const double* b, const double* c, int32_t pcap,
                                   msdp_handle* out) {
@@ -390,7 +434,7 @@ extern "C" int msdp_set_point(msdp_handle h, int32_t p, const double* Y) {
     }
     d.p = p;
     d.ld = ((p + 1) / 2) * 2;
-    if (!h->use_comm) d.full = d.md;       // overwritten per launch by allgather_rows
+    if (!h->use_comm && h->nranks == 1) d.full = d.md;   // overwritten per launch by allgather_rows
     choose_grid(h);
     if (d.costkind != COST_SPARSE) {
         int rc = msdp_dense_reserve(h, d.costkind == COST_AFFINE ? 2 : 1);
@@ -436,12 +480,20 @@ int msdp_allreduce_partials(msdp_handle h, int first, int count) {
 // one message per xGMI link).  With one rank the local buffer is used directly.
 int msdp_allgather_rows(msdp_handle h, const double* local_rows) {
     if (!h->use_comm) {
+        if (h->nranks > 1) {        // a lone process standing in for one shard (tests / per-shard measurement)
+            const size_t cnt1 = (size_t)rows_capacity(h) * h->d.ld;
+            HIPCHK(hipMemcpyAsync(h->full_buf + (size_t)h->rank * cnt1, local_rows, cnt1 * sizeof(double),
+                                  hipMemcpyDeviceToDevice, h->stream));
+            h->d.full = h->full_buf;
+            return 0;
+        }
         h->d.full = const_cast<double*>(local_rows);
         return 0;
     }
     const size_t cnt = (size_t)rows_capacity(h) * h->d.ld;
     // slabs are packed with the CURRENT ld so the full buffer is n_pad x ld row-major
-    ncclResult_t r = ncclAllGather(local_rows, h->d.full, cnt, ncclDouble, (ncclComm_t)h->comm, h->stream);
+    h->d.full = h->full_buf;
+    ncclResult_t r = ncclAllGather(local_rows, h->full_buf, cnt, ncclDouble, (ncclComm_t)h->comm, h->stream);
     if (r != ncclSuccess) { msdp_set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return MSDP_ECOMM; }
     return 0;
 }
@@ -460,6 +512,7 @@ extern "C" int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const
     CHECK_H(h);
     if (nranks < 1 || rank < 0 || rank >= nranks || !id128) { msdp_set_error("bad comm arguments"); return MSDP_EINVAL; }
     if (h->have_point) { msdp_set_error("comm_init must precede set_point"); return MSDP_ESTATE; }
+    if (h->presharded && (nranks != h->nranks || rank != h->rank)) { msdp_set_error("comm_init: shard was created as rank %d of %d", h->rank, h->nranks); return MSDP_EINVAL; }
     if (h->d.costkind == COST_AFFINE && nranks > 1) {
         msdp_set_error("row sharding of the affine (A-operator) kinds is not implemented yet");
         return MSDP_EUNSUPPORTED;
@@ -481,8 +534,8 @@ extern "C" int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const
     int rc = alloc_common(h);
     if (rc) return rc;
     if (h->d.costkind == COST_SPARSE && (rc = upload_sparse_rows(h))) return rc;
-    if (h->d.costkind == COST_DENSE) {
-        msdp_set_error("dense C must be created per shard (msdp_create_onlyunitdiag_dense_shard)");
+    if (h->d.costkind == COST_DENSE && !h->presharded) {
+        msdp_set_error("dense C must be created per shard (msdp_create_onlyunitdiag_dense_synthetic)");
         return MSDP_EUNSUPPORTED;
     }
     return msdp_alloc_vectors(h, h->pcap);

@@ -121,6 +121,8 @@ struct msdp_handle_s {
     // host copies needed for re-allocation / sharding
     int nranks = 1, rank = 0;
     void* comm = nullptr;          // ncclComm_t
+    bool presharded = false;       // created per shard (dense synthetic): row0/n_loc fixed at creation
+    double* full_buf = nullptr;    // gather buffer (nranks x cap rows) when the rows are sharded
     bool use_comm = false;         // route the exchanges through RCCL (set by msdp_comm_init, any nranks)
     std::vector<int> h_rowptr; std::vector<int> h_colind; std::vector<double> h_cval;
     // device-side sparse arrays owned by the handle

@@ -21,6 +21,7 @@
 // Kernel 2 (row-tiled epilogue): sums the slabs and applies the fused projection.
 #include "msdp_device.h"
 #include <math.h>
+#include <cstdlib>
 #include <cstring>
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -98,6 +99,136 @@ __global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial(DenseOp op, 
         }
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
+    double* out = op.slab + (int64_t)blockIdx.y * op.slab_stride;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = 16 * t + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + g + 4 * r;
+            if (row < op.n_loc && col < ld) out[(int64_t)row * ld + col] = acc[t][r];
+        }
+    }
+}
+
+// Software-pipelined variant: KT2 = 64 k per LDS tile, two LDS buffers, one barrier per tile, and TWO
+// statically named register sets (A fragments + staged panel rows) used alternately by a 2x unrolled tile
+// loop: hipcc can then count the outstanding loads exactly (s_waitcnt vmcnt(N), not vmcnt(0)), so the loads
+// of tile t+1 stay in flight under the 16*NT MFMAs of tile t.  The B operands of one k-quad (NT ds_read_b64)
+// are all requested before the first MFMA that needs them; the LDS tile is zero-padded to 16*NT columns so
+// the inner loop has no column predicate.
+#define DENSE_KT2 64
+template <int NT>
+struct DenseRegs {
+    double2 a[DENSE_KT2 / 16][2];
+    double sc[DENSE_KT2 / 16];
+    double2 stg[2 * NT];
+};
+
+template <int NT>
+__global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial2(DenseOp op, const int* active_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // 2 x DENSE_KT2 x ldl
+    if (active_flag && !*active_flag) return;
+    constexpr int NTHR = DENSE_WAVES * 64;
+    constexpr int SS = DENSE_KT2 / 16;
+    constexpr int MAXS = 2 * NT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int row0 = (blockIdx.x * DENSE_WAVES + wave) * 16;
+    const int arow = min(row0 + i, op.n_loc - 1);
+    const int64_t Ktot = (int64_t)op.nmat * op.nS;
+    const int64_t kbeg = (int64_t)blockIdx.y * op.kslice;
+    int64_t kend = kbeg + op.kslice;
+    if (kend > Ktot) kend = Ktot;
+    const int ld = op.ld, ldl = op.ldl, half = ld >> 1;
+    const int tile_elems = DENSE_KT2 * half;
+    // zero both LDS tiles once: pad columns [ld, ldl) are never written again
+    for (int e = threadIdx.x; e < 2 * DENSE_KT2 * ldl; e += NTHR) lds[e] = 0.0;
+    // per-thread staging slots (independent of the tile): panel row r, global offset r*ld + 2*c2, LDS offset
+    int srow[MAXS], sg[MAXS], sl[MAXS];
+#pragma unroll
+    for (int q = 0; q < MAXS; ++q) {
+        const int e = threadIdx.x + q * NTHR;
+        const int r = (e < tile_elems) ? e / half : -1;
+        const int c2 = (e < tile_elems) ? e - r * half : 0;
+        srow[q] = r; sg[q] = r * ld + 2 * c2; sl[q] = r * ldl + 2 * c2;
+    }
+    double4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const double* arow_p[2] = {op.M[0] + (int64_t)arow * op.nS + 4 * g, op.M[1] + (int64_t)arow * op.nS + 4 * g};
+
+    // Branch-free: every call issues exactly 2*SS + MAXS loads (out-of-range pieces read a valid dummy
+    // address and are zeroed by a select), so hipcc can count the loads in flight across the loop.
+    auto load_tile = [&](int64_t k0, DenseRegs<NT>& R) {
+#pragma unroll
+        for (int s = 0; s < SS; ++s) {
+            const int64_t ks = k0 + 16 * s;
+            const bool ok = ks < kend;
+            const int64_t kc = ok ? ks : kbeg;
+            const int m = (kc >= op.nS) ? 1 : 0;
+            const double* ap = arow_p[m] + (kc - (int64_t)m * op.nS);
+            R.a[s][0] = ld2(ap); R.a[s][1] = ld2(ap + 2);
+            R.sc[s] = ok ? op.scale[m] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < MAXS; ++q) {
+            const int64_t kk = k0 + (srow[q] >= 0 ? srow[q] : 0);
+            const bool inr = srow[q] >= 0 && kk < kend;
+            const int64_t kc = inr ? kk : kbeg;
+            const int m = (kc >= op.nS) ? 1 : 0;
+            const int64_t kl = kc - (int64_t)m * op.nS;
+            const bool ok = inr && kl < op.n;
+            const double2 v = ld2(op.X[m] + (ok ? kl * ld + (sg[q] - srow[q] * ld) : 0));
+            R.stg[q] = ok ? v : make_double2(0.0, 0.0);
+        }
+    };
+    auto store_tile = [&](double* buf, const DenseRegs<NT>& R) {
+#pragma unroll
+        for (int q = 0; q < MAXS; ++q)
+            if (srow[q] >= 0) *reinterpret_cast<double2*>(&buf[sl[q]]) = R.stg[q];
+    };
+    auto compute_tile = [&](const double* bt, const DenseRegs<NT>& R) {
+#pragma unroll
+        for (int s = 0; s < SS; ++s) {
+            const double sc = R.sc[s];
+            const double av[4] = {R.a[s][0].x * sc, R.a[s][0].y * sc, R.a[s][1].x * sc, R.a[s][1].y * sc};
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const double* brow = &bt[(16 * s + 4 * g + t4) * ldl + i];
+                double bv[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bv[t] = brow[16 * t];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t4], bv[t], acc[t], 0, 0, 0);
+            }
+        }
+    };
+
+    double* buf0 = lds;
+    double* buf1 = lds + DENSE_KT2 * ldl;
+    DenseRegs<NT> R0, R1;
+    __syncthreads();                                           // zero fill done
+    load_tile(kbeg, R0);
+    store_tile(buf0, R0);
+    for (int64_t k0 = kbeg; k0 < kend; k0 += 2 * DENSE_KT2) {
+        // ---- even tile: data in (buf0, R0); prefetch the odd tile into R1
+        __syncthreads();
+        const int64_t k1 = k0 + DENSE_KT2;
+        const bool has1 = k1 < kend;
+        load_tile(k1, R1);
+        compute_tile(buf0, R0);
+        if (!has1) break;
+        store_tile(buf1, R1);
+        // ---- odd tile: data in (buf1, R1); prefetch the next even tile into R0
+        __syncthreads();
+        const int64_t k2 = k1 + DENSE_KT2;
+        const bool has2 = k2 < kend;
+        load_tile(k2, R0);
+        compute_tile(buf1, R1);
+        if (!has2) break;
+        store_tile(buf0, R0);
+    }
     double* out = op.slab + (int64_t)blockIdx.y * op.slab_stride;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -242,13 +373,15 @@ static void dense_plan(msdp_handle h, int nmat, int* row_blocks_out, int* SK_out
     const int nS = msdp_dense_nS(d.n);
     const int row_blocks = (d.n_loc + DENSE_WAVES * 16 - 1) / (DENSE_WAVES * 16);
     const int64_t Ktot = (int64_t)nmat * nS;
-    int SK = (1024 + row_blocks - 1) / row_blocks;      // aim at ~4 workgroups per CU
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("MSDP_DENSE_BLOCKS"); target = e ? atoi(e) : 1024; if (target < 1) target = 1024; }
+    int SK = (target + row_blocks - 1) / row_blocks;     // aim at ~target/256 workgroups per CU
     const int maxSK = (int)((Ktot + 4 * DENSE_KT - 1) / (4 * DENSE_KT));
     if (SK > maxSK) SK = maxSK;
     if (SK > 32) SK = 32;
     if (SK < 1) SK = 1;
     int64_t kslice = (Ktot + SK - 1) / SK;
-    kslice = ((kslice + DENSE_KT - 1) / DENSE_KT) * DENSE_KT;
+    kslice = ((kslice + 63) / 64) * 64;
     SK = (int)((Ktot + kslice - 1) / kslice);
     *row_blocks_out = row_blocks; *SK_out = SK; *kslice_out = kslice;
 }
@@ -275,7 +408,7 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
     op.nS = msdp_dense_nS(d.n);
     op.n_loc = d.n_loc;
     op.ld = d.ld;
-    int ldl = d.ld;
+    int ldl = ((d.ld + 15) / 16) * 16;                   // zero-padded to 16*NT columns (no column predicate)
     while ((ldl & 7) != 4) ldl += 2;                    // ldl = 4 (mod 8): conflict-free B reads
     op.ldl = ldl;
     int SK; int64_t kslice; int row_blocks;
@@ -290,16 +423,32 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
     const int NT = (d.ld + 15) / 16;
     if (NT > 8) { msdp_set_error("dense path supports p <= 128 (got ld = %d)", d.ld); return MSDP_EUNSUPPORTED; }
     dim3 grid(row_blocks, SK), block(DENSE_WAVES * 64);
-    const size_t shmem = (size_t)DENSE_KT * ldl * sizeof(double);
-    switch (NT) {
-        case 1: hipLaunchKernelGGL((k_dense_partial<1>), grid, block, shmem, h->stream, op, active_flag); break;
-        case 2: hipLaunchKernelGGL((k_dense_partial<2>), grid, block, shmem, h->stream, op, active_flag); break;
-        case 3: hipLaunchKernelGGL((k_dense_partial<3>), grid, block, shmem, h->stream, op, active_flag); break;
-        case 4: hipLaunchKernelGGL((k_dense_partial<4>), grid, block, shmem, h->stream, op, active_flag); break;
-        case 5: hipLaunchKernelGGL((k_dense_partial<5>), grid, block, shmem, h->stream, op, active_flag); break;
-        case 6: hipLaunchKernelGGL((k_dense_partial<6>), grid, block, shmem, h->stream, op, active_flag); break;
-        case 7: hipLaunchKernelGGL((k_dense_partial<7>), grid, block, shmem, h->stream, op, active_flag); break;
-        default: hipLaunchKernelGGL((k_dense_partial<8>), grid, block, shmem, h->stream, op, active_flag); break;
+    static int v1 = -1;
+    if (v1 < 0) { const char* e = getenv("MSDP_DENSE_V1"); v1 = (e && atoi(e)) ? 1 : 0; }
+    if (v1) {
+        const size_t shmem = (size_t)DENSE_KT * ldl * sizeof(double);
+        switch (NT) {
+            case 1: hipLaunchKernelGGL((k_dense_partial<1>), grid, block, shmem, h->stream, op, active_flag); break;
+            case 2: hipLaunchKernelGGL((k_dense_partial<2>), grid, block, shmem, h->stream, op, active_flag); break;
+            case 3: hipLaunchKernelGGL((k_dense_partial<3>), grid, block, shmem, h->stream, op, active_flag); break;
+            case 4: hipLaunchKernelGGL((k_dense_partial<4>), grid, block, shmem, h->stream, op, active_flag); break;
+            case 5: hipLaunchKernelGGL((k_dense_partial<5>), grid, block, shmem, h->stream, op, active_flag); break;
+            case 6: hipLaunchKernelGGL((k_dense_partial<6>), grid, block, shmem, h->stream, op, active_flag); break;
+            case 7: hipLaunchKernelGGL((k_dense_partial<7>), grid, block, shmem, h->stream, op, active_flag); break;
+            default: hipLaunchKernelGGL((k_dense_partial<8>), grid, block, shmem, h->stream, op, active_flag); break;
+        }
+    } else {
+        const size_t shmem = (size_t)2 * DENSE_KT2 * ldl * sizeof(double);
+        switch (NT) {
+            case 1: hipLaunchKernelGGL((k_dense_partial2<1>), grid, block, shmem, h->stream, op, active_flag); break;
+            case 2: hipLaunchKernelGGL((k_dense_partial2<2>), grid, block, shmem, h->stream, op, active_flag); break;
+            case 3: hipLaunchKernelGGL((k_dense_partial2<3>), grid, block, shmem, h->stream, op, active_flag); break;
+            case 4: hipLaunchKernelGGL((k_dense_partial2<4>), grid, block, shmem, h->stream, op, active_flag); break;
+            case 5: hipLaunchKernelGGL((k_dense_partial2<5>), grid, block, shmem, h->stream, op, active_flag); break;
+            case 6: hipLaunchKernelGGL((k_dense_partial2<6>), grid, block, shmem, h->stream, op, active_flag); break;
+            case 7: hipLaunchKernelGGL((k_dense_partial2<7>), grid, block, shmem, h->stream, op, active_flag); break;
+            default: hipLaunchKernelGGL((k_dense_partial2<8>), grid, block, shmem, h->stream, op, active_flag); break;
+        }
     }
     HIPCHK(hipGetLastError());
     *slab_out = h->slab;
@@ -342,6 +491,44 @@ int msdp_dense_setup(msdp_handle h, const double* C) {
     HIPCHK(hipMemset(d.Cd, 0, (size_t)d.n * nS * sizeof(double)));
     HIPCHK(hipMemcpy2D(d.Cd, (size_t)nS * sizeof(double), C, (size_t)d.n * sizeof(double), (size_t)d.n * sizeof(double),
                        d.n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Counter-based generator of a dense symmetric test matrix: entry (i,j) depends only on (min,max,seed), so
+// every rank can fill ITS rows on the device without any host array (the full
+// n = 100000 matrix would be 80 GB).  Uniform in (-1,1)/sqrt(n).
+__host__ __device__ inline double msdp_syn_entry(int64_t n, int64_t i, int64_t j, uint64_t seed) {
+    const int64_t a = i < j ? i : j, b = i < j ? j : i;
+    uint64_t x = (uint64_t)(a * n + b) + seed * 0x9E3779B97F4A7C15ULL;
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    x = x ^ (x >> 31);
+    const double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);      // [0,1)
+    return (2.0 * u - 1.0) / sqrt((double)n);
+}
+extern "C" double msdp_synthetic_dense_entry(int64_t n, int64_t i, int64_t j, uint64_t seed) {
+    return msdp_syn_entry(n, i, j, seed);
+}
+__global__ void k_fill_dense_sym(double* __restrict__ Cd, int n, int nS, int row0, int n_loc, uint64_t seed) {
+    const int64_t tot = (int64_t)n_loc * nS;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t il = e / nS, j = e - il * nS;
+        Cd[e] = (j < n) ? msdp_syn_entry(n, row0 + il, j, seed) : 0.0;
+    }
+}
+int msdp_dense_setup_synthetic(msdp_handle h, uint64_t seed) {
+    Dev& d = h->d;
+    const int nS = msdp_dense_nS(d.n);
+    void* p = nullptr;
+    const size_t rows = (size_t)((d.n + h->nranks - 1) / h->nranks);
+    int rc = msdp_dev_alloc_bytes(h, &p, rows * nS * sizeof(double));
+    if (rc) return rc;
+    d.Cd = (double*)p;
+    HIPCHK(hipMemsetAsync(d.Cd, 0, rows * nS * sizeof(double), h->stream));
+    hipLaunchKernelGGL(k_fill_dense_sym, dim3(4096), dim3(256), 0, h->stream, d.Cd, d.n, nS, d.row0, d.n_loc, seed);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
 

@@ -67,3 +67,36 @@ def test_dense_solver_known_answer(lib):
     Y, obj, data = solvers.ManiSDP_onlyunitdiag(C, {}, verbose=False)
     assert data["dinf"] < 1e-8
     assert abs(-obj - known["mcp124-1"]) < 1e-6 * abs(known["mcp124-1"])
+
+
+def test_synthetic_dense_shards_match_full_matrix(lib):
+    """Config-5 style pre-sharded dense C: every shard (rank r of 3, standing alone on one GPU with the gather
+    buffer filled by the test) reproduces its rows of cost state, gradient and Hess-vec of the full problem."""
+    from oracle import manisdp_ref as R
+    n, p, seed, N = 301, 6, 7, 3
+    L = lib.load()
+    C = np.array([[L.msdp_synthetic_dense_entry(n, i, j, seed) for j in range(n)] for i in range(n)])
+    assert np.array_equal(C, C.T)
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    prob = R._OnlyUnitDiagProblem(C, n, p)
+    f_ref = prob.cost(Y); G_ref = prob.grad(Y); H_ref = prob.hess(Y, U)
+    # unsharded synthetic handle == dense handle built from the host copy of the same matrix
+    h = lib.Handle.dense_synthetic(n, seed)
+    h.set_point(Y)
+    assert _relerr(h.rgrad(), G_ref) < 1e-12 and _relerr(h.hessvec(U), H_ref) < 1e-12
+    h.close()
+    f_sum = 0.0
+    for r in range(N):
+        h = lib.Handle.dense_synthetic(n, seed, nranks=N, rank=r)
+        r0, r1 = h.local_rows()
+        h.set_point(Y)
+        h.debug_set_full_rows(Y)
+        G = h.rgrad()
+        assert _relerr(G[r0:r1], G_ref[r0:r1]) < 1e-12
+        assert _relerr(h.get_z()[r0:r1], np.sum((C @ Y) * Y, axis=1)[r0:r1]) < 1e-12
+        h.debug_set_full_rows(U)
+        H = h.hessvec(U)
+        assert _relerr(H[r0:r1], H_ref[r0:r1]) < 1e-12
+        h.close()
