@@ -15,6 +15,7 @@
 // The constraint matrices A_k and C are symmetric (SeDuMi data), so row-major == column-major.
 #include "msdp_device.h"
 #include <math.h>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -27,6 +28,13 @@ struct AffineDev {
     int n, nS, p, ld;
     int64_t m;
     const int* cjc;        // m+1 column pointers (CSC by constraint)
+    // long columns are cut into work items of <= SDDMM_CHUNK nonzeros so that one constraint (e.g. the trace
+    // row of a theta problem: n nonzeros) cannot serialise a whole launch on a single lane group
+    int64_t nitems;
+    const int* it0;        // first nonzero of item
+    const int* it1;        // one past the last nonzero of item
+    const int* kit;        // m+1: items of constraint k are kit[k] .. kit[k+1]-1
+    double* ival;          // partial value per item
     const int* ci;         // row i of each nonzero
     const int* cj;         // col j of each nonzero
     const double* cv;
@@ -39,22 +47,18 @@ struct AffineDev {
     double* Axb[2];        // per slot
 };
 
-// w_k = sum_{(i,j) in A_k} val * <Ya_i, Yb_j>; mode 0: store w.  mode 1 (cost): Axb = w - b - y/sigma into
-// axb_out, partial sum of Axb^2 -> P_AUX.
+#define SDDMM_CHUNK 64
+// item value = sum over the item's nonzeros (i,j,val) of val * <Ya_i, Yb_j>   (one LPR-lane group per item)
 template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm(AffineDev a, const double* __restrict__ Ya,
-                                                    const double* __restrict__ Yb, int mode, double* axb_out,
-                                                    double sigma, double* P, int G, const int* skip_flag,
-                                                    int skip_when) {
-    __shared__ double sh[3 * MSDP_WAVES];
+                                                    const double* __restrict__ Yb, const int* skip_flag, int skip_when) {
     if (skip_flag && *skip_flag == skip_when) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int CPW = 64 / LPR;                       // constraints per wave
+    constexpr int CPW = 64 / LPR;                       // items per wave
     const int sub = lane & (LPR - 1), csub = lane / LPR;
-    double pss = 0.0;
     const int64_t stride = (int64_t)gridDim.x * MSDP_WAVES * CPW;
-    for (int64_t k = ((int64_t)blockIdx.x * MSDP_WAVES + wave) * CPW + csub; k < a.m; k += stride) {
-        const int s0 = a.cjc[k], s1 = a.cjc[k + 1];
+    for (int64_t it = ((int64_t)blockIdx.x * MSDP_WAVES + wave) * CPW + csub; it < a.nitems; it += stride) {
+        const int s0 = a.it0[it], s1 = a.it1[it];
         double acc = 0.0;
         for (int t = s0; t < s1; ++t) {
             const int i = a.ci[t], j = a.cj[t];
@@ -72,14 +76,24 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm(AffineDev a, const double*
             acc = fma(v, dd, acc);
         }
         acc = msdp_group_sum<LPR>(acc);
-        if (sub == 0) {
-            if (mode == 0) a.w[k] = acc;
-            else {
-                const double r = acc - a.b[k] - a.y[k] / sigma;
-                a.w[k] = acc;
-                axb_out[k] = r;
-                pss += r * r;
-            }
+        if (sub == 0) a.ival[it] = acc;
+    }
+}
+// w_k = sum of the items of constraint k (fixed order).  mode 0: store w.  mode 1 (cost): also
+// Axb = w - b - y/sigma into axb_out and the partial sums of Axb^2 -> P_AUX.
+__global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm_finish(AffineDev a, int mode, double* axb_out, double sigma, double* P,
+                                                           const int* skip_flag, int skip_when) {
+    __shared__ double sh[3 * MSDP_WAVES];
+    if (skip_flag && *skip_flag == skip_when) return;
+    double pss = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * MSDP_BLOCK + threadIdx.x; k < a.m; k += (int64_t)gridDim.x * MSDP_BLOCK) {
+        double acc = 0.0;
+        for (int it = a.kit[k]; it < a.kit[k + 1]; ++it) acc += a.ival[it];
+        a.w[k] = acc;
+        if (mode == 1) {
+            const double r = acc - a.b[k] - a.y[k] / sigma;
+            axb_out[k] = r;
+            pss += r * r;
         }
     }
     if (mode == 1) msdp_put_partial(P, P_AUX, pss, sh);
@@ -300,7 +314,20 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
                 rk[pos] = (int)k; rv[pos] = pr[t];
             }
     }
+    std::vector<int> it0, it1, kit(m + 1);
+    for (int64_t k = 0; k < m; ++k) {
+        kit[k] = (int)it0.size();
+        for (int t = cjc[k]; t < cjc[k + 1]; t += SDDMM_CHUNK) { it0.push_back(t); it1.push_back(std::min(t + SDDMM_CHUNK, cjc[k + 1])); }
+    }
+    kit[m] = (int)it0.size();
+    a.nitems = (int64_t)it0.size();
     int rc;
+    if ((rc = up(h, it0, &a.it0)) || (rc = up(h, it1, &a.it1)) || (rc = up(h, kit, &a.kit))) return rc;
+    {
+        void* pv = nullptr;
+        if ((rc = msdp_dev_alloc_bytes(h, &pv, (size_t)std::max<int64_t>(a.nitems, 1) * sizeof(double)))) return rc;
+        a.ival = (double*)pv;
+    }
     if ((rc = up(h, cjc, &a.cjc)) || (rc = up(h, ci, &a.ci)) || (rc = up(h, cj, &a.cj)) || (rc = up(h, cv, &a.cv)) ||
         (rc = up(h, rp, &a.rp)) || (rc = up(h, rk, &a.rk)) || (rc = up(h, rv, &a.rv)))
         return rc;
@@ -371,6 +398,17 @@ int msdp_affine_set_multipliers(msdp_handle h, const double* y, double sigma) {
 int msdp_dense_hess_epilogue_obl(msdp_handle h, const double* slab, int64_t stride, int SK);   // msdp_dense.hip
 int msdp_sphere_hess_raw(msdp_handle h, const double* slab, int64_t stride, int SK);           // below
 
+// k_sddmm has no reductions, so its grid follows the number of work items, not the number of rows
+static int sddmm_grid(const AffineDev& a, int ld) {
+    int half = ld / 2, lpr = 1;
+    while (lpr < half && lpr < 64) lpr <<= 1;
+    const int64_t per_block = (int64_t)MSDP_WAVES * (64 / lpr);
+    int64_t g = (a.nitems + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > 8192) g = 8192;
+    return (int)g;
+}
+
 static int adjoint_grid(const AffineDev& a) {
     int64_t tot = (int64_t)a.n * a.nS;
     int64_t g = (tot + 255) / 256;
@@ -388,7 +426,9 @@ int msdp_affine_costgrad(msdp_handle h, int slot) {
     const double sigma = st->sigma;
     const double* Ys = d.Y[slot];
     const int* done = &d.ctl->done;
-    DISPATCH_LPR_A(k_sddmm, h, d.G, a, Ys, Ys, 1, a.Axb[slot], sigma, d.P, d.G, done, 1);
+    DISPATCH_LPR_A(k_sddmm, h, sddmm_grid(a, d.ld), a, Ys, Ys, done, 1);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_sddmm_finish, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, a, 1, a.Axb[slot], sigma, d.P, done, 1);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_adjoint_dense, dim3(adjoint_grid(a)), dim3(256), 0, h->stream, a, d.Cd, a.Axb[slot], sigma,
                        d.eS[slot], done, 1);
@@ -429,7 +469,13 @@ int msdp_affine_hess(msdp_handle h) {
     const int cur = h->h_ctl->cur;
     const int* act = &d.F[0].active;
     // w = A(Y U') ; AyU = A'(w)
-    DISPATCH_LPR_A(k_sddmm, h, d.G, a, d.Y[cur], d.md, 0, (double*)nullptr, sigma, d.P, d.G, act, 0);
+    DISPATCH_LPR_A(k_sddmm, h, sddmm_grid(a, d.ld), a, d.Y[cur], d.md, act, 0);
+    HIPCHK(hipGetLastError());
+    {   // mode 0 has no reduction: size the grid by m
+        int64_t gf = (a.m + MSDP_BLOCK - 1) / MSDP_BLOCK;
+        if (gf > 2048) gf = 2048;
+        hipLaunchKernelGGL(k_sddmm_finish, dim3((int)gf), dim3(MSDP_BLOCK), 0, h->stream, a, 0, (double*)nullptr, sigma, d.P, act, 0);
+    }
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_adjoint_dense, dim3(adjoint_grid(a)), dim3(256), 0, h->stream, a, (const double*)nullptr, a.w, 1.0,
                        d.AyU, act, 0);
@@ -486,7 +532,9 @@ int msdp_affine_linesearch_cost(msdp_handle h, const double* Yt, double* val) {
     a.p = d.p; a.ld = d.ld;
     const double sigma = st->sigma;
     const int other = h->h_ctl->cur ^ 1;
-    DISPATCH_LPR_A(k_sddmm, h, d.G, a, Yt, Yt, 1, a.Axb[other], sigma, d.P, d.G, (const int*)nullptr, 0);
+    DISPATCH_LPR_A(k_sddmm, h, sddmm_grid(a, d.ld), a, Yt, Yt, (const int*)nullptr, 0);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_sddmm_finish, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, a, 1, a.Axb[other], sigma, d.P, (const int*)nullptr, 0);
     HIPCHK(hipGetLastError());
     const double* slab; int64_t stride; int SK;
     const double* M[1] = {d.Cd}; const double* X[1] = {Yt}; const double sc[1] = {1.0};
