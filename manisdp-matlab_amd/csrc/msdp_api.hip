@@ -651,7 +651,7 @@ static int launch_chunk(msdp_handle h, int CH, bool graph) {
 // Run the tCG inner loop of the current TR iteration: chunks of CH trips are enqueued one
 // ahead of the device (so the graph-launch latency is hidden) while the host polls the
 // host-mapped progress word the lead thread of k_tcg_upd2 publishes every trip.
-static int run_tcg(msdp_handle h, int maxinner, int k) {
+static int run_tcg(msdp_handle h, int maxinner, int k, bool* done_out = nullptr) {
     const int CH = tcg_chunk();
     const bool graph = use_graphs() && !h->use_comm;
     int rc;
@@ -686,7 +686,9 @@ static int run_tcg(msdp_handle h, int maxinner, int k) {
         const unsigned long long s = *h->h_status;
         if ((s >> 32) == want) {
             const int active = (int)(s & 1ULL);
-            const int j = (int)((s & 0xffffffffULL) >> 1);
+            const int jraw = (int)((s & 0xffffffffULL) >> 1);
+            if (done_out && (jraw & 0x40000000)) *done_out = true;
+            const int j = jraw & 0x3fffffff;
             if (!active) break;
             if (enq * CH < maxinner && j >= (enq - 1) * CH) {
                 if ((rc = launch_chunk(h, CH, graph))) return rc;
@@ -698,7 +700,10 @@ static int run_tcg(msdp_handle h, int maxinner, int k) {
             if (hipStreamQuery(h->stream) == hipSuccess) {
                 // everything enqueued has run: the final status must be visible now
                 const unsigned long long s2 = *h->h_status;
-                if ((s2 >> 32) == want && !(s2 & 1ULL)) break;
+                if ((s2 >> 32) == want && !(s2 & 1ULL)) {
+                    if (done_out && (((s2 & 0xffffffffULL) >> 1) & 0x40000000)) *done_out = true;
+                    break;
+                }
                 if (enq * CH >= maxinner || (s2 >> 32) != want) {
                     msdp_set_error("tCG progress word inconsistent (status %llx, TR iteration %d)", s2, k);
                     return MSDP_EHIP;
@@ -732,7 +737,30 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
     if ((rc = pull_ctl(h))) return rc;
     static int timing = -1;
     if (timing < 0) { const char* e = getenv("MSDP_TIMING"); timing = (e && atoi(e)) ? 1 : 0; }
+    static int sync_tr = -1;
+    if (sync_tr < 0) { const char* e = getenv("MSDP_SYNC_TR"); sync_tr = (e && atoi(e)) ? 1 : 0; }
     double t_tcg = 0.0, t_rest = 0.0;
+    const char* nopub_env = getenv("MSDP_NO_PUBLISH");
+    const bool async_tr = !sync_tr && h->d.costkind == COST_SPARSE && !h->use_comm && !(nopub_env && atoi(nopub_env));
+    if (async_tr) {
+        // No host sync between TR iterations: the proposal slot is resolved on the device, the next
+        // iteration's tcg_init + first chunks are enqueued right behind k_rtr_decide, and k_tcg_init
+        // publishes `done` through the progress word (a finished solve turns everything enqueued into no-ops).
+        int k = 0;
+        bool done = false;
+        while (k < opts->maxiter) {
+            const auto ta = std::chrono::steady_clock::now();
+            if ((rc = run_tcg(h, opts->maxinner, k, &done))) return rc;
+            const auto tb = std::chrono::steady_clock::now();
+            t_tcg += std::chrono::duration<double>(tb - ta).count();
+            if (done) break;
+            if ((rc = msdp_launch_retract(h))) return rc;             // :540
+            if ((rc = msdp_launch_costgrad(h, 3))) return rc;         // :544 (proposal slot, device-resolved)
+            if ((rc = msdp_launch_rtr_decide(h))) return rc;          // :548-729
+            ++k;
+        }
+        if ((rc = pull_ctl(h))) return rc;
+    } else {
     while (!h->h_ctl->done) {                                     // trustregions.m:441
         cur = h->h_ctl->cur;
         const auto ta = std::chrono::steady_clock::now();
@@ -745,6 +773,7 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
         const auto tc = std::chrono::steady_clock::now();
         t_tcg += std::chrono::duration<double>(tb - ta).count();
         t_rest += std::chrono::duration<double>(tc - tb).count();
+    }
     }
     if (timing)
         fprintf(stderr, "[msdp_rtr] k=%d hessvecs=%d  tCG phase %.3f ms  (retract+cost+decide+sync) %.3f ms\n",

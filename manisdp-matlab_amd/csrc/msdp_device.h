@@ -138,7 +138,9 @@ __device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<do
 // the lead thread): the host polls it to decide whether to enqueue another chunk.
 __device__ __forceinline__ void msdp_publish(const Dev& d, int k, int j, int active) {
     if (!d.status) return;
+    // bit 30 of the j field carries ctl->done so that the host can stop enqueuing TR iterations without a sync
+    const unsigned jj = ((unsigned)j & 0x3fffffffu) | (d.ctl->done ? 0x40000000u : 0u);
     const unsigned long long v = ((unsigned long long)(unsigned)(k + 1) << 32) |
-                                 ((unsigned long long)(unsigned)j << 1) | (unsigned long long)(active & 1);
+                                 ((unsigned long long)jj << 1) | (unsigned long long)(active & 1);
     __hip_atomic_store(d.status, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -84,8 +84,10 @@ __device__ __forceinline__ void costgrad_sparse_obl_body(const Dev& d, int slot)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RPW = 64 / LPR;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    const bool rel = slot >= 2;                      // 2: current slot, 3: proposal slot, resolved on the device
+    if (rel) slot = d.ctl->cur ^ (slot & 1);
     const double* __restrict__ Yl = slot ? d.Y[1] : d.Y[0];
-    const double* __restrict__ Xf = d.full;
+    const double* __restrict__ Xf = rel ? Yl : d.full;
     double* __restrict__ Gr = slot ? d.Gr[1] : d.Gr[0];
     double* __restrict__ eG = slot ? d.eG[1] : d.eG[0];
     double pf = 0.0, pgg = 0.0;
@@ -783,8 +785,13 @@ int msdp_sphere_upd2(msdp_handle h);
 int msdp_sphere_retract(msdp_handle h);
 
 int msdp_launch_costgrad(msdp_handle h, int slot) {
-    // gather source: all rows of Y[slot]
-    int rc = msdp_allgather_rows(h, h->d.Y[slot]);
+    // gather source: all rows of Y[slot] (slot >= 2: resolved on the device, single rank, sparse C only)
+    int rc = 0;
+    if (slot >= 2) {
+        if (h->d.costkind != COST_SPARSE || h->use_comm) { msdp_set_error("relative slot: sparse single-rank only"); return MSDP_EINVAL; }
+    } else {
+        rc = msdp_allgather_rows(h, h->d.Y[slot]);
+    }
     if (rc) return rc;
     if (h->d.costkind == COST_SPARSE) {
         if (h->d.ellW > 0) DISPATCH_LPR(k_costgrad_ell_obl, h, h->d, slot);
