@@ -1,0 +1,136 @@
+"""GPU edge cases through the C-ABI: ragged / empty rows, tiny and odd sizes, widths that exercise every lane
+mapping (p = 1 pad column ... p > 128 multi-chunk), dense orders that are not multiples of the MFMA tile,
+degenerate constraint sets, and the error paths (call-order violations, unsupported sizes)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _relerr(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from manisdp_matlab_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def _pt(n, p, seed):
+    rng = np.random.default_rng(seed)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    return Y, rng.standard_normal((n, p))
+
+
+@pytest.mark.parametrize("n,p", [(1, 1), (2, 1), (7, 3), (63, 2), (65, 17), (129, 64), (300, 129), (257, 200), (100, 300)])
+def test_sparse_ragged_and_empty_rows(lib, n, p):
+    from oracle import manisdp_ref as R
+    rng = np.random.default_rng(n * 1000 + p)
+    A = sp.random(n, n, density=min(1.0, 6.0 / max(n, 1)), random_state=np.random.RandomState(n), format="csr")
+    C = (A + A.T).tocsr()
+    if n > 3:                              # force some empty rows/columns and one long row
+        C = C.tolil(); C[1, :] = 0; C[:, 1] = 0; C[0, :] = 1.0; C[:, 0] = 1.0; C = C.tocsr()
+    C.eliminate_zeros()
+    Y, U = _pt(n, p, 1)
+    h = lib.Handle.onlyunitdiag(C)
+    h.set_point(Y)
+    prob = R._OnlyUnitDiagProblem(C, n, p)
+    f = prob.cost(Y)
+    assert abs(h.cost() - f) <= 1e-12 * max(1.0, abs(f))
+    assert _relerr(h.rgrad(), prob.grad(Y)) < 1e-12 or np.linalg.norm(prob.grad(Y)) < 1e-13
+    assert _relerr(h.hessvec(U), prob.hess(Y, U)) < 1e-12
+    st = h.rtr(lib.default_opts(maxiter=3, maxinner=5, tolgradnorm=1e-10))
+    assert np.isfinite(st.cost) and np.allclose(np.linalg.norm(h.get_point(), axis=1), 1.0, atol=1e-13)
+    h.close()
+
+
+def test_zero_matrix_and_already_optimal_point(lib):
+    n, p = 50, 4
+    C = sp.csr_matrix((n, n))
+    Y, U = _pt(n, p, 0)
+    h = lib.Handle.onlyunitdiag(C)
+    h.set_point(Y)
+    assert h.cost() == 0.0 and np.all(h.rgrad() == 0.0) and np.all(h.hessvec(U) == 0.0)
+    st = h.rtr(lib.default_opts(maxiter=5, maxinner=5, tolgradnorm=1e-8))     # gradnorm 0 < tol: stops at k = 0
+    assert st.iters == 0 and st.hessvecs == 0 and st.cost == 0.0
+    assert np.array_equal(h.get_point(), Y)
+    h.close()
+
+
+@pytest.mark.parametrize("n,p", [(1, 1), (15, 2), (17, 16), (33, 33), (130, 128)])
+def test_dense_odd_orders(lib, n, p):
+    from oracle import manisdp_ref as R
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n, n)); C = (G + G.T) / 2
+    Y, U = _pt(n, p, 2)
+    h = lib.Handle.onlyunitdiag(C)
+    h.set_point(Y)
+    prob = R._OnlyUnitDiagProblem(C, n, p)
+    f = prob.cost(Y)
+    assert abs(h.cost() - f) <= 1e-12 * max(1.0, abs(f))
+    assert _relerr(h.hessvec(U), prob.hess(Y, U)) < 1e-12
+    h.close()
+
+
+def test_affine_degenerate_constraints(lib):
+    """One constraint only (the trace), an empty constraint column, and a constraint touching a single entry."""
+    from oracle import manisdp_ref as R
+    n, p = 12, 3
+    rows = [i * n + i for i in range(n)] + [5 * n + 5]
+    cols = [0] * n + [2]                       # column 1 is empty
+    At = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(n * n, 3)).tocsc()
+    b = np.array([1.0, 0.0, 0.1])
+    rng = np.random.default_rng(0)
+    G = rng.standard_normal((n, n)); c = ((G + G.T) / 2).ravel(order="F")
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y)
+    U = rng.standard_normal((n, p))
+    y = np.array([0.3, -0.2, 0.1]); sigma = 2.0
+    for kind, Prob in ((lib.KIND_UNITTRACE, R._UnitTraceProblem), (lib.KIND_UNITDIAG, R._UnitDiagProblem)):
+        Yk = Y if kind == lib.KIND_UNITTRACE else Y / np.linalg.norm(Y, axis=1, keepdims=True)
+        prob = Prob(At, b, c, n, p); prob.y, prob.sigma = y, sigma
+        f = prob.cost(Yk); Gr = prob.grad(Yk); H = prob.hess(Yk, U)
+        h = lib.Handle.affine(kind, At, b, c, n)
+        h.set_multipliers(y, sigma)
+        h.set_point(Yk)
+        assert abs(h.cost() - f) <= 1e-11 * max(1.0, abs(f))
+        assert _relerr(h.rgrad(), Gr) < 1e-11 and _relerr(h.hessvec(U), H) < 1e-11
+        h.close()
+
+
+def test_width_changes_between_calls_and_reallocation(lib):
+    """The AL loop changes p every iteration; capacity grows on demand and state never leaks between widths."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R
+    C = problems.toroidal_grid_maxcut(12, 11, seed=9)
+    n = C.shape[0]
+    h = lib.Handle.onlyunitdiag(C, pcap=4)
+    for p in (2, 40, 3, 97, 8):
+        Y, U = _pt(n, p, p)
+        h.set_point(Y)
+        prob = R._OnlyUnitDiagProblem(C, n, p); prob.cost(Y)
+        assert _relerr(h.hessvec(U), prob.hess(Y, U)) < 1e-12
+        st = h.rtr(lib.default_opts(maxiter=2, maxinner=4, tolgradnorm=1e-12))
+        assert st.hessvecs > 0
+    h.close()
+
+
+def test_error_paths(lib):
+    from manisdp_matlab_amd import problems
+    C = problems.toroidal_grid_maxcut(6, 6, seed=1)
+    h = lib.Handle.onlyunitdiag(C)
+    with pytest.raises(lib.MsdpError):            # no resident point yet
+        h.rtr(lib.default_opts(maxiter=1, maxinner=1))
+    with pytest.raises(lib.MsdpError):
+        h.get_point()
+    Y, _ = _pt(C.shape[0], 3, 0)
+    h.set_point(Y)
+    with pytest.raises(lib.MsdpError):            # rho_prime must be < 1/4 (trustregions.m:373-374)
+        h.rtr(lib.default_opts(maxiter=1, maxinner=1, rho_prime=0.3))
+    with pytest.raises(lib.MsdpError):            # multipliers on a handle without affine constraints
+        h.set_multipliers(np.zeros(3), 1.0)
+    with pytest.raises(lib.MsdpError):            # p > 512 unsupported
+        h.set_point(np.ones((C.shape[0], 600)))
+    h.close()
