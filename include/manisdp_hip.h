@@ -177,6 +177,11 @@ int msdp_linesearch_accept(msdp_handle h);
 int msdp_escape_eigs(msdp_handle h, int32_t k, double tol, int32_t maxit,
                      double* lam_min, double* V, double* lam_max, int32_t* iters);
 
+/* Same escape for an explicit dense symmetric S (n x n, column-major = row-major) formed by the AL loop of the
+ * affine kinds (ManiSDP_unitdiag.m:65-68, ManiSDP_unittrace.m:65-68: S = eS - diag(z) / eS - z*I, eig(S)). */
+int msdp_escape_eigs_matrix(msdp_handle h, const double* S, int32_t k, double tol, int32_t maxit,
+                            double* lam_min, double* V, double* lam_max, int32_t* iters);
+
 /* ------------------------------------------------------------- multi-GPU */
 
 /* Row sharding: call on every rank right after create, before any

@@ -73,6 +73,8 @@ SIGNATURES = {
     "msdp_linesearch_cost": (C.c_int, [C.c_void_p, _dp, C.c_double, _dp]),
     "msdp_linesearch_accept": (C.c_int, [C.c_void_p]),
     "msdp_escape_eigs": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, _dp, _dp, _dp, _P(C.c_int32)]),
+    "msdp_escape_eigs_matrix": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_double, C.c_int32, _dp, _dp, _dp,
+                                         _P(C.c_int32)]),
     "msdp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "msdp_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "msdp_local_rows": (C.c_int, [C.c_void_p, _i64p, _i64p]),
@@ -284,6 +286,17 @@ class Handle:
         lmax = C.c_double()
         its = C.c_int32()
         _check(self._lib.msdp_escape_eigs(self._h, k, tol, maxit, _dptr(lam), _dptr(V), C.byref(lmax), C.byref(its)))
+        return lam, np.ascontiguousarray(V), lmax.value, its.value
+
+    def escape_eigs_matrix(self, S, k, tol=1e-10, maxit=20000):
+        """k bottom eigenpairs and lambda_max of an explicit dense symmetric S (device Lanczos, dense GEMV)."""
+        S = np.ascontiguousarray(S, dtype=np.float64)
+        lam = np.empty(k)
+        V = np.empty((self.n, k), order="F")
+        lmax = C.c_double()
+        its = C.c_int32()
+        _check(self._lib.msdp_escape_eigs_matrix(self._h, _dptr(S), k, tol, maxit, _dptr(lam), _dptr(V), C.byref(lmax),
+                                                 C.byref(its)))
         return lam, np.ascontiguousarray(V), lmax.value, its.value
 
     # ---- multi-GPU

@@ -389,8 +389,12 @@ int msdp_affine_set_multipliers(msdp_handle h, const double* y, double sigma) {
                 case 32: hipLaunchKernelGGL((KERNEL<32, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
                 default: hipLaunchKernelGGL((KERNEL<64, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
             }                                                                                        \
+        } else if (nch == 2) {                                                                       \
+            hipLaunchKernelGGL((KERNEL<64, 2>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
+        } else if (nch <= 4) {                                                                       \
+            hipLaunchKernelGGL((KERNEL<64, 4>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
         } else {                                                                                     \
-            msdp_set_error("affine path supports p <= 128");                                         \
+            msdp_set_error("factor width p = %d exceeds the supported maximum of 512", (h)->d.p);    \
             return MSDP_EUNSUPPORTED;                                                                \
         }                                                                                            \
     } while (0)

@@ -38,7 +38,9 @@ int msdp_dense_setup(msdp_handle h, const double* C);
 int msdp_dense_reserve(msdp_handle h, int nmat);
 int msdp_dense_setup_synthetic(msdp_handle h, uint64_t seed);
 void msdp_affine_release(msdp_handle h);
-int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam, double* V, double* lmax, int* iters);
+int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam, double* V, double* lmax, int* iters,
+                     const double* Mdev);
+int msdp_dense_nS(int n);
 
 #define CHECK_H(h)                                          \
     if (!(h)) { msdp_set_error("null handle"); return MSDP_EINVAL; }
@@ -938,7 +940,31 @@ extern "C" int msdp_escape_eigs(msdp_handle h, int32_t k, double tol, int32_t ma
         h->h_ctl->fx = v[1];
         h->gradnorm_valid = true;
     }
-    return msdp_escape_impl(h, k, tol, maxit, lam_min, V, lam_max, iters);
+    return msdp_escape_impl(h, k, tol, maxit, lam_min, V, lam_max, iters, nullptr);
+}
+
+// Same for an explicit dense symmetric S handed over by the AL loop of the affine kinds (S = C - A'y - diag(z) or
+// - z*I is formed on the host exactly as in ManiSDP_unitdiag.m:65-67 / ManiSDP_unittrace.m:65-67): replaces the
+// O(n^3) eig(S) of :68 by Lanczos runs whose S*v is a device GEMV.  span(Y) is deflated when the last RTR call
+// ended with a small gradient (grad = 2*S*Y for these problems).
+extern "C" int msdp_escape_eigs_matrix(msdp_handle h, const double* S, int32_t k, double tol, int32_t maxit,
+                                       double* lam_min, double* V, double* lam_max, int32_t* iters) {
+    CHECK_H(h);
+    if (!S || !lam_min || !V) { msdp_set_error("escape_eigs_matrix: null argument"); return MSDP_EINVAL; }
+    if (!h->have_point) { msdp_set_error("no resident point"); return MSDP_ESTATE; }
+    const int n = h->d.n, nS = msdp_dense_nS(n);
+    double* M = nullptr;
+    if (hipMalloc((void**)&M, (size_t)n * nS * sizeof(double)) != hipSuccess) { msdp_set_error("escape_eigs_matrix: allocation failed"); return MSDP_ENOMEM; }
+    hipError_t e = hipMemsetAsync(M, 0, (size_t)n * nS * sizeof(double), h->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(M, (size_t)nS * sizeof(double), S, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n,
+                             hipMemcpyHostToDevice, h->stream);
+    int rc = 0;
+    if (e != hipSuccess) { msdp_set_error("escape_eigs_matrix: upload failed: %s", hipGetErrorString(e)); rc = MSDP_EHIP; }
+    if (!rc) rc = msdp_escape_impl(h, k, tol, maxit, lam_min, V, lam_max, iters, M);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(M);
+    return rc;
 }
 
 // ------------------------------------------------------------------ measurement

@@ -21,6 +21,7 @@
 // Kernel 2 (row-tiled epilogue): sums the slabs and applies the fused projection.
 #include "msdp_device.h"
 #include <math.h>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -37,6 +38,7 @@ struct DenseOp {
     int n;                       // true matrix order (panel rows)
     int nS;                      // padded leading dimension / k extent per matrix
     int n_loc, ld, ldl;          // rows, panel stride, LDS row stride
+    int colofs, ncols;           // column block [colofs, colofs+ncols) of the panel handled by this launch (ncols <= 128)
     int SK;                      // k slices
     int kslice;                  // k extent per slice (multiple of DENSE_KT) over the concatenated K = nmat*nS
     double* slab;                // SK x n_loc_cap x ld
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial(DenseOp op, 
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
     const int ld = op.ld, ldl = op.ldl;
-    const int half = ld >> 1;                                  // double2 per panel row
+    const int half = op.ncols >> 1;                            // double2 per panel row of this column block
     for (int64_t k0 = kbeg; k0 < kend; k0 += DENSE_KT) {
         // which matrix does this tile belong to (tiles never straddle: nS % DENSE_KT == 0 is not
         // required, only nS % 16 == 0, so resolve per 16-k step below; the panel tile is staged per step pair)
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial(DenseOp op, 
             if (kk < kend) {
                 const int m = (kk >= op.nS) ? 1 : 0;
                 const int64_t kl = kk - (int64_t)m * op.nS;
-                if (kl < op.n) v = ld2(op.X[m] + kl * ld + 2 * c2);
+                if (kl < op.n) v = ld2(op.X[m] + kl * ld + op.colofs + 2 * c2);
             }
             *reinterpret_cast<double2*>(&lds[r * ldl + 2 * c2]) = v;
         }
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial(DenseOp op, 
                 const double* brow = &lds[(16 * s + 4 * g + t4) * ldl + i];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const double b = (16 * t + i < ld) ? brow[16 * t] : 0.0;
+                    const double b = (16 * t + i < op.ncols) ? brow[16 * t] : 0.0;
                     acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t4], b, acc[t], 0, 0, 0);
                 }
             }
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial(DenseOp op, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = row0 + g + 4 * r;
-            if (row < op.n_loc && col < ld) out[(int64_t)row * ld + col] = acc[t][r];
+            if (row < op.n_loc && col < op.ncols) out[(int64_t)row * ld + op.colofs + col] = acc[t][r];
         }
     }
 }
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial2(DenseOp op,
     const int64_t kbeg = (int64_t)blockIdx.y * op.kslice;
     int64_t kend = kbeg + op.kslice;
     if (kend > Ktot) kend = Ktot;
-    const int ld = op.ld, ldl = op.ldl, half = ld >> 1;
+    const int ld = op.ld, ldl = op.ldl, half = op.ncols >> 1;
     const int tile_elems = DENSE_KT2 * half;
     // zero both LDS tiles once: pad columns [ld, ldl) are never written again
     for (int e = threadIdx.x; e < 2 * DENSE_KT2 * ldl; e += NTHR) lds[e] = 0.0;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial2(DenseOp op,
         const int e = threadIdx.x + q * NTHR;
         const int r = (e < tile_elems) ? e / half : -1;
         const int c2 = (e < tile_elems) ? e - r * half : 0;
-        srow[q] = r; sg[q] = r * ld + 2 * c2; sl[q] = r * ldl + 2 * c2;
+        srow[q] = r; sg[q] = r * ld + op.colofs + 2 * c2; sl[q] = r * ldl + 2 * c2;
     }
     double4_t acc[NT];
 #pragma unroll
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial2(DenseOp op,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = row0 + g + 4 * r;
-            if (row < op.n_loc && col < ld) out[(int64_t)row * ld + col] = acc[t][r];
+            if (row < op.n_loc && col < op.ncols) out[(int64_t)row * ld + op.colofs + col] = acc[t][r];
         }
     }
 }
@@ -408,9 +410,6 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
     op.nS = msdp_dense_nS(d.n);
     op.n_loc = d.n_loc;
     op.ld = d.ld;
-    int ldl = ((d.ld + 15) / 16) * 16;                   // zero-padded to 16*NT columns (no column predicate)
-    while ((ldl & 7) != 4) ldl += 2;                    // ldl = 4 (mod 8): conflict-free B reads
-    op.ldl = ldl;
     int SK; int64_t kslice; int row_blocks;
     dense_plan(h, nmat, &row_blocks, &SK, &kslice);
     op.SK = SK;
@@ -420,34 +419,41 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
     int rc = ensure_slab(h, (size_t)SK * op.slab_stride);
     if (rc) return rc;
     op.slab = h->slab;
-    const int NT = (d.ld + 15) / 16;
-    if (NT > 8) { msdp_set_error("dense path supports p <= 128 (got ld = %d)", d.ld); return MSDP_EUNSUPPORTED; }
-    dim3 grid(row_blocks, SK), block(DENSE_WAVES * 64);
     static int v1 = -1;
     if (v1 < 0) { const char* e = getenv("MSDP_DENSE_V1"); v1 = (e && atoi(e)) ? 1 : 0; }
-    if (v1) {
-        const size_t shmem = (size_t)DENSE_KT * ldl * sizeof(double);
-        switch (NT) {
-            case 1: hipLaunchKernelGGL((k_dense_partial<1>), grid, block, shmem, h->stream, op, active_flag); break;
-            case 2: hipLaunchKernelGGL((k_dense_partial<2>), grid, block, shmem, h->stream, op, active_flag); break;
-            case 3: hipLaunchKernelGGL((k_dense_partial<3>), grid, block, shmem, h->stream, op, active_flag); break;
-            case 4: hipLaunchKernelGGL((k_dense_partial<4>), grid, block, shmem, h->stream, op, active_flag); break;
-            case 5: hipLaunchKernelGGL((k_dense_partial<5>), grid, block, shmem, h->stream, op, active_flag); break;
-            case 6: hipLaunchKernelGGL((k_dense_partial<6>), grid, block, shmem, h->stream, op, active_flag); break;
-            case 7: hipLaunchKernelGGL((k_dense_partial<7>), grid, block, shmem, h->stream, op, active_flag); break;
-            default: hipLaunchKernelGGL((k_dense_partial<8>), grid, block, shmem, h->stream, op, active_flag); break;
-        }
-    } else {
-        const size_t shmem = (size_t)2 * DENSE_KT2 * ldl * sizeof(double);
-        switch (NT) {
-            case 1: hipLaunchKernelGGL((k_dense_partial2<1>), grid, block, shmem, h->stream, op, active_flag); break;
-            case 2: hipLaunchKernelGGL((k_dense_partial2<2>), grid, block, shmem, h->stream, op, active_flag); break;
-            case 3: hipLaunchKernelGGL((k_dense_partial2<3>), grid, block, shmem, h->stream, op, active_flag); break;
-            case 4: hipLaunchKernelGGL((k_dense_partial2<4>), grid, block, shmem, h->stream, op, active_flag); break;
-            case 5: hipLaunchKernelGGL((k_dense_partial2<5>), grid, block, shmem, h->stream, op, active_flag); break;
-            case 6: hipLaunchKernelGGL((k_dense_partial2<6>), grid, block, shmem, h->stream, op, active_flag); break;
-            case 7: hipLaunchKernelGGL((k_dense_partial2<7>), grid, block, shmem, h->stream, op, active_flag); break;
-            default: hipLaunchKernelGGL((k_dense_partial2<8>), grid, block, shmem, h->stream, op, active_flag); break;
+    // p > 128: column blocks of 128 (the matrix is re-streamed once per block; NT <= 8 accumulator tiles per wave)
+    for (int colofs = 0; colofs < d.ld; colofs += 128) {
+        op.colofs = colofs;
+        op.ncols = std::min(128, d.ld - colofs);
+        int ldl = ((op.ncols + 15) / 16) * 16;                // zero-padded to 16*NT columns (no column predicate)
+        while ((ldl & 7) != 4) ldl += 2;                      // ldl = 4 (mod 8): conflict-free B reads
+        op.ldl = ldl;
+        const int NT = (op.ncols + 15) / 16;
+        dim3 grid(row_blocks, SK), block(DENSE_WAVES * 64);
+        if (v1) {
+            const size_t shmem = (size_t)DENSE_KT * ldl * sizeof(double);
+            switch (NT) {
+                case 1: hipLaunchKernelGGL((k_dense_partial<1>), grid, block, shmem, h->stream, op, active_flag); break;
+                case 2: hipLaunchKernelGGL((k_dense_partial<2>), grid, block, shmem, h->stream, op, active_flag); break;
+                case 3: hipLaunchKernelGGL((k_dense_partial<3>), grid, block, shmem, h->stream, op, active_flag); break;
+                case 4: hipLaunchKernelGGL((k_dense_partial<4>), grid, block, shmem, h->stream, op, active_flag); break;
+                case 5: hipLaunchKernelGGL((k_dense_partial<5>), grid, block, shmem, h->stream, op, active_flag); break;
+                case 6: hipLaunchKernelGGL((k_dense_partial<6>), grid, block, shmem, h->stream, op, active_flag); break;
+                case 7: hipLaunchKernelGGL((k_dense_partial<7>), grid, block, shmem, h->stream, op, active_flag); break;
+                default: hipLaunchKernelGGL((k_dense_partial<8>), grid, block, shmem, h->stream, op, active_flag); break;
+            }
+        } else {
+            const size_t shmem = (size_t)2 * DENSE_KT2 * ldl * sizeof(double);
+            switch (NT) {
+                case 1: hipLaunchKernelGGL((k_dense_partial2<1>), grid, block, shmem, h->stream, op, active_flag); break;
+                case 2: hipLaunchKernelGGL((k_dense_partial2<2>), grid, block, shmem, h->stream, op, active_flag); break;
+                case 3: hipLaunchKernelGGL((k_dense_partial2<3>), grid, block, shmem, h->stream, op, active_flag); break;
+                case 4: hipLaunchKernelGGL((k_dense_partial2<4>), grid, block, shmem, h->stream, op, active_flag); break;
+                case 5: hipLaunchKernelGGL((k_dense_partial2<5>), grid, block, shmem, h->stream, op, active_flag); break;
+                case 6: hipLaunchKernelGGL((k_dense_partial2<6>), grid, block, shmem, h->stream, op, active_flag); break;
+                case 7: hipLaunchKernelGGL((k_dense_partial2<7>), grid, block, shmem, h->stream, op, active_flag); break;
+                default: hipLaunchKernelGGL((k_dense_partial2<8>), grid, block, shmem, h->stream, op, active_flag); break;
+            }
         }
     }
     HIPCHK(hipGetLastError());
@@ -473,8 +479,12 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
                 case 32: hipLaunchKernelGGL((KERNEL<32, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
                 default: hipLaunchKernelGGL((KERNEL<64, 1>), grid, block, 0, (h)->stream, __VA_ARGS__); break; \
             }                                                                                        \
+        } else if (nch == 2) {                                                                       \
+            hipLaunchKernelGGL((KERNEL<64, 2>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
+        } else if (nch <= 4) {                                                                       \
+            hipLaunchKernelGGL((KERNEL<64, 4>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
         } else {                                                                                     \
-            msdp_set_error("dense path supports p <= 128");                                          \
+            msdp_set_error("factor width p = %d exceeds the supported maximum of 512", (h)->d.p);    \
             return MSDP_EUNSUPPORTED;                                                                \
         }                                                                                            \
     } while (0)

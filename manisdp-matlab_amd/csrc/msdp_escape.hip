@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_sv_dense(int n, int nS, const double* _
         acc += c2.x * v[j] + ((j + 1 < n) ? c2.y * v[j + 1] : 0.0);
     }
     acc = msdp_wave_sum(acc);
-    if (lane == 0) w[row] = acc - z[row] * v[row];
+    if (lane == 0) w[row] = acc - (z ? z[row] * v[row] : 0.0);
 }
 // h[c] = <B_c, w>, c = 0..nb-1 (columns contiguous, stride ldb): one workgroup per column
 __global__ __launch_bounds__(MSDP_BLOCK) void k_multidot(int n, const double* __restrict__ B, int64_t ldb,
@@ -195,12 +195,15 @@ struct EscCtx {
     int n;
     const double* z;
     double* hbuf;
+    const double* M;     // explicit dense S (n x nS, device) for the affine kinds; nullptr: S = C - diag(z)
 };
 
 static int sapply(EscCtx& c, const double* v, double* w) {
     msdp_handle h = c.h;
     const Dev& d = h->d;
-    if (d.costkind == COST_SPARSE)
+    if (c.M)
+        hipLaunchKernelGGL(k_sv_dense, dim3((c.n + 3) / 4), dim3(256), 0, h->stream, c.n, msdp_dense_nS(c.n), c.M, (const double*)nullptr, v, w);
+    else if (d.costkind == COST_SPARSE)
         hipLaunchKernelGGL(k_sv_sparse, dim3((c.n + 255) / 256), dim3(256), 0, h->stream, c.n, d.rowptr, d.colind, d.cval, c.z, v, w);
     else
         hipLaunchKernelGGL(k_sv_dense, dim3((c.n + 3) / 4), dim3(256), 0, h->stream, c.n, msdp_dense_nS(c.n), d.Cd, c.z, v, w);
@@ -309,9 +312,9 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
 }
 
 int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_out, double* V_out, double* lmax_out,
-                     int* iters_out) {
+                     int* iters_out, const double* Mdev) {
     Dev& d = h->d;
-    if (h->kind != MSDP_KIND_ONLYUNITDIAG) { msdp_set_error("escape_eigs: implemented for onlyunitdiag handles"); return MSDP_EUNSUPPORTED; }
+    if (!Mdev && h->kind != MSDP_KIND_ONLYUNITDIAG) { msdp_set_error("escape_eigs: affine handles pass S explicitly (msdp_escape_eigs_matrix)"); return MSDP_EUNSUPPORTED; }
     if (h->nranks != 1) { msdp_set_error("escape_eigs: single-GPU only in this build"); return MSDP_EUNSUPPORTED; }
     if (k < 1) { msdp_set_error("escape_eigs: k >= 1"); return MSDP_EINVAL; }
     const int n = d.n, p = d.p;
@@ -322,7 +325,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     if (maxit > cap) maxit = (int)std::max<int64_t>(64, cap);
     const int cur = h->h_ctl->cur;
     EscCtx c;
-    c.h = h; c.n = n; c.z = d.eG[cur];
+    c.h = h; c.n = n; c.z = Mdev ? nullptr : d.eG[cur]; c.M = Mdev;
     const int qcap = p + k + 1;
     double* mem = nullptr;
     const size_t total = (size_t)(qcap + maxit + 2 + qcap) * n + (size_t)n + 2 * (size_t)(maxit + 2) + 4096;

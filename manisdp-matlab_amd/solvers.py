@@ -211,6 +211,7 @@ def _affine_common(kind, At, b, c, K, options, verbose, rng, defaults):
     Atc = sp.csc_matrix(At)
     A = Atc.T.tocsr()
     sphere = kind == _lib.KIND_UNITTRACE
+    eig_mode = o.get("eig", "host" if n <= int(o.get("dense_eig_max", 400)) else "device")
     _say(verbose, "ManiSDP is starting...")
     _say(verbose, f"SDP size: n = {n}, m = {b.size}")
     h = _lib.Handle.affine(kind, Atc, b, c, n, pcap=max(32, int(o["p0"]) + 2 * int(o["delta"])))
@@ -267,7 +268,13 @@ def _affine_common(kind, At, b, c, K, options, verbose, rng, defaults):
                 z = np.sum(X * eS, axis=0)                 # unitdiag :66
                 S = eS - np.diag(z)                        # :67
                 by = float(b @ y) + float(np.sum(z))       # :70
-            dS, vS = np.linalg.eigh(S)                     # :68
+            if eig_mode == "device":
+                # few-eigenvector escape on the device instead of the O(n^3) eig(S) of :68
+                lam, vS, lam_max, _ = h.escape_eigs_matrix(S, int(o["delta"]), tol=float(o.get("eig_tol", 1e-10)),
+                                                           maxit=int(o.get("eig_maxit", 20000)))
+                dS = np.concatenate([lam, [lam_max]])      # dS[0] = lambda_min ... dS[-1] = lambda_max
+            else:
+                dS, vS = np.linalg.eigh(S)                 # :68
             data["eig_seconds"] += time.time() - t1
             dinf = max(0.0, -dS[0]) / (1.0 + dS[-1])       # :69
             gap = abs(obj - by) / (abs(by) + abs(obj) + 1.0)   # :71
@@ -289,7 +296,7 @@ def _affine_common(kind, At, b, c, K, options, verbose, rng, defaults):
             if r <= p - 1:                                 # :93-96
                 Y = _rank_cut(Y, Q, e, r)
                 p = r
-            nneg = int(np.sum(dS < 0))
+            nneg = int(np.sum(dS[:-1] < 0)) if eig_mode == "device" else int(np.sum(dS < 0))
             if sphere:
                 nne = min(nneg, int(o["delta"]))           # unittrace :101
             else:

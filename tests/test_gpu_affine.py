@@ -32,7 +32,7 @@ def _bqp(d):
     return At, b, c / np.abs(c).max(), K
 
 
-@pytest.mark.parametrize("case,p", [("gpp100", 2), ("gpp100", 7), ("bqp10", 5), ("bqp20", 16), ("gpp124-1", 33)])
+@pytest.mark.parametrize("case,p", [("gpp100", 2), ("gpp100", 7), ("bqp10", 5), ("bqp20", 16), ("gpp124-1", 33), ("gpp100", 140), ("bqp10", 300)])
 def test_unitdiag_operators(lib, case, p):
     from manisdp_matlab_amd import problems
     from oracle import manisdp_ref as R
@@ -62,7 +62,7 @@ def test_unitdiag_operators(lib, case, p):
     h.close()
 
 
-@pytest.mark.parametrize("case,p", [("theta1", 1), ("theta1", 6), ("theta2", 20)])
+@pytest.mark.parametrize("case,p", [("theta1", 1), ("theta1", 6), ("theta2", 20), ("theta1", 131)])
 def test_unittrace_operators(lib, case, p):
     from manisdp_matlab_amd import problems
     from oracle import manisdp_ref as R
@@ -184,3 +184,34 @@ def test_solver_theta1_known_answer(lib):
             # primal side is still good when the dual certificate stalls
             assert max(data["gap"], data["pinf"]) < 1e-3
     assert converged >= 1
+
+
+def test_solver_bqp_with_device_escape(lib):
+    """ManiSDP_unitdiag with the device few-eigenvector escape (explicit dense S, Lanczos with a GEMV S*v) instead
+    of the host eig(S): same certified optimum as the host-eig run."""
+    from manisdp_matlab_amd import solvers
+    At, b, c, K = _bqp(20)
+    Y1, obj1, d1 = solvers.ManiSDP_unitdiag(At, b, c, K, {"eig": "host"}, verbose=False)
+    Y2, obj2, d2 = solvers.ManiSDP_unitdiag(At, b, c, K, {"eig": "device"}, verbose=False)
+    for d in (d1, d2):
+        assert d["status"] == 0 and max(d["gap"], d["pinf"], d["dinf"]) < 1e-8
+    assert abs(obj1 - obj2) < 1e-6 * max(1.0, abs(obj1))
+
+
+def test_escape_matrix_matches_lapack(lib):
+    from manisdp_matlab_amd import problems
+    At, b, c, K = _bqp(20)
+    n = K["s"]
+    rng = np.random.default_rng(0)
+    G = rng.standard_normal((n, n)); S = (G + G.T) / 2
+    Y = rng.standard_normal((n, 4)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    h = lib.Handle.affine(lib.KIND_UNITDIAG, At, b, c, n)
+    h.set_multipliers(np.zeros(b.size), 1.0)
+    h.set_point(Y)
+    lam, V, lmax, its = h.escape_eigs_matrix(S, 6, tol=1e-10, maxit=5000)
+    h.close()
+    dS = np.linalg.eigh(S)[0]
+    assert abs(lmax - dS[-1]) < 1e-6 * abs(dS[-1])
+    assert np.allclose(lam, dS[:6], rtol=0, atol=1e-8 * abs(dS[0]))
+    for t in range(6):
+        assert np.linalg.norm(S @ V[:, t] - lam[t] * V[:, t]) < 1e-5 * abs(dS[0])

@@ -33,8 +33,10 @@ if which == "bqp":
         B = 2 * At.nnz * 12 + 3 * 8 * n * n + 24 * n * p
         print("  p=%d Hess-vec %.1f us  (%.0f GB/s algorithmic)" % (p, us, B / us / 1e3), flush=True)
     if d <= 40:
-        t = time.time(); Y, obj, data = solvers.ManiSDP_unitdiag(At, b, c, K, {}, verbose=False); tg = time.time() - t
-        print("  GPU solve: obj %.8f eta %.1e iters %d hessvecs %d time %.2f s (rtr %.2f s)" % (
+        for mode in ("host", "device"):
+          t = time.time(); Y, obj, data = solvers.ManiSDP_unitdiag(At, b, c, K, {"eig": mode}, verbose=False); tg = time.time() - t
+          print("  eig=%s eig_s %.2f" % (mode, data["eig_seconds"]), end="")
+          print("  GPU solve: obj %.8f eta %.1e iters %d hessvecs %d time %.2f s (rtr %.2f s)" % (
             obj, max(data["gap"], data["pinf"], data["dinf"]), data["iters"], data["hessvecs"], tg, data["rtr_seconds"]), flush=True)
         if d <= 30:
             from oracle import manisdp_ref as R
