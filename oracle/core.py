@@ -25,8 +25,15 @@ def load():
     if _lib is None:
         if not os.path.exists(_PATH):
             subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _lib = C.CDLL(_PATH)
         _lib.oc_num_threads.restype = C.c_int
+        # at most 16 threads, never more than the CPUs this process may run on
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        _lib.oc_set_threads(max(1, min(16, avail)))
     return _lib
 
 

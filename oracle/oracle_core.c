@@ -32,6 +32,16 @@ typedef struct {
     int iters, hessvecs, accepted, rejected, cost_evals, last_stop_inner;
 } oc_stats;
 
+/* Cap the OpenMP team: on a many-core host (the GPU box reports 256 logical CPUs, possibly under a cgroup
+ * quota) a 256-thread team on these short row loops spends its time in barriers. */
+void oc_set_threads(int t) {
+#ifdef _OPENMP
+    if (t >= 1) omp_set_num_threads(t);
+#else
+    (void)t;
+#endif
+}
+
 int oc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
