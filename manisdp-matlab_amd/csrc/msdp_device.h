@@ -14,8 +14,11 @@
 __device__ __forceinline__ void msdp_chunk_rows(int n_loc, int G, int& lo, int& hi, int plain = 0) {
     const int b = blockIdx.x;
     const int c = plain ? b : (b & 7) * (G >> 3) + (b >> 3);
-    lo = (int)(((int64_t)n_loc * c) / G);
-    hi = (int)(((int64_t)n_loc * (c + 1)) / G);
+    // balanced split with one 32-bit division (a 64-bit n_loc*c/G costs ~350 instructions of preamble in
+    // every launch): the first n_loc % G chunks get one extra row
+    const unsigned q = (unsigned)n_loc / (unsigned)G, r = (unsigned)n_loc - q * (unsigned)G;
+    lo = (int)(c * q + ((unsigned)c < r ? (unsigned)c : r));
+    hi = lo + (int)q + ((unsigned)c < r ? 1 : 0);
 }
 
 // v moved by a DPP control (both halves of the double).

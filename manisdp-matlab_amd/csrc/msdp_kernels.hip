@@ -248,16 +248,37 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd1(Dev d) {
     double* __restrict__ nHeta = ix ? d.Heta[0] : d.Heta[1];
     const double* __restrict__ g = c->cur ? d.Gr[1] : d.Gr[0];
     const int64_t i0 = e0 + 2 * threadIdx.x;
+    // Every vector load of the first two passes is issued BEFORE the partial sums are re-reduced: the
+    // launch is a chain of dependent memory round trips (cold L2 at every kernel boundary), and this takes
+    // {partials} -> {vectors, pass 1} -> {vectors, pass 2} down to a single round trip.
+    constexpr int64_t STEP = 2 * MSDP_BLOCK;
+    const double2 zz = make_double2(0.0, 0.0);
+    double2 E[2], HE[2], M[2], HM[2], RR[2], GV[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int64_t i = i0 + q * STEP;
+        E[q] = HE[q] = M[q] = HM[q] = RR[q] = GV[q] = zz;
+        if (i < e1) {
+            E[q] = ld2(eta + i); HE[q] = ld2(Heta + i); M[q] = ld2(mdp + i); HM[q] = ld2(d.Hmd + i);
+            RR[q] = ld2(d.r + i); GV[q] = ld2(g + i);
+        }
+    }
     const double d_Hd = (d.variant & 64) ? msdp_sum_partials(d.P, P_DHD, d.G)
                                          : msdp_sum_partials_block(d.P, P_DHD, d.G, shb);       // :166
     const double alpha = z_r / d_Hd;                                 // :170
     const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;  // :173
     if (!bench && (d_Hd <= 0.0 || e_Pe_new >= Delta * Delta)) {         // :183
         const double tau = (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta * Delta - e_Pe))) / d_Pd;  // :188
-        for (int64_t i = i0; i < e1; i += 2 * MSDP_BLOCK) {
-            const double2 e = ld2(eta + i), he = ld2(Heta + i), m = ld2(mdp + i), hm = ld2(d.Hmd + i);
-            st2(neta + i, make_double2(e.x - tau * m.x, e.y - tau * m.y));       // :192
-            st2(nHeta + i, make_double2(he.x - tau * hm.x, he.y - tau * hm.y));  // :198
+        for (int64_t ib = i0; ib < e1; ib += 2 * STEP) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int64_t i = ib + q * STEP;
+                if (i < e1) {
+                    if (ib != i0) { E[q] = ld2(eta + i); HE[q] = ld2(Heta + i); M[q] = ld2(mdp + i); HM[q] = ld2(d.Hmd + i); }
+                    st2(neta + i, make_double2(E[q].x - tau * M[q].x, E[q].y - tau * M[q].y));        // :192
+                    st2(nHeta + i, make_double2(HE[q].x - tau * HM[q].x, HE[q].y - tau * HM[q].y));  // :198
+                }
+            }
         }
         if (lead) {
             frame_store(&d.F[1], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha0, beta0, 0, j + 1,
@@ -267,18 +288,27 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd1(Dev d) {
         return;
     }
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int64_t i = i0; i < e1; i += 2 * MSDP_BLOCK) {
-        const double2 e = ld2(eta + i), he = ld2(Heta + i), m = ld2(mdp + i), hm = ld2(d.Hmd + i);
-        const double2 rr = ld2(d.r + i), gv = ld2(g + i);
-        const double2 ne = make_double2(e.x - alpha * m.x, e.y - alpha * m.y);         // :215
-        const double2 nh = make_double2(he.x - alpha * hm.x, he.y - alpha * hm.y);     // :220
-        const double2 nr = make_double2(rr.x - alpha * hm.x, rr.y - alpha * hm.y);     // :238
-        st2(neta + i, ne);
-        st2(nHeta + i, nh);
-        st2(d.r + i, nr);
-        s1 += ne.x * gv.x + ne.y * gv.y;      // <new_eta, grad>     :227
-        s2 += ne.x * nh.x + ne.y * nh.y;      // <new_eta, new_Heta>
-        s3 += nr.x * nr.x + nr.y * nr.y;      // r_r                 :241
+    for (int64_t ib = i0; ib < e1; ib += 2 * STEP) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t i = ib + q * STEP;
+            if (i < e1) {
+                if (ib != i0) {
+                    E[q] = ld2(eta + i); HE[q] = ld2(Heta + i); M[q] = ld2(mdp + i); HM[q] = ld2(d.Hmd + i);
+                    RR[q] = ld2(d.r + i); GV[q] = ld2(g + i);
+                }
+                const double2 e = E[q], he = HE[q], m = M[q], hm = HM[q], rr = RR[q], gv = GV[q];
+                const double2 ne = make_double2(e.x - alpha * m.x, e.y - alpha * m.y);         // :215
+                const double2 nh = make_double2(he.x - alpha * hm.x, he.y - alpha * hm.y);     // :220
+                const double2 nr = make_double2(rr.x - alpha * hm.x, rr.y - alpha * hm.y);     // :238
+                st2(neta + i, ne);
+                st2(nHeta + i, nh);
+                st2(d.r + i, nr);
+                s1 += ne.x * gv.x + ne.y * gv.y;      // <new_eta, grad>     :227
+                s2 += ne.x * nh.x + ne.y * nh.y;      // <new_eta, new_Heta>
+                s3 += nr.x * nr.x + nr.y * nr.y;      // r_r                 :241
+            }
+        }
     }
     msdp_put_partials3(d.P, P_S1, s1, P_S2, s2, P_S3, s3, sh);
     if (lead)   // :214
@@ -311,6 +341,25 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd2_obl(Dev d) {
     constexpr int RPW = 64 / LPR;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
     const double* __restrict__ Yl = c->cur ? d.Y[1] : d.Y[0];
+    // rows of the first pass (two rows per lane group when NCH == 1) are loaded before the partial sums
+    // are re-reduced: one memory round trip instead of {partials} -> {rows, pass 1} -> {rows, pass 2}
+    constexpr int R = (NCH == 1) ? 2 : 1;
+    constexpr int RSTEP = MSDP_WAVES * RPW;
+    const int rowf = lo + wave * RPW;
+    double2 PR[R][NCH], PM[R][NCH], PY[R][NCH];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = rowf + r * RSTEP + rsub;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int col = 2 * sub + ch * 2 * LPR;
+            PR[r][ch] = PM[r][ch] = PY[r][ch] = make_double2(0.0, 0.0);
+            if (row < hi && col < d.ld) {
+                const int64_t o = (int64_t)row * d.ld + col;
+                PR[r][ch] = ld2(d.r + o); PM[r][ch] = ld2(d.md + o); PY[r][ch] = ld2(Yl + o);
+            }
+        }
+    }
     double s1, s2, r_r;
     if (!(d.variant & 64)) {
         msdp_sum_partials3_block(d.P, P_S1, P_S2, P_S3, d.G, shb, s1, s2, r_r);
@@ -356,29 +405,33 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd2_obl(Dev d) {
         msdp_publish(d, c->k, j, 1);
     }
     // mdelta = tangent(z + beta*mdelta), z = r   :273,283
-    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
-        const int row = row0 + rsub;
-        if (row < hi) {
-            double2 v[NCH], y[NCH];
-            double dot = 0.0;
+    for (int row0 = rowf; row0 < hi; row0 += R * RSTEP) {
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int col = 2 * sub + ch * 2 * LPR;
-                if (col < d.ld) {
-                    const int64_t o = (int64_t)row * d.ld + col;
-                    const double2 rr = ld2(d.r + o), m = ld2(d.md + o);
-                    y[ch] = ld2(Yl + o);
-                    v[ch] = make_double2(rr.x + beta * m.x, rr.y + beta * m.y);
-                    dot += v[ch].x * y[ch].x + v[ch].y * y[ch].y;
-                } else { v[ch] = make_double2(0.0, 0.0); y[ch] = v[ch]; }
-            }
-            dot = msdp_group_sum<LPR>(dot);
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r * RSTEP + rsub;
+            if (row < hi) {
+                double2 v[NCH], y[NCH];
+                double dot = 0.0;
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int col = 2 * sub + ch * 2 * LPR;
-                if (col < d.ld)
-                    st2(d.md + (int64_t)row * d.ld + col,
-                        make_double2(v[ch].x - y[ch].x * dot, v[ch].y - y[ch].y * dot));
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int col = 2 * sub + ch * 2 * LPR;
+                    if (col < d.ld) {
+                        const int64_t o = (int64_t)row * d.ld + col;
+                        if (row0 != rowf) { PR[r][ch] = ld2(d.r + o); PM[r][ch] = ld2(d.md + o); PY[r][ch] = ld2(Yl + o); }
+                        const double2 rr = PR[r][ch], m = PM[r][ch];
+                        y[ch] = PY[r][ch];
+                        v[ch] = make_double2(rr.x + beta * m.x, rr.y + beta * m.y);
+                        dot += v[ch].x * y[ch].x + v[ch].y * y[ch].y;
+                    } else { v[ch] = make_double2(0.0, 0.0); y[ch] = v[ch]; }
+                }
+                dot = msdp_group_sum<LPR>(dot);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int col = 2 * sub + ch * 2 * LPR;
+                    if (col < d.ld)
+                        st2(d.md + (int64_t)row * d.ld + col,
+                            make_double2(v[ch].x - y[ch].x * dot, v[ch].y - y[ch].y * dot));
+                }
             }
         }
     }
