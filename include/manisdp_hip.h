@@ -192,6 +192,12 @@ int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const void* id12
 /* Local row range [row0, row1) of this rank. */
 int msdp_local_rows(msdp_handle h, int64_t* row0, int64_t* row1);
 
+/* Which implementation msdp_rtr uses for the tCG inner loop at the resident point:
+ * 1 = persistent single-launch kernel (working set in registers/LDS, sparse C, oblique,
+ * one rank, n and p small enough to stay on chip), 0 = chunked hipGraph of three kernels
+ * per trip.  Both follow tCG.m:95-292; the choice is a speed matter only. */
+int msdp_tcg_path(msdp_handle h, int32_t* path);
+
 /* ------------------------------------------------------------ measurement */
 
 /* Launch the Hess-vec kernel `reps` times on the library's stream between two

@@ -78,6 +78,7 @@ SIGNATURES = {
     "msdp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "msdp_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "msdp_local_rows": (C.c_int, [C.c_void_p, _i64p, _i64p]),
+    "msdp_tcg_path": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "msdp_bench_hessvec": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
     "msdp_bench_tcg_trip": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "msdp_bench_kernel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
@@ -314,6 +315,12 @@ class Handle:
         a, b = C.c_int64(), C.c_int64()
         _check(self._lib.msdp_local_rows(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def tcg_path(self):
+        """1: persistent single-launch tCG kernel, 0: chunked hipGraph (three kernels per trip)."""
+        v = C.c_int32()
+        _check(self._lib.msdp_tcg_path(self._h, C.byref(v)))
+        return v.value
 
     # ---- measurement
     def bench_hessvec(self, reps):

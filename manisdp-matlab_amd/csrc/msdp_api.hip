@@ -136,6 +136,13 @@ static int alloc_common(msdp_handle h) {
     HIPCHK(hipMemset(d.ctl, 0, sizeof(Ctl)));
     HIPCHK(hipMemset(d.F, 0, 2 * sizeof(Frame)));
     HIPCHK(hipMemset(d.P, 0, (size_t)MSDP_NPART * MSDP_MAX_GRID * sizeof(double)));
+    {
+        char* ps = nullptr;
+        if ((rc = dev_alloc<char>(h, &ps, msdp_psync_bytes()))) return rc;
+        h->psync_slots = (unsigned long long*)ps;
+        if ((rc = dev_alloc<int>(h, &h->psync_err, 1))) return rc;
+        HIPCHK(hipMemset(h->psync_err, 0, sizeof(int)));
+    }
     const size_t rows = (size_t)rows_capacity(h);
     for (int s = 0; s < 2; ++s) {
         if (d.eG[s]) dev_free(h, d.eG[s]);
@@ -209,6 +216,9 @@ static int upload_sparse_rows(msdp_handle h) {
     d.ellW = 0; d.ellc = nullptr; d.ellv = nullptr;
     const char* noell = getenv("MSDP_NO_ELL");
     if (W >= 1 && W <= 8 && !(noell && atoi(noell))) {
+        // stored width 5 or 8 (the persistent tCG kernel is instantiated for these and loads every slice
+        // without a branch); the padding entries are (own row, 0.0)
+        W = W <= 5 ? 5 : 8;
         const size_t cap = (size_t)rows_capacity(h);
         std::vector<int> ec((size_t)W * cap);
         std::vector<double> ev((size_t)W * cap, 0.0);
@@ -550,6 +560,17 @@ extern "C" int msdp_local_rows(msdp_handle h, int64_t* row0, int64_t* row1) {
     return 0;
 }
 
+extern "C" int msdp_tcg_path(msdp_handle h, int32_t* path) {
+    CHECK_H(h);
+    if (!path) return MSDP_EINVAL;
+    if (!h->have_point) { msdp_set_error("tcg_path: no resident point"); return MSDP_ESTATE; }
+    const char* e1 = getenv("MSDP_SYNC_TR");
+    const char* e2 = getenv("MSDP_NO_PUBLISH");
+    const bool async_ok = !(e1 && atoi(e1)) && !(e2 && atoi(e2));
+    *path = (async_ok && msdp_persist_eligible(h)) ? 1 : 0;
+    return 0;
+}
+
 // ------------------------------------------------------------------ RTR driver
 static int push_ctl(msdp_handle h) {
     HIPCHK(hipMemcpyAsync(h->d.ctl, h->h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, h->stream));
@@ -744,7 +765,51 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
     double t_tcg = 0.0, t_rest = 0.0;
     const char* nopub_env = getenv("MSDP_NO_PUBLISH");
     const bool async_tr = !sync_tr && h->d.costkind == COST_SPARSE && !h->use_comm && !(nopub_env && atoi(nopub_env));
-    if (async_tr) {
+    if (async_tr && msdp_persist_eligible(h)) {
+        // Persistent path: one launch runs the whole tCG of a TR iteration with the working set on chip
+        // (msdp_persist.hip).  The host stays one TR iteration ahead of the device: iteration i+1 is enqueued
+        // as soon as the kernel of iteration i publishes that it has started; a finished solve (ctl->done)
+        // turns everything still enqueued into no-ops and is reported through the same progress word.
+        auto enqueue_iter = [&]() -> int {
+            int r2;
+            if ((r2 = msdp_launch_tcg_persist(h))) return r2;             // trustregions.m:484-496 + tCG.m
+            if ((r2 = msdp_launch_retract(h))) return r2;                 // :540
+            if ((r2 = msdp_launch_costgrad(h, 3))) return r2;             // :544 (proposal slot, device-resolved)
+            return msdp_launch_rtr_decide(h);                             // :548-729
+        };
+        int enq = 0;
+        bool done = false;
+        const auto ta = std::chrono::steady_clock::now();
+        if (opts->maxiter > 0) { if ((rc = enqueue_iter())) return rc; enq = 1; }
+        while (enq > 0 && !done) {
+            const unsigned long long want = (unsigned long long)(unsigned)enq;
+            long spins = 0;
+            for (;;) {
+                const unsigned long long s = *h->h_status;
+                if ((s >> 32) == want) { if (((s & 0xffffffffULL) >> 1) & 0x40000000) done = true; break; }
+                if ((++spins & 0xfff) == 0) {
+                    if (hipStreamQuery(h->stream) == hipSuccess) {
+                        const unsigned long long s2 = *h->h_status;
+                        if ((s2 >> 32) == want) { if (((s2 & 0xffffffffULL) >> 1) & 0x40000000) done = true; break; }
+                        msdp_set_error("persistent tCG: progress word inconsistent (status %llx, expected iteration %d)", s2, enq);
+                        return MSDP_EHIP;
+                    }
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count() > 300.0) {
+                        msdp_set_error("persistent tCG made no progress for 300 s");
+                        return MSDP_EHIP;
+                    }
+                }
+            }
+            if (done || enq >= opts->maxiter) break;
+            if ((rc = enqueue_iter())) return rc;
+            ++enq;
+        }
+        if ((rc = pull_ctl(h))) return rc;
+        int perr = 0;
+        HIPCHK(hipMemcpy(&perr, h->psync_err, sizeof(int), hipMemcpyDeviceToHost));
+        if (perr) { msdp_set_error("persistent tCG: grid synchronisation timed out"); return MSDP_EHIP; }
+        t_tcg = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+    } else if (async_tr) {
         // No host sync between TR iterations: the proposal slot is resolved on the device, the next
         // iteration's tcg_init + first chunks are enqueued right behind k_rtr_decide, and k_tcg_init
         // publishes `done` through the progress word (a finished solve turns everything enqueued into no-ops).
@@ -1092,6 +1157,38 @@ extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms) 
     fill_ctl(h, &o);
     h->h_ctl->bench_mode = 1;
     h->d.fused = fused_enabled(h) ? 1 : 0;
+    if (msdp_persist_eligible(h) && !getenv("MSDP_BENCH_CLASSIC")) {
+        // persistent kernel: `reps` trips with the exits disabled in one launch (run twice, time the second)
+        h->h_ctl->maxinner = reps;
+        if ((rc = push_ctl(h))) return rc;
+        if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
+        if ((rc = msdp_launch_rtr_begin(h))) return rc;
+        h->d.status = nullptr;
+        rc = msdp_launch_tcg_persist(h);
+        if (!rc) {
+            hipError_t e1 = hipEventRecord(h->ev0, h->stream);
+            rc = msdp_launch_tcg_persist(h);
+            hipError_t e2 = hipEventRecord(h->ev1, h->stream);
+            hipError_t e3 = hipEventSynchronize(h->ev1);
+            float ms = 0.f;
+            hipError_t e4 = hipEventElapsedTime(&ms, h->ev0, h->ev1);
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) { msdp_set_error("bench events failed"); rc = MSDP_EHIP; }
+            *avg_ms = (double)ms / reps;
+        }
+        {
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, (void*)h->h_status, 0) == hipSuccess) h->d.status = (unsigned long long*)dp;
+        }
+        h->h_ctl->bench_mode = 0;
+        h->h_ctl->done = 0;
+        int rc2 = push_ctl(h);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->state_valid = false;
+        int perr = 0;
+        HIPCHK(hipMemcpy(&perr, h->psync_err, sizeof(int), hipMemcpyDeviceToHost));
+        if (perr) { msdp_set_error("persistent tCG: grid synchronisation timed out"); return MSDP_EHIP; }
+        return rc ? rc : rc2;
+    }
     if ((rc = push_ctl(h))) return rc;
     if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
     if ((rc = msdp_launch_rtr_begin(h))) return rc;

@@ -137,6 +137,10 @@ struct msdp_handle_s {
     volatile unsigned long long* h_status = nullptr;   // host view of Dev::status
     double* slab = nullptr;        // split-K partial slabs of the dense MFMA path
     size_t slab_cap = 0;
+    // persistent tCG kernel (msdp_persist.hip): grid-sync slots, error flag, cached eligibility
+    unsigned long long* psync_slots = nullptr;
+    int* psync_err = nullptr;
+    int persist_sig_lpr = 0, persist_sig_ew = 0, persist_sig_r = 0, persist_sig_G = 0, persist_sig_ok = 0;
 };
 
 // --- launchers implemented in the .hip units (all asynchronous on h->stream) ---
@@ -150,5 +154,8 @@ int msdp_launch_retract(msdp_handle h);                       // Y[cur]+eta -> Y
 int msdp_launch_rtr_begin(msdp_handle h);
 int msdp_launch_rtr_decide(msdp_handle h);
 int msdp_alloc_vectors(msdp_handle h, int pcap);
+int msdp_persist_eligible(msdp_handle h);                     // msdp_persist.hip
+int msdp_launch_tcg_persist(msdp_handle h);                   // whole tCG of the current TR iteration, one launch
+size_t msdp_psync_bytes();
 int msdp_allreduce_partials(msdp_handle h, int first, int count);   // no-op when nranks == 1
 int msdp_allgather_rows(msdp_handle h, const double* local_rows);   // local -> d.full

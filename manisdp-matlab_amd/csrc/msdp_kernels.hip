@@ -184,17 +184,6 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_hess_sparse_obl(Dev d) { hess_sp
 template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_hess_ell_obl(Dev d) { hess_sparse_obl_body<LPR, NCH, true>(d); }
 
-// Frame fields are read one by one into scalars and written field by field by the lead
-// thread: a by-value Frame copy is lowered through per-thread LDS/scratch by hipcc and
-// cost 10 us per launch (measured: 19.3 -> 9.4 us for k_tcg_upd1).
-__device__ __forceinline__ void frame_store(Frame* o, double z_r, double d_Pd, double e_Pd, double e_Pe,
-                                            double model_value, double norm_r0, double alpha, double beta,
-                                            int active, int j, int stop, int eta_idx, int md_idx = 0, int fresh = 0) {
-    o->z_r = z_r; o->d_Pd = d_Pd; o->e_Pd = e_Pd; o->e_Pe = e_Pe; o->model_value = model_value;
-    o->norm_r0 = norm_r0; o->alpha = alpha; o->beta = beta;
-    o->active = active; o->j = j; o->stop = stop; o->eta_idx = eta_idx; o->md_idx = md_idx; o->fresh = fresh;
-}
-
 // ------------------------------------------------------------------ tCG kernels
 // tCG.m:102-157: eta=0, Heta=0, r=grad, mdelta=r, scalars.
 __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_init(Dev d) {

@@ -1,0 +1,460 @@
+// msdp_persist.hip -- the whole truncated-CG solve of one trust-region iteration in ONE launch
+// (sparse C, oblique manifold, single rank): tCG.m:95-292 with the working set on chip.
+//
+// Why: at n = 20000, p = 32 every tCG vector is 5 MB and the whole working set (eta, Heta, r, mdelta,
+// Hmdelta, Y, grad: 36 MB) fits in the register files + LDS of the 256 CUs (128 MB + 40 MB).  The
+// three-launch trip (k_hess / k_tcg_upd1 / k_tcg_upd2) streams ~83 MB through HBM/MALL per trip and pays
+// three launch gaps; here each workgroup keeps ITS rows of every vector in registers (eta, r, mdelta,
+// Hmdelta) and LDS (Y, grad, eG and the ELL rows of C) for the whole solve.  The only global traffic per
+// trip is the new direction (written once, gathered by the neighbours' S*U) and the partial sums of the
+// three reductions, which double as grid barriers.
+//
+// Grid synchronisation = deterministic all-to-all reduction: every workgroup stores its partial sums
+// into its own slot of a generation buffer (agent-scope atomic store), then wave 0 of every workgroup
+// polls all G slots until none holds the sentinel and sums them in the same fixed order (the order of
+// msdp_sum_partials), so all workgroups take bit-identical decisions.  Three generation buffers rotate;
+// a workgroup resets its slot of the previous generation after it has passed the current one (at that
+// point every workgroup has finished reading it).  All G workgroups must be co-resident: G <= number of
+// CUs and one 1024-thread workgroup per CU (checked on the host with the occupancy API); a bounded spin
+// turns a would-be hang into an error flag.
+//
+// Reference lines are quoted next to the statements (manopt7.0/manopt/solvers/trustregions/tCG.m);
+// cost/projection expressions are those of ManiSDP_onlyunitdiag.m:127-156.
+#include "msdp_device.h"
+#include <math.h>
+#include <cstdlib>
+
+#define PSYNC_NV 4                       // value arrays per generation
+#define PSYNC_GEN 3
+#define PSYNC_SENT 0xFFF8DEADBEEF0001ULL  // NaN payload no arithmetic produces
+#define PSYNC_SPIN_LIMIT (1 << 22)
+// 512 threads per workgroup, one workgroup per CU: 2 waves per SIMD, i.e. a 256-register budget per lane
+// for the resident rows (1024-thread workgroups leave 128 and spill)
+#define PB 512
+#define PWAVES (PB / 64)
+
+// Rows of the new direction are exchanged between workgroups on different XCDs (one L2 each) inside the launch.
+// Agent-scope release/acquire fences (buffer_wbl2 / buffer_inv sc1 by every wave) were measured at 37 us per
+// trip; instead the exchanged rows are written and gathered with sc1 (agent-coherent) buffer accesses, which
+// the other L2s never hold stale, and ordered by the grid reduction that follows the stores.
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+#define MSDP_CPOL_SC1 16
+__device__ __forceinline__ double2 ld2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, MSDP_CPOL_SC1);
+    double2 o;
+    o.x = __longlong_as_double(((long long)v.y << 32) | (long long)v.x);
+    o.y = __longlong_as_double(((long long)v.w << 32) | (long long)v.z);
+    return o;
+}
+__device__ __forceinline__ void st2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, double2 d2) {
+    const long long a = __double_as_longlong(d2.x), b = __double_as_longlong(d2.y);
+    v4u v;
+    v.x = (unsigned)(a & 0xffffffffLL); v.y = (unsigned)((unsigned long long)a >> 32);
+    v.z = (unsigned)(b & 0xffffffffLL); v.w = (unsigned)((unsigned long long)b >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, MSDP_CPOL_SC1);
+}
+
+size_t msdp_psync_bytes() { return (size_t)PSYNC_GEN * PSYNC_NV * MSDP_MAX_GRID * sizeof(double); }
+
+__global__ void k_psync_reset(unsigned long long* slots, int* err) {
+    const int tot = PSYNC_GEN * PSYNC_NV * MSDP_MAX_GRID;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += gridDim.x * blockDim.x) slots[i] = PSYNC_SENT;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *err = 0;
+}
+
+// Reduce (a, b, c) over the whole grid; nv = number of meaningful values (1 or 3).  Returns false when the
+// spin bound was hit (error flag set; the caller leaves the kernel).
+__device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, int G, int nv, double& a, double& b,
+                                      double& c, double* sh, double* shb, int* err) {
+    a = msdp_wave_sum(a);
+    if (nv > 1) { b = msdp_wave_sum(b); c = msdp_wave_sum(c); }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sh[w] = a; sh[PWAVES + w] = b; sh[2 * PWAVES + w] = c; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned long long* base = slots + (size_t)(gen % PSYNC_GEN) * PSYNC_NV * MSDP_MAX_GRID;
+        if (lane < nv) {
+            double s = 0.0;
+            for (int i = 0; i < PWAVES; ++i) s += sh[lane * PWAVES + i];
+            // the reset store of this slot's other generations (issued one sync ago) must have been performed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(base + lane * MSDP_MAX_GRID + blockIdx.x, (unsigned long long)__double_as_longlong(s),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        double r0, r1 = 0.0, r2 = 0.0;
+        int spins = 0;
+        bool fail = false;
+        const unsigned long long* p0 = base + lane;
+        for (;;) {
+            // all slot loads of one poll are issued back to back with ONE wait (the compiler puts a full
+            // s_waitcnt after every atomic load: 12 serialized round trips per poll, measured 20 us per sync)
+            unsigned long long b0[4], b1[4], b2[4];
+            if (nv > 1) {
+                const unsigned long long* p1 = p0 + MSDP_MAX_GRID;
+                const unsigned long long* p2 = p0 + 2 * MSDP_MAX_GRID;
+                asm volatile(
+                    "global_load_dwordx2 %0, %12, off sc1\n\t"
+                    "global_load_dwordx2 %1, %12, off offset:512 sc1\n\t"
+                    "global_load_dwordx2 %2, %12, off offset:1024 sc1\n\t"
+                    "global_load_dwordx2 %3, %12, off offset:1536 sc1\n\t"
+                    "global_load_dwordx2 %4, %13, off sc1\n\t"
+                    "global_load_dwordx2 %5, %13, off offset:512 sc1\n\t"
+                    "global_load_dwordx2 %6, %13, off offset:1024 sc1\n\t"
+                    "global_load_dwordx2 %7, %13, off offset:1536 sc1\n\t"
+                    "global_load_dwordx2 %8, %14, off sc1\n\t"
+                    "global_load_dwordx2 %9, %14, off offset:512 sc1\n\t"
+                    "global_load_dwordx2 %10, %14, off offset:1024 sc1\n\t"
+                    "global_load_dwordx2 %11, %14, off offset:1536 sc1\n\t"
+                    "s_waitcnt vmcnt(0)"
+                    : "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3]), "=&v"(b1[0]), "=&v"(b1[1]), "=&v"(b1[2]),
+                      "=&v"(b1[3]), "=&v"(b2[0]), "=&v"(b2[1]), "=&v"(b2[2]), "=&v"(b2[3])
+                    : "v"(p0), "v"(p1), "v"(p2)
+                    : "memory");
+            } else {
+                asm volatile(
+                    "global_load_dwordx2 %0, %4, off sc1\n\t"
+                    "global_load_dwordx2 %1, %4, off offset:512 sc1\n\t"
+                    "global_load_dwordx2 %2, %4, off offset:1024 sc1\n\t"
+                    "global_load_dwordx2 %3, %4, off offset:1536 sc1\n\t"
+                    "s_waitcnt vmcnt(0)"
+                    : "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3])
+                    : "v"(p0)
+                    : "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { b1[q] = 0ULL; b2[q] = 0ULL; }
+            }
+            bool ok = true;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (lane + 64 * q < G) {                                   // slots >= G hold the sentinel for ever
+                    ok = ok && b0[q] != PSYNC_SENT && b1[q] != PSYNC_SENT && b2[q] != PSYNC_SENT;
+                    t0 += __longlong_as_double((long long)b0[q]);         // same order as msdp_sum_partials
+                    t1 += __longlong_as_double((long long)b1[q]);
+                    t2 += __longlong_as_double((long long)b2[q]);
+                }
+            }
+            r0 = t0; r1 = t1; r2 = t2;
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ULL) break;
+            ++spins;
+            if (spins > PSYNC_SPIN_LIMIT ||
+                ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
+        }
+        r0 = msdp_wave_sum(r0);
+        if (nv > 1) { r1 = msdp_wave_sum(r1); r2 = msdp_wave_sum(r2); }
+        if (lane == 0) {
+            shb[0] = r0; shb[1] = r1; shb[2] = r2; shb[3] = fail ? 1.0 : 0.0;
+            if (fail) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // everybody has finished reading the previous generation (they all posted this one): reset my slots of it
+        if (lane < PSYNC_NV)
+            __hip_atomic_store(slots + (size_t)((gen + PSYNC_GEN - 1) % PSYNC_GEN) * PSYNC_NV * MSDP_MAX_GRID +
+                                   lane * MSDP_MAX_GRID + blockIdx.x,
+                               PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    a = shb[0]; b = shb[1]; c = shb[2];
+    return shb[3] == 0.0;
+}
+
+// LPR lanes per row (one double2 per lane), EW = stored ELL width, R = row slots per lane group.
+template <int LPR, int EW, int R>
+__global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long long* slots, int* err) {
+    extern __shared__ double lds[];
+    __shared__ double sh[3 * PWAVES];
+    __shared__ double shb[4];
+    constexpr int RPW = 64 / LPR;
+    constexpr int RSTEP = PWAVES * RPW;       // rows per pass of the workgroup
+    constexpr int ROWS = R * RSTEP;               // row slots of the workgroup
+    double2* Ys = reinterpret_cast<double2*>(lds);                 // [R][PB]
+    double2* Gs = Ys + R * PB;                             // [R][PB]
+    double* eGs = reinterpret_cast<double*>(Gs + R * PB);  // [ROWS]
+    double* vs = eGs + ROWS;                                       // [EW][ROWS]
+    int* cs = reinterpret_cast<int*>(vs + EW * ROWS);              // [EW][ROWS]
+
+    const Ctl* c = d.ctl;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    const int k_tr = c->k;
+    if (c->done) {                                                 // same as k_tcg_init on a finished solve
+        if (lead) {
+            frame_store(&d.F[0], c->gg, c->gg, 0.0, 0.0, 0.0, sqrt(c->gg), 0.0, 0.0, 0, 0, 5, 0, 0, 1);
+            d.ctl->tcg_running = 0;
+            msdp_publish(d, k_tr, 0, 0);
+        }
+        return;
+    }
+    if (lead) msdp_publish(d, k_tr, 0, 1);                         // "TR iteration k_tr has started" (host pipelining)
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    const bool colok = 2 * sub < d.ld;
+    const int cur = c->cur;
+    const bool bench = c->bench_mode != 0;
+    const double Delta = c->Delta, kappa = c->kappa, theta = c->theta;
+    const int mininner = c->mininner, maxinner = c->maxinner;
+    const double gg = c->gg;
+    const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
+    const double* __restrict__ gl = cur ? d.Gr[1] : d.Gr[0];
+    const double* __restrict__ eGl = cur ? d.eG[1] : d.eG[0];
+
+    // row slot r of this lane group: slot = r*RSTEP + slot0, row = lo + slot (recomputed where needed: arrays
+    // of R row indices / flags would sit in registers next to the resident rows)
+    const int slot0 = wave * RPW + rsub;
+#define SLOT(r) ((r) * RSTEP + slot0)
+#define ROW(r) (lo + SLOT(r))
+#define ROK(r) (ROW(r) < hi)
+#define OK(r) (ROK(r) && colok)
+    double2 eta[R], rr[R], md[R], hmd[R];
+    const double2 zz = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        // unconditional loads from a clamped row (then masked): branches around the loads serialise them
+        const bool rok = ROK(r);
+        const int rc = rok ? ROW(r) : lo;
+        const int64_t o = (int64_t)rc * d.ld + (colok ? 2 * sub : 0);
+        double2 y = ld2(Yl + o), g = ld2(gl + o);
+        if (!OK(r)) { y = zz; g = zz; }
+        Ys[r * PB + threadIdx.x] = y;
+        Gs[r * PB + threadIdx.x] = g;
+        eta[r] = zz; rr[r] = g; md[r] = g; hmd[r] = zz;           // tCG.m:102-157
+        const double egv = eGl[rc];
+        int cw[EW];
+        double vw[EW];
+#pragma unroll
+        for (int w = 0; w < EW; ++w) {
+            cw[w] = d.ellc[(int64_t)w * d.ell_stride + rc];
+            vw[w] = d.ellv[(int64_t)w * d.ell_stride + rc];
+        }
+        if (sub == 0) {
+            eGs[SLOT(r)] = rok ? egv : 0.0;
+#pragma unroll
+            for (int w = 0; w < EW; ++w) {
+                cs[w * ROWS + SLOT(r)] = cw[w];
+                vs[w * ROWS + SLOT(r)] = rok ? vw[w] : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+
+    double z_r = gg, d_Pd = gg, e_Pd = 0.0, e_Pe = 0.0, model_value = 0.0, alpha = 0.0, beta = 0.0;
+    const double norm_r0 = sqrt(gg);
+    int j = 0, stop = 5;
+    unsigned gen = 0;
+    // first direction = gradient: already in global memory (written by an earlier launch); later trips gather the
+    // rows the other workgroups stored with sc1 during this launch
+    const unsigned vec_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
+    __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(gl), 0, vec_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(d.md, 0, vec_bytes, 0x00020000);
+    bool first = true;
+    bool failed = false;
+    for (;;) {
+        // ---- Hmdelta = proj(C*mdelta) - mdelta.*eG   (tCG.m:163, ManiSDP_onlyunitdiag.m:127-130)
+        double pd = 0.0, u1 = 0.0, u2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double2 x[EW];
+            double v[EW];
+#pragma unroll
+            for (int w = 0; w < EW; ++w) {
+                const int cidx = cs[w * ROWS + SLOT(r)];
+                v[w] = vs[w * ROWS + SLOT(r)];
+                const unsigned off = ((unsigned)cidx * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u;
+                x[w] = first ? ld2_sc1(rs_g, off) : ld2_sc1(rs_md, off);
+            }
+            double2 acc = zz;
+#pragma unroll
+            for (int w = 0; w < EW; ++w) {
+                acc.x = fma(v[w], x[w].x, acc.x);
+                acc.y = fma(v[w], x[w].y, acc.y);
+            }
+            if (!colok) acc = zz;
+            const double2 y = Ys[r * PB + threadIdx.x];
+            double dot = acc.x * y.x + acc.y * y.y;
+            dot = msdp_group_sum<LPR>(dot);
+            const double eg = eGs[SLOT(r)];
+            hmd[r].x = acc.x - y.x * dot - md[r].x * eg;
+            hmd[r].y = acc.y - y.y * dot - md[r].y * eg;
+            if (!OK(r)) hmd[r] = zz;
+            pd += md[r].x * hmd[r].x + md[r].y * hmd[r].y;
+            // R = 8 keeps 128 registers of resident rows: do not let the scheduler hoist all 40 gathers (160
+            // more registers) above the first use; two rows (10 gathers) in flight per wave
+            if (R > 4 && (r & 1)) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!psync(slots, gen++, d.G, 1, pd, u1, u2, sh, shb, err)) { failed = true; break; }
+        const double d_Hd = pd;                                                        // :166
+        alpha = z_r / d_Hd;                                                            // :170
+        const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;      // :173
+        if (!bench && (d_Hd <= 0.0 || e_Pe_new >= Delta * Delta)) {                    // :183
+            const double tau = (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta * Delta - e_Pe))) / d_Pd;   // :188
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                eta[r].x -= tau * md[r].x; eta[r].y -= tau * md[r].y;                  // :192
+                rr[r].x -= tau * hmd[r].x; rr[r].y -= tau * hmd[r].y;                  // :198 (Heta = r - grad)
+            }
+            stop = (d_Hd <= 0.0) ? 1 : 2;
+            ++j;
+            break;
+        }
+        // ---- trial step and its three inner products (tCG.m:215-241)
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double2 g = Gs[r * PB + threadIdx.x];
+            const double2 ne = make_double2(eta[r].x - alpha * md[r].x, eta[r].y - alpha * md[r].y);     // :215
+            const double2 nr = make_double2(rr[r].x - alpha * hmd[r].x, rr[r].y - alpha * hmd[r].y);    // :238
+            const double2 nh = make_double2(nr.x - g.x, nr.y - g.y);                                     // new_Heta (:220)
+            s1 += ne.x * g.x + ne.y * g.y;
+            s2 += ne.x * nh.x + ne.y * nh.y;
+            s3 += nr.x * nr.x + nr.y * nr.y;
+        }
+        if (!psync(slots, gen++, d.G, 3, s1, s2, s3, sh, shb, err)) { failed = true; break; }
+        e_Pe = e_Pe_new;
+        const double new_model = s1 + 0.5 * s2;                                        // :227
+        const double r_r = s3;
+        if (!bench && new_model >= model_value) { stop = 6; ++j; break; }              // :228 (eta, Heta stay)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {                                                  // :233-238 commit (same bits as the trial)
+            eta[r].x -= alpha * md[r].x; eta[r].y -= alpha * md[r].y;
+            rr[r].x -= alpha * hmd[r].x; rr[r].y -= alpha * hmd[r].y;
+        }
+        model_value = new_model;
+        ++j;
+        const double norm_r = sqrt(r_r);
+        const double nr0t = (theta == 1.0) ? norm_r0 : pow(norm_r0, theta);
+        if (!bench && j >= mininner && norm_r <= norm_r0 * fmin(nr0t, kappa)) {       // :249
+            stop = (kappa < nr0t) ? 3 : 4;
+            break;
+        }
+        if (j >= maxinner) break;                                                      // :160 (stop stays 5)
+        beta = r_r / z_r;                                                              // :272
+        e_Pd = beta * (e_Pd + alpha * d_Pd);                                           // :286
+        d_Pd = r_r + beta * beta * d_Pd;                                               // :287
+        z_r = r_r;
+        // ---- mdelta = tangent(r + beta*mdelta)  (:273,283) and hand the new rows to the neighbours
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double2 y = Ys[r * PB + threadIdx.x];
+            const double2 v = make_double2(rr[r].x + beta * md[r].x, rr[r].y + beta * md[r].y);
+            double dot = v.x * y.x + v.y * y.y;
+            dot = msdp_group_sum<LPR>(dot);
+            md[r] = make_double2(v.x - y.x * dot, v.y - y.y * dot);
+            if (OK(r)) st2_sc1(rs_md, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, md[r]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my rows are performed before my workgroup posts
+        double t0 = 0.0;
+        if (!psync(slots, gen++, d.G, 1, t0, u1, u2, sh, shb, err)) { failed = true; break; }
+        first = false;
+    }
+    if (failed) return;
+    // ---- hand eta, Heta = r - grad and the final scalars to the RTR kernels (trustregions.m:540-550)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (OK(r)) {
+            const int64_t o = (int64_t)ROW(r) * d.ld + 2 * sub;
+            const double2 g = Gs[r * PB + threadIdx.x];
+            st2(d.eta[0] + o, eta[r]);
+            st2(d.Heta[0] + o, make_double2(rr[r].x - g.x, rr[r].y - g.y));
+        }
+    }
+    if (lead) {
+        frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha, beta, 0, j, stop, 0, 0, 0);
+        d.ctl->tcg_running = 0;
+        msdp_publish(d, k_tr, j, 0);
+    }
+}
+
+#undef SLOT
+#undef ROW
+#undef ROK
+#undef OK
+
+// ------------------------------------------------------------------ host side
+struct PersistPlan { int lpr, ew, r; size_t lds; };
+
+static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
+    if (d.ellW < 1 || d.ellW > 8) return false;
+    int half = d.ld / 2, lpr = 1;
+    while (lpr < half && lpr < 64) lpr <<= 1;
+    if (half > 32) return false;                       // p <= 64: the resident rows must fit the register budget
+    if (lpr < 8) lpr = 8;
+    pl.lpr = lpr;
+    pl.ew = d.ellW <= 5 ? 5 : 8;
+    pl.r = lpr / 4;                                    // 128 row slots per workgroup
+    const int rstep = PWAVES * (64 / lpr);
+    const int need = (d.n_loc + G - 1) / G;
+    if (need > pl.r * rstep) return false;
+    const size_t rows = (size_t)pl.r * rstep;
+    pl.lds = (size_t)2 * pl.r * PB * sizeof(double2) + rows * sizeof(double) + (size_t)pl.ew * rows * (sizeof(double) + sizeof(int));
+    return true;
+}
+
+typedef void (*persist_fn)(Dev, unsigned long long*, int*);
+static persist_fn persist_kernel(const PersistPlan& pl) {
+#define PK(L, E) if (pl.lpr == L && pl.ew == E && pl.r == L / 4) return k_tcg_persist_obl<L, E, L / 4>;
+    PK(8, 5) PK(8, 8) PK(16, 5) PK(16, 8) PK(32, 5) PK(32, 8)
+#undef PK
+    return nullptr;
+}
+
+// The persistent kernel has its own grid: at most one workgroup per CU (co-residency), independent of the grid
+// of the row-parallel kernels around it (those exchange data through global memory only).
+static int persist_grid(const Dev& d) {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = v;
+        else cus = 0;
+        (void)hipGetLastError();
+    }
+    int g = d.G;
+    if (g > cus) g = (cus / 8) * 8;
+    if (g > 256) g = 256;                              // psync polls 4 x 64 slots
+    return g;
+}
+
+// 1: the persistent kernel can run this handle's tCG (and all its workgroups are co-resident); 0: use the chunked path
+int msdp_persist_eligible(msdp_handle h) {
+    const Dev& d = h->d;
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("MSDP_NO_PERSIST"); off = (e && atoi(e)) ? 1 : 0; }
+    if (off || h->use_comm || h->nranks != 1 || d.costkind != COST_SPARSE || d.manifold != MANI_OBLIQUE) return 0;
+    if (!h->psync_slots) return 0;
+    const int G = persist_grid(d);
+    if (G < 8) return 0;
+    PersistPlan pl;
+    if (!persist_plan(d, G, pl)) return 0;
+    persist_fn fn = persist_kernel(pl);
+    if (!fn) return 0;
+    // the ELL copy must be stored with the width the kernel is instantiated for
+    if (d.ellW != pl.ew) return 0;
+    if (h->persist_sig_lpr == pl.lpr && h->persist_sig_ew == pl.ew && h->persist_sig_r == pl.r && h->persist_sig_G == G)
+        return h->persist_sig_ok;
+    int ok = 0;
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, PB, pl.lds) == hipSuccess)
+        ok = (per_cu >= 1 && cus >= G) ? 1 : 0;        // one workgroup per CU: never rely on two sharing a CU
+    (void)hipGetLastError();
+    h->persist_sig_lpr = pl.lpr; h->persist_sig_ew = pl.ew; h->persist_sig_r = pl.r; h->persist_sig_G = G;
+    h->persist_sig_ok = ok;
+    return ok;
+}
+
+int msdp_launch_tcg_persist(msdp_handle h) {
+    const int G = persist_grid(h->d);
+    PersistPlan pl;
+    if (!persist_plan(h->d, G, pl)) { msdp_set_error("persistent tCG: not eligible"); return MSDP_ESTATE; }
+    persist_fn fn = persist_kernel(pl);
+    if (!fn) { msdp_set_error("persistent tCG: no kernel instance"); return MSDP_ESTATE; }
+    Dev dp = h->d;
+    dp.G = G;
+    hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, h->stream, h->psync_slots, h->psync_err);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(fn, dim3(G), dim3(PB), pl.lds, h->stream, dp, h->psync_slots, h->psync_err);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

@@ -162,7 +162,70 @@ def test_fused_trip_matches_classic(lib, monkeypatch):
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for fused in ("0", "1"):
-        env = dict(os.environ, MSDP_FUSED=fused)
+        env = dict(os.environ, MSDP_FUSED=fused, MSDP_NO_PERSIST="1")   # both are chunked-graph variants
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True)
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1]
+
+
+def _ring_lattice_cost(n, k, seed):
+    """Symmetric sparse C with 2k off-diagonal entries + the diagonal per row (ELL width 2k+1)."""
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = [], [], []
+    for d in range(1, k + 1):
+        w = rng.standard_normal(n)
+        i = np.arange(n)
+        j = (i + d) % n
+        rows += [i, j]; cols += [j, i]; vals += [w, w]
+    rows.append(np.arange(n)); cols.append(np.arange(n)); vals.append(rng.standard_normal(n))
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+
+
+@pytest.mark.parametrize("shape,p,k", [((20, 30), 4, 0), ((20, 30), 16, 0), ((33, 37), 20, 0), ((20, 30), 32, 0),
+                                      ((25, 40), 40, 0), ((20, 30), 64, 0), ((1, 997), 12, 3), ((1, 2500), 32, 2)])
+def test_persistent_tcg_matches_oracle(lib, shape, p, k):
+    """The single-launch persistent tCG kernel (msdp_persist.hip) against the oracle's tCG: with maxiter = 1
+    the solve is ONE tCG, so the Hess-vec count, the stop reason and the cost after the step must agree to
+    rounding for every inner-iteration cap.  Covers LPR = 8/16/32, both stored ELL widths (5 and 8),
+    ragged row chunks and pad lanes (p = 12, 20, 40)."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R, manopt_rtr
+    C = problems.toroidal_grid_maxcut(shape[0], shape[1], seed=3) if k == 0 else _ring_lattice_cost(shape[1], k, seed=4)
+    n = C.shape[0]
+    Y, _ = _rand_point(n, p, seed=11)
+    h = lib.Handle.onlyunitdiag(C, pcap=p)
+    h.set_point(Y)
+    assert h.tcg_path() == 1, "persistent kernel not selected"
+    prob = R._OnlyUnitDiagProblem(C, n, p, q1="correct")
+    for maxinner in (1, 2, 7, 100):
+        h.set_point(Y)
+        st = h.rtr(lib.default_opts(maxiter=1, maxinner=maxinner, tolgradnorm=1e-8))
+        _, f_ref, info = manopt_rtr.trustregions(prob, Y.copy(), 1, maxinner, 1e-8)
+        assert st.hessvecs == info.hessvecs
+        assert st.last_stop_inner == info.stop_inner[-1]
+        assert abs(st.cost - f_ref) < 1e-11 * max(1.0, abs(f_ref))
+        assert abs(st.gradnorm - info.gradnorm) < 1e-8 * max(1.0, info.gradnorm)
+    # a full solve lands on the same optimum as the chunked path's oracle
+    h.set_point(Y)
+    st = h.rtr(lib.default_opts(maxiter=40, maxinner=100, tolgradnorm=1e-8))
+    _, f_ref, info = manopt_rtr.trustregions(prob, Y.copy(), 40, 100, 1e-8)
+    assert abs(st.cost - f_ref) < 1e-6 * max(1.0, abs(f_ref))
+    assert np.allclose(np.linalg.norm(h.get_point(), axis=1), 1.0, atol=1e-14)
+    h.close()
+
+
+def test_persistent_path_not_used_when_ineligible(lib):
+    """Rows longer than the ELL limit (G1: up to ~50 nonzeros per row) or p > 64 keep the chunked path."""
+    from manisdp_matlab_amd import problems
+    C = problems.maxcut_cost_matrix(golden_path("G1.txt.gz"))
+    Y, _ = _rand_point(C.shape[0], 8, seed=1)
+    h = lib.Handle.onlyunitdiag(C)
+    h.set_point(Y)
+    assert h.tcg_path() == 0
+    h.close()
+    C = problems.toroidal_grid_maxcut(20, 30, seed=3)
+    Y, _ = _rand_point(C.shape[0], 80, seed=1)
+    h = lib.Handle.onlyunitdiag(C, pcap=80)
+    h.set_point(Y)
+    assert h.tcg_path() == 0
+    h.close()
