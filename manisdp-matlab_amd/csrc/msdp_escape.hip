@@ -24,6 +24,11 @@
 #include <vector>
 
 int msdp_dense_nS(int n);
+// msdp_lanczos.hip: persistent kernel for the recurrence (sparse C, single rank)
+size_t msdp_lanczos_slot_bytes();
+int msdp_lanczos_persist_ok(msdp_handle h, int nq);
+int msdp_lanczos_persist_run(msdp_handle h, const double* z, const double* Q, int nq, double* V, double* X, double* dalpha,
+                             double* dbeta, unsigned long long* slots, int* err, int m0, int m1);
 
 // ---------------------------------------------------------------- kernels
 // w = S*v for S = C - diag(z), sparse C (one thread per row; rows are short)
@@ -196,6 +201,9 @@ struct EscCtx {
     const double* z;
     double* hbuf;
     const double* M;     // explicit dense S (n x nS, device) for the affine kinds; nullptr: S = C - diag(z)
+    double* X;           // persistent Lanczos: exchange buffer (n), grid-sync slots, error flag
+    unsigned long long* slots;
+    int* err;
 };
 
 static int sapply(EscCtx& c, const double* v, double* w) {
@@ -254,7 +262,14 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
     std::vector<double> a, b, s;
     int m = 0, next_check = 32;
     double theta = 0.0, res = 1e300, lmax = 0.0;
+    const bool persist = !c.M && c.slots && msdp_lanczos_persist_ok(h, nq);
     while (m < maxit) {
+        if (persist) {
+            // all steps up to the next checkpoint in one launch (msdp_lanczos.hip)
+            const int m1 = std::min(next_check, maxit);
+            if ((rc = msdp_lanczos_persist_run(h, c.z, Q, nq, V, c.X, dalpha, dbeta, c.slots, c.err, m, m1))) return rc;
+            m = m1;
+        } else {
         double* vj = V + (size_t)m * n;
         if ((rc = sapply(c, vj, w))) return rc;
         hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, n, w, vj, dalpha + m, 0);
@@ -266,11 +281,17 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
         hipLaunchKernelGGL(k_normalize_to, gr, bl, 0, h->stream, n, w, dbeta + m + 1, vj + n);
         HIPCHK(hipGetLastError());
         ++m;
+        }
         if (m == next_check || m == maxit) {
             a.resize(m); b.resize(m + 1);
             HIPCHK(hipMemcpyAsync(a.data(), dalpha, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipMemcpyAsync(b.data(), dbeta, (m + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
+            if (persist) {
+                int perr = 0;
+                HIPCHK(hipMemcpy(&perr, c.err, sizeof(int), hipMemcpyDeviceToHost));
+                if (perr) { msdp_set_error("persistent Lanczos: grid synchronisation timed out"); return MSDP_EHIP; }
+            }
             // T_m: diagonal a[0..m-1], couplings b[1..m-1]; b[m] closes the residual
             std::vector<double> off(m);
             for (int i = 0; i + 1 < m; ++i) off[i] = b[i + 1];
@@ -328,7 +349,8 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     c.h = h; c.n = n; c.z = Mdev ? nullptr : d.eG[cur]; c.M = Mdev;
     const int qcap = p + k + 1;
     double* mem = nullptr;
-    const size_t total = (size_t)(qcap + maxit + 2 + qcap) * n + (size_t)n + 2 * (size_t)(maxit + 2) + 4096;
+    const size_t slot_doubles = msdp_lanczos_slot_bytes() / sizeof(double);
+    const size_t total = (size_t)(qcap + maxit + 2 + qcap) * n + (size_t)n + 2 * (size_t)(maxit + 2) + 4096 + (size_t)n + slot_doubles + 16;
     hipError_t me = hipMalloc((void**)&mem, total * sizeof(double));
     if (me != hipSuccess) { msdp_set_error("escape_eigs: workspace allocation (%zu MB) failed", total * 8 >> 20); return MSDP_ENOMEM; }
     double* Q = mem;                                   // deflation set: orth(Y) then accepted eigenvectors
@@ -338,6 +360,9 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     double* dalpha = w + n;
     double* dbeta = dalpha + (maxit + 2);
     c.hbuf = dbeta + (maxit + 2);
+    c.X = c.hbuf + 4096;
+    c.slots = reinterpret_cast<unsigned long long*>(c.X + n);
+    c.err = reinterpret_cast<int*>(c.slots + slot_doubles);
     int rc = 0, r = 0, nfound = 0, total_steps = 0;
     double lam_max = -1e300;
     const dim3 gr((n + 255) / 256), bl(256);

@@ -1,0 +1,335 @@
+// msdp_lanczos.hip -- persistent kernel for the deflated three-term Lanczos recurrence of the
+// saddle-escape step (msdp_escape.hip; replaces eig(full(S)) of ManiSDP_onlyunitdiag.m:50).
+//
+// A Lanczos step on S = C - diag(z) is tiny at n = 20000 (one length-n SpMV, a handful of
+// length-n dot products / axpys) and certifying lambda_min >= -1e-8 needs ~10^4..10^5 of them
+// per call: as seven launches per step (33-58 us per step measured) the eigen-escape was 85% of
+// the G81 wall-clock.  Here ONE launch runs the steps [m0, m1): every workgroup keeps its rows of
+// v_{j-1}, v_j, w in registers and its rows of the deflation basis Q in LDS; per step
+//   1. w = S*v_j                      (neighbour entries gathered from the exchange buffer, sc1)
+//   2. grid reduction of [Q'w ; v_j'w]  (one sync: alpha_j and the nq deflation coefficients)
+//   3. w -= alpha_j v_j + beta_j v_{j-1} + Q (Q'w);  exchange buffer <- w;  grid reduction of |w|^2
+//   4. beta_{j+1} = |w|, v_{j+1} = w / beta_{j+1}  -> column j+1 of the stored Lanczos basis
+// i.e. two grid synchronisations per step.  The synchronisation is the slot scheme of
+// msdp_persist.hip (agent-coherent sc1 stores, sentinel polling, three rotating generations,
+// bounded spin); slots are workgroup-major so that lane c sums value c over the workgroups in a
+// fixed order -- every workgroup obtains bit-identical scalars.
+#include "msdp_device.h"
+#include <math.h>
+#include <cstdlib>
+
+#define LZ_PB 512
+#define LZ_PWAVES (LZ_PB / 64)
+#define LZ_NV 128                         // values per workgroup slot: Q'w, Q'v (<= 63 columns each) + alpha
+#define LZ_GMAX 256
+#define LZ_GEN 3
+#define LZ_SENT 0xFFF8DEADBEEF0001ULL
+#define LZ_SPIN_LIMIT (1 << 22)
+#define LZ_CPOL_SC1 16
+#define LZ_RMAX 2                         // rows per thread
+
+typedef unsigned int lz_v2u __attribute__((ext_vector_type(2)));
+
+size_t msdp_lanczos_slot_bytes() { return (size_t)LZ_GEN * LZ_GMAX * LZ_NV * sizeof(unsigned long long); }
+
+struct LzArgs {
+    int n, G, nq, m0, m1, RW;             // RW: row capacity of a workgroup (LDS stride of a Q column)
+    const int* rp; const int* ci; const double* cv; const double* z;
+    const double* Q;                      // nq columns, stride n
+    double* V;                            // Lanczos basis, column j at V + j*n
+    double* X;                            // exchange buffer (n)
+    double* dalpha; double* dbeta;
+    unsigned long long* slots;            // [LZ_GEN][LZ_GMAX][LZ_NV]
+    int* err;
+};
+
+__device__ __forceinline__ double lz_ld_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    const lz_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, LZ_CPOL_SC1);
+    return __longlong_as_double(((long long)v.y << 32) | (long long)v.x);
+}
+__device__ __forceinline__ unsigned long long lz_ld_sc1_u64(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    const lz_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, LZ_CPOL_SC1);
+    return ((unsigned long long)v.y << 32) | (unsigned long long)v.x;
+}
+__device__ __forceinline__ void lz_st_sc1_u64(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, unsigned long long b) {
+    lz_v2u v;
+    v.x = (unsigned)(b & 0xffffffffULL); v.y = (unsigned)(b >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(v, rs, byte_off, 0, LZ_CPOL_SC1);
+}
+
+__global__ void k_lz_reset(unsigned long long* slots, int* err) {
+    const int tot = LZ_GEN * LZ_GMAX * LZ_NV;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += gridDim.x * blockDim.x) slots[i] = LZ_SENT;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *err = 0;
+}
+
+// Grid reduction of nv (<= LZ_NV) values.  In: vals[c] (LDS, this workgroup's partial of value c).  Out: tot[c]
+// (LDS, grid total, identical bits in every workgroup).  All 8 waves poll: wave k owns the workgroups
+// [k*G/8, (k+1)*G/8) and lane c (and c+64) sums value c over them in index order, one batch of loads = one
+// round trip; the eight partial sums are then added in wave order.  part: LDS [LZ_PWAVES][LZ_NV].
+__device__ __forceinline__ bool lz_sync(__amdgpu_buffer_rsrc_t rs, unsigned gen, int G, int nv, const double* vals,
+                                        double* tot, double* part, double* flag, int* err) {
+    if (threadIdx.x == 0) *flag = 0.0;
+    __syncthreads();                                     // vals complete
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned gbase = (gen % LZ_GEN) * (unsigned)(LZ_GMAX * LZ_NV * 8);
+    if (wave == 0) {
+        // the reset stores of the previous sync must have been performed before this post can be seen
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < LZ_NV / 64; ++ps) {
+            const int c = lane + 64 * ps;
+            if (c < nv) lz_st_sc1_u64(rs, gbase + ((unsigned)blockIdx.x * LZ_NV + c) * 8u, (unsigned long long)__double_as_longlong(vals[c]));
+        }
+    }
+    const int gpw = G / LZ_PWAVES, g_lo = wave * gpw;
+#pragma unroll
+    for (int ps = 0; ps < LZ_NV / 64; ++ps) {
+        const int c = lane + 64 * ps;
+        if (ps * 64 >= nv) break;                        // uniform
+        double s = 0.0;
+        int spins = 0;
+        for (;;) {
+            bool ok = true;
+            s = 0.0;
+            if (c < nv) {
+                for (int g0 = 0; g0 < gpw; g0 += 8) {
+                    unsigned long long b[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int g = g_lo + g0 + u;
+                        b[u] = (g0 + u < gpw) ? lz_ld_sc1_u64(rs, gbase + ((unsigned)g * LZ_NV + c) * 8u) : 0ULL;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (g0 + u < gpw) {
+                            ok = ok && (b[u] != LZ_SENT);
+                            s += __longlong_as_double((long long)b[u]);
+                        }
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");               // the loads must be re-issued on every poll
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ULL) break;
+            ++spins;
+            if (spins > LZ_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (lane == 0) { *flag = 1.0; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                break;
+            }
+        }
+        if (c < nv) part[wave * LZ_NV + c] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < LZ_PWAVES; ++k) s += part[k * LZ_NV + threadIdx.x];
+        tot[threadIdx.x] = s;
+    }
+    if (wave == 0) {
+        // every workgroup has posted this generation, hence finished reading the previous one: reset my slot of it
+        const unsigned pbase = ((gen + LZ_GEN - 1) % LZ_GEN) * (unsigned)(LZ_GMAX * LZ_NV * 8);
+#pragma unroll
+        for (int ps = 0; ps < LZ_NV / 64; ++ps)
+            lz_st_sc1_u64(rs, pbase + ((unsigned)blockIdx.x * LZ_NV + lane + 64 * ps) * 8u, LZ_SENT);
+    }
+    __syncthreads();
+    return *flag == 0.0;
+}
+
+// partial (over my rows) of <col_c, x> for c in [c0, c0+64): thread (c, seg) sums an eighth of the rows
+__device__ __forceinline__ double lz_coldot(const double* cols, int RW, int nrow, int c, int ncol, const double* x) {
+    const int seg = threadIdx.x & 7;
+    double acc = 0.0;
+    if (c < ncol) {
+        const double* qc = cols + (size_t)c * RW;
+        for (int t = seg; t < nrow; t += 8) acc = fma(qc[t], x[t], acc);
+    }
+    return msdp_group_sum<8>(acc);
+}
+
+__global__ __launch_bounds__(LZ_PB) void k_lanczos_persist(LzArgs a) {
+    extern __shared__ double lds[];
+    const int nq = a.nq;
+    double* Qs = lds;                                   // [nq][RW] deflation columns
+    double* vs = Qs + (size_t)nq * a.RW;                // [RW] v_j
+    double* ws = vs + a.RW;                             // [RW] w
+    double* vals = ws + a.RW;                           // [LZ_NV]
+    double* tot = vals + LZ_NV;                         // [LZ_NV]
+    double* part = tot + LZ_NV;                         // [LZ_PWAVES][LZ_NV]
+    double* hvp = part + LZ_PWAVES * LZ_NV;             // [64]  Q'v_{j-1}
+    double* flag = hvp + 64;                            // [8]
+    // reduced values: [0, nq) = Q'w, [nq, 2nq) = Q'v_j, 2nq = v_j'w
+    const int nv = 2 * nq + 1;
+    const unsigned q = (unsigned)a.n / (unsigned)a.G, rem = (unsigned)a.n - q * (unsigned)a.G;
+    const unsigned b = blockIdx.x;
+    const int lo = (int)(b * q + (b < rem ? b : rem));
+    const int hi = lo + (int)q + (b < rem ? 1 : 0);
+    const int nrow = hi - lo;
+    __amdgpu_buffer_rsrc_t rs_slots = __builtin_amdgcn_make_buffer_rsrc(a.slots, 0, (unsigned)(LZ_GEN * LZ_GMAX * LZ_NV * 8), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a.X, 0, (unsigned)a.n * 8u, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_v0 = __builtin_amdgcn_make_buffer_rsrc(a.V + (size_t)a.m0 * a.n, 0, (unsigned)a.n * 8u, 0x00020000);
+
+    for (int c = 0; c < nq; ++c)
+        for (int t = threadIdx.x; t < nrow; t += LZ_PB) Qs[(size_t)c * a.RW + t] = a.Q[(size_t)c * a.n + lo + t];
+    double v[LZ_RMAX], vp[LZ_RMAX], w[LZ_RMAX], zr[LZ_RMAX];
+#pragma unroll
+    for (int r = 0; r < LZ_RMAX; ++r) {
+        const int t = threadIdx.x + r * LZ_PB;
+        const bool ok = t < nrow;
+        v[r] = ok ? a.V[(size_t)a.m0 * a.n + lo + t] : 0.0;
+        vp[r] = (ok && a.m0 > 0) ? a.V[(size_t)(a.m0 - 1) * a.n + lo + t] : 0.0;
+        zr[r] = ok ? a.z[lo + t] : 0.0;
+        w[r] = 0.0;
+        if (ok) ws[t] = vp[r];
+    }
+    double beta = a.m0 > 0 ? a.dbeta[a.m0] : 0.0;
+    double sc = 1.0;                                    // gather source holds v_j / sc
+    bool first = true;
+    unsigned gen = 0;
+    const int cth = threadIdx.x >> 3;                   // value index served by this thread's 8-lane group
+    __syncthreads();
+    // Q'v_{m0-1} (zero for m0 = 0): one extra reduction per launch
+    if (nq > 0) {
+        const double d0 = lz_coldot(Qs, a.RW, nrow, cth, nq, ws);
+        if ((threadIdx.x & 7) == 0 && cth < LZ_NV) vals[cth] = d0;
+        if (!lz_sync(rs_slots, gen++, a.G, nq, vals, tot, part, flag, a.err)) return;
+        if ((int)threadIdx.x < 64) hvp[threadIdx.x] = ((int)threadIdx.x < nq) ? tot[threadIdx.x] : 0.0;
+        __syncthreads();
+    }
+    for (int m = a.m0; m < a.m1; ++m) {
+        // ---- w = S*v_j
+#pragma unroll
+        for (int r = 0; r < LZ_RMAX; ++r) {
+            const int t = threadIdx.x + r * LZ_PB;
+            if (t < nrow) {
+                const int row = lo + t;
+                double acc = 0.0;
+                const int s0 = a.rp[row], s1 = a.rp[row + 1];
+                for (int k = s0; k < s1; ++k) {
+                    const unsigned off = (unsigned)a.ci[k] * 8u;
+                    const double x = first ? lz_ld_sc1(rs_v0, off) : lz_ld_sc1(rs_x, off);
+                    acc = fma(a.cv[k], x, acc);
+                }
+                w[r] = sc * acc - zr[r] * v[r];
+                ws[t] = w[r];
+                vs[t] = v[r];
+            }
+        }
+        __syncthreads();
+        // ---- partials of [Q'w ; Q'v ; v'w]
+        {
+            const double hw = lz_coldot(Qs, a.RW, nrow, cth, nq, ws);
+            const double hv = lz_coldot(Qs, a.RW, nrow, cth, nq, vs);
+            const double al = lz_coldot(vs, a.RW, nrow, cth, 1, ws);
+            if ((threadIdx.x & 7) == 0) {
+                if (cth < nq) { vals[cth] = hw; vals[nq + cth] = hv; }
+                if (cth == 0) vals[2 * nq] = al;
+            }
+        }
+        if (!lz_sync(rs_slots, gen++, a.G, nv, vals, tot, part, flag, a.err)) return;
+        const double alpha = tot[2 * nq];
+        // ---- w -= alpha v + beta v_prev + Q Q'(w - alpha v - beta v_prev);  |w|^2
+        double nn = 0.0;
+#pragma unroll
+        for (int r = 0; r < LZ_RMAX; ++r) {
+            const int t = threadIdx.x + r * LZ_PB;
+            if (t < nrow) {
+                double x = w[r] - alpha * v[r] - beta * vp[r];
+                double dq = 0.0;
+                for (int c = 0; c < nq; ++c) dq = fma(tot[c] - alpha * tot[nq + c] - beta * hvp[c], Qs[(size_t)c * a.RW + t], dq);
+                x -= dq;
+                w[r] = x;
+                nn = fma(x, x, nn);
+                lz_st_sc1_u64(rs_x, (unsigned)(lo + t) * 8u, (unsigned long long)__double_as_longlong(x));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my rows of w are performed before my workgroup posts
+        nn = msdp_wave_sum(nn);
+        __syncthreads();                                           // everyone has used tot[] / hvp[] of the first reduction
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = nn;    // ws is free again
+        if ((int)threadIdx.x < nq) hvp[threadIdx.x] = tot[nq + threadIdx.x];      // Q'v_j becomes Q'v_{j-1}
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int i = 0; i < LZ_PWAVES; ++i) s += ws[i];
+            vals[0] = s;
+        }
+        if (!lz_sync(rs_slots, gen++, a.G, 1, vals, tot, part, flag, a.err)) return;
+        const double n2 = tot[0];
+        const double bnew = sqrt(n2 > 0.0 ? n2 : 0.0);
+        const double inv = bnew > 0.0 ? 1.0 / bnew : 0.0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.dalpha[m] = alpha; a.dbeta[m + 1] = bnew; }
+        // ---- v_{j+1} = w / beta_{j+1}
+#pragma unroll
+        for (int r = 0; r < LZ_RMAX; ++r) {
+            const int t = threadIdx.x + r * LZ_PB;
+            if (t < nrow) {
+                vp[r] = v[r];
+                v[r] = w[r] * inv;
+                a.V[(size_t)(m + 1) * a.n + lo + t] = v[r];
+            }
+        }
+        sc = inv;
+        beta = bnew;
+        first = false;
+        __syncthreads();                                           // tot[0] consumed before the next vals/tot traffic
+    }
+}
+
+// ---------------------------------------------------------------- host side
+static int lz_grid(int n, int nq, int* RW_out, size_t* lds_out) {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = v;
+        else cus = 0;
+        (void)hipGetLastError();
+    }
+    int gmax = (cus / 8) * 8;
+    if (gmax > LZ_GMAX) gmax = LZ_GMAX;
+    for (int G = 64; G <= gmax; G += 8) {
+        const int rw = (n + G - 1) / G;
+        if (rw > LZ_RMAX * LZ_PB) continue;
+        const size_t lds = ((size_t)(nq + 2) * rw + 2 * LZ_NV + LZ_PWAVES * LZ_NV + 64 + 8) * sizeof(double);
+        if (lds > 150 * 1024) continue;
+        *RW_out = rw; *lds_out = lds;
+        return G;
+    }
+    return 0;
+}
+
+// 1 when the persistent kernel can run the recurrence for this problem (sparse C, single rank, everything fits)
+int msdp_lanczos_persist_ok(msdp_handle h, int nq) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("MSDP_NO_PERSIST"); off = (e && atoi(e)) ? 1 : 0; }
+    if (off || h->nranks != 1 || h->use_comm || h->d.costkind != COST_SPARSE || !h->d.rowptr) return 0;
+    if (2 * nq + 1 > LZ_NV || h->d.n < 64) return 0;
+    int rw; size_t lds;
+    const int G = lz_grid(h->d.n, nq, &rw, &lds);
+    if (G <= 0) return 0;
+    static int attr_ok = -1;
+    if (attr_ok < 0) {
+        attr_ok = hipFuncSetAttribute((const void*)k_lanczos_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess ? 1 : 0;
+        (void)hipGetLastError();
+    }
+    return attr_ok;
+}
+
+// Steps [m0, m1) of the recurrence; V[:, m0] (and V[:, m0-1], dbeta[m0] when m0 > 0) must be in place.
+int msdp_lanczos_persist_run(msdp_handle h, const double* z, const double* Q, int nq, double* V, double* X, double* dalpha,
+                             double* dbeta, unsigned long long* slots, int* err, int m0, int m1) {
+    LzArgs a;
+    a.n = h->d.n; a.nq = nq; a.m0 = m0; a.m1 = m1;
+    size_t lds;
+    a.G = lz_grid(a.n, nq, &a.RW, &lds);
+    if (a.G <= 0) { msdp_set_error("persistent Lanczos: not eligible"); return MSDP_ESTATE; }
+    a.rp = h->d.rowptr; a.ci = h->d.colind; a.cv = h->d.cval; a.z = z;
+    a.Q = Q; a.V = V; a.X = X; a.dalpha = dalpha; a.dbeta = dbeta; a.slots = slots; a.err = err;
+    hipLaunchKernelGGL(k_lz_reset, dim3(64), dim3(256), 0, h->stream, slots, err);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_lanczos_persist, dim3(a.G), dim3(LZ_PB), lds, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
