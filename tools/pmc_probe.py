@@ -11,4 +11,6 @@ rng = np.random.default_rng(0)
 Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
 h = _lib.Handle.onlyunitdiag(C, pcap=p)
 h.set_point(Y)
-print(h.bench_tcg_trip(8) * 1e3)
+trips = 64
+print("trip us", h.bench_tcg_trip(trips) * 1e3, "path", h.tcg_path(), "trips per persistent launch", trips)
+print("hess us", h.bench_hessvec(8)[0] * 1e3)
