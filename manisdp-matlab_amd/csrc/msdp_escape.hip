@@ -19,6 +19,7 @@
 #include "msdp_device.h"
 #include <math.h>
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -249,7 +250,8 @@ static int dev_norm(EscCtx& c, const double* w, double* out) {
 // residual <= tol*scale, or when [theta - residual] is already above -tol*scale (certified non-negative).
 static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* maxit+1 columns */, double* w,
                             double* dalpha, double* dbeta, int maxit, double tol, unsigned seed,
-                            double* theta_out, double* res_out, double* lmax_out, double* x_out, int* m_out) {
+                            double* theta_out, double* res_out, double* lmax_out, double* x_out, int* m_out,
+                            int kwant = 1, int* nacc_out = nullptr, double* thetas_out = nullptr) {
     msdp_handle h = c.h;
     const int n = c.n;
     const dim3 gr((n + 255) / 256), bl(256);
@@ -311,23 +313,70 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
         }
     }
     // Ritz vector x = V s
-    {
-        double* sdev = nullptr;
-        HIPCHK(hipMalloc((void**)&sdev, (size_t)m * sizeof(double)));
-        hipError_t e = hipMemcpyAsync(sdev, s.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(x_out, 0, (size_t)n * sizeof(double), h->stream);
+    double* sdev = nullptr;
+    HIPCHK(hipMalloc((void**)&sdev, (size_t)m * sizeof(double)));
+    auto assemble = [&](const std::vector<double>& sv, double* dst) -> int {
+        hipError_t e = hipMemcpyAsync(sdev, sv.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(dst, 0, (size_t)n * sizeof(double), h->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_multiaxpy, gr, bl, 0, h->stream, n, m, V, (int64_t)n, sdev, 1.0, x_out);
+            hipLaunchKernelGGL(k_multiaxpy, gr, bl, 0, h->stream, n, m, V, (int64_t)n, sdev, 1.0, dst);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        (void)hipFree(sdev);
         if (e != hipSuccess) { msdp_set_error("escape: Ritz vector assembly failed: %s", hipGetErrorString(e)); return MSDP_EHIP; }
-    }
+        return 0;
+    };
+    int nacc = 1;
+    rc = assemble(s, x_out);
     // clean up the Ritz vector: project out Q once more and normalise
-    if ((rc = deflate(c, Q, nq, x_out, 1))) return rc;
-    double nx; if ((rc = dev_norm(c, x_out, &nx))) return rc;
-    if (nx > 0) hipLaunchKernelGGL(k_scale_copy, gr, bl, 0, h->stream, n, x_out, 1.0 / nx, x_out);
+    if (!rc) rc = deflate(c, Q, nq, x_out, 1);
+    double nx = 0.0;
+    if (!rc) rc = dev_norm(c, x_out, &nx);
+    if (!rc && nx > 0) hipLaunchKernelGGL(k_scale_copy, gr, bl, 0, h->stream, n, x_out, 1.0 / nx, x_out);
+    if (thetas_out) thetas_out[0] = theta;
+    // ---- further negative Ritz pairs of the SAME Krylov space.  On G81 the first outer iteration has 8 negative
+    // eigenvalues 1e-6 apart: peeling them one run at a time cost 8 x 8192 steps, while the run that resolves
+    // the smallest one has (nearly) resolved its neighbours too.  Candidates are taken in increasing order;
+    // ghost copies (Ritz values equal to 1e-10*scale) are skipped, a candidate must have a converged Ritz
+    // estimate, survive orthogonalisation against everything accepted so far and pass a TRUE residual check
+    // |S x - (x'Sx) x| <= 1e-6*scale; the first failure ends the extraction (the next run picks up from there).
+    if (!rc && kwant > 1 && m > 1) {
+        const double scale = std::max(fabs(theta), fabs(lmax)) + 1e-300;
+        if (theta < -tol * scale) {
+            std::vector<double> off(m), s2;
+            for (int i = 0; i + 1 < m; ++i) off[i] = b[i + 1];
+            double last = theta;
+            for (int idx = 1; idx < m && nacc < kwant && !rc; ++idx) {
+                const double th = tri_eig_kth(a, off, m, idx, last, 0.0);
+                if (!(th < -tol * scale)) break;
+                if (th - last <= 1e-10 * scale) continue;                 // ghost copy
+                last = th;
+                tri_eigvec(a, off, m, th, s2);
+                if (fabs(b[m] * s2[m - 1]) > 1e-7 * scale) break;          // not converged in this Krylov space
+                double* xk = x_out + (size_t)nacc * n;
+                if ((rc = assemble(s2, xk))) break;
+                double n0, n1;
+                if ((rc = dev_norm(c, xk, &n0))) break;
+                if ((rc = deflate(c, Q, nq + nacc, xk, 2))) break;          // Q and the vectors accepted in this call are contiguous
+                if ((rc = dev_norm(c, xk, &n1))) break;
+                if (!(n1 > 0.5 * n0) || !(n1 > 0)) continue;                // a direction we already have
+                hipLaunchKernelGGL(k_scale_copy, gr, bl, 0, h->stream, n, xk, 1.0 / n1, xk);
+                // true residual
+                if ((rc = sapply(c, xk, w))) break;
+                hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, n, w, xk, c.hbuf + 8, 0);
+                hipLaunchKernelGGL(k_lanczos_update, gr, bl, 0, h->stream, n, w, xk, (const double*)nullptr, c.hbuf + 8, (const double*)nullptr);
+                double rq = 0.0, rn = 0.0;
+                if ((rc = dev_norm(c, w, &rn))) break;
+                if (hipMemcpy(&rq, c.hbuf + 8, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { msdp_set_error("escape: memcpy failed"); rc = MSDP_EHIP; break; }
+                if (!(rn <= 1e-6 * scale) || !(rq < -tol * scale)) break;
+                if (thetas_out) thetas_out[nacc] = rq;
+                ++nacc;
+            }
+        }
+    }
+    (void)hipFree(sdev);
+    if (rc) return rc;
+    if (nacc_out) *nacc_out = nacc;
     *theta_out = theta; *res_out = res; *lmax_out = lmax; *m_out = m;
     return 0;
 }
@@ -394,14 +443,17 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         const int ry = r;
         // sequential deflation: smallest eigenpair of the complement; if negative keep it and repeat (<= k times)
         std::vector<double> found;
-        for (int t = 0; t < k; ++t) {
-            double theta, res, lmx; int m;
+        for (int t = 0; t < k;) {
+            double theta, res, lmx; int m, nacc = 1;
+            double thetas[64];
             double* x = Q + (size_t)r * n;
-            ESC_CHECK(lanczos_smallest(c, Q, r, V, w, dalpha, dbeta, maxit, tol, 12345u + 7919u * t, &theta, &res, &lmx, x, &m));
+            ESC_CHECK(lanczos_smallest(c, Q, r, V, w, dalpha, dbeta, maxit, tol, 12345u + 7919u * t, &theta, &res, &lmx, x, &m,
+                                       std::min(k - t, 64), &nacc, thetas));
             total_steps += m;
+            if (getenv("MSDP_ESC_DEBUG")) fprintf(stderr, "[escape] run at t=%d: nq=%d steps=%d theta=%.6e res=%.2e lmax=%.4f accepted=%d\n", t, r, m, theta, res, lmx, nacc);
             lam_max = std::max(lam_max, lmx);
-            found.push_back(theta);
-            ++r; ++nfound;
+            for (int i = 0; i < nacc; ++i) found.push_back(thetas[i]);
+            r += nacc; nfound += nacc; t += nacc;
             const double scale = std::max(fabs(theta), fabs(lam_max)) + 1e-300;
             if (!(theta < -tol * scale)) break;           // no further negative direction
         }
