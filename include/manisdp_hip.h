@@ -49,6 +49,7 @@ typedef struct msdp_handle_s* msdp_handle;
 #define MSDP_KIND_ONLYUNITDIAG 1   /* src/primal/ManiSDP_onlyunitdiag.m */
 #define MSDP_KIND_UNITDIAG     2   /* src/primal/ManiSDP_unitdiag.m     */
 #define MSDP_KIND_UNITTRACE    3   /* src/primal/ManiSDP_unittrace.m    */
+#define MSDP_KIND_GENERIC      4   /* src/primal/ManiSDP.m (Euclidean manifold) */
 
 /* Options of one Riemannian trust-region solve: the fields ManiSDP sets
  * (ManiSDP_unitdiag.m:44-47) plus Manopt's defaults that are in force
@@ -114,8 +115,10 @@ int msdp_debug_set_full_rows(msdp_handle h, const double* rows_host);
 
 /* min <C,X>, A(X) = b, diag X = 1 (kind = MSDP_KIND_UNITDIAG;
  * ManiSDP_unitdiag.m:152-171) or tr X = 1 (kind = MSDP_KIND_UNITTRACE;
- * ManiSDP_unittrace.m:156-177).  At is n^2 x m CSC (column k = vec(A_k)),
- * b dense m, c dense n^2 (the shim densifies a sparse c). */
+ * ManiSDP_unittrace.m:156-177), or no further structure at all (kind =
+ * MSDP_KIND_GENERIC; ManiSDP.m:149-164 on euclideanfactory(n, p): proj = identity,
+ * retr = Y + U).  At is n^2 x m CSC (column k = vec(A_k)), b dense m, c dense n^2
+ * (the shim densifies a sparse c).  Y is n x p column-major for UNITTRACE and GENERIC. */
 int msdp_create_affine(int32_t kind, int64_t n, int64_t m,
                        const int64_t* at_jc, const int64_t* at_ir, const double* at_pr,
                        const double* b, const double* c, int32_t pcap, msdp_handle* out);

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmanisdp_hip.so")
 
-KIND_ONLYUNITDIAG, KIND_UNITDIAG, KIND_UNITTRACE = 1, 2, 3
+KIND_ONLYUNITDIAG, KIND_UNITDIAG, KIND_UNITTRACE, KIND_GENERIC = 1, 2, 3, 4
 
 
 class RtrOpts(C.Structure):
@@ -207,12 +207,12 @@ class Handle:
     # ---- layout helpers
     def _to_boundary(self, Y):
         Y = np.asarray(Y, dtype=np.float64)
-        if self.kind == KIND_UNITTRACE:
+        if self.kind in (KIND_UNITTRACE, KIND_GENERIC):
             return np.asfortranarray(Y)           # MATLAB n x p column-major
         return np.ascontiguousarray(Y)            # bytes of MATLAB p x n column-major
 
     def _empty(self):
-        if self.kind == KIND_UNITTRACE:
+        if self.kind in (KIND_UNITTRACE, KIND_GENERIC):
             return np.empty((self.n, self.p), dtype=np.float64, order="F")
         return np.empty((self.n, self.p), dtype=np.float64, order="C")
 

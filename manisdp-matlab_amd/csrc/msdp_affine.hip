@@ -199,7 +199,8 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_obl_grad_finish(Dev d, int slot,
 // sphere gradient finish: Gr holds 2*eS*Y, z = <eS*Y, Y> partials in P_S2: G = 2 eS Y - 2 z Y.
 __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_grad_finish(Dev d, int slot, double sigma) {
     __shared__ double sh[3 * MSDP_WAVES + 8];
-    const double z = msdp_sum_partials_block(d.P, P_S2, d.G, sh);
+    // Euclidean manifold (generic ManiSDP.m:153-156): G = 2*S*Y, no projection term
+    const double z = (d.manifold == MANI_EUCLID) ? 0.0 : msdp_sum_partials_block(d.P, P_S2, d.G, sh);
     __syncthreads();
     const double cx = msdp_sum_partials_block(d.P, P_S1, d.G, sh);
     __syncthreads();
@@ -226,10 +227,12 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_grad_finish(Dev d, int slot,
 __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_finish(Dev d) {
     __shared__ double sh[3 * MSDP_WAVES + 8];
     if (!d.F[0].active) return;
-    const double t = msdp_sum_partials_block(d.P, P_AUX, d.G, sh);
+    // Euclidean manifold (generic ManiSDP.m:158-162): H = 2*S*U + 4*sigma*AyU*Y as is
+    const bool euc = d.manifold == MANI_EUCLID;
+    const double t = euc ? 0.0 : msdp_sum_partials_block(d.P, P_AUX, d.G, sh);
     __syncthreads();
     const int cur = d.ctl->cur;
-    const double z = d.ctl->z_sphere[cur];
+    const double z = euc ? 0.0 : d.ctl->z_sphere[cur];
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi);
     const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];

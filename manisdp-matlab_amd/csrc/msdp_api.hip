@@ -71,7 +71,7 @@ static void dev_free(msdp_handle h, void* p) {
     (void)hipFree(p);
 }
 
-static bool boundary_colmajor(msdp_handle h) { return h->kind == MSDP_KIND_UNITTRACE; }
+static bool boundary_colmajor(msdp_handle h) { return h->kind == MSDP_KIND_UNITTRACE || h->kind == MSDP_KIND_GENERIC; }
 
 static int rows_capacity(msdp_handle h) {
     // equal per-rank row count so the all-gather is one uniform RCCL call
@@ -165,7 +165,7 @@ static int new_handle(int kind, int64_t n, msdp_handle* out) {
     h->d.n = (int)n;
     h->d.n_loc = (int)n;
     h->d.row0 = 0;
-    h->d.manifold = (kind == MSDP_KIND_UNITTRACE) ? MANI_SPHERE : MANI_OBLIQUE;
+    h->d.manifold = (kind == MSDP_KIND_UNITTRACE) ? MANI_SPHERE : (kind == MSDP_KIND_GENERIC ? MANI_EUCLID : MANI_OBLIQUE);
     if (const char* ev = getenv("MSDP_VARIANT")) h->d.variant = atoi(ev);
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
@@ -344,7 +344,7 @@ extern "C" int msdp_debug_set_full_rows(msdp_handle h, const double* rows_host) 
 extern "C" int msdp_create_affine(int32_t kind, int64_t n, int64_t m, const int64_t* at_jc, const int64_t* at_ir,
                                   const double* at_pr, const double* b, const double* c, int32_t pcap,
                                   msdp_handle* out) {
-    if (kind != MSDP_KIND_UNITDIAG && kind != MSDP_KIND_UNITTRACE) { msdp_set_error("bad kind %d", kind); return MSDP_EINVAL; }
+    if (kind != MSDP_KIND_UNITDIAG && kind != MSDP_KIND_UNITTRACE && kind != MSDP_KIND_GENERIC) { msdp_set_error("bad kind %d", kind); return MSDP_EINVAL; }
     if (!at_jc || !b || !c || m <= 0) { msdp_set_error("null/empty affine data"); return MSDP_EINVAL; }
     msdp_handle h = nullptr;
     int rc = new_handle(kind, n, &h);
@@ -593,7 +593,9 @@ static void fill_ctl(msdp_handle h, const msdp_rtr_opts* o) {
     c->tolgradnorm = o->tolgradnorm; c->kappa = o->kappa; c->theta = o->theta;
     c->rho_prime = o->rho_prime; c->rho_reg = o->rho_regularization;
     // trustregions.m:363-372; typicaldist: pi*sqrt(n) (ManiSDP_onlyunitdiag.m:137) or pi (spherefactory.m:111)
-    const double typical = (h->d.manifold == MANI_OBLIQUE) ? M_PI * sqrt((double)h->d.n) : M_PI;
+    // ... or sqrt(n*p) (euclideanfactory.m:57)
+    const double typical = (h->d.manifold == MANI_OBLIQUE) ? M_PI * sqrt((double)h->d.n)
+                           : (h->d.manifold == MANI_EUCLID ? sqrt((double)h->d.n * (double)h->d.p) : M_PI);
     c->Delta_bar = (o->Delta_bar > 0) ? o->Delta_bar : typical;
     c->Delta0 = (o->Delta0 > 0) ? o->Delta0 : c->Delta_bar / 8.0;
 }

@@ -52,7 +52,7 @@ struct Frame {
 // Partial-sum array ids
 enum { P_F = 0, P_GG = 1, P_DHD = 2, P_S1 = 3, P_S2 = 4, P_S3 = 5, P_RD = 6, P_AUX = 7 };
 
-enum { MANI_OBLIQUE = 0, MANI_SPHERE = 1 };
+enum { MANI_OBLIQUE = 0, MANI_SPHERE = 1, MANI_EUCLID = 2 };
 enum { COST_SPARSE = 0, COST_DENSE = 1, COST_AFFINE = 2 };
 
 // Everything a kernel needs, passed by value.

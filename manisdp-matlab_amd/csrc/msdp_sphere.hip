@@ -1,4 +1,6 @@
-// msdp_sphere.hip -- manifold kernels of the unit-Frobenius-norm sphere (unittrace):
+// msdp_sphere.hip -- manifold kernels of the unit-Frobenius-norm sphere (unittrace) and of the Euclidean
+// manifold of the generic ManiSDP.m (euclideanfactory.m:59-76: proj = identity, retr = x + d; the same kernels
+// with the projection / normalisation terms switched off):
 //   proj/tangent  d - x*(x(:)'*d(:))          manopt/manifolds/sphere/spherefactory.m:113
 //   retr          (x+d)/norm(x+d,'fro')       spherefactory.m:220-232
 // Unlike the oblique manifold the projection needs one GLOBAL inner product, so the tCG
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_upd2a(Dev d) {
         st2(d.md + i, v);
         pt += v.x * y.x + v.y * y.y;
     }
+    if (d.manifold == MANI_EUCLID) return;                  // tangent = identity: no projection pass follows
     msdp_put_partial(d.P, P_AUX, pt, sh);
 }
 
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_retr_simple(const double* Y,
 int msdp_sphere_upd2(msdp_handle h) {
     hipLaunchKernelGGL(k_sph_upd2a, dim3(h->d.G), dim3(MSDP_BLOCK), 0, h->stream, h->d);
     HIPCHK(hipGetLastError());
+    if (h->d.manifold == MANI_EUCLID) return 0;
     int rc = msdp_allreduce_partials(h, P_AUX, 1);
     if (rc) return rc;
     hipLaunchKernelGGL(k_sph_upd2b, dim3(h->d.G), dim3(MSDP_BLOCK), 0, h->stream, h->d);
@@ -172,16 +176,31 @@ int msdp_sphere_retract(msdp_handle h) {
     HIPCHK(hipGetLastError());
     int rc = msdp_allreduce_partials(h, P_RD, 2);   // P_RD and P_AUX are adjacent
     if (rc) return rc;
+    if (h->d.manifold == MANI_EUCLID) return 0;     // retr(x, d) = x + d (euclideanfactory.m:67-76)
     hipLaunchKernelGGL(k_sph_retract_b, dim3(h->d.G), dim3(MSDP_BLOCK), 0, h->stream, h->d);
     HIPCHK(hipGetLastError());
     return 0;
 }
+__global__ void k_euc_axpy(const double* Y, const double* U, double* Z, double alpha, double ycoef, int64_t cnt) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x)
+        Z[i] = ycoef * Y[i] + alpha * U[i];
+}
 int msdp_sphere_proj(msdp_handle h, const double* Y, const double* U, double* V) {
+    if (h->d.manifold == MANI_EUCLID) {
+        hipLaunchKernelGGL(k_euc_axpy, dim3(256), dim3(256), 0, h->stream, Y, U, V, 1.0, 0.0, (int64_t)h->d.n_loc * h->d.ld);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_sph_proj_simple, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, Y, U, V, (int64_t)h->d.n_loc * h->d.ld);
     HIPCHK(hipGetLastError());
     return 0;
 }
 int msdp_sphere_retr(msdp_handle h, const double* Y, const double* U, double* Z, double alpha) {
+    if (h->d.manifold == MANI_EUCLID) {
+        hipLaunchKernelGGL(k_euc_axpy, dim3(256), dim3(256), 0, h->stream, Y, U, Z, alpha, 1.0, (int64_t)h->d.n_loc * h->d.ld);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_sph_retr_simple, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, Y, U, Z, alpha,
                        (int64_t)h->d.n_loc * h->d.ld);
     HIPCHK(hipGetLastError());

@@ -7,6 +7,7 @@
 //   h   = manisdp_mex('create_onlyunitdiag', C)              % C sparse or dense n x n double
 //   h   = manisdp_mex('create_unitdiag',  At, b, c, n)       % At sparse n^2 x m, b/c sparse or dense
 //   h   = manisdp_mex('create_unittrace', At, b, c, n)
+//   h   = manisdp_mex('create_generic', At, b, c, n)          (ManiSDP.m, Euclidean manifold; Y is n x p)
 //         manisdp_mex('set_multipliers', h, y, sigma)
 //   [Y, info] = manisdp_mex('rtr', h, Y, opts)               % opts: struct with maxiter,maxinner,tolgradnorm
 //   val = manisdp_mex('linesearch_cost', h, Y, U, alpha)     % co(retr(Y + alpha U))
@@ -73,7 +74,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         }
         if (rc) fail("create_onlyunitdiag", rc);
         plhs[0] = put_handle(h);
-    } else if (cmd == "create_unitdiag" || cmd == "create_unittrace") {
+    } else if (cmd == "create_unitdiag" || cmd == "create_unittrace" || cmd == "create_generic") {
         if (nrhs != 5) mexErrMsgIdAndTxt("ManiSDP:hip:nrhs", "%s(At, b, c, n)", cmd.c_str());
         const mxArray* At = prhs[1];
         if (!mxIsSparse(At)) mexErrMsgIdAndTxt("ManiSDP:hip:At", "At must be sparse (n^2 x m)");
@@ -82,7 +83,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         std::vector<double> b = densify(prhs[2], (size_t)m);          // bqpmom.m:37 gives a sparse b
         std::vector<double> c = densify(prhs[3], (size_t)n * n);      // bqpmom.m:115 gives a sparse c
         msdp_handle h = nullptr;
-        const int kind = cmd == "create_unitdiag" ? MSDP_KIND_UNITDIAG : MSDP_KIND_UNITTRACE;
+        const int kind = cmd == "create_unitdiag" ? MSDP_KIND_UNITDIAG
+                         : (cmd == "create_generic" ? MSDP_KIND_GENERIC : MSDP_KIND_UNITTRACE);
         int rc = msdp_create_affine(kind, n, m, (const int64_t*)mxGetJc(At), (const int64_t*)mxGetIr(At), mxGetPr(At),
                                     b.data(), c.data(), 32, &h);
         if (rc) fail(cmd.c_str(), rc);

@@ -211,6 +211,7 @@ def _affine_common(kind, At, b, c, K, options, verbose, rng, defaults):
     Atc = sp.csc_matrix(At)
     A = Atc.T.tocsr()
     sphere = kind == _lib.KIND_UNITTRACE
+    generic = kind == _lib.KIND_GENERIC                # src/primal/ManiSDP.m: Euclidean manifold, no z term
     eig_mode = o.get("eig", "host" if n <= int(o.get("dense_eig_max", 400)) else "device")
     _say(verbose, "ManiSDP is starting...")
     _say(verbose, f"SDP size: n = {n}, m = {b.size}")
@@ -224,7 +225,9 @@ def _affine_common(kind, At, b, c, K, options, verbose, rng, defaults):
     Y = o.get("Y0", None)
     if Y is None:
         Y = rng.standard_normal((n, p))
-        if sphere:
+        if generic:
+            pass                                           # euclideanfactory.m:82 (M.rand = randn)
+        elif sphere:
             Y /= np.linalg.norm(Y)                         # spherefactory.m:249-254
         else:
             Y /= np.sqrt(np.sum(Y * Y, axis=1, keepdims=True))
@@ -237,7 +240,7 @@ def _affine_common(kind, At, b, c, K, options, verbose, rng, defaults):
     gap0 = pinf0 = dinf0 = None
     obj = gap = pinf = dinf = gradnorm = eta_kkt = None
     S = z = None
-    slow_every, slow_after = (20, 50) if sphere else (50, 100)
+    slow_every, slow_after = (20, 50) if (sphere or generic) else (50, 100)
     try:
         for it in range(1, int(o["AL_maxiter"]) + 1):
             fac_size.append(p)
@@ -260,7 +263,10 @@ def _affine_common(kind, At, b, c, K, options, verbose, rng, defaults):
             y = y - sigma * Axb                            # :64
             eS = (c - Atc @ y).reshape((n, n), order="F")  # :65
             t1 = time.time()
-            if sphere:
+            if generic:
+                S = eS                                     # ManiSDP.m:64
+                by = float(b @ y)                          # :67
+            elif sphere:
                 z = float(np.sum(eS * X))                  # unittrace :66
                 S = eS - z * np.eye(n)                     # :67
                 by = float(b @ y) + z                      # :70
@@ -297,8 +303,8 @@ def _affine_common(kind, At, b, c, K, options, verbose, rng, defaults):
                 Y = _rank_cut(Y, Q, e, r)
                 p = r
             nneg = int(np.sum(dS[:-1] < 0)) if eig_mode == "device" else int(np.sum(dS < 0))
-            if sphere:
-                nne = min(nneg, int(o["delta"]))           # unittrace :101
+            if sphere or generic:
+                nne = min(nneg, int(o["delta"]))           # unittrace :101 / ManiSDP.m:99
             else:
                 nne = max(min(nneg, int(o["delta"])), 1)   # unitdiag :97
             if o["line_search"] == 1:
@@ -308,7 +314,9 @@ def _affine_common(kind, At, b, c, K, options, verbose, rng, defaults):
                 Y = np.hstack([Y, np.zeros((n, nne))])
             else:
                 Y = np.hstack([Y, o["alpha"] * vS[:, :nne]])
-                if sphere:
+                if generic:
+                    pass                                   # ManiSDP.m:107
+                elif sphere:
                     Y = Y / np.linalg.norm(Y)              # unittrace :110
                 else:
                     Y = Y / np.sqrt(np.sum(Y * Y, axis=1, keepdims=True))   # unitdiag :106
@@ -321,7 +329,7 @@ def _affine_common(kind, At, b, c, K, options, verbose, rng, defaults):
         h.close()
     data.update({"Y": Y, "X": Y @ Y.T, "y": y, "S": S, "z": z, "gap": gap, "pinf": pinf, "dinf": dinf,
                  "gradnorm": gradnorm, "time": time.time() - t0, "sigma": sigma})
-    if not sphere:
+    if not sphere and not generic:
         data["fac_size"] = fac_size
     if data["status"] == 0 and eta_kkt > o["tol"]:
         data["status"] = 1
@@ -346,3 +354,13 @@ def ManiSDP_unittrace(At, b, c, K, options=None, verbose=True, rng=None):
                     theta=1e-2, delta=8, alpha=0.05, tolgradnorm=1e-8, TR_maxinner=40, TR_maxiter=3,
                     tau1=1e-5, tau2=1e-4, line_search=1)
     return _affine_common(_lib.KIND_UNITTRACE, At, b, c, K, options, verbose, rng, defaults)
+
+
+def ManiSDP(At, b, c, K, options=None, verbose=True, rng=None):
+    """``[X, obj, data] = ManiSDP(At, b, c, K, options)`` -- the generic entry point on the Euclidean manifold
+    (reference src/primal/ManiSDP.m:6; defaults :9-25).  Same device kernels as the two structured affine entry
+    points with the projection / retraction terms switched off."""
+    defaults = dict(p0=1, AL_maxiter=1000, gama=2, sigma0=1e-2, sigma_min=1e-1, sigma_max=1e7, tol=1e-8,
+                    theta=1e-2, delta=8, alpha=0.1, tolgradnorm=1e-8, TR_maxinner=20, TR_maxiter=4,
+                    tau1=1e-2, tau2=1e-1, line_search=1, solver=0)
+    return _affine_common(_lib.KIND_GENERIC, At, b, c, K, options, verbose, rng, defaults)

@@ -601,3 +601,188 @@ def ManiSDP_unittrace(At, b, c, K, options=None, rng=None, verbose=False):
         _say(verbose, "Iteration maximum is reached!")
     _say(verbose, "ManiSDP: optimum = %0.8f, time = %0.2fs" % (obj, time.time() - t0))
     return Y, obj, data
+
+
+# --------------------------------------------------------------------------- generic ManiSDP.m (Euclidean manifold)
+class EuclidNP:
+    """``euclideanfactory(n, p)`` (manopt/manifolds/euclidean/euclideanfactory.m:49-82): flat n x p matrices."""
+
+    def __init__(self, n, p):
+        self.n, self.p = n, p
+
+    def dim(self):
+        return self.n * self.p                             # :49
+
+    def inner(self, x, d1, d2):
+        return float(d1.ravel() @ d2.ravel())              # :51
+
+    def norm(self, x, d):
+        return float(np.linalg.norm(d))                    # :53
+
+    def typicaldist(self):
+        return math.sqrt(self.n * self.p)                  # :57
+
+    def proj(self, x, d):
+        return d                                           # :59
+
+    tangent = proj                                         # :65
+
+    def retr(self, x, d):
+        return x + d                                       # :67-76 (retr = exp)
+
+    def zerovec(self, x):
+        return np.zeros((self.n, self.p))
+
+    def rand(self, rng):
+        return rng.standard_normal((self.n, self.p))       # :82
+
+
+class _GenericProblem:
+    """cost/grad/hess closures of src/primal/ManiSDP.m:149-164.  ``S`` is set by ``grad`` (Manopt evaluates the
+    gradient at accepted points only), ``Axb`` by ``cost``; kept per point here."""
+
+    def __init__(self, At, b, c, n, p):
+        self.At = At.tocsc()
+        self.A = self.At.T.tocsr()
+        self.b = b
+        self.c = c
+        self.n = n
+        self.M = EuclidNP(n, p)
+        self.y = np.zeros(b.size)
+        self.sigma = 1.0
+        self.cur = None
+        self.prop = None
+        self.nhess = 0
+
+    def cost(self, Y):
+        n = self.n
+        x = (Y @ Y.T).ravel(order="F")                     # :150-151
+        Axb = self.A @ x - self.b - self.y / self.sigma    # :152
+        f = float(self.c @ x) + self.sigma / 2.0 * float(Axb @ Axb)   # :153
+        S = (self.c + self.sigma * (self.At @ Axb)).reshape((n, n), order="F")   # :157
+        self.prop = {"S": S, "G": 2.0 * (S @ Y)}           # :158
+        if self.cur is None:
+            self.cur = self.prop
+        return f
+
+    def on_accept(self):
+        self.cur = self.prop
+
+    def grad(self, Y):
+        return self.cur["G"]
+
+    def hess(self, Y, U):
+        self.nhess += 1
+        n = self.n
+        YU = U @ Y.T                                       # :162
+        AyU = (self.At @ (self.A @ YU.ravel(order="F"))).reshape((n, n), order="F")   # :163
+        return 2.0 * (self.cur["S"] @ U) + 4.0 * self.sigma * (AyU @ Y)                # :164
+
+
+def ManiSDP(At, b, c, K, options=None, rng=None, verbose=False):
+    """``[X, obj, data] = ManiSDP(At, b, c, K, options)`` (src/primal/ManiSDP.m:6; defaults :9-25); returns
+    (Y, obj, data)."""
+    o = dict(options or {})
+    n = int(K["s"])
+    p0 = o.get("p0", 1); AL_maxiter = o.get("AL_maxiter", 1000); gama = o.get("gama", 2)
+    sigma0 = o.get("sigma0", 1e-2); sigma_min = o.get("sigma_min", 1e-1); sigma_max = o.get("sigma_max", 1e7)
+    tol = o.get("tol", 1e-8); theta = o.get("theta", 1e-2); delta = o.get("delta", 8)
+    alpha = o.get("alpha", 0.1); tolgradnorm = o.get("tolgradnorm", 1e-8)
+    TR_maxinner = o.get("TR_maxinner", 20); TR_maxiter = o.get("TR_maxiter", 4)
+    tau1 = o.get("tau1", 1e-2); tau2 = o.get("tau2", 1e-1); line_search = o.get("line_search", 1)
+    rng = rng or np.random.default_rng(0)
+    b = _as_dense_vec(b)
+    c = _as_dense_vec(c)
+    _say(verbose, "ManiSDP is starting...")
+    _say(verbose, f"SDP size: n = {n}, m = {b.size}")
+    prob = _GenericProblem(At, b, c, n, p0)
+    A, Atc = prob.A, prob.At
+    p = p0
+    sigma = sigma0
+    y = np.zeros(b.size)
+    normb = 1.0 + np.linalg.norm(b)
+    Y = o.get("Y0", None)                                  # :35-39
+    U = None
+    data = {"status": 0, "hessvecs": 0, "cost_evals": 0, "rejected": 0, "rtr_seconds": 0.0}
+    t0 = time.time()
+    gap0 = pinf0 = dinf0 = None
+
+    def co(Yv):                                            # :142-147
+        x = (Yv @ Yv.T).ravel(order="F")
+        Axb = A @ x - b - y / sigma
+        return float(c @ x) + sigma / 2.0 * float(Axb @ Axb)
+
+    def do_line_search(Yv, Uv):                            # :130-140
+        a = 1.0
+        cost0 = co(Yv)
+        i = 1
+        nY = Yv + a * Uv
+        while i <= 15 and co(nY) - cost0 > -1e-3:
+            a = 0.8 * a
+            nY = Yv + a * Uv
+            i += 1
+        return nY
+
+    obj = gap = pinf = dinf = gradnorm = eta_kkt = None
+    S = None
+    for it in range(1, AL_maxiter + 1):                    # :51
+        prob.M = EuclidNP(n, p)                            # :52
+        prob.y, prob.sigma = y, sigma
+        prob.cur = prob.prop = None
+        if U is not None:
+            Y = do_line_search(Y, U)                       # :53-55
+        t1 = time.time()
+        Y, _, info = trustregions(prob, Y, TR_maxiter, TR_maxinner, tolgradnorm, rng=rng)  # :56
+        data["rtr_seconds"] += time.time() - t1
+        data["hessvecs"] += info.hessvecs
+        data["cost_evals"] += info.cost_evals
+        data["rejected"] += info.rejected
+        gradnorm = info.gradnorm
+        X = Y @ Y.T                                        # :58
+        x = X.ravel(order="F")
+        Axb = A @ x - b                                    # :60
+        pinf = float(np.linalg.norm(Axb)) / normb          # :61
+        y = y - sigma * Axb                                # :62
+        obj = float(c @ x)                                 # :63
+        S = (c - Atc @ y).reshape((n, n), order="F")       # :64
+        dS, vS = np.linalg.eigh(S)                         # :65
+        dinf = max(0.0, -dS[0]) / (1.0 + dS[-1])           # :66
+        by = float(b @ y)                                  # :67
+        gap = abs(obj - by) / (abs(by) + abs(obj) + 1.0)   # :68
+        V, e, r = _thin_svd_rank(Y, theta)                 # :69-75
+        _say(verbose, "Iter %d, obj:%0.8f, gap:%0.1e, pinf:%0.1e, dinf:%0.1e, gradnorm:%0.1e, r:%d, p:%d, sigma:%0.3f, time:%0.2fs"
+             % (it, obj, gap, pinf, dinf, gradnorm, r, p, sigma, time.time() - t0))
+        eta_kkt = max(pinf, gap, dinf)                     # :79
+        data["iters"] = it
+        if eta_kkt < tol:
+            _say(verbose, "Optimality is reached!")
+            break
+        if it % 20 == 0:                                   # :84-94
+            if it > 50 and gap > gap0 and pinf > pinf0 and dinf > dinf0:
+                data["status"] = 2
+                _say(verbose, "Slow progress!")
+                break
+            else:
+                gap0, pinf0, dinf0 = gap, pinf, dinf
+        if r <= p - 1:                                     # :95-98
+            Y = V[:, :r] * e[:r]
+            p = r
+        nne = min(int(np.sum(dS < 0)), delta)              # :99
+        if line_search == 1:
+            U = np.hstack([np.zeros((n, p)), vS[:, :nne]])  # :101
+        p = p + nne
+        if line_search == 1:
+            Y = np.hstack([Y, np.zeros((n, nne))])         # :105
+        else:
+            Y = np.hstack([Y, alpha * vS[:, :nne]])        # :107
+        if pinf < tau1 * gradnorm:                         # :109-113
+            sigma = max(sigma / gama, sigma_min)
+        elif pinf > tau2 * gradnorm:
+            sigma = min(sigma * gama, sigma_max)
+    data.update({"Y": Y, "y": y, "S": S, "gap": gap, "pinf": pinf, "dinf": dinf,
+                 "gradnorm": gradnorm, "time": time.time() - t0, "X": Y @ Y.T, "sigma": sigma})
+    if data["status"] == 0 and eta_kkt > tol:
+        data["status"] = 1
+        _say(verbose, "Iteration maximum is reached!")
+    _say(verbose, "ManiSDP: optimum = %0.8f, time = %0.2fs" % (obj, time.time() - t0))
+    return Y, obj, data

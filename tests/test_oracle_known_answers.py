@@ -81,3 +81,14 @@ def test_unittrace_theta1():
     assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-5
     assert abs(-obj - KNOWN["theta1"]) < 1e-5 * KNOWN["theta1"]
     assert abs(np.linalg.norm(Y) - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["mcp100", "mcp124-1"])
+def test_generic_sdplib_mcp(name):
+    """The generic entry point (src/primal/ManiSDP.m, Euclidean manifold) on the same SDPLIB instances, treated
+    as plain A(X) = b problems: same README values."""
+    At, b, c, K = problems.from_sdpa(golden_path(name + ".dat-s.gz"))
+    Y, obj, data = R.ManiSDP(At, b, c, K, {})
+    assert data["status"] == 0
+    assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
+    assert abs(-obj - KNOWN[name]) < 1e-6 * abs(KNOWN[name])
