@@ -134,3 +134,27 @@ def test_error_paths(lib):
     with pytest.raises(lib.MsdpError):            # p > 512 unsupported
         h.set_point(np.ones((C.shape[0], 600)))
     h.close()
+
+
+@pytest.mark.parametrize("shape,p", [((1, 9), 3), ((5, 10), 5), ((7, 9), 2)])
+def test_persistent_tcg_tiny_problems(shape, p):
+    """Fewer rows than workgroups / lanes: most workgroups of the persistent tCG kernel own no row at all and
+    still have to take part in every grid reduction."""
+    from manisdp_matlab_amd import _lib, problems
+    from oracle import manisdp_ref as R, manopt_rtr
+    C = problems.toroidal_grid_maxcut(shape[0], shape[1], seed=5)
+    n = C.shape[0]
+    rng = np.random.default_rng(4)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    h = _lib.Handle.onlyunitdiag(C, pcap=p)
+    h.set_point(Y)
+    assert h.tcg_path() == 1
+    prob = R._OnlyUnitDiagProblem(C, n, p, q1="correct")
+    for maxinner in (1, 4, 50):
+        h.set_point(Y)
+        st = h.rtr(_lib.default_opts(maxiter=1, maxinner=maxinner, tolgradnorm=1e-8))
+        _, f_ref, info = manopt_rtr.trustregions(prob, Y.copy(), 1, maxinner, 1e-8)
+        assert st.hessvecs == info.hessvecs
+        assert st.last_stop_inner == info.stop_inner[-1]
+        assert abs(st.cost - f_ref) < 1e-11 * max(1.0, abs(f_ref))
+    h.close()
