@@ -38,7 +38,9 @@ struct AffineDev {
     const int* ci;         // row i of each nonzero
     const int* cj;         // col j of each nonzero
     const double* cv;
-    const int64_t* rp;     // n*n+1 row pointers (CSR by matrix entry r = i*n + j)
+    const int* rp;         // n*n+1 row pointers (CSR by matrix entry r = i*n + j)
+    const int* cidx;       // i*nS + j of each nonzero: position in the dense Gram matrix W = Ya*Yb' (Gram route)
+    double* W;             // n x nS scratch for the Gram route (aliases the AyU buffer)
     const int* rk;         // constraint index
     const double* rv;
     const double* b;
@@ -99,6 +101,75 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm_finish(AffineDev a, int mo
     if (mode == 1) msdp_put_partial(P, P_AUX, pss, sh);
 }
 
+// ---- Gram route for A(Ya Yb'): when At is dense in its rows (BQP moment relaxations: 4.8 M nonzeros for an
+// 1831 x 1831 matrix) the SDDMM above gathers two p-wide rows per nonzero (2.5 GB of L2 traffic at p = 32,
+// measured 154 us); forming W = Ya*Yb' once (n^2 p flops, 27 MB) and gathering ONE double per nonzero is what
+// the reference does (ManiSDP_unitdiag.m:153,167: X = Y'*Y, YU = Y'*U) and moves 20x less.
+// W[i][j] = <Ya_i, Yb_j>  (n x nS row-major, pad columns zero).  64 x 64 output tile per 256-thread workgroup,
+// 4 x 4 micro-tile per thread, K staged through LDS in chunks of 32 columns.
+__global__ __launch_bounds__(256) void k_gram(int n, int nS, int ld, const double* __restrict__ Ya,
+                                              const double* __restrict__ Yb, double* __restrict__ W,
+                                              const int* skip_flag, int skip_when) {
+    __shared__ double As[64][33];
+    __shared__ double Bs[64][33];
+    if (skip_flag && *skip_flag == skip_when) return;
+    const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k0 = 0; k0 < ld; k0 += 32) {
+        // 64 rows x 32 columns of each panel: 2048 doubles / 256 threads = 8 each
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = threadIdx.x + q * 256;
+            const int r = e >> 5, cc = e & 31;
+            const int col = k0 + cc;
+            As[r][cc] = (ti + r < n && col < ld) ? Ya[(int64_t)(ti + r) * ld + col] : 0.0;
+            Bs[r][cc] = (tj + r < n && col < ld) ? Yb[(int64_t)(tj + r) * ld + col] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) av[a] = As[ty * 4 + a][kk];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = Bs[tx * 4 + b][kk];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = ti + ty * 4 + a;
+        if (i < n) {
+            const int j = tj + tx * 4;
+            if (j + 3 < nS) {
+                st2(W + (int64_t)i * nS + j, make_double2(acc[a][0], acc[a][1]));
+                st2(W + (int64_t)i * nS + j + 2, make_double2(acc[a][2], acc[a][3]));
+            } else {
+                for (int b = 0; b < 4; ++b) if (j + b < nS) W[(int64_t)i * nS + j + b] = acc[a][b];
+            }
+        }
+    }
+}
+// item value = sum over the item's nonzeros of val * W[cidx]   (one thread per item)
+__global__ __launch_bounds__(256) void k_gram_gather(AffineDev a, const double* __restrict__ W, const int* skip_flag, int skip_when) {
+    if (skip_flag && *skip_flag == skip_when) return;
+    for (int64_t it = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; it < a.nitems; it += (int64_t)gridDim.x * blockDim.x) {
+        const int s0 = a.it0[it], s1 = a.it1[it];
+        double acc = 0.0;
+        for (int t = s0; t < s1; ++t) acc = fma(a.cv[t], W[a.cidx[t]], acc);
+        a.ival[it] = acc;
+    }
+}
+
 // out[i][j] = (base ? base[i][j] : 0) + scale * sum_k At[(i,j),k] * vec[k]   (dense n x nS, zero pad)
 __global__ void k_adjoint_dense(AffineDev a, const double* __restrict__ base, const double* __restrict__ vec,
                                 double scale, double* __restrict__ out, const int* skip_flag, int skip_when) {
@@ -109,9 +180,9 @@ __global__ void k_adjoint_dense(AffineDev a, const double* __restrict__ base, co
         double v = 0.0;
         if (j < a.n) {
             const int64_t r = (int64_t)i * a.n + j;
-            const int64_t s0 = a.rp[r], s1 = a.rp[r + 1];
+            const int s0 = a.rp[r], s1 = a.rp[r + 1];
             double acc = 0.0;
-            for (int64_t t = s0; t < s1; ++t) acc = fma(a.rv[t], vec[a.rk[t]], acc);
+            for (int t = s0; t < s1; ++t) acc = fma(a.rv[t], vec[a.rk[t]], acc);
             v = (base ? base[e] : 0.0) + scale * acc;
         }
         out[e] = v;
@@ -258,6 +329,7 @@ __global__ void k_cost_only(Dev d, double sigma, double* out) {
 // ------------------------------------------------------------------ host side
 struct AffineState {
     AffineDev a{};
+    int64_t nnz = 0;
     double sigma = 1.0;
     double* Cdense = nullptr;      // n x nS
     double* d_y = nullptr;
@@ -293,27 +365,30 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
     g_aff.push_back({h, st});
     AffineDev& a = st->a;
     a.n = n; a.nS = msdp_dense_nS(n); a.m = m;
+    st->nnz = nnz;
     std::vector<int> cjc(m + 1), ci(nnz), cj(nnz);
     std::vector<double> cv(pr, pr + nnz);
     for (int64_t k = 0; k <= m; ++k) cjc[k] = (int)jc[k];
     const int64_t nn = (int64_t)n * n;
-    std::vector<int64_t> rp(nn + 1, 0);
+    if ((int64_t)n * msdp_dense_nS(n) > 0x7fffffffLL) { msdp_set_error("n too large for the affine kinds"); return MSDP_EUNSUPPORTED; }
+    std::vector<int> rp(nn + 1, 0), cidx(nnz);
     for (int64_t t = 0; t < nnz; ++t) {
         const int64_t e = ir[t];
         if (e < 0 || e >= nn) { msdp_set_error("At row index out of range"); return MSDP_EINVAL; }
         const int i = (int)(e % n), j = (int)(e / n);      // column-major vec index (bqpmom.m:57, example_theta.m:20)
         ci[t] = i; cj[t] = j;
+        cidx[t] = i * a.nS + j;
         rp[(int64_t)i * n + j + 1]++;
     }
     for (int64_t r = 0; r < nn; ++r) rp[r + 1] += rp[r];
     std::vector<int> rk(nnz);
     std::vector<double> rv(nnz);
     {
-        std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
+        std::vector<int> fill(rp.begin(), rp.end() - 1);
         for (int64_t k = 0; k < m; ++k)
             for (int64_t t = jc[k]; t < jc[k + 1]; ++t) {
                 const int64_t r = (int64_t)ci[t] * n + cj[t];
-                const int64_t pos = fill[r]++;
+                const int pos = fill[r]++;
                 rk[pos] = (int)k; rv[pos] = pr[t];
             }
     }
@@ -332,7 +407,7 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
         a.ival = (double*)pv;
     }
     if ((rc = up(h, cjc, &a.cjc)) || (rc = up(h, ci, &a.ci)) || (rc = up(h, cj, &a.cj)) || (rc = up(h, cv, &a.cv)) ||
-        (rc = up(h, rp, &a.rp)) || (rc = up(h, rk, &a.rk)) || (rc = up(h, rv, &a.rv)))
+        (rc = up(h, rp, &a.rp)) || (rc = up(h, rk, &a.rk)) || (rc = up(h, rv, &a.rv)) || (rc = up(h, cidx, &a.cidx)))
         return rc;
     std::vector<double> bv(b, b + m);
     if ((rc = up(h, bv, &a.b))) return rc;
@@ -361,6 +436,9 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
     if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
     d.AyU = (double*)p;
     HIPCHK(hipMemset(d.AyU, 0, msz));
+    // the Gram scratch may share AyU: W is consumed (k_gram_gather) before the adjoint rewrites AyU, and the cost /
+    // line-search calls never touch AyU
+    a.W = d.AyU;
     h->h_ctl->sigma = 1.0;
     return 0;
 }
@@ -416,6 +494,36 @@ static int sddmm_grid(const AffineDev& a, int ld) {
     return (int)g;
 }
 
+// A(Ya Yb') -> item values.  SDDMM (gathers 2 p-wide rows per nonzero) or the Gram route (dense W = Ya*Yb' once,
+// one double per nonzero), whichever moves fewer bytes; MSDP_AFFINE_ROUTE=sddmm|gram overrides.
+static bool use_gram_route(const AffineDev& a, int64_t nnz, int ld) {
+    static int force = -1;
+    if (force < 0) {
+        const char* e = getenv("MSDP_AFFINE_ROUTE");
+        force = !e ? 0 : (!strcmp(e, "gram") ? 2 : (!strcmp(e, "sddmm") ? 1 : 0));
+    }
+    if (force) return force == 2;
+    const double sddmm_bytes = (double)nnz * ld * 16.0;
+    const double gram_bytes = 2.0 * a.n * (double)a.nS * 8.0 + (double)nnz * 20.0;
+    return sddmm_bytes > 4.0 * gram_bytes && (double)a.n * a.nS * 8.0 <= 2.0e9;
+}
+static int launch_aop(msdp_handle h, const AffineDev& a, int64_t nnz, const double* Ya, const double* Yb, const int* flag, int when) {
+    if (use_gram_route(a, nnz, a.ld)) {
+        dim3 grid((a.nS + 63) / 64, (a.n + 63) / 64);
+        hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, h->stream, a.n, a.nS, a.ld, Ya, Yb, a.W, flag, when);
+        HIPCHK(hipGetLastError());
+        int64_t g = (a.nitems + 255) / 256;
+        if (g > 16384) g = 16384;
+        if (g < 1) g = 1;
+        hipLaunchKernelGGL(k_gram_gather, dim3((int)g), dim3(256), 0, h->stream, a, (const double*)a.W, flag, when);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    DISPATCH_LPR_A(k_sddmm, h, sddmm_grid(a, a.ld), a, Ya, Yb, flag, when);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int adjoint_grid(const AffineDev& a) {
     int64_t tot = (int64_t)a.n * a.nS;
     int64_t g = (tot + 255) / 256;
@@ -433,8 +541,7 @@ int msdp_affine_costgrad(msdp_handle h, int slot) {
     const double sigma = st->sigma;
     const double* Ys = d.Y[slot];
     const int* done = &d.ctl->done;
-    DISPATCH_LPR_A(k_sddmm, h, sddmm_grid(a, d.ld), a, Ys, Ys, done, 1);
-    HIPCHK(hipGetLastError());
+    { int rc0 = launch_aop(h, a, st->nnz, Ys, Ys, done, 1); if (rc0) return rc0; }
     hipLaunchKernelGGL(k_sddmm_finish, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, a, 1, a.Axb[slot], sigma, d.P, done, 1);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_adjoint_dense, dim3(adjoint_grid(a)), dim3(256), 0, h->stream, a, d.Cd, a.Axb[slot], sigma,
@@ -476,8 +583,7 @@ int msdp_affine_hess(msdp_handle h) {
     const int cur = h->h_ctl->cur;
     const int* act = &d.F[0].active;
     // w = A(Y U') ; AyU = A'(w)
-    DISPATCH_LPR_A(k_sddmm, h, sddmm_grid(a, d.ld), a, d.Y[cur], d.md, act, 0);
-    HIPCHK(hipGetLastError());
+    { int rc0 = launch_aop(h, a, st->nnz, d.Y[cur], d.md, act, 0); if (rc0) return rc0; }
     {   // mode 0 has no reduction: size the grid by m
         int64_t gf = (a.m + MSDP_BLOCK - 1) / MSDP_BLOCK;
         if (gf > 2048) gf = 2048;
@@ -539,8 +645,7 @@ int msdp_affine_linesearch_cost(msdp_handle h, const double* Yt, double* val) {
     a.p = d.p; a.ld = d.ld;
     const double sigma = st->sigma;
     const int other = h->h_ctl->cur ^ 1;
-    DISPATCH_LPR_A(k_sddmm, h, sddmm_grid(a, d.ld), a, Yt, Yt, (const int*)nullptr, 0);
-    HIPCHK(hipGetLastError());
+    { int rc0 = launch_aop(h, a, st->nnz, Yt, Yt, (const int*)nullptr, 0); if (rc0) return rc0; }
     hipLaunchKernelGGL(k_sddmm_finish, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, a, 1, a.Axb[other], sigma, d.P, (const int*)nullptr, 0);
     HIPCHK(hipGetLastError());
     const double* slab; int64_t stride; int SK;
