@@ -256,8 +256,8 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         Gs[r * PB + threadIdx.x] = g;
         eta[r] = zz; rr[r] = g; md[r] = g; hmd[r] = zz;           // tCG.m:102-157
         const double egv = eGl[rc];
-        int cw[EW];
-        double vw[EW];
+        int cw[EW > 0 ? EW : 1];
+        double vw[EW > 0 ? EW : 1];
 #pragma unroll
         for (int w = 0; w < EW; ++w) {
             cw[w] = d.ellc[(int64_t)w * d.ell_stride + rc];
@@ -290,20 +290,60 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         double pd = 0.0, u1 = 0.0, u2 = 0.0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            double2 x[EW];
-            double v[EW];
-#pragma unroll
-            for (int w = 0; w < EW; ++w) {
-                const int cidx = cs[w * ROWS + SLOT(r)];
-                v[w] = vs[w * ROWS + SLOT(r)];
-                const unsigned off = ((unsigned)cidx * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u;
-                x[w] = first ? ld2_sc1(rs_g, off) : ld2_sc1(rs_md, off);
-            }
             double2 acc = zz;
+            if (EW > 0) {
+                double2 x[EW > 0 ? EW : 1];
+                double v[EW > 0 ? EW : 1];
 #pragma unroll
-            for (int w = 0; w < EW; ++w) {
-                acc.x = fma(v[w], x[w].x, acc.x);
-                acc.y = fma(v[w], x[w].y, acc.y);
+                for (int w = 0; w < EW; ++w) {
+                    const int cidx = cs[w * ROWS + SLOT(r)];
+                    v[w] = vs[w * ROWS + SLOT(r)];
+                    const unsigned off = ((unsigned)cidx * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u;
+                    x[w] = first ? ld2_sc1(rs_g, off) : ld2_sc1(rs_md, off);
+                }
+#pragma unroll
+                for (int w = 0; w < EW; ++w) {
+                    acc.x = fma(v[w], x[w].x, acc.x);
+                    acc.y = fma(v[w], x[w].y, acc.y);
+                }
+            } else if (ROK(r)) {
+                // CSR rows of any length: (col, val) are static (plain loads, L2 resident), the direction rows are not
+                const int s0 = d.rowptr[ROW(r)], s1 = d.rowptr[ROW(r) + 1];
+                // batches of 8 gathers in flight, software pipelined: the (col, val) pairs of batch b+1 are loaded
+                // while the gathers of batch b are outstanding; the tail is clamped (weight 0), not peeled
+                int cn[8];
+                double vn[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = s0 + u < s1;
+                    const int k = in ? s0 + u : (s1 > s0 ? s1 - 1 : 0);
+                    cn[u] = (s1 > s0) ? d.colind[k] : ROW(r);
+                    vn[u] = in ? d.cval[k] : 0.0;
+                }
+                for (int k0 = s0; k0 < s1; k0 += 8) {
+                    double2 x[8];
+                    double cvk[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned off = ((unsigned)cn[u] * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u;
+                        cvk[u] = vn[u];
+                        x[u] = first ? ld2_sc1(rs_g, off) : ld2_sc1(rs_md, off);
+                    }
+                    if (k0 + 8 < s1) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const bool in = k0 + 8 + u < s1;
+                            const int k = in ? k0 + 8 + u : s1 - 1;
+                            cn[u] = d.colind[k];
+                            vn[u] = in ? d.cval[k] : 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        acc.x = fma(cvk[u], x[u].x, acc.x);
+                        acc.y = fma(cvk[u], x[u].y, acc.y);
+                    }
+                }
             }
             if (!colok) acc = zz;
             const double2 y = Ys[r * PB + threadIdx.x];
@@ -409,13 +449,13 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
 struct PersistPlan { int lpr, ew, r; size_t lds; };
 
 static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
-    if (d.ellW < 1 || d.ellW > 8) return false;
+    if (!d.rowptr) return false;
     int half = d.ld / 2, lpr = 1;
     while (lpr < half && lpr < 64) lpr <<= 1;
     if (half > 32) return false;                       // p <= 64: the resident rows must fit the register budget
     if (lpr < 8) lpr = 8;
     pl.lpr = lpr;
-    pl.ew = d.ellW <= 5 ? 5 : 8;
+    pl.ew = (d.ellW < 1 || d.ellW > 8) ? 0 : (d.ellW <= 5 ? 5 : 8);      // 0: CSR rows of any length
     pl.r = lpr / 4;                                    // 128 row slots per workgroup
     const int rstep = PWAVES * (64 / lpr);
     const int need = (d.n_loc + G - 1) / G;
@@ -428,7 +468,7 @@ static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
 typedef void (*persist_fn)(Dev, unsigned long long*, int*);
 static persist_fn persist_kernel(const PersistPlan& pl) {
 #define PK(L, E) if (pl.lpr == L && pl.ew == E && pl.r == L / 4) return k_tcg_persist_obl<L, E, L / 4>;
-    PK(8, 5) PK(8, 8) PK(16, 5) PK(16, 8) PK(32, 5) PK(32, 8)
+    PK(8, 5) PK(8, 8) PK(16, 5) PK(16, 8) PK(32, 5) PK(32, 8) PK(8, 0) PK(16, 0) PK(32, 0)
 #undef PK
     return nullptr;
 }
@@ -464,7 +504,7 @@ int msdp_persist_eligible(msdp_handle h) {
     persist_fn fn = persist_kernel(pl);
     if (!fn) return 0;
     // the ELL copy must be stored with the width the kernel is instantiated for
-    if (d.ellW != pl.ew) return 0;
+    if (pl.ew > 0 && d.ellW != pl.ew) return 0;
     if (h->persist_sig_lpr == pl.lpr && h->persist_sig_ew == pl.ew && h->persist_sig_r == pl.r && h->persist_sig_G == G)
         return h->persist_sig_ok;
     int ok = 0;

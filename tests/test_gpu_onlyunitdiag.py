@@ -214,18 +214,47 @@ def test_persistent_tcg_matches_oracle(lib, shape, p, k):
     h.close()
 
 
-def test_persistent_path_not_used_when_ineligible(lib):
-    """Rows longer than the ELL limit (G1: up to ~50 nonzeros per row) or p > 64 keep the chunked path."""
+def test_persistent_path_selection(lib):
+    """CSR rows of any length run in the persistent kernel too (G1: up to ~50 nonzeros per row); p > 64 or more
+    than 128 rows per workgroup (n = 40000 at p = 32) keep the chunked path."""
     from manisdp_matlab_amd import problems
     C = problems.maxcut_cost_matrix(golden_path("G1.txt.gz"))
     Y, _ = _rand_point(C.shape[0], 8, seed=1)
     h = lib.Handle.onlyunitdiag(C)
     h.set_point(Y)
-    assert h.tcg_path() == 0
+    assert h.tcg_path() == 1
     h.close()
     C = problems.toroidal_grid_maxcut(20, 30, seed=3)
     Y, _ = _rand_point(C.shape[0], 80, seed=1)
     h = lib.Handle.onlyunitdiag(C, pcap=80)
     h.set_point(Y)
     assert h.tcg_path() == 0
+    h.close()
+    C = problems.toroidal_grid_maxcut(200, 200, seed=3)
+    Y, _ = _rand_point(C.shape[0], 32, seed=1)
+    h = lib.Handle.onlyunitdiag(C, pcap=32)
+    h.set_point(Y)
+    assert h.tcg_path() == 0
+    h.close()
+
+
+@pytest.mark.parametrize("p", [3, 16, 24, 50])
+def test_persistent_tcg_csr_rows_G1(lib, p):
+    """Persistent kernel, CSR mode (rows longer than the ELL limit), against the oracle's single tCG."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R, manopt_rtr
+    C = problems.maxcut_cost_matrix(golden_path("G1.txt.gz"))
+    n = C.shape[0]
+    Y, _ = _rand_point(n, p, seed=5)
+    h = lib.Handle.onlyunitdiag(C, pcap=p)
+    h.set_point(Y)
+    assert h.tcg_path() == 1
+    prob = R._OnlyUnitDiagProblem(C, n, p, q1="correct")
+    for maxinner in (1, 6, 100):
+        h.set_point(Y)
+        st = h.rtr(lib.default_opts(maxiter=1, maxinner=maxinner, tolgradnorm=1e-8))
+        _, f_ref, info = manopt_rtr.trustregions(prob, Y.copy(), 1, maxinner, 1e-8)
+        assert st.hessvecs == info.hessvecs
+        assert st.last_stop_inner == info.stop_inner[-1]
+        assert abs(st.cost - f_ref) < 1e-11 * max(1.0, abs(f_ref))
     h.close()
