@@ -251,13 +251,28 @@ static int dev_norm(EscCtx& c, const double* w, double* out) {
 static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* maxit+1 columns */, double* w,
                             double* dalpha, double* dbeta, int maxit, double tol, unsigned seed,
                             double* theta_out, double* res_out, double* lmax_out, double* x_out, int* m_out,
-                            int kwant = 1, int* nacc_out = nullptr, double* thetas_out = nullptr) {
+                            int kwant = 1, int* nacc_out = nullptr, double* thetas_out = nullptr,
+                            double* xstart = nullptr, bool* have_xstart = nullptr) {
     msdp_handle h = c.h;
     const int n = c.n;
     const dim3 gr((n + 255) / 256), bl(256);
     int rc;
-    hipLaunchKernelGGL(k_fill_hash, gr, bl, 0, h->stream, n, seed, w);
-    if ((rc = deflate(c, Q, nq, w, 2))) return rc;
+    // start vector: the sum of the still unconverged negative Ritz vectors of the previous run when there is one
+    // (the Krylov space then starts with good approximations of exactly the directions that are still wanted),
+    // else a hashed pseudo-random vector
+    bool warm = false;
+    if (xstart && have_xstart && *have_xstart) {
+        HIPCHK(hipMemcpyAsync(w, xstart, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if ((rc = deflate(c, Q, nq, w, 2))) return rc;
+        double nw = 0.0;
+        if ((rc = dev_norm(c, w, &nw))) return rc;
+        warm = nw > 1e-6;
+        *have_xstart = false;
+    }
+    if (!warm) {
+        hipLaunchKernelGGL(k_fill_hash, gr, bl, 0, h->stream, n, seed, w);
+        if ((rc = deflate(c, Q, nq, w, 2))) return rc;
+    }
     hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, n, w, w, dbeta, 1);
     hipLaunchKernelGGL(k_normalize_to, gr, bl, 0, h->stream, n, w, dbeta, V);
     HIPCHK(hipGetLastError());
@@ -309,7 +324,8 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
             const double scale = std::max(fabs(theta), fabs(lmax)) + 1e-300;
             const bool breakdown = b[m] <= 1e-14 * scale;
             if (res <= tol * scale || theta - res > -tol * scale || breakdown) break;
-            next_check = std::min(maxit, 2 * m);
+            // doubling up to 1024 steps, then x1.5: a late checkpoint wastes steps, an early one costs a host analysis
+            next_check = std::min(maxit, m < 1024 ? 2 * m : m + m / 2);
         }
     }
     // Ritz vector x = V s
@@ -371,6 +387,32 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
                 if (!(rn <= 1e-6 * scale) || !(rq < -tol * scale)) break;
                 if (thetas_out) thetas_out[nacc] = rq;
                 ++nacc;
+            }
+        }
+    }
+    // warm start for the next run: sum of the Ritz vectors of the next distinct negative Ritz values that were NOT
+    // accepted (V*s is linear in s: one block axpy)
+    if (!rc && xstart && have_xstart && kwant > nacc && m > 1) {
+        const double scale = std::max(fabs(theta), fabs(lmax)) + 1e-300;
+        if (theta < -tol * scale) {
+            std::vector<double> off(m), s2, ssum(m, 0.0);
+            for (int i = 0; i + 1 < m; ++i) off[i] = b[i + 1];
+            double last = theta;
+            int distinct = 1, taken = 0;
+            for (int idx = 1; idx < m && taken < kwant - nacc && idx < 64 * kwant; ++idx) {
+                const double th = tri_eig_kth(a, off, m, idx, last, 0.0);
+                if (!(th < -tol * scale)) break;
+                if (th - last <= 1e-10 * scale) continue;
+                last = th;
+                ++distinct;
+                if (distinct <= nacc) continue;                     // already accepted in this run
+                tri_eigvec(a, off, m, th, s2);
+                for (int i = 0; i < m; ++i) ssum[i] += s2[i];
+                ++taken;
+            }
+            if (taken > 0) {
+                rc = assemble(ssum, xstart);
+                if (!rc) *have_xstart = true;
             }
         }
     }
@@ -443,12 +485,13 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         const int ry = r;
         // sequential deflation: smallest eigenpair of the complement; if negative keep it and repeat (<= k times)
         std::vector<double> found;
+        bool have_xstart = false;                       // Z doubles as the warm-start buffer until the final Rayleigh-Ritz
         for (int t = 0; t < k;) {
             double theta, res, lmx; int m, nacc = 1;
             double thetas[64];
             double* x = Q + (size_t)r * n;
             ESC_CHECK(lanczos_smallest(c, Q, r, V, w, dalpha, dbeta, maxit, tol, 12345u + 7919u * t, &theta, &res, &lmx, x, &m,
-                                       std::min(k - t, 64), &nacc, thetas));
+                                       std::min(k - t, 64), &nacc, thetas, Z, &have_xstart));
             total_steps += m;
             if (getenv("MSDP_ESC_DEBUG")) fprintf(stderr, "[escape] run at t=%d: nq=%d steps=%d theta=%.6e res=%.2e lmax=%.4f accepted=%d\n", t, r, m, theta, res, lmx, nacc);
             lam_max = std::max(lam_max, lmx);
