@@ -242,7 +242,18 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
 #define ROW(r) (lo + SLOT(r))
 #define ROK(r) (ROW(r) < hi)
 #define OK(r) (ROK(r) && colok)
-    double2 eta[R], rr[R], md[R], hmd[R];
+    // R = 8 (p = 33..64): four resident vectors = 128 registers + temporaries spill.  There mdelta and Hmdelta live
+    // in LDS (the regions that hold Y and grad otherwise) and Y / grad are re-read from global memory (static
+    // during the launch: plain cached loads, L2 resident); only eta and r stay in registers.
+    constexpr bool LOWREG = (R > 4);
+    double2 eta[R], rr[R], md[LOWREG ? 1 : R], hmd[LOWREG ? 1 : R];
+#define VOFF(r) ((int64_t)ROW(r) * d.ld + 2 * sub)
+#define Y_GET(r) (LOWREG ? (OK(r) ? ld2(Yl + VOFF(r)) : zz) : Ys[(r) * PB + threadIdx.x])
+#define G_GET(r) (LOWREG ? (OK(r) ? ld2(gl + VOFF(r)) : zz) : Gs[(r) * PB + threadIdx.x])
+#define MD_GET(r) (LOWREG ? Ys[(r) * PB + threadIdx.x] : md[LOWREG ? 0 : (r)])
+#define MD_SET(r, val) do { if (LOWREG) Ys[(r) * PB + threadIdx.x] = (val); else md[LOWREG ? 0 : (r)] = (val); } while (0)
+#define HMD_GET(r) (LOWREG ? Gs[(r) * PB + threadIdx.x] : hmd[LOWREG ? 0 : (r)])
+#define HMD_SET(r, val) do { if (LOWREG) Gs[(r) * PB + threadIdx.x] = (val); else hmd[LOWREG ? 0 : (r)] = (val); } while (0)
     const double2 zz = make_double2(0.0, 0.0);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -252,9 +263,8 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         const int64_t o = (int64_t)rc * d.ld + (colok ? 2 * sub : 0);
         double2 y = ld2(Yl + o), g = ld2(gl + o);
         if (!OK(r)) { y = zz; g = zz; }
-        Ys[r * PB + threadIdx.x] = y;
-        Gs[r * PB + threadIdx.x] = g;
-        eta[r] = zz; rr[r] = g; md[r] = g; hmd[r] = zz;           // tCG.m:102-157
+        if (!LOWREG) { Ys[r * PB + threadIdx.x] = y; Gs[r * PB + threadIdx.x] = g; }
+        eta[r] = zz; rr[r] = g; MD_SET(r, g); HMD_SET(r, zz);      // tCG.m:102-157
         const double egv = eGl[rc];
         int cw[EW > 0 ? EW : 1];
         double vw[EW > 0 ? EW : 1];
@@ -288,8 +298,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     for (;;) {
         // ---- Hmdelta = proj(C*mdelta) - mdelta.*eG   (tCG.m:163, ManiSDP_onlyunitdiag.m:127-130)
         double pd = 0.0, u1 = 0.0, u2 = 0.0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
+        auto hrow = [&](int r) {
             double2 acc = zz;
             if (EW > 0) {
                 double2 x[EW > 0 ? EW : 1];
@@ -346,17 +355,23 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
                 }
             }
             if (!colok) acc = zz;
-            const double2 y = Ys[r * PB + threadIdx.x];
+            const double2 y = Y_GET(r), mdr = MD_GET(r);
             double dot = acc.x * y.x + acc.y * y.y;
             dot = msdp_group_sum<LPR>(dot);
             const double eg = eGs[SLOT(r)];
-            hmd[r].x = acc.x - y.x * dot - md[r].x * eg;
-            hmd[r].y = acc.y - y.y * dot - md[r].y * eg;
-            if (!OK(r)) hmd[r] = zz;
-            pd += md[r].x * hmd[r].x + md[r].y * hmd[r].y;
-            // R = 8 keeps 128 registers of resident rows: do not let the scheduler hoist all 40 gathers (160
-            // more registers) above the first use; two rows (10 gathers) in flight per wave
-            if (R > 4 && (r & 1)) __builtin_amdgcn_sched_barrier(0);
+            double2 hq = make_double2(acc.x - y.x * dot - mdr.x * eg, acc.y - y.y * dot - mdr.y * eg);
+            if (!OK(r)) hq = zz;
+            HMD_SET(r, hq);
+            pd += mdr.x * hq.x + mdr.y * hq.y;
+        };
+        if (LOWREG) {
+            // rolled: in this mode the loop touches LDS / global memory only (no register arrays), and unrolling it
+            // lets the compiler hoist the loads of all 8 rows (spills)
+#pragma unroll 1
+            for (int r0 = 0; r0 < R; r0 += 4) { hrow(r0); hrow(r0 + 1); hrow(r0 + 2); hrow(r0 + 3); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) hrow(r);
         }
         if (!psync(slots, gen++, d.G, 1, pd, u1, u2, sh, shb, err)) { failed = true; break; }
         const double d_Hd = pd;                                                        // :166
@@ -366,8 +381,9 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
             const double tau = (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta * Delta - e_Pe))) / d_Pd;   // :188
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                eta[r].x -= tau * md[r].x; eta[r].y -= tau * md[r].y;                  // :192
-                rr[r].x -= tau * hmd[r].x; rr[r].y -= tau * hmd[r].y;                  // :198 (Heta = r - grad)
+                const double2 mdr = MD_GET(r), hq = HMD_GET(r);
+                eta[r].x -= tau * mdr.x; eta[r].y -= tau * mdr.y;                      // :192
+                rr[r].x -= tau * hq.x; rr[r].y -= tau * hq.y;                          // :198 (Heta = r - grad)
             }
             stop = (d_Hd <= 0.0) ? 1 : 2;
             ++j;
@@ -377,9 +393,9 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         double s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const double2 g = Gs[r * PB + threadIdx.x];
-            const double2 ne = make_double2(eta[r].x - alpha * md[r].x, eta[r].y - alpha * md[r].y);     // :215
-            const double2 nr = make_double2(rr[r].x - alpha * hmd[r].x, rr[r].y - alpha * hmd[r].y);    // :238
+            const double2 g = G_GET(r), mdr = MD_GET(r), hq = HMD_GET(r);
+            const double2 ne = make_double2(eta[r].x - alpha * mdr.x, eta[r].y - alpha * mdr.y);         // :215
+            const double2 nr = make_double2(rr[r].x - alpha * hq.x, rr[r].y - alpha * hq.y);             // :238
             const double2 nh = make_double2(nr.x - g.x, nr.y - g.y);                                     // new_Heta (:220)
             s1 += ne.x * g.x + ne.y * g.y;
             s2 += ne.x * nh.x + ne.y * nh.y;
@@ -392,8 +408,9 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         if (!bench && new_model >= model_value) { stop = 6; ++j; break; }              // :228 (eta, Heta stay)
 #pragma unroll
         for (int r = 0; r < R; ++r) {                                                  // :233-238 commit (same bits as the trial)
-            eta[r].x -= alpha * md[r].x; eta[r].y -= alpha * md[r].y;
-            rr[r].x -= alpha * hmd[r].x; rr[r].y -= alpha * hmd[r].y;
+            const double2 mdr = MD_GET(r), hq = HMD_GET(r);
+            eta[r].x -= alpha * mdr.x; eta[r].y -= alpha * mdr.y;
+            rr[r].x -= alpha * hq.x; rr[r].y -= alpha * hq.y;
         }
         model_value = new_model;
         ++j;
@@ -411,12 +428,13 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         // ---- mdelta = tangent(r + beta*mdelta)  (:273,283) and hand the new rows to the neighbours
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const double2 y = Ys[r * PB + threadIdx.x];
-            const double2 v = make_double2(rr[r].x + beta * md[r].x, rr[r].y + beta * md[r].y);
+            const double2 y = Y_GET(r), mdr = MD_GET(r);
+            const double2 v = make_double2(rr[r].x + beta * mdr.x, rr[r].y + beta * mdr.y);
             double dot = v.x * y.x + v.y * y.y;
             dot = msdp_group_sum<LPR>(dot);
-            md[r] = make_double2(v.x - y.x * dot, v.y - y.y * dot);
-            if (OK(r)) st2_sc1(rs_md, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, md[r]);
+            const double2 mnew = make_double2(v.x - y.x * dot, v.y - y.y * dot);
+            MD_SET(r, mnew);
+            if (OK(r)) st2_sc1(rs_md, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, mnew);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my rows are performed before my workgroup posts
         if (!pbarrier(slots, nbar++, d.G, shb, err)) { failed = true; break; }
@@ -428,7 +446,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     for (int r = 0; r < R; ++r) {
         if (OK(r)) {
             const int64_t o = (int64_t)ROW(r) * d.ld + 2 * sub;
-            const double2 g = Gs[r * PB + threadIdx.x];
+            const double2 g = G_GET(r);
             st2(d.eta[0] + o, eta[r]);
             st2(d.Heta[0] + o, make_double2(rr[r].x - g.x, rr[r].y - g.y));
         }
@@ -440,6 +458,13 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     }
 }
 
+#undef VOFF
+#undef Y_GET
+#undef G_GET
+#undef MD_GET
+#undef MD_SET
+#undef HMD_GET
+#undef HMD_SET
 #undef SLOT
 #undef ROW
 #undef ROK
