@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -370,6 +371,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     if (h->h_status) (void)hipHostFree((void*)h->h_status);
     for (int s2 = 0; s2 < 2; ++s2) if (h->chunk_execs[s2]) (void)hipGraphExecDestroy(h->chunk_execs[s2]);
     msdp_affine_release(h);
+    if (h->esc_mem) (void)hipFree(h->esc_mem);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -706,6 +708,7 @@ static int run_tcg(msdp_handle h, int maxinner, int k, bool* done_out = nullptr)
     if (enq * CH < maxinner) { if ((rc = launch_chunk(h, CH, graph))) return rc; enq = 2; }
     const unsigned long long want = (unsigned long long)(unsigned)(k + 1);
     const auto t0 = std::chrono::steady_clock::now();
+    auto last_query = t0;
     long spins = 0;
     for (;;) {
         const unsigned long long s = *h->h_status;
@@ -721,7 +724,10 @@ static int run_tcg(msdp_handle h, int maxinner, int k, bool* done_out = nullptr)
                 continue;
             }
         }
-        if ((++spins & 0xfff) == 0) {
+        std::this_thread::sleep_for(std::chrono::microseconds(10));     // polite polling (a chunk of 8 trips lasts ~0.2 ms)
+        if ((++spins & 0xff) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - last_query).count() > 1.0) {
+            last_query = std::chrono::steady_clock::now();      // hipStreamQuery is not a cheap poll (can block for tens of ms): safety net only
             if (hipStreamQuery(h->stream) == hipSuccess) {
                 // everything enqueued has run: the final status must be visible now
                 const unsigned long long s2 = *h->h_status;
@@ -764,7 +770,7 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
     if (timing < 0) { const char* e = getenv("MSDP_TIMING"); timing = (e && atoi(e)) ? 1 : 0; }
     static int sync_tr = -1;
     if (sync_tr < 0) { const char* e = getenv("MSDP_SYNC_TR"); sync_tr = (e && atoi(e)) ? 1 : 0; }
-    double t_tcg = 0.0, t_rest = 0.0;
+    double t_tcg = 0.0, t_rest = 0.0, t_enq_sum = 0.0, t_enq_max = 0.0;
     const char* nopub_env = getenv("MSDP_NO_PUBLISH");
     const bool async_tr = !sync_tr && h->d.costkind == COST_SPARSE && !h->use_comm && !(nopub_env && atoi(nopub_env));
     if (async_tr && msdp_persist_eligible(h)) {
@@ -782,6 +788,7 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
         int enq = 0;
         bool done = false;
         const auto ta = std::chrono::steady_clock::now();
+        auto last_query = ta;
         if (opts->maxiter > 0) { if ((rc = enqueue_iter())) return rc; enq = 1; }
         while (enq > 0 && !done) {
             const unsigned long long want = (unsigned long long)(unsigned)enq;
@@ -789,21 +796,38 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
             for (;;) {
                 const unsigned long long s = *h->h_status;
                 if ((s >> 32) == want) { if (((s & 0xffffffffULL) >> 1) & 0x40000000) done = true; break; }
-                if ((++spins & 0xfff) == 0) {
-                    if (hipStreamQuery(h->stream) == hipSuccess) {
-                        const unsigned long long s2 = *h->h_status;
-                        if ((s2 >> 32) == want) { if (((s2 & 0xffffffffULL) >> 1) & 0x40000000) done = true; break; }
-                        msdp_set_error("persistent tCG: progress word inconsistent (status %llx, expected iteration %d)", s2, enq);
-                        return MSDP_EHIP;
+                // a TR iteration lasts 0.3-2 ms and the host only has to stay one iteration ahead: poll politely
+                // (a hard spin burns a full core; under a container CPU quota that got this thread throttled
+                // for tens of ms at a time, seen as 60 ms holes in the kernel trace of the G81 solve)
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+                if ((++spins & 0xff) == 0) {
+                    // hipStreamQuery is NOT a cheap poll (every call makes the runtime touch the queue; called every
+                    // few microseconds it stalled the stream for tens of ms, seen as gaps in the kernel trace): it is
+                    // only the safety net against a lost progress word; on a stream that is running a long kernel one call was
+                    // measured to block for ~40 ms, so ask only after 2 s without any progress
+                    const auto now = std::chrono::steady_clock::now();
+                    if (std::chrono::duration<double>(now - last_query).count() > 2.0) {
+                        last_query = now;
+                        if (hipStreamQuery(h->stream) == hipSuccess) {
+                            const unsigned long long s2 = *h->h_status;
+                            if ((s2 >> 32) == want) { if (((s2 & 0xffffffffULL) >> 1) & 0x40000000) done = true; break; }
+                            msdp_set_error("persistent tCG: progress word inconsistent (status %llx, expected iteration %d)", s2, enq);
+                            return MSDP_EHIP;
+                        }
                     }
-                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count() > 300.0) {
+                    if (std::chrono::duration<double>(now - ta).count() > 300.0) {
                         msdp_set_error("persistent tCG made no progress for 300 s");
                         return MSDP_EHIP;
                     }
                 }
             }
             if (done || enq >= opts->maxiter) break;
+            last_query = std::chrono::steady_clock::now();
             if ((rc = enqueue_iter())) return rc;
+            if (timing) {
+                const double de = std::chrono::duration<double>(std::chrono::steady_clock::now() - last_query).count();
+                t_enq_sum += de; if (de > t_enq_max) t_enq_max = de;
+            }
             ++enq;
         }
         if ((rc = pull_ctl(h))) return rc;
@@ -845,8 +869,11 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
     }
     }
     if (timing)
-        fprintf(stderr, "[msdp_rtr] k=%d hessvecs=%d  tCG phase %.3f ms  (retract+cost+decide+sync) %.3f ms\n",
-                h->h_ctl->k, h->h_ctl->hessvecs, t_tcg * 1e3, t_rest * 1e3);
+        fprintf(stderr, "[msdp_rtr] enqueue total %.3f ms, slowest %.3f ms\n", t_enq_sum * 1e3, t_enq_max * 1e3);
+    if (timing)
+        fprintf(stderr, "[msdp_rtr] p=%d ld=%d G=%d path=%d k=%d hessvecs=%d acc=%d rej=%d  tCG phase %.3f ms  (retract+cost+decide+sync) %.3f ms\n",
+                h->d.p, h->d.ld, h->d.G, (async_tr && msdp_persist_eligible(h)) ? 1 : 0, h->h_ctl->k, h->h_ctl->hessvecs,
+                h->h_ctl->accepted, h->h_ctl->rejected, t_tcg * 1e3, t_rest * 1e3);
     h->state_valid = true;
     h->gradnorm_valid = true;
     if (stats) {

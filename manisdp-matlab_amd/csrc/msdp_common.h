@@ -137,6 +137,10 @@ struct msdp_handle_s {
     volatile unsigned long long* h_status = nullptr;   // host view of Dev::status
     double* slab = nullptr;        // split-K partial slabs of the dense MFMA path
     size_t slab_cap = 0;
+    // escape workspace, kept between calls (freeing 3 GB after every call stalled the NEXT kernels on the stream
+    // for ~60 ms while the driver unmapped it: gaps seen in the kernel trace of the G81 solve)
+    double* esc_mem = nullptr;
+    size_t esc_cap = 0;               // doubles
     // persistent tCG kernel (msdp_persist.hip): grid-sync slots, error flag, cached eligibility
     unsigned long long* psync_slots = nullptr;
     int* psync_err = nullptr;

@@ -442,8 +442,13 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     double* mem = nullptr;
     const size_t slot_doubles = msdp_lanczos_slot_bytes() / sizeof(double);
     const size_t total = (size_t)(qcap + maxit + 2 + qcap) * n + (size_t)n + 2 * (size_t)(maxit + 2) + 4096 + (size_t)n + slot_doubles + 16;
-    hipError_t me = hipMalloc((void**)&mem, total * sizeof(double));
-    if (me != hipSuccess) { msdp_set_error("escape_eigs: workspace allocation (%zu MB) failed", total * 8 >> 20); return MSDP_ENOMEM; }
+    if (h->esc_cap < total) {
+        if (h->esc_mem) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->esc_mem); h->esc_mem = nullptr; h->esc_cap = 0; }
+        hipError_t me = hipMalloc((void**)&h->esc_mem, total * sizeof(double));
+        if (me != hipSuccess) { h->esc_mem = nullptr; msdp_set_error("escape_eigs: workspace allocation (%zu MB) failed", total * 8 >> 20); return MSDP_ENOMEM; }
+        h->esc_cap = total;
+    }
+    mem = h->esc_mem;
     double* Q = mem;                                   // deflation set: orth(Y) then accepted eigenvectors
     double* V = Q + (size_t)qcap * n;                   // Lanczos vectors
     double* Z = V + (size_t)(maxit + 2) * n;            // Rayleigh-Ritz basis copy
@@ -542,6 +547,6 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     }
 done:
     (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(mem);
+    (void)mem;                                       // kept in the handle for the next call
     return rc;
 }

@@ -518,8 +518,8 @@ static int persist_grid(const Dev& d) {
 // 1: the persistent kernel can run this handle's tCG (and all its workgroups are co-resident); 0: use the chunked path
 int msdp_persist_eligible(msdp_handle h) {
     const Dev& d = h->d;
-    static int off = -1;
-    if (off < 0) { const char* e = getenv("MSDP_NO_PERSIST"); off = (e && atoi(e)) ? 1 : 0; }
+    const char* e_off = getenv("MSDP_NO_PERSIST");         // read on every call: tests flip it inside one process
+    const int off = (e_off && atoi(e_off)) ? 1 : 0;
     if (off || h->use_comm || h->nranks != 1 || d.costkind != COST_SPARSE || d.manifold != MANI_OBLIQUE) return 0;
     if (!h->psync_slots) return 0;
     const int G = persist_grid(d);

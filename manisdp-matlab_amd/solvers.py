@@ -22,6 +22,29 @@ import scipy.sparse as sp
 
 from . import _lib
 
+
+def _host_threads():
+    """Context manager capping the BLAS/LAPACK threads of the host-side AL bookkeeping (thin SVD, residues) at the
+    CPUs this process may actually use.  On a 256-core box inside a 16-CPU cgroup quota the default (256 threads on
+    20000 x 40 matrices) burns the quota and gets the thread that feeds the GPU throttled."""
+    import contextlib
+    import os
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:                                      # pragma: no cover
+        return contextlib.nullcontext()
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except Exception:                                      # pragma: no cover
+        ncpu = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            ncpu = min(ncpu, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return threadpool_limits(limits=max(1, min(ncpu, 16)))
+
 __all__ = ["ManiSDP_onlyunitdiag", "ManiSDP_unitdiag", "ManiSDP_unittrace"]
 
 
@@ -66,6 +89,11 @@ def _extreme_eigs_host(S, k, dense_max):
 
 # =============================================================== onlyunitdiag
 def ManiSDP_onlyunitdiag(C, options=None, verbose=True, rng=None):
+    with _host_threads():
+        return _onlyunitdiag_impl(C, options, verbose, rng)
+
+
+def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
     """``[X, obj, data] = ManiSDP_onlyunitdiag(C, options)`` (reference
     src/primal/ManiSDP_onlyunitdiag.m:6).  Extra, optional option fields that the
     reference does not have: ``Y0`` (start point instead of ``randn``), ``eig``
@@ -201,6 +229,11 @@ def _dense_vec(v):
 
 
 def _affine_common(kind, At, b, c, K, options, verbose, rng, defaults):
+    with _host_threads():
+        return _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults)
+
+
+def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
     o = dict(options or {})
     for k, v in defaults.items():
         o.setdefault(k, v)

@@ -10,7 +10,8 @@ from conftest import golden_path
 pytestmark = pytest.mark.gpu
 
 
-def test_size1_communicator_is_bit_identical():
+def test_size1_communicator_is_bit_identical(monkeypatch):
+    monkeypatch.setenv("MSDP_NO_PERSIST", "1")       # compare with the communicator-free CHUNKED path (same kernels)
     from manisdp_matlab_amd import _lib, problems
     _lib.load()
     C = problems.maxcut_cost_matrix(golden_path("G1.txt.gz"))
