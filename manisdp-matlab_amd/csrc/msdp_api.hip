@@ -773,7 +773,23 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
     double t_tcg = 0.0, t_rest = 0.0, t_enq_sum = 0.0, t_enq_max = 0.0;
     const char* nopub_env = getenv("MSDP_NO_PUBLISH");
     const bool async_tr = !sync_tr && h->d.costkind == COST_SPARSE && !h->use_comm && !(nopub_env && atoi(nopub_env));
-    if (async_tr && msdp_persist_eligible(h)) {
+    if (async_tr && msdp_persist_fused_ok(h)) {
+        // Fused path: the whole trustregions() loop (every tCG, retraction, cost/gradient at the proposal and the
+        // accept/reject logic) runs in ONE launch; the host only waits for it (msdp_persist.hip, FUSE = true).
+        const auto ta = std::chrono::steady_clock::now();
+        h->d.status = nullptr;                                            // no progress word needed
+        rc = msdp_launch_rtr_fused(h);
+        {
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, (void*)h->h_status, 0) == hipSuccess) h->d.status = (unsigned long long*)dp;
+        }
+        if (rc) return rc;
+        if ((rc = pull_ctl(h))) return rc;
+        int perr = 0;
+        HIPCHK(hipMemcpy(&perr, h->psync_err, sizeof(int), hipMemcpyDeviceToHost));
+        if (perr) { msdp_set_error("fused RTR: grid synchronisation timed out"); return MSDP_EHIP; }
+        t_tcg = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+    } else if (async_tr && msdp_persist_eligible(h)) {
         // Persistent path: one launch runs the whole tCG of a TR iteration with the working set on chip
         // (msdp_persist.hip).  The host stays one TR iteration ahead of the device: iteration i+1 is enqueued
         // as soon as the kernel of iteration i publishes that it has started; a finished solve (ctl->done)

@@ -145,6 +145,7 @@ struct msdp_handle_s {
     unsigned long long* psync_slots = nullptr;
     int* psync_err = nullptr;
     int persist_sig_lpr = 0, persist_sig_ew = 0, persist_sig_r = 0, persist_sig_G = 0, persist_sig_ok = 0;
+    int fused_sig_lpr = 0, fused_sig_ew = 0, fused_sig_G = 0, fused_sig_ok = 0;
 };
 
 // --- launchers implemented in the .hip units (all asynchronous on h->stream) ---
@@ -160,6 +161,8 @@ int msdp_launch_rtr_decide(msdp_handle h);
 int msdp_alloc_vectors(msdp_handle h, int pcap);
 int msdp_persist_eligible(msdp_handle h);                     // msdp_persist.hip
 int msdp_launch_tcg_persist(msdp_handle h);                   // whole tCG of the current TR iteration, one launch
+int msdp_persist_fused_ok(msdp_handle h);                     // whole trustregions() loop in one launch possible?
+int msdp_launch_rtr_fused(msdp_handle h);
 size_t msdp_psync_bytes();
 int msdp_allreduce_partials(msdp_handle h, int first, int count);   // no-op when nranks == 1
 int msdp_allgather_rows(msdp_handle h, const double* local_rows);   // local -> d.full

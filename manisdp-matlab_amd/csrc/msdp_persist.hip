@@ -163,8 +163,9 @@ __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, i
                                PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    a = shb[0]; b = shb[1]; c = shb[2];
-    return shb[3] == 0.0;
+    // wave-uniform results: readlane moves them to scalar registers (they live across the whole solve)
+    a = msdp_readlane(shb[0], 0); b = msdp_readlane(shb[1], 0); c = msdp_readlane(shb[2], 0);
+    return msdp_readlane(shb[3], 0) == 0.0;
 }
 
 // Barrier without a value (the new direction rows are in place): workgroup b adds to counter b & 7, everybody
@@ -195,7 +196,7 @@ __device__ __forceinline__ bool pbarrier(unsigned long long* slots, unsigned nba
 }
 
 // LPR lanes per row (one double2 per lane), EW = stored ELL width, R = row slots per lane group.
-template <int LPR, int EW, int R>
+template <int LPR, int EW, int R, bool FUSE>
 __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long long* slots, int* err) {
     extern __shared__ double lds[];
     __shared__ double sh[3 * PWAVES];
@@ -208,6 +209,10 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     double* eGs = reinterpret_cast<double*>(Gs + R * PB);  // [ROWS]
     double* vs = eGs + ROWS;                                       // [EW][ROWS]
     int* cs = reinterpret_cast<int*>(vs + EW * ROWS);              // [EW][ROWS]
+    // FUSE only: the proposal point, its gradient and eG (the cost/gradient phase runs rolled, out of LDS)
+    double2* YPs = reinterpret_cast<double2*>(cs + ((EW * ROWS + 3) & ~3));   // [R][PB]
+    double2* GPs = YPs + R * PB;                                   // [R][PB]
+    double* EGPs = reinterpret_cast<double*>(GPs + R * PB);        // [ROWS]
 
     const Ctl* c = d.ctl;
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
@@ -220,17 +225,24 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         }
         return;
     }
-    if (lead) msdp_publish(d, k_tr, 0, 1);                         // "TR iteration k_tr has started" (host pipelining)
+    if (lead && !FUSE) msdp_publish(d, k_tr, 0, 1);                // "TR iteration k_tr has started" (host pipelining)
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
     const bool colok = 2 * sub < d.ld;
-    const int cur = c->cur;
+    int cur = c->cur;
     const bool bench = c->bench_mode != 0;
-    const double Delta = c->Delta, kappa = c->kappa, theta = c->theta;
+    double Delta = c->Delta;
+    const double kappa = c->kappa, theta = c->theta;
     const int mininner = c->mininner, maxinner = c->maxinner;
-    const double gg = c->gg;
+    double gg = c->gg;
+    // trust-region level state (FUSE: the whole trustregions() loop runs in this launch; trustregions.m:441-767)
+    double fx = c->fx, rho = 0.0, rhonum = 0.0, rhoden = 0.0, fx_prop = 0.0, gg_prop = 0.0;
+    const double Delta_bar = c->Delta_bar, tolgradnorm = c->tolgradnorm, rho_prime = c->rho_prime, rho_reg_opt = c->rho_reg;
+    const int maxiter = c->maxiter;
+    int k_it = c->k, hessvecs = c->hessvecs, accepted = c->accepted, rejected = c->rejected, cost_evals = c->cost_evals;
+    int last_stop = c->last_stop_inner;
     const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
     const double* __restrict__ gl = cur ? d.Gr[1] : d.Gr[0];
     const double* __restrict__ eGl = cur ? d.eG[1] : d.eG[0];
@@ -284,21 +296,31 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     }
     __syncthreads();
 
+    unsigned gen = 0, nbar = 0;
+    const unsigned vec_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
+    __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(d.md, 0, vec_bytes, 0x00020000);
+    bool failed = false;
+    bool first_tr = true;
+  for (;;) {   // ---- trust-region iterations (exactly one pass when !FUSE)
+    if (FUSE && !first_tr) {
+        // tCG.m:102-157 at the (possibly new) current point: eta = 0, r = mdelta = grad
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double2 g = Gs[r * PB + threadIdx.x];
+            eta[r] = zz; rr[r] = g; MD_SET(r, g); HMD_SET(r, zz);
+        }
+    }
+    first_tr = false;
     double z_r = gg, d_Pd = gg, e_Pd = 0.0, e_Pe = 0.0, model_value = 0.0, alpha = 0.0, beta = 0.0;
     const double norm_r0 = sqrt(gg);
     int j = 0, stop = 5;
-    unsigned gen = 0, nbar = 0;
-    // first direction = gradient: already in global memory (written by an earlier launch); later trips gather the
-    // rows the other workgroups stored with sc1 during this launch
-    const unsigned vec_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
-    __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(gl), 0, vec_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(d.md, 0, vec_bytes, 0x00020000);
+    // first direction = gradient: already in global memory (written by an earlier launch, or with sc1 stores by
+    // the cost/gradient phase of the previous TR iteration); later trips gather the rows the other workgroups
+    // stored with sc1 during this launch
+    __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[1] : d.Gr[0], 0, vec_bytes, 0x00020000);
     bool first = true;
-    bool failed = false;
-    for (;;) {
-        // ---- Hmdelta = proj(C*mdelta) - mdelta.*eG   (tCG.m:163, ManiSDP_onlyunitdiag.m:127-130)
-        double pd = 0.0, u1 = 0.0, u2 = 0.0;
-        auto hrow = [&](int r) {
+    // acc = sum_k C[row,k] * X[k, my columns] with X read through the agent-coherent resource rs
+    auto gather_row = [&](int r, __amdgpu_buffer_rsrc_t rs) -> double2 {
             double2 acc = zz;
             if (EW > 0) {
                 double2 x[EW > 0 ? EW : 1];
@@ -308,7 +330,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
                     const int cidx = cs[w * ROWS + SLOT(r)];
                     v[w] = vs[w * ROWS + SLOT(r)];
                     const unsigned off = ((unsigned)cidx * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u;
-                    x[w] = first ? ld2_sc1(rs_g, off) : ld2_sc1(rs_md, off);
+                    x[w] = ld2_sc1(rs, off);
                 }
 #pragma unroll
                 for (int w = 0; w < EW; ++w) {
@@ -336,7 +358,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
                     for (int u = 0; u < 8; ++u) {
                         const unsigned off = ((unsigned)cn[u] * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u;
                         cvk[u] = vn[u];
-                        x[u] = first ? ld2_sc1(rs_g, off) : ld2_sc1(rs_md, off);
+                        x[u] = ld2_sc1(rs, off);
                     }
                     if (k0 + 8 < s1) {
 #pragma unroll
@@ -355,6 +377,13 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
                 }
             }
             if (!colok) acc = zz;
+            return acc;
+    };
+    for (;;) {
+        // ---- Hmdelta = proj(C*mdelta) - mdelta.*eG   (tCG.m:163, ManiSDP_onlyunitdiag.m:127-130)
+        double pd = 0.0, u1 = 0.0, u2 = 0.0;
+        auto hrow = [&](int r) {
+            const double2 acc = gather_row(r, first ? rs_g : rs_md);
             const double2 y = Y_GET(r), mdr = MD_GET(r);
             double dot = acc.x * y.x + acc.y * y.y;
             dot = msdp_group_sum<LPR>(dot);
@@ -441,20 +470,105 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         first = false;
     }
     if (failed) return;
-    // ---- hand eta, Heta = r - grad and the final scalars to the RTR kernels (trustregions.m:540-550)
+    if (!FUSE) {
+        // ---- hand eta, Heta = r - grad and the final scalars to the RTR kernels (trustregions.m:540-550)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (OK(r)) {
+                const int64_t o = (int64_t)ROW(r) * d.ld + 2 * sub;
+                const double2 g = G_GET(r);
+                st2(d.eta[0] + o, eta[r]);
+                st2(d.Heta[0] + o, make_double2(rr[r].x - g.x, rr[r].y - g.y));
+            }
+        }
+        if (lead) {
+            frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha, beta, 0, j, stop, 0, 0, 0);
+            d.ctl->tcg_running = 0;
+            msdp_publish(d, k_tr, j, 0);
+        }
+        return;
+    }
+    // ================= rest of the TR iteration (FUSE): trustregions.m:540-729 =================
+    // x_prop = retr(x, eta) (ManiSDP_onlyunitdiag.m:142-145), <eta, grad + .5*Heta> (trustregions.m:549-550)
+    double prd = 0.0, pf = 0.0, pgg = 0.0;
+    __amdgpu_buffer_rsrc_t rs_yp = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Y[0] : d.Y[1], 0, vec_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_gp = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[0] : d.Gr[1], 0, vec_bytes, 0x00020000);
+    double* eGp = cur ? d.eG[0] : d.eG[1];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        if (OK(r)) {
-            const int64_t o = (int64_t)ROW(r) * d.ld + 2 * sub;
-            const double2 g = G_GET(r);
-            st2(d.eta[0] + o, eta[r]);
-            st2(d.Heta[0] + o, make_double2(rr[r].x - g.x, rr[r].y - g.y));
-        }
+        const double2 y = Ys[r * PB + threadIdx.x], g = Gs[r * PB + threadIdx.x];
+        const double2 he = make_double2(rr[r].x - g.x, rr[r].y - g.y);
+        prd += eta[r].x * (g.x + 0.5 * he.x) + eta[r].y * (g.y + 0.5 * he.y);
+        const double2 x = make_double2(y.x + eta[r].x, y.y + eta[r].y);
+        double nn = sqrt(msdp_group_sum<LPR>(x.x * x.x + x.y * x.y));
+        if (!(nn > 0.0)) nn = 1.0;                                  // empty row slot
+        const double2 ypr = OK(r) ? make_double2(x.x / nn, x.y / nn) : zz;
+        YPs[r * PB + threadIdx.x] = ypr;
+        if (OK(r)) st2_sc1(rs_yp, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, ypr);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!pbarrier(slots, nbar++, d.G, shb, err)) return;
+    // cost and gradient at the proposal (ManiSDP_onlyunitdiag.m:117-125): YC = Y*C, eG = sum(YC.*Y), G = YC - Y.*eG.
+    // Rolled loop over the row slots (LDS in, LDS out): this phase runs once per TR iteration and must not add
+    // register pressure to the tCG loop above.
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+        const double2 acc = gather_row(r, rs_yp);
+        const double2 ypr = YPs[r * PB + threadIdx.x];
+        const double dot = msdp_group_sum<LPR>(acc.x * ypr.x + acc.y * ypr.y);
+        const double2 gpr = OK(r) ? make_double2(acc.x - ypr.x * dot, acc.y - ypr.y * dot) : zz;
+        GPs[r * PB + threadIdx.x] = gpr;
+        pgg += gpr.x * gpr.x + gpr.y * gpr.y;
+        if (sub == 0) {
+            EGPs[SLOT(r)] = ROK(r) ? dot : 0.0;
+            if (ROK(r)) { pf += 0.5 * dot; eGp[ROW(r)] = dot; }
+        }
+        if (OK(r)) st2_sc1(rs_gp, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, gpr);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the proposal's gradient rows are in place before the post
+    if (!psync(slots, gen++, d.G, 3, pf, pgg, prd, sh, shb, err)) return;
+    {   // trustregions.m:548-729, identical in every workgroup (same bits in, same decision out)
+        const double fp = pf, ggp = pgg;
+        rhonum = fx - fp;                                                    // :548
+        rhoden = -prd;                                                       // :550
+        const double rreg = fmax(1.0, fabs(fx)) * 2.220446049250313e-16 * rho_reg_opt;   // :579
+        rhonum += rreg;
+        rhoden += rreg;
+        const bool model_decreased = rhoden >= 0.0;                          // :614
+        rho = rhonum / rhoden;                                               // :621
+        if (rho < 0.25 || !model_decreased || isnan(rho)) Delta = Delta / 4.0;            // :653
+        else if (rho > 0.75 && (stop == 1 || stop == 2)) Delta = fmin(2.0 * Delta, Delta_bar);   // :669
+        fx_prop = fp; gg_prop = ggp;
+        if (model_decreased && rho > rho_prime) {                            // :688
+            cur ^= 1;
+            fx = fp; gg = ggp;
+            ++accepted;
+#pragma unroll 1
+            for (int r = 0; r < R; ++r) {
+                Ys[r * PB + threadIdx.x] = YPs[r * PB + threadIdx.x];
+                Gs[r * PB + threadIdx.x] = GPs[r * PB + threadIdx.x];
+                if (sub == 0) eGs[SLOT(r)] = EGPs[SLOT(r)];
+            }
+        } else {
+            ++rejected;
+        }
+        ++k_it;                                                              // :729
+        hessvecs += j;
+        ++cost_evals;
+        last_stop = stop;
+    }
+    __syncthreads();                                                         // eGs / Ys / Gs updates visible to the whole workgroup
+    if (sqrt(gg) < tolgradnorm || k_it >= maxiter) break;                    // stoppingcriterion.m:51-72
+  }
     if (lead) {
-        frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha, beta, 0, j, stop, 0, 0, 0);
-        d.ctl->tcg_running = 0;
-        msdp_publish(d, k_tr, j, 0);
+        Ctl* cw = d.ctl;
+        cw->fx = fx; cw->gg = gg; cw->norm_grad = sqrt(gg); cw->Delta = Delta;
+        cw->rho = rho; cw->rhonum = rhonum; cw->rhoden = rhoden; cw->fx_prop = fx_prop; cw->gg_prop = gg_prop;
+        cw->k = k_it; cw->cur = cur; cw->hessvecs = hessvecs; cw->accepted = accepted; cw->rejected = rejected;
+        cw->cost_evals = cost_evals; cw->last_stop_inner = last_stop;
+        cw->done = 1;
+        cw->tcg_running = 0;
+        frame_store(&d.F[0], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, last_stop, 0, 0, 0);
     }
 }
 
@@ -491,10 +605,14 @@ static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
 }
 
 typedef void (*persist_fn)(Dev, unsigned long long*, int*);
-static persist_fn persist_kernel(const PersistPlan& pl) {
-#define PK(L, E) if (pl.lpr == L && pl.ew == E && pl.r == L / 4) return k_tcg_persist_obl<L, E, L / 4>;
+static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false) {
+#define PK(L, E) if (pl.lpr == L && pl.ew == E && pl.r == L / 4) return k_tcg_persist_obl<L, E, L / 4, false>;
+#define PKF(L, E) if (fuse && pl.lpr == L && pl.ew == E && pl.r == L / 4) return k_tcg_persist_obl<L, E, L / 4, true>;
+    PKF(8, 5) PKF(8, 8) PKF(16, 5) PKF(16, 8) PKF(8, 0) PKF(16, 0)
+    if (fuse) return nullptr;                          // the fused form needs Y and grad in LDS (p <= 32)
     PK(8, 5) PK(8, 8) PK(16, 5) PK(16, 8) PK(32, 5) PK(32, 8) PK(8, 0) PK(16, 0) PK(32, 0)
 #undef PK
+#undef PKF
     return nullptr;
 }
 
@@ -551,6 +669,53 @@ int msdp_launch_tcg_persist(msdp_handle h) {
     if (!persist_plan(h->d, G, pl)) { msdp_set_error("persistent tCG: not eligible"); return MSDP_ESTATE; }
     persist_fn fn = persist_kernel(pl);
     if (!fn) { msdp_set_error("persistent tCG: no kernel instance"); return MSDP_ESTATE; }
+    Dev dp = h->d;
+    dp.G = G;
+    hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, h->stream, h->psync_slots, h->psync_err);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(fn, dim3(G), dim3(PB), pl.lds, h->stream, dp, h->psync_slots, h->psync_err);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// LDS of the fused form: + the proposal point, its gradient (R x PB double2 each) and eG
+static size_t fused_lds(const PersistPlan& pl) {
+    const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr);
+    return pl.lds + 16 + (size_t)2 * pl.r * PB * sizeof(double2) + rows * sizeof(double);
+}
+
+// Whole trustregions() loop in one launch (FUSE = true): tCG + retraction + cost/gradient at the proposal + the
+// accept/reject logic, iterated on the device until gradnorm < tol or maxiter.  Needs Y and grad in LDS (p <= 32).
+// Opt-in (MSDP_FUSED_RTR=1): correct (tests/test_gpu_onlyunitdiag.py runs it) but measured 5% SLOWER on G81 p = 32
+// (14.58 vs 13.86 ms per RTR call): the larger kernel spills 33 registers and its tCG trips cost 14.2 instead of
+// 12.85 us, more than the 4 launches per TR iteration it saves.
+int msdp_persist_fused_ok(msdp_handle h) {
+    const char* e = getenv("MSDP_FUSED_RTR");
+    if (!(e && atoi(e))) return 0;
+    if (!msdp_persist_eligible(h)) return 0;
+    PersistPlan pl;
+    const int G = persist_grid(h->d);
+    if (!persist_plan(h->d, G, pl)) return 0;
+    persist_fn fn = persist_kernel(pl, true);
+    if (!fn) return 0;
+    pl.lds = fused_lds(pl);
+    if (h->fused_sig_lpr == pl.lpr && h->fused_sig_ew == pl.ew && h->fused_sig_G == G) return h->fused_sig_ok;
+    int ok = 0, per_cu = 0;
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, PB, pl.lds) == hipSuccess)
+        ok = per_cu >= 1 ? 1 : 0;
+    (void)hipGetLastError();
+    h->fused_sig_lpr = pl.lpr; h->fused_sig_ew = pl.ew; h->fused_sig_G = G; h->fused_sig_ok = ok;
+    return ok;
+}
+
+int msdp_launch_rtr_fused(msdp_handle h) {
+    const int G = persist_grid(h->d);
+    PersistPlan pl;
+    if (!persist_plan(h->d, G, pl)) { msdp_set_error("fused RTR: not eligible"); return MSDP_ESTATE; }
+    persist_fn fn = persist_kernel(pl, true);
+    if (!fn) { msdp_set_error("fused RTR: no kernel instance"); return MSDP_ESTATE; }
+    pl.lds = fused_lds(pl);
     Dev dp = h->d;
     dp.G = G;
     hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, h->stream, h->psync_slots, h->psync_err);

@@ -258,3 +258,24 @@ def test_persistent_tcg_csr_rows_G1(lib, p):
         assert st.last_stop_inner == info.stop_inner[-1]
         assert abs(st.cost - f_ref) < 1e-11 * max(1.0, abs(f_ref))
     h.close()
+
+
+def test_fused_rtr_kernel_matches_per_iteration_path(lib, monkeypatch):
+    """MSDP_FUSED_RTR=1 (opt-in: the whole trustregions() loop in one launch) takes the same decisions as one
+    persistent launch per TR iteration: same iteration / Hess-vec / accept counts and the same cost to rounding."""
+    from manisdp_matlab_amd import problems
+    C = problems.toroidal_grid_maxcut(30, 40, seed=2)
+    n, p = C.shape[0], 10
+    Y, _ = _rand_point(n, p, seed=1)
+    out = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("MSDP_FUSED_RTR", fused)
+        h = lib.Handle.onlyunitdiag(C, pcap=p)
+        h.set_point(Y)
+        st = h.rtr(lib.default_opts(maxiter=6, maxinner=40, tolgradnorm=1e-9))
+        out.append((st.iters, st.hessvecs, st.accepted, st.rejected, st.cost, st.gradnorm, h.cost()))
+        h.close()
+    a, b = out
+    assert a[:4] == b[:4]
+    assert abs(a[4] - b[4]) < 1e-11 * max(1.0, abs(a[4])) and abs(a[5] - b[5]) < 1e-8 * max(1.0, a[5])
+    assert abs(b[6] - b[4]) < 1e-10 * max(1.0, abs(b[4]))       # the resident point IS the accepted one
