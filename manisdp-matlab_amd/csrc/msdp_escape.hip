@@ -75,6 +75,33 @@ __global__ void k_multiaxpy(int n, int nb, const double* __restrict__ B, int64_t
         w[i] += sign * acc;
     }
 }
+// Ritz-vector assembly x = V*s for thousands of columns: one thread per row walking all columns is a serial chain of
+// m dependent FMAs on 79 workgroups (2 ms at m = 5184); here the columns are cut into gridDim.y chunks that write
+// partial vectors, summed in chunk order afterwards (deterministic).
+__global__ void k_multiaxpy_chunks(int n, int nb, const double* __restrict__ B, int64_t ldb, const double* __restrict__ h,
+                                   double* __restrict__ part) {
+    const int nch = gridDim.y, ch = blockIdx.y;
+    const int c0 = (int)(((int64_t)nb * ch) / nch), c1 = (int)(((int64_t)nb * (ch + 1)) / nch);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int c = c0;
+        for (; c + 3 < c1; c += 4) {
+            a0 = fma(h[c], B[(int64_t)c * ldb + i], a0);
+            a1 = fma(h[c + 1], B[(int64_t)(c + 1) * ldb + i], a1);
+            a2 = fma(h[c + 2], B[(int64_t)(c + 2) * ldb + i], a2);
+            a3 = fma(h[c + 3], B[(int64_t)(c + 3) * ldb + i], a3);
+        }
+        for (; c < c1; ++c) a0 = fma(h[c], B[(int64_t)c * ldb + i], a0);
+        part[(int64_t)ch * n + i] = (a0 + a1) + (a2 + a3);
+    }
+}
+__global__ void k_sum_chunks(int n, int nch, const double* __restrict__ part, double* __restrict__ dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int ch = 0; ch < nch; ++ch) acc += part[(int64_t)ch * n + i];
+        dst[i] = acc;
+    }
+}
 __global__ void k_scale_copy(int n, const double* __restrict__ src, double s, double* __restrict__ dst) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = s * src[i];
 }
@@ -141,8 +168,9 @@ static int sturm_count(const std::vector<double>& a, const std::vector<double>& 
     }
     return cnt;
 }
-static double tri_eig_kth(const std::vector<double>& a, const std::vector<double>& b, int m, int kth, double lo, double hi) {
-    for (int it = 0; it < 200 && hi - lo > 4e-16 * std::max(fabs(lo), fabs(hi)) + 1e-300; ++it) {
+static double tri_eig_kth(const std::vector<double>& a, const std::vector<double>& b, int m, int kth, double lo, double hi,
+                          double abstol = 0.0) {
+    for (int it = 0; it < 200 && hi - lo > 4e-16 * std::max(fabs(lo), fabs(hi)) + 1e-300 + abstol; ++it) {
         const double mid = 0.5 * (lo + hi);
         if (sturm_count(a, b, m, mid) > kth) hi = mid; else lo = mid;
     }
@@ -317,13 +345,20 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
                 const double rad = (i > 0 ? fabs(off[i - 1]) : 0.0) + (i + 1 < m ? fabs(off[i]) : 0.0);
                 glo = std::min(glo, a[i] - rad); ghi = std::max(ghi, a[i] + rad);
             }
-            theta = tri_eig_kth(a, off, m, 0, glo, ghi);
-            lmax = tri_eig_kth(a, off, m, m - 1, glo, ghi);
+            // Host cost of a checkpoint is ~m divisions per Sturm count: the largest Ritz value is converged after
+            // a few hundred steps and only sets the scale, so it is refreshed up to m = 1024 and once more at the
+            // end; the smallest one is bisected to 1e-14*scale (the residual test needs 1e-9*scale).
+            if (m <= 1024 || lmax == 0.0) lmax = tri_eig_kth(a, off, m, m - 1, glo, ghi);
+            const double scale0 = std::max(fabs(glo), fabs(lmax)) + 1e-300;
+            theta = tri_eig_kth(a, off, m, 0, glo, ghi, 1e-14 * scale0);
             tri_eigvec(a, off, m, theta, s);
             res = fabs(b[m] * s[m - 1]);
             const double scale = std::max(fabs(theta), fabs(lmax)) + 1e-300;
             const bool breakdown = b[m] <= 1e-14 * scale;
-            if (res <= tol * scale || theta - res > -tol * scale || breakdown) break;
+            if (res <= tol * scale || theta - res > -tol * scale || breakdown) {
+                if (m > 1024) lmax = tri_eig_kth(a, off, m, m - 1, glo, ghi);
+                break;
+            }
             // doubling up to 1024 steps, then x1.5: a late checkpoint wastes steps, an early one costs a host analysis
             next_check = std::min(maxit, m < 1024 ? 2 * m : m + m / 2);
         }
@@ -333,10 +368,18 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
     HIPCHK(hipMalloc((void**)&sdev, (size_t)m * sizeof(double)));
     auto assemble = [&](const std::vector<double>& sv, double* dst) -> int {
         hipError_t e = hipMemcpyAsync(sdev, sv.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(dst, 0, (size_t)n * sizeof(double), h->stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_multiaxpy, gr, bl, 0, h->stream, n, m, V, (int64_t)n, sdev, 1.0, dst);
+        const int NCH = 32;
+        if (e == hipSuccess && m >= 256 && m + 2 + NCH <= maxit + 2) {
+            double* part = V + (size_t)(m + 2) * n;              // unused tail of the Lanczos basis as scratch
+            hipLaunchKernelGGL(k_multiaxpy_chunks, dim3(gr.x, NCH), bl, 0, h->stream, n, m, V, (int64_t)n, sdev, part);
+            hipLaunchKernelGGL(k_sum_chunks, gr, bl, 0, h->stream, n, NCH, part, dst);
             e = hipGetLastError();
+        } else {
+            if (e == hipSuccess) e = hipMemsetAsync(dst, 0, (size_t)n * sizeof(double), h->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_multiaxpy, gr, bl, 0, h->stream, n, m, V, (int64_t)n, sdev, 1.0, dst);
+                e = hipGetLastError();
+            }
         }
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) { msdp_set_error("escape: Ritz vector assembly failed: %s", hipGetErrorString(e)); return MSDP_EHIP; }
