@@ -195,6 +195,22 @@ int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const void* id12
 /* Local row range [row0, row1) of this rank. */
 int msdp_local_rows(msdp_handle h, int64_t* row0, int64_t* row1);
 
+/* ------------------------------------------- AL bookkeeping */
+
+/* Affine handles, at the resident point (x = vec(YY')): obj = c'x and Ax = A x (m doubles;
+ * the caller forms Axb = Ax - b) -- ManiSDP_unitdiag.m:59-62, ManiSDP_unittrace.m:59-62,
+ * ManiSDP.m:58-63 without the n x n X on the host. */
+int msdp_al_primal(msdp_handle h, double* obj, double* Ax);
+/* Dual slack for the multipliers y: eS = reshape(c - At*y, n, n); unit diagonal:
+ * z = sum(X.*eS) (n values), S = eS - diag(z) (ManiSDP_unitdiag.m:65-67); unit trace:
+ * z = sum(eS.*X,'all') (1 value), S = eS - z*I (ManiSDP_unittrace.m:65-67); generic: S = eS
+ * (ManiSDP.m:64; z untouched, may be NULL).  S stays on the device for msdp_escape_eigs_dual. */
+int msdp_al_dual(msdp_handle h, const double* y, double* z);
+/* lambda_min, lambda_max and <= k bottom eigenvectors of the S of the last msdp_al_dual call
+ * (eig(S) of ManiSDP_unitdiag.m:68 / ManiSDP_unittrace.m:68 / ManiSDP.m:65). */
+int msdp_escape_eigs_dual(msdp_handle h, int32_t k, double tol, int32_t maxit,
+                          double* lam_min, double* V, double* lam_max, int32_t* iters);
+
 /* Which implementation msdp_rtr uses for the tCG inner loop at the resident point:
  * 1 = persistent single-launch kernel (working set in registers/LDS, sparse C, oblique,
  * one rank, n and p small enough to stay on chip), 0 = chunked hipGraph of three kernels

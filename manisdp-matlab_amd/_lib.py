@@ -79,6 +79,9 @@ SIGNATURES = {
     "msdp_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "msdp_local_rows": (C.c_int, [C.c_void_p, _i64p, _i64p]),
     "msdp_tcg_path": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "msdp_al_primal": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "msdp_al_dual": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "msdp_escape_eigs_dual": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, _dp, _dp, _dp, _P(C.c_int32)]),
     "msdp_bench_hessvec": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp, _dp]),
     "msdp_bench_tcg_trip": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "msdp_bench_kernel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
@@ -298,6 +301,38 @@ class Handle:
         its = C.c_int32()
         _check(self._lib.msdp_escape_eigs_matrix(self._h, _dptr(S), k, tol, maxit, _dptr(lam), _dptr(V), C.byref(lmax),
                                                  C.byref(its)))
+        return lam, np.ascontiguousarray(V), lmax.value, its.value
+
+    # ---- AL bookkeeping on the device (affine handles)
+    def al_primal(self, m):
+        """obj = c'x and A x (length m) at the resident point, without forming X = YY' on the host."""
+        obj = C.c_double()
+        Ax = np.empty(m)
+        _check(self._lib.msdp_al_primal(self._h, C.byref(obj), _dptr(Ax)))
+        return obj.value, Ax
+
+    def al_dual(self, y):
+        """Build the dual slack S for the multipliers y on the device; returns z (n values for unitdiag, a scalar for
+        unittrace, None for the generic kind).  S stays resident for escape_eigs_dual."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if self.kind == KIND_UNITDIAG:
+            z = np.empty(self.n)
+        elif self.kind == KIND_UNITTRACE:
+            z = np.empty(1)
+        else:
+            z = None
+        _check(self._lib.msdp_al_dual(self._h, _dptr(y), _dptr(z) if z is not None else None))
+        if z is None:
+            return None
+        return z if self.kind == KIND_UNITDIAG else float(z[0])
+
+    def escape_eigs_dual(self, k, tol=1e-10, maxit=20000):
+        """k bottom eigenpairs and lambda_max of the device-resident S of the last al_dual call."""
+        lam = np.empty(k)
+        V = np.empty((self.n, k), order="F")
+        lmax = C.c_double()
+        its = C.c_int32()
+        _check(self._lib.msdp_escape_eigs_dual(self._h, k, tol, maxit, _dptr(lam), _dptr(V), C.byref(lmax), C.byref(its)))
         return lam, np.ascontiguousarray(V), lmax.value, its.value
 
     # ---- multi-GPU

@@ -21,6 +21,7 @@
 
 int msdp_dev_alloc_bytes(msdp_handle h, void** out, size_t bytes);
 int msdp_dense_nS(int n);
+int msdp_k_sum_to_fwd(msdp_handle h, int which, double* out);
 int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const double* const* X, const double* scale,
                     const int* active_flag, const double** slab_out, int64_t* stride_out, int* SK_out);
 
@@ -660,5 +661,85 @@ int msdp_affine_linesearch_cost(msdp_handle h, const double* Yt, double* val) {
     HIPCHK(hipMemcpyAsync(&v, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     *val = v;
+    return 0;
+}
+
+// ------------------------------------------------------------------ AL bookkeeping on the device
+// The host AL loop of the affine entry points needs, once per outer iteration (ManiSDP_unitdiag.m:59-70,
+// ManiSDP_unittrace.m:59-70, ManiSDP.m:58-68): obj = c'x and Axb = A x - b at the new point, then with the NEW
+// multipliers eS = reshape(c - At*y), z = sum(X.*eS) and S = eS - diag(z) (unit diagonal) / S = eS - z*I
+// (unit trace) / S = eS (generic).  On the host that is n^2-sized NumPy/SciPy work (X = YY', two SpMVs with
+// 4.8 M nonzeros, the dense eS): 49% of the BQP d = 60 solve.  Here the same quantities come from the kernels
+// of the hot path: A(YY') (SDDMM or Gram route), the dense adjoint, the MFMA contraction and a row-dot.
+
+// rows: S[i][j] -= (i == j) * (zrow ? zrow[i] : *zscalar)
+__global__ void k_sub_diag(int n, int nS, double* __restrict__ S, const double* __restrict__ zrow, const double* __restrict__ zscalar) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        S[(int64_t)i * nS + i] -= zrow ? zrow[i] : *zscalar;
+}
+
+// obj = c'x, w = A x (m doubles to the host; the caller subtracts b)
+int msdp_affine_al_primal(msdp_handle h, double* obj, double* Ax_host) {
+    AffineState* st = astate(h);
+    if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
+    Dev& d = h->d;
+    AffineDev a = st->a;
+    a.p = d.p; a.ld = d.ld;
+    const int cur = h->h_ctl->cur;
+    const double* Ys = d.Y[cur];
+    int rc = launch_aop(h, a, st->nnz, Ys, Ys, (const int*)nullptr, 0);
+    if (rc) return rc;
+    {
+        int64_t gf = (a.m + MSDP_BLOCK - 1) / MSDP_BLOCK;
+        if (gf > 2048) gf = 2048;
+        hipLaunchKernelGGL(k_sddmm_finish, dim3((int)gf), dim3(MSDP_BLOCK), 0, h->stream, a, 0, (double*)nullptr, 1.0, d.P, (const int*)nullptr, 0);
+        HIPCHK(hipGetLastError());
+    }
+    const double* slab; int64_t stride; int SK;
+    const double* M[1] = {d.Cd}; const double* X[1] = {Ys}; const double sc[1] = {1.0};
+    if ((rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK))) return rc;
+    DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 1.0, (double*)nullptr, (double*)nullptr, P_S1);
+    HIPCHK(hipGetLastError());
+    if ((rc = msdp_k_sum_to_fwd(h, P_S1, &d.ctl->fx_prop))) return rc;
+    double v = 0.0;
+    HIPCHK(hipMemcpyAsync(&v, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(Ax_host, a.w, (size_t)a.m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *obj = v;
+    return 0;
+}
+
+// eS = c - At*y, z, S (left in d.AyU for msdp_escape_eigs_dual); z -> host (n values, or 1 for the sphere, none for generic)
+int msdp_affine_al_dual(msdp_handle h, const double* y_host, double* z_host) {
+    AffineState* st = astate(h);
+    if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
+    Dev& d = h->d;
+    AffineDev a = st->a;
+    a.p = d.p; a.ld = d.ld;
+    const int cur = h->h_ctl->cur;
+    const double* Ys = d.Y[cur];
+    HIPCHK(hipMemcpyAsync(a.w, y_host, (size_t)a.m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_adjoint_dense, dim3(adjoint_grid(a)), dim3(256), 0, h->stream, a, d.Cd, (const double*)a.w, -1.0,
+                       d.AyU, (const int*)nullptr, 0);
+    HIPCHK(hipGetLastError());
+    if (d.manifold == MANI_EUCLID) { HIPCHK(hipStreamSynchronize(h->stream)); return 0; }
+    // t_i = <(eS*Y)_i, Y_i>  (= sum(X.*eS) per row); their total for the sphere
+    const double* slab; int64_t stride; int SK;
+    const double* M[1] = {d.AyU}; const double* X[1] = {Ys}; const double sc[1] = {1.0};
+    int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
+    if (rc) return rc;
+    DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 1.0, (double*)nullptr, d.W0, P_S2);
+    HIPCHK(hipGetLastError());
+    if (d.manifold == MANI_OBLIQUE) {
+        hipLaunchKernelGGL(k_sub_diag, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, a.n, a.nS, d.AyU, (const double*)d.W0, (const double*)nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(z_host, d.W0, (size_t)a.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    } else {
+        if ((rc = msdp_k_sum_to_fwd(h, P_S2, &d.ctl->fx_prop))) return rc;
+        hipLaunchKernelGGL(k_sub_diag, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, a.n, a.nS, d.AyU, (const double*)nullptr, (const double*)&d.ctl->fx_prop);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(z_host, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }

@@ -1077,6 +1077,39 @@ extern "C" int msdp_escape_eigs_matrix(msdp_handle h, const double* S, int32_t k
     return rc;
 }
 
+int msdp_affine_al_primal(msdp_handle h, double* obj, double* Ax_host);       // msdp_affine.hip
+int msdp_affine_al_dual(msdp_handle h, const double* y_host, double* z_host);
+
+extern "C" int msdp_al_primal(msdp_handle h, double* obj, double* Ax) {
+    CHECK_H(h);
+    if (!obj || !Ax) { msdp_set_error("al_primal: null argument"); return MSDP_EINVAL; }
+    if (h->d.costkind != COST_AFFINE) { msdp_set_error("al_primal: affine handles only"); return MSDP_EUNSUPPORTED; }
+    if (!h->have_point) { msdp_set_error("no resident point"); return MSDP_ESTATE; }
+    h->state_valid = false;                    // the scratch vectors / partial sums of the resident state are reused
+    return msdp_affine_al_primal(h, obj, Ax);
+}
+
+extern "C" int msdp_al_dual(msdp_handle h, const double* y, double* z) {
+    CHECK_H(h);
+    if (!y || (!z && h->kind != MSDP_KIND_GENERIC)) { msdp_set_error("al_dual: null argument"); return MSDP_EINVAL; }
+    if (h->d.costkind != COST_AFFINE) { msdp_set_error("al_dual: affine handles only"); return MSDP_EUNSUPPORTED; }
+    if (!h->have_point) { msdp_set_error("no resident point"); return MSDP_ESTATE; }
+    h->state_valid = false;
+    int rc = msdp_affine_al_dual(h, y, z);
+    h->dual_valid = (rc == 0);
+    return rc;
+}
+
+extern "C" int msdp_escape_eigs_dual(msdp_handle h, int32_t k, double tol, int32_t maxit, double* lam_min, double* V,
+                                     double* lam_max, int32_t* iters) {
+    CHECK_H(h);
+    if (!lam_min || !V) { msdp_set_error("escape_eigs_dual: null argument"); return MSDP_EINVAL; }
+    if (h->d.costkind != COST_AFFINE || !h->dual_valid) { msdp_set_error("escape_eigs_dual: call msdp_al_dual first"); return MSDP_ESTATE; }
+    int rc = msdp_escape_impl(h, k, tol, maxit, lam_min, V, lam_max, iters, h->d.AyU);
+    (void)hipStreamSynchronize(h->stream);
+    return rc;
+}
+
 // ------------------------------------------------------------------ measurement
 static void algo_cost(msdp_handle h, double* bytes, double* flops) {
     const Dev& d = h->d;

@@ -113,6 +113,7 @@ struct msdp_handle_s {
     bool have_point = false;
     bool state_valid = false;      // cost/grad state computed at the resident point
     bool gradnorm_valid = false;   // h_ctl->norm_grad / fx describe the resident point
+    bool dual_valid = false;       // d.AyU holds the dual slack S of the last msdp_al_dual call
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Ctl* h_ctl = nullptr;          // pinned host mirror

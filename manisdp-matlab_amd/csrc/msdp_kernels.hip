@@ -949,3 +949,5 @@ int msdp_k_sum_to(msdp_handle h, int which, double* out) {
     HIPCHK(hipGetLastError());
     return 0;
 }
+
+int msdp_k_sum_to_fwd(msdp_handle h, int which, double* out) { return msdp_k_sum_to(h, which, out); }

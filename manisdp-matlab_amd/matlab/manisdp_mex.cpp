@@ -13,6 +13,9 @@
 //   val = manisdp_mex('linesearch_cost', h, Y, U, alpha)     % co(retr(Y + alpha U))
 //   z   = manisdp_mex('get_z', h)
 //   [lam, V, lmax] = manisdp_mex('escape_eigs', h, k, tol, maxit)
+//   [obj, Ax]      = manisdp_mex('al_primal', h, m)          % affine kinds: c'x and A*x at the resident point
+//   z              = manisdp_mex('al_dual', h, y)            % builds S = eS - diag(z) | eS - z*I | eS on the device
+//   [lam, V, lmax] = manisdp_mex('escape_eigs_dual', h, k, tol, maxit)
 //         manisdp_mex('destroy', h)
 //
 // Handles travel as uint64 scalars.  The library returns codes (no exceptions cross the C ABI);
@@ -151,6 +154,35 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         int32_t its = 0;
         int rc = msdp_escape_eigs(h, k, mxGetScalar(prhs[3]), (int32_t)mxGetScalar(prhs[4]), mxGetPr(plhs[0]), mxGetPr(V), &lmax, &its);
         if (rc) { mxDestroyArray(V); fail("escape_eigs", rc); }
+        if (nlhs > 1) plhs[1] = V; else mxDestroyArray(V);
+        if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(lmax);
+    } else if (cmd == "al_primal") {
+        msdp_handle h = get_handle(prhs[1]);
+        const mwSize m = (mwSize)mxGetScalar(prhs[2]);
+        double obj = 0.0;
+        mxArray* Ax = mxCreateDoubleMatrix(m, 1, mxREAL);
+        int rc = msdp_al_primal(h, &obj, mxGetPr(Ax));
+        if (rc) { mxDestroyArray(Ax); fail("al_primal", rc); }
+        plhs[0] = mxCreateDoubleScalar(obj);
+        if (nlhs > 1) plhs[1] = Ax; else mxDestroyArray(Ax);
+    } else if (cmd == "al_dual") {
+        msdp_handle h = get_handle(prhs[1]);
+        int64_t r0 = 0, r1 = 0;
+        (void)msdp_local_rows(h, &r0, &r1);
+        plhs[0] = mxCreateDoubleMatrix((mwSize)r1, 1, mxREAL);      // unit trace / generic: only z(1) is meaningful
+        int rc = msdp_al_dual(h, mxGetPr(prhs[2]), mxGetPr(plhs[0]));
+        if (rc) fail("al_dual", rc);
+    } else if (cmd == "escape_eigs_dual") {
+        msdp_handle h = get_handle(prhs[1]);
+        const int32_t k = (int32_t)mxGetScalar(prhs[2]);
+        int64_t r0 = 0, r1 = 0;
+        (void)msdp_local_rows(h, &r0, &r1);
+        plhs[0] = mxCreateDoubleMatrix(k, 1, mxREAL);
+        mxArray* V = mxCreateDoubleMatrix((mwSize)r1, k, mxREAL);
+        double lmax = 0.0;
+        int32_t its = 0;
+        int rc = msdp_escape_eigs_dual(h, k, mxGetScalar(prhs[3]), (int32_t)mxGetScalar(prhs[4]), mxGetPr(plhs[0]), mxGetPr(V), &lmax, &its);
+        if (rc) { mxDestroyArray(V); fail("escape_eigs_dual", rc); }
         if (nlhs > 1) plhs[1] = V; else mxDestroyArray(V);
         if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(lmax);
     } else if (cmd == "destroy") {

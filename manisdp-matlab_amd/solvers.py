@@ -288,15 +288,40 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
             data["rejected"] += st.rejected
             gradnorm = st.gradnorm
             Y = h.get_point()
-            X = Y @ Y.T                                    # unitdiag :59 / unittrace :59
-            x = X.ravel(order="F")
-            obj = float(c @ x)                             # :61
-            Axb = A @ x - b                                # :62
-            pinf = float(np.linalg.norm(Axb)) / normb      # :63
-            y = y - sigma * Axb                            # :64
-            eS = (c - Atc @ y).reshape((n, n), order="F")  # :65
-            t1 = time.time()
-            if generic:
+            dev_al = (eig_mode == "device") and bool(o.get("device_al", True))
+            if dev_al:
+                # obj, A x, eS, z and S from the device kernels (no n x n work on the host)
+                obj, Ax = h.al_primal(b.size)              # :59-61
+                Axb = Ax - b                               # :62
+                pinf = float(np.linalg.norm(Axb)) / normb  # :63
+                y = y - sigma * Axb                        # :64
+                t1 = time.time()
+                zz = h.al_dual(y)                          # :65-67 (S stays on the device)
+                if generic:
+                    by = float(b @ y)
+                elif sphere:
+                    z = zz
+                    by = float(b @ y) + z
+                else:
+                    z = zz
+                    by = float(b @ y) + float(np.sum(z))
+                lam, vS, lam_max, _ = h.escape_eigs_dual(int(o["delta"]), tol=float(o.get("eig_tol", 1e-10)),
+                                                         maxit=int(o.get("eig_maxit", 20000)))   # :68
+                dS = np.concatenate([lam, [lam_max]])
+                S = None
+                data["eig_seconds"] += time.time() - t1
+            else:
+                X = Y @ Y.T                                # unitdiag :59 / unittrace :59
+                x = X.ravel(order="F")
+                obj = float(c @ x)                         # :61
+                Axb = A @ x - b                            # :62
+                pinf = float(np.linalg.norm(Axb)) / normb  # :63
+                y = y - sigma * Axb                        # :64
+                eS = (c - Atc @ y).reshape((n, n), order="F")  # :65
+                t1 = time.time()
+            if dev_al:
+                pass
+            elif generic:
                 S = eS                                     # ManiSDP.m:64
                 by = float(b @ y)                          # :67
             elif sphere:
@@ -307,14 +332,17 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
                 z = np.sum(X * eS, axis=0)                 # unitdiag :66
                 S = eS - np.diag(z)                        # :67
                 by = float(b @ y) + float(np.sum(z))       # :70
-            if eig_mode == "device":
+            if dev_al:
+                pass
+            elif eig_mode == "device":
                 # few-eigenvector escape on the device instead of the O(n^3) eig(S) of :68
                 lam, vS, lam_max, _ = h.escape_eigs_matrix(S, int(o["delta"]), tol=float(o.get("eig_tol", 1e-10)),
                                                            maxit=int(o.get("eig_maxit", 20000)))
                 dS = np.concatenate([lam, [lam_max]])      # dS[0] = lambda_min ... dS[-1] = lambda_max
+                data["eig_seconds"] += time.time() - t1
             else:
                 dS, vS = np.linalg.eigh(S)                 # :68
-            data["eig_seconds"] += time.time() - t1
+                data["eig_seconds"] += time.time() - t1
             dinf = max(0.0, -dS[0]) / (1.0 + dS[-1])       # :69
             gap = abs(obj - by) / (abs(by) + abs(obj) + 1.0)   # :71
             Q, e, r = _thin_svd_rank(Y, float(o["theta"]))     # :72-74
@@ -360,7 +388,7 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
                 sigma = min(sigma * gama, o["sigma_max"])
     finally:
         h.close()
-    data.update({"Y": Y, "X": Y @ Y.T, "y": y, "S": S, "z": z, "gap": gap, "pinf": pinf, "dinf": dinf,
+    data.update({"Y": Y, "X": (Y @ Y.T if n <= int(o.get("dense_X_max", 6000)) else None), "y": y, "S": S, "z": z, "gap": gap, "pinf": pinf, "dinf": dinf,
                  "gradnorm": gradnorm, "time": time.time() - t0, "sigma": sigma})
     if not sphere and not generic:
         data["fac_size"] = fac_size

@@ -22,6 +22,7 @@ FILES = [
     "sdplib/theta1.dat-s", "sdplib/theta2.dat-s",
     "bqp_Q_10_1.txt", "bqp_e_10_1.txt", "bqp_Q_20_1.txt", "bqp_e_20_1.txt",
     "bqp_Q_30_1.txt", "bqp_e_30_1.txt", "qs_c_10_1.txt",
+    "bqp_Q_60_1.txt", "bqp_e_60_1.txt",          # BASELINE.json configs[2] (n = 1831, m = 1 155 281)
 ]
 
 # data/sdplib/README:39-51 (gpp), :71-88 (maxG/mcp), :98-105 (theta): optimal objective values

@@ -215,3 +215,58 @@ def test_escape_matrix_matches_lapack(lib):
     assert np.allclose(lam, dS[:6], rtol=0, atol=1e-8 * abs(dS[0]))
     for t in range(6):
         assert np.linalg.norm(S @ V[:, t] - lam[t] * V[:, t]) < 1e-5 * abs(dS[0])
+
+
+@pytest.mark.parametrize("kind_name,case,p", [("unitdiag", "gpp100", 6), ("unitdiag", "bqp20", 24), ("unittrace", "theta1", 9),
+                                              ("generic", "mcp124-1", 5), ("unitdiag", "bqp10", 140)])
+def test_al_bookkeeping_on_device(lib, kind_name, case, p):
+    """msdp_al_primal / msdp_al_dual / msdp_escape_eigs_dual against the host expressions of the
+    AL loop (ManiSDP_unitdiag.m:59-69, ManiSDP_unittrace.m:59-69, ManiSDP.m:58-66) on seeded inputs."""
+    from manisdp_matlab_amd import problems
+    if case.startswith("bqp"):
+        At, b, c, K = _bqp(int(case[3:]))
+    else:
+        At, b, c, K = problems.from_sdpa(golden_path(case + ".dat-s.gz"))
+        c = np.asarray(c.todense()).ravel()
+    b = np.asarray(b, float)
+    n = K["s"]
+    kind = {"unitdiag": lib.KIND_UNITDIAG, "unittrace": lib.KIND_UNITTRACE, "generic": lib.KIND_GENERIC}[kind_name]
+    rng = np.random.default_rng(p)
+    Y = rng.standard_normal((n, p))
+    if kind_name == "unitdiag":
+        Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    elif kind_name == "unittrace":
+        Y /= np.linalg.norm(Y)
+    y = rng.standard_normal(b.size) * 0.3
+    h = lib.Handle.affine(kind, At, b, c, n, pcap=p)
+    h.set_multipliers(np.zeros(b.size), 1.0)
+    h.set_point(Y)
+    X = Y @ Y.T
+    x = X.ravel(order="F")
+    obj, Ax = h.al_primal(b.size)
+    assert abs(obj - float(c @ x)) <= 1e-11 * max(1.0, abs(float(c @ x)))
+    assert _relerr(Ax, At.T @ x) < 1e-11
+    eS = (c - At @ y).reshape((n, n), order="F")
+    z = h.al_dual(y)
+    if kind_name == "unitdiag":
+        z_ref = np.sum(X * eS, axis=0)
+        S = eS - np.diag(z_ref)
+        assert _relerr(z, z_ref) < 1e-11
+    elif kind_name == "unittrace":
+        z_ref = float(np.sum(eS * X))
+        S = eS - z_ref * np.eye(n)
+        assert abs(z - z_ref) <= 1e-11 * max(1.0, abs(z_ref))
+    else:
+        S = eS
+        assert z is None
+    S = 0.5 * (S + S.T)
+    dS = np.linalg.eigvalsh(S)
+    lam, V, lmax, _ = h.escape_eigs_dual(3, tol=1e-10, maxit=20000)
+    scale = max(abs(dS[0]), abs(dS[-1]))
+    assert abs(lam[0] - dS[0]) < 1e-7 * scale
+    assert abs(lmax - dS[-1]) < 1e-5 * scale
+    # the point is still resident and usable after the bookkeeping calls
+    assert _relerr(h.get_point(), Y) == 0.0
+    f0 = h.cost()
+    assert np.isfinite(f0)
+    h.close()
