@@ -794,8 +794,18 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
         // (msdp_persist.hip).  The host stays one TR iteration ahead of the device: iteration i+1 is enqueued
         // as soon as the kernel of iteration i publishes that it has started; a finished solve (ctl->done)
         // turns everything still enqueued into no-ops and is reported through the same progress word.
+        static int no_tail = -1;
+        if (no_tail < 0) { const char* e = getenv("MSDP_NO_TR_TAIL"); no_tail = (e && atoi(e)) ? 1 : 0; }
+        bool first_iter = true;
         auto enqueue_iter = [&]() -> int {
             int r2;
+            if (!no_tail) {
+                // two launches per TR iteration: the persistent tCG kernel and the tail kernel (retraction, cost and
+                // gradient at the proposal, accept/reject); each clears the other's synchronisation slots
+                if ((r2 = msdp_launch_tcg_persist(h, first_iter ? 1 : 0))) return r2;   // trustregions.m:484-496 + tCG.m
+                first_iter = false;
+                return msdp_launch_tr_tail(h);                            // :540-729
+            }
             if ((r2 = msdp_launch_tcg_persist(h))) return r2;             // trustregions.m:484-496 + tCG.m
             if ((r2 = msdp_launch_retract(h))) return r2;                 // :540
             if ((r2 = msdp_launch_costgrad(h, 3))) return r2;             // :544 (proposal slot, device-resolved)

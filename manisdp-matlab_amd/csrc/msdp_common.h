@@ -161,7 +161,8 @@ int msdp_launch_rtr_begin(msdp_handle h);
 int msdp_launch_rtr_decide(msdp_handle h);
 int msdp_alloc_vectors(msdp_handle h, int pcap);
 int msdp_persist_eligible(msdp_handle h);                     // msdp_persist.hip
-int msdp_launch_tcg_persist(msdp_handle h);                   // whole tCG of the current TR iteration, one launch
+int msdp_launch_tcg_persist(msdp_handle h, int reset_slots = 1);   // whole tCG of the current TR iteration, one launch
+int msdp_launch_tr_tail(msdp_handle h);                       // retract + cost/grad at the proposal + accept/reject, one launch
 int msdp_persist_fused_ok(msdp_handle h);                     // whole trustregions() loop in one launch possible?
 int msdp_launch_rtr_fused(msdp_handle h);
 size_t msdp_psync_bytes();

@@ -1,0 +1,179 @@
+// msdp_psync.h -- grid-wide synchronisation / reduction primitives of the persistent kernels
+// (msdp_persist.hip: tCG and the TR-iteration tail).  See msdp_persist.hip for the design notes.
+#pragma once
+#include "msdp_device.h"
+
+#define PSYNC_NV 4                       // value arrays per generation
+#define PSYNC_GEN 3
+// Every workgroup posts its partials into PSYNC_REP replicas and polls replica (blockIdx & 7), i.e. the one of
+// its XCD under round-robin dispatch: 32 pollers per cache line instead of 256 (tools/microbench_sync.hip:
+// 3.03 -> 2.09 us per grid reduction at G = 256).  The barrier that carries no value uses 8 counters the same way.
+#define PSYNC_REP 8
+#define PSYNC_CNT_OFF ((size_t)PSYNC_GEN * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID)   // counters behind the slots, 64 B apart
+#define PSYNC_SENT 0xFFF8DEADBEEF0001ULL  // NaN payload no arithmetic produces
+#define PSYNC_SPIN_LIMIT (1 << 22)
+// 512 threads per workgroup, one workgroup per CU: 2 waves per SIMD, i.e. a 256-register budget per lane
+// for the resident rows (1024-thread workgroups leave 128 and spill)
+#define PB 512
+#define PWAVES (PB / 64)
+
+// Rows of the new direction are exchanged between workgroups on different XCDs (one L2 each) inside the launch.
+// Agent-scope release/acquire fences (buffer_wbl2 / buffer_inv sc1 by every wave) were measured at 37 us per
+// trip; instead the exchanged rows are written and gathered with sc1 (agent-coherent) buffer accesses, which
+// the other L2s never hold stale, and ordered by the grid reduction that follows the stores.
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+#define MSDP_CPOL_SC1 16
+__device__ __forceinline__ double2 ld2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, MSDP_CPOL_SC1);
+    double2 o;
+    o.x = __longlong_as_double(((long long)v.y << 32) | (long long)v.x);
+    o.y = __longlong_as_double(((long long)v.w << 32) | (long long)v.z);
+    return o;
+}
+__device__ __forceinline__ void st2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, double2 d2) {
+    const long long a = __double_as_longlong(d2.x), b = __double_as_longlong(d2.y);
+    v4u v;
+    v.x = (unsigned)(a & 0xffffffffLL); v.y = (unsigned)((unsigned long long)a >> 32);
+    v.z = (unsigned)(b & 0xffffffffLL); v.w = (unsigned)((unsigned long long)b >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, MSDP_CPOL_SC1);
+}
+
+
+// Reduce (a, b, c) over the whole grid; nv = number of meaningful values (1 or 3).  Returns false when the
+// spin bound was hit (error flag set; the caller leaves the kernel).
+__device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, int G, int nv, double& a, double& b,
+                                      double& c, double* sh, double* shb, int* err) {
+    a = msdp_wave_sum(a);
+    if (nv > 1) { b = msdp_wave_sum(b); c = msdp_wave_sum(c); }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sh[w] = a; sh[PWAVES + w] = b; sh[2 * PWAVES + w] = c; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned long long* gbase = slots + (size_t)(gen % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID;
+        if (lane < PSYNC_REP * PSYNC_NV) {
+            const int rep = lane / PSYNC_NV, vi = lane % PSYNC_NV;
+            if (vi < nv) {
+                double s = 0.0;
+                for (int i = 0; i < PWAVES; ++i) s += sh[vi * PWAVES + i];
+                // the reset store of this slot's other generations (issued one sync ago) must have been performed
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(gbase + ((size_t)rep * PSYNC_NV + vi) * MSDP_MAX_GRID + blockIdx.x,
+                                   (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        unsigned long long* base = gbase + (size_t)(blockIdx.x & (PSYNC_REP - 1)) * PSYNC_NV * MSDP_MAX_GRID;
+        double r0, r1 = 0.0, r2 = 0.0;
+        int spins = 0;
+        bool fail = false;
+        const unsigned long long* p0 = base + lane;
+        for (;;) {
+            // all slot loads of one poll are issued back to back with ONE wait (the compiler puts a full
+            // s_waitcnt after every atomic load: 12 serialized round trips per poll, measured 20 us per sync)
+            unsigned long long b0[4], b1[4], b2[4];
+            if (nv > 1) {
+                const unsigned long long* p1 = p0 + MSDP_MAX_GRID;
+                const unsigned long long* p2 = p0 + 2 * MSDP_MAX_GRID;
+                asm volatile(
+                    "global_load_dwordx2 %0, %12, off sc1\n\t"
+                    "global_load_dwordx2 %1, %12, off offset:512 sc1\n\t"
+                    "global_load_dwordx2 %2, %12, off offset:1024 sc1\n\t"
+                    "global_load_dwordx2 %3, %12, off offset:1536 sc1\n\t"
+                    "global_load_dwordx2 %4, %13, off sc1\n\t"
+                    "global_load_dwordx2 %5, %13, off offset:512 sc1\n\t"
+                    "global_load_dwordx2 %6, %13, off offset:1024 sc1\n\t"
+                    "global_load_dwordx2 %7, %13, off offset:1536 sc1\n\t"
+                    "global_load_dwordx2 %8, %14, off sc1\n\t"
+                    "global_load_dwordx2 %9, %14, off offset:512 sc1\n\t"
+                    "global_load_dwordx2 %10, %14, off offset:1024 sc1\n\t"
+                    "global_load_dwordx2 %11, %14, off offset:1536 sc1\n\t"
+                    "s_waitcnt vmcnt(0)"
+                    : "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3]), "=&v"(b1[0]), "=&v"(b1[1]), "=&v"(b1[2]),
+                      "=&v"(b1[3]), "=&v"(b2[0]), "=&v"(b2[1]), "=&v"(b2[2]), "=&v"(b2[3])
+                    : "v"(p0), "v"(p1), "v"(p2)
+                    : "memory");
+            } else {
+                asm volatile(
+                    "global_load_dwordx2 %0, %4, off sc1\n\t"
+                    "global_load_dwordx2 %1, %4, off offset:512 sc1\n\t"
+                    "global_load_dwordx2 %2, %4, off offset:1024 sc1\n\t"
+                    "global_load_dwordx2 %3, %4, off offset:1536 sc1\n\t"
+                    "s_waitcnt vmcnt(0)"
+                    : "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3])
+                    : "v"(p0)
+                    : "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { b1[q] = 0ULL; b2[q] = 0ULL; }
+            }
+            bool ok = true;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (lane + 64 * q < G) {                                   // slots >= G hold the sentinel for ever
+                    ok = ok && b0[q] != PSYNC_SENT && b1[q] != PSYNC_SENT && b2[q] != PSYNC_SENT;
+                    t0 += __longlong_as_double((long long)b0[q]);         // same order as msdp_sum_partials
+                    t1 += __longlong_as_double((long long)b1[q]);
+                    t2 += __longlong_as_double((long long)b2[q]);
+                }
+            }
+            r0 = t0; r1 = t1; r2 = t2;
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ULL) break;
+            ++spins;
+            if (spins > PSYNC_SPIN_LIMIT ||
+                ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
+        }
+        r0 = msdp_wave_sum(r0);
+        if (nv > 1) { r1 = msdp_wave_sum(r1); r2 = msdp_wave_sum(r2); }
+        if (lane == 0) {
+            shb[0] = r0; shb[1] = r1; shb[2] = r2; shb[3] = fail ? 1.0 : 0.0;
+            if (fail) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // everybody has finished reading the previous generation (they all posted this one): reset my slots of it
+        if (lane < PSYNC_REP * PSYNC_NV)
+            __hip_atomic_store(slots + (size_t)((gen + PSYNC_GEN - 1) % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID +
+                                   (size_t)lane * MSDP_MAX_GRID + blockIdx.x,
+                               PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    // wave-uniform results: readlane moves them to scalar registers (they live across the whole solve)
+    a = msdp_readlane(shb[0], 0); b = msdp_readlane(shb[1], 0); c = msdp_readlane(shb[2], 0);
+    return msdp_readlane(shb[3], 0) == 0.0;
+}
+
+// Barrier without a value (the new direction rows are in place): workgroup b adds to counter b & 7, everybody
+// polls the 8 counters (64 B apart).  nbar = number of barriers passed before this one.  G is a multiple of 8.
+__device__ __forceinline__ bool pbarrier(unsigned long long* slots, unsigned nbar, int G, double* shb, int* err) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        unsigned long long* cnt = slots + PSYNC_CNT_OFF;
+        if (lane == 0) __hip_atomic_fetch_add(cnt + 8 * (blockIdx.x & 7), 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long want = (unsigned long long)(nbar + 1) * (unsigned)(G / 8);
+        int spins = 0;
+        bool fail = false;
+        for (;;) {
+            unsigned long long v = want;
+            if (lane < 8) v = __hip_atomic_load(cnt + 8 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_ballot_w64(v < want) == 0ULL) break;
+            ++spins;
+            if (spins > PSYNC_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
+        }
+        if (lane == 0) {
+            shb[3] = fail ? 1.0 : 0.0;
+            if (fail) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    return shb[3] == 0.0;
+}
+
+// One region = the slots of psync (3 generations x 8 replicas x PSYNC_NV values x MSDP_MAX_GRID) + 8 barrier counters.
+#define PSYNC_REGION (PSYNC_CNT_OFF + 64)
+
+// Two kernels alternate on a stream (persistent tCG, TR-iteration tail), each with its own region; a kernel may
+// not reset its own region while its workgroups poll it, so each one resets the OTHER kernel's region at its start:
+// workgroup b clears column b of every slot array, workgroup 0 the counters (completed at the kernel boundary).
+__device__ __forceinline__ void psync_reset_other(unsigned long long* other) {
+    const int t = threadIdx.x;
+    if (t < PSYNC_GEN * PSYNC_REP * PSYNC_NV) other[(size_t)t * MSDP_MAX_GRID + blockIdx.x] = PSYNC_SENT;
+    if (blockIdx.x == 0 && t >= 128 && t < 192) other[PSYNC_CNT_OFF + (t - 128)] = 0ULL;
+}

@@ -1,0 +1,152 @@
+// msdp_trtail.hip -- everything of a trust-region iteration that follows the tCG solve, in ONE launch
+// (sparse C, oblique manifold, the persistent path of msdp_persist.hip):
+//   x_prop = retr(x, eta)                      ManiSDP_onlyunitdiag.m:142-145, trustregions.m:540
+//   <eta, grad + .5*Heta>                      trustregions.m:549-550
+//   cost / gradient at x_prop                  ManiSDP_onlyunitdiag.m:117-125, trustregions.m:544
+//   rho, radius update, accept / reject, stop  trustregions.m:548-729
+// Before: k_retract_obl, k_costgrad_*, k_rtr_decide + the slot-reset launch = 4 launches per TR iteration
+// next to the persistent tCG kernel; now 1.  The kernel needs one grid barrier (the proposal rows must be
+// in place before the S*Y_prop gathers) and one grid reduction (f, |grad|^2, model decrease), for which it
+// uses region B of the synchronisation slots; it clears region A for the next tCG launch.
+#include "msdp_psync.h"
+#include <math.h>
+#include <cstdlib>
+
+template <int LPR>
+__global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* slots, int* err) {
+    extern __shared__ double lds[];
+    __shared__ double sh[3 * PWAVES];
+    __shared__ double shb[4];
+    constexpr int RPW = 64 / LPR;
+    constexpr int RSTEP = PWAVES * RPW;
+    double2* YPs = reinterpret_cast<double2*>(lds);            // [R][PB] proposal rows of this workgroup
+    Ctl* c = d.ctl;
+    if (c->done) return;
+    psync_reset_other(slots);                                  // region A belongs to the persistent tCG kernel
+    unsigned long long* sb = slots + PSYNC_REGION;
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
+    const int R = (hi - lo + RSTEP - 1) / RSTEP;               // row slots actually needed (<= LPR/4 by construction)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    const bool colok = 2 * sub < d.ld;
+    const int slot0 = wave * RPW + rsub;
+    const int cur = c->cur, ix = d.F[0].eta_idx;
+    const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
+    const double* __restrict__ gl = cur ? d.Gr[1] : d.Gr[0];
+    const double* __restrict__ eta = ix ? d.eta[1] : d.eta[0];
+    const double* __restrict__ Heta = ix ? d.Heta[1] : d.Heta[0];
+    const unsigned vec_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
+    __amdgpu_buffer_rsrc_t rs_yp = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Y[0] : d.Y[1], 0, vec_bytes, 0x00020000);
+    double* __restrict__ Gp = cur ? d.Gr[0] : d.Gr[1];
+    double* __restrict__ eGp = cur ? d.eG[0] : d.eG[1];
+    const double2 zz = make_double2(0.0, 0.0);
+    double prd = 0.0, pf = 0.0, pgg = 0.0;
+    for (int r = 0; r < R; ++r) {
+        const int row = lo + r * RSTEP + slot0;
+        const bool ok = row < hi && colok;
+        const int rc = row < hi ? row : lo;
+        const int64_t o = (int64_t)rc * d.ld + (colok ? 2 * sub : 0);
+        const double2 y = ld2(Yl + o), g = ld2(gl + o), e = ld2(eta + o), he = ld2(Heta + o);
+        double2 x = zz;
+        if (ok) {
+            prd += e.x * (g.x + 0.5 * he.x) + e.y * (g.y + 0.5 * he.y);
+            x = make_double2(y.x + e.x, y.y + e.y);
+        }
+        double nn = sqrt(msdp_group_sum<LPR>(x.x * x.x + x.y * x.y));
+        if (!(nn > 0.0)) nn = 1.0;
+        const double2 ypr = ok ? make_double2(x.x / nn, x.y / nn) : zz;
+        YPs[r * PB + threadIdx.x] = ypr;
+        if (ok) st2_sc1(rs_yp, ((unsigned)row * (unsigned)d.ld + 2 * sub) * 8u, ypr);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my proposal rows are performed before my workgroup arrives
+    if (!pbarrier(sb, 0, d.G, shb, err)) return;
+    for (int r = 0; r < R; ++r) {
+        const int row = lo + r * RSTEP + slot0;
+        const bool rok = row < hi, ok = rok && colok;
+        double2 acc = zz;
+        if (rok) {
+            // CSR row of C (static data: plain loads); the proposal rows of other workgroups through sc1
+            const int s0 = d.rowptr[row], s1 = d.rowptr[row + 1];
+            for (int k0 = s0; k0 < s1; k0 += 8) {
+                double2 x[8];
+                double cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = k0 + u < s1;
+                    const int k = in ? k0 + u : s1 - 1;
+                    cv[u] = in ? d.cval[k] : 0.0;
+                    x[u] = ld2_sc1(rs_yp, ((unsigned)d.colind[k] * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x = fma(cv[u], x[u].x, acc.x); acc.y = fma(cv[u], x[u].y, acc.y); }
+            }
+        }
+        if (!colok) acc = zz;
+        const double2 ypr = YPs[r * PB + threadIdx.x];
+        const double dot = msdp_group_sum<LPR>(acc.x * ypr.x + acc.y * ypr.y);     // eG(row) = sum(YC.*Y)
+        const double2 gpr = ok ? make_double2(acc.x - ypr.x * dot, acc.y - ypr.y * dot) : zz;   // G = YC - Y.*eG
+        pgg += gpr.x * gpr.x + gpr.y * gpr.y;
+        if (ok) st2(Gp + (int64_t)row * d.ld + 2 * sub, gpr);
+        if (sub == 0 && rok) { pf += 0.5 * dot; eGp[row] = dot; }
+    }
+    if (!psync(sb, 0, d.G, 3, pf, pgg, prd, sh, shb, err)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                 // trustregions.m:548-729 (same arithmetic as k_rtr_decide)
+        const int f_stop = d.F[0].stop, f_j = d.F[0].j;
+        const double fp = pf, ggp = pgg;
+        double rhonum = c->fx - fp;                                          // :548
+        double rhoden = -prd;                                                // :550
+        const double rho_reg = fmax(1.0, fabs(c->fx)) * 2.220446049250313e-16 * c->rho_reg;   // :579
+        rhonum += rho_reg;
+        rhoden += rho_reg;
+        const bool model_decreased = rhoden >= 0.0;                          // :614
+        const double rho = rhonum / rhoden;                                  // :621
+        if (rho < 0.25 || !model_decreased || isnan(rho)) {                  // :653
+            c->Delta = c->Delta / 4.0;
+        } else if (rho > 0.75 && (f_stop == 1 || f_stop == 2)) {             // :669
+            c->Delta = fmin(2.0 * c->Delta, c->Delta_bar);
+        }
+        if (model_decreased && rho > c->rho_prime) {                         // :688
+            c->cur ^= 1;
+            c->fx = fp; c->gg = ggp; c->norm_grad = sqrt(ggp);
+            c->accepted++;
+        } else {
+            c->rejected++;
+        }
+        c->rho = rho; c->rhonum = rhonum; c->rhoden = rhoden; c->fx_prop = fp; c->gg_prop = ggp;
+        c->k++;                                                              // :729
+        c->hessvecs += f_j;
+        c->cost_evals++;
+        c->last_stop_inner = f_stop;
+        c->done = (c->norm_grad < c->tolgradnorm) || (c->k >= c->maxiter);
+    }
+}
+
+static int tail_lpr(const Dev& d) {
+    int half = d.ld / 2, lpr = 1;
+    while (lpr < half && lpr < 64) lpr <<= 1;
+    if (lpr < 8) lpr = 8;
+    return lpr;
+}
+
+// Same grid as the persistent tCG kernel (one workgroup per CU, all co-resident); LDS = one proposal row set.
+int msdp_tr_tail_grid(msdp_handle h);           // msdp_persist.hip (persist_grid)
+int msdp_launch_tr_tail(msdp_handle h) {
+    const int G = msdp_tr_tail_grid(h);
+    const int lpr = tail_lpr(h->d);
+    if (G < 8 || lpr > 32) { msdp_set_error("TR tail: not eligible"); return MSDP_ESTATE; }
+    const size_t lds = (size_t)(lpr / 4) * PB * sizeof(double2);
+    Dev dp = h->d;
+    dp.G = G;
+    typedef void (*fn_t)(Dev, unsigned long long*, int*);
+    fn_t fn = lpr == 8 ? k_tr_tail_obl<8> : (lpr == 16 ? k_tr_tail_obl<16> : k_tr_tail_obl<32>);
+    static bool attr_set[3] = {false, false, false};
+    const int ai = lpr == 8 ? 0 : (lpr == 16 ? 1 : 2);
+    if (!attr_set[ai]) {
+        HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[ai] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(G), dim3(PB), lds, h->stream, dp, h->psync_slots, h->psync_err);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
