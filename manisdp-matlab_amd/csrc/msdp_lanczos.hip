@@ -7,8 +7,9 @@
 // the G81 wall-clock.  Here ONE launch runs the steps [m0, m1): every workgroup keeps its rows of
 // v_{j-1}, v_j, w in registers and its rows of the deflation basis Q in LDS; per step
 //   1. w = S*v_j                      (neighbour entries gathered from the exchange buffer, sc1)
-//   2. grid reduction of [Q'w ; v_j'w]  (one sync: alpha_j and the nq deflation coefficients)
-//   3. w -= alpha_j v_j + beta_j v_{j-1} + Q (Q'w);  exchange buffer <- w;  grid reduction of |w|^2
+//   2. grid reduction of [Q'w ; Q'v_j ; v_j'w]  (one sync: alpha_j and the deflation coefficients of the UPDATED
+//      vector, Q'(w - alpha v_j - beta v_{j-1}) = Q'w - alpha Q'v_j - beta Q'v_{j-1}, by linearity)
+//   3. w -= alpha_j v_j + beta_j v_{j-1} + Q Q'(...);  exchange buffer <- w;  grid reduction of |w|^2
 //   4. beta_{j+1} = |w|, v_{j+1} = w / beta_{j+1}  -> column j+1 of the stored Lanczos basis
 // i.e. two grid synchronisations per step.  The synchronisation is the slot scheme of
 // msdp_persist.hip (agent-coherent sc1 stores, sentinel polling, three rotating generations,
