@@ -28,6 +28,7 @@
 #define LZ_SPIN_LIMIT (1 << 22)
 #define LZ_CPOL_SC1 16
 #define LZ_RMAX 2                         // rows per thread
+#define LZ_KREG 6                         // (col, val) pairs of a row kept in registers
 
 typedef unsigned int lz_v2u __attribute__((ext_vector_type(2)));
 
@@ -84,28 +85,34 @@ __device__ __forceinline__ bool lz_sync(__amdgpu_buffer_rsrc_t rs, unsigned gen,
         }
     }
     const int gpw = G / LZ_PWAVES, g_lo = wave * gpw;
-#pragma unroll
-    for (int ps = 0; ps < LZ_NV / 64; ++ps) {
-        const int c = lane + 64 * ps;
-        if (ps * 64 >= nv) break;                        // uniform
-        double s = 0.0;
+    {
+        // lane c serves the values c and c + 64 in the SAME batch of loads: one round trip per poll whatever nv is
+        constexpr int NP = LZ_NV / 64;
+        double s[NP];
         int spins = 0;
         for (;;) {
             bool ok = true;
-            s = 0.0;
-            if (c < nv) {
-                for (int g0 = 0; g0 < gpw; g0 += 8) {
-                    unsigned long long b[8];
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) s[ps] = 0.0;
+            for (int g0 = 0; g0 < gpw; g0 += 8) {
+                unsigned long long b[NP][8];
+#pragma unroll
+                for (int ps = 0; ps < NP; ++ps) {
+                    const int c = lane + 64 * ps;
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int g = g_lo + g0 + u;
-                        b[u] = (g0 + u < gpw) ? lz_ld_sc1_u64(rs, gbase + ((unsigned)g * LZ_NV + c) * 8u) : 0ULL;
+                        b[ps][u] = (c < nv && g0 + u < gpw) ? lz_ld_sc1_u64(rs, gbase + ((unsigned)g * LZ_NV + c) * 8u) : 0ULL;
                     }
+                }
+#pragma unroll
+                for (int ps = 0; ps < NP; ++ps) {
+                    const int c = lane + 64 * ps;
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        if (g0 + u < gpw) {
-                            ok = ok && (b[u] != LZ_SENT);
-                            s += __longlong_as_double((long long)b[u]);
+                        if (c < nv && g0 + u < gpw) {
+                            ok = ok && (b[ps][u] != LZ_SENT);
+                            s[ps] += __longlong_as_double((long long)b[ps][u]);
                         }
                     }
                 }
@@ -118,7 +125,11 @@ __device__ __forceinline__ bool lz_sync(__amdgpu_buffer_rsrc_t rs, unsigned gen,
                 break;
             }
         }
-        if (c < nv) part[wave * LZ_NV + c] = s;
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int c = lane + 64 * ps;
+            if (c < nv) part[wave * LZ_NV + c] = s[ps];
+        }
     }
     __syncthreads();
     if ((int)threadIdx.x < nv) {
@@ -174,11 +185,31 @@ __global__ __launch_bounds__(LZ_PB) void k_lanczos_persist(LzArgs a) {
     for (int c = 0; c < nq; ++c)
         for (int t = threadIdx.x; t < nrow; t += LZ_PB) Qs[(size_t)c * a.RW + t] = a.Q[(size_t)c * a.n + lo + t];
     double v[LZ_RMAX], vp[LZ_RMAX], w[LZ_RMAX], zr[LZ_RMAX];
+    int rc[LZ_RMAX][LZ_KREG], cnt[LZ_RMAX], kbeg[LZ_RMAX];
+    double rvv[LZ_RMAX][LZ_KREG];
 #pragma unroll
     for (int r = 0; r < LZ_RMAX; ++r) {
         const int t = threadIdx.x + r * LZ_PB;
         const bool ok = t < nrow;
         v[r] = ok ? a.V[(size_t)a.m0 * a.n + lo + t] : 0.0;
+        // the first LZ_KREG (col, val) pairs of the row stay in registers for the whole launch (S is static):
+        // removes two dependent loads (rowptr -> col/val) from every step's S*v chain
+        cnt[r] = 0;
+        if (ok) {
+            const int s0 = a.rp[lo + t], s1 = a.rp[lo + t + 1];
+            cnt[r] = s1 - s0;
+            kbeg[r] = s0;
+#pragma unroll
+            for (int u = 0; u < LZ_KREG; ++u) {
+                const bool in = s0 + u < s1;
+                rc[r][u] = in ? a.ci[s0 + u] : lo + t;
+                rvv[r][u] = in ? a.cv[s0 + u] : 0.0;
+            }
+        } else {
+            kbeg[r] = 0;
+#pragma unroll
+            for (int u = 0; u < LZ_KREG; ++u) { rc[r][u] = lo; rvv[r][u] = 0.0; }
+        }
         vp[r] = (ok && a.m0 > 0) ? a.V[(size_t)(a.m0 - 1) * a.n + lo + t] : 0.0;
         zr[r] = ok ? a.z[lo + t] : 0.0;
         w[r] = 0.0;
@@ -206,12 +237,20 @@ __global__ __launch_bounds__(LZ_PB) void k_lanczos_persist(LzArgs a) {
             if (t < nrow) {
                 const int row = lo + t;
                 double acc = 0.0;
-                const int s0 = a.rp[row], s1 = a.rp[row + 1];
-                for (int k = s0; k < s1; ++k) {
+                double xr[LZ_KREG];
+#pragma unroll
+                for (int u = 0; u < LZ_KREG; ++u) {
+                    const unsigned off = (unsigned)rc[r][u] * 8u;
+                    xr[u] = first ? lz_ld_sc1(rs_v0, off) : lz_ld_sc1(rs_x, off);
+                }
+#pragma unroll
+                for (int u = 0; u < LZ_KREG; ++u) acc = fma(rvv[r][u], xr[u], acc);
+                for (int k = kbeg[r] + LZ_KREG; k < kbeg[r] + cnt[r]; ++k) {       // rows longer than LZ_KREG entries
                     const unsigned off = (unsigned)a.ci[k] * 8u;
                     const double x = first ? lz_ld_sc1(rs_v0, off) : lz_ld_sc1(rs_x, off);
                     acc = fma(a.cv[k], x, acc);
                 }
+                (void)row;
                 w[r] = sc * acc - zr[r] * v[r];
                 ws[t] = w[r];
                 vs[t] = v[r];
