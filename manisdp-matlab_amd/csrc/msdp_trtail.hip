@@ -26,6 +26,7 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
     unsigned long long* sb = slots + PSYNC_REGION;
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
+    constexpr int RMAX = (LPR / 4 < 4) ? LPR / 4 : 4;            // row slots processed together (their loads overlap)
     const int R = (hi - lo + RSTEP - 1) / RSTEP;               // row slots actually needed (<= LPR/4 by construction)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
@@ -42,53 +43,82 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
     double* __restrict__ eGp = cur ? d.eG[0] : d.eG[1];
     const double2 zz = make_double2(0.0, 0.0);
     double prd = 0.0, pf = 0.0, pgg = 0.0;
-    for (int r = 0; r < R; ++r) {
-        const int row = lo + r * RSTEP + slot0;
-        const bool ok = row < hi && colok;
-        const int rc = row < hi ? row : lo;
-        const int64_t o = (int64_t)rc * d.ld + (colok ? 2 * sub : 0);
-        const double2 y = ld2(Yl + o), g = ld2(gl + o), e = ld2(eta + o), he = ld2(Heta + o);
-        double2 x = zz;
-        if (ok) {
-            prd += e.x * (g.x + 0.5 * he.x) + e.y * (g.y + 0.5 * he.y);
-            x = make_double2(y.x + e.x, y.y + e.y);
+    for (int r0 = 0; r0 < R; r0 += RMAX) {
+        double2 y[RMAX], g[RMAX], e[RMAX], he[RMAX];
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q) {
+            const int row = lo + (r0 + q) * RSTEP + slot0;
+            const int rc = row < hi ? row : lo;
+            const int64_t o = (int64_t)rc * d.ld + (colok ? 2 * sub : 0);
+            y[q] = ld2(Yl + o); g[q] = ld2(gl + o); e[q] = ld2(eta + o); he[q] = ld2(Heta + o);
         }
-        double nn = sqrt(msdp_group_sum<LPR>(x.x * x.x + x.y * x.y));
-        if (!(nn > 0.0)) nn = 1.0;
-        const double2 ypr = ok ? make_double2(x.x / nn, x.y / nn) : zz;
-        YPs[r * PB + threadIdx.x] = ypr;
-        if (ok) st2_sc1(rs_yp, ((unsigned)row * (unsigned)d.ld + 2 * sub) * 8u, ypr);
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q) {
+            const int r = r0 + q;
+            const int row = lo + r * RSTEP + slot0;
+            const bool ok = row < hi && colok;
+            double2 x = zz;
+            if (ok) {
+                prd += e[q].x * (g[q].x + 0.5 * he[q].x) + e[q].y * (g[q].y + 0.5 * he[q].y);
+                x = make_double2(y[q].x + e[q].x, y[q].y + e[q].y);
+            }
+            double nn = sqrt(msdp_group_sum<LPR>(x.x * x.x + x.y * x.y));
+            if (!(nn > 0.0)) nn = 1.0;
+            const double2 ypr = ok ? make_double2(x.x / nn, x.y / nn) : zz;
+            if (r < LPR / 4) YPs[r * PB + threadIdx.x] = ypr;
+            if (ok) st2_sc1(rs_yp, ((unsigned)row * (unsigned)d.ld + 2 * sub) * 8u, ypr);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my proposal rows are performed before my workgroup arrives
     if (!pbarrier(sb, 0, d.G, shb, err)) return;
-    for (int r = 0; r < R; ++r) {
-        const int row = lo + r * RSTEP + slot0;
-        const bool rok = row < hi, ok = rok && colok;
-        double2 acc = zz;
-        if (rok) {
-            // CSR row of C (static data: plain loads); the proposal rows of other workgroups through sc1
-            const int s0 = d.rowptr[row], s1 = d.rowptr[row + 1];
-            for (int k0 = s0; k0 < s1; k0 += 8) {
-                double2 x[8];
-                double cv[8];
+    for (int r0 = 0; r0 < R; r0 += RMAX) {
+        int s0[RMAX], s1[RMAX];
+        double2 acc[RMAX];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const bool in = k0 + u < s1;
-                    const int k = in ? k0 + u : s1 - 1;
-                    cv[u] = in ? d.cval[k] : 0.0;
-                    x[u] = ld2_sc1(rs_yp, ((unsigned)d.colind[k] * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { acc.x = fma(cv[u], x[u].x, acc.x); acc.y = fma(cv[u], x[u].y, acc.y); }
-            }
+        for (int q = 0; q < RMAX; ++q) {
+            const int row = lo + (r0 + q) * RSTEP + slot0;
+            const bool rok = row < hi;
+            s0[q] = rok ? d.rowptr[row] : 0;
+            s1[q] = rok ? d.rowptr[row + 1] : 0;
+            acc[q] = zz;
         }
-        if (!colok) acc = zz;
-        const double2 ypr = YPs[r * PB + threadIdx.x];
-        const double dot = msdp_group_sum<LPR>(acc.x * ypr.x + acc.y * ypr.y);     // eG(row) = sum(YC.*Y)
-        const double2 gpr = ok ? make_double2(acc.x - ypr.x * dot, acc.y - ypr.y * dot) : zz;   // G = YC - Y.*eG
-        pgg += gpr.x * gpr.x + gpr.y * gpr.y;
-        if (ok) st2(Gp + (int64_t)row * d.ld + 2 * sub, gpr);
-        if (sub == 0 && rok) { pf += 0.5 * dot; eGp[row] = dot; }
+        int len = 0;
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q) len = max(len, s1[q] - s0[q]);
+        // CSR rows of C (static data: plain loads); the proposal rows of other workgroups through sc1.  The RMAX
+        // rows advance together, 4 entries each per batch, so 4*RMAX gathers are in flight.
+        for (int kb = 0; kb < len; kb += 4) {
+            double2 x[RMAX][4];
+            double cv[RMAX][4];
+#pragma unroll
+            for (int q = 0; q < RMAX; ++q) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool in = s0[q] + kb + u < s1[q];
+                    const int k = in ? s0[q] + kb + u : (s1[q] > s0[q] ? s1[q] - 1 : 0);
+                    cv[q][u] = in ? d.cval[k] : 0.0;
+                    const int col = (s1[q] > s0[q]) ? d.colind[k] : lo;
+                    x[q][u] = ld2_sc1(rs_yp, ((unsigned)col * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RMAX; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc[q].x = fma(cv[q][u], x[q][u].x, acc[q].x); acc[q].y = fma(cv[q][u], x[q][u].y, acc[q].y); }
+        }
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q) {
+            const int r = r0 + q;
+            const int row = lo + r * RSTEP + slot0;
+            const bool rok = row < hi, ok = rok && colok;
+            double2 a2 = colok ? acc[q] : zz;
+            const double2 ypr = (r < LPR / 4) ? YPs[r * PB + threadIdx.x] : zz;
+            const double dot = msdp_group_sum<LPR>(a2.x * ypr.x + a2.y * ypr.y);     // eG(row) = sum(YC.*Y)
+            const double2 gpr = ok ? make_double2(a2.x - ypr.x * dot, a2.y - ypr.y * dot) : zz;   // G = YC - Y.*eG
+            pgg += gpr.x * gpr.x + gpr.y * gpr.y;
+            if (ok) st2(Gp + (int64_t)row * d.ld + 2 * sub, gpr);
+            if (sub == 0 && rok) { pf += 0.5 * dot; eGp[row] = dot; }
+        }
     }
     if (!psync(sb, 0, d.G, 3, pf, pgg, prd, sh, shb, err)) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) {                 // trustregions.m:548-729 (same arithmetic as k_rtr_decide)
