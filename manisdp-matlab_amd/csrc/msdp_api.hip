@@ -371,7 +371,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     if (h->h_status) (void)hipHostFree((void*)h->h_status);
     for (int s2 = 0; s2 < 2; ++s2) if (h->chunk_execs[s2]) (void)hipGraphExecDestroy(h->chunk_execs[s2]);
     msdp_affine_release(h);
-    if (h->esc_mem) (void)hipFree(h->esc_mem);
+    if (h->esc_mem) (void)hipFree(h->esc_mem);       // esc_prev lives inside it
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -142,6 +142,8 @@ struct msdp_handle_s {
     // for ~60 ms while the driver unmapped it: gaps seen in the kernel trace of the G81 solve)
     double* esc_mem = nullptr;
     size_t esc_cap = 0;               // doubles
+    double* esc_prev = nullptr;       // sum of the bottom eigenvectors found by the previous escape call (warm start)
+    int esc_prev_n = 0;
     // persistent tCG kernel (msdp_persist.hip): grid-sync slots, error flag, cached eligibility
     unsigned long long* psync_slots = nullptr;
     int* psync_err = nullptr;

@@ -484,14 +484,25 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     const int qcap = p + k + 1;
     double* mem = nullptr;
     const size_t slot_doubles = msdp_lanczos_slot_bytes() / sizeof(double);
-    const size_t total = (size_t)(qcap + maxit + 2 + qcap) * n + (size_t)n + 2 * (size_t)(maxit + 2) + 4096 + (size_t)n + slot_doubles + 16;
+    // [prev | Q | V | Z | w | alpha | beta | hbuf | X | slots | err]; prev (n doubles) = warm start kept between calls
+    const size_t total = (size_t)n + (size_t)(qcap + maxit + 2 + qcap) * n + (size_t)n + 2 * (size_t)(maxit + 2) + 4096 + (size_t)n + slot_doubles + 16;
     if (h->esc_cap < total) {
-        if (h->esc_mem) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->esc_mem); h->esc_mem = nullptr; h->esc_cap = 0; }
-        hipError_t me = hipMalloc((void**)&h->esc_mem, total * sizeof(double));
-        if (me != hipSuccess) { h->esc_mem = nullptr; msdp_set_error("escape_eigs: workspace allocation (%zu MB) failed", total * 8 >> 20); return MSDP_ENOMEM; }
-        h->esc_cap = total;
+        // grow with head room for 16 more factor columns: the factor width changes every outer iteration and a
+        // reallocation of this size stalls the stream for ~0.1 s
+        const size_t want = total + (size_t)32 * n;
+        double* nm = nullptr;
+        (void)hipStreamSynchronize(h->stream);
+        hipError_t me = hipMalloc((void**)&nm, want * sizeof(double));
+        if (me != hipSuccess) { (void)hipGetLastError(); me = hipMalloc((void**)&nm, total * sizeof(double)); }
+        if (me != hipSuccess) { msdp_set_error("escape_eigs: workspace allocation (%zu MB) failed", total * 8 >> 20); return MSDP_ENOMEM; }
+        if (h->esc_mem && h->esc_prev_n == n) (void)hipMemcpy(nm, h->esc_mem, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice);
+        else h->esc_prev_n = 0;
+        if (h->esc_mem) (void)hipFree(h->esc_mem);
+        h->esc_mem = nm;
+        h->esc_cap = (me == hipSuccess) ? want : total;
     }
-    mem = h->esc_mem;
+    mem = h->esc_mem + n;
+    h->esc_prev = h->esc_mem;
     double* Q = mem;                                   // deflation set: orth(Y) then accepted eigenvectors
     double* V = Q + (size_t)qcap * n;                   // Lanczos vectors
     double* Z = V + (size_t)(maxit + 2) * n;            // Rayleigh-Ritz basis copy
@@ -534,6 +545,14 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         // sequential deflation: smallest eigenpair of the complement; if negative keep it and repeat (<= k times)
         std::vector<double> found;
         bool have_xstart = false;                       // Z doubles as the warm-start buffer until the final Rayleigh-Ritz
+        // Across calls: S changes little from one outer iteration to the next, so the first run starts from the
+        // bottom eigenvectors the previous call found (deflated against the current Q inside lanczos_smallest)
+        static int no_warm = -1;
+        if (no_warm < 0) { const char* e = getenv("MSDP_ESC_NO_WARM"); no_warm = (e && atoi(e)) ? 1 : 0; }
+        if (!no_warm && h->esc_prev && h->esc_prev_n == n) {
+            ESC_HIP(hipMemcpyAsync(Z, h->esc_prev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            have_xstart = true;
+        }
         for (int t = 0; t < k;) {
             double theta, res, lmx; int m, nacc = 1;
             double thetas[64];
@@ -547,6 +566,17 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
             r += nacc; nfound += nacc; t += nacc;
             const double scale = std::max(fabs(theta), fabs(lam_max)) + 1e-300;
             if (!(theta < -tol * scale)) break;           // no further negative direction
+        }
+        // remember what was found for the next call's warm start (sum of the accepted vectors)
+        if (r > ry) {
+            if (h->esc_prev) {
+                std::vector<double> ones(r - ry, 1.0);
+                ESC_HIP(hipMemcpyAsync(c.hbuf, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                ESC_HIP(hipMemsetAsync(h->esc_prev, 0, (size_t)n * sizeof(double), h->stream));
+                hipLaunchKernelGGL(k_multiaxpy, gr, bl, 0, h->stream, n, r - ry, Q + (size_t)ry * n, (int64_t)n, c.hbuf, 1.0, h->esc_prev);
+                ESC_HIP(hipStreamSynchronize(h->stream));
+                h->esc_prev_n = n;
+            }
         }
         // ---- final Rayleigh-Ritz on Z = [Q_Y | X]: recouples the blocks when S*Y is only approximately zero
         const int nz = r;
