@@ -359,8 +359,8 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
                 if (m > 1024) lmax = tri_eig_kth(a, off, m, m - 1, glo, ghi);
                 break;
             }
-            // doubling up to 1024 steps, then x1.5: a late checkpoint wastes steps, an early one costs a host analysis
-            next_check = std::min(maxit, m < 1024 ? 2 * m : m + m / 2);
+            // doubling up to 1024 steps, then x1.5, x1.25 from 2048 on: a late checkpoint wastes steps, an early one costs a host analysis
+            next_check = std::min(maxit, m < 1024 ? 2 * m : (m < 2048 ? m + m / 2 : m + m / 4));
         }
     }
     // Ritz vector x = V s
