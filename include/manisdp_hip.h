@@ -112,6 +112,10 @@ int msdp_create_onlyunitdiag_dense_synthetic(int64_t n, uint64_t seed, int32_t n
 double msdp_synthetic_dense_entry(int64_t n, int64_t i, int64_t j, uint64_t seed);
 /* Test-only: stand in for the all-gather on a communicator-free shard (one process = rank r of N). */
 int msdp_debug_set_full_rows(msdp_handle h, const double* rows_host);
+/* Test-only: make a sparse-C handle rank `rank` of `nranks` WITHOUT a communicator (same row split, local CSR/ELL
+ * rows with global column indices and gather buffer as msdp_comm_init sets up), so that one GPU can check every
+ * shard's kernels against the unsharded result.  Call right after create, before any point is set. */
+int msdp_debug_shard(msdp_handle h, int32_t nranks, int32_t rank);
 
 /* min <C,X>, A(X) = b, diag X = 1 (kind = MSDP_KIND_UNITDIAG;
  * ManiSDP_unitdiag.m:152-171) or tr X = 1 (kind = MSDP_KIND_UNITTRACE;

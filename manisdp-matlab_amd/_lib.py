@@ -78,6 +78,7 @@ SIGNATURES = {
     "msdp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "msdp_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "msdp_local_rows": (C.c_int, [C.c_void_p, _i64p, _i64p]),
+    "msdp_debug_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "msdp_tcg_path": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "msdp_al_primal": (C.c_int, [C.c_void_p, _dp, _dp]),
     "msdp_al_dual": (C.c_int, [C.c_void_p, _dp, _dp]),
@@ -176,6 +177,10 @@ class Handle:
         out = C.c_void_p()
         _check(lib.msdp_create_onlyunitdiag_dense_synthetic(n, seed, nranks, rank, pcap, C.byref(out)))
         return cls(out.value, KIND_ONLYUNITDIAG, n)
+
+    def debug_shard(self, nranks, rank):
+        """Test-only: rank `rank` of `nranks` without a communicator (sparse C)."""
+        _check(self._lib.msdp_debug_shard(self._h, nranks, rank))
 
     def debug_set_full_rows(self, rows):
         rows = np.ascontiguousarray(rows, dtype=np.float64)

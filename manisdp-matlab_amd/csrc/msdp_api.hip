@@ -555,6 +555,25 @@ extern "C" int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const
     return msdp_alloc_vectors(h, h->pcap);
 }
 
+extern "C" int msdp_debug_shard(msdp_handle h, int32_t nranks, int32_t rank) {
+    CHECK_H(h);
+    if (nranks < 1 || rank < 0 || rank >= nranks) { msdp_set_error("bad shard (%d of %d)", rank, nranks); return MSDP_EINVAL; }
+    if (h->have_point || h->use_comm) { msdp_set_error("debug_shard must precede set_point / comm_init"); return MSDP_ESTATE; }
+    if (h->d.costkind != COST_SPARSE) { msdp_set_error("debug_shard: sparse-C handles only"); return MSDP_EUNSUPPORTED; }
+    h->nranks = nranks;
+    h->rank = rank;
+    h->presharded = true;                  // lets msdp_debug_set_full_rows stand in for the all-gather
+    const int cap = rows_capacity(h);
+    h->d.row0 = rank * cap;
+    int r1 = h->d.row0 + cap;
+    if (r1 > h->d.n) r1 = h->d.n;
+    h->d.n_loc = r1 > h->d.row0 ? r1 - h->d.row0 : 0;
+    int rc = alloc_common(h);
+    if (rc) return rc;
+    if ((rc = upload_sparse_rows(h))) return rc;
+    return msdp_alloc_vectors(h, h->pcap);
+}
+
 extern "C" int msdp_local_rows(msdp_handle h, int64_t* row0, int64_t* row1) {
     CHECK_H(h);
     if (row0) *row0 = h->d.row0;
