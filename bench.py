@@ -51,6 +51,12 @@ def cpu_baseline(C, Y0, budget_s=15.0):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON result of rank 0).  Native libraries print there too (RCCL's version
+    # banner with NCCL_DEBUG=VERSION arrives from C stdio at exit, i.e. after the JSON line), so file descriptor 1 is
+    # pointed at stderr for the whole run and the result goes to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -58,6 +64,9 @@ def main():
     ap.add_argument("--p", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kkt", action="store_true", help="skip the full G81 solve to KKT 1e-8")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="diagnostic: run the N = 1 workload through the RCCL code path of the multi-GPU run "
+                         "(size-1 communicator: all-gather + all-reduces per trip, chunked tCG)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -67,16 +76,19 @@ def main():
     if world != N and N > 1:
         raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
-    from manisdp_matlab_amd import _lib, problems
-    _lib.load()
-    _lib.set_device(local_rank)
-
     dist = None
-    if N > 1:
+    if N > 1 or args.force_comm:
+        # torch (its bundled HIP runtime + RCCL) must come up BEFORE libmanisdp_hip.so pulls in the system HIP
+        # runtime: the other order leaves torch with "No HIP GPUs are available" (seen on the MI355X box)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        torch.cuda.init()
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    _lib.set_device(local_rank)
 
     p = args.p
     g81 = os.path.join(ROOT, "tests", "golden", "G81.txt.gz")
@@ -95,7 +107,7 @@ def main():
     Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
 
     h = _lib.Handle.onlyunitdiag(C, pcap=p)
-    if N > 1:
+    if N > 1 or args.force_comm:
         import torch
         uid = [_lib.Handle.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -107,7 +119,7 @@ def main():
         return h.rtr(opts)
 
     def sync():
-        if N > 1:
+        if N > 1 or args.force_comm:
             import torch
             dist.barrier()
             torch.cuda.synchronize()
@@ -201,11 +213,12 @@ def main():
                           "rtr_seconds": data["rtr_seconds"], "escape_seconds": data["eig_seconds"],
                           "options": {"p0": 40}}
     h.close()
-    if N > 1:
+    if N > 1 or args.force_comm:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
 
 
 if __name__ == "__main__":
