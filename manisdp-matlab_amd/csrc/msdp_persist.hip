@@ -7,15 +7,18 @@
 // three launch gaps; here each workgroup keeps ITS rows of every vector in registers (eta, r, mdelta,
 // Hmdelta) and LDS (Y, grad, eG and the ELL rows of C) for the whole solve.  The only global traffic per
 // trip is the new direction (written once, gathered by the neighbours' S*U) and the partial sums of the
-// three reductions, which double as grid barriers.
+// two reductions (d_Hd; model value + r_r) plus one value-less barrier before the gathers.
+// Variants: p = 33..64 keeps mdelta / Hmdelta in LDS and re-reads Y / grad from L2 (LOWREG); rows longer than
+// 8 entries are walked in CSR form (EW = 0); FUSE = true (opt-in) runs the whole trustregions() loop here.
+// The rest of a TR iteration (retraction, cost/gradient at the proposal, accept/reject) is msdp_trtail.hip.
 //
 // Grid synchronisation = deterministic all-to-all reduction: every workgroup stores its partial sums
-// into its own slot of a generation buffer (agent-scope atomic store), then wave 0 of every workgroup
-// polls all G slots until none holds the sentinel and sums them in the same fixed order (the order of
+// into its own slot of a generation buffer (agent-scope atomic store, 8 per-XCD replicas), then wave 0 of
+// every workgroup polls the G slots of its replica until none holds the sentinel and sums them in the same fixed order (the order of
 // msdp_sum_partials), so all workgroups take bit-identical decisions.  Three generation buffers rotate;
 // a workgroup resets its slot of the previous generation after it has passed the current one (at that
 // point every workgroup has finished reading it).  All G workgroups must be co-resident: G <= number of
-// CUs and one 1024-thread workgroup per CU (checked on the host with the occupancy API); a bounded spin
+// CUs and one 512-thread workgroup per CU (checked on the host with the occupancy API); a bounded spin
 // turns a would-be hang into an error flag.
 //
 // Reference lines are quoted next to the statements (manopt7.0/manopt/solvers/trustregions/tCG.m);
