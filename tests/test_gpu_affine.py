@@ -270,3 +270,36 @@ def test_al_bookkeeping_on_device(lib, kind_name, case, p):
     f0 = h.cost()
     assert np.isfinite(f0)
     h.close()
+
+
+def test_solvers_with_device_al_bookkeeping_all_kinds(lib):
+    """eig='device' routes the whole AL step of the three affine-type entry points through msdp_al_primal / _dual /
+    msdp_escape_eigs_dual; each must land on the optimum the host-bookkeeping run (eig='host') certifies."""
+    from manisdp_matlab_amd import problems, solvers
+    known = json.load(open(golden_path("known_answers.json")))
+    # generic entry point on mcp100 (known answer)
+    At, b, c, K = problems.from_sdpa(golden_path("mcp100.dat-s.gz"))
+    c = np.asarray(c.todense()).ravel(); b = np.asarray(b, float)
+    Y, obj, d = solvers.ManiSDP(At, b, c, K, {"eig": "device"}, verbose=False, rng=np.random.default_rng(0))
+    assert d["status"] == 0 and max(d["gap"], d["pinf"], d["dinf"]) < 1e-8
+    assert abs(-obj - known["mcp100"]) < 1e-6 * known["mcp100"]
+    # unit diagonal on gpp100 (known answer, options of the oracle test)
+    At, b, c, K = problems.from_sdpa(golden_path("gpp100.dat-s.gz"))
+    c = np.asarray(c.todense()).ravel(); b = np.asarray(b, float)
+    opts = dict(sigma0=1e-1, sigma_min=1e-1, tau1=1e-2, tau2=1e-1, TR_maxinner=40, TR_maxiter=6, eig="device")
+    Y, obj, d = solvers.ManiSDP_unitdiag(At, b, c, K, opts, verbose=False)
+    assert max(d["gap"], d["pinf"], d["dinf"]) < 1e-6
+    assert abs(-obj - known["gpp100"]) < 2e-5 * abs(known["gpp100"])
+    # unit trace on theta1: same start point with host and device bookkeeping
+    At, b, c, K = problems.from_sdpa(golden_path("theta1.dat-s.gz"))
+    c = np.asarray(c.todense()).ravel(); b = np.asarray(b, float)
+    rng = np.random.default_rng(3)
+    Y0 = rng.standard_normal((K["s"], 1)); Y0 /= np.linalg.norm(Y0)
+    res = []
+    for mode in ("host", "device"):
+        Y, obj, d = solvers.ManiSDP_unittrace(At, b, c, K, dict(tol=1e-6, sigma0=1e5, sigma_max=1e8, Y0=Y0, eig=mode), verbose=False)
+        res.append((obj, max(d["gap"], d["pinf"]), d["status"]))
+        assert abs(np.linalg.norm(Y) - 1.0) < 1e-12
+    # the primal side agrees (the dual certificate of this instance may stall for either, see the theta1 test)
+    assert max(res[0][1], res[1][1]) < 1e-3
+    assert abs(res[0][0] - res[1][0]) < 1e-3 * abs(res[0][0])
