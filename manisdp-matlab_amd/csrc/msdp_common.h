@@ -76,6 +76,7 @@ struct Dev {
     double* r;
     double* md;       // mdelta, local rows
     double* md2;      // second direction buffer (fused two-launch trips)
+    double* mdx;      // persistent tCG: exchange buffer of the direction rows (uncached memory, sc1 accesses only)
     int fused;        // 1: trips are {k_hess_fused, k_tcg_upd1}; the final frame is F[1]
     double* Hmd;
     double* full;     // gather source of n x ld (== local buffer when nranks == 1)
@@ -142,6 +143,7 @@ struct msdp_handle_s {
     // for ~60 ms while the driver unmapped it: gaps seen in the kernel trace of the G81 solve)
     double* esc_mem = nullptr;
     size_t esc_cap = 0;               // doubles
+    unsigned long long* lz_slots = nullptr;   // grid-sync slots of the persistent Lanczos kernel (uncached device memory)
     double* esc_prev = nullptr;       // sum of the bottom eigenvectors found by the previous escape call (warm start)
     int esc_prev_n = 0;
     // persistent tCG kernel (msdp_persist.hip): grid-sync slots, error flag, cached eligibility

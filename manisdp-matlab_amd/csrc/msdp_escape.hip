@@ -512,7 +512,16 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     c.hbuf = dbeta + (maxit + 2);
     c.X = c.hbuf + 4096;
     c.slots = reinterpret_cast<unsigned long long*>(c.X + n);
-    c.err = reinterpret_cast<int*>(c.slots + slot_doubles);
+    // the slots proper live in uncached device memory (sc1 accesses skip the L2 look-up: -0.75 us per grid reduction,
+    // tools/microbench_sync.hip); the workspace copy above is the fallback
+    if (!h->lz_slots) {
+        const char* e = getenv("MSDP_NO_UNCACHED");
+        void* pu = nullptr;
+        if (!(e && atoi(e)) && hipExtMallocWithFlags(&pu, msdp_lanczos_slot_bytes(), hipDeviceMallocUncached) == hipSuccess) h->lz_slots = (unsigned long long*)pu;
+        else (void)hipGetLastError();
+    }
+    if (h->lz_slots) c.slots = h->lz_slots;
+    c.err = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(c.X + n) + slot_doubles);   // always in the workspace
     int rc = 0, r = 0, nfound = 0, total_steps = 0;
     double lam_max = -1e300;
     const dim3 gr((n + 255) / 256), bl(256);

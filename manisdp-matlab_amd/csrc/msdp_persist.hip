@@ -142,7 +142,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
 
     unsigned gen = 0, nbar = 0;
     const unsigned vec_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
-    __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(d.md, 0, vec_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, vec_bytes, 0x00020000);
     bool failed = false;
     bool first_tr = true;
   for (;;) {   // ---- trust-region iterations (exactly one pass when !FUSE)

@@ -70,10 +70,11 @@ __global__ __launch_bounds__(512) void k(unsigned long long* slots, unsigned lon
     if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 __global__ void fill(unsigned long long* s, size_t n) { for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s[i] = SENT; }
+static int g_alloc_mode = 0;   // 0 hipMalloc, 1 fine-grained, 2 uncached
 template <int VAR, int REPL = 8> void run(int G, int N) {
     unsigned long long* slots; unsigned long long* cnt; double* out;
     const size_t ns = 3 * 64 * MAXG;
-    hipMalloc(&slots, ns * 8); hipMalloc(&cnt, 1024); hipMalloc(&out, MAXG * 8);
+    if (g_alloc_mode == 0) hipMalloc(&slots, ns * 8); else hipExtMallocWithFlags((void**)&slots, ns * 8, g_alloc_mode == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached); hipMalloc(&cnt, 1024); hipMalloc(&out, MAXG * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         fill<<<64, 256>>>(slots, ns); hipMemset(cnt, 0, 1024);
@@ -81,11 +82,11 @@ template <int VAR, int REPL = 8> void run(int G, int N) {
         k<VAR, REPL><<<G, 512>>>(slots, cnt, N, out);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        if (rep) printf("variant %d repl %d G=%d: %.3f us per sync\n", VAR, REPL, G, ms * 1e3 / N);
+        if (rep) printf("alloc %d variant %d repl %d G=%d: %.3f us per sync\n", g_alloc_mode, VAR, REPL, G, ms * 1e3 / N);
     }
 }
 int main(int argc, char** argv) {
     const int N = 2000;
-    for (int G : {256, 128, 64}) { run<0>(G, N); run<1>(G, N); run<2, 8>(G, N); run<2, 16>(G, N); run<2, 32>(G, N); run<2, 64>(G, N); run<4>(G, N); }
+    for (int mode : {0, 1, 2}) { g_alloc_mode = mode; for (int G : {256, 64}) { run<0>(G, N); run<2, 8>(G, N); run<4>(G, N); } }
     return 0;
 }
