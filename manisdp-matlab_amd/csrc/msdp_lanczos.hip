@@ -256,19 +256,37 @@ __global__ __launch_bounds__(LZ_PB) void k_lanczos_persist(LzArgs a) {
                 vs[t] = v[r];
             }
         }
-        __syncthreads();
-        // ---- partials of [Q'w ; Q'v ; v'w]
+        // ---- partials of [Q'w ; Q'v ; v'w].  v'w: every thread owns its rows' products (wave sums + 8 LDS words);
+        // Q'w and Q'v: thread (c, seg) walks an eighth of the rows once for both (one pass over the Q column).
         {
-            const double hw = lz_coldot(Qs, a.RW, nrow, cth, nq, ws);
-            const double hv = lz_coldot(Qs, a.RW, nrow, cth, nq, vs);
-            const double al = lz_coldot(vs, a.RW, nrow, cth, 1, ws);
-            if ((threadIdx.x & 7) == 0) {
-                if (cth < nq) { vals[cth] = hw; vals[nq + cth] = hv; }
-                if (cth == 0) vals[2 * nq] = al;
+            double al = 0.0;
+#pragma unroll
+            for (int r = 0; r < LZ_RMAX; ++r) if ((int)threadIdx.x + r * LZ_PB < nrow) al = fma(w[r], v[r], al);
+            al = msdp_wave_sum(al);
+            if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = al;       // part[] is free between reductions
+        }
+        __syncthreads();
+        {
+            const int seg = threadIdx.x & 7;
+            double hw = 0.0, hv = 0.0;
+            if (cth < nq) {
+                const double* qc = Qs + (size_t)cth * a.RW;
+                for (int t = seg; t < nrow; t += 8) { const double qv = qc[t]; hw = fma(qv, ws[t], hw); hv = fma(qv, vs[t], hv); }
+            }
+            hw = msdp_group_sum<8>(hw);
+            hv = msdp_group_sum<8>(hv);
+            if (seg == 0 && cth < nq) { vals[cth] = hw; vals[nq + cth] = hv; }
+            if (threadIdx.x == 0) {
+                double s2 = 0.0;
+                for (int i = 0; i < LZ_PWAVES; ++i) s2 += part[i];
+                vals[2 * nq] = s2;
             }
         }
         if (!lz_sync(rs_slots, gen++, a.G, nv, vals, tot, part, flag, a.err)) return;
         const double alpha = tot[2 * nq];
+        // deflation coefficients Q'(w - alpha v - beta v_prev), once per workgroup (vals[] is free until the next post)
+        if ((int)threadIdx.x < nq) vals[threadIdx.x] = tot[threadIdx.x] - alpha * tot[nq + threadIdx.x] - beta * hvp[threadIdx.x];
+        __syncthreads();
         // ---- w -= alpha v + beta v_prev + Q Q'(w - alpha v - beta v_prev);  |w|^2
         double nn = 0.0;
 #pragma unroll
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(LZ_PB) void k_lanczos_persist(LzArgs a) {
             if (t < nrow) {
                 double x = w[r] - alpha * v[r] - beta * vp[r];
                 double dq = 0.0;
-                for (int c = 0; c < nq; ++c) dq = fma(tot[c] - alpha * tot[nq + c] - beta * hvp[c], Qs[(size_t)c * a.RW + t], dq);
+                for (int c = 0; c < nq; ++c) dq = fma(vals[c], Qs[(size_t)c * a.RW + t], dq);
                 x -= dq;
                 w[r] = x;
                 nn = fma(x, x, nn);
