@@ -20,6 +20,7 @@
 #include <math.h>
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -537,6 +538,8 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         double dthr = 1e-6;
         if (const char* ev = getenv("MSDP_ESCAPE_DEFLATE")) dthr = atof(ev);
         const bool deflate_y = h->gradnorm_valid && gnorm <= dthr * std::max(1.0, fabs(h->h_ctl->fx));
+        const bool dbg = getenv("MSDP_ESC_DEBUG") != nullptr;
+        auto tp0 = std::chrono::steady_clock::now();
         double ynorm_max = 0.0;
         for (int cidx = 0; deflate_y && cidx < p; ++cidx) {
             double* q = Q + (size_t)r * n;
@@ -551,6 +554,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
             }
         }
         const int ry = r;
+        auto tp1 = std::chrono::steady_clock::now();
         // sequential deflation: smallest eigenpair of the complement; if negative keep it and repeat (<= k times)
         std::vector<double> found;
         bool have_xstart = false;                       // Z doubles as the warm-start buffer until the final Rayleigh-Ritz
@@ -576,6 +580,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
             const double scale = std::max(fabs(theta), fabs(lam_max)) + 1e-300;
             if (!(theta < -tol * scale)) break;           // no further negative direction
         }
+        auto tp2 = std::chrono::steady_clock::now();
         // remember what was found for the next call's warm start (sum of the accepted vectors)
         if (r > ry) {
             if (h->esc_prev) {
@@ -624,6 +629,11 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
             }
         }
         (void)ry; (void)nfound;
+        if (dbg) {
+            auto tp3 = std::chrono::steady_clock::now();
+            auto ms = [](std::chrono::steady_clock::time_point a2, std::chrono::steady_clock::time_point b2) { return std::chrono::duration<double>(b2 - a2).count() * 1e3; };
+            fprintf(stderr, "[escape] orth(Y) %.2f ms (%d cols)  lanczos runs %.2f ms  Rayleigh-Ritz + output %.2f ms\n", ms(tp0, tp1), ry, ms(tp1, tp2), ms(tp2, tp3));
+        }
         if (lmax_out) *lmax_out = std::max(lam_max, ew[eo[nz - 1]]);
         if (iters_out) *iters_out = total_steps;
     }
