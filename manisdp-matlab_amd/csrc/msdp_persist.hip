@@ -82,11 +82,10 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     const int mininner = c->mininner, maxinner = c->maxinner;
     double gg = c->gg;
     // trust-region level state (FUSE: the whole trustregions() loop runs in this launch; trustregions.m:441-767)
-    double fx = c->fx, rho = 0.0, rhonum = 0.0, rhoden = 0.0, fx_prop = 0.0, gg_prop = 0.0;
+    double fx = c->fx;
     const double Delta_bar = c->Delta_bar, tolgradnorm = c->tolgradnorm, rho_prime = c->rho_prime, rho_reg_opt = c->rho_reg;
     const int maxiter = c->maxiter;
-    int k_it = c->k, hessvecs = c->hessvecs, accepted = c->accepted, rejected = c->rejected, cost_evals = c->cost_evals;
-    int last_stop = c->last_stop_inner;
+    int k_it = c->k;            // the statistics (counts, rho, ...) are kept in d.ctl by the lead thread, not in registers
     const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
     const double* __restrict__ gl = cur ? d.Gr[1] : d.Gr[0];
     const double* __restrict__ eGl = cur ? d.eG[1] : d.eG[0];
@@ -373,33 +372,35 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     if (!psync(slots, gen++, d.G, 3, pf, pgg, prd, sh, shb, err)) return;
     {   // trustregions.m:548-729, identical in every workgroup (same bits in, same decision out)
         const double fp = pf, ggp = pgg;
-        rhonum = fx - fp;                                                    // :548
-        rhoden = -prd;                                                       // :550
+        double rhonum = fx - fp;                                             // :548
+        double rhoden = -prd;                                                // :550
         const double rreg = fmax(1.0, fabs(fx)) * 2.220446049250313e-16 * rho_reg_opt;   // :579
         rhonum += rreg;
         rhoden += rreg;
         const bool model_decreased = rhoden >= 0.0;                          // :614
-        rho = rhonum / rhoden;                                               // :621
+        const double rho = rhonum / rhoden;                                  // :621
         if (rho < 0.25 || !model_decreased || isnan(rho)) Delta = Delta / 4.0;            // :653
         else if (rho > 0.75 && (stop == 1 || stop == 2)) Delta = fmin(2.0 * Delta, Delta_bar);   // :669
-        fx_prop = fp; gg_prop = ggp;
-        if (model_decreased && rho > rho_prime) {                            // :688
+        const bool accept = model_decreased && rho > rho_prime;              // :688
+        if (lead) {
+            Ctl* cw = d.ctl;
+            cw->rho = rho; cw->rhonum = rhonum; cw->rhoden = rhoden; cw->fx_prop = fp; cw->gg_prop = ggp;
+            if (accept) cw->accepted++; else cw->rejected++;
+            cw->hessvecs += j;
+            cw->cost_evals++;
+            cw->last_stop_inner = stop;
+        }
+        if (accept) {
             cur ^= 1;
             fx = fp; gg = ggp;
-            ++accepted;
 #pragma unroll 1
             for (int r = 0; r < R; ++r) {
                 Ys[r * PB + threadIdx.x] = YPs[r * PB + threadIdx.x];
                 Gs[r * PB + threadIdx.x] = GPs[r * PB + threadIdx.x];
                 if (sub == 0) eGs[SLOT(r)] = EGPs[SLOT(r)];
             }
-        } else {
-            ++rejected;
         }
         ++k_it;                                                              // :729
-        hessvecs += j;
-        ++cost_evals;
-        last_stop = stop;
     }
     __syncthreads();                                                         // eGs / Ys / Gs updates visible to the whole workgroup
     if (sqrt(gg) < tolgradnorm || k_it >= maxiter) break;                    // stoppingcriterion.m:51-72
@@ -407,12 +408,10 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     if (lead) {
         Ctl* cw = d.ctl;
         cw->fx = fx; cw->gg = gg; cw->norm_grad = sqrt(gg); cw->Delta = Delta;
-        cw->rho = rho; cw->rhonum = rhonum; cw->rhoden = rhoden; cw->fx_prop = fx_prop; cw->gg_prop = gg_prop;
-        cw->k = k_it; cw->cur = cur; cw->hessvecs = hessvecs; cw->accepted = accepted; cw->rejected = rejected;
-        cw->cost_evals = cost_evals; cw->last_stop_inner = last_stop;
+        cw->k = k_it; cw->cur = cur;
         cw->done = 1;
         cw->tcg_running = 0;
-        frame_store(&d.F[0], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, last_stop, 0, 0, 0);
+        frame_store(&d.F[0], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, cw->last_stop_inner, 0, 0, 0);
     }
 }
 
@@ -534,12 +533,14 @@ static size_t fused_lds(const PersistPlan& pl) {
 
 // Whole trustregions() loop in one launch (FUSE = true): tCG + retraction + cost/gradient at the proposal + the
 // accept/reject logic, iterated on the device until gradnorm < tol or maxiter.  Needs Y and grad in LDS (p <= 32).
-// Opt-in (MSDP_FUSED_RTR=1): correct (tests/test_gpu_onlyunitdiag.py runs it) but measured 5% SLOWER on G81 p = 32
-// (14.58 vs 13.86 ms per RTR call): the larger kernel spills 33 registers and its tCG trips cost 14.2 instead of
-// 12.85 us, more than the 4 launches per TR iteration it saves.
+// Default where it applies (MSDP_NO_FUSED_RTR=1 keeps two launches per TR iteration): 10.5 vs 11.1 ms per RTR call on
+// G81 p = 32 once the per-iteration statistics moved from registers to d.ctl (the first version spilled 33 registers
+// inside the tCG loop and was 5% slower).
 int msdp_persist_fused_ok(msdp_handle h) {
-    const char* e = getenv("MSDP_FUSED_RTR");
-    if (!(e && atoi(e))) return 0;
+    const char* e = getenv("MSDP_NO_FUSED_RTR");
+    if (e && atoi(e)) return 0;
+    const char* e2 = getenv("MSDP_FUSED_RTR");
+    if (e2 && !atoi(e2)) return 0;                     // MSDP_FUSED_RTR=0 also switches it off
     if (!msdp_persist_eligible(h)) return 0;
     PersistPlan pl;
     const int G = persist_grid(h->d);
