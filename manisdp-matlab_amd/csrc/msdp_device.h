@@ -42,6 +42,25 @@ __device__ __forceinline__ double msdp_readlane(double v, int lane) {
     return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
 
+template <int W>
+__device__ __forceinline__ double msdp_rowpair_sum(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)(b & 0xffffffffLL), hi = (unsigned)((unsigned long long)b >> 32);
+    unsigned l0, l1, h0, h1;
+    if (W == 16) {
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        l0 = rl[0]; l1 = rl[1]; h0 = rh[0]; h1 = rh[1];
+    } else {
+        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        l0 = rl[0]; l1 = rl[1]; h0 = rh[0]; h1 = rh[1];
+    }
+    const double a = __longlong_as_double((long long)(((unsigned long long)h0 << 32) | l0));
+    const double c = __longlong_as_double((long long)(((unsigned long long)h1 << 32) | l1));
+    return a + c;
+}
+
 // Sum over the LPR consecutive lanes that serve one row; valid in every lane of the
 // group.  All lanes of a group must be active together (they are: a group = a row).
 template <int LPR>
@@ -50,8 +69,11 @@ __device__ __forceinline__ double msdp_group_sum(double v) {
     if (LPR >= 4) v += msdp_dpp<MSDP_DPP_XOR2>(v);
     if (LPR >= 8) v += msdp_dpp<MSDP_DPP_HALF_MIRROR>(v);
     if (LPR >= 16) v += msdp_dpp<MSDP_DPP_MIRROR>(v);
-    if (LPR >= 32) v += __shfl_xor(v, 16, 64);
-    if (LPR >= 64) v += __shfl_xor(v, 32, 64);
+    // gfx950: v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows in the VALU (a __shfl_xor across
+    // rows is a ds_bpermute round trip through the LDS crossbar).  swap(v, v) returns {even-row value everywhere in
+    // the pair, odd-row value everywhere in the pair}; both rows add them in the same order.
+    if (LPR >= 32) v = msdp_rowpair_sum<16>(v);
+    if (LPR >= 64) v = msdp_rowpair_sum<32>(v);
     return v;
 }
 
