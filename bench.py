@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--p", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kkt", action="store_true", help="skip the full G81 solve to KKT 1e-8")
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-C (fp64 MFMA) Hess-vec figure")
     ap.add_argument("--force-comm", action="store_true",
                     help="diagnostic: run the N = 1 workload through the RCCL code path of the multi-GPU run "
                          "(size-1 communicator: all-gather + all-reduces per trip, chunked tCG)")
@@ -213,6 +214,23 @@ def main():
                           "rtr_seconds": data["rtr_seconds"], "escape_seconds": data["eig_seconds"],
                           "options": {"p0": 40}}
     h.close()
+    if not args.no_dense and N == 1 and rank == 0 and not args.force_comm:
+        # The dense tall-skinny contraction S*U is the one place the path uses the matrix cores (north_star): report its
+        # fp64 MFMA and HBM fractions on the dense-C shapes of BASELINE configs 4 / 5 (synthetic symmetric C, seed 0).
+        MFMA_F64_TFLOPS = 78.6                      # MI355X_MICROARCH.md: dense fp64 matrix peak
+        dense = []
+        for (dn, dp) in ((5000, 32), (5000, 64)):
+            hd = _lib.Handle.dense_synthetic(dn, 0, pcap=dp)
+            rngd = np.random.default_rng(0)
+            Yd = rngd.standard_normal((dn, dp)); Yd /= np.linalg.norm(Yd, axis=1, keepdims=True)
+            hd.set_point(Yd)
+            for _ in range(2):
+                msd, byd, fld = hd.bench_hessvec(100)
+            hd.close()
+            dense.append({"n": dn, "p": dp, "kernel": "k_dense_partial2 + k_dense_hess_epi_obl", "hessvec_us": msd * 1e3,
+                          "TFLOPs_f64": fld / msd / 1e9, "frac_mfma_f64_peak": fld / msd / 1e9 / MFMA_F64_TFLOPS,
+                          "GBps": byd / msd / 1e6, "frac_hbm_peak": byd / msd / 1e6 / HBM_PEAK_GBS})
+        out["dense_mfma"] = dense
     if N > 1 or args.force_comm:
         dist.barrier()
         dist.destroy_process_group()
