@@ -199,6 +199,8 @@ def main():
         "roofline": roofline,
         "hessvec_kernel": hess_kernel,
         "tcg_trip_us": trip_ms * 1e3,
+        "hessvec_per_s_kernel_only": 1e3 / ms,           # stand-alone S*U kernel back to back (both figures)
+        "hessvec_per_s_whole_tcg": 1e3 / trip_ms,        # one Hess-vec + all vector work and reductions of a tCG trip
         "hessvec_per_s_in_rtr": hv / rtr_s if rtr_s > 0 else None,
     }
     if rank == 0 and not args.no_cpu_baseline:
