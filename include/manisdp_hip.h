@@ -142,6 +142,11 @@ int msdp_get_p(msdp_handle h, int32_t* p);
 
 /* ------------------------------------------------------------------ hot path */
 
+/* Keep / bring back a device-side copy of the resident point (same width): restart a solve from the same
+ * start point without another host upload (measurement; line searches that want to back-track on the device). */
+int msdp_point_snapshot(msdp_handle h);
+int msdp_point_restore(msdp_handle h);
+
 /* [Y, ~, info] = trustregions(problem, Y, opts) on the resident point: the whole
  * RTR/tCG loop (trustregions.m:441-767, tCG.m:160-289) runs on the device. */
 int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats* stats);

@@ -80,6 +80,8 @@ SIGNATURES = {
     "msdp_local_rows": (C.c_int, [C.c_void_p, _i64p, _i64p]),
     "msdp_debug_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "msdp_tcg_path": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "msdp_point_snapshot": (C.c_int, [C.c_void_p]),
+    "msdp_point_restore": (C.c_int, [C.c_void_p]),
     "msdp_al_primal": (C.c_int, [C.c_void_p, _dp, _dp]),
     "msdp_al_dual": (C.c_int, [C.c_void_p, _dp, _dp]),
     "msdp_escape_eigs_dual": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, _dp, _dp, _dp, _P(C.c_int32)]),
@@ -355,6 +357,12 @@ class Handle:
         a, b = C.c_int64(), C.c_int64()
         _check(self._lib.msdp_local_rows(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def point_snapshot(self):
+        _check(self._lib.msdp_point_snapshot(self._h))
+
+    def point_restore(self):
+        _check(self._lib.msdp_point_restore(self._h))
 
     def tcg_path(self):
         """1: persistent single-launch tCG kernel, 0: chunked hipGraph (three kernels per trip)."""

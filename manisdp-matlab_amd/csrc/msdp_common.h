@@ -137,6 +137,9 @@ struct msdp_handle_s {
     Dev chunk_sig{};
     int chunk_len = 0;
     volatile unsigned long long* h_status = nullptr;   // host view of Dev::status
+    double* snap = nullptr;        // msdp_point_snapshot copy of the resident point
+    size_t snap_cap = 0;
+    int snap_p = 0;
     double* slab = nullptr;        // split-K partial slabs of the dense MFMA path
     size_t slab_cap = 0;
     // escape workspace, kept between calls (freeing 3 GB after every call stalled the NEXT kernels on the stream

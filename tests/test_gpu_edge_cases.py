@@ -158,3 +158,28 @@ def test_persistent_tcg_tiny_problems(shape, p):
         assert st.last_stop_inner == info.stop_inner[-1]
         assert abs(st.cost - f_ref) < 1e-11 * max(1.0, abs(f_ref))
     h.close()
+
+
+def test_point_snapshot_restore(lib):
+    """msdp_point_snapshot / _restore: restarting from the device-side copy gives exactly the solve that a fresh
+    upload of the same point gives."""
+    from manisdp_matlab_amd import problems
+    C = problems.toroidal_grid_maxcut(20, 30, seed=9)
+    n, p = C.shape[0], 6
+    rng = np.random.default_rng(5)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    h = lib.Handle.onlyunitdiag(C, pcap=p)
+    opts = lib.default_opts(maxiter=8, maxinner=30, tolgradnorm=1e-9)
+    h.set_point(Y)
+    h.point_snapshot()
+    a = h.rtr(opts)
+    Ya = h.get_point()
+    h.point_restore()
+    assert np.array_equal(h.get_point(), Y)
+    b = h.rtr(opts)
+    assert (a.cost, a.gradnorm, a.hessvecs, a.iters) == (b.cost, b.gradnorm, b.hessvecs, b.iters)
+    assert np.array_equal(h.get_point(), Ya)
+    h.set_point(np.hstack([Y, np.zeros((n, 2))]))
+    with pytest.raises(lib.MsdpError):
+        h.point_restore()                         # snapshot of another width
+    h.close()
