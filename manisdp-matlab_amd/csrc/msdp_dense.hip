@@ -243,6 +243,128 @@ __global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial2(DenseOp op,
     }
 }
 
+// Third structure (default): the same data flow as k_dense_partial2 with a register budget that lets 3-4 waves
+// share a SIMD (partial2 needs 200-256 VGPRs: 1-2 waves, so every barrier and every LDS round trip idles the matrix
+// pipe; a pure-MFMA loop measures 72 TFLOP/s on this chip, partial2 reaches 26-35).
+//   * ONE register ring for the matrix fragments: the loads of k-step s of tile t+1 are issued right after the MFMAs
+//     of step s of tile t were issued, into the registers that step just released (one tile of look-ahead, 8 VGPRs
+//     per 16 k);
+//   * ONE staging set for the panel tile, filled at the top of a tile, written to the other LDS buffer at its end;
+//   * the staging decomposition (thread -> column pair, row) needs no per-thread tables: HP = pow2 >= ncols/2 lanes
+//     cover a panel row, 256/HP rows per pass;
+//   * the scale of a k-step is a wave-uniform scalar computed where it is used;
+//   * KT = 64 for p <= 32, 32 beyond (LDS: four workgroups per CU up to p = 64).
+template <int NT> struct Dense3Cfg {
+    static constexpr int KT = NT <= 2 ? 64 : 32;
+    static constexpr int HP = NT == 1 ? 8 : (NT == 2 ? 16 : (NT <= 4 ? 32 : 64));
+    static constexpr int RPP = DENSE_WAVES * 64 / HP;          // panel rows staged per pass
+    static constexpr int NPASS = KT / RPP;
+    static constexpr int SS = KT / 16;
+};
+
+template <int NT>
+__global__ __launch_bounds__(DENSE_WAVES * 64, (NT <= 4 ? 3 : 1)) void k_dense_partial3(DenseOp op, const int* active_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // 2 x KT x ldl
+    if (active_flag && !*active_flag) return;
+    typedef Dense3Cfg<NT> Cfg;
+    constexpr int KT = Cfg::KT, HP = Cfg::HP, RPP = Cfg::RPP, NPASS = Cfg::NPASS, SS = Cfg::SS;
+    constexpr int NTHR = DENSE_WAVES * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int row0 = (blockIdx.x * DENSE_WAVES + wave) * 16;
+    const int arow = min(row0 + i, op.n_loc - 1);
+    const int nS = op.nS;
+    const int Ktot = op.nmat * nS;
+    const int kbeg = blockIdx.y * op.kslice;
+    const int kend = min(kbeg + op.kslice, Ktot);
+    const int ld = op.ld, ldl = op.ldl;
+    for (int e = threadIdx.x; e < 2 * KT * ldl; e += NTHR) lds[e] = 0.0;   // pad columns stay zero
+    const int c2 = threadIdx.x & (HP - 1), sr0 = threadIdx.x / HP;
+    const bool colok = 2 * c2 < op.ncols;
+    const int sgo = op.colofs + (colok ? 2 * c2 : 0);
+    const int slo = sr0 * ldl + 2 * c2;
+    double4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const double* a0 = op.M[0] + (int64_t)arow * nS + 4 * g;
+    const double* a1 = op.M[1] + (int64_t)arow * nS + 4 * g - nS;      // indexed with the concatenated k
+    double2 areg[SS][2];
+    double2 stg[NPASS];
+
+    auto load_a = [&](int ks, int s) {                          // branch-free: out-of-range steps read the slice start
+        const int kc = ks < kend ? ks : kbeg;
+        const double* ap = (kc >= nS ? a1 : a0) + kc;
+        areg[s][0] = ld2(ap); areg[s][1] = ld2(ap + 2);
+    };
+    auto load_stg = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            const int kk = k0 + sr0 + q * RPP;
+            const int kc = kk < kend ? kk : kbeg;
+            const int m = kc >= nS ? 1 : 0;
+            const int kl = kc - m * nS;
+            const bool ok = kk < kend && kl < op.n;
+            const double2 v = ld2((m ? op.X[1] : op.X[0]) + (ok ? (int64_t)kl * ld + sgo : 0));
+            stg[q] = ok ? v : make_double2(0.0, 0.0);
+        }
+    };
+    auto store_stg = [&](double* buf) {
+        if (colok) {
+#pragma unroll
+            for (int q = 0; q < NPASS; ++q) *reinterpret_cast<double2*>(&buf[slo + q * RPP * ldl]) = stg[q];
+        }
+    };
+    // one tile: MFMAs of step s, then the refill of the fragment registers of step s for the next tile
+    auto compute_tile = [&](const double* bt, int k0) {
+#pragma unroll
+        for (int s = 0; s < SS; ++s) {
+            const int ks = k0 + 16 * s;
+            const double sc = ks < kend ? (ks >= nS ? op.scale[1] : op.scale[0]) : 0.0;
+            const double av[4] = {areg[s][0].x * sc, areg[s][0].y * sc, areg[s][1].x * sc, areg[s][1].y * sc};
+            load_a(ks + KT, s);
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const double* brow = &bt[(16 * s + 4 * g + t4) * ldl + i];
+                double bv[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bv[t] = brow[16 * t];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t4], bv[t], acc[t], 0, 0, 0);
+            }
+        }
+    };
+
+    double* buf0 = lds;
+    double* buf1 = lds + KT * ldl;
+    __syncthreads();                                           // zero fill done
+#pragma unroll
+    for (int s = 0; s < SS; ++s) load_a(kbeg + 16 * s, s);
+    load_stg(kbeg);
+    store_stg(buf0);
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * KT) {
+        __syncthreads();
+        load_stg(k0 + KT);
+        compute_tile(buf0, k0);
+        if (k0 + KT >= kend) break;
+        store_stg(buf1);
+        __syncthreads();
+        load_stg(k0 + 2 * KT);
+        compute_tile(buf1, k0 + KT);
+        if (k0 + 2 * KT >= kend) break;
+        store_stg(buf0);
+    }
+    double* out = op.slab + (int64_t)blockIdx.y * op.slab_stride;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = 16 * t + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + g + 4 * r;
+            if (row < op.n_loc && col < op.ncols) out[(int64_t)row * ld + op.colofs + col] = acc[t][r];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- epilogues (oblique)
 // eH(row) = sum of the SK slabs; then ManiSDP_onlyunitdiag.m:129 / ManiSDP_unitdiag.m:170.
 template <int LPR, int NCH>
@@ -370,21 +492,80 @@ static int ensure_slab(msdp_handle h, size_t need) {
 
 int msdp_dense_nS(int n) { return ((n + 15) / 16) * 16; }
 
+typedef void (*dense3_fn_t)(DenseOp, const int*);
+static dense3_fn_t dense3_fn(int NT) {
+    switch (NT) {
+        case 1: return k_dense_partial3<1>; case 2: return k_dense_partial3<2>; case 3: return k_dense_partial3<3>;
+        case 4: return k_dense_partial3<4>; case 5: return k_dense_partial3<5>; case 6: return k_dense_partial3<6>;
+        case 7: return k_dense_partial3<7>; default: return k_dense_partial3<8>;
+    }
+}
+static int dense3_kt(int NT) { return NT <= 2 ? 64 : 32; }
+static int dense_ldl(int ncols) {
+    int ldl = ((ncols + 15) / 16) * 16;                      // zero-padded to 16*NT columns (no column predicate)
+    while ((ldl & 7) != 4) ldl += 2;                         // ldl = 4 (mod 8): conflict-free B reads
+    return ldl;
+}
+// Workgroups of k_dense_partial3<NT> the chip holds at once (registers and LDS), cached per NT.
+static int dense3_capacity(int NT, int ldl) {
+    static int cap[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    }
+    if (!cap[NT]) {
+        int per_cu = 0;
+        const size_t shmem = (size_t)2 * dense3_kt(NT) * ldl * sizeof(double);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)dense3_fn(NT), DENSE_WAVES * 64, shmem) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        cap[NT] = per_cu * cus;
+    }
+    return cap[NT];
+}
+
+// Split-K plan.  The k range is cut into SK slices so that the launch fills the chip: the workgroup count
+// row_blocks*SK should sit just below a multiple of what the chip holds at once (a partial last round idles most
+// CUs), the slices should be equal (multiples of 16 k), and every extra slab costs a write and a read of n_loc x ld.
 static void dense_plan(msdp_handle h, int nmat, int* row_blocks_out, int* SK_out, int64_t* kslice_out) {
     const Dev& d = h->d;
     const int nS = msdp_dense_nS(d.n);
     const int row_blocks = (d.n_loc + DENSE_WAVES * 16 - 1) / (DENSE_WAVES * 16);
     const int64_t Ktot = (int64_t)nmat * nS;
-    static int target = -1;
-    if (target < 0) { const char* e = getenv("MSDP_DENSE_BLOCKS"); target = e ? atoi(e) : 1024; if (target < 1) target = 1024; }
-    int SK = (target + row_blocks - 1) / row_blocks;     // aim at ~target/256 workgroups per CU
-    const int maxSK = (int)((Ktot + 4 * DENSE_KT - 1) / (4 * DENSE_KT));
-    if (SK > maxSK) SK = maxSK;
-    if (SK > 32) SK = 32;
-    if (SK < 1) SK = 1;
-    int64_t kslice = (Ktot + SK - 1) / SK;
-    kslice = ((kslice + 63) / 64) * 64;
-    SK = (int)((Ktot + kslice - 1) / kslice);
+    static int target = -2;
+    if (target == -2) { const char* e = getenv("MSDP_DENSE_BLOCKS"); target = e ? atoi(e) : -1; }
+    int SK;
+    int64_t kslice;
+    if (target > 0) {                                         // experiment: fixed workgroup target, 64-k granularity
+        SK = (target + row_blocks - 1) / row_blocks;
+        const int maxSK = (int)((Ktot + 4 * DENSE_KT - 1) / (4 * DENSE_KT));
+        if (SK > maxSK) SK = maxSK;
+        if (SK > 32) SK = 32;
+        if (SK < 1) SK = 1;
+        kslice = (Ktot + SK - 1) / SK;
+        kslice = ((kslice + 63) / 64) * 64;
+        SK = (int)((Ktot + kslice - 1) / kslice);
+    } else {
+        const int ncols = std::min(128, d.ld);
+        const int NT = (ncols + 15) / 16;
+        const double cap = (double)dense3_capacity(NT, dense_ldl(ncols));
+        double best = 1e300;
+        SK = 1; kslice = ((Ktot + 15) / 16) * 16;
+        for (int cand = 1; cand <= 32; ++cand) {
+            int64_t ks = (Ktot + cand - 1) / cand;
+            ks = ((ks + 15) / 16) * 16;
+            if (ks < 128 && cand > 1) break;
+            const int sk = (int)((Ktot + ks - 1) / ks);
+            const double W = (double)row_blocks * sk;
+            const double rounds = ceil(W / cap);
+            const double fill = W / (rounds * cap);
+            const double balance = (double)Ktot / ((double)sk * (double)ks);
+            const double slab = 1.0 + 2.0 * sk * (double)d.ld / (double)Ktot;
+            const double cost = slab / (fill * balance);
+            if (cost < best * 0.999) { best = cost; SK = sk; kslice = ks; }
+        }
+    }
     *row_blocks_out = row_blocks; *SK_out = SK; *kslice_out = kslice;
 }
 
@@ -419,14 +600,14 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
     int rc = ensure_slab(h, (size_t)SK * op.slab_stride);
     if (rc) return rc;
     op.slab = h->slab;
-    static int v1 = -1;
+    static int v1 = -1, v2 = -1;
     if (v1 < 0) { const char* e = getenv("MSDP_DENSE_V1"); v1 = (e && atoi(e)) ? 1 : 0; }
+    if (v2 < 0) { const char* e = getenv("MSDP_DENSE_V2"); v2 = (e && atoi(e)) ? 1 : 0; }
     // p > 128: column blocks of 128 (the matrix is re-streamed once per block; NT <= 8 accumulator tiles per wave)
     for (int colofs = 0; colofs < d.ld; colofs += 128) {
         op.colofs = colofs;
         op.ncols = std::min(128, d.ld - colofs);
-        int ldl = ((op.ncols + 15) / 16) * 16;                // zero-padded to 16*NT columns (no column predicate)
-        while ((ldl & 7) != 4) ldl += 2;                      // ldl = 4 (mod 8): conflict-free B reads
+        const int ldl = dense_ldl(op.ncols);
         op.ldl = ldl;
         const int NT = (op.ncols + 15) / 16;
         dim3 grid(row_blocks, SK), block(DENSE_WAVES * 64);
@@ -442,6 +623,13 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
                 case 7: hipLaunchKernelGGL((k_dense_partial<7>), grid, block, shmem, h->stream, op, active_flag); break;
                 default: hipLaunchKernelGGL((k_dense_partial<8>), grid, block, shmem, h->stream, op, active_flag); break;
             }
+        } else if (!v2) {
+#define DENSE3_CASE(N) case N: hipLaunchKernelGGL((k_dense_partial3<N>), grid, block, (size_t)2 * Dense3Cfg<N>::KT * ldl * sizeof(double), h->stream, op, active_flag); break;
+            switch (NT) {
+                DENSE3_CASE(1) DENSE3_CASE(2) DENSE3_CASE(3) DENSE3_CASE(4) DENSE3_CASE(5) DENSE3_CASE(6) DENSE3_CASE(7)
+                default: hipLaunchKernelGGL((k_dense_partial3<8>), grid, block, (size_t)2 * Dense3Cfg<8>::KT * ldl * sizeof(double), h->stream, op, active_flag); break;
+            }
+#undef DENSE3_CASE
         } else {
             const size_t shmem = (size_t)2 * DENSE_KT2 * ldl * sizeof(double);
             switch (NT) {
