@@ -246,16 +246,16 @@ __global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial2(DenseOp op,
 // Third structure (default): the same data flow as k_dense_partial2 with a register budget that lets 3-4 waves
 // share a SIMD (partial2 needs 200-256 VGPRs: 1-2 waves, so every barrier and every LDS round trip idles the matrix
 // pipe; a pure-MFMA loop measures 72 TFLOP/s on this chip, partial2 reaches 26-35).
-//   * ONE register ring for the matrix fragments: the loads of k-step s of tile t+1 are issued right after the MFMAs
-//     of step s of tile t were issued, into the registers that step just released (one tile of look-ahead, 8 VGPRs
-//     per 16 k);
-//   * ONE staging set for the panel tile, filled at the top of a tile, written to the other LDS buffer at its end;
+//   * two statically named fragment sets (tile in work / next tile, 8 VGPRs per 16 k each) so that hipcc emits
+//     counted vmcnt(N) waits, but only ONE staging set for the panel tile, filled at the top of a tile and written
+//     to the other LDS buffer at its end (a single fragment ring refilled step by step was tried: hipcc sinks the
+//     refills below the last MFMA of the tile, and pinning them with sched_barrier costs a second register set anyway);
 //   * the staging decomposition (thread -> column pair, row) needs no per-thread tables: HP = pow2 >= ncols/2 lanes
 //     cover a panel row, 256/HP rows per pass;
 //   * the scale of a k-step is a wave-uniform scalar computed where it is used;
 //   * KT = 64 for p <= 32, 32 beyond (LDS: four workgroups per CU up to p = 64).
 template <int NT> struct Dense3Cfg {
-    static constexpr int KT = NT <= 2 ? 64 : 32;
+    static constexpr int KT = NT <= 1 ? 64 : 32;
     static constexpr int HP = NT == 1 ? 8 : (NT == 2 ? 16 : (NT <= 4 ? 32 : 64));
     static constexpr int RPP = DENSE_WAVES * 64 / HP;          // panel rows staged per pass
     static constexpr int NPASS = KT / RPP;
@@ -264,7 +264,7 @@ template <int NT> struct Dense3Cfg {
 
 template <int NT>
 __global__ __launch_bounds__(DENSE_WAVES * 64, (NT <= 4 ? 3 : 1)) void k_dense_partial3(DenseOp op, const int* active_flag) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // 2 x KT x ldl
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // 2 x KT x ldl + 128 (dummy slots)
     if (active_flag && !*active_flag) return;
     typedef Dense3Cfg<NT> Cfg;
     constexpr int KT = Cfg::KT, HP = Cfg::HP, RPP = Cfg::RPP, NPASS = Cfg::NPASS, SS = Cfg::SS;
@@ -288,13 +288,17 @@ __global__ __launch_bounds__(DENSE_WAVES * 64, (NT <= 4 ? 3 : 1)) void k_dense_p
     for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
     const double* a0 = op.M[0] + (int64_t)arow * nS + 4 * g;
     const double* a1 = op.M[1] + (int64_t)arow * nS + 4 * g - nS;      // indexed with the concatenated k
-    double2 areg[SS][2];
+    double2 A0[SS][2], A1[SS][2];                              // fragments of the tile in work / of the next tile
     double2 stg[NPASS];
 
-    auto load_a = [&](int ks, int s) {                          // branch-free: out-of-range steps read the slice start
-        const int kc = ks < kend ? ks : kbeg;
-        const double* ap = (kc >= nS ? a1 : a0) + kc;
-        areg[s][0] = ld2(ap); areg[s][1] = ld2(ap + 2);
+    auto load_a = [&](int k0, double2 (&A)[SS][2]) {           // branch-free: out-of-range steps read the slice start
+#pragma unroll
+        for (int s = 0; s < SS; ++s) {
+            const int ks = k0 + 16 * s;
+            const int kc = ks < kend ? ks : kbeg;
+            const double* ap = (kc >= nS ? a1 : a0) + kc;
+            A[s][0] = ld2(ap); A[s][1] = ld2(ap + 2);
+        }
     };
     auto load_stg = [&](int k0) {
 #pragma unroll
@@ -308,20 +312,19 @@ __global__ __launch_bounds__(DENSE_WAVES * 64, (NT <= 4 ? 3 : 1)) void k_dense_p
             stg[q] = ok ? v : make_double2(0.0, 0.0);
         }
     };
+    // branch-free (a conditional store lets hipcc sink the staging loads into the branch, next to their use):
+    // lanes beyond the last column pair write a per-lane dummy slot behind the two tiles
     auto store_stg = [&](double* buf) {
-        if (colok) {
 #pragma unroll
-            for (int q = 0; q < NPASS; ++q) *reinterpret_cast<double2*>(&buf[slo + q * RPP * ldl]) = stg[q];
-        }
+        for (int q = 0; q < NPASS; ++q)
+            *reinterpret_cast<double2*>(colok ? &buf[slo + q * RPP * ldl] : &lds[2 * KT * ldl + 2 * lane]) = stg[q];
     };
-    // one tile: MFMAs of step s, then the refill of the fragment registers of step s for the next tile
-    auto compute_tile = [&](const double* bt, int k0) {
+    auto compute_tile = [&](const double* bt, int k0, const double2 (&A)[SS][2]) {
 #pragma unroll
         for (int s = 0; s < SS; ++s) {
             const int ks = k0 + 16 * s;
             const double sc = ks < kend ? (ks >= nS ? op.scale[1] : op.scale[0]) : 0.0;
-            const double av[4] = {areg[s][0].x * sc, areg[s][0].y * sc, areg[s][1].x * sc, areg[s][1].y * sc};
-            load_a(ks + KT, s);
+            const double av[4] = {A[s][0].x * sc, A[s][0].y * sc, A[s][1].x * sc, A[s][1].y * sc};
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
                 const double* brow = &bt[(16 * s + 4 * g + t4) * ldl + i];
@@ -337,20 +340,21 @@ __global__ __launch_bounds__(DENSE_WAVES * 64, (NT <= 4 ? 3 : 1)) void k_dense_p
     double* buf0 = lds;
     double* buf1 = lds + KT * ldl;
     __syncthreads();                                           // zero fill done
-#pragma unroll
-    for (int s = 0; s < SS; ++s) load_a(kbeg + 16 * s, s);
+    load_a(kbeg, A0);
     load_stg(kbeg);
     store_stg(buf0);
+    // No exits inside the body: a break between the loads and the code that uses them lets hipcc sink the loads
+    // past the branch, next to their use.  An odd tile count costs one tile of zero work (sc = 0, staged zeros).
     for (int k0 = kbeg; k0 < kend; k0 += 2 * KT) {
         __syncthreads();
-        load_stg(k0 + KT);
-        compute_tile(buf0, k0);
-        if (k0 + KT >= kend) break;
+        load_stg(k0 + KT);                                      // older than the fragment loads: its wait leaves them in flight
+        load_a(k0 + KT, A1);
+        compute_tile(buf0, k0, A0);
         store_stg(buf1);
         __syncthreads();
         load_stg(k0 + 2 * KT);
-        compute_tile(buf1, k0 + KT);
-        if (k0 + 2 * KT >= kend) break;
+        load_a(k0 + 2 * KT, A0);
+        compute_tile(buf1, k0 + KT, A1);
         store_stg(buf0);
     }
     double* out = op.slab + (int64_t)blockIdx.y * op.slab_stride;
@@ -500,7 +504,8 @@ static dense3_fn_t dense3_fn(int NT) {
         case 7: return k_dense_partial3<7>; default: return k_dense_partial3<8>;
     }
 }
-static int dense3_kt(int NT) { return NT <= 2 ? 64 : 32; }
+static int dense3_kt(int NT) { return NT <= 1 ? 64 : 32; }
+static size_t dense3_lds(int NT, int ldl) { return ((size_t)2 * dense3_kt(NT) * ldl + 128) * sizeof(double); }   // two tiles + dummy slots
 static int dense_ldl(int ncols) {
     int ldl = ((ncols + 15) / 16) * 16;                      // zero-padded to 16*NT columns (no column predicate)
     while ((ldl & 7) != 4) ldl += 2;                         // ldl = 4 (mod 8): conflict-free B reads
@@ -517,7 +522,7 @@ static int dense3_capacity(int NT, int ldl) {
     }
     if (!cap[NT]) {
         int per_cu = 0;
-        const size_t shmem = (size_t)2 * dense3_kt(NT) * ldl * sizeof(double);
+        const size_t shmem = dense3_lds(NT, ldl);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)dense3_fn(NT), DENSE_WAVES * 64, shmem) != hipSuccess || per_cu < 1)
             per_cu = 1;
         cap[NT] = per_cu * cus;
@@ -554,7 +559,7 @@ static void dense_plan(msdp_handle h, int nmat, int* row_blocks_out, int* SK_out
         SK = 1; kslice = ((Ktot + 15) / 16) * 16;
         for (int cand = 1; cand <= 32; ++cand) {
             int64_t ks = (Ktot + cand - 1) / cand;
-            ks = ((ks + 15) / 16) * 16;
+            ks = ((ks + 63) / 64) * 64;                       // whole tile pairs
             if (ks < 128 && cand > 1) break;
             const int sk = (int)((Ktot + ks - 1) / ks);
             const double W = (double)row_blocks * sk;
@@ -624,10 +629,10 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
                 default: hipLaunchKernelGGL((k_dense_partial<8>), grid, block, shmem, h->stream, op, active_flag); break;
             }
         } else if (!v2) {
-#define DENSE3_CASE(N) case N: hipLaunchKernelGGL((k_dense_partial3<N>), grid, block, (size_t)2 * Dense3Cfg<N>::KT * ldl * sizeof(double), h->stream, op, active_flag); break;
+#define DENSE3_CASE(N) case N: hipLaunchKernelGGL((k_dense_partial3<N>), grid, block, dense3_lds(N, ldl), h->stream, op, active_flag); break;
             switch (NT) {
                 DENSE3_CASE(1) DENSE3_CASE(2) DENSE3_CASE(3) DENSE3_CASE(4) DENSE3_CASE(5) DENSE3_CASE(6) DENSE3_CASE(7)
-                default: hipLaunchKernelGGL((k_dense_partial3<8>), grid, block, (size_t)2 * Dense3Cfg<8>::KT * ldl * sizeof(double), h->stream, op, active_flag); break;
+                default: hipLaunchKernelGGL((k_dense_partial3<8>), grid, block, dense3_lds(8, ldl), h->stream, op, active_flag); break;
             }
 #undef DENSE3_CASE
         } else {
