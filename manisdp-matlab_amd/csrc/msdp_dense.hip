@@ -9,15 +9,15 @@
 // aligned global_load_dwordx4.  The matrix is symmetric, so "row-major rows" are also the
 // columns the reference's U*C touches.
 //
-// Kernel 1 (k_dense_partial): one wave owns 16 rows x all p columns as NT accumulator
+// Kernel 1 (k_dense_partial3): one wave owns 16 rows x all p columns as NT accumulator
 // tiles of v_mfma_f64_16x16x4_f64; the matrix is streamed from HBM exactly once straight
 // into the MFMA A layout (lane (g = lane>>4, i = lane&15) holds S[row0+i][k0+4g+t], t=0..3,
 // two dwordx4 per 16 k -- each matrix row contributes a full 128-byte line per step); the
-// thin panel tile U[k0:k0+KT, :] is staged through LDS once per workgroup and read as the
-// B operand with a row stride = 4 (mod 8) doubles, which places the four k-groups of a
-// wave on disjoint bank halves (conflict-free ds_read_b64).  The K range is split over
-// blockIdx.y so that >= 2 workgroups per CU exist even for n = 5000; each slice writes a
-// partial slab with plain stores (deterministic, no fp64 atomics).
+// thin panel tile U[k0:k0+KT, :] is staged through LDS once per workgroup (4 waves up to
+// p = 32, 8 beyond) and read as the B operand (ds_read_b64: the 16 lanes of a k-group read
+// 128 contiguous bytes; SQ_LDS_BANK_CONFLICT = 0).  The K range is split over blockIdx.y so
+// that the launch fills the chip exactly once or a whole number of times (dense_plan); each
+// slice writes a partial slab with plain stores (deterministic, no fp64 atomics).
 // Kernel 2 (row-tiled epilogue): sums the slabs and applies the fused projection.
 #include "msdp_device.h"
 #include <math.h>
@@ -27,8 +27,6 @@
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-#define DENSE_KT 32              // k extent of one LDS panel tile
-#define DENSE_WAVES 4            // waves per workgroup (64 matrix rows)
 
 struct DenseOp {
     const double* M[2];          // n_loc x nS row-major matrices (rows = local rows)
@@ -40,238 +38,45 @@ struct DenseOp {
     int n_loc, ld, ldl;          // rows, panel stride, LDS row stride
     int colofs, ncols;           // column block [colofs, colofs+ncols) of the panel handled by this launch (ncols <= 128)
     int SK;                      // k slices
-    int kslice;                  // k extent per slice (multiple of DENSE_KT) over the concatenated K = nmat*nS
+    int kslice;                  // k extent per slice (multiple of 64) over the concatenated K = nmat*nS
     double* slab;                // SK x n_loc_cap x ld
     int64_t slab_stride;         // doubles between slabs
 };
 
-template <int NT>
-__global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial(DenseOp op, const int* active_flag) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // DENSE_KT x ldl
-    if (active_flag && !*active_flag) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, i = lane & 15;
-    const int row0 = (blockIdx.x * DENSE_WAVES + wave) * 16;
-    const int arow = min(row0 + i, op.n_loc - 1);            // clamp: pad rows are never stored
-    const int64_t Ktot = (int64_t)op.nmat * op.nS;
-    const int64_t kbeg = (int64_t)blockIdx.y * op.kslice;
-    int64_t kend = kbeg + op.kslice;
-    if (kend > Ktot) kend = Ktot;
-    double4_t acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    const int ld = op.ld, ldl = op.ldl;
-    const int half = op.ncols >> 1;                            // double2 per panel row of this column block
-    for (int64_t k0 = kbeg; k0 < kend; k0 += DENSE_KT) {
-        // which matrix does this tile belong to (tiles never straddle: nS % DENSE_KT == 0 is not
-        // required, only nS % 16 == 0, so resolve per 16-k step below; the panel tile is staged per step pair)
-        __syncthreads();
-        // stage panel tile rows k0 .. k0+KT-1 (concatenated K index -> matrix m, local k)
-        for (int e = threadIdx.x; e < DENSE_KT * half; e += DENSE_WAVES * 64) {
-            const int r = e / half, c2 = e - r * half;
-            const int64_t kk = k0 + r;
-            double2 v = make_double2(0.0, 0.0);
-            if (kk < kend) {
-                const int m = (kk >= op.nS) ? 1 : 0;
-                const int64_t kl = kk - (int64_t)m * op.nS;
-                if (kl < op.n) v = ld2(op.X[m] + kl * ld + op.colofs + 2 * c2);
-            }
-            *reinterpret_cast<double2*>(&lds[r * ldl + 2 * c2]) = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < DENSE_KT / 16; ++s) {
-            const int64_t ks = k0 + 16 * s;
-            if (ks >= kend) break;
-            const int m = (ks >= op.nS) ? 1 : 0;               // a 16-step never straddles (nS % 16 == 0)
-            const int64_t kl = ks - (int64_t)m * op.nS;
-            const double* ap = op.M[m] + (int64_t)arow * op.nS + kl + 4 * g;
-            const double2 a01 = ld2(ap), a23 = ld2(ap + 2);
-            const double sc = op.scale[m];
-            const double a[4] = {a01.x * sc, a01.y * sc, a23.x * sc, a23.y * sc};
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const double* brow = &lds[(16 * s + 4 * g + t4) * ldl + i];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const double b = (16 * t + i < op.ncols) ? brow[16 * t] : 0.0;
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t4], b, acc[t], 0, 0, 0);
-                }
-            }
-        }
-    }
-    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
-    double* out = op.slab + (int64_t)blockIdx.y * op.slab_stride;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int col = 16 * t + i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + g + 4 * r;
-            if (row < op.n_loc && col < op.ncols) out[(int64_t)row * ld + op.colofs + col] = acc[t][r];
-        }
-    }
-}
-
-// Software-pipelined variant: KT2 = 64 k per LDS tile, two LDS buffers, one barrier per tile, and TWO
-// statically named register sets (A fragments + staged panel rows) used alternately by a 2x unrolled tile
-// loop: hipcc can then count the outstanding loads exactly (s_waitcnt vmcnt(N), not vmcnt(0)), so the loads
-// of tile t+1 stay in flight under the 16*NT MFMAs of tile t.  The B operands of one k-quad (NT ds_read_b64)
-// are all requested before the first MFMA that needs them; the LDS tile is zero-padded to 16*NT columns so
-// the inner loop has no column predicate.
-#define DENSE_KT2 64
-template <int NT>
-struct DenseRegs {
-    double2 a[DENSE_KT2 / 16][2];
-    double sc[DENSE_KT2 / 16];
-    double2 stg[2 * NT];
-};
-
-template <int NT>
-__global__ __launch_bounds__(DENSE_WAVES * 64) void k_dense_partial2(DenseOp op, const int* active_flag) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // 2 x DENSE_KT2 x ldl
-    if (active_flag && !*active_flag) return;
-    constexpr int NTHR = DENSE_WAVES * 64;
-    constexpr int SS = DENSE_KT2 / 16;
-    constexpr int MAXS = 2 * NT;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, i = lane & 15;
-    const int row0 = (blockIdx.x * DENSE_WAVES + wave) * 16;
-    const int arow = min(row0 + i, op.n_loc - 1);
-    const int64_t Ktot = (int64_t)op.nmat * op.nS;
-    const int64_t kbeg = (int64_t)blockIdx.y * op.kslice;
-    int64_t kend = kbeg + op.kslice;
-    if (kend > Ktot) kend = Ktot;
-    const int ld = op.ld, ldl = op.ldl, half = op.ncols >> 1;
-    const int tile_elems = DENSE_KT2 * half;
-    // zero both LDS tiles once: pad columns [ld, ldl) are never written again
-    for (int e = threadIdx.x; e < 2 * DENSE_KT2 * ldl; e += NTHR) lds[e] = 0.0;
-    // per-thread staging slots (independent of the tile): panel row r, global offset r*ld + 2*c2, LDS offset
-    int srow[MAXS], sg[MAXS], sl[MAXS];
-#pragma unroll
-    for (int q = 0; q < MAXS; ++q) {
-        const int e = threadIdx.x + q * NTHR;
-        const int r = (e < tile_elems) ? e / half : -1;
-        const int c2 = (e < tile_elems) ? e - r * half : 0;
-        srow[q] = r; sg[q] = r * ld + op.colofs + 2 * c2; sl[q] = r * ldl + 2 * c2;
-    }
-    double4_t acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    const double* arow_p[2] = {op.M[0] + (int64_t)arow * op.nS + 4 * g, op.M[1] + (int64_t)arow * op.nS + 4 * g};
-
-    // Branch-free: every call issues exactly 2*SS + MAXS loads (out-of-range pieces read a valid dummy
-    // address and are zeroed by a select), so hipcc can count the loads in flight across the loop.
-    auto load_tile = [&](int64_t k0, DenseRegs<NT>& R) {
-#pragma unroll
-        for (int s = 0; s < SS; ++s) {
-            const int64_t ks = k0 + 16 * s;
-            const bool ok = ks < kend;
-            const int64_t kc = ok ? ks : kbeg;
-            const int m = (kc >= op.nS) ? 1 : 0;
-            const double* ap = arow_p[m] + (kc - (int64_t)m * op.nS);
-            R.a[s][0] = ld2(ap); R.a[s][1] = ld2(ap + 2);
-            R.sc[s] = ok ? op.scale[m] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < MAXS; ++q) {
-            const int64_t kk = k0 + (srow[q] >= 0 ? srow[q] : 0);
-            const bool inr = srow[q] >= 0 && kk < kend;
-            const int64_t kc = inr ? kk : kbeg;
-            const int m = (kc >= op.nS) ? 1 : 0;
-            const int64_t kl = kc - (int64_t)m * op.nS;
-            const bool ok = inr && kl < op.n;
-            const double2 v = ld2(op.X[m] + (ok ? kl * ld + (sg[q] - srow[q] * ld) : 0));
-            R.stg[q] = ok ? v : make_double2(0.0, 0.0);
-        }
-    };
-    auto store_tile = [&](double* buf, const DenseRegs<NT>& R) {
-#pragma unroll
-        for (int q = 0; q < MAXS; ++q)
-            if (srow[q] >= 0) *reinterpret_cast<double2*>(&buf[sl[q]]) = R.stg[q];
-    };
-    auto compute_tile = [&](const double* bt, const DenseRegs<NT>& R) {
-#pragma unroll
-        for (int s = 0; s < SS; ++s) {
-            const double sc = R.sc[s];
-            const double av[4] = {R.a[s][0].x * sc, R.a[s][0].y * sc, R.a[s][1].x * sc, R.a[s][1].y * sc};
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const double* brow = &bt[(16 * s + 4 * g + t4) * ldl + i];
-                double bv[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bv[t] = brow[16 * t];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t4], bv[t], acc[t], 0, 0, 0);
-            }
-        }
-    };
-
-    double* buf0 = lds;
-    double* buf1 = lds + DENSE_KT2 * ldl;
-    DenseRegs<NT> R0, R1;
-    __syncthreads();                                           // zero fill done
-    load_tile(kbeg, R0);
-    store_tile(buf0, R0);
-    for (int64_t k0 = kbeg; k0 < kend; k0 += 2 * DENSE_KT2) {
-        // ---- even tile: data in (buf0, R0); prefetch the odd tile into R1
-        __syncthreads();
-        const int64_t k1 = k0 + DENSE_KT2;
-        const bool has1 = k1 < kend;
-        load_tile(k1, R1);
-        compute_tile(buf0, R0);
-        if (!has1) break;
-        store_tile(buf1, R1);
-        // ---- odd tile: data in (buf1, R1); prefetch the next even tile into R0
-        __syncthreads();
-        const int64_t k2 = k1 + DENSE_KT2;
-        const bool has2 = k2 < kend;
-        load_tile(k2, R0);
-        compute_tile(buf1, R1);
-        if (!has2) break;
-        store_tile(buf0, R0);
-    }
-    double* out = op.slab + (int64_t)blockIdx.y * op.slab_stride;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int col = 16 * t + i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + g + 4 * r;
-            if (row < op.n_loc && col < op.ncols) out[(int64_t)row * ld + op.colofs + col] = acc[t][r];
-        }
-    }
-}
-
-// Third structure (default): the same data flow as k_dense_partial2 with a register budget that lets 3-4 waves
-// share a SIMD (partial2 needs 200-256 VGPRs: 1-2 waves, so every barrier and every LDS round trip idles the matrix
-// pipe; a pure-MFMA loop measures 72 TFLOP/s on this chip, partial2 reaches 26-35).
-//   * two statically named fragment sets (tile in work / next tile, 8 VGPRs per 16 k each) so that hipcc emits
-//     counted vmcnt(N) waits, but only ONE staging set for the panel tile, filled at the top of a tile and written
-//     to the other LDS buffer at its end (a single fragment ring refilled step by step was tried: hipcc sinks the
-//     refills below the last MFMA of the tile, and pinning them with sched_barrier costs a second register set anyway);
-//   * the staging decomposition (thread -> column pair, row) needs no per-thread tables: HP = pow2 >= ncols/2 lanes
-//     cover a panel row, 256/HP rows per pass;
-//   * the scale of a k-step is a wave-uniform scalar computed where it is used;
-//   * KT = 64 for p <= 32, 32 beyond (LDS: four workgroups per CU up to p = 64).
+// What shaped the kernel (all measured on MI355X, tools/dense_sweep.sh; a pure-MFMA loop reaches 72 TFLOP/s,
+// tools/microbench_mfma64.hip):
+//   * registers first: an earlier version with two fragment sets AND two staging sets and per-thread staging tables
+//     needed 200-256 VGPRs = 1-2 waves per SIMD, so every barrier and LDS round trip idled the matrix pipe (26-35 TF).
+//     Now: two statically named fragment sets (tile in work / next tile, 8 VGPRs per 16 k each; static names let
+//     hipcc emit counted vmcnt(N) waits), ONE staging set, no tables (HP = pow2 >= ncols/2 lanes cover a panel row,
+//     WAVES*64/HP rows per pass), the scale of a k-step as a wave-uniform scalar where it is used, KT = 32 beyond
+//     p = 16: 112-128 VGPRs = 4 waves per SIMD;
+//   * hipcc's occupancy-driven scheduler sinks prefetch loads next to their use whenever it can: the loop body has
+//     no exits and no conditional stores, and beyond p = 32 a sched_barrier closes the prefetch block of each tile
+//     (load_stg below describes the two forms);
+//   * a single fragment ring refilled step by step was tried: the refills were sunk below the last MFMA of the tile,
+//     and pinning them cost a second register set anyway.
 template <int NT> struct Dense3Cfg {
     static constexpr int KT = NT <= 1 ? 64 : 32;
     static constexpr int HP = NT == 1 ? 8 : (NT == 2 ? 16 : (NT <= 4 ? 32 : 64));
-    static constexpr int RPP = DENSE_WAVES * 64 / HP;          // panel rows staged per pass
+    static constexpr int WAVES = NT <= 2 ? 4 : 8;              // 16 matrix rows each (8 waves beyond p = 32: the panel tile
+                                                               // is shared by twice the rows: +6..14 % there, -3 % at p <= 32)
+    static constexpr int RPP = WAVES * 64 / HP;                // panel rows staged per pass
     static constexpr int NPASS = KT / RPP;
     static constexpr int SS = KT / 16;
+    static constexpr bool PIN = NT >= 3;                       // keep the prefetch block of a tile in place (see below)
 };
 
 template <int NT>
-__global__ __launch_bounds__(DENSE_WAVES * 64, (NT <= 4 ? 3 : 1)) void k_dense_partial3(DenseOp op, const int* active_flag) {
+__global__ __launch_bounds__(Dense3Cfg<NT>::WAVES * 64, (NT <= 4 ? 3 : 1)) void k_dense_partial3(DenseOp op, const int* active_flag) {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // 2 x KT x ldl + 128 (dummy slots)
     if (active_flag && !*active_flag) return;
     typedef Dense3Cfg<NT> Cfg;
     constexpr int KT = Cfg::KT, HP = Cfg::HP, RPP = Cfg::RPP, NPASS = Cfg::NPASS, SS = Cfg::SS;
-    constexpr int NTHR = DENSE_WAVES * 64;
+    constexpr int NTHR = Cfg::WAVES * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
-    const int row0 = (blockIdx.x * DENSE_WAVES + wave) * 16;
+    const int row0 = (blockIdx.x * Cfg::WAVES + wave) * 16;
     const int arow = min(row0 + i, op.n_loc - 1);
     const int nS = op.nS;
     const int Ktot = op.nmat * nS;
@@ -300,16 +105,31 @@ __global__ __launch_bounds__(DENSE_WAVES * 64, (NT <= 4 ? 3 : 1)) void k_dense_p
             A[s][0] = ld2(ap); A[s][1] = ld2(ap + 2);
         }
     };
+    // Rows outside the slice or in the pad range [n, nS) contribute nothing: the matching matrix entries are exact
+    // zeros (pad columns) or are multiplied by sc = 0 (beyond the slice).  PIN form (p > 32): such rows read panel
+    // row 0 (any finite value will do), the staged value is used as loaded and a sched_barrier keeps the whole
+    // prefetch block at the top of the tile.  Up to p = 32 the kernel is bound by the bytes in flight rather than
+    // by the matrix pipe, and the form below measured best of four (n = 20000, p = 32: 625 us; PIN form 658; neither
+    // select nor pin 656; 32-bit offsets + select 690): hipcc keeps the fragment loads and the first staging load
+    // at the top of the tile and fits 90 VGPRs = 5 waves per SIMD (PIN form: 127 = 4).
     auto load_stg = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < NPASS; ++q) {
             const int kk = k0 + sr0 + q * RPP;
-            const int kc = kk < kend ? kk : kbeg;
-            const int m = kc >= nS ? 1 : 0;
-            const int kl = kc - m * nS;
-            const bool ok = kk < kend && kl < op.n;
-            const double2 v = ld2((m ? op.X[1] : op.X[0]) + (ok ? (int64_t)kl * ld + sgo : 0));
-            stg[q] = ok ? v : make_double2(0.0, 0.0);
+            if constexpr (Cfg::PIN) {
+                const bool inr = kk < kend;
+                const int m = (inr && kk >= nS) ? 1 : 0;
+                int kl = kk - m * nS;
+                kl = (inr && kl < op.n) ? kl : 0;
+                stg[q] = ld2((m ? op.X[1] : op.X[0]) + (unsigned)(kl * ld + sgo));
+            } else {
+                const int kc = kk < kend ? kk : kbeg;
+                const int m = kc >= nS ? 1 : 0;
+                const int kl = kc - m * nS;
+                const bool ok = kk < kend && kl < op.n;
+                const double2 v = ld2((m ? op.X[1] : op.X[0]) + (ok ? (int64_t)kl * ld + sgo : 0));
+                stg[q] = ok ? v : make_double2(0.0, 0.0);
+            }
         }
     };
     // branch-free (a conditional store lets hipcc sink the staging loads into the branch, next to their use):
@@ -349,11 +169,13 @@ __global__ __launch_bounds__(DENSE_WAVES * 64, (NT <= 4 ? 3 : 1)) void k_dense_p
         __syncthreads();
         load_stg(k0 + KT);                                      // older than the fragment loads: its wait leaves them in flight
         load_a(k0 + KT, A1);
+        if constexpr (Cfg::PIN) __builtin_amdgcn_sched_barrier(0);   // hipcc's occupancy-driven scheduler otherwise sinks the prefetch next to its use
         compute_tile(buf0, k0, A0);
         store_stg(buf1);
         __syncthreads();
         load_stg(k0 + 2 * KT);
         load_a(k0 + 2 * KT, A0);
+        if constexpr (Cfg::PIN) __builtin_amdgcn_sched_barrier(0);
         compute_tile(buf1, k0 + KT, A1);
         store_stg(buf0);
     }
@@ -505,6 +327,7 @@ static dense3_fn_t dense3_fn(int NT) {
     }
 }
 static int dense3_kt(int NT) { return NT <= 1 ? 64 : 32; }
+static int dense3_waves(int NT) { return NT <= 2 ? 4 : 8; }
 static size_t dense3_lds(int NT, int ldl) { return ((size_t)2 * dense3_kt(NT) * ldl + 128) * sizeof(double); }   // two tiles + dummy slots
 static int dense_ldl(int ncols) {
     int ldl = ((ncols + 15) / 16) * 16;                      // zero-padded to 16*NT columns (no column predicate)
@@ -523,7 +346,7 @@ static int dense3_capacity(int NT, int ldl) {
     if (!cap[NT]) {
         int per_cu = 0;
         const size_t shmem = dense3_lds(NT, ldl);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)dense3_fn(NT), DENSE_WAVES * 64, shmem) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)dense3_fn(NT), dense3_waves(NT) * 64, shmem) != hipSuccess || per_cu < 1)
             per_cu = 1;
         cap[NT] = per_cu * cus;
     }
@@ -536,7 +359,8 @@ static int dense3_capacity(int NT, int ldl) {
 static void dense_plan(msdp_handle h, int nmat, int* row_blocks_out, int* SK_out, int64_t* kslice_out) {
     const Dev& d = h->d;
     const int nS = msdp_dense_nS(d.n);
-    const int row_blocks = (d.n_loc + DENSE_WAVES * 16 - 1) / (DENSE_WAVES * 16);
+    const int NT0 = (std::min(128, d.ld) + 15) / 16;         // the plan follows the first column block
+    const int row_blocks = (d.n_loc + dense3_waves(NT0) * 16 - 1) / (dense3_waves(NT0) * 16);
     const int64_t Ktot = (int64_t)nmat * nS;
     static int target = -2;
     if (target == -2) { const char* e = getenv("MSDP_DENSE_BLOCKS"); target = e ? atoi(e) : -1; }
@@ -544,7 +368,7 @@ static void dense_plan(msdp_handle h, int nmat, int* row_blocks_out, int* SK_out
     int64_t kslice;
     if (target > 0) {                                         // experiment: fixed workgroup target, 64-k granularity
         SK = (target + row_blocks - 1) / row_blocks;
-        const int maxSK = (int)((Ktot + 4 * DENSE_KT - 1) / (4 * DENSE_KT));
+        const int maxSK = (int)((Ktot + 127) / 128);
         if (SK > maxSK) SK = maxSK;
         if (SK > 32) SK = 32;
         if (SK < 1) SK = 1;
@@ -605,9 +429,6 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
     int rc = ensure_slab(h, (size_t)SK * op.slab_stride);
     if (rc) return rc;
     op.slab = h->slab;
-    static int v1 = -1, v2 = -1;
-    if (v1 < 0) { const char* e = getenv("MSDP_DENSE_V1"); v1 = (e && atoi(e)) ? 1 : 0; }
-    if (v2 < 0) { const char* e = getenv("MSDP_DENSE_V2"); v2 = (e && atoi(e)) ? 1 : 0; }
     // p > 128: column blocks of 128 (the matrix is re-streamed once per block; NT <= 8 accumulator tiles per wave)
     for (int colofs = 0; colofs < d.ld; colofs += 128) {
         op.colofs = colofs;
@@ -615,39 +436,9 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
         const int ldl = dense_ldl(op.ncols);
         op.ldl = ldl;
         const int NT = (op.ncols + 15) / 16;
-        dim3 grid(row_blocks, SK), block(DENSE_WAVES * 64);
-        if (v1) {
-            const size_t shmem = (size_t)DENSE_KT * ldl * sizeof(double);
-            switch (NT) {
-                case 1: hipLaunchKernelGGL((k_dense_partial<1>), grid, block, shmem, h->stream, op, active_flag); break;
-                case 2: hipLaunchKernelGGL((k_dense_partial<2>), grid, block, shmem, h->stream, op, active_flag); break;
-                case 3: hipLaunchKernelGGL((k_dense_partial<3>), grid, block, shmem, h->stream, op, active_flag); break;
-                case 4: hipLaunchKernelGGL((k_dense_partial<4>), grid, block, shmem, h->stream, op, active_flag); break;
-                case 5: hipLaunchKernelGGL((k_dense_partial<5>), grid, block, shmem, h->stream, op, active_flag); break;
-                case 6: hipLaunchKernelGGL((k_dense_partial<6>), grid, block, shmem, h->stream, op, active_flag); break;
-                case 7: hipLaunchKernelGGL((k_dense_partial<7>), grid, block, shmem, h->stream, op, active_flag); break;
-                default: hipLaunchKernelGGL((k_dense_partial<8>), grid, block, shmem, h->stream, op, active_flag); break;
-            }
-        } else if (!v2) {
-#define DENSE3_CASE(N) case N: hipLaunchKernelGGL((k_dense_partial3<N>), grid, block, dense3_lds(N, ldl), h->stream, op, active_flag); break;
-            switch (NT) {
-                DENSE3_CASE(1) DENSE3_CASE(2) DENSE3_CASE(3) DENSE3_CASE(4) DENSE3_CASE(5) DENSE3_CASE(6) DENSE3_CASE(7)
-                default: hipLaunchKernelGGL((k_dense_partial3<8>), grid, block, dense3_lds(8, ldl), h->stream, op, active_flag); break;
-            }
-#undef DENSE3_CASE
-        } else {
-            const size_t shmem = (size_t)2 * DENSE_KT2 * ldl * sizeof(double);
-            switch (NT) {
-                case 1: hipLaunchKernelGGL((k_dense_partial2<1>), grid, block, shmem, h->stream, op, active_flag); break;
-                case 2: hipLaunchKernelGGL((k_dense_partial2<2>), grid, block, shmem, h->stream, op, active_flag); break;
-                case 3: hipLaunchKernelGGL((k_dense_partial2<3>), grid, block, shmem, h->stream, op, active_flag); break;
-                case 4: hipLaunchKernelGGL((k_dense_partial2<4>), grid, block, shmem, h->stream, op, active_flag); break;
-                case 5: hipLaunchKernelGGL((k_dense_partial2<5>), grid, block, shmem, h->stream, op, active_flag); break;
-                case 6: hipLaunchKernelGGL((k_dense_partial2<6>), grid, block, shmem, h->stream, op, active_flag); break;
-                case 7: hipLaunchKernelGGL((k_dense_partial2<7>), grid, block, shmem, h->stream, op, active_flag); break;
-                default: hipLaunchKernelGGL((k_dense_partial2<8>), grid, block, shmem, h->stream, op, active_flag); break;
-            }
-        }
+        const int rows_wg = dense3_waves(NT) * 16;
+        dim3 grid((d.n_loc + rows_wg - 1) / rows_wg, SK), block(dense3_waves(NT) * 64);
+        hipLaunchKernelGGL(dense3_fn(NT), grid, block, dense3_lds(NT, ldl), h->stream, op, active_flag);
     }
     HIPCHK(hipGetLastError());
     *slab_out = h->slab;
