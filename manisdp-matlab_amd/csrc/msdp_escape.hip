@@ -42,19 +42,30 @@ __global__ void k_sv_sparse(int n, const int* __restrict__ rp, const int* __rest
         w[i] = acc - z[i] * v[i];
     }
 }
-// dense C (n x nS row-major): one wave per row
+// dense C (n x nS row-major, zero pad columns, nS % 16 == 0): one wave per row, four 1-KB pieces of the row in
+// flight per lane (a single dependent accumulator chain left the loads of one piece at a time: 45 us per
+// 200-MB product at n = 5000)
 __global__ __launch_bounds__(256) void k_sv_dense(int n, int nS, const double* __restrict__ Cd, const double* __restrict__ z,
                                                    const double* __restrict__ v, double* __restrict__ w) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const double* cr = Cd + (int64_t)row * nS;
-    double acc = 0.0;
-    for (int j = 2 * lane; j < n; j += 128) {
-        const double2 c2 = ld2(cr + j);
-        acc += c2.x * v[j] + ((j + 1 < n) ? c2.y * v[j + 1] : 0.0);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int j = 2 * lane;
+    for (; j + 384 < n - 1; j += 512) {                          // all four pieces fully inside [0, n)
+        const double2 c0 = ld2(cr + j), c1 = ld2(cr + j + 128), c2 = ld2(cr + j + 256), c3 = ld2(cr + j + 384);
+        // v may sit at an odd multiple of 8 bytes inside the workspace: 8-byte loads
+        a0 = fma(c0.x, v[j], fma(c0.y, v[j + 1], a0));
+        a1 = fma(c1.x, v[j + 128], fma(c1.y, v[j + 129], a1));
+        a2 = fma(c2.x, v[j + 256], fma(c2.y, v[j + 257], a2));
+        a3 = fma(c3.x, v[j + 384], fma(c3.y, v[j + 385], a3));
     }
-    acc = msdp_wave_sum(acc);
+    for (; j < n; j += 128) {
+        const double2 c2 = ld2(cr + j);
+        a0 += c2.x * v[j] + ((j + 1 < n) ? c2.y * v[j + 1] : 0.0);
+    }
+    const double acc = msdp_wave_sum((a0 + a1) + (a2 + a3));
     if (lane == 0) w[row] = acc - (z ? z[row] * v[row] : 0.0);
 }
 // h[c] = <B_c, w>, c = 0..nb-1 (columns contiguous, stride ldb): one workgroup per column
@@ -225,6 +236,93 @@ __global__ void k_normalize_to(int n, const double* __restrict__ w, const double
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = w[i] * inv;
 }
 
+// One Lanczos step after w = S*v for vectors that fit one workgroup's LDS (n <= LZS_MAXN): alpha = <w,v>,
+// w -= alpha*v + beta*vprev, one classical Gram-Schmidt pass against the nq deflation columns, beta' = |w|,
+// vnext = w/beta'.  Replaces k_dot1, k_lanczos_update, k_multidot, k_multiaxpy, k_dot1, k_normalize_to: at
+// n = 5000 each of those is a ~4.7 us launch for 40 KB of data (28 of the 57 us of a dense-S step, rocprofv3).
+#define LZS_THREADS 1024
+#define LZS_MAXN 16384
+#define LZS_MAXQ 128
+__device__ __forceinline__ double lzs_block_sum(double v, double* red) {
+    v = msdp_wave_sum(v);
+    __syncthreads();                                   // red may still be read by the previous reduction
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < LZS_THREADS / 64; ++k) s += red[k];
+    return s;
+}
+template <int R>
+__global__ __launch_bounds__(LZS_THREADS) void k_lz_step_small(int n, double* __restrict__ w, const double* __restrict__ v,
+                                                               const double* __restrict__ vprev, const double* __restrict__ beta_in,
+                                                               const double* __restrict__ Q, int nq,
+                                                               double* __restrict__ alpha_out, double* __restrict__ beta_out,
+                                                               double* __restrict__ vnext) {
+    extern __shared__ double ws[];                     // n (used only with deflation columns)
+    __shared__ double red[LZS_THREADS / 64];
+    __shared__ double hq[LZS_MAXQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // each thread keeps its R elements of w in registers; all loads of a phase are issued together
+    double wr[R], vr[R], pr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + r * LZS_THREADS;
+        const bool ok = i < n;
+        const int ic = ok ? i : 0;
+        const double a = w[ic], bq = v[ic], cq = vprev ? vprev[ic] : 0.0;
+        wr[r] = ok ? a : 0.0; vr[r] = ok ? bq : 0.0; pr[r] = ok ? cq : 0.0;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc = fma(wr[r], vr[r], acc);
+    const double alpha = lzs_block_sum(acc, red);
+    const double b = (vprev && beta_in) ? *beta_in : 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) wr[r] = wr[r] - alpha * vr[r] - b * pr[r];
+    if (nq > 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const int i = tid + r * LZS_THREADS; if (i < n) ws[i] = wr[r]; }
+        __syncthreads();
+        for (int c0 = 0; c0 < nq; c0 += LZS_MAXQ) {    // deflation columns in groups of LZS_MAXQ, one wave per column
+            const int nc = min(LZS_MAXQ, nq - c0);
+            for (int c = wave; c < nc; c += LZS_THREADS / 64) {
+                const double* qc = Q + (int64_t)(c0 + c) * n;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                int i = lane;
+                for (; i + 192 < n; i += 256) {
+                    a0 = fma(qc[i], ws[i], a0); a1 = fma(qc[i + 64], ws[i + 64], a1);
+                    a2 = fma(qc[i + 128], ws[i + 128], a2); a3 = fma(qc[i + 192], ws[i + 192], a3);
+                }
+                for (; i < n; i += 64) a0 = fma(qc[i], ws[i], a0);
+                const double a = msdp_wave_sum((a0 + a1) + (a2 + a3));
+                if (lane == 0) hq[c] = a;
+            }
+            __syncthreads();
+            for (int c = 0; c < nc; ++c) {
+                const double hc = hq[c];
+                const double* qc = Q + (int64_t)(c0 + c) * n;
+#pragma unroll
+                for (int r = 0; r < R; ++r) { const int i = tid + r * LZS_THREADS; wr[r] -= hc * qc[i < n ? i : 0]; }
+            }
+            if (c0 + LZS_MAXQ < nq) {                  // another group follows: it needs the updated vector in LDS
+#pragma unroll
+                for (int r = 0; r < R; ++r) { const int i = tid + r * LZS_THREADS; if (i < n) ws[i] = wr[r]; }
+            }
+            __syncthreads();
+        }
+    }
+    acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int i = tid + r * LZS_THREADS; acc = fma(i < n ? wr[r] : 0.0, wr[r], acc); }
+    const double nn = lzs_block_sum(acc, red);
+    const double beta = sqrt(nn > 0.0 ? nn : 0.0);
+    const double inv = beta > 0.0 ? 1.0 / beta : 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int i = tid + r * LZS_THREADS; if (i < n) { w[i] = wr[r]; vnext[i] = wr[r] * inv; } }
+    if (tid == 0) { *alpha_out = alpha; *beta_out = beta; }
+}
+
 struct EscCtx {
     msdp_handle h;
     int n;
@@ -309,6 +407,17 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
     int m = 0, next_check = 32;
     double theta = 0.0, res = 1e300, lmax = 0.0;
     const bool persist = !c.M && c.slots && msdp_lanczos_persist_ok(h, nq);
+    static int no_fused_small = -1;
+    if (no_fused_small < 0) { const char* e = getenv("MSDP_LZ_NO_FUSED"); no_fused_small = (e && atoi(e)) ? 1 : 0; }
+    const bool fused_small = !persist && !no_fused_small && n <= LZS_MAXN;
+    if (fused_small) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_lz_step_small<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * LZS_THREADS * (int)sizeof(double)));
+            HIPCHK(hipFuncSetAttribute((const void*)k_lz_step_small<16>, hipFuncAttributeMaxDynamicSharedMemorySize, LZS_MAXN * (int)sizeof(double)));
+            attr_set = true;
+        }
+    }
     while (m < maxit) {
         if (persist) {
             // all steps up to the next checkpoint in one launch (msdp_lanczos.hip)
@@ -318,6 +427,18 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
         } else {
         double* vj = V + (size_t)m * n;
         if ((rc = sapply(c, vj, w))) return rc;
+        if (fused_small) {
+            const size_t lds = nq > 0 ? (size_t)n * sizeof(double) : 0;
+            const double* vp = m > 0 ? (const double*)(vj - n) : (const double*)nullptr;
+            const double* bp = m > 0 ? (const double*)(dbeta + m) : (const double*)nullptr;
+            if (n <= 4 * LZS_THREADS)
+                hipLaunchKernelGGL(k_lz_step_small<4>, dim3(1), dim3(LZS_THREADS), lds, h->stream, n, w, (const double*)vj, vp, bp, Q, nq, dalpha + m, dbeta + m + 1, vj + n);
+            else if (n <= 8 * LZS_THREADS)
+                hipLaunchKernelGGL(k_lz_step_small<8>, dim3(1), dim3(LZS_THREADS), lds, h->stream, n, w, (const double*)vj, vp, bp, Q, nq, dalpha + m, dbeta + m + 1, vj + n);
+            else
+                hipLaunchKernelGGL(k_lz_step_small<16>, dim3(1), dim3(LZS_THREADS), lds, h->stream, n, w, (const double*)vj, vp, bp, Q, nq, dalpha + m, dbeta + m + 1, vj + n);
+            HIPCHK(hipGetLastError());
+        } else {
         hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, n, w, vj, dalpha + m, 0);
         hipLaunchKernelGGL(k_lanczos_update, gr, bl, 0, h->stream, n, w, vj, m > 0 ? vj - n : (const double*)nullptr,
                            dalpha + m, m > 0 ? dbeta + m : (const double*)nullptr);
@@ -326,6 +447,7 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
         hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, n, w, w, dbeta + m + 1, 1);
         hipLaunchKernelGGL(k_normalize_to, gr, bl, 0, h->stream, n, w, dbeta + m + 1, vj + n);
         HIPCHK(hipGetLastError());
+        }
         ++m;
         }
         if (m == next_check || m == maxit) {
