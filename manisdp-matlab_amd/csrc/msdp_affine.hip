@@ -102,6 +102,92 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm_finish(AffineDev a, int mo
     if (mode == 1) msdp_put_partial(P, P_AUX, pss, sh);
 }
 
+// fp64-MFMA version of k_gram (default): W = Ya * Yb' as 64 x 64 tiles, four waves per tile in a 2 x 2 arrangement,
+// each wave 32 x 32 = 2 x 2 accumulator tiles of v_mfma_f64_16x16x4_f64.  Both operands are rows of a thin panel with k
+// contiguous, so they are staged the same way (64 rows x 32 k per panel, row stride 36 doubles: the 16 rows of a
+// fragment read start on distinct 32-byte bank groups) and read as fragments of 4 contiguous k per lane (two
+// ds_read_b128), which feed four MFMAs -- the k order inside a 16-k step is permuted identically for A and B.
+// In the BQP d = 60 solve the factor grows to p = 300 and the VALU kernel above was the largest single kernel of the
+// RTR phase (228 us = 8.8 TFLOP/s at p = 300).  Prefetching the next tile's panel pieces into registers under the
+// MFMAs was measured: 124 instead of 92 VGPRs (3 instead of 4 waves per SIMD) and 3 % slower.
+typedef double gram_d4 __attribute__((ext_vector_type(4)));
+#define GRAM_KT 32
+#define GRAM_LDS (GRAM_KT + 4)
+__global__ __launch_bounds__(256) void k_gram_mfma(int n, int nS, int ld, const double* __restrict__ Ya,
+                                                   const double* __restrict__ Yb, double* __restrict__ W,
+                                                   const int* skip_flag, int skip_when) {
+    __shared__ __attribute__((aligned(16))) double As[64 * GRAM_LDS];
+    __shared__ __attribute__((aligned(16))) double Bs[64 * GRAM_LDS];
+    if (skip_flag && *skip_flag == skip_when) return;
+    const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int wr = wave >> 1, wc = wave & 1;
+    gram_d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (gram_d4){0.0, 0.0, 0.0, 0.0};
+    // staging: thread -> (row = tid / 16 + 16 * q, column pair = tid % 16), q = 0..3, both panels
+    const int sr = threadIdx.x >> 4, sc = 2 * (threadIdx.x & 15);
+    for (int k0 = 0; k0 < ld; k0 += GRAM_KT) {
+        double2 ra[4], rb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = sr + 16 * q;
+            const bool ck = k0 + sc < ld;                           // ld is even: a pair is in or out as a whole
+            const bool oa = ck && ti + r < n, ob = ck && tj + r < n;
+            const double2 va = ld2(Ya + (oa ? (int64_t)(ti + r) * ld + k0 + sc : 0));
+            const double2 vb = ld2(Yb + (ob ? (int64_t)(tj + r) * ld + k0 + sc : 0));
+            ra[q] = oa ? va : make_double2(0.0, 0.0);
+            rb[q] = ob ? vb : make_double2(0.0, 0.0);
+        }
+        __syncthreads();                                            // previous tile's fragment reads are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = sr + 16 * q;
+            *reinterpret_cast<double2*>(&As[r * GRAM_LDS + sc]) = ra[q];
+            *reinterpret_cast<double2*>(&Bs[r * GRAM_LDS + sc]) = rb[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < GRAM_KT / 16; ++s) {
+            double2 fa[2][2], fb[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const double* pa = &As[(wr * 32 + 16 * a + i) * GRAM_LDS + 16 * s + 4 * g];
+                const double* pb = &Bs[(wc * 32 + 16 * a + i) * GRAM_LDS + 16 * s + 4 * g];
+                fa[a][0] = *reinterpret_cast<const double2*>(pa); fa[a][1] = *reinterpret_cast<const double2*>(pa + 2);
+                fb[a][0] = *reinterpret_cast<const double2*>(pb); fb[a][1] = *reinterpret_cast<const double2*>(pb + 2);
+            }
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const double av = (t4 == 0) ? fa[a][0].x : (t4 == 1) ? fa[a][0].y : (t4 == 2) ? fa[a][1].x : fa[a][1].y;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const double bv = (t4 == 0) ? fb[b][0].x : (t4 == 1) ? fb[b][0].y : (t4 == 2) ? fb[b][1].x : fb[b][1].y;
+                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[a][b], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = tj + wc * 32 + 16 * b + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ti + wr * 32 + 16 * a + g + 4 * r;
+                if (row < n && col < nS) W[(int64_t)row * nS + col] = acc[a][b][r];
+            }
+        }
+}
+
 // ---- Gram route for A(Ya Yb'): when At is dense in its rows (BQP moment relaxations: 4.8 M nonzeros for an
 // 1831 x 1831 matrix) the SDDMM above gathers two p-wide rows per nonzero (2.5 GB of L2 traffic at p = 32,
 // measured 154 us); forming W = Ya*Yb' once (n^2 p flops, 27 MB) and gathering ONE double per nonzero is what
@@ -498,11 +584,8 @@ static int sddmm_grid(const AffineDev& a, int ld) {
 // A(Ya Yb') -> item values.  SDDMM (gathers 2 p-wide rows per nonzero) or the Gram route (dense W = Ya*Yb' once,
 // one double per nonzero), whichever moves fewer bytes; MSDP_AFFINE_ROUTE=sddmm|gram overrides.
 static bool use_gram_route(const AffineDev& a, int64_t nnz, int ld) {
-    static int force = -1;
-    if (force < 0) {
-        const char* e = getenv("MSDP_AFFINE_ROUTE");
-        force = !e ? 0 : (!strcmp(e, "gram") ? 2 : (!strcmp(e, "sddmm") ? 1 : 0));
-    }
+    const char* e = getenv("MSDP_AFFINE_ROUTE");              // read on every call: the tests switch it
+    const int force = !e ? 0 : (!strcmp(e, "gram") ? 2 : (!strcmp(e, "sddmm") ? 1 : 0));
     if (force) return force == 2;
     const double sddmm_bytes = (double)nnz * ld * 16.0;
     const double gram_bytes = 2.0 * a.n * (double)a.nS * 8.0 + (double)nnz * 20.0;
@@ -511,7 +594,10 @@ static bool use_gram_route(const AffineDev& a, int64_t nnz, int ld) {
 static int launch_aop(msdp_handle h, const AffineDev& a, int64_t nnz, const double* Ya, const double* Yb, const int* flag, int when) {
     if (use_gram_route(a, nnz, a.ld)) {
         dim3 grid((a.nS + 63) / 64, (a.n + 63) / 64);
-        hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, h->stream, a.n, a.nS, a.ld, Ya, Yb, a.W, flag, when);
+        const char* ev = getenv("MSDP_GRAM_VALU");
+        const bool valu = ev && atoi(ev);
+        if (valu) hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, h->stream, a.n, a.nS, a.ld, Ya, Yb, a.W, flag, when);
+        else hipLaunchKernelGGL(k_gram_mfma, grid, dim3(256), 0, h->stream, a.n, a.nS, a.ld, Ya, Yb, a.W, flag, when);
         HIPCHK(hipGetLastError());
         int64_t g = (a.nitems + 255) / 256;
         if (g > 16384) g = 16384;

@@ -62,6 +62,38 @@ def test_unitdiag_operators(lib, case, p):
     h.close()
 
 
+@pytest.mark.parametrize("route", ["gram", "sddmm", "gram-valu"])
+@pytest.mark.parametrize("case,p", [("bqp10", 3), ("bqp20", 32), ("bqp20", 70), ("gpp124-1", 130)])
+def test_unitdiag_operator_routes(lib, monkeypatch, route, case, p):
+    """A(Ya Yb') through each route (SDDMM per nonzero; Gram matrix by fp64 MFMA or by the VALU kernel + gather)
+    against the oracle: the library picks the route by bytes moved, here each one is forced."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R
+    monkeypatch.setenv("MSDP_AFFINE_ROUTE", "gram" if route.startswith("gram") else "sddmm")
+    if route == "gram-valu":
+        monkeypatch.setenv("MSDP_GRAM_VALU", "1")
+    if case.startswith("bqp"):
+        At, b, c, K = _bqp(int(case[3:]))
+    else:
+        At, b, c, K = problems.from_sdpa(golden_path(case + ".dat-s.gz"))
+        c = np.asarray(c.todense()).ravel()
+    n = K["s"]
+    rng = np.random.default_rng(100 + p)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    y = rng.standard_normal(b.size) * 0.1
+    prob = R._UnitDiagProblem(At, np.asarray(b, float), c, n, p)
+    prob.y, prob.sigma = y, 0.8
+    f_ref = prob.cost(Y); G_ref = prob.grad(Y); H_ref = prob.hess(Y, U)
+    h = lib.Handle.affine(lib.KIND_UNITDIAG, At, b, c, n)
+    h.set_multipliers(y, 0.8)
+    h.set_point(Y)
+    assert abs(h.cost() - f_ref) <= 1e-11 * max(1.0, abs(f_ref))
+    assert _relerr(h.rgrad(), G_ref) < 1e-11
+    assert _relerr(h.hessvec(U), H_ref) < 1e-11
+    h.close()
+
+
 @pytest.mark.parametrize("case,p", [("theta1", 1), ("theta1", 6), ("theta2", 20), ("theta1", 131)])
 def test_unittrace_operators(lib, case, p):
     from manisdp_matlab_amd import problems
