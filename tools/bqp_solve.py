@@ -15,7 +15,7 @@ t = time.time(); At, b, c, K = problems.bqpmom(d, Q, e); tg = time.time() - t
 c = np.asarray(c.todense()).ravel(); c = c / np.abs(c).max()
 print("BQP d=%d: n=%d m=%d nnz(At)=%d (generated in %.1f s)" % (d, K["s"], len(b), At.nnz, tg), flush=True)
 t = time.time()
-Y, obj, data = solvers.ManiSDP_unitdiag(At, b, c, K, {}, verbose=False)
+Y, obj, data = solvers.ManiSDP_unitdiag(At, b, c, K, {}, verbose=bool(os.environ.get("BQP_VERBOSE")))
 tt = time.time() - t
 print("solve: obj %.8f eta %.1e status %d iters %d hessvecs %d  %.2f s (rtr %.2f s, eig %.2f s, host AL bookkeeping %.2f s)" % (
     obj, max(data["gap"], data["pinf"], data["dinf"]), data["status"], data["iters"], data["hessvecs"], tt,
