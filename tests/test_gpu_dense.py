@@ -18,7 +18,7 @@ def lib():
     return _lib
 
 
-@pytest.mark.parametrize("n,p", [(64, 2), (100, 3), (257, 16), (500, 31), (1000, 32), (777, 64), (300, 100), (300, 130), (200, 260)])
+@pytest.mark.parametrize("n,p", [(17, 1), (33, 5), (64, 2), (100, 3), (257, 16), (500, 31), (1000, 32), (1000, 48), (777, 64), (150, 80), (300, 100), (300, 130), (200, 260), (2050, 20)])
 def test_dense_operators_match_oracle(lib, n, p):
     from manisdp_matlab_amd import problems
     from oracle import manisdp_ref as R
