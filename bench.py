@@ -235,6 +235,23 @@ def main():
             dense.append({"n": dn, "p": dp, "kernel": "k_dense_partial3 + k_dense_hess_epi_obl", "hessvec_us": msd * 1e3,
                           "TFLOPs_f64": fld / msd / 1e9, "frac_mfma_f64_peak": fld / msd / 1e9 / MFMA_F64_TFLOPS,
                           "GBps": byd / msd / 1e6, "frac_hbm_peak": byd / msd / 1e6 / HBM_PEAK_GBS})
+        # config 5 per-GPU shard: rank 0 of 8 of the n = 100 000 problem (12 500 x 100 000 rows of C = 10 GB, generated on the
+        # device), p = 64; the full direction is supplied locally instead of by the all-gather
+        try:
+            hk = _lib.Handle.dense_synthetic(100000, 0, nranks=8, rank=0, pcap=64)
+            rngk = np.random.default_rng(0)
+            Yk = rngk.standard_normal((100000, 64)); Yk /= np.linalg.norm(Yk, axis=1, keepdims=True)
+            hk.set_point(Yk)
+            hk.debug_set_full_rows(Yk)
+            for _ in range(2):
+                msk, byk, flk = hk.bench_hessvec(50)
+            hk.close()
+            dense.append({"n": 100000, "rows_on_this_gpu": 12500, "p": 64, "shard": "rank 0 of 8 (BASELINE config 5)",
+                          "kernel": "k_dense_partial3 + k_dense_hess_epi_obl", "hessvec_us": msk * 1e3,
+                          "TFLOPs_f64": flk / msk / 1e9, "frac_mfma_f64_peak": flk / msk / 1e9 / MFMA_F64_TFLOPS,
+                          "GBps": byk / msk / 1e6, "frac_hbm_peak": byk / msk / 1e6 / HBM_PEAK_GBS})
+        except Exception as e:  # noqa: BLE001 -- secondary figure
+            dense.append({"n": 100000, "p": 64, "error": "%s: %s" % (type(e).__name__, e)})
         out["dense_mfma"] = dense
     if N > 1 or args.force_comm:
         # BASELINE config 5 next to the headline metric: synthetic dense C generated per shard on the device
