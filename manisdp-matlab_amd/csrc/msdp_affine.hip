@@ -48,6 +48,8 @@ struct AffineDev {
     const double* y;
     double* w;             // A(.) result, length m
     double* Axb[2];        // per slot
+    const int* sup;        // entries r = i*n + j that occur in some constraint (nsup > 0: At touches few entries)
+    int nsup;
 };
 
 #define SDDMM_CHUNK 64
@@ -276,6 +278,24 @@ __global__ void k_adjoint_dense(AffineDev a, const double* __restrict__ base, co
     }
 }
 
+// The same update restricted to the entries that occur in some constraint.  For the SDPLIB-type problems (theta, gpp:
+// m = O(n) constraints of a few entries each) At touches a fraction of a percent of the n^2 entries, and `out` keeps
+// its value everywhere else from one call to the next (eS = C there, AyU = 0 there), so the full sweep above moves
+// 2-3 matrices through HBM to change 55 000 numbers (theta-like n = 5000: 55 us per call, 3 us here).
+__global__ __launch_bounds__(256) void k_adjoint_support(AffineDev a, const double* __restrict__ base, const double* __restrict__ vec,
+                                                         double scale, double* __restrict__ out, const int* skip_flag, int skip_when) {
+    if (skip_flag && *skip_flag == skip_when) return;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < a.nsup; q += gridDim.x * blockDim.x) {
+        const int r = a.sup[q];
+        const int i = r / a.n, j = r - i * a.n;
+        const int64_t e = (int64_t)i * a.nS + j;
+        const int s0 = a.rp[r], s1 = a.rp[r + 1];
+        double acc = 0.0;
+        for (int t = s0; t < s1; ++t) acc = fma(a.rv[t], vec[a.rk[t]], acc);
+        out[e] = (base ? base[e] : 0.0) + scale * acc;
+    }
+}
+
 // rows: t_i = <S_i, Y_i> where S = sum of slabs (S = M*Y); writes optional S to dst and partial sum -> P[which]
 template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_rowdot_slabs(Dev d, const double* __restrict__ Yl, const double* slab,
@@ -496,6 +516,19 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
     if ((rc = up(h, cjc, &a.cjc)) || (rc = up(h, ci, &a.ci)) || (rc = up(h, cj, &a.cj)) || (rc = up(h, cv, &a.cv)) ||
         (rc = up(h, rp, &a.rp)) || (rc = up(h, rk, &a.rk)) || (rc = up(h, rv, &a.rv)) || (rc = up(h, cidx, &a.cidx)))
         return rc;
+    {
+        // entries touched by At; the restricted adjoint is used when they are few (<= 1/8 of the matrix)
+        int64_t ns = 0;
+        for (int64_t r = 0; r < nn; ++r) ns += rp[r + 1] > rp[r];
+        a.sup = nullptr; a.nsup = 0;
+        if (ns > 0 && ns * 8 <= nn && !(getenv("MSDP_ADJ_FULL") && atoi(getenv("MSDP_ADJ_FULL")))) {
+            std::vector<int> sup;
+            sup.reserve((size_t)ns);
+            for (int64_t r = 0; r < nn; ++r) if (rp[r + 1] > rp[r]) sup.push_back((int)r);
+            if ((rc = up(h, sup, &a.sup))) return rc;
+            a.nsup = (int)ns;
+        }
+    }
     std::vector<double> bv(b, b + m);
     if ((rc = up(h, bv, &a.b))) return rc;
     void* p = nullptr;
@@ -518,14 +551,25 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
     for (int s = 0; s < 2; ++s) {
         if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
         d.eS[s] = (double*)p;
-        HIPCHK(hipMemset(d.eS[s], 0, msz));
+        // restricted adjoint: eS = C outside the entries At touches, from the start
+        if (a.nsup > 0) HIPCHK(hipMemcpy(d.eS[s], st->Cdense, msz, hipMemcpyDeviceToDevice));
+        else HIPCHK(hipMemset(d.eS[s], 0, msz));
     }
     if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
     d.AyU = (double*)p;
     HIPCHK(hipMemset(d.AyU, 0, msz));
     // the Gram scratch may share AyU: W is consumed (k_gram_gather) before the adjoint rewrites AyU, and the cost /
-    // line-search calls never touch AyU
+    // line-search calls never touch AyU.  With the restricted adjoint AyU must stay zero outside the entries At
+    // touches, so the Gram scratch and the dual slack of msdp_al_dual get buffers of their own.
     a.W = d.AyU;
+    d.Sdual = d.AyU;
+    if (a.nsup > 0) {
+        if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
+        a.W = (double*)p;
+        if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
+        d.Sdual = (double*)p;
+        HIPCHK(hipMemset(d.Sdual, 0, msz));
+    }
     h->h_ctl->sigma = 1.0;
     return 0;
 }
@@ -618,6 +662,20 @@ static int adjoint_grid(const AffineDev& a) {
     return (int)g;
 }
 
+// out = base + scale * At*vec.  `restricted_ok`: `out` already holds base (or 0) outside the entries At touches.
+static int launch_adjoint(msdp_handle h, const AffineDev& a, const double* base, const double* vec, double scale, double* out,
+                          const int* flag, int when, bool restricted_ok) {
+    if (restricted_ok && a.nsup > 0) {
+        int g = (a.nsup + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(k_adjoint_support, dim3(g), dim3(256), 0, h->stream, a, base, vec, scale, out, flag, when);
+    } else {
+        hipLaunchKernelGGL(k_adjoint_dense, dim3(adjoint_grid(a)), dim3(256), 0, h->stream, a, base, vec, scale, out, flag, when);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // cost + gradient state at Y[slot]:  w = A(YY'), Axb, eS, eS*Y, C*Y  (see header comment)
 int msdp_affine_costgrad(msdp_handle h, int slot) {
     AffineState* st = astate(h);
@@ -631,9 +689,7 @@ int msdp_affine_costgrad(msdp_handle h, int slot) {
     { int rc0 = launch_aop(h, a, st->nnz, Ys, Ys, done, 1); if (rc0) return rc0; }
     hipLaunchKernelGGL(k_sddmm_finish, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, a, 1, a.Axb[slot], sigma, d.P, done, 1);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_adjoint_dense, dim3(adjoint_grid(a)), dim3(256), 0, h->stream, a, d.Cd, a.Axb[slot], sigma,
-                       d.eS[slot], done, 1);
-    HIPCHK(hipGetLastError());
+    { int rca = launch_adjoint(h, a, d.Cd, a.Axb[slot], sigma, d.eS[slot], done, 1, true); if (rca) return rca; }
     // c'x = <C*Y, Y>
     const double* slab; int64_t stride; int SK;
     {
@@ -677,9 +733,7 @@ int msdp_affine_hess(msdp_handle h) {
         hipLaunchKernelGGL(k_sddmm_finish, dim3((int)gf), dim3(MSDP_BLOCK), 0, h->stream, a, 0, (double*)nullptr, sigma, d.P, act, 0);
     }
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_adjoint_dense, dim3(adjoint_grid(a)), dim3(256), 0, h->stream, a, (const double*)nullptr, a.w, 1.0,
-                       d.AyU, act, 0);
-    HIPCHK(hipGetLastError());
+    { int rca = launch_adjoint(h, a, (const double*)nullptr, a.w, 1.0, d.AyU, act, 0, true); if (rca) return rca; }
     const double* M[2] = {d.eS[cur], d.AyU};
     const double* X[2] = {d.md, d.Y[cur]};
     const double sc[2] = {2.0, 4.0 * sigma};
@@ -795,7 +849,7 @@ int msdp_affine_al_primal(msdp_handle h, double* obj, double* Ax_host) {
     return 0;
 }
 
-// eS = c - At*y, z, S (left in d.AyU for msdp_escape_eigs_dual); z -> host (n values, or 1 for the sphere, none for generic)
+// eS = c - At*y, z, S (left in d.Sdual for msdp_escape_eigs_dual); z -> host (n values, or 1 for the sphere, none for generic)
 int msdp_affine_al_dual(msdp_handle h, const double* y_host, double* z_host) {
     AffineState* st = astate(h);
     if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
@@ -805,24 +859,23 @@ int msdp_affine_al_dual(msdp_handle h, const double* y_host, double* z_host) {
     const int cur = h->h_ctl->cur;
     const double* Ys = d.Y[cur];
     HIPCHK(hipMemcpyAsync(a.w, y_host, (size_t)a.m * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_adjoint_dense, dim3(adjoint_grid(a)), dim3(256), 0, h->stream, a, d.Cd, (const double*)a.w, -1.0,
-                       d.AyU, (const int*)nullptr, 0);
-    HIPCHK(hipGetLastError());
+    // full sweep: the diagonal of Sdual was modified by k_sub_diag after the previous call
+    { int rca = launch_adjoint(h, a, d.Cd, (const double*)a.w, -1.0, d.Sdual, (const int*)nullptr, 0, false); if (rca) return rca; }
     if (d.manifold == MANI_EUCLID) { HIPCHK(hipStreamSynchronize(h->stream)); return 0; }
     // t_i = <(eS*Y)_i, Y_i>  (= sum(X.*eS) per row); their total for the sphere
     const double* slab; int64_t stride; int SK;
-    const double* M[1] = {d.AyU}; const double* X[1] = {Ys}; const double sc[1] = {1.0};
+    const double* M[1] = {d.Sdual}; const double* X[1] = {Ys}; const double sc[1] = {1.0};
     int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
     if (rc) return rc;
     DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 1.0, (double*)nullptr, d.W0, P_S2);
     HIPCHK(hipGetLastError());
     if (d.manifold == MANI_OBLIQUE) {
-        hipLaunchKernelGGL(k_sub_diag, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, a.n, a.nS, d.AyU, (const double*)d.W0, (const double*)nullptr);
+        hipLaunchKernelGGL(k_sub_diag, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, a.n, a.nS, d.Sdual, (const double*)d.W0, (const double*)nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(z_host, d.W0, (size_t)a.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     } else {
         if ((rc = msdp_k_sum_to_fwd(h, P_S2, &d.ctl->fx_prop))) return rc;
-        hipLaunchKernelGGL(k_sub_diag, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, a.n, a.nS, d.AyU, (const double*)nullptr, (const double*)&d.ctl->fx_prop);
+        hipLaunchKernelGGL(k_sub_diag, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, a.n, a.nS, d.Sdual, (const double*)nullptr, (const double*)&d.ctl->fx_prop);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(z_host, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }

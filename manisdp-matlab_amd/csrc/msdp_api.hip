@@ -1186,7 +1186,7 @@ extern "C" int msdp_escape_eigs_dual(msdp_handle h, int32_t k, double tol, int32
     CHECK_H(h);
     if (!lam_min || !V) { msdp_set_error("escape_eigs_dual: null argument"); return MSDP_EINVAL; }
     if (h->d.costkind != COST_AFFINE || !h->dual_valid) { msdp_set_error("escape_eigs_dual: call msdp_al_dual first"); return MSDP_ESTATE; }
-    int rc = msdp_escape_impl(h, k, tol, maxit, lam_min, V, lam_max, iters, h->d.AyU);
+    int rc = msdp_escape_impl(h, k, tol, maxit, lam_min, V, lam_max, iters, h->d.Sdual);
     (void)hipStreamSynchronize(h->stream);
     return rc;
 }

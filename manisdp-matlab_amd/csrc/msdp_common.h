@@ -96,6 +96,7 @@ struct Dev {
     double* Cd;       // dense cost matrix rows (COST_DENSE) or c reshaped (COST_AFFINE)
     double* eS[2];    // affine kinds: eS per slot (n_loc x n)
     double* AyU;      // affine kinds: A'(A(.)) scratch (n_loc x n)
+    double* Sdual;    // affine kinds: dual slack S of msdp_al_dual (= AyU unless the restricted adjoint is in use)
     // affine operator: At in CSC (by constraint) and CSR (by matrix entry)
     int64_t m;
     const int64_t* at_jc; const int64_t* at_ir; const double* at_pr;     // CSC n^2 x m
@@ -114,7 +115,7 @@ struct msdp_handle_s {
     bool have_point = false;
     bool state_valid = false;      // cost/grad state computed at the resident point
     bool gradnorm_valid = false;   // h_ctl->norm_grad / fx describe the resident point
-    bool dual_valid = false;       // d.AyU holds the dual slack S of the last msdp_al_dual call
+    bool dual_valid = false;       // d.Sdual holds the dual slack S of the last msdp_al_dual call
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Ctl* h_ctl = nullptr;          // pinned host mirror
