@@ -49,6 +49,7 @@ struct AffineDev {
     double* w;             // A(.) result, length m
     double* Axb[2];        // per slot
     const int* sup;        // entries r = i*n + j that occur in some constraint (nsup > 0: At touches few entries)
+    const int* suprow;     // n+1: the entries of matrix row i are sup[suprow[i] .. suprow[i+1])
     int nsup;
 };
 
@@ -296,6 +297,41 @@ __global__ __launch_bounds__(256) void k_adjoint_support(AffineDev a, const doub
     }
 }
 
+// out(i,:) = scale * sum_j (A'(w))_ij * Yp(j,:) over the entries (i,j) At touches: the product AyU*Y of the Hess-vec
+// without forming AyU (ManiSDP_unitdiag.m:168-169, ManiSDP_unittrace.m:173-174).  One wave per matrix row; the
+// adjoint value of an entry is computed by all lanes from the same addresses (one transaction), the panel row is
+// read 16 bytes per lane.  The result is handed to the epilogue as one more split-K slab.
+template <int NCH>
+__global__ __launch_bounds__(256) void k_support_spmm(AffineDev a, const double* __restrict__ w, const double* __restrict__ Yp,
+                                                      double scale, double* __restrict__ out, const int* skip_flag, int skip_when) {
+    if (skip_flag && *skip_flag == skip_when) return;
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < a.n; i += gridDim.x * 4) {
+        double2 acc[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) acc[ch] = make_double2(0.0, 0.0);
+        for (int q = a.suprow[i]; q < a.suprow[i + 1]; ++q) {
+            const int r = a.sup[q];
+            const int j = r - i * a.n;
+            double v = 0.0;
+            for (int t = a.rp[r]; t < a.rp[r + 1]; ++t) v = fma(a.rv[t], w[a.rk[t]], v);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c = 2 * lane + 128 * ch;
+                if (c < a.ld) {
+                    const double2 y = ld2(Yp + (int64_t)j * a.ld + c);
+                    acc[ch].x = fma(v, y.x, acc[ch].x); acc[ch].y = fma(v, y.y, acc[ch].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = 2 * lane + 128 * ch;
+            if (c < a.ld) st2(out + (int64_t)i * a.ld + c, make_double2(scale * acc[ch].x, scale * acc[ch].y));
+        }
+    }
+}
+
 // rows: t_i = <S_i, Y_i> where S = sum of slabs (S = M*Y); writes optional S to dst and partial sum -> P[which]
 template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_rowdot_slabs(Dev d, const double* __restrict__ Yl, const double* slab,
@@ -520,12 +556,15 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
         // entries touched by At; the restricted adjoint is used when they are few (<= 1/8 of the matrix)
         int64_t ns = 0;
         for (int64_t r = 0; r < nn; ++r) ns += rp[r + 1] > rp[r];
-        a.sup = nullptr; a.nsup = 0;
+        a.sup = nullptr; a.suprow = nullptr; a.nsup = 0;
         if (ns > 0 && ns * 8 <= nn && !(getenv("MSDP_ADJ_FULL") && atoi(getenv("MSDP_ADJ_FULL")))) {
             std::vector<int> sup;
             sup.reserve((size_t)ns);
             for (int64_t r = 0; r < nn; ++r) if (rp[r + 1] > rp[r]) sup.push_back((int)r);
-            if ((rc = up(h, sup, &a.sup))) return rc;
+            std::vector<int> suprow(n + 1, 0);
+            for (int r : sup) suprow[r / n + 1]++;
+            for (int i = 0; i < n; ++i) suprow[i + 1] += suprow[i];
+            if ((rc = up(h, sup, &a.sup)) || (rc = up(h, suprow, &a.suprow))) return rc;
             a.nsup = (int)ns;
         }
     }
@@ -733,13 +772,33 @@ int msdp_affine_hess(msdp_handle h) {
         hipLaunchKernelGGL(k_sddmm_finish, dim3((int)gf), dim3(MSDP_BLOCK), 0, h->stream, a, 0, (double*)nullptr, sigma, d.P, act, 0);
     }
     HIPCHK(hipGetLastError());
-    { int rca = launch_adjoint(h, a, (const double*)nullptr, a.w, 1.0, d.AyU, act, 0, true); if (rca) return rca; }
-    const double* M[2] = {d.eS[cur], d.AyU};
-    const double* X[2] = {d.md, d.Y[cur]};
-    const double sc[2] = {2.0, 4.0 * sigma};
     const double* slab; int64_t stride; int SK;
-    int rc = msdp_dense_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK);
-    if (rc) return rc;
+    int rc;
+    if (a.nsup > 0 && h->nranks == 1 && d.ld <= 512) {
+        // At touches few entries: AyU*Y is a sparse product over those entries (appended as one more slab); only
+        // 2*eS*U goes through the dense contraction
+        const double* M[1] = {d.eS[cur]};
+        const double* X[1] = {d.md};
+        const double sc[1] = {2.0};
+        if ((rc = msdp_dense_gemm(h, 1, M, X, sc, act, &slab, &stride, &SK))) return rc;
+        double* extra = const_cast<double*>(slab) + (int64_t)SK * stride;
+        const int nch = (d.ld + 127) / 128;
+        const dim3 g(std::min((a.n + 3) / 4, 2048)), b(256);
+        switch (nch) {
+            case 1: hipLaunchKernelGGL(k_support_spmm<1>, g, b, 0, h->stream, a, (const double*)a.w, (const double*)d.Y[cur], 4.0 * sigma, extra, act, 0); break;
+            case 2: hipLaunchKernelGGL(k_support_spmm<2>, g, b, 0, h->stream, a, (const double*)a.w, (const double*)d.Y[cur], 4.0 * sigma, extra, act, 0); break;
+            case 3: hipLaunchKernelGGL(k_support_spmm<3>, g, b, 0, h->stream, a, (const double*)a.w, (const double*)d.Y[cur], 4.0 * sigma, extra, act, 0); break;
+            default: hipLaunchKernelGGL(k_support_spmm<4>, g, b, 0, h->stream, a, (const double*)a.w, (const double*)d.Y[cur], 4.0 * sigma, extra, act, 0); break;
+        }
+        HIPCHK(hipGetLastError());
+        ++SK;
+    } else {
+        { int rca = launch_adjoint(h, a, (const double*)nullptr, a.w, 1.0, d.AyU, act, 0, true); if (rca) return rca; }
+        const double* M[2] = {d.eS[cur], d.AyU};
+        const double* X[2] = {d.md, d.Y[cur]};
+        const double sc[2] = {2.0, 4.0 * sigma};
+        if ((rc = msdp_dense_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
+    }
     if (d.manifold == MANI_OBLIQUE) return msdp_dense_hess_epilogue_obl(h, slab, stride, SK);
     return msdp_sphere_hess_raw(h, slab, stride, SK);
 }

@@ -401,10 +401,16 @@ static void dense_plan(msdp_handle h, int nmat, int* row_blocks_out, int* SK_out
 // Reserve the split-K slab for the current p BEFORE any graph capture (hipMalloc is illegal
 // while a stream is capturing).
 int msdp_dense_reserve(msdp_handle h, int nmat) {
-    int SK, row_blocks; int64_t kslice;
-    dense_plan(h, nmat, &row_blocks, &SK, &kslice);
+    // room for the plans of 1..nmat matrices plus one extra slab (the affine Hess-vec appends the sparse A'(w)*Y
+    // product as one more slab when At touches few entries)
+    int SKmax = 1;
+    for (int q = 1; q <= nmat; ++q) {
+        int SK, row_blocks; int64_t kslice;
+        dense_plan(h, q, &row_blocks, &SK, &kslice);
+        SKmax = std::max(SKmax, SK);
+    }
     const int64_t cap_rows = (h->d.n + h->nranks - 1) / h->nranks;
-    return ensure_slab(h, (size_t)SK * cap_rows * (size_t)h->d.ld);
+    return ensure_slab(h, (size_t)(SKmax + 1) * cap_rows * (size_t)h->d.ld);
 }
 
 // Launch the partial GEMM for up to two (matrix, panel, scale) pairs; returns slab info.
@@ -426,7 +432,7 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
     op.kslice = (int)kslice;
     const int64_t cap_rows = (d.n + h->nranks - 1) / h->nranks;
     op.slab_stride = cap_rows * (int64_t)d.ld;
-    int rc = ensure_slab(h, (size_t)SK * op.slab_stride);
+    int rc = ensure_slab(h, (size_t)(SK + 1) * op.slab_stride);       // + 1: see msdp_dense_reserve
     if (rc) return rc;
     op.slab = h->slab;
     // p > 128: column blocks of 128 (the matrix is re-streamed once per block; NT <= 8 accumulator tiles per wave)
