@@ -66,20 +66,35 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm(AffineDev a, const double*
     for (int64_t it = ((int64_t)blockIdx.x * MSDP_WAVES + wave) * CPW + csub; it < a.nitems; it += stride) {
         const int s0 = a.it0[it], s1 = a.it1[it];
         double acc = 0.0;
-        for (int t = s0; t < s1; ++t) {
-            const int i = a.ci[t], j = a.cj[t];
-            const double v = a.cv[t];
-            const double* ya = Ya + (int64_t)i * a.ld + 2 * sub;
-            const double* yb = Yb + (int64_t)j * a.ld + 2 * sub;
-            double dd = 0.0;
+        // U nonzeros at a time (16 at a time was measured: 2x slower on BQP, whose constraints have ~4 nonzeros): their index loads and row gathers are independent, one at a time left a lane group
+        // with a single request in flight (64 dependent round trips per item = 39 us for the trace row of a theta
+        // problem, whatever the size of the rest)
+        constexpr int U = NCH == 1 ? 4 : 2;
+        for (int t = s0; t < s1; t += U) {
+            int ii[U], jj[U];
+            double vv[U], dd[U];
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                if (2 * sub + ch * 2 * LPR < a.ld) {
-                    const double2 x = ld2(ya + ch * 2 * LPR), z = ld2(yb + ch * 2 * LPR);
-                    dd += x.x * z.x + x.y * z.y;
+            for (int u = 0; u < U; ++u) {
+                const bool in = t + u < s1;
+                const int tt = in ? t + u : s1 - 1;
+                ii[u] = a.ci[tt]; jj[u] = a.cj[tt];
+                vv[u] = in ? a.cv[tt] : 0.0;
+                dd[u] = 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double* ya = Ya + (int64_t)ii[u] * a.ld + 2 * sub;
+                const double* yb = Yb + (int64_t)jj[u] * a.ld + 2 * sub;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    if (2 * sub + ch * 2 * LPR < a.ld) {
+                        const double2 x = ld2(ya + ch * 2 * LPR), z = ld2(yb + ch * 2 * LPR);
+                        dd[u] += x.x * z.x + x.y * z.y;
+                    }
                 }
             }
-            acc = fma(v, dd, acc);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = fma(vv[u], dd[u], acc);
         }
         acc = msdp_group_sum<LPR>(acc);
         if (sub == 0) a.ival[it] = acc;
@@ -301,6 +316,7 @@ __global__ __launch_bounds__(256) void k_adjoint_support(AffineDev a, const doub
 // without forming AyU (ManiSDP_unitdiag.m:168-169, ManiSDP_unittrace.m:173-174).  One wave per matrix row; the
 // adjoint value of an entry is computed by all lanes from the same addresses (one transaction), the panel row is
 // read 16 bytes per lane.  The result is handed to the epilogue as one more split-K slab.
+#define SPB 4
 template <int NCH>
 __global__ __launch_bounds__(256) void k_support_spmm(AffineDev a, const double* __restrict__ w, const double* __restrict__ Yp,
                                                       double scale, double* __restrict__ out, const int* skip_flag, int skip_when) {
@@ -310,17 +326,41 @@ __global__ __launch_bounds__(256) void k_support_spmm(AffineDev a, const double*
         double2 acc[NCH];
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) acc[ch] = make_double2(0.0, 0.0);
-        for (int q = a.suprow[i]; q < a.suprow[i + 1]; ++q) {
-            const int r = a.sup[q];
-            const int j = r - i * a.n;
-            double v = 0.0;
-            for (int t = a.rp[r]; t < a.rp[r + 1]; ++t) v = fma(a.rv[t], w[a.rk[t]], v);
+        // SPB entries at a time: entry -> row pointer -> (coefficient, constraint) -> w -> panel row is a chain of
+        // dependent loads, and the entries of a row are independent of each other
+        const int q1 = a.suprow[i + 1];
+        for (int q = a.suprow[i]; q < q1; q += SPB) {
+            int jj[SPB], s0[SPB], s1[SPB];
+            double v[SPB];
+#pragma unroll
+            for (int u = 0; u < SPB; ++u) {
+                const bool in = q + u < q1;
+                const int r = a.sup[in ? q + u : q1 - 1];
+                jj[u] = r - i * a.n;
+                s0[u] = a.rp[r]; s1[u] = in ? a.rp[r + 1] : s0[u];
+                v[u] = 0.0;
+            }
+            int len = 0;
+#pragma unroll
+            for (int u = 0; u < SPB; ++u) len = max(len, s1[u] - s0[u]);
+            for (int t = 0; t < len; ++t) {
+#pragma unroll
+                for (int u = 0; u < SPB; ++u) {
+                    const bool has = s0[u] + t < s1[u];
+                    const int tt = has ? s0[u] + t : 0;
+                    const double cv = has ? a.rv[tt] : 0.0;
+                    v[u] = fma(cv, w[a.rk[tt]], v[u]);
+                }
+            }
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int c = 2 * lane + 128 * ch;
                 if (c < a.ld) {
-                    const double2 y = ld2(Yp + (int64_t)j * a.ld + c);
-                    acc[ch].x = fma(v, y.x, acc[ch].x); acc[ch].y = fma(v, y.y, acc[ch].y);
+                    double2 y[SPB];
+#pragma unroll
+                    for (int u = 0; u < SPB; ++u) y[u] = ld2(Yp + (int64_t)jj[u] * a.ld + c);
+#pragma unroll
+                    for (int u = 0; u < SPB; ++u) { acc[ch].x = fma(v[u], y[u].x, acc[ch].x); acc[ch].y = fma(v[u], y[u].y, acc[ch].y); }
                 }
             }
         }
