@@ -35,6 +35,8 @@ struct AffineDev {
     const int* it0;        // first nonzero of item
     const int* it1;        // one past the last nonzero of item
     const int* kit;        // m+1: items of constraint k are kit[k] .. kit[k+1]-1
+    const int* longk;      // constraints with more than FIN_SHORT items
+    int nlong;
     double* ival;          // partial value per item
     const int* ci;         // row i of each nonzero
     const int* cj;         // col j of each nonzero
@@ -53,7 +55,8 @@ struct AffineDev {
     int nsup;
 };
 
-#define SDDMM_CHUNK 64
+#define SDDMM_CHUNK 16
+#define FIN_SHORT 8           // constraints with more items than this are summed by a whole wave (k_sddmm_finish)
 // item value = sum over the item's nonzeros (i,j,val) of val * <Ya_i, Yb_j>   (one LPR-lane group per item)
 template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm(AffineDev a, const double* __restrict__ Ya,
@@ -107,14 +110,40 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm_finish(AffineDev a, int mo
     __shared__ double sh[3 * MSDP_WAVES];
     if (skip_flag && *skip_flag == skip_when) return;
     double pss = 0.0;
+    // short constraints: one thread each
     for (int64_t k = (int64_t)blockIdx.x * MSDP_BLOCK + threadIdx.x; k < a.m; k += (int64_t)gridDim.x * MSDP_BLOCK) {
+        const int i0 = a.kit[k], i1 = a.kit[k + 1];
+        if (i1 - i0 > FIN_SHORT) continue;
         double acc = 0.0;
-        for (int it = a.kit[k]; it < a.kit[k + 1]; ++it) acc += a.ival[it];
+        for (int it = i0; it < i1; ++it) acc += a.ival[it];
         a.w[k] = acc;
         if (mode == 1) {
             const double r = acc - a.b[k] - a.y[k] / sigma;
             axb_out[k] = r;
             pss += r * r;
+        }
+    }
+    // long constraints (the trace row of a theta problem, the all-ones constraint of a gpp problem: up to n^2/16
+    // items): one wave each, lanes stride over the items
+    {
+        const int lane = threadIdx.x & 63;
+        const int wv = blockIdx.x * (MSDP_BLOCK / 64) + (threadIdx.x >> 6), nwv = gridDim.x * (MSDP_BLOCK / 64);
+        for (int q = wv; q < a.nlong; q += nwv) {
+            const int k = a.longk[q];
+            const int i0 = a.kit[k], i1 = a.kit[k + 1];
+            double a0 = 0.0, a1 = 0.0;
+            int it = i0 + lane;
+            for (; it + 64 < i1; it += 128) { a0 += a.ival[it]; a1 += a.ival[it + 64]; }
+            if (it < i1) a0 += a.ival[it];
+            const double acc = msdp_wave_sum(a0 + a1);
+            if (lane == 0) {
+                a.w[k] = acc;
+                if (mode == 1) {
+                    const double r = acc - a.b[k] - a.y[k] / sigma;
+                    axb_out[k] = r;
+                    pss += r * r;
+                }
+            }
         }
     }
     if (mode == 1) msdp_put_partial(P, P_AUX, pss, sh);
@@ -584,6 +613,13 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
     a.nitems = (int64_t)it0.size();
     int rc;
     if ((rc = up(h, it0, &a.it0)) || (rc = up(h, it1, &a.it1)) || (rc = up(h, kit, &a.kit))) return rc;
+    {
+        std::vector<int> longk;
+        for (int64_t k = 0; k < m; ++k) if (kit[k + 1] - kit[k] > FIN_SHORT) longk.push_back((int)k);
+        a.nlong = (int)longk.size();
+        if (longk.empty()) longk.push_back(0);
+        if ((rc = up(h, longk, &a.longk))) return rc;
+    }
     {
         void* pv = nullptr;
         if ((rc = msdp_dev_alloc_bytes(h, &pv, (size_t)std::max<int64_t>(a.nitems, 1) * sizeof(double)))) return rc;
