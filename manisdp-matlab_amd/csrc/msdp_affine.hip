@@ -343,8 +343,7 @@ __global__ __launch_bounds__(256) void k_adjoint_support(AffineDev a, const doub
 
 // out(i,:) = scale * sum_j (A'(w))_ij * Yp(j,:) over the entries (i,j) At touches: the product AyU*Y of the Hess-vec
 // without forming AyU (ManiSDP_unitdiag.m:168-169, ManiSDP_unittrace.m:173-174).  One wave per matrix row; the
-// adjoint value of an entry is computed by all lanes from the same addresses (one transaction), the panel row is
-// read 16 bytes per lane.  The result is handed to the epilogue as one more split-K slab.
+// adjoint values of the entries of a row are computed one per lane, the panel rows are read 16 bytes per lane.  The result is handed to the epilogue as one more split-K slab.
 #define SPB 4
 template <int NCH>
 __global__ __launch_bounds__(256) void k_support_spmm(AffineDev a, const double* __restrict__ w, const double* __restrict__ Yp,
@@ -355,41 +354,39 @@ __global__ __launch_bounds__(256) void k_support_spmm(AffineDev a, const double*
         double2 acc[NCH];
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) acc[ch] = make_double2(0.0, 0.0);
-        // SPB entries at a time: entry -> row pointer -> (coefficient, constraint) -> w -> panel row is a chain of
-        // dependent loads, and the entries of a row are independent of each other
+        // Phase 1: the lanes take one entry each (64 at a time) and run its chain of dependent loads -- entry -> row
+        // pointer -> (coefficient, constraint) -> w -- side by side.  Phase 2: the values and column indices are
+        // broadcast lane by lane and all lanes accumulate v * Yp(j,:); four panel rows are requested together.
         const int q1 = a.suprow[i + 1];
-        for (int q = a.suprow[i]; q < q1; q += SPB) {
-            int jj[SPB], s0[SPB], s1[SPB];
-            double v[SPB];
-#pragma unroll
-            for (int u = 0; u < SPB; ++u) {
-                const bool in = q + u < q1;
-                const int r = a.sup[in ? q + u : q1 - 1];
-                jj[u] = r - i * a.n;
-                s0[u] = a.rp[r]; s1[u] = in ? a.rp[r + 1] : s0[u];
-                v[u] = 0.0;
+        for (int q0 = a.suprow[i]; q0 < q1; q0 += 64) {
+            const int cnt = min(64, q1 - q0);
+            int jl = 0;
+            double vl = 0.0;
+            if (lane < cnt) {
+                const int r = a.sup[q0 + lane];
+                jl = r - i * a.n;
+                const int s0 = a.rp[r], s1 = a.rp[r + 1];
+                for (int t = s0; t < s1; ++t) vl = fma(a.rv[t], w[a.rk[t]], vl);
             }
-            int len = 0;
-#pragma unroll
-            for (int u = 0; u < SPB; ++u) len = max(len, s1[u] - s0[u]);
-            for (int t = 0; t < len; ++t) {
+            for (int e0 = 0; e0 < cnt; e0 += SPB) {
+                int jj[SPB];
+                double v[SPB];
 #pragma unroll
                 for (int u = 0; u < SPB; ++u) {
-                    const bool has = s0[u] + t < s1[u];
-                    const int tt = has ? s0[u] + t : 0;
-                    const double cv = has ? a.rv[tt] : 0.0;
-                    v[u] = fma(cv, w[a.rk[tt]], v[u]);
+                    const int e = min(e0 + u, cnt - 1);
+                    jj[u] = __shfl(jl, e);
+                    v[u] = (e0 + u < cnt) ? __shfl(vl, e) : 0.0;
                 }
-            }
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int c = 2 * lane + 128 * ch;
-                if (c < a.ld) {
-                    double2 y[SPB];
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int c = 2 * lane + 128 * ch;
+                    if (c < a.ld) {
+                        double2 y[SPB];
 #pragma unroll
-                    for (int u = 0; u < SPB; ++u) y[u] = ld2(Yp + (int64_t)jj[u] * a.ld + c);
+                        for (int u = 0; u < SPB; ++u) y[u] = ld2(Yp + (int64_t)jj[u] * a.ld + c);
 #pragma unroll
-                    for (int u = 0; u < SPB; ++u) { acc[ch].x = fma(v[u], y[u].x, acc[ch].x); acc[ch].y = fma(v[u], y[u].y, acc[ch].y); }
+                        for (int u = 0; u < SPB; ++u) { acc[ch].x = fma(v[u], y[u].x, acc[ch].x); acc[ch].y = fma(v[u], y[u].y, acc[ch].y); }
+                    }
                 }
             }
         }
