@@ -92,3 +92,20 @@ def test_generic_sdplib_mcp(name):
     assert data["status"] == 0
     assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
     assert abs(-obj - KNOWN[name]) < 1e-6 * abs(KNOWN[name])
+
+
+def test_generic_quartic_on_sphere_kkt_self_certification():
+    """example/example_qsphere.m:18-27 with the reference's coefficient file data/qs_c_10_1.txt: the reference stores
+    no optimum for these instances, so the result is pinned by the KKT residues (gap, pinf, dinf < 1e-8 certify the
+    objective to ~1e-8 by weak duality) and by the constraints A(X) = b of the moment matrix X = Y Y'."""
+    import numpy as np
+    coe = np.loadtxt(golden_path("qs_c_10_1.txt.gz"), delimiter=",").ravel()
+    At, b, c, K = problems.qsmom(10, coe)
+    b = np.asarray(b.todense()).ravel() if hasattr(b, "todense") else np.asarray(b, float)
+    c = np.asarray(c.todense()).ravel() if hasattr(c, "todense") else np.asarray(c, float).ravel()
+    Y, obj, data = R.ManiSDP(At, b, c, K, {})
+    assert data["status"] == 0
+    assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
+    X = Y @ Y.T
+    assert np.linalg.norm(At.T @ X.ravel(order="F") - b) / (1 + np.linalg.norm(b)) < 1e-8
+    assert abs(obj - c @ X.ravel(order="F")) < 1e-9 * max(1.0, abs(obj))
