@@ -788,6 +788,22 @@ static int launch_adjoint(msdp_handle h, const AffineDev& a, const double* base,
     return 0;
 }
 
+// slab <- scale * (A'(vec) restricted to the touched entries) * Yp   (k_support_spmm; a.nsup > 0, ld <= 512)
+static int launch_support_spmm(msdp_handle h, const AffineDev& a, const double* vec, const double* Yp, double scale,
+                               double* out, const int* flag, int when) {
+    const int nch = (a.ld + 127) / 128;
+    const dim3 g(std::min((a.n + 3) / 4, 2048)), b(256);
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(k_support_spmm<1>, g, b, 0, h->stream, a, vec, Yp, scale, out, flag, when); break;
+        case 2: hipLaunchKernelGGL(k_support_spmm<2>, g, b, 0, h->stream, a, vec, Yp, scale, out, flag, when); break;
+        case 3: hipLaunchKernelGGL(k_support_spmm<3>, g, b, 0, h->stream, a, vec, Yp, scale, out, flag, when); break;
+        default: hipLaunchKernelGGL(k_support_spmm<4>, g, b, 0, h->stream, a, vec, Yp, scale, out, flag, when); break;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+
 // cost + gradient state at Y[slot]:  w = A(YY'), Axb, eS, eS*Y, C*Y  (see header comment)
 int msdp_affine_costgrad(msdp_handle h, int slot) {
     AffineState* st = astate(h);
@@ -812,7 +828,16 @@ int msdp_affine_costgrad(msdp_handle h, int slot) {
         HIPCHK(hipGetLastError());
     }
     // eG = 2*eS*Y -> Gr[slot]; row dots (YeG = sum(Y.*eG)) and their total (2z)
-    {
+    if (a.nsup > 0 && h->nranks == 1 && d.ld <= 512) {
+        // At touches few entries: eS*Y = C*Y (the slabs just computed) + sigma * (A'(Axb) on those entries) * Y,
+        // appended as one more slab -- one dense product per cost/gradient evaluation instead of two
+        double* extra = const_cast<double*>(slab) + (int64_t)SK * stride;
+        int rc = launch_support_spmm(h, a, (const double*)a.Axb[slot], Ys, sigma, extra, done, 1);
+        if (rc) return rc;
+        ++SK;
+        DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 2.0, d.Gr[slot], d.eG[slot], P_S2);
+        HIPCHK(hipGetLastError());
+    } else {
         const double* M[1] = {d.eS[slot]}; const double* X[1] = {Ys}; const double sc[1] = {1.0};
         int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
         if (rc) return rc;
@@ -855,15 +880,7 @@ int msdp_affine_hess(msdp_handle h) {
         const double sc[1] = {2.0};
         if ((rc = msdp_dense_gemm(h, 1, M, X, sc, act, &slab, &stride, &SK))) return rc;
         double* extra = const_cast<double*>(slab) + (int64_t)SK * stride;
-        const int nch = (d.ld + 127) / 128;
-        const dim3 g(std::min((a.n + 3) / 4, 2048)), b(256);
-        switch (nch) {
-            case 1: hipLaunchKernelGGL(k_support_spmm<1>, g, b, 0, h->stream, a, (const double*)a.w, (const double*)d.Y[cur], 4.0 * sigma, extra, act, 0); break;
-            case 2: hipLaunchKernelGGL(k_support_spmm<2>, g, b, 0, h->stream, a, (const double*)a.w, (const double*)d.Y[cur], 4.0 * sigma, extra, act, 0); break;
-            case 3: hipLaunchKernelGGL(k_support_spmm<3>, g, b, 0, h->stream, a, (const double*)a.w, (const double*)d.Y[cur], 4.0 * sigma, extra, act, 0); break;
-            default: hipLaunchKernelGGL(k_support_spmm<4>, g, b, 0, h->stream, a, (const double*)a.w, (const double*)d.Y[cur], 4.0 * sigma, extra, act, 0); break;
-        }
-        HIPCHK(hipGetLastError());
+        if ((rc = launch_support_spmm(h, a, (const double*)a.w, (const double*)d.Y[cur], 4.0 * sigma, extra, act, 0))) return rc;
         ++SK;
     } else {
         { int rca = launch_adjoint(h, a, (const double*)nullptr, a.w, 1.0, d.AyU, act, 0, true); if (rca) return rca; }
