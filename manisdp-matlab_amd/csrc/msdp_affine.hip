@@ -419,11 +419,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_rowdot_slabs(Dev d, const double
                 const int col = 2 * sub + ch * 2 * LPR;
                 if (col < d.ld) {
                     const int64_t o = (int64_t)row * d.ld + col;
-                    double2 acc = make_double2(0.0, 0.0);
-                    for (int s = 0; s < SK; ++s) {
-                        const double2 v = ld2(slab + s * slab_stride + o);
-                        acc.x += v.x; acc.y += v.y;
-                    }
+                    const double2 acc = msdp_sum_slabs(slab, slab_stride, SK, o);
                     const double2 y = ld2(Yl + o);
                     dot += acc.x * y.x + acc.y * y.y;
                     if (dst) st2(dst + o, make_double2(scale_out * acc.x, scale_out * acc.y));
@@ -905,11 +901,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_raw(Dev d, const double
     const int64_t e0 = (int64_t)lo * d.ld, e1 = (int64_t)hi * d.ld;
     double pt = 0.0;
     for (int64_t i = e0 + 2 * threadIdx.x; i < e1; i += 2 * MSDP_BLOCK) {
-        double2 acc = make_double2(0.0, 0.0);
-        for (int s = 0; s < SK; ++s) {
-            const double2 v = ld2(slab + s * slab_stride + i);
-            acc.x += v.x; acc.y += v.y;
-        }
+        const double2 acc = msdp_sum_slabs(slab, slab_stride, SK, i);
         const double2 y = ld2(Yl + i);
         st2(d.Hmd + i, acc);
         pt += acc.x * y.x + acc.y * y.y;

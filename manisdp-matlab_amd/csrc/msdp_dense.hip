@@ -217,10 +217,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_dense_hess_epi_obl(Dev d, const 
                 acc[ch] = make_double2(0.0, 0.0); y[ch] = acc[ch]; u[ch] = acc[ch];
                 if (col < d.ld) {
                     const int64_t o = (int64_t)row * d.ld + col;
-                    for (int s = 0; s < SK; ++s) {
-                        const double2 v = ld2(slab + s * slab_stride + o);
-                        acc[ch].x += v.x; acc[ch].y += v.y;
-                    }
+                    acc[ch] = msdp_sum_slabs(slab, slab_stride, SK, o);
                     y[ch] = ld2(Yl + o); u[ch] = ld2(d.md + o);
                     dot += acc[ch].x * y[ch].x + acc[ch].y * y[ch].y;
                 }
@@ -270,10 +267,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_dense_costgrad_epi_obl(Dev d, in
                 acc[ch] = make_double2(0.0, 0.0); y[ch] = acc[ch];
                 if (col < d.ld) {
                     const int64_t o = (int64_t)row * d.ld + col;
-                    for (int s = 0; s < SK; ++s) {
-                        const double2 v = ld2(slab + s * slab_stride + o);
-                        acc[ch].x += v.x; acc[ch].y += v.y;
-                    }
+                    acc[ch] = msdp_sum_slabs(slab, slab_stride, SK, o);
                     y[ch] = ld2(Yl + o);
                     dot += acc[ch].x * y[ch].x + acc[ch].y * y[ch].y;
                 }

@@ -181,3 +181,21 @@ __device__ __forceinline__ void frame_store(Frame* o, double z_r, double d_Pd, d
     o->active = active; o->j = j; o->stop = stop; o->eta_idx = eta_idx; o->md_idx = md_idx; o->fresh = fresh;
 }
 
+
+// Sum of the SK split-K slabs at offset o (two doubles), in slab order.  Four loads are requested together: with a
+// plain loop hipcc keeps one load in flight per lane (SK is a run-time value), and the epilogues are latency-bound.
+__device__ __forceinline__ double2 msdp_sum_slabs(const double* __restrict__ slab, int64_t slab_stride, int SK, int64_t o) {
+    double2 acc = make_double2(0.0, 0.0);
+    int s = 0;
+    for (; s + 4 <= SK; s += 4) {
+        const double2 v0 = ld2(slab + (int64_t)s * slab_stride + o), v1 = ld2(slab + (int64_t)(s + 1) * slab_stride + o);
+        const double2 v2 = ld2(slab + (int64_t)(s + 2) * slab_stride + o), v3 = ld2(slab + (int64_t)(s + 3) * slab_stride + o);
+        acc.x += v0.x; acc.y += v0.y; acc.x += v1.x; acc.y += v1.y;
+        acc.x += v2.x; acc.y += v2.y; acc.x += v3.x; acc.y += v3.y;
+    }
+    for (; s < SK; ++s) {
+        const double2 v = ld2(slab + (int64_t)s * slab_stride + o);
+        acc.x += v.x; acc.y += v.y;
+    }
+    return acc;
+}
