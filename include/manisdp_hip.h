@@ -139,6 +139,9 @@ int msdp_set_multipliers(msdp_handle h, const double* y, double sigma);
 int msdp_set_point(msdp_handle h, int32_t p, const double* Y);
 int msdp_get_point(msdp_handle h, double* Y);
 int msdp_get_p(msdp_handle h, int32_t* p);
+/* MSDP_KIND_* of the handle: tells a binding which factor layout the handle expects at the boundary
+ * (p x n for ONLYUNITDIAG / UNITDIAG, n x p for UNITTRACE / GENERIC) without guessing from array shapes. */
+int msdp_get_kind(msdp_handle h, int32_t* kind);
 
 /* ------------------------------------------------------------------ hot path */
 
@@ -194,6 +197,15 @@ int msdp_escape_eigs(msdp_handle h, int32_t k, double tol, int32_t maxit,
 int msdp_escape_eigs_matrix(msdp_handle h, const double* S, int32_t k, double tol, int32_t maxit,
                             double* lam_min, double* V, double* lam_max, int32_t* iters);
 
+/* Outcome of the LAST msdp_escape_eigs / _matrix / _dual call on this handle.  The reference's eig(S) is exact;
+ * a Lanczos run that reaches `maxit` without passing a stop test only yields an UPPER bound of lambda_min, so
+ * dinf = max(0,-lambda_min)/(1+lambda_max) (ManiSDP_onlyunitdiag.m:51) would be under-estimated: the AL loop
+ * must not declare optimality on it.
+ *   *nvalid    : how many of the k requested pairs are real (the others are returned as lam = +inf, V = 0);
+ *   *converged : 1 if every Lanczos run passed a stop test, 0 if one ended at maxit;
+ *   *residual  : largest relative residual |S x - theta x| / max(|theta|, |lam_max|) among the unconverged runs. */
+int msdp_escape_info(msdp_handle h, int32_t* nvalid, int32_t* converged, double* residual);
+
 /* ------------------------------------------------------------- multi-GPU */
 
 /* Row sharding: call on every rank right after create, before any
@@ -219,6 +231,9 @@ int msdp_al_dual(msdp_handle h, const double* y, double* z);
  * (eig(S) of ManiSDP_unitdiag.m:68 / ManiSDP_unittrace.m:68 / ManiSDP.m:65). */
 int msdp_escape_eigs_dual(msdp_handle h, int32_t k, double tol, int32_t maxit,
                           double* lam_min, double* V, double* lam_max, int32_t* iters);
+/* The dense S (n x n, symmetric: column-major = row-major) of the last msdp_al_dual call: the reference's
+ * data.S (ManiSDP_unitdiag.m:116, ManiSDP_unittrace.m:121) and the input of a host eig(S) for small n. */
+int msdp_get_dual_slack(msdp_handle h, double* S);
 
 /* Which implementation msdp_rtr uses for the tCG inner loop at the resident point:
  * 1 = persistent single-launch kernel (working set in registers/LDS, sparse C, oblique,

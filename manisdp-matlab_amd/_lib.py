@@ -62,6 +62,7 @@ SIGNATURES = {
     "msdp_set_point": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "msdp_get_point": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_p": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "msdp_get_kind": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "msdp_rtr": (C.c_int, [C.c_void_p, _P(RtrOpts), _P(RtrStats)]),
     "msdp_rtr_host": (C.c_int, [C.c_void_p, C.c_int32, _dp, _P(RtrOpts), _P(RtrStats)]),
     "msdp_cost": (C.c_int, [C.c_void_p, _dp]),
@@ -75,6 +76,8 @@ SIGNATURES = {
     "msdp_escape_eigs": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, _dp, _dp, _dp, _P(C.c_int32)]),
     "msdp_escape_eigs_matrix": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_double, C.c_int32, _dp, _dp, _dp,
                                          _P(C.c_int32)]),
+    "msdp_escape_info": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _dp]),
+    "msdp_get_dual_slack": (C.c_int, [C.c_void_p, _dp]),
     "msdp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "msdp_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "msdp_local_rows": (C.c_int, [C.c_void_p, _i64p, _i64p]),
@@ -222,9 +225,10 @@ class Handle:
         return np.ascontiguousarray(Y)            # bytes of MATLAB p x n column-major
 
     def _empty(self):
+        # zero-initialised: a row-sharded handle (comm_init / debug_shard) only writes its own rows
         if self.kind in (KIND_UNITTRACE, KIND_GENERIC):
-            return np.empty((self.n, self.p), dtype=np.float64, order="F")
-        return np.empty((self.n, self.p), dtype=np.float64, order="C")
+            return np.zeros((self.n, self.p), dtype=np.float64, order="F")
+        return np.zeros((self.n, self.p), dtype=np.float64, order="C")
 
     # ---- point I/O
     def set_point(self, Y):
@@ -275,7 +279,7 @@ class Handle:
         return self._vec_op(self._lib.msdp_retr, U)
 
     def get_z(self):
-        z = np.empty(self.n)
+        z = np.zeros(self.n)
         _check(self._lib.msdp_get_z(self._h, _dptr(z)))
         return z
 
@@ -309,6 +313,24 @@ class Handle:
         _check(self._lib.msdp_escape_eigs_matrix(self._h, _dptr(S), k, tol, maxit, _dptr(lam), _dptr(V), C.byref(lmax),
                                                  C.byref(its)))
         return lam, np.ascontiguousarray(V), lmax.value, its.value
+
+    def escape_info(self):
+        """(nvalid, converged, residual) of the last escape_eigs* call: how many returned pairs are real, whether
+        every Lanczos run passed a stop test, and the worst relative residual of the runs that did not."""
+        nv, cv, res = C.c_int32(), C.c_int32(), C.c_double()
+        _check(self._lib.msdp_escape_info(self._h, C.byref(nv), C.byref(cv), C.byref(res)))
+        return nv.value, bool(cv.value), res.value
+
+    def get_kind(self):
+        k = C.c_int32()
+        _check(self._lib.msdp_get_kind(self._h, C.byref(k)))
+        return k.value
+
+    def get_dual_slack(self):
+        """Dense S (n x n) of the last al_dual call."""
+        S = np.empty((self.n, self.n))
+        _check(self._lib.msdp_get_dual_slack(self._h, _dptr(S)))
+        return S
 
     # ---- AL bookkeeping on the device (affine handles)
     def al_primal(self, m):

@@ -153,6 +153,12 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
 static int alloc_common(msdp_handle h) {
     Dev& d = h->d;
     int rc;
+    // msdp_comm_init / msdp_debug_shard call this a second time (the row split changed): release the first set
+    if (d.ctl) { dev_free(h, d.ctl); d.ctl = nullptr; }
+    if (d.F) { dev_free(h, d.F); d.F = nullptr; }
+    if (d.P) { dev_free(h, d.P); d.P = nullptr; }
+    if (h->psync_slots) { dev_free(h, h->psync_slots); h->psync_slots = nullptr; }
+    if (h->psync_err) { dev_free(h, h->psync_err); h->psync_err = nullptr; }
     if ((rc = dev_alloc<Ctl>(h, &d.ctl, 1))) return rc;
     if ((rc = dev_alloc<Frame>(h, &d.F, 2))) return rc;
     if ((rc = dev_alloc<double>(h, &d.P, (size_t)MSDP_NPART * MSDP_MAX_GRID))) return rc;
@@ -168,7 +174,7 @@ static int alloc_common(msdp_handle h) {
     }
     const size_t rows = (size_t)rows_capacity(h);
     for (int s = 0; s < 2; ++s) {
-        if (d.eG[s]) dev_free(h, d.eG[s]);
+        if (d.eG[s]) { dev_free(h, d.eG[s]); d.eG[s] = nullptr; }
         if ((rc = dev_alloc<double>(h, &d.eG[s], rows))) return rc;
         HIPCHK(hipMemset(d.eG[s], 0, rows * sizeof(double)));
     }
@@ -528,6 +534,13 @@ extern "C" int msdp_get_p(msdp_handle h, int32_t* p) {
     CHECK_H(h);
     if (!p) return MSDP_EINVAL;
     *p = h->d.p;
+    return 0;
+}
+
+extern "C" int msdp_get_kind(msdp_handle h, int32_t* kind) {
+    CHECK_H(h);
+    if (!kind) return MSDP_EINVAL;
+    *kind = h->kind;
     return 0;
 }
 
@@ -1189,6 +1202,25 @@ extern "C" int msdp_escape_eigs_dual(msdp_handle h, int32_t k, double tol, int32
     int rc = msdp_escape_impl(h, k, tol, maxit, lam_min, V, lam_max, iters, h->d.Sdual);
     (void)hipStreamSynchronize(h->stream);
     return rc;
+}
+
+extern "C" int msdp_escape_info(msdp_handle h, int32_t* nvalid, int32_t* converged, double* residual) {
+    CHECK_H(h);
+    if (nvalid) *nvalid = h->esc_nvalid;
+    if (converged) *converged = h->esc_converged;
+    if (residual) *residual = h->esc_maxres;
+    return 0;
+}
+
+extern "C" int msdp_get_dual_slack(msdp_handle h, double* S) {
+    CHECK_H(h);
+    if (!S) { msdp_set_error("get_dual_slack: null argument"); return MSDP_EINVAL; }
+    if (h->d.costkind != COST_AFFINE || !h->dual_valid) { msdp_set_error("get_dual_slack: call msdp_al_dual first"); return MSDP_ESTATE; }
+    const int n = h->d.n, nS = msdp_dense_nS(n);
+    HIPCHK(hipMemcpy2DAsync(S, (size_t)n * sizeof(double), h->d.Sdual, (size_t)nS * sizeof(double), (size_t)n * sizeof(double), n,
+                            hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
 }
 
 // ------------------------------------------------------------------ measurement

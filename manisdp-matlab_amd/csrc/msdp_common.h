@@ -150,6 +150,10 @@ struct msdp_handle_s {
     unsigned long long* lz_slots = nullptr;   // grid-sync slots of the persistent Lanczos kernel (uncached device memory)
     double* esc_prev = nullptr;       // sum of the bottom eigenvectors found by the previous escape call (warm start)
     int esc_prev_n = 0;
+    // outcome of the last escape call (msdp_escape_info): real pairs returned, every Lanczos run passed a stop test,
+    // largest relative residual |S x - theta x| / max(|theta|, |lam_max|) among the runs that hit maxit instead
+    int esc_nvalid = 0, esc_converged = 0;
+    double esc_maxres = 0.0;
     // persistent tCG kernel (msdp_persist.hip): grid-sync slots, error flag, cached eligibility
     unsigned long long* psync_slots = nullptr;
     int* psync_err = nullptr;

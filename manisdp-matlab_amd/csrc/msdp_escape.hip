@@ -379,7 +379,7 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
                             double* dalpha, double* dbeta, int maxit, double tol, unsigned seed,
                             double* theta_out, double* res_out, double* lmax_out, double* x_out, int* m_out,
                             int kwant = 1, int* nacc_out = nullptr, double* thetas_out = nullptr,
-                            double* xstart = nullptr, bool* have_xstart = nullptr) {
+                            double* xstart = nullptr, bool* have_xstart = nullptr, bool* conv_out = nullptr) {
     msdp_handle h = c.h;
     const int n = c.n;
     const dim3 gr((n + 255) / 256), bl(256);
@@ -406,6 +406,7 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
     std::vector<double> a, b, s;
     int m = 0, next_check = 32;
     double theta = 0.0, res = 1e300, lmax = 0.0;
+    bool converged = false;          // one of the three stop tests passed (else the run ended at maxit: theta is only an upper bound)
     const bool persist = !c.M && c.slots && msdp_lanczos_persist_ok(h, nq);
     static int no_fused_small = -1;
     if (no_fused_small < 0) { const char* e = getenv("MSDP_LZ_NO_FUSED"); no_fused_small = (e && atoi(e)) ? 1 : 0; }
@@ -480,6 +481,7 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
             const bool breakdown = b[m] <= 1e-14 * scale;
             if (res <= tol * scale || theta - res > -tol * scale || breakdown) {
                 if (m > 1024) lmax = tri_eig_kth(a, off, m, m - 1, glo, ghi);
+                converged = true;
                 break;
             }
             // doubling up to 1024 steps, then x1.5, x1.25 from 2048 on: a late checkpoint wastes steps, an early one costs a host analysis
@@ -585,6 +587,7 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
     (void)hipFree(sdev);
     if (rc) return rc;
     if (nacc_out) *nacc_out = nacc;
+    if (conv_out) *conv_out = converged;
     *theta_out = theta; *res_out = res; *lmax_out = lmax; *m_out = m;
     return 0;
 }
@@ -688,13 +691,19 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
             ESC_HIP(hipMemcpyAsync(Z, h->esc_prev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
             have_xstart = true;
         }
+        h->esc_converged = 1; h->esc_maxres = 0.0; h->esc_nvalid = 0;
         for (int t = 0; t < k;) {
             double theta, res, lmx; int m, nacc = 1;
             double thetas[64];
             double* x = Q + (size_t)r * n;
+            bool conv = false;
             ESC_CHECK(lanczos_smallest(c, Q, r, V, w, dalpha, dbeta, maxit, tol, 12345u + 7919u * t, &theta, &res, &lmx, x, &m,
-                                       std::min(k - t, 64), &nacc, thetas, Z, &have_xstart));
+                                       std::min(k - t, 64), &nacc, thetas, Z, &have_xstart, &conv));
             total_steps += m;
+            if (!conv) {
+                h->esc_converged = 0;
+                h->esc_maxres = std::max(h->esc_maxres, res / (std::max(fabs(theta), fabs(lmx)) + 1e-300));
+            }
             if (getenv("MSDP_ESC_DEBUG")) fprintf(stderr, "[escape] run at t=%d: nq=%d steps=%d theta=%.6e res=%.2e lmax=%.4f accepted=%d\n", t, r, m, theta, res, lmx, nacc);
             lam_max = std::max(lam_max, lmx);
             for (int i = 0; i < nacc; ++i) found.push_back(thetas[i]);
@@ -746,10 +755,13 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
                 ESC_HIP(hipMemcpyAsync(V_out + (size_t)t * n, w, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
                 ESC_HIP(hipStreamSynchronize(h->stream));
             } else {
-                lam_out[t] = (nout > 0) ? lam_out[nout - 1] : 0.0;
+                // fewer than k Ritz pairs exist: +inf marks the missing values (never counted as negative) and the
+                // vectors are zero; msdp_escape_info reports how many pairs are real
+                lam_out[t] = INFINITY;
                 memset(V_out + (size_t)t * n, 0, n * sizeof(double));
             }
         }
+        h->esc_nvalid = nout;
         (void)ry; (void)nfound;
         if (dbg) {
             auto tp3 = std::chrono::steady_clock::now();

@@ -1,192 +1,282 @@
 // manisdp_mex.cpp -- thin MEX gateway over the C ABI of libmanisdp_hip.so (include/manisdp_hip.h).
 //
-// Follows the only native-call convention the reference has (src/C-files/<fn>.cpp: plain
-// mexFunction entry, double data via mxGetPr, errors via mexErrMsgIdAndTxt("MyToolbox:<fn>:...")).
-// One gateway, string-dispatched:
+// Follows the only native-call convention the reference has (src/C-files/innerc.cpp:3-33: plain
+// mexFunction entry, double data via mxGetPr, argument-count checks and errors through
+// mexErrMsgIdAndTxt("<toolbox>:<fn>:<what>", ...)).  One gateway, string-dispatched:
 //
-//   h   = manisdp_mex('create_onlyunitdiag', C)              % C sparse or dense n x n double
-//   h   = manisdp_mex('create_unitdiag',  At, b, c, n)       % At sparse n^2 x m, b/c sparse or dense
-//   h   = manisdp_mex('create_unittrace', At, b, c, n)
-//   h   = manisdp_mex('create_generic', At, b, c, n)          (ManiSDP.m, Euclidean manifold; Y is n x p)
-//         manisdp_mex('set_multipliers', h, y, sigma)
-//   [Y, info] = manisdp_mex('rtr', h, Y, opts)               % opts: struct with maxiter,maxinner,tolgradnorm
-//   val = manisdp_mex('linesearch_cost', h, Y, U, alpha)     % co(retr(Y + alpha U))
-//   z   = manisdp_mex('get_z', h)
-//   [lam, V, lmax] = manisdp_mex('escape_eigs', h, k, tol, maxit)
-//   [obj, Ax]      = manisdp_mex('al_primal', h, m)          % affine kinds: c'x and A*x at the resident point
-//   z              = manisdp_mex('al_dual', h, y)            % builds S = eS - diag(z) | eS - z*I | eS on the device
-//   [lam, V, lmax] = manisdp_mex('escape_eigs_dual', h, k, tol, maxit)
-//         manisdp_mex('destroy', h)
+//   h = manisdp_mex('create_onlyunitdiag', C)            C sparse or dense n x n double
+//   h = manisdp_mex('create_unitdiag',  At, b, c, n)     At sparse n^2 x m; b, c sparse or dense
+//   h = manisdp_mex('create_unittrace', At, b, c, n)
+//   h = manisdp_mex('create_generic',   At, b, c, n)
+//       manisdp_mex('set_multipliers', h, y, sigma)
+//       manisdp_mex('set_point', h, Y)                   Y in the reference layout of the handle's kind
+//   Y = manisdp_mex('get_point', h)
+//   info = manisdp_mex('rtr', h, opts)                   trustregions() on the resident point; opts.maxiter/maxinner/tolgradnorm
+//   v = manisdp_mex('linesearch_cost', h, U, alpha)      co(retr(Y + alpha*U)); alpha = 0 (U may be []) gives co(Y)
+//       manisdp_mex('linesearch_accept', h)
+//   z = manisdp_mex('get_z', h)                          onlyunitdiag: 1 x n
+//   [lam, V, lmax, ok] = manisdp_mex('escape_eigs', h, k, tol, maxit)
+//   [obj, Ax] = manisdp_mex('al_primal', h)
+//   z = manisdp_mex('al_dual', h, y)                     n x 1 (unitdiag), scalar (unittrace), [] (generic)
+//   [lam, V, lmax, ok] = manisdp_mex('escape_eigs_dual', h, k, tol, maxit)
+//   S = manisdp_mex('get_dual_slack', h)
+//   k = manisdp_mex('kind', h)
+//       manisdp_mex('destroy', h)
 //
-// Handles travel as uint64 scalars.  The library returns codes (no exceptions cross the C ABI);
-// this shim turns a non-zero code into mexErrMsgIdAndTxt after releasing its temporaries.
-// MATLAB owns every input (read-only) and every output (mxCreate*).  Not compiled in this
-// repository's CI (no MATLAB / mex.h in the build image): build with
-//   mex -R2018a manisdp_mex.cpp -I../../include -L../lib -lmanisdp_hip
+// Handles travel as uint64 scalars and are remembered here together with (kind, n, m), so the factor layout is
+// taken from the handle, never guessed from array shapes; handles still alive when MATLAB clears the MEX file are
+// destroyed by the mexAtExit hook.  The library returns codes (no exceptions cross the C ABI); this shim turns a
+// non-zero code into mexErrMsgIdAndTxt after releasing its temporaries.  MATLAB owns every input (read-only) and
+// every output (mxCreate*).
+// Build:  mex -R2018a manisdp_mex.cpp -I<repo>/include -L<repo>/manisdp-matlab_amd/lib -lmanisdp_hip
+// (tests/mex_stub/ holds a stand-in mex.h that lets the repository's own tests compile and drive this file
+//  without MATLAB; see tests/test_mex_shim.py).
+#include <cstdint>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 #include "mex.h"
 #include "matrix.h"
 #include "manisdp_hip.h"
 
-static void fail(const char* what, int rc) {
-    mexErrMsgIdAndTxt("ManiSDP:hip", "%s failed (%d): %s", what, rc, msdp_last_error());
+namespace {
+
+struct Meta { int kind; int64_t n; int64_t m; };
+std::map<uint64_t, Meta> g_live;
+bool g_exit_hooked = false;
+
+void destroy_all() {
+    for (auto& kv : g_live) msdp_destroy((msdp_handle)(uintptr_t)kv.first);
+    g_live.clear();
 }
-static msdp_handle get_handle(const mxArray* a) {
-    if (!mxIsUint64(a) || mxGetNumberOfElements(a) != 1) mexErrMsgIdAndTxt("ManiSDP:hip:handle", "handle must be a uint64 scalar");
-    return (msdp_handle)(uintptr_t)(*(uint64_t*)mxGetData(a));
+
+void fail(const char* what, int rc) {
+    mexErrMsgIdAndTxt("ManiSDP:hip:call", "%s failed (%d): %s", what, rc, msdp_last_error());
 }
-static mxArray* put_handle(msdp_handle h) {
+
+void need(bool ok, const char* usage) {
+    if (!ok) mexErrMsgIdAndTxt("ManiSDP:hip:nrhs", "usage: %s", usage);
+}
+
+uint64_t handle_key(const mxArray* a) {
+    if (!mxIsUint64(a) || mxGetNumberOfElements(a) != 1)
+        mexErrMsgIdAndTxt("ManiSDP:hip:handle", "handle must be a uint64 scalar");
+    const uint64_t key = *(const uint64_t*)mxGetData(a);
+    if (!g_live.count(key)) mexErrMsgIdAndTxt("ManiSDP:hip:handle", "unknown or already destroyed handle");
+    return key;
+}
+
+mxArray* wrap_handle(msdp_handle h, int kind, int64_t n, int64_t m) {
+    const uint64_t key = (uint64_t)(uintptr_t)h;
+    g_live[key] = Meta{kind, n, m};
+    if (!g_exit_hooked) { mexAtExit(destroy_all); g_exit_hooked = true; }
     mxArray* o = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
-    *(uint64_t*)mxGetData(o) = (uint64_t)(uintptr_t)h;
+    *(uint64_t*)mxGetData(o) = key;
     return o;
 }
-static std::vector<double> densify(const mxArray* a, size_t len) {
+
+// bqpmom.m:37-38,114-115 hand over sparse b and c, example_theta.m:9-12 dense ones
+std::vector<double> as_dense(const mxArray* a, size_t len) {
     std::vector<double> v(len, 0.0);
     if (mxIsSparse(a)) {
-        const mwIndex* ir = mxGetIr(a); const mwIndex* jc = mxGetJc(a); const double* pr = mxGetPr(a);
+        const mwIndex* ir = mxGetIr(a);
+        const mwIndex* jc = mxGetJc(a);
+        const double* pr = mxGetPr(a);
         const mwSize ncol = mxGetN(a), nrow = mxGetM(a);
-        for (mwSize j = 0; j < ncol; ++j) for (mwIndex t = jc[j]; t < jc[j + 1]; ++t) v[ir[t] + j * nrow] = pr[t];
+        for (mwSize j = 0; j < ncol; ++j)
+            for (mwIndex t = jc[j]; t < jc[j + 1]; ++t) {
+                const size_t pos = (size_t)ir[t] + (size_t)j * nrow;
+                if (pos < len) v[pos] = pr[t];
+            }
     } else {
-        memcpy(v.data(), mxGetPr(a), len * sizeof(double));
+        const size_t have = mxGetNumberOfElements(a);
+        memcpy(v.data(), mxGetPr(a), (have < len ? have : len) * sizeof(double));
     }
     return v;
 }
-static double opt_field(const mxArray* s, const char* name, double dflt) {
-    const mxArray* f = mxIsStruct(s) ? mxGetField(s, 0, name) : nullptr;
+
+double field_or(const mxArray* s, const char* name, double dflt) {
+    const mxArray* f = (s && mxIsStruct(s)) ? mxGetField(s, 0, name) : nullptr;
     return f ? mxGetScalar(f) : dflt;
 }
+
+bool factor_is_n_by_p(int kind) { return kind == MSDP_KIND_UNITTRACE || kind == MSDP_KIND_GENERIC; }
+
+// p of a factor handed over in the layout of `kind`; checks the other dimension against n
+int32_t width_of(const mxArray* Y, const Meta& me) {
+    const mwSize r = mxGetM(Y), c = mxGetN(Y);
+    if (mxIsSparse(Y)) mexErrMsgIdAndTxt("ManiSDP:hip:layout", "the factor must be a full double matrix");
+    if (factor_is_n_by_p(me.kind)) {
+        if ((int64_t)r != me.n) mexErrMsgIdAndTxt("ManiSDP:hip:layout", "expected an n x p factor with n = %d rows", (int)me.n);
+        return (int32_t)c;
+    }
+    if ((int64_t)c != me.n) mexErrMsgIdAndTxt("ManiSDP:hip:layout", "expected a p x n factor with n = %d columns", (int)me.n);
+    return (int32_t)r;
+}
+
+mxArray* new_factor(const Meta& me, int32_t p) {
+    return factor_is_n_by_p(me.kind) ? mxCreateDoubleMatrix((mwSize)me.n, (mwSize)p, mxREAL)
+                                     : mxCreateDoubleMatrix((mwSize)p, (mwSize)me.n, mxREAL);
+}
+
+typedef int (*escape_fn)(msdp_handle, int32_t, double, int32_t, double*, double*, double*, int32_t*);
+
+void run_escape(escape_fn fn, const char* name, msdp_handle h, const Meta& me, int nlhs, mxArray* plhs[],
+                int nrhs, const mxArray* prhs[]) {
+    need(nrhs == 5, "[lam, V, lmax, ok] = manisdp_mex('escape_eigs[_dual]', h, k, tol, maxit)");
+    const int32_t k = (int32_t)mxGetScalar(prhs[2]);
+    if (k < 1) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "k must be >= 1");
+    mxArray* lam = mxCreateDoubleMatrix((mwSize)k, 1, mxREAL);
+    mxArray* V = mxCreateDoubleMatrix((mwSize)me.n, (mwSize)k, mxREAL);
+    double lmax = 0.0;
+    int32_t steps = 0;
+    const int rc = fn(h, k, mxGetScalar(prhs[3]), (int32_t)mxGetScalar(prhs[4]), mxGetPr(lam), mxGetPr(V), &lmax, &steps);
+    if (rc) { mxDestroyArray(lam); mxDestroyArray(V); fail(name, rc); }
+    int32_t nvalid = 0, conv = 0;
+    double res = 0.0;
+    (void)msdp_escape_info(h, &nvalid, &conv, &res);
+    plhs[0] = lam;
+    if (nlhs > 1) plhs[1] = V; else mxDestroyArray(V);
+    if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(lmax);
+    if (nlhs > 3) plhs[3] = mxCreateDoubleScalar(conv ? 1.0 : 0.0);
+}
+
+}  // namespace
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgIdAndTxt("ManiSDP:hip:nrhs", "first argument must be a command string");
     char cmdbuf[64];
-    mxGetString(prhs[0], cmdbuf, sizeof(cmdbuf));
+    if (mxGetString(prhs[0], cmdbuf, sizeof(cmdbuf))) mexErrMsgIdAndTxt("ManiSDP:hip:cmd", "command string too long");
     const std::string cmd(cmdbuf);
+
+    // ---------------------------------------------------------------- construction
     if (cmd == "create_onlyunitdiag") {
-        if (nrhs != 2) mexErrMsgIdAndTxt("ManiSDP:hip:nrhs", "create_onlyunitdiag(C)");
+        need(nrhs == 2, "h = manisdp_mex('create_onlyunitdiag', C)");
         const mxArray* C = prhs[1];
         const int64_t n = (int64_t)mxGetM(C);
+        if ((int64_t)mxGetN(C) != n) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "C must be square");
         msdp_handle h = nullptr;
-        int rc;
-        if (mxIsSparse(C)) {
-            // MATLAB sparse = CSC with 64-bit mwIndex: exactly the library's input format
-            rc = msdp_create_onlyunitdiag_csc(n, (const int64_t*)mxGetJc(C), (const int64_t*)mxGetIr(C), mxGetPr(C), 32, &h);
-        } else {
-            rc = msdp_create_onlyunitdiag_dense(n, mxGetPr(C), 32, &h);
-        }
+        // MATLAB sparse = compressed columns with 64-bit mwIndex: the library's own input format
+        const int rc = mxIsSparse(C)
+            ? msdp_create_onlyunitdiag_csc(n, (const int64_t*)mxGetJc(C), (const int64_t*)mxGetIr(C), mxGetPr(C), 32, &h)
+            : msdp_create_onlyunitdiag_dense(n, mxGetPr(C), 32, &h);
         if (rc) fail("create_onlyunitdiag", rc);
-        plhs[0] = put_handle(h);
-    } else if (cmd == "create_unitdiag" || cmd == "create_unittrace" || cmd == "create_generic") {
-        if (nrhs != 5) mexErrMsgIdAndTxt("ManiSDP:hip:nrhs", "%s(At, b, c, n)", cmd.c_str());
+        plhs[0] = wrap_handle(h, MSDP_KIND_ONLYUNITDIAG, n, n);
+        return;
+    }
+    if (cmd == "create_unitdiag" || cmd == "create_unittrace" || cmd == "create_generic") {
+        need(nrhs == 5, "h = manisdp_mex('create_unitdiag' | 'create_unittrace' | 'create_generic', At, b, c, n)");
         const mxArray* At = prhs[1];
-        if (!mxIsSparse(At)) mexErrMsgIdAndTxt("ManiSDP:hip:At", "At must be sparse (n^2 x m)");
+        if (!mxIsSparse(At)) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "At must be sparse (n^2 x m)");
         const int64_t n = (int64_t)mxGetScalar(prhs[4]);
         const int64_t m = (int64_t)mxGetN(At);
-        std::vector<double> b = densify(prhs[2], (size_t)m);          // bqpmom.m:37 gives a sparse b
-        std::vector<double> c = densify(prhs[3], (size_t)n * n);      // bqpmom.m:115 gives a sparse c
-        msdp_handle h = nullptr;
+        if ((int64_t)mxGetM(At) != n * n) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "At must have n^2 rows");
+        const std::vector<double> b = as_dense(prhs[2], (size_t)m);
+        const std::vector<double> c = as_dense(prhs[3], (size_t)n * n);
         const int kind = cmd == "create_unitdiag" ? MSDP_KIND_UNITDIAG
-                         : (cmd == "create_generic" ? MSDP_KIND_GENERIC : MSDP_KIND_UNITTRACE);
-        int rc = msdp_create_affine(kind, n, m, (const int64_t*)mxGetJc(At), (const int64_t*)mxGetIr(At), mxGetPr(At),
-                                    b.data(), c.data(), 32, &h);
+                         : (cmd == "create_unittrace" ? MSDP_KIND_UNITTRACE : MSDP_KIND_GENERIC);
+        msdp_handle h = nullptr;
+        const int rc = msdp_create_affine(kind, n, m, (const int64_t*)mxGetJc(At), (const int64_t*)mxGetIr(At), mxGetPr(At),
+                                          b.data(), c.data(), 32, &h);
         if (rc) fail(cmd.c_str(), rc);
-        plhs[0] = put_handle(h);
+        plhs[0] = wrap_handle(h, kind, n, m);
+        return;
+    }
+
+    // ---------------------------------------------------------------- everything else takes a handle
+    need(nrhs >= 2, "manisdp_mex(command, h, ...)");
+    const uint64_t key = handle_key(prhs[1]);
+    const Meta me = g_live[key];
+    msdp_handle h = (msdp_handle)(uintptr_t)key;
+
+    if (cmd == "destroy") {
+        g_live.erase(key);
+        msdp_destroy(h);
+    } else if (cmd == "kind") {
+        int32_t k = 0;
+        const int rc = msdp_get_kind(h, &k);
+        if (rc) fail("get_kind", rc);
+        plhs[0] = mxCreateDoubleScalar((double)k);
     } else if (cmd == "set_multipliers") {
-        msdp_handle h = get_handle(prhs[1]);
-        int rc = msdp_set_multipliers(h, mxGetPr(prhs[2]), mxGetScalar(prhs[3]));
+        need(nrhs == 4, "manisdp_mex('set_multipliers', h, y, sigma)");
+        if ((int64_t)mxGetNumberOfElements(prhs[2]) != me.m) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "y must have m entries");
+        const int rc = msdp_set_multipliers(h, mxGetPr(prhs[2]), mxGetScalar(prhs[3]));
         if (rc) fail("set_multipliers", rc);
+    } else if (cmd == "set_point") {
+        need(nrhs == 3, "manisdp_mex('set_point', h, Y)");
+        const int32_t p = width_of(prhs[2], me);
+        const int rc = msdp_set_point(h, p, mxGetPr(prhs[2]));
+        if (rc) fail("set_point", rc);
+    } else if (cmd == "get_point") {
+        int32_t p = 0;
+        int rc = msdp_get_p(h, &p);
+        if (rc) fail("get_p", rc);
+        mxArray* Y = new_factor(me, p);
+        rc = msdp_get_point(h, mxGetPr(Y));
+        if (rc) { mxDestroyArray(Y); fail("get_point", rc); }
+        plhs[0] = Y;
     } else if (cmd == "rtr") {
-        // [Y, info] = rtr(h, Y, opts): Y in the reference layout (p x n for the oblique kinds, n x p for unittrace)
-        msdp_handle h = get_handle(prhs[1]);
-        const mxArray* Y = prhs[2];
-        int32_t p_old = 0;
-        (void)msdp_get_p(h, &p_old);
+        need(nrhs == 3, "info = manisdp_mex('rtr', h, opts)");
         msdp_rtr_opts o;
         msdp_rtr_default_opts(&o);
-        o.maxiter = (int32_t)opt_field(prhs[3], "maxiter", o.maxiter);
-        o.maxinner = (int32_t)opt_field(prhs[3], "maxinner", o.maxinner);
-        o.tolgradnorm = opt_field(prhs[3], "tolgradnorm", o.tolgradnorm);
-        const bool colmajor_np = opt_field(prhs[3], "unittrace", 0.0) != 0.0;
-        const int32_t p = (int32_t)(colmajor_np ? mxGetN(Y) : mxGetM(Y));
-        plhs[0] = mxDuplicateArray(Y);
+        o.maxiter = (int32_t)field_or(prhs[2], "maxiter", o.maxiter);          // opts of ManiSDP_unitdiag.m:44-47
+        o.maxinner = (int32_t)field_or(prhs[2], "maxinner", o.maxinner);
+        o.tolgradnorm = field_or(prhs[2], "tolgradnorm", o.tolgradnorm);
         msdp_rtr_stats st;
-        int rc = msdp_rtr_host(h, p, mxGetPr(plhs[0]), &o, &st);
-        if (rc) { mxDestroyArray(plhs[0]); fail("rtr", rc); }
-        if (nlhs > 1) {
-            const char* fields[] = {"gradnorm", "cost", "iters", "hessvecs", "accepted", "rejected", "seconds"};
-            plhs[1] = mxCreateStructMatrix(1, 1, 7, fields);
-            mxSetField(plhs[1], 0, "gradnorm", mxCreateDoubleScalar(st.gradnorm));
-            mxSetField(plhs[1], 0, "cost", mxCreateDoubleScalar(st.cost));
-            mxSetField(plhs[1], 0, "iters", mxCreateDoubleScalar(st.iters));
-            mxSetField(plhs[1], 0, "hessvecs", mxCreateDoubleScalar(st.hessvecs));
-            mxSetField(plhs[1], 0, "accepted", mxCreateDoubleScalar(st.accepted));
-            mxSetField(plhs[1], 0, "rejected", mxCreateDoubleScalar(st.rejected));
-            mxSetField(plhs[1], 0, "seconds", mxCreateDoubleScalar(st.seconds));
-        }
+        const int rc = msdp_rtr(h, &o, &st);
+        if (rc) fail("rtr", rc);
+        const char* names[] = {"gradnorm", "cost", "iters", "hessvecs", "accepted", "rejected", "seconds"};
+        const double vals[] = {st.gradnorm, st.cost, (double)st.iters, (double)st.hessvecs, (double)st.accepted,
+                               (double)st.rejected, st.seconds};
+        plhs[0] = mxCreateStructMatrix(1, 1, 7, names);
+        for (int i = 0; i < 7; ++i) mxSetField(plhs[0], 0, names[i], mxCreateDoubleScalar(vals[i]));
     } else if (cmd == "linesearch_cost") {
-        msdp_handle h = get_handle(prhs[1]);
-        int32_t p = 0;
-        const mxArray* Y = prhs[2];
-        const bool np_layout = mxGetM(Y) > mxGetN(Y);      // n x p (unittrace) vs p x n
-        p = (int32_t)(np_layout ? mxGetN(Y) : mxGetM(Y));
-        int rc = msdp_set_point(h, p, mxGetPr(Y));
-        if (rc) fail("set_point", rc);
+        need(nrhs == 4, "v = manisdp_mex('linesearch_cost', h, U, alpha)");
+        const double alpha = mxGetScalar(prhs[3]);
+        const double* U = nullptr;
+        if (alpha != 0.0) {
+            int32_t p = 0;
+            (void)msdp_get_p(h, &p);
+            if (width_of(prhs[2], me) != p) mexErrMsgIdAndTxt("ManiSDP:hip:layout", "U must have the width of the resident point");
+            U = mxGetPr(prhs[2]);
+        }
         double v = 0.0;
-        rc = msdp_linesearch_cost(h, mxGetPr(prhs[3]), mxGetScalar(prhs[4]), &v);
+        const int rc = msdp_linesearch_cost(h, U, alpha, &v);
         if (rc) fail("linesearch_cost", rc);
         plhs[0] = mxCreateDoubleScalar(v);
+    } else if (cmd == "linesearch_accept") {
+        const int rc = msdp_linesearch_accept(h);
+        if (rc) fail("linesearch_accept", rc);
     } else if (cmd == "get_z") {
-        msdp_handle h = get_handle(prhs[1]);
-        int64_t r0 = 0, r1 = 0;
-        (void)msdp_local_rows(h, &r0, &r1);
-        plhs[0] = mxCreateDoubleMatrix(1, (mwSize)r1, mxREAL);
-        int rc = msdp_get_z(h, mxGetPr(plhs[0]));
-        if (rc) fail("get_z", rc);
+        mxArray* z = mxCreateDoubleMatrix(1, (mwSize)me.n, mxREAL);
+        const int rc = msdp_get_z(h, mxGetPr(z));
+        if (rc) { mxDestroyArray(z); fail("get_z", rc); }
+        plhs[0] = z;
     } else if (cmd == "escape_eigs") {
-        msdp_handle h = get_handle(prhs[1]);
-        const int32_t k = (int32_t)mxGetScalar(prhs[2]);
-        int64_t r0 = 0, r1 = 0;
-        (void)msdp_local_rows(h, &r0, &r1);
-        plhs[0] = mxCreateDoubleMatrix(k, 1, mxREAL);
-        mxArray* V = mxCreateDoubleMatrix((mwSize)r1, k, mxREAL);
-        double lmax = 0.0;
-        int32_t its = 0;
-        int rc = msdp_escape_eigs(h, k, mxGetScalar(prhs[3]), (int32_t)mxGetScalar(prhs[4]), mxGetPr(plhs[0]), mxGetPr(V), &lmax, &its);
-        if (rc) { mxDestroyArray(V); fail("escape_eigs", rc); }
-        if (nlhs > 1) plhs[1] = V; else mxDestroyArray(V);
-        if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(lmax);
+        run_escape(msdp_escape_eigs, "escape_eigs", h, me, nlhs, plhs, nrhs, prhs);
+    } else if (cmd == "escape_eigs_dual") {
+        run_escape(msdp_escape_eigs_dual, "escape_eigs_dual", h, me, nlhs, plhs, nrhs, prhs);
     } else if (cmd == "al_primal") {
-        msdp_handle h = get_handle(prhs[1]);
-        const mwSize m = (mwSize)mxGetScalar(prhs[2]);
         double obj = 0.0;
-        mxArray* Ax = mxCreateDoubleMatrix(m, 1, mxREAL);
-        int rc = msdp_al_primal(h, &obj, mxGetPr(Ax));
+        mxArray* Ax = mxCreateDoubleMatrix((mwSize)me.m, 1, mxREAL);
+        const int rc = msdp_al_primal(h, &obj, mxGetPr(Ax));
         if (rc) { mxDestroyArray(Ax); fail("al_primal", rc); }
         plhs[0] = mxCreateDoubleScalar(obj);
         if (nlhs > 1) plhs[1] = Ax; else mxDestroyArray(Ax);
     } else if (cmd == "al_dual") {
-        msdp_handle h = get_handle(prhs[1]);
-        int64_t r0 = 0, r1 = 0;
-        (void)msdp_local_rows(h, &r0, &r1);
-        plhs[0] = mxCreateDoubleMatrix((mwSize)r1, 1, mxREAL);      // unit trace / generic: only z(1) is meaningful
-        int rc = msdp_al_dual(h, mxGetPr(prhs[2]), mxGetPr(plhs[0]));
-        if (rc) fail("al_dual", rc);
-    } else if (cmd == "escape_eigs_dual") {
-        msdp_handle h = get_handle(prhs[1]);
-        const int32_t k = (int32_t)mxGetScalar(prhs[2]);
-        int64_t r0 = 0, r1 = 0;
-        (void)msdp_local_rows(h, &r0, &r1);
-        plhs[0] = mxCreateDoubleMatrix(k, 1, mxREAL);
-        mxArray* V = mxCreateDoubleMatrix((mwSize)r1, k, mxREAL);
-        double lmax = 0.0;
-        int32_t its = 0;
-        int rc = msdp_escape_eigs_dual(h, k, mxGetScalar(prhs[3]), (int32_t)mxGetScalar(prhs[4]), mxGetPr(plhs[0]), mxGetPr(V), &lmax, &its);
-        if (rc) { mxDestroyArray(V); fail("escape_eigs_dual", rc); }
-        if (nlhs > 1) plhs[1] = V; else mxDestroyArray(V);
-        if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(lmax);
-    } else if (cmd == "destroy") {
-        msdp_destroy(get_handle(prhs[1]));
+        need(nrhs == 3, "z = manisdp_mex('al_dual', h, y)");
+        if ((int64_t)mxGetNumberOfElements(prhs[2]) != me.m) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "y must have m entries");
+        const mwSize zlen = me.kind == MSDP_KIND_UNITDIAG ? (mwSize)me.n : (me.kind == MSDP_KIND_UNITTRACE ? 1 : 0);
+        mxArray* z = mxCreateDoubleMatrix(zlen, zlen ? 1 : 0, mxREAL);
+        const int rc = msdp_al_dual(h, mxGetPr(prhs[2]), zlen ? mxGetPr(z) : nullptr);
+        if (rc) { mxDestroyArray(z); fail("al_dual", rc); }
+        plhs[0] = z;
+    } else if (cmd == "get_dual_slack") {
+        mxArray* S = mxCreateDoubleMatrix((mwSize)me.n, (mwSize)me.n, mxREAL);
+        const int rc = msdp_get_dual_slack(h, mxGetPr(S));
+        if (rc) { mxDestroyArray(S); fail("get_dual_slack", rc); }
+        plhs[0] = S;
     } else {
         mexErrMsgIdAndTxt("ManiSDP:hip:cmd", "unknown command '%s'", cmd.c_str());
     }

@@ -58,9 +58,15 @@ def _rtr_opts(o):
                              tolgradnorm=float(o["tolgradnorm"]))
 
 
+_RANK_CUT_SVD = False
+
+
 def _thin_svd_rank(Y, theta):
     """svd(Y) and r = sum(e >= theta*e(1)) (ManiSDP_onlyunitdiag.m:52-54) through the
     p x p Gram matrix: never forms the n x n V of the reference."""
+    if _RANK_CUT_SVD:
+        _, e, Qt = np.linalg.svd(Y, full_matrices=False)
+        return Qt.T, e, int(np.sum(e >= theta * e[0]))
     G = Y.T @ Y
     w, Q = np.linalg.eigh(G)
     order = np.argsort(w)[::-1]
@@ -85,6 +91,23 @@ def _extreme_eigs_host(S, k, dense_max):
         dS, vS = np.linalg.eigh(Sd)
         return dS, vS, int(np.sum(dS < 0))
     raise RuntimeError("host eigensolver limit exceeded; use the device escape (options['eig'] = 'device')")
+
+
+def _device_escape(h, run, o, data, default_tol, default_maxit):
+    """One device escape call (``run(tol, maxit)`` -> lam, V, lam_max, steps) with the convergence contract of
+    ``msdp_escape_info``: a Lanczos run that hit ``maxit`` only bounds lambda_min from above, so it is repeated
+    once with four times the step budget; ``certified`` tells the AL loop whether dinf may end the solve."""
+    tol = float(o.get("eig_tol", default_tol))
+    maxit = int(o.get("eig_maxit", default_maxit))
+    lam, vS, lam_max, _ = run(tol, maxit)
+    nvalid, conv, res = h.escape_info()
+    if not conv:
+        data["eig_retries"] = data.get("eig_retries", 0) + 1
+        lam, vS, lam_max, _ = run(tol, 4 * maxit)
+        nvalid, conv, res = h.escape_info()
+    if not conv:
+        data["eig_unconverged"] = data.get("eig_unconverged", 0) + 1
+    return lam, vS, lam_max, nvalid, conv
 
 
 # =============================================================== onlyunitdiag
@@ -128,6 +151,7 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
     dinf0 = None
     obj = dinf = gradnorm = None
     z = S = None
+    certified = True
     try:
         for it in range(1, int(o["AL_maxiter"]) + 1):      # :38
             h.set_point(Y)
@@ -143,6 +167,7 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
             z = h.get_z()                                  # :46-47  z = sum((Y*C).*Y)
             obj = float(np.sum(z))                         # :48
             t1 = time.time()
+            certified = True
             if eig_mode == "host":
                 S = (Csp - sp.diags(z)) if sp.issparse(Csp) else (Csp - np.diag(z))   # :49
                 dS, vS, nneg = _extreme_eigs_host(S, int(o["delta"]), dense_max)     # :50
@@ -159,10 +184,10 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
                 nneg = int(np.sum(lam < 0))
             else:
                 k = int(o["delta"])
-                lam, vS, lam_max, _ = h.escape_eigs(k, tol=float(o.get("eig_tol", 1e-9)),
-                                                    maxit=int(o.get("eig_maxit", 60000)))
+                lam, vS, lam_max, _, certified = _device_escape(
+                    h, lambda tol, maxit: h.escape_eigs(k, tol=tol, maxit=maxit), o, data, 1e-9, 60000)
                 lam_min = lam[0]
-                nneg = int(np.sum(lam < 0))
+                nneg = int(np.sum(lam < 0))            # missing pairs come back as +inf
                 S = None
             data["eig_seconds"] += time.time() - t1
             dinf = max(0.0, -lam_min) / (1.0 + lam_max)    # :51
@@ -171,7 +196,7 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
                  % (it, obj, dinf, r, p, time.time() - t0))
             data["log"].append((it, obj, dinf, r, p, time.time() - t0, st.hessvecs))
             data["iters"] = it
-            if dinf < o["tol"]:                            # :57-60
+            if dinf < o["tol"] and certified:              # :57-60 (an unconverged Lanczos run certifies nothing)
                 _say(verbose, "Optimality is reached!")
                 break
             if it % 20 == 0:                               # :61-69
@@ -199,7 +224,7 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
                  "time": time.time() - t0, "p": Y.shape[1]})
     if n <= dense_X_max:
         data["X"] = Y @ Y.T                                # :45,86
-    if data["status"] == 0 and dinf > o["tol"]:            # :92-95
+    if data["status"] == 0 and (dinf > o["tol"] or not certified):   # :92-95
         data["status"] = 1
         _say(verbose, "Iteration maximum is reached!")
     _say(verbose, "ManiSDP: optimum = %0.8f, time = %0.2fs" % (obj, time.time() - t0))
@@ -274,6 +299,7 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
     obj = gap = pinf = dinf = gradnorm = eta_kkt = None
     S = z = None
     slow_every, slow_after = (20, 50) if (sphere or generic) else (50, 100)
+    certified = True
     try:
         for it in range(1, int(o["AL_maxiter"]) + 1):
             fac_size.append(p)
@@ -289,6 +315,7 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
             gradnorm = st.gradnorm
             Y = h.get_point()
             dev_al = (eig_mode == "device") and bool(o.get("device_al", True))
+            certified = True
             if dev_al:
                 # obj, A x, eS, z and S from the device kernels (no n x n work on the host)
                 obj, Ax = h.al_primal(b.size)              # :59-61
@@ -305,8 +332,9 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
                 else:
                     z = zz
                     by = float(b @ y) + float(np.sum(z))
-                lam, vS, lam_max, _ = h.escape_eigs_dual(int(o["delta"]), tol=float(o.get("eig_tol", 1e-10)),
-                                                         maxit=int(o.get("eig_maxit", 20000)))   # :68
+                lam, vS, lam_max, _, certified = _device_escape(
+                    h, lambda tol, maxit: h.escape_eigs_dual(int(o["delta"]), tol=tol, maxit=maxit), o, data,
+                    1e-10, 20000)                          # :68
                 dS = np.concatenate([lam, [lam_max]])
                 S = None
                 data["eig_seconds"] += time.time() - t1
@@ -336,8 +364,9 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
                 pass
             elif eig_mode == "device":
                 # few-eigenvector escape on the device instead of the O(n^3) eig(S) of :68
-                lam, vS, lam_max, _ = h.escape_eigs_matrix(S, int(o["delta"]), tol=float(o.get("eig_tol", 1e-10)),
-                                                           maxit=int(o.get("eig_maxit", 20000)))
+                lam, vS, lam_max, _, certified = _device_escape(
+                    h, lambda tol, maxit: h.escape_eigs_matrix(S, int(o["delta"]), tol=tol, maxit=maxit), o, data,
+                    1e-10, 20000)
                 dS = np.concatenate([lam, [lam_max]])      # dS[0] = lambda_min ... dS[-1] = lambda_max
                 data["eig_seconds"] += time.time() - t1
             else:
@@ -351,7 +380,9 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
             data["log"].append((it, obj, gap, pinf, dinf, gradnorm, r, p, sigma, time.time() - t0))
             eta_kkt = max(gap, pinf, dinf)                 # :77
             data["iters"] = it
-            if eta_kkt < o["tol"]:
+            if "iter_hook" in o:                           # diagnostics (tools/): sees the loop's local state
+                o["iter_hook"](locals())
+            if eta_kkt < o["tol"] and certified:
                 _say(verbose, "Optimality is reached!")
                 break
             if it % slow_every == 0:                       # unitdiag :82-92 / unittrace :86-96
@@ -392,7 +423,7 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
                  "gradnorm": gradnorm, "time": time.time() - t0, "sigma": sigma})
     if not sphere and not generic:
         data["fac_size"] = fac_size
-    if data["status"] == 0 and eta_kkt > o["tol"]:
+    if data["status"] == 0 and (eta_kkt > o["tol"] or not certified):
         data["status"] = 1
         _say(verbose, "Iteration maximum is reached!")
     _say(verbose, "ManiSDP: optimum = %0.8f, time = %0.2fs" % (obj, time.time() - t0))
