@@ -50,6 +50,29 @@ def cpu_baseline(C, Y0, budget_s=15.0):
                       f"evaluations) of the same G81 p={Y0.shape[1]} step in the C/OpenMP oracle, {dt:.1f} s"}
 
 
+def cpu_dense_hessvec(n, p, budget_s=3.0):
+    """The oracle's dense-C Hess-vec (ManiSDP_onlyunitdiag.m:127-130 restated in NumPy: one dgemm + the projection
+    terms) on this box's host cores, same shape, random symmetric C."""
+    from oracle import manisdp_ref
+    rng = np.random.default_rng(0)
+    C = rng.standard_normal((n, n)); C = (C + C.T) / (2.0 * np.sqrt(n))
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    manisdp_ref.hessvec_onlyunitdiag(C, Y, U)
+    t0 = time.time(); reps = 0
+    while time.time() - t0 < budget_s:
+        manisdp_ref.hessvec_onlyunitdiag(C, Y, U)
+        reps += 1
+    dt = (time.time() - t0) / reps
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:                                     # pragma: no cover
+        cores = os.cpu_count()
+    return {"value": 1.0 / dt, "unit": "Hess-vec/s", "cores": cores, "kind": "port",
+            "sample": "%d NumPy (BLAS dgemm) Hess-vecs of the oracle, dense C n=%d p=%d" % (reps, n, p)}
+
+
 def main():
     # stdout carries exactly ONE line (the JSON result of rank 0).  Native libraries print there too (RCCL's version
     # banner with NCCL_DEBUG=VERSION arrives from C stdio at exit, i.e. after the JSON line), so file descriptor 1 is
@@ -156,26 +179,33 @@ def main():
     trip_ms = h.bench_tcg_trip(512)
     persistent = (N == 1 and h.tcg_path() == 1)
     hess_achieved = abytes / (ms * 1e-3) / 1e9
-    # algorithmic traffic of one trip: the Hess-vec + ~10 passes over an n x p vector for
-    # tCG.m:166-287 (eta, Heta, r, mdelta updates and the tangent re-projection)
-    trip_bytes = abytes + 10.0 * n * p * 8
-    trip_achieved = trip_bytes / (trip_ms * 1e-3) / 1e9
+    # the algorithmic traffic of the path is that of the S*U (ehess) product, `abytes` per Hess-vec;
+    # one tCG trip = one Hess-vec.  For the persistent kernel (one launch = all trips of a solve) bytes and time are
+    # quoted per trip: achieved = abytes / trip time.  The streaming three-kernel formulation of a trip would move
+    # abytes + ~10 n*p*8 (tCG.m:166-287); that figure is kept as a labelled extra, it is NOT the roofline number.
+    trip_achieved = abytes / (trip_ms * 1e-3) / 1e9
+    streaming_trip_bytes = abytes + 10.0 * n * p * 8
 
-    def pmc(name):
-        f = os.path.join(ROOT, "profiles", name)
-        if N == 1 and p == 32 and os.path.exists(f):
-            return json.load(open(f))
+    def pmc(*names):
+        for name in names:
+            f = os.path.join(ROOT, "profiles", name)
+            if N == 1 and p == 32 and os.path.exists(f):
+                return json.load(open(f))
         return None
-    pm_h, pm_t = pmc("r1_pmc_hess_g81_p32.json"), pmc("r1_pmc_persist_g81_p32.json")
+    pm_h = pmc("r2_pmc_hess_g81_p32.json", "r1_pmc_hess_g81_p32.json")
+    pm_t = pmc("r2_pmc_persist_g81_p32.json", "r1_pmc_persist_g81_p32.json")
     if persistent:
+        traffic = (pm_t or {}).get("hbm_bytes_per_trip")
         roofline = {"bound": "hbm", "achieved": trip_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": trip_achieved / HBM_PEAK_GBS,
-                    "traffic": (pm_t or {}).get("hbm_bytes_per_trip"),
+                    "frac": trip_achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "kernel": "k_tcg_persist_obl", "kernel_us": trip_ms * 1e3, "per": "tCG trip (one Hess-vec)",
-                    "algorithmic_bytes_per_launch": trip_bytes,
-                    "note": "one launch runs all trips of a tCG solve; bytes and time are per trip. The working set is "
-                            "register/LDS resident, so the kernel is bound by its three grid synchronisations per trip, "
-                            "not by HBM: measured traffic is far below the algorithmic bytes of the streaming formulation"}
+                    "algorithmic_bytes_per_launch": abytes,
+                    "streaming_formulation_bytes_per_trip": streaming_trip_bytes,
+                    "streaming_equivalent_GBps": streaming_trip_bytes / (trip_ms * 1e-3) / 1e9,
+                    "note": "one launch runs all trips of a solve; bytes, traffic and time are per trip.  The working "
+                            "set is register/LDS resident and the trip is bound by its three grid-wide synchronisations "
+                            "(~1.7 us each), not by HBM: the fraction of the HBM roofline is therefore low by "
+                            "construction at n*p*8 = 5 MB per vector"}
     else:
         roofline = {"bound": "hbm", "achieved": hess_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hess_achieved / HBM_PEAK_GBS, "traffic": (pm_h or {}).get("hbm_bytes_per_launch"),
@@ -224,7 +254,8 @@ def main():
         # fp64 MFMA and HBM fractions on the dense-C shapes of BASELINE configs 4 / 5 (synthetic symmetric C, seed 0).
         MFMA_F64_TFLOPS = 78.6                      # MI355X_MICROARCH.md: dense fp64 matrix peak
         dense = []
-        for (dn, dp) in ((5000, 32), (5000, 64)):
+        # n = 20000, p = 32 is the shape north_star's ">= 60 % of the HBM roofline on the S*Y / ehess kernel" names
+        for (dn, dp) in ((5000, 32), (5000, 64), (20000, 16), (20000, 32), (20000, 64)):
             hd = _lib.Handle.dense_synthetic(dn, 0, pcap=dp)
             rngd = np.random.default_rng(0)
             Yd = rngd.standard_normal((dn, dp)); Yd /= np.linalg.norm(Yd, axis=1, keepdims=True)
@@ -232,9 +263,13 @@ def main():
             for _ in range(2):
                 msd, byd, fld = hd.bench_hessvec(100)
             hd.close()
-            dense.append({"n": dn, "p": dp, "kernel": "k_dense_partial3 + k_dense_hess_epi_obl", "hessvec_us": msd * 1e3,
-                          "TFLOPs_f64": fld / msd / 1e9, "frac_mfma_f64_peak": fld / msd / 1e9 / MFMA_F64_TFLOPS,
-                          "GBps": byd / msd / 1e6, "frac_hbm_peak": byd / msd / 1e6 / HBM_PEAK_GBS})
+            ent = {"n": dn, "p": dp, "kernel": "k_dense_partial3 + k_dense_hess_epi_obl", "hessvec_us": msd * 1e3,
+                   "algorithmic_bytes": byd, "algorithmic_flops": fld,
+                   "TFLOPs_f64": fld / msd / 1e9, "frac_mfma_f64_peak": fld / msd / 1e9 / MFMA_F64_TFLOPS,
+                   "GBps": byd / msd / 1e6, "frac_hbm_peak": byd / msd / 1e6 / HBM_PEAK_GBS}
+            if dn == 5000 and not args.no_cpu_baseline:
+                ent["cpu_baseline"] = cpu_dense_hessvec(dn, dp)
+            dense.append(ent)
         # config 5 per-GPU shard: rank 0 of 8 of the n = 100 000 problem (12 500 x 100 000 rows of C = 10 GB, generated on the
         # device), p = 64; the full direction is supplied locally instead of by the all-gather
         try:

@@ -43,6 +43,13 @@ struct AffineDev {
     const double* cv;
     const int* rp;         // n*n+1 row pointers (CSR by matrix entry r = i*n + j)
     const int* cidx;       // i*nS + j of each nonzero: position in the dense Gram matrix W = Ya*Yb' (Gram route)
+    // symmetric data: the same constraints over their entries i <= j only (coefficient halved on the diagonal), for the
+    // Gram route on Wsym = Ya*Yb' + Yb*Ya' -- half the gathers (upper_view() swaps these in)
+    int usym;
+    int64_t unitems;
+    const int* uit0; const int* uit1; const int* ukit; const int* ulongk; int unlong;
+    const int* ucjc;       // m+1 column pointers of the upper view
+    const int* ucidx; const double* ucv;
     double* W;             // n x nS scratch for the Gram route (aliases the AyU buffer)
     const int* rk;         // constraint index
     const double* rv;
@@ -50,6 +57,21 @@ struct AffineDev {
     const double* y;
     double* w;             // A(.) result, length m
     double* Axb[2];        // per slot
+    // tiled upper-triangle copy of the CSR-by-entry arrays (symmetric data only; k_adjoint_tiled): the entries of
+    // every 32 x 32 tile (bi <= bj) are stored together, row-major inside the tile
+    const int* trp;        // ntp*1024 + 1 offsets into trk / trv
+    const int* trk;
+    const double* trv;
+    const short* tp_i;     // tile pair -> (bi, bj)
+    const short* tp_j;
+    int ntp;               // number of tile pairs (0: data not symmetric, flat kernel)
+    // entries with more than ADJ_LONG nonzeros (the (x_i, x_j) block of a BQP moment matrix: 59 each) are left out
+    // by the tile workgroups and summed by one wave each in extra workgroups of the same launch
+    const int* lpos;       // i*nS + j of long entry q (i <= j)
+    const int* lmir;       // j*nS + i
+    const int* ls0;        // its range in trk / trv
+    const int* ls1;
+    int nlong_e;
     const int* sup;        // entries r = i*n + j that occur in some constraint (nsup > 0: At touches few entries)
     const int* suprow;     // n+1: the entries of matrix row i are sup[suprow[i] .. suprow[i+1])
     int nsup;
@@ -104,7 +126,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm(AffineDev a, const double*
     }
 }
 // w_k = sum of the items of constraint k (fixed order).  mode 0: store w.  mode 1 (cost): also
-// Axb = w - b - y/sigma into axb_out and the partial sums of Axb^2 -> P_AUX.
+// Axb = w - b - y/sigma into axb_out and the partial sums of Axb^2 -> P_AXB (launch with MSDP_MAX_GRID workgroups).
 __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm_finish(AffineDev a, int mode, double* axb_out, double sigma, double* P,
                                                            const int* skip_flag, int skip_when) {
     __shared__ double sh[3 * MSDP_WAVES];
@@ -146,7 +168,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm_finish(AffineDev a, int mo
             }
         }
     }
-    if (mode == 1) msdp_put_partial(P, P_AUX, pss, sh);
+    if (mode == 1) msdp_put_partial(P, P_AXB, pss, sh);
 }
 
 // fp64-MFMA version of k_gram (default): W = Ya * Yb' as 64 x 64 tiles, four waves per tile in a 2 x 2 arrangement,
@@ -160,14 +182,31 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm_finish(AffineDev a, int mo
 typedef double gram_d4 __attribute__((ext_vector_type(4)));
 #define GRAM_KT 32
 #define GRAM_LDS (GRAM_KT + 4)
-__global__ __launch_bounds__(256) void k_gram_mfma(int n, int nS, int ld, const double* __restrict__ Ya,
-                                                   const double* __restrict__ Yb, double* __restrict__ W,
-                                                   const int* skip_flag, int skip_when) {
-    __shared__ __attribute__((aligned(16))) double As[64 * GRAM_LDS];
-    __shared__ __attribute__((aligned(16))) double Bs[64 * GRAM_LDS];
+// sym != 0: Wsym = Ya*Yb' + Yb*Ya' on the tiles on and above the diagonal only -- the same flops as the full W, half the
+// stores, and the gather that follows reads one entry per symmetric pair of a constraint.
+// 512 threads = two groups of four waves, each with its own staging buffers: with the symmetric form group g computes
+// product g (Ya_I*Yb_J' or Yb_I*Ya_J'); otherwise (one product) group g takes half of the k range.  The partial tiles
+// are added through LDS at the end.  (Half as many workgroups as the full W would otherwise leave 1-2 four-wave
+// workgroups per CU, too few to cover the staging latency: 79 instead of 57 us at p = 300.)
+__global__ __launch_bounds__(512) void k_gram_mfma(int n, int nS, int ld, const double* __restrict__ Ya0,
+                                                   const double* __restrict__ Yb0, double* __restrict__ W,
+                                                   const int* skip_flag, int skip_when, int sym) {
+    __shared__ __attribute__((aligned(16))) double Stage[2 * 2 * 64 * GRAM_LDS];      // [group][A|B][64 x GRAM_LDS]
     if (skip_flag && *skip_flag == skip_when) return;
+    if (sym && blockIdx.y > blockIdx.x) return;
     const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const bool two = sym && Ya0 != Yb0;                                 // two products, one per group
+    const double post = (sym && Ya0 == Yb0) ? 2.0 : 1.0;
+    const double* __restrict__ Ya = (two && grp) ? Yb0 : Ya0;
+    const double* __restrict__ Yb = (two && grp) ? Ya0 : Yb0;
+    const int nk = (ld + GRAM_KT - 1) / GRAM_KT;
+    const int niter = two ? nk : (nk + 1) / 2;                          // the same trip count in both groups (barriers)
+    const int kbeg = two ? 0 : grp * niter * GRAM_KT;
+    const int kend = two ? ld : min(ld, (grp + 1) * niter * GRAM_KT);
+    double* As = Stage + grp * (2 * 64 * GRAM_LDS);
+    double* Bs = As + 64 * GRAM_LDS;
+    const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
     const int wr = wave >> 1, wc = wave & 1;
     gram_d4 acc[2][2];
@@ -176,13 +215,14 @@ __global__ __launch_bounds__(256) void k_gram_mfma(int n, int nS, int ld, const 
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (gram_d4){0.0, 0.0, 0.0, 0.0};
     // staging: thread -> (row = tid / 16 + 16 * q, column pair = tid % 16), q = 0..3, both panels
-    const int sr = threadIdx.x >> 4, sc = 2 * (threadIdx.x & 15);
-    for (int k0 = 0; k0 < ld; k0 += GRAM_KT) {
+    const int sr = tid >> 4, sc = 2 * (tid & 15);
+    for (int it = 0; it < niter; ++it) {
+        const int k0 = kbeg + it * GRAM_KT;
         double2 ra[4], rb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = sr + 16 * q;
-            const bool ck = k0 + sc < ld;                           // ld is even: a pair is in or out as a whole
+            const bool ck = k0 + sc < kend;                         // ld is even: a pair is in or out as a whole
             const bool oa = ck && ti + r < n, ob = ck && tj + r < n;
             const double2 va = ld2(Ya + (oa ? (int64_t)(ti + r) * ld + k0 + sc : 0));
             const double2 vb = ld2(Yb + (ob ? (int64_t)(tj + r) * ld + k0 + sc : 0));
@@ -221,6 +261,18 @@ __global__ __launch_bounds__(256) void k_gram_mfma(int n, int nS, int ld, const 
             }
         }
     }
+    // group 1 hands its partial tile to group 0 through LDS (4096 doubles, the staging space is 9216)
+    __syncthreads();
+    if (grp == 1) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Stage[(((wave * 2 + a) * 2 + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -230,78 +282,75 @@ __global__ __launch_bounds__(256) void k_gram_mfma(int n, int nS, int ld, const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = ti + wr * 32 + 16 * a + g + 4 * r;
-                if (row < n && col < nS) W[(int64_t)row * nS + col] = acc[a][b][r];
+                const double v = acc[a][b][r] + Stage[(((wave * 2 + a) * 2 + b) * 4 + r) * 64 + lane];
+                if (row < n && col < nS) W[(int64_t)row * nS + col] = post * v;
             }
         }
 }
 
 // ---- Gram route for A(Ya Yb'): when At is dense in its rows (BQP moment relaxations: 4.8 M nonzeros for an
 // 1831 x 1831 matrix) the SDDMM above gathers two p-wide rows per nonzero (2.5 GB of L2 traffic at p = 32,
-// measured 154 us); forming W = Ya*Yb' once (n^2 p flops, 27 MB) and gathering ONE double per nonzero is what
-// the reference does (ManiSDP_unitdiag.m:153,167: X = Y'*Y, YU = Y'*U) and moves 20x less.
-// W[i][j] = <Ya_i, Yb_j>  (n x nS row-major, pad columns zero).  64 x 64 output tile per 256-thread workgroup,
-// 4 x 4 micro-tile per thread, K staged through LDS in chunks of 32 columns.
-__global__ __launch_bounds__(256) void k_gram(int n, int nS, int ld, const double* __restrict__ Ya,
-                                              const double* __restrict__ Yb, double* __restrict__ W,
-                                              const int* skip_flag, int skip_when) {
-    __shared__ double As[64][33];
-    __shared__ double Bs[64][33];
+// measured 154 us); forming W = Ya*Yb' once (n^2 p flops, 27 MB; k_gram_mfma above) and gathering ONE double per
+// nonzero is what the reference does (ManiSDP_unitdiag.m:153,167: X = Y'*Y, YU = Y'*U) and moves 20x less.
+// w_k = sum over the nonzeros of constraint k of val * W[cidx], straight from the Gram matrix: one thread per
+// constraint (its nonzeros are contiguous), a whole wave for the few constraints with more than
+// FIN_SHORT*SDDMM_CHUNK nonzeros (trace rows).  Four nonzeros are in flight per thread (one at a time left a thread
+// with a single request outstanding: 33 us for the 1.16 M constraints of BQP d = 60).  mode as in k_sddmm_finish: the
+// per-item partial values and the separate finish launch of the SDDMM route are not needed here.
+__global__ __launch_bounds__(MSDP_BLOCK) void k_gram_apply(AffineDev a, const double* __restrict__ W, int mode, double* axb_out,
+                                                         double sigma, double* P, const int* skip_flag, int skip_when) {
+    __shared__ double sh[3 * MSDP_WAVES];
     if (skip_flag && *skip_flag == skip_when) return;
-    const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    double acc[4][4];
+    double pss = 0.0;
+    constexpr int LONG = FIN_SHORT * SDDMM_CHUNK;
+    for (int64_t k = (int64_t)blockIdx.x * MSDP_BLOCK + threadIdx.x; k < a.m; k += (int64_t)gridDim.x * MSDP_BLOCK) {
+        const int s0 = a.cjc[k], s1 = a.cjc[k + 1];
+        if (s1 - s0 > LONG) continue;
+        double acc = 0.0;
+        for (int t = s0; t < s1; t += 4) {
+            int cc[4];
+            double vv[4], ww[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+            for (int u = 0; u < 4; ++u) {
+                const bool in = t + u < s1;
+                const int tt = in ? t + u : s1 - 1;
+                cc[u] = a.cidx[tt];
+                vv[u] = in ? a.cv[tt] : 0.0;
+            }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    for (int k0 = 0; k0 < ld; k0 += 32) {
-        // 64 rows x 32 columns of each panel: 2048 doubles / 256 threads = 8 each
+            for (int u = 0; u < 4; ++u) ww[u] = W[cc[u]];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = threadIdx.x + q * 256;
-            const int r = e >> 5, cc = e & 31;
-            const int col = k0 + cc;
-            As[r][cc] = (ti + r < n && col < ld) ? Ya[(int64_t)(ti + r) * ld + col] : 0.0;
-            Bs[r][cc] = (tj + r < n && col < ld) ? Yb[(int64_t)(tj + r) * ld + col] : 0.0;
+            for (int u = 0; u < 4; ++u) acc = fma(vv[u], ww[u], acc);
         }
-        __syncthreads();
-#pragma unroll 8
-        for (int kk = 0; kk < 32; ++kk) {
-            double av[4], bv[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) av[a] = As[ty * 4 + a][kk];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) bv[b] = Bs[tx * 4 + b][kk];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+        a.w[k] = acc;
+        if (mode == 1) {
+            const double r = acc - a.b[k] - a.y[k] / sigma;
+            axb_out[k] = r;
+            pss += r * r;
         }
-        __syncthreads();
     }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int i = ti + ty * 4 + a;
-        if (i < n) {
-            const int j = tj + tx * 4;
-            if (j + 3 < nS) {
-                st2(W + (int64_t)i * nS + j, make_double2(acc[a][0], acc[a][1]));
-                st2(W + (int64_t)i * nS + j + 2, make_double2(acc[a][2], acc[a][3]));
-            } else {
-                for (int b = 0; b < 4; ++b) if (j + b < nS) W[(int64_t)i * nS + j + b] = acc[a][b];
+    {
+        const int lane = threadIdx.x & 63;
+        const int wv = blockIdx.x * (MSDP_BLOCK / 64) + (threadIdx.x >> 6), nwv = gridDim.x * (MSDP_BLOCK / 64);
+        for (int q = wv; q < a.nlong; q += nwv) {
+            const int k = a.longk[q];
+            const int s0 = a.cjc[k], s1 = a.cjc[k + 1];
+            double a0 = 0.0, a1 = 0.0;
+            int t = s0 + lane;
+            for (; t + 64 < s1; t += 128) { a0 = fma(a.cv[t], W[a.cidx[t]], a0); a1 = fma(a.cv[t + 64], W[a.cidx[t + 64]], a1); }
+            if (t < s1) a0 = fma(a.cv[t], W[a.cidx[t]], a0);
+            const double acc = msdp_wave_sum(a0 + a1);
+            if (lane == 0) {
+                a.w[k] = acc;
+                if (mode == 1) {
+                    const double r = acc - a.b[k] - a.y[k] / sigma;
+                    axb_out[k] = r;
+                    pss += r * r;
+                }
             }
         }
     }
-}
-// item value = sum over the item's nonzeros of val * W[cidx]   (one thread per item)
-__global__ __launch_bounds__(256) void k_gram_gather(AffineDev a, const double* __restrict__ W, const int* skip_flag, int skip_when) {
-    if (skip_flag && *skip_flag == skip_when) return;
-    for (int64_t it = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; it < a.nitems; it += (int64_t)gridDim.x * blockDim.x) {
-        const int s0 = a.it0[it], s1 = a.it1[it];
-        double acc = 0.0;
-        for (int t = s0; t < s1; ++t) acc = fma(a.cv[t], W[a.cidx[t]], acc);
-        a.ival[it] = acc;
-    }
+    if (mode == 1) msdp_put_partial(P, P_AXB, pss, sh);
 }
 
 // out[i][j] = (base ? base[i][j] : 0) + scale * sum_k At[(i,j),k] * vec[k]   (dense n x nS, zero pad)
@@ -320,6 +369,95 @@ __global__ void k_adjoint_dense(AffineDev a, const double* __restrict__ base, co
             v = (base ? base[e] : 0.0) + scale * acc;
         }
         out[e] = v;
+    }
+}
+
+// Same result for SYMMETRIC data (A_k = A_k', base = base': SeDuMi's convention, bqpmom.m:80-91, qsmom.m, fromsdpa.m),
+// which is what the affine entry points are fed: only the 32 x 32 tiles on and above the diagonal are computed (half
+// the (coefficient, constraint) reads and half the 8-byte gathers of `vec`) and every off-diagonal tile is stored
+// twice, the second time transposed through LDS, so both stores are 256-byte row segments.  The CSR-by-entry
+// arrays are laid out in tile order (trp/trk/trv), so a workgroup streams one contiguous range of them; each
+// thread owns four entries of the tile and runs their chains of dependent loads (offsets -> coefficient and
+// constraint -> vec) side by side.  The flat kernel above walked all n^2 entries with one chain per thread and a
+// 64-bit division per entry: 85-104 us per call on BQP d = 60 (0.10 of the HBM roofline).
+#define ADJ_T 32
+#define ADJ_LONG 8
+__global__ __launch_bounds__(256) void k_adjoint_tiled(AffineDev a, const double* __restrict__ base, const double* __restrict__ vec,
+                                                       double scale, double* __restrict__ out, const int* skip_flag, int skip_when) {
+    __shared__ double tile[ADJ_T][ADJ_T + 1];
+    if (skip_flag && *skip_flag == skip_when) return;
+    if ((int)blockIdx.x >= a.ntp) {
+        // ---- long entries: one wave each, lanes stride over the (coefficient, constraint) pairs; both copies stored
+        const int lane = threadIdx.x & 63;
+        const int q = ((int)blockIdx.x - a.ntp) * 4 + (threadIdx.x >> 6);
+        if (q >= a.nlong_e) return;
+        const int t0 = a.ls0[q], t1 = a.ls1[q];
+        double acc = 0.0;
+        for (int t = t0 + lane; t < t1; t += 64) acc = fma(a.trv[t], vec[a.trk[t]], acc);
+        acc = msdp_wave_sum(acc);
+        if (lane == 0) {
+            const int o = a.lpos[q], om = a.lmir[q];
+            const double v = (base ? base[o] : 0.0) + scale * acc;
+            out[o] = v;
+            if (om != o) out[om] = v;
+        }
+        return;
+    }
+    const int bi = a.tp_i[blockIdx.x], bj = a.tp_j[blockIdx.x];
+    const int lj = threadIdx.x & 31, li0 = threadIdx.x >> 5;          // rows li0 + 8 q, q = 0..3
+    const int* __restrict__ trp = a.trp + (size_t)blockIdx.x * (ADJ_T * ADJ_T);
+    int s0[4], s1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = (li0 + 8 * q) * ADJ_T + lj;
+        s0[q] = trp[e]; s1[q] = trp[e + 1];
+    }
+    bool lng[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { lng[q] = s1[q] - s0[q] > ADJ_LONG; if (lng[q]) s1[q] = s0[q]; }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // the first two nonzeros of the four entries side by side (most entries have at most two); trk / trv carry one
+    // padding element, so the clamped index of an exhausted entry is always readable
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        int kk[4];
+        double vv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = s0[q] + r < s1[q];
+            const int t = in ? s0[q] + r : s0[q];
+            kk[q] = a.trk[t];
+            vv[q] = in ? a.trv[t] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = fma(vv[q], vec[kk[q]], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int t = s0[q] + 2; t < s1[q]; ++t) acc[q] = fma(a.trv[t], vec[a.trk[t]], acc[q]);   // <= ADJ_LONG - 2 trips
+    const int j = bj * ADJ_T + lj;
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = bi * ADJ_T + li0 + 8 * q;
+        v[q] = 0.0;
+        if (i < a.n && j < a.nS && !lng[q]) {
+            const size_t o = (size_t)i * a.nS + j;
+            if (j < a.n) v[q] = (base ? base[o] : 0.0) + scale * acc[q];
+            out[o] = v[q];                                           // pad columns are written as zeros
+        }
+    }
+    if (bi == bj) return;                                            // diagonal tile: both triangles were computed
+    // mirrored copy; long entries are marked with a NaN and skipped (the long-entry waves store both copies)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tile[li0 + 8 * q][lj] = lng[q] ? __longlong_as_double(0x7ff8000000000000LL) : v[q];
+    __syncthreads();
+    const int jm = bi * ADJ_T + lj;                                  // mirrored column = row index of the tile
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int im = bj * ADJ_T + li0 + 8 * q;                     // mirrored row = column index of the tile
+        const double tv = tile[lj][li0 + 8 * q];
+        if (im < a.n && jm < a.nS && tv == tv) out[(size_t)im * a.nS + jm] = (jm < a.n) ? tv : 0.0;
     }
 }
 
@@ -462,10 +600,10 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_obl_grad_finish(Dev d, int slot,
             }
         }
     }
-    // f = c'x + .5*sigma*|Axb|^2 : c'x partial sums are in P_S1 (sum <C*Y, Y>), |Axb|^2 in P_AUX
+    // f = c'x + .5*sigma*|Axb|^2 : c'x partial sums are in P_S1 (sum <C*Y, Y>), |Axb|^2 in P_AXB
     const double cx = msdp_sum_partials_block(d.P, P_S1, d.G, sh);
     __syncthreads();
-    const double ss = msdp_sum_partials_block(d.P, P_AUX, d.G, sh);
+    const double ss = msdp_sum_partials_block(d.P, P_AXB, MSDP_MAX_GRID, sh);
     __syncthreads();
     double pf = 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) pf = cx + 0.5 * sigma * ss;
@@ -480,7 +618,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_grad_finish(Dev d, int slot,
     __syncthreads();
     const double cx = msdp_sum_partials_block(d.P, P_S1, d.G, sh);
     __syncthreads();
-    const double ss = msdp_sum_partials_block(d.P, P_AUX, d.G, sh);
+    const double ss = msdp_sum_partials_block(d.P, P_AXB, MSDP_MAX_GRID, sh);
     __syncthreads();
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi);
@@ -527,7 +665,7 @@ __global__ void k_cost_only(Dev d, double sigma, double* out) {
     __shared__ double sh[8];
     const double cx = msdp_sum_partials_block(d.P, P_S1, d.G, sh);
     __syncthreads();
-    const double ss = msdp_sum_partials_block(d.P, P_AUX, d.G, sh);
+    const double ss = msdp_sum_partials_block(d.P, P_AXB, MSDP_MAX_GRID, sh);
     if (threadIdx.x == 0) *out = cx + 0.5 * sigma * ss;
 }
 
@@ -622,6 +760,92 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
         (rc = up(h, rp, &a.rp)) || (rc = up(h, rk, &a.rk)) || (rc = up(h, rv, &a.rv)) || (rc = up(h, cidx, &a.cidx)))
         return rc;
     {
+        // tiled upper-triangle arrays for k_adjoint_tiled, only when the data is symmetric entry by entry
+        bool sym = true;
+        for (int i = 0; i < n && sym; ++i)
+            for (int j = i + 1; j < n && sym; ++j) {
+                if (c[(size_t)i * n + j] != c[(size_t)j * n + i]) { sym = false; break; }
+                const int64_t r = (int64_t)i * n + j, rt = (int64_t)j * n + i;
+                const int len = rp[r + 1] - rp[r];
+                if (len != rp[rt + 1] - rp[rt]) { sym = false; break; }
+                for (int t = 0; t < len; ++t)
+                    if (rk[rp[r] + t] != rk[rp[rt] + t] || rv[rp[r] + t] != rv[rp[rt] + t]) { sym = false; break; }
+            }
+        a.trp = nullptr; a.trk = nullptr; a.trv = nullptr; a.tp_i = nullptr; a.tp_j = nullptr; a.ntp = 0;
+        a.lpos = nullptr; a.lmir = nullptr; a.ls0 = nullptr; a.ls1 = nullptr; a.nlong_e = 0;
+        a.usym = 0; a.unitems = 0; a.uit0 = a.uit1 = a.ukit = a.ulongk = a.ucidx = a.ucjc = nullptr; a.ucv = nullptr; a.unlong = 0;
+        if (sym) {
+            std::vector<int> ucidx, uit0, uit1, ukit(m + 1), ulongk, ucjc(m + 1);
+            std::vector<double> ucv;
+            ucidx.reserve((size_t)nnz / 2 + n); ucv.reserve((size_t)nnz / 2 + n);
+            for (int64_t k = 0; k < m; ++k) {
+                ukit[k] = (int)uit0.size();
+                const int first = (int)ucidx.size();
+                ucjc[k] = first;
+                for (int t = cjc[k]; t < cjc[k + 1]; ++t) {
+                    if (ci[t] > cj[t]) continue;
+                    ucidx.push_back(ci[t] * a.nS + cj[t]);
+                    ucv.push_back(ci[t] == cj[t] ? 0.5 * cv[t] : cv[t]);      // Wsym_ii = 2 W_ii
+                }
+                const int last = (int)ucidx.size();
+                for (int t = first; t < last; t += SDDMM_CHUNK) { uit0.push_back(t); uit1.push_back(std::min(t + SDDMM_CHUNK, last)); }
+                if ((int)uit0.size() - ukit[k] > FIN_SHORT) ulongk.push_back((int)k);
+            }
+            ukit[m] = (int)uit0.size();
+            ucjc[m] = (int)ucidx.size();
+            a.unitems = (int64_t)uit0.size();
+            a.unlong = (int)ulongk.size();
+            if (ulongk.empty()) ulongk.push_back(0);
+            if (ucidx.empty()) { ucidx.push_back(0); ucv.push_back(0.0); }
+            if (uit0.empty()) { uit0.push_back(0); uit1.push_back(0); }
+            if ((rc = up(h, ucidx, &a.ucidx)) || (rc = up(h, ucv, &a.ucv)) || (rc = up(h, uit0, &a.uit0)) ||
+                (rc = up(h, uit1, &a.uit1)) || (rc = up(h, ukit, &a.ukit)) || (rc = up(h, ulongk, &a.ulongk)) ||
+                (rc = up(h, ucjc, &a.ucjc))) return rc;
+            a.usym = 1;
+        }
+        const int ntile = (a.nS + ADJ_T - 1) / ADJ_T;
+        if (sym && ntile < 32768) {
+            std::vector<short> tpi, tpj;
+            std::vector<int> trp;
+            std::vector<int> trk;
+            std::vector<double> trv;
+            trp.reserve((size_t)ntile * (ntile + 1) / 2 * ADJ_T * ADJ_T + 1);
+            trk.reserve((size_t)nnz / 2 + n + 16);
+            trv.reserve((size_t)nnz / 2 + n + 16);
+            for (int bi = 0; bi < ntile; ++bi)
+                for (int bj = bi; bj < ntile; ++bj) {
+                    tpi.push_back((short)bi); tpj.push_back((short)bj);
+                    for (int li = 0; li < ADJ_T; ++li)
+                        for (int lj = 0; lj < ADJ_T; ++lj) {
+                            trp.push_back((int)trk.size());
+                            const int i = bi * ADJ_T + li, j = bj * ADJ_T + lj;
+                            if (i >= n || j >= n) continue;
+                            const int64_t r = (int64_t)i * n + j;
+                            for (int t = rp[r]; t < rp[r + 1]; ++t) { trk.push_back(rk[t]); trv.push_back(rv[t]); }
+                        }
+                }
+            trp.push_back((int)trk.size());
+            trk.push_back(0); trv.push_back(0.0);                    // padding element (see the kernel)
+            a.ntp = (int)tpi.size();
+            // long entries (i <= j; a diagonal tile holds both (i,j) and (j,i): keep the upper one, its mirror is stored too)
+            std::vector<int> lpos, lmir, ls0, ls1;
+            for (size_t tp = 0; tp < tpi.size(); ++tp)
+                for (int e = 0; e < ADJ_T * ADJ_T; ++e) {
+                    const size_t g = tp * (ADJ_T * ADJ_T) + e;
+                    if (trp[g + 1] - trp[g] <= ADJ_LONG) continue;
+                    const int i = tpi[tp] * ADJ_T + e / ADJ_T, j = tpj[tp] * ADJ_T + e % ADJ_T;
+                    if (i > j) continue;
+                    lpos.push_back(i * a.nS + j); lmir.push_back(j * a.nS + i);
+                    ls0.push_back(trp[g]); ls1.push_back(trp[g + 1]);
+                }
+            a.nlong_e = (int)lpos.size();
+            if (lpos.empty()) { lpos.push_back(0); lmir.push_back(0); ls0.push_back(0); ls1.push_back(0); }
+            if ((rc = up(h, trp, &a.trp)) || (rc = up(h, trk, &a.trk)) || (rc = up(h, trv, &a.trv)) ||
+                (rc = up(h, tpi, &a.tp_i)) || (rc = up(h, tpj, &a.tp_j)) || (rc = up(h, lpos, &a.lpos)) ||
+                (rc = up(h, lmir, &a.lmir)) || (rc = up(h, ls0, &a.ls0)) || (rc = up(h, ls1, &a.ls1))) return rc;
+        }
+    }
+    {
         // entries touched by At; the restricted adjoint is used when they are few (<= 1/8 of the matrix)
         int64_t ns = 0;
         for (int64_t r = 0; r < nn; ++r) ns += rp[r + 1] > rp[r];
@@ -666,7 +890,7 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
     if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
     d.AyU = (double*)p;
     HIPCHK(hipMemset(d.AyU, 0, msz));
-    // the Gram scratch may share AyU: W is consumed (k_gram_gather) before the adjoint rewrites AyU, and the cost /
+    // the Gram scratch may share AyU: W is consumed (k_gram_apply) before the adjoint rewrites AyU, and the cost /
     // line-search calls never touch AyU.  With the restricted adjoint AyU must stay zero outside the entries At
     // touches, so the Gram scratch and the dual slack of msdp_al_dual get buffers of their own.
     a.W = d.AyU;
@@ -743,22 +967,34 @@ static bool use_gram_route(const AffineDev& a, int64_t nnz, int ld) {
     const double gram_bytes = 2.0 * a.n * (double)a.nS * 8.0 + (double)nnz * 20.0;
     return sddmm_bytes > 4.0 * gram_bytes && (double)a.n * a.nS * 8.0 <= 2.0e9;
 }
-static int launch_aop(msdp_handle h, const AffineDev& a, int64_t nnz, const double* Ya, const double* Yb, const int* flag, int when) {
+// The constraints restricted to their entries i <= j (symmetric data): what the Gram route and the finish kernel
+// that follows it iterate over.
+static void upper_view(AffineDev& a) {
+    a.nitems = a.unitems; a.it0 = a.uit0; a.it1 = a.uit1; a.kit = a.ukit; a.longk = a.ulongk; a.nlong = a.unlong;
+    a.cidx = a.ucidx; a.cv = a.ucv; a.cjc = a.ucjc;
+}
+// w = A(Ya Yb') (mode 0), or additionally Axb = w - b - y/sigma into axb_out and the partial sums of Axb^2 -> P_AXB
+// (mode 1: exactly MSDP_MAX_GRID workgroups, the count the consumers re-reduce).  `a` is the caller's copy: on the
+// symmetric Gram route it is switched to the upper view.
+static int launch_A(msdp_handle h, AffineDev& a, int64_t nnz, const double* Ya, const double* Yb, const int* flag, int when,
+                    int mode, double* axb_out, double sigma) {
+    int64_t gm = (a.m + MSDP_BLOCK - 1) / MSDP_BLOCK;           // mode 0: no reduction, size the grid by m
+    if (gm > 2048) gm = 2048;
+    const int G = mode == 1 ? MSDP_MAX_GRID : (int)gm;
     if (use_gram_route(a, nnz, a.ld)) {
         dim3 grid((a.nS + 63) / 64, (a.n + 63) / 64);
-        const char* ev = getenv("MSDP_GRAM_VALU");
-        const bool valu = ev && atoi(ev);
-        if (valu) hipLaunchKernelGGL(k_gram, grid, dim3(256), 0, h->stream, a.n, a.nS, a.ld, Ya, Yb, a.W, flag, when);
-        else hipLaunchKernelGGL(k_gram_mfma, grid, dim3(256), 0, h->stream, a.n, a.nS, a.ld, Ya, Yb, a.W, flag, when);
+        const int sym = a.usym ? 1 : 0;
+        if (sym) upper_view(a);
+        hipLaunchKernelGGL(k_gram_mfma, grid, dim3(512), 0, h->stream, a.n, a.nS, a.ld, Ya, Yb, a.W, flag, when, sym);
         HIPCHK(hipGetLastError());
-        int64_t g = (a.nitems + 255) / 256;
-        if (g > 16384) g = 16384;
-        if (g < 1) g = 1;
-        hipLaunchKernelGGL(k_gram_gather, dim3((int)g), dim3(256), 0, h->stream, a, (const double*)a.W, flag, when);
+        hipLaunchKernelGGL(k_gram_apply, dim3(G), dim3(MSDP_BLOCK), 0, h->stream, a, (const double*)a.W, mode, axb_out, sigma,
+                           h->d.P, flag, when);
         HIPCHK(hipGetLastError());
         return 0;
     }
     DISPATCH_LPR_A(k_sddmm, h, sddmm_grid(a, a.ld), a, Ya, Yb, flag, when);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_sddmm_finish, dim3(G), dim3(MSDP_BLOCK), 0, h->stream, a, mode, axb_out, sigma, h->d.P, flag, when);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -777,6 +1013,8 @@ static int launch_adjoint(msdp_handle h, const AffineDev& a, const double* base,
         int g = (a.nsup + 255) / 256;
         if (g > 4096) g = 4096;
         hipLaunchKernelGGL(k_adjoint_support, dim3(g), dim3(256), 0, h->stream, a, base, vec, scale, out, flag, when);
+    } else if (a.ntp > 0) {
+        hipLaunchKernelGGL(k_adjoint_tiled, dim3(a.ntp + (a.nlong_e + 3) / 4), dim3(256), 0, h->stream, a, base, vec, scale, out, flag, when);
     } else {
         hipLaunchKernelGGL(k_adjoint_dense, dim3(adjoint_grid(a)), dim3(256), 0, h->stream, a, base, vec, scale, out, flag, when);
     }
@@ -810,9 +1048,7 @@ int msdp_affine_costgrad(msdp_handle h, int slot) {
     const double sigma = st->sigma;
     const double* Ys = d.Y[slot];
     const int* done = &d.ctl->done;
-    { int rc0 = launch_aop(h, a, st->nnz, Ys, Ys, done, 1); if (rc0) return rc0; }
-    hipLaunchKernelGGL(k_sddmm_finish, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, a, 1, a.Axb[slot], sigma, d.P, done, 1);
-    HIPCHK(hipGetLastError());
+    { int rc0 = launch_A(h, a, st->nnz, Ys, Ys, done, 1, 1, a.Axb[slot], sigma); if (rc0) return rc0; }
     { int rca = launch_adjoint(h, a, d.Cd, a.Axb[slot], sigma, d.eS[slot], done, 1, true); if (rca) return rca; }
     // c'x = <C*Y, Y>
     const double* slab; int64_t stride; int SK;
@@ -859,13 +1095,7 @@ int msdp_affine_hess(msdp_handle h) {
     const int cur = h->h_ctl->cur;
     const int* act = &d.F[0].active;
     // w = A(Y U') ; AyU = A'(w)
-    { int rc0 = launch_aop(h, a, st->nnz, d.Y[cur], d.md, act, 0); if (rc0) return rc0; }
-    {   // mode 0 has no reduction: size the grid by m
-        int64_t gf = (a.m + MSDP_BLOCK - 1) / MSDP_BLOCK;
-        if (gf > 2048) gf = 2048;
-        hipLaunchKernelGGL(k_sddmm_finish, dim3((int)gf), dim3(MSDP_BLOCK), 0, h->stream, a, 0, (double*)nullptr, sigma, d.P, act, 0);
-    }
-    HIPCHK(hipGetLastError());
+    { int rc0 = launch_A(h, a, st->nnz, d.Y[cur], d.md, act, 0, 0, (double*)nullptr, sigma); if (rc0) return rc0; }
     const double* slab; int64_t stride; int SK;
     int rc;
     if (a.nsup > 0 && h->nranks == 1 && d.ld <= 512) {
@@ -927,9 +1157,7 @@ int msdp_affine_linesearch_cost(msdp_handle h, const double* Yt, double* val) {
     a.p = d.p; a.ld = d.ld;
     const double sigma = st->sigma;
     const int other = h->h_ctl->cur ^ 1;
-    { int rc0 = launch_aop(h, a, st->nnz, Yt, Yt, (const int*)nullptr, 0); if (rc0) return rc0; }
-    hipLaunchKernelGGL(k_sddmm_finish, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, a, 1, a.Axb[other], sigma, d.P, (const int*)nullptr, 0);
-    HIPCHK(hipGetLastError());
+    { int rc0 = launch_A(h, a, st->nnz, Yt, Yt, (const int*)nullptr, 0, 1, a.Axb[other], sigma); if (rc0) return rc0; }
     const double* slab; int64_t stride; int SK;
     const double* M[1] = {d.Cd}; const double* X[1] = {Yt}; const double sc[1] = {1.0};
     int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
@@ -968,14 +1196,8 @@ int msdp_affine_al_primal(msdp_handle h, double* obj, double* Ax_host) {
     a.p = d.p; a.ld = d.ld;
     const int cur = h->h_ctl->cur;
     const double* Ys = d.Y[cur];
-    int rc = launch_aop(h, a, st->nnz, Ys, Ys, (const int*)nullptr, 0);
+    int rc = launch_A(h, a, st->nnz, Ys, Ys, (const int*)nullptr, 0, 0, (double*)nullptr, 1.0);
     if (rc) return rc;
-    {
-        int64_t gf = (a.m + MSDP_BLOCK - 1) / MSDP_BLOCK;
-        if (gf > 2048) gf = 2048;
-        hipLaunchKernelGGL(k_sddmm_finish, dim3((int)gf), dim3(MSDP_BLOCK), 0, h->stream, a, 0, (double*)nullptr, 1.0, d.P, (const int*)nullptr, 0);
-        HIPCHK(hipGetLastError());
-    }
     const double* slab; int64_t stride; int SK;
     const double* M[1] = {d.Cd}; const double* X[1] = {Ys}; const double sc[1] = {1.0};
     if ((rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK))) return rc;

@@ -10,7 +10,7 @@
 #define MSDP_BLOCK 1024           // threads per workgroup (16 waves: one row step per wave, latency hidden by occupancy)
 #define MSDP_WAVES (MSDP_BLOCK / 64)
 #define MSDP_MAX_GRID 512         // <= 512 partial sums per reduction (2 per CU)
-#define MSDP_NPART 8              // number of partial-sum arrays
+#define MSDP_NPART 9              // number of partial-sum arrays
 
 void msdp_set_error(const char* fmt, ...);
 
@@ -50,7 +50,9 @@ struct Frame {
 };
 
 // Partial-sum array ids
-enum { P_F = 0, P_GG = 1, P_DHD = 2, P_S1 = 3, P_S2 = 4, P_S3 = 5, P_RD = 6, P_AUX = 7 };
+// P_AXB: |A x - b - y/sigma|^2 of the affine kinds, summed over the constraints by MSDP_MAX_GRID workgroups (every other
+// array is filled by the d.G workgroups of a row-parallel launch)
+enum { P_F = 0, P_GG = 1, P_DHD = 2, P_S1 = 3, P_S2 = 4, P_S3 = 5, P_RD = 6, P_AUX = 7, P_AXB = 8 };
 
 enum { MANI_OBLIQUE = 0, MANI_SPHERE = 1, MANI_EUCLID = 2 };
 enum { COST_SPARSE = 0, COST_DENSE = 1, COST_AFFINE = 2 };

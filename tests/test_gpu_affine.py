@@ -62,16 +62,14 @@ def test_unitdiag_operators(lib, case, p):
     h.close()
 
 
-@pytest.mark.parametrize("route", ["gram", "sddmm", "gram-valu"])
+@pytest.mark.parametrize("route", ["gram", "sddmm"])
 @pytest.mark.parametrize("case,p", [("bqp10", 3), ("bqp20", 32), ("bqp20", 70), ("gpp124-1", 130)])
 def test_unitdiag_operator_routes(lib, monkeypatch, route, case, p):
-    """A(Ya Yb') through each route (SDDMM per nonzero; Gram matrix by fp64 MFMA or by the VALU kernel + gather)
+    """A(Ya Yb') through each route (SDDMM per nonzero; Gram matrix by fp64 MFMA + one gather per symmetric pair)
     against the oracle: the library picks the route by bytes moved, here each one is forced."""
     from manisdp_matlab_amd import problems
     from oracle import manisdp_ref as R
-    monkeypatch.setenv("MSDP_AFFINE_ROUTE", "gram" if route.startswith("gram") else "sddmm")
-    if route == "gram-valu":
-        monkeypatch.setenv("MSDP_GRAM_VALU", "1")
+    monkeypatch.setenv("MSDP_AFFINE_ROUTE", route)
     if case.startswith("bqp"):
         At, b, c, K = _bqp(int(case[3:]))
     else:

@@ -2,9 +2,14 @@
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of the bytes of a 16-B-per-lane
 coalesced read stream -> doubled; WRITE_SIZE is exact; both are in KiB."""
 import csv, glob, json, sys
-kern, out = sys.argv[1], sys.argv[2]
+# usage: pmc_to_json.py <kernel-name-substring> <out.json> [--per N] <dir>...   (--per: units, e.g. tCG trips, per launch)
+argv = sys.argv[1:]
+per = None
+if "--per" in argv:
+    i = argv.index("--per"); per = float(argv[i + 1]); del argv[i:i + 2]
+kern, out = argv[0], argv[1]
 vals = {}
-for d in sys.argv[3:]:
+for d in argv[2:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if kern in r["Kernel_Name"]:
@@ -13,5 +18,8 @@ avg = {k: sum(v) / len(v) for k, v in vals.items()}
 res = {"kernel": kern, "counters_avg_per_launch": avg, "launches": {k: len(v) for k, v in vals.items()},
        "fetch_bytes_corrected": 2 * avg.get("FETCH_SIZE", 0) * 1024, "write_bytes": avg.get("WRITE_SIZE", 0) * 1024}
 res["hbm_bytes_per_launch"] = res["fetch_bytes_corrected"] + res["write_bytes"]
+if per:
+    res["trips_per_launch"] = per
+    res["hbm_bytes_per_trip"] = res["hbm_bytes_per_launch"] / per
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))
