@@ -235,6 +235,16 @@ int msdp_escape_eigs_dual(msdp_handle h, int32_t k, double tol, int32_t maxit,
  * data.S (ManiSDP_unitdiag.m:116, ManiSDP_unittrace.m:121) and the input of a host eig(S) for small n. */
 int msdp_get_dual_slack(msdp_handle h, double* S);
 
+/* Run-time switches of one handle (production = the defaults; the tests and the profiling scripts use them):
+ *   "persist"      1/0  persistent single-launch tCG / Lanczos kernels where they fit (default 1; env MSDP_NO_PERSIST=1)
+ *   "fused_rtr"    1/0  whole trustregions() loop in one launch for p <= 32          (default 1; env MSDP_NO_FUSED_RTR=1)
+ *   "graph"        1/0  chunked tCG trips replayed as hipGraphs                      (default 1; env MSDP_NO_GRAPH=1)
+ *   "affine_route" 0 = choose by bytes moved, 1 = SDDMM, 2 = Gram                    (default 0; env MSDP_AFFINE_ROUTE)
+ *   "timing", "esc_debug"  1/0  diagnostics on stderr                                (env MSDP_TIMING, MSDP_ESC_DEBUG)
+ *   "debug_fail_persist"   1    test hook: the next persistent launch reports a synchronisation time-out
+ * The environment variables are read once, when the handle is created.  Unknown names -> MSDP_EINVAL. */
+int msdp_set_option(msdp_handle h, const char* name, int32_t value);
+
 /* Which implementation msdp_rtr uses for the tCG inner loop at the resident point:
  * 1 = persistent single-launch kernel (working set in registers/LDS, sparse C, oblique,
  * one rank, n and p small enough to stay on chip), 0 = chunked hipGraph of three kernels

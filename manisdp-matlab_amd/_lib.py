@@ -63,6 +63,7 @@ SIGNATURES = {
     "msdp_get_point": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_p": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "msdp_get_kind": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "msdp_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "msdp_rtr": (C.c_int, [C.c_void_p, _P(RtrOpts), _P(RtrStats)]),
     "msdp_rtr_host": (C.c_int, [C.c_void_p, C.c_int32, _dp, _P(RtrOpts), _P(RtrStats)]),
     "msdp_cost": (C.c_int, [C.c_void_p, _dp]),
@@ -320,6 +321,10 @@ class Handle:
         nv, cv, res = C.c_int32(), C.c_int32(), C.c_double()
         _check(self._lib.msdp_escape_info(self._h, C.byref(nv), C.byref(cv), C.byref(res)))
         return nv.value, bool(cv.value), res.value
+
+    def set_option(self, name, value):
+        """Run-time switch of this handle (see msdp_set_option in include/manisdp_hip.h)."""
+        _check(self._lib.msdp_set_option(self._h, name.encode(), int(value)))
 
     def get_kind(self):
         k = C.c_int32()

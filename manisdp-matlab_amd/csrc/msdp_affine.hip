@@ -850,7 +850,7 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
         int64_t ns = 0;
         for (int64_t r = 0; r < nn; ++r) ns += rp[r + 1] > rp[r];
         a.sup = nullptr; a.suprow = nullptr; a.nsup = 0;
-        if (ns > 0 && ns * 8 <= nn && !(getenv("MSDP_ADJ_FULL") && atoi(getenv("MSDP_ADJ_FULL")))) {
+        if (ns > 0 && ns * 8 <= nn) {
             std::vector<int> sup;
             sup.reserve((size_t)ns);
             for (int64_t r = 0; r < nn; ++r) if (rp[r + 1] > rp[r]) sup.push_back((int)r);
@@ -958,11 +958,9 @@ static int sddmm_grid(const AffineDev& a, int ld) {
 }
 
 // A(Ya Yb') -> item values.  SDDMM (gathers 2 p-wide rows per nonzero) or the Gram route (dense W = Ya*Yb' once,
-// one double per nonzero), whichever moves fewer bytes; MSDP_AFFINE_ROUTE=sddmm|gram overrides.
-static bool use_gram_route(const AffineDev& a, int64_t nnz, int ld) {
-    const char* e = getenv("MSDP_AFFINE_ROUTE");              // read on every call: the tests switch it
-    const int force = !e ? 0 : (!strcmp(e, "gram") ? 2 : (!strcmp(e, "sddmm") ? 1 : 0));
-    if (force) return force == 2;
+// one double per nonzero), whichever moves fewer bytes; the option affine_route (msdp_set_option) overrides.
+static bool use_gram_route(msdp_handle h, const AffineDev& a, int64_t nnz, int ld) {
+    if (h->tune.affine_route) return h->tune.affine_route == 2;
     const double sddmm_bytes = (double)nnz * ld * 16.0;
     const double gram_bytes = 2.0 * a.n * (double)a.nS * 8.0 + (double)nnz * 20.0;
     return sddmm_bytes > 4.0 * gram_bytes && (double)a.n * a.nS * 8.0 <= 2.0e9;
@@ -981,7 +979,7 @@ static int launch_A(msdp_handle h, AffineDev& a, int64_t nnz, const double* Ya, 
     int64_t gm = (a.m + MSDP_BLOCK - 1) / MSDP_BLOCK;           // mode 0: no reduction, size the grid by m
     if (gm > 2048) gm = 2048;
     const int G = mode == 1 ? MSDP_MAX_GRID : (int)gm;
-    if (use_gram_route(a, nnz, a.ld)) {
+    if (use_gram_route(h, a, nnz, a.ld)) {
         dim3 grid((a.nS + 63) / 64, (a.n + 63) / 64);
         const int sym = a.usym ? 1 : 0;
         if (sym) upper_view(a);

@@ -60,15 +60,13 @@ static int dev_alloc(msdp_handle h, T** out, size_t count) {
     return 0;
 }
 // Uncached (MTYPE UC) device memory for the words that workgroups on different XCDs exchange inside one launch:
-// sc1 accesses to it skip the L2 look-up on both ends (tools/microbench_sync.hip: grid reduction 1.99 -> 1.24 us).
-// Falls back to plain hipMalloc where the flag is not supported.
+// sc1 accesses to it skip the L2 look-up on both ends (tools/microbench_sync.hip: grid reduction 1.99 -> 1.24 us;
+// 12.8 -> 10.0 us per tCG trip).  Falls back to plain hipMalloc where the flag is not supported.
 template <typename T>
 static int dev_alloc_uncached(msdp_handle h, T** out, size_t count) {
     void* p = nullptr;
     if (count == 0) count = 1;
-    static int off = -1;
-    if (off < 0) { const char* e = getenv("MSDP_NO_UNCACHED"); off = (e && atoi(e)) ? 1 : 0; }
-    hipError_t e = off ? hipErrorNotSupported : hipExtMallocWithFlags(&p, count * sizeof(T), hipDeviceMallocUncached);
+    hipError_t e = hipExtMallocWithFlags(&p, count * sizeof(T), hipDeviceMallocUncached);
     if (e != hipSuccess) { (void)hipGetLastError(); return dev_alloc<T>(h, out, count); }
     h->allocs.push_back(p);
     *out = (T*)p;
@@ -98,15 +96,12 @@ static void choose_grid(msdp_handle h) {
     Dev& d = h->d;
     int half = d.ld / 2, lpr = 1;
     while (lpr < half && lpr < 64) lpr <<= 1;
-    if (const char* e = getenv("MSDP_LPR_SHIFT")) for (int s2 = 0; s2 < atoi(e) && lpr > 1; ++s2) lpr >>= 1;
     const int rows_per_step = MSDP_WAVES * (64 / lpr);
     int want = (rows_capacity(h) + rows_per_step - 1) / rows_per_step;
     // One or two workgroups per CU, never a fraction in between: with 256 < G < 512 some CUs get two
     // 1024-thread workgroups and the launch waits for them (measured on G81 p=32: G=320 -> 27.4 us per tCG
     // trip, G=256 -> 24.1 us).
-    int gmax = 512;
-    if (const char* e = getenv("MSDP_GRID")) { int v = atoi(e); if (v >= 8) gmax = v; }
-    if (gmax > MSDP_MAX_GRID) gmax = MSDP_MAX_GRID;
+    const int gmax = MSDP_MAX_GRID;
     int G = ((want + 7) / 8) * 8;
     if (G < 8) G = 8;
     if (G > 256 && G < 512) G = 256;
@@ -195,12 +190,24 @@ static int new_handle(int kind, int64_t n, msdp_handle* out) {
     h->d.n_loc = (int)n;
     h->d.row0 = 0;
     h->d.manifold = (kind == MSDP_KIND_UNITTRACE) ? MANI_SPHERE : (kind == MSDP_KIND_GENERIC ? MANI_EUCLID : MANI_OBLIQUE);
-    if (const char* ev = getenv("MSDP_VARIANT")) h->d.variant = atoi(ev);
+    {
+        // the documented environment switches, read once per handle (msdp_set_option changes them afterwards)
+        auto on = [](const char* name) { const char* e = getenv(name); return e && atoi(e) != 0; };
+        if (on("MSDP_NO_PERSIST")) h->tune.persist = 0;
+        if (on("MSDP_NO_FUSED_RTR")) h->tune.fused_rtr = 0;
+        if (on("MSDP_NO_GRAPH")) h->tune.graph = 0;
+        if (on("MSDP_TIMING")) h->tune.timing = 1;
+        if (on("MSDP_ESC_DEBUG")) h->tune.esc_debug = 1;
+        if (const char* e = getenv("MSDP_AFFINE_ROUTE")) h->tune.affine_route = !strcmp(e, "gram") ? 2 : (!strcmp(e, "sddmm") ? 1 : 0);
+    }
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_ctl, sizeof(Ctl), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_frame, 2 * sizeof(Frame), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_flags, 64, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_flag[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_flag[1], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_status, 64, hipHostMallocMapped);
     if (e == hipSuccess) {
         *h->h_status = 0;
@@ -243,8 +250,7 @@ static int upload_sparse_rows(msdp_handle h) {
     int W = 0;
     for (int i = 0; i < d.n_loc; ++i) W = std::max(W, rp[i + 1] - rp[i]);
     d.ellW = 0; d.ellc = nullptr; d.ellv = nullptr;
-    const char* noell = getenv("MSDP_NO_ELL");
-    if (W >= 1 && W <= 8 && !(noell && atoi(noell))) {
+    if (W >= 1 && W <= 8) {
         // stored width 5 or 8 (the persistent tCG kernel is instantiated for these and loads every slice
         // without a branch); the padding entries are (own row, 0.0)
         W = W <= 5 ? 5 : 8;
@@ -397,6 +403,8 @@ extern "C" int msdp_destroy(msdp_handle h) {
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
     if (h->h_frame) (void)hipHostFree(h->h_frame);
     if (h->h_status) (void)hipHostFree((void*)h->h_status);
+    if (h->h_flags) (void)hipHostFree((void*)h->h_flags);
+    for (int s2 = 0; s2 < 2; ++s2) if (h->ev_flag[s2]) (void)hipEventDestroy(h->ev_flag[s2]);
     for (int s2 = 0; s2 < 2; ++s2) if (h->chunk_execs[s2]) (void)hipGraphExecDestroy(h->chunk_execs[s2]);
     msdp_affine_release(h);
     if (h->esc_mem) (void)hipFree(h->esc_mem);       // esc_prev lives inside it
@@ -537,6 +545,21 @@ extern "C" int msdp_get_p(msdp_handle h, int32_t* p) {
     return 0;
 }
 
+extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
+    CHECK_H(h);
+    if (!name) { msdp_set_error("set_option: null name"); return MSDP_EINVAL; }
+    Tuning& t = h->tune;
+    if (!strcmp(name, "persist")) t.persist = value != 0;
+    else if (!strcmp(name, "fused_rtr")) t.fused_rtr = value != 0;
+    else if (!strcmp(name, "graph")) { t.graph = value != 0; h->chunk_len = 0; }
+    else if (!strcmp(name, "affine_route")) { if (value < 0 || value > 2) { msdp_set_error("affine_route: 0 auto, 1 sddmm, 2 gram"); return MSDP_EINVAL; } t.affine_route = value; h->chunk_len = 0; h->state_valid = false; }
+    else if (!strcmp(name, "timing")) t.timing = value != 0;
+    else if (!strcmp(name, "esc_debug")) t.esc_debug = value != 0;
+    else if (!strcmp(name, "debug_fail_persist")) t.fail_persist = value != 0;
+    else { msdp_set_error("set_option: unknown option '%s'", name); return MSDP_EINVAL; }
+    return 0;
+}
+
 extern "C" int msdp_get_kind(msdp_handle h, int32_t* kind) {
     CHECK_H(h);
     if (!kind) return MSDP_EINVAL;
@@ -650,10 +673,7 @@ extern "C" int msdp_tcg_path(msdp_handle h, int32_t* path) {
     CHECK_H(h);
     if (!path) return MSDP_EINVAL;
     if (!h->have_point) { msdp_set_error("tcg_path: no resident point"); return MSDP_ESTATE; }
-    const char* e1 = getenv("MSDP_SYNC_TR");
-    const char* e2 = getenv("MSDP_NO_PUBLISH");
-    const bool async_ok = !(e1 && atoi(e1)) && !(e2 && atoi(e2));
-    *path = (async_ok && msdp_persist_eligible(h)) ? 1 : 0;
+    *path = msdp_persist_eligible(h) ? 1 : 0;
     return 0;
 }
 
@@ -686,35 +706,11 @@ static void fill_ctl(msdp_handle h, const msdp_rtr_opts* o) {
     c->Delta0 = (o->Delta0 > 0) ? o->Delta0 : c->Delta_bar / 8.0;
 }
 
-static int tcg_chunk() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MSDP_TCG_CHUNK"); v = e ? atoi(e) : 8; if (v < 1) v = 1; }
-    return v;
-}
-static bool use_graphs() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MSDP_NO_GRAPH"); v = (e && atoi(e)) ? 0 : 1; }
-    return v != 0;
-}
-
-static bool fused_enabled(msdp_handle h) {
-    // Opt-in (MSDP_FUSED=1): the fused two-launch trip is correct (tests/test_gpu_onlyunitdiag.py runs it) but
-    // measured SLOWER on G81 p=32 (26.0 us vs 24.6 us per trip): recomputing the neighbours' directions costs
-    // 15 row loads + 5 group reductions per row, more than the launch and the 2 vectors of traffic it saves.
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MSDP_FUSED"); v = (e && atoi(e)) ? 1 : 0; }
-    return v && h->d.costkind == COST_SPARSE && h->d.manifold == MANI_OBLIQUE && !h->use_comm;
-}
+#define TCG_CHUNK 8           // tCG trips per enqueued chunk (one hipGraph of 3 x 8 kernel nodes)
+static bool use_graphs(msdp_handle h) { return h->tune.graph && !h->use_comm; }
 
 static int enqueue_trips(msdp_handle h, int cnt) {
     int rc;
-    if (h->d.fused) {
-        for (int t = 0; t < cnt; ++t) {
-            if ((rc = msdp_launch_hess_fused(h))) return rc;  // tCG.m:227-287 of the previous trip + :163
-            if ((rc = msdp_launch_upd1(h))) return rc;        // tCG.m:166-241
-        }
-        return 0;
-    }
     for (int t = 0; t < cnt; ++t) {
         if ((rc = msdp_launch_hess(h))) return rc;        // tCG.m:163
         if ((rc = msdp_launch_upd1(h))) return rc;        // tCG.m:166-241
@@ -759,31 +755,44 @@ static int launch_chunk(msdp_handle h, int CH, bool graph) {
     return enqueue_trips(h, CH);
 }
 
+// tCG of the current TR iteration when the rows are sharded over a communicator.  Every rank must issue the SAME
+// sequence of collectives, so how many chunks are enqueued may depend only on device state that is identical on all
+// ranks: the `tcg_running` flag, which every rank computes from the same all-reduced sums.  The flag after each chunk
+// is copied to a pinned word behind the chunk (an event marks the copy); the host stays ONE chunk ahead of the device
+// -- chunk i+1 is already enqueued when the flag of chunk i is read -- so the stream never drains while the host
+// decides, and at most one chunk of no-op trips (whose collectives still run) follows the end of a tCG.
+static int run_tcg_lockstep(msdp_handle h, int maxinner) {
+    const int CH = TCG_CHUNK;
+    const int nchunks = (maxinner + CH - 1) / CH;
+    int rc;
+    h->d.status = nullptr;                                         // no host-mapped progress word on this path
+    if ((rc = msdp_launch_tcg_init(h))) return rc;                 // trustregions.m:484-496
+    int enq = 0;
+    auto push_chunk = [&]() -> int {
+        int r2 = enqueue_trips(h, CH);
+        if (r2) return r2;
+        HIPCHK(hipMemcpyAsync((void*)&h->h_flags[enq & 1], &h->d.ctl->tcg_running, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->ev_flag[enq & 1], h->stream));
+        ++enq;
+        return 0;
+    };
+    if ((rc = push_chunk())) return rc;
+    if (nchunks > 1 && (rc = push_chunk())) return rc;
+    for (int i = 0; i < enq; ++i) {
+        HIPCHK(hipEventSynchronize(h->ev_flag[i & 1]));
+        if (!h->h_flags[i & 1]) break;                             // finished inside chunk i; what follows is a no-op
+        if (enq < nchunks && (rc = push_chunk())) return rc;       // slot (i & 1) is free again: chunk i + 2 takes it
+    }
+    return 0;
+}
+
 // Run the tCG inner loop of the current TR iteration: chunks of CH trips are enqueued one
 // ahead of the device (so the graph-launch latency is hidden) while the host polls the
 // host-mapped progress word the lead thread of k_tcg_upd2 publishes every trip.
 static int run_tcg(msdp_handle h, int maxinner, int k, bool* done_out = nullptr) {
-    const int CH = tcg_chunk();
-    const bool graph = use_graphs() && !h->use_comm;
+    const int CH = TCG_CHUNK;
+    const bool graph = use_graphs(h);
     int rc;
-    static int nopub = -1;
-    if (nopub < 0) { const char* e = getenv("MSDP_NO_PUBLISH"); nopub = (e && atoi(e)) ? 1 : 0; }
-    if (nopub || h->use_comm) {
-        // blocking variant: one stream sync per chunk, no host-mapped progress word.  Mandatory with RCCL:
-        // every rank must enqueue the SAME number of collectives, so the chunk count may only depend on
-        // device state that is identical on all ranks (the frames are), never on host timing.
-        h->d.status = nullptr;
-        if (graph && (rc = ensure_chunk_graph(h, CH))) return rc;
-        if ((rc = msdp_launch_tcg_init(h))) return rc;
-        for (int j = 0; j < maxinner; j += CH) {
-            if ((rc = launch_chunk(h, CH, graph))) return rc;
-            HIPCHK(hipMemcpyAsync(&h->h_ctl->tcg_running, &h->d.ctl->tcg_running, sizeof(int),
-                                  hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            if (!h->h_ctl->tcg_running) break;
-        }
-        return 0;
-    }
     if (graph && (rc = ensure_chunk_graph(h, CH))) return rc;
     if ((rc = msdp_launch_tcg_init(h))) return rc;                // trustregions.m:484-496
     int enq = 0;
@@ -833,67 +842,67 @@ static int run_tcg(msdp_handle h, int maxinner, int k, bool* done_out = nullptr)
     return 0;
 }
 
-extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats* stats) {
-    CHECK_H(h);
-    if (!opts) { msdp_set_error("rtr: null options"); return MSDP_EINVAL; }
-    if (!h->have_point) { msdp_set_error("rtr: no resident point (call msdp_set_point)"); return MSDP_ESTATE; }
-    if (opts->rho_prime >= 0.25) { msdp_set_error("options.rho_prime must be strictly smaller than 1/4"); return MSDP_EINVAL; }
-    if (opts->maxinner < 1 || opts->maxiter < 0) { msdp_set_error("rtr: maxinner >= 1 and maxiter >= 0 required"); return MSDP_EINVAL; }
-    const auto t0 = std::chrono::steady_clock::now();
+static void restore_status_ptr(msdp_handle h) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, (void*)h->h_status, 0) == hipSuccess) h->d.status = (unsigned long long*)dp;
+}
+
+// Did a persistent launch give up on a grid synchronisation?  (Its bounded spins turn a would-be hang -- the
+// workgroups of the launch not all resident because something else occupies CUs -- into this flag.)
+static int persist_timed_out(msdp_handle h, bool* out) {
+    int perr = 0;
+    HIPCHK(hipMemcpy(&perr, h->psync_err, sizeof(int), hipMemcpyDeviceToHost));
+    *out = perr != 0;
+    return 0;
+}
+
+// The body of msdp_rtr.  *timed_out: a persistent launch reported a grid-synchronisation time-out (the resident
+// point is then in an undefined state; the caller restores the start point and calls again, which takes the
+// chunked path because h->persist_failed is set).
+static int rtr_core(msdp_handle h, const msdp_rtr_opts* opts, bool* timed_out) {
     int rc;
+    *timed_out = false;
     fill_ctl(h, opts);
-    h->last_opts = *opts;
-    h->d.fused = fused_enabled(h) ? 1 : 0;
     *h->h_status = 0;
     if ((rc = push_ctl(h))) return rc;
     int cur = h->h_ctl->cur;
     if ((rc = msdp_launch_costgrad(h, cur))) return rc;          // trustregions.m:405
     if ((rc = msdp_launch_rtr_begin(h))) return rc;
     if ((rc = pull_ctl(h))) return rc;
-    static int timing = -1;
-    if (timing < 0) { const char* e = getenv("MSDP_TIMING"); timing = (e && atoi(e)) ? 1 : 0; }
-    static int sync_tr = -1;
-    if (sync_tr < 0) { const char* e = getenv("MSDP_SYNC_TR"); sync_tr = (e && atoi(e)) ? 1 : 0; }
+    const bool timing = h->tune.timing != 0;
     double t_tcg = 0.0, t_rest = 0.0, t_enq_sum = 0.0, t_enq_max = 0.0;
-    const char* nopub_env = getenv("MSDP_NO_PUBLISH");
-    const bool async_tr = !sync_tr && h->d.costkind == COST_SPARSE && !h->use_comm && !(nopub_env && atoi(nopub_env));
-    if (async_tr && msdp_persist_fused_ok(h)) {
+    const bool async_tr = h->d.costkind == COST_SPARSE && !h->use_comm;
+    const bool persist = async_tr && msdp_persist_eligible(h);
+    if (persist && h->tune.fail_persist) {                       // test hook: behave as if the launch had timed out
+        h->tune.fail_persist = 0;
+        *timed_out = true;
+        return 0;
+    }
+    if (persist && msdp_persist_fused_ok(h)) {
         // Fused path: the whole trustregions() loop (every tCG, retraction, cost/gradient at the proposal and the
         // accept/reject logic) runs in ONE launch; the host only waits for it (msdp_persist.hip, FUSE = true).
         const auto ta = std::chrono::steady_clock::now();
         h->d.status = nullptr;                                            // no progress word needed
         rc = msdp_launch_rtr_fused(h);
-        {
-            void* dp = nullptr;
-            if (hipHostGetDevicePointer(&dp, (void*)h->h_status, 0) == hipSuccess) h->d.status = (unsigned long long*)dp;
-        }
+        restore_status_ptr(h);
         if (rc) return rc;
         if ((rc = pull_ctl(h))) return rc;
-        int perr = 0;
-        HIPCHK(hipMemcpy(&perr, h->psync_err, sizeof(int), hipMemcpyDeviceToHost));
-        if (perr) { msdp_set_error("fused RTR: grid synchronisation timed out"); return MSDP_EHIP; }
+        if ((rc = persist_timed_out(h, timed_out))) return rc;
+        if (*timed_out) return 0;
         t_tcg = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
-    } else if (async_tr && msdp_persist_eligible(h)) {
+    } else if (persist) {
         // Persistent path: one launch runs the whole tCG of a TR iteration with the working set on chip
-        // (msdp_persist.hip).  The host stays one TR iteration ahead of the device: iteration i+1 is enqueued
-        // as soon as the kernel of iteration i publishes that it has started; a finished solve (ctl->done)
-        // turns everything still enqueued into no-ops and is reported through the same progress word.
-        static int no_tail = -1;
-        if (no_tail < 0) { const char* e = getenv("MSDP_NO_TR_TAIL"); no_tail = (e && atoi(e)) ? 1 : 0; }
+        // (msdp_persist.hip), a second one the rest of the iteration (msdp_trtail.hip: retraction, cost and gradient at
+        // the proposal, accept/reject; each clears the other's synchronisation slots).  The host stays one TR iteration
+        // ahead of the device: iteration i+1 is enqueued as soon as the kernel of iteration i publishes that it has
+        // started; a finished solve (ctl->done) turns everything still enqueued into no-ops and is reported through
+        // the same progress word.
         bool first_iter = true;
         auto enqueue_iter = [&]() -> int {
             int r2;
-            if (!no_tail) {
-                // two launches per TR iteration: the persistent tCG kernel and the tail kernel (retraction, cost and
-                // gradient at the proposal, accept/reject); each clears the other's synchronisation slots
-                if ((r2 = msdp_launch_tcg_persist(h, first_iter ? 1 : 0))) return r2;   // trustregions.m:484-496 + tCG.m
-                first_iter = false;
-                return msdp_launch_tr_tail(h);                            // :540-729
-            }
-            if ((r2 = msdp_launch_tcg_persist(h))) return r2;             // trustregions.m:484-496 + tCG.m
-            if ((r2 = msdp_launch_retract(h))) return r2;                 // :540
-            if ((r2 = msdp_launch_costgrad(h, 3))) return r2;             // :544 (proposal slot, device-resolved)
-            return msdp_launch_rtr_decide(h);                             // :548-729
+            if ((r2 = msdp_launch_tcg_persist(h, first_iter ? 1 : 0))) return r2;   // trustregions.m:484-496 + tCG.m
+            first_iter = false;
+            return msdp_launch_tr_tail(h);                                // :540-729
         };
         int enq = 0;
         bool done = false;
@@ -921,6 +930,10 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
                         if (hipStreamQuery(h->stream) == hipSuccess) {
                             const unsigned long long s2 = *h->h_status;
                             if ((s2 >> 32) == want) { if (((s2 & 0xffffffffULL) >> 1) & 0x40000000) done = true; break; }
+                            // everything enqueued has run and the word never arrived: a launch that gave up on a grid
+                            // synchronisation exits without publishing
+                            if ((rc = persist_timed_out(h, timed_out))) return rc;
+                            if (*timed_out) return 0;
                             msdp_set_error("persistent tCG: progress word inconsistent (status %llx, expected iteration %d)", s2, enq);
                             return MSDP_EHIP;
                         }
@@ -941,9 +954,8 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
             ++enq;
         }
         if ((rc = pull_ctl(h))) return rc;
-        int perr = 0;
-        HIPCHK(hipMemcpy(&perr, h->psync_err, sizeof(int), hipMemcpyDeviceToHost));
-        if (perr) { msdp_set_error("persistent tCG: grid synchronisation timed out"); return MSDP_EHIP; }
+        if ((rc = persist_timed_out(h, timed_out))) return rc;
+        if (*timed_out) return 0;
         t_tcg = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
     } else if (async_tr) {
         // No host sync between TR iterations: the proposal slot is resolved on the device, the next
@@ -964,26 +976,75 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
         }
         if ((rc = pull_ctl(h))) return rc;
     } else {
-    while (!h->h_ctl->done) {                                     // trustregions.m:441
-        cur = h->h_ctl->cur;
-        const auto ta = std::chrono::steady_clock::now();
-        if ((rc = run_tcg(h, opts->maxinner, h->h_ctl->k))) return rc;   // :495
-        const auto tb = std::chrono::steady_clock::now();
-        if ((rc = msdp_launch_retract(h))) return rc;             // :540
-        if ((rc = msdp_launch_costgrad(h, cur ^ 1))) return rc;   // :544
-        if ((rc = msdp_launch_rtr_decide(h))) return rc;          // :548-729
-        if ((rc = pull_ctl(h))) return rc;
-        const auto tc = std::chrono::steady_clock::now();
-        t_tcg += std::chrono::duration<double>(tb - ta).count();
-        t_rest += std::chrono::duration<double>(tc - tb).count();
+        // One host synchronisation per TR iteration (dense / affine kinds bake the slot into their launches; with a
+        // communicator the tCG runs in lock-step, see run_tcg_lockstep)
+        while (!h->h_ctl->done) {                                     // trustregions.m:441
+            cur = h->h_ctl->cur;
+            const auto ta = std::chrono::steady_clock::now();
+            if (h->use_comm) rc = run_tcg_lockstep(h, opts->maxinner);
+            else rc = run_tcg(h, opts->maxinner, h->h_ctl->k);        // :495
+            if (rc) return rc;
+            const auto tb = std::chrono::steady_clock::now();
+            if ((rc = msdp_launch_retract(h))) return rc;             // :540
+            if ((rc = msdp_launch_costgrad(h, cur ^ 1))) return rc;   // :544
+            if ((rc = msdp_launch_rtr_decide(h))) return rc;          // :548-729
+            if ((rc = pull_ctl(h))) return rc;
+            const auto tc = std::chrono::steady_clock::now();
+            t_tcg += std::chrono::duration<double>(tb - ta).count();
+            t_rest += std::chrono::duration<double>(tc - tb).count();
+        }
     }
-    }
-    if (timing)
+    if (timing) {
         fprintf(stderr, "[msdp_rtr] enqueue total %.3f ms, slowest %.3f ms\n", t_enq_sum * 1e3, t_enq_max * 1e3);
-    if (timing)
         fprintf(stderr, "[msdp_rtr] p=%d ld=%d G=%d path=%d k=%d hessvecs=%d acc=%d rej=%d  tCG phase %.3f ms  (retract+cost+decide+sync) %.3f ms\n",
-                h->d.p, h->d.ld, h->d.G, (async_tr && msdp_persist_eligible(h)) ? 1 : 0, h->h_ctl->k, h->h_ctl->hessvecs,
+                h->d.p, h->d.ld, h->d.G, persist ? 1 : 0, h->h_ctl->k, h->h_ctl->hessvecs,
                 h->h_ctl->accepted, h->h_ctl->rejected, t_tcg * 1e3, t_rest * 1e3);
+    }
+    return 0;
+}
+
+extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats* stats) {
+    CHECK_H(h);
+    if (!opts) { msdp_set_error("rtr: null options"); return MSDP_EINVAL; }
+    if (!h->have_point) { msdp_set_error("rtr: no resident point (call msdp_set_point)"); return MSDP_ESTATE; }
+    if (opts->rho_prime >= 0.25) { msdp_set_error("options.rho_prime must be strictly smaller than 1/4"); return MSDP_EINVAL; }
+    if (opts->maxinner < 1 || opts->maxiter < 0) { msdp_set_error("rtr: maxinner >= 1 and maxiter >= 0 required"); return MSDP_EINVAL; }
+    const auto t0 = std::chrono::steady_clock::now();
+    h->last_opts = *opts;
+    // The persistent kernels assume that all their workgroups are resident together.  When the GPU is shared (a
+    // second handle solving on another stream, another process) that can fail; the launch then gives up after a
+    // bounded spin.  Keep a copy of the start point so that the call can be repeated on the chunked path.
+    const int cur0 = h->h_ctl->cur;
+    const size_t cnt = (size_t)rows_capacity(h) * h->ldcap;
+    const bool guard = h->d.costkind == COST_SPARSE && !h->use_comm && msdp_persist_eligible(h);
+    if (guard) {
+        if (h->rtr_start_cap < cnt) {
+            if (h->rtr_start) dev_free(h, h->rtr_start);
+            h->rtr_start = nullptr; h->rtr_start_cap = 0;
+            int rc0 = dev_alloc<double>(h, &h->rtr_start, cnt);
+            if (rc0) return rc0;
+            h->rtr_start_cap = cnt;
+        }
+        HIPCHK(hipMemcpyAsync(h->rtr_start, h->d.Y[cur0], cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    bool timed_out = false;
+    int rc = rtr_core(h, opts, &timed_out);
+    if (rc) return rc;
+    if (timed_out) {
+        if (!guard) { msdp_set_error("persistent tCG: grid synchronisation timed out"); return MSDP_EHIP; }
+        fprintf(stderr, "libmanisdp_hip: a persistent tCG launch could not synchronise its workgroups (GPU shared with another "
+                        "launch?); this handle continues on the chunked path\n");
+        h->persist_failed = true;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemset(h->psync_err, 0, sizeof(int)));
+        h->h_ctl->cur = cur0;
+        HIPCHK(hipMemcpyAsync(h->d.Y[cur0], h->rtr_start, cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        restore_status_ptr(h);
+        h->chunk_len = 0;                                          // re-capture the chunk graph against the current Dev
+        rc = rtr_core(h, opts, &timed_out);
+        if (rc) return rc;
+        if (timed_out) { msdp_set_error("persistent tCG: time-out on the chunked path (internal error)"); return MSDP_EHIP; }
+    }
     h->state_valid = true;
     h->gradnorm_valid = true;
     if (stats) {
@@ -1253,7 +1314,7 @@ extern "C" int msdp_bench_hessvec(msdp_handle h, int32_t reps, double* avg_ms, d
     const int per = 50;
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
-    const bool graph = use_graphs() && !h->use_comm;
+    const bool graph = use_graphs(h);
     if (graph) {
         HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         for (int i = 0; i < per && !rc; ++i) rc = msdp_launch_hess(h);
@@ -1298,7 +1359,6 @@ extern "C" int msdp_bench_kernel(msdp_handle h, int32_t which, int32_t reps, dou
     o.maxinner = 0x7ffffff0; o.maxiter = 1;
     fill_ctl(h, &o);
     h->h_ctl->bench_mode = 1;
-    h->d.fused = 0;                      // the three classic kernels, one at a time
     if ((rc = push_ctl(h))) return rc;
     if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
     if ((rc = msdp_launch_rtr_begin(h))) return rc;
@@ -1347,8 +1407,7 @@ extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms) 
     o.maxinner = 0x7ffffff0; o.maxiter = 1;
     fill_ctl(h, &o);
     h->h_ctl->bench_mode = 1;
-    h->d.fused = fused_enabled(h) ? 1 : 0;
-    if (msdp_persist_eligible(h) && !getenv("MSDP_BENCH_CLASSIC")) {
+    if (msdp_persist_eligible(h)) {
         // persistent kernel: `reps` trips with the exits disabled in one launch (run twice, time the second)
         h->h_ctl->maxinner = reps;
         if ((rc = push_ctl(h))) return rc;
@@ -1386,8 +1445,8 @@ extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms) 
     h->h_ctl->done = 0;
     if ((rc = msdp_launch_tcg_init(h))) return rc;
     if ((rc = enqueue_trips(h, 2))) return rc;
-    const int CH = tcg_chunk();
-    const bool graph = use_graphs() && !h->use_comm;
+    const int CH = TCG_CHUNK;
+    const bool graph = use_graphs(h);
     if (graph && (rc = ensure_chunk_graph(h, CH))) return rc;
     const int nchunks = (reps + CH - 1) / CH;
     reps = nchunks * CH;

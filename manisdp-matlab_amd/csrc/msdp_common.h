@@ -79,7 +79,6 @@ struct Dev {
     double* md;       // mdelta, local rows
     double* md2;      // second direction buffer (fused two-launch trips)
     double* mdx;      // persistent tCG: exchange buffer of the direction rows (uncached memory, sc1 accesses only)
-    int fused;        // 1: trips are {k_hess_fused, k_tcg_upd1}; the final frame is F[1]
     double* Hmd;
     double* full;     // gather source of n x ld (== local buffer when nranks == 1)
     double* W0;       // scratch n_loc x ld
@@ -105,12 +104,29 @@ struct Dev {
     const int64_t* a_rp;  const int* a_ci;  const double* a_v;           // CSR by entry (n^2 rows)
     const double* b; double* yv; double* Axb[2]; double* w;              // length m
     double* Pm;       // partial sums for m-length reductions
-    int variant;      // experiment switch (MSDP_VARIANT), 0 in production
     unsigned long long* status;   // host-mapped progress word: (TR iteration+1) << 32 | tCG j << 1 | active
+};
+
+// Run-time switches of a handle (msdp_set_option; the environment variables of the same meaning are read ONCE, when
+// the handle is created).  Production = the defaults.
+struct Tuning {
+    int persist = 1;       // persistent single-launch tCG / Lanczos kernels where they fit        (MSDP_NO_PERSIST=1 -> 0)
+    int fused_rtr = 1;     // whole trustregions() loop in one launch for p <= 32                  (MSDP_NO_FUSED_RTR=1 -> 0)
+    int graph = 1;         // chunked tCG trips replayed as hipGraphs                              (MSDP_NO_GRAPH=1 -> 0;
+                           //   rocprofv3 7.2 crashes on graph replay)
+    int affine_route = 0;  // A(Ya Yb'): 0 = by bytes moved, 1 = SDDMM, 2 = Gram                   (MSDP_AFFINE_ROUTE=sddmm|gram)
+    int timing = 0;        // per-call timing lines on stderr                                       (MSDP_TIMING=1)
+    int esc_debug = 0;     // per-run Lanczos statistics on stderr                                  (MSDP_ESC_DEBUG=1)
+    int fail_persist = 0;  // test hook (msdp_set_option "debug_fail_persist"): the next persistent launch reports a
+                           //   grid-synchronisation time-out without running, to exercise the recovery path
 };
 
 struct msdp_handle_s {
     int kind = 0;
+    Tuning tune{};
+    bool persist_failed = false;   // a persistent launch timed out on this handle: stay on the chunked path
+    double* rtr_start = nullptr;   // copy of the start point of the running msdp_rtr call (persistent path: recovery)
+    size_t rtr_start_cap = 0;
     Dev d{};
     int pcap = 0;
     int ldcap = 0;
@@ -140,6 +156,8 @@ struct msdp_handle_s {
     Dev chunk_sig{};
     int chunk_len = 0;
     volatile unsigned long long* h_status = nullptr;   // host view of Dev::status
+    volatile int* h_flags = nullptr;                   // pinned copies of ctl->tcg_running, one per chunk in flight (lock-step path)
+    hipEvent_t ev_flag[2] = {nullptr, nullptr};
     double* snap = nullptr;        // msdp_point_snapshot copy of the resident point
     size_t snap_cap = 0;
     int snap_p = 0;
@@ -166,7 +184,6 @@ struct msdp_handle_s {
 // --- launchers implemented in the .hip units (all asynchronous on h->stream) ---
 int msdp_launch_costgrad(msdp_handle h, int slot);            // Y[slot] -> Gr[slot], eG[slot], P_F, P_GG
 int msdp_launch_hess(msdp_handle h);
-int msdp_launch_hess_fused(msdp_handle h);                          // md -> Hmd, P_DHD (oblique sparse/dense)
 int msdp_launch_tcg_init(msdp_handle h);
 int msdp_launch_upd1(msdp_handle h);
 int msdp_launch_upd2(msdp_handle h);

@@ -356,20 +356,9 @@ static void dense_plan(msdp_handle h, int nmat, int* row_blocks_out, int* SK_out
     const int NT0 = (std::min(128, d.ld) + 15) / 16;         // the plan follows the first column block
     const int row_blocks = (d.n_loc + dense3_waves(NT0) * 16 - 1) / (dense3_waves(NT0) * 16);
     const int64_t Ktot = (int64_t)nmat * nS;
-    static int target = -2;
-    if (target == -2) { const char* e = getenv("MSDP_DENSE_BLOCKS"); target = e ? atoi(e) : -1; }
     int SK;
     int64_t kslice;
-    if (target > 0) {                                         // experiment: fixed workgroup target, 64-k granularity
-        SK = (target + row_blocks - 1) / row_blocks;
-        const int maxSK = (int)((Ktot + 127) / 128);
-        if (SK > maxSK) SK = maxSK;
-        if (SK > 32) SK = 32;
-        if (SK < 1) SK = 1;
-        kslice = (Ktot + SK - 1) / SK;
-        kslice = ((kslice + 63) / 64) * 64;
-        SK = (int)((Ktot + kslice - 1) / kslice);
-    } else {
+    {
         const int ncols = std::min(128, d.ld);
         const int NT = (ncols + 15) / 16;
         const double cap = (double)dense3_capacity(NT, dense_ldl(ncols));

@@ -408,9 +408,7 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
     double theta = 0.0, res = 1e300, lmax = 0.0;
     bool converged = false;          // one of the three stop tests passed (else the run ended at maxit: theta is only an upper bound)
     const bool persist = !c.M && c.slots && msdp_lanczos_persist_ok(h, nq);
-    static int no_fused_small = -1;
-    if (no_fused_small < 0) { const char* e = getenv("MSDP_LZ_NO_FUSED"); no_fused_small = (e && atoi(e)) ? 1 : 0; }
-    const bool fused_small = !persist && !no_fused_small && n <= LZS_MAXN;
+    const bool fused_small = !persist && n <= LZS_MAXN;
     if (fused_small) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -641,9 +639,8 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     // the slots proper live in uncached device memory (sc1 accesses skip the L2 look-up: -0.75 us per grid reduction,
     // tools/microbench_sync.hip); the workspace copy above is the fallback
     if (!h->lz_slots) {
-        const char* e = getenv("MSDP_NO_UNCACHED");
         void* pu = nullptr;
-        if (!(e && atoi(e)) && hipExtMallocWithFlags(&pu, msdp_lanczos_slot_bytes(), hipDeviceMallocUncached) == hipSuccess) h->lz_slots = (unsigned long long*)pu;
+        if (hipExtMallocWithFlags(&pu, msdp_lanczos_slot_bytes(), hipDeviceMallocUncached) == hipSuccess) h->lz_slots = (unsigned long long*)pu;
         else (void)hipGetLastError();
     }
     if (h->lz_slots) c.slots = h->lz_slots;
@@ -659,11 +656,10 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         // at 0 and plain Lanczos is both sufficient and more accurate.
         const double gnorm = h->h_ctl->norm_grad;
         // Validated on G81/G11/G1: with this threshold the AL loop converges exactly as with the undeflated
-        // process (dinf trace to < 1e-8) while the Lanczos runs are ~6x shorter (MSDP_ESCAPE_DEFLATE overrides).
-        double dthr = 1e-6;
-        if (const char* ev = getenv("MSDP_ESCAPE_DEFLATE")) dthr = atof(ev);
+        // process (dinf trace to < 1e-8) while the Lanczos runs are ~6x shorter.
+        const double dthr = 1e-6;
         const bool deflate_y = h->gradnorm_valid && gnorm <= dthr * std::max(1.0, fabs(h->h_ctl->fx));
-        const bool dbg = getenv("MSDP_ESC_DEBUG") != nullptr;
+        const bool dbg = h->tune.esc_debug != 0;
         auto tp0 = std::chrono::steady_clock::now();
         double ynorm_max = 0.0;
         for (int cidx = 0; deflate_y && cidx < p; ++cidx) {
@@ -685,9 +681,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         bool have_xstart = false;                       // Z doubles as the warm-start buffer until the final Rayleigh-Ritz
         // Across calls: S changes little from one outer iteration to the next, so the first run starts from the
         // bottom eigenvectors the previous call found (deflated against the current Q inside lanczos_smallest)
-        static int no_warm = -1;
-        if (no_warm < 0) { const char* e = getenv("MSDP_ESC_NO_WARM"); no_warm = (e && atoi(e)) ? 1 : 0; }
-        if (!no_warm && h->esc_prev && h->esc_prev_n == n) {
+        if (h->esc_prev && h->esc_prev_n == n) {
             ESC_HIP(hipMemcpyAsync(Z, h->esc_prev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
             have_xstart = true;
         }
@@ -704,7 +698,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
                 h->esc_converged = 0;
                 h->esc_maxres = std::max(h->esc_maxres, res / (std::max(fabs(theta), fabs(lmx)) + 1e-300));
             }
-            if (getenv("MSDP_ESC_DEBUG")) fprintf(stderr, "[escape] run at t=%d: nq=%d steps=%d theta=%.6e res=%.2e lmax=%.4f accepted=%d\n", t, r, m, theta, res, lmx, nacc);
+            if (dbg) fprintf(stderr, "[escape] run at t=%d: nq=%d steps=%d theta=%.6e res=%.2e lmax=%.4f accepted=%d\n", t, r, m, theta, res, lmx, nacc);
             lam_max = std::max(lam_max, lmx);
             for (int i = 0; i < nacc; ++i) found.push_back(thetas[i]);
             r += nacc; nfound += nacc; t += nacc;

@@ -80,7 +80,7 @@ __device__ __forceinline__ void costgrad_sparse_obl_body(const Dev& d, int slot)
     __shared__ double sh[3 * MSDP_WAVES];
     if (d.ctl->done) return;
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RPW = 64 / LPR;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
@@ -130,7 +130,7 @@ __device__ __forceinline__ void hess_sparse_obl_body(const Dev& d) {
     __shared__ double sh[3 * MSDP_WAVES];
     if (!d.F[0].active) return;
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RPW = 64 / LPR;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_init(Dev d) {
     }
     if (c->done) return;
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
     const double* __restrict__ g = c->cur ? d.Gr[1] : d.Gr[0];
     const int64_t e0 = (int64_t)lo * d.ld, e1 = (int64_t)hi * d.ld;
     const double2 z = make_double2(0.0, 0.0);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd1(Dev d) {
     const bool bench = c->bench_mode != 0;
     const double Delta = c->Delta;
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
     const int64_t e0 = (int64_t)lo * d.ld, e1 = (int64_t)hi * d.ld;
     const double* __restrict__ eta = ix ? d.eta[1] : d.eta[0];
     const double* __restrict__ Heta = ix ? d.Heta[1] : d.Heta[0];
@@ -252,8 +252,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd1(Dev d) {
             RR[q] = ld2(d.r + i); GV[q] = ld2(g + i);
         }
     }
-    const double d_Hd = (d.variant & 64) ? msdp_sum_partials(d.P, P_DHD, d.G)
-                                         : msdp_sum_partials_block(d.P, P_DHD, d.G, shb);       // :166
+    const double d_Hd = msdp_sum_partials_block(d.P, P_DHD, d.G, shb);       // :166
     const double alpha = z_r / d_Hd;                                 // :170
     const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;  // :173
     if (!bench && (d_Hd <= 0.0 || e_Pe_new >= Delta * Delta)) {         // :183
@@ -272,7 +271,6 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd1(Dev d) {
         if (lead) {
             frame_store(&d.F[1], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha0, beta0, 0, j + 1,
                         (d_Hd <= 0.0) ? 1 : 2, ix ^ 1, mi, 0);
-            if (d.fused) { d.ctl->tcg_running = 0; msdp_publish(d, c->k, j + 1, 0); }
         }
         return;
     }
@@ -325,7 +323,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd2_obl(Dev d) {
     const Ctl* c = d.ctl;
     const bool bench = c->bench_mode != 0;
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RPW = 64 / LPR;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
@@ -350,13 +348,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd2_obl(Dev d) {
         }
     }
     double s1, s2, r_r;
-    if (!(d.variant & 64)) {
-        msdp_sum_partials3_block(d.P, P_S1, P_S2, P_S3, d.G, shb, s1, s2, r_r);
-    } else {
-        s1 = msdp_sum_partials(d.P, P_S1, d.G);
-        s2 = msdp_sum_partials(d.P, P_S2, d.G);
-        r_r = msdp_sum_partials(d.P, P_S3, d.G);
-    }
+    msdp_sum_partials3_block(d.P, P_S1, P_S2, P_S3, d.G, shb, s1, s2, r_r);
     const double new_model = s1 + 0.5 * s2;                 // :227
     const int j = j0 + 1;
     if (!bench && new_model >= model_value) {               // :228
@@ -426,186 +418,6 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd2_obl(Dev d) {
     }
 }
 
-// ------------------------------------------------------------------ fused trip head (sparse C, oblique)
-// One launch = tCG.m:227-287 (model check, convergence test, beta, new direction with the tangent
-// re-projection) + the next Hess-vec (tCG.m:163).  The new direction of a NEIGHBOUR row k is recomputed
-// on the fly from (r_k, mdelta_k, Y_k) -- the projection is row-local -- so no workgroup has to wait for
-// another one's mdelta: the global synchronisation between "new direction" and "S*U" disappears and a
-// trip is two launches (this one + k_tcg_upd1) instead of three.  The recomputed values are bit-identical
-// to the stored ones (same operations in the same order).  mdelta ping-pongs between d.md and d.md2.
-template <int LPR, int NCH>
-__device__ __forceinline__ void fused_row_vec(const Dev& d, bool fresh, double beta, int k, int sub,
-                                              const double* __restrict__ mdo, const double* __restrict__ Yl,
-                                              double2 (&u)[NCH]) {
-    double2 y[NCH];
-    double dot = 0.0;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int col = 2 * sub + ch * 2 * LPR;
-        u[ch] = make_double2(0.0, 0.0); y[ch] = u[ch];
-        if (col < d.ld) {
-            const int64_t o = (int64_t)k * d.ld + col;
-            const double2 m = ld2(mdo + o);
-            if (fresh) u[ch] = m;
-            else {
-                const double2 rr = ld2(d.r + o);
-                y[ch] = ld2(Yl + o);
-                u[ch] = make_double2(rr.x + beta * m.x, rr.y + beta * m.y);      // tCG.m:273
-                dot += u[ch].x * y[ch].x + u[ch].y * y[ch].y;
-            }
-        }
-    }
-    if (!fresh) {
-        dot = msdp_group_sum<LPR>(dot);
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) { u[ch].x -= y[ch].x * dot; u[ch].y -= y[ch].y * dot; }   // tCG.m:283
-    }
-}
-
-template <int LPR, int NCH, bool ELL>
-__device__ __forceinline__ void hess_fused_body(const Dev& d) {
-    __shared__ double sh[3 * MSDP_WAVES];
-    __shared__ double shb[4];
-    const Frame* fi = &d.F[1];
-    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
-    const int active = fi->active;
-    const double z_r = fi->z_r, d_Pd = fi->d_Pd, e_Pd = fi->e_Pd, e_Pe = fi->e_Pe;
-    const double model_value = fi->model_value, norm_r0 = fi->norm_r0, beta0 = fi->beta, alpha = fi->alpha;
-    const int j0 = fi->j, stop0 = fi->stop, ix = fi->eta_idx, mi = fi->md_idx, fresh = fi->fresh;
-    const Ctl* c = d.ctl;
-    if (!active) {
-        if (lead) {
-            frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha, beta0, 0, j0, stop0, ix, mi, 0);
-            d.ctl->tcg_running = 0;
-            msdp_publish(d, c->k, j0, 0);
-        }
-        return;
-    }
-    const bool bench = c->bench_mode != 0;
-    double beta = 0.0;
-    int j = j0, nix = ix, nmi = mi;
-    double nz_r = z_r, nd_Pd = d_Pd, ne_Pd = e_Pd, nmodel = model_value;
-    if (!fresh) {
-        double s1, s2, r_r;
-        msdp_sum_partials3_block(d.P, P_S1, P_S2, P_S3, d.G, shb, s1, s2, r_r);
-        const double new_model = s1 + 0.5 * s2;                 // tCG.m:227
-        j = j0 + 1;
-        if (!bench && new_model >= model_value) {               // :228
-            if (lead) {
-                frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha, beta0, 0, j, 6, ix, mi, 0);
-                d.ctl->tcg_running = 0;
-                msdp_publish(d, c->k, j, 0);
-            }
-            return;
-        }
-        nix = ix ^ 1;                                           // :233-235
-        nmodel = new_model;
-        const double norm_r = sqrt(r_r);
-        const double nr0t = (c->theta == 1.0) ? norm_r0 : pow(norm_r0, c->theta);
-        if (!bench && j >= c->mininner && norm_r <= norm_r0 * fmin(nr0t, c->kappa)) {   // :249
-            if (lead) {
-                frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, new_model, norm_r0, alpha, beta0, 0, j,
-                            (c->kappa < nr0t) ? 3 : 4, nix, mi, 0);
-                d.ctl->tcg_running = 0;
-                msdp_publish(d, c->k, j, 0);
-            }
-            return;
-        }
-        if (j >= c->maxinner) {                                 // loop bound :160
-            if (lead) {
-                frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, new_model, norm_r0, alpha, beta0, 0, j, stop0, nix, mi, 0);
-                d.ctl->tcg_running = 0;
-                msdp_publish(d, c->k, j, 0);
-            }
-            return;
-        }
-        beta = r_r / z_r;                                       // :272
-        ne_Pd = beta * (e_Pd + alpha * d_Pd);                   // :286
-        nd_Pd = r_r + beta * beta * d_Pd;                       // :287
-        nz_r = r_r;
-        nmi = mi ^ 1;
-    }
-    if (lead) {
-        frame_store(&d.F[0], nz_r, nd_Pd, ne_Pd, e_Pe, nmodel, norm_r0, alpha, fresh ? beta0 : beta, 1, j, stop0, nix, nmi, 0);
-        msdp_publish(d, c->k, j, 1);
-    }
-    const double* __restrict__ mdo = mi ? d.md2 : d.md;         // direction of the previous trip
-    double* __restrict__ mdn = nmi ? d.md2 : d.md;              // direction of this trip (== mdo when fresh)
-    int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int RPW = 64 / LPR;
-    const int sub = lane & (LPR - 1), rsub = lane / LPR;
-    const int cur = c->cur;
-    const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
-    const double* __restrict__ eG = cur ? d.eG[1] : d.eG[0];
-    double pd = 0.0;
-    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
-        const int row = row0 + rsub;
-        if (row < hi) {
-            double2 u[NCH], y[NCH], acc[NCH];
-            fused_row_vec<LPR, NCH>(d, fresh != 0, beta, row, sub, mdo, Yl, u);
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int col = 2 * sub + ch * 2 * LPR;
-                acc[ch] = make_double2(0.0, 0.0);
-                y[ch] = (col < d.ld) ? ld2(Yl + (int64_t)row * d.ld + col) : make_double2(0.0, 0.0);
-                if (!fresh && col < d.ld) st2(mdn + (int64_t)row * d.ld + col, u[ch]);
-            }
-            const double eg = eG[row];
-            if (ELL) {
-#pragma unroll
-                for (int w = 0; w < MSDP_ELL_MAXW; ++w) {
-                    if (w < d.ellW) {
-                        const int k = d.ellc[(int64_t)w * d.ell_stride + row];
-                        const double v = d.ellv[(int64_t)w * d.ell_stride + row];
-                        double2 x[NCH];
-                        if (k == row) {
-#pragma unroll
-                            for (int ch = 0; ch < NCH; ++ch) x[ch] = u[ch];
-                        } else fused_row_vec<LPR, NCH>(d, fresh != 0, beta, k, sub, mdo, Yl, x);
-#pragma unroll
-                        for (int ch = 0; ch < NCH; ++ch) { acc[ch].x = fma(v, x[ch].x, acc[ch].x); acc[ch].y = fma(v, x[ch].y, acc[ch].y); }
-                    }
-                }
-            } else {
-                const int start = d.rowptr[row], end = d.rowptr[row + 1];
-                for (int t = start; t < end; ++t) {
-                    const int k = d.colind[t];
-                    const double v = d.cval[t];
-                    double2 x[NCH];
-                    if (k == row) {
-#pragma unroll
-                        for (int ch = 0; ch < NCH; ++ch) x[ch] = u[ch];
-                    } else fused_row_vec<LPR, NCH>(d, fresh != 0, beta, k, sub, mdo, Yl, x);
-#pragma unroll
-                    for (int ch = 0; ch < NCH; ++ch) { acc[ch].x = fma(v, x[ch].x, acc[ch].x); acc[ch].y = fma(v, x[ch].y, acc[ch].y); }
-                }
-            }
-            double dot = 0.0;
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) dot += acc[ch].x * y[ch].x + acc[ch].y * y[ch].y;
-            dot = msdp_group_sum<LPR>(dot);
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int col = 2 * sub + ch * 2 * LPR;
-                if (col < d.ld) {
-                    double2 hq;
-                    hq.x = acc[ch].x - y[ch].x * dot - u[ch].x * eg;
-                    hq.y = acc[ch].y - y[ch].y * dot - u[ch].y * eg;
-                    st2(d.Hmd + (int64_t)row * d.ld + col, hq);
-                    pd += u[ch].x * hq.x + u[ch].y * hq.y;
-                }
-            }
-        }
-    }
-    msdp_put_partial(d.P, P_DHD, pd, sh);
-}
-template <int LPR, int NCH>
-__global__ __launch_bounds__(MSDP_BLOCK) void k_hess_fused_csr(Dev d) { hess_fused_body<LPR, NCH, false>(d); }
-template <int LPR, int NCH>
-__global__ __launch_bounds__(MSDP_BLOCK) void k_hess_fused_ell(Dev d) { hess_fused_body<LPR, NCH, true>(d); }
-
 // x_prop = retr(x, eta) (ManiSDP_onlyunitdiag.m:142-145) into the other slot, and the
 // partial of <eta, grad + .5*Heta> (trustregions.m:549-550).
 template <int LPR, int NCH>
@@ -614,11 +426,11 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_retract_obl(Dev d) {
     const Ctl* c = d.ctl;
     if (c->done) return;
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RPW = 64 / LPR;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
-    const int cur = c->cur, ix = d.F[d.fused ? 1 : 0].eta_idx;
+    const int cur = c->cur, ix = d.F[0].eta_idx;
     const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
     const double* __restrict__ g = cur ? d.Gr[1] : d.Gr[0];
     const double* __restrict__ eta = ix ? d.eta[1] : d.eta[0];
@@ -679,7 +491,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_rtr_decide(Dev d) {
     const double rd = msdp_sum_partials(d.P, P_RD, d.G);
     if (threadIdx.x == 0) {
         Ctl* c = d.ctl;
-        const int f_stop = d.F[d.fused ? 1 : 0].stop, f_j = d.F[d.fused ? 1 : 0].j;
+        const int f_stop = d.F[0].stop, f_j = d.F[0].j;
         double rhonum = c->fx - fp;                                          // :548
         double rhoden = -rd;                                                 // :550
         const double rho_reg = fmax(1.0, fabs(c->fx)) * 2.220446049250313e-16 * c->rho_reg;   // :579
@@ -783,9 +595,6 @@ static inline void lpr_for(int ld, int& lpr, int& nch) {
     int half = ld / 2;
     lpr = 1;
     while (lpr < half && lpr < 64) lpr <<= 1;
-    static int shift = -1;
-    if (shift < 0) { const char* e = getenv("MSDP_LPR_SHIFT"); shift = e ? atoi(e) : 0; }
-    for (int s2 = 0; s2 < shift && lpr > 1; ++s2) lpr >>= 1;      // experiment: fewer lanes per row, more columns per lane
     nch = (half + lpr - 1) / lpr;
     if (nch < 1) nch = 1;
 }
@@ -864,13 +673,6 @@ int msdp_launch_hess(msdp_handle h) {
     }
     HIPCHK(hipGetLastError());
     return msdp_allreduce_partials(h, P_DHD, 1);
-}
-
-int msdp_launch_hess_fused(msdp_handle h) {
-    if (h->d.ellW > 0) DISPATCH_LPR(k_hess_fused_ell, h, h->d);
-    else DISPATCH_LPR(k_hess_fused_csr, h, h->d);
-    HIPCHK(hipGetLastError());
-    return 0;
 }
 
 int msdp_launch_tcg_init(msdp_handle h) {

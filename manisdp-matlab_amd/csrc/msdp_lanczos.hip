@@ -360,9 +360,7 @@ static int lz_grid(int n, int nq, int* RW_out, size_t* lds_out) {
 
 // 1 when the persistent kernel can run the recurrence for this problem (sparse C, single rank, everything fits)
 int msdp_lanczos_persist_ok(msdp_handle h, int nq) {
-    const char* e_off = getenv("MSDP_NO_PERSIST");         // read on every call: tests flip it inside one process
-    const int off = (e_off && atoi(e_off)) ? 1 : 0;
-    if (off || h->nranks != 1 || h->use_comm || h->d.costkind != COST_SPARSE || !h->d.rowptr) return 0;
+    if (!h->tune.persist || h->persist_failed || h->nranks != 1 || h->use_comm || h->d.costkind != COST_SPARSE || !h->d.rowptr) return 0;
     if (2 * nq + 1 > LZ_NV || h->d.n < 64) return 0;
     int rw; size_t lds;
     const int G = lz_grid(h->d.n, nq, &rw, &lds);

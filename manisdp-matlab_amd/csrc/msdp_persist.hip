@@ -71,7 +71,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     if (lead && !FUSE) msdp_publish(d, k_tr, 0, 1);                // "TR iteration k_tr has started" (host pipelining)
     if (!FUSE) psync_reset_other(slots + PSYNC_REGION);            // region B belongs to the TR-iteration tail kernel
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
     const bool colok = 2 * sub < d.ld;
@@ -101,7 +101,15 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     // in LDS (the regions that hold Y and grad otherwise) and Y / grad are re-read from global memory (static
     // during the launch: plain cached loads, L2 resident); only eta and r stay in registers.
     constexpr bool LOWREG = (R > 4);
-    double2 eta[R], rr[R], md[LOWREG ? 1 : R], hmd[LOWREG ? 1 : R];
+    // TWOSYNC (everything but LOWREG): two grid synchronisations per trip instead of three.  The workgroups publish
+    // the rows of the new RESIDUAL (known before the second reduction) instead of the new direction (known only after
+    // it), the stores complete before the workgroup posts its partial sums, so the second reduction doubles as the
+    // barrier in front of the gathers; the product with the new direction follows from linearity,
+    //   C*mdelta_new = C*r_new + beta * C*mdelta_old      (mdelta_new = r_new + beta*mdelta_old, tCG.m:273)
+    // with C*mdelta_old kept in registers (cmd).  Each workgroup's own rows of mdelta are still formed and
+    // re-projected exactly as tCG.m:273,283 do.
+    constexpr bool TWOSYNC = !LOWREG;
+    double2 eta[R], rr[R], md[LOWREG ? 1 : R], hmd[LOWREG ? 1 : R], cmd[TWOSYNC ? R : 1];
 #define VOFF(r) ((int64_t)ROW(r) * d.ld + 2 * sub)
 #define Y_GET(r) (LOWREG ? (OK(r) ? ld2(Yl + VOFF(r)) : zz) : Ys[(r) * PB + threadIdx.x])
 #define G_GET(r) (LOWREG ? (OK(r) ? ld2(gl + VOFF(r)) : zz) : Gs[(r) * PB + threadIdx.x])
@@ -226,7 +234,12 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         // ---- Hmdelta = proj(C*mdelta) - mdelta.*eG   (tCG.m:163, ManiSDP_onlyunitdiag.m:127-130)
         double pd = 0.0, u1 = 0.0, u2 = 0.0;
         auto hrow = [&](int r) {
-            const double2 acc = gather_row(r, first ? rs_g : rs_md);
+            double2 acc = gather_row(r, first ? rs_g : rs_md);
+            if (TWOSYNC) {
+                // the gathered rows are those of r_new (first trip: of the gradient = mdelta)
+                if (!first) { acc.x = fma(beta, cmd[TWOSYNC ? r : 0].x, acc.x); acc.y = fma(beta, cmd[TWOSYNC ? r : 0].y, acc.y); }
+                cmd[TWOSYNC ? r : 0] = acc;
+            }
             const double2 y = Y_GET(r), mdr = MD_GET(r);
             double dot = acc.x * y.x + acc.y * y.y;
             dot = msdp_group_sum<LPR>(dot);
@@ -272,7 +285,9 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
             s1 += ne.x * g.x + ne.y * g.y;
             s2 += ne.x * nh.x + ne.y * nh.y;
             s3 += nr.x * nr.x + nr.y * nr.y;
+            if (TWOSYNC && OK(r)) st2_sc1(rs_md, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, nr);
         }
+        if (TWOSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my residual rows are performed before I post
         if (!psync(slots, gen++, d.G, 3, s1, s2, s3, sh, shb, err)) { failed = true; break; }
         e_Pe = e_Pe_new;
         const double new_model = s1 + 0.5 * s2;                                        // :227
@@ -306,10 +321,12 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
             dot = msdp_group_sum<LPR>(dot);
             const double2 mnew = make_double2(v.x - y.x * dot, v.y - y.y * dot);
             MD_SET(r, mnew);
-            if (OK(r)) st2_sc1(rs_md, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, mnew);
+            if (!TWOSYNC && OK(r)) st2_sc1(rs_md, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, mnew);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my rows are performed before my workgroup posts
-        if (!pbarrier(slots, nbar++, d.G, shb, err)) { failed = true; break; }
+        if (!TWOSYNC) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my rows are performed before my workgroup posts
+            if (!pbarrier(slots, nbar++, d.G, shb, err)) { failed = true; break; }
+        }
         first = false;
     }
     if (failed) return;
@@ -479,9 +496,7 @@ static int persist_grid(const Dev& d) {
 // 1: the persistent kernel can run this handle's tCG (and all its workgroups are co-resident); 0: use the chunked path
 int msdp_persist_eligible(msdp_handle h) {
     const Dev& d = h->d;
-    const char* e_off = getenv("MSDP_NO_PERSIST");         // read on every call: tests flip it inside one process
-    const int off = (e_off && atoi(e_off)) ? 1 : 0;
-    if (off || h->use_comm || h->nranks != 1 || d.costkind != COST_SPARSE || d.manifold != MANI_OBLIQUE) return 0;
+    if (!h->tune.persist || h->persist_failed || h->use_comm || h->nranks != 1 || d.costkind != COST_SPARSE || d.manifold != MANI_OBLIQUE) return 0;
     if (!h->psync_slots) return 0;
     const int G = persist_grid(d);
     if (G < 8) return 0;
@@ -533,14 +548,11 @@ static size_t fused_lds(const PersistPlan& pl) {
 
 // Whole trustregions() loop in one launch (FUSE = true): tCG + retraction + cost/gradient at the proposal + the
 // accept/reject logic, iterated on the device until gradnorm < tol or maxiter.  Needs Y and grad in LDS (p <= 32).
-// Default where it applies (MSDP_NO_FUSED_RTR=1 keeps two launches per TR iteration): 10.5 vs 11.1 ms per RTR call on
+// Default where it applies (option fused_rtr = 0 keeps two launches per TR iteration): 10.5 vs 11.1 ms per RTR call on
 // G81 p = 32 once the per-iteration statistics moved from registers to d.ctl (the first version spilled 33 registers
 // inside the tCG loop and was 5% slower).
 int msdp_persist_fused_ok(msdp_handle h) {
-    const char* e = getenv("MSDP_NO_FUSED_RTR");
-    if (e && atoi(e)) return 0;
-    const char* e2 = getenv("MSDP_FUSED_RTR");
-    if (e2 && !atoi(e2)) return 0;                     // MSDP_FUSED_RTR=0 also switches it off
+    if (!h->tune.fused_rtr) return 0;
     if (!msdp_persist_eligible(h)) return 0;
     PersistPlan pl;
     const int G = persist_grid(h->d);

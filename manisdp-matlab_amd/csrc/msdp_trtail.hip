@@ -25,7 +25,7 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
     psync_reset_other(slots);                                  // region A belongs to the persistent tCG kernel
     unsigned long long* sb = slots + PSYNC_REGION;
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi, d.variant & 32);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
     constexpr int RMAX = (LPR / 4 < 4) ? LPR / 4 : 4;            // row slots processed together (their loads overlap)
     const int R = (hi - lo + RSTEP - 1) / RSTEP;               // row slots actually needed (<= LPR/4 by construction)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

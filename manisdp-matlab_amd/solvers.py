@@ -45,7 +45,31 @@ def _host_threads():
         pass
     return threadpool_limits(limits=max(1, min(ncpu, 16)))
 
-__all__ = ["ManiSDP_onlyunitdiag", "ManiSDP_unitdiag", "ManiSDP_unittrace"]
+__all__ = ["ManiSDP_onlyunitdiag", "ManiSDP_unitdiag", "ManiSDP_unittrace", "ManiSDP", "DEFAULTS", "DATA_FIELDS"]
+
+# Option defaults of the reference's entry points: ManiSDP_onlyunitdiag.m:8-17,
+# ManiSDP_unitdiag.m:10-26, ManiSDP_unittrace.m:10-25, ManiSDP.m:9-25.
+DEFAULTS = {
+    "onlyunitdiag": dict(p0=2, AL_maxiter=20, tol=1e-8, theta=1e-1, delta=8, alpha=0.5, tolgradnorm=1e-8,
+                         TR_maxinner=100, TR_maxiter=40, line_search=0),
+    "unitdiag": dict(p0=2, AL_maxiter=300, gama=2, sigma0=1e-3, sigma_min=1e-2, sigma_max=1e7, tol=1e-8,
+                     theta=1e-3, delta=8, alpha=0.1, tolgradnorm=1e-8, TR_maxinner=20, TR_maxiter=4,
+                     tau1=1, tau2=1, line_search=0),
+    "unittrace": dict(p0=1, AL_maxiter=1000, gama=2, sigma0=1e1, sigma_min=1e2, sigma_max=1e7, tol=1e-8,
+                      theta=1e-2, delta=8, alpha=0.05, tolgradnorm=1e-8, TR_maxinner=40, TR_maxiter=3,
+                      tau1=1e-5, tau2=1e-4, line_search=1),
+    "generic": dict(p0=1, AL_maxiter=1000, gama=2, sigma0=1e-2, sigma_min=1e-1, sigma_max=1e7, tol=1e-8,
+                    theta=1e-2, delta=8, alpha=0.1, tolgradnorm=1e-8, TR_maxinner=20, TR_maxiter=4,
+                    tau1=1e-2, tau2=1e-1, line_search=1, solver=0),
+}
+# Fields of the reference's `data` output (ManiSDP_onlyunitdiag.m:86-95, ManiSDP_unitdiag.m:114-127,
+# ManiSDP_unittrace.m:119-131); the Python mirrors add counters (hessvecs, rtr_seconds, ...) next to them.
+DATA_FIELDS = {
+    "onlyunitdiag": ("X", "S", "z", "dinf", "gradnorm", "time", "status"),
+    "unitdiag": ("X", "y", "S", "z", "gap", "pinf", "dinf", "gradnorm", "time", "fac_size", "status"),
+    "unittrace": ("X", "y", "S", "z", "gap", "pinf", "dinf", "gradnorm", "time", "status"),
+    "generic": ("X", "y", "S", "gap", "pinf", "dinf", "gradnorm", "time", "status"),
+}
 
 
 def _say(verbose, msg):
@@ -123,10 +147,8 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
     (``'host'`` dense LAPACK | ``'device'`` few-eigenvector escape; default by size),
     ``dense_X_max``."""
     o = dict(options or {})
-    o.setdefault("p0", 2); o.setdefault("AL_maxiter", 20); o.setdefault("tol", 1e-8)
-    o.setdefault("theta", 1e-1); o.setdefault("delta", 8); o.setdefault("alpha", 0.5)
-    o.setdefault("tolgradnorm", 1e-8); o.setdefault("TR_maxinner", 100); o.setdefault("TR_maxiter", 40)
-    o.setdefault("line_search", 0)
+    for k, v in DEFAULTS["onlyunitdiag"].items():
+        o.setdefault(k, v)
     dense_max = int(o.get("dense_eig_max", 3000))
     dense_X_max = int(o.get("dense_X_max", 4000))
     rng = rng or np.random.default_rng(0)
@@ -220,10 +242,11 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
             Y = np.ascontiguousarray(Y)
     finally:
         h.close()
+    if S is None and sp.issparse(Csp) and z is not None:
+        S = Csp - sp.diags(z)                              # :49 (kept sparse; the reference returns full(S))
     data.update({"Y": Y, "S": S, "z": z, "dinf": dinf, "gradnorm": gradnorm,
-                 "time": time.time() - t0, "p": Y.shape[1]})
-    if n <= dense_X_max:
-        data["X"] = Y @ Y.T                                # :45,86
+                 "time": time.time() - t0, "p": Y.shape[1],
+                 "X": (Y @ Y.T if n <= dense_X_max else None)})   # :45,86
     if data["status"] == 0 and (dinf > o["tol"] or not certified):   # :92-95
         data["status"] = 1
         _say(verbose, "Iteration maximum is reached!")
@@ -417,6 +440,8 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
                 sigma = max(sigma / gama, o["sigma_min"])
             elif pinf > o["tau2"] * gradnorm:
                 sigma = min(sigma * gama, o["sigma_max"])
+        if S is None and obj is not None and n <= int(o.get("dense_X_max", 6000)):
+            S = h.get_dual_slack()                         # data.S of the reference (:116), from the device
     finally:
         h.close()
     data.update({"Y": Y, "X": (Y @ Y.T if n <= int(o.get("dense_X_max", 6000)) else None), "y": y, "S": S, "z": z, "gap": gap, "pinf": pinf, "dinf": dinf,
@@ -433,26 +458,17 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
 def ManiSDP_unitdiag(At, b, c, K, options=None, verbose=True, rng=None):
     """``[X, obj, data] = ManiSDP_unitdiag(At, b, c, K, options)`` (reference
     src/primal/ManiSDP_unitdiag.m:7; defaults :10-26)."""
-    defaults = dict(p0=2, AL_maxiter=300, gama=2, sigma0=1e-3, sigma_min=1e-2, sigma_max=1e7, tol=1e-8,
-                    theta=1e-3, delta=8, alpha=0.1, tolgradnorm=1e-8, TR_maxinner=20, TR_maxiter=4,
-                    tau1=1, tau2=1, line_search=0)
-    return _affine_common(_lib.KIND_UNITDIAG, At, b, c, K, options, verbose, rng, defaults)
+    return _affine_common(_lib.KIND_UNITDIAG, At, b, c, K, options, verbose, rng, DEFAULTS["unitdiag"])
 
 
 def ManiSDP_unittrace(At, b, c, K, options=None, verbose=True, rng=None):
     """``[X, obj, data] = ManiSDP_unittrace(At, b, c, K, options)`` (reference
     src/primal/ManiSDP_unittrace.m:7; defaults :10-25)."""
-    defaults = dict(p0=1, AL_maxiter=1000, gama=2, sigma0=1e1, sigma_min=1e2, sigma_max=1e7, tol=1e-8,
-                    theta=1e-2, delta=8, alpha=0.05, tolgradnorm=1e-8, TR_maxinner=40, TR_maxiter=3,
-                    tau1=1e-5, tau2=1e-4, line_search=1)
-    return _affine_common(_lib.KIND_UNITTRACE, At, b, c, K, options, verbose, rng, defaults)
+    return _affine_common(_lib.KIND_UNITTRACE, At, b, c, K, options, verbose, rng, DEFAULTS["unittrace"])
 
 
 def ManiSDP(At, b, c, K, options=None, verbose=True, rng=None):
     """``[X, obj, data] = ManiSDP(At, b, c, K, options)`` -- the generic entry point on the Euclidean manifold
     (reference src/primal/ManiSDP.m:6; defaults :9-25).  Same device kernels as the two structured affine entry
     points with the projection / retraction terms switched off."""
-    defaults = dict(p0=1, AL_maxiter=1000, gama=2, sigma0=1e-2, sigma_min=1e-1, sigma_max=1e7, tol=1e-8,
-                    theta=1e-2, delta=8, alpha=0.1, tolgradnorm=1e-8, TR_maxinner=20, TR_maxiter=4,
-                    tau1=1e-2, tau2=1e-1, line_search=1, solver=0)
-    return _affine_common(_lib.KIND_GENERIC, At, b, c, K, options, verbose, rng, defaults)
+    return _affine_common(_lib.KIND_GENERIC, At, b, c, K, options, verbose, rng, DEFAULTS["generic"])

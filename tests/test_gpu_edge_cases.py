@@ -183,3 +183,91 @@ def test_point_snapshot_restore(lib):
     with pytest.raises(lib.MsdpError):
         h.point_restore()                         # snapshot of another width
     h.close()
+
+
+# ------------------------------------------------------------------ persistent path: recovery and sharing the GPU
+def _grid_problem(seed):
+    from manisdp_matlab_amd import problems
+    C = problems.toroidal_grid_maxcut(40, 50, seed=seed)
+    rng = np.random.default_rng(seed)
+    Y = rng.standard_normal((C.shape[0], 16)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    return C, Y
+
+
+def test_persistent_timeout_falls_back_to_the_chunked_path(lib, capfd):
+    """A persistent launch that cannot synchronise its workgroups (here: provoked through the test hook) must not
+    surface as an error: msdp_rtr restores the start point, repeats the call on the chunked path inside the same
+    process and keeps the handle there."""
+    C, Y = _grid_problem(3)
+    opts = lib.default_opts(maxiter=25, maxinner=60, tolgradnorm=1e-9)
+    h = lib.Handle.onlyunitdiag(C, pcap=16)
+    h.set_point(Y)
+    assert h.tcg_path() == 1
+    ref = h.rtr(opts)                                    # persistent path, undisturbed
+    Yref = h.get_point()
+    h.set_point(Y)
+    h.set_option("debug_fail_persist", 1)
+    st = h.rtr(opts)                                     # time-out -> restore -> chunked
+    assert "continues on the chunked path" in capfd.readouterr().err
+    assert h.tcg_path() == 0                             # the handle stays on the chunked path
+    assert abs(st.cost - ref.cost) <= 1e-9 * abs(ref.cost) and st.gradnorm < 1e-6
+    assert _relerr(np.abs(h.get_point() @ h.get_point().T), np.abs(Yref @ Yref.T)) < 1e-6
+    # and keeps working from other points without further messages
+    h.set_point(Y[:, ::-1].copy())
+    st2 = h.rtr(opts)
+    assert capfd.readouterr().err == ""
+    assert abs(st2.cost - ref.cost) <= 1e-6 * abs(ref.cost)
+    h.close()
+
+
+def test_two_handles_on_two_streams_share_the_gpu(lib):
+    """Two handles solving concurrently from two host threads (each handle has its own stream): whichever way the
+    hardware interleaves their persistent launches -- both resident, or one starved until its bounded spin gives up and
+    the call is repeated on the chunked path -- both calls return the right answer and neither reports an error."""
+    import threading
+    probs = [_grid_problem(5), _grid_problem(6)]
+    opts = lib.default_opts(maxiter=40, maxinner=100, tolgradnorm=1e-9)
+    solo = []
+    for C, Y in probs:
+        h = lib.Handle.onlyunitdiag(C, pcap=16)
+        h.set_point(Y)
+        solo.append(h.rtr(opts).cost)
+        h.close()
+    handles = [lib.Handle.onlyunitdiag(C, pcap=16) for C, _ in probs]
+    for h, (_, Y) in zip(handles, probs):
+        h.set_point(Y)
+    out = [None, None]
+
+    def work(i):
+        try:
+            costs = []
+            for _ in range(3):
+                handles[i].set_point(probs[i][1])
+                costs.append(handles[i].rtr(opts).cost)
+            out[i] = costs
+        except Exception as e:                            # noqa: BLE001 -- reported below
+            out[i] = e
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    for i in range(2):
+        assert isinstance(out[i], list), out[i]
+        for cst in out[i]:
+            assert abs(cst - solo[i]) <= 1e-6 * abs(solo[i])
+    for h in handles:
+        h.close()
+
+
+def test_set_option_rejects_unknown_names(lib):
+    C, Y = _grid_problem(1)
+    h = lib.Handle.onlyunitdiag(C)
+    with pytest.raises(lib.MsdpError):
+        h.set_option("no_such_option", 1)
+    h.set_option("persist", 0)
+    h.set_point(Y)
+    assert h.tcg_path() == 0
+    h.set_option("persist", 1)
+    assert h.tcg_path() == 1
+    h.close()

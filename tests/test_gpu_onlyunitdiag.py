@@ -147,27 +147,6 @@ def test_solver_G1_matches_oracle(lib):
     assert abs(-obj11 - known["maxG11"]) < 1e-6 * known["maxG11"]
 
 
-def test_fused_trip_matches_classic(lib, monkeypatch):
-    """MSDP_FUSED=1 (two launches per tCG trip: the direction update is recomputed inside the Hess-vec kernel)
-    must reproduce the classic three-launch trip bit for bit: same arithmetic in the same order."""
-    import subprocess, sys, os, json
-    code = (
-        "import sys, json, numpy as np; sys.path.insert(0, %r);"
-        "from manisdp_matlab_amd import _lib, problems;"
-        "C = problems.toroidal_grid_maxcut(30, 40, seed=2); n = C.shape[0]; rng = np.random.default_rng(1);"
-        "Y = rng.standard_normal((n, 10)); Y /= np.linalg.norm(Y, axis=1, keepdims=True);"
-        "h = _lib.Handle.onlyunitdiag(C); h.set_point(Y);"
-        "st = h.rtr(_lib.default_opts(maxiter=12, maxinner=40, tolgradnorm=1e-9));"
-        "print(json.dumps([st.cost, st.gradnorm, st.hessvecs, st.accepted, st.rejected, float(np.sum(h.get_point()))]))"
-    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for fused in ("0", "1"):
-        env = dict(os.environ, MSDP_FUSED=fused, MSDP_NO_PERSIST="1")   # both are chunked-graph variants
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True)
-        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    assert outs[0] == outs[1]
-
-
 def _ring_lattice_cost(n, k, seed):
     """Symmetric sparse C with 2k off-diagonal entries + the diagonal per row (ELL width 2k+1)."""
     rng = np.random.default_rng(seed)
@@ -260,17 +239,17 @@ def test_persistent_tcg_csr_rows_G1(lib, p):
     h.close()
 
 
-def test_fused_rtr_kernel_matches_per_iteration_path(lib, monkeypatch):
-    """MSDP_FUSED_RTR=1 (opt-in: the whole trustregions() loop in one launch) takes the same decisions as one
-    persistent launch per TR iteration: same iteration / Hess-vec / accept counts and the same cost to rounding."""
+def test_fused_rtr_kernel_matches_per_iteration_path(lib):
+    """The whole trustregions() loop in one launch (option fused_rtr, the default for p <= 32) takes the same decisions
+    as one persistent launch per TR iteration: same iteration / Hess-vec / accept counts and the same cost to rounding."""
     from manisdp_matlab_amd import problems
     C = problems.toroidal_grid_maxcut(30, 40, seed=2)
     n, p = C.shape[0], 10
     Y, _ = _rand_point(n, p, seed=1)
     out = []
-    for fused in ("0", "1"):
-        monkeypatch.setenv("MSDP_FUSED_RTR", fused)
+    for fused in (0, 1):
         h = lib.Handle.onlyunitdiag(C, pcap=p)
+        h.set_option("fused_rtr", fused)
         h.set_point(Y)
         st = h.rtr(lib.default_opts(maxiter=6, maxinner=40, tolgradnorm=1e-9))
         out.append((st.iters, st.hessvecs, st.accepted, st.rejected, st.cost, st.gradnorm, h.cost()))

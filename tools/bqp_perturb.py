@@ -12,6 +12,8 @@ e = np.loadtxt(os.path.join(gold, "bqp_e_%d_1.txt.gz" % d), delimiter=",")
 At, b, c, K = problems.bqpmom(d, Q, e)
 c = np.asarray(c.todense()).ravel(); c = c / np.abs(c).max()
 n = K["s"]
+import json
+extra = json.loads(os.environ.get("BQP_OPTS", "{}"))            # e.g. BQP_OPTS='{"eig": "host", "dense_eig_max": 100000}'
 ks = [int(x) for x in sys.argv[1:]] or list(range(0, 21))
 bad = 0
 for k in ks:
@@ -21,7 +23,7 @@ for k in ks:
         Y0 += 1e-13 * np.random.default_rng(1000 + k).standard_normal((n, 2))
     Y0 /= np.sqrt(np.sum(Y0 * Y0, axis=1, keepdims=True))
     t = time.time()
-    Y, obj, data = solvers.ManiSDP_unitdiag(At, b, c, K, {"Y0": Y0, "AL_maxiter": 160}, verbose=False)
+    Y, obj, data = solvers.ManiSDP_unitdiag(At, b, c, K, dict({"Y0": Y0, "AL_maxiter": 160}, **extra), verbose=False)
     eta = max(data["gap"], data["pinf"], data["dinf"])
     bad += data["status"] != 0
     print("gpu pert %d: obj %.8f eta %.1e status %d iters %d hessvecs %d %.1f s" % (
