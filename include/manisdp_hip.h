@@ -240,6 +240,9 @@ int msdp_get_dual_slack(msdp_handle h, double* S);
  *   "fused_rtr"    1/0  whole trustregions() loop in one launch for p <= 32          (default 1; env MSDP_NO_FUSED_RTR=1)
  *   "graph"        1/0  chunked tCG trips replayed as hipGraphs                      (default 1; env MSDP_NO_GRAPH=1)
  *   "affine_route" 0 = choose by bytes moved, 1 = SDDMM, 2 = Gram                    (default 0; env MSDP_AFFINE_ROUTE)
+ *   "escape_deflate" 1/0 escape: deflate span(Y) at near-stationary points (default 1).  Fast, but only as accurate as
+ *                       S*Y is small; a caller about to DECLARE optimality re-checks lambda_min with 0 (see solvers.py)
+ *   "escape_warm"  1/0  escape: start from what the previous call found (default 1; 0 = hashed random start vector)
  *   "timing", "esc_debug"  1/0  diagnostics on stderr                                (env MSDP_TIMING, MSDP_ESC_DEBUG)
  *   "debug_fail_persist"   1    test hook: the next persistent launch reports a synchronisation time-out
  * The environment variables are read once, when the handle is created.  Unknown names -> MSDP_EINVAL. */

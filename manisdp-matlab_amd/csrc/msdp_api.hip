@@ -555,6 +555,8 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "affine_route")) { if (value < 0 || value > 2) { msdp_set_error("affine_route: 0 auto, 1 sddmm, 2 gram"); return MSDP_EINVAL; } t.affine_route = value; h->chunk_len = 0; h->state_valid = false; }
     else if (!strcmp(name, "timing")) t.timing = value != 0;
     else if (!strcmp(name, "esc_debug")) t.esc_debug = value != 0;
+    else if (!strcmp(name, "escape_deflate")) t.escape_deflate = value != 0;
+    else if (!strcmp(name, "escape_warm")) t.escape_warm = value != 0;
     else if (!strcmp(name, "debug_fail_persist")) t.fail_persist = value != 0;
     else { msdp_set_error("set_option: unknown option '%s'", name); return MSDP_EINVAL; }
     return 0;

@@ -117,6 +117,8 @@ struct Tuning {
     int affine_route = 0;  // A(Ya Yb'): 0 = by bytes moved, 1 = SDDMM, 2 = Gram                   (MSDP_AFFINE_ROUTE=sddmm|gram)
     int timing = 0;        // per-call timing lines on stderr                                       (MSDP_TIMING=1)
     int esc_debug = 0;     // per-run Lanczos statistics on stderr                                  (MSDP_ESC_DEBUG=1)
+    int escape_deflate = 1;  // escape: deflate span(Y) at near-stationary points (fast, approximate when S*Y != 0)
+    int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
     int fail_persist = 0;  // test hook (msdp_set_option "debug_fail_persist"): the next persistent launch reports a
                            //   grid-synchronisation time-out without running, to exercise the recovery path
 };

@@ -598,7 +598,9 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     if (k < 1) { msdp_set_error("escape_eigs: k >= 1"); return MSDP_EINVAL; }
     const int n = d.n, p = d.p;
     if (maxit < 8) maxit = 8;
-    if (maxit > n) maxit = n;
+    // Without re-orthogonalisation the process may need more than n steps for the extreme pairs (ghost copies use
+    // up steps); small matrices are cheap, so allow 4 n there
+    if (maxit > 4 * n) maxit = 4 * n;
     // keep the stored Lanczos basis below ~24 GB
     const int64_t cap = (int64_t)(24.0e9 / 8.0 / n);
     if (maxit > cap) maxit = (int)std::max<int64_t>(64, cap);
@@ -658,7 +660,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         // Validated on G81/G11/G1: with this threshold the AL loop converges exactly as with the undeflated
         // process (dinf trace to < 1e-8) while the Lanczos runs are ~6x shorter.
         const double dthr = 1e-6;
-        const bool deflate_y = h->gradnorm_valid && gnorm <= dthr * std::max(1.0, fabs(h->h_ctl->fx));
+        const bool deflate_y = h->tune.escape_deflate && h->gradnorm_valid && gnorm <= dthr * std::max(1.0, fabs(h->h_ctl->fx));
         const bool dbg = h->tune.esc_debug != 0;
         auto tp0 = std::chrono::steady_clock::now();
         double ynorm_max = 0.0;
@@ -681,7 +683,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         bool have_xstart = false;                       // Z doubles as the warm-start buffer until the final Rayleigh-Ritz
         // Across calls: S changes little from one outer iteration to the next, so the first run starts from the
         // bottom eigenvectors the previous call found (deflated against the current Q inside lanczos_smallest)
-        if (h->esc_prev && h->esc_prev_n == n) {
+        if (h->tune.escape_warm && h->esc_prev && h->esc_prev_n == n) {
             ESC_HIP(hipMemcpyAsync(Z, h->esc_prev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
             have_xstart = true;
         }

@@ -21,6 +21,7 @@
 //   [lam, V, lmax, ok] = manisdp_mex('escape_eigs_dual', h, k, tol, maxit)
 //   S = manisdp_mex('get_dual_slack', h)
 //   k = manisdp_mex('kind', h)
+//       manisdp_mex('set_option', h, name, value)        run-time switch of the handle (msdp_set_option)
 //       manisdp_mex('destroy', h)
 //
 // Handles travel as uint64 scalars and are remembered here together with (kind, n, m), so the factor layout is
@@ -198,6 +199,12 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         const int rc = msdp_get_kind(h, &k);
         if (rc) fail("get_kind", rc);
         plhs[0] = mxCreateDoubleScalar((double)k);
+    } else if (cmd == "set_option") {
+        need(nrhs == 4 && mxIsChar(prhs[2]), "manisdp_mex('set_option', h, name, value)");
+        char name[64];
+        if (mxGetString(prhs[2], name, sizeof(name))) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "option name too long");
+        const int rc = msdp_set_option(h, name, (int32_t)mxGetScalar(prhs[3]));
+        if (rc) fail("set_option", rc);
     } else if (cmd == "set_multipliers") {
         need(nrhs == 4, "manisdp_mex('set_multipliers', h, y, sigma)");
         if ((int64_t)mxGetNumberOfElements(prhs[2]) != me.m) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "y must have m entries");

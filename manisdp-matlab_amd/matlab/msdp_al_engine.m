@@ -76,6 +76,7 @@ for iter = 1:opt.AL_maxiter
     info = manisdp_mex('rtr', h, tr_opts);
     gradnorm = info.gradnorm;
     Y = manisdp_mex('get_point', h);
+    Yeval = Y;                                 % the point the residues below belong to; what X is built from at the end
 
     % ---- KKT quantities from the device
     if T.affine
@@ -94,6 +95,19 @@ for iter = 1:opt.AL_maxiter
     end
     certified = (okflag ~= 0);                 % a Lanczos run that ran out of steps certifies nothing
     dinf = max(0, -lam(1))/(1 + lam_top);
+    if T.affine, eta_now = max([gap, pinf, dinf]); else, eta_now = dinf; end
+    if certified && (eta_now < opt.tol || iter == opt.AL_maxiter)
+        % The regular escape call deflates span(Y) and starts from the previous call's vectors: fast, but only as
+        % accurate as S*Y is small.  Before dinf may end the solve (and on the last pass, so that the reported dinf
+        % is the true one) lambda_min is recomputed by plain Lanczos on S: no deflation, random start.
+        [lam1, v1, top1, okflag] = independent_lambda_min(h, T.affine, n, opt);
+        certified = (okflag ~= 0);
+        dcheck = max(0, -lam1)/(1 + top1);
+        if dcheck >= opt.tol && dinf < opt.tol
+            V = [v1, V(:, 1:max(opt.delta - 1, 0))];  lam = [lam1; lam(1:end-1)];
+        end
+        dinf = dcheck;
+    end
 
     % ---- numerical rank of the factor from its p x p Gram matrix
     if T.wide, G = Y*Y'; else, G = Y'*Y; end
@@ -158,14 +172,14 @@ end
 
 % ---- outputs in the reference's shape
 if opt.dense_output
-    if T.wide, X = Y'*Y; else, X = Y*Y'; end
+    if T.wide, X = Yeval'*Yeval; else, X = Yeval*Yeval'; end
     if T.affine
         data.S = manisdp_mex('get_dual_slack', h);
     else
         data.S = prob.C - spdiags(z(:), 0, n, n);
     end
 else
-    X = Y;  data.S = [];
+    X = Yeval;  data.S = [];
 end
 data.X = X;
 data.z = z;
@@ -209,6 +223,27 @@ if strcmp(kind, 'unitdiag')
     T.watch_every = 50;  T.watch_after = 100;
 else
     T.watch_every = 20;  T.watch_after = 50;
+end
+end
+
+% -------------------------------------------------------------------------
+function [lam1, v1, top1, okflag] = independent_lambda_min(h, affine, n, opt)
+% Affine kinds with a dense S of moderate order: the reference's own eig(S) on the S the device holds.  Otherwise
+% plain Lanczos on the device (no deflation of span(Y), random start vector; twice if the first budget runs out).
+if ~isfield(opt, 'verify_dense_max'), opt.verify_dense_max = 4000; end
+if affine && n <= opt.verify_dense_max
+    S = manisdp_mex('get_dual_slack', h);
+    [W, w] = eig((S + S')/2, 'vector');
+    lam1 = w(1);  v1 = W(:, 1);  top1 = w(end);  okflag = 1;
+    return;
+end
+manisdp_mex('set_option', h, 'escape_deflate', 0);
+manisdp_mex('set_option', h, 'escape_warm', 0);
+restore = onCleanup(@() cellfun(@(nm) manisdp_mex('set_option', h, nm, 1), {'escape_deflate', 'escape_warm'})); %#ok<NASGU>
+if affine, cmd = 'escape_eigs_dual'; else, cmd = 'escape_eigs'; end
+[lam1, v1, top1, okflag] = manisdp_mex(cmd, h, 1, opt.eig_tol, opt.eig_maxit);
+if ~okflag
+    [lam1, v1, top1, okflag] = manisdp_mex(cmd, h, 1, opt.eig_tol, 4*opt.eig_maxit);
 end
 end
 

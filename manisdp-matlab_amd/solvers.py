@@ -134,6 +134,37 @@ def _device_escape(h, run, o, data, default_tol, default_maxit):
     return lam, vS, lam_max, nvalid, conv
 
 
+def _verify_lambda_min(h, run1, o, data, default_tol, default_maxit, dense_n=0):
+    """The independent check behind "Optimality is reached!".  The regular escape call deflates span(Y) and starts
+    from what the previous call found: fast, but its lambda_min is only as good as S*Y is small and it can stay above
+    the true one.  Before dinf may end the solve -- and once at the end of a solve that did not converge, so that the
+    reported dinf is the true one -- lambda_min and lambda_max are recomputed without those shortcuts:
+      * affine kinds with a dense S of moderate order (dense_n <= options.verify_dense_max, default 4000): the
+        reference's own eig(S) (ManiSDP_unitdiag.m:68) on the host, on the S the device holds;
+      * otherwise plain Lanczos runs on S itself: no deflation, hashed random start vector.
+    Returns (lambda_min, its eigenvector as an n x 1 array, lambda_max, converged)."""
+    t1 = time.time()
+    data["eig_verifications"] = data.get("eig_verifications", 0) + 1
+    if 0 < dense_n <= int(o.get("verify_dense_max", 4000)):
+        S = h.get_dual_slack()
+        w, V = np.linalg.eigh(0.5 * (S + S.T))
+        data["eig_seconds"] += time.time() - t1
+        return float(w[0]), V[:, :1], float(w[-1]), True
+    h.set_option("escape_deflate", 0)
+    h.set_option("escape_warm", 0)
+    try:
+        lam, vS, lam_max, _ = run1(float(o.get("eig_tol", default_tol)), int(o.get("eig_maxit", default_maxit)))
+        _, conv, _ = h.escape_info()
+        if not conv:                                      # once more with four times the step budget
+            lam, vS, lam_max, _ = run1(float(o.get("eig_tol", default_tol)), 4 * int(o.get("eig_maxit", default_maxit)))
+            _, conv, _ = h.escape_info()
+    finally:
+        h.set_option("escape_deflate", 1)
+        h.set_option("escape_warm", 1)
+    data["eig_seconds"] += time.time() - t1
+    return float(lam[0]), vS[:, :1], float(lam_max), conv
+
+
 # =============================================================== onlyunitdiag
 def ManiSDP_onlyunitdiag(C, options=None, verbose=True, rng=None):
     with _host_threads():
@@ -174,6 +205,7 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
     obj = dinf = gradnorm = None
     z = S = None
     certified = True
+    last_verified = True
     try:
         for it in range(1, int(o["AL_maxiter"]) + 1):      # :38
             h.set_point(Y)
@@ -186,6 +218,7 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
             data["rejected"] += st.rejected
             gradnorm = st.gradnorm                         # :44
             Y = h.get_point()
+            Y_eval = Y                                     # X = Y'*Y of :45 -- what the reference returns (:86)
             z = h.get_z()                                  # :46-47  z = sum((Y*C).*Y)
             obj = float(np.sum(z))                         # :48
             t1 = time.time()
@@ -213,6 +246,16 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
                 S = None
             data["eig_seconds"] += time.time() - t1
             dinf = max(0.0, -lam_min) / (1.0 + lam_max)    # :51
+            last_verified = eig_mode != "device"
+            if eig_mode == "device" and certified and (dinf < o["tol"] or it == int(o["AL_maxiter"])):
+                last_verified = True
+                lam_v, v_v, lmax_v, certified = _verify_lambda_min(
+                    h, lambda tol, maxit: h.escape_eigs(1, tol=tol, maxit=maxit), o, data, 1e-9, 60000)
+                dinf_v = max(0.0, -lam_v) / (1.0 + lmax_v)
+                if dinf_v >= o["tol"] > dinf:              # the deflated run had missed the bottom of the spectrum
+                    vS = np.hstack([v_v, vS[:, :max(int(o["delta"]) - 1, 0)]])
+                    nneg = max(nneg, 1)
+                dinf = dinf_v
             Q, e, r = _thin_svd_rank(Y, float(o["theta"]))  # :52-54
             _say(verbose, "Iter %d, obj:%0.8f, dinf:%0.1e, r:%d, p:%d, time:%0.2fs"
                  % (it, obj, dinf, r, p, time.time() - t0))
@@ -240,8 +283,14 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
                 Y = np.hstack([Y, o["alpha"] * vS[:, :nne]])   # :82
                 Y = Y / np.sqrt(np.sum(Y * Y, axis=1, keepdims=True))   # :83
             Y = np.ascontiguousarray(Y)
+        if obj is not None and not last_verified and certified:   # a solve that stopped on "Slow progress": report the true dinf
+            lam_v, _, lmax_v, certified = _verify_lambda_min(
+                h, lambda tol, maxit: h.escape_eigs(1, tol=tol, maxit=maxit), o, data, 1e-9, 60000)
+            dinf = max(0.0, -lam_v) / (1.0 + lmax_v)
     finally:
         h.close()
+    if obj is not None:
+        Y = Y_eval          # the point the residues belong to (the loop's last pass has already widened its own copy)
     if S is None and sp.issparse(Csp) and z is not None:
         S = Csp - sp.diags(z)                              # :49 (kept sparse; the reference returns full(S))
     data.update({"Y": Y, "S": S, "z": z, "dinf": dinf, "gradnorm": gradnorm,
@@ -323,6 +372,7 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
     S = z = None
     slow_every, slow_after = (20, 50) if (sphere or generic) else (50, 100)
     certified = True
+    last_verified = True
     try:
         for it in range(1, int(o["AL_maxiter"]) + 1):
             fac_size.append(p)
@@ -337,6 +387,7 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
             data["rejected"] += st.rejected
             gradnorm = st.gradnorm
             Y = h.get_point()
+            Y_eval = Y                                     # X of :59 -- what the reference returns (:114)
             dev_al = (eig_mode == "device") and bool(o.get("device_al", True))
             certified = True
             if dev_al:
@@ -397,6 +448,16 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
                 data["eig_seconds"] += time.time() - t1
             dinf = max(0.0, -dS[0]) / (1.0 + dS[-1])       # :69
             gap = abs(obj - by) / (abs(by) + abs(obj) + 1.0)   # :71
+            last_verified = not dev_al
+            if dev_al and certified and ((max(gap, pinf, dinf) < o["tol"]) or it == int(o["AL_maxiter"])):
+                last_verified = True
+                lam_v, v_v, lmax_v, certified = _verify_lambda_min(
+                    h, lambda tol, maxit: h.escape_eigs_dual(1, tol=tol, maxit=maxit), o, data, 1e-10, 20000, dense_n=n)
+                dinf_v = max(0.0, -lam_v) / (1.0 + lmax_v)
+                if dinf_v >= o["tol"] > dinf:
+                    vS = np.hstack([v_v, vS[:, :max(int(o["delta"]) - 1, 0)]])
+                    dS = np.concatenate([[lam_v], dS[:-2], [lmax_v]])
+                dinf = dinf_v
             Q, e, r = _thin_svd_rank(Y, float(o["theta"]))     # :72-74
             _say(verbose, "Iter %d, obj:%0.8f, gap:%0.1e, pinf:%0.1e, dinf:%0.1e, gradnorm:%0.1e, r:%d, p:%d, sigma:%0.3f, time:%0.2fs"
                  % (it, obj, gap, pinf, dinf, gradnorm, r, p, sigma, time.time() - t0))
@@ -440,10 +501,16 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
                 sigma = max(sigma / gama, o["sigma_min"])
             elif pinf > o["tau2"] * gradnorm:
                 sigma = min(sigma * gama, o["sigma_max"])
+        if obj is not None and not last_verified and certified:   # stopped on "Slow progress": report the true dinf
+            lam_v, _, lmax_v, certified = _verify_lambda_min(
+                h, lambda tol, maxit: h.escape_eigs_dual(1, tol=tol, maxit=maxit), o, data, 1e-10, 20000, dense_n=n)
+            dinf = max(0.0, -lam_v) / (1.0 + lmax_v)
         if S is None and obj is not None and n <= int(o.get("dense_X_max", 6000)):
             S = h.get_dual_slack()                         # data.S of the reference (:116), from the device
     finally:
         h.close()
+    if obj is not None:
+        Y = Y_eval          # the point the residues belong to (the loop's last pass has already widened its own copy)
     data.update({"Y": Y, "X": (Y @ Y.T if n <= int(o.get("dense_X_max", 6000)) else None), "y": y, "S": S, "z": z, "gap": gap, "pinf": pinf, "dinf": dinf,
                  "gradnorm": gradnorm, "time": time.time() - t0, "sigma": sigma})
     if not sphere and not generic:

@@ -231,6 +231,7 @@ def ManiSDP_onlyunitdiag(C, options=None, rng=None, verbose=False, eig_fn=None, 
         data["cost_evals"] += info.cost_evals
         data["rejected"] += info.rejected
         gradnorm = info.gradnorm                           # :44
+        Y_eval = Y                                         # :45 X = Y'*Y is what the reference returns (:86)
         z = np.sum((Csp @ Y) * Y, axis=1)                  # :46-47 (z = sum(C.*X) = sum((Y*C).*Y))
         obj = float(np.sum(z))                             # :48
         S = Csp - sp.diags(z) if sp.issparse(Csp) else Csp - np.diag(z)   # :49
@@ -264,6 +265,7 @@ def ManiSDP_onlyunitdiag(C, options=None, rng=None, verbose=False, eig_fn=None, 
         else:
             Y = np.hstack([Y, alpha * vS[:, :nne]])        # :82
             Y = Y / np.sqrt(np.sum(Y ** 2, axis=1, keepdims=True))   # :83
+    Y = Y_eval                                             # the loop's last pass has already widened its own copy
     data.update({"Y": Y, "S": S, "z": z, "dinf": dinf, "gradnorm": gradnorm,
                  "time": time.time() - t0, "p": Y.shape[1]})
     if n <= 4000:
@@ -435,7 +437,7 @@ def ManiSDP_unitdiag(At, b, c, K, options=None, rng=None, verbose=False):
             sigma = min(sigma * gama, sigma_max)
     data.update({"Y": Y, "y": y, "S": S, "z": z, "gap": gap, "pinf": pinf, "dinf": dinf,
                  "gradnorm": gradnorm, "time": time.time() - t0, "fac_size": fac_size,
-                 "X": Y @ Y.T, "sigma": sigma})
+                 "X": X, "sigma": sigma})     # X of the evaluated point (:59), as the reference returns it
     if data["status"] == 0 and eta_kkt > tol:
         data["status"] = 1
         _say(verbose, "Iteration maximum is reached!")
@@ -595,7 +597,7 @@ def ManiSDP_unittrace(At, b, c, K, options=None, rng=None, verbose=False):
         elif pinf > tau2 * gradnorm:
             sigma = min(sigma * gama, sigma_max)
     data.update({"Y": Y, "y": y, "S": S, "z": z, "gap": gap, "pinf": pinf, "dinf": dinf,
-                 "gradnorm": gradnorm, "time": time.time() - t0, "X": Y @ Y.T, "sigma": sigma})
+                 "gradnorm": gradnorm, "time": time.time() - t0, "X": X, "sigma": sigma})     # X of the evaluated point (:59), as the reference returns it
     if data["status"] == 0 and eta_kkt > tol:
         data["status"] = 1
         _say(verbose, "Iteration maximum is reached!")
@@ -780,7 +782,7 @@ def ManiSDP(At, b, c, K, options=None, rng=None, verbose=False):
         elif pinf > tau2 * gradnorm:
             sigma = min(sigma * gama, sigma_max)
     data.update({"Y": Y, "y": y, "S": S, "gap": gap, "pinf": pinf, "dinf": dinf,
-                 "gradnorm": gradnorm, "time": time.time() - t0, "X": Y @ Y.T, "sigma": sigma})
+                 "gradnorm": gradnorm, "time": time.time() - t0, "X": X, "sigma": sigma})     # X of the evaluated point (:59), as the reference returns it
     if data["status"] == 0 and eta_kkt > tol:
         data["status"] = 1
         _say(verbose, "Iteration maximum is reached!")

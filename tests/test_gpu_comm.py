@@ -71,3 +71,56 @@ def test_sparse_shards_match_unsharded(N, case, p):
         assert h.tcg_path() == 0                      # shards never take the single-GPU persistent path
         h.close()
     assert covered.all()
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("case", ["sparse", "dense"])
+@pytest.mark.parametrize("N", [2, 4, 8])
+def test_ranks_on_separate_gpus_match_one_rank(tmp_path, case, N):
+    """The real thing: N processes, one per GPU, RCCL all-gather of the direction before every S*U and all-reduce of the
+    partial sums, against the same calls on one unsharded handle.  Needs N visible GPUs: skipped
+    on the single-GPU box, runs wherever the driver has a multi-GPU node."""
+    import os, subprocess, sys
+    import torch
+    if torch.cuda.device_count() < N:
+        pytest.skip("needs %d GPUs, %d visible" % (N, torch.cuda.device_count()))
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    out = str(tmp_path / "ranks.npz")
+    port = _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "multirank_worker.py")
+    procs = []
+    for r in range(N):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, worker, case, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    got = np.load(out)
+    rng = np.random.default_rng(11)
+    if case == "sparse":
+        C = problems.toroidal_grid_maxcut(61, 50, seed=4)
+        n, p = C.shape[0], 12
+        h = _lib.Handle.onlyunitdiag(C, pcap=p)
+    else:
+        n, p = 1000, 24
+        h = _lib.Handle.dense_synthetic(n, 3, pcap=p)
+    h.set_option("persist", 0)                        # the sharded run uses the chunked kernels
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    h.set_point(Y)
+    f = h.cost(); G = h.rgrad(); H = h.hessvec(U)
+    st = h.rtr(_lib.default_opts(maxiter=8, maxinner=25, tolgradnorm=1e-9))
+    Yout = h.get_point(); z = h.get_z()
+    h.close()
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)   # noqa: E731
+    assert abs(float(got["f"]) - f) <= 1e-12 * abs(f)
+    assert rel(got["G"], G) < 1e-13 and rel(got["H"], H) < 1e-13
+    # the partial sums are grouped differently (per shard, then all-reduced), so the solve agrees to rounding
+    assert int(got["hessvecs"]) == st.hessvecs and int(got["accepted"]) == st.accepted and int(got["rejected"]) == st.rejected
+    assert abs(float(got["cost"]) - st.cost) <= 1e-10 * abs(st.cost)
+    assert rel(got["Y"], Yout) < 1e-8 and rel(got["z"], z) < 1e-8

@@ -76,7 +76,7 @@ def test_m_engine_keeps_protocol_and_fields():
         assert re.search(r"data\.%s\b" % field, src), field
     # no reference-style n x n host work inside the loop: everything goes through the gateway
     code = "\n".join(ln.split("%", 1)[0] for ln in src.splitlines())
-    for banned in ("eig(full(", "svd(", "trustregions(", "Y'*Y;\n    x =", "reshape("):
+    for banned in ("eig(full(S", "svd(", "trustregions(", "Y'*Y;\n    x =", "reshape("):
         assert banned not in code, banned
 
 

@@ -1,0 +1,20 @@
+"""Dense-C Hess-vecs on the synthetic generator for a rocprofv3 run: argv = n p [p ...] [--shard N] (rank 0 of N rows only)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from manisdp_matlab_amd import _lib
+args = sys.argv[1:]
+N = 1
+if "--shard" in args:
+    i = args.index("--shard"); N = int(args[i + 1]); del args[i:i + 2]
+n = int(args[0])
+for p in [int(x) for x in args[1:]]:
+    h = _lib.Handle.dense_synthetic(n, 0, nranks=N, rank=0, pcap=p)
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    h.set_point(Y)
+    if N > 1:
+        h.debug_set_full_rows(Y)
+    ms, by, fl = h.bench_hessvec(50)
+    print("n=%d p=%d shard 1/%d: Hess-vec %.1f us, %.0f GB/s algorithmic, %.1f TFLOP/s fp64" % (n, p, N, ms * 1e3, by / ms / 1e6, fl / ms / 1e9), flush=True)
+    h.close()
