@@ -173,7 +173,8 @@ def main():
     #  * the S*U (ehess) kernel alone: algorithmic bytes of SURVEY.md 8(d) / average launch time;
     #  * one whole tCG trip (S*U + every vector update + the three reductions).  On one GPU at this size the
     #    trips run inside the persistent kernel k_tcg_persist_obl (working set resident in registers/LDS), which
-    #    is where >90% of the step's device time goes: it is the dominant kernel of the roofline object.
+    #    is where >90% of the step's device time goes: it is the dominant kernel of the roofline object
+    #    (profiles/r2_bench_kernel_stats.csv: k_tcg_persist_obl<16,5,4,false> = the 512 timed trips of bench_tcg_trip).
     h.set_point(Y0)
     ms, abytes, aflops = h.bench_hessvec(200)
     trip_ms = h.bench_tcg_trip(512)
@@ -203,9 +204,9 @@ def main():
                     "streaming_formulation_bytes_per_trip": streaming_trip_bytes,
                     "streaming_equivalent_GBps": streaming_trip_bytes / (trip_ms * 1e-3) / 1e9,
                     "note": "one launch runs all trips of a solve; bytes, traffic and time are per trip.  The working "
-                            "set is register/LDS resident and the trip is bound by its three grid-wide synchronisations "
-                            "(~1.7 us each), not by HBM: the fraction of the HBM roofline is therefore low by "
-                            "construction at n*p*8 = 5 MB per vector"}
+                            "set is register/LDS resident and the trip is bound by its two grid-wide synchronisations "
+                            "(~1.7 us each) and the coherent exchange of the residual rows, not by HBM: the fraction of "
+                            "the HBM roofline is low by construction at n*p*8 = 5 MB per vector"}
     else:
         roofline = {"bound": "hbm", "achieved": hess_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hess_achieved / HBM_PEAK_GBS, "traffic": (pm_h or {}).get("hbm_bytes_per_launch"),
@@ -247,7 +248,10 @@ def main():
         out["g81_kkt"] = {"seconds_to_dinf_1e-8": time.perf_counter() - t1, "obj": obj, "dinf": data["dinf"],
                           "status": data["status"], "AL_iters": data["iters"], "hessvecs": data["hessvecs"],
                           "rtr_seconds": data["rtr_seconds"], "escape_seconds": data["eig_seconds"],
-                          "options": {"p0": 40}}
+                          "independent_lambda_min_checks": data.get("eig_verifications", 0),
+                          "options": {"p0": 40},
+                          "note": "dinf is confirmed by a plain (undeflated, cold-started) Lanczos run before the solve "
+                                  "stops; that run is inside seconds_to_dinf_1e-8 and escape_seconds"}
     h.close()
     if not args.no_dense and N == 1 and rank == 0 and not args.force_comm:
         # The dense tall-skinny contraction S*U is the one place the path uses the matrix cores (north_star): report its

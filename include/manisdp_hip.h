@@ -205,6 +205,13 @@ int msdp_escape_eigs_matrix(msdp_handle h, const double* S, int32_t k, double to
  *   *converged : 1 if every Lanczos run passed a stop test, 0 if one ended at maxit;
  *   *residual  : largest relative residual |S x - theta x| / max(|theta|, |lam_max|) among the unconverged runs. */
 int msdp_escape_info(msdp_handle h, int32_t* nvalid, int32_t* converged, double* residual);
+/* Lower bound of lambda_min(S) from the LAST escape call (-inf when the call gives none, e.g. all k runs still found
+ * negative pairs).  With Z = [orth(Y) | found vectors] and S = [A E'; E B] in the basis [Z, complement]:
+ *   lambda_min(S) >= min(lambda_min(A), lambda_min(B)) - |E|_F     (Weyl)
+ * A = Z'SZ is known exactly, lambda_min(B) is bounded by the last, converged, non-negative Lanczos run, and
+ * |E|_F = |(I - ZZ')SZ|_F is measured.  dinf computed from this bound can only over-estimate the true
+ * dinf = max(0,-lambda_min)/(1+lambda_max) (ManiSDP_onlyunitdiag.m:51): if it is below tol, so is the true one. */
+int msdp_escape_lower_bound(msdp_handle h, double* lam_lower);
 
 /* ------------------------------------------------------------- multi-GPU */
 

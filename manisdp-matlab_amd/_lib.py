@@ -78,6 +78,7 @@ SIGNATURES = {
     "msdp_escape_eigs_matrix": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_double, C.c_int32, _dp, _dp, _dp,
                                          _P(C.c_int32)]),
     "msdp_escape_info": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _dp]),
+    "msdp_escape_lower_bound": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_dual_slack": (C.c_int, [C.c_void_p, _dp]),
     "msdp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "msdp_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -325,6 +326,12 @@ class Handle:
     def set_option(self, name, value):
         """Run-time switch of this handle (see msdp_set_option in include/manisdp_hip.h)."""
         _check(self._lib.msdp_set_option(self._h, name.encode(), int(value)))
+
+    def escape_lower_bound(self):
+        """Weyl lower bound of lambda_min(S) from the last escape call (-inf when there is none)."""
+        v = C.c_double()
+        _check(self._lib.msdp_escape_lower_bound(self._h, C.byref(v)))
+        return v.value
 
     def get_kind(self):
         k = C.c_int32()

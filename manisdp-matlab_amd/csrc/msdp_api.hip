@@ -1275,6 +1275,13 @@ extern "C" int msdp_escape_info(msdp_handle h, int32_t* nvalid, int32_t* converg
     return 0;
 }
 
+extern "C" int msdp_escape_lower_bound(msdp_handle h, double* lam_lower) {
+    CHECK_H(h);
+    if (!lam_lower) return MSDP_EINVAL;
+    *lam_lower = h->esc_lower;
+    return 0;
+}
+
 extern "C" int msdp_get_dual_slack(msdp_handle h, double* S) {
     CHECK_H(h);
     if (!S) { msdp_set_error("get_dual_slack: null argument"); return MSDP_EINVAL; }

@@ -176,6 +176,7 @@ struct msdp_handle_s {
     // largest relative residual |S x - theta x| / max(|theta|, |lam_max|) among the runs that hit maxit instead
     int esc_nvalid = 0, esc_converged = 0;
     double esc_maxres = 0.0;
+    double esc_lower = 0.0;           // rigorous-by-Weyl lower bound of lambda_min(S) from the last call (-inf: none)
     // persistent tCG kernel (msdp_persist.hip): grid-sync slots, error flag, cached eligibility
     unsigned long long* psync_slots = nullptr;
     int* psync_err = nullptr;

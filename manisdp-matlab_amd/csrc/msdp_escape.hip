@@ -687,7 +687,9 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
             ESC_HIP(hipMemcpyAsync(Z, h->esc_prev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
             have_xstart = true;
         }
-        h->esc_converged = 1; h->esc_maxres = 0.0; h->esc_nvalid = 0;
+        h->esc_converged = 1; h->esc_maxres = 0.0; h->esc_nvalid = 0; h->esc_lower = -INFINITY;
+        double last_theta = 0.0, last_res = 0.0;
+        bool complement_nonneg = false;                   // the last run ended on a Ritz value >= -tol*scale
         for (int t = 0; t < k;) {
             double theta, res, lmx; int m, nacc = 1;
             double thetas[64];
@@ -705,7 +707,8 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
             for (int i = 0; i < nacc; ++i) found.push_back(thetas[i]);
             r += nacc; nfound += nacc; t += nacc;
             const double scale = std::max(fabs(theta), fabs(lam_max)) + 1e-300;
-            if (!(theta < -tol * scale)) break;           // no further negative direction
+            last_theta = theta; last_res = res;
+            if (!(theta < -tol * scale)) { complement_nonneg = conv; break; }    // no further negative direction
         }
         auto tp2 = std::chrono::steady_clock::now();
         // remember what was found for the next call's warm start (sum of the accepted vectors)
@@ -722,13 +725,21 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         // ---- final Rayleigh-Ritz on Z = [Q_Y | X]: recouples the blocks when S*Y is only approximately zero
         const int nz = r;
         ESC_HIP(hipMemcpyAsync(Z, Q, (size_t)nz * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        std::vector<double> M((size_t)nz * nz, 0.0), col(nz);
+        // ... and measures how far span(Z) is from invariant: coupling = |(I - ZZ') S Z|_F, from which a LOWER bound of
+        // lambda_min follows (Weyl): S = [A E'; E B] in the basis [Z, complement], lambda_min(S) >= min(lambda_min(A),
+        // lambda_min(B)) - |E|_2, with A = Z'SZ known exactly, lambda_min(B) >= theta - res of the last (converged,
+        // non-negative) run, |E|_2 <= |E|_F.  The bound is what lets a caller declare dinf < tol without another run.
+        std::vector<double> M((size_t)nz * nz, 0.0), col(nz + 1);
+        double coupling2 = 0.0;
         for (int j = 0; j < nz; ++j) {
             ESC_CHECK(sapply(c, Z + (size_t)j * n, w));
             hipLaunchKernelGGL(k_multidot, dim3(nz), dim3(MSDP_BLOCK), 0, h->stream, n, Z, (int64_t)n, w, c.hbuf);
-            ESC_HIP(hipMemcpyAsync(col.data(), c.hbuf, nz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, n, w, w, c.hbuf + nz, 0);
+            ESC_HIP(hipMemcpyAsync(col.data(), c.hbuf, (nz + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             ESC_HIP(hipStreamSynchronize(h->stream));
-            for (int i = 0; i < nz; ++i) M[(size_t)i * nz + j] = col[i];
+            double inside = 0.0;
+            for (int i = 0; i < nz; ++i) { M[(size_t)i * nz + j] = col[i]; inside += col[i] * col[i]; }
+            coupling2 += std::max(0.0, col[nz] - inside);
         }
         for (int i = 0; i < nz; ++i) for (int j = i + 1; j < nz; ++j) {
             const double sm = 0.5 * (M[(size_t)i * nz + j] + M[(size_t)j * nz + i]);
@@ -758,6 +769,10 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
             }
         }
         h->esc_nvalid = nout;
+        if (complement_nonneg && nz > 0)
+            h->esc_lower = std::min(ew[eo[0]], last_theta - last_res) - sqrt(coupling2);
+        if (dbg) fprintf(stderr, "[escape] Rayleigh-Ritz bottom %.6e, complement theta %.6e (res %.1e), coupling %.3e -> lower bound %.6e\n",
+                         nz > 0 ? ew[eo[0]] : 0.0, last_theta, last_res, sqrt(coupling2), h->esc_lower);
         (void)ry; (void)nfound;
         if (dbg) {
             auto tp3 = std::chrono::steady_clock::now();

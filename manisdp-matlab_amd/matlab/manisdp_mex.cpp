@@ -15,10 +15,10 @@
 //   v = manisdp_mex('linesearch_cost', h, U, alpha)      co(retr(Y + alpha*U)); alpha = 0 (U may be []) gives co(Y)
 //       manisdp_mex('linesearch_accept', h)
 //   z = manisdp_mex('get_z', h)                          onlyunitdiag: 1 x n
-//   [lam, V, lmax, ok] = manisdp_mex('escape_eigs', h, k, tol, maxit)
+//   [lam, V, lmax, ok, lower] = manisdp_mex('escape_eigs', h, k, tol, maxit)   lower: Weyl bound of lambda_min
 //   [obj, Ax] = manisdp_mex('al_primal', h)
 //   z = manisdp_mex('al_dual', h, y)                     n x 1 (unitdiag), scalar (unittrace), [] (generic)
-//   [lam, V, lmax, ok] = manisdp_mex('escape_eigs_dual', h, k, tol, maxit)
+//   [lam, V, lmax, ok, lower] = manisdp_mex('escape_eigs_dual', h, k, tol, maxit)
 //   S = manisdp_mex('get_dual_slack', h)
 //   k = manisdp_mex('kind', h)
 //       manisdp_mex('set_option', h, name, value)        run-time switch of the handle (msdp_set_option)
@@ -141,6 +141,11 @@ void run_escape(escape_fn fn, const char* name, msdp_handle h, const Meta& me, i
     if (nlhs > 1) plhs[1] = V; else mxDestroyArray(V);
     if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(lmax);
     if (nlhs > 3) plhs[3] = mxCreateDoubleScalar(conv ? 1.0 : 0.0);
+    if (nlhs > 4) {
+        double lower = 0.0;
+        (void)msdp_escape_lower_bound(h, &lower);
+        plhs[4] = mxCreateDoubleScalar(lower);
+    }
 }
 
 }  // namespace

@@ -86,17 +86,18 @@ for iter = 1:opt.AL_maxiter
         y = y - sigma*resid;
         z = manisdp_mex('al_dual', h, y);
         by = bvec'*y + sum(z);                 % sum([]) = 0 for the generic kind
-        [lam, V, lam_top, okflag] = manisdp_mex('escape_eigs_dual', h, opt.delta, opt.eig_tol, opt.eig_maxit);
+        [lam, V, lam_top, okflag, lam_lower] = manisdp_mex('escape_eigs_dual', h, opt.delta, opt.eig_tol, opt.eig_maxit);
         gap = abs(obj - by)/(abs(by) + abs(obj) + 1);
     else
         z = manisdp_mex('get_z', h);
         obj = sum(z);
-        [lam, V, lam_top, okflag] = manisdp_mex('escape_eigs', h, opt.delta, opt.eig_tol, opt.eig_maxit);
+        [lam, V, lam_top, okflag, lam_lower] = manisdp_mex('escape_eigs', h, opt.delta, opt.eig_tol, opt.eig_maxit);
     end
     certified = (okflag ~= 0);                 % a Lanczos run that ran out of steps certifies nothing
     dinf = max(0, -lam(1))/(1 + lam_top);
     if T.affine, eta_now = max([gap, pinf, dinf]); else, eta_now = dinf; end
-    if certified && (eta_now < opt.tol || iter == opt.AL_maxiter)
+    proven = eta_now < opt.tol && max(0, -lam_lower)/(1 + lam_top) < opt.tol;    % Weyl bound of the same call
+    if certified && ~proven && (eta_now < opt.tol || iter == opt.AL_maxiter)
         % The regular escape call deflates span(Y) and starts from the previous call's vectors: fast, but only as
         % accurate as S*Y is small.  Before dinf may end the solve (and on the last pass, so that the reported dinf
         % is the true one) lambda_min is recomputed by plain Lanczos on S: no deflation, random start.

@@ -247,7 +247,12 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
             data["eig_seconds"] += time.time() - t1
             dinf = max(0.0, -lam_min) / (1.0 + lam_max)    # :51
             last_verified = eig_mode != "device"
-            if eig_mode == "device" and certified and (dinf < o["tol"] or it == int(o["AL_maxiter"])):
+            if eig_mode == "device" and certified and dinf < o["tol"] and \
+                    max(0.0, -h.escape_lower_bound()) / (1.0 + lam_max) < o["tol"]:
+                # the Weyl bound of the same escape call (msdp_escape_lower_bound) already proves dinf < tol
+                last_verified = True
+                data["eig_bound_certificates"] = data.get("eig_bound_certificates", 0) + 1
+            elif eig_mode == "device" and certified and (dinf < o["tol"] or it == int(o["AL_maxiter"])):
                 last_verified = True
                 lam_v, v_v, lmax_v, certified = _verify_lambda_min(
                     h, lambda tol, maxit: h.escape_eigs(1, tol=tol, maxit=maxit), o, data, 1e-9, 60000)
@@ -449,7 +454,11 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
             dinf = max(0.0, -dS[0]) / (1.0 + dS[-1])       # :69
             gap = abs(obj - by) / (abs(by) + abs(obj) + 1.0)   # :71
             last_verified = not dev_al
-            if dev_al and certified and ((max(gap, pinf, dinf) < o["tol"]) or it == int(o["AL_maxiter"])):
+            if dev_al and certified and max(gap, pinf, dinf) < o["tol"] and \
+                    max(0.0, -h.escape_lower_bound()) / (1.0 + dS[-1]) < o["tol"]:
+                last_verified = True                       # proven by the Weyl bound of the same escape call
+                data["eig_bound_certificates"] = data.get("eig_bound_certificates", 0) + 1
+            elif dev_al and certified and ((max(gap, pinf, dinf) < o["tol"]) or it == int(o["AL_maxiter"])):
                 last_verified = True
                 lam_v, v_v, lmax_v, certified = _verify_lambda_min(
                     h, lambda tol, maxit: h.escape_eigs_dual(1, tol=tol, maxit=maxit), o, data, 1e-10, 20000, dense_n=n)
