@@ -50,6 +50,7 @@ typedef struct msdp_handle_s* msdp_handle;
 #define MSDP_KIND_UNITDIAG     2   /* src/primal/ManiSDP_unitdiag.m     */
 #define MSDP_KIND_UNITTRACE    3   /* src/primal/ManiSDP_unittrace.m    */
 #define MSDP_KIND_GENERIC      4   /* src/primal/ManiSDP.m (Euclidean manifold) */
+#define MSDP_KIND_MULTIBLOCK   5   /* src/primal/ManiSDP_multiblock.m (product manifold) */
 
 /* Options of one Riemannian trust-region solve: the fields ManiSDP sets
  * (ManiSDP_unitdiag.m:44-47) plus Manopt's defaults that are in force
@@ -126,6 +127,20 @@ int msdp_debug_shard(msdp_handle h, int32_t nranks, int32_t rank);
 int msdp_create_affine(int32_t kind, int64_t n, int64_t m,
                        const int64_t* at_jc, const int64_t* at_ir, const double* at_pr,
                        const double* b, const double* c, int32_t pcap, msdp_handle* out);
+
+/* min <C,X>, A(X) = b over block-diagonal X = diag(X_1..X_nb) with diag(X_i) = 1 for the first `nob` blocks
+ * (ManiSDP_multiblock.m:1-7; closures cost/grad/hess :208-249; manifold = multiblockmanifold.m:1-42 over the MEX
+ * helpers src/C-files/{innerc,lincombc,projc,retrc,randc,zerovecc}.cpp: oblique factors for the first nob blocks,
+ * Euclidean ones for the rest).  SeDuMi data for several SDP blocks: At is (sum n_i^2) x m CSC whose rows are the
+ * concatenated column-major vecs of the blocks, c likewise, b dense m.
+ * The factor crosses the boundary as ONE p x N column-major array, N = sum n_i: block i occupies columns
+ * [N_i, N_i + n_i) and, when its own width p_i is smaller than p, rows p_i..p-1 of those columns are zero (zero
+ * rows of a block stay zero under cost, gradient, Hess-vec, projection and retraction, so padding changes nothing).
+ * Internally the problem is the unit-diagonal affine kind of order N whose constraint matrices are block diagonal,
+ * with a per-row flag that switches the projection / normalisation terms off for the Euclidean blocks. */
+int msdp_create_multiblock(int32_t nb, const int64_t* block_n, int32_t nob, int64_t m,
+                           const int64_t* at_jc, const int64_t* at_ir, const double* at_pr,
+                           const double* b, const double* c, int32_t pcap, msdp_handle* out);
 
 int msdp_destroy(msdp_handle h);
 

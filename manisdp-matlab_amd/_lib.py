@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmanisdp_hip.so")
 
-KIND_ONLYUNITDIAG, KIND_UNITDIAG, KIND_UNITTRACE, KIND_GENERIC = 1, 2, 3, 4
+KIND_ONLYUNITDIAG, KIND_UNITDIAG, KIND_UNITTRACE, KIND_GENERIC, KIND_MULTIBLOCK = 1, 2, 3, 4, 5
 
 
 class RtrOpts(C.Structure):
@@ -57,6 +57,8 @@ SIGNATURES = {
     "msdp_debug_set_full_rows": (C.c_int, [C.c_void_p, _dp]),
     "msdp_create_affine": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp,
                                      C.c_int32, _P(C.c_void_p)]),
+    "msdp_create_multiblock": (C.c_int, [C.c_int32, _i64p, C.c_int32, C.c_int64, _i64p, _i64p, _dp, _dp, _dp,
+                                         C.c_int32, _P(C.c_void_p)]),
     "msdp_destroy": (C.c_int, [C.c_void_p]),
     "msdp_set_multipliers": (C.c_int, [C.c_void_p, _dp, C.c_double]),
     "msdp_set_point": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
@@ -208,6 +210,24 @@ class Handle:
                                       _dptr(pr), _dptr(b), _dptr(c), pcap, C.byref(out)))
         return cls(out.value, kind, n)
 
+    @classmethod
+    def multiblock(cls, At, b, c, block_n, nob, pcap=32):
+        """Block-diagonal X = diag(X_1..X_nb), unit diagonal on the first `nob` blocks (ManiSDP_multiblock.m).  At is
+        (sum n_i^2) x m over the concatenated vecs of the blocks.  The factor is one (N, p) array, N = sum n_i."""
+        lib = load()
+        out = C.c_void_p()
+        Atc = At.tocsc()
+        Atc.sort_indices()
+        jc = np.ascontiguousarray(Atc.indptr, dtype=np.int64)
+        ir = np.ascontiguousarray(Atc.indices, dtype=np.int64)
+        pr = np.ascontiguousarray(Atc.data, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        bn = np.ascontiguousarray(block_n, dtype=np.int64)
+        _check(lib.msdp_create_multiblock(len(bn), bn.ctypes.data_as(_i64p), int(nob), Atc.shape[1], jc.ctypes.data_as(_i64p),
+                                          ir.ctypes.data_as(_i64p), _dptr(pr), _dptr(b), _dptr(c), pcap, C.byref(out)))
+        return cls(out.value, KIND_MULTIBLOCK, int(bn.sum()))
+
     def close(self):
         if self._h is not None and self._h.value:
             self._lib.msdp_destroy(self._h)
@@ -356,7 +376,7 @@ class Handle:
         """Build the dual slack S for the multipliers y on the device; returns z (n values for unitdiag, a scalar for
         unittrace, None for the generic kind).  S stays resident for escape_eigs_dual."""
         y = np.ascontiguousarray(y, dtype=np.float64)
-        if self.kind == KIND_UNITDIAG:
+        if self.kind in (KIND_UNITDIAG, KIND_MULTIBLOCK):
             z = np.empty(self.n)
         elif self.kind == KIND_UNITTRACE:
             z = np.empty(1)
@@ -365,7 +385,7 @@ class Handle:
         _check(self._lib.msdp_al_dual(self._h, _dptr(y), _dptr(z) if z is not None else None))
         if z is None:
             return None
-        return z if self.kind == KIND_UNITDIAG else float(z[0])
+        return z if self.kind in (KIND_UNITDIAG, KIND_MULTIBLOCK) else float(z[0])
 
     def escape_eigs_dual(self, k, tol=1e-10, maxit=20000):
         """k bottom eigenpairs and lambda_max of the device-resident S of the last al_dual call."""

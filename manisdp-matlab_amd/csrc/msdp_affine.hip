@@ -564,7 +564,10 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_rowdot_slabs(Dev d, const double
                 }
             }
             dot = msdp_group_sum<LPR>(dot);
-            if (sub == 0) { if (rowdot_out) rowdot_out[row] = scale_out * dot; ps += dot; }
+            // rows of a Euclidean block (multiblock kind) carry no diagonal multiplier: YeG / z stay 0 there
+            // (ManiSDP_multiblock.m:80-84,225-228)
+            const bool freerow = d.rowfree && d.rowfree[row];
+            if (sub == 0) { if (rowdot_out) rowdot_out[row] = freerow ? 0.0 : scale_out * dot; ps += dot; }
         }
     }
     msdp_put_partial(d.P, which, ps, sh);

@@ -395,6 +395,54 @@ extern "C" int msdp_create_affine(int32_t kind, int64_t n, int64_t m, const int6
     return 0;
 }
 
+extern "C" int msdp_create_multiblock(int32_t nb, const int64_t* block_n, int32_t nob, int64_t m, const int64_t* at_jc,
+                                      const int64_t* at_ir, const double* at_pr, const double* b, const double* c,
+                                      int32_t pcap, msdp_handle* out) {
+    if (nb < 1 || !block_n || nob < 0 || nob > nb) { msdp_set_error("multiblock: bad block description"); return MSDP_EINVAL; }
+    if (!at_jc || !b || !c || m <= 0) { msdp_set_error("null/empty affine data"); return MSDP_EINVAL; }
+    // offsets of the blocks inside the direct sum (rows) and inside the concatenated vec (entries)
+    std::vector<int64_t> r0((size_t)nb + 1, 0), e0((size_t)nb + 1, 0);
+    for (int i = 0; i < nb; ++i) {
+        if (block_n[i] < 1) { msdp_set_error("multiblock: block %d has order %lld", i, (long long)block_n[i]); return MSDP_EINVAL; }
+        r0[i + 1] = r0[i] + block_n[i];
+        e0[i + 1] = e0[i] + block_n[i] * block_n[i];
+    }
+    const int64_t N = r0[nb], E = e0[nb], nnz = at_jc[m];
+    if (N > 46000) { msdp_set_error("multiblock: total order %lld too large for the embedded dense representation", (long long)N); return MSDP_EUNSUPPORTED; }
+    // embed: entry (a, b) of block i -> entry (r0_i + a, r0_i + b) of the N x N direct sum (column-major vec index)
+    auto embed = [&](int64_t e, int64_t* g) -> bool {
+        if (e < 0 || e >= E) return false;
+        const int i = (int)(std::upper_bound(e0.begin(), e0.end(), e) - e0.begin()) - 1;
+        const int64_t l = e - e0[i], a = l % block_n[i], bb = l / block_n[i];
+        *g = (r0[i] + a) + (r0[i] + bb) * N;
+        return true;
+    };
+    std::vector<int64_t> ir((size_t)nnz);
+    for (int64_t t = 0; t < nnz; ++t)
+        if (!embed(at_ir[t], &ir[(size_t)t])) { msdp_set_error("multiblock: At row index out of range"); return MSDP_EINVAL; }
+    std::vector<double> cN((size_t)N * N, 0.0);
+    for (int i = 0; i < nb; ++i)
+        for (int64_t bb = 0; bb < block_n[i]; ++bb)
+            for (int64_t a = 0; a < block_n[i]; ++a)
+                cN[(size_t)((r0[i] + a) + (r0[i] + bb) * N)] = c[e0[i] + a + bb * block_n[i]];
+    msdp_handle h = nullptr;
+    int rc = msdp_create_affine(MSDP_KIND_UNITDIAG, N, m, at_jc, ir.data(), at_pr, b, cN.data(), pcap, &h);
+    if (rc) return rc;
+    h->kind = MSDP_KIND_MULTIBLOCK;
+    std::vector<unsigned char> rf((size_t)N, 0);
+    bool any = false;
+    for (int i = nob; i < nb; ++i)
+        for (int64_t a = r0[i]; a < r0[i + 1]; ++a) { rf[(size_t)a] = 1; any = true; }
+    if (any) {
+        unsigned char* drf = nullptr;
+        if ((rc = dev_alloc<unsigned char>(h, &drf, (size_t)N))) { msdp_destroy(h); return rc; }
+        if (hipMemcpy(drf, rf.data(), (size_t)N, hipMemcpyHostToDevice) != hipSuccess) { msdp_set_error("multiblock: upload failed"); msdp_destroy(h); return MSDP_EHIP; }
+        h->d.rowfree = drf;
+    }
+    *out = h;
+    return 0;
+}
+
 extern "C" int msdp_destroy(msdp_handle h) {
     if (!h) return 0;
     if (h->stream) (void)hipStreamSynchronize(h->stream);

@@ -105,6 +105,9 @@ struct Dev {
     const double* b; double* yv; double* Axb[2]; double* w;              // length m
     double* Pm;       // partial sums for m-length reductions
     unsigned long long* status;   // host-mapped progress word: (TR iteration+1) << 32 | tCG j << 1 | active
+    // multiblock kind: rowfree[i] != 0 marks the rows of the blocks that carry no unit-diagonal constraint (Euclidean
+    // factor of the product manifold: no projection term, no normalisation); nullptr = every row is oblique
+    const unsigned char* rowfree;
 };
 
 // Run-time switches of a handle (msdp_set_option; the environment variables of the same meaning are read ONCE, when

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_dense_hess_epi_obl(Dev d, const 
                 }
             }
             dot = msdp_group_sum<LPR>(dot);
+            if (d.rowfree && d.rowfree[row]) dot = 0.0;           // Euclidean block of a multiblock problem (eG is 0 there)
             const double eg = eG[row];
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {

@@ -406,6 +406,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg_upd2_obl(Dev d) {
                     } else { v[ch] = make_double2(0.0, 0.0); y[ch] = v[ch]; }
                 }
                 dot = msdp_group_sum<LPR>(dot);
+                if (d.rowfree && d.rowfree[row]) dot = 0.0;           // Euclidean block: tangent = identity
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) {
                     const int col = 2 * sub + ch * 2 * LPR;
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_retract_obl(Dev d) {
                 } else x[ch] = make_double2(0.0, 0.0);
             }
             nn = sqrt(msdp_group_sum<LPR>(nn));
+            if (d.rowfree && d.rowfree[row]) nn = 1.0;               // Euclidean block: retr(x, eta) = x + eta
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int col = 2 * sub + ch * 2 * LPR;
@@ -559,22 +561,23 @@ __global__ void k_unpack_cols(const double* __restrict__ src, double* __restrict
 // V = U - Y.*rowdot(Y,U) (M.proj, ManiSDP_onlyunitdiag.m:138); flat one-thread-per-row
 // version for the test-only fine-grained entry point.
 __global__ void k_proj_obl_simple(const double* __restrict__ Y, const double* __restrict__ U,
-                                  double* __restrict__ V, int n, int ld) {
+                                  double* __restrict__ V, int n, int ld, const unsigned char* __restrict__ rowfree) {
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x) {
         double dot = 0.0;
         for (int c = 0; c < ld; ++c) dot += Y[(int64_t)row * ld + c] * U[(int64_t)row * ld + c];
+        if (rowfree && rowfree[row]) dot = 0.0;
         for (int c = 0; c < ld; ++c) V[(int64_t)row * ld + c] = U[(int64_t)row * ld + c] - Y[(int64_t)row * ld + c] * dot;
     }
 }
 __global__ void k_retr_obl_simple(const double* __restrict__ Y, const double* __restrict__ U,
-                                  double* __restrict__ Z, double alpha, int n, int ld) {
+                                  double* __restrict__ Z, double alpha, int n, int ld, const unsigned char* __restrict__ rowfree) {
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x) {
         double nn = 0.0;
         for (int c = 0; c < ld; ++c) {
             const double x = Y[(int64_t)row * ld + c] + alpha * U[(int64_t)row * ld + c];
             nn += x * x;
         }
-        nn = sqrt(nn);
+        nn = (rowfree && rowfree[row]) ? 1.0 : sqrt(nn);
         for (int c = 0; c < ld; ++c)
             Z[(int64_t)row * ld + c] = (Y[(int64_t)row * ld + c] + alpha * U[(int64_t)row * ld + c]) / nn;
     }
@@ -732,12 +735,12 @@ int msdp_k_unpack(msdp_handle h, const double* src, double* dst, int n, int p, i
     return 0;
 }
 int msdp_k_proj_obl(msdp_handle h, const double* Y, const double* U, double* V) {
-    hipLaunchKernelGGL(k_proj_obl_simple, dim3(256), dim3(256), 0, h->stream, Y, U, V, h->d.n_loc, h->d.ld);
+    hipLaunchKernelGGL(k_proj_obl_simple, dim3(256), dim3(256), 0, h->stream, Y, U, V, h->d.n_loc, h->d.ld, h->d.rowfree);
     HIPCHK(hipGetLastError());
     return 0;
 }
 int msdp_k_retr_obl(msdp_handle h, const double* Y, const double* U, double* Z, double alpha) {
-    hipLaunchKernelGGL(k_retr_obl_simple, dim3(256), dim3(256), 0, h->stream, Y, U, Z, alpha, h->d.n_loc, h->d.ld);
+    hipLaunchKernelGGL(k_retr_obl_simple, dim3(256), dim3(256), 0, h->stream, Y, U, Z, alpha, h->d.n_loc, h->d.ld, h->d.rowfree);
     HIPCHK(hipGetLastError());
     return 0;
 }

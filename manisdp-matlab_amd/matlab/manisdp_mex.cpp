@@ -8,10 +8,14 @@
 //   h = manisdp_mex('create_unitdiag',  At, b, c, n)     At sparse n^2 x m; b, c sparse or dense
 //   h = manisdp_mex('create_unittrace', At, b, c, n)
 //   h = manisdp_mex('create_generic',   At, b, c, n)
+//   h = manisdp_mex('create_multiblock', At, b, c, nset, nob)   block orders nset (vector), first nob blocks unit-diagonal;
+//                                                        the factor is one p x sum(nset) matrix (blocks side by side, zero rows
+//                                                        below a block's own width)
 //       manisdp_mex('set_multipliers', h, y, sigma)
 //       manisdp_mex('set_point', h, Y)                   Y in the reference layout of the handle's kind
 //   Y = manisdp_mex('get_point', h)
 //   info = manisdp_mex('rtr', h, opts)                   trustregions() on the resident point; opts.maxiter/maxinner/tolgradnorm
+//                                                        [/Delta_bar: M.typicaldist() of a product manifold]
 //   v = manisdp_mex('linesearch_cost', h, U, alpha)      co(retr(Y + alpha*U)); alpha = 0 (U may be []) gives co(Y)
 //       manisdp_mex('linesearch_accept', h)
 //   z = manisdp_mex('get_z', h)                          onlyunitdiag: 1 x n
@@ -190,6 +194,27 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         return;
     }
 
+    if (cmd == "create_multiblock") {
+        need(nrhs == 6, "h = manisdp_mex('create_multiblock', At, b, c, nset, nob)");
+        const mxArray* At = prhs[1];
+        if (!mxIsSparse(At)) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "At must be sparse (sum(n_i^2) x m)");
+        const size_t nb = mxGetNumberOfElements(prhs[4]);
+        if (nb < 1) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "nset must list at least one block");
+        std::vector<int64_t> nset(nb);
+        int64_t N = 0, E = 0;
+        for (size_t i = 0; i < nb; ++i) { nset[i] = (int64_t)mxGetPr(prhs[4])[i]; N += nset[i]; E += nset[i] * nset[i]; }
+        if ((int64_t)mxGetM(At) != E) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "At must have sum(n_i^2) rows");
+        const int64_t m = (int64_t)mxGetN(At);
+        const std::vector<double> b = as_dense(prhs[2], (size_t)m);
+        const std::vector<double> c = as_dense(prhs[3], (size_t)E);
+        msdp_handle h = nullptr;
+        const int rc = msdp_create_multiblock((int32_t)nb, nset.data(), (int32_t)mxGetScalar(prhs[5]), m, (const int64_t*)mxGetJc(At),
+                                              (const int64_t*)mxGetIr(At), mxGetPr(At), b.data(), c.data(), 32, &h);
+        if (rc) fail("create_multiblock", rc);
+        plhs[0] = wrap_handle(h, MSDP_KIND_MULTIBLOCK, N, m);
+        return;
+    }
+
     // ---------------------------------------------------------------- everything else takes a handle
     need(nrhs >= 2, "manisdp_mex(command, h, ...)");
     const uint64_t key = handle_key(prhs[1]);
@@ -235,6 +260,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         o.maxiter = (int32_t)field_or(prhs[2], "maxiter", o.maxiter);          // opts of ManiSDP_unitdiag.m:44-47
         o.maxinner = (int32_t)field_or(prhs[2], "maxinner", o.maxinner);
         o.tolgradnorm = field_or(prhs[2], "tolgradnorm", o.tolgradnorm);
+        o.Delta_bar = field_or(prhs[2], "Delta_bar", o.Delta_bar);
         msdp_rtr_stats st;
         const int rc = msdp_rtr(h, &o, &st);
         if (rc) fail("rtr", rc);
@@ -279,7 +305,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     } else if (cmd == "al_dual") {
         need(nrhs == 3, "z = manisdp_mex('al_dual', h, y)");
         if ((int64_t)mxGetNumberOfElements(prhs[2]) != me.m) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "y must have m entries");
-        const mwSize zlen = me.kind == MSDP_KIND_UNITDIAG ? (mwSize)me.n : (me.kind == MSDP_KIND_UNITTRACE ? 1 : 0);
+        const mwSize zlen = (me.kind == MSDP_KIND_UNITDIAG || me.kind == MSDP_KIND_MULTIBLOCK) ? (mwSize)me.n
+                            : (me.kind == MSDP_KIND_UNITTRACE ? 1 : 0);
         mxArray* z = mxCreateDoubleMatrix(zlen, zlen ? 1 : 0, mxREAL);
         const int rc = msdp_al_dual(h, mxGetPr(prhs[2]), zlen ? mxGetPr(z) : nullptr);
         if (rc) { mxDestroyArray(z); fail("al_dual", rc); }

@@ -45,7 +45,8 @@ def _host_threads():
         pass
     return threadpool_limits(limits=max(1, min(ncpu, 16)))
 
-__all__ = ["ManiSDP_onlyunitdiag", "ManiSDP_unitdiag", "ManiSDP_unittrace", "ManiSDP", "DEFAULTS", "DATA_FIELDS"]
+__all__ = ["ManiSDP_onlyunitdiag", "ManiSDP_unitdiag", "ManiSDP_unittrace", "ManiSDP", "ManiSDP_multiblock", "DEFAULTS",
+           "DATA_FIELDS"]
 
 # Option defaults of the reference's entry points: ManiSDP_onlyunitdiag.m:8-17,
 # ManiSDP_unitdiag.m:10-26, ManiSDP_unittrace.m:10-25, ManiSDP.m:9-25.
@@ -548,3 +549,156 @@ def ManiSDP(At, b, c, K, options=None, verbose=True, rng=None):
     (reference src/primal/ManiSDP.m:6; defaults :9-25).  Same device kernels as the two structured affine entry
     points with the projection / retraction terms switched off."""
     return _affine_common(_lib.KIND_GENERIC, At, b, c, K, options, verbose, rng, DEFAULTS["generic"])
+
+
+# ================================================================= multiblock
+DEFAULTS["multiblock"] = dict(min_facsize=2, AL_maxiter=1000, gama=2, sigma0=1e-1, sigma_min=1e-2, sigma_max=1e7,
+                              tol=1e-8, theta=1e-2, delta=8, alpha=0.1, tolgradnorm=1e-8, TR_maxinner=20,
+                              TR_maxiter=4, tau1=1e1, tau2=1e1, line_search=0)       # ManiSDP_multiblock.m:10-27 (+ p0 = ones)
+DATA_FIELDS["multiblock"] = ("X", "y", "S", "gap", "pinf", "dinf", "gradnorm", "time", "status")   # :156-163
+
+
+def _pack_blocks(blocks, r0, N, pmax):
+    """Cell array of factors (n_i, p_i) -> one (N, pmax) array, zero beyond each block's own width."""
+    Y = np.zeros((N, pmax))
+    for i, Yi in enumerate(blocks):
+        Y[r0[i]:r0[i + 1], :Yi.shape[1]] = Yi
+    return Y
+
+
+def ManiSDP_multiblock(At, b, c, K, options=None, verbose=True, rng=None):
+    """``[X, obj, data] = ManiSDP_multiblock(At, b, c, K, options)`` (reference src/primal/ManiSDP_multiblock.m:7):
+    block-diagonal X with unit diagonal on the first ``K['nob']`` blocks of orders ``K['s']``.  The product manifold
+    of ``multiblockmanifold.m`` lives on the device as ONE factor of N = sum n_i rows whose blocks are zero-padded to a
+    common width; the per-block bookkeeping of the outer loop (eig(S{i}), svd(Y{i}), escape directions; :78-147) stays
+    on the host -- the blocks are small by construction.  Returns (list of factors, obj, data)."""
+    with _host_threads():
+        return _multiblock_impl(At, b, c, K, options, verbose, rng)
+
+
+def _multiblock_impl(At, b, c, K, options, verbose, rng):
+    o = dict(options or {})
+    for k, v in DEFAULTS["multiblock"].items():
+        o.setdefault(k, v)
+    nset = [int(v) for v in np.atleast_1d(K["s"])]
+    nob = int(K.get("nob", 0))
+    nb = len(nset)
+    p0 = [int(v) for v in np.atleast_1d(o.get("p0", np.ones(nb, int)))]
+    rng = rng or np.random.default_rng(0)
+    b = _dense_vec(b)
+    c = _dense_vec(c)
+    Atc = sp.csc_matrix(At)
+    r0 = np.concatenate([[0], np.cumsum(nset)]).astype(int)
+    N = int(r0[-1])
+    _say(verbose, "ManiSDP is starting...")
+    _say(verbose, f"SDP size: n = {max(nset)}, m = {b.size}")
+    p = [p0[i] if nset[i] >= o["min_facsize"] else nset[i] for i in range(nb)]        # :34-39
+    h = _lib.Handle.multiblock(Atc, b, c, nset, nob, pcap=max(32, max(p) + 2 * int(o["delta"])))
+    sigma = float(o["sigma0"]); gama = float(o["gama"])
+    y = np.zeros(b.size)
+    normb = 1.0 + np.linalg.norm(b)
+
+    def normalise(Yi, i):
+        return Yi / np.sqrt(np.sum(Yi * Yi, axis=1, keepdims=True)) if i < nob else Yi
+
+    Yb = o.get("Y0", None)
+    if Yb is None:                                          # trustregions.m:390-392 -> M.rand() (randc.cpp)
+        Yb = [normalise(rng.standard_normal((nset[i], p[i])), i) for i in range(nb)]
+    Yb = [np.ascontiguousarray(Yi, dtype=np.float64) for Yi in Yb]
+    Ub = None
+    data = {"status": 0, "hessvecs": 0, "cost_evals": 0, "rejected": 0, "rtr_seconds": 0.0, "eig_seconds": 0.0, "log": []}
+    t0 = time.time()
+    gap0 = pinf0 = dinf0 = None
+    obj = gap = pinf = dinf = gradnorm = eta_kkt = None
+    X = S = Y_eval = None
+    try:
+        for it in range(1, int(o["AL_maxiter"]) + 1):       # :57
+            pmax = max(p)
+            # M.typicaldist of multiblockmanifold.m:11-15
+            tdist = math.sqrt(math.pi * sum(nset[:nob]) + sum(pi * ni for pi, ni in zip(p[nob:], nset[nob:])))
+            topts = _lib.default_opts(maxiter=int(o["TR_maxiter"]), maxinner=int(o["TR_maxinner"]),
+                                      tolgradnorm=float(o["tolgradnorm"]), Delta_bar=tdist)
+            h.set_multipliers(y, sigma)
+            h.set_point(_pack_blocks(Yb, r0, N, pmax))
+            if Ub is not None:
+                _line_search(h, _pack_blocks(Ub, r0, N, pmax))   # :59-61, 171-193
+            st = h.rtr(topts)                               # :62
+            data["rtr_seconds"] += st.seconds
+            data["hessvecs"] += st.hessvecs
+            data["cost_evals"] += st.cost_evals
+            data["rejected"] += st.rejected
+            gradnorm = st.gradnorm                          # :63
+            Yfull = h.get_point()
+            Yb = [np.ascontiguousarray(Yfull[r0[i]:r0[i + 1], :p[i]]) for i in range(nb)]
+            Y_eval = Yb
+            obj, Ax = h.al_primal(b.size)                   # :65-70
+            Axb = Ax - b                                    # :71
+            pinf = float(np.linalg.norm(Axb)) / normb       # :72
+            y = y - sigma * Axb                             # :73
+            t1 = time.time()
+            z = h.al_dual(y)                                # :74-84 on the device: S = cy blocks - diag(z), z = 0 on free rows
+            by = float(b @ y) + float(np.sum(z))            # :75,82
+            Sfull = h.get_dual_slack()
+            S, vS, dS, dinfs = [], [], [], []
+            for i in range(nb):                             # :78-88
+                Si = Sfull[r0[i]:r0[i + 1], r0[i]:r0[i + 1]]
+                w, V = np.linalg.eigh(0.5 * (Si + Si.T))    # :86
+                S.append(Si); dS.append(w); vS.append(V)
+                dinfs.append(max(0.0, -w[0]) / (1.0 + abs(w[-1])))   # :87
+            data["eig_seconds"] += time.time() - t1
+            dinf = max(dinfs)                               # :89
+            gap = abs(obj - by) / (abs(by) + abs(obj) + 1.0)   # :90
+            _say(verbose, "Iter %d, obj:%0.8f, gap:%0.1e, pinf:%0.1e, dinf:%0.1e, gradnorm:%0.1e, p_max:%d, sigma:%0.3f, time:%0.2fs"
+                 % (it, obj, gap, pinf, dinf, gradnorm, max(p), sigma, time.time() - t0))
+            data["log"].append((it, obj, gap, pinf, dinf, gradnorm, max(p), sigma, time.time() - t0))
+            eta_kkt = max(gap, pinf, dinf)                  # :93
+            data["iters"] = it
+            if eta_kkt < o["tol"]:
+                _say(verbose, "Optimality is reached!")
+                break
+            if it % 50 == 0:                                # :98-108
+                if it > 100 and gap > gap0 and pinf > pinf0 and dinf > dinf0:
+                    data["status"] = 2
+                    _say(verbose, "Slow progress!")
+                    break
+                gap0, pinf0, dinf0 = gap, pinf, dinf
+            newY, newU = [], []
+            for i, n in enumerate(nset):                    # :109-147
+                Yi = Yb[i]
+                Ui = None
+                if n >= o["min_facsize"]:
+                    if p[i] > 1:
+                        Q, e, r = _thin_svd_rank(Yi, float(o["theta"]))   # :112-121
+                        r = max(r, 1)
+                        if r < p[i]:
+                            Yi = _rank_cut(Yi, Q, e, r)     # :125
+                            p[i] = r
+                    nneg = int(np.sum(dS[i] < 0))
+                    nne = max(min(nneg, int(o["delta"])), 1) if i < nob else min(nneg, int(o["delta"]))   # :129-133
+                    if p[i] + nne > n:
+                        nne = 0                             # :134-136
+                    if o["line_search"] == 1:
+                        Ui = np.hstack([np.zeros((n, p[i])), vS[i][:, :nne]])    # :137-139
+                        Yi = np.hstack([Yi, np.zeros((n, nne))])                 # :141-142
+                    else:
+                        Yi = normalise(np.hstack([Yi, o["alpha"] * vS[i][:, :nne]]), i)   # :143-147
+                    p[i] = p[i] + nne                       # :140
+                newY.append(np.ascontiguousarray(Yi))
+                newU.append(Ui if Ui is not None else np.zeros_like(Yi))
+            Yb = newY
+            Ub = newU if o["line_search"] == 1 else None
+            if pinf < o["tau1"] * gradnorm:                 # :150-154
+                sigma = max(sigma / gama, o["sigma_min"])
+            elif pinf > o["tau2"] * gradnorm:
+                sigma = min(sigma * gama, o["sigma_max"])
+    finally:
+        h.close()
+    if Y_eval is not None:
+        X = [Yi @ Yi.T for Yi in Y_eval]                    # :65-69, 156
+    data.update({"Y": Y_eval, "X": X, "y": y, "S": S, "gap": gap, "pinf": pinf, "dinf": dinf, "gradnorm": gradnorm,
+                 "time": time.time() - t0, "sigma": sigma, "p": [Yi.shape[1] for Yi in (Y_eval or [])]})
+    if data["status"] == 0 and eta_kkt > o["tol"]:
+        data["status"] = 1
+        _say(verbose, "Iteration maximum is reached!")
+    _say(verbose, "ManiSDP: optimum = %0.8f, time = %0.2fs" % (obj, time.time() - t0))
+    return Y_eval, obj, data

@@ -788,3 +788,272 @@ def ManiSDP(At, b, c, K, options=None, rng=None, verbose=False):
         _say(verbose, "Iteration maximum is reached!")
     _say(verbose, "ManiSDP: optimum = %0.8f, time = %0.2fs" % (obj, time.time() - t0))
     return Y, obj, data
+
+
+# ------------------------------------------------------------------------ multiblock (src/primal/ManiSDP_multiblock.m)
+class BlockVec:
+    """A point / tangent vector of the product manifold: the cell array ``Y{1..nb}`` of the reference, block i an
+    (n_i, p_i) array (the bytes of MATLAB's p_i x n_i).  Supports exactly the arithmetic Manopt's tCG performs through
+    ``M.lincomb`` (src/C-files/lincombc.cpp:3-67: a1*u1 [+ a2*u2] block by block)."""
+
+    def __init__(self, blocks):
+        self.b = list(blocks)
+
+    def __add__(self, o):
+        return BlockVec([x + y for x, y in zip(self.b, o.b)])
+
+    def __sub__(self, o):
+        return BlockVec([x - y for x, y in zip(self.b, o.b)])
+
+    def __mul__(self, a):
+        return BlockVec([x * a for x in self.b])
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return BlockVec([-x for x in self.b])
+
+    def copy(self):
+        return BlockVec([x.copy() for x in self.b])
+
+
+class MultiBlockManifold:
+    """src/basicfunction/multiblockmanifold.m:1-42 over the MEX helpers of src/C-files: the first ``nob`` blocks are
+    oblique (unit rows here = unit columns of MATLAB's p x n), the others Euclidean.
+    Quirk Q5: the shipped projc.cpp source subtracts ONE Frobenius inner product per block
+    (``:36-43``), which is the projection of a sphere, not of the oblique manifold whose retraction retrc.cpp applies
+    column by column; the sources are stale against the (Windows-only) binaries.  This restatement uses the per-column
+    projection that is consistent with the retraction and with the single-block code (ManiSDP_unitdiag.m:180)."""
+
+    def __init__(self, pset, nset, nob):
+        self.pset, self.nset, self.nob = list(pset), list(nset), int(nob)
+
+    def inner(self, x, u, v):
+        return float(sum(float(a.ravel() @ b.ravel()) for a, b in zip(u.b, v.b)))    # innerc.cpp:3-33
+
+    def norm(self, x, d):
+        return math.sqrt(self.inner(x, d, d))                                          # :10
+
+    def typicaldist(self):                                                             # :11-15
+        t = math.pi * sum(self.nset[:self.nob])
+        t += sum(p * n for p, n in zip(self.pset[self.nob:], self.nset[self.nob:]))
+        return math.sqrt(t)
+
+    def proj(self, x, u):                                                              # :17-21
+        out = []
+        for i, (xi, ui) in enumerate(zip(x.b, u.b)):
+            out.append(ui - xi * np.sum(xi * ui, axis=1, keepdims=True) if i < self.nob else ui.copy())
+        return BlockVec(out)
+
+    tangent = proj
+
+    def retr(self, x, u):                                                              # :23-26 (retrc.cpp:4-52)
+        out = []
+        for i, (xi, ui) in enumerate(zip(x.b, u.b)):
+            yi = xi + ui
+            out.append(yi / np.sqrt(np.sum(yi * yi, axis=1, keepdims=True)) if i < self.nob else yi)
+        return BlockVec(out)
+
+    def zerovec(self, x):                                                              # :38-41
+        return BlockVec([np.zeros_like(xi) for xi in x.b])
+
+    def rand(self, rng):                                                               # :33-36 (randc.cpp:30-83)
+        out = []
+        for i, (p, n) in enumerate(zip(self.pset, self.nset)):
+            yi = rng.standard_normal((n, p))
+            out.append(yi / np.sqrt(np.sum(yi * yi, axis=1, keepdims=True)) if i < self.nob else yi)
+        return BlockVec(out)
+
+
+class _MultiBlockProblem:
+    """cost / grad / hess closures of ManiSDP_multiblock.m:208-249 (shared variables ``Axb``, ``S``; ``eG`` in the store)."""
+
+    def __init__(self, At, b, c, nset, nob):
+        self.At = At.tocsc()
+        self.A = self.At.T.tocsr()
+        self.b, self.c = b, c
+        self.nset, self.nob = list(nset), int(nob)
+        self.off = np.concatenate([[0], np.cumsum([n * n for n in self.nset])])
+        self.M = None
+        self.y = np.zeros(b.size)
+        self.sigma = 1.0
+        self.Axb = None
+        self.S = None
+        self.eG = None
+        self.nhess = 0
+
+    def _x(self, Y):
+        return np.concatenate([(yi @ yi.T).ravel(order="F") for yi in Y.b])           # :209-214
+
+    def cost(self, Y):
+        x = self._x(Y)
+        self.Axb = self.A @ x - self.b - self.y / self.sigma                           # :215
+        return float(self.c @ x) + 0.5 * self.sigma * float(self.Axb @ self.Axb)       # :216
+
+    def grad(self, Y):
+        tt = self.c + self.sigma * (self.At @ self.Axb)                                # :220
+        self.S, self.eG, G = [], [], []
+        for i, (yi, n) in enumerate(zip(Y.b, self.nset)):
+            Si = tt[self.off[i]:self.off[i + 1]].reshape((n, n), order="F")           # :223
+            Gi = 2.0 * (Si.T @ yi)                                                     # :224  G{i} = 2*Y{i}*S{i}
+            if i < self.nob:
+                eGi = np.sum(yi * Gi, axis=1, keepdims=True)                           # :226
+                Gi = Gi - yi * eGi                                                     # :227
+            else:
+                eGi = None
+            self.S.append(Si); self.eG.append(eGi); G.append(Gi)
+        return BlockVec(G)
+
+    def hess(self, Y, U):
+        self.nhess += 1
+        YU = np.concatenate([(yi @ ui.T).ravel(order="F") for yi, ui in zip(Y.b, U.b)])    # :235-237 T = Y{i}'*U{i}
+        AyU = self.At @ (self.A @ YU)                                                  # :240
+        H = []
+        for i, (yi, ui, n) in enumerate(zip(Y.b, U.b, self.nset)):
+            Hi = 2.0 * (self.S[i].T @ ui)                                              # :238
+            Ai = AyU[self.off[i]:self.off[i + 1]].reshape((n, n), order="F")
+            Hi = Hi + 4.0 * self.sigma * (Ai.T @ yi)                                   # :243
+            if i < self.nob:
+                Hi = Hi - yi * np.sum(yi * Hi, axis=1, keepdims=True) - ui * self.eG[i]    # :245
+            H.append(Hi)
+        return BlockVec(H)
+
+
+def ManiSDP_multiblock(At, b, c, K, options=None, rng=None, verbose=False):
+    """``[X, obj, data] = ManiSDP_multiblock(At, b, c, K, options)`` (src/primal/ManiSDP_multiblock.m:7; defaults
+    :10-27): ``K['s']`` = block orders, ``K['nob']`` = number of leading unit-diagonal blocks.  Returns (Y, obj, data)
+    with ``Y`` the list of factors (n_i, p_i); ``options['Y0']`` optionally fixes the start point."""
+    o = dict(options or {})
+    nset = [int(v) for v in np.atleast_1d(K["s"])]
+    nob = int(K.get("nob", 0))
+    nb = len(nset)
+    min_facsize = o.get("min_facsize", 2); p0 = list(np.atleast_1d(o.get("p0", np.ones(nb, int))).astype(int))
+    AL_maxiter = o.get("AL_maxiter", 1000); gama = o.get("gama", 2)
+    sigma0 = o.get("sigma0", 1e-1); sigma_min = o.get("sigma_min", 1e-2); sigma_max = o.get("sigma_max", 1e7)
+    tol = o.get("tol", 1e-8); theta = o.get("theta", 1e-2); delta = o.get("delta", 8)
+    alpha = o.get("alpha", 0.1); tolgradnorm = o.get("tolgradnorm", 1e-8)
+    TR_maxinner = o.get("TR_maxinner", 20); TR_maxiter = o.get("TR_maxiter", 4)
+    tau1 = o.get("tau1", 1e1); tau2 = o.get("tau2", 1e1); line_search = o.get("line_search", 0)
+    rng = rng or np.random.default_rng(0)
+    b = _as_dense_vec(b)
+    c = _as_dense_vec(c)
+    _say(verbose, "ManiSDP is starting...")
+    _say(verbose, f"SDP size: n = {max(nset)}, m = {b.size}")
+    prob = _MultiBlockProblem(At, b, c, nset, nob)
+    A, Atc, off = prob.A, prob.At, prob.off
+    p = [p0[i] if nset[i] >= min_facsize else nset[i] for i in range(nb)]              # :34-39
+    sigma = sigma0
+    y = np.zeros(b.size)
+    normb = 1.0 + np.linalg.norm(b)
+    Y = o.get("Y0", None)
+    U = None
+    data = {"status": 0, "hessvecs": 0, "cost_evals": 0, "rejected": 0, "rtr_seconds": 0.0}
+    t0 = time.time()
+    gap0 = pinf0 = dinf0 = None
+    obj = gap = pinf = dinf = gradnorm = eta_kkt = None
+    X = S = None
+
+    def co(Yv):                                                                        # :160-169
+        x = prob._x(Yv)
+        Axb = A @ x - b - y / sigma
+        return float(c @ x) + 0.5 * sigma * float(Axb @ Axb)
+
+    def normalise(Yb, i):
+        return Yb / np.sqrt(np.sum(Yb * Yb, axis=1, keepdims=True)) if i < nob else Yb
+
+    def do_line_search(Yv, Uv):                                                        # :171-193
+        a = 1.0
+        cost0 = co(Yv)
+        nY = BlockVec([normalise(yi + a * ui, i) for i, (yi, ui) in enumerate(zip(Yv.b, Uv.b))])
+        k = 1
+        while k <= 15 and co(nY) - cost0 > -1e-3:
+            a = 0.8 * a
+            nY = BlockVec([normalise(yi + a * ui, i) for i, (yi, ui) in enumerate(zip(Yv.b, Uv.b))])
+            k += 1
+        return nY
+
+    for it in range(1, AL_maxiter + 1):                                                # :57
+        prob.M = MultiBlockManifold(p, nset, nob)                                      # :58
+        prob.y, prob.sigma = y, sigma
+        if U is not None:
+            Y = do_line_search(Y, U)                                                   # :59-61
+        t1 = time.time()
+        Y, _, info = trustregions(prob, Y, TR_maxiter, TR_maxinner, tolgradnorm, rng=rng)   # :62
+        data["rtr_seconds"] += time.time() - t1
+        data["hessvecs"] += info.hessvecs
+        data["cost_evals"] += info.cost_evals
+        data["rejected"] += info.rejected
+        gradnorm = info.gradnorm                                                       # :63
+        X = [yi @ yi.T for yi in Y.b]                                                  # :65-69
+        x = np.concatenate([Xi.ravel(order="F") for Xi in X])
+        obj = float(c @ x)                                                             # :70
+        Axb = A @ x - b                                                                # :71
+        pinf = float(np.linalg.norm(Axb)) / normb                                      # :72
+        y = y - sigma * Axb                                                            # :73
+        cy = c - Atc @ y                                                               # :74
+        by = float(b @ y)                                                              # :75
+        S, vS, dS, dinfs = [], [], [], []
+        for i, n in enumerate(nset):                                                   # :78-88
+            Si = cy[off[i]:off[i + 1]].reshape((n, n), order="F")
+            if i < nob:
+                z = np.sum(X[i] * Si, axis=0)                                          # :81
+                by += float(np.sum(z))
+                Si = Si - np.diag(z)
+            w, V = np.linalg.eigh(0.5 * (Si + Si.T))                                   # :86
+            S.append(Si); dS.append(w); vS.append(V)
+            dinfs.append(max(0.0, -w[0]) / (1.0 + abs(w[-1])))                         # :87
+        dinf = max(dinfs)                                                              # :89
+        gap = abs(obj - by) / (abs(by) + abs(obj) + 1.0)                               # :90
+        _say(verbose, "Iter %d, obj:%0.8f, gap:%0.1e, pinf:%0.1e, dinf:%0.1e, gradnorm:%0.1e, p_max:%d, sigma:%0.3f, time:%0.2fs"
+             % (it, obj, gap, pinf, dinf, gradnorm, max(p), sigma, time.time() - t0))
+        eta_kkt = max(gap, pinf, dinf)                                                 # :93
+        data["iters"] = it
+        data.setdefault("log", []).append((it, obj, gap, pinf, dinf, gradnorm, max(p), sigma))
+        Y_eval = Y
+        if eta_kkt < tol:
+            _say(verbose, "Optimality is reached!")
+            break
+        if it % 50 == 0:                                                               # :98-108
+            if it > 100 and gap > gap0 and pinf > pinf0 and dinf > dinf0:
+                data["status"] = 2
+                _say(verbose, "Slow progress!")
+                break
+            gap0, pinf0, dinf0 = gap, pinf, dinf
+        newY, newU = [], []
+        for i, n in enumerate(nset):                                                   # :109-147
+            yi = Y.b[i]
+            ui = None
+            if n >= min_facsize:
+                if p[i] > 1:
+                    V, e, _ = np.linalg.svd(yi, full_matrices=False)                   # :112-118
+                    r = int(np.sum(e >= theta * e[0]))
+                    if r == 0:
+                        r = 1
+                    if r < p[i]:
+                        yi = V[:, :r] * e[:r]                                          # :125
+                        p[i] = r
+                nneg = int(np.sum(dS[i] < 0))
+                nne = max(min(nneg, delta), 1) if i < nob else min(nneg, delta)        # :129-133
+                if p[i] + nne > n:
+                    nne = 0                                                            # :134-136
+                if line_search == 1:
+                    ui = np.hstack([np.zeros((n, p[i])), vS[i][:, :nne]])              # :137-139
+                    yi = np.hstack([yi, np.zeros((n, nne))])                           # :141-142
+                else:
+                    yi = normalise(np.hstack([yi, alpha * vS[i][:, :nne]]), i)         # :143-147
+                p[i] = p[i] + nne                                                      # :140
+            newY.append(yi)
+            newU.append(ui if ui is not None else np.zeros_like(yi))
+        Y = BlockVec(newY)
+        U = BlockVec(newU) if line_search == 1 else None
+        if pinf < tau1 * gradnorm:                                                     # :150-154
+            sigma = max(sigma / gama, sigma_min)
+        elif pinf > tau2 * gradnorm:
+            sigma = min(sigma * gama, sigma_max)
+    data.update({"Y": Y_eval, "X": X, "y": y, "S": S, "gap": gap, "pinf": pinf, "dinf": dinf, "gradnorm": gradnorm,
+                 "time": time.time() - t0, "sigma": sigma, "p": list(p)})
+    if data["status"] == 0 and eta_kkt > tol:
+        data["status"] = 1
+        _say(verbose, "Iteration maximum is reached!")
+    _say(verbose, "ManiSDP: optimum = %0.8f, time = %0.2fs" % (obj, time.time() - t0))
+    return Y_eval, obj, data

@@ -1,0 +1,168 @@
+"""GPU parity for the multiblock entry point: ManiSDP_multiblock.m + multiblockmanifold.m
+(product of oblique and Euclidean factors; the reference attaches it through the MEX helpers of src/C-files).
+
+Operators through the C ABI against the oracle's restatement of the closures (ManiSDP_multiblock.m:208-249) on a
+three-block problem with a Euclidean block, unequal widths and a constraint that couples two blocks; full solves against
+SDPLIB known answers (a direct sum of two maxcut problems has the sum of their optima) and against the oracle."""
+import json
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _relerr(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from manisdp_matlab_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def _random_multiblock(nset, m, seed):
+    """SeDuMi data over the concatenated vecs of the blocks: symmetric constraint matrices with a few entries each,
+    some of them touching two blocks, dense symmetric costs."""
+    rng = np.random.default_rng(seed)
+    off = np.concatenate([[0], np.cumsum([n * n for n in nset])])
+    rows, cols, vals = [], [], []
+    for k in range(m):
+        for _ in range(rng.integers(1, 4)):
+            i = int(rng.integers(0, len(nset)))
+            n = nset[i]
+            a, bb = int(rng.integers(0, n)), int(rng.integers(0, n))
+            v = rng.standard_normal()
+            for (u, w) in {(a, bb), (bb, a)}:
+                rows.append(off[i] + u + w * n); cols.append(k); vals.append(v)
+    At = sp.coo_matrix((vals, (rows, cols)), shape=(off[-1], m)).tocsc()
+    At.sum_duplicates()
+    c = []
+    for n in nset:
+        G = rng.standard_normal((n, n))
+        c.append(((G + G.T) / 2).ravel(order="F"))
+    return At, rng.standard_normal(m), np.concatenate(c)
+
+
+def test_multiblock_operators(lib):
+    from oracle import manisdp_ref as R
+    from manisdp_matlab_amd.solvers import _pack_blocks
+    nset, nob, p = [30, 17, 24], 2, [4, 3, 5]
+    At, b, c = _random_multiblock(nset, 40, seed=1)
+    r0 = np.concatenate([[0], np.cumsum(nset)])
+    N, pmax = int(r0[-1]), max(p)
+    rng = np.random.default_rng(2)
+    M = R.MultiBlockManifold(p, nset, nob)
+    Y = M.rand(rng)
+    U = R.BlockVec([rng.standard_normal((n, pi)) for n, pi in zip(nset, p)])
+    y = 0.1 * rng.standard_normal(b.size)
+    sigma = 0.7
+    prob = R._MultiBlockProblem(At, b, c, nset, nob)
+    prob.M = M
+    prob.y, prob.sigma = y, sigma
+    f_ref = prob.cost(Y); G_ref = prob.grad(Y); H_ref = prob.hess(Y, U)
+    h = lib.Handle.multiblock(At, b, c, nset, nob)
+    assert h.get_kind() == lib.KIND_MULTIBLOCK and h.n == N
+    h.set_multipliers(y, sigma)
+    h.set_point(_pack_blocks(Y.b, r0, N, pmax))
+    pack = lambda V: _pack_blocks(V.b, r0, N, pmax)         # noqa: E731
+    assert abs(h.cost() - f_ref) <= 1e-11 * max(1.0, abs(f_ref))
+    assert _relerr(h.rgrad(), pack(G_ref)) < 1e-11
+    assert _relerr(h.hessvec(pack(U)), pack(H_ref)) < 1e-11
+    assert _relerr(h.proj(pack(U)), pack(M.proj(Y, U))) < 1e-13
+    assert _relerr(h.retr(pack(U)), pack(M.retr(Y, U))) < 1e-13
+    # the zero padding of the narrower blocks stays zero under every operator
+    for A_ in (h.rgrad(), h.hessvec(pack(U)), h.retr(pack(U))):
+        for i in range(len(nset)):
+            assert np.all(A_[r0[i]:r0[i + 1], p[i]:] == 0.0)
+    # AL bookkeeping: obj, A x, z (zero on the Euclidean block), S blocks (ManiSDP_multiblock.m:65-84)
+    obj, Ax = h.al_primal(b.size)
+    x = prob._x(Y)
+    assert abs(obj - c @ x) <= 1e-11 * max(1.0, abs(c @ x)) and _relerr(Ax, prob.A @ x) < 1e-11
+    z = h.al_dual(y)
+    S = h.get_dual_slack()
+    cy = c - prob.At @ y
+    for i, n in enumerate(nset):
+        Si = cy[prob.off[i]:prob.off[i + 1]].reshape((n, n), order="F")
+        if i < nob:
+            zi = np.sum((Y.b[i] @ Y.b[i].T) * Si, axis=0)
+            Si = Si - np.diag(zi)
+            assert _relerr(z[r0[i]:r0[i + 1]], zi) < 1e-11
+        else:
+            assert np.all(z[r0[i]:r0[i + 1]] == 0.0)
+        assert _relerr(S[r0[i]:r0[i + 1], r0[i]:r0[i + 1]], Si) < 1e-11
+    # one tCG through the device RTR agrees with the oracle's (Hess-vec count, stop code, cost)
+    from oracle import manopt_rtr
+    st = h.rtr(lib.default_opts(maxiter=1, maxinner=12, tolgradnorm=1e-9, Delta_bar=M.typicaldist()))
+    _, f1, info = manopt_rtr.trustregions(prob, Y, 1, 12, 1e-9)
+    assert st.hessvecs == info.hessvecs and st.last_stop_inner == info.stop_inner[-1]
+    assert abs(st.cost - f1) <= 1e-10 * max(1.0, abs(f1))
+    h.close()
+
+
+def _maxcut_block(name):
+    from manisdp_matlab_amd import problems
+    At, b, c, K = problems.from_sdpa(golden_path(name + ".dat-s.gz"))
+    return At, np.asarray(b, float), np.asarray(c.todense()).ravel(), K["s"]
+
+
+def _direct_sum(nob):
+    At1, b1, c1, n1 = _maxcut_block("mcp100")
+    At2, b2, c2, n2 = _maxcut_block("mcp124-1")
+    c = np.concatenate([c1, c2])
+    if nob == 2:
+        # the manifold enforces every diagonal; SeDuMi data still needs one constraint: X1(1,1) = 1
+        At = sp.csc_matrix((np.ones(1), ([0], [0])), shape=(n1 * n1 + n2 * n2, 1)); b = np.ones(1)
+    else:
+        At = sp.vstack([sp.csc_matrix((n1 * n1, At2.shape[1])), sp.csc_matrix(At2)]).tocsc(); b = b2
+    return At, b, c, {"s": [n1, n2], "nob": nob}
+
+
+def test_multiblock_direct_sum_known_answer(lib):
+    """mcp100 (+) mcp124-1 as ONE two-block SDP with both unit diagonals in the product manifold (nob = 2): the optimum
+    is the sum of the two SDPLIB values (data/sdplib/README:76-77); the oracle certifies the same."""
+    from manisdp_matlab_amd import solvers
+    from oracle import manisdp_ref as R
+    known = json.load(open(golden_path("known_answers.json")))
+    At, b, c, K = _direct_sum(2)
+    Y, obj, d = solvers.ManiSDP_multiblock(At, b, c, K, {}, verbose=False)
+    assert d["status"] == 0 and max(d["gap"], d["pinf"], d["dinf"]) < 1e-8
+    want = -(known["mcp100"] + known["mcp124-1"])
+    assert abs(obj - want) <= 1e-6 * abs(want)
+    for Yi in Y:
+        assert np.abs(np.diag(Yi @ Yi.T) - 1).max() < 1e-12
+    Yr, objr, dr = R.ManiSDP_multiblock(At, b, c, K, {})
+    assert dr["status"] == 0 and abs(obj - objr) <= 1e-6 * abs(objr)
+
+
+def test_multiblock_mixed_manifold_follows_the_oracle(lib):
+    """nob = 1: the second block is Euclidean and its X_ii = 1 are ordinary affine constraints -- the mixed product
+    manifold of multiblockmanifold.m.  On this instance the reference's scheme levels off between 1e-7 and 1e-6 for
+    every option set tried (oracle and GPU alike), so the test pins the path instead of the end point: from the same
+    start the device solver and the oracle produce the same outer iterates (objective, residues, factor widths) for the
+    first twelve AL iterations, and a longer run ends near the known optimum."""
+    from manisdp_matlab_amd import solvers
+    from oracle import manisdp_ref as R
+    known = json.load(open(golden_path("known_answers.json")))
+    At, b, c, K = _direct_sum(1)
+    n1, n2 = K["s"]
+    rng = np.random.default_rng(0)
+    Y0 = [rng.standard_normal((n1, 1)), rng.standard_normal((n2, 1))]
+    Y0[0] /= np.linalg.norm(Y0[0], axis=1, keepdims=True)
+    _, _, d = solvers.ManiSDP_multiblock(At, b, c, K, {"AL_maxiter": 12, "Y0": [y.copy() for y in Y0]}, verbose=False)
+    _, _, dr = R.ManiSDP_multiblock(At, b, c, K, {"AL_maxiter": 12, "Y0": R.BlockVec([y.copy() for y in Y0])})
+    assert len(d["log"]) == len(dr["log"]) == 12
+    for g, r in zip(d["log"], dr["log"]):
+        assert g[0] == r[0] and g[6] == r[6]                               # iteration, p_max
+        assert abs(g[1] - r[1]) <= 1e-7 * abs(r[1])                        # obj
+        for q in (2, 3, 4, 5):                                             # gap, pinf, dinf, gradnorm
+            assert abs(g[q] - r[q]) <= 1e-5 * max(abs(r[q]), 1e-8)
+    Y, obj, d = solvers.ManiSDP_multiblock(At, b, c, K, {"AL_maxiter": 60}, verbose=False)
+    want = -(known["mcp100"] + known["mcp124-1"])
+    assert max(d["gap"], d["pinf"], d["dinf"]) < 1e-4 and abs(obj - want) <= 1e-5 * abs(want)
+    assert np.abs(np.diag(Y[0] @ Y[0].T) - 1).max() < 1e-12               # the oblique block stays on its manifold

@@ -51,6 +51,9 @@ APPENDIX_A = {      # SURVEY.md appendix A (reference file:line in the module do
     "ManiSDP_unitdiag.m": dict(p0=2, AL_maxiter=300, gama=2, sigma0=1e-3, sigma_min=1e-2, sigma_max=1e7, tol=1e-8,
                                theta=1e-3, delta=8, alpha=0.1, tolgradnorm=1e-8, TR_maxinner=20, TR_maxiter=4,
                                tau1=1, tau2=1, line_search=0),
+    "ManiSDP_multiblock.m": dict(min_facsize=2, AL_maxiter=1000, gama=2, sigma0=1e-1, sigma_min=1e-2, sigma_max=1e7,
+                                 tol=1e-8, theta=1e-2, delta=8, alpha=0.1, tolgradnorm=1e-8, TR_maxinner=20,
+                                 TR_maxiter=4, tau1=1e1, tau2=1e1, line_search=0),    # ManiSDP_multiblock.m:10-27
     "ManiSDP_unittrace.m": dict(p0=1, AL_maxiter=1000, gama=2, sigma0=1e1, sigma_min=1e2, sigma_max=1e7, tol=1e-8,
                                 theta=1e-2, delta=8, alpha=0.05, tolgradnorm=1e-8, TR_maxinner=40, TR_maxiter=3,
                                 tau1=1e-5, tau2=1e-4, line_search=1),

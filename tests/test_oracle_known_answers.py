@@ -109,3 +109,22 @@ def test_generic_quartic_on_sphere_kkt_self_certification():
     X = Y @ Y.T
     assert np.linalg.norm(At.T @ X.ravel(order="F") - b) / (1 + np.linalg.norm(b)) < 1e-8
     assert abs(obj - c @ X.ravel(order="F")) < 1e-9 * max(1.0, abs(obj))
+
+
+def test_multiblock_direct_sum_of_two_maxcut_problems():
+    """ManiSDP_multiblock.m restated (oracle): mcp100 (+) mcp124-1 as one two-block SDP with both unit diagonals in the
+    product manifold has the sum of the two SDPLIB optima (data/sdplib/README:76-77)."""
+    import scipy.sparse as sp
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R
+    known = json.load(open(golden_path("known_answers.json")))
+    cs, ns = [], []
+    for name in ("mcp100", "mcp124-1"):
+        At, b, c, K = problems.from_sdpa(golden_path(name + ".dat-s.gz"))
+        cs.append(np.asarray(c.todense()).ravel()); ns.append(K["s"])
+    c = np.concatenate(cs)
+    At = sp.csc_matrix((np.ones(1), ([0], [0])), shape=(c.size, 1))
+    Y, obj, d = R.ManiSDP_multiblock(At, np.ones(1), c, {"s": ns, "nob": 2}, {})
+    assert d["status"] == 0 and max(d["gap"], d["pinf"], d["dinf"]) < 1e-8
+    want = -(known["mcp100"] + known["mcp124-1"])
+    assert abs(obj - want) <= 1e-6 * abs(want)

@@ -55,3 +55,11 @@ def test_data_fields_and_protocol_in_source():
         assert line in src, line
     assert solvers.DATA_FIELDS["onlyunitdiag"] == ("X", "S", "z", "dinf", "gradnorm", "time", "status")
     assert set(solvers.DATA_FIELDS["unitdiag"]) - set(solvers.DATA_FIELDS["unittrace"]) == {"fac_size"}   # ManiSDP_unitdiag.m:123
+
+
+def test_multiblock_defaults():
+    from manisdp_matlab_amd import solvers
+    assert solvers.DEFAULTS["multiblock"] == dict(min_facsize=2, AL_maxiter=1000, gama=2, sigma0=1e-1, sigma_min=1e-2,
+                                                  sigma_max=1e7, tol=1e-8, theta=1e-2, delta=8, alpha=0.1,
+                                                  tolgradnorm=1e-8, TR_maxinner=20, TR_maxiter=4, tau1=1e1, tau2=1e1,
+                                                  line_search=0)                      # ManiSDP_multiblock.m:10-27
