@@ -191,9 +191,11 @@ def test_solver_gpp100_known_answer(lib):
 
 def test_solver_theta1_known_answer(lib):
     """theta1 with the options of example/example_theta.m:50-53.  The reference algorithm itself is
-    start-point sensitive on this instance (the oracle ends with "Slow progress!" for 2 of 5 seeds, and
-    accept/reject decisions at rounding level make the trajectory chaotic), so the test asks that the
-    seeds that converge reproduce the SDPLIB optimum and that at least one of three does."""
+    start-point sensitive on this instance: over the seeds 0..5 the oracle certifies for {0, 2, 3}, the GPU path with
+    host eig for {1, 2, 4}, with the device escape for {0, 4} (profiles/r2_theta_seeds.log) -- accept/reject and sigma
+    decisions at rounding level make the trajectory chaotic, and which starts succeed is not a property the two
+    implementations share.  So the test asks that the seeds that converge reproduce the SDPLIB optimum and that at
+    least one of three does."""
     from manisdp_matlab_amd import problems, solvers
     known = json.load(open(golden_path("known_answers.json")))
     At, b, c, K = problems.from_sdpa(golden_path("theta1.dat-s.gz"))
@@ -214,6 +216,26 @@ def test_solver_theta1_known_answer(lib):
             # primal side is still good when the dual certificate stalls
             assert max(data["gap"], data["pinf"]) < 1e-3
     assert converged >= 1
+
+
+def test_solver_theta2_reaches_the_known_value(lib):
+    """theta2 (n = 100, m = 498; data/sdplib/README:99) with the options of example/example_theta.m:50-53.  No run of
+    the reference's scheme certifies 1e-6 on this instance -- the oracle and the GPU path end on "Slow progress" at
+    eta = 2e-4...5e-4 from every start tried (profiles/r2_theta_seeds.log) -- but every run lands on the SDPLIB optimum
+    to 5 digits, which is what this test pins, for the host-eig and the device-escape bookkeeping alike."""
+    from manisdp_matlab_amd import problems, solvers
+    known = json.load(open(golden_path("known_answers.json")))
+    At, b, c, K = problems.from_sdpa(golden_path("theta2.dat-s.gz"))
+    c = np.asarray(c.todense()).ravel(); b = np.asarray(b, float)
+    n = K["s"]
+    for seed, mode in ((0, "host"), (1, "device")):
+        rng = np.random.default_rng(seed)
+        Y0 = rng.standard_normal((n, 1)); Y0 /= np.linalg.norm(Y0)
+        Y, obj, d = solvers.ManiSDP_unittrace(At, b, c, K, dict(tol=1e-6, sigma0=1e5, sigma_max=1e8, Y0=Y0, eig=mode), verbose=False)
+        assert abs(np.linalg.norm(Y) - 1.0) < 1e-12
+        assert d["status"] in (0, 2)
+        assert abs(-obj - known["theta2"]) <= 5e-5 * known["theta2"]
+        assert max(d["gap"], d["pinf"]) < 1e-3
 
 
 def test_solver_bqp_with_device_escape(lib):
