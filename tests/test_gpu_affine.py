@@ -119,6 +119,40 @@ def test_unittrace_operators(lib, case, p):
     h.close()
 
 
+@pytest.mark.parametrize("route", ["gram", "sddmm"])
+def test_unitdiag_operators_on_slightly_asymmetric_data(lib, monkeypatch, route):
+    """SeDuMi data is symmetric and the affine kernels exploit it (upper-triangle adjoint and Gram route).  Data that is
+    not exactly symmetric -- here one coefficient of one A_k and one entry of C moved by 1e-13 -- must be detected at
+    set-up and take the general kernels (k_adjoint_dense, full Gram matrix); the results stay within the test's
+    tolerance of the oracle because the asymmetry itself is far below it."""
+    from oracle import manisdp_ref as R
+    monkeypatch.setenv("MSDP_AFFINE_ROUTE", route)
+    At, b, c, K = _bqp(20)
+    n, p = K["s"], 24
+    At = At.tocsc(copy=True)
+    k = At.shape[1] // 2
+    lo, hi = At.indptr[k], At.indptr[k + 1]
+    offdiag = [t for t in range(lo, hi) if At.indices[t] % n != At.indices[t] // n]
+    At.data[offdiag[0]] *= 1.0 + 1e-13                                 # A_k(i,j) != A_k(j,i)
+    c = c.copy(); c[1] += 1e-13                                        # C(2,1) != C(1,2)
+    rng = np.random.default_rng(5)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    y = rng.standard_normal(b.size) * 0.1
+    prob = R._UnitDiagProblem(At, np.asarray(b, float), c, n, p)
+    prob.y, prob.sigma = y, 0.8
+    f_ref = prob.cost(Y); G_ref = prob.grad(Y); H_ref = prob.hess(Y, U)
+    h = lib.Handle.affine(lib.KIND_UNITDIAG, At, b, c, n)
+    h.set_multipliers(y, 0.8)
+    h.set_point(Y)
+    assert abs(h.cost() - f_ref) <= 1e-11 * max(1.0, abs(f_ref))
+    assert _relerr(h.rgrad(), G_ref) < 1e-11
+    assert _relerr(h.hessvec(U), H_ref) < 1e-11
+    obj, Ax = h.al_primal(b.size)
+    assert _relerr(Ax, prob.A @ (Y @ Y.T).ravel(order="F")) < 1e-11
+    h.close()
+
+
 def test_unitdiag_rtr_single_tcg(lib):
     """maxiter = 1: one tCG; Hess-vec count, stop code and cost agree with the oracle."""
     from manisdp_matlab_amd import problems
