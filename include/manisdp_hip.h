@@ -265,6 +265,8 @@ int msdp_get_dual_slack(msdp_handle h, double* S);
  *   "escape_deflate" 1/0 escape: deflate span(Y) at near-stationary points (default 1).  Fast, but only as accurate as
  *                       S*Y is small; a caller about to DECLARE optimality re-checks lambda_min with 0 (see solvers.py)
  *   "escape_warm"  1/0  escape: start from what the previous call found (default 1; 0 = hashed random start vector)
+ *   "dense_pack"   1/0  dense C*U reads the MFMA-fragment-ordered copy of C (default 1; 0 = the row-major one;
+ *                       bit-identical results, for A/B timing)
  *   "timing", "esc_debug"  1/0  diagnostics on stderr                                (env MSDP_TIMING, MSDP_ESC_DEBUG)
  *   "debug_fail_persist"   1    test hook: the next persistent launch reports a synchronisation time-out
  * The environment variables are read once, when the handle is created.  Unknown names -> MSDP_EINVAL. */

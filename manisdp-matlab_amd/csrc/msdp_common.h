@@ -95,6 +95,7 @@ struct Dev {
     const double* ellv;
     // dense C / eS (n_loc x n row-major) per slot for affine kinds
     double* Cd;       // dense cost matrix rows (COST_DENSE) or c reshaped (COST_AFFINE)
+    double* Cpk;      // COST_DENSE: the same rows in MFMA-fragment order (msdp_dense.hip, k_pack_fragments)
     double* eS[2];    // affine kinds: eS per slot (n_loc x n)
     double* AyU;      // affine kinds: A'(A(.)) scratch (n_loc x n)
     double* Sdual;    // affine kinds: dual slack S of msdp_al_dual (= AyU unless the restricted adjoint is in use)
@@ -121,6 +122,7 @@ struct Tuning {
     int timing = 0;        // per-call timing lines on stderr                                       (MSDP_TIMING=1)
     int esc_debug = 0;     // per-run Lanczos statistics on stderr                                  (MSDP_ESC_DEBUG=1)
     int escape_deflate = 1;  // escape: deflate span(Y) at near-stationary points (fast, approximate when S*Y != 0)
+    int dense_pack = 1;    // dense C*U reads the fragment-ordered copy of C (0: the row-major one; same results)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
     int fail_persist = 0;  // test hook (msdp_set_option "debug_fail_persist"): the next persistent launch reports a
                            //   grid-synchronisation time-out without running, to exercise the recovery path

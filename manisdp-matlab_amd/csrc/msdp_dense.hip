@@ -30,6 +30,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 struct DenseOp {
     const double* M[2];          // n_loc x nS row-major matrices (rows = local rows)
+    const double* Mpk;           // M[0] again in MFMA-fragment order (k_pack_fragments), or null
     const double* X[2];          // n x ld panels (all rows)
     double scale[2];
     int nmat;
@@ -67,7 +68,11 @@ template <int NT> struct Dense3Cfg {
     static constexpr bool PIN = NT >= 3;                       // keep the prefetch block of a tile in place (see below)
 };
 
-template <int NT>
+// PK: the (single) matrix is read from its fragment-ordered copy: tile (rb, kb) of 16 rows x 16 k is 256 contiguous
+// doubles, first the (t = 0,1) pairs of the 64 lanes, then the (t = 2,3) pairs, so each of the two dwordx4 loads of a
+// k-step reads one contiguous kilobyte per wave instead of sixteen 128-byte lines 8*nS bytes apart.  Same values into
+// the same MFMA sequence: results are bit-identical to the row-major form.
+template <int NT, bool PK>
 __global__ __launch_bounds__(Dense3Cfg<NT>::WAVES * 64, (NT <= 4 ? 3 : 1)) void k_dense_partial3(DenseOp op, const int* active_flag) {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // 2 x KT x ldl + 128 (dummy slots)
     if (active_flag && !*active_flag) return;
@@ -91,7 +96,8 @@ __global__ __launch_bounds__(Dense3Cfg<NT>::WAVES * 64, (NT <= 4 ? 3 : 1)) void 
     double4_t acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    const double* a0 = op.M[0] + (int64_t)arow * nS + 4 * g;
+    const double* a0 = PK ? op.Mpk + (int64_t)(arow >> 4) * nS * 16 + 2 * lane      // tile (rb, kb) starts at (rb*nS/16 + kb)*256
+                          : op.M[0] + (int64_t)arow * nS + 4 * g;
     const double* a1 = op.M[1] + (int64_t)arow * nS + 4 * g - nS;      // indexed with the concatenated k
     double2 A0[SS][2], A1[SS][2];                              // fragments of the tile in work / of the next tile
     double2 stg[NPASS];
@@ -101,8 +107,13 @@ __global__ __launch_bounds__(Dense3Cfg<NT>::WAVES * 64, (NT <= 4 ? 3 : 1)) void 
         for (int s = 0; s < SS; ++s) {
             const int ks = k0 + 16 * s;
             const int kc = ks < kend ? ks : kbeg;
-            const double* ap = (kc >= nS ? a1 : a0) + kc;
-            A[s][0] = ld2(ap); A[s][1] = ld2(ap + 2);
+            if constexpr (PK) {
+                const double* ap = a0 + (int64_t)kc * 16;
+                A[s][0] = ld2(ap); A[s][1] = ld2(ap + 128);
+            } else {
+                const double* ap = (kc >= nS ? a1 : a0) + kc;
+                A[s][0] = ld2(ap); A[s][1] = ld2(ap + 2);
+            }
         }
     };
     // Rows outside the slice or in the pad range [n, nS) contribute nothing: the matching matrix entries are exact
@@ -314,11 +325,17 @@ static int ensure_slab(msdp_handle h, size_t need) {
 int msdp_dense_nS(int n) { return ((n + 15) / 16) * 16; }
 
 typedef void (*dense3_fn_t)(DenseOp, const int*);
-static dense3_fn_t dense3_fn(int NT) {
+static dense3_fn_t dense3_fn(int NT, bool pk = false) {
+    if (pk)
+        switch (NT) {
+            case 1: return k_dense_partial3<1, true>; case 2: return k_dense_partial3<2, true>; case 3: return k_dense_partial3<3, true>;
+            case 4: return k_dense_partial3<4, true>; case 5: return k_dense_partial3<5, true>; case 6: return k_dense_partial3<6, true>;
+            case 7: return k_dense_partial3<7, true>; default: return k_dense_partial3<8, true>;
+        }
     switch (NT) {
-        case 1: return k_dense_partial3<1>; case 2: return k_dense_partial3<2>; case 3: return k_dense_partial3<3>;
-        case 4: return k_dense_partial3<4>; case 5: return k_dense_partial3<5>; case 6: return k_dense_partial3<6>;
-        case 7: return k_dense_partial3<7>; default: return k_dense_partial3<8>;
+        case 1: return k_dense_partial3<1, false>; case 2: return k_dense_partial3<2, false>; case 3: return k_dense_partial3<3, false>;
+        case 4: return k_dense_partial3<4, false>; case 5: return k_dense_partial3<5, false>; case 6: return k_dense_partial3<6, false>;
+        case 7: return k_dense_partial3<7, false>; default: return k_dense_partial3<8, false>;
     }
 }
 static int dense3_kt(int NT) { return NT <= 1 ? 64 : 32; }
@@ -406,6 +423,8 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
     op.nmat = nmat;
     for (int m = 0; m < nmat; ++m) { op.M[m] = M[m]; op.X[m] = X[m]; op.scale[m] = scale[m]; }
     if (nmat == 1) { op.M[1] = M[0]; op.X[1] = X[0]; op.scale[1] = 0.0; }
+    const bool pk = nmat == 1 && d.Cpk && M[0] == d.Cd && h->tune.dense_pack;                // the constant dense cost matrix has a fragment-ordered copy
+    op.Mpk = pk ? d.Cpk : nullptr;
     op.n = d.n;
     op.nS = msdp_dense_nS(d.n);
     op.n_loc = d.n_loc;
@@ -428,7 +447,7 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
         const int NT = (op.ncols + 15) / 16;
         const int rows_wg = dense3_waves(NT) * 16;
         dim3 grid((d.n_loc + rows_wg - 1) / rows_wg, SK), block(dense3_waves(NT) * 64);
-        hipLaunchKernelGGL(dense3_fn(NT), grid, block, dense3_lds(NT, ldl), h->stream, op, active_flag);
+        hipLaunchKernelGGL(dense3_fn(NT, pk), grid, block, dense3_lds(NT, ldl), h->stream, op, active_flag);
     }
     HIPCHK(hipGetLastError());
     *slab_out = h->slab;
@@ -463,6 +482,32 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
         }                                                                                            \
     } while (0)
 
+// Fragment-ordered copy of the local rows of the cost matrix (k_dense_partial3<NT, true> reads it); rows beyond
+// n_loc in the last 16-row block are zero.
+__global__ void k_pack_fragments(const double* __restrict__ Cd, double* __restrict__ Cpk, int nS, int n_loc, int64_t tot) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t tile = e >> 8;
+        const int w = (int)(e & 255);
+        const int L = (w & 127) >> 1, t = ((w >> 7) << 1) | (w & 1);
+        const int64_t rb = tile / (nS >> 4), kb = tile - rb * (nS >> 4);
+        const int64_t row = rb * 16 + (L & 15), k = kb * 16 + 4 * (L >> 4) + t;
+        Cpk[e] = row < n_loc ? Cd[row * nS + k] : 0.0;
+    }
+}
+static int dense_pack(msdp_handle h) {
+    Dev& d = h->d;
+    const int nS = msdp_dense_nS(d.n);
+    const int64_t tot = (int64_t)((d.n_loc + 15) / 16) * 16 * nS;
+    void* p = nullptr;
+    int rc = msdp_dev_alloc_bytes(h, &p, (size_t)tot * sizeof(double));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pack_fragments, dim3(4096), dim3(256), 0, h->stream, d.Cd, (double*)p, nS, d.n_loc, tot);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    d.Cpk = (double*)p;
+    return 0;
+}
+
 // Upload a dense symmetric n x n matrix (host, column-major == row-major) with the padded
 // leading dimension nS.
 int msdp_dense_setup(msdp_handle h, const double* C) {
@@ -475,7 +520,7 @@ int msdp_dense_setup(msdp_handle h, const double* C) {
     HIPCHK(hipMemset(d.Cd, 0, (size_t)d.n * nS * sizeof(double)));
     HIPCHK(hipMemcpy2D(d.Cd, (size_t)nS * sizeof(double), C, (size_t)d.n * sizeof(double), (size_t)d.n * sizeof(double),
                        d.n, hipMemcpyHostToDevice));
-    return 0;
+    return dense_pack(h);
 }
 
 // Counter-based generator of a dense symmetric test matrix: entry (i,j) depends only on (min,max,seed), so
@@ -513,7 +558,7 @@ int msdp_dense_setup_synthetic(msdp_handle h, uint64_t seed) {
     hipLaunchKernelGGL(k_fill_dense_sym, dim3(4096), dim3(256), 0, h->stream, d.Cd, d.n, nS, d.row0, d.n_loc, seed);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    return 0;
+    return dense_pack(h);
 }
 
 int msdp_dense_costgrad(msdp_handle h, int slot) {

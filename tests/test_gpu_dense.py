@@ -38,6 +38,26 @@ def test_dense_operators_match_oracle(lib, n, p):
     h.close()
 
 
+@pytest.mark.parametrize("n,p", [(33, 5), (1000, 32), (777, 64), (300, 130), (2050, 20)])
+def test_dense_fragment_ordered_copy_is_bit_identical(lib, n, p):
+    """The fragment-ordered copy of C feeds the same values into the same MFMA sequence as the row-major one."""
+    from manisdp_matlab_amd import problems
+    C = problems.dense_unitdiag_cost(n, seed=n + 1)
+    rng = np.random.default_rng(p)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    out = []
+    for pack in (1, 0):
+        h = lib.Handle.onlyunitdiag(C)
+        h.set_option("dense_pack", pack)
+        h.set_point(Y)
+        out.append((h.cost(), h.rgrad(), h.hessvec(U)))
+        h.close()
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2])
+
+
 def test_dense_matches_sparse_path(lib):
     """The same matrix through the CSR kernels and through the MFMA kernels."""
     import scipy.sparse as sp
