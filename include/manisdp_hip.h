@@ -51,6 +51,7 @@ typedef struct msdp_handle_s* msdp_handle;
 #define MSDP_KIND_UNITTRACE    3   /* src/primal/ManiSDP_unittrace.m    */
 #define MSDP_KIND_GENERIC      4   /* src/primal/ManiSDP.m (Euclidean manifold) */
 #define MSDP_KIND_MULTIBLOCK   5   /* src/primal/ManiSDP_multiblock.m (product manifold) */
+#define MSDP_KIND_DUAL_UNITDIAG 6  /* src/dual/ManiDSDP_unitdiag.m (dual approach, diag(S) = 1) */
 
 /* Options of one Riemannian trust-region solve: the fields ManiSDP sets
  * (ManiSDP_unitdiag.m:44-47) plus Manopt's defaults that are in force
@@ -141,6 +142,25 @@ int msdp_create_affine(int32_t kind, int64_t n, int64_t m,
 int msdp_create_multiblock(int32_t nb, const int64_t* block_n, int32_t nob, int64_t m,
                            const int64_t* at_jc, const int64_t* at_ir, const double* at_pr,
                            const double* b, const double* c, int32_t pcap, msdp_handle* out);
+
+/* Dual approach with a unit-diagonal dual slack (src/dual/ManiDSDP_unitdiag.m:8-220):
+ *     sup <C,X> + <cf,w>   s.t.  A(X) + B(w) = b,  X psd,  the variable of the Riemannian subproblem is S = Y'Y with
+ * diag(S) = 1 (obliquefactoryNTrans, :196-219), the multipliers are x = vec(X) and w.  Closures replaced:
+ * cost :174-181, grad :183-187, hess :189-194, co/line_search :155-172; outer-step bookkeeping :70-85.
+ * at_* is A' (n^2 x m CSC: column k = vec of the k-th row of the PSD part A(:, K.f+1:end)), dAAt = diag(A*A') (:37,
+ * options.dAAt), c the PSD part of the cost (dense n^2), B = A(:, 1:K.f) as m x nf CSC (nf may be 0), cf its costs. */
+int msdp_create_dual_unitdiag(int64_t n, int64_t m, const int64_t* at_jc, const int64_t* at_ir, const double* at_pr,
+                              const double* dAAt, const double* b, const double* c, int32_t nf, const int64_t* b_jc,
+                              const int64_t* b_ir, const double* b_pr, const double* cf, int32_t pcap, msdp_handle* out);
+/* sigma and the free multipliers w (nf values) for the following trustregions() calls (the matrix multiplier x lives on
+ * the device and starts at 0, :48).  Must be called before the first solve and after every msdp_dual_outer_step. */
+int msdp_dual_set_penalty(msdp_handle h, double sigma, const double* w);
+/* Outer step :70-81 at the resident point with the current sigma: y = iA'*(S(:) - c); As = A'y - sc; x -= sigma*As on the
+ * device; eX = x + bA; z = sum(S.*eX); X = eX - diag(z) stays on the device for msdp_escape_eigs_dual /
+ * msdp_get_dual_slack.  scal[0] = b'y, scal[1] = <C, eX>, scal[2] = |As|^2; Af[nf] = B'y - cf; z[n]. */
+int msdp_dual_outer_step(msdp_handle h, double* scal, double* Af, double* z);
+/* y of the last msdp_dual_outer_step (m values; data.y, :134) */
+int msdp_dual_get_y(msdp_handle h, double* y);
 
 int msdp_destroy(msdp_handle h);
 

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmanisdp_hip.so")
 
-KIND_ONLYUNITDIAG, KIND_UNITDIAG, KIND_UNITTRACE, KIND_GENERIC, KIND_MULTIBLOCK = 1, 2, 3, 4, 5
+KIND_ONLYUNITDIAG, KIND_UNITDIAG, KIND_UNITTRACE, KIND_GENERIC, KIND_MULTIBLOCK, KIND_DUAL_UNITDIAG = 1, 2, 3, 4, 5, 6
 
 
 class RtrOpts(C.Structure):
@@ -82,6 +82,11 @@ SIGNATURES = {
     "msdp_escape_info": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _dp]),
     "msdp_escape_lower_bound": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_dual_slack": (C.c_int, [C.c_void_p, _dp]),
+    "msdp_create_dual_unitdiag": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, _dp, C.c_int32, _i64p, _i64p, _dp,
+                                            _dp, C.c_int32, C.POINTER(C.c_void_p)]),
+    "msdp_dual_set_penalty": (C.c_int, [C.c_void_p, C.c_double, _dp]),
+    "msdp_dual_outer_step": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "msdp_dual_get_y": (C.c_int, [C.c_void_p, _dp]),
     "msdp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "msdp_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "msdp_local_rows": (C.c_int, [C.c_void_p, _i64p, _i64p]),
@@ -227,6 +232,57 @@ class Handle:
         _check(lib.msdp_create_multiblock(len(bn), bn.ctypes.data_as(_i64p), int(nob), Atc.shape[1], jc.ctypes.data_as(_i64p),
                                           ir.ctypes.data_as(_i64p), _dptr(pr), _dptr(b), _dptr(c), pcap, C.byref(out)))
         return cls(out.value, KIND_MULTIBLOCK, int(bn.sum()))
+
+    @classmethod
+    def dual_unitdiag(cls, A, b, c, dAAt, B=None, cf=None, pcap=32):
+        """Dual approach, diag(S) = 1 (ManiDSDP_unitdiag.m).  ``A`` is the m x n^2 PSD part (rows = vec(A_k)), ``c`` its
+        cost (n^2), ``B`` the m x nf free part with costs ``cf``, ``dAAt = diag(A A')``.  The factor of S is (n, p)."""
+        import scipy.sparse as sp
+        lib = load()
+        out = C.c_void_p()
+        Atc = sp.csc_matrix(sp.csr_matrix(A).T)
+        Atc.sort_indices()
+        n = int(round(np.sqrt(Atc.shape[0])))
+        jc = np.ascontiguousarray(Atc.indptr, dtype=np.int64)
+        ir = np.ascontiguousarray(Atc.indices, dtype=np.int64)
+        pr = np.ascontiguousarray(Atc.data, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        d = np.ascontiguousarray(dAAt, dtype=np.float64)
+        nf = 0 if B is None else int(B.shape[1])
+        if nf:
+            Bc = sp.csc_matrix(B)
+            Bc.sort_indices()
+            bjc = np.ascontiguousarray(Bc.indptr, dtype=np.int64)
+            bir = np.ascontiguousarray(Bc.indices, dtype=np.int64)
+            bpr = np.ascontiguousarray(Bc.data, dtype=np.float64)
+            cfv = np.ascontiguousarray(cf, dtype=np.float64)
+            args = (bjc.ctypes.data_as(_i64p), bir.ctypes.data_as(_i64p), _dptr(bpr), _dptr(cfv))
+        else:
+            args = (None, None, None, None)
+        _check(lib.msdp_create_dual_unitdiag(n, Atc.shape[1], jc.ctypes.data_as(_i64p), ir.ctypes.data_as(_i64p), _dptr(pr), _dptr(d),
+                                             _dptr(b), _dptr(c), nf, *args, pcap, C.byref(out)))
+        hd = cls(out.value, KIND_DUAL_UNITDIAG, n)
+        hd.m = Atc.shape[1]
+        hd.nf = nf
+        return hd
+
+    def dual_set_penalty(self, sigma, w=None):
+        w = np.ascontiguousarray(w if w is not None else np.zeros(max(self.nf, 1)), dtype=np.float64)
+        _check(self._lib.msdp_dual_set_penalty(self._h, float(sigma), _dptr(w)))
+
+    def dual_outer_step(self):
+        """Outer step of ManiDSDP_unitdiag.m:70-81 on the device: returns (b'y, <C,eX>, |As|^2, Af, z)."""
+        scal = np.zeros(3)
+        Af = np.zeros(max(self.nf, 1))
+        z = np.zeros(self.n)
+        _check(self._lib.msdp_dual_outer_step(self._h, _dptr(scal), _dptr(Af), _dptr(z)))
+        return float(scal[0]), float(scal[1]), float(scal[2]), Af[:self.nf], z
+
+    def dual_get_y(self):
+        y = np.zeros(self.m)
+        _check(self._lib.msdp_dual_get_y(self._h, _dptr(y)))
+        return y
 
     def close(self):
         if self._h is not None and self._h.value:

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_rowdot_slabs(Dev d, const double
 
 // unitdiag gradient finish: eG (n x ld, = 2*eS*Y) in Gr, YeG rows known -> G = eG - Y.*YeG, |G|^2; and f.
 template <int LPR, int NCH>
-__global__ __launch_bounds__(MSDP_BLOCK) void k_obl_grad_finish(Dev d, int slot, double sigma) {
+__global__ __launch_bounds__(MSDP_BLOCK) void k_obl_grad_finish(Dev d, int slot, double sigma, const double* f_given) {
     __shared__ double sh[3 * MSDP_WAVES + 8];
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi);
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_obl_grad_finish(Dev d, int slot,
     const double ss = msdp_sum_partials_block(d.P, P_AXB, MSDP_MAX_GRID, sh);
     __syncthreads();
     double pf = 0.0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) pf = cx + 0.5 * sigma * ss;
+    if (blockIdx.x == 0 && threadIdx.x == 0) pf = f_given ? *f_given : cx + 0.5 * sigma * ss;   // f_given: the dual kind's cost
     msdp_put_partials3(d.P, P_F, pf, P_GG, pgg, -1, 0.0, sh + 8);
 }
 
@@ -679,7 +679,9 @@ struct AffineState {
     double sigma = 1.0;
     double* Cdense = nullptr;      // n x nS
     double* d_y = nullptr;
+    struct DualState* dual = nullptr;   // MSDP_KIND_DUAL_UNITDIAG (below)
 };
+static void msdp_dual_release(struct DualState* ds);
 static std::vector<std::pair<msdp_handle, AffineState*>> g_aff;
 static AffineState* astate(msdp_handle h) {
     for (auto& pr : g_aff) if (pr.first == h) return pr.second;
@@ -687,7 +689,7 @@ static AffineState* astate(msdp_handle h) {
 }
 void msdp_affine_release(msdp_handle h) {
     for (size_t i = 0; i < g_aff.size(); ++i)
-        if (g_aff[i].first == h) { delete g_aff[i].second; g_aff.erase(g_aff.begin() + i); return; }
+        if (g_aff[i].first == h) { msdp_dual_release(g_aff[i].second->dual); delete g_aff[i].second; g_aff.erase(g_aff.begin() + i); return; }
 }
 
 template <typename T>
@@ -1040,9 +1042,14 @@ static int launch_support_spmm(msdp_handle h, const AffineDev& a, const double* 
 
 
 // cost + gradient state at Y[slot]:  w = A(YY'), Axb, eS, eS*Y, C*Y  (see header comment)
+static int dual_costgrad(msdp_handle h, AffineState* st, int slot);
+static int dual_hess(msdp_handle h, AffineState* st);
+static int dual_linesearch_cost(msdp_handle h, AffineState* st, const double* Yt, double* val);
+
 int msdp_affine_costgrad(msdp_handle h, int slot) {
     AffineState* st = astate(h);
     if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
+    if (st->dual) return dual_costgrad(h, st, slot);
     Dev& d = h->d;
     AffineDev a = st->a;
     a.p = d.p; a.ld = d.ld;
@@ -1078,7 +1085,7 @@ int msdp_affine_costgrad(msdp_handle h, int slot) {
         HIPCHK(hipGetLastError());
     }
     if (d.manifold == MANI_OBLIQUE) {
-        DISPATCH_LPR_A(k_obl_grad_finish, h, d.G, d, slot, sigma);
+        DISPATCH_LPR_A(k_obl_grad_finish, h, d.G, d, slot, sigma, (const double*)nullptr);
     } else {
         hipLaunchKernelGGL(k_sph_grad_finish, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, d, slot, sigma);
     }
@@ -1089,6 +1096,7 @@ int msdp_affine_costgrad(msdp_handle h, int slot) {
 int msdp_affine_hess(msdp_handle h) {
     AffineState* st = astate(h);
     if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
+    if (st->dual) return dual_hess(h, st);
     Dev& d = h->d;
     AffineDev a = st->a;
     a.p = d.p; a.ld = d.ld;
@@ -1153,6 +1161,7 @@ int msdp_sphere_hess_raw(msdp_handle h, const double* slab, int64_t stride, int 
 int msdp_affine_linesearch_cost(msdp_handle h, const double* Yt, double* val) {
     AffineState* st = astate(h);
     if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
+    if (st->dual) return dual_linesearch_cost(h, st, Yt, val);
     Dev& d = h->d;
     AffineDev a = st->a;
     a.p = d.p; a.ld = d.ld;
@@ -1243,6 +1252,413 @@ int msdp_affine_al_dual(msdp_handle h, const double* y_host, double* z_host) {
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(z_host, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+
+// ================================================================== dual, unit diagonal
+// src/dual/ManiDSDP_unitdiag.m: the variable is the dual slack S = Y'Y with diag(S) = 1 (oblique factor, as in the
+// primal unit-diagonal entry point); the multipliers are the primal matrix x (n^2, dense) and the free part w.
+//   cost  :174-181   S = Y'Y; sc = S(:) - c; y = iA'*sc; As = A'y - sc - x/sigma; Af = B'y - cf - w/sigma;
+//                    f = b'y + sigma/2 (|As|^2 + |Af|^2)
+//   grad  :183-187   X = reshape(bA - sigma*As); eG = 2*Y*X; G = eG - Y.*sum(Y.*eG)
+//   hess  :189-194   yAU = reshape(A'(iA'*vec(Y'U))); eH = 2*U*X - 4*sigma*(Y*yAU) + 2*sigma*((Y*U')*Y + (Y*Y')*U)
+// with iA = (diag(A*A')\A)' (:38) and bA = iA*b (:39).  The rows of A are the columns of this handle's At, so
+// iA'*vec(M) is the primal kind's A(M) divided by dAAt, and A'y its adjoint: launch_A / launch_adjoint and the MFMA
+// contraction are reused as they are.  With T = bA + x - sigma*C (rebuilt when the multipliers change):
+//   X = T + sigma*S - sigma*A'y,      sigma*As = bA - X.
+// New here: the dense Gram S = Y*Y' (k_gram_mfma, one product), the two p x p Gram matrices of the last Hessian
+// term, and the element-wise kernels.
+struct DualState {
+    int nf = 0;                     // free variables (K.f)
+    const double* dinv = nullptr;   // 1 ./ dAAt                         (m)
+    const double* Ac = nullptr;     // A*c                                (m)
+    const int* bjc = nullptr;       // B in CSC (m x nf)
+    const int* bir = nullptr;
+    const double* bpr = nullptr;
+    const double* cf = nullptr;     // nf
+    double* wf = nullptr;           // free multipliers w                 (nf)
+    double* Af = nullptr;           // Af of the last cost evaluation     (nf)
+    double* x = nullptr;            // multiplier matrix x                (n x nS)
+    double* bA = nullptr;           // reshape(iA*b)                      (n x nS)
+    double* T = nullptr;            // bA + x - sigma*C                   (n x nS)
+    double* Sg = nullptr;           // S = Y*Y'                           (n x nS)
+    double* G2[2] = {nullptr, nullptr};   // Y'*Y per slot                (ld x ld)
+    double* M1 = nullptr;           // U'*Y of the current Hess-vec       (ld x ld)
+    double* pp_part = nullptr;      // DUAL_PP_BLOCKS x ld x ld partials
+    double* scal = nullptr;         // [0] f, [1] b'y, [2] <C,eX>, [3] |As|^2
+    bool T_valid = false;
+};
+static void msdp_dual_release(DualState* ds) { delete ds; }
+#define DUAL_PP_BLOCKS 64
+#define DUAL_PP_MAXLD 128
+
+// y = (A(S) - A c) ./ dAAt in place, partial sums of b'y -> P_S1   (grid d.G)
+__global__ __launch_bounds__(MSDP_BLOCK) void k_dual_y(int64_t m, double* __restrict__ w, const double* __restrict__ dinv,
+                                                       const double* __restrict__ Ac, const double* __restrict__ b, double* P,
+                                                       const int* skip_flag, int skip_when) {
+    __shared__ double sh[3 * MSDP_WAVES];
+    if (skip_flag && *skip_flag == skip_when) return;
+    double pb = 0.0;
+    for (int64_t k = blockIdx.x * (int64_t)MSDP_BLOCK + threadIdx.x; k < m; k += (int64_t)gridDim.x * MSDP_BLOCK) {
+        const double y = (w[k] - Ac[k]) * dinv[k];
+        w[k] = y;
+        pb = fma(b[k], y, pb);
+    }
+    msdp_put_partial(P, P_S1, pb, sh);
+}
+// w .*= dinv (Hess-vec: iA'*vec(Y'U))
+__global__ void k_dual_scale(int64_t m, double* __restrict__ w, const double* __restrict__ dinv, const int* skip_flag, int skip_when) {
+    if (skip_flag && *skip_flag == skip_when) return;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < m; k += (int64_t)gridDim.x * blockDim.x) w[k] *= dinv[k];
+}
+// Af_j = B(:,j)'y - cf_j - (wf ? wf_j / sigma : 0): one workgroup per free variable
+__global__ __launch_bounds__(256) void k_dual_free(const int* __restrict__ bjc, const int* __restrict__ bir, const double* __restrict__ bpr,
+                                                   const double* __restrict__ y, const double* __restrict__ cf, const double* wf,
+                                                   double sigma, double* __restrict__ Af, const int* skip_flag, int skip_when) {
+    __shared__ double sh[MSDP_WAVES];
+    if (skip_flag && *skip_flag == skip_when) return;
+    const int j = blockIdx.x;
+    double v = 0.0;
+    for (int t = bjc[j] + threadIdx.x; t < bjc[j + 1]; t += blockDim.x) v = fma(bpr[t], y[bir[t]], v);
+    v = msdp_block_sum(v, sh);
+    if (threadIdx.x == 0) Af[j] = v - cf[j] - (wf ? wf[j] / sigma : 0.0);
+}
+// X += sigma*S, and the partial sums of |bA - X|^2 (= sigma^2 |As|^2) -> P_AXB   (MSDP_MAX_GRID workgroups)
+__global__ __launch_bounds__(256) void k_dual_finish_X(int64_t tot, double* __restrict__ X, const double* __restrict__ S,
+                                                       const double* __restrict__ bA, double sigma, double* P,
+                                                       const int* skip_flag, int skip_when) {
+    __shared__ double sh[3 * MSDP_WAVES];
+    if (skip_flag && *skip_flag == skip_when) return;
+    double ps = 0.0;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+        const double xv = fma(sigma, S[e], X[e]);
+        X[e] = xv;
+        const double r = bA[e] - xv;
+        ps = fma(r, r, ps);
+    }
+    msdp_put_partial(P, P_AXB, ps, sh);
+}
+// f = b'y + |bA - X|^2 / (2 sigma) + sigma/2 |Af|^2   (one workgroup)
+__global__ __launch_bounds__(MSDP_BLOCK) void k_dual_cost(Dev d, double sigma, const double* __restrict__ Af, int nf, double* out,
+                                                          const int* skip_flag, int skip_when) {
+    __shared__ double sh[8];
+    if (skip_flag && *skip_flag == skip_when) return;
+    const double by = msdp_sum_partials_block(d.P, P_S1, d.G, sh);
+    __syncthreads();
+    const double ss = msdp_sum_partials_block(d.P, P_AXB, MSDP_MAX_GRID, sh);
+    if (threadIdx.x == 0) {
+        double af = 0.0;
+        for (int j = 0; j < nf; ++j) af = fma(Af[j], Af[j], af);
+        out[0] = by + 0.5 * ss / sigma + 0.5 * sigma * af;
+        out[1] = by;
+    }
+}
+// T = bA + x - sigma*C
+__global__ void k_dual_T(int64_t tot, double* __restrict__ T, const double* __restrict__ bA, const double* __restrict__ x,
+                         const double* __restrict__ C, double sigma) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x)
+        T[e] = bA[e] + x[e] - sigma * C[e];
+}
+// P = Xa' * Xb (ld x ld) from two n x ld panels: per-workgroup partials over a row range, then their sum
+__global__ __launch_bounds__(256) void k_pp_gram_part(int n, int ld, const double* __restrict__ Xa, const double* __restrict__ Xb,
+                                                      double* __restrict__ part, const int* skip_flag, int skip_when) {
+    if (skip_flag && *skip_flag == skip_when) return;
+    const int rows = (n + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows, r1 = min(n, r0 + rows);
+    for (int e = threadIdx.x; e < ld * ld; e += blockDim.x) {
+        const int a = e / ld, b = e - a * ld;
+        double acc = 0.0;
+        for (int k = r0; k < r1; ++k) acc = fma(Xa[(int64_t)k * ld + a], Xb[(int64_t)k * ld + b], acc);
+        part[(int64_t)blockIdx.x * ld * ld + e] = acc;
+    }
+}
+__global__ void k_pp_gram_sum(int ld, int nblk, const double* __restrict__ part, double* __restrict__ out, const int* skip_flag, int skip_when) {
+    if (skip_flag && *skip_flag == skip_when) return;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ld * ld; e += gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int q = 0; q < nblk; ++q) acc += part[(int64_t)q * ld * ld + e];
+        out[e] = acc;
+    }
+}
+// out(i,:) = coef * (Y(i,:)*M1 + U(i,:)*G2): the 2*sigma*((Y*U')*Y + (Y*Y')*U) term of :192, one more split-K slab
+__global__ void k_pp_apply(int n_loc, int ld, const double* __restrict__ Y, const double* __restrict__ U, const double* __restrict__ M1,
+                           const double* __restrict__ G2, double coef, double* __restrict__ out, const int* skip_flag, int skip_when) {
+    if (skip_flag && *skip_flag == skip_when) return;
+    const int64_t tot = (int64_t)n_loc * ld;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / ld; const int c = (int)(e - i * ld);
+        double acc = 0.0;
+        for (int a = 0; a < ld; ++a) acc = fma(Y[i * ld + a], M1[a * ld + c], fma(U[i * ld + a], G2[a * ld + c], acc));
+        out[e] = coef * acc;
+    }
+}
+// Outer step :73-81 on the rows of a workgroup: As = (C + A'y) - S (in Xd), x -= sigma*As, eX = x + bA,
+// z_i = sum_j S_ij eX_ij, Xd = eX - diag(z); partial sums of <C, eX> -> P_S2 and |As|^2 -> P_S3   (grid d.G)
+__global__ __launch_bounds__(MSDP_BLOCK) void k_dual_outer(Dev d, int nS, double* __restrict__ Xd, const double* __restrict__ S,
+                                                           double* __restrict__ x, const double* __restrict__ bA,
+                                                           const double* __restrict__ C, double sigma, double* __restrict__ z) {
+    __shared__ double sh[3 * MSDP_WAVES];
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double pc = 0.0, pa = 0.0;
+    for (int row = lo + wave; row < hi; row += MSDP_WAVES) {
+        const int64_t o = (int64_t)row * nS;
+        double zr = 0.0, exd = 0.0;
+        for (int j = lane; j < d.n; j += 64) {
+            const double as = Xd[o + j] - S[o + j];
+            const double xn = x[o + j] - sigma * as;
+            const double ex = xn + bA[o + j];
+            x[o + j] = xn;
+            Xd[o + j] = ex;
+            zr = fma(S[o + j], ex, zr);
+            pc = fma(C[o + j], ex, pc);
+            pa = fma(as, as, pa);
+            if (j == row) exd = ex;
+        }
+        zr = msdp_wave_sum(zr);
+        if (lane == (row & 63)) { Xd[o + row] = exd - zr; z[row] = zr; }
+    }
+    msdp_put_partials3(d.P, P_S2, pc, P_S3, pa, -1, 0.0, sh);
+}
+
+static int dual_pp_gram(msdp_handle h, DualState* ds, const double* Xa, const double* Xb, double* out, const int* flag, int when) {
+    const Dev& d = h->d;
+    hipLaunchKernelGGL(k_pp_gram_part, dim3(DUAL_PP_BLOCKS), dim3(256), 0, h->stream, d.n, d.ld, Xa, Xb, ds->pp_part, flag, when);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_pp_gram_sum, dim3((d.ld * d.ld + 255) / 256), dim3(256), 0, h->stream, d.ld, DUAL_PP_BLOCKS,
+                       (const double*)ds->pp_part, out, flag, when);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int dual_check(msdp_handle h, DualState* ds) {
+    if (h->d.ld > DUAL_PP_MAXLD) { msdp_set_error("dual kind: factor width p = %d exceeds the supported maximum of %d", h->d.p, DUAL_PP_MAXLD); return MSDP_EUNSUPPORTED; }
+    if (!ds->T_valid) { msdp_set_error("dual kind: call msdp_dual_set_penalty after msdp_dual_outer_step"); return MSDP_ESTATE; }
+    return 0;
+}
+// steps shared by cost/grad and the line-search cost: y, Af, S, X = T + sigma*S - sigma*A'y into Xout, f -> scal[0]
+static int dual_cost_state(msdp_handle h, AffineState* st, const double* Ys, double* Xout, const int* flag, int when) {
+    DualState* ds = st->dual;
+    Dev& d = h->d;
+    AffineDev a = st->a;
+    a.p = d.p; a.ld = d.ld;
+    const double sigma = st->sigma;
+    int rc;
+    if ((rc = launch_A(h, a, st->nnz, Ys, Ys, flag, when, 0, (double*)nullptr, sigma))) return rc;
+    hipLaunchKernelGGL(k_dual_y, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, a.m, a.w, ds->dinv, ds->Ac, a.b, d.P, flag, when);
+    HIPCHK(hipGetLastError());
+    if (ds->nf > 0) {
+        hipLaunchKernelGGL(k_dual_free, dim3(ds->nf), dim3(256), 0, h->stream, ds->bjc, ds->bir, ds->bpr, (const double*)a.w, ds->cf,
+                           (const double*)ds->wf, sigma, ds->Af, flag, when);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_gram_mfma, dim3((a.nS + 63) / 64, (a.n + 63) / 64), dim3(512), 0, h->stream, a.n, a.nS, a.ld, Ys, Ys, ds->Sg, flag, when, 0);
+    HIPCHK(hipGetLastError());
+    if ((rc = launch_adjoint(h, a, (const double*)ds->T, (const double*)a.w, -sigma, Xout, flag, when, false))) return rc;
+    hipLaunchKernelGGL(k_dual_finish_X, dim3(MSDP_MAX_GRID), dim3(256), 0, h->stream, (int64_t)a.n * a.nS, Xout, (const double*)ds->Sg,
+                       (const double*)ds->bA, sigma, d.P, flag, when);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_dual_cost, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, d, sigma, (const double*)ds->Af, ds->nf, ds->scal, flag, when);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int dual_costgrad(msdp_handle h, AffineState* st, int slot) {
+    DualState* ds = st->dual;
+    Dev& d = h->d;
+    int rc;
+    if ((rc = dual_check(h, ds))) return rc;
+    const double* Ys = d.Y[slot];
+    const int* done = &d.ctl->done;
+    if ((rc = dual_cost_state(h, st, Ys, d.eS[slot], done, 1))) return rc;
+    // eG = 2*X*Y -> Gr[slot], row dots YeG
+    const double* slab; int64_t stride; int SK;
+    const double* M[1] = {d.eS[slot]}; const double* X[1] = {Ys}; const double sc[1] = {1.0};
+    if ((rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK))) return rc;
+    DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 2.0, d.Gr[slot], d.eG[slot], P_S2);
+    HIPCHK(hipGetLastError());
+    DISPATCH_LPR_A(k_obl_grad_finish, h, d.G, d, slot, st->sigma, (const double*)ds->scal);
+    HIPCHK(hipGetLastError());
+    return dual_pp_gram(h, ds, Ys, Ys, ds->G2[slot], done, 1);
+}
+
+static int dual_hess(msdp_handle h, AffineState* st) {
+    DualState* ds = st->dual;
+    Dev& d = h->d;
+    AffineDev a = st->a;
+    a.p = d.p; a.ld = d.ld;
+    const double sigma = st->sigma;
+    const int cur = h->h_ctl->cur;
+    const int* act = &d.F[0].active;
+    int rc;
+    if ((rc = dual_check(h, ds))) return rc;
+    if ((rc = launch_A(h, a, st->nnz, d.Y[cur], d.md, act, 0, 0, (double*)nullptr, sigma))) return rc;
+    { int64_t g = (a.m + 255) / 256; if (g > 2048) g = 2048;
+      hipLaunchKernelGGL(k_dual_scale, dim3((int)g), dim3(256), 0, h->stream, a.m, a.w, ds->dinv, act, 0); }
+    HIPCHK(hipGetLastError());
+    if ((rc = launch_adjoint(h, a, (const double*)nullptr, (const double*)a.w, 1.0, d.AyU, act, 0, false))) return rc;
+    const double* slab; int64_t stride; int SK;
+    const double* M[2] = {d.eS[cur], d.AyU};
+    const double* X[2] = {d.md, d.Y[cur]};
+    const double sc[2] = {2.0, -4.0 * sigma};
+    if ((rc = msdp_dense_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
+    if ((rc = dual_pp_gram(h, ds, d.md, d.Y[cur], ds->M1, act, 0))) return rc;
+    double* extra = const_cast<double*>(slab) + (int64_t)SK * stride;
+    { int64_t g = ((int64_t)d.n_loc * d.ld + 255) / 256; if (g > 4096) g = 4096;
+      hipLaunchKernelGGL(k_pp_apply, dim3((int)g), dim3(256), 0, h->stream, d.n_loc, d.ld, (const double*)d.Y[cur], (const double*)d.md,
+                         (const double*)ds->M1, (const double*)ds->G2[cur], 2.0 * sigma, extra, act, 0); }
+    HIPCHK(hipGetLastError());
+    ++SK;
+    return msdp_dense_hess_epilogue_obl(h, slab, stride, SK);
+}
+
+// co(Y) of :155-162 at the trial point Yt
+static int dual_linesearch_cost(msdp_handle h, AffineState* st, const double* Yt, double* val) {
+    DualState* ds = st->dual;
+    Dev& d = h->d;
+    int rc;
+    if ((rc = dual_check(h, ds))) return rc;
+    const int other = h->h_ctl->cur ^ 1;
+    if ((rc = dual_cost_state(h, st, Yt, d.eS[other], (const int*)nullptr, 0))) return rc;
+    double v = 0.0;
+    HIPCHK(hipMemcpyAsync(&v, ds->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *val = v;
+    return 0;
+}
+
+// Second half of msdp_create_dual_unitdiag: msdp_affine_setup has uploaded At (= A'), b and C = reshape(c).
+int msdp_dual_setup(msdp_handle h, const int64_t* at_jc, const int64_t* at_ir, const double* at_pr, const double* b, const double* c,
+                    const double* dAAt, int32_t nf, const int64_t* b_jc, const int64_t* b_ir, const double* b_pr, const double* cf) {
+    AffineState* st = astate(h);
+    if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
+    Dev& d = h->d;
+    const int n = d.n, nS = st->a.nS;
+    const int64_t m = st->a.m;
+    DualState* ds = new DualState();
+    st->dual = ds;
+    ds->nf = nf;
+    std::vector<double> dinv((size_t)m), Ac((size_t)m, 0.0), bA((size_t)n * nS, 0.0);
+    for (int64_t k = 0; k < m; ++k) {
+        if (!(dAAt[k] > 0.0)) { msdp_set_error("dual kind: dAAt(%lld) = %g is not positive", (long long)k, dAAt[k]); return MSDP_EINVAL; }
+        dinv[(size_t)k] = 1.0 / dAAt[k];
+        double acc = 0.0;
+        const double bk = b[k] * dinv[(size_t)k];
+        for (int64_t t = at_jc[k]; t < at_jc[k + 1]; ++t) {
+            const int64_t r = at_ir[t];                    // column-major vec index i + j*n -> row-major (i, j)
+            acc += at_pr[t] * c[r];
+            bA[(size_t)((r % n) * nS + r / n)] += at_pr[t] * bk;       // bA = iA*b (:39)
+        }
+        Ac[(size_t)k] = acc;
+    }
+    int rc;
+    if ((rc = up(h, dinv, &ds->dinv)) || (rc = up(h, Ac, &ds->Ac))) return rc;
+    std::vector<int> bjc((size_t)nf + 1, 0), bir;
+    std::vector<double> bpr, cfv((size_t)std::max(nf, 1), 0.0);
+    for (int j = 0; j < nf; ++j) {
+        for (int64_t t = b_jc[j]; t < b_jc[j + 1]; ++t) {
+            if (b_ir[t] < 0 || b_ir[t] >= m) { msdp_set_error("dual kind: row index of B out of range"); return MSDP_EINVAL; }
+            bir.push_back((int)b_ir[t]); bpr.push_back(b_pr[t]);
+        }
+        bjc[(size_t)j + 1] = (int)bir.size();
+        cfv[(size_t)j] = cf[j];
+    }
+    if (bir.empty()) { bir.push_back(0); bpr.push_back(0.0); }
+    if ((rc = up(h, bjc, &ds->bjc)) || (rc = up(h, bir, &ds->bir)) || (rc = up(h, bpr, &ds->bpr)) || (rc = up(h, cfv, &ds->cf))) return rc;
+    const size_t msz = (size_t)n * nS * sizeof(double);
+    void* p = nullptr;
+    double** mats[4] = {&ds->x, &ds->bA, &ds->T, &ds->Sg};
+    for (int q = 0; q < 4; ++q) {
+        if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
+        *mats[q] = (double*)p;
+        HIPCHK(hipMemset(p, 0, msz));
+    }
+    HIPCHK(hipMemcpy(ds->bA, bA.data(), msz, hipMemcpyHostToDevice));
+    const size_t ppsz = (size_t)DUAL_PP_MAXLD * DUAL_PP_MAXLD * sizeof(double);
+    double** pps[3] = {&ds->G2[0], &ds->G2[1], &ds->M1};
+    for (int q = 0; q < 3; ++q) {
+        if ((rc = msdp_dev_alloc_bytes(h, &p, ppsz))) return rc;
+        *pps[q] = (double*)p;
+        HIPCHK(hipMemset(p, 0, ppsz));
+    }
+    if ((rc = msdp_dev_alloc_bytes(h, &p, ppsz * DUAL_PP_BLOCKS))) return rc;
+    ds->pp_part = (double*)p;
+    const size_t nfb = (size_t)std::max(nf, 1) * sizeof(double);
+    if ((rc = msdp_dev_alloc_bytes(h, &p, nfb))) return rc;
+    ds->wf = (double*)p; HIPCHK(hipMemset(p, 0, nfb));
+    if ((rc = msdp_dev_alloc_bytes(h, &p, nfb))) return rc;
+    ds->Af = (double*)p; HIPCHK(hipMemset(p, 0, nfb));
+    if ((rc = msdp_dev_alloc_bytes(h, &p, 8 * sizeof(double)))) return rc;
+    ds->scal = (double*)p; HIPCHK(hipMemset(p, 0, 8 * sizeof(double)));
+    // the adjoint of the dual kind always sweeps the whole matrix (X and As are dense)
+    return 0;
+}
+
+// sigma and the free multipliers w for the next trustregions() call; T = bA + x - sigma*C
+int msdp_dual_set_penalty_impl(msdp_handle h, double sigma, const double* wf_host) {
+    AffineState* st = astate(h);
+    if (!st || !st->dual) { msdp_set_error("dual_set_penalty: not a dual handle"); return MSDP_ESTATE; }
+    if (!(sigma > 0)) { msdp_set_error("sigma must be positive"); return MSDP_EINVAL; }
+    DualState* ds = st->dual;
+    if (ds->nf > 0) {
+        if (!wf_host) { msdp_set_error("dual_set_penalty: w is null"); return MSDP_EINVAL; }
+        HIPCHK(hipMemcpyAsync(ds->wf, wf_host, (size_t)ds->nf * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    st->sigma = sigma;
+    h->h_ctl->sigma = sigma;
+    const int64_t tot = (int64_t)st->a.n * st->a.nS;
+    hipLaunchKernelGGL(k_dual_T, dim3(2048), dim3(256), 0, h->stream, tot, ds->T, (const double*)ds->bA, (const double*)ds->x,
+                       (const double*)h->d.Cd, sigma);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    ds->T_valid = true;
+    return 0;
+}
+
+// :70-81 at the resident point: scal = {b'y, <C, eX>, |As|^2}, Af = B'y - cf (nf), z (n); x is updated on the device,
+// X = eX - diag(z) is left in d.Sdual for msdp_escape_eigs_dual / msdp_get_dual_slack, y in a.w for msdp_dual_get_y.
+int msdp_dual_outer_step_impl(msdp_handle h, double* scal_host, double* Af_host, double* z_host) {
+    AffineState* st = astate(h);
+    if (!st || !st->dual) { msdp_set_error("dual_outer_step: not a dual handle"); return MSDP_ESTATE; }
+    DualState* ds = st->dual;
+    Dev& d = h->d;
+    AffineDev a = st->a;
+    a.p = d.p; a.ld = d.ld;
+    const double sigma = st->sigma;
+    const double* Ys = d.Y[h->h_ctl->cur];
+    int rc;
+    if ((rc = launch_A(h, a, st->nnz, Ys, Ys, (const int*)nullptr, 0, 0, (double*)nullptr, sigma))) return rc;
+    hipLaunchKernelGGL(k_dual_y, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, a.m, a.w, ds->dinv, ds->Ac, a.b, d.P, (const int*)nullptr, 0);
+    HIPCHK(hipGetLastError());
+    if ((rc = msdp_k_sum_to_fwd(h, P_S1, ds->scal + 1))) return rc;
+    if (ds->nf > 0) {
+        hipLaunchKernelGGL(k_dual_free, dim3(ds->nf), dim3(256), 0, h->stream, ds->bjc, ds->bir, ds->bpr, (const double*)a.w, ds->cf,
+                           (const double*)nullptr, sigma, ds->Af, (const int*)nullptr, 0);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_gram_mfma, dim3((a.nS + 63) / 64, (a.n + 63) / 64), dim3(512), 0, h->stream, a.n, a.nS, a.ld, Ys, Ys, ds->Sg,
+                       (const int*)nullptr, 0, 0);
+    HIPCHK(hipGetLastError());
+    // (d.Sdual may alias the Gram scratch a.W: launch_A has consumed it by now)
+    if ((rc = launch_adjoint(h, a, (const double*)d.Cd, (const double*)a.w, 1.0, d.Sdual, (const int*)nullptr, 0, false))) return rc;
+    hipLaunchKernelGGL(k_dual_outer, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, d, a.nS, d.Sdual, (const double*)ds->Sg, ds->x,
+                       (const double*)ds->bA, (const double*)d.Cd, sigma, d.W0);
+    HIPCHK(hipGetLastError());
+    if ((rc = msdp_k_sum_to_fwd(h, P_S2, ds->scal + 2)) || (rc = msdp_k_sum_to_fwd(h, P_S3, ds->scal + 3))) return rc;
+    HIPCHK(hipMemcpyAsync(scal_host, ds->scal + 1, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (ds->nf > 0) HIPCHK(hipMemcpyAsync(Af_host, ds->Af, (size_t)ds->nf * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(z_host, d.W0, (size_t)a.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    ds->T_valid = false;
+    return 0;
+}
+
+int msdp_dual_get_y_impl(msdp_handle h, double* y_host) {
+    AffineState* st = astate(h);
+    if (!st || !st->dual) { msdp_set_error("dual_get_y: not a dual handle"); return MSDP_ESTATE; }
+    HIPCHK(hipMemcpyAsync(y_host, st->a.w, (size_t)st->a.m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }

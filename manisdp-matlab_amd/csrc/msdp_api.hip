@@ -443,6 +443,51 @@ extern "C" int msdp_create_multiblock(int32_t nb, const int64_t* block_n, int32_
     return 0;
 }
 
+int msdp_dual_setup(msdp_handle h, const int64_t* at_jc, const int64_t* at_ir, const double* at_pr, const double* b, const double* c,
+                    const double* dAAt, int32_t nf, const int64_t* b_jc, const int64_t* b_ir, const double* b_pr, const double* cf);
+int msdp_dual_set_penalty_impl(msdp_handle h, double sigma, const double* wf_host);
+int msdp_dual_outer_step_impl(msdp_handle h, double* scal_host, double* Af_host, double* z_host);
+int msdp_dual_get_y_impl(msdp_handle h, double* y_host);
+
+extern "C" int msdp_create_dual_unitdiag(int64_t n, int64_t m, const int64_t* at_jc, const int64_t* at_ir, const double* at_pr,
+                                         const double* dAAt, const double* b, const double* c, int32_t nf, const int64_t* b_jc,
+                                         const int64_t* b_ir, const double* b_pr, const double* cf, int32_t pcap, msdp_handle* out) {
+    if (!at_jc || !at_ir || !at_pr || !dAAt || !b || !c || m <= 0) { msdp_set_error("dual_unitdiag: null/empty data"); return MSDP_EINVAL; }
+    if (nf < 0 || (nf > 0 && (!b_jc || !b_ir || !b_pr || !cf))) { msdp_set_error("dual_unitdiag: bad free part"); return MSDP_EINVAL; }
+    msdp_handle h = nullptr;
+    int rc = msdp_create_affine(MSDP_KIND_UNITDIAG, n, m, at_jc, at_ir, at_pr, b, c, pcap, &h);
+    if (rc) return rc;
+    h->kind = MSDP_KIND_DUAL_UNITDIAG;
+    if ((rc = msdp_dual_setup(h, at_jc, at_ir, at_pr, b, c, dAAt, nf, b_jc, b_ir, b_pr, cf))) { msdp_destroy(h); return rc; }
+    *out = h;
+    return 0;
+}
+
+extern "C" int msdp_dual_set_penalty(msdp_handle h, double sigma, const double* w) {
+    CHECK_H(h);
+    if (h->kind != MSDP_KIND_DUAL_UNITDIAG) { msdp_set_error("dual_set_penalty: not a dual handle"); return MSDP_ESTATE; }
+    h->state_valid = false;
+    h->gradnorm_valid = false;
+    return msdp_dual_set_penalty_impl(h, sigma, w);
+}
+
+extern "C" int msdp_dual_outer_step(msdp_handle h, double* scal, double* Af, double* z) {
+    CHECK_H(h);
+    if (h->kind != MSDP_KIND_DUAL_UNITDIAG) { msdp_set_error("dual_outer_step: not a dual handle"); return MSDP_ESTATE; }
+    if (!scal || !z) { msdp_set_error("dual_outer_step: null argument"); return MSDP_EINVAL; }
+    if (!h->have_point) { msdp_set_error("no resident point"); return MSDP_ESTATE; }
+    h->state_valid = false;
+    int rc = msdp_dual_outer_step_impl(h, scal, Af, z);
+    h->dual_valid = (rc == 0);
+    return rc;
+}
+
+extern "C" int msdp_dual_get_y(msdp_handle h, double* y) {
+    CHECK_H(h);
+    if (h->kind != MSDP_KIND_DUAL_UNITDIAG || !h->dual_valid || !y) { msdp_set_error("dual_get_y: call msdp_dual_outer_step first"); return MSDP_ESTATE; }
+    return msdp_dual_get_y_impl(h, y);
+}
+
 extern "C" int msdp_destroy(msdp_handle h) {
     if (!h) return 0;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -467,6 +512,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
 extern "C" int msdp_set_multipliers(msdp_handle h, const double* y, double sigma) {
     CHECK_H(h);
     if (h->d.costkind != COST_AFFINE) { msdp_set_error("set_multipliers: handle has no affine constraints"); return MSDP_ESTATE; }
+    if (h->kind == MSDP_KIND_DUAL_UNITDIAG) { msdp_set_error("set_multipliers: dual handles take msdp_dual_set_penalty"); return MSDP_ESTATE; }
     h->state_valid = false;
     h->chunk_len = 0;      // sigma is baked into the captured launches: force a re-capture
     return msdp_affine_set_multipliers(h, y, sigma);

@@ -335,6 +335,51 @@ def bqpmom(n, Q, e):
     return At, b, c, {"s": mb}
 
 
+def bqpsos(Q, e, n):
+    """Second-order SOS relaxation of ``min x'Qx + e'x, x_i^2 = 1`` (the dual of :func:`bqpmom`'s problem) as
+    ``(A, b, dAAt, mb)``: ``A`` is ``lsp x mb^2`` with one row per multilinear monomial of degree <= 4 (row 0 = the
+    identity), ``dAAt = diag(A A')``.  Restates src/basicfunction/bqpsos.m:7-39 (same monomial order, same rows)."""
+    Q = np.asarray(Q, dtype=np.float64)
+    e = np.asarray(e, dtype=np.float64).ravel()
+    from itertools import combinations
+    spl = [()]
+    for deg in range(1, 5):                                # multilinear monomials of degree <= 4 (:8-11), comp.m order
+        spl += sorted(combinations(range(n), deg), key=lambda mno: _sp_order_key(mno, n))
+    lsp = len(spl)
+    index = {mno: k for k, mno in enumerate(spl)}
+    mb = comb(n + 2, 2) - n                                # :12  the monomials of degree <= 2 come first in sp
+    rows = [0] * mb
+    cols = [k * mb + k for k in range(mb)]                 # :20  row 1 = identity
+    dAAt = np.zeros(lsp)
+    dAAt[0] = mb
+    for i in range(mb):                                    # :22-33
+        si = set(spl[i])
+        for j in range(i + 1, mb):
+            loc = index[tuple(sorted(si.symmetric_difference(spl[j])))]    # mod(sp_i + sp_j, 2)
+            rows += [loc, loc]
+            cols += [i * mb + j, j * mb + i]
+            dAAt[loc] += 2
+    A = sp.coo_matrix((np.ones(len(rows)), (np.array(rows), np.array(cols))), shape=(lsp, mb * mb)).tocsr()
+    b = np.zeros(lsp)                                      # :36-39
+    b[0] = np.trace(Q)
+    b[1:n + 1] = e
+    b[n + 1:n + 1 + n * (n - 1) // 2] = [2.0 * Q[i, j] for j in range(1, n) for i in range(j)]
+    return A, b, dAAt, mb
+
+
+def bqpsos_dual_problem(Q, e, n):
+    """The dual-form SeDuMi data example/dual/example_bqp_dual.m:21-37 passes to ``ManiDSDP_unitdiag``: one free
+    variable (column ``e_1``, cost 1), ``b`` scaled by ``max|b|``.  Returns ``(A, b, c, K, dAAt, maxb)``; the optimum of
+    the BQP relaxation is ``maxb * obj``."""
+    A, b, dAAt, mb = bqpsos(Q, e, n)
+    v = sp.csr_matrix(([1.0], ([0], [0])), shape=(A.shape[0], 1))
+    Afull = sp.hstack([v, A]).tocsc()
+    c = np.zeros(1 + mb * mb)
+    c[0] = 1.0
+    maxb = float(np.max(np.abs(b)))
+    return Afull, b / maxb, c, {"f": 1, "s": mb}, dAAt, maxb
+
+
 def qsmom(n, coe):
     """Second-order moment relaxation of ``min coe'[x]_4, |x|^2 = 1`` in SeDuMi
     format.  Restates src/basicfunction/qsmom.m:6-116 (the reference's own example solves it

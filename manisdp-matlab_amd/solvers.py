@@ -45,8 +45,8 @@ def _host_threads():
         pass
     return threadpool_limits(limits=max(1, min(ncpu, 16)))
 
-__all__ = ["ManiSDP_onlyunitdiag", "ManiSDP_unitdiag", "ManiSDP_unittrace", "ManiSDP", "ManiSDP_multiblock", "DEFAULTS",
-           "DATA_FIELDS"]
+__all__ = ["ManiSDP_onlyunitdiag", "ManiSDP_unitdiag", "ManiSDP_unittrace", "ManiSDP", "ManiSDP_multiblock",
+           "ManiDSDP_unitdiag", "DEFAULTS", "DATA_FIELDS"]
 
 # Option defaults of the reference's entry points: ManiSDP_onlyunitdiag.m:8-17,
 # ManiSDP_unitdiag.m:10-26, ManiSDP_unittrace.m:10-25, ManiSDP.m:9-25.
@@ -702,3 +702,151 @@ def _multiblock_impl(At, b, c, K, options, verbose, rng):
         _say(verbose, "Iteration maximum is reached!")
     _say(verbose, "ManiSDP: optimum = %0.8f, time = %0.2fs" % (obj, time.time() - t0))
     return Y_eval, obj, data
+
+
+# ================================================================= dual approach, unit diagonal
+DEFAULTS["dual_unitdiag"] = dict(ADMM_maxiter=300, gama=2, sigma0=1e-3, sigma_min=1e-3, sigma_max=1e7, tol=1e-8, theta=1e-3,
+                                 delta=8, alpha=0.1, tolgradnorm=1e-8, TR_maxinner=20, TR_maxiter=4, tau1=1e1, tau2=1e2,
+                                 line_search=0)      # ManiDSDP_unitdiag.m:10-26 (+ p0 = ceil(log(m)), :11)
+DATA_FIELDS["dual_unitdiag"] = ("X", "y", "S", "w", "gap", "pinf", "dinf", "gradnorm", "time", "fac_size", "seta", "status")   # :132-144
+
+
+def ManiDSDP_unitdiag(A, b, c, K, options=None, verbose=True, rng=None):
+    """``[X, obj, data] = ManiDSDP_unitdiag(A, b, c, K, options)`` (reference src/dual/ManiDSDP_unitdiag.m:8): the dual
+    approach for SDPs whose dual slack has a unit diagonal.  ``A`` is m x (K['f'] + K['s']^2) -- free columns first --
+    and ``c`` has K['f'] + K['s']^2 entries.  The Riemannian subproblem (cost/grad/hess :174-194 on the oblique factor
+    of S), the line search and the outer-step bookkeeping (:70-81) run on the device; the multiplier matrix x never
+    leaves it.  Returns (X, obj, data); ``data['Y']`` is the factor of S (n x p)."""
+    with _host_threads():
+        return _dual_unitdiag_impl(A, b, c, K, options, verbose, rng)
+
+
+def _dual_unitdiag_impl(A, b, c, K, options, verbose, rng):
+    o = dict(options or {})
+    for k, v in DEFAULTS["dual_unitdiag"].items():
+        o.setdefault(k, v)
+    n = int(K["s"]); nf = int(K.get("f", 0))
+    b = _dense_vec(b)
+    call = _dense_vec(c)
+    m = b.size
+    o.setdefault("p0", int(math.ceil(math.log(m))))        # :11
+    rng = rng or np.random.default_rng(0)
+    _say(verbose, "ManiSDP is starting...")
+    _say(verbose, f"SDP size: n = {n}, m = {m}")
+    normc = 1.0 + np.linalg.norm(call)                     # :32
+    Aall = sp.csc_matrix(A)
+    B = Aall[:, :nf]; Apsd = sp.csr_matrix(Aall[:, nf:])   # :33-34
+    cf = call[:nf]; cpsd = call[nf:]                       # :35-36
+    dAAt = o.get("dAAt", None)
+    if dAAt is None:
+        dAAt = np.asarray(Apsd.multiply(Apsd).sum(axis=1)).ravel()      # :37
+    dense_max = int(o.get("dense_eig_max", 3000))
+    eig_mode = o.get("eig", "host" if n <= dense_max else "device")
+    p = int(o["p0"])
+    delta = int(o["delta"])
+    h = _lib.Handle.dual_unitdiag(Apsd, b, cpsd, dAAt, B if nf else None, cf, pcap=max(32, p + 2 * delta))
+    topts = _rtr_opts(o)
+    sigma = float(o["sigma0"]); gama = float(o["gama"])
+    w = np.zeros(nf)
+    Y = o.get("Y0", None)
+    if Y is None:                                          # trustregions.m:390-392 -> M.rand()
+        Y = rng.standard_normal((n, p))
+        Y /= np.sqrt(np.sum(Y * Y, axis=1, keepdims=True))
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    U = None
+    data = {"status": 0, "hessvecs": 0, "cost_evals": 0, "rejected": 0, "rtr_seconds": 0.0, "eig_seconds": 0.0, "log": []}
+    fac_size, seta = [], []
+    t0 = time.time()
+    gap0 = pinf0 = dinf0 = None
+    obj = gap = pinf = dinf = gradnorm = eta = None
+    Y_eval = None
+    certified = True
+    try:
+        for it in range(1, int(o["ADMM_maxiter"]) + 1):    # :62
+            fac_size.append(p)
+            h.dual_set_penalty(sigma, w)
+            h.set_point(Y)
+            if U is not None:
+                _line_search(h, U)                         # :65-67, 164-172
+            st = h.rtr(topts)                              # :68
+            data["rtr_seconds"] += st.seconds
+            data["hessvecs"] += st.hessvecs; data["cost_evals"] += st.cost_evals; data["rejected"] += st.rejected
+            gradnorm = st.gradnorm                         # :69
+            Y = h.get_point()
+            Y_eval = Y
+            by, cex, as2, Af, z = h.dual_outer_step()      # :70-81 (x <- x - sigma*As on the device)
+            pinf = (math.sqrt(as2) + float(np.linalg.norm(Af))) / normc      # :75
+            w = w - sigma * Af                             # :78
+            obj = cex + float(cf @ w) + float(np.sum(z))   # :85
+            t1 = time.time()
+            certified = True
+            if eig_mode == "host":
+                Xd = h.get_dual_slack()
+                dX, vX = np.linalg.eigh(0.5 * (Xd + Xd.T)) # :82
+                lam_min, lam_max = float(dX[0]), float(dX[-1])
+                nneg = int(np.sum(dX < 0))
+            else:
+                lam, vX, lam_max, _, certified = _device_escape(
+                    h, lambda tol, maxit: h.escape_eigs_dual(delta, tol=tol, maxit=maxit), o, data, 1e-10, 20000)
+                lam_min = float(lam[0])
+                nneg = int(np.sum(lam < 0))
+            dinf = max(0.0, -lam_min) / (1.0 + abs(lam_max))     # :86
+            if eig_mode != "host" and certified and (dinf < o["tol"] or it == int(o["ADMM_maxiter"])):
+                lam_v, v_v, lmax_v, certified = _verify_lambda_min(
+                    h, lambda tol, maxit: h.escape_eigs_dual(1, tol=tol, maxit=maxit), o, data, 1e-10, 20000, dense_n=n)
+                dinf_v = max(0.0, -lam_v) / (1.0 + abs(lmax_v))
+                if dinf_v >= o["tol"] > dinf:
+                    vX = np.hstack([v_v, vX[:, :max(delta - 1, 0)]])
+                    nneg = max(nneg, 1)
+                dinf = dinf_v
+            data["eig_seconds"] += time.time() - t1
+            gap = abs(obj - by) / (1.0 + abs(obj) + abs(by))     # :87
+            if _RANK_CUT_SVD:
+                _, e, Qt = np.linalg.svd(Y, full_matrices=False); Q = Qt.T
+            else:
+                Q, e, _ = _thin_svd_rank(Y, float(o["theta"]))
+            r = int(np.sum(e > float(o["theta"]) * e[0]))  # :88-90 (strict, unlike the primal entry points)
+            _say(verbose, "Iter %d, obj:%0.8f, gap:%0.1e, pinf:%0.1e, dinf:%0.1e, gradnorm:%0.1e, r:%d, p:%d, sigma:%0.3f, time:%0.2fs"
+                 % (it, obj, gap, pinf, dinf, gradnorm, r, p, sigma, time.time() - t0))
+            data["log"].append((obj, gap, pinf, dinf, gradnorm, r, p, sigma))
+            eta = max(gap, pinf, dinf)                     # :93
+            seta.append(eta)
+            data["iters"] = it
+            if eta < o["tol"] and certified:
+                _say(verbose, "Optimality is reached!")
+                break
+            if it % 50 == 0:                               # :99-109
+                if it > 100 and gap > gap0 and pinf > pinf0 and dinf > dinf0:
+                    data["status"] = 2
+                    _say(verbose, "Slow progress!")
+                    break
+                gap0, pinf0, dinf0 = gap, pinf, dinf
+            if r <= p - 1:                                 # :110-113
+                Y = _rank_cut(Y, Q, e, r)
+                p = r
+            nne = max(min(nneg, delta), 1)                 # :114
+            if o["line_search"] == 1:
+                U = np.hstack([np.zeros((n, p)), vX[:, :nne]])   # :116
+            p = p + nne
+            if o["line_search"] == 1:
+                Y = np.hstack([Y, np.zeros((n, nne))])     # :120
+            else:
+                Y = np.hstack([Y, o["alpha"] * vX[:, :nne]])     # :122-123
+                Y = Y / np.sqrt(np.sum(Y * Y, axis=1, keepdims=True))
+            Y = np.ascontiguousarray(Y)
+            if pinf < o["tau1"] * gradnorm:                # :125-129
+                sigma = max(sigma / gama, float(o["sigma_min"]))
+            elif pinf > o["tau2"] * gradnorm:
+                sigma = min(sigma * gama, float(o["sigma_max"]))
+        X = h.get_dual_slack() if obj is not None else None
+        y = h.dual_get_y() if obj is not None else None
+    finally:
+        h.close()
+    data.update({"X": X, "y": y, "S": (Y_eval @ Y_eval.T if Y_eval is not None and n <= int(o.get("dense_X_max", 4000)) else None),
+                 "w": w, "gap": gap, "pinf": pinf, "dinf": dinf, "gradnorm": gradnorm, "time": time.time() - t0,
+                 "fac_size": fac_size, "seta": seta, "Y": Y_eval, "sigma": sigma})
+    if data["status"] == 0 and (eta is None or eta > o["tol"] or not certified):
+        data["status"] = 1
+        _say(verbose, "Iteration maximum is reached!")
+    _say(verbose, "ManiDSDP: optimum = %0.8f, time = %0.2fs" % (obj, time.time() - t0))
+    return X, obj, data

@@ -9,6 +9,7 @@ Follows (paths relative to the reference tree):
   * src/primal/ManiSDP_unitdiag.m:7-198
   * src/primal/ManiSDP_unittrace.m:7-177
   * manopt7.0/manopt/manifolds/sphere/spherefactory.m:83-153,220-232,249-254
+  * src/primal/ManiSDP_multiblock.m, src/dual/ManiDSDP_unitdiag.m:8-220 (the "next" rows of SURVEY.md 8f-4)
 with the RTR/tCG restatement in ``oracle/manopt_rtr.py``.
 
 Parity status: the MATLAB reference cannot be executed in this environment; the
@@ -1057,3 +1058,184 @@ def ManiSDP_multiblock(At, b, c, K, options=None, rng=None, verbose=False):
         _say(verbose, "Iteration maximum is reached!")
     _say(verbose, "ManiSDP: optimum = %0.8f, time = %0.2fs" % (obj, time.time() - t0))
     return Y_eval, obj, data
+
+
+# ------------------------------------------------------------------ dual, unit diagonal
+class _DualUnitDiagProblem:
+    """cost/grad/hess closures of src/dual/ManiDSDP_unitdiag.m:174-194.  ``A`` is the
+    m x n^2 PSD part, ``B`` the m x K.f free part, ``iA = (diag(dAAt)\\A)'`` (:38).  The
+    closures share ``As, Af, X, eG`` through the parent workspace; ``X`` and ``eG`` are set
+    by ``grad`` and used by ``hess`` (at the last accepted point)."""
+
+    def __init__(self, A, B, b, c, cf, dAAt, n, p):
+        self.A = sp.csr_matrix(A)
+        self.At = self.A.T.tocsr()
+        self.B = sp.csr_matrix(B)
+        self.iAt = sp.diags(1.0 / np.asarray(dAAt, dtype=np.float64)) @ self.A      # iA' = D^-1 A   (:38)
+        self.bA = self.iAt.T @ b                                                 # :39
+        self.b, self.c, self.cf, self.n = b, c, cf, n
+        self.M = ObliqueNT(p, n, inner_all=False)
+        self.x = np.zeros(n * n)
+        self.w = np.zeros(cf.size)
+        self.sigma = 1.0
+        self.As = self.Af = self.X = self.YeG = None
+        self.nhess = 0
+
+    def parts(self, Y):
+        S = Y @ Y.T                                        # :175  S = Y'*Y
+        sc = S.ravel(order="F") - self.c                   # :176
+        y = self.iAt @ sc                                  # :177
+        return S, sc, y
+
+    def cost(self, Y):
+        _, sc, y = self.parts(Y)
+        self.As = self.At @ y - sc - self.x / self.sigma   # :178
+        self.Af = self.B.T @ y - self.cf - self.w / self.sigma      # :179
+        return float(self.b @ y) + 0.5 * self.sigma * (float(self.As @ self.As) + float(self.Af @ self.Af))   # :180
+
+    def grad(self, Y):
+        n = self.n
+        self.X = (self.bA - self.sigma * self.As).reshape((n, n), order="F")      # :184
+        eG = 2.0 * (self.X.T @ Y)                          # :185  eG = 2*Y*X
+        self.YeG = np.sum(Y * eG, axis=1, keepdims=True)
+        return eG - Y * self.YeG                           # :186
+
+    def hess(self, Y, U):
+        self.nhess += 1
+        n = self.n
+        YU = Y @ U.T                                       # :190  YU = Y'*U
+        yAU = (self.At @ (self.iAt @ YU.ravel(order="F"))).reshape((n, n), order="F")   # :191
+        eH = (2.0 * (self.X.T @ U) - 4.0 * self.sigma * (yAU.T @ Y)
+              + 2.0 * self.sigma * (Y @ (U.T @ Y) + U @ (Y.T @ Y)))               # :192
+        return eH - Y * np.sum(Y * eH, axis=1, keepdims=True) - U * self.YeG     # :193
+
+
+def ManiDSDP_unitdiag(A, b, c, K, options=None, rng=None, verbose=False):
+    """``[X, obj, data] = ManiDSDP_unitdiag(A, b, c, K, options)`` (src/dual/ManiDSDP_unitdiag.m:8-172):
+    ``A`` is m x (K.f + K.s^2), ``c`` has K.f + K.s^2 entries.  Returns (X, obj, data); the factor
+    of ``S`` is ``data['Y']`` (n x p)."""
+    o = dict(options or {})
+    n = int(K["s"]); nf = int(K.get("f", 0))
+    b = _as_dense_vec(b)
+    call = _as_dense_vec(c)
+    m = b.size
+    p0 = o.get("p0", int(math.ceil(math.log(m))))          # :11
+    maxiter = o.get("ADMM_maxiter", 300); gama = o.get("gama", 2)
+    sigma0 = o.get("sigma0", 1e-3); sigma_min = o.get("sigma_min", 1e-3); sigma_max = o.get("sigma_max", 1e7)
+    tol = o.get("tol", 1e-8); theta = o.get("theta", 1e-3); delta = o.get("delta", 8)
+    alpha = o.get("alpha", 0.1); tolgradnorm = o.get("tolgradnorm", 1e-8)
+    TR_maxinner = o.get("TR_maxinner", 20); TR_maxiter = o.get("TR_maxiter", 4)
+    tau1 = o.get("tau1", 1e1); tau2 = o.get("tau2", 1e2); line_search = o.get("line_search", 0)
+    rng = rng or np.random.default_rng(0)
+    _say(verbose, "ManiSDP is starting...")
+    _say(verbose, f"SDP size: n = {n}, m = {m}")
+    normc = 1.0 + np.linalg.norm(call)                     # :32
+    Aall = sp.csc_matrix(A)
+    B = Aall[:, :nf]; Apsd = Aall[:, nf:]                  # :33-34
+    cf = call[:nf]; c = call[nf:]                          # :35-36
+    dAAt = o.get("dAAt", None)
+    if dAAt is None:
+        dAAt = np.asarray(Apsd.multiply(Apsd).sum(axis=1)).ravel()     # :37  diag(A*A')
+    p = p0
+    prob = _DualUnitDiagProblem(Apsd, B, b, c, cf, dAAt, n, p)
+    sigma = sigma0
+    Y = o.get("Y0", None)
+    U = None
+    fac_size = []; seta = []
+    data = {"status": 0, "hessvecs": 0, "cost_evals": 0, "rejected": 0, "rtr_seconds": 0.0, "log": []}
+    t0 = time.time()
+    gap0 = pinf0 = dinf0 = None
+
+    def rownorm(Z):
+        return Z / np.sqrt(np.sum(Z ** 2, axis=1, keepdims=True))
+
+    def co(Yv):                                            # :131-138
+        _, sc, yv = prob.parts(Yv)
+        As = prob.At @ yv - sc - prob.x / sigma
+        Af = prob.B.T @ yv - cf - prob.w / sigma
+        return float(b @ yv) + 0.5 * sigma * (float(As @ As) + float(Af @ Af))
+
+    def do_line_search(Yv, Uv):                            # :140-152
+        a = 1.0
+        cost0 = co(Yv)
+        i = 1
+        nY = rownorm(Yv + a * Uv)
+        while i <= 15 and co(nY) - cost0 > -1e-3:
+            a = 0.8 * a
+            nY = rownorm(Yv + a * Uv)
+            i += 1
+        return nY
+
+    obj = gap = pinf = dinf = gradnorm = eta = None
+    X = S = y = None
+    for it in range(1, maxiter + 1):                       # :62
+        fac_size.append(p)
+        prob.M = ObliqueNT(p, n, inner_all=False)          # :64
+        prob.sigma = sigma
+        if U is not None:
+            Y = do_line_search(Y, U)                       # :65-67
+        t1 = time.time()
+        Y, _, info = trustregions(prob, Y, TR_maxiter, TR_maxinner, tolgradnorm, rng=rng)   # :68
+        data["rtr_seconds"] += time.time() - t1
+        data["hessvecs"] += info.hessvecs; data["cost_evals"] += info.cost_evals; data["rejected"] += info.rejected
+        gradnorm = info.gradnorm
+        Yeval = Y
+        S, sc, y = prob.parts(Y)                           # :70-72
+        As = prob.At @ y - sc                              # :73
+        Af = prob.B.T @ y - cf                             # :74
+        pinf = (np.linalg.norm(As) + np.linalg.norm(Af)) / normc     # :75
+        by = float(b @ y)                                  # :76
+        prob.x = prob.x - sigma * As                       # :77
+        prob.w = prob.w - sigma * Af                       # :78
+        eX = (prob.x + prob.bA).reshape((n, n), order="F")  # :79
+        z = np.sum(S * eX, axis=0)                         # :80
+        X = eX - np.diag(z)                                # :81
+        dX, vX = np.linalg.eigh(X)                         # :82
+        obj = float(c @ eX.ravel(order="F")) + float(cf @ prob.w) + float(np.sum(z))   # :85
+        dinf = max(0.0, -dX[0]) / (1.0 + abs(dX[-1]))      # :86
+        gap = abs(obj - by) / (1.0 + abs(obj) + abs(by))   # :87
+        V, e, r = _thin_svd_rank_strict(Y, theta)          # :88-90  (strict >)
+        _say(verbose, "Iter %d, obj:%0.8f, gap:%0.1e, pinf:%0.1e, dinf:%0.1e, gradnorm:%0.1e, r:%d, p:%d, sigma:%0.3f, time:%0.2fs"
+             % (it, obj, gap, pinf, dinf, gradnorm, r, p, sigma, time.time() - t0))
+        data["log"].append((obj, gap, pinf, dinf, gradnorm, r, p, sigma))
+        eta = max(gap, pinf, dinf)                         # :93
+        seta.append(eta)
+        data["iters"] = it
+        if eta < tol:
+            _say(verbose, "Optimality is reached!")
+            break
+        if it % 50 == 0:                                   # :99-109
+            if it > 100 and gap > gap0 and pinf > pinf0 and dinf > dinf0:
+                data["status"] = 2
+                _say(verbose, "Slow progress!")
+                break
+            else:
+                gap0, pinf0, dinf0 = gap, pinf, dinf
+        if r <= p - 1:                                     # :110-113
+            Y = V[:, :r] * e[:r]
+            p = r
+        nne = max(min(int(np.sum(dX < 0)), delta), 1)      # :114
+        if line_search == 1:
+            U = np.hstack([np.zeros((n, p)), vX[:, :nne]])  # :116
+        p = p + nne
+        if line_search == 1:
+            Y = np.hstack([Y, np.zeros((n, nne))])         # :120
+        else:
+            Y = rownorm(np.hstack([Y, alpha * vX[:, :nne]]))    # :122-123
+        if pinf < tau1 * gradnorm:                         # :125-129
+            sigma = max(sigma / gama, sigma_min)
+        elif pinf > tau2 * gradnorm:
+            sigma = min(sigma * gama, sigma_max)
+    data.update({"X": X, "y": y, "S": S, "w": prob.w.copy(), "gap": gap, "pinf": pinf, "dinf": dinf, "gradnorm": gradnorm,
+                 "time": time.time() - t0, "fac_size": fac_size, "seta": seta, "Y": Yeval, "sigma": sigma})
+    if data["status"] == 0 and eta > tol:
+        data["status"] = 1
+        _say(verbose, "Iteration maximum is reached!")
+    _say(verbose, "ManiDSDP: optimum = %0.8f, time = %0.2fs" % (obj, time.time() - t0))
+    return X, obj, data
+
+
+def _thin_svd_rank_strict(Y, theta):
+    """``[~, D, V] = svd(Y)`` + ``r = sum(e > theta*e(1))`` (ManiDSDP_unitdiag.m:88-90: strict, unlike the primal files)."""
+    V, e, _ = np.linalg.svd(Y, full_matrices=False)
+    return V, e, int(np.sum(e > theta * e[0]))

@@ -128,3 +128,24 @@ def test_multiblock_direct_sum_of_two_maxcut_problems():
     assert d["status"] == 0 and max(d["gap"], d["pinf"], d["dinf"]) < 1e-8
     want = -(known["mcp100"] + known["mcp124-1"])
     assert abs(obj - want) <= 1e-6 * abs(want)
+
+
+def test_dual_oracle_agrees_with_primal_oracle():
+    """ManiDSDP_unitdiag on the SOS relaxation of a BQP (bqpsos.m data as example_bqp_dual.m builds it) and
+    ManiSDP_unitdiag on the moment relaxation of the same BQP (bqpmom.m) are a primal/dual pair: same optimum.  Pins the
+    dual restatement to the primal one, which is pinned to the SDPLIB values above."""
+    import numpy as np
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R
+    for d, seed in ((6, 0), (9, 4)):
+        rng = np.random.default_rng(seed)
+        Q = rng.standard_normal((d, d)); Q = (Q + Q.T) / 2
+        e = rng.standard_normal(d)
+        At, b, c, K = problems.bqpmom(d, Q, e)
+        _, fp, dp = R.ManiSDP_unitdiag(At, b, c, K, {"tol": 1e-8}, rng=np.random.default_rng(0))
+        A, bs, cs, Ks, dAAt, maxb = problems.bqpsos_dual_problem(Q, e, d)
+        assert Ks["s"] == K["s"] and np.allclose(dAAt, np.asarray(A[:, 1:].multiply(A[:, 1:]).sum(axis=1)).ravel())
+        for ls in (0, 1):
+            _, fd, dd = R.ManiDSDP_unitdiag(A, bs, cs, Ks, {"tol": 1e-8, "dAAt": dAAt, "line_search": ls}, rng=np.random.default_rng(0))
+            assert dd["status"] == 0 and max(dd["gap"], dd["pinf"], dd["dinf"]) < 1e-8
+            assert abs(fd * maxb - fp) <= 1e-6 * max(1.0, abs(fp))
