@@ -11,6 +11,12 @@
 //   h = manisdp_mex('create_multiblock', At, b, c, nset, nob)   block orders nset (vector), first nob blocks unit-diagonal;
 //                                                        the factor is one p x sum(nset) matrix (blocks side by side, zero rows
 //                                                        below a block's own width)
+//   h = manisdp_mex('create_dual_unitdiag', At, dAAt, b, c, n, B, cf)   dual approach (ManiDSDP_unitdiag.m): At = A(:,K.f+1:end)'
+//                                                        sparse n^2 x m, dAAt = diag(A*A'), c the PSD part of the cost,
+//                                                        B = A(:,1:K.f) sparse m x nf (or []), cf its costs
+//       manisdp_mex('dual_set_penalty', h, sigma, w)     before every rtr of a dual handle (w: nf x 1)
+//   [by, cex, as2, Af, z] = manisdp_mex('dual_outer_step', h)   ManiDSDP_unitdiag.m:70-81 on the device
+//   y = manisdp_mex('dual_get_y', h)
 //       manisdp_mex('set_multipliers', h, y, sigma)
 //       manisdp_mex('set_point', h, Y)                   Y in the reference layout of the handle's kind
 //   Y = manisdp_mex('get_point', h)
@@ -47,7 +53,7 @@
 
 namespace {
 
-struct Meta { int kind; int64_t n; int64_t m; };
+struct Meta { int kind; int64_t n; int64_t m; int64_t nf; };
 std::map<uint64_t, Meta> g_live;
 bool g_exit_hooked = false;
 
@@ -72,9 +78,9 @@ uint64_t handle_key(const mxArray* a) {
     return key;
 }
 
-mxArray* wrap_handle(msdp_handle h, int kind, int64_t n, int64_t m) {
+mxArray* wrap_handle(msdp_handle h, int kind, int64_t n, int64_t m, int64_t nf = 0) {
     const uint64_t key = (uint64_t)(uintptr_t)h;
-    g_live[key] = Meta{kind, n, m};
+    g_live[key] = Meta{kind, n, m, nf};
     if (!g_exit_hooked) { mexAtExit(destroy_all); g_exit_hooked = true; }
     mxArray* o = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
     *(uint64_t*)mxGetData(o) = key;
@@ -215,6 +221,30 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         return;
     }
 
+    if (cmd == "create_dual_unitdiag") {
+        need(nrhs == 8, "h = manisdp_mex('create_dual_unitdiag', At, dAAt, b, c, n, B, cf)");
+        const mxArray* At = prhs[1];
+        if (!mxIsSparse(At)) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "At must be sparse (n^2 x m)");
+        const int64_t n = (int64_t)mxGetScalar(prhs[5]);
+        const int64_t m = (int64_t)mxGetN(At);
+        if ((int64_t)mxGetM(At) != n * n) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "At must have n^2 rows");
+        if ((int64_t)mxGetNumberOfElements(prhs[2]) != m) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "dAAt must have m entries");
+        const std::vector<double> dAAt = as_dense(prhs[2], (size_t)m);
+        const std::vector<double> b = as_dense(prhs[3], (size_t)m);
+        const std::vector<double> c = as_dense(prhs[4], (size_t)(n * n));
+        const mxArray* B = prhs[6];
+        const int64_t nf = mxIsEmpty(B) ? 0 : (int64_t)mxGetN(B);
+        if (nf > 0 && (!mxIsSparse(B) || (int64_t)mxGetM(B) != m)) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "B must be sparse m x nf");
+        const std::vector<double> cf = as_dense(prhs[7], (size_t)(nf > 0 ? nf : 1));
+        msdp_handle h = nullptr;
+        const int rc = msdp_create_dual_unitdiag(n, m, (const int64_t*)mxGetJc(At), (const int64_t*)mxGetIr(At), mxGetPr(At), dAAt.data(),
+                                                 b.data(), c.data(), (int32_t)nf, nf ? (const int64_t*)mxGetJc(B) : nullptr,
+                                                 nf ? (const int64_t*)mxGetIr(B) : nullptr, nf ? mxGetPr(B) : nullptr, cf.data(), 32, &h);
+        if (rc) fail("create_dual_unitdiag", rc);
+        plhs[0] = wrap_handle(h, MSDP_KIND_DUAL_UNITDIAG, n, m, nf);
+        return;
+    }
+
     // ---------------------------------------------------------------- everything else takes a handle
     need(nrhs >= 2, "manisdp_mex(command, h, ...)");
     const uint64_t key = handle_key(prhs[1]);
@@ -311,6 +341,31 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         const int rc = msdp_al_dual(h, mxGetPr(prhs[2]), zlen ? mxGetPr(z) : nullptr);
         if (rc) { mxDestroyArray(z); fail("al_dual", rc); }
         plhs[0] = z;
+    } else if (cmd == "dual_set_penalty") {
+        need(nrhs == 4, "manisdp_mex('dual_set_penalty', h, sigma, w)");
+        if ((int64_t)mxGetNumberOfElements(prhs[3]) != me.nf) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "w must have K.f entries");
+        const std::vector<double> w = as_dense(prhs[3], (size_t)(me.nf > 0 ? me.nf : 1));
+        const int rc = msdp_dual_set_penalty(h, mxGetScalar(prhs[2]), w.data());
+        if (rc) fail("dual_set_penalty", rc);
+    } else if (cmd == "dual_outer_step") {
+        need(nrhs == 2, "[by, cex, as2, Af, z] = manisdp_mex('dual_outer_step', h)");
+        double scal[3] = {0.0, 0.0, 0.0};
+        mxArray* Af = mxCreateDoubleMatrix((mwSize)me.nf, 1, mxREAL);
+        mxArray* z = mxCreateDoubleMatrix(1, (mwSize)me.n, mxREAL);
+        std::vector<double> afbuf((size_t)(me.nf > 0 ? me.nf : 1), 0.0);
+        const int rc = msdp_dual_outer_step(h, scal, afbuf.data(), mxGetPr(z));
+        if (rc) { mxDestroyArray(Af); mxDestroyArray(z); fail("dual_outer_step", rc); }
+        if (me.nf > 0) memcpy(mxGetPr(Af), afbuf.data(), (size_t)me.nf * sizeof(double));
+        plhs[0] = mxCreateDoubleScalar(scal[0]);
+        if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(scal[1]);
+        if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(scal[2]);
+        if (nlhs > 3) plhs[3] = Af; else mxDestroyArray(Af);
+        if (nlhs > 4) plhs[4] = z; else mxDestroyArray(z);
+    } else if (cmd == "dual_get_y") {
+        mxArray* y = mxCreateDoubleMatrix((mwSize)me.m, 1, mxREAL);
+        const int rc = msdp_dual_get_y(h, mxGetPr(y));
+        if (rc) { mxDestroyArray(y); fail("dual_get_y", rc); }
+        plhs[0] = y;
     } else if (cmd == "get_dual_slack") {
         mxArray* S = mxCreateDoubleMatrix((mwSize)me.n, (mwSize)me.n, mxREAL);
         const int rc = msdp_get_dual_slack(h, mxGetPr(S));

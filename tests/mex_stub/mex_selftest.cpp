@@ -222,6 +222,62 @@ int run_affine(const char* in, const char* outp) {
     return bad;
 }
 
+int run_dual(const char* in, const char* outp) {
+    Reader r(in);
+    const int64_t n = r.i64(), m = r.i64(), nnz = r.i64(), nnzB = r.i64(), p = r.i64(), maxiter = r.i64(), maxinner = r.i64();
+    const double sigma = r.f64(), alpha = r.f64(), w0 = r.f64(), cf0 = r.f64();
+    mxArray* At = sparse_from(r, (mwSize)(n * n), (mwSize)m, nnz);
+    mxArray* B = sparse_from(r, (mwSize)m, 1, nnzB);
+    mxArray* dAAt = full_from(r, (mwSize)m, 1);
+    mxArray* b = full_from(r, (mwSize)m, 1);
+    mxArray* c = full_from(r, (mwSize)(n * n), 1);
+    mxArray* Y0 = full_from(r, (mwSize)p, (mwSize)n);                // p x n like ManiDSDP_unitdiag.m:64
+    mxArray* U = full_from(r, (mwSize)p, (mwSize)n);
+    Writer w(outp);
+    mxArray* c_create = mxCreateString("create_dual_unitdiag");
+    mxArray* nn = mxCreateDoubleScalar((double)n);
+    mxArray* cf = mxCreateDoubleScalar(cf0);
+    mxArray* h = call(1, {c_create, At, dAAt, b, c, nn, B, cf})[0];
+    mxArray* c_pen = mxCreateString("dual_set_penalty");
+    mxArray* sg = mxCreateDoubleScalar(sigma);
+    mxArray* wf = mxCreateDoubleScalar(w0);
+    call(0, {c_pen, h, sg, wf});
+    mxArray* c_set = mxCreateString("set_point");
+    call(0, {c_set, h, Y0});
+    mxArray* c_ls = mxCreateString("linesearch_cost");
+    mxArray* zero = mxCreateDoubleScalar(0.0);
+    mxArray* al = mxCreateDoubleScalar(alpha);
+    mxArray* co0 = call(1, {c_ls, h, U, zero})[0];
+    mxArray* co1 = call(1, {c_ls, h, U, al})[0];
+    mxArray* c_rtr = mxCreateString("rtr");
+    mxArray* opts = rtr_opts((int)maxiter, (int)maxinner, 1e-8);
+    mxArray* info = call(1, {c_rtr, h, opts})[0];
+    mxArray* c_get = mxCreateString("get_point");
+    mxArray* Y = call(1, {c_get, h})[0];
+    mxArray* c_step = mxCreateString("dual_outer_step");
+    std::vector<mxArray*> st = call(5, {c_step, h});
+    mxArray* c_y = mxCreateString("dual_get_y");
+    mxArray* y = call(1, {c_y, h})[0];
+    mxArray* c_S = mxCreateString("get_dual_slack");
+    mxArray* X = call(1, {c_S, h})[0];
+    mxArray* c_kind = mxCreateString("kind");
+    mxArray* kind = call(1, {c_kind, h})[0];
+    w.put(Y); w.put(st[3]); w.put(st[4]); w.put(y); w.put(X);
+    printf("{\"kind\": %d, \"rows\": %zu, \"cols\": %zu, \"co0\": %.17g, \"co1\": %.17g, \"cost\": %.17g, \"gradnorm\": %.17g, "
+           "\"hessvecs\": %d, \"by\": %.17g, \"cex\": %.17g, \"as2\": %.17g}\n",
+           (int)mxGetScalar(kind), mxGetM(Y), mxGetN(Y), mxGetScalar(co0), mxGetScalar(co1), field(info, "cost"), field(info, "gradnorm"),
+           (int)field(info, "hessvecs"), mxGetScalar(st[0]), mxGetScalar(st[1]), mxGetScalar(st[2]));
+    int bad = 0;
+    // a second solve without a fresh dual_set_penalty must be refused (the multipliers have moved)
+    bad += expect_error("rtr after dual_outer_step without dual_set_penalty", "ManiSDP:hip:call", {c_rtr, h, opts});
+    mxArray* c_destroy = mxCreateString("destroy");
+    call(0, {c_destroy, h});
+    for (mxArray* a : {At, B, dAAt, b, c, Y0, U, c_create, nn, cf, h, c_pen, sg, wf, c_set, c_ls, zero, al, co0, co1, c_rtr, opts, info,
+                       c_get, Y, c_step, st[0], st[1], st[2], st[3], st[4], c_y, y, c_S, X, c_kind, kind, c_destroy})
+        mxDestroyArray(a);
+    return bad;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -230,6 +286,7 @@ int main(int argc, char** argv) {
         if (mode == "errors") return run_errors();
         if (mode == "onlyunitdiag" && argc == 4) return run_onlyunitdiag(argv[2], argv[3]);
         if (mode == "affine" && argc == 4) return run_affine(argv[2], argv[3]);
+        if (mode == "dual" && argc == 4) return run_dual(argv[2], argv[3]);
     } catch (const mex_stub_error& e) {
         fprintf(stderr, "mexErrMsgIdAndTxt(%s): %s\n", e.id.c_str(), e.what());
         return 3;

@@ -54,6 +54,9 @@ APPENDIX_A = {      # SURVEY.md appendix A (reference file:line in the module do
     "ManiSDP_multiblock.m": dict(min_facsize=2, AL_maxiter=1000, gama=2, sigma0=1e-1, sigma_min=1e-2, sigma_max=1e7,
                                  tol=1e-8, theta=1e-2, delta=8, alpha=0.1, tolgradnorm=1e-8, TR_maxinner=20,
                                  TR_maxiter=4, tau1=1e1, tau2=1e1, line_search=0),    # ManiSDP_multiblock.m:10-27
+    "ManiDSDP_unitdiag.m": dict(ADMM_maxiter=300, gama=2, sigma0=1e-3, sigma_min=1e-3, sigma_max=1e7, tol=1e-8, theta=1e-3,
+                                delta=8, alpha=0.1, tolgradnorm=1e-8, TR_maxinner=20, TR_maxiter=4, tau1=1e1, tau2=1e2,
+                                line_search=0),      # src/dual/ManiDSDP_unitdiag.m:12-26 (p0 = ceil(log(m)), :11)
     "ManiSDP_unittrace.m": dict(p0=1, AL_maxiter=1000, gama=2, sigma0=1e1, sigma_min=1e2, sigma_max=1e7, tol=1e-8,
                                 theta=1e-2, delta=8, alpha=0.05, tolgradnorm=1e-8, TR_maxinner=40, TR_maxiter=3,
                                 tau1=1e-5, tau2=1e-4, line_search=1),
@@ -183,4 +186,51 @@ def test_gateway_affine_matches_ctypes(tmp_path, kind_name, sparse_bc):
         assert np.array_equal(got, ref)
     assert o == arr.size
     assert (meta["co0"], meta["co1"], meta["cost"], meta["obj"], meta["lmax"]) == (co0, co1, st.cost, obj, lmax)
+    assert meta["hessvecs"] == st.hessvecs
+
+
+@pytest.mark.gpu
+def test_gateway_dual_matches_ctypes(tmp_path):
+    """create_dual_unitdiag / dual_set_penalty / dual_outer_step / dual_get_y through the gateway, the way
+    ManiDSDP_unitdiag.m drives them, against the ctypes binding."""
+    import scipy.sparse as sp
+    from manisdp_matlab_amd import _lib, problems
+    d = 7
+    rng = np.random.default_rng(3)
+    Q = rng.standard_normal((d, d)); Q = (Q + Q.T) / 2
+    e = rng.standard_normal(d)
+    A, b, c, K, dAAt, _ = problems.bqpsos_dual_problem(Q, e, d)
+    n, m, nf = K["s"], b.size, K["f"]
+    Ac = sp.csc_matrix(A)
+    Apsd, B = sp.csr_matrix(Ac[:, nf:]), sp.csc_matrix(Ac[:, :nf])
+    At = sp.csc_matrix(Apsd.T); At.sort_indices(); B.sort_indices()
+    p = 6
+    Y0 = rng.standard_normal((n, p)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    U = 0.3 * rng.standard_normal((n, p))
+    sigma, alpha, w0 = 0.05, 0.5, 0.1
+    blob = (_i64(n, m, At.nnz, B.nnz, p, 3, 15) + np.asarray([sigma, alpha, w0, c[0]]).tobytes()
+            + At.indptr.astype(np.int64).tobytes() + At.indices.astype(np.int64).tobytes() + At.data.astype(np.float64).tobytes()
+            + B.indptr.astype(np.int64).tobytes() + B.indices.astype(np.int64).tobytes() + B.data.astype(np.float64).tobytes()
+            + dAAt.astype(np.float64).tobytes() + b.tobytes() + c[nf:].tobytes()
+            + np.ascontiguousarray(Y0).tobytes() + np.ascontiguousarray(U).tobytes())
+    meta, arr, stdout = _run("dual", blob, tmp_path)
+    assert meta["kind"] == _lib.KIND_DUAL_UNITDIAG and (meta["rows"], meta["cols"]) == (p, n)
+    assert "rtr after dual_outer_step without dual_set_penalty" in stdout and "ManiSDP:hip:call" in stdout
+    h = _lib.Handle.dual_unitdiag(Apsd, b, c[nf:], dAAt, B, c[:nf])
+    h.dual_set_penalty(sigma, np.array([w0]))
+    h.set_point(Y0)
+    co0 = h.linesearch_cost(None, 0.0)
+    co1 = h.linesearch_cost(U, alpha)
+    st = h.rtr(_lib.default_opts(maxiter=3, maxinner=15, tolgradnorm=1e-8))
+    Y = h.get_point()
+    by, cex, as2, Af, z = h.dual_outer_step()
+    y = h.dual_get_y()
+    X = h.get_dual_slack()
+    h.close()
+    o = 0
+    for ref in (Y.ravel(), Af, z, y, X.ravel()):
+        got = arr[o:o + ref.size]; o += ref.size
+        assert np.array_equal(got, ref)
+    assert o == arr.size
+    assert (meta["co0"], meta["co1"], meta["cost"], meta["by"], meta["cex"], meta["as2"]) == (co0, co1, st.cost, by, cex, as2)
     assert meta["hessvecs"] == st.hessvecs
