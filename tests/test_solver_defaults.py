@@ -63,3 +63,15 @@ def test_multiblock_defaults():
                                                   sigma_max=1e7, tol=1e-8, theta=1e-2, delta=8, alpha=0.1,
                                                   tolgradnorm=1e-8, TR_maxinner=20, TR_maxiter=4, tau1=1e1, tau2=1e1,
                                                   line_search=0)                      # ManiSDP_multiblock.m:10-27
+
+
+def test_dual_unitdiag_defaults():
+    from manisdp_matlab_amd import solvers
+    assert solvers.DEFAULTS["dual_unitdiag"] == dict(ADMM_maxiter=300, gama=2, sigma0=1e-3, sigma_min=1e-3, sigma_max=1e7,
+                                                     tol=1e-8, theta=1e-3, delta=8, alpha=0.1, tolgradnorm=1e-8,
+                                                     TR_maxinner=20, TR_maxiter=4, tau1=1e1, tau2=1e2,
+                                                     line_search=0)                   # src/dual/ManiDSDP_unitdiag.m:12-26
+    assert solvers.DATA_FIELDS["dual_unitdiag"] == ("X", "y", "S", "w", "gap", "pinf", "dinf", "gradnorm", "time", "fac_size",
+                                                    "seta", "status")                 # :132-144
+    src = inspect.getsource(solvers)
+    assert "ManiDSDP: optimum = %0.8f, time = %0.2fs" in src and "math.ceil(math.log(m))" in src   # :148, :11
