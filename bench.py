@@ -108,6 +108,9 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         torch.cuda.init()
+        if N == 1:                               # --force-comm outside a launcher: a one-rank rendezvous of its own
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517")):
+                os.environ.setdefault(k, v)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from manisdp_matlab_amd import _lib, problems

@@ -285,6 +285,8 @@ int msdp_get_dual_slack(msdp_handle h, double* S);
  *   "escape_deflate" 1/0 escape: deflate span(Y) at near-stationary points (default 1).  Fast, but only as accurate as
  *                       S*Y is small; a caller about to DECLARE optimality re-checks lambda_min with 0 (see solvers.py)
  *   "escape_warm"  1/0  escape: start from what the previous call found (default 1; 0 = hashed random start vector)
+ *   "lanczos_onesync" 1/0  undeflated persistent Lanczos runs use one grid synchronisation per step (default 1; 0 = the
+ *                       two-synchronisation kernel the deflated runs use)
  *   "dense_pack"   1/0  dense C*U reads the MFMA-fragment-ordered copy of C (default 1; 0 = the row-major one;
  *                       bit-identical results, for A/B timing)
  *   "timing", "esc_debug"  1/0  diagnostics on stderr                                (env MSDP_TIMING, MSDP_ESC_DEBUG)

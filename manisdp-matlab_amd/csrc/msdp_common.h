@@ -122,6 +122,7 @@ struct Tuning {
     int timing = 0;        // per-call timing lines on stderr                                       (MSDP_TIMING=1)
     int esc_debug = 0;     // per-run Lanczos statistics on stderr                                  (MSDP_ESC_DEBUG=1)
     int escape_deflate = 1;  // escape: deflate span(Y) at near-stationary points (fast, approximate when S*Y != 0)
+    int lanczos_onesync = 1;  // undeflated persistent Lanczos runs: one grid synchronisation per step (0: two)
     int dense_pack = 1;    // dense C*U reads the fragment-ordered copy of C (0: the row-major one; same results)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
     int fail_persist = 0;  // test hook (msdp_set_option "debug_fail_persist"): the next persistent launch reports a

@@ -610,8 +610,9 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     const int qcap = p + k + 1;
     double* mem = nullptr;
     const size_t slot_doubles = msdp_lanczos_slot_bytes() / sizeof(double);
-    // [prev | Q | V | Z | w | alpha | beta | hbuf | X | slots | err]; prev (n doubles) = warm start kept between calls
-    const size_t total = (size_t)n + (size_t)(qcap + maxit + 2 + qcap) * n + (size_t)n + 2 * (size_t)(maxit + 2) + 4096 + (size_t)n + slot_doubles + 16;
+    // [prev | Q | V | Z | w | alpha | beta | hbuf | X | slots | err]; prev (n doubles) = warm start kept between calls;
+    // X = 4 n doubles: the exchange buffers of the persistent Lanczos kernels (msdp_lanczos.hip)
+    const size_t total = (size_t)n + (size_t)(qcap + maxit + 2 + qcap) * n + (size_t)n + 2 * (size_t)(maxit + 2) + 4096 + 4 * (size_t)n + slot_doubles + 16;
     if (h->esc_cap < total) {
         // grow with head room for 16 more factor columns: the factor width changes every outer iteration and a
         // reallocation of this size stalls the stream for ~0.1 s
@@ -637,7 +638,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     double* dbeta = dalpha + (maxit + 2);
     c.hbuf = dbeta + (maxit + 2);
     c.X = c.hbuf + 4096;
-    c.slots = reinterpret_cast<unsigned long long*>(c.X + n);
+    c.slots = reinterpret_cast<unsigned long long*>(c.X + 4 * (size_t)n);
     // the slots proper live in uncached device memory (sc1 accesses skip the L2 look-up: -0.75 us per grid reduction,
     // tools/microbench_sync.hip); the workspace copy above is the fallback
     if (!h->lz_slots) {
@@ -646,7 +647,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         else (void)hipGetLastError();
     }
     if (h->lz_slots) c.slots = h->lz_slots;
-    c.err = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(c.X + n) + slot_doubles);   // always in the workspace
+    c.err = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(c.X + 4 * (size_t)n) + slot_doubles);   // always in the workspace
     int rc = 0, r = 0, nfound = 0, total_steps = 0;
     double lam_max = -1e300;
     const dim3 gr((n + 255) / 256), bl(256);

@@ -335,6 +335,151 @@ __global__ __launch_bounds__(LZ_PB) void k_lanczos_persist(LzArgs a) {
     }
 }
 
+// Undeflated runs (nq = 0: the first escape call of a solve and the independent lambda_min check that precedes
+// "Optimality is reached!" -- 33 000 steps on G81) with ONE grid synchronisation per step.  Before the reduction a
+// workgroup knows w' = S*v_j - beta_j*v_{j-1} on its rows; it publishes those rows AND its rows of v_j, and reduces
+// v_j'w', |w'|^2 and |v_j|^2 together.  After the reduction alpha = v_j'w' / |v_j|^2 and
+// beta_{j+1}^2 = |w' - alpha*v_j|^2 = |w'|^2 - alpha^2 |v_j|^2 exactly, whatever the norm of v_j is (with the norm
+// ASSUMED to be 1 a deviation eps of |v_j|^2 comes back as (alpha/beta)^2 * eps in |v_{j+1}|^2 -- a factor of four per
+// step for a spectrum in [0, lambda_max]: measured, theta = -0.62 on G81).  alpha^2 and beta^2 are of the same order
+// for a Lanczos process, so the difference keeps its digits; when it does not (beta^2 < 1e-8*|w'|^2: breakdown) the
+// step falls back to a second reduction of the exact norm.  A neighbour
+// entry of the NEW vector is formed where it is needed from the two published values,
+// v_{j+1}[c] = (w'[c] - alpha*v_j[c]) / beta_{j+1}, with the same operations the owner of row c uses: bit-identical,
+// no recurrence through S (a recurrence S*v_{j+1} = (S*w' - alpha*S*v_j)/beta would amplify rounding errors by
+// alpha/beta per step).  The exchange buffers alternate with the parity of j: the rows a workgroup overwrites were last
+// read before the previous synchronisation.
+__device__ __forceinline__ double lz_next(double wv, double vv, double alpha, double inv) { return fma(-alpha, vv, wv) * inv; }
+
+__global__ __launch_bounds__(LZ_PB) void k_lanczos_plain(LzArgs a) {
+    __shared__ double vals[LZ_NV], tot[LZ_NV], part[LZ_PWAVES * LZ_NV], red[3 * LZ_PWAVES], flag[8];
+    const unsigned q = (unsigned)a.n / (unsigned)a.G, rem = (unsigned)a.n - q * (unsigned)a.G;
+    const unsigned b = blockIdx.x;
+    const int lo = (int)(b * q + (b < rem ? b : rem));
+    const int hi = lo + (int)q + (b < rem ? 1 : 0);
+    const int nrow = hi - lo;
+    __amdgpu_buffer_rsrc_t rs_slots = __builtin_amdgcn_make_buffer_rsrc(a.slots, 0, (unsigned)(LZ_GEN * LZ_GMAX * LZ_NV * 8), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a.X, 0, (unsigned)a.n * 32u, 0x00020000);   // [w' even | w' odd | v even | v odd]
+    __amdgpu_buffer_rsrc_t rs_v0 = __builtin_amdgcn_make_buffer_rsrc(a.V + (size_t)a.m0 * a.n, 0, (unsigned)a.n * 8u, 0x00020000);
+    const unsigned nb = (unsigned)a.n * 8u;
+    double v[LZ_RMAX], vp[LZ_RMAX], w[LZ_RMAX], zr[LZ_RMAX], xn[LZ_RMAX][LZ_KREG];
+    int rc[LZ_RMAX][LZ_KREG], cnt[LZ_RMAX], kbeg[LZ_RMAX];
+    double rvv[LZ_RMAX][LZ_KREG];
+#pragma unroll
+    for (int r = 0; r < LZ_RMAX; ++r) {
+        const int t = threadIdx.x + r * LZ_PB;
+        const bool ok = t < nrow;
+        v[r] = ok ? a.V[(size_t)a.m0 * a.n + lo + t] : 0.0;
+        vp[r] = (ok && a.m0 > 0) ? a.V[(size_t)(a.m0 - 1) * a.n + lo + t] : 0.0;
+        zr[r] = ok ? a.z[lo + t] : 0.0;
+        w[r] = 0.0;
+        cnt[r] = 0; kbeg[r] = 0;
+        const int s0 = ok ? a.rp[lo + t] : 0, s1 = ok ? a.rp[lo + t + 1] : 0;
+        cnt[r] = s1 - s0; kbeg[r] = s0;
+#pragma unroll
+        for (int u = 0; u < LZ_KREG; ++u) {
+            const bool in = s0 + u < s1;
+            rc[r][u] = in ? a.ci[s0 + u] : lo;
+            rvv[r][u] = in ? a.cv[s0 + u] : 0.0;
+            xn[r][u] = lz_ld_sc1(rs_v0, (unsigned)rc[r][u] * 8u);            // neighbour entries of v_{m0} (previous launch / host)
+        }
+    }
+    double beta = a.m0 > 0 ? a.dbeta[a.m0] : 0.0;
+    double alpha_prev = 0.0, inv_prev = 0.0;          // the scalars that turn the published (w', v) of step m-1 into v_m
+    unsigned gen = 0;
+    for (int m = a.m0; m < a.m1; ++m) {
+        const unsigned par = (unsigned)(m & 1), ppar = par ^ 1u;
+        const bool first = m == a.m0;
+        // ---- w' = S*v_m - beta_m*v_{m-1} on my rows; publish w' and v_m; partials of alpha and |w'|^2
+        double al = 0.0, ww = 0.0, vv = 0.0;
+#pragma unroll
+        for (int r = 0; r < LZ_RMAX; ++r) {
+            const int t = threadIdx.x + r * LZ_PB;
+            if (t < nrow) {
+                double acc = 0.0;
+                vv = fma(v[r], v[r], vv);
+#pragma unroll
+                for (int u = 0; u < LZ_KREG; ++u) acc = fma(rvv[r][u], xn[r][u], acc);
+                for (int k = kbeg[r] + LZ_KREG; k < kbeg[r] + cnt[r]; ++k) {       // rows longer than LZ_KREG entries
+                    const unsigned off = (unsigned)a.ci[k] * 8u;
+                    const double x = first ? lz_ld_sc1(rs_v0, off)
+                                           : lz_next(lz_ld_sc1(rs_x, ppar * nb + off), lz_ld_sc1(rs_x, (2u + ppar) * nb + off), alpha_prev, inv_prev);
+                    acc = fma(a.cv[k], x, acc);
+                }
+                const double wv = acc - zr[r] * v[r] - beta * vp[r];
+                w[r] = wv;
+                al = fma(wv, v[r], al);
+                ww = fma(wv, wv, ww);
+                lz_st_sc1_u64(rs_x, par * nb + (unsigned)(lo + t) * 8u, (unsigned long long)__double_as_longlong(wv));
+                lz_st_sc1_u64(rs_x, (2u + par) * nb + (unsigned)(lo + t) * 8u, (unsigned long long)__double_as_longlong(v[r]));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my rows are performed before my workgroup posts
+        al = msdp_wave_sum(al);
+        ww = msdp_wave_sum(ww);
+        vv = msdp_wave_sum(vv);
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = al; red[LZ_PWAVES + (threadIdx.x >> 6)] = ww; red[2 * LZ_PWAVES + (threadIdx.x >> 6)] = vv; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double s2 = 0.0;
+            for (int i = 0; i < LZ_PWAVES; ++i) s2 += red[threadIdx.x * LZ_PWAVES + i];
+            vals[threadIdx.x] = s2;
+        }
+        if (!lz_sync(rs_slots, gen++, a.G, 3, vals, tot, part, flag, a.err)) return;
+        const double w2 = tot[1], v2 = tot[2];
+        const double alpha = v2 > 0.0 ? tot[0] / v2 : 0.0;
+        double n2 = w2 - alpha * alpha * v2;
+        __syncthreads();                                           // tot[] read by everyone before the next reduction reuses it
+        if (!(n2 >= 1e-8 * w2)) {
+            // (near) breakdown: the difference has lost its digits -- reduce the exact norm (uniform branch: every
+            // workgroup holds the same bits of alpha and |w'|^2)
+            double nn = 0.0;
+#pragma unroll
+            for (int r = 0; r < LZ_RMAX; ++r)
+                if ((int)threadIdx.x + r * LZ_PB < nrow) { const double x = fma(-alpha, v[r], w[r]); nn = fma(x, x, nn); }
+            nn = msdp_wave_sum(nn);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nn;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double s2 = 0.0;
+                for (int i = 0; i < LZ_PWAVES; ++i) s2 += red[i];
+                vals[0] = s2;
+            }
+            if (!lz_sync(rs_slots, gen++, a.G, 1, vals, tot, part, flag, a.err)) return;
+            n2 = tot[0];
+            __syncthreads();
+        }
+        const double bnew = sqrt(n2 > 0.0 ? n2 : 0.0);
+        const double inv = bnew > 0.0 ? 1.0 / bnew : 0.0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.dalpha[m] = alpha; a.dbeta[m + 1] = bnew; }
+        // ---- v_{m+1} on my rows and, for the next product, at my rows' neighbours
+        const bool more = m + 1 < a.m1;
+#pragma unroll
+        for (int r = 0; r < LZ_RMAX; ++r) {
+            const int t = threadIdx.x + r * LZ_PB;
+            if (t < nrow) {
+                const double vn = lz_next(w[r], v[r], alpha, inv);
+                vp[r] = v[r];
+                v[r] = vn;
+                a.V[(size_t)(m + 1) * a.n + lo + t] = vn;
+                if (more) {
+                    double xw[LZ_KREG], xv[LZ_KREG];
+#pragma unroll
+                    for (int u = 0; u < LZ_KREG; ++u) {
+                        const unsigned off = (unsigned)rc[r][u] * 8u;
+                        xw[u] = lz_ld_sc1(rs_x, par * nb + off);
+                        xv[u] = lz_ld_sc1(rs_x, (2u + par) * nb + off);
+                    }
+#pragma unroll
+                    for (int u = 0; u < LZ_KREG; ++u) xn[r][u] = lz_next(xw[u], xv[u], alpha, inv);
+                }
+            }
+        }
+        alpha_prev = alpha; inv_prev = inv;
+        beta = bnew;
+    }
+}
+
 // ---------------------------------------------------------------- host side
 static int lz_grid(int n, int nq, int* RW_out, size_t* lds_out) {
     static int cus = -1;
@@ -385,6 +530,11 @@ int msdp_lanczos_persist_run(msdp_handle h, const double* z, const double* Q, in
     a.Q = Q; a.V = V; a.X = X; a.dalpha = dalpha; a.dbeta = dbeta; a.slots = slots; a.err = err;
     hipLaunchKernelGGL(k_lz_reset, dim3(64), dim3(256), 0, h->stream, slots, err);
     HIPCHK(hipGetLastError());
+    if (nq == 0 && h->tune.lanczos_onesync) {                 // X holds 4 n doubles (msdp_escape.hip)
+        hipLaunchKernelGGL(k_lanczos_plain, dim3(a.G), dim3(LZ_PB), 0, h->stream, a);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_lanczos_persist, dim3(a.G), dim3(LZ_PB), lds, h->stream, a);
     HIPCHK(hipGetLastError());
     return 0;

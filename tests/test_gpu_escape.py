@@ -88,3 +88,34 @@ def test_solver_with_device_escape(lib):
     Y, obj, data = solvers.ManiSDP_onlyunitdiag(C, {"eig": "device"}, verbose=False)
     assert data["dinf"] < 1e-8
     assert abs(-obj - known["maxG11"]) < 1e-6 * known["maxG11"]
+
+
+def test_onesync_lanczos_matches_twosync_kernel(lib):
+    """Undeflated persistent Lanczos runs: the one-synchronisation kernel (beta from |w'|^2 - alpha^2 |v|^2, neighbour
+    entries rebuilt from the published pair) against the two-synchronisation kernel on the same S (toroidal grid, n = 6000)
+    and against LAPACK."""
+    from manisdp_matlab_amd import problems
+    C = problems.toroidal_grid_maxcut(60, 100, seed=9)
+    n, p = C.shape[0], 8
+    rng = np.random.default_rng(4)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    out = []
+    for one in (1, 0):
+        h = lib.Handle.onlyunitdiag(C)
+        h.set_option("lanczos_onesync", one)
+        h.set_option("escape_deflate", 0)
+        h.set_option("escape_warm", 0)
+        h.set_point(Y)
+        lam, V, lmax, steps = h.escape_eigs(1, tol=1e-10, maxit=20000)
+        _, conv, _ = h.escape_info()
+        z = h.get_z()
+        out.append((lam[0], lmax, V[:, 0].copy(), conv))
+        h.close()
+    S = (C - __import__("scipy.sparse", fromlist=["diags"]).diags(z)).toarray()
+    w = np.linalg.eigvalsh(S)
+    for lam0, lmax, v, conv in out:
+        assert conv
+        assert abs(lam0 - w[0]) <= 1e-8 * max(1.0, abs(w[-1]))
+        assert abs(lmax - w[-1]) <= 1e-6 * abs(w[-1])
+        assert np.linalg.norm(S @ v - lam0 * v) <= 1e-6 * abs(w[-1])
+    assert abs(out[0][0] - out[1][0]) <= 1e-9 * abs(w[-1])
