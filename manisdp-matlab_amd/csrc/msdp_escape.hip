@@ -180,11 +180,39 @@ static int sturm_count(const std::vector<double>& a, const std::vector<double>& 
     }
     return cnt;
 }
+// Sturm counts at NS shifts in one pass: the recurrence is a chain of dependent divisions (m of them, ~5 ns each), so
+// eight independent chains cost little more than one -- the bisection below then cuts its bracket nine-fold per pass
+// (15 passes instead of 47 for the 1e-14 bracket of a checkpoint; the host analysis was a third of a long Lanczos run).
+#define STURM_NS 8
+static void sturm_count_multi(const std::vector<double>& a, const std::vector<double>& b, int m, const double* x, int* cnt) {
+    double q[STURM_NS];
+    for (int s = 0; s < STURM_NS; ++s) { q[s] = a[0] - x[s]; cnt[s] = q[s] < 0 ? 1 : 0; }
+    for (int i = 1; i < m; ++i) {
+        const double bb = b[i - 1] * b[i - 1], ai = a[i];
+        for (int s = 0; s < STURM_NS; ++s) {
+            const double den = fabs(q[s]) < 1e-300 ? (q[s] < 0 ? -1e-300 : 1e-300) : q[s];
+            q[s] = ai - x[s] - bb / den;
+            cnt[s] += q[s] < 0 ? 1 : 0;
+        }
+    }
+}
 static double tri_eig_kth(const std::vector<double>& a, const std::vector<double>& b, int m, int kth, double lo, double hi,
                           double abstol = 0.0) {
     for (int it = 0; it < 200 && hi - lo > 4e-16 * std::max(fabs(lo), fabs(hi)) + 1e-300 + abstol; ++it) {
-        const double mid = 0.5 * (lo + hi);
-        if (sturm_count(a, b, m, mid) > kth) hi = mid; else lo = mid;
+        if (m < 256) {                                   // short recurrences: plain bisection
+            const double mid = 0.5 * (lo + hi);
+            if (sturm_count(a, b, m, mid) > kth) hi = mid; else lo = mid;
+            continue;
+        }
+        double x[STURM_NS]; int cnt[STURM_NS];
+        const double hstep = (hi - lo) / (STURM_NS + 1);
+        for (int s = 0; s < STURM_NS; ++s) x[s] = lo + hstep * (s + 1);
+        sturm_count_multi(a, b, m, x, cnt);
+        // the k-th eigenvalue lies between the last shift with count <= kth and the first one with count > kth
+        double nlo = lo, nhi = hi;
+        for (int s = 0; s < STURM_NS; ++s) { if (cnt[s] > kth) { nhi = x[s]; break; } nlo = x[s]; }
+        if (!(nhi - nlo < hi - lo)) break;               // the bracket no longer shrinks (rounding)
+        lo = nlo; hi = nhi;
     }
     return 0.5 * (lo + hi);
 }
@@ -329,9 +357,10 @@ struct EscCtx {
     const double* z;
     double* hbuf;
     const double* M;     // explicit dense S (n x nS, device) for the affine kinds; nullptr: S = C - diag(z)
-    double* X;           // persistent Lanczos: exchange buffer (n), grid-sync slots, error flag
+    double* X;           // persistent Lanczos: exchange buffers (4 n), grid-sync slots, error flag
     unsigned long long* slots;
     int* err;
+    double host_analysis_s = 0.0;   // time the host spent analysing T_m at the checkpoints (esc_debug statistics)
 };
 
 static int sapply(EscCtx& c, const double* v, double* w) {
@@ -459,6 +488,8 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
                 HIPCHK(hipMemcpy(&perr, c.err, sizeof(int), hipMemcpyDeviceToHost));
                 if (perr) { msdp_set_error("persistent Lanczos: grid synchronisation timed out"); return MSDP_EHIP; }
             }
+            const auto t_an0 = std::chrono::steady_clock::now();
+            struct AnTimer { std::chrono::steady_clock::time_point t0; double* acc; ~AnTimer() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } an_timer{t_an0, &c.host_analysis_s};
             // T_m: diagonal a[0..m-1], couplings b[1..m-1]; b[m] closes the residual
             std::vector<double> off(m);
             for (int i = 0; i + 1 < m; ++i) off[i] = b[i + 1];
@@ -703,7 +734,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
                 h->esc_converged = 0;
                 h->esc_maxres = std::max(h->esc_maxres, res / (std::max(fabs(theta), fabs(lmx)) + 1e-300));
             }
-            if (dbg) fprintf(stderr, "[escape] run at t=%d: nq=%d steps=%d theta=%.6e res=%.2e lmax=%.4f accepted=%d\n", t, r, m, theta, res, lmx, nacc);
+            if (dbg) fprintf(stderr, "[escape] run at t=%d: nq=%d steps=%d theta=%.6e res=%.2e lmax=%.4f accepted=%d (host checkpoint analysis so far %.1f ms)\n", t, r, m, theta, res, lmx, nacc, 1e3 * c.host_analysis_s);
             lam_max = std::max(lam_max, lmx);
             for (int i = 0; i < nacc; ++i) found.push_back(thetas[i]);
             r += nacc; nfound += nacc; t += nacc;
