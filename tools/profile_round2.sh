@@ -29,6 +29,8 @@ stats k5shard 300 python3 "$ROOT/tools/dense_probe.py" 100000 64 --shard 8
 stats bqp60_p32 300 python3 "$ROOT/tools/gram_probe.py" 32
 stats bqp60_p300 300 python3 "$ROOT/tools/gram_probe.py" 300
 stats theta5000 300 python3 "$ROOT/tools/theta_probe.py" 32
+stats g81_kkt 300 python3 "$ROOT/tools/g81_escape_profile.py"
+stats dual30 300 python3 "$ROOT/tools/dual_probe.py" 30
 cd "$ROOT"
 python3 tools/pmc_to_json.py k_hess_ "$OUT/pmc_hess_g81_p32.json" "$OUT/fetch" "$OUT/write"
 python3 tools/pmc_to_json.py k_tcg_persist_obl "$OUT/pmc_persist_g81_p32.json" --per 64 "$OUT/fetch" "$OUT/write"
