@@ -470,7 +470,6 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_retract_obl(Dev d) {
 // ------------------------------------------------------------------ RTR scalars
 // trustregions.m:405-409 after the first cost/grad.
 __global__ __launch_bounds__(MSDP_BLOCK) void k_rtr_begin(Dev d) {
-    __shared__ double sh[3 * MSDP_WAVES];
     const double f = msdp_sum_partials(d.P, P_F, d.G);
     const double gg = msdp_sum_partials(d.P, P_GG, d.G);
     if (threadIdx.x == 0) {
@@ -486,7 +485,6 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_rtr_begin(Dev d) {
 
 // trustregions.m:548-729: rho, radius update, accept/reject, stopping test.
 __global__ __launch_bounds__(MSDP_BLOCK) void k_rtr_decide(Dev d) {
-    __shared__ double sh[3 * MSDP_WAVES];
     if (d.ctl->done) return;
     const double fp = msdp_sum_partials(d.P, P_F, d.G);
     const double ggp = msdp_sum_partials(d.P, P_GG, d.G);
@@ -588,7 +586,6 @@ __global__ void k_set_frame_active(Dev d, int active) {
     }
 }
 __global__ void k_sum_to(Dev d, int which, double* out) {
-    __shared__ double sh[3 * MSDP_WAVES];
     const double s = msdp_sum_partials(d.P, which, d.G);
     if (threadIdx.x == 0) *out = s;
 }
