@@ -172,3 +172,36 @@ def test_dual_example_size_d30(lib):
     _, objo, datao = R.ManiDSDP_unitdiag(A, b, c, K, dict(o))
     assert datao["status"] == 0
     assert abs(obj - objo) * maxb <= 1e-6 * max(1.0, abs(objo) * maxb)
+
+
+def test_dual_without_free_variables_and_width_limit(lib):
+    """K.f = 0 (no free block: B, c_f, w absent) against the oracle's closures, and the documented width limit of the
+    dual kind (p <= 128) reported as an error, not a wrong answer."""
+    import scipy.sparse as sp
+    from oracle import manisdp_ref as R
+    _, _, A, b, c, K, dAAt, _ = _dual_data(7, seed=11)
+    n = K["s"]
+    Apsd = sp.csr_matrix(sp.csc_matrix(A)[:, 1:])
+    rng = np.random.default_rng(0)
+    cpsd = rng.standard_normal((n, n)); cpsd = 0.1 * (cpsd + cpsd.T)
+    p = 9
+    prob = R._DualUnitDiagProblem(Apsd, sp.csr_matrix((b.size, 0)), b, cpsd.ravel(order="F"), np.zeros(0), dAAt, n, p)
+    prob.sigma = 0.8
+    h = lib.Handle.dual_unitdiag(Apsd, b, cpsd.ravel(order="F"), dAAt, None, None)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = prob.M.proj(Y, rng.standard_normal((n, p)))
+    h.dual_set_penalty(0.8)
+    h.set_point(Y)
+    f_ref = prob.cost(Y)
+    assert abs(h.cost() - f_ref) <= 1e-11 * max(1.0, abs(f_ref))
+    assert _relerr(h.rgrad(), prob.grad(Y)) < 1e-11
+    assert _relerr(h.hessvec(U), prob.hess(Y, U)) < 1e-11
+    by, cex, as2, Af, z = h.dual_outer_step()
+    assert Af.size == 0 and abs(by - b @ prob.parts(Y)[2]) < 1e-11 * max(1.0, abs(by))
+    # width limit
+    Yw = rng.standard_normal((n, 140)); Yw /= np.linalg.norm(Yw, axis=1, keepdims=True)
+    h.dual_set_penalty(0.8)
+    h.set_point(Yw)
+    with pytest.raises(lib.MsdpError, match="exceeds the supported maximum"):
+        h.cost()
+    h.close()
