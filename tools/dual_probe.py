@@ -8,6 +8,10 @@ args = sys.argv[1:]
 with_oracle = "--oracle" in args
 if with_oracle:
     args.remove("--oracle")
+eig = None
+for a in list(args):
+    if a.startswith("--eig="):
+        eig = a.split("=", 1)[1]; args.remove(a)
 for d in [int(a) for a in args]:
     rng = np.random.default_rng(1)
     Q = rng.standard_normal((d, d)); Q = (Q + Q.T) / 2
@@ -16,6 +20,8 @@ for d in [int(a) for a in args]:
     A, b, c, K, dAAt, maxb = problems.bqpsos_dual_problem(Q, e, d)
     tg = time.time() - t
     o = {"tol": 1e-8, "dAAt": dAAt, "line_search": 1}
+    if eig:
+        o["eig"] = eig
     t = time.time()
     _, obj, data = solvers.ManiDSDP_unitdiag(A, b, c, K, dict(o), verbose=False)
     ts = time.time() - t
