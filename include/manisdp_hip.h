@@ -173,6 +173,10 @@ int msdp_set_multipliers(msdp_handle h, const double* y, double sigma);
 /* Upload the current point in the reference layout (see header comment). */
 int msdp_set_point(msdp_handle h, int32_t p, const double* Y);
 int msdp_get_point(msdp_handle h, double* Y);
+/* Row-sharded handles (msdp_comm_init): every row of the resident point on EVERY rank (one all-gather, then the
+ * download).  The host loops of the row-sharded affine kinds run replicated on all ranks and take their rank / escape
+ * decisions on identical data.  Without a communicator: the same as msdp_get_point. */
+int msdp_get_point_all(msdp_handle h, double* Y);
 int msdp_get_p(msdp_handle h, int32_t* p);
 /* MSDP_KIND_* of the handle: tells a binding which factor layout the handle expects at the boundary
  * (p x n for ONLYUNITDIAG / UNITDIAG, n x p for UNITTRACE / GENERIC) without guessing from array shapes. */

@@ -82,6 +82,7 @@ SIGNATURES = {
     "msdp_escape_info": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _dp]),
     "msdp_escape_lower_bound": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_dual_slack": (C.c_int, [C.c_void_p, _dp]),
+    "msdp_get_point_all": (C.c_int, [C.c_void_p, _dp]),
     "msdp_create_dual_unitdiag": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, _dp, C.c_int32, _i64p, _i64p, _dp,
                                             _dp, C.c_int32, C.POINTER(C.c_void_p)]),
     "msdp_dual_set_penalty": (C.c_int, [C.c_void_p, C.c_double, _dp]),
@@ -318,6 +319,12 @@ class Handle:
     def get_point(self):
         out = self._empty()
         _check(self._lib.msdp_get_point(self._h, _dptr(out)))
+        return np.ascontiguousarray(out)
+
+    def get_point_all(self):
+        """All n rows of the resident point on every rank of a row-sharded handle (one all-gather + download)."""
+        out = self._empty()
+        _check(self._lib.msdp_get_point_all(self._h, _dptr(out)))
         return np.ascontiguousarray(out)
 
     def set_multipliers(self, y, sigma):

@@ -22,6 +22,9 @@
 int msdp_dev_alloc_bytes(msdp_handle h, void** out, size_t bytes);
 int msdp_dense_nS(int n);
 int msdp_k_sum_to_fwd(msdp_handle h, int which, double* out);
+int msdp_allreduce_partials(msdp_handle h, int first, int count);          // msdp_api.hip
+int msdp_allgather_rows(msdp_handle h, const double* local_rows);
+int msdp_allgather_vec(msdp_handle h, const double* local, double* all, size_t count_per_rank);
 int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const double* const* X, const double* scale,
                     const int* active_flag, const double** slab_out, int64_t* stride_out, int* SK_out);
 
@@ -609,7 +612,8 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_obl_grad_finish(Dev d, int slot,
     const double ss = msdp_sum_partials_block(d.P, P_AXB, MSDP_MAX_GRID, sh);
     __syncthreads();
     double pf = 0.0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) pf = f_given ? *f_given : cx + 0.5 * sigma * ss;   // f_given: the dual kind's cost
+    // f_given: the dual kind's cost.  Row-sharded runs: the value enters the all-reduced sum once (rank 0)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && d.row0 == 0) pf = f_given ? *f_given : cx + 0.5 * sigma * ss;
     msdp_put_partials3(d.P, P_F, pf, P_GG, pgg, -1, 0.0, sh + 8);
 }
 
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_grad_finish(Dev d, int slot,
         pgg += gq.x * gq.x + gq.y * gq.y;
     }
     double pf = 0.0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { pf = cx + 0.5 * sigma * ss; d.ctl->z_sphere[slot] = z; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { if (d.row0 == 0) pf = cx + 0.5 * sigma * ss; d.ctl->z_sphere[slot] = z; }
     msdp_put_partials3(d.P, P_F, pf, P_GG, pgg, -1, 0.0, sh + 8);
 }
 
@@ -1042,6 +1046,27 @@ static int launch_support_spmm(msdp_handle h, const AffineDev& a, const double* 
 
 
 // cost + gradient state at Y[slot]:  w = A(YY'), Axb, eS, eS*Y, C*Y  (see header comment)
+// ------------------------------------------------------------------ Row sharding of the affine kinds
+// The rows of Y, U, G, H are split over the ranks as for the other kinds; the OPERATOR state is replicated: every rank
+// holds At, the dense eS / AyU / S and computes A(Ya Yb'), Axb and the adjoint for the whole matrix itself -- the same
+// kernels on the same inputs give the same bits on every rank, so no m-vector travels (for BQP d = 60 an all-reduce of
+// the 9-MB A(U Y') per Hess-vec would cost more than recomputing it: 17 us).  What is shared is the dense contraction
+// (each rank multiplies ITS rows of eS / AyU with the gathered panel) and every row-parallel kernel; their partial sums
+// are all-reduced like those of the other kinds.  The operators read all rows of the point: yfull[slot] keeps the
+// gathered copy of Y[slot] (the Hess-vec needs it next to the gathered direction).
+static bool sharded(msdp_handle h) { return h->use_comm || h->nranks > 1; }
+// All n rows of Y[slot].  `gathered`: d.full holds them right now (the caller's all-gather) -> refresh the copy.
+static int full_rows(msdp_handle h, int slot, const double* local, bool gathered, const double** out) {
+    if (!sharded(h)) { *out = local; return 0; }
+    if (!h->yfull[slot]) { msdp_set_error("row-sharded affine handle without gather buffers"); return MSDP_ESTATE; }
+    if (!gathered) { int rc = msdp_allgather_rows(h, local); if (rc) return rc; }
+    const size_t cap = (size_t)((h->d.n + h->nranks - 1) / h->nranks);
+    HIPCHK(hipMemcpyAsync(h->yfull[slot], h->d.full, cap * h->nranks * (size_t)h->d.ld * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    *out = h->yfull[slot];
+    return 0;
+}
+static const double* kept_rows(msdp_handle h, int slot) { return sharded(h) ? h->yfull[slot] : h->d.Y[slot]; }
+
 static int dual_costgrad(msdp_handle h, AffineState* st, int slot);
 static int dual_hess(msdp_handle h, AffineState* st);
 static int dual_linesearch_cost(msdp_handle h, AffineState* st, const double* Yt, double* val);
@@ -1054,21 +1079,24 @@ int msdp_affine_costgrad(msdp_handle h, int slot) {
     AffineDev a = st->a;
     a.p = d.p; a.ld = d.ld;
     const double sigma = st->sigma;
-    const double* Ys = d.Y[slot];
+    const double* Ys = d.Y[slot];                         // my rows
+    const double* Yf = nullptr;                           // all rows (the caller, msdp_launch_costgrad, has gathered them)
+    { int rcf = full_rows(h, slot, Ys, true, &Yf); if (rcf) return rcf; }
+    const size_t roff = (size_t)d.row0 * a.nS;            // my rows of the replicated n x nS matrices
     const int* done = &d.ctl->done;
-    { int rc0 = launch_A(h, a, st->nnz, Ys, Ys, done, 1, 1, a.Axb[slot], sigma); if (rc0) return rc0; }
+    { int rc0 = launch_A(h, a, st->nnz, Yf, Yf, done, 1, 1, a.Axb[slot], sigma); if (rc0) return rc0; }
     { int rca = launch_adjoint(h, a, d.Cd, a.Axb[slot], sigma, d.eS[slot], done, 1, true); if (rca) return rca; }
     // c'x = <C*Y, Y>
     const double* slab; int64_t stride; int SK;
     {
-        const double* M[1] = {d.Cd}; const double* X[1] = {Ys}; const double sc[1] = {1.0};
+        const double* M[1] = {d.Cd + roff}; const double* X[1] = {Yf}; const double sc[1] = {1.0};
         int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
         if (rc) return rc;
         DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 1.0, (double*)nullptr, (double*)nullptr, P_S1);
         HIPCHK(hipGetLastError());
     }
     // eG = 2*eS*Y -> Gr[slot]; row dots (YeG = sum(Y.*eG)) and their total (2z)
-    if (a.nsup > 0 && h->nranks == 1 && d.ld <= 512) {
+    if (a.nsup > 0 && !sharded(h) && d.ld <= 512) {
         // At touches few entries: eS*Y = C*Y (the slabs just computed) + sigma * (A'(Axb) on those entries) * Y,
         // appended as one more slab -- one dense product per cost/gradient evaluation instead of two
         double* extra = const_cast<double*>(slab) + (int64_t)SK * stride;
@@ -1078,12 +1106,13 @@ int msdp_affine_costgrad(msdp_handle h, int slot) {
         DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 2.0, d.Gr[slot], d.eG[slot], P_S2);
         HIPCHK(hipGetLastError());
     } else {
-        const double* M[1] = {d.eS[slot]}; const double* X[1] = {Ys}; const double sc[1] = {1.0};
+        const double* M[1] = {d.eS[slot] + roff}; const double* X[1] = {Yf}; const double sc[1] = {1.0};
         int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
         if (rc) return rc;
         DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 2.0, d.Gr[slot], d.eG[slot], P_S2);
         HIPCHK(hipGetLastError());
     }
+    { int rcr = msdp_allreduce_partials(h, P_S1, 2); if (rcr) return rcr; }      // <C*Y, Y> and the row dots over all ranks
     if (d.manifold == MANI_OBLIQUE) {
         DISPATCH_LPR_A(k_obl_grad_finish, h, d.G, d, slot, sigma, (const double*)nullptr);
     } else {
@@ -1103,11 +1132,15 @@ int msdp_affine_hess(msdp_handle h) {
     const double sigma = st->sigma;
     const int cur = h->h_ctl->cur;
     const int* act = &d.F[0].active;
+    // all rows of the point (kept since its cost/gradient evaluation) and of the direction (gathered by msdp_launch_hess)
+    const double* Yf = kept_rows(h, cur);
+    const double* Uf = sharded(h) ? (const double*)d.full : (const double*)d.md;
+    const size_t roff = (size_t)d.row0 * a.nS;
     // w = A(Y U') ; AyU = A'(w)
-    { int rc0 = launch_A(h, a, st->nnz, d.Y[cur], d.md, act, 0, 0, (double*)nullptr, sigma); if (rc0) return rc0; }
+    { int rc0 = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 0, (double*)nullptr, sigma); if (rc0) return rc0; }
     const double* slab; int64_t stride; int SK;
     int rc;
-    if (a.nsup > 0 && h->nranks == 1 && d.ld <= 512) {
+    if (a.nsup > 0 && !sharded(h) && d.ld <= 512) {
         // At touches few entries: AyU*Y is a sparse product over those entries (appended as one more slab); only
         // 2*eS*U goes through the dense contraction
         const double* M[1] = {d.eS[cur]};
@@ -1119,8 +1152,8 @@ int msdp_affine_hess(msdp_handle h) {
         ++SK;
     } else {
         { int rca = launch_adjoint(h, a, (const double*)nullptr, a.w, 1.0, d.AyU, act, 0, true); if (rca) return rca; }
-        const double* M[2] = {d.eS[cur], d.AyU};
-        const double* X[2] = {d.md, d.Y[cur]};
+        const double* M[2] = {d.eS[cur] + roff, d.AyU + roff};
+        const double* X[2] = {Uf, Yf};
         const double sc[2] = {2.0, 4.0 * sigma};
         if ((rc = msdp_dense_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
     }
@@ -1152,6 +1185,7 @@ int msdp_sphere_hess_raw(msdp_handle h, const double* slab, int64_t stride, int 
     Dev& d = h->d;
     hipLaunchKernelGGL((k_sph_hess_raw<1, 1>), dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, d, slab, stride, SK);
     HIPCHK(hipGetLastError());
+    { int rcr = msdp_allreduce_partials(h, P_AUX, 1); if (rcr) return rcr; }     // <H_raw, Y> over all ranks
     hipLaunchKernelGGL(k_sph_hess_finish, dim3(d.G), dim3(MSDP_BLOCK), 0, h->stream, d);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1167,13 +1201,16 @@ int msdp_affine_linesearch_cost(msdp_handle h, const double* Yt, double* val) {
     a.p = d.p; a.ld = d.ld;
     const double sigma = st->sigma;
     const int other = h->h_ctl->cur ^ 1;
-    { int rc0 = launch_A(h, a, st->nnz, Yt, Yt, (const int*)nullptr, 0, 1, a.Axb[other], sigma); if (rc0) return rc0; }
+    const double* Yf = nullptr;
+    { int rcf = full_rows(h, other, Yt, false, &Yf); if (rcf) return rcf; }
+    { int rc0 = launch_A(h, a, st->nnz, Yf, Yf, (const int*)nullptr, 0, 1, a.Axb[other], sigma); if (rc0) return rc0; }
     const double* slab; int64_t stride; int SK;
-    const double* M[1] = {d.Cd}; const double* X[1] = {Yt}; const double sc[1] = {1.0};
+    const double* M[1] = {d.Cd + (size_t)d.row0 * a.nS}; const double* X[1] = {Yf}; const double sc[1] = {1.0};
     int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
     if (rc) return rc;
     DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Yt, slab, stride, SK, 1.0, (double*)nullptr, (double*)nullptr, P_S1);
     HIPCHK(hipGetLastError());
+    if ((rc = msdp_allreduce_partials(h, P_S1, 1))) return rc;
     hipLaunchKernelGGL(k_cost_only, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, d, sigma, &d.ctl->fx_prop);
     HIPCHK(hipGetLastError());
     double v = 0.0;
@@ -1206,13 +1243,16 @@ int msdp_affine_al_primal(msdp_handle h, double* obj, double* Ax_host) {
     a.p = d.p; a.ld = d.ld;
     const int cur = h->h_ctl->cur;
     const double* Ys = d.Y[cur];
-    int rc = launch_A(h, a, st->nnz, Ys, Ys, (const int*)nullptr, 0, 0, (double*)nullptr, 1.0);
+    const double* Yf = nullptr;
+    int rc = full_rows(h, cur, Ys, false, &Yf);
     if (rc) return rc;
+    if ((rc = launch_A(h, a, st->nnz, Yf, Yf, (const int*)nullptr, 0, 0, (double*)nullptr, 1.0))) return rc;
     const double* slab; int64_t stride; int SK;
-    const double* M[1] = {d.Cd}; const double* X[1] = {Ys}; const double sc[1] = {1.0};
+    const double* M[1] = {d.Cd + (size_t)d.row0 * a.nS}; const double* X[1] = {Yf}; const double sc[1] = {1.0};
     if ((rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK))) return rc;
     DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 1.0, (double*)nullptr, (double*)nullptr, P_S1);
     HIPCHK(hipGetLastError());
+    if ((rc = msdp_allreduce_partials(h, P_S1, 1))) return rc;
     if ((rc = msdp_k_sum_to_fwd(h, P_S1, &d.ctl->fx_prop))) return rc;
     double v = 0.0;
     HIPCHK(hipMemcpyAsync(&v, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1236,17 +1276,28 @@ int msdp_affine_al_dual(msdp_handle h, const double* y_host, double* z_host) {
     { int rca = launch_adjoint(h, a, d.Cd, (const double*)a.w, -1.0, d.Sdual, (const int*)nullptr, 0, false); if (rca) return rca; }
     if (d.manifold == MANI_EUCLID) { HIPCHK(hipStreamSynchronize(h->stream)); return 0; }
     // t_i = <(eS*Y)_i, Y_i>  (= sum(X.*eS) per row); their total for the sphere
-    const double* slab; int64_t stride; int SK;
-    const double* M[1] = {d.Sdual}; const double* X[1] = {Ys}; const double sc[1] = {1.0};
-    int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
+    const double* Yf = nullptr;
+    int rc = full_rows(h, cur, Ys, false, &Yf);          // also what the escape deflates against (msdp_escape.hip)
     if (rc) return rc;
+    const double* slab; int64_t stride; int SK;
+    const double* M[1] = {d.Sdual + (size_t)d.row0 * a.nS}; const double* X[1] = {Yf}; const double sc[1] = {1.0};
+    if ((rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK))) return rc;
     DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 1.0, (double*)nullptr, d.W0, P_S2);
     HIPCHK(hipGetLastError());
     if (d.manifold == MANI_OBLIQUE) {
-        hipLaunchKernelGGL(k_sub_diag, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, a.n, a.nS, d.Sdual, (const double*)d.W0, (const double*)nullptr);
+        const double* zall = d.W0;
+        if (sharded(h)) {
+            // z of all rows: one all-gather of the cap-long row blocks (the gather buffer is free here)
+            if (!h->use_comm) { msdp_set_error("al_dual on a communicator-free shard"); return MSDP_ESTATE; }
+            const size_t cap = (size_t)((d.n + h->nranks - 1) / h->nranks);
+            if ((rc = msdp_allgather_vec(h, d.W0, h->full_buf, cap))) return rc;
+            zall = h->full_buf;
+        }
+        hipLaunchKernelGGL(k_sub_diag, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, a.n, a.nS, d.Sdual, zall, (const double*)nullptr);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(z_host, d.W0, (size_t)a.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(z_host, zall, (size_t)a.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     } else {
+        if ((rc = msdp_allreduce_partials(h, P_S2, 1))) return rc;
         if ((rc = msdp_k_sum_to_fwd(h, P_S2, &d.ctl->fx_prop))) return rc;
         hipLaunchKernelGGL(k_sub_diag, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, a.n, a.nS, d.Sdual, (const double*)nullptr, (const double*)&d.ctl->fx_prop);
         HIPCHK(hipGetLastError());

@@ -139,6 +139,13 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(h->full_buf, 0, cnt * h->nranks * sizeof(double), h->stream));
         d.full = h->full_buf;
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (h->yfull[s2]) { dev_free(h, h->yfull[s2]); h->yfull[s2] = nullptr; }
+            if (d.costkind != COST_AFFINE) continue;
+            int rc2 = dev_alloc<double>(h, &h->yfull[s2], cnt * (size_t)h->nranks);
+            if (rc2) return rc2;
+            HIPCHK(hipMemsetAsync(h->yfull[s2], 0, cnt * h->nranks * sizeof(double), h->stream));
+        }
     }
     h->pcap = pcap;
     h->ldcap = ldcap;
@@ -632,6 +639,26 @@ extern "C" int msdp_get_point(msdp_handle h, double* Y) {
     return download_rows(h, h->d.Y[host_cur(h)], Y);
 }
 
+// Every row of the resident point on every rank (one all-gather, then the download): the host loops of the row-sharded
+// affine kinds run replicated on all ranks and need identical inputs for their rank / escape decisions.
+extern "C" int msdp_get_point_all(msdp_handle h, double* Y) {
+    CHECK_H(h);
+    if (!h->have_point || !Y) { msdp_set_error("get_point_all: no resident point / null out"); return MSDP_ESTATE; }
+    if (h->nranks == 1 && !h->use_comm) return download_rows(h, h->d.Y[host_cur(h)], Y);
+    if (!h->use_comm) { msdp_set_error("get_point_all: needs a communicator"); return MSDP_ESTATE; }
+    Dev& d = h->d;
+    int rc = msdp_allgather_rows(h, d.Y[host_cur(h)]);
+    if (rc) return rc;
+    const size_t cnt = (size_t)d.n * d.p;
+    double* stage = nullptr;
+    if (hipMalloc((void**)&stage, (cnt ? cnt : 1) * sizeof(double)) != hipSuccess) { msdp_set_error("staging alloc failed"); return MSDP_ENOMEM; }
+    rc = msdp_k_unpack(h, h->full_buf, stage, d.n, d.p, d.ld, boundary_colmajor(h));
+    if (!rc && hipMemcpyAsync(Y, stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess) { msdp_set_error("D2H copy failed"); rc = MSDP_EHIP; }
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(stage);
+    return rc;
+}
+
 extern "C" int msdp_get_p(msdp_handle h, int32_t* p) {
     CHECK_H(h);
     if (!p) return MSDP_EINVAL;
@@ -698,6 +725,14 @@ int msdp_allgather_rows(msdp_handle h, const double* local_rows) {
     return 0;
 }
 
+// count_per_rank doubles from every rank, in rank order
+int msdp_allgather_vec(msdp_handle h, const double* local, double* all, size_t count_per_rank) {
+    if (!h->use_comm) { msdp_set_error("allgather_vec: no communicator"); return MSDP_ESTATE; }
+    ncclResult_t r = ncclAllGather(local, all, count_per_rank, ncclDouble, (ncclComm_t)h->comm, h->stream);
+    if (r != ncclSuccess) { msdp_set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return MSDP_ECOMM; }
+    return 0;
+}
+
 extern "C" int msdp_comm_unique_id(void* id128) {
     if (!id128) return MSDP_EINVAL;
     ncclUniqueId id;
@@ -713,8 +748,8 @@ extern "C" int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const
     if (nranks < 1 || rank < 0 || rank >= nranks || !id128) { msdp_set_error("bad comm arguments"); return MSDP_EINVAL; }
     if (h->have_point) { msdp_set_error("comm_init must precede set_point"); return MSDP_ESTATE; }
     if (h->presharded && (nranks != h->nranks || rank != h->rank)) { msdp_set_error("comm_init: shard was created as rank %d of %d", h->rank, h->nranks); return MSDP_EINVAL; }
-    if (h->d.costkind == COST_AFFINE && nranks > 1) {
-        msdp_set_error("row sharding of the affine (A-operator) kinds is not implemented yet");
+    if (h->kind == MSDP_KIND_MULTIBLOCK || h->kind == MSDP_KIND_DUAL_UNITDIAG) {
+        msdp_set_error("row sharding is not implemented for the multiblock and dual kinds");
         return MSDP_EUNSUPPORTED;
     }
     ncclUniqueId id;
@@ -745,7 +780,10 @@ extern "C" int msdp_debug_shard(msdp_handle h, int32_t nranks, int32_t rank) {
     CHECK_H(h);
     if (nranks < 1 || rank < 0 || rank >= nranks) { msdp_set_error("bad shard (%d of %d)", rank, nranks); return MSDP_EINVAL; }
     if (h->have_point || h->use_comm) { msdp_set_error("debug_shard must precede set_point / comm_init"); return MSDP_ESTATE; }
-    if (h->d.costkind != COST_SPARSE) { msdp_set_error("debug_shard: sparse-C handles only"); return MSDP_EUNSUPPORTED; }
+    if (h->d.costkind == COST_DENSE || h->kind == MSDP_KIND_MULTIBLOCK || h->kind == MSDP_KIND_DUAL_UNITDIAG) {
+        msdp_set_error("debug_shard: sparse-C and affine (unitdiag / unittrace / generic) handles only");
+        return MSDP_EUNSUPPORTED;
+    }
     h->nranks = nranks;
     h->rank = rank;
     h->presharded = true;                  // lets msdp_debug_set_full_rows stand in for the all-gather
@@ -756,7 +794,7 @@ extern "C" int msdp_debug_shard(msdp_handle h, int32_t nranks, int32_t rank) {
     h->d.n_loc = r1 > h->d.row0 ? r1 - h->d.row0 : 0;
     int rc = alloc_common(h);
     if (rc) return rc;
-    if ((rc = upload_sparse_rows(h))) return rc;
+    if (h->d.costkind == COST_SPARSE && (rc = upload_sparse_rows(h))) return rc;
     return msdp_alloc_vectors(h, h->pcap);
 }
 

@@ -625,7 +625,10 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
                      int* iters_out, const double* Mdev) {
     Dev& d = h->d;
     if (!Mdev && h->kind != MSDP_KIND_ONLYUNITDIAG) { msdp_set_error("escape_eigs: affine handles pass S explicitly (msdp_escape_eigs_matrix)"); return MSDP_EUNSUPPORTED; }
-    if (h->nranks != 1) { msdp_set_error("escape_eigs: single-GPU only in this build"); return MSDP_EUNSUPPORTED; }
+    // Row-sharded handles: the escape on an explicit dense S (affine kinds) runs replicated -- every rank holds S and all
+    // rows of the point (yfull, refreshed by msdp_al_dual) and finds the same vectors; S = C - diag(z) is not sharded yet
+    const bool rep_rows = (h->nranks != 1 || h->use_comm) && Mdev && h->yfull[h->h_ctl->cur];
+    if (h->nranks != 1 && !rep_rows) { msdp_set_error("escape_eigs: single-GPU only for the onlyunitdiag kind in this build"); return MSDP_EUNSUPPORTED; }
     if (k < 1) { msdp_set_error("escape_eigs: k >= 1"); return MSDP_EINVAL; }
     const int n = d.n, p = d.p;
     if (maxit < 8) maxit = 8;
@@ -698,7 +701,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         double ynorm_max = 0.0;
         for (int cidx = 0; deflate_y && cidx < p; ++cidx) {
             double* q = Q + (size_t)r * n;
-            hipLaunchKernelGGL(k_extract_col, gr, bl, 0, h->stream, n, d.ld, cidx, d.Y[cur], q);
+            hipLaunchKernelGGL(k_extract_col, gr, bl, 0, h->stream, n, d.ld, cidx, rep_rows ? (const double*)h->yfull[cur] : (const double*)d.Y[cur], q);
             double n0; ESC_CHECK(dev_norm(c, q, &n0));
             ynorm_max = std::max(ynorm_max, n0);
             ESC_CHECK(deflate(c, Q, r, q, 2));

@@ -181,6 +181,33 @@ int msdp_sphere_retract(msdp_handle h) {
     HIPCHK(hipGetLastError());
     return 0;
 }
+// Row-sharded forms: the partial sum of the local rows goes through the all-reduced partial array (one workgroup, slot 0
+// of P_AUX; the other slots are zeroed), then every rank applies the global scalar to its rows.
+__global__ __launch_bounds__(MSDP_BLOCK) void k_sph_simple_partial(const double* Y, const double* U, double alpha, int mode, int64_t cnt, double* P) {
+    __shared__ double sh[MSDP_WAVES];
+    double p = 0.0;
+    for (int64_t i = threadIdx.x; i < cnt; i += MSDP_BLOCK) {
+        if (mode == 0) p += Y[i] * U[i];
+        else { const double x = Y[i] + alpha * U[i]; p += x * x; }
+    }
+    const double t = msdp_block_sum(p, sh);
+    for (int i = threadIdx.x; i < MSDP_MAX_GRID; i += MSDP_BLOCK) P[P_AUX * MSDP_MAX_GRID + i] = (i == 0) ? t : 0.0;
+}
+__global__ void k_sph_simple_apply(const double* Y, const double* U, double* Z, double alpha, int mode, int64_t cnt, const double* P) {
+    const double t = P[P_AUX * MSDP_MAX_GRID];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x)
+        Z[i] = mode == 0 ? U[i] - Y[i] * t : (Y[i] + alpha * U[i]) / sqrt(t);
+}
+static int sph_simple_sharded(msdp_handle h, const double* Y, const double* U, double* Z, double alpha, int mode) {
+    const int64_t cnt = (int64_t)h->d.n_loc * h->d.ld;
+    hipLaunchKernelGGL(k_sph_simple_partial, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, Y, U, alpha, mode, cnt, h->d.P);
+    HIPCHK(hipGetLastError());
+    int rc = msdp_allreduce_partials(h, P_AUX, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sph_simple_apply, dim3(256), dim3(256), 0, h->stream, Y, U, Z, alpha, mode, cnt, (const double*)h->d.P);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 __global__ void k_euc_axpy(const double* Y, const double* U, double* Z, double alpha, double ycoef, int64_t cnt) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x)
         Z[i] = ycoef * Y[i] + alpha * U[i];
@@ -191,6 +218,7 @@ int msdp_sphere_proj(msdp_handle h, const double* Y, const double* U, double* V)
         HIPCHK(hipGetLastError());
         return 0;
     }
+    if (h->use_comm) return sph_simple_sharded(h, Y, U, V, 0.0, 0);
     hipLaunchKernelGGL(k_sph_proj_simple, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, Y, U, V, (int64_t)h->d.n_loc * h->d.ld);
     HIPCHK(hipGetLastError());
     return 0;
@@ -201,6 +229,7 @@ int msdp_sphere_retr(msdp_handle h, const double* Y, const double* U, double* Z,
         HIPCHK(hipGetLastError());
         return 0;
     }
+    if (h->use_comm) return sph_simple_sharded(h, Y, U, Z, alpha, 1);
     hipLaunchKernelGGL(k_sph_retr_simple, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, Y, U, Z, alpha,
                        (int64_t)h->d.n_loc * h->d.ld);
     HIPCHK(hipGetLastError());

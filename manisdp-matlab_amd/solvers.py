@@ -352,6 +352,13 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
     _say(verbose, "ManiSDP is starting...")
     _say(verbose, f"SDP size: n = {n}, m = {b.size}")
     h = _lib.Handle.affine(kind, Atc, b, c, n, pcap=max(32, int(o["p0"]) + 2 * int(o["delta"])))
+    # options['comm'] = (nranks, rank, unique_id): one process per GPU, rows of the factor sharded over the ranks
+    # (msdp_comm_init).  Every rank runs this same host loop on identical data -- the operator state is replicated on
+    # the device, the start point must be the same on all ranks (pass Y0 or seed rng identically) -- and reaches the same
+    # decisions; collectives happen inside the library calls.
+    comm = o.get("comm")
+    if comm is not None:
+        h.comm_init(int(comm[0]), int(comm[1]), comm[2])
     topts = _rtr_opts(o)
     p = int(o["p0"])
     sigma = float(o["sigma0"])
@@ -392,7 +399,7 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
             data["cost_evals"] += st.cost_evals
             data["rejected"] += st.rejected
             gradnorm = st.gradnorm
-            Y = h.get_point()
+            Y = h.get_point_all() if comm is not None else h.get_point()
             Y_eval = Y                                     # X of :59 -- what the reference returns (:114)
             dev_al = (eig_mode == "device") and bool(o.get("device_al", True))
             certified = True

@@ -24,6 +24,8 @@ def main():
     uid = [_lib.Handle.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(uid, src=0)
     rng = np.random.default_rng(11)
+    if case == "affine":
+        return affine_case(out, rank, world, uid[0], dist, torch, _lib, problems)
     if case == "sparse":
         C = problems.toroidal_grid_maxcut(61, 50, seed=4)           # n = 3050: ragged last shard for N = 4, 8
         n, p = C.shape[0], 12
@@ -53,6 +55,59 @@ def main():
                  rows=np.array([r0, r1]))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def affine_case(out, rank, world, uid, dist, torch, _lib, problems):
+    """BQP d = 10 moment relaxation (ManiSDP_unitdiag) with its rows sharded: operators, one trustregions() call, the AL
+    bookkeeping and the replicated escape; then a whole solve through the host loop with options['comm']."""
+    import scipy.sparse as sp
+    from manisdp_matlab_amd import solvers
+    gold = os.path.join(ROOT, "tests", "golden")
+    Q = np.loadtxt(os.path.join(gold, "bqp_Q_10_1.txt.gz"), delimiter=",")
+    e = np.loadtxt(os.path.join(gold, "bqp_e_10_1.txt.gz"), delimiter=",")
+    At, b, c, K = problems.bqpmom(10, Q, e)
+    c = np.asarray(c.todense()).ravel(); b = np.asarray(b.todense()).ravel() if sp.issparse(b) else np.asarray(b, float).ravel()
+    At = sp.csc_matrix(At); At.sort_indices()
+    n, m, p = K["s"], b.size, 6
+    rng = np.random.default_rng(3)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = 0.3 * rng.standard_normal((n, p))
+    y = 0.1 * rng.standard_normal(m)
+    h = _lib.Handle.affine(_lib.KIND_UNITDIAG, At, b, c, n)
+    h.comm_init(world, rank, uid)
+    h.set_multipliers(y, 0.7)
+    h.set_point(Y)
+    f = h.cost(); G = h.rgrad(); H = h.hessvec(h.proj(U))
+    co = h.linesearch_cost(U, 0.5)
+    st = h.rtr(_lib.default_opts(maxiter=3, maxinner=15, tolgradnorm=1e-8))
+    Yr = h.get_point_all()
+    obj, Ax = h.al_primal(m)
+    z = h.al_dual(y)
+    lam, V, lmax, _ = h.escape_eigs_dual(3, tol=1e-10, maxit=4000)
+    h.close()
+    parts = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (G, H)]
+    for t in parts:
+        dist.all_reduce(t)                      # every rank filled its own rows only
+    # the replicated quantities must be identical on every rank
+    same = torch.from_numpy(np.concatenate([[f, co, st.cost, obj, lmax], Ax, z, lam, Yr.ravel()])).cuda()
+    lo, hi = same.clone(), same.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    replicated_ok = bool(torch.equal(lo, hi))
+    rng0 = np.random.default_rng(5)
+    Y0 = rng0.standard_normal((n, 2)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    Ys, objs, ds = solvers.ManiSDP_unitdiag(At, b, c, K, {"Y0": Y0, "tol": 1e-8, "comm": (world, rank, _second_uid(dist, _lib, rank))}, verbose=False)
+    if rank == 0:
+        np.savez(out, f=f, G=parts[0].cpu().numpy(), H=parts[1].cpu().numpy(), co=co, cost=st.cost, hessvecs=st.hessvecs, Y=Yr, obj=obj,
+                 Ax=Ax, z=z, lam=lam, lmax=lmax, replicated_ok=replicated_ok, solve_obj=objs, solve_status=ds["status"],
+                 solve_eta=max(ds["gap"], ds["pinf"], ds["dinf"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _second_uid(dist, _lib, rank):
+    uid = [_lib.Handle.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    return uid[0]
 
 
 if __name__ == "__main__":

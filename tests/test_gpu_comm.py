@@ -124,3 +124,63 @@ def test_ranks_on_separate_gpus_match_one_rank(tmp_path, case, N):
     assert int(got["hessvecs"]) == st.hessvecs and int(got["accepted"]) == st.accepted and int(got["rejected"]) == st.rejected
     assert abs(float(got["cost"]) - st.cost) <= 1e-10 * abs(st.cost)
     assert rel(got["Y"], Yout) < 1e-8 and rel(got["z"], z) < 1e-8
+
+
+@pytest.mark.parametrize("N", [2, 4])
+def test_affine_ranks_on_separate_gpus_match_one_rank(tmp_path, N):
+    """Row-sharded ManiSDP_unitdiag (BQP d = 10) on N GPUs against one unsharded handle: operators, trustregions(), AL
+    bookkeeping, the replicated escape, a whole solve.  Needs N visible GPUs (skipped on the single-GPU box; the
+    single-GPU stand-ins are in tests/test_gpu_affine_sharded.py)."""
+    import os, subprocess, sys
+    import scipy.sparse as sp
+    import torch
+    if torch.cuda.device_count() < N:
+        pytest.skip("needs %d GPUs, %d visible" % (N, torch.cuda.device_count()))
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    out = str(tmp_path / "ranks.npz")
+    port = _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "multirank_worker.py")
+    procs = []
+    for r in range(N):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, worker, "affine", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    got = np.load(out)
+    Q = np.loadtxt(golden_path("bqp_Q_10_1.txt.gz"), delimiter=",")
+    e = np.loadtxt(golden_path("bqp_e_10_1.txt.gz"), delimiter=",")
+    At, b, c, K = problems.bqpmom(10, Q, e)
+    c = np.asarray(c.todense()).ravel(); b = np.asarray(b.todense()).ravel() if sp.issparse(b) else np.asarray(b, float).ravel()
+    At = sp.csc_matrix(At); At.sort_indices()
+    n, m, p = K["s"], b.size, 6
+    rng = np.random.default_rng(3)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = 0.3 * rng.standard_normal((n, p))
+    y = 0.1 * rng.standard_normal(m)
+    h = _lib.Handle.affine(_lib.KIND_UNITDIAG, At, b, c, n)
+    h.set_multipliers(y, 0.7)
+    h.set_point(Y)
+    f = h.cost(); G = h.rgrad(); H = h.hessvec(h.proj(U))
+    co = h.linesearch_cost(U, 0.5)
+    st = h.rtr(_lib.default_opts(maxiter=3, maxinner=15, tolgradnorm=1e-8))
+    Yr = h.get_point()
+    obj, Ax = h.al_primal(m)
+    z = h.al_dual(y)
+    lam, V, lmax, _ = h.escape_eigs_dual(3, tol=1e-10, maxit=4000)
+    h.close()
+    rel = lambda a, b: np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)   # noqa: E731
+    assert bool(got["replicated_ok"])
+    assert abs(float(got["f"]) - f) <= 1e-12 * abs(f) and abs(float(got["co"]) - co) <= 1e-12 * abs(co)
+    assert rel(got["G"], G) < 1e-12 and rel(got["H"], H) < 1e-12
+    assert int(got["hessvecs"]) == st.hessvecs and abs(float(got["cost"]) - st.cost) <= 1e-10 * abs(st.cost)
+    assert rel(got["Y"], Yr) < 1e-8 and rel(got["Ax"], Ax) < 1e-8 and rel(got["z"], z) < 1e-8
+    assert abs(float(got["obj"]) - obj) <= 1e-9 * abs(obj)
+    assert rel(got["lam"][np.isfinite(got["lam"])], lam[np.isfinite(lam)]) < 1e-6 and abs(float(got["lmax"]) - lmax) <= 1e-6 * abs(lmax)
+    from manisdp_matlab_amd import solvers
+    rng0 = np.random.default_rng(5)
+    Y0 = rng0.standard_normal((n, 2)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    _, obj1, d1 = solvers.ManiSDP_unitdiag(At, b, c, K, {"Y0": Y0, "tol": 1e-8}, verbose=False)
+    assert int(got["solve_status"]) == 0 and float(got["solve_eta"]) < 1e-8
+    assert abs(float(got["solve_obj"]) - obj1) <= 1e-6 * max(1.0, abs(obj1))
