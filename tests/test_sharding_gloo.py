@@ -6,6 +6,7 @@ import socket
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -76,3 +77,81 @@ def test_partition_properties():
         assert ranges[0][0] == 0 and ranges[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
         assert all(r1 - r0 <= cap for r0, r1 in ranges)
+
+
+def _affine_worker(rank, world, port, out):
+    """The row-sharded affine data path in NumPy over gloo: replicated operator state (A(.), Axb, the
+    adjoint eS and AyU computed whole on every rank from the gathered factor), row-sharded dense contraction and row dots,
+    all-reduced partial sums -- against the oracle's unsharded ManiSDP_unitdiag closures."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(2)
+    d = 5
+    Q = rng.standard_normal((d, d)); Q = (Q + Q.T) / 2
+    e = rng.standard_normal(d)
+    At, b, c, K = problems.bqpmom(d, Q, e)
+    b = np.asarray(b.todense()).ravel() if sp.issparse(b) else np.asarray(b, float).ravel()
+    c = np.asarray(c.todense()).ravel() if sp.issparse(c) else np.asarray(c, float).ravel()
+    A = At.T.tocsr(); n, p, sigma = K["s"], 4, 0.7
+    y = 0.1 * rng.standard_normal(b.size)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p)); U -= Y * np.sum(Y * U, axis=1, keepdims=True)
+    r0, r1 = sharding.row_range(n, world, rank)
+    Yl, Ul = Y[r0:r1], U[r0:r1]
+
+    def allgather(local):
+        slab = torch.from_numpy(sharding.pad_slab(local, n, world))
+        outs = [torch.empty_like(slab) for _ in range(world)]
+        dist.all_gather(outs, slab)
+        return sharding.unpad_gathered([o.numpy() for o in outs], n)
+
+    def allsum(v):
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        dist.all_reduce(t)
+        return t.item()
+
+    Yf = allgather(Yl)                                                   # yfull[slot]
+    Axb = A @ (Yf @ Yf.T).ravel(order="F") - b - y / sigma               # replicated: identical on every rank
+    eS = (c + sigma * (At @ Axb)).reshape((n, n), order="F")             # replicated adjoint
+    CY = c.reshape((n, n), order="F")[r0:r1] @ Yf                         # my rows of C*Y
+    cx = allsum(np.sum(CY * Yl))                                          # P_S1, all-reduced
+    f = cx + 0.5 * sigma * float(Axb @ Axb)                               # P_AXB is replicated: NOT all-reduced
+    eGl = 2.0 * (eS[r0:r1] @ Yf)                                          # my rows of the dense contraction
+    YeG = np.sum(Yl * eGl, axis=1, keepdims=True)
+    Gl = eGl - Yl * YeG
+    Uf = allgather(Ul)                                                    # the direction, gathered before the Hess-vec
+    AyU = (At @ (A @ (Yf @ Uf.T).ravel(order="F"))).reshape((n, n), order="F")   # replicated
+    eHl = 2.0 * (eS[r0:r1] @ Uf) + 4.0 * sigma * (AyU[r0:r1] @ Yf)
+    Hl = eHl - Yl * np.sum(Yl * eHl, axis=1, keepdims=True) - Ul * YeG
+    dHd = allsum(np.sum(Ul * Hl))                                         # P_DHD, all-reduced
+    Gf, Hf = allgather(Gl), allgather(Hl)
+    if rank == 0:
+        np.save(out, np.concatenate([[f, dHd], Gf.ravel(), Hf.ravel()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_affine_path_matches_oracle(tmp_path):
+    from oracle import manisdp_ref as R
+    out = str(tmp_path / "a.npy")
+    mp.spawn(_affine_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    rng = np.random.default_rng(2)
+    d = 5
+    Q = rng.standard_normal((d, d)); Q = (Q + Q.T) / 2
+    e = rng.standard_normal(d)
+    At, b, c, K = problems.bqpmom(d, Q, e)
+    b = np.asarray(b.todense()).ravel() if sp.issparse(b) else np.asarray(b, float).ravel()
+    c = np.asarray(c.todense()).ravel() if sp.issparse(c) else np.asarray(c, float).ravel()
+    n, p, sigma = K["s"], 4, 0.7
+    y = 0.1 * rng.standard_normal(b.size)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p)); U -= Y * np.sum(Y * U, axis=1, keepdims=True)
+    prob = R._UnitDiagProblem(At, b, c, n, p)
+    prob.y, prob.sigma = y, sigma
+    f = prob.cost(Y); G = prob.grad(Y); H = prob.hess(Y, U)
+    assert abs(got[0] - f) <= 1e-12 * max(1.0, abs(f))
+    assert abs(got[1] - np.sum(U * H)) <= 1e-11 * max(1.0, abs(np.sum(U * H)))
+    assert np.allclose(got[2:2 + n * p].reshape(n, p), G, rtol=0, atol=1e-12 * np.linalg.norm(G))
+    assert np.allclose(got[2 + n * p:].reshape(n, p), H, rtol=0, atol=1e-12 * np.linalg.norm(H))
