@@ -289,6 +289,8 @@ int msdp_get_dual_slack(msdp_handle h, double* S);
  *   "escape_deflate" 1/0 escape: deflate span(Y) at near-stationary points (default 1).  Fast, but only as accurate as
  *                       S*Y is small; a caller about to DECLARE optimality re-checks lambda_min with 0 (see solvers.py)
  *   "escape_warm"  1/0  escape: start from what the previous call found (default 1; 0 = hashed random start vector)
+ *   "escape_start_y" 1/0  undeflated cold-start escape runs start from a random combination of the columns of Y plus 5 %
+ *                       noise instead of pure noise (default 0; the independent lambda_min check of the host loops sets it)
  *   "lanczos_onesync" 1/0  undeflated persistent Lanczos runs use one grid synchronisation per step (default 1; 0 = the
  *                       two-synchronisation kernel the deflated runs use)
  *   "dense_pack"   1/0  dense C*U reads the MFMA-fragment-ordered copy of C (default 1; 0 = the row-major one;

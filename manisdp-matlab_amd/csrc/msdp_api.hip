@@ -678,6 +678,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "esc_debug")) t.esc_debug = value != 0;
     else if (!strcmp(name, "escape_deflate")) t.escape_deflate = value != 0;
     else if (!strcmp(name, "escape_warm")) t.escape_warm = value != 0;
+    else if (!strcmp(name, "escape_start_y")) t.escape_start_y = value != 0;
     else if (!strcmp(name, "lanczos_onesync")) t.lanczos_onesync = value != 0;
     else if (!strcmp(name, "dense_pack")) { t.dense_pack = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "debug_fail_persist")) t.fail_persist = value != 0;

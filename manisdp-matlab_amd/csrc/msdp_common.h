@@ -122,6 +122,7 @@ struct Tuning {
     int timing = 0;        // per-call timing lines on stderr                                       (MSDP_TIMING=1)
     int esc_debug = 0;     // per-run Lanczos statistics on stderr                                  (MSDP_ESC_DEBUG=1)
     int escape_deflate = 1;  // escape: deflate span(Y) at near-stationary points (fast, approximate when S*Y != 0)
+    int escape_start_y = 0;   // undeflated cold-start runs begin in span(Y) + 5 % noise (the independent lambda_min check sets it)
     int lanczos_onesync = 1;  // undeflated persistent Lanczos runs: one grid synchronisation per step (0: two)
     int dense_pack = 1;    // dense C*U reads the fragment-ordered copy of C (0: the row-major one; same results)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)

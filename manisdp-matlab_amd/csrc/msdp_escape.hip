@@ -128,6 +128,22 @@ __global__ void k_fill_hash(int n, unsigned seed, double* __restrict__ dst) {
         dst[i] = (double)x / 4294967296.0 - 0.5;
     }
 }
+// Start vector of an undeflated check run: a hashed random combination of the columns of Y plus 5 % hashed noise.  At a
+// near-stationary point span(Y) is the near-kernel of S -- exactly where a lambda_min that the deflated estimate missed
+// would live -- so the Krylov space starts rich in the bottom cluster instead of having to amplify 1/sqrt(n) components.
+__global__ void k_fill_ycomb(int n, int ld, int p, const double* __restrict__ Y, unsigned seed, double* __restrict__ dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int c = 0; c < p; ++c) {
+            unsigned x = (unsigned)(c + 1) * 2246822519u ^ seed;
+            x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+            acc = fma(Y[(int64_t)i * ld + c], (double)x / 4294967296.0 - 0.5, acc);
+        }
+        unsigned x = (unsigned)i * 2654435761u ^ seed;
+        x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+        dst[i] = acc + 0.05 * ((double)x / 4294967296.0 - 0.5);
+    }
+}
 
 // ---------------------------------------------------------------- host helpers
 // Dense symmetric eigen-decomposition by cyclic Jacobi (small matrices only). A is n x n row-major,
@@ -361,6 +377,8 @@ struct EscCtx {
     unsigned long long* slots;
     int* err;
     double host_analysis_s = 0.0;   // time the host spent analysing T_m at the checkpoints (esc_debug statistics)
+    const double* Ypt = nullptr;    // all rows of the resident point (n x ld), for the escape_start_y start vector
+    int ld = 0, p = 0;
 };
 
 static int sapply(EscCtx& c, const double* v, double* w) {
@@ -426,7 +444,10 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
         *have_xstart = false;
     }
     if (!warm) {
-        hipLaunchKernelGGL(k_fill_hash, gr, bl, 0, h->stream, n, seed, w);
+        if (h->tune.escape_start_y && c.Ypt && nq == 0)
+            hipLaunchKernelGGL(k_fill_ycomb, gr, bl, 0, h->stream, n, c.ld, c.p, c.Ypt, seed, w);
+        else
+            hipLaunchKernelGGL(k_fill_hash, gr, bl, 0, h->stream, n, seed, w);
         if ((rc = deflate(c, Q, nq, w, 2))) return rc;
     }
     hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, n, w, w, dbeta, 1);
@@ -514,7 +535,8 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
                 break;
             }
             // doubling up to 1024 steps, then x1.5, x1.25 from 2048 on: a late checkpoint wastes steps, an early one costs a host analysis
-            next_check = std::min(maxit, m < 1024 ? 2 * m : (m < 2048 ? m + m / 2 : m + m / 4));
+            // (x1.125 from 8192 on: with the eight-shift bisection a checkpoint at m = 30000 costs 1.5 ms, a late stop 4 us per step)
+            next_check = std::min(maxit, m < 1024 ? 2 * m : (m < 2048 ? m + m / 2 : (m < 8192 ? m + m / 4 : m + m / 8)));
         }
     }
     // Ritz vector x = V s
@@ -641,6 +663,8 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     const int cur = h->h_ctl->cur;
     EscCtx c;
     c.h = h; c.n = n; c.z = Mdev ? nullptr : d.eG[cur]; c.M = Mdev;
+    c.Ypt = ((h->nranks != 1 || h->use_comm) && h->yfull[cur]) ? (const double*)h->yfull[cur] : (const double*)d.Y[cur];
+    c.ld = d.ld; c.p = d.p;
     const int qcap = p + k + 1;
     double* mem = nullptr;
     const size_t slot_doubles = msdp_lanczos_slot_bytes() / sizeof(double);

@@ -153,6 +153,7 @@ def _verify_lambda_min(h, run1, o, data, default_tol, default_maxit, dense_n=0):
         return float(w[0]), V[:, :1], float(w[-1]), True
     h.set_option("escape_deflate", 0)
     h.set_option("escape_warm", 0)
+    h.set_option("escape_start_y", int(o.get("verify_start_in_span_y", 1)))
     try:
         lam, vS, lam_max, _ = run1(float(o.get("eig_tol", default_tol)), int(o.get("eig_maxit", default_maxit)))
         _, conv, _ = h.escape_info()
@@ -162,6 +163,7 @@ def _verify_lambda_min(h, run1, o, data, default_tol, default_maxit, dense_n=0):
     finally:
         h.set_option("escape_deflate", 1)
         h.set_option("escape_warm", 1)
+        h.set_option("escape_start_y", 0)
     data["eig_seconds"] += time.time() - t1
     return float(lam[0]), vS[:, :1], float(lam_max), conv
 
