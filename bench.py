@@ -253,7 +253,7 @@ def main():
                           "rtr_seconds": data["rtr_seconds"], "escape_seconds": data["eig_seconds"],
                           "independent_lambda_min_checks": data.get("eig_verifications", 0),
                           "options": {"p0": 40},
-                          "note": "dinf is confirmed by a plain (undeflated, cold-started) Lanczos run before the solve "
+                          "note": "dinf is confirmed by a plain Lanczos run (no deflation, nothing reused from earlier calls) before the solve "
                                   "stops; that run is inside seconds_to_dinf_1e-8 and escape_seconds"}
     h.close()
     if not args.no_dense and N == 1 and rank == 0 and not args.force_comm:

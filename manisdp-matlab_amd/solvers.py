@@ -142,7 +142,9 @@ def _verify_lambda_min(h, run1, o, data, default_tol, default_maxit, dense_n=0):
     reported dinf is the true one -- lambda_min and lambda_max are recomputed without those shortcuts:
       * affine kinds with a dense S of moderate order (dense_n <= options.verify_dense_max, default 4000): the
         reference's own eig(S) (ManiSDP_unitdiag.m:68) on the host, on the S the device holds;
-      * otherwise plain Lanczos runs on S itself: no deflation, hashed random start vector.
+      * otherwise plain Lanczos runs on S itself: no deflation, nothing carried over from earlier calls; the start
+        vector is a hashed random combination of the columns of Y plus 5 % hashed noise (span(Y), the near-kernel of S
+        at a near-stationary point, is where a lambda_min the deflated estimate missed would live).
     Returns (lambda_min, its eigenvector as an n x 1 array, lambda_max, converged)."""
     t1 = time.time()
     data["eig_verifications"] = data.get("eig_verifications", 0) + 1
