@@ -230,7 +230,8 @@ end
 % -------------------------------------------------------------------------
 function [lam1, v1, top1, okflag] = independent_lambda_min(h, affine, n, opt)
 % Affine kinds with a dense S of moderate order: the reference's own eig(S) on the S the device holds.  Otherwise
-% plain Lanczos on the device (no deflation of span(Y), random start vector; twice if the first budget runs out).
+% plain Lanczos on the device (no deflation of span(Y), nothing reused from earlier calls, start vector = random
+% combination of the columns of Y plus noise; twice if the first budget runs out).
 if ~isfield(opt, 'verify_dense_max'), opt.verify_dense_max = 4000; end
 if affine && n <= opt.verify_dense_max
     S = manisdp_mex('get_dual_slack', h);
@@ -240,7 +241,8 @@ if affine && n <= opt.verify_dense_max
 end
 manisdp_mex('set_option', h, 'escape_deflate', 0);
 manisdp_mex('set_option', h, 'escape_warm', 0);
-restore = onCleanup(@() cellfun(@(nm) manisdp_mex('set_option', h, nm, 1), {'escape_deflate', 'escape_warm'})); %#ok<NASGU>
+manisdp_mex('set_option', h, 'escape_start_y', 1);
+restore = onCleanup(@() cellfun(@(nm, v) manisdp_mex('set_option', h, nm, v), {'escape_deflate', 'escape_warm', 'escape_start_y'}, {1, 1, 0})); %#ok<NASGU>
 if affine, cmd = 'escape_eigs_dual'; else, cmd = 'escape_eigs'; end
 [lam1, v1, top1, okflag] = manisdp_mex(cmd, h, 1, opt.eig_tol, opt.eig_maxit);
 if ~okflag
