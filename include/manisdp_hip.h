@@ -177,6 +177,19 @@ int msdp_get_point(msdp_handle h, double* Y);
  * download).  The host loops of the row-sharded affine kinds run replicated on all ranks and take their rank / escape
  * decisions on identical data.  Without a communicator: the same as msdp_get_point. */
 int msdp_get_point_all(msdp_handle h, double* Y);
+
+/* The rank decision and the re-shaping of the factor between two trustregions() calls without the factor leaving the
+ * device (ManiSDP_onlyunitdiag.m:52-54 svd(Y), :70-73 Y = V(:,1:r)'.*e(1:r), :78-83 Y = [Y; alpha*vS'],
+ * Y = Y./sqrt(sum(Y.^2)); the same lines of ManiSDP_unitdiag.m:72-74,93-106).
+ * msdp_factor_gram: G (p x p, symmetric) = Gram matrix of the p columns of the factor; its eigen-decomposition
+ *   G = Q diag(e.^2) Q' gives the singular values e of Y and V(:,k)*e_k = Y*Q(:,k).
+ * msdp_factor_rotate: Y <- Y*Q with Q p x r ROW-major (the rank cut; new width r).
+ * msdp_factor_append: Y <- [Y, alpha*V], V n x k column-major (as msdp_escape_eigs returns it), then every row scaled to
+ *   unit norm if normalize != 0 (oblique kinds).  MSDP_EUNSUPPORTED when p + k exceeds the width the handle has
+ *   allocated: re-enter through msdp_set_point then. */
+int msdp_factor_gram(msdp_handle h, double* G);
+int msdp_factor_rotate(msdp_handle h, int32_t r, const double* Q);
+int msdp_factor_append(msdp_handle h, int32_t k, const double* V, double alpha, int32_t normalize);
 int msdp_get_p(msdp_handle h, int32_t* p);
 /* MSDP_KIND_* of the handle: tells a binding which factor layout the handle expects at the boundary
  * (p x n for ONLYUNITDIAG / UNITDIAG, n x p for UNITTRACE / GENERIC) without guessing from array shapes. */

@@ -83,6 +83,9 @@ SIGNATURES = {
     "msdp_escape_lower_bound": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_dual_slack": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_point_all": (C.c_int, [C.c_void_p, _dp]),
+    "msdp_factor_gram": (C.c_int, [C.c_void_p, _dp]),
+    "msdp_factor_rotate": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
+    "msdp_factor_append": (C.c_int, [C.c_void_p, C.c_int32, _dp, C.c_double, C.c_int32]),
     "msdp_create_dual_unitdiag": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, _dp, C.c_int32, _i64p, _i64p, _dp,
                                             _dp, C.c_int32, C.POINTER(C.c_void_p)]),
     "msdp_dual_set_penalty": (C.c_int, [C.c_void_p, C.c_double, _dp]),
@@ -326,6 +329,26 @@ class Handle:
         out = self._empty()
         _check(self._lib.msdp_get_point_all(self._h, _dptr(out)))
         return np.ascontiguousarray(out)
+
+    def factor_gram(self):
+        """p x p Gram matrix of the columns of the resident factor (computed on the device)."""
+        G = np.zeros((self.p, self.p))
+        _check(self._lib.msdp_factor_gram(self._h, _dptr(G)))
+        return G
+
+    def factor_rotate(self, Q):
+        """Resident factor <- factor @ Q (Q: p x r): the rank cut, on the device."""
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        assert Q.shape[0] == self.p
+        _check(self._lib.msdp_factor_rotate(self._h, Q.shape[1], _dptr(Q)))
+        self.p = Q.shape[1]
+
+    def factor_append(self, V, alpha, normalize=True):
+        """Resident factor <- [factor, alpha*V] (V: n x k), rows renormalised (oblique kinds), on the device."""
+        Vf = np.asfortranarray(V, dtype=np.float64)
+        assert Vf.shape[0] == self.n
+        _check(self._lib.msdp_factor_append(self._h, Vf.shape[1], _dptr(Vf), float(alpha), 1 if normalize else 0))
+        self.p += Vf.shape[1]
 
     def set_multipliers(self, y, sigma):
         y = np.ascontiguousarray(y, dtype=np.float64)

@@ -604,6 +604,86 @@ extern "C" int msdp_set_point(msdp_handle h, int32_t p, const double* Y) {
     return 0;
 }
 
+int msdp_k_fgram(msdp_handle h, const double* Y, double* part, int nblk, double* out);          // msdp_kernels.hip
+int msdp_k_frotate(msdp_handle h, int cap, int r, int ldn, const double* Y, const double* Q, double* Yn);
+int msdp_k_fappend(msdp_handle h, int cap, int k, int ldn, const double* Y, const double* V, double alpha, int normalize, double* Yn);
+
+// The resident point has been rewritten into slot `slot` with width p: make it the current one
+static int adopt_point(msdp_handle h, int slot, int p) {
+    Dev& d = h->d;
+    d.p = p;
+    d.ld = ((p + 1) / 2) * 2;
+    if (!h->use_comm && h->nranks == 1) d.full = d.md;
+    choose_grid(h);
+    if (d.costkind != COST_SPARSE) {
+        int rc = msdp_dense_reserve(h, d.costkind == COST_AFFINE ? 2 : 1);
+        if (rc) return rc;
+    }
+    h->h_ctl->cur = slot;
+    h->state_valid = false;
+    h->gradnorm_valid = false;
+    return 0;
+}
+
+extern "C" int msdp_factor_gram(msdp_handle h, double* G) {
+    CHECK_H(h);
+    if (!h->have_point || !G) { msdp_set_error("factor_gram: no resident point / null out"); return MSDP_ESTATE; }
+    Dev& d = h->d;
+    const int ld = d.ld, p = d.p;
+    int nblk = (int)std::min<int64_t>(64, std::max<int64_t>(1, (int64_t)(1 << 22) / ((int64_t)ld * ld)));
+    double* buf = nullptr;
+    if (hipMalloc((void**)&buf, ((size_t)nblk + 1) * ld * ld * sizeof(double)) != hipSuccess) { msdp_set_error("factor_gram: scratch alloc failed"); return MSDP_ENOMEM; }
+    double* out = buf + (size_t)nblk * ld * ld;
+    int rc = msdp_k_fgram(h, d.Y[host_cur(h)], buf, nblk, out);
+    if (!rc && h->use_comm) {
+        ncclResult_t r = ncclAllReduce(out, out, (size_t)ld * ld, ncclDouble, ncclSum, (ncclComm_t)h->comm, h->stream);
+        if (r != ncclSuccess) { msdp_set_error("ncclAllReduce failed: %s", ncclGetErrorString(r)); rc = MSDP_ECOMM; }
+    }
+    if (!rc && hipMemcpy2DAsync(G, (size_t)p * sizeof(double), out, (size_t)ld * sizeof(double), (size_t)p * sizeof(double), p,
+                                hipMemcpyDeviceToHost, h->stream) != hipSuccess) { msdp_set_error("factor_gram: D2H failed"); rc = MSDP_EHIP; }
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(buf);
+    return rc;
+}
+
+extern "C" int msdp_factor_rotate(msdp_handle h, int32_t r, const double* Q) {
+    CHECK_H(h);
+    if (!h->have_point || !Q) { msdp_set_error("factor_rotate: no resident point / null Q"); return MSDP_ESTATE; }
+    Dev& d = h->d;
+    if (r < 1 || r > d.p) { msdp_set_error("factor_rotate: r = %d outside 1..p = %d", r, d.p); return MSDP_EINVAL; }
+    const int cur = host_cur(h), ldn = ((r + 1) / 2) * 2;
+    double* qd = nullptr;
+    if (hipMalloc((void**)&qd, (size_t)d.p * r * sizeof(double)) != hipSuccess) { msdp_set_error("factor_rotate: scratch alloc failed"); return MSDP_ENOMEM; }
+    int rc = 0;
+    if (hipMemcpyAsync(qd, Q, (size_t)d.p * r * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) { msdp_set_error("factor_rotate: H2D failed"); rc = MSDP_EHIP; }
+    if (!rc) rc = msdp_k_frotate(h, rows_capacity(h), r, ldn, d.Y[cur], qd, d.Y[cur ^ 1]);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(qd);
+    if (rc) return rc;
+    return adopt_point(h, cur ^ 1, r);
+}
+
+extern "C" int msdp_factor_append(msdp_handle h, int32_t k, const double* V, double alpha, int32_t normalize) {
+    CHECK_H(h);
+    if (!h->have_point || !V) { msdp_set_error("factor_append: no resident point / null V"); return MSDP_ESTATE; }
+    Dev& d = h->d;
+    if (k < 1) { msdp_set_error("factor_append: k = %d", k); return MSDP_EINVAL; }
+    if (d.p + k > h->pcap) { msdp_set_error("factor_append: width %d exceeds the allocated capacity %d (use msdp_set_point)", d.p + k, h->pcap); return MSDP_EUNSUPPORTED; }
+    if (d.manifold != MANI_OBLIQUE && normalize) { msdp_set_error("factor_append: row normalisation is the oblique kinds'"); return MSDP_EUNSUPPORTED; }
+    const int cur = host_cur(h), pn = d.p + k, ldn = ((pn + 1) / 2) * 2;
+    double* vd = nullptr;
+    if (hipMalloc((void**)&vd, (size_t)std::max(d.n_loc, 1) * k * sizeof(double)) != hipSuccess) { msdp_set_error("factor_append: scratch alloc failed"); return MSDP_ENOMEM; }
+    int rc = 0;
+    // my rows of every column of the n x k column-major V
+    if (hipMemcpy2DAsync(vd, (size_t)d.n_loc * sizeof(double), V + d.row0, (size_t)d.n * sizeof(double), (size_t)d.n_loc * sizeof(double), k,
+                         hipMemcpyHostToDevice, h->stream) != hipSuccess) { msdp_set_error("factor_append: H2D failed"); rc = MSDP_EHIP; }
+    if (!rc) rc = msdp_k_fappend(h, rows_capacity(h), k, ldn, d.Y[cur], vd, alpha, normalize, d.Y[cur ^ 1]);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(vd);
+    if (rc) return rc;
+    return adopt_point(h, cur ^ 1, pn);
+}
+
 // Device-side copy of the resident point and back: lets a caller restart from the same point without another PCIe
 // upload (bench.py: the start point of every timed step is already in HBM).
 extern "C" int msdp_point_snapshot(msdp_handle h) {

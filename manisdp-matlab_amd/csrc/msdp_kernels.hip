@@ -716,6 +716,71 @@ int msdp_launch_rtr_decide(msdp_handle h) {
     return 0;
 }
 
+// ---- the factor's p x p Gram matrix, rank cut and widening on the device (svd(Y), Y = V(:,1:r)'.*e(1:r),
+// Y = [Y; alpha*vS'], Y = Y./sqrt(sum(Y.^2)) of ManiSDP_onlyunitdiag.m:52-54,70-83 without the factor leaving the GPU)
+__global__ __launch_bounds__(256) void k_fgram_part(int n_loc, int ld, const double* __restrict__ Y, double* __restrict__ part) {
+    const int rows = (n_loc + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows, r1 = min(n_loc, r0 + rows);
+    for (int e = threadIdx.x; e < ld * ld; e += blockDim.x) {
+        const int a = e / ld, b = e - a * ld;
+        double acc = 0.0;
+        for (int k = r0; k < r1; ++k) acc = fma(Y[(int64_t)k * ld + a], Y[(int64_t)k * ld + b], acc);
+        part[(int64_t)blockIdx.x * ld * ld + e] = acc;
+    }
+}
+__global__ void k_fgram_sum(int ld, int nblk, const double* __restrict__ part, double* __restrict__ out) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ld * ld; e += gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int q = 0; q < nblk; ++q) acc += part[(int64_t)q * ld * ld + e];
+        out[e] = acc;
+    }
+}
+// Ynew (cap x ldn) = Y (n_loc x ld, first p columns) * Q (p x r row-major); pad rows / columns zero
+__global__ void k_frotate(int cap, int n_loc, int ld, int p, int ldn, int r, const double* __restrict__ Y,
+                          const double* __restrict__ Q, double* __restrict__ Yn) {
+    const int64_t tot = (int64_t)cap * ldn;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / ldn; const int col = (int)(e - row * ldn);
+        double acc = 0.0;
+        if (row < n_loc && col < r)
+            for (int a = 0; a < p; ++a) acc = fma(Y[row * ld + a], Q[a * r + col], acc);
+        Yn[e] = acc;
+    }
+}
+// Ynew = [Y, alpha*V] (V: n_loc x k column-major), rows scaled to unit norm when normalize != 0 (rows flagged free keep theirs)
+__global__ void k_fappend(int cap, int n_loc, int ld, int p, int ldn, int k, const double* __restrict__ Y, const double* __restrict__ V,
+                          double alpha, int normalize, const unsigned char* __restrict__ rowfree, double* __restrict__ Yn) {
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < cap; row += gridDim.x * blockDim.x) {
+        double* yn = Yn + (int64_t)row * ldn;
+        if (row >= n_loc) { for (int c = 0; c < ldn; ++c) yn[c] = 0.0; continue; }
+        const double* y = Y + (int64_t)row * ld;
+        double nn = 0.0;
+        for (int c = 0; c < p; ++c) nn = fma(y[c], y[c], nn);
+        for (int c = 0; c < k; ++c) { const double v = alpha * V[(int64_t)c * n_loc + row]; nn = fma(v, v, nn); }
+        const double sc = (normalize && !(rowfree && rowfree[row]) && nn > 0.0) ? 1.0 / sqrt(nn) : 1.0;
+        for (int c = 0; c < p; ++c) yn[c] = y[c] * sc;
+        for (int c = 0; c < k; ++c) yn[p + c] = alpha * V[(int64_t)c * n_loc + row] * sc;
+        for (int c = p + k; c < ldn; ++c) yn[c] = 0.0;
+    }
+}
+int msdp_k_fgram(msdp_handle h, const double* Y, double* part, int nblk, double* out) {
+    hipLaunchKernelGGL(k_fgram_part, dim3(nblk), dim3(256), 0, h->stream, h->d.n_loc, h->d.ld, Y, part);
+    hipLaunchKernelGGL(k_fgram_sum, dim3((h->d.ld * h->d.ld + 255) / 256), dim3(256), 0, h->stream, h->d.ld, nblk, (const double*)part, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int msdp_k_frotate(msdp_handle h, int cap, int r, int ldn, const double* Y, const double* Q, double* Yn) {
+    hipLaunchKernelGGL(k_frotate, dim3(1024), dim3(256), 0, h->stream, cap, h->d.n_loc, h->d.ld, h->d.p, ldn, r, Y, Q, Yn);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int msdp_k_fappend(msdp_handle h, int cap, int k, int ldn, const double* Y, const double* V, double alpha, int normalize, double* Yn) {
+    hipLaunchKernelGGL(k_fappend, dim3((cap + 255) / 256), dim3(256), 0, h->stream, cap, h->d.n_loc, h->d.ld, h->d.p, ldn, k, Y, V, alpha,
+                       normalize, h->d.rowfree, Yn);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ---- small launch wrappers used by the API unit ----
 int msdp_k_pack(msdp_handle h, const double* src, double* dst, int n, int p, int ld, bool colmajor) {
     const int grid = 1024;

@@ -86,13 +86,14 @@ def _rtr_opts(o):
 _RANK_CUT_SVD = False
 
 
-def _thin_svd_rank(Y, theta):
+def _thin_svd_rank(Y, theta, gram=None):
     """svd(Y) and r = sum(e >= theta*e(1)) (ManiSDP_onlyunitdiag.m:52-54) through the
-    p x p Gram matrix: never forms the n x n V of the reference."""
-    if _RANK_CUT_SVD:
+    p x p Gram matrix: never forms the n x n V of the reference.  ``gram``: the Gram matrix
+    as the device computed it (msdp_factor_gram), Y is not needed then."""
+    if _RANK_CUT_SVD and gram is None:
         _, e, Qt = np.linalg.svd(Y, full_matrices=False)
         return Qt.T, e, int(np.sum(e >= theta * e[0]))
-    G = Y.T @ Y
+    G = gram if gram is not None else Y.T @ Y
     w, Q = np.linalg.eigh(G)
     order = np.argsort(w)[::-1]
     w = np.maximum(w[order], 0.0)
@@ -211,9 +212,15 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
     z = S = None
     certified = True
     last_verified = True
+    # Rank decision, rank cut and widening of the factor on the device (msdp_factor_gram / _rotate / _append): the factor
+    # stays resident between the trustregions() calls and comes to the host once, when the solve ends.  Default with the
+    # device escape (large n); the line-search variant keeps the host form (its direction U is a host array anyway).
+    device_factor = bool(o.get("device_factor", eig_mode == "device" and o["line_search"] != 1))
+    resident = False
     try:
         for it in range(1, int(o["AL_maxiter"]) + 1):      # :38
-            h.set_point(Y)
+            if not resident:
+                h.set_point(Y)
             if U is not None:                              # :40-42 line_search
                 _line_search(h, U)
             st = h.rtr(topts)                              # :43
@@ -222,8 +229,9 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
             data["cost_evals"] += st.cost_evals
             data["rejected"] += st.rejected
             gradnorm = st.gradnorm                         # :44
-            Y = h.get_point()
-            Y_eval = Y                                     # X = Y'*Y of :45 -- what the reference returns (:86)
+            if not device_factor:
+                Y = h.get_point()
+                Y_eval = Y                                 # X = Y'*Y of :45 -- what the reference returns (:86)
             z = h.get_z()                                  # :46-47  z = sum((Y*C).*Y)
             obj = float(np.sum(z))                         # :48
             t1 = time.time()
@@ -266,24 +274,51 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
                     vS = np.hstack([v_v, vS[:, :max(int(o["delta"]) - 1, 0)]])
                     nneg = max(nneg, 1)
                 dinf = dinf_v
-            Q, e, r = _thin_svd_rank(Y, float(o["theta"]))  # :52-54
+            if device_factor:
+                Q, e, r = _thin_svd_rank(None, float(o["theta"]), gram=h.factor_gram())   # :52-54 from the device's Gram matrix
+            else:
+                Q, e, r = _thin_svd_rank(Y, float(o["theta"]))  # :52-54
             _say(verbose, "Iter %d, obj:%0.8f, dinf:%0.1e, r:%d, p:%d, time:%0.2fs"
                  % (it, obj, dinf, r, p, time.time() - t0))
             data["log"].append((it, obj, dinf, r, p, time.time() - t0, st.hessvecs))
             data["iters"] = it
             if dinf < o["tol"] and certified:              # :57-60 (an unconverged Lanczos run certifies nothing)
                 _say(verbose, "Optimality is reached!")
+                if device_factor:
+                    Y_eval = h.get_point()
                 break
             if it % 20 == 0:                               # :61-69
                 if it > 50 and dinf > dinf0:
                     data["status"] = 2
                     _say(verbose, "Slow progress!")
+                    if device_factor:
+                        Y_eval = h.get_point()
                     break
                 dinf0 = dinf
+            nne = max(min(nneg, int(o["delta"])), 1)       # :74
+            if device_factor:
+                if it == int(o["AL_maxiter"]):
+                    Y_eval = h.get_point()                 # last pass: the evaluated point, before it is re-shaped
+                try:
+                    if r <= p - 1:                         # :70-73
+                        h.factor_rotate(Q[:, :r])
+                        p = r
+                    h.factor_append(vS[:, :nne], float(o["alpha"]), normalize=True)   # :78-83
+                    p = p + nne
+                    resident = True
+                    continue
+                except _lib.MsdpError as err:              # wider than the handle's buffers: re-enter through set_point
+                    if "allocated capacity" not in str(err):
+                        raise
+                    Y = h.get_point()                      # the factor as the device holds it (already cut)
+                    Y = np.hstack([Y, o["alpha"] * vS[:, :nne]])
+                    Y = np.ascontiguousarray(Y / np.sqrt(np.sum(Y * Y, axis=1, keepdims=True)))
+                    p = Y.shape[1]
+                    resident = False
+                    continue
             if r <= p - 1:                                 # :70-73
                 Y = _rank_cut(Y, Q, e, r)
                 p = r
-            nne = max(min(nneg, int(o["delta"])), 1)       # :74
             if o["line_search"] == 1:                      # :75-77
                 U = np.hstack([np.zeros((n, p)), vS[:, :nne]])
             p = p + nne                                    # :78

@@ -271,3 +271,54 @@ def test_set_option_rejects_unknown_names(lib):
     h.set_option("persist", 1)
     assert h.tcg_path() == 1
     h.close()
+
+
+def test_factor_gram_rotate_append_on_device():
+    """msdp_factor_gram / _rotate / _append against NumPy (the rank decision and the re-shaping of the factor
+    between two trustregions() calls happen on the device), odd and even widths, and the capacity error."""
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    C = problems.toroidal_grid_maxcut(20, 31, seed=2)
+    n = C.shape[0]
+    rng = np.random.default_rng(0)
+    for p, r, k in ((7, 4, 3), (12, 12, 1), (5, 1, 8)):
+        Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+        h = _lib.Handle.onlyunitdiag(C, pcap=32)
+        h.set_point(Y)
+        G = h.factor_gram()
+        assert np.linalg.norm(G - Y.T @ Y) <= 1e-12 * np.linalg.norm(Y.T @ Y)
+        Q = np.linalg.qr(rng.standard_normal((p, r)))[0]
+        h.factor_rotate(Q)
+        Yr = h.get_point()
+        assert Yr.shape == (n, r) and np.linalg.norm(Yr - Y @ Q) <= 1e-13 * np.linalg.norm(Y @ Q)
+        V = rng.standard_normal((n, k))
+        h.factor_append(V, 0.3, normalize=True)
+        Ya = h.get_point()
+        ref = np.hstack([Y @ Q, 0.3 * V]); ref /= np.linalg.norm(ref, axis=1, keepdims=True)
+        assert Ya.shape == (n, r + k) and np.linalg.norm(Ya - ref) <= 1e-13 * np.linalg.norm(ref)
+        # the re-shaped point is a valid resident point: cost / gradient follow
+        h2 = _lib.Handle.onlyunitdiag(C, pcap=32)
+        h2.set_point(ref)
+        assert abs(h.cost() - h2.cost()) <= 1e-12 * abs(h2.cost())
+        assert np.linalg.norm(h.rgrad() - h2.rgrad()) <= 1e-12 * np.linalg.norm(h2.rgrad())
+        with pytest.raises(_lib.MsdpError, match="allocated capacity"):
+            h.factor_append(rng.standard_normal((n, 40)), 0.1)
+        h.close(); h2.close()
+
+
+def test_device_factor_path_follows_host_path():
+    """ManiSDP_onlyunitdiag with the factor kept on the device between the trustregions() calls against the host form of the
+    same steps (G1, device escape): same number of outer iterations, same optimum."""
+    from manisdp_matlab_amd import problems, solvers
+    from conftest import golden_path
+    C = problems.maxcut_cost_matrix(golden_path("G1.txt.gz"))
+    rng = np.random.default_rng(3)
+    Y0 = rng.standard_normal((C.shape[0], 2)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    out = []
+    for dev in (True, False):
+        Y, obj, data = solvers.ManiSDP_onlyunitdiag(C, {"Y0": Y0, "eig": "device", "device_factor": dev, "tol": 1e-8}, verbose=False)
+        assert data["status"] == 0 and data["dinf"] < 1e-8
+        assert np.allclose(np.linalg.norm(Y, axis=1), 1.0, atol=1e-12)
+        out.append((obj, data["iters"], Y.shape[1]))
+    assert abs(out[0][0] - out[1][0]) <= 1e-7 * abs(out[1][0])
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
