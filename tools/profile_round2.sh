@@ -18,7 +18,7 @@ pmc() {     # pmc <tag> <timeout> "<counters>" python3 args...
     timeout "$to" rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$OUT/$tag" -- "$@" > "$OUT/$tag.log" 2>&1
     echo "pmc $tag rc=$?"
 }
-stats bench 300 python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-kkt --no-dense
+stats bench 300 python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-kkt --no-dense --no-affine
 pmc fetch 120 FETCH_SIZE python3 "$ROOT/tools/pmc_probe.py" 32
 pmc write 120 WRITE_SIZE python3 "$ROOT/tools/pmc_probe.py" 32
 stats dense20000 300 python3 "$ROOT/tools/dense_probe.py" 20000 16 32 64
