@@ -225,6 +225,8 @@ int msdp_retr(msdp_handle h, const double* U, double* Z);
 /* Per-point vector the AL step needs after RTR without recomputing it on the host:
  * onlyunitdiag: z = sum((Y*C).*Y) (ManiSDP_onlyunitdiag.m:46-47), length n. */
 int msdp_get_z(msdp_handle h, double* z);
+/* Row-sharded handles: z of all rows on every rank (one all-gather); otherwise the same as msdp_get_z. */
+int msdp_get_z_all(msdp_handle h, double* z);
 
 /* co(Y) of the line search (ManiSDP_onlyunitdiag.m:99-101, ManiSDP_unitdiag.m:131-136,
  * ManiSDP_unittrace.m:135-140) evaluated at the retraction of Y + alpha*U, U given in

@@ -83,6 +83,7 @@ SIGNATURES = {
     "msdp_escape_lower_bound": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_dual_slack": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_point_all": (C.c_int, [C.c_void_p, _dp]),
+    "msdp_get_z_all": (C.c_int, [C.c_void_p, _dp]),
     "msdp_factor_gram": (C.c_int, [C.c_void_p, _dp]),
     "msdp_factor_rotate": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "msdp_factor_append": (C.c_int, [C.c_void_p, C.c_int32, _dp, C.c_double, C.c_int32]),
@@ -389,6 +390,11 @@ class Handle:
     def get_z(self):
         z = np.zeros(self.n)
         _check(self._lib.msdp_get_z(self._h, _dptr(z)))
+        return z
+
+    def get_z_all(self):
+        z = np.zeros(self.n)
+        _check(self._lib.msdp_get_z_all(self._h, _dptr(z)))
         return z
 
     def linesearch_cost(self, U, alpha):

@@ -507,6 +507,10 @@ extern "C" int msdp_destroy(msdp_handle h) {
     for (int s2 = 0; s2 < 2; ++s2) if (h->ev_flag[s2]) (void)hipEventDestroy(h->ev_flag[s2]);
     for (int s2 = 0; s2 < 2; ++s2) if (h->chunk_execs[s2]) (void)hipGraphExecDestroy(h->chunk_execs[s2]);
     msdp_affine_release(h);
+    if (h->esc_rp) (void)hipFree(h->esc_rp);
+    if (h->esc_ci) (void)hipFree(h->esc_ci);
+    if (h->esc_cv) (void)hipFree(h->esc_cv);
+    if (h->esc_z) (void)hipFree(h->esc_z);
     if (h->esc_mem) (void)hipFree(h->esc_mem);       // esc_prev lives inside it
     if (h->lz_slots) (void)hipFree(h->lz_slots);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1361,6 +1365,20 @@ extern "C" int msdp_get_z(msdp_handle h, double* z) {
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(z + h->d.row0, h->d.eG[host_cur(h)], (size_t)h->d.n_loc * sizeof(double),
                           hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// z of ALL rows on every rank of a row-sharded handle (one all-gather): input of the replicated host loop
+extern "C" int msdp_get_z_all(msdp_handle h, double* z) {
+    CHECK_H(h);
+    if (h->kind != MSDP_KIND_ONLYUNITDIAG || !z) { msdp_set_error("get_z_all: onlyunitdiag handles / null out"); return MSDP_EUNSUPPORTED; }
+    if (!h->use_comm || h->nranks == 1) return msdp_get_z(h, z);
+    int rc = ensure_state(h);
+    if (rc) return rc;
+    const size_t cap = (size_t)rows_capacity(h);
+    if ((rc = msdp_allgather_vec(h, h->d.eG[host_cur(h)], h->full_buf, cap))) return rc;     // the gather buffer is free here
+    HIPCHK(hipMemcpyAsync(z, h->full_buf, (size_t)h->d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }

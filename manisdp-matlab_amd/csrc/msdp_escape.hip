@@ -26,6 +26,8 @@
 #include <vector>
 
 int msdp_dense_nS(int n);
+int msdp_allgather_rows(msdp_handle h, const double* local_rows);          // msdp_api.hip
+int msdp_allgather_vec(msdp_handle h, const double* local, double* all, size_t count_per_rank);
 // msdp_lanczos.hip: persistent kernel for the recurrence (sparse C, single rank)
 size_t msdp_lanczos_slot_bytes();
 int msdp_lanczos_persist_ok(msdp_handle h, int nq);
@@ -379,6 +381,7 @@ struct EscCtx {
     double host_analysis_s = 0.0;   // time the host spent analysing T_m at the checkpoints (esc_debug statistics)
     const double* Ypt = nullptr;    // all rows of the resident point (n x ld), for the escape_start_y start vector
     int ld = 0, p = 0;
+    const int* rp = nullptr; const int* ci = nullptr; const double* cv = nullptr;   // CSR of C (all rows)
 };
 
 static int sapply(EscCtx& c, const double* v, double* w) {
@@ -387,7 +390,7 @@ static int sapply(EscCtx& c, const double* v, double* w) {
     if (c.M)
         hipLaunchKernelGGL(k_sv_dense, dim3((c.n + 3) / 4), dim3(256), 0, h->stream, c.n, msdp_dense_nS(c.n), c.M, (const double*)nullptr, v, w);
     else if (d.costkind == COST_SPARSE)
-        hipLaunchKernelGGL(k_sv_sparse, dim3((c.n + 255) / 256), dim3(256), 0, h->stream, c.n, d.rowptr, d.colind, d.cval, c.z, v, w);
+        hipLaunchKernelGGL(k_sv_sparse, dim3((c.n + 255) / 256), dim3(256), 0, h->stream, c.n, c.rp, c.ci, c.cv, c.z, v, w);
     else
         hipLaunchKernelGGL(k_sv_dense, dim3((c.n + 3) / 4), dim3(256), 0, h->stream, c.n, msdp_dense_nS(c.n), d.Cd, c.z, v, w);
     HIPCHK(hipGetLastError());
@@ -650,7 +653,27 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     // Row-sharded handles: the escape on an explicit dense S (affine kinds) runs replicated -- every rank holds S and all
     // rows of the point (yfull, refreshed by msdp_al_dual) and finds the same vectors; S = C - diag(z) is not sharded yet
     const bool rep_rows = (h->nranks != 1 || h->use_comm) && Mdev && h->yfull[h->h_ctl->cur];
-    if (h->nranks != 1 && !rep_rows) { msdp_set_error("escape_eigs: single-GPU only for the onlyunitdiag kind in this build"); return MSDP_EUNSUPPORTED; }
+    // Row-sharded onlyunitdiag with sparse C: replicated as well -- every rank keeps a full copy of C's CSR arrays for this
+    // purpose (1.2 MB for G81), gathers z and the rows of Y, and runs the same Lanczos recurrence on the multi-kernel path
+    // (a Lanczos process with sharded vectors and an all-gather per step is the follow-up)
+    // (taken with ANY communicator, also of size 1, so that one GPU exercises the gathers and the replicated copy)
+    const bool rep_sparse = h->use_comm && !Mdev && d.costkind == COST_SPARSE && !h->h_rowptr.empty();
+    if (h->nranks != 1 && !rep_rows && !rep_sparse) { msdp_set_error("escape_eigs: row-sharded handles need sparse C or an explicit S"); return MSDP_EUNSUPPORTED; }
+    if (rep_sparse) {
+        const size_t nnz = h->h_cval.size(), cap = (size_t)((d.n + h->nranks - 1) / h->nranks);
+        if (!h->esc_rp) {
+            if (hipMalloc((void**)&h->esc_rp, ((size_t)d.n + 1) * sizeof(int)) != hipSuccess || hipMalloc((void**)&h->esc_ci, (nnz ? nnz : 1) * sizeof(int)) != hipSuccess ||
+                hipMalloc((void**)&h->esc_cv, (nnz ? nnz : 1) * sizeof(double)) != hipSuccess || hipMalloc((void**)&h->esc_z, cap * h->nranks * sizeof(double)) != hipSuccess) {
+                msdp_set_error("escape_eigs: allocation of the replicated copy of C failed"); return MSDP_ENOMEM;
+            }
+            HIPCHK(hipMemcpy(h->esc_rp, h->h_rowptr.data(), ((size_t)d.n + 1) * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(h->esc_ci, h->h_colind.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(h->esc_cv, h->h_cval.data(), nnz * sizeof(double), hipMemcpyHostToDevice));
+        }
+        int rcg = msdp_allgather_vec(h, d.eG[h->h_ctl->cur], h->esc_z, cap);
+        if (!rcg) rcg = msdp_allgather_rows(h, d.Y[h->h_ctl->cur]);        // all rows of the point in the gather buffer
+        if (rcg) return rcg;
+    }
     if (k < 1) { msdp_set_error("escape_eigs: k >= 1"); return MSDP_EINVAL; }
     const int n = d.n, p = d.p;
     if (maxit < 8) maxit = 8;
@@ -662,8 +685,10 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     if (maxit > cap) maxit = (int)std::max<int64_t>(64, cap);
     const int cur = h->h_ctl->cur;
     EscCtx c;
-    c.h = h; c.n = n; c.z = Mdev ? nullptr : d.eG[cur]; c.M = Mdev;
-    c.Ypt = ((h->nranks != 1 || h->use_comm) && h->yfull[cur]) ? (const double*)h->yfull[cur] : (const double*)d.Y[cur];
+    c.h = h; c.n = n; c.z = Mdev ? nullptr : (rep_sparse ? (const double*)h->esc_z : (const double*)d.eG[cur]); c.M = Mdev;
+    c.rp = rep_sparse ? h->esc_rp : d.rowptr; c.ci = rep_sparse ? h->esc_ci : d.colind; c.cv = rep_sparse ? h->esc_cv : d.cval;
+    c.Ypt = rep_sparse ? (const double*)h->full_buf
+                       : (((h->nranks != 1 || h->use_comm) && h->yfull[cur]) ? (const double*)h->yfull[cur] : (const double*)d.Y[cur]);
     c.ld = d.ld; c.p = d.p;
     const int qcap = p + k + 1;
     double* mem = nullptr;
@@ -725,7 +750,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         double ynorm_max = 0.0;
         for (int cidx = 0; deflate_y && cidx < p; ++cidx) {
             double* q = Q + (size_t)r * n;
-            hipLaunchKernelGGL(k_extract_col, gr, bl, 0, h->stream, n, d.ld, cidx, rep_rows ? (const double*)h->yfull[cur] : (const double*)d.Y[cur], q);
+            hipLaunchKernelGGL(k_extract_col, gr, bl, 0, h->stream, n, d.ld, cidx, (rep_rows || rep_sparse) ? c.Ypt : (const double*)d.Y[cur], q);
             double n0; ESC_CHECK(dev_norm(c, q, &n0));
             ynorm_max = std::max(ynorm_max, n0);
             ESC_CHECK(deflate(c, Q, r, q, 2));

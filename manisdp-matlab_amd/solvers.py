@@ -196,6 +196,15 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
     Csp = C.tocsr() if sp.issparse(C) else np.asarray(C, dtype=np.float64)
     eig_mode = o.get("eig", "host" if n <= dense_max else "device")
     h = _lib.Handle.onlyunitdiag(Csp, pcap=max(32, int(o["p0"]) + 2 * int(o["delta"])))
+    # options['comm'] = (nranks, rank, unique_id): rows of the factor and of C sharded over the ranks (msdp_comm_init); this
+    # host loop then runs replicated -- same start point (pass Y0 or seed rng identically), same data, same decisions on
+    # every rank; the escape runs replicated on a full copy of the sparse C (device eigen-solver only)
+    comm = o.get("comm")
+    if comm is not None:
+        if not sp.issparse(Csp):
+            raise ValueError("row-sharded solves need a sparse C")
+        eig_mode = "device"
+        h.comm_init(int(comm[0]), int(comm[1]), comm[2])
     topts = _rtr_opts(o)
     p = int(o["p0"])
     Y = o.get("Y0", None)
@@ -230,9 +239,9 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
             data["rejected"] += st.rejected
             gradnorm = st.gradnorm                         # :44
             if not device_factor:
-                Y = h.get_point()
+                Y = (h.get_point_all() if comm is not None else h.get_point())
                 Y_eval = Y                                 # X = Y'*Y of :45 -- what the reference returns (:86)
-            z = h.get_z()                                  # :46-47  z = sum((Y*C).*Y)
+            z = h.get_z_all() if comm is not None else h.get_z()    # :46-47  z = sum((Y*C).*Y)
             obj = float(np.sum(z))                         # :48
             t1 = time.time()
             certified = True
@@ -285,20 +294,20 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
             if dinf < o["tol"] and certified:              # :57-60 (an unconverged Lanczos run certifies nothing)
                 _say(verbose, "Optimality is reached!")
                 if device_factor:
-                    Y_eval = h.get_point()
+                    Y_eval = (h.get_point_all() if comm is not None else h.get_point())
                 break
             if it % 20 == 0:                               # :61-69
                 if it > 50 and dinf > dinf0:
                     data["status"] = 2
                     _say(verbose, "Slow progress!")
                     if device_factor:
-                        Y_eval = h.get_point()
+                        Y_eval = (h.get_point_all() if comm is not None else h.get_point())
                     break
                 dinf0 = dinf
             nne = max(min(nneg, int(o["delta"])), 1)       # :74
             if device_factor:
                 if it == int(o["AL_maxiter"]):
-                    Y_eval = h.get_point()                 # last pass: the evaluated point, before it is re-shaped
+                    Y_eval = (h.get_point_all() if comm is not None else h.get_point())                 # last pass: the evaluated point, before it is re-shaped
                 try:
                     if r <= p - 1:                         # :70-73
                         h.factor_rotate(Q[:, :r])
@@ -310,7 +319,7 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
                 except _lib.MsdpError as err:              # wider than the handle's buffers: re-enter through set_point
                     if "allocated capacity" not in str(err):
                         raise
-                    Y = h.get_point()                      # the factor as the device holds it (already cut)
+                    Y = (h.get_point_all() if comm is not None else h.get_point())                      # the factor as the device holds it (already cut)
                     Y = np.hstack([Y, o["alpha"] * vS[:, :nne]])
                     Y = np.ascontiguousarray(Y / np.sqrt(np.sum(Y * Y, axis=1, keepdims=True)))
                     p = Y.shape[1]

@@ -26,6 +26,8 @@ def main():
     rng = np.random.default_rng(11)
     if case == "affine":
         return affine_case(out, rank, world, uid[0], dist, torch, _lib, problems)
+    if case == "solve":
+        return solve_case(out, rank, world, uid[0], dist, _lib, problems)
     if case == "sparse":
         C = problems.toroidal_grid_maxcut(61, 50, seed=4)           # n = 3050: ragged last shard for N = 4, 8
         n, p = C.shape[0], 12
@@ -100,6 +102,20 @@ def affine_case(out, rank, world, uid, dist, torch, _lib, problems):
         np.savez(out, f=f, G=parts[0].cpu().numpy(), H=parts[1].cpu().numpy(), co=co, cost=st.cost, hessvecs=st.hessvecs, Y=Yr, obj=obj,
                  Ax=Ax, z=z, lam=lam, lmax=lmax, replicated_ok=replicated_ok, solve_obj=objs, solve_status=ds["status"],
                  solve_eta=max(ds["gap"], ds["pinf"], ds["dinf"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def solve_case(out, rank, world, uid, dist, _lib, problems):
+    """ManiSDP_onlyunitdiag end to end on a row-sharded toroidal-grid MaxCut problem (sparse C): sharded RTR, replicated
+    escape, replicated host loop."""
+    from manisdp_matlab_amd import solvers
+    C = problems.toroidal_grid_maxcut(40, 50, seed=6)
+    rng = np.random.default_rng(9)
+    Y0 = rng.standard_normal((C.shape[0], 2)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    Y, obj, data = solvers.ManiSDP_onlyunitdiag(C, {"Y0": Y0, "tol": 1e-8, "comm": (world, rank, uid)}, verbose=False)
+    if rank == 0:
+        np.savez(out, obj=obj, status=data["status"], dinf=data["dinf"], iters=data["iters"], Y=Y, z=data["z"])
     dist.barrier()
     dist.destroy_process_group()
 

@@ -184,3 +184,48 @@ def test_affine_ranks_on_separate_gpus_match_one_rank(tmp_path, N):
     _, obj1, d1 = solvers.ManiSDP_unitdiag(At, b, c, K, {"Y0": Y0, "tol": 1e-8}, verbose=False)
     assert int(got["solve_status"]) == 0 and float(got["solve_eta"]) < 1e-8
     assert abs(float(got["solve_obj"]) - obj1) <= 1e-6 * max(1.0, abs(obj1))
+
+
+def test_size1_communicator_onlyunitdiag_solve(monkeypatch):
+    """ManiSDP_onlyunitdiag through the host loop with options['comm'] (size-1 communicator): sharded RTR, the escape on the
+    replicated copy of C with gathered z and Y, get_point_all / get_z_all, the device-resident factor -- against the
+    communicator-free solve of the same instance (G1; KKT 1e-8, same optimum)."""
+    from manisdp_matlab_amd import _lib, problems, solvers
+    C = problems.maxcut_cost_matrix(golden_path("G1.txt.gz"))
+    rng = np.random.default_rng(2)
+    Y0 = rng.standard_normal((C.shape[0], 2)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    o = {"Y0": Y0, "tol": 1e-8, "eig": "device"}
+    Ya, obja, da = solvers.ManiSDP_onlyunitdiag(C, dict(o), verbose=False)
+    Yb, objb, db = solvers.ManiSDP_onlyunitdiag(C, dict(o, comm=(1, 0, _lib.Handle.comm_unique_id())), verbose=False)
+    assert da["status"] == 0 and db["status"] == 0 and db["dinf"] < 1e-8
+    assert abs(obja - objb) <= 1e-7 * abs(obja)
+    assert np.allclose(np.linalg.norm(Yb, axis=1), 1.0, atol=1e-12) and db["z"].shape == (C.shape[0],)
+
+
+@pytest.mark.parametrize("N", [2, 4, 8])
+def test_onlyunitdiag_solve_on_separate_gpus(tmp_path, N):
+    """Whole ManiSDP_onlyunitdiag solve on N GPUs (sharded RTR, replicated escape and host loop) against the one-GPU solve.
+    Needs N visible GPUs (skipped on the single-GPU box; its single-GPU stand-in is test_size1_communicator_onlyunitdiag_solve)."""
+    import os, subprocess, sys
+    import torch
+    if torch.cuda.device_count() < N:
+        pytest.skip("needs %d GPUs, %d visible" % (N, torch.cuda.device_count()))
+    from manisdp_matlab_amd import problems, solvers
+    out = str(tmp_path / "solve.npz")
+    port = _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "multirank_worker.py")
+    procs = []
+    for r in range(N):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, worker, "solve", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=900)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    got = np.load(out)
+    C = problems.toroidal_grid_maxcut(40, 50, seed=6)
+    rng = np.random.default_rng(9)
+    Y0 = rng.standard_normal((C.shape[0], 2)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    _, obj1, d1 = solvers.ManiSDP_onlyunitdiag(C, {"Y0": Y0, "tol": 1e-8, "eig": "device"}, verbose=False)
+    assert int(got["status"]) == 0 and float(got["dinf"]) < 1e-8 and d1["status"] == 0
+    assert abs(float(got["obj"]) - obj1) <= 1e-7 * abs(obj1)
+    assert np.allclose(np.linalg.norm(got["Y"], axis=1), 1.0, atol=1e-12)
