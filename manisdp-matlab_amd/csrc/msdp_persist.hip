@@ -97,11 +97,14 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
 #define ROW(r) (lo + SLOT(r))
 #define ROK(r) (ROW(r) < hi)
 #define OK(r) (ROK(r) && colok)
-    // R = 8 (p = 33..64): four resident vectors = 128 registers + temporaries spill.  There mdelta and Hmdelta live
+    // p = 33..64 (LPR = 32).  R = 5 row slots (80 rows per workgroup: n <= 20480 on 256 CUs): every vector stays in
+    // registers, 256 VGPRs with 7 dwords of scratch, two-synchronisation trip -- 9.9 us per trip on G81 at p = 40.
+    // R = 8 (larger n): four resident vectors = 128 registers + temporaries spill; there mdelta and Hmdelta live
     // in LDS (the regions that hold Y and grad otherwise) and Y / grad are re-read from global memory (static
-    // during the launch: plain cached loads, L2 resident); only eta and r stay in registers.
-    constexpr bool LOWREG = (R > 4);
-    // TWOSYNC (everything but LOWREG): two grid synchronisations per trip instead of three.  The workgroups publish
+    // during the launch: plain cached loads, L2 resident); only eta and r stay in registers (LOWREG, three
+    // synchronisations: 17.6 us per trip).
+    constexpr bool LOWREG = (R > 5);
+    // TWOSYNC (everything but LOWREG; measured with LOWREG: the extra C*mdelta registers spill, 21 us): two grid synchronisations per trip instead of three.  The workgroups publish
     // the rows of the new RESIDUAL (known before the second reduction) instead of the new direction (known only after
     // it), the stores complete before the workgroup posts its partial sums, so the second reduction doubles as the
     // barrier in front of the gathers; the product with the new direction follows from linearity,
@@ -458,6 +461,9 @@ static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
     pl.r = lpr / 4;                                    // 128 row slots per workgroup
     const int rstep = PWAVES * (64 / lpr);
     const int need = (d.n_loc + G - 1) / G;
+    // p = 33..64: five row slots (80 rows per workgroup: n <= 20480 on 256 CUs) keep every vector in registers and take
+    // the two-synchronisation trip; eight slots (LOWREG: mdelta / Hmdelta in LDS, three synchronisations) beyond that
+    if (lpr == 32 && need <= 5 * rstep) pl.r = 5;
     if (need > pl.r * rstep) return false;
     const size_t rows = (size_t)pl.r * rstep;
     pl.lds = (size_t)2 * pl.r * PB * sizeof(double2) + rows * sizeof(double) + (size_t)pl.ew * rows * (sizeof(double) + sizeof(int));
@@ -467,6 +473,11 @@ static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
 typedef void (*persist_fn)(Dev, unsigned long long*, int*);
 static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false) {
 #define PK(L, E) if (pl.lpr == L && pl.ew == E && pl.r == L / 4) return k_tcg_persist_obl<L, E, L / 4, false>;
+    if (!fuse && pl.lpr == 32 && pl.r == 5) {
+        if (pl.ew == 5) return k_tcg_persist_obl<32, 5, 5, false>;
+        if (pl.ew == 8) return k_tcg_persist_obl<32, 8, 5, false>;
+        if (pl.ew == 0) return k_tcg_persist_obl<32, 0, 5, false>;
+    }
 #define PKF(L, E) if (fuse && pl.lpr == L && pl.ew == E && pl.r == L / 4) return k_tcg_persist_obl<L, E, L / 4, true>;
     PKF(8, 5) PKF(8, 8) PKF(16, 5) PKF(16, 8) PKF(8, 0) PKF(16, 0)
     if (fuse) return nullptr;                          // the fused form needs Y and grad in LDS (p <= 32)
