@@ -464,6 +464,9 @@ static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
     // p = 33..64: five row slots (80 rows per workgroup: n <= 20480 on 256 CUs) keep every vector in registers and take
     // the two-synchronisation trip; eight slots (LOWREG: mdelta / Hmdelta in LDS, three synchronisations) beyond that
     if (lpr == 32 && need <= 5 * rstep) pl.r = 5;
+    // p = 17..32: three row slots (96 rows per workgroup) when they suffice -- the fourth slot of the 128-slot form would be
+    // a quarter of the trip's gathers and arithmetic spent on masked rows (G81 on 256 CUs owns 79 rows per workgroup)
+    if (lpr == 16 && need <= 3 * rstep) pl.r = 3;
     if (need > pl.r * rstep) return false;
     const size_t rows = (size_t)pl.r * rstep;
     pl.lds = (size_t)2 * pl.r * PB * sizeof(double2) + rows * sizeof(double) + (size_t)pl.ew * rows * (sizeof(double) + sizeof(int));
@@ -473,6 +476,17 @@ static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
 typedef void (*persist_fn)(Dev, unsigned long long*, int*);
 static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false) {
 #define PK(L, E) if (pl.lpr == L && pl.ew == E && pl.r == L / 4) return k_tcg_persist_obl<L, E, L / 4, false>;
+    if (pl.lpr == 16 && pl.r == 3) {
+        if (fuse) {
+            if (pl.ew == 5) return k_tcg_persist_obl<16, 5, 3, true>;
+            if (pl.ew == 8) return k_tcg_persist_obl<16, 8, 3, true>;
+            if (pl.ew == 0) return k_tcg_persist_obl<16, 0, 3, true>;
+        } else {
+            if (pl.ew == 5) return k_tcg_persist_obl<16, 5, 3, false>;
+            if (pl.ew == 8) return k_tcg_persist_obl<16, 8, 3, false>;
+            if (pl.ew == 0) return k_tcg_persist_obl<16, 0, 3, false>;
+        }
+    }
     if (!fuse && pl.lpr == 32 && pl.r == 5) {
         if (pl.ew == 5) return k_tcg_persist_obl<32, 5, 5, false>;
         if (pl.ew == 8) return k_tcg_persist_obl<32, 8, 5, false>;
