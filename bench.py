@@ -238,7 +238,7 @@ def main():
     #  * one whole tCG trip (S*U + every vector update + the three reductions).  On one GPU at this size the
     #    trips run inside the persistent kernel k_tcg_persist_obl (working set resident in registers/LDS), which
     #    is where >90% of the step's device time goes: it is the dominant kernel of the roofline object
-    #    (profiles/r2_bench_kernel_stats.csv: k_tcg_persist_obl<16,5,4,false> = the 512 timed trips of bench_tcg_trip).
+    #    (profiles/r2_bench_kernel_stats.csv: k_tcg_persist_obl<16,5,3,false> = the 512 timed trips of bench_tcg_trip).
     h.set_point(Y0)
     ms, abytes, aflops = h.bench_hessvec(200)
     trip_ms = h.bench_tcg_trip(512)
