@@ -515,6 +515,15 @@ static int persist_grid(const Dev& d) {
     int g = d.G;
     if (g > cus) g = (cus / 8) * 8;
     if (g > 256) g = 256;                              // psync polls 4 x 64 slots
+    // the fewest workgroups that need the same number of row slots: a workgroup with 93 rows in three slots of 32 takes as
+    // long as one with 79, and the grid synchronisation has fewer slots to poll
+    PersistPlan pl;
+    if (g >= 8 && persist_plan(d, g, pl)) {
+        const int cap = pl.r * PWAVES * (64 / pl.lpr);
+        int gmin = (((d.n_loc + cap - 1) / cap + 7) / 8) * 8;
+        if (gmin < 8) gmin = 8;
+        if (gmin < g) g = gmin;
+    }
     return g;
 }
 
