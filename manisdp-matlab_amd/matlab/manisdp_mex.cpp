@@ -20,6 +20,9 @@
 //       manisdp_mex('set_multipliers', h, y, sigma)
 //       manisdp_mex('set_point', h, Y)                   Y in the reference layout of the handle's kind
 //   Y = manisdp_mex('get_point', h)
+//   G = manisdp_mex('factor_gram', h)                    p x p Gram matrix of the resident factor (computed on the GPU)
+//       manisdp_mex('factor_rotate', h, Qt)              resident factor <- its rank cut; Qt = Q(:,1:r)' is r x p
+//       manisdp_mex('factor_append', h, D, alpha, normalize)   resident factor <- [factor; alpha*D'] (D: n x k), columns renormalised
 //   info = manisdp_mex('rtr', h, opts)                   trustregions() on the resident point; opts.maxiter/maxinner/tolgradnorm
 //                                                        [/Delta_bar: M.typicaldist() of a product manifold]
 //   v = manisdp_mex('linesearch_cost', h, U, alpha)      co(retr(Y + alpha*U)); alpha = 0 (U may be []) gives co(Y)
@@ -283,6 +286,28 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         rc = msdp_get_point(h, mxGetPr(Y));
         if (rc) { mxDestroyArray(Y); fail("get_point", rc); }
         plhs[0] = Y;
+    } else if (cmd == "factor_gram") {
+        int32_t p = 0;
+        int rc = msdp_get_p(h, &p);
+        if (rc) fail("get_p", rc);
+        mxArray* G = mxCreateDoubleMatrix((mwSize)p, (mwSize)p, mxREAL);
+        rc = msdp_factor_gram(h, mxGetPr(G));
+        if (rc) { mxDestroyArray(G); fail("factor_gram", rc); }
+        plhs[0] = G;
+    } else if (cmd == "factor_rotate") {
+        need(nrhs == 3, "manisdp_mex('factor_rotate', h, Qt)   % Qt = Q(:,1:r)' (r x p)");
+        int32_t p = 0;
+        int rc = msdp_get_p(h, &p);
+        if (rc) fail("get_p", rc);
+        if (mxIsSparse(prhs[2]) || (int32_t)mxGetN(prhs[2]) != p) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "Qt must be a full r x p matrix (p = %d)", (int)p);
+        // r x p column-major == p x r row-major, the layout msdp_factor_rotate reads
+        rc = msdp_factor_rotate(h, (int32_t)mxGetM(prhs[2]), mxGetPr(prhs[2]));
+        if (rc) fail("factor_rotate", rc);
+    } else if (cmd == "factor_append") {
+        need(nrhs == 5, "manisdp_mex('factor_append', h, D, alpha, normalize)");
+        if (mxIsSparse(prhs[2]) || (int64_t)mxGetM(prhs[2]) != me.n) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "D must be a full n x k matrix");
+        const int rc = msdp_factor_append(h, (int32_t)mxGetN(prhs[2]), mxGetPr(prhs[2]), mxGetScalar(prhs[3]), (int32_t)mxGetScalar(prhs[4]));
+        if (rc) fail("factor_append", rc);
     } else if (cmd == "rtr") {
         need(nrhs == 3, "info = manisdp_mex('rtr', h, opts)");
         msdp_rtr_opts o;

@@ -13,7 +13,10 @@ function [X, obj, data] = msdp_al_engine(kind, prob, options, defaults)
 %       eS, z, S                              -> 'al_dual'                             (S stays on the GPU)
 %       eig(S): lambda_min, lambda_max, <= delta bottom eigenvectors -> 'escape_eigs' / 'escape_eigs_dual'
 %       co() inside line_search               -> 'linesearch_cost' / 'linesearch_accept'
-%       svd(Y) for the rank estimate          -> eig of the p x p Gram matrix (host, p is small)
+%       svd(Y) for the rank estimate          -> eig of the p x p Gram matrix (host, p is small); for onlyunitdiag the Gram
+%                                                matrix itself, the rank cut and the widening by the escape directions
+%                                                are 'factor_gram' / 'factor_rotate' / 'factor_append': the factor stays
+%                                                on the GPU between two trustregions() calls
 %   Option names, defaults, the printed protocol and the fields of DATA are the reference's (README.md:19-111 of
 %   the reference; SURVEY.md appendix A).  Extra optional fields: options.Y0 (start point, any kind),
 %   options.eig_tol / options.eig_maxit (Lanczos controls), options.dense_output (return dense X and S; default
@@ -61,6 +64,9 @@ if ~isfield(opt, 'eig_tol'),   opt.eig_tol = 1e-10; end
 if ~isfield(opt, 'eig_maxit'), opt.eig_maxit = 20000; end
 if ~isfield(opt, 'dense_output'), opt.dense_output = (n <= 8192); end
 
+% onlyunitdiag without line search: the factor is re-shaped on the device and comes to the host once, at the end
+keep_on_device = strcmp(kind, 'onlyunitdiag') && opt.line_search ~= 1;
+resident = false;
 data.status = 0;
 if strcmp(kind, 'unitdiag'), fac_size = []; end
 watch = [];                        % residues remembered for the slow-progress test
@@ -71,12 +77,14 @@ t0 = tic;
 for iter = 1:opt.AL_maxiter
     if strcmp(kind, 'unitdiag'), fac_size(end + 1) = p; end %#ok<AGROW>
     if T.affine, manisdp_mex('set_multipliers', h, y, sigma); end
-    manisdp_mex('set_point', h, Y);
+    if ~resident, manisdp_mex('set_point', h, Y); end
     if ~isempty(U), backtrack_on_device(h, U); end
     info = manisdp_mex('rtr', h, tr_opts);
     gradnorm = info.gradnorm;
-    Y = manisdp_mex('get_point', h);
-    Yeval = Y;                                 % the point the residues below belong to; what X is built from at the end
+    if ~keep_on_device
+        Y = manisdp_mex('get_point', h);
+        Yeval = Y;                             % the point the residues below belong to; what X is built from at the end
+    end
 
     % ---- KKT quantities from the device
     if T.affine
@@ -111,7 +119,7 @@ for iter = 1:opt.AL_maxiter
     end
 
     % ---- numerical rank of the factor from its p x p Gram matrix
-    if T.wide, G = Y*Y'; else, G = Y'*Y; end
+    if keep_on_device, G = manisdp_mex('factor_gram', h); elseif T.wide, G = Y*Y'; else, G = Y'*Y; end
     [Qg, wg] = eig((G + G')/2, 'vector');
     [wg, order] = sort(max(wg, 0), 'descend');
     Qg = Qg(:, order);
@@ -130,24 +138,47 @@ for iter = 1:opt.AL_maxiter
     end
     if eta < opt.tol && certified
         fprintf('Optimality is reached!\n');
+        if keep_on_device, Yeval = manisdp_mex('get_point', h); end
         break;
     end
     if mod(iter, T.watch_every) == 0
         if iter > T.watch_after && ~isempty(watch) && all(now > watch)
             data.status = 2;
             fprintf('Slow progress!\n');
+            if keep_on_device, Yeval = manisdp_mex('get_point', h); end
             break;
         end
         watch = now;
     end
 
     % ---- rank cut, then escape directions (or the line-search direction for the next round)
+    nneg = min(sum(lam < 0), opt.delta);       % missing pairs come back as +inf
+    if T.at_least_one, nneg = max(nneg, 1); end
+    if keep_on_device
+        if iter == opt.AL_maxiter, Yeval = manisdp_mex('get_point', h); end     % last pass: the evaluated point
+        if r <= p - 1
+            manisdp_mex('factor_rotate', h, Qg(:, 1:r)');
+            p = r;
+        end
+        try
+            manisdp_mex('factor_append', h, V(:, 1:nneg), opt.alpha, 1);
+            p = p + nneg;
+            resident = true;
+            continue;
+        catch err
+            % wider than the buffers the handle has allocated: finish this step on the host, re-enter through set_point
+            if isempty(strfind(err.message, 'allocated capacity')), rethrow(err); end %#ok<STREMP>
+            Y = manisdp_mex('get_point', h);   % already cut
+            Y = T.normalise([Y; opt.alpha*V(:, 1:nneg)']);
+            p = p + nneg;
+            resident = false;
+            continue;
+        end
+    end
     if r <= p - 1
         if T.wide, Y = Qg(:, 1:r)'*Y; else, Y = Y*Qg(:, 1:r); end
         p = r;
     end
-    nneg = min(sum(lam < 0), opt.delta);       % missing pairs come back as +inf
-    if T.at_least_one, nneg = max(nneg, 1); end
     D = V(:, 1:nneg);                          % n x nneg
     if opt.line_search == 1
         if T.wide

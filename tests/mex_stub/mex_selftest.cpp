@@ -129,6 +129,24 @@ int run_onlyunitdiag(const char* in, const char* outp) {
     mxArray* c_kind = mxCreateString("kind");
     mxArray* kind = call(1, {c_kind, h})[0];
     w.put(Y); w.put(z); w.put(e[0]); w.put(e[1]);
+    // the resident-factor commands the engine uses between two rtr calls: Gram matrix, rank cut to r = p - 2 with the
+    // leading columns of the identity (Qt = [I_r 0]), widening by the first escape vector
+    mxArray* c_gram = mxCreateString("factor_gram");
+    mxArray* G = call(1, {c_gram, h})[0];
+    const mwSize rr = (mwSize)p - 2;
+    mxArray* Qt = mxCreateDoubleMatrix(rr, (mwSize)p, mxREAL);
+    for (mwSize i = 0; i < rr; ++i) mxGetPr(Qt)[i + i * rr] = 1.0;
+    mxArray* c_rot = mxCreateString("factor_rotate");
+    call(0, {c_rot, h, Qt});
+    mxArray* c_app = mxCreateString("factor_append");
+    mxArray* D = mxCreateDoubleMatrix((mwSize)n, 1, mxREAL);
+    for (int64_t i = 0; i < n; ++i) mxGetPr(D)[i] = mxGetPr(e[1])[i];
+    mxArray* alpha = mxCreateDoubleScalar(0.5);
+    mxArray* one = mxCreateDoubleScalar(1.0);
+    call(0, {c_app, h, D, alpha, one});
+    mxArray* Y2 = call(1, {c_get, h})[0];
+    w.put(G); w.put(Y2);
+    for (mxArray* a : {c_gram, G, Qt, c_rot, c_app, D, alpha, one, Y2}) mxDestroyArray(a);
     printf("{\"kind\": %d, \"rows\": %zu, \"cols\": %zu, \"cost\": %.17g, \"gradnorm\": %.17g, \"hessvecs\": %d, \"iters\": %d, "
            "\"lmax\": %.17g, \"ok\": %d}\n",
            (int)mxGetScalar(kind), mxGetM(Y), mxGetN(Y), field(info, "cost"), field(info, "gradnorm"), (int)field(info, "hessvecs"),

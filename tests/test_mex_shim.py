@@ -120,9 +120,15 @@ def test_gateway_onlyunitdiag_matches_ctypes(tmp_path):
     Y = h.get_point(); z = h.get_z()
     lam, V, lmax, _ = h.escape_eigs(k, tol=1e-10, maxit=2000)
     _, conv, _ = h.escape_info()
+    G = h.factor_gram()
+    Q = np.eye(p)[:, :p - 2]
+    h.factor_rotate(Q)
+    h.factor_append(V[:, :1], 0.5, normalize=True)
+    Y2 = h.get_point()
+    assert Y2.shape == (n, p - 1)
     h.close()
     o = 0
-    for ref in (Y.ravel(), z, lam, V.ravel(order="F")):
+    for ref in (Y.ravel(), z, lam, V.ravel(order="F"), G.ravel(), Y2.ravel()):
         got = arr[o:o + ref.size]; o += ref.size
         assert np.array_equal(got, ref)
     assert o == arr.size
