@@ -322,3 +322,29 @@ def test_device_factor_path_follows_host_path():
         out.append((obj, data["iters"], Y.shape[1]))
     assert abs(out[0][0] - out[1][0]) <= 1e-7 * abs(out[1][0])
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+
+
+@pytest.mark.parametrize("rows,cols,p", [(100, 200, 40), (150, 160, 40), (150, 160, 32), (130, 200, 32), (100, 200, 16)])
+def test_persistent_instances_agree_with_chunked_path(rows, cols, p):
+    """Every row-slot instance of the persistent tCG kernel (three / four slots at p <= 32, five / eight at p = 33..64, chosen
+    by the rows a workgroup owns) against the chunked three-kernel path on the same start point: same Hess-vec count and
+    stop decisions, cost and gradient norm to rounding."""
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    C = problems.toroidal_grid_maxcut(rows, cols, seed=3)
+    n = C.shape[0]
+    rng = np.random.default_rng(p)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    res = []
+    for persist in (1, 0):
+        h = _lib.Handle.onlyunitdiag(C, pcap=p)
+        h.set_option("persist", persist)
+        h.set_point(Y)
+        assert h.tcg_path() == persist
+        st = h.rtr(_lib.default_opts(maxiter=6, maxinner=40, tolgradnorm=1e-9))
+        res.append((st.hessvecs, st.accepted, st.rejected, st.cost, st.gradnorm, h.get_point()))
+        h.close()
+    a, b = res
+    assert a[:3] == b[:3]
+    assert abs(a[3] - b[3]) <= 1e-11 * abs(b[3]) and abs(a[4] - b[4]) <= 1e-7 * max(b[4], 1e-12)
+    assert np.linalg.norm(a[5] - b[5]) <= 1e-8 * np.linalg.norm(b[5])
