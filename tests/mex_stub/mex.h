@@ -52,7 +52,7 @@ inline mxArray* mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity) {
 inline mxArray* mxCreateDoubleScalar(double v) { mxArray* a = mxCreateDoubleMatrix(1, 1, mxREAL); a->pr[0] = v; return a; }
 inline mxArray* mxCreateNumericMatrix(mwSize m, mwSize n, mxClassID cls, mxComplexity) {
     if (cls == mxDOUBLE_CLASS) return mxCreateDoubleMatrix(m, n, mxREAL);
-    mxArray* a = new mxArray(); a->cls = cls; a->m = m; a->n = n; a->u64.assign(m * n ? m * n : 1, 0); return a;
+    mxArray* a = new mxArray(); a->cls = cls; a->m = m; a->n = n; a->u64.assign((m * n) != 0 ? m * n : 1, 0); return a;
 }
 inline mxArray* mxCreateSparse(mwSize m, mwSize n, mwSize nzmax, mxComplexity) {
     mxArray* a = new mxArray(); a->cls = mxDOUBLE_CLASS; a->m = m; a->n = n; a->sparse = true;
