@@ -47,7 +47,7 @@ struct mex_stub_error : std::runtime_error {
 
 /* ---- creation / destruction */
 inline mxArray* mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity) {
-    mxArray* a = new mxArray(); a->cls = mxDOUBLE_CLASS; a->m = m; a->n = n; a->pr.assign(m * n ? m * n : 1, 0.0); return a;
+    mxArray* a = new mxArray(); a->cls = mxDOUBLE_CLASS; a->m = m; a->n = n; a->pr.assign((m * n) != 0 ? m * n : 1, 0.0); return a;
 }
 inline mxArray* mxCreateDoubleScalar(double v) { mxArray* a = mxCreateDoubleMatrix(1, 1, mxREAL); a->pr[0] = v; return a; }
 inline mxArray* mxCreateNumericMatrix(mwSize m, mwSize n, mxClassID cls, mxComplexity) {
