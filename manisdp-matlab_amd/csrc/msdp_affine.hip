@@ -946,8 +946,10 @@ int msdp_affine_set_multipliers(msdp_handle h, const double* y, double sigma) {
             hipLaunchKernelGGL((KERNEL<64, 2>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
         } else if (nch <= 4) {                                                                       \
             hipLaunchKernelGGL((KERNEL<64, 4>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
+        } else if (nch <= 8) {                                                                       \
+            hipLaunchKernelGGL((KERNEL<64, 8>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
         } else {                                                                                     \
-            msdp_set_error("factor width p = %d exceeds the supported maximum of 512", (h)->d.p);    \
+            msdp_set_error("factor width p = %d exceeds the supported maximum of 1024", (h)->d.p);    \
             return MSDP_EUNSUPPORTED;                                                                \
         }                                                                                            \
     } while (0)

@@ -582,7 +582,7 @@ static int download_rows(msdp_handle h, const double* src, double* host) {
 extern "C" int msdp_set_point(msdp_handle h, int32_t p, const double* Y) {
     CHECK_H(h);
     if (p < 1 || !Y) { msdp_set_error("set_point: p = %d, Y = %p", p, (const void*)Y); return MSDP_EINVAL; }
-    if (p > 512) { msdp_set_error("factor width p = %d exceeds the supported maximum of 512", p); return MSDP_EUNSUPPORTED; }
+    if (p > 1024) { msdp_set_error("factor width p = %d exceeds the supported maximum of 1024", p); return MSDP_EUNSUPPORTED; }
     Dev& d = h->d;
     if (p > h->pcap) {
         int rc = msdp_alloc_vectors(h, p + 16);

@@ -622,8 +622,10 @@ static inline void lpr_for(int ld, int& lpr, int& nch) {
             hipLaunchKernelGGL((KERNEL<64, 2>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
         } else if (nch <= 4 && lpr == 64) {                                                          \
             hipLaunchKernelGGL((KERNEL<64, 4>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
+        } else if (nch <= 8 && lpr == 64) {                                                          \
+            hipLaunchKernelGGL((KERNEL<64, 8>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
         } else {                                                                                     \
-            msdp_set_error("factor width p = %d exceeds the supported maximum of 512", (h)->d.p);    \
+            msdp_set_error("factor width p = %d exceeds the supported maximum of 1024", (h)->d.p);    \
             return MSDP_EUNSUPPORTED;                                                                \
         }                                                                                            \
     } while (0)

@@ -131,8 +131,8 @@ def test_error_paths(lib):
         h.rtr(lib.default_opts(maxiter=1, maxinner=1, rho_prime=0.3))
     with pytest.raises(lib.MsdpError):            # multipliers on a handle without affine constraints
         h.set_multipliers(np.zeros(3), 1.0)
-    with pytest.raises(lib.MsdpError):            # p > 512 unsupported
-        h.set_point(np.ones((C.shape[0], 600)))
+    with pytest.raises(lib.MsdpError):            # p > 1024 unsupported
+        h.set_point(np.ones((C.shape[0], 1100)))
     h.close()
 
 
@@ -348,3 +348,51 @@ def test_persistent_instances_agree_with_chunked_path(rows, cols, p):
     assert a[:3] == b[:3]
     assert abs(a[3] - b[3]) <= 1e-11 * abs(b[3]) and abs(a[4] - b[4]) <= 1e-7 * max(b[4], 1e-12)
     assert np.linalg.norm(a[5] - b[5]) <= 1e-8 * np.linalg.norm(b[5])
+
+
+@pytest.mark.parametrize("p", [600, 1000])
+def test_wide_factors_up_to_1024(p):
+    """Factor widths beyond 512 (eight column chunks per lane; a quartic-on-sphere relaxation with d = 100 asks for p = 518):
+    sparse C, dense C and the unit-diagonal affine operators against the oracle; p > 1024 is refused."""
+    import scipy.sparse as sp
+    from manisdp_matlab_amd import _lib, problems
+    from oracle import manisdp_ref as R
+    from conftest import golden_path
+    _lib.load()
+    rng = np.random.default_rng(p)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)    # noqa: E731
+    # sparse and dense onlyunitdiag
+    C = problems.toroidal_grid_maxcut(30, 40, seed=1)
+    n = C.shape[0]
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    prob = R._OnlyUnitDiagProblem(C, n, p)
+    f, G, H = prob.cost(Y), prob.grad(Y), prob.hess(Y, U)
+    for Cin in (C, C.toarray()):
+        h = _lib.Handle.onlyunitdiag(Cin, pcap=p)
+        h.set_point(Y)
+        assert abs(h.cost() - f) <= 1e-11 * abs(f)
+        assert rel(h.rgrad(), G) < 1e-11 and rel(h.hessvec(U), H) < 1e-11
+        st = h.rtr(_lib.default_opts(maxiter=2, maxinner=5, tolgradnorm=1e-9))
+        assert st.hessvecs > 0 and np.isfinite(st.cost)
+        h.close()
+    # unit-diagonal affine kind (BQP d = 10)
+    Q = np.loadtxt(golden_path("bqp_Q_10_1.txt.gz"), delimiter=",")
+    e = np.loadtxt(golden_path("bqp_e_10_1.txt.gz"), delimiter=",")
+    At, b, c, K = problems.bqpmom(10, Q, e)
+    c = np.asarray(c.todense()).ravel(); b = np.asarray(b.todense()).ravel() if sp.issparse(b) else np.asarray(b, float).ravel()
+    n = K["s"]
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p)); U -= Y * np.sum(Y * U, axis=1, keepdims=True)
+    y = 0.1 * rng.standard_normal(b.size)
+    pa = R._UnitDiagProblem(At, b, c, n, p)
+    pa.y, pa.sigma = y, 0.7
+    fa, Ga, Ha = pa.cost(Y), pa.grad(Y), pa.hess(Y, U)
+    h = _lib.Handle.affine(_lib.KIND_UNITDIAG, sp.csc_matrix(At), b, c, n, pcap=p)
+    h.set_multipliers(y, 0.7)
+    h.set_point(Y)
+    assert abs(h.cost() - fa) <= 1e-10 * abs(fa)
+    assert rel(h.rgrad(), Ga) < 1e-10 and rel(h.hessvec(U), Ha) < 1e-10
+    with pytest.raises(_lib.MsdpError, match="maximum of 1024"):
+        h.set_point(np.ones((n, 1030)) / np.sqrt(1030.0))
+    h.close()
