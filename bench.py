@@ -162,6 +162,19 @@ def main():
         raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
     dist = None
+    if N > 1:
+        # A multi-rank run that stops making progress (a collective that one rank never enters) must end by itself with
+        # a message instead of sitting in the launcher until an outer time limit: 20 minutes is ten times the expected run
+        import threading
+
+        def _stuck():
+            sys.stderr.write("bench.py: rank %d made no progress for 1200 s -- giving up\n" % rank)
+            sys.stderr.flush()
+            os._exit(3)
+
+        _dog = threading.Timer(1200.0, _stuck)
+        _dog.daemon = True
+        _dog.start()
     if N > 1 or args.force_comm:
         # torch (its bundled HIP runtime + RCCL) must come up BEFORE libmanisdp_hip.so pulls in the system HIP
         # runtime: the other order leaves torch with "No HIP GPUs are available" (seen on the MI355X box)
