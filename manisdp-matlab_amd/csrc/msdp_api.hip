@@ -450,6 +450,7 @@ extern "C" int msdp_create_multiblock(int32_t nb, const int64_t* block_n, int32_
     return 0;
 }
 
+void msdp_escape_workspace_park(double* ptr, size_t cap_doubles);     // msdp_escape.hip
 int msdp_dual_setup(msdp_handle h, const int64_t* at_jc, const int64_t* at_ir, const double* at_pr, const double* b, const double* c,
                     const double* dAAt, int32_t nf, const int64_t* b_jc, const int64_t* b_ir, const double* b_pr, const double* cf);
 int msdp_dual_set_penalty_impl(msdp_handle h, double sigma, const double* wf_host);
@@ -511,7 +512,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     if (h->esc_ci) (void)hipFree(h->esc_ci);
     if (h->esc_cv) (void)hipFree(h->esc_cv);
     if (h->esc_z) (void)hipFree(h->esc_z);
-    if (h->esc_mem) (void)hipFree(h->esc_mem);       // esc_prev lives inside it
+    msdp_escape_workspace_park(h->esc_mem, h->esc_cap);      // esc_prev lives inside it; kept for the next handle of the process
     if (h->lz_slots) (void)hipFree(h->lz_slots);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

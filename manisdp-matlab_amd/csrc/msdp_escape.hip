@@ -646,6 +646,34 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
     return 0;
 }
 
+// One parked workspace per process: msdp_destroy hands the escape workspace of a handle here instead of freeing it, the
+// next handle that needs one of at most that size takes it over (the device is the process's current one; a workspace
+// parked on another device is released instead).
+#include <mutex>
+static std::mutex g_ws_mutex;
+static double* g_ws_ptr = nullptr;
+static size_t g_ws_cap = 0;
+static int g_ws_dev = -1;
+void msdp_escape_workspace_park(double* ptr, size_t cap_doubles) {
+    if (!ptr) return;
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    if (g_ws_ptr && g_ws_cap >= cap_doubles && g_ws_dev == dev) { (void)hipFree(ptr); return; }    // keep the larger one
+    if (g_ws_ptr) (void)hipFree(g_ws_ptr);
+    g_ws_ptr = ptr; g_ws_cap = cap_doubles; g_ws_dev = dev;
+}
+double* msdp_escape_workspace_take(size_t need_doubles, size_t* cap_out) {
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    if (!g_ws_ptr || g_ws_dev != dev || g_ws_cap < need_doubles) return nullptr;
+    double* p = g_ws_ptr;
+    *cap_out = g_ws_cap;
+    g_ws_ptr = nullptr; g_ws_cap = 0; g_ws_dev = -1;
+    return p;
+}
+
 int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_out, double* V_out, double* lmax_out,
                      int* iters_out, const double* Mdev) {
     Dev& d = h->d;
@@ -699,17 +727,25 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     if (h->esc_cap < total) {
         // grow with head room for 16 more factor columns: the factor width changes every outer iteration and a
         // reallocation of this size stalls the stream for ~0.1 s
-        const size_t want = total + (size_t)32 * n;
+        size_t want = total + (size_t)32 * n;
         double* nm = nullptr;
         (void)hipStreamSynchronize(h->stream);
-        hipError_t me = hipMalloc((void**)&nm, want * sizeof(double));
-        if (me != hipSuccess) { (void)hipGetLastError(); me = hipMalloc((void**)&nm, total * sizeof(double)); }
-        if (me != hipSuccess) { msdp_set_error("escape_eigs: workspace allocation (%zu MB) failed", total * 8 >> 20); return MSDP_ENOMEM; }
+        // a workspace parked by a destroyed handle of this process (same device) is taken over when it is large enough:
+        // allocating the 10-GB Lanczos basis of a G81-sized problem costs 0.05-0.5 s, once per process instead of per solve
+        size_t got = 0;
+        nm = msdp_escape_workspace_take(total, &got);
+        hipError_t me = hipSuccess;
+        if (nm) want = got;
+        else {
+            me = hipMalloc((void**)&nm, want * sizeof(double));
+            if (me != hipSuccess) { (void)hipGetLastError(); me = hipMalloc((void**)&nm, total * sizeof(double)); if (me == hipSuccess) want = total; }
+            if (me != hipSuccess) { msdp_set_error("escape_eigs: workspace allocation (%zu MB) failed", total * 8 >> 20); return MSDP_ENOMEM; }
+        }
         if (h->esc_mem && h->esc_prev_n == n) (void)hipMemcpy(nm, h->esc_mem, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice);
         else h->esc_prev_n = 0;
         if (h->esc_mem) (void)hipFree(h->esc_mem);
         h->esc_mem = nm;
-        h->esc_cap = (me == hipSuccess) ? want : total;
+        h->esc_cap = want;
     }
     mem = h->esc_mem + n;
     h->esc_prev = h->esc_mem;

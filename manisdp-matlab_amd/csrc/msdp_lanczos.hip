@@ -492,14 +492,21 @@ static int lz_grid(int n, int nq, int* RW_out, size_t* lds_out) {
     }
     int gmax = (cus / 8) * 8;
     if (gmax > LZ_GMAX) gmax = LZ_GMAX;
-    for (int G = 64; G <= gmax; G += 8) {
-        const int rw = (n + G - 1) / G;
-        if (rw > LZ_RMAX * LZ_PB) continue;
-        const size_t lds = ((size_t)(nq + 2) * rw + 2 * LZ_NV + LZ_PWAVES * LZ_NV + 64 + 8) * sizeof(double);
-        if (lds > 150 * 1024) continue;
-        *RW_out = rw; *lds_out = lds;
-        return G;
-    }
+    // The fewest workgroups with one row per thread (undeflated runs: a step is synchronisation latency plus one dependent gather: fewer
+    // slots to poll is faster as long as no thread walks two rows -- G81 undeflated: 3.6 us per step on 40 workgroups,
+    // 4.2 on 64, 4.9 on 32), more only where the rows or the LDS copy of Q demand it; two rows per thread as a last resort
+    // deflated runs: the per-step LDS work on the rows of Q grows with the rows per workgroup; measured on G81 with
+    // nq = 28..43: 64 workgroups 29.5 / 38.1 ms per run, 40: 32.5 / 41.5, 96: 34.5 / 44.6
+    const int gfirst = nq > 0 ? 64 : 8;
+    for (int rows_per_thread = 1; rows_per_thread <= LZ_RMAX; ++rows_per_thread)
+        for (int G = gfirst; G <= gmax; G += 8) {
+            const int rw = (n + G - 1) / G;
+            if (rw > rows_per_thread * LZ_PB) continue;
+            const size_t lds = ((size_t)(nq + 2) * rw + 2 * LZ_NV + LZ_PWAVES * LZ_NV + 64 + 8) * sizeof(double);
+            if (lds > 150 * 1024) continue;
+            *RW_out = rw; *lds_out = lds;
+            return G;
+        }
     return 0;
 }
 
