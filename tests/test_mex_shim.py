@@ -240,3 +240,59 @@ def test_gateway_dual_matches_ctypes(tmp_path):
     assert o == arr.size
     assert (meta["co0"], meta["co1"], meta["cost"], meta["by"], meta["cex"], meta["as2"]) == (co0, co1, st.cost, by, cex, as2)
     assert meta["hessvecs"] == st.hessvecs
+
+
+def _m_code(line):
+    """One line of MATLAB without its comment and with string literals emptied (a quote after an identifier, a closing
+    bracket or another quote is the transpose operator)."""
+    out, inq, i = "", False, 0
+    while i < len(line):
+        ch = line[i]
+        if inq:
+            if ch == "'":
+                if i + 1 < len(line) and line[i + 1] == "'":
+                    i += 2
+                    continue
+                inq = False
+            i += 1
+            continue
+        if ch == "'":
+            prev = line[i - 1] if i > 0 else " "
+            if not (prev.isalnum() or prev in ")]}'._"):
+                inq = True
+                i += 1
+                continue
+        if ch == "%":
+            break
+        out += ch
+        i += 1
+    return out
+
+
+def test_m_files_are_structurally_balanced():
+    """MATLAB is not in the image: at least every statement of the shipped .m files closes its brackets and every
+    function / for / while / if / switch / try has its end."""
+    import glob
+    for fn in sorted(glob.glob(os.path.join(MATLAB, "*.m"))):
+        lines = [_m_code(l) for l in open(fn).read().splitlines()]
+        stmt, start = "", 0
+        for k, c in enumerate(lines, 1):
+            if not stmt:
+                start = k
+            if c.rstrip().endswith("..."):
+                stmt += c.rstrip()[:-3]
+                continue
+            stmt += c
+            for o, cl in ("()", "[]", "{}"):
+                assert stmt.count(o) == stmt.count(cl), (os.path.basename(fn), start, stmt.strip()[:120])
+            stmt = ""
+        text = "\n".join(lines).replace("...\n", " ")
+        prev = None
+        while prev != text:                      # `end` inside an index expression is not a block end
+            prev = text
+            text = re.sub(r"\([^()\[\]{}]*\)|\[[^()\[\]{}]*\]|\{[^()\[\]{}]*\}", "", text)
+        depth = 0
+        for tok in re.findall(r"\b(function|for|while|if|switch|try|end)\b", text):
+            depth += -1 if tok == "end" else 1
+            assert depth >= 0, os.path.basename(fn)
+        assert depth == 0, os.path.basename(fn)
