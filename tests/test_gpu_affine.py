@@ -392,3 +392,21 @@ def test_solvers_with_device_al_bookkeeping_all_kinds(lib):
     assert max(res[0][1], res[1][1]) < 1e-3
     for obj, _, status in res:
         assert abs(-obj - known["theta1"]) < (1e-5 if status == 0 else 1e-2) * known["theta1"]
+
+
+def test_theta1_with_the_reference_examples_options(lib):
+    """example_theta.m:48-55 does not run ManiSDP_unittrace with its defaults but with tol = 1e-6, sigma0 = 1e5,
+    sigma_max = 1e8 and the line search.  With those options the solve converges (status 0, eta < 1e-6) for about half of
+    the start points -- the oracle: 2 of 3 -- and every converged run hits SDPLIB's value 23 (data/sdplib/README:98) to
+    1e-6 relative, the tolerance north_star states."""
+    from manisdp_matlab_amd import problems, solvers
+    At, b, c, K = problems.from_sdpa(golden_path("theta1.dat-s.gz"))
+    opts = {"tol": 1e-6, "sigma0": 1e5, "sigma_max": 1e8, "line_search": 1}
+    converged = 0
+    for seed in range(6):
+        _, obj, d = solvers.ManiSDP_unittrace(At, b, c, K, dict(opts), rng=np.random.default_rng(seed), verbose=False)
+        if d["status"] == 0:
+            converged += 1
+            assert max(d["gap"], d["pinf"], d["dinf"]) < 1e-6
+            assert abs(obj + 23.0) <= 1e-6 * 23.0, (seed, obj)
+    assert converged >= 2, converged
