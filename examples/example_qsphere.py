@@ -14,5 +14,5 @@ At, b, c, K = problems.qsmom(d, coe)
 b = np.asarray(b.todense()).ravel() if hasattr(b, "todense") else np.asarray(b, float)
 c = np.asarray(c.todense()).ravel() if hasattr(c, "todense") else np.asarray(c, float).ravel()
 t = time.time()
-Y, fval, data = solvers.ManiSDP(At, b, c, K, {"tol": 1e-8}, verbose=False)
+Y, fval, data = solvers.ManiSDP(At, b, c, K, {"tol": 1e-8, "theta": 1e-2, "tau1": 0.02}, verbose=False)    # example_qsphere.m:21-25
 print("ManiSDP: optimum = %.8f, eta = %.1e, time = %.2fs (n = %d, m = %d)" % (fval, eta(data), time.time() - t, K["s"], b.size))
