@@ -163,6 +163,10 @@ int msdp_dual_outer_step(msdp_handle h, double* scal, double* Af, double* z);
 int msdp_dual_get_y(msdp_handle h, double* y);
 
 int msdp_destroy(msdp_handle h);
+/* The library keeps ONE device allocation beyond the life of the handles: the Lanczos workspace of the escape (up to 24 GB for
+ * n = 20000; allocating it costs 0.05-0.5 s) is parked by msdp_destroy for the next handle of the process.  This call
+ * frees it (a long-lived host such as MATLAB calls it when it unloads the binding). */
+int msdp_release_cache(void);
 
 /* AL state that changes between trustregions() calls: y and sigma
  * (ManiSDP_unitdiag.m:64,108-112).  No-op error for onlyunitdiag handles. */

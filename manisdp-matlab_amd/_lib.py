@@ -82,6 +82,7 @@ SIGNATURES = {
     "msdp_escape_info": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _dp]),
     "msdp_escape_lower_bound": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_dual_slack": (C.c_int, [C.c_void_p, _dp]),
+    "msdp_release_cache": (C.c_int, []),
     "msdp_get_point_all": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_z_all": (C.c_int, [C.c_void_p, _dp]),
     "msdp_factor_gram": (C.c_int, [C.c_void_p, _dp]),

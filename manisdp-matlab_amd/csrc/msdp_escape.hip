@@ -663,6 +663,12 @@ void msdp_escape_workspace_park(double* ptr, size_t cap_doubles) {
     if (g_ws_ptr) (void)hipFree(g_ws_ptr);
     g_ws_ptr = ptr; g_ws_cap = cap_doubles; g_ws_dev = dev;
 }
+extern "C" int msdp_release_cache(void) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    if (g_ws_ptr) (void)hipFree(g_ws_ptr);
+    g_ws_ptr = nullptr; g_ws_cap = 0; g_ws_dev = -1;
+    return 0;
+}
 double* msdp_escape_workspace_take(size_t need_doubles, size_t* cap_out) {
     int dev = -1;
     (void)hipGetDevice(&dev);

@@ -63,6 +63,7 @@ bool g_exit_hooked = false;
 void destroy_all() {
     for (auto& kv : g_live) msdp_destroy((msdp_handle)(uintptr_t)kv.first);
     g_live.clear();
+    msdp_release_cache();                      // the escape workspace the library parks between handles
 }
 
 void fail(const char* what, int rc) {
