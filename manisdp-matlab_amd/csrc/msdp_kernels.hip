@@ -599,10 +599,22 @@ static inline void lpr_for(int ld, int& lpr, int& nch) {
     if (nch < 1) nch = 1;
 }
 
+// A workgroup walks its rows in passes of MSDP_WAVES*64/lpr rows.  When it owns between one and two passes' worth (G81 at
+// p = 17..32 on 256 workgroups: 79 rows, 64 per pass) the second pass runs with most waves idle but costs a full dependent
+// round of loads; half the lanes per row with two column chunks per lane puts all rows into ONE pass with twice the loads in
+// flight per lane.
+static inline void lpr_rebalance(msdp_handle h, int& lpr, int& nch) {
+    // (k_hess_ell_obl on G81 at p = 32: 6.18 -> 5.58 us.)
+    if (nch != 1 || (lpr != 16 && lpr != 32)) return;
+    const int rows_wg = (h->d.n_loc + h->d.G - 1) / h->d.G, per_pass = MSDP_WAVES * (64 / lpr);
+    if (rows_wg > per_pass && rows_wg <= 2 * per_pass) { lpr /= 2; nch = 2; }
+}
+
 #define DISPATCH_LPR(KERNEL, h, ...)                                                                 \
     do {                                                                                             \
         int lpr, nch;                                                                                \
         lpr_for((h)->d.ld, lpr, nch);                                                                \
+        lpr_rebalance((h), lpr, nch);                                                                \
         dim3 grid((h)->d.G), block(MSDP_BLOCK);                                                      \
         if (nch == 1) {                                                                              \
             switch (lpr) {                                                                           \
@@ -616,6 +628,8 @@ static inline void lpr_for(int ld, int& lpr, int& nch) {
             }                                                                                        \
         } else if (nch == 2 && lpr == 8) {                                                           \
             hipLaunchKernelGGL((KERNEL<8, 2>), grid, block, 0, (h)->stream, __VA_ARGS__);            \
+        } else if (nch == 2 && lpr == 16) {                                                          \
+            hipLaunchKernelGGL((KERNEL<16, 2>), grid, block, 0, (h)->stream, __VA_ARGS__);           \
         } else if (nch == 4 && lpr == 4) {                                                           \
             hipLaunchKernelGGL((KERNEL<4, 4>), grid, block, 0, (h)->stream, __VA_ARGS__);            \
         } else if (nch == 2 && lpr == 64) {                                                          \
