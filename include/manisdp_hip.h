@@ -278,6 +278,13 @@ int msdp_escape_lower_bound(msdp_handle h, double* lam_lower);
  * msdp_comm_unique_id and broadcast by the host launcher. */
 int msdp_comm_unique_id(void* id128);
 int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const void* id128);
+/* Test / diagnostic stand-in for the communicator: member `rank` of the in-process group `group_id` of `nranks` handles
+ * (one process, ONE GPU, one host thread per handle).  Same row partition and the same code paths as msdp_comm_init --
+ * row offsets, replicated operator state, lock-step tCG, order and number of collective calls -- with the three
+ * collectives carried out by a host barrier and device copies / a summation kernel between the members' buffers, so a
+ * single GPU executes the N-rank paths.  A member that never makes the matching call breaks the group after 120 s
+ * (MSDP_ECOMM) instead of hanging the process. */
+int msdp_comm_init_local(msdp_handle h, int32_t nranks, int32_t rank, int32_t group_id);
 /* Local row range [row0, row1) of this rank. */
 int msdp_local_rows(msdp_handle h, int64_t* row0, int64_t* row1);
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "msdp_escape_lower_bound": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_dual_slack": (C.c_int, [C.c_void_p, _dp]),
     "msdp_release_cache": (C.c_int, []),
+    "msdp_comm_init_local": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "msdp_get_point_all": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_z_all": (C.c_int, [C.c_void_p, _dp]),
     "msdp_factor_gram": (C.c_int, [C.c_void_p, _dp]),
@@ -499,6 +500,11 @@ class Handle:
     def comm_init(self, nranks, rank, uid):
         buf = (C.c_char * 128).from_buffer_copy(uid)
         _check(self._lib.msdp_comm_init(self._h, nranks, rank, C.cast(buf, C.c_void_p)))
+
+    def comm_init_local(self, nranks, rank, group):
+        """Member `rank` of an in-process group of `nranks` handles on one GPU (one host thread per handle): the N-rank code
+        paths with local stand-ins for the RCCL collectives."""
+        _check(self._lib.msdp_comm_init_local(self._h, int(nranks), int(rank), int(group)))
 
     def local_rows(self):
         a, b = C.c_int64(), C.c_int64()

@@ -496,6 +496,8 @@ extern "C" int msdp_dual_get_y(msdp_handle h, double* y) {
     return msdp_dual_get_y_impl(h, y);
 }
 
+static void local_leave(msdp_handle h);       // in-process communicator stand-in, below
+
 extern "C" int msdp_destroy(msdp_handle h) {
     if (!h) return 0;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -508,6 +510,8 @@ extern "C" int msdp_destroy(msdp_handle h) {
     for (int s2 = 0; s2 < 2; ++s2) if (h->ev_flag[s2]) (void)hipEventDestroy(h->ev_flag[s2]);
     for (int s2 = 0; s2 < 2; ++s2) if (h->chunk_execs[s2]) (void)hipGraphExecDestroy(h->chunk_execs[s2]);
     msdp_affine_release(h);
+    local_leave(h);
+    if (h->lc_tmp) (void)hipFree(h->lc_tmp);
     if (h->esc_rp) (void)hipFree(h->esc_rp);
     if (h->esc_ci) (void)hipFree(h->esc_ci);
     if (h->esc_cv) (void)hipFree(h->esc_cv);
@@ -609,6 +613,7 @@ extern "C" int msdp_set_point(msdp_handle h, int32_t p, const double* Y) {
     return 0;
 }
 
+int msdp_allreduce_array(msdp_handle h, double* buf, size_t count);                             // below (local stand-in only)
 int msdp_k_fgram(msdp_handle h, const double* Y, double* part, int nblk, double* out);          // msdp_kernels.hip
 int msdp_k_frotate(msdp_handle h, int cap, int r, int ldn, const double* Y, const double* Q, double* Yn);
 int msdp_k_fappend(msdp_handle h, int cap, int k, int ldn, const double* Y, const double* V, double alpha, int normalize, double* Yn);
@@ -640,7 +645,8 @@ extern "C" int msdp_factor_gram(msdp_handle h, double* G) {
     if (hipMalloc((void**)&buf, ((size_t)nblk + 1) * ld * ld * sizeof(double)) != hipSuccess) { msdp_set_error("factor_gram: scratch alloc failed"); return MSDP_ENOMEM; }
     double* out = buf + (size_t)nblk * ld * ld;
     int rc = msdp_k_fgram(h, d.Y[host_cur(h)], buf, nblk, out);
-    if (!rc && h->use_comm) {
+    if (!rc && h->use_comm && h->lgroup) rc = msdp_allreduce_array(h, out, (size_t)ld * ld);
+    else if (!rc && h->use_comm) {
         ncclResult_t r = ncclAllReduce(out, out, (size_t)ld * ld, ncclDouble, ncclSum, (ncclComm_t)h->comm, h->stream);
         if (r != ncclSuccess) { msdp_set_error("ncclAllReduce failed: %s", ncclGetErrorString(r)); rc = MSDP_ECOMM; }
     }
@@ -778,9 +784,100 @@ extern "C" int msdp_get_kind(msdp_handle h, int32_t* kind) {
     return 0;
 }
 
+// ------------------------------------------------------------------ in-process stand-in for the communicator
+// N handles of ONE process on ONE GPU, each driven by its own host thread, stand in for N ranks: the three collectives the
+// library uses (all-reduce of a device array, all-gather of equal slabs) are carried out with a host barrier and device
+// copies / a summation kernel between the handles' buffers.  Everything else -- the row partition, the row offsets into the
+// replicated operator state, the lock-step tCG driver, the order and number of collective calls on every rank -- is the
+// code of the RCCL run, so one GPU can execute the N-rank paths (tests/test_gpu_local_ranks.py).  Sums run in rank order on
+// every member: all members obtain the same bits, as with ncclAllReduce.
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <mutex>
+#define LOCAL_MAX_RANKS 8
+struct LocalGroup {
+    int n = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long gen = 0;
+    bool broken = false;
+    const double* ptr[LOCAL_MAX_RANKS] = {nullptr};
+    int members = 0;
+};
+static std::mutex g_groups_mutex;
+static std::map<int, LocalGroup*> g_groups;
+// false: a member did not arrive within 120 s (it failed or never made the matching call) -- the group is broken and every
+// later collective fails at once instead of hanging the process
+static bool local_barrier(LocalGroup* g) {
+    std::unique_lock<std::mutex> lk(g->m);
+    if (g->broken) return false;
+    const unsigned long long my = g->gen;
+    if (++g->arrived == g->n) { g->arrived = 0; ++g->gen; g->cv.notify_all(); return true; }
+    if (!g->cv.wait_for(lk, std::chrono::seconds(120), [&] { return g->gen != my || g->broken; }) || g->broken) {
+        g->broken = true;
+        g->cv.notify_all();
+        return false;
+    }
+    return true;
+}
+#define LOCAL_BARRIER(g) do { if (!local_barrier(g)) { msdp_set_error("in-process communicator: a member did not reach the collective (group broken)"); return MSDP_ECOMM; } } while (0)
+struct LocalPtrs { const double* p[LOCAL_MAX_RANKS]; };
+__global__ void k_local_sum(LocalPtrs src, int n, size_t count, double* __restrict__ out) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int r = 0; r < n; ++r) acc += src.p[r][i];
+        out[i] = acc;
+    }
+}
+static int local_allreduce(msdp_handle h, double* buf, size_t count) {
+    LocalGroup* g = h->lgroup;
+    if (h->lc_tmp_cap < count) {
+        if (h->lc_tmp) (void)hipFree(h->lc_tmp);
+        h->lc_tmp = nullptr; h->lc_tmp_cap = 0;
+        if (hipMalloc((void**)&h->lc_tmp, count * sizeof(double)) != hipSuccess) { msdp_set_error("local all-reduce: scratch allocation failed"); return MSDP_ENOMEM; }
+        h->lc_tmp_cap = count;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));               // my contribution is complete
+    { std::lock_guard<std::mutex> lk(g->m); g->ptr[h->rank] = buf; }
+    LOCAL_BARRIER(g);
+    LocalPtrs src;
+    for (int r = 0; r < LOCAL_MAX_RANKS; ++r) src.p[r] = r < g->n ? g->ptr[r] : nullptr;
+    int blocks = (int)std::min<size_t>(1024, (count + 255) / 256);
+    hipLaunchKernelGGL(k_local_sum, dim3(blocks), dim3(256), 0, h->stream, src, g->n, count, h->lc_tmp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    LOCAL_BARRIER(g);                                      // every member has read every contribution
+    HIPCHK(hipMemcpyAsync(buf, h->lc_tmp, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+static int local_allgather(msdp_handle h, const double* local, double* all, size_t count_per_rank) {
+    LocalGroup* g = h->lgroup;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    { std::lock_guard<std::mutex> lk(g->m); g->ptr[h->rank] = local; }
+    LOCAL_BARRIER(g);
+    for (int r = 0; r < g->n; ++r)
+        HIPCHK(hipMemcpyAsync(all + (size_t)r * count_per_rank, g->ptr[r], count_per_rank * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    LOCAL_BARRIER(g);                                      // nobody overwrites its slab before everyone has copied it
+    return 0;
+}
+static void local_leave(msdp_handle h) {
+    if (!h->lgroup) return;
+    std::lock_guard<std::mutex> lk(g_groups_mutex);
+    LocalGroup* g = h->lgroup;
+    h->lgroup = nullptr;
+    if (--g->members == 0) {
+        for (auto it = g_groups.begin(); it != g_groups.end(); ++it) if (it->second == g) { g_groups.erase(it); break; }
+        delete g;
+    }
+}
+
 // ------------------------------------------------------------------ collectives
 int msdp_allreduce_partials(msdp_handle h, int first, int count) {
     if (!h->use_comm) return 0;
+    if (h->lgroup) return local_allreduce(h, h->d.P + (size_t)first * MSDP_MAX_GRID, (size_t)count * MSDP_MAX_GRID);
     double* buf = h->d.P + (size_t)first * MSDP_MAX_GRID;
     ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count * MSDP_MAX_GRID, ncclDouble, ncclSum,
                                    (ncclComm_t)h->comm, h->stream);
@@ -806,14 +903,21 @@ int msdp_allgather_rows(msdp_handle h, const double* local_rows) {
     const size_t cnt = (size_t)rows_capacity(h) * h->d.ld;
     // slabs are packed with the CURRENT ld so the full buffer is n_pad x ld row-major
     h->d.full = h->full_buf;
+    if (h->lgroup) return local_allgather(h, local_rows, h->full_buf, cnt);
     ncclResult_t r = ncclAllGather(local_rows, h->full_buf, cnt, ncclDouble, (ncclComm_t)h->comm, h->stream);
     if (r != ncclSuccess) { msdp_set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return MSDP_ECOMM; }
     return 0;
 }
 
+int msdp_allreduce_array(msdp_handle h, double* buf, size_t count) {
+    if (!h->lgroup) { msdp_set_error("allreduce_array: local group only"); return MSDP_ESTATE; }
+    return local_allreduce(h, buf, count);
+}
+
 // count_per_rank doubles from every rank, in rank order
 int msdp_allgather_vec(msdp_handle h, const double* local, double* all, size_t count_per_rank) {
     if (!h->use_comm) { msdp_set_error("allgather_vec: no communicator"); return MSDP_ESTATE; }
+    if (h->lgroup) return local_allgather(h, local, all, count_per_rank);
     ncclResult_t r = ncclAllGather(local, all, count_per_rank, ncclDouble, (ncclComm_t)h->comm, h->stream);
     if (r != ncclSuccess) { msdp_set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return MSDP_ECOMM; }
     return 0;
@@ -827,6 +931,27 @@ extern "C" int msdp_comm_unique_id(void* id128) {
     static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
     memcpy(id128, &id, 128);
     return 0;
+}
+
+static int comm_partition(msdp_handle h, int32_t nranks, int32_t rank);
+
+// Test / diagnostic: member `rank` of the in-process group `group_id` of `nranks` handles (one process, one GPU, one host
+// thread per handle).  Same partition, same code paths as msdp_comm_init; the collectives are the local stand-ins above.
+extern "C" int msdp_comm_init_local(msdp_handle h, int32_t nranks, int32_t rank, int32_t group_id) {
+    CHECK_H(h);
+    if (nranks < 1 || nranks > LOCAL_MAX_RANKS || rank < 0 || rank >= nranks) { msdp_set_error("comm_init_local: bad arguments"); return MSDP_EINVAL; }
+    if (h->have_point || h->use_comm) { msdp_set_error("comm_init_local must precede set_point / comm_init"); return MSDP_ESTATE; }
+    if (h->presharded && (nranks != h->nranks || rank != h->rank)) { msdp_set_error("comm_init_local: shard was created as rank %d of %d", h->rank, h->nranks); return MSDP_EINVAL; }
+    if (h->kind == MSDP_KIND_MULTIBLOCK || h->kind == MSDP_KIND_DUAL_UNITDIAG) { msdp_set_error("row sharding is not implemented for the multiblock and dual kinds"); return MSDP_EUNSUPPORTED; }
+    {
+        std::lock_guard<std::mutex> lk(g_groups_mutex);
+        LocalGroup*& g = g_groups[group_id];
+        if (!g) { g = new LocalGroup(); g->n = nranks; }
+        if (g->n != nranks || g->members >= nranks) { msdp_set_error("comm_init_local: group %d has %d of %d members", group_id, g->members, g->n); return MSDP_EINVAL; }
+        ++g->members;
+        h->lgroup = g;
+    }
+    return comm_partition(h, nranks, rank);
 }
 
 extern "C" int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const void* id128) {
@@ -844,6 +969,11 @@ extern "C" int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const
     ncclResult_t r = ncclCommInitRank(&comm, nranks, id, rank);
     if (r != ncclSuccess) { msdp_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r)); return MSDP_ECOMM; }
     h->comm = comm;
+    return comm_partition(h, nranks, rank);
+}
+
+// The row partition of a communicator of `nranks` members (RCCL or the in-process stand-in)
+static int comm_partition(msdp_handle h, int32_t nranks, int32_t rank) {
     h->nranks = nranks;
     h->rank = rank;
     h->use_comm = true;      // also with nranks == 1: a size-1 communicator exercises the same RCCL calls

@@ -153,6 +153,8 @@ struct msdp_handle_s {
     void* comm = nullptr;          // ncclComm_t
     bool presharded = false;       // created per shard (dense synthetic): row0/n_loc fixed at creation
     double* full_buf = nullptr;    // gather buffer (nranks x cap rows) when the rows are sharded
+    struct LocalGroup* lgroup = nullptr;   // in-process stand-in for the RCCL communicator (msdp_comm_init_local)
+    double* lc_tmp = nullptr; size_t lc_tmp_cap = 0;   // its reduction scratch
     // row-sharded onlyunitdiag (sparse C): the escape runs replicated on full copies of C's CSR arrays and of z
     int* esc_rp = nullptr; int* esc_ci = nullptr; double* esc_cv = nullptr; double* esc_z = nullptr;
     double* yfull[2] = {nullptr, nullptr};   // row-sharded affine kinds: all rows of Y[slot] (the A(.) operator and the dense

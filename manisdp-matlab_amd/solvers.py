@@ -73,6 +73,15 @@ DATA_FIELDS = {
 }
 
 
+def _join_comm(h, comm):
+    """options['comm']: (nranks, rank, rccl_unique_id) -- one process per GPU -- or ("local", nranks, rank, group) -- the
+    in-process stand-in of msdp_comm_init_local: N handles of one process on one GPU, one host thread each."""
+    if comm[0] == "local":
+        h.comm_init_local(int(comm[1]), int(comm[2]), int(comm[3]))
+    else:
+        h.comm_init(int(comm[0]), int(comm[1]), comm[2])
+
+
 def _say(verbose, msg):
     if verbose:
         print(msg, flush=True)
@@ -204,7 +213,7 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
         if not sp.issparse(Csp):
             raise ValueError("row-sharded solves need a sparse C")
         eig_mode = "device"
-        h.comm_init(int(comm[0]), int(comm[1]), comm[2])
+        _join_comm(h, comm)
     topts = _rtr_opts(o)
     p = int(o["p0"])
     Y = o.get("Y0", None)
@@ -406,7 +415,7 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
     # decisions; collectives happen inside the library calls.
     comm = o.get("comm")
     if comm is not None:
-        h.comm_init(int(comm[0]), int(comm[1]), comm[2])
+        _join_comm(h, comm)
     topts = _rtr_opts(o)
     p = int(o["p0"])
     sigma = float(o["sigma0"])

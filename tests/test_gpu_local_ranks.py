@@ -1,0 +1,193 @@
+"""The N-rank code paths on ONE GPU: N handles of this process, one host thread each, joined by the in-process stand-in for the
+communicator (msdp_comm_init_local: same row partition, same lock-step tCG driver, same order and number of collective calls as
+the RCCL run; the collectives themselves are a host barrier plus device copies / a summation kernel).  Every test compares
+the ranks' combined result with one unsharded handle.  What stays untested on this box is RCCL itself with more than one
+member -- tests/test_gpu_comm.py runs that wherever N GPUs are visible."""
+import threading
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+_group = [1000]
+
+
+def run_ranks(N, fn):
+    """fn(rank, group) on N threads; returns the list of results, re-raises the first exception."""
+    _group[0] += 1
+    group = _group[0]
+    out, err = [None] * N, [None] * N
+
+    def body(r):
+        try:
+            out[r] = fn(r, group)
+        except BaseException as e:      # noqa: BLE001
+            err[r] = e
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(N)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("N", [2, 3, 8])
+@pytest.mark.parametrize("case", ["sparse", "dense"])
+def test_onlyunitdiag_ranks_match_one_handle(N, case):
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    rng = np.random.default_rng(11)
+    if case == "sparse":
+        C = problems.toroidal_grid_maxcut(61, 50, seed=4)           # n = 3050: ragged last shard for N = 3, 8
+        n, p = C.shape[0], 12
+    else:
+        n, p = 1000, 24
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    opts = _lib.default_opts(maxiter=8, maxinner=25, tolgradnorm=1e-9)
+
+    def make(nranks=1, rank=0):
+        return _lib.Handle.onlyunitdiag(C, pcap=p) if case == "sparse" else _lib.Handle.dense_synthetic(n, 3, nranks=nranks, rank=rank, pcap=p)
+
+    def one_rank(r, group):
+        h = make(N, r)
+        h.comm_init_local(N, r, group)
+        r0, r1 = h.local_rows()
+        h.set_point(Y)
+        f = h.cost(); G = h.rgrad(); H = h.hessvec(U)
+        st = h.rtr(opts)
+        Yall = h.get_point_all()
+        z = h.get_z_all()
+        h.close()
+        return dict(rows=(r0, r1), f=f, G=G[r0:r1], H=H[r0:r1], cost=st.cost, gradnorm=st.gradnorm, hessvecs=st.hessvecs,
+                    accepted=st.accepted, rejected=st.rejected, Y=Yall, z=z)
+
+    res = run_ranks(N, one_rank)
+    h = make()
+    h.set_option("persist", 0)                            # the sharded run uses the chunked kernels
+    h.set_point(Y)
+    f = h.cost(); G = h.rgrad(); H = h.hessvec(U)
+    st = h.rtr(opts)
+    Yout = h.get_point(); z = h.get_z()
+    h.close()
+    assert res[0]["rows"][0] == 0 and res[-1]["rows"][1] == n
+    Gs = np.vstack([q["G"] for q in res]); Hs = np.vstack([q["H"] for q in res])
+    assert rel(Gs, G) < 1e-12 and rel(Hs, H) < 1e-12
+    for q in res:
+        assert abs(q["f"] - f) <= 1e-12 * abs(f)
+        assert (q["hessvecs"], q["accepted"], q["rejected"]) == (st.hessvecs, st.accepted, st.rejected)
+        assert abs(q["cost"] - st.cost) <= 1e-10 * abs(st.cost)
+        assert rel(q["Y"], Yout) < 1e-8 and rel(q["z"], z) < 1e-8
+        assert np.array_equal(q["Y"], res[0]["Y"]) and np.array_equal(q["z"], res[0]["z"])       # replicated data is identical
+
+
+def _bqp10():
+    from manisdp_matlab_amd import problems
+    Q = np.loadtxt(golden_path("bqp_Q_10_1.txt.gz"), delimiter=",")
+    e = np.loadtxt(golden_path("bqp_e_10_1.txt.gz"), delimiter=",")
+    At, b, c, K = problems.bqpmom(10, Q, e)
+    c = np.asarray(c.todense()).ravel(); b = np.asarray(b.todense()).ravel() if sp.issparse(b) else np.asarray(b, float).ravel()
+    At = sp.csc_matrix(At); At.sort_indices()
+    return At, b, c, K
+
+
+@pytest.mark.parametrize("N", [2, 3])
+@pytest.mark.parametrize("kind_name", ["unitdiag", "unittrace"])
+def test_affine_ranks_match_one_handle(N, kind_name):
+    """Row-sharded affine kinds with the replicated operator state: operators, line-search cost, trustregions(), AL
+    bookkeeping and the replicated escape on N in-process ranks against one handle."""
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    if kind_name == "unitdiag":
+        At, b, c, K = _bqp10()
+        kind = _lib.KIND_UNITDIAG
+    else:
+        At, b, c, K = problems.from_sdpa(golden_path("theta1.dat-s.gz"))
+        c = np.asarray(c.todense()).ravel() if sp.issparse(c) else np.asarray(c, float).ravel()
+        b = np.asarray(b.todense()).ravel() if sp.issparse(b) else np.asarray(b, float).ravel()
+        At = sp.csc_matrix(At); At.sort_indices()
+        kind = _lib.KIND_UNITTRACE
+    n, m, p = K["s"], b.size, 6
+    rng = np.random.default_rng(3)
+    Y = rng.standard_normal((n, p))
+    Y = Y / np.linalg.norm(Y, axis=1, keepdims=True) if kind == _lib.KIND_UNITDIAG else Y / np.linalg.norm(Y)
+    U = 0.3 * rng.standard_normal((n, p))
+    y = 0.1 * rng.standard_normal(m)
+    opts = _lib.default_opts(maxiter=3, maxinner=15, tolgradnorm=1e-8)
+
+    def session(h, all_rows):
+        h.set_multipliers(y, 0.7)
+        h.set_point(Y)
+        f = h.cost(); G = h.rgrad(); H = h.hessvec(h.proj(U))
+        co = h.linesearch_cost(U, 0.5)
+        st = h.rtr(opts)
+        Yr = h.get_point_all() if all_rows else h.get_point()
+        obj, Ax = h.al_primal(m)
+        z = h.al_dual(y)
+        lam, V, lmax, _ = h.escape_eigs_dual(3, tol=1e-10, maxit=4000)
+        return dict(f=f, G=G, H=H, co=co, cost=st.cost, hessvecs=st.hessvecs, Y=Yr, obj=obj, Ax=Ax, z=np.atleast_1d(z), lam=lam, lmax=lmax)
+
+    def one_rank(r, group):
+        h = _lib.Handle.affine(kind, At, b, c, n)
+        h.comm_init_local(N, r, group)
+        r0, r1 = h.local_rows()
+        q = session(h, True)
+        h.close()
+        q["G"], q["H"], q["rows"] = q["G"][r0:r1], q["H"][r0:r1], (r0, r1)
+        return q
+
+    res = run_ranks(N, one_rank)
+    h = _lib.Handle.affine(kind, At, b, c, n)
+    ref = session(h, False)
+    h.close()
+    assert rel(np.vstack([q["G"] for q in res]), ref["G"]) < 1e-10
+    assert rel(np.vstack([q["H"] for q in res]), ref["H"]) < 1e-10
+    for q in res:
+        assert abs(q["f"] - ref["f"]) <= 1e-11 * abs(ref["f"]) and abs(q["co"] - ref["co"]) <= 1e-11 * abs(ref["co"])
+        assert q["hessvecs"] == ref["hessvecs"] and abs(q["cost"] - ref["cost"]) <= 1e-9 * abs(ref["cost"])
+        assert rel(q["Y"], ref["Y"]) < 1e-7 and rel(q["Ax"], ref["Ax"]) < 1e-7 and rel(q["z"], ref["z"]) < 1e-7
+        assert abs(q["obj"] - ref["obj"]) <= 1e-8 * max(1.0, abs(ref["obj"]))
+        ok = np.isfinite(ref["lam"])
+        assert np.array_equal(np.isfinite(q["lam"]), ok) and rel(q["lam"][ok], ref["lam"][ok]) < 1e-5
+        assert abs(q["lmax"] - ref["lmax"]) <= 1e-6 * abs(ref["lmax"])
+        for key in ("f", "co", "cost", "obj", "lmax"):                                   # replicated scalars: identical bits
+            assert q[key] == res[0][key], key
+        assert np.array_equal(q["Y"], res[0]["Y"]) and np.array_equal(q["Ax"], res[0]["Ax"])
+
+
+@pytest.mark.parametrize("N", [2, 4])
+def test_whole_solves_on_in_process_ranks(N):
+    """The replicated host loops with options['comm'] = ('local', N, rank, group): ManiSDP_onlyunitdiag (sharded RTR, escape on
+    the replicated copy of C, device-resident factor) and ManiSDP_unitdiag (BQP d = 10) against the one-handle solves."""
+    from manisdp_matlab_amd import problems, solvers
+    C = problems.toroidal_grid_maxcut(30, 40, seed=6)
+    rng = np.random.default_rng(9)
+    Y0 = rng.standard_normal((C.shape[0], 2)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    At, b, c, K = _bqp10()
+    Z0 = rng.standard_normal((K["s"], 2)); Z0 /= np.linalg.norm(Z0, axis=1, keepdims=True)
+
+    def one_rank(r, group):
+        Y, obj, d = solvers.ManiSDP_onlyunitdiag(C, {"Y0": Y0, "tol": 1e-8, "comm": ("local", N, r, group)}, verbose=False)
+        Ya, obja, da = solvers.ManiSDP_unitdiag(At, b, c, K, {"Y0": Z0, "tol": 1e-8, "comm": ("local", N, r, group + 500)}, verbose=False)
+        return (obj, d["status"], d["dinf"], Y, obja, da["status"], max(da["gap"], da["pinf"], da["dinf"]))
+
+    res = run_ranks(N, one_rank)
+    _, obj1, d1 = solvers.ManiSDP_onlyunitdiag(C, {"Y0": Y0, "tol": 1e-8, "eig": "device"}, verbose=False)
+    _, obja1, da1 = solvers.ManiSDP_unitdiag(At, b, c, K, {"Y0": Z0, "tol": 1e-8}, verbose=False)
+    assert d1["status"] == 0 and da1["status"] == 0
+    for q in res:
+        assert q[1] == 0 and q[2] < 1e-8 and abs(q[0] - obj1) <= 1e-7 * abs(obj1)
+        assert np.allclose(np.linalg.norm(q[3], axis=1), 1.0, atol=1e-12)
+        assert q[5] == 0 and q[6] < 1e-8 and abs(q[4] - obja1) <= 1e-6 * max(1.0, abs(obja1))
+        assert q[0] == res[0][0] and q[4] == res[0][4]                                     # every rank reports the same numbers
