@@ -191,3 +191,36 @@ def test_whole_solves_on_in_process_ranks(N):
         assert np.allclose(np.linalg.norm(q[3], axis=1), 1.0, atol=1e-12)
         assert q[5] == 0 and q[6] < 1e-8 and abs(q[4] - obja1) <= 1e-6 * max(1.0, abs(obja1))
         assert q[0] == res[0][0] and q[4] == res[0][4]                                     # every rank reports the same numbers
+
+
+def test_ragged_partition_with_an_empty_rank():
+    """n = 20 over 8 ranks: blocks of 3 rows, the seventh rank owns 2, the eighth none -- and the solve is the unsharded one."""
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    C = problems.toroidal_grid_maxcut(5, 4, seed=1)
+    n, p, N = C.shape[0], 3, 8
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    opts = _lib.default_opts(maxiter=5, maxinner=10, tolgradnorm=1e-9)
+
+    def one_rank(r, group):
+        h = _lib.Handle.onlyunitdiag(C, pcap=p)
+        h.comm_init_local(N, r, group)
+        rows = h.local_rows()
+        h.set_point(Y)
+        f = h.cost()
+        st = h.rtr(opts)
+        Yall = h.get_point_all()
+        h.close()
+        return rows, f, st.cost, st.hessvecs, Yall
+
+    res = run_ranks(N, one_rank)
+    assert [q[0] for q in res][-2:] == [(18, 20), (21, 21)]
+    h = _lib.Handle.onlyunitdiag(C, pcap=p)
+    h.set_option("persist", 0)
+    h.set_point(Y)
+    f = h.cost(); st = h.rtr(opts); Y1 = h.get_point()
+    h.close()
+    for q in res:
+        assert abs(q[1] - f) <= 1e-13 * abs(f) and abs(q[2] - st.cost) <= 1e-12 * abs(st.cost) and q[3] == st.hessvecs
+        assert rel(q[4], Y1) < 1e-10
