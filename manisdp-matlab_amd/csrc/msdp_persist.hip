@@ -467,6 +467,12 @@ static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
     // p = 17..32: three row slots (96 rows per workgroup) when they suffice -- the fourth slot of the 128-slot form would be
     // a quarter of the trip's gathers and arithmetic spent on masked rows (G81 on 256 CUs owns 79 rows per workgroup)
     if (lpr == 16 && need <= 3 * rstep) pl.r = 3;
+    // p = 17..32 beyond 128 rows per workgroup (n > 32768 on 256 CUs): eight row slots in the LOWREG form (mdelta / Hmdelta in
+    // LDS, three synchronisations) instead of falling back to the chunked path
+    if (lpr == 16 && need > 4 * rstep && need <= 8 * rstep) pl.r = 8;
+    // p <= 16 (64 rows per slot): four slots (all in registers, two synchronisations) up to 256 rows per workgroup, i.e.
+    // n <= 65536 on 256 CUs (eight slots would need 163 KB of LDS with the ELL rows)
+    if (lpr == 8 && need > 2 * rstep && need <= 4 * rstep) pl.r = 4;
     if (need > pl.r * rstep) return false;
     const size_t rows = (size_t)pl.r * rstep;
     pl.lds = (size_t)2 * pl.r * PB * sizeof(double2) + rows * sizeof(double) + (size_t)pl.ew * rows * (sizeof(double) + sizeof(int));
@@ -486,6 +492,16 @@ static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false) {
             if (pl.ew == 8) return k_tcg_persist_obl<16, 8, 3, false>;
             if (pl.ew == 0) return k_tcg_persist_obl<16, 0, 3, false>;
         }
+    }
+    if (!fuse && pl.lpr == 8 && pl.r == 4) {
+        if (pl.ew == 5) return k_tcg_persist_obl<8, 5, 4, false>;
+        if (pl.ew == 8) return k_tcg_persist_obl<8, 8, 4, false>;
+        if (pl.ew == 0) return k_tcg_persist_obl<8, 0, 4, false>;
+    }
+    if (!fuse && pl.lpr == 16 && pl.r == 8) {
+        if (pl.ew == 5) return k_tcg_persist_obl<16, 5, 8, false>;
+        if (pl.ew == 8) return k_tcg_persist_obl<16, 8, 8, false>;
+        if (pl.ew == 0) return k_tcg_persist_obl<16, 0, 8, false>;
     }
     if (!fuse && pl.lpr == 32 && pl.r == 5) {
         if (pl.ew == 5) return k_tcg_persist_obl<32, 5, 5, false>;

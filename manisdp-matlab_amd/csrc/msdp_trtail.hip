@@ -13,13 +13,13 @@
 #include <cstdlib>
 
 template <int LPR>
-__global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* slots, int* err) {
+__global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* slots, int* err, int rcap) {
     extern __shared__ double lds[];
     __shared__ double sh[3 * PWAVES];
     __shared__ double shb[4];
     constexpr int RPW = 64 / LPR;
     constexpr int RSTEP = PWAVES * RPW;
-    double2* YPs = reinterpret_cast<double2*>(lds);            // [R][PB] proposal rows of this workgroup
+    double2* YPs = reinterpret_cast<double2*>(lds);            // [rcap][PB] proposal rows of this workgroup
     Ctl* c = d.ctl;
     if (c->done) return;
     psync_reset_other(slots);                                  // region A belongs to the persistent tCG kernel
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi);
     constexpr int RMAX = (LPR / 4 < 4) ? LPR / 4 : 4;            // row slots processed together (their loads overlap)
-    const int R = (hi - lo + RSTEP - 1) / RSTEP;               // row slots actually needed (<= LPR/4 by construction)
+    const int R = (hi - lo + RSTEP - 1) / RSTEP;               // row slots actually needed (<= rcap: the host sizes the LDS for the largest chunk)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
     const bool colok = 2 * sub < d.ld;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
             double nn = sqrt(msdp_group_sum<LPR>(x.x * x.x + x.y * x.y));
             if (!(nn > 0.0)) nn = 1.0;
             const double2 ypr = ok ? make_double2(x.x / nn, x.y / nn) : zz;
-            if (r < LPR / 4) YPs[r * PB + threadIdx.x] = ypr;
+            if (r < rcap) YPs[r * PB + threadIdx.x] = ypr;
             if (ok) st2_sc1(rs_yp, ((unsigned)row * (unsigned)d.ld + 2 * sub) * 8u, ypr);
         }
     }
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
             const int row = lo + r * RSTEP + slot0;
             const bool rok = row < hi, ok = rok && colok;
             double2 a2 = colok ? acc[q] : zz;
-            const double2 ypr = (r < LPR / 4) ? YPs[r * PB + threadIdx.x] : zz;
+            const double2 ypr = (r < rcap) ? YPs[r * PB + threadIdx.x] : zz;
             const double dot = msdp_group_sum<LPR>(a2.x * ypr.x + a2.y * ypr.y);     // eG(row) = sum(YC.*Y)
             const double2 gpr = ok ? make_double2(a2.x - ypr.x * dot, a2.y - ypr.y * dot) : zz;   // G = YC - Y.*eG
             pgg += gpr.x * gpr.x + gpr.y * gpr.y;
@@ -165,18 +165,23 @@ int msdp_launch_tr_tail(msdp_handle h) {
     const int G = msdp_tr_tail_grid(h);
     const int lpr = tail_lpr(h->d);
     if (G < 8 || lpr > 32) { msdp_set_error("TR tail: not eligible"); return MSDP_ESTATE; }
-    const size_t lds = (size_t)(lpr / 4) * PB * sizeof(double2);
+    // one LDS row set per row slot of the largest chunk (3 slots for G81 at p = 32, 8 for the eight-slot instances)
+    const int rstep = PWAVES * (64 / lpr);
+    int rcap = ((h->d.n_loc + G - 1) / G + rstep - 1) / rstep;
+    if (rcap < 1) rcap = 1;
+    const size_t lds = (size_t)rcap * PB * sizeof(double2);
+    if (lds > 128 * 1024) { msdp_set_error("TR tail: %d row slots do not fit the LDS", rcap); return MSDP_ESTATE; }
     Dev dp = h->d;
     dp.G = G;
-    typedef void (*fn_t)(Dev, unsigned long long*, int*);
+    typedef void (*fn_t)(Dev, unsigned long long*, int*, int);
     fn_t fn = lpr == 8 ? k_tr_tail_obl<8> : (lpr == 16 ? k_tr_tail_obl<16> : k_tr_tail_obl<32>);
     static bool attr_set[3] = {false, false, false};
     const int ai = lpr == 8 ? 0 : (lpr == 16 ? 1 : 2);
     if (!attr_set[ai]) {
-        HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set[ai] = true;
     }
-    hipLaunchKernelGGL(fn, dim3(G), dim3(PB), lds, h->stream, dp, h->psync_slots, h->psync_err);
+    hipLaunchKernelGGL(fn, dim3(G), dim3(PB), lds, h->stream, dp, h->psync_slots, h->psync_err, rcap);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -324,10 +324,12 @@ def test_device_factor_path_follows_host_path():
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
 
 
-@pytest.mark.parametrize("rows,cols,p", [(100, 200, 40), (150, 160, 40), (150, 160, 32), (130, 200, 32), (100, 200, 16)])
+@pytest.mark.parametrize("rows,cols,p", [(100, 200, 40), (150, 160, 40), (150, 160, 32), (130, 200, 32), (100, 200, 16),
+                                         (200, 200, 32), (250, 250, 24), (200, 200, 16), (250, 250, 12)])
 def test_persistent_instances_agree_with_chunked_path(rows, cols, p):
-    """Every row-slot instance of the persistent tCG kernel (three / four slots at p <= 32, five / eight at p = 33..64, chosen
-    by the rows a workgroup owns) against the chunked three-kernel path on the same start point: same Hess-vec count and
+    """Every row-slot instance of the persistent tCG kernel (two / four slots at p <= 16, three / four / eight at
+    p = 17..32, five / eight at p = 33..64, chosen by the rows a workgroup owns; n up to 62 500 here) against the chunked
+    three-kernel path on the same start point: same Hess-vec count and
     stop decisions, cost and gradient norm to rounding."""
     from manisdp_matlab_amd import _lib, problems
     _lib.load()

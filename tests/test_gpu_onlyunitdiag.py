@@ -194,8 +194,9 @@ def test_persistent_tcg_matches_oracle(lib, shape, p, k):
 
 
 def test_persistent_path_selection(lib):
-    """CSR rows of any length run in the persistent kernel too (G1: up to ~50 nonzeros per row); p > 64 or more
-    than 128 rows per workgroup (n = 40000 at p = 32) keep the chunked path."""
+    """CSR rows of any length run in the persistent kernel too (G1: up to ~50 nonzeros per row); p > 64 keeps the chunked
+    path, and so do more rows per workgroup than the largest row-slot instance of the width holds (p = 33..64: 128,
+    p <= 32: 256 -- on 256 CUs n = 40000 at p = 32 is persistent, n = 62500 at p = 40 is not)."""
     from manisdp_matlab_amd import problems
     C = problems.maxcut_cost_matrix(golden_path("G1.txt.gz"))
     Y, _ = _rand_point(C.shape[0], 8, seed=1)
@@ -212,6 +213,12 @@ def test_persistent_path_selection(lib):
     C = problems.toroidal_grid_maxcut(200, 200, seed=3)
     Y, _ = _rand_point(C.shape[0], 32, seed=1)
     h = lib.Handle.onlyunitdiag(C, pcap=32)
+    h.set_point(Y)
+    assert h.tcg_path() == 1
+    h.close()
+    C = problems.toroidal_grid_maxcut(250, 250, seed=3)
+    Y, _ = _rand_point(C.shape[0], 40, seed=1)
+    h = lib.Handle.onlyunitdiag(C, pcap=40)
     h.set_point(Y)
     assert h.tcg_path() == 0
     h.close()
