@@ -224,3 +224,45 @@ def test_ragged_partition_with_an_empty_rank():
     for q in res:
         assert abs(q[1] - f) <= 1e-13 * abs(f) and abs(q[2] - st.cost) <= 1e-12 * abs(st.cost) and q[3] == st.hessvecs
         assert rel(q[4], Y1) < 1e-10
+
+
+@pytest.mark.parametrize("N", [2, 4])
+def test_bench_entry_points_on_ranks(N):
+    """What bench.py --gpus N calls on every rank (snapshot / restore of the start point, whole RTR calls, the Hess-vec and
+    tCG-trip timers) on N in-process ranks of the weak-scaled G81-family grid: same Hess-vec count on every rank and as the
+    one-handle run of the same problem."""
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    C = problems.toroidal_grid_maxcut(20 * N, 50, seed=81)
+    n, p = C.shape[0], 16
+    rng = np.random.default_rng(0)
+    Y0 = rng.standard_normal((n, p)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    opts = _lib.default_opts(maxiter=10, maxinner=30, tolgradnorm=1e-8)
+
+    def session(h):
+        h.set_point(Y0)
+        h.point_snapshot()
+        hv = 0
+        for _ in range(2):
+            h.point_restore()
+            st = h.rtr(opts)
+            hv += st.hessvecs
+        h.set_point(Y0)
+        ms, by, fl = h.bench_hessvec(5)
+        trip = h.bench_tcg_trip(16)
+        return hv, st.cost, ms > 0 and trip > 0
+
+    def one_rank(r, group):
+        h = _lib.Handle.onlyunitdiag(C, pcap=p)
+        h.comm_init_local(N, r, group)
+        q = session(h)
+        h.close()
+        return q
+
+    res = run_ranks(N, one_rank)
+    h = _lib.Handle.onlyunitdiag(C, pcap=p)
+    h.set_option("persist", 0)
+    ref = session(h)
+    h.close()
+    for q in res:
+        assert q[0] == ref[0] and q[2] and abs(q[1] - ref[1]) <= 1e-10 * abs(ref[1])
