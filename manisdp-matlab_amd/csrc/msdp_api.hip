@@ -497,6 +497,7 @@ extern "C" int msdp_dual_get_y(msdp_handle h, double* y) {
 }
 
 static void local_leave(msdp_handle h);       // in-process communicator stand-in, below
+static void halo_release(msdp_handle h);
 
 extern "C" int msdp_destroy(msdp_handle h) {
     if (!h) return 0;
@@ -510,6 +511,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     for (int s2 = 0; s2 < 2; ++s2) if (h->ev_flag[s2]) (void)hipEventDestroy(h->ev_flag[s2]);
     for (int s2 = 0; s2 < 2; ++s2) if (h->chunk_execs[s2]) (void)hipGraphExecDestroy(h->chunk_execs[s2]);
     msdp_affine_release(h);
+    halo_release(h);
     local_leave(h);
     if (h->lc_tmp) (void)hipFree(h->lc_tmp);
     if (h->esc_rp) (void)hipFree(h->esc_rp);
@@ -771,6 +773,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "escape_warm")) t.escape_warm = value != 0;
     else if (!strcmp(name, "escape_start_y")) t.escape_start_y = value != 0;
     else if (!strcmp(name, "lanczos_onesync")) t.lanczos_onesync = value != 0;
+    else if (!strcmp(name, "halo_exchange")) { t.halo_exchange = value != 0; h->state_valid = false; }
     else if (!strcmp(name, "dense_pack")) { t.dense_pack = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "debug_fail_persist")) t.fail_persist = value != 0;
     else { msdp_set_error("set_option: unknown option '%s'", name); return MSDP_EINVAL; }
@@ -783,6 +786,18 @@ extern "C" int msdp_get_kind(msdp_handle h, int32_t* kind) {
     *kind = h->kind;
     return 0;
 }
+
+// send / receive lists of the halo exchange ("Halo exchange" below)
+struct Halo {
+    int N = 0;
+    std::vector<int> send_cnt, send_off, recv_cnt, recv_off;     // per peer, in rows
+    int send_rows = 0, recv_rows = 0;
+    int* send_idx = nullptr;       // device: local row index of every row to send (peer-major)
+    int* recv_idx = nullptr;       // device: global row index of every row to receive (peer-major)
+    double* sendbuf = nullptr;     // device: send_rows x ldcap
+    double* recvbuf = nullptr;     // device: recv_rows x ldcap
+    int ldcap = 0;
+};
 
 // ------------------------------------------------------------------ in-process stand-in for the communicator
 // N handles of ONE process on ONE GPU, each driven by its own host thread, stand in for N ranks: the three collectives the
@@ -804,6 +819,7 @@ struct LocalGroup {
     unsigned long long gen = 0;
     bool broken = false;
     const double* ptr[LOCAL_MAX_RANKS] = {nullptr};
+    const Halo* halo[LOCAL_MAX_RANKS] = {nullptr};
     int members = 0;
 };
 static std::mutex g_groups_mutex;
@@ -863,6 +879,23 @@ static int local_allgather(msdp_handle h, const double* local, double* all, size
     LOCAL_BARRIER(g);                                      // nobody overwrites its slab before everyone has copied it
     return 0;
 }
+// halo rows between in-process members: every member publishes its packed send buffer and its per-peer offsets
+static int local_halo(msdp_handle h, Halo* ha, int ld) {
+    LocalGroup* g = h->lgroup;
+    HIPCHK(hipStreamSynchronize(h->stream));               // my send buffer is packed
+    { std::lock_guard<std::mutex> lk(g->m); g->ptr[h->rank] = ha->sendbuf; g->halo[h->rank] = ha; }
+    LOCAL_BARRIER(g);
+    for (int q = 0; q < g->n; ++q) {
+        if (q == h->rank || ha->recv_cnt[q] == 0) continue;
+        const Halo* pq = g->halo[q];
+        if (pq->send_cnt[h->rank] != ha->recv_cnt[q]) { msdp_set_error("halo exchange: rank %d sends %d rows, rank %d expects %d", q, pq->send_cnt[h->rank], h->rank, ha->recv_cnt[q]); return MSDP_ECOMM; }
+        HIPCHK(hipMemcpyAsync(ha->recvbuf + (size_t)ha->recv_off[q] * ld, g->ptr[q] + (size_t)pq->send_off[h->rank] * ld,
+                              (size_t)ha->recv_cnt[q] * ld * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    LOCAL_BARRIER(g);
+    return 0;
+}
 static void local_leave(msdp_handle h) {
     if (!h->lgroup) return;
     std::lock_guard<std::mutex> lk(g_groups_mutex);
@@ -872,6 +905,135 @@ static void local_leave(msdp_handle h) {
         for (auto it = g_groups.begin(); it != g_groups.end(); ++it) if (it->second == g) { g_groups.erase(it); break; }
         delete g;
     }
+}
+
+int msdp_allgather_rows(msdp_handle h, const double* local_rows);
+// ------------------------------------------------------------------ Halo exchange (sparse C)
+// The all-gather of the n x p direction moves (N-1)/N * n*p*8 bytes into every rank before every S*U -- for the G81 family
+// on eight ranks 35 MB per trip where the rows of C a rank owns reference 400 rows of other ranks (100 KB).  With the option
+// "halo_exchange" a rank packs, for every peer, the rows that peer's rows of C reference, one grouped ncclSend / ncclRecv
+// per peer moves them, and an unpack kernel scatters the received rows to their global positions in the gather buffer, which
+// the S*U kernels read exactly as after an all-gather.  Every rank holds the whole CSR structure on the host, so all send /
+// receive lists are computed locally and agree by construction.  Only for sparse C and only for the two exchanges in front
+// of the cost/gradient and Hess-vec kernels; msdp_get_point_all and the replicated escape keep the all-gather (they need
+// every row).
+__global__ void k_halo_pack(int rows, int ld, const int* __restrict__ idx, const double* __restrict__ local, double* __restrict__ buf) {
+    const int64_t tot = (int64_t)rows * ld;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = e / ld; const int c = (int)(e - k * ld);
+        buf[e] = local[(int64_t)idx[k] * ld + c];
+    }
+}
+__global__ void k_halo_unpack(int rows, int ld, const int* __restrict__ idx, const double* __restrict__ buf, double* __restrict__ full) {
+    const int64_t tot = (int64_t)rows * ld;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = e / ld; const int c = (int)(e - k * ld);
+        full[(int64_t)idx[k] * ld + c] = buf[e];
+    }
+}
+static void halo_release(msdp_handle h) {
+    Halo* ha = h->halo;
+    if (!ha) return;
+    if (ha->send_idx) (void)hipFree(ha->send_idx);
+    if (ha->recv_idx) (void)hipFree(ha->recv_idx);
+    if (ha->sendbuf) (void)hipFree(ha->sendbuf);
+    if (ha->recvbuf) (void)hipFree(ha->recvbuf);
+    delete ha;
+    h->halo = nullptr;
+}
+// Lists for the current partition (called by comm_partition for sparse C); buffers follow the vectors' capacity
+static int halo_setup(msdp_handle h) {
+    halo_release(h);
+    if (h->d.costkind != COST_SPARSE || h->h_rowptr.empty() || h->nranks < 2) return 0;
+    const int N = h->nranks, n = h->d.n, cap = rows_capacity(h), me = h->rank;
+    Halo* ha = new Halo();
+    ha->N = N;
+    ha->send_cnt.assign(N, 0); ha->send_off.assign(N + 1, 0); ha->recv_cnt.assign(N, 0); ha->recv_off.assign(N + 1, 0);
+    // needs[q]: rows outside q's range that q's rows of C reference (sorted, unique)
+    std::vector<std::vector<int>> send_rows(N);          // what I send to q (local indices), in the order q will unpack
+    std::vector<int> recv_rows;
+    std::vector<char> mark((size_t)n, 0);
+    for (int q = 0; q < N; ++q) {
+        const int q0 = std::min(n, q * cap), q1 = std::min(n, q0 + cap);
+        std::vector<int> need;
+        for (int i = q0; i < q1; ++i)
+            for (int t = h->h_rowptr[i]; t < h->h_rowptr[i + 1]; ++t) {
+                const int c = h->h_colind[t];
+                if ((c < q0 || c >= q1) && !mark[c]) { mark[c] = 1; need.push_back(c); }
+            }
+        std::sort(need.begin(), need.end());
+        for (int c : need) mark[c] = 0;
+        if (q == me) {
+            recv_rows = need;                            // sorted by global row = grouped by owning peer
+            for (int c : need) ha->recv_cnt[c / cap]++;
+        } else {
+            const int m0 = std::min(n, me * cap), m1 = std::min(n, m0 + cap);
+            for (int c : need) if (c >= m0 && c < m1) send_rows[q].push_back(c - m0);
+            ha->send_cnt[q] = (int)send_rows[q].size();
+        }
+    }
+    std::vector<int> sidx;
+    for (int q = 0; q < N; ++q) { ha->send_off[q + 1] = ha->send_off[q] + ha->send_cnt[q]; ha->recv_off[q + 1] = ha->recv_off[q] + ha->recv_cnt[q]; sidx.insert(sidx.end(), send_rows[q].begin(), send_rows[q].end()); }
+    ha->send_rows = ha->send_off[N]; ha->recv_rows = ha->recv_off[N];
+    ha->ldcap = h->ldcap > 0 ? h->ldcap : ((h->pcap + 1) / 2) * 2;
+    auto upi = [&](const std::vector<int>& v, int** out) -> int {
+        if (hipMalloc((void**)out, (v.size() ? v.size() : 1) * sizeof(int)) != hipSuccess) return MSDP_ENOMEM;
+        if (!v.empty() && hipMemcpy(*out, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return MSDP_EHIP;
+        return 0;
+    };
+    int rc = upi(sidx, &ha->send_idx);
+    if (!rc) rc = upi(recv_rows, &ha->recv_idx);
+    if (!rc && hipMalloc((void**)&ha->sendbuf, (size_t)std::max(ha->send_rows, 1) * ha->ldcap * sizeof(double)) != hipSuccess) rc = MSDP_ENOMEM;
+    if (!rc && hipMalloc((void**)&ha->recvbuf, (size_t)std::max(ha->recv_rows, 1) * ha->ldcap * sizeof(double)) != hipSuccess) rc = MSDP_ENOMEM;
+    h->halo = ha;
+    if (rc) { msdp_set_error("halo exchange: set-up allocation failed"); halo_release(h); }
+    return rc;
+}
+static int local_halo(msdp_handle h, Halo* ha, int ld);      // in-process stand-in, below the LocalGroup definition
+// rows of `local` the other ranks reference -> their gather buffers; mine + what I reference -> my gather buffer
+static int halo_exchange(msdp_handle h, const double* local_rows) {
+    Halo* ha = h->halo;
+    const int ld = h->d.ld;
+    if (ld > ha->ldcap) {                                  // the vectors were re-allocated for a wider factor: follow
+        const int cap = h->ldcap;
+        if (ha->sendbuf) (void)hipFree(ha->sendbuf);
+        if (ha->recvbuf) (void)hipFree(ha->recvbuf);
+        ha->sendbuf = ha->recvbuf = nullptr;
+        if (hipMalloc((void**)&ha->sendbuf, (size_t)std::max(ha->send_rows, 1) * cap * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&ha->recvbuf, (size_t)std::max(ha->recv_rows, 1) * cap * sizeof(double)) != hipSuccess) { msdp_set_error("halo exchange: buffer allocation failed"); return MSDP_ENOMEM; }
+        ha->ldcap = cap;
+    }
+    h->d.full = h->full_buf;
+    const size_t own = (size_t)rows_capacity(h) * ld;
+    HIPCHK(hipMemcpyAsync(h->full_buf + (size_t)h->rank * own, local_rows, own * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (ha->send_rows > 0) {
+        const int64_t tot = (int64_t)ha->send_rows * ld;
+        hipLaunchKernelGGL(k_halo_pack, dim3((int)std::min<int64_t>(1024, (tot + 255) / 256)), dim3(256), 0, h->stream, ha->send_rows, ld,
+                           (const int*)ha->send_idx, local_rows, ha->sendbuf);
+        HIPCHK(hipGetLastError());
+    }
+    if (h->lgroup) { int rc = local_halo(h, ha, ld); if (rc) return rc; }
+    else {
+        ncclResult_t r = ncclGroupStart();
+        for (int q = 0; q < ha->N && r == ncclSuccess; ++q) {
+            if (q == h->rank) continue;
+            if (ha->send_cnt[q] > 0) r = ncclSend(ha->sendbuf + (size_t)ha->send_off[q] * ld, (size_t)ha->send_cnt[q] * ld, ncclDouble, q, (ncclComm_t)h->comm, h->stream);
+            if (r == ncclSuccess && ha->recv_cnt[q] > 0) r = ncclRecv(ha->recvbuf + (size_t)ha->recv_off[q] * ld, (size_t)ha->recv_cnt[q] * ld, ncclDouble, q, (ncclComm_t)h->comm, h->stream);
+        }
+        ncclResult_t r2 = ncclGroupEnd();
+        if (r != ncclSuccess || r2 != ncclSuccess) { msdp_set_error("halo exchange: ncclSend/ncclRecv failed: %s", ncclGetErrorString(r != ncclSuccess ? r : r2)); return MSDP_ECOMM; }
+    }
+    if (ha->recv_rows > 0) {
+        const int64_t tot = (int64_t)ha->recv_rows * ld;
+        hipLaunchKernelGGL(k_halo_unpack, dim3((int)std::min<int64_t>(1024, (tot + 255) / 256)), dim3(256), 0, h->stream, ha->recv_rows, ld,
+                           (const int*)ha->recv_idx, (const double*)ha->recvbuf, h->full_buf);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+int msdp_exchange_rows(msdp_handle h, const double* local_rows) {
+    if (h->use_comm && h->halo && h->tune.halo_exchange && h->nranks > 1) return halo_exchange(h, local_rows);
+    return msdp_allgather_rows(h, local_rows);
 }
 
 // ------------------------------------------------------------------ collectives
@@ -989,7 +1151,8 @@ static int comm_partition(msdp_handle h, int32_t nranks, int32_t rank) {
         msdp_set_error("dense C must be created per shard (msdp_create_onlyunitdiag_dense_synthetic)");
         return MSDP_EUNSUPPORTED;
     }
-    return msdp_alloc_vectors(h, h->pcap);
+    if ((rc = msdp_alloc_vectors(h, h->pcap))) return rc;
+    return halo_setup(h);
 }
 
 extern "C" int msdp_debug_shard(msdp_handle h, int32_t nranks, int32_t rank) {

@@ -123,6 +123,7 @@ struct Tuning {
     int esc_debug = 0;     // per-run Lanczos statistics on stderr                                  (MSDP_ESC_DEBUG=1)
     int escape_deflate = 1;  // escape: deflate span(Y) at near-stationary points (fast, approximate when S*Y != 0)
     int escape_start_y = 0;   // undeflated cold-start runs begin in span(Y) + 5 % noise (the independent lambda_min check sets it)
+    int halo_exchange = 0;    // row-sharded sparse C: exchange only the referenced rows before S*U (0: the all-gather north_star prescribes)
     int lanczos_onesync = 1;  // undeflated persistent Lanczos runs: one grid synchronisation per step (0: two)
     int dense_pack = 1;    // dense C*U reads the fragment-ordered copy of C (0: the row-major one; same results)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
@@ -153,6 +154,9 @@ struct msdp_handle_s {
     void* comm = nullptr;          // ncclComm_t
     bool presharded = false;       // created per shard (dense synthetic): row0/n_loc fixed at creation
     double* full_buf = nullptr;    // gather buffer (nranks x cap rows) when the rows are sharded
+    // halo exchange (sparse C, option "halo_exchange"): instead of all rows of the direction every rank receives only the rows
+    // its rows of C reference (msdp_api.hip, "Halo exchange")
+    struct Halo* halo = nullptr;
     struct LocalGroup* lgroup = nullptr;   // in-process stand-in for the RCCL communicator (msdp_comm_init_local)
     double* lc_tmp = nullptr; size_t lc_tmp_cap = 0;   // its reduction scratch
     // row-sharded onlyunitdiag (sparse C): the escape runs replicated on full copies of C's CSR arrays and of z
@@ -215,3 +219,4 @@ int msdp_launch_rtr_fused(msdp_handle h);
 size_t msdp_psync_bytes();
 int msdp_allreduce_partials(msdp_handle h, int first, int count);   // no-op when nranks == 1
 int msdp_allgather_rows(msdp_handle h, const double* local_rows);   // local -> d.full
+int msdp_exchange_rows(msdp_handle h, const double* local_rows);    // sparse C: halo rows only when option halo_exchange is set, else the all-gather

@@ -657,7 +657,7 @@ int msdp_launch_costgrad(msdp_handle h, int slot) {
     if (slot >= 2) {
         if (h->d.costkind != COST_SPARSE || h->use_comm) { msdp_set_error("relative slot: sparse single-rank only"); return MSDP_EINVAL; }
     } else {
-        rc = msdp_allgather_rows(h, h->d.Y[slot]);
+        rc = (h->d.costkind == COST_SPARSE) ? msdp_exchange_rows(h, h->d.Y[slot]) : msdp_allgather_rows(h, h->d.Y[slot]);
     }
     if (rc) return rc;
     if (h->d.costkind == COST_SPARSE) {
@@ -675,7 +675,7 @@ int msdp_launch_costgrad(msdp_handle h, int slot) {
 }
 
 int msdp_launch_hess(msdp_handle h) {
-    int rc = msdp_allgather_rows(h, h->d.md);
+    int rc = (h->d.costkind == COST_SPARSE) ? msdp_exchange_rows(h, h->d.md) : msdp_allgather_rows(h, h->d.md);
     if (rc) return rc;
     if (h->d.costkind == COST_SPARSE) {
         if (h->d.ellW > 0) DISPATCH_LPR(k_hess_ell_obl, h, h->d);

@@ -214,6 +214,8 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
             raise ValueError("row-sharded solves need a sparse C")
         eig_mode = "device"
         _join_comm(h, comm)
+        if o.get("halo_exchange"):                         # only the rows this rank's rows of C reference travel before S*U
+            h.set_option("halo_exchange", 1)
     topts = _rtr_opts(o)
     p = int(o["p0"])
     Y = o.get("Y0", None)

@@ -43,8 +43,10 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("N", [2, 3, 8])
-@pytest.mark.parametrize("case", ["sparse", "dense"])
+@pytest.mark.parametrize("case", ["sparse", "dense", "sparse-halo"])
 def test_onlyunitdiag_ranks_match_one_handle(N, case):
+    halo = case == "sparse-halo"                   # option halo_exchange: only the referenced rows travel before S*U
+    case = case.split("-")[0]
     from manisdp_matlab_amd import _lib, problems
     _lib.load()
     rng = np.random.default_rng(11)
@@ -63,6 +65,8 @@ def test_onlyunitdiag_ranks_match_one_handle(N, case):
     def one_rank(r, group):
         h = make(N, r)
         h.comm_init_local(N, r, group)
+        if halo:
+            h.set_option("halo_exchange", 1)
         r0, r1 = h.local_rows()
         h.set_point(Y)
         f = h.cost(); G = h.rgrad(); H = h.hessvec(U)
@@ -266,3 +270,57 @@ def test_bench_entry_points_on_ranks(N):
     h.close()
     for q in res:
         assert q[0] == ref[0] and q[2] and abs(q[1] - ref[1]) <= 1e-10 * abs(ref[1])
+
+
+@pytest.mark.parametrize("N", [2, 4, 7])
+@pytest.mark.parametrize("graph", ["grid", "random"])
+def test_halo_exchange_is_bit_identical_to_all_gather(N, graph):
+    """The rows a rank's rows of C reference arrive through the packed point-to-point exchange instead of the all-gather:
+    the S*U kernels read the same numbers, so every result is bit-identical.  'random' is a graph without locality (every
+    rank references rows of every other rank, the lists are long and ragged); N = 7 leaves an uneven last shard."""
+    from manisdp_matlab_amd import _lib, problems, solvers
+    _lib.load()
+    if graph == "grid":
+        C = problems.toroidal_grid_maxcut(36, 50, seed=2)
+    else:
+        rng = np.random.default_rng(8)
+        n = 1500
+        A = sp.random(n, n, density=4.0 / n, random_state=rng, data_rvs=lambda k: rng.choice([-1.0, 1.0], k))
+        A = sp.triu(A, 1); A = A + A.T
+        C = sp.csr_matrix(-0.25 * (sp.diags(np.asarray(A.sum(axis=1)).ravel()) - A))
+    n, p = C.shape[0], 10
+    rng = np.random.default_rng(5)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    opts = _lib.default_opts(maxiter=6, maxinner=30, tolgradnorm=1e-9)
+    Y0 = Y[:, :2] / np.linalg.norm(Y[:, :2], axis=1, keepdims=True)
+
+    def runner(halo):
+        def one_rank(r, group):
+            h = _lib.Handle.onlyunitdiag(C, pcap=p)
+            h.comm_init_local(N, r, group)
+            h.set_option("halo_exchange", halo)
+            h.set_point(Y)
+            f = h.cost(); G = h.rgrad(); H = h.hessvec(U)
+            st = h.rtr(opts)
+            Yall = h.get_point_all()
+            h.close()
+            return f, G, H, st.cost, st.gradnorm, st.hessvecs, Yall
+        return one_rank
+
+    a = run_ranks(N, runner(0))
+    b = run_ranks(N, runner(1))
+    for qa, qb in zip(a, b):
+        for x, y in zip(qa, qb):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+
+    def solve(halo):
+        def one_rank(r, group):
+            Ys, obj, d = solvers.ManiSDP_onlyunitdiag(C, {"Y0": Y0, "tol": 1e-8, "comm": ("local", N, r, group), "halo_exchange": halo}, verbose=False)
+            return obj, d["iters"], d["hessvecs"], d["status"], Ys
+        return one_rank
+
+    if N == 4:
+        sa, sb = run_ranks(N, solve(0)), run_ranks(N, solve(1))
+        for qa, qb in zip(sa, sb):
+            assert qa[:4] == qb[:4] and np.array_equal(qa[4], qb[4])
