@@ -319,6 +319,9 @@ int msdp_get_dual_slack(msdp_handle h, double* S);
  *                       noise instead of pure noise (default 0; the independent lambda_min check of the host loops sets it)
  *   "lanczos_onesync" 1/0  undeflated persistent Lanczos runs use one grid synchronisation per step (default 1; 0 = the
  *                       two-synchronisation kernel the deflated runs use)
+ *   "halo_exchange" 1/0  row-sharded sparse C (after msdp_comm_init*): before S*U every rank receives only the rows of the
+ *                       direction its rows of C reference (grouped ncclSend / ncclRecv) instead of all rows (ncclAllGather,
+ *                       default 0).  Bit-identical results; msdp_get_point_all and the escape keep the all-gather
  *   "dense_pack"   1/0  dense C*U reads the MFMA-fragment-ordered copy of C (default 1; 0 = the row-major one;
  *                       bit-identical results, for A/B timing)
  *   "timing", "esc_debug"  1/0  diagnostics on stderr                                (env MSDP_TIMING, MSDP_ESC_DEBUG)

@@ -28,7 +28,7 @@ def main():
         return affine_case(out, rank, world, uid[0], dist, torch, _lib, problems)
     if case == "solve":
         return solve_case(out, rank, world, uid[0], dist, _lib, problems)
-    if case == "sparse":
+    if case in ("sparse", "sparse-halo"):
         C = problems.toroidal_grid_maxcut(61, 50, seed=4)           # n = 3050: ragged last shard for N = 4, 8
         n, p = C.shape[0], 12
         h = _lib.Handle.onlyunitdiag(C, pcap=p)
@@ -38,6 +38,8 @@ def main():
     Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
     U = rng.standard_normal((n, p))
     h.comm_init(world, rank, uid[0])
+    if case == "sparse-halo":
+        h.set_option("halo_exchange", 1)
     r0, r1 = h.local_rows()
     h.set_point(Y)
     f = h.cost()

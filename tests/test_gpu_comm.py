@@ -78,7 +78,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("case", ["sparse", "dense"])
+@pytest.mark.parametrize("case", ["sparse", "dense", "sparse-halo"])
 @pytest.mark.parametrize("N", [2, 4, 8])
 def test_ranks_on_separate_gpus_match_one_rank(tmp_path, case, N):
     """The real thing: N processes, one per GPU, RCCL all-gather of the direction before every S*U and all-reduce of the
@@ -102,7 +102,7 @@ def test_ranks_on_separate_gpus_match_one_rank(tmp_path, case, N):
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     got = np.load(out)
     rng = np.random.default_rng(11)
-    if case == "sparse":
+    if case.startswith("sparse"):                     # "sparse-halo": option halo_exchange (grouped ncclSend / ncclRecv)
         C = problems.toroidal_grid_maxcut(61, 50, seed=4)
         n, p = C.shape[0], 12
         h = _lib.Handle.onlyunitdiag(C, pcap=p)

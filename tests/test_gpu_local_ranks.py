@@ -230,8 +230,9 @@ def test_ragged_partition_with_an_empty_rank():
         assert rel(q[4], Y1) < 1e-10
 
 
+@pytest.mark.parametrize("halo", [0, 1])
 @pytest.mark.parametrize("N", [2, 4])
-def test_bench_entry_points_on_ranks(N):
+def test_bench_entry_points_on_ranks(N, halo):
     """What bench.py --gpus N calls on every rank (snapshot / restore of the start point, whole RTR calls, the Hess-vec and
     tCG-trip timers) on N in-process ranks of the weak-scaled G81-family grid: same Hess-vec count on every rank and as the
     one-handle run of the same problem."""
@@ -259,6 +260,7 @@ def test_bench_entry_points_on_ranks(N):
     def one_rank(r, group):
         h = _lib.Handle.onlyunitdiag(C, pcap=p)
         h.comm_init_local(N, r, group)
+        h.set_option("halo_exchange", halo)                # bench.py's second leg at N > 1
         q = session(h)
         h.close()
         return q
