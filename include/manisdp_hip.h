@@ -114,6 +114,11 @@ int msdp_create_onlyunitdiag_dense_synthetic(int64_t n, uint64_t seed, int32_t n
 double msdp_synthetic_dense_entry(int64_t n, int64_t i, int64_t j, uint64_t seed);
 /* Test-only: stand in for the all-gather on a communicator-free shard (one process = rank r of N). */
 int msdp_debug_set_full_rows(msdp_handle h, const double* rows_host);
+/* Test-only: the point-to-point calls of the halo exchange (one ncclGroupStart .. ncclSend + ncclRecv .. ncclGroupEnd on the
+ * handle's communicator and stream) with the handle's own rank as peer: `count` doubles in -> out through two device
+ * buffers.  Lets a single-GPU box run the RCCL half of the exchange; the send / receive lists are covered by the
+ * in-process ranks (tests/test_gpu_local_ranks.py). */
+int msdp_debug_p2p_self(msdp_handle h, int64_t count, const double* in_host, double* out_host);
 /* Test-only: make a sparse-C handle rank `rank` of `nranks` WITHOUT a communicator (same row split, local CSR/ELL
  * rows with global column indices and gather buffer as msdp_comm_init sets up), so that one GPU can check every
  * shard's kernels against the unsharded result.  Call right after create, before any point is set. */

@@ -55,6 +55,7 @@ SIGNATURES = {
                                                           _P(C.c_void_p)]),
     "msdp_synthetic_dense_entry": (C.c_double, [C.c_int64, C.c_int64, C.c_int64, C.c_uint64]),
     "msdp_debug_set_full_rows": (C.c_int, [C.c_void_p, _dp]),
+    "msdp_debug_p2p_self": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp]),
     "msdp_create_affine": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, _i64p, _i64p, _dp, _dp, _dp,
                                      C.c_int32, _P(C.c_void_p)]),
     "msdp_create_multiblock": (C.c_int, [C.c_int32, _i64p, C.c_int32, C.c_int64, _i64p, _i64p, _dp, _dp, _dp,
@@ -202,6 +203,12 @@ class Handle:
     def debug_shard(self, nranks, rank):
         """Test-only: rank `rank` of `nranks` without a communicator (sparse C)."""
         _check(self._lib.msdp_debug_shard(self._h, nranks, rank))
+
+    def debug_p2p_self(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty_like(x)
+        _check(self._lib.msdp_debug_p2p_self(self._h, x.size, _dptr(x), _dptr(out)))
+        return out
 
     def debug_set_full_rows(self, rows):
         rows = np.ascontiguousarray(rows, dtype=np.float64)

@@ -1031,6 +1031,28 @@ static int halo_exchange(msdp_handle h, const double* local_rows) {
     }
     return 0;
 }
+extern "C" int msdp_debug_p2p_self(msdp_handle h, int64_t count, const double* in_host, double* out_host) {
+    if (!h || !h->use_comm || h->lgroup || !h->comm || count <= 0) { msdp_set_error("debug_p2p_self: needs an RCCL communicator"); return MSDP_ESTATE; }
+    double *a = nullptr, *b = nullptr;
+    if (hipMalloc((void**)&a, count * sizeof(double)) != hipSuccess || hipMalloc((void**)&b, count * sizeof(double)) != hipSuccess) {
+        if (a) (void)hipFree(a);
+        msdp_set_error("debug_p2p_self: allocation failed"); return MSDP_ENOMEM;
+    }
+    int rc = 0;
+    if (hipMemcpyAsync(a, in_host, count * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = MSDP_EHIP;
+    if (!rc) {
+        ncclResult_t r = ncclGroupStart();
+        if (r == ncclSuccess) r = ncclSend(a, (size_t)count, ncclDouble, h->rank, (ncclComm_t)h->comm, h->stream);
+        if (r == ncclSuccess) r = ncclRecv(b, (size_t)count, ncclDouble, h->rank, (ncclComm_t)h->comm, h->stream);
+        ncclResult_t r2 = ncclGroupEnd();
+        if (r != ncclSuccess || r2 != ncclSuccess) { msdp_set_error("debug_p2p_self: %s", ncclGetErrorString(r != ncclSuccess ? r : r2)); rc = MSDP_ECOMM; }
+    }
+    if (!rc && hipMemcpyAsync(out_host, b, count * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = MSDP_EHIP;
+    if (hipStreamSynchronize(h->stream) != hipSuccess && !rc) rc = MSDP_EHIP;
+    (void)hipFree(a); (void)hipFree(b);
+    return rc;
+}
+
 int msdp_exchange_rows(msdp_handle h, const double* local_rows) {
     if (h->use_comm && h->halo && h->tune.halo_exchange && h->nranks > 1) return halo_exchange(h, local_rows);
     return msdp_allgather_rows(h, local_rows);

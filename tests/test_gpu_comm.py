@@ -37,6 +37,22 @@ def test_size1_communicator_is_bit_identical(monkeypatch):
     assert np.array_equal(a[6], b[6])
 
 
+def test_rccl_point_to_point_calls_of_the_halo_exchange():
+    """ncclGroupStart .. ncclSend + ncclRecv .. ncclGroupEnd on the handle's communicator and stream, the handle's own rank
+    as peer (the one pairing a single GPU offers): the RCCL half of the halo exchange; its lists are covered by
+    tests/test_gpu_local_ranks.py."""
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    C = problems.toroidal_grid_maxcut(10, 10, seed=1)
+    h = _lib.Handle.onlyunitdiag(C)
+    h.comm_init(1, 0, _lib.Handle.comm_unique_id())
+    rng = np.random.default_rng(2)
+    for count in (1, 400 * 32, 1 << 20):
+        x = rng.standard_normal(count)
+        assert np.array_equal(h.debug_p2p_self(x), x)
+    h.close()
+
+
 @pytest.mark.parametrize("N", [2, 3, 8])
 @pytest.mark.parametrize("case,p", [("G11", 12), ("G1", 7)])
 def test_sparse_shards_match_unsharded(N, case, p):
