@@ -47,11 +47,13 @@ __global__ void k_sv_sparse(int n, const int* __restrict__ rp, const int* __rest
 // dense C (n x nS row-major, zero pad columns, nS % 16 == 0): one wave per row, four 1-KB pieces of the row in
 // flight per lane (a single dependent accumulator chain left the loads of one piece at a time: 45 us per
 // 200-MB product at n = 5000)
-__global__ __launch_bounds__(256) void k_sv_dense(int n, int nS, const double* __restrict__ Cd, const double* __restrict__ z,
-                                                   const double* __restrict__ v, double* __restrict__ w) {
+// Row shard: `nrows` rows starting at global row `row0` (Cd holds those rows only); z and v have all n entries, w gets the
+// nrows local ones.  Unsharded: nrows = n, row0 = 0.
+__global__ __launch_bounds__(256) void k_sv_dense(int nrows, int n, int nS, const double* __restrict__ Cd, const double* __restrict__ z,
+                                                   const double* __restrict__ v, double* __restrict__ w, int row0) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
+    if (row >= nrows) return;
     const double* cr = Cd + (int64_t)row * nS;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int j = 2 * lane;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void k_sv_dense(int n, int nS, const double* _
         a0 += c2.x * v[j] + ((j + 1 < n) ? c2.y * v[j + 1] : 0.0);
     }
     const double acc = msdp_wave_sum((a0 + a1) + (a2 + a3));
-    if (lane == 0) w[row] = acc - (z ? z[row] * v[row] : 0.0);
+    if (lane == 0) w[row] = acc - (z ? z[row0 + row] * v[row0 + row] : 0.0);
 }
 // h[c] = <B_c, w>, c = 0..nb-1 (columns contiguous, stride ldb): one workgroup per column
 __global__ __launch_bounds__(MSDP_BLOCK) void k_multidot(int n, const double* __restrict__ B, int64_t ldb,
@@ -382,17 +384,29 @@ struct EscCtx {
     const double* Ypt = nullptr;    // all rows of the resident point (n x ld), for the escape_start_y start vector
     int ld = 0, p = 0;
     const int* rp = nullptr; const int* ci = nullptr; const double* cv = nullptr;   // CSR of C (all rows)
+    // pre-sharded dense C: this rank multiplies ITS rows (w_loc), the ranks all-gather the pieces (w_all: nranks*cap), and
+    // every rank continues the same recurrence on the same full-length vectors
+    double* w_loc = nullptr; double* w_all = nullptr; int cap = 0;
 };
 
 static int sapply(EscCtx& c, const double* v, double* w) {
     msdp_handle h = c.h;
     const Dev& d = h->d;
+    if (c.w_loc) {
+        if (d.n_loc > 0)
+            hipLaunchKernelGGL(k_sv_dense, dim3((d.n_loc + 3) / 4), dim3(256), 0, h->stream, d.n_loc, c.n, msdp_dense_nS(c.n), (const double*)d.Cd, c.z, v, c.w_loc, d.row0);
+        HIPCHK(hipGetLastError());
+        int rc = msdp_allgather_vec(h, c.w_loc, c.w_all, (size_t)c.cap);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(w, c.w_all, (size_t)c.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        return 0;
+    }
     if (c.M)
-        hipLaunchKernelGGL(k_sv_dense, dim3((c.n + 3) / 4), dim3(256), 0, h->stream, c.n, msdp_dense_nS(c.n), c.M, (const double*)nullptr, v, w);
+        hipLaunchKernelGGL(k_sv_dense, dim3((c.n + 3) / 4), dim3(256), 0, h->stream, c.n, c.n, msdp_dense_nS(c.n), c.M, (const double*)nullptr, v, w, 0);
     else if (d.costkind == COST_SPARSE)
         hipLaunchKernelGGL(k_sv_sparse, dim3((c.n + 255) / 256), dim3(256), 0, h->stream, c.n, c.rp, c.ci, c.cv, c.z, v, w);
     else
-        hipLaunchKernelGGL(k_sv_dense, dim3((c.n + 3) / 4), dim3(256), 0, h->stream, c.n, msdp_dense_nS(c.n), d.Cd, c.z, v, w);
+        hipLaunchKernelGGL(k_sv_dense, dim3((c.n + 3) / 4), dim3(256), 0, h->stream, c.n, c.n, msdp_dense_nS(c.n), (const double*)d.Cd, c.z, v, w, 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -692,7 +706,21 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     // (a Lanczos process with sharded vectors and an all-gather per step is the follow-up)
     // (taken with ANY communicator, also of size 1, so that one GPU exercises the gathers and the replicated copy)
     const bool rep_sparse = h->use_comm && !Mdev && d.costkind == COST_SPARSE && !h->h_rowptr.empty();
-    if (h->nranks != 1 && !rep_rows && !rep_sparse) { msdp_set_error("escape_eigs: row-sharded handles need sparse C or an explicit S"); return MSDP_EUNSUPPORTED; }
+    // Pre-sharded dense C (config 5): the matrix-vector product is sharded -- every rank multiplies its rows of C - diag(z)
+    // with the full vector and one all-gather of n doubles per Lanczos step puts the product back together;
+    // the recurrence itself (dots, axpys, the stored basis, the host analysis) runs replicated on identical numbers
+    const bool shard_dense = h->use_comm && !Mdev && d.costkind == COST_DENSE && h->presharded;
+    if (h->nranks != 1 && !rep_rows && !rep_sparse && !shard_dense) { msdp_set_error("escape_eigs: row-sharded handles need a communicator (sparse or pre-sharded dense C) or an explicit S"); return MSDP_EUNSUPPORTED; }
+    const size_t shard_cap = (size_t)((d.n + h->nranks - 1) / h->nranks);
+    if (shard_dense) {
+        if (!h->esc_z) {
+            // [z of all rows | this rank's rows of the product | the gathered product]
+            if (hipMalloc((void**)&h->esc_z, (2 * shard_cap * h->nranks + shard_cap) * sizeof(double)) != hipSuccess) { msdp_set_error("escape_eigs: allocation of the gather buffers failed"); return MSDP_ENOMEM; }
+        }
+        int rcg = msdp_allgather_vec(h, d.eG[h->h_ctl->cur], h->esc_z, shard_cap);
+        if (!rcg) rcg = msdp_allgather_rows(h, d.Y[h->h_ctl->cur]);
+        if (rcg) return rcg;
+    }
     if (rep_sparse) {
         const size_t nnz = h->h_cval.size(), cap = (size_t)((d.n + h->nranks - 1) / h->nranks);
         if (!h->esc_rp) {
@@ -719,9 +747,10 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     if (maxit > cap) maxit = (int)std::max<int64_t>(64, cap);
     const int cur = h->h_ctl->cur;
     EscCtx c;
-    c.h = h; c.n = n; c.z = Mdev ? nullptr : (rep_sparse ? (const double*)h->esc_z : (const double*)d.eG[cur]); c.M = Mdev;
+    c.h = h; c.n = n; c.z = Mdev ? nullptr : ((rep_sparse || shard_dense) ? (const double*)h->esc_z : (const double*)d.eG[cur]); c.M = Mdev;
+    if (shard_dense) { c.cap = (int)shard_cap; c.w_loc = h->esc_z + shard_cap * h->nranks; c.w_all = c.w_loc + shard_cap; }
     c.rp = rep_sparse ? h->esc_rp : d.rowptr; c.ci = rep_sparse ? h->esc_ci : d.colind; c.cv = rep_sparse ? h->esc_cv : d.cval;
-    c.Ypt = rep_sparse ? (const double*)h->full_buf
+    c.Ypt = (rep_sparse || shard_dense) ? (const double*)h->full_buf
                        : (((h->nranks != 1 || h->use_comm) && h->yfull[cur]) ? (const double*)h->yfull[cur] : (const double*)d.Y[cur]);
     c.ld = d.ld; c.p = d.p;
     const int qcap = p + k + 1;
@@ -792,7 +821,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         double ynorm_max = 0.0;
         for (int cidx = 0; deflate_y && cidx < p; ++cidx) {
             double* q = Q + (size_t)r * n;
-            hipLaunchKernelGGL(k_extract_col, gr, bl, 0, h->stream, n, d.ld, cidx, (rep_rows || rep_sparse) ? c.Ypt : (const double*)d.Y[cur], q);
+            hipLaunchKernelGGL(k_extract_col, gr, bl, 0, h->stream, n, d.ld, cidx, (rep_rows || rep_sparse || shard_dense) ? c.Ypt : (const double*)d.Y[cur], q);
             double n0; ESC_CHECK(dev_norm(c, q, &n0));
             ynorm_max = std::max(ynorm_max, n0);
             ESC_CHECK(deflate(c, Q, r, q, 2));

@@ -493,3 +493,35 @@ def dense_unitdiag_cost(n, seed=0):
     rng = np.random.default_rng(seed)
     G = rng.standard_normal((n, n))
     return (G + G.T) / (2.0 * np.sqrt(n))
+
+
+class SyntheticDenseC:
+    """The synthetic dense symmetric cost of BASELINE config 5 (n = 100 000, p = 64: the matrix is 80 GB and never exists
+    as a host array).  Entry (i, j) is a counter-based hash of (min(i,j), max(i,j), seed) mapped to U(-1, 1)/sqrt(n) --
+    the generator every rank runs on the device for ITS rows (``msdp_create_onlyunitdiag_dense_synthetic``;
+    ``msdp_synthetic_dense_entry`` is the same function on the host).  ``ManiSDP_onlyunitdiag`` accepts an instance in
+    place of ``C``; ``rows`` / ``toarray`` restate the generator in NumPy for parity tests at small n."""
+
+    def __init__(self, n, seed=0):
+        self.n, self.seed = int(n), int(seed)
+        self.shape = (self.n, self.n)
+
+    def rows(self, rows):
+        n = self.n
+        rows = np.asarray(rows, dtype=np.uint64)[:, None]
+        cols = np.arange(n, dtype=np.uint64)[None, :]
+        a = np.minimum(rows, cols); bb = np.maximum(rows, cols)
+        g = np.uint64(0x9E3779B97F4A7C15)
+        with np.errstate(over="ignore"):
+            x = a * np.uint64(n) + bb + np.uint64(self.seed) * g
+            x = x + g
+            x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            x = x ^ (x >> np.uint64(31))
+        u = (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        return (2.0 * u - 1.0) / np.sqrt(float(n))
+
+    def toarray(self):
+        if self.n > 20000:
+            raise ValueError("SyntheticDenseC.toarray: n = %d is a %0.f-GB matrix" % (self.n, 8e-9 * self.n * self.n))
+        return self.rows(np.arange(self.n))

@@ -202,16 +202,27 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
     _say(verbose, "ManiSDP is starting...")
     n = C.shape[0]
     _say(verbose, f"SDP size: n = {n}, m = {n}")
-    Csp = C.tocsr() if sp.issparse(C) else np.asarray(C, dtype=np.float64)
-    eig_mode = o.get("eig", "host" if n <= dense_max else "device")
-    h = _lib.Handle.onlyunitdiag(Csp, pcap=max(32, int(o["p0"]) + 2 * int(o["delta"])))
+    from .problems import SyntheticDenseC
+    comm = o.get("comm")
+    pcap = max(32, int(o["p0"]) + 2 * int(o["delta"]))
+    if isinstance(C, SyntheticDenseC):
+        # BASELINE config 5: every rank generates its rows of the dense C on the device; the matrix never exists on the host
+        # (only the host eigen-solver of small test problems asks for it)
+        eig_mode = o.get("eig", "host" if (n <= dense_max and comm is None) else "device")
+        Csp = C.toarray() if eig_mode == "host" else None
+        nr, rk = (1, 0) if comm is None else ((int(comm[1]), int(comm[2])) if comm[0] == "local" else (int(comm[0]), int(comm[1])))
+        h = _lib.Handle.dense_synthetic(n, C.seed, nranks=nr, rank=rk, pcap=pcap)
+    else:
+        Csp = C.tocsr() if sp.issparse(C) else np.asarray(C, dtype=np.float64)
+        eig_mode = o.get("eig", "host" if n <= dense_max else "device")
+        h = _lib.Handle.onlyunitdiag(Csp, pcap=pcap)
     # options['comm'] = (nranks, rank, unique_id): rows of the factor and of C sharded over the ranks (msdp_comm_init); this
     # host loop then runs replicated -- same start point (pass Y0 or seed rng identically), same data, same decisions on
     # every rank; the escape runs replicated on a full copy of the sparse C (device eigen-solver only)
-    comm = o.get("comm")
     if comm is not None:
-        if not sp.issparse(Csp):
-            raise ValueError("row-sharded solves need a sparse C")
+        if not (sp.issparse(Csp) or isinstance(C, SyntheticDenseC)):
+            h.close()
+            raise ValueError("row-sharded solves need a sparse C or a problems.SyntheticDenseC")
         eig_mode = "device"
         _join_comm(h, comm)
         if o.get("halo_exchange"):                         # only the rows this rank's rows of C reference travel before S*U
@@ -356,7 +367,7 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
         h.close()
     if obj is not None:
         Y = Y_eval          # the point the residues belong to (the loop's last pass has already widened its own copy)
-    if S is None and sp.issparse(Csp) and z is not None:
+    if S is None and Csp is not None and sp.issparse(Csp) and z is not None:
         S = Csp - sp.diags(z)                              # :49 (kept sparse; the reference returns full(S))
     data.update({"Y": Y, "S": S, "z": z, "dinf": dinf, "gradnorm": gradnorm,
                  "time": time.time() - t0, "p": Y.shape[1],

@@ -26,8 +26,8 @@ def main():
     rng = np.random.default_rng(11)
     if case == "affine":
         return affine_case(out, rank, world, uid[0], dist, torch, _lib, problems)
-    if case == "solve":
-        return solve_case(out, rank, world, uid[0], dist, _lib, problems)
+    if case in ("solve", "solve-dense"):
+        return solve_case(out, rank, world, uid[0], dist, _lib, problems, dense=(case == "solve-dense"))
     if case in ("sparse", "sparse-halo"):
         C = problems.toroidal_grid_maxcut(61, 50, seed=4)           # n = 3050: ragged last shard for N = 4, 8
         n, p = C.shape[0], 12
@@ -108,11 +108,11 @@ def affine_case(out, rank, world, uid, dist, torch, _lib, problems):
     dist.destroy_process_group()
 
 
-def solve_case(out, rank, world, uid, dist, _lib, problems):
+def solve_case(out, rank, world, uid, dist, _lib, problems, dense=False):
     """ManiSDP_onlyunitdiag end to end on a row-sharded toroidal-grid MaxCut problem (sparse C): sharded RTR, replicated
-    escape, replicated host loop."""
+    escape, replicated host loop; dense: the synthetic dense C generated per rank, sharded escape product."""
     from manisdp_matlab_amd import solvers
-    C = problems.toroidal_grid_maxcut(40, 50, seed=6)
+    C = problems.SyntheticDenseC(1000, seed=6) if dense else problems.toroidal_grid_maxcut(40, 50, seed=6)
     rng = np.random.default_rng(9)
     Y0 = rng.standard_normal((C.shape[0], 2)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
     Y, obj, data = solvers.ManiSDP_onlyunitdiag(C, {"Y0": Y0, "tol": 1e-8, "comm": (world, rank, uid)}, verbose=False)

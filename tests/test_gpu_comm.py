@@ -218,9 +218,29 @@ def test_size1_communicator_onlyunitdiag_solve(monkeypatch):
     assert np.allclose(np.linalg.norm(Yb, axis=1), 1.0, atol=1e-12) and db["z"].shape == (C.shape[0],)
 
 
+def test_size1_communicator_dense_synthetic_solve():
+    """The same for the pre-sharded synthetic dense C (config 5's layout, scaled down): sharded RTR and the escape with the
+    sharded product + ncclAllGather of the pieces per Lanczos step, against the communicator-free solve."""
+    from manisdp_matlab_amd import _lib, problems, solvers
+    Csyn = problems.SyntheticDenseC(600, seed=5)
+    rng = np.random.default_rng(4)
+    Y0 = rng.standard_normal((Csyn.n, 2)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    o = {"Y0": Y0, "tol": 1e-8, "eig": "device"}
+    Ya, obja, da = solvers.ManiSDP_onlyunitdiag(Csyn, dict(o), verbose=False)
+    Yb, objb, db = solvers.ManiSDP_onlyunitdiag(Csyn, dict(o, comm=(1, 0, _lib.Handle.comm_unique_id())), verbose=False)
+    assert da["status"] == 0 and db["status"] == 0 and db["dinf"] < 1e-8
+    assert abs(obja - objb) <= 1e-7 * abs(obja)
+    # LAPACK on the explicit matrix at the returned point: the reported dinf is the true one
+    z = db["z"]
+    w = np.linalg.eigvalsh(Csyn.toarray() - np.diag(z))
+    assert max(0.0, -w[0]) / (1.0 + w[-1]) < 1e-8 and abs(np.sum(z) - objb) <= 1e-10 * abs(objb)
+
+
+@pytest.mark.parametrize("case", ["solve", "solve-dense"])
 @pytest.mark.parametrize("N", [2, 4, 8])
-def test_onlyunitdiag_solve_on_separate_gpus(tmp_path, N):
-    """Whole ManiSDP_onlyunitdiag solve on N GPUs (sharded RTR, replicated escape and host loop) against the one-GPU solve.
+def test_onlyunitdiag_solve_on_separate_gpus(tmp_path, N, case):
+    """Whole ManiSDP_onlyunitdiag solve on N GPUs (sharded RTR, replicated escape and host loop) against the one-GPU solve;
+    'solve-dense': the pre-sharded synthetic dense C with the sharded escape product.
     Needs N visible GPUs (skipped on the single-GPU box; its single-GPU stand-in is test_size1_communicator_onlyunitdiag_solve)."""
     import os, subprocess, sys
     import torch
@@ -234,11 +254,11 @@ def test_onlyunitdiag_solve_on_separate_gpus(tmp_path, N):
     for r in range(N):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, worker, "solve", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        procs.append(subprocess.Popen([sys.executable, worker, case, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=900)[0].decode(errors="replace") for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     got = np.load(out)
-    C = problems.toroidal_grid_maxcut(40, 50, seed=6)
+    C = problems.toroidal_grid_maxcut(40, 50, seed=6) if case == "solve" else problems.SyntheticDenseC(1000, seed=6)
     rng = np.random.default_rng(9)
     Y0 = rng.standard_normal((C.shape[0], 2)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
     _, obj1, d1 = solvers.ManiSDP_onlyunitdiag(C, {"Y0": Y0, "tol": 1e-8, "eig": "device"}, verbose=False)

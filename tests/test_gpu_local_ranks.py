@@ -326,3 +326,67 @@ def test_halo_exchange_is_bit_identical_to_all_gather(N, graph):
         sa, sb = run_ranks(N, solve(0)), run_ranks(N, solve(1))
         for qa, qb in zip(sa, sb):
             assert qa[:4] == qb[:4] and np.array_equal(qa[4], qb[4])
+
+
+@pytest.mark.parametrize("N", [2, 3])
+def test_dense_shard_escape_matches_one_handle(N):
+    """Pre-sharded dense C (BASELINE config 5's layout): the escape multiplies every rank's rows of C - diag(z) with the full
+    Lanczos vector and all-gathers the pieces; the ranks must find the eigenpairs of the one-handle run and the
+    same bits as each other."""
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    n, p, seed = 700, 6, 3
+    rng = np.random.default_rng(1)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    opts = _lib.default_opts(maxiter=20, maxinner=40, tolgradnorm=1e-7)
+
+    def session(h):
+        h.set_point(Y)
+        h.rtr(opts)
+        lam, V, lmax, _ = h.escape_eigs(3, tol=1e-10, maxit=4000)
+        return lam, V, lmax
+
+    def one_rank(r, group):
+        h = _lib.Handle.dense_synthetic(n, seed, nranks=N, rank=r, pcap=p)
+        h.comm_init_local(N, r, group)
+        q = session(h)
+        h.close()
+        return q
+
+    res = run_ranks(N, one_rank)
+    h = _lib.Handle.dense_synthetic(n, seed, pcap=p)
+    lam, V, lmax = session(h)
+    h.close()
+    # against LAPACK on the explicit matrix at the one-handle point is test_gpu_dense's job; here: ranks == one handle
+    for q in res:
+        assert np.allclose(q[0], lam, rtol=0, atol=1e-8 * max(1.0, abs(lmax))) and abs(q[2] - lmax) <= 1e-6 * abs(lmax)
+        for j in range(3):
+            assert min(np.linalg.norm(q[1][:, j] - V[:, j]), np.linalg.norm(q[1][:, j] + V[:, j])) < 1e-5
+        assert np.array_equal(q[0], res[0][0]) and np.array_equal(q[1], res[0][1])
+
+
+@pytest.mark.parametrize("N", [2, 4])
+def test_whole_solve_dense_synthetic_on_ranks(N):
+    """ManiSDP_onlyunitdiag on the synthetic dense C of config 5 (scaled down), rows of C generated per rank on the device,
+    sharded RTR, sharded escape product: against the one-handle solve and the oracle on the explicit matrix."""
+    from manisdp_matlab_amd import problems, solvers
+    from oracle import manisdp_ref as ref
+    Csyn = problems.SyntheticDenseC(420, seed=7)
+    n = Csyn.n
+    rng = np.random.default_rng(2)
+    Y0 = rng.standard_normal((n, 2)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+
+    def one_rank(r, group):
+        Y, obj, d = solvers.ManiSDP_onlyunitdiag(Csyn, {"Y0": Y0, "tol": 1e-8, "comm": ("local", N, r, group)}, verbose=False)
+        return obj, d["status"], d["dinf"], Y
+
+    res = run_ranks(N, one_rank)
+    _, obj1, d1 = solvers.ManiSDP_onlyunitdiag(Csyn, {"Y0": Y0, "tol": 1e-8, "eig": "device"}, verbose=False)
+    _, obj_h, d_h = solvers.ManiSDP_onlyunitdiag(Csyn, {"Y0": Y0, "tol": 1e-8}, verbose=False)     # host eig on Csyn.toarray()
+    _, obj_o, d_o = ref.ManiSDP_onlyunitdiag(Csyn.toarray(), {"Y0": Y0, "tol": 1e-8})
+    assert d1["status"] == 0 and d_h["status"] == 0 and d_o["status"] == 0
+    assert abs(obj1 - obj_o) <= 1e-7 * abs(obj_o) and abs(obj_h - obj_o) <= 1e-7 * abs(obj_o)
+    for q in res:
+        assert q[1] == 0 and q[2] < 1e-8 and abs(q[0] - obj_o) <= 1e-7 * abs(obj_o)
+        assert np.allclose(np.linalg.norm(q[3], axis=1), 1.0, atol=1e-12)
+        assert q[0] == res[0][0] and np.array_equal(q[3], res[0][3])
