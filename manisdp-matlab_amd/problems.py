@@ -488,6 +488,29 @@ def theta_problem(n, ndraws=None, seed=1):
     return At, b, c, {"s": n}
 
 
+def matrix_completion(p, q, k, m=None, seed=3):
+    """Nuclear-norm matrix completion as an SDP for the generic ``ManiSDP`` (reference example/example_matrixcompletion.m:8-41):
+    ``M = randn(p,k) randn(k,q)``, ``m`` sampled positions (default ``400 (p+q)`` draws with replacement, duplicates removed,
+    as in the example), ``min <I, X>  s.t.  X[j, p+l] + X[p+l, j] = 2 M[j, l]`` for the sampled ``(j, l)``, ``X`` of order
+    ``n = p + q``.  NumPy's generator replaces MATLAB's, so instances differ from the reference's; the structure does not.
+    Returns ``At (n^2 x m, CSC), b, c, K, M, (rows, cols)``."""
+    rng = np.random.default_rng(seed)
+    n = p + q
+    M = rng.standard_normal((p, k)) @ rng.standard_normal((k, q))
+    m = 400 * n if m is None else int(m)
+    omega = np.unique(rng.integers(0, p * q, size=m))              # :15-17 (row-major position j*q + l here)
+    j, l = omega // q, omega % q
+    m = omega.size
+    b = 2.0 * M[j, l]                                              # :33
+    col = np.repeat(np.arange(m), 2)
+    row = np.empty(2 * m, dtype=np.int64)
+    row[0::2] = j * n + (l + p)                                    # :34  vec index of (l+p, j), column-major
+    row[1::2] = (l + p) * n + j                                    #      and of (j, l+p)
+    At = sp.csc_matrix((np.ones(2 * m), (row, col)), shape=(n * n, m))
+    c = np.eye(n).ravel()
+    return At, b, c, {"s": n, "l": 0}, M, (j, l)
+
+
 def dense_unitdiag_cost(n, seed=0):
     """Random dense symmetric cost ``C = (G + G')/(2 sqrt(n))``."""
     rng = np.random.default_rng(seed)

@@ -138,3 +138,37 @@ def test_generic_solver_quartic_on_sphere_matches_oracle(lib, d):
         Y, obj, data = solvers.ManiSDP(At, b, c, K, {"eig": mode}, verbose=False)
         assert data["status"] == 0 and max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
         assert abs(obj - obj_ref) < 1e-6 * abs(obj_ref)
+
+
+MC_OPTS = {"tol": 1e-8, "theta": 1e-2, "TR_maxinner": 6, "TR_maxiter": 8, "delta": 10, "alpha": 0.1}   # example_matrixcompletion.m:51-57
+
+
+def test_matrix_completion_matches_oracle(lib):
+    """Nuclear-norm matrix completion through the generic ManiSDP with the options of example/example_matrixcompletion.m
+    (the instance generator follows :8-41 with NumPy's random stream): same optimum as the oracle, KKT 1e-8, and the
+    four unsampled entries of the rank-2 matrix are recovered (896 of the 900 positions are drawn; with a third of them the
+    reference algorithm -- oracle and GPU alike -- ends in its "Slow progress" exit at eta ~ 1e-6)."""
+    from manisdp_matlab_amd import problems, solvers
+    from oracle import manisdp_ref as R
+    At, b, c, K, M, _ = problems.matrix_completion(30, 30, 2, m=6000, seed=3)
+    rng = np.random.default_rng(1)
+    Y0 = rng.standard_normal((K["s"], 1))
+    Yo, objo, do = R.ManiSDP(At, b, c, K, dict(MC_OPTS, Y0=Y0))
+    Y, obj, d = solvers.ManiSDP(At, b, c, K, dict(MC_OPTS, Y0=Y0), verbose=False)
+    assert do["status"] == 0 and d["status"] == 0
+    assert max(d["gap"], d["pinf"], d["dinf"]) < 1e-8
+    assert abs(obj - objo) <= 1e-7 * abs(objo)
+    X12 = Y[:30] @ Y[30:].T
+    assert np.linalg.norm(X12 - M) <= 1e-6 * np.linalg.norm(M)
+
+
+def test_matrix_completion_n1000(lib):
+    """p = q = 500, rank 5 (n = 1000, m ~ 200 000 sampled entries): KKT 1e-8, trace = nuclear norm of the completed
+    matrix, recovery to 1e-6."""
+    from manisdp_matlab_amd import problems, solvers
+    At, b, c, K, M, _ = problems.matrix_completion(500, 500, 5, seed=3)
+    Y, obj, d = solvers.ManiSDP(At, b, c, K, dict(MC_OPTS), verbose=False, rng=np.random.default_rng(0))
+    assert d["status"] == 0 and max(d["gap"], d["pinf"], d["dinf"]) < 1e-8
+    X12 = Y[:500] @ Y[500:].T
+    assert np.linalg.norm(X12 - M) <= 1e-6 * np.linalg.norm(M)
+    assert abs(obj - 2.0 * np.linalg.svd(M, compute_uv=False).sum()) <= 1e-6 * obj      # tr X = 2 |M|_*
