@@ -115,12 +115,16 @@ def affine_shapes(_lib, problems, with_cpu):
             Y /= np.linalg.norm(Y, axis=1, keepdims=True) if kind == _lib.KIND_UNITDIAG else np.linalg.norm(Y)
             h = _lib.Handle.affine(kind, At, b, c, n, pcap=p)
             h.set_multipliers(np.zeros(b.size), 1.0)
-            h.set_point(Y)
-            for _ in range(2):
-                ms, _, _ = h.bench_hessvec(100)
+            sweep = {}
+            for pp in (8, 16, 32):                                # Hess-vec at p in {8, 16, 32}; p = 32 last = the headline entry
+                h.set_point(np.ascontiguousarray(Y[:, :pp] / (np.linalg.norm(Y[:, :pp], axis=1, keepdims=True) if kind == _lib.KIND_UNITDIAG
+                                                                else np.linalg.norm(Y[:, :pp]))))
+                for _ in range(2):
+                    ms, _, _ = h.bench_hessvec(100)
+                sweep["p%d" % pp] = ms * 1e3
             h.close()
             ent = {"workload": name, "entry_point": label, "n": n, "m": int(b.size), "nnz_At": int(At.nnz), "p": p, "hessvec_us": ms * 1e3,
-                   "hessvec_per_s": 1e3 / ms}
+                   "hessvec_per_s": 1e3 / ms, "hessvec_us_by_p": sweep}
             if with_cpu:
                 from oracle import manisdp_ref
                 U = rng.standard_normal((n, p))
@@ -314,6 +318,22 @@ def main():
         "hessvec_per_s_whole_tcg": 1e3 / trip_ms,        # one Hess-vec + all vector work and reductions of a tCG trip
         "hessvec_per_s_in_rtr": hv / rtr_s if rtr_s > 0 else None,
     }
+    if N == 1 and rank == 0 and not args.force_comm:
+        # the Hess-vec microbenchmark at p in {8, 16, 32} -- stand-alone S*U kernel and whole tCG trip
+        sweep = {}
+        for pp in (8, 16, 32):
+            try:
+                hp = _lib.Handle.onlyunitdiag(C, pcap=pp)
+                hp.set_point(np.ascontiguousarray(Y0[:, :pp] / np.linalg.norm(Y0[:, :pp], axis=1, keepdims=True)) if pp <= p else
+                             (lambda Z: Z / np.linalg.norm(Z, axis=1, keepdims=True))(np.random.default_rng(pp).standard_normal((n, pp))))
+                hms, hby, _ = hp.bench_hessvec(200)
+                tms = hp.bench_tcg_trip(512)
+                sweep["p%d" % pp] = {"hessvec_kernel_us": hms * 1e3, "hessvec_kernel_GBps": hby / (hms * 1e-3) / 1e9, "tcg_trip_us": tms * 1e3,
+                                     "hessvec_per_s_whole_tcg": 1e3 / tms}
+                hp.close()
+            except Exception as e:  # noqa: BLE001
+                sweep["p%d" % pp] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["hessvec_by_p"] = sweep
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(C, Y0) if N == 1 else None
     if not args.no_kkt and N == 1 and rank == 0 and data_kind.startswith("Gset"):
