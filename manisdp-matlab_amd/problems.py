@@ -488,6 +488,118 @@ def theta_problem(n, ndraws=None, seed=1):
     return At, b, c, {"s": n}
 
 
+def chain_cliques(t, q):
+    """``t`` cliques of ``q`` consecutive variables, neighbours sharing two (reference example/example_bqp_sparse.m:3-10):
+    ``n = q + (q-2)(t-1)`` variables, clique i = {(q-2) i, ..., (q-2) i + q - 1} (0-based)."""
+    return [list(range((q - 2) * i, (q - 2) * i + q)) for i in range(t)], q + (q - 2) * (t - 1)
+
+
+def bqp_sparse_monomials(cliques):
+    """The monomials of a sparse BQP objective: ``x_a`` and ``x_a x_b`` (a < b) with both variables in one clique, as
+    sorted tuples, in lexicographic order (example_bqp_sparse.m:11-18 without the constant)."""
+    mons = set()
+    for I in cliques:
+        for a in I:
+            mons.add((a,))
+        for ia, a in enumerate(I):
+            for bb in I[ia + 1:]:
+                mons.add((a, bb))
+    return sorted(mons)
+
+
+def bqpmom_sparse(n, cliques, coe):
+    """Second-order moment relaxation of a BQP with correlative sparsity, one PSD block per clique, for
+    ``ManiSDP_multiblock`` (what src/basicfunction/bqpmom_sparse.m:6-133 builds; written from the definition, not its loops):
+
+    * block k is the moment matrix of the basis ``[1, x_a (a in I_k), x_a x_b (a < b in I_k)]`` (pairs ordered by their
+      larger variable), ``K['s'][k] = 1 + |I_k| + |I_k|(|I_k|-1)/2``, all blocks with unit diagonal (``K['nob'] = t``);
+    * entries are indexed by UNREDUCED products (exponents 0..2); the constraints are: the (1,1) entry of block 1 is 1; every
+      other diagonal entry of a constant / degree-1 basis element equals it; the diagonal entry of a pair equals those of its
+      two variables; ``L(x_a^2 m) = L(m)`` for every clique variable a and basis monomial m != 1 of its block without a
+      (both sides averaged over all entries that carry the monomial); all entries carrying one monomial are equal;
+    * ``coe`` gives the coefficients of ``bqp_sparse_monomials(cliques)``, each spread evenly over the entries that carry
+      its monomial.
+
+    Returns ``At (sum s_k^2 x m, CSC), b, c, K``; every moment vector of a point in {-1, 1}^n satisfies ``At' x = b`` and
+    ``c' x = f(x)`` (tests/test_problems.py)."""
+    t = len(cliques)
+    bases = []
+    for I in cliques:
+        bs = [()] + [(a,) for a in I]
+        for jb in range(1, len(I)):
+            for ia in range(jb):
+                bs.append((I[ia], I[jb]))
+        bases.append(bs)
+    mb = [len(bs) for bs in bases]
+    off = np.concatenate([[0], np.cumsum([v * v for v in mb])]).astype(np.int64)
+
+    def entry(k, i, j):                                    # position of entry (i, j) of block k in the stacked vecs
+        return int(off[k] + j * mb[k] + i)
+
+    def product(u, v):                                     # exponent pattern of the unreduced product, as a sorted tuple
+        return tuple(sorted(u + v))
+
+    # every off-diagonal entry (i < j) grouped by the monomial it carries; diagonal entries carry squares
+    where = {}
+    for k, bs in enumerate(bases):
+        for i in range(mb[k]):
+            for j in range(i + 1, mb[k]):
+                where.setdefault(product(bs[i], bs[j]), []).append((i, j, k))
+    rows, cols, vals = [entry(0, 0, 0)], [0], [1.0]
+    m = 1
+
+    def add(pairs):
+        nonlocal m
+        for r, v in pairs:
+            rows.append(r); cols.append(m); vals.append(v)
+        m += 1
+
+    for k, I in enumerate(cliques):                         # unit diagonal, constant and degree-1 part
+        for i in range(1 if k == 0 else 0, len(I) + 1):
+            add([(entry(0, 0, 0), 0.5), (entry(k, i, i), -0.5)])
+    for k, I in enumerate(cliques):                         # unit diagonal, pairs: tied to both variables
+        pos = {a: 1 + ia for ia, a in enumerate(I)}
+        for i in range(len(I) + 1, mb[k]):
+            for a in bases[k][i]:
+                add([(entry(k, pos[a], pos[a]), 0.5), (entry(k, i, i), -0.5)])
+
+    def spots(mon):
+        out = []
+        for (i, j, k) in where[mon]:
+            out += [entry(k, i, j), entry(k, j, i)]
+        return out
+
+    for k, I in enumerate(cliques):                         # x_a^2 m = m
+        for a in I:
+            for i in range(1, mb[k]):
+                mon = bases[k][i]
+                if a in mon:
+                    continue
+                hi, lo = spots(product(mon, (a, a))), spots(mon)
+                if len(hi) < len(lo):
+                    add([(r, 1.0) for r in hi] + [(r, -len(hi) / len(lo)) for r in lo])
+                else:
+                    add([(r, len(lo) / len(hi)) for r in hi] + [(r, -1.0) for r in lo])
+    for mon in sorted(where):                               # one value per monomial
+        lst = where[mon]
+        ref = max(range(len(lst)), key=lambda q: (lst[q][0], -q))      # the first entry with the largest row index
+        i0, j0, k0 = lst[ref]
+        for q, (i, j, k) in enumerate(lst):
+            if q != ref:
+                add([(entry(k0, i0, j0), 0.5), (entry(k0, j0, i0), 0.5), (entry(k, i, j), -0.5), (entry(k, j, i), -0.5)])
+    At = sp.csc_matrix((vals, (rows, cols)), shape=(int(off[-1]), m))
+    b = np.zeros(m); b[0] = 1.0
+    c = np.zeros(int(off[-1]))
+    mons = bqp_sparse_monomials(cliques)
+    coe = np.asarray(coe, dtype=np.float64).ravel()
+    if coe.size != len(mons):
+        raise ValueError("bqpmom_sparse: %d coefficients for %d monomials" % (coe.size, len(mons)))
+    for mon, v in zip(mons, coe):
+        lo = spots(mon)
+        c[lo] += v / len(lo)
+    return At, b, c, {"s": mb, "nob": t}
+
+
 def matrix_completion(p, q, k, m=None, seed=3):
     """Nuclear-norm matrix completion as an SDP for the generic ``ManiSDP`` (reference example/example_matrixcompletion.m:8-41):
     ``M = randn(p,k) randn(k,q)``, ``m`` sampled positions (default ``400 (p+q)`` draws with replacement, duplicates removed,

@@ -166,3 +166,31 @@ def test_multiblock_mixed_manifold_follows_the_oracle(lib):
     want = -(known["mcp100"] + known["mcp124-1"])
     assert max(d["gap"], d["pinf"], d["dinf"]) < 1e-4 and abs(obj - want) <= 1e-5 * abs(want)
     assert np.abs(np.diag(Y[0] @ Y[0].T) - 1).max() < 1e-12               # the oblique block stays on its manifold
+
+
+SPARSE_OPTS = {"tol": 1e-8, "line_search": 1, "tau1": 1}          # example_bqp_sparse.m:25-29
+
+
+@pytest.mark.parametrize("t,q", [(4, 5), (6, 8)])
+def test_multiblock_sparse_bqp_matches_oracle(lib, t, q):
+    """The workload ManiSDP_multiblock was written for: the sparse second-order moment relaxation of a BQP with chain
+    cliques (example_bqp_sparse.m, bqpmom_sparse.m), one unit-diagonal block per clique coupled through the shared moments.
+    Same optimum as the oracle, KKT 1e-8, and a lower bound on f over sign vectors (tight on the small chain)."""
+    import itertools
+    from manisdp_matlab_amd import problems as P, solvers
+    from oracle import manisdp_ref as R
+    cl, n = P.chain_cliques(t, q)
+    mons = P.bqp_sparse_monomials(cl)
+    coe = np.random.default_rng(1).standard_normal(len(mons))
+    At, b, c, K = P.bqpmom_sparse(n, cl, coe)
+    Y, obj, d = solvers.ManiSDP_multiblock(At, b, c, K, dict(SPARSE_OPTS), verbose=False)
+    assert d["status"] == 0 and max(d["gap"], d["pinf"], d["dinf"]) < 1e-8
+    Yr, objr, dr = R.ManiSDP_multiblock(At, b, c, K, dict(SPARSE_OPTS))
+    assert dr["status"] == 0 and abs(obj - objr) <= 1e-7 * abs(objr)
+    f = lambda x: sum(cv * np.prod([x[a] for a in mon]) for mon, cv in zip(mons, coe))      # noqa: E731
+    if n <= 14:
+        best = min(f(x) for x in itertools.product([-1.0, 1.0], repeat=n))
+        assert abs(obj - best) <= 1e-7 * abs(best)
+    else:
+        rng = np.random.default_rng(2)
+        assert all(obj <= f(rng.choice([-1.0, 1.0], n)) + 1e-7 for _ in range(50))

@@ -1,5 +1,6 @@
 """CPU tests of the instance readers / generators against facts stated in the reference tree."""
 import numpy as np
+import pytest
 import scipy.sparse as sp
 
 from conftest import golden_path
@@ -88,3 +89,68 @@ def test_theta_generator():
     assert np.array_equal(last, np.eye(n))
     A0 = At[:, 0].toarray().reshape(n, n, order="F")
     assert np.array_equal(A0, A0.T) and A0.sum() == 2
+
+
+def _sparse_moment_vector(cliques, x):
+    vec = []
+    for I in cliques:
+        v = [1.0] + [x[a] for a in I]
+        for jb in range(1, len(I)):
+            for ia in range(jb):
+                v.append(x[I[ia]] * x[I[jb]])
+        v = np.array(v)
+        vec.append(np.outer(v, v).ravel(order="F"))
+    return np.concatenate(vec)
+
+
+@pytest.mark.parametrize("t,q", [(1, 4), (3, 4), (4, 5), (3, 6)])
+def test_bqpmom_sparse_structure(t, q):
+    """Sparse second-order moment relaxation of a BQP (bqpmom_sparse.m): block sizes, the reference's constraint count
+    (bqpmom_sparse.m:46), and validity -- the moments of every point of {-1,1}^n satisfy all constraints and reproduce f."""
+    import itertools
+    cl, n = P.chain_cliques(t, q)
+    assert n == q + (q - 2) * (t - 1) and all(len(I) == q for I in cl) and cl[-1][-1] == n - 1
+    mons = P.bqp_sparse_monomials(cl)
+    rng = np.random.default_rng(10 * t + q)
+    coe = rng.standard_normal(len(mons))
+    At, b, c, K = P.bqpmom_sparse(n, cl, coe)
+    mb = np.array(K["s"]); mc = np.array([len(I) for I in cl])
+    assert K["nob"] == t and (mb == 1 + mc + mc * (mc - 1) // 2).all() and At.shape[0] == int(np.sum(mb * mb))
+    support = set()                                            # monomials of degree <= 4, exponents <= 2, not a square
+    for I in cl:
+        for d in range(1, 5):
+            for combo in itertools.combinations_with_replacement(I, d):
+                cnt = [combo.count(v) for v in set(combo)]
+                if max(cnt) <= 2 and any(e % 2 for e in cnt):
+                    support.add(combo)
+    assert At.shape[1] == int(np.sum(mb * (mb + 1) // 2) - len(support) + np.sum(mc * (mb - 1)) - np.sum(mb) + t)
+    assert b[0] == 1 and not b[1:].any()
+    for _ in range(4):
+        x = rng.choice([-1.0, 1.0], n)
+        X = _sparse_moment_vector(cl, x)
+        f = sum(cv * np.prod([x[a] for a in mon]) for mon, cv in zip(mons, coe))
+        assert np.abs(At.T @ X - b).max() == 0.0 and abs(c @ X - f) < 1e-12
+    # symmetric constraint and cost matrices, block by block
+    off = np.concatenate([[0], np.cumsum(mb * mb)])
+    for k in range(t):
+        Ck = c[off[k]:off[k + 1]].reshape(mb[k], mb[k])
+        assert np.array_equal(Ck, Ck.T)
+    col = At[:, At.shape[1] - 1].toarray().ravel()
+    for k in range(t):
+        Ak = col[off[k]:off[k + 1]].reshape(mb[k], mb[k])
+        assert np.array_equal(Ak, Ak.T)
+
+
+def test_bqpmom_sparse_relaxation_is_tight_on_a_small_chain():
+    """Oracle ManiSDP_multiblock on the sparse relaxation (options of example_bqp_sparse.m:25-29) against brute force over
+    {-1,1}^8: the relaxation of this chain is exact."""
+    import itertools
+    from oracle import manisdp_ref as R
+    cl, n = P.chain_cliques(3, 4)
+    mons = P.bqp_sparse_monomials(cl)
+    coe = np.random.default_rng(1).standard_normal(len(mons))
+    At, b, c, K = P.bqpmom_sparse(n, cl, coe)
+    best = min(sum(cv * np.prod([x[a] for a in mon]) for mon, cv in zip(mons, coe)) for x in itertools.product([-1.0, 1.0], repeat=n))
+    Y, obj, d = R.ManiSDP_multiblock(At, b, c, K, {"tol": 1e-8, "line_search": 1, "tau1": 1})
+    assert d["status"] == 0 and max(d["gap"], d["pinf"], d["dinf"]) < 1e-8
+    assert abs(obj - best) <= 1e-7 * abs(best)
