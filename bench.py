@@ -232,6 +232,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def join(hh):                                   # a fresh communicator over the same ranks for a fresh handle
+        ident = [_lib.Handle.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        hh.comm_init(N, rank, ident[0])
+
+    def allmax(x):
+        import torch
+        tt = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     for _ in range(args.warmup):
         step()
     sync()
@@ -422,7 +433,7 @@ def main():
             # Results are bit-identical (tests/test_gpu_local_ranks.py); the all-gather figure above was taken first and
             # stays in the line, so a failure of this leg costs nothing.
             try:
-                hl = halo_leg(_lib, dist, N, rank, C, Y0, p, opts, args)
+                hl = halo_leg(_lib, join, sync, allmax, N, rank, C, Y0, p, opts, args.steps, args.warmup)
                 out["row_exchange"] = {"all_gather": {"value": out["value"], "ms_per_step": out["ms_per_step"]}, "halo": hl}
                 if hl["hessvecs"] == hv and hl["value"] > out["value"]:
                     out["value"], out["ms_per_step"] = hl["value"], hl["ms_per_step"]
@@ -434,7 +445,7 @@ def main():
                 out["config"]["row_exchange"] = "all-gather"
         if not args.no_dense:
             try:
-                out["k5_dense_sharded"] = k5_dense_sharded(_lib, dist, N, rank)
+                out["k5_dense_sharded"] = k5_dense_sharded(_lib, join, sync, allmax, N, rank)
             except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline line
                 out["k5_dense_sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
         dist.barrier()
@@ -446,45 +457,37 @@ def main():
         result_out.flush()
 
 
-def halo_leg(_lib, dist, N, rank, C, Y0, p, opts, args):
-    """The timed region of main() once more on a fresh handle with the halo exchange in front of S*U."""
-    import torch
-    uid = [_lib.Handle.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
+def halo_leg(_lib, join, sync, allmax, N, rank, C, Y0, p, opts, steps, warmup):
+    """The timed region of main() once more on a fresh handle with the halo exchange in front of S*U.  `join(h)` makes the handle
+    a member of the job's communicator, `sync()` is the barrier + device synchronisation of main(), `allmax(x)` the maximum
+    of x over the ranks (closures, so that tests can drive this on in-process ranks)."""
     h = _lib.Handle.onlyunitdiag(C, pcap=p)
-    h.comm_init(N, rank, uid[0])
+    join(h)
     h.set_option("halo_exchange", 1)
     h.set_point(Y0)
     h.point_snapshot()
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         h.point_restore()
         h.rtr(opts)
-    dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     hv = 0
-    for _ in range(args.steps):
+    for _ in range(steps):
         h.point_restore()
         hv += h.rtr(opts).hessvecs
-    dist.barrier()
-    torch.cuda.synchronize()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    sync()
+    dt = allmax(time.perf_counter() - t0)
     h.close()
-    return {"value": hv * N / dt, "ms_per_step": dt / args.steps * 1e3, "hessvecs": hv}
+    return {"value": hv * N / dt, "ms_per_step": dt / steps * 1e3, "hessvecs": hv}
 
 
-def k5_dense_sharded(_lib, dist, N, rank, rows_per_gpu=12500, p=64):
+def k5_dense_sharded(_lib, join, sync, allmax, N, rank, rows_per_gpu=12500, p=64):
     """One short RTR call (6 TR iterations, at most 8 inner trips each) on the row-sharded dense-C problem; every rank fills its
     own rows on the device.  Reports the time per S*X product (Hess-vecs + cost/gradient evaluations) and the
-    aggregate fp64 rate 2 n^2 p per product."""
-    import torch
+    aggregate fp64 rate 2 n^2 p per product.  join / sync / allmax: see halo_leg."""
     n = rows_per_gpu * N
-    uid = [_lib.Handle.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
     h = _lib.Handle.dense_synthetic(n, 0, nranks=N, rank=rank, pcap=p)
-    h.comm_init(N, rank, uid[0])
+    join(h)
     rng = np.random.default_rng(0)
     Y = rng.standard_normal((n, p))
     Y /= np.linalg.norm(Y, axis=1, keepdims=True)
@@ -494,16 +497,14 @@ def k5_dense_sharded(_lib, dist, N, rank, rows_per_gpu=12500, p=64):
     best = None
     for _ in range(3):
         h.point_restore()
-        dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         st = h.rtr(opts)
-        torch.cuda.synchronize()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        sync()
+        dt = allmax(time.perf_counter() - t0)
         products = st.hessvecs + st.iters + 1
-        if best is None or dt.item() < best[0]:
-            best = (dt.item(), products, st.hessvecs)
+        if best is None or dt < best[0]:
+            best = (dt, products, st.hessvecs)
     h.close()
     sec, products, hv = best
     return {"workload": "synthetic dense-C unit-diag SDP, n=%d, p=%d, rows sharded over %d GPUs (BASELINE config 5 at N=8)" % (n, p, N),

@@ -390,3 +390,49 @@ def test_whole_solve_dense_synthetic_on_ranks(N):
         assert q[1] == 0 and q[2] < 1e-8 and abs(q[0] - obj_o) <= 1e-7 * abs(obj_o)
         assert np.allclose(np.linalg.norm(q[3], axis=1), 1.0, atol=1e-12)
         assert q[0] == res[0][0] and np.array_equal(q[3], res[0][3])
+
+
+@pytest.mark.parametrize("N", [2, 4])
+def test_bench_multi_rank_legs_on_in_process_ranks(N):
+    """bench.py's two extra legs of a --gpus N run -- the K steps once more with the halo exchange, the row-sharded dense
+    config-5 shape -- with the communicator, the barrier and the max-over-ranks replaced by their in-process stand-ins."""
+    import bench
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    C = problems.toroidal_grid_maxcut(20 * N, 50, seed=81)
+    n, p = C.shape[0], 16
+    rng = np.random.default_rng(0)
+    Y0 = rng.standard_normal((n, p)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    opts = _lib.default_opts(maxiter=10, maxinner=30, tolgradnorm=1e-8)
+    bar = threading.Barrier(N)
+    box = [0.0] * N
+
+    def one_rank(r, group):
+        serial = [0]
+
+        def join(h):
+            serial[0] += 1
+            h.comm_init_local(N, r, group * 10 + serial[0])
+
+        def allmax(x):
+            box[r] = x
+            bar.wait()
+            m = max(box)
+            bar.wait()
+            return m
+
+        hl = bench.halo_leg(_lib, join, bar.wait, allmax, N, r, C, Y0, p, opts, 2, 1)
+        k5 = bench.k5_dense_sharded(_lib, join, bar.wait, allmax, N, r, rows_per_gpu=300, p=16)
+        return hl, k5
+
+    res = run_ranks(N, one_rank)
+    h = _lib.Handle.onlyunitdiag(C, pcap=p)
+    h.set_option("persist", 0)
+    h.set_point(Y0); h.point_snapshot()
+    hv = 0
+    for _ in range(2):
+        h.point_restore(); hv += h.rtr(opts).hessvecs
+    h.close()
+    for hl, k5 in res:
+        assert hl["hessvecs"] == hv and hl["value"] > 0 and hl == res[0][0]
+        assert k5["n"] == 300 * N and k5["S_times_X_products"] > 0 and k5["aggregate_TFLOPs_f64"] > 0 and k5 == res[0][1]
