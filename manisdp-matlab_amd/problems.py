@@ -600,6 +600,91 @@ def bqpmom_sparse(n, cliques, coe):
     return At, b, c, {"s": mb, "nob": t}
 
 
+def quartic_sparse_monomials(cliques):
+    """All monomials of degree <= 4 whose variables lie in one clique, as sorted tuples (() = the constant), in lexicographic
+    order: the support of the sparse quartic of example/example_qsphere_sparse.m:11-16."""
+    import itertools
+    mons = set()
+    for I in cliques:
+        for d in range(5):
+            mons.update(itertools.combinations_with_replacement(I, d))
+    return sorted(mons)
+
+
+def qsmom_sparse(n, cliques, coe):
+    """Second-order moment relaxation of a quartic with correlative sparsity whose clique sub-vectors all lie on unit spheres
+    (``|x_{I_k}| = 1`` for every k), one PSD block per clique, for ``ManiSDP_multiblock`` with ``K['nob'] = 0`` (what
+    src/basicfunction/qsmom_sparse.m:6-121 builds; written from the definition):
+
+    * block k is the moment matrix of all monomials of degree <= 2 in ``x_{I_k}`` (``[1, x_a, x_a x_b (a <= b, ordered by b)]``);
+    * constraints: ``L(1) = 1``; for every clique k and basis monomial m of its block ``sum_a L(x_a^2 m) - L(m) = 0`` (a over
+      ``I_k``; every ``L`` the average of all entries that carry the monomial); all entries carrying one monomial are equal;
+    * ``coe`` gives the coefficients of ``quartic_sparse_monomials(cliques)`` (constant included), each spread evenly over the
+      entries that carry its monomial.
+
+    Returns ``At, b, c, K``; the moments of every point with ``|x_{I_k}| = 1`` for all k satisfy ``At' x = b`` and give
+    ``c' x = f(x)`` (tests/test_problems.py)."""
+    t = len(cliques)
+    bases = []
+    for I in cliques:
+        bs = [()] + [(a,) for a in I]
+        for jb in range(len(I)):
+            for ia in range(jb + 1):
+                bs.append((I[ia], I[jb]))
+        bases.append(bs)
+    mb = [len(bs) for bs in bases]
+    off = np.concatenate([[0], np.cumsum([v * v for v in mb])]).astype(np.int64)
+
+    def entry(k, i, j):
+        return int(off[k] + j * mb[k] + i)
+
+    where = {}
+    for k, bs in enumerate(bases):
+        for i in range(mb[k]):
+            for j in range(i, mb[k]):
+                where.setdefault(tuple(sorted(bs[i] + bs[j])), []).append((i, j, k))
+
+    def spots(mon):                                        # every entry carrying the monomial (diagonal ones once)
+        out = []
+        for (i, j, k) in where[mon]:
+            out += [entry(k, i, i)] if i == j else [entry(k, i, j), entry(k, j, i)]
+        return out
+
+    rows, cols, vals = [entry(0, 0, 0)], [0], [1.0]
+    m = 1
+    for k, I in enumerate(cliques):                         # (|x_I|^2 - 1) m = 0
+        for i in range(mb[k]):
+            for a in I:
+                hi = spots(tuple(sorted(bases[k][i] + (a, a))))
+                rows += hi; cols += [m] * len(hi); vals += [1.0 / len(hi)] * len(hi)
+            lo = spots(bases[k][i])
+            rows += lo; cols += [m] * len(lo); vals += [-1.0 / len(lo)] * len(lo)
+            m += 1
+    for mon in sorted(where):                               # one value per monomial
+        lst = where[mon]
+        ref = max(range(len(lst)), key=lambda q: (lst[q][0], -q))
+        for q, (i, j, k) in enumerate(lst):
+            if q == ref:
+                continue
+            for (ii, jj, kk), sgn in ((lst[ref], 1.0), ((i, j, k), -1.0)):
+                if ii == jj:
+                    rows.append(entry(kk, ii, ii)); cols.append(m); vals.append(sgn)
+                else:
+                    rows += [entry(kk, ii, jj), entry(kk, jj, ii)]; cols += [m, m]; vals += [0.5 * sgn, 0.5 * sgn]
+            m += 1
+    At = sp.csc_matrix((vals, (rows, cols)), shape=(int(off[-1]), m))
+    b = np.zeros(m); b[0] = 1.0
+    c = np.zeros(int(off[-1]))
+    mons = quartic_sparse_monomials(cliques)
+    coe = np.asarray(coe, dtype=np.float64).ravel()
+    if coe.size != len(mons):
+        raise ValueError("qsmom_sparse: %d coefficients for %d monomials" % (coe.size, len(mons)))
+    for mon, v in zip(mons, coe):
+        lo = spots(mon)
+        c[lo] += v / len(lo)
+    return At, b, c, {"s": mb, "nob": 0}
+
+
 def matrix_completion(p, q, k, m=None, seed=3):
     """Nuclear-norm matrix completion as an SDP for the generic ``ManiSDP`` (reference example/example_matrixcompletion.m:8-41):
     ``M = randn(p,k) randn(k,q)``, ``m`` sampled positions (default ``400 (p+q)`` draws with replacement, duplicates removed,

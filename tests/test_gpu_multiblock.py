@@ -194,3 +194,20 @@ def test_multiblock_sparse_bqp_matches_oracle(lib, t, q):
     else:
         rng = np.random.default_rng(2)
         assert all(obj <= f(rng.choice([-1.0, 1.0], n)) + 1e-7 for _ in range(50))
+
+
+@pytest.mark.parametrize("opts", [{"tol": 1e-8}, {"tol": 1e-4, "theta": 1e-4, "tau1": 1e-3, "tau2": 1e-2, "line_search": 0, "alpha": 0.01}])
+def test_multiblock_sparse_quartic_matches_oracle(lib, opts):
+    """Sparse quartic on clique spheres (example_qsphere_sparse.m, qsmom_sparse.m): K.nob = 0, every block on the Euclidean
+    factor of the product manifold.  Defaults to KKT 1e-8, and the example's own options (:25-31, tol 1e-4)."""
+    from manisdp_matlab_amd import problems as P, solvers
+    from oracle import manisdp_ref as R
+    cl, n = P.chain_cliques(4, 5)
+    mons = P.quartic_sparse_monomials(cl)
+    coe = np.random.default_rng(1).standard_normal(len(mons))
+    At, b, c, K = P.qsmom_sparse(n, cl, coe)
+    Y, obj, d = solvers.ManiSDP_multiblock(At, b, c, K, dict(opts), verbose=False)
+    Yr, objr, dr = R.ManiSDP_multiblock(At, b, c, K, dict(opts))
+    assert d["status"] == 0 and dr["status"] == 0
+    assert max(d["gap"], d["pinf"], d["dinf"]) < opts["tol"]
+    assert abs(obj - objr) <= 10 * opts["tol"] * max(1.0, abs(objr))

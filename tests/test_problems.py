@@ -154,3 +154,56 @@ def test_bqpmom_sparse_relaxation_is_tight_on_a_small_chain():
     Y, obj, d = R.ManiSDP_multiblock(At, b, c, K, {"tol": 1e-8, "line_search": 1, "tau1": 1})
     assert d["status"] == 0 and max(d["gap"], d["pinf"], d["dinf"]) < 1e-8
     assert abs(obj - best) <= 1e-7 * abs(best)
+
+
+def _chain_sphere_point(cliques, n, rng):
+    """A point whose every clique sub-vector has unit norm (the feasible set of the sparse quartic problem)."""
+    x = np.zeros(n); done = set()
+    for I in cliques:
+        free = [a for a in I if a not in done]
+        s = sum(x[a] ** 2 for a in I if a in done)
+        v = rng.standard_normal(len(free)); v *= np.sqrt(max(1.0 - s, 0.0)) / np.linalg.norm(v)
+        x[free] = v
+        done.update(I)
+    return x
+
+
+@pytest.mark.parametrize("t,q", [(1, 3), (2, 4), (3, 4), (3, 5)])
+def test_qsmom_sparse_structure(t, q):
+    """Sparse second-order moment relaxation of a quartic on clique spheres (qsmom_sparse.m): block sizes, the reference's
+    constraint count (qsmom_sparse.m:29), validity on feasible points."""
+    cl, n = P.chain_cliques(t, q)
+    mons = P.quartic_sparse_monomials(cl)
+    rng = np.random.default_rng(10 * t + q)
+    coe = rng.standard_normal(len(mons))
+    At, b, c, K = P.qsmom_sparse(n, cl, coe)
+    mb = np.array(K["s"])
+    assert K["nob"] == 0 and (mb == (q + 2) * (q + 1) // 2).all()
+    assert At.shape == (int(np.sum(mb * mb)), int(np.sum(mb * (mb + 1) // 2) - len(mons) + np.sum(mb) + 1))
+    for _ in range(3):
+        x = _chain_sphere_point(cl, n, rng)
+        assert all(abs(np.linalg.norm(x[I]) - 1.0) < 1e-12 for I in cl)
+        vec = []
+        for I in cl:
+            v = [1.0] + [x[a] for a in I]
+            for jb in range(len(I)):
+                for ia in range(jb + 1):
+                    v.append(x[I[ia]] * x[I[jb]])
+            v = np.array(v)
+            vec.append(np.outer(v, v).ravel(order="F"))
+        X = np.concatenate(vec)
+        f = sum(cv * np.prod([x[a] for a in mon]) for mon, cv in zip(mons, coe))
+        assert np.abs(At.T @ X - b).max() < 1e-14 and abs(c @ X - f) < 1e-12
+
+
+def test_qsmom_sparse_oracle_solve_is_a_lower_bound():
+    from oracle import manisdp_ref as R
+    cl, n = P.chain_cliques(3, 4)
+    mons = P.quartic_sparse_monomials(cl)
+    coe = np.random.default_rng(1).standard_normal(len(mons))
+    At, b, c, K = P.qsmom_sparse(n, cl, coe)
+    Y, obj, d = R.ManiSDP_multiblock(At, b, c, K, {"tol": 1e-8})
+    assert d["status"] == 0 and max(d["gap"], d["pinf"], d["dinf"]) < 1e-8
+    rng = np.random.default_rng(3)
+    f = lambda x: sum(cv * np.prod([x[a] for a in mon]) for mon, cv in zip(mons, coe))      # noqa: E731
+    assert all(obj <= f(_chain_sphere_point(cl, n, rng)) + 1e-8 for _ in range(200))
