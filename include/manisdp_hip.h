@@ -327,6 +327,8 @@ int msdp_get_dual_slack(msdp_handle h, double* S);
  *   "halo_exchange" 1/0  row-sharded sparse C (after msdp_comm_init*): before S*U every rank receives only the rows of the
  *                       direction its rows of C reference (grouped ncclSend / ncclRecv) instead of all rows (ncclAllGather,
  *                       default 0).  Bit-identical results; msdp_get_point_all and the escape keep the all-gather
+ *   "lanczos_qglobal" 1/0  deflated persistent Lanczos runs read the deflation columns in place instead of from their LDS
+ *                       copy (default 0: in place only where the copy does not fit, n > ~117 000 with 40 columns; bit-identical)
  *   "dense_pack"   1/0  dense C*U reads the MFMA-fragment-ordered copy of C (default 1; 0 = the row-major one;
  *                       bit-identical results, for A/B timing)
  *   "timing", "esc_debug"  1/0  diagnostics on stderr                                (env MSDP_TIMING, MSDP_ESC_DEBUG)

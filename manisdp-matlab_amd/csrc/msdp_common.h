@@ -124,6 +124,7 @@ struct Tuning {
     int escape_deflate = 1;  // escape: deflate span(Y) at near-stationary points (fast, approximate when S*Y != 0)
     int escape_start_y = 0;   // undeflated cold-start runs begin in span(Y) + 5 % noise (the independent lambda_min check sets it)
     int halo_exchange = 0;    // row-sharded sparse C: exchange only the referenced rows before S*U (0: the all-gather north_star prescribes)
+    int lanczos_qglobal = 0;  // tests: deflated persistent Lanczos reads the deflation columns in place even where they fit the LDS
     int lanczos_onesync = 1;  // undeflated persistent Lanczos runs: one grid synchronisation per step (0: two)
     int dense_pack = 1;    // dense C*U reads the fragment-ordered copy of C (0: the row-major one; same results)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)

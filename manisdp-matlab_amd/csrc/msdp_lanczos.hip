@@ -36,6 +36,7 @@ size_t msdp_lanczos_slot_bytes() { return (size_t)LZ_GEN * LZ_GMAX * LZ_NV * siz
 
 struct LzArgs {
     int n, G, nq, m0, m1, RW;             // RW: row capacity of a workgroup (LDS stride of a Q column)
+    int qglobal;                          // 1: the deflation columns do not fit the LDS and are read from Q itself (stride n)
     const int* rp; const int* ci; const double* cv; const double* z;
     const double* Q;                      // nq columns, stride n
     double* V;                            // Lanczos basis, column j at V + j*n
@@ -150,7 +151,7 @@ __device__ __forceinline__ bool lz_sync(__amdgpu_buffer_rsrc_t rs, unsigned gen,
 }
 
 // partial (over my rows) of <col_c, x> for c in [c0, c0+64): thread (c, seg) sums an eighth of the rows
-__device__ __forceinline__ double lz_coldot(const double* cols, int RW, int nrow, int c, int ncol, const double* x) {
+__device__ __forceinline__ double lz_coldot(const double* cols, size_t RW, int nrow, int c, int ncol, const double* x) {
     const int seg = threadIdx.x & 7;
     double acc = 0.0;
     if (c < ncol) {
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(LZ_PB) void k_lanczos_persist(LzArgs a) {
     extern __shared__ double lds[];
     const int nq = a.nq;
     double* Qs = lds;                                   // [nq][RW] deflation columns
-    double* vs = Qs + (size_t)nq * a.RW;                // [RW] v_j
+    double* vs = Qs + (a.qglobal ? (size_t)0 : (size_t)nq * a.RW);   // [RW] v_j
     double* ws = vs + a.RW;                             // [RW] w
     double* vals = ws + a.RW;                           // [LZ_NV]
     double* tot = vals + LZ_NV;                         // [LZ_NV]
@@ -182,8 +183,14 @@ __global__ __launch_bounds__(LZ_PB) void k_lanczos_persist(LzArgs a) {
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a.X, 0, (unsigned)a.n * 8u, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_v0 = __builtin_amdgcn_make_buffer_rsrc(a.V + (size_t)a.m0 * a.n, 0, (unsigned)a.n * 8u, 0x00020000);
 
-    for (int c = 0; c < nq; ++c)
-        for (int t = threadIdx.x; t < nrow; t += LZ_PB) Qs[(size_t)c * a.RW + t] = a.Q[(size_t)c * a.n + lo + t];
+    // deflation columns: the workgroup's rows in LDS, or -- where (nq + 2) rows-per-workgroup doubles exceed it (n > ~117 000
+    // with 40 columns) -- read in place: two passes over this workgroup's rows of Q per step, 2 n nq 8 bytes per step over the
+    // grid, which the Infinity Cache holds (70 MB at n = 160 000, nq = 55)
+    const double* __restrict__ Qc = a.qglobal ? a.Q + lo : (const double*)Qs;
+    const size_t qst = a.qglobal ? (size_t)a.n : (size_t)a.RW;
+    if (!a.qglobal)
+        for (int c = 0; c < nq; ++c)
+            for (int t = threadIdx.x; t < nrow; t += LZ_PB) Qs[(size_t)c * a.RW + t] = a.Q[(size_t)c * a.n + lo + t];
     double v[LZ_RMAX], vp[LZ_RMAX], w[LZ_RMAX], zr[LZ_RMAX];
     int rc[LZ_RMAX][LZ_KREG], cnt[LZ_RMAX], kbeg[LZ_RMAX];
     double rvv[LZ_RMAX][LZ_KREG];
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(LZ_PB) void k_lanczos_persist(LzArgs a) {
     __syncthreads();
     // Q'v_{m0-1} (zero for m0 = 0): one extra reduction per launch
     if (nq > 0) {
-        const double d0 = lz_coldot(Qs, a.RW, nrow, cth, nq, ws);
+        const double d0 = lz_coldot(Qc, qst, nrow, cth, nq, ws);
         if ((threadIdx.x & 7) == 0 && cth < LZ_NV) vals[cth] = d0;
         if (!lz_sync(rs_slots, gen++, a.G, nq, vals, tot, part, flag, a.err)) return;
         if ((int)threadIdx.x < 64) hvp[threadIdx.x] = ((int)threadIdx.x < nq) ? tot[threadIdx.x] : 0.0;
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(LZ_PB) void k_lanczos_persist(LzArgs a) {
             const int seg = threadIdx.x & 7;
             double hw = 0.0, hv = 0.0;
             if (cth < nq) {
-                const double* qc = Qs + (size_t)cth * a.RW;
+                const double* qc = Qc + (size_t)cth * qst;
                 for (int t = seg; t < nrow; t += 8) { const double qv = qc[t]; hw = fma(qv, ws[t], hw); hv = fma(qv, vs[t], hv); }
             }
             hw = msdp_group_sum<8>(hw);
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(LZ_PB) void k_lanczos_persist(LzArgs a) {
             if (t < nrow) {
                 double x = w[r] - alpha * v[r] - beta * vp[r];
                 double dq = 0.0;
-                for (int c = 0; c < nq; ++c) dq = fma(vals[c], Qs[(size_t)c * a.RW + t], dq);
+                for (int c = 0; c < nq; ++c) dq = fma(vals[c], Qc[(size_t)c * qst + t], dq);
                 x -= dq;
                 w[r] = x;
                 nn = fma(x, x, nn);
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(LZ_PB) void k_lanczos_plain(LzArgs a) {
 }
 
 // ---------------------------------------------------------------- host side
-static int lz_grid(int n, int nq, int* RW_out, size_t* lds_out) {
+static int lz_grid(int n, int nq, int* RW_out, size_t* lds_out, int* qglobal_out = nullptr, int force_qglobal = 0) {
     static int cus = -1;
     if (cus < 0) {
         int dev = 0, v = 0;
@@ -498,15 +505,26 @@ static int lz_grid(int n, int nq, int* RW_out, size_t* lds_out) {
     // deflated runs: the per-step LDS work on the rows of Q grows with the rows per workgroup; measured on G81 with
     // nq = 28..43: 64 workgroups 29.5 / 38.1 ms per run, 40: 32.5 / 41.5, 96: 34.5 / 44.6
     const int gfirst = nq > 0 ? 64 : 8;
+    if (qglobal_out) *qglobal_out = 0;
     for (int rows_per_thread = 1; rows_per_thread <= LZ_RMAX; ++rows_per_thread)
         for (int G = gfirst; G <= gmax; G += 8) {
             const int rw = (n + G - 1) / G;
             if (rw > rows_per_thread * LZ_PB) continue;
             const size_t lds = ((size_t)(nq + 2) * rw + 2 * LZ_NV + LZ_PWAVES * LZ_NV + 64 + 8) * sizeof(double);
             if (lds > 150 * 1024) continue;
-            *RW_out = rw; *lds_out = lds;
+            *RW_out = rw;
+            // option lanczos_qglobal (tests): the same grid with the columns read in place
+            if (force_qglobal && nq > 0 && qglobal_out) { *qglobal_out = 1; *lds_out = ((size_t)2 * rw + 2 * LZ_NV + LZ_PWAVES * LZ_NV + 64 + 8) * sizeof(double); }
+            else *lds_out = lds;
             return G;
         }
+    // the deflation columns do not fit the LDS at any grid: read them in place, on all workgroups (their rows of Q stream
+    // from the caches twice per step: the more workgroups, the more bandwidth)
+    if (nq > 0 && qglobal_out && gmax >= 8) {
+        const int rw = (n + gmax - 1) / gmax;
+        const size_t lds = ((size_t)2 * rw + 2 * LZ_NV + LZ_PWAVES * LZ_NV + 64 + 8) * sizeof(double);
+        if (rw <= LZ_RMAX * LZ_PB && lds <= 150 * 1024) { *RW_out = rw; *lds_out = lds; *qglobal_out = 1; return gmax; }
+    }
     return 0;
 }
 
@@ -515,7 +533,8 @@ int msdp_lanczos_persist_ok(msdp_handle h, int nq) {
     if (!h->tune.persist || h->persist_failed || h->nranks != 1 || h->use_comm || h->d.costkind != COST_SPARSE || !h->d.rowptr) return 0;
     if (2 * nq + 1 > LZ_NV || h->d.n < 64) return 0;
     int rw; size_t lds;
-    const int G = lz_grid(h->d.n, nq, &rw, &lds);
+    int qg;
+    const int G = lz_grid(h->d.n, nq, &rw, &lds, &qg, h->tune.lanczos_qglobal);
     if (G <= 0) return 0;
     static int attr_ok = -1;
     if (attr_ok < 0) {
@@ -531,7 +550,7 @@ int msdp_lanczos_persist_run(msdp_handle h, const double* z, const double* Q, in
     LzArgs a;
     a.n = h->d.n; a.nq = nq; a.m0 = m0; a.m1 = m1;
     size_t lds;
-    a.G = lz_grid(a.n, nq, &a.RW, &lds);
+    a.G = lz_grid(a.n, nq, &a.RW, &lds, &a.qglobal, h->tune.lanczos_qglobal);
     if (a.G <= 0) { msdp_set_error("persistent Lanczos: not eligible"); return MSDP_ESTATE; }
     a.rp = h->d.rowptr; a.ci = h->d.colind; a.cv = h->d.cval; a.z = z;
     a.Q = Q; a.V = V; a.X = X; a.dalpha = dalpha; a.dbeta = dbeta; a.slots = slots; a.err = err;

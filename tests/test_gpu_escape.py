@@ -119,3 +119,33 @@ def test_onesync_lanczos_matches_twosync_kernel(lib):
         assert abs(lmax - w[-1]) <= 1e-6 * abs(w[-1])
         assert np.linalg.norm(S @ v - lam0 * v) <= 1e-6 * abs(w[-1])
     assert abs(out[0][0] - out[1][0]) <= 1e-9 * abs(w[-1])
+
+
+def test_deflation_columns_read_in_place_are_bit_identical(lib):
+    """Deflated persistent Lanczos runs with the deflation columns read from Q itself (what n > ~117 000 falls back to when the
+    LDS copy does not fit; option lanczos_qglobal forces it on the same grid) against the LDS copy: same arithmetic, same bits.
+    Four pairs at a random point (every accepted vector joins the deflation set) and the span(Y)-deflated run at a
+    stationary point."""
+    from manisdp_matlab_amd import problems
+    C = problems.toroidal_grid_maxcut(60, 100, seed=9)
+    n, p = C.shape[0], 8
+    rng = np.random.default_rng(4)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    out = []
+    for inplace in (0, 1):
+        h = lib.Handle.onlyunitdiag(C)
+        h.set_option("lanczos_qglobal", inplace)
+        h.set_option("escape_warm", 0)
+        h.set_point(Y)
+        lam, V, lmax, steps = h.escape_eigs(4, tol=1e-10, maxit=20000)
+        for _ in range(12):                                  # near-stationary: span(Y) is deflated (|grad| <= 1e-6 |f|)
+            st = h.rtr(lib.default_opts(maxiter=100, maxinner=400, tolgradnorm=1e-9))
+            if st.gradnorm < 1e-3:
+                break
+        lam2, V2, lmax2, steps2 = h.escape_eigs(2, tol=1e-10, maxit=20000)
+        out.append((lam, V, lmax, steps, lam2, V2, lmax2, steps2, st.gradnorm))
+        h.close()
+    a, b = out
+    assert a[8] < 1e-3                                       # the second call did deflate span(Y)
+    for x, y in zip(a, b):
+        assert np.array_equal(np.asarray(x), np.asarray(y))

@@ -1,0 +1,19 @@
+"""The weak-scaled G81 family of bench.py --gpus N (toroidal 100N x 200 grid, +-1 weights) solved to KKT 1e-8 on ONE GPU:
+ManiSDP_onlyunitdiag with options.p0 = 40 (example_maxcut.m:32).  usage: python tools/g81_family_solve.py [N ...]"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.getcwd())
+from manisdp_matlab_amd import _lib, problems, solvers
+_lib.load()
+for N in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+    C = problems.toroidal_grid_maxcut(100 * N, 200, seed=81)
+    best = None
+    for rep in range(2 if N < 8 else 1):
+        t0 = time.time()
+        Y, obj, d = solvers.ManiSDP_onlyunitdiag(C, {"p0": 40}, verbose=False)
+        dt = time.time() - t0
+        if best is None or dt < best[0]:
+            best = (dt, obj, d)
+    dt, obj, d = best
+    print(json.dumps({"n": C.shape[0], "seconds": dt, "obj": obj, "dinf": d["dinf"], "status": d["status"], "AL_iters": d["iters"], "hessvecs": d["hessvecs"],
+                      "rtr_seconds": d["rtr_seconds"], "escape_seconds": d["eig_seconds"], "p_final": int(Y.shape[1])}), flush=True)
