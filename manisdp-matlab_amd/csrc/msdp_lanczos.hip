@@ -161,11 +161,13 @@ __device__ __forceinline__ double lz_coldot(const double* cols, size_t RW, int n
     return msdp_group_sum<8>(acc);
 }
 
+// QG: the deflation columns are read in place (a.qglobal); a template parameter so that the LDS form keeps its ds_read accesses
+template <bool QG>
 __global__ __launch_bounds__(LZ_PB) void k_lanczos_persist(LzArgs a) {
     extern __shared__ double lds[];
     const int nq = a.nq;
     double* Qs = lds;                                   // [nq][RW] deflation columns
-    double* vs = Qs + (a.qglobal ? (size_t)0 : (size_t)nq * a.RW);   // [RW] v_j
+    double* vs = Qs + (QG ? (size_t)0 : (size_t)nq * a.RW);   // [RW] v_j
     double* ws = vs + a.RW;                             // [RW] w
     double* vals = ws + a.RW;                           // [LZ_NV]
     double* tot = vals + LZ_NV;                         // [LZ_NV]
@@ -186,9 +188,9 @@ __global__ __launch_bounds__(LZ_PB) void k_lanczos_persist(LzArgs a) {
     // deflation columns: the workgroup's rows in LDS, or -- where (nq + 2) rows-per-workgroup doubles exceed it (n > ~117 000
     // with 40 columns) -- read in place: two passes over this workgroup's rows of Q per step, 2 n nq 8 bytes per step over the
     // grid, which the Infinity Cache holds (70 MB at n = 160 000, nq = 55)
-    const double* __restrict__ Qc = a.qglobal ? a.Q + lo : (const double*)Qs;
-    const size_t qst = a.qglobal ? (size_t)a.n : (size_t)a.RW;
-    if (!a.qglobal)
+    const double* __restrict__ Qc = QG ? a.Q + lo : (const double*)Qs;
+    const size_t qst = QG ? (size_t)a.n : (size_t)a.RW;
+    if (!QG)
         for (int c = 0; c < nq; ++c)
             for (int t = threadIdx.x; t < nrow; t += LZ_PB) Qs[(size_t)c * a.RW + t] = a.Q[(size_t)c * a.n + lo + t];
     double v[LZ_RMAX], vp[LZ_RMAX], w[LZ_RMAX], zr[LZ_RMAX];
@@ -538,7 +540,8 @@ int msdp_lanczos_persist_ok(msdp_handle h, int nq) {
     if (G <= 0) return 0;
     static int attr_ok = -1;
     if (attr_ok < 0) {
-        attr_ok = hipFuncSetAttribute((const void*)k_lanczos_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess ? 1 : 0;
+        attr_ok = (hipFuncSetAttribute((const void*)k_lanczos_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)k_lanczos_persist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess) ? 1 : 0;
         (void)hipGetLastError();
     }
     return attr_ok;
@@ -561,7 +564,8 @@ int msdp_lanczos_persist_run(msdp_handle h, const double* z, const double* Q, in
         HIPCHK(hipGetLastError());
         return 0;
     }
-    hipLaunchKernelGGL(k_lanczos_persist, dim3(a.G), dim3(LZ_PB), lds, h->stream, a);
+    if (a.qglobal) hipLaunchKernelGGL(k_lanczos_persist<true>, dim3(a.G), dim3(LZ_PB), lds, h->stream, a);
+    else hipLaunchKernelGGL(k_lanczos_persist<false>, dim3(a.G), dim3(LZ_PB), lds, h->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
