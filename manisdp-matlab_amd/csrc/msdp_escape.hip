@@ -742,8 +742,19 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     // Without re-orthogonalisation the process may need more than n steps for the extreme pairs (ghost copies use
     // up steps); small matrices are cheap, so allow 4 n there
     if (maxit > 4 * n) maxit = 4 * n;
-    // keep the stored Lanczos basis below ~24 GB
-    const int64_t cap = (int64_t)(24.0e9 / 8.0 / n);
+    // keep the stored Lanczos basis below ~24 GB, or below half of what the device has free where that is more (288 GB of
+    // HBM: at n = 80 000 the 24-GB bound would end the independent lambda_min run after 37 500 steps, unconverged)
+    double basis_bytes = 24.0e9;
+    {
+        size_t freeb = 0, totb = 0;
+        if (hipMemGetInfo(&freeb, &totb) == hipSuccess) {
+            size_t parked = 0;
+            { std::lock_guard<std::mutex> lk(g_ws_mutex); parked = g_ws_cap * sizeof(double); }
+            const double avail = (double)freeb + (double)h->esc_cap * sizeof(double) + (double)parked;    // what this call could hold
+            if (0.5 * avail > basis_bytes) basis_bytes = 0.5 * avail;
+        } else (void)hipGetLastError();
+    }
+    const int64_t cap = (int64_t)(basis_bytes / 8.0 / n);
     if (maxit > cap) maxit = (int)std::max<int64_t>(64, cap);
     const int cur = h->h_ctl->cur;
     EscCtx c;
