@@ -207,3 +207,30 @@ def test_qsmom_sparse_oracle_solve_is_a_lower_bound():
     rng = np.random.default_rng(3)
     f = lambda x: sum(cv * np.prod([x[a] for a in mon]) for mon, cv in zip(mons, coe))      # noqa: E731
     assert all(obj <= f(_chain_sphere_point(cl, n, rng)) + 1e-8 for _ in range(200))
+
+
+def test_synthetic_dense_generator_matches_the_library_host_function():
+    """problems.SyntheticDenseC (NumPy) against msdp_synthetic_dense_entry, the host twin of the generator every rank runs on
+    the device for its rows of BASELINE config 5's matrix (a pure host function: callable without a GPU)."""
+    import ctypes
+    import os
+    from manisdp_matlab_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.msdp_synthetic_dense_entry.restype = ctypes.c_double
+    lib.msdp_synthetic_dense_entry.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64]
+    for n, seed in ((37, 0), (1000, 5), (100000, 0)):
+        Cs = P.SyntheticDenseC(n, seed)
+        rows = [0, 1, n // 3, n - 1]
+        R = Cs.rows(rows)
+        for q, i in enumerate(rows):
+            for j in (0, 1, i, n // 2, n - 1):
+                assert R[q, j] == lib.msdp_synthetic_dense_entry(n, i, j, seed)
+                assert R[q, j] == lib.msdp_synthetic_dense_entry(n, j, i, seed)              # symmetric
+        assert np.abs(R).max() <= 1.0 / np.sqrt(n)
+    A = P.SyntheticDenseC(50, 2).toarray()
+    assert np.array_equal(A, A.T)
+    with pytest.raises(ValueError):
+        P.SyntheticDenseC(30000).toarray()
