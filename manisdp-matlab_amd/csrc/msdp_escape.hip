@@ -30,9 +30,10 @@ int msdp_allgather_rows(msdp_handle h, const double* local_rows);          // ms
 int msdp_allgather_vec(msdp_handle h, const double* local, double* all, size_t count_per_rank);
 // msdp_lanczos.hip: persistent kernel for the recurrence (sparse C, single rank)
 size_t msdp_lanczos_slot_bytes();
-int msdp_lanczos_persist_ok(msdp_handle h, int nq);
+int msdp_lanczos_persist_ok(msdp_handle h, int nq, const int* full_csr);
 int msdp_lanczos_persist_run(msdp_handle h, const double* z, const double* Q, int nq, double* V, double* X, double* dalpha,
-                             double* dbeta, unsigned long long* slots, int* err, int m0, int m1);
+                             double* dbeta, unsigned long long* slots, int* err, int m0, int m1,
+                             const int* rp, const int* ci, const double* cv);
 
 // ---------------------------------------------------------------- kernels
 // w = S*v for S = C - diag(z), sparse C (one thread per row; rows are short)
@@ -384,6 +385,7 @@ struct EscCtx {
     const double* Ypt = nullptr;    // all rows of the resident point (n x ld), for the escape_start_y start vector
     int ld = 0, p = 0;
     const int* rp = nullptr; const int* ci = nullptr; const double* cv = nullptr;   // CSR of C (all rows)
+    bool replicated_csr = false;    // rp/ci/cv are this rank's full copy of a row-sharded C (the handle's own CSR holds its rows only)
     // pre-sharded dense C: this rank multiplies ITS rows (w_loc), the ranks all-gather the pieces (w_all: nranks*cap), and
     // every rank continues the same recurrence on the same full-length vectors
     double* w_loc = nullptr; double* w_all = nullptr; int cap = 0;
@@ -474,7 +476,7 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
     int m = 0, next_check = 32;
     double theta = 0.0, res = 1e300, lmax = 0.0;
     bool converged = false;          // one of the three stop tests passed (else the run ended at maxit: theta is only an upper bound)
-    const bool persist = !c.M && c.slots && msdp_lanczos_persist_ok(h, nq);
+    const bool persist = !c.M && !c.w_loc && c.slots && msdp_lanczos_persist_ok(h, nq, c.replicated_csr ? c.rp : nullptr);
     const bool fused_small = !persist && n <= LZS_MAXN;
     if (fused_small) {
         static bool attr_set = false;
@@ -488,7 +490,7 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
         if (persist) {
             // all steps up to the next checkpoint in one launch (msdp_lanczos.hip)
             const int m1 = std::min(next_check, maxit);
-            if ((rc = msdp_lanczos_persist_run(h, c.z, Q, nq, V, c.X, dalpha, dbeta, c.slots, c.err, m, m1))) return rc;
+            if ((rc = msdp_lanczos_persist_run(h, c.z, Q, nq, V, c.X, dalpha, dbeta, c.slots, c.err, m, m1, c.rp, c.ci, c.cv))) return rc;
             m = m1;
         } else {
         double* vj = V + (size_t)m * n;
@@ -702,7 +704,8 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     // rows of the point (yfull, refreshed by msdp_al_dual) and finds the same vectors; S = C - diag(z) is not sharded yet
     const bool rep_rows = (h->nranks != 1 || h->use_comm) && Mdev && h->yfull[h->h_ctl->cur];
     // Row-sharded onlyunitdiag with sparse C: replicated as well -- every rank keeps a full copy of C's CSR arrays for this
-    // purpose (1.2 MB for G81), gathers z and the rows of Y, and runs the same Lanczos recurrence on the multi-kernel path
+    // purpose (1.2 MB for G81), gathers z and the rows of Y, and runs the same Lanczos recurrence -- a single-GPU computation
+    // on every rank, so the persistent kernels of msdp_lanczos.hip apply with the replicated CSR in place of the handle's own
     // (a Lanczos process with sharded vectors and an all-gather per step is the follow-up)
     // (taken with ANY communicator, also of size 1, so that one GPU exercises the gathers and the replicated copy)
     const bool rep_sparse = h->use_comm && !Mdev && d.costkind == COST_SPARSE && !h->h_rowptr.empty();
@@ -761,6 +764,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     c.h = h; c.n = n; c.z = Mdev ? nullptr : ((rep_sparse || shard_dense) ? (const double*)h->esc_z : (const double*)d.eG[cur]); c.M = Mdev;
     if (shard_dense) { c.cap = (int)shard_cap; c.w_loc = h->esc_z + shard_cap * h->nranks; c.w_all = c.w_loc + shard_cap; }
     c.rp = rep_sparse ? h->esc_rp : d.rowptr; c.ci = rep_sparse ? h->esc_ci : d.colind; c.cv = rep_sparse ? h->esc_cv : d.cval;
+    c.replicated_csr = rep_sparse;
     c.Ypt = (rep_sparse || shard_dense) ? (const double*)h->full_buf
                        : (((h->nranks != 1 || h->use_comm) && h->yfull[cur]) ? (const double*)h->yfull[cur] : (const double*)d.Y[cur]);
     c.ld = d.ld; c.p = d.p;

@@ -531,8 +531,12 @@ static int lz_grid(int n, int nq, int* RW_out, size_t* lds_out, int* qglobal_out
 }
 
 // 1 when the persistent kernel can run the recurrence for this problem (sparse C, single rank, everything fits)
-int msdp_lanczos_persist_ok(msdp_handle h, int nq) {
-    if (!h->tune.persist || h->persist_failed || h->nranks != 1 || h->use_comm || h->d.costkind != COST_SPARSE || !h->d.rowptr) return 0;
+// full_csr: the caller holds ALL rows of C (the replicated escape of a row-sharded handle, msdp_escape.hip): the recurrence
+// is a single-GPU computation on every rank then and the kernels apply as they are.  Not with the in-process ranks: N handles
+// of one GPU would each need their workgroups co-resident.
+int msdp_lanczos_persist_ok(msdp_handle h, int nq, const int* full_csr) {
+    if (!h->tune.persist || h->persist_failed || h->d.costkind != COST_SPARSE) return 0;
+    if (full_csr ? (h->lgroup != nullptr) : (h->nranks != 1 || h->use_comm || !h->d.rowptr)) return 0;
     if (2 * nq + 1 > LZ_NV || h->d.n < 64) return 0;
     int rw; size_t lds;
     int qg;
@@ -549,13 +553,14 @@ int msdp_lanczos_persist_ok(msdp_handle h, int nq) {
 
 // Steps [m0, m1) of the recurrence; V[:, m0] (and V[:, m0-1], dbeta[m0] when m0 > 0) must be in place.
 int msdp_lanczos_persist_run(msdp_handle h, const double* z, const double* Q, int nq, double* V, double* X, double* dalpha,
-                             double* dbeta, unsigned long long* slots, int* err, int m0, int m1) {
+                             double* dbeta, unsigned long long* slots, int* err, int m0, int m1,
+                             const int* rp, const int* ci, const double* cv) {
     LzArgs a;
     a.n = h->d.n; a.nq = nq; a.m0 = m0; a.m1 = m1;
     size_t lds;
     a.G = lz_grid(a.n, nq, &a.RW, &lds, &a.qglobal, h->tune.lanczos_qglobal);
     if (a.G <= 0) { msdp_set_error("persistent Lanczos: not eligible"); return MSDP_ESTATE; }
-    a.rp = h->d.rowptr; a.ci = h->d.colind; a.cv = h->d.cval; a.z = z;
+    a.rp = rp; a.ci = ci; a.cv = cv; a.z = z;             // all n rows of C (the handle's own CSR, or the replicated copy)
     a.Q = Q; a.V = V; a.X = X; a.dalpha = dalpha; a.dbeta = dbeta; a.slots = slots; a.err = err;
     hipLaunchKernelGGL(k_lz_reset, dim3(64), dim3(256), 0, h->stream, slots, err);
     HIPCHK(hipGetLastError());

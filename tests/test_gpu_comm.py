@@ -218,6 +218,35 @@ def test_size1_communicator_onlyunitdiag_solve(monkeypatch):
     assert np.allclose(np.linalg.norm(Yb, axis=1), 1.0, atol=1e-12) and db["z"].shape == (C.shape[0],)
 
 
+def test_size1_communicator_escape_uses_the_persistent_lanczos_kernels():
+    """The replicated escape of a row-sharded sparse handle is a single-GPU computation on every rank: it runs the persistent
+    Lanczos kernels on the replicated CSR copy, and finds bit for bit what the communicator-free handle finds (undeflated
+    and deflated runs, four pairs)."""
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    C = problems.toroidal_grid_maxcut(60, 100, seed=9)
+    n, p = C.shape[0], 8
+    rng = np.random.default_rng(4)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    out = []
+    for use_comm in (False, True):
+        h = _lib.Handle.onlyunitdiag(C)
+        if use_comm:
+            h.comm_init(1, 0, _lib.Handle.comm_unique_id())
+        h.set_option("escape_warm", 0)
+        h.set_point(Y)
+        h.cost()
+        import time
+        t0 = time.perf_counter()
+        lam, V, lmax, steps = h.escape_eigs(4, tol=1e-10, maxit=20000)
+        out.append((lam, V, lmax, steps, time.perf_counter() - t0))
+        h.close()
+    a, b = out
+    for x, y in zip(a[:4], b[:4]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    assert b[4] < 3.0 * a[4] + 0.05          # the multi-kernel path (seven launches per step) is ~10x slower at this size
+
+
 def test_size1_communicator_dense_synthetic_solve():
     """The same for the pre-sharded synthetic dense C (config 5's layout, scaled down): sharded RTR and the escape with the
     sharded product + ncclAllGather of the pieces per Lanczos step, against the communicator-free solve."""
