@@ -311,6 +311,10 @@ int msdp_escape_eigs_dual(msdp_handle h, int32_t k, double tol, int32_t maxit,
 /* The dense S (n x n, symmetric: column-major = row-major) of the last msdp_al_dual call: the reference's
  * data.S (ManiSDP_unitdiag.m:116, ManiSDP_unittrace.m:121) and the input of a host eig(S) for small n. */
 int msdp_get_dual_slack(msdp_handle h, double* S);
+/* The nb x nb diagonal block of the same matrix that starts at row / column row0 (column-major == row-major: symmetric).
+ * ManiSDP_multiblock.m:78-88 takes eig(S_i) block by block: with a hundred blocks the whole N x N matrix is 100 times what
+ * the host reads (N = 21 100 for example_bqp_sparse.m with t = 100: 3.5 GB per outer iteration against 35 MB). */
+int msdp_get_dual_slack_block(msdp_handle h, int64_t row0, int64_t nb, double* S);
 
 /* Run-time switches of one handle (production = the defaults; the tests and the profiling scripts use them):
  *   "persist"      1/0  persistent single-launch tCG / Lanczos kernels where they fit (default 1; env MSDP_NO_PERSIST=1)

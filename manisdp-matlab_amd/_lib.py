@@ -83,6 +83,7 @@ SIGNATURES = {
     "msdp_escape_info": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _dp]),
     "msdp_escape_lower_bound": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_dual_slack": (C.c_int, [C.c_void_p, _dp]),
+    "msdp_get_dual_slack_block": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
     "msdp_release_cache": (C.c_int, []),
     "msdp_comm_init_local": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "msdp_get_point_all": (C.c_int, [C.c_void_p, _dp]),
@@ -458,6 +459,12 @@ class Handle:
         k = C.c_int32()
         _check(self._lib.msdp_get_kind(self._h, C.byref(k)))
         return k.value
+
+    def get_dual_slack_block(self, row0, nb):
+        """The nb x nb diagonal block of S that starts at row0 (multiblock: eig(S_i) block by block)."""
+        S = np.empty((nb, nb))
+        _check(self._lib.msdp_get_dual_slack_block(self._h, int(row0), int(nb), _dptr(S)))
+        return S
 
     def get_dual_slack(self):
         """Dense S (n x n) of the last al_dual call."""

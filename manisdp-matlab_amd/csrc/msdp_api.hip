@@ -1843,6 +1843,18 @@ extern "C" int msdp_get_dual_slack(msdp_handle h, double* S) {
     return 0;
 }
 
+extern "C" int msdp_get_dual_slack_block(msdp_handle h, int64_t row0, int64_t nb, double* S) {
+    CHECK_H(h);
+    if (!S) { msdp_set_error("get_dual_slack_block: null argument"); return MSDP_EINVAL; }
+    if (h->d.costkind != COST_AFFINE || !h->dual_valid) { msdp_set_error("get_dual_slack_block: call msdp_al_dual first"); return MSDP_ESTATE; }
+    const int n = h->d.n, nS = msdp_dense_nS(n);
+    if (row0 < 0 || nb < 1 || row0 + nb > n) { msdp_set_error("get_dual_slack_block: rows %lld..%lld outside 0..%d", (long long)row0, (long long)(row0 + nb), n); return MSDP_EINVAL; }
+    HIPCHK(hipMemcpy2DAsync(S, (size_t)nb * sizeof(double), h->d.Sdual + (size_t)row0 * nS + row0, (size_t)nS * sizeof(double),
+                            (size_t)nb * sizeof(double), (size_t)nb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 // ------------------------------------------------------------------ measurement
 static void algo_cost(msdp_handle h, double* bytes, double* flops) {
     const Dev& d = h->d;

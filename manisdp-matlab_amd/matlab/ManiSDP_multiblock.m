@@ -61,10 +61,9 @@ for iter = 1:opt.AL_maxiter
     y = y - sigma*resid;
     z = manisdp_mex('al_dual', h, y);                       % zero on the blocks without a diagonal constraint
     by = bvec'*y + sum(z);
-    Sjoint = manisdp_mex('get_dual_slack', h);
     S = cell(nb, 1);  lowvec = cell(nb, 1);  nneg = zeros(1, nb);  dinfs = zeros(1, nb);
     for i = 1:nb
-        S{i} = Sjoint(cols{i}, cols{i});
+        S{i} = manisdp_mex('get_dual_slack_block', h, cols{i}(1), numel(cols{i}));   % only the diagonal blocks leave the device
         [V, w] = eig((S{i} + S{i}')/2, 'vector');
         dinfs(i) = max(0, -w(1))/(1 + abs(w(end)));
         nneg(i) = sum(w < 0);  lowvec{i} = V;

@@ -392,6 +392,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         const int rc = msdp_dual_get_y(h, mxGetPr(y));
         if (rc) { mxDestroyArray(y); fail("dual_get_y", rc); }
         plhs[0] = y;
+    } else if (cmd == "get_dual_slack_block") {           // (h, first row (1-based), order): one diagonal block of S
+        need(nrhs == 4, "S_i = manisdp_mex('get_dual_slack_block', h, first_row, order)");
+        const mwSize nb = (mwSize)mxGetScalar(prhs[3]);
+        mxArray* S = mxCreateDoubleMatrix(nb, nb, mxREAL);
+        const int rc = msdp_get_dual_slack_block(h, (int64_t)mxGetScalar(prhs[2]) - 1, (int64_t)nb, mxGetPr(S));
+        if (rc) { mxDestroyArray(S); fail("get_dual_slack_block", rc); }
+        plhs[0] = S;
     } else if (cmd == "get_dual_slack") {
         mxArray* S = mxCreateDoubleMatrix((mwSize)me.n, (mwSize)me.n, mxREAL);
         const int rc = msdp_get_dual_slack(h, mxGetPr(S));

@@ -715,10 +715,9 @@ def _multiblock_impl(At, b, c, K, options, verbose, rng):
             t1 = time.time()
             z = h.al_dual(y)                                # :74-84 on the device: S = cy blocks - diag(z), z = 0 on free rows
             by = float(b @ y) + float(np.sum(z))            # :75,82
-            Sfull = h.get_dual_slack()
             S, vS, dS, dinfs = [], [], [], []
-            for i in range(nb):                             # :78-88
-                Si = Sfull[r0[i]:r0[i + 1], r0[i]:r0[i + 1]]
+            for i in range(nb):                             # :78-88 (only the diagonal blocks come to the host)
+                Si = h.get_dual_slack_block(r0[i], nset[i])
                 w, V = np.linalg.eigh(0.5 * (Si + Si.T))    # :86
                 S.append(Si); dS.append(w); vS.append(V)
                 dinfs.append(max(0.0, -w[0]) / (1.0 + abs(w[-1])))   # :87

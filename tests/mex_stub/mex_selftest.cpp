@@ -218,7 +218,12 @@ int run_affine(const char* in, const char* outp) {
     std::vector<mxArray*> e = call(4, {c_esc, h, kk, tol, mit});
     mxArray* c_S = mxCreateString("get_dual_slack");
     mxArray* S = call(1, {c_S, h})[0];
-    w.put(Y); w.put(pr[1]); w.put(z); w.put(e[0]); w.put(e[1]); w.put(S);
+    // one diagonal block of S (rows 3..n-2, 1-based first row 3): what ManiSDP_multiblock.m reads per block
+    mxArray* c_Sb = mxCreateString("get_dual_slack_block");
+    mxArray* b_r0 = mxCreateDoubleScalar(3.0);
+    mxArray* b_nb = mxCreateDoubleScalar((double)(n - 4));
+    mxArray* Sb = call(1, {c_Sb, h, b_r0, b_nb})[0];
+    w.put(Y); w.put(pr[1]); w.put(z); w.put(e[0]); w.put(e[1]); w.put(S); w.put(Sb);
     printf("{\"rows\": %zu, \"cols\": %zu, \"co0\": %.17g, \"co1\": %.17g, \"cost\": %.17g, \"gradnorm\": %.17g, \"hessvecs\": %d, "
            "\"obj\": %.17g, \"zlen\": %zu, \"lmax\": %.17g, \"ok\": %d}\n",
            mxGetM(Y), mxGetN(Y), mxGetScalar(co0), mxGetScalar(co1), field(info, "cost"), field(info, "gradnorm"),

@@ -211,3 +211,23 @@ def test_multiblock_sparse_quartic_matches_oracle(lib, opts):
     assert d["status"] == 0 and dr["status"] == 0
     assert max(d["gap"], d["pinf"], d["dinf"]) < opts["tol"]
     assert abs(obj - objr) <= 10 * opts["tol"] * max(1.0, abs(objr))
+
+
+def test_dual_slack_block_getter(lib):
+    """msdp_get_dual_slack_block: the diagonal blocks the multiblock host loop reads, against the full N x N download."""
+    At, b, c = _random_multiblock([30, 17, 24], 40, seed=1)
+    nset = [30, 17, 24]
+    h = lib.Handle.multiblock(At, b, c, nset, 2)
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((sum(nset), 4)); Y[:47] /= np.linalg.norm(Y[:47], axis=1, keepdims=True)
+    h.set_multipliers(0.1 * rng.standard_normal(b.size), 0.5)
+    h.set_point(Y)
+    h.cost()
+    h.al_dual(0.1 * rng.standard_normal(b.size))
+    S = h.get_dual_slack()
+    r0 = np.concatenate([[0], np.cumsum(nset)])
+    for i, nb in enumerate(nset):
+        assert np.array_equal(h.get_dual_slack_block(r0[i], nb), S[r0[i]:r0[i + 1], r0[i]:r0[i + 1]])
+    with pytest.raises(lib.MsdpError):
+        h.get_dual_slack_block(60, 20)
+    h.close()

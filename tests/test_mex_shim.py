@@ -187,7 +187,8 @@ def test_gateway_affine_matches_ctypes(tmp_path, kind_name, sparse_bc):
     assert meta["zlen"] == zarr.size
     o = 0
     Yb = Y.ravel() if kind == _lib.KIND_UNITDIAG else Y.ravel(order="F")
-    for ref in (Yb, Ax, zarr, lam, V.ravel(order="F"), S.ravel()):
+    Sb = S[2:n - 2, 2:n - 2]                             # get_dual_slack_block with first row 3 (1-based), order n - 4
+    for ref in (Yb, Ax, zarr, lam, V.ravel(order="F"), S.ravel(), Sb.ravel()):
         got = arr[o:o + ref.size]; o += ref.size
         assert np.array_equal(got, ref)
     assert o == arr.size
