@@ -2,7 +2,7 @@
 K4 = theta-like unit-trace SDP with dense C (ManiSDP_unittrace).  Reports Hess-vec device time (SDDMM + adjoint +
 two-matrix MFMA contraction + epilogue) and, for small d, a full solve next to the oracle."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from manisdp_matlab_amd import _lib, problems, solvers
 

@@ -1,7 +1,7 @@
 """BASELINE config 4's named workload: quartic on the sphere (qsmom, second-order moment relaxation) through the generic
 ManiSDP entry point, as example/example_qsphere.m does.  argv: d [oracle]  (random coefficients, seed 5, for d != 10)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from manisdp_matlab_amd import problems as P
 d = int(sys.argv[1]) if len(sys.argv) > 1 else 30

@@ -2,11 +2,11 @@
 dump run of oracle/manisdp_ref.py: the point Y, multipliers y and sigma going INTO the RTR call of AL iteration k, and
 what the oracle's RTR returned): does the device RTR do the same job on identical input?"""
 import glob, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from manisdp_matlab_amd import _lib, problems
 d = 60
-gold = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "golden")
 Q = np.loadtxt(os.path.join(gold, "bqp_Q_%d_1.txt.gz" % d), delimiter=",")
 e = np.loadtxt(os.path.join(gold, "bqp_e_%d_1.txt.gz" % d), delimiter=",")
 At, b, c, K = problems.bqpmom(d, Q, e)

@@ -1,10 +1,10 @@
 """theta1 / theta2 (SDPLIB, options of example_theta.m:50-53) from several start points: GPU path next to the oracle."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from manisdp_matlab_amd import problems, solvers
 from oracle import manisdp_ref as R
-gold = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "golden")
 known = json.load(open(os.path.join(gold, "known_answers.json")))
 for case in sys.argv[1:] or ["theta1", "theta2"]:
     At, b, c, K = problems.from_sdpa(os.path.join(gold, case + ".dat-s.gz"))

@@ -1,13 +1,10 @@
 """Dual approach (ManiDSDP_unitdiag) on the SOS relaxation of a random BQP with d variables, as
-example/dual/example_bqp_dual.m builds it: argv = d [d ...] [--oracle] (also time the CPU oracle)."""
+example/dual/example_bqp_dual.m builds it: argv = d [d ...] [--eig=host|device]  (GPU path against the CPU restatement: tests/test_gpu_dual.py)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from manisdp_matlab_amd import problems, solvers
 args = sys.argv[1:]
-with_oracle = "--oracle" in args
-if with_oracle:
-    args.remove("--oracle")
 eig = None
 for a in list(args):
     if a.startswith("--eig="):
@@ -29,8 +26,3 @@ for d in [int(a) for a in args]:
           "obj %.8f, eta %.1e, status %d, p %d" % (d, K["s"], b.size, A.nnz, tg, ts, data["rtr_seconds"], data["eig_seconds"],
           data["iters"], data["hessvecs"], obj * maxb, max(data["gap"], data["pinf"], data["dinf"]), data["status"], data["fac_size"][-1]),
           flush=True)
-    if with_oracle:
-        from oracle import manisdp_ref as R
-        t = time.time()
-        _, objo, do = R.ManiDSDP_unitdiag(A, b, c, K, dict(o))
-        print("      oracle (CPU) %.2f s, %d outer iterations, %d Hess-vecs, obj %.8f, status %d" % (time.time() - t, do["iters"], do["hessvecs"], objo * maxb, do["status"]), flush=True)
