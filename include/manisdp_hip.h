@@ -333,6 +333,8 @@ int msdp_get_dual_slack_block(msdp_handle h, int64_t row0, int64_t nb, double* S
  *                       default 0).  Bit-identical results; msdp_get_point_all and the escape keep the all-gather
  *   "lanczos_qglobal" 1/0  deflated persistent Lanczos runs read the deflation columns in place instead of from their LDS
  *                       copy (default 0: in place only where the copy does not fit, n > ~117 000 with 40 columns; bit-identical)
+ *   "block_skip"   1/0  multiblock kind: the dense contraction skips the zero off-diagonal blocks of its operands (default 1;
+ *                       0 = stream the whole N x N matrices; same results, for A/B timing)
  *   "dense_pack"   1/0  dense C*U reads the MFMA-fragment-ordered copy of C (default 1; 0 = the row-major one;
  *                       bit-identical results, for A/B timing)
  *   "timing", "esc_debug"  1/0  diagnostics on stderr                                (env MSDP_TIMING, MSDP_ESC_DEBUG)

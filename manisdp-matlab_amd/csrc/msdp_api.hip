@@ -446,6 +446,16 @@ extern "C" int msdp_create_multiblock(int32_t nb, const int64_t* block_n, int32_
         if (hipMemcpy(drf, rf.data(), (size_t)N, hipMemcpyHostToDevice) != hipSuccess) { msdp_set_error("multiblock: upload failed"); msdp_destroy(h); return MSDP_EHIP; }
         h->d.rowfree = drf;
     }
+    if (nb > 1) {                                          // block ranges per row: the dense contraction skips the zero off-diagonal blocks
+        std::vector<int> lo((size_t)N), hi((size_t)N);
+        for (int i = 0; i < nb; ++i)
+            for (int64_t a = r0[i]; a < r0[i + 1]; ++a) { lo[(size_t)a] = (int)r0[i]; hi[(size_t)a] = (int)r0[i + 1]; }
+        int *dlo = nullptr, *dhi = nullptr;
+        if ((rc = dev_alloc<int>(h, &dlo, (size_t)N)) || (rc = dev_alloc<int>(h, &dhi, (size_t)N))) { msdp_destroy(h); return rc; }
+        if (hipMemcpy(dlo, lo.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dhi, hi.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { msdp_set_error("multiblock: upload failed"); msdp_destroy(h); return MSDP_EHIP; }
+        h->d.blk_lo = dlo; h->d.blk_hi = dhi;
+    }
     *out = h;
     return 0;
 }
@@ -774,6 +784,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "escape_start_y")) t.escape_start_y = value != 0;
     else if (!strcmp(name, "lanczos_onesync")) t.lanczos_onesync = value != 0;
     else if (!strcmp(name, "lanczos_qglobal")) t.lanczos_qglobal = value != 0;
+    else if (!strcmp(name, "block_skip")) t.block_skip = value != 0;
     else if (!strcmp(name, "halo_exchange")) { t.halo_exchange = value != 0; h->state_valid = false; }
     else if (!strcmp(name, "dense_pack")) { t.dense_pack = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "debug_fail_persist")) t.fail_persist = value != 0;

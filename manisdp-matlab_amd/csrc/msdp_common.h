@@ -109,6 +109,10 @@ struct Dev {
     // multiblock kind: rowfree[i] != 0 marks the rows of the blocks that carry no unit-diagonal constraint (Euclidean
     // factor of the product manifold: no projection term, no normalisation); nullptr = every row is oblique
     const unsigned char* rowfree;
+    // multiblock kind: [blk_lo[i], blk_hi[i]) = the rows (= columns) of the diagonal block row i belongs to.  Every dense
+    // n x n operand of that kind (cost, eS, AyU, S) is block diagonal: the contraction skips the k range outside a row
+    // tile's blocks (exact zeros there).  nullptr for every other kind.
+    const int* blk_lo; const int* blk_hi;
 };
 
 // Run-time switches of a handle (msdp_set_option; the environment variables of the same meaning are read ONCE, when
@@ -124,6 +128,7 @@ struct Tuning {
     int escape_deflate = 1;  // escape: deflate span(Y) at near-stationary points (fast, approximate when S*Y != 0)
     int escape_start_y = 0;   // undeflated cold-start runs begin in span(Y) + 5 % noise (the independent lambda_min check sets it)
     int halo_exchange = 0;    // row-sharded sparse C: exchange only the referenced rows before S*U (0: the all-gather north_star prescribes)
+    int block_skip = 1;       // multiblock kind: the dense contraction skips the k range outside a row tile's diagonal blocks (0: A/B, tests)
     int lanczos_qglobal = 0;  // tests: deflated persistent Lanczos reads the deflation columns in place even where they fit the LDS
     int lanczos_onesync = 1;  // undeflated persistent Lanczos runs: one grid synchronisation per step (0: two)
     int dense_pack = 1;    // dense C*U reads the fragment-ordered copy of C (0: the row-major one; same results)

@@ -42,6 +42,7 @@ struct DenseOp {
     int kslice;                  // k extent per slice (multiple of 64) over the concatenated K = nmat*nS
     double* slab;                // SK x n_loc_cap x ld
     int64_t slab_stride;         // doubles between slabs
+    const int* blk_lo; const int* blk_hi;   // block-diagonal operands (multiblock kind, Dev::blk_lo): column range per row, or null
 };
 
 // What shaped the kernel (all measured on MI355X, tools/dense_sweep.sh; a pure-MFMA loop reaches 72 TFLOP/s,
@@ -85,8 +86,27 @@ __global__ __launch_bounds__(Dense3Cfg<NT>::WAVES * 64, (NT <= 4 ? 3 : 1)) void 
     const int arow = min(row0 + i, op.n_loc - 1);
     const int nS = op.nS;
     const int Ktot = op.nmat * nS;
-    const int kbeg = blockIdx.y * op.kslice;
-    const int kend = min(kbeg + op.kslice, Ktot);
+    int kbeg = blockIdx.y * op.kslice;
+    int kend = min(kbeg + op.kslice, Ktot);
+    if (op.blk_lo) {
+        // block-diagonal operands: outside the column range of the blocks this workgroup's rows belong to the matrices hold
+        // exact zeros -- trim the slice to the hull of its overlaps (whole tile pairs, so the tile sequence inside is the
+        // one of the untrimmed loop), or to nothing: the slab rows are then written as zeros
+        const int rfirst = blockIdx.x * Cfg::WAVES * 16, rlast = min(rfirst + Cfg::WAVES * 16, op.n_loc) - 1;
+        const int clo = op.blk_lo[rfirst], chi = op.blk_hi[rlast];
+        int lo = 0x7fffffff, hi = -1;
+        for (int m = 0; m < op.nmat; ++m) {
+            const int a = max(m * nS + clo, kbeg), b = min(m * nS + chi, kend);
+            if (a < b) { lo = min(lo, a); hi = max(hi, b); }
+        }
+        if (hi < 0) kend = kbeg;
+        else {
+            const int k0 = kbeg + ((lo - kbeg) / (2 * KT)) * (2 * KT);
+            const int k1 = kbeg + ((hi - kbeg + 2 * KT - 1) / (2 * KT)) * (2 * KT);
+            kend = min(kend, k1);
+            kbeg = k0;
+        }
+    }
     const int ld = op.ld, ldl = op.ldl;
     for (int e = threadIdx.x; e < 2 * KT * ldl; e += NTHR) lds[e] = 0.0;   // pad columns stay zero
     const int c2 = threadIdx.x & (HP - 1), sr0 = threadIdx.x / HP;
@@ -438,6 +458,7 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
     int rc = ensure_slab(h, (size_t)(SK + 1) * op.slab_stride);       // + 1: see msdp_dense_reserve
     if (rc) return rc;
     op.slab = h->slab;
+    if (h->tune.block_skip) { op.blk_lo = d.blk_lo; op.blk_hi = d.blk_hi; }
     // p > 128: column blocks of 128 (the matrix is re-streamed once per block; NT <= 8 accumulator tiles per wave)
     for (int colofs = 0; colofs < d.ld; colofs += 128) {
         op.colofs = colofs;

@@ -231,3 +231,28 @@ def test_dual_slack_block_getter(lib):
     with pytest.raises(lib.MsdpError):
         h.get_dual_slack_block(60, 20)
     h.close()
+
+
+def test_block_skip_gives_the_same_results(lib):
+    """The contraction of the multiblock kind trims every k slice to the diagonal blocks of its row tile (exact zeros
+    elsewhere): cost, gradient, Hess-vec and a trustregions() call against the untrimmed kernels -- many small blocks, so
+    that most (row tile, k slice) pairs are skipped, unequal block sizes, blocks that straddle tile boundaries."""
+    rng = np.random.default_rng(5)
+    nset = [int(v) for v in rng.integers(20, 90, size=24)]
+    At, b, c = _random_multiblock(nset, 300, seed=3)
+    N, p = sum(nset), 6
+    Y = rng.standard_normal((N, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((N, p))
+    y = 0.1 * rng.standard_normal(b.size)
+    out = []
+    for skip in (1, 0):
+        h = lib.Handle.multiblock(At, b, c, nset, len(nset))
+        h.set_option("block_skip", skip)
+        h.set_multipliers(y, 0.5)
+        h.set_point(Y)
+        f, G, H = h.cost(), h.rgrad(), h.hessvec(h.proj(U))
+        st = h.rtr(lib.default_opts(maxiter=4, maxinner=20, tolgradnorm=1e-9))
+        out.append((f, G, H, st.cost, st.gradnorm, st.hessvecs, h.get_point()))
+        h.close()
+    for x, yv in zip(*out):
+        assert np.array_equal(np.asarray(x), np.asarray(yv))
