@@ -23,6 +23,12 @@ import scipy.sparse as sp
 from . import _lib
 
 
+# Several replicated host loops in ONE process (the in-process ranks of tests/test_gpu_local_ranks.py: N threads, one BLAS
+# pool) must not race for BLAS threads: how many each call gets would decide the summation order of the p x p Gram / thin-SVD
+# arithmetic, and replicated loops must produce the same bits.  The harness sets this to 1; one process per GPU never needs it.
+FORCED_HOST_THREADS = None
+
+
 def _host_threads():
     """Context manager capping the BLAS/LAPACK threads of the host-side AL bookkeeping (thin SVD, residues) at the
     CPUs this process may actually use.  On a 256-core box inside a 16-CPU cgroup quota the default (256 threads on
@@ -43,6 +49,8 @@ def _host_threads():
             ncpu = min(ncpu, max(1, int(int(quota) / int(period))))
     except Exception:
         pass
+    if FORCED_HOST_THREADS:
+        return threadpool_limits(limits=int(FORCED_HOST_THREADS))
     return threadpool_limits(limits=max(1, min(ncpu, 16)))
 
 __all__ = ["ManiSDP_onlyunitdiag", "ManiSDP_unitdiag", "ManiSDP_unittrace", "ManiSDP", "ManiSDP_multiblock",

@@ -20,6 +20,8 @@ def run_ranks(N, fn):
     _group[0] += 1
     group = _group[0]
     out, err = [None] * N, [None] * N
+    from manisdp_matlab_amd import solvers
+    solvers.FORCED_HOST_THREADS = 1          # N replicated host loops share this process's BLAS pool: see solvers.py
 
     def body(r):
         try:
@@ -32,6 +34,7 @@ def run_ranks(N, fn):
         t.start()
     for t in th:
         t.join(600)
+    solvers.FORCED_HOST_THREADS = None
     for e in err:
         if e is not None:
             raise e
