@@ -234,3 +234,24 @@ def test_synthetic_dense_generator_matches_the_library_host_function():
     assert np.array_equal(A, A.T)
     with pytest.raises(ValueError):
         P.SyntheticDenseC(30000).toarray()
+
+
+def test_matrix_completion_generator_and_oracle():
+    """example_matrixcompletion.m:8-41 restated: every constraint reads X[j, p+l] + X[p+l, j] = 2 M[j, l] on a sampled
+    position, the cost is the trace; the lifted matrix [U; V][U; V]' of a factorisation M = U V' is feasible; the oracle's
+    generic ManiSDP recovers M (tr X = 2 |M|_*)."""
+    from oracle import manisdp_ref as R
+    p, q, k = 30, 25, 2
+    At, b, c, K, M, (j, l) = P.matrix_completion(p, q, k, m=6000, seed=3)
+    n = p + q
+    assert K["s"] == n and At.shape == (n * n, b.size) and np.array_equal(c.reshape(n, n), np.eye(n))
+    assert len(set(zip(j.tolist(), l.tolist()))) == b.size and np.array_equal(b, 2.0 * M[j, l])
+    A0 = At[:, 0].toarray().reshape(n, n, order="F")
+    assert A0[j[0], p + l[0]] == 1 and A0[p + l[0], j[0]] == 1 and A0.sum() == 2
+    U, s, Vt = np.linalg.svd(M, full_matrices=False)
+    L = np.vstack([U[:, :k] * np.sqrt(s[:k]), Vt[:k].T * np.sqrt(s[:k])])
+    X = L @ L.T
+    assert np.abs(At.T @ X.ravel(order="F") - b).max() < 1e-12 and abs(np.trace(X) - 2 * s.sum()) < 1e-10
+    Y, obj, d = R.ManiSDP(At, b, c, K, {"tol": 1e-8, "theta": 1e-2, "TR_maxinner": 6, "TR_maxiter": 8, "delta": 10, "alpha": 0.1})
+    assert d["status"] == 0 and abs(obj - 2 * s.sum()) <= 1e-6 * obj
+    assert np.linalg.norm(Y[:p] @ Y[p:].T - M) <= 1e-6 * np.linalg.norm(M)
