@@ -46,3 +46,28 @@ def unpad_gathered(slabs, n):
         r1 = min(n, r0 + cap)
         rows.append(s[: r1 - r0])
     return np.vstack(rows)
+
+
+def halo_lists(C, nranks, rank):
+    """Send / receive lists of the halo exchange for sparse C (option ``halo_exchange``; the host-side statement of
+    ``halo_setup`` in csrc/msdp_api.hip).  Every rank holds the whole sparsity structure, so both ends of a pair compute
+    the same lists: ``need[q]`` = the sorted global rows outside q's range that q's rows of C reference.
+
+    Returns ``(send, recv)``: ``send[q]`` = local row indices this rank packs for peer q (in the order q unpacks them),
+    ``recv[q]`` = global row indices this rank receives from peer q; both empty for ``q == rank``."""
+    C = C.tocsr()
+    n = C.shape[0]
+    cap = row_capacity(n, nranks)
+    m0, m1 = row_range(n, nranks, rank)
+    send = [np.zeros(0, dtype=np.int64) for _ in range(nranks)]
+    recv = [np.zeros(0, dtype=np.int64) for _ in range(nranks)]
+    for q in range(nranks):
+        q0, q1 = row_range(n, nranks, q)
+        cols = np.unique(C.indices[C.indptr[q0]:C.indptr[q1]]) if q1 > q0 else np.zeros(0, dtype=np.int64)
+        need = cols[(cols < q0) | (cols >= q1)]
+        if q == rank:
+            for o in range(nranks):
+                recv[o] = need[need // cap == o].astype(np.int64)
+        else:
+            send[q] = (need[(need >= m0) & (need < m1)] - m0).astype(np.int64)
+    return send, recv
