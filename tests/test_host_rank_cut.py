@@ -36,3 +36,35 @@ def test_rank_threshold_is_inclusive_in_the_primal_files_and_strict_in_the_dual(
     assert np.allclose(e, [2.0, 1.0, 0.25]) and r == 2
     _, e_s, r_s = R._thin_svd_rank_strict(Y, 0.5)
     assert np.allclose(e_s, [2.0, 1.0, 0.25]) and r_s == 1
+
+
+class _FakeHandle:
+    """Stands in for the device in solvers._line_search: co(alpha) is a given function."""
+    def __init__(self, co):
+        self.co, self.calls, self.accepted = co, [], 0
+
+    def linesearch_cost(self, U, alpha):
+        self.calls.append(alpha)
+        return self.co(alpha)
+
+    def linesearch_accept(self):
+        self.accepted += 1
+
+
+def test_line_search_backtracking_schedule():
+    """line_search (ManiSDP_onlyunitdiag.m:103-115): alpha = 1, then x 0.8 at most 15 times until
+    co(nY) - co(Y) <= -1e-3; the last trial point is accepted either way."""
+    # decrease only for alpha <= 0.5: 1, .8, .64, .512, .4096 -> accepted at the fifth trial
+    h = _FakeHandle(lambda a: 0.0 if a == 0.0 else (-1.0 if a <= 0.5 else +1.0))
+    solvers._line_search(h, object())
+    assert h.accepted == 1 and h.calls[0] == 0.0
+    assert np.allclose(h.calls[1:], [1.0, 0.8, 0.64, 0.512, 0.4096])
+    # a decrease smaller than 1e-3 does not count; after 15 reductions the search stops (16 trials in all)
+    h = _FakeHandle(lambda a: 0.0 if a == 0.0 else -5e-4)
+    solvers._line_search(h, object())
+    assert h.accepted == 1 and len(h.calls) == 1 + 16
+    assert np.isclose(h.calls[-1], 0.8 ** 15)
+    # immediate success
+    h = _FakeHandle(lambda a: 0.0 if a == 0.0 else -2e-3)
+    solvers._line_search(h, object())
+    assert h.calls == [0.0, 1.0] and h.accepted == 1
