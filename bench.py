@@ -12,7 +12,9 @@ retraction and cost evaluation of the solve).
 N > 1 (one process per GPU, RCCL): rows of the factor are sharded over the ranks with an
 all-gather of the thin n x p direction before every S*U and an all-reduce of the partial
 sums; the instance is the same toroidal-grid family scaled to n = 20000 * N rows so the
-per-GPU work is fixed ("weak" scaling); value counts 20000-row-equivalent Hess-vecs.
+per-GPU work is fixed ("weak" scaling); value counts 20000-row-equivalent Hess-vecs.  The same K steps are then timed once
+more with the halo exchange (option halo_exchange: only the rows a rank's rows of C reference travel, bit-identical results);
+both figures are in the line under "row_exchange", `value` is the faster one and config.row_exchange names it.
 
 One JSON line is printed by rank 0.
 """
