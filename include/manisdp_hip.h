@@ -119,6 +119,11 @@ int msdp_debug_set_full_rows(msdp_handle h, const double* rows_host);
  * buffers.  Lets a single-GPU box run the RCCL half of the exchange; the send / receive lists are covered by the
  * in-process ranks (tests/test_gpu_local_ranks.py). */
 int msdp_debug_p2p_self(msdp_handle h, int64_t count, const double* in_host, double* out_host);
+/* Test-only, host code only (no GPU touched): the dense symmetric eigen-solver (Householder + implicit QL; w ascending, row i
+ * of Z = eigenvector i) and the generalised Rayleigh-Ritz problem H c = theta G c (theta ascending, +inf beyond *rank; W b x b
+ * row-major, column j = coefficients of Ritz vector j, W'GW = I on the first *rank columns) of the block eigen-solver. */
+int msdp_debug_sym_eig(int32_t n, const double* A, double* w, double* Z);
+int msdp_debug_ritz(int32_t b, const double* G, const double* H, double* theta, double* W, int32_t* rank);
 /* Test-only: make a sparse-C handle rank `rank` of `nranks` WITHOUT a communicator (same row split, local CSR/ELL
  * rows with global column indices and gather buffer as msdp_comm_init sets up), so that one GPU can check every
  * shard's kernels against the unsharded result.  Call right after create, before any point is set. */
@@ -260,6 +265,11 @@ int msdp_escape_eigs(msdp_handle h, int32_t k, double tol, int32_t maxit,
 int msdp_escape_eigs_matrix(msdp_handle h, const double* S, int32_t k, double tol, int32_t maxit,
                             double* lam_min, double* V, double* lam_max, int32_t* iters);
 
+/* Which eigen-solver the LAST escape call on this handle ran: 1 = block Chebyshev-filtered subspace iteration
+ * (msdp_blockeig.hip: sparse C; a 64- or 128-wide panel, reduction-free filter steps on the S*U kernel, Rayleigh-Ritz every
+ * few hundred steps), 0 = deflated single-vector Lanczos runs (msdp_escape.hip: dense S, pre-sharded dense C, small n). */
+int msdp_escape_method(msdp_handle h, int32_t* method);
+
 /* Outcome of the LAST msdp_escape_eigs / _matrix / _dual call on this handle.  The reference's eig(S) is exact;
  * a Lanczos run that reaches `maxit` without passing a stop test only yields an UPPER bound of lambda_min, so
  * dinf = max(0,-lambda_min)/(1+lambda_max) (ManiSDP_onlyunitdiag.m:51) would be under-estimated: the AL loop
@@ -268,12 +278,15 @@ int msdp_escape_eigs_matrix(msdp_handle h, const double* S, int32_t k, double to
  *   *converged : 1 if every Lanczos run passed a stop test, 0 if one ended at maxit;
  *   *residual  : largest relative residual |S x - theta x| / max(|theta|, |lam_max|) among the unconverged runs. */
 int msdp_escape_info(msdp_handle h, int32_t* nvalid, int32_t* converged, double* residual);
-/* Lower bound of lambda_min(S) from the LAST escape call (-inf when the call gives none, e.g. all k runs still found
- * negative pairs).  With Z = [orth(Y) | found vectors] and S = [A E'; E B] in the basis [Z, complement]:
- *   lambda_min(S) >= min(lambda_min(A), lambda_min(B)) - |E|_F     (Weyl)
- * A = Z'SZ is known exactly, lambda_min(B) is bounded by the last, converged, non-negative Lanczos run, and
- * |E|_F = |(I - ZZ')SZ|_F is measured.  dinf computed from this bound can only over-estimate the true
- * dinf = max(0,-lambda_min)/(1+lambda_max) (ManiSDP_onlyunitdiag.m:51): if it is below tol, so is the true one. */
+/* Lower ESTIMATE of lambda_min(S) from the LAST escape call; -inf unless that call was cold-started and undeflated
+ * (options escape_deflate = 0, escape_warm = 0) and converged.  Block path: theta_0 minus its error estimate.  Lanczos path:
+ * with Z = [found vectors] and S = [A E'; E B] in the basis [Z, complement],
+ *   min(lambda_min(A), theta - res) - |E|_F
+ * where A = Z'SZ is known exactly, |E|_F = |(I - ZZ')SZ|_F is measured and (theta, res) is the last converged,
+ * non-negative Ritz pair of the complement.  NOT a certificate: a converged Ritz pair proves that SOME eigenvalue lies within
+ * res of theta, not that none lies below; a warm-started or deflated run that missed the bottom of the
+ * spectrum would report a bound that is too high, which is why such runs report -inf and the host loops always finish with
+ * the independent, cold-started check. */
 int msdp_escape_lower_bound(msdp_handle h, double* lam_lower);
 
 /* ------------------------------------------------------------- multi-GPU */
@@ -324,6 +337,10 @@ int msdp_get_dual_slack_block(msdp_handle h, int64_t row0, int64_t nb, double* S
  *   "escape_deflate" 1/0 escape: deflate span(Y) at near-stationary points (default 1).  Fast, but only as accurate as
  *                       S*Y is small; a caller about to DECLARE optimality re-checks lambda_min with 0 (see solvers.py)
  *   "escape_warm"  1/0  escape: start from what the previous call found (default 1; 0 = hashed random start vector)
+ *   "escape_method" 0 = block eigen-solver where it applies (sparse C, n >= 2048), Lanczos otherwise (default); 1 = Lanczos
+ *                       always; 2 = block also for small n (tests)
+ *   "be_width" 0/32/64/128, "be_degree", "be_grid", "be_lpr"  block eigen-solver: panel width, filter degree per round,
+ *                       workgroups and lanes per row of the filter step (0 = automatic; measurement and tests)
  *   "escape_start_y" 1/0  undeflated cold-start escape runs start from a random combination of the columns of Y plus 5 %
  *                       noise instead of pure noise (default 0; the independent lambda_min check of the host loops sets it)
  *   "lanczos_onesync" 1/0  undeflated persistent Lanczos runs use one grid synchronisation per step (default 1; 0 = the

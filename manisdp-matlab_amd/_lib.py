@@ -82,6 +82,9 @@ SIGNATURES = {
                                          _P(C.c_int32)]),
     "msdp_escape_info": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _dp]),
     "msdp_escape_lower_bound": (C.c_int, [C.c_void_p, _dp]),
+    "msdp_escape_method": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "msdp_debug_sym_eig": (C.c_int, [C.c_int32, _dp, _dp, _dp]),
+    "msdp_debug_ritz": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _P(C.c_int32)]),
     "msdp_get_dual_slack": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_dual_slack_block": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
     "msdp_release_cache": (C.c_int, []),
@@ -449,8 +452,15 @@ class Handle:
         """Run-time switch of this handle (see msdp_set_option in include/manisdp_hip.h)."""
         _check(self._lib.msdp_set_option(self._h, name.encode(), int(value)))
 
+    def escape_method(self):
+        """Which eigen-solver the last escape call ran: 1 = block Chebyshev-filtered subspace iteration, 0 = Lanczos."""
+        v = C.c_int32()
+        _check(self._lib.msdp_escape_method(self._h, C.byref(v)))
+        return v.value
+
     def escape_lower_bound(self):
-        """Weyl lower bound of lambda_min(S) from the last escape call (-inf when there is none)."""
+        """Lower estimate of lambda_min(S) from the last escape call; -inf unless that call was cold-started and
+        undeflated (see msdp_escape_lower_bound in include/manisdp_hip.h: an estimate, not a certificate)."""
         v = C.c_double()
         _check(self._lib.msdp_escape_lower_bound(self._h, C.byref(v)))
         return v.value

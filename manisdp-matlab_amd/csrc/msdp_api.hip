@@ -42,6 +42,7 @@ void msdp_affine_release(msdp_handle h);
 int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam, double* V, double* lmax, int* iters,
                      const double* Mdev);
 int msdp_dense_nS(int n);
+void msdp_blockeig_release(msdp_handle h);
 
 #define CHECK_H(h)                                          \
     if (!(h)) { msdp_set_error("null handle"); return MSDP_EINVAL; }
@@ -530,6 +531,8 @@ extern "C" int msdp_destroy(msdp_handle h) {
     if (h->esc_z) (void)hipFree(h->esc_z);
     msdp_escape_workspace_park(h->esc_mem, h->esc_cap);      // esc_prev lives inside it; kept for the next handle of the process
     if (h->lz_slots) (void)hipFree(h->lz_slots);
+    msdp_blockeig_release(h);
+    if (h->esc_top) (void)hipFree(h->esc_top);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -782,6 +785,11 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "escape_deflate")) t.escape_deflate = value != 0;
     else if (!strcmp(name, "escape_warm")) t.escape_warm = value != 0;
     else if (!strcmp(name, "escape_start_y")) t.escape_start_y = value != 0;
+    else if (!strcmp(name, "escape_method")) { if (value < 0 || value > 2) { msdp_set_error("escape_method: 0 auto, 1 lanczos, 2 block"); return MSDP_EINVAL; } t.escape_method = value; }
+    else if (!strcmp(name, "be_width")) { if (value != 0 && value != 32 && value != 64 && value != 128) { msdp_set_error("be_width: 0, 32, 64 or 128"); return MSDP_EINVAL; } t.be_width = value; }
+    else if (!strcmp(name, "be_degree")) t.be_degree = value > 0 ? value : 0;
+    else if (!strcmp(name, "be_grid")) t.be_grid = value > 0 ? (value > MSDP_MAX_GRID ? MSDP_MAX_GRID : value) : 0;
+    else if (!strcmp(name, "be_lpr")) { if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) { msdp_set_error("be_lpr: 0, 8, 16, 32 or 64"); return MSDP_EINVAL; } t.be_lpr = value; }
     else if (!strcmp(name, "lanczos_onesync")) t.lanczos_onesync = value != 0;
     else if (!strcmp(name, "lanczos_qglobal")) t.lanczos_qglobal = value != 0;
     else if (!strcmp(name, "block_skip")) t.block_skip = value != 0;
@@ -1844,6 +1852,13 @@ extern "C" int msdp_escape_info(msdp_handle h, int32_t* nvalid, int32_t* converg
     if (nvalid) *nvalid = h->esc_nvalid;
     if (converged) *converged = h->esc_converged;
     if (residual) *residual = h->esc_maxres;
+    return 0;
+}
+
+extern "C" int msdp_escape_method(msdp_handle h, int32_t* method) {
+    CHECK_H(h);
+    if (!method) return MSDP_EINVAL;
+    *method = h->esc_method_last;
     return 0;
 }
 

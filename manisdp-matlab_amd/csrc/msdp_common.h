@@ -133,6 +133,12 @@ struct Tuning {
     int lanczos_onesync = 1;  // undeflated persistent Lanczos runs: one grid synchronisation per step (0: two)
     int dense_pack = 1;    // dense C*U reads the fragment-ordered copy of C (0: the row-major one; same results)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
+    int escape_method = 0;   // 0: block Chebyshev-filtered subspace iteration where it applies (msdp_blockeig.hip), else Lanczos;
+                             //   1: Lanczos always (msdp_escape.hip); 2: block also below its size threshold (tests)
+    int be_width = 0;        // block eigen-solver: panel width 32 / 64 / 128 (0: 64, or 128 when the start block needs it)
+    int be_degree = 0;       // ... filter degree per round (0: 200 warm, 400 cold)
+    int be_grid = 0;         // ... workgroups of the filter step (0: by rows)
+    int be_lpr = 0;          // ... lanes per row of the filter step (0: by rows per workgroup)
     int fail_persist = 0;  // test hook (msdp_set_option "debug_fail_persist"): the next persistent launch reports a
                            //   grid-synchronisation time-out without running, to exercise the recovery path
 };
@@ -199,7 +205,11 @@ struct msdp_handle_s {
     // largest relative residual |S x - theta x| / max(|theta|, |lam_max|) among the runs that hit maxit instead
     int esc_nvalid = 0, esc_converged = 0;
     double esc_maxres = 0.0;
-    double esc_lower = 0.0;           // rigorous-by-Weyl lower bound of lambda_min(S) from the last call (-inf: none)
+    double esc_lower = 0.0;           // lower estimate of lambda_min(S) from the last call (-inf: none), see msdp_escape_lower_bound
+    void* be = nullptr;               // workspace and warm-start state of the block eigen-solver (msdp_blockeig.hip)
+    double* esc_top = nullptr;        // top eigenvector of the previous escape call (warm start of the lambda_max run), esc_top_n entries
+    int esc_top_n = 0;
+    int esc_method_last = 0;          // what the last escape call ran: 0 Lanczos, 1 block
     // persistent tCG kernel (msdp_persist.hip): grid-sync slots, error flag, cached eligibility
     unsigned long long* psync_slots = nullptr;
     int* psync_err = nullptr;

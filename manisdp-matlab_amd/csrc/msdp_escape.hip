@@ -35,6 +35,13 @@ int msdp_lanczos_persist_run(msdp_handle h, const double* z, const double* Q, in
                              double* dbeta, unsigned long long* slots, int* err, int m0, int m1,
                              const int* rp, const int* ci, const double* cv);
 
+// msdp_blockeig.hip: Chebyshev-filtered subspace iteration on a b-wide panel (sparse C)
+int msdp_blockeig_eligible(msdp_handle h, const double* Mdev, bool w_loc);
+int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const double* cv, const double* z, bool own_rows,
+                      const double* Ypt, int ld, int p, int k, double tol, int maxdeg, double lmax, double lmax_res, double lmin_est,
+                      bool cold, bool use_y, double* lam, double* V_dev, int* degree_out, bool* conv_out, double* err_out,
+                      double* lower_out);
+
 // ---------------------------------------------------------------- kernels
 // w = S*v for S = C - diag(z), sparse C (one thread per row; rows are short)
 __global__ void k_sv_sparse(int n, const int* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ cv,
@@ -436,6 +443,139 @@ static int dev_norm(EscCtx& c, const double* w, double* out) {
     return 0;
 }
 
+// Advance the recurrence from step m to step m1 (columns m+1..m1 of V, alpha[m..m1-1], beta[m+1..m1]).
+struct LzMode { bool persist, fused_small; };
+static LzMode lanczos_mode(EscCtx& c, int nq) {
+    LzMode md;
+    md.persist = !c.M && !c.w_loc && c.slots && msdp_lanczos_persist_ok(c.h, nq, c.replicated_csr ? c.rp : nullptr);
+    md.fused_small = !md.persist && c.n <= LZS_MAXN;
+    if (md.fused_small) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k_lz_step_small<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * LZS_THREADS * (int)sizeof(double));
+            (void)hipFuncSetAttribute((const void*)k_lz_step_small<16>, hipFuncAttributeMaxDynamicSharedMemorySize, LZS_MAXN * (int)sizeof(double));
+            attr_set = true;
+        }
+    }
+    return md;
+}
+static int lanczos_advance(EscCtx& c, const LzMode& md, const double* Q, int nq, double* V, double* w, double* dalpha, double* dbeta,
+                           int& m, int m1) {
+    msdp_handle h = c.h;
+    const int n = c.n;
+    const dim3 gr((n + 255) / 256), bl(256);
+    int rc;
+    if (md.persist) {
+        // all steps up to the next checkpoint in one launch (msdp_lanczos.hip)
+        if ((rc = msdp_lanczos_persist_run(h, c.z, Q, nq, V, c.X, dalpha, dbeta, c.slots, c.err, m, m1, c.rp, c.ci, c.cv))) return rc;
+        m = m1;
+        return 0;
+    }
+    while (m < m1) {
+        double* vj = V + (size_t)m * n;
+        if ((rc = sapply(c, vj, w))) return rc;
+        if (md.fused_small) {
+            const size_t lds = nq > 0 ? (size_t)n * sizeof(double) : 0;
+            const double* vp = m > 0 ? (const double*)(vj - n) : (const double*)nullptr;
+            const double* bp = m > 0 ? (const double*)(dbeta + m) : (const double*)nullptr;
+            if (n <= 4 * LZS_THREADS)
+                hipLaunchKernelGGL(k_lz_step_small<4>, dim3(1), dim3(LZS_THREADS), lds, h->stream, n, w, (const double*)vj, vp, bp, Q, nq, dalpha + m, dbeta + m + 1, vj + n);
+            else if (n <= 8 * LZS_THREADS)
+                hipLaunchKernelGGL(k_lz_step_small<8>, dim3(1), dim3(LZS_THREADS), lds, h->stream, n, w, (const double*)vj, vp, bp, Q, nq, dalpha + m, dbeta + m + 1, vj + n);
+            else
+                hipLaunchKernelGGL(k_lz_step_small<16>, dim3(1), dim3(LZS_THREADS), lds, h->stream, n, w, (const double*)vj, vp, bp, Q, nq, dalpha + m, dbeta + m + 1, vj + n);
+            HIPCHK(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, n, w, vj, dalpha + m, 0);
+            hipLaunchKernelGGL(k_lanczos_update, gr, bl, 0, h->stream, n, w, vj, m > 0 ? vj - n : (const double*)nullptr,
+                               dalpha + m, m > 0 ? dbeta + m : (const double*)nullptr);
+            HIPCHK(hipGetLastError());
+            if ((rc = deflate(c, Q, nq, w, 1))) return rc;
+            hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, n, w, w, dbeta + m + 1, 1);
+            hipLaunchKernelGGL(k_normalize_to, gr, bl, 0, h->stream, n, w, dbeta + m + 1, vj + n);
+            HIPCHK(hipGetLastError());
+        }
+        ++m;
+    }
+    return 0;
+}
+
+// Largest eigenvalue of S by a short undeflated Lanczos run (the block eigen-solver of msdp_blockeig.hip needs the upper
+// edge of the spectrum for its filter, the AL loop needs lambda_max for dinf).  Start: `warm` (the top vector of the
+// previous call: S changes by a small diagonal between outer iterations) plus hashed noise, or noise alone.  Stops when the
+// top Ritz pair has residual <= tol*scale.  Outputs: lambda_max, its residual bound, the smallest Ritz value of the run (a
+// rough UPPER estimate of lambda_min: it only normalises the filter) and the top Ritz vector (device, n).
+__global__ void k_add_hash(int n, unsigned seed, double amp, double* __restrict__ dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u ^ seed;
+        x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+        dst[i] += amp * ((double)x / 4294967296.0 - 0.5);
+    }
+}
+static int lanczos_top(EscCtx& c, double* V, double* w, double* dalpha, double* dbeta, int maxit, double tol, unsigned seed,
+                       const double* warm, double* lmax_out, double* res_out, double* lmin_out, double* top_out, int* m_out) {
+    msdp_handle h = c.h;
+    const int n = c.n;
+    const dim3 gr((n + 255) / 256), bl(256);
+    int rc;
+    if (warm) {
+        HIPCHK(hipMemcpyAsync(w, warm, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        // the stored vector has unit norm: entries ~ 1/sqrt(n); 10 % of that as noise keeps every eigen-direction alive
+        hipLaunchKernelGGL(k_add_hash, gr, bl, 0, h->stream, n, seed, 0.35 / sqrt((double)n), w);
+    } else {
+        hipLaunchKernelGGL(k_fill_hash, gr, bl, 0, h->stream, n, seed, w);
+    }
+    hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, n, w, w, dbeta, 1);
+    hipLaunchKernelGGL(k_normalize_to, gr, bl, 0, h->stream, n, w, dbeta, V);
+    HIPCHK(hipGetLastError());
+    const LzMode md = lanczos_mode(c, 0);
+    std::vector<double> a, b, s, off;
+    int m = 0, next_check = warm ? 16 : 64;
+    double lmax = 0.0, lmin = 0.0, res = 1e300;
+    while (m < maxit) {
+        if ((rc = lanczos_advance(c, md, nullptr, 0, V, w, dalpha, dbeta, m, std::min(next_check, maxit)))) return rc;
+        a.resize(m); b.resize(m + 1);
+        HIPCHK(hipMemcpyAsync(a.data(), dalpha, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(b.data(), dbeta, (m + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (md.persist) {
+            int perr = 0;
+            HIPCHK(hipMemcpy(&perr, c.err, sizeof(int), hipMemcpyDeviceToHost));
+            if (perr) { msdp_set_error("persistent Lanczos: grid synchronisation timed out"); return MSDP_EHIP; }
+        }
+        off.assign(m, 0.0);
+        for (int i = 0; i + 1 < m; ++i) off[i] = b[i + 1];
+        double glo = 1e300, ghi = -1e300;
+        for (int i = 0; i < m; ++i) {
+            const double rad = (i > 0 ? fabs(off[i - 1]) : 0.0) + (i + 1 < m ? fabs(off[i]) : 0.0);
+            glo = std::min(glo, a[i] - rad); ghi = std::max(ghi, a[i] + rad);
+        }
+        lmax = tri_eig_kth(a, off, m, m - 1, glo, ghi);
+        lmin = tri_eig_kth(a, off, m, 0, glo, ghi, 1e-10 * (fabs(glo) + fabs(ghi)));
+        tri_eigvec(a, off, m, lmax, s);
+        res = fabs(b[m] * s[m - 1]);
+        const double scale = std::max(fabs(lmax), fabs(lmin)) + 1e-300;
+        if (res <= tol * scale || b[m] <= 1e-14 * scale) break;
+        next_check = std::min(maxit, 2 * m);
+    }
+    // top Ritz vector (warm start of the next call)
+    if (top_out) {
+        double* sdev = nullptr;
+        HIPCHK(hipMalloc((void**)&sdev, (size_t)m * sizeof(double)));
+        hipError_t e = hipMemcpyAsync(sdev, s.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(top_out, 0, (size_t)n * sizeof(double), h->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_multiaxpy, gr, bl, 0, h->stream, n, m, V, (int64_t)n, sdev, 1.0, top_out);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        (void)hipFree(sdev);
+        if (e != hipSuccess) { msdp_set_error("escape: top Ritz vector assembly failed: %s", hipGetErrorString(e)); return MSDP_EHIP; }
+    }
+    *lmax_out = lmax; *res_out = res; *lmin_out = lmin; *m_out = m;
+    return 0;
+}
+
 // Plain (three-term) Lanczos on the complement of the nq columns of Q: smallest Ritz pair and the largest
 // Ritz value.  No re-orthogonalisation against earlier Lanczos vectors -- extreme Ritz values stay valid
 // (ghosts only duplicate converged ones), which is what makes 10^4 steps affordable; the Lanczos vectors are
@@ -476,48 +616,10 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
     int m = 0, next_check = 32;
     double theta = 0.0, res = 1e300, lmax = 0.0;
     bool converged = false;          // one of the three stop tests passed (else the run ended at maxit: theta is only an upper bound)
-    const bool persist = !c.M && !c.w_loc && c.slots && msdp_lanczos_persist_ok(h, nq, c.replicated_csr ? c.rp : nullptr);
-    const bool fused_small = !persist && n <= LZS_MAXN;
-    if (fused_small) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIPCHK(hipFuncSetAttribute((const void*)k_lz_step_small<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * LZS_THREADS * (int)sizeof(double)));
-            HIPCHK(hipFuncSetAttribute((const void*)k_lz_step_small<16>, hipFuncAttributeMaxDynamicSharedMemorySize, LZS_MAXN * (int)sizeof(double)));
-            attr_set = true;
-        }
-    }
+    const LzMode md = lanczos_mode(c, nq);
+    const bool persist = md.persist;
     while (m < maxit) {
-        if (persist) {
-            // all steps up to the next checkpoint in one launch (msdp_lanczos.hip)
-            const int m1 = std::min(next_check, maxit);
-            if ((rc = msdp_lanczos_persist_run(h, c.z, Q, nq, V, c.X, dalpha, dbeta, c.slots, c.err, m, m1, c.rp, c.ci, c.cv))) return rc;
-            m = m1;
-        } else {
-        double* vj = V + (size_t)m * n;
-        if ((rc = sapply(c, vj, w))) return rc;
-        if (fused_small) {
-            const size_t lds = nq > 0 ? (size_t)n * sizeof(double) : 0;
-            const double* vp = m > 0 ? (const double*)(vj - n) : (const double*)nullptr;
-            const double* bp = m > 0 ? (const double*)(dbeta + m) : (const double*)nullptr;
-            if (n <= 4 * LZS_THREADS)
-                hipLaunchKernelGGL(k_lz_step_small<4>, dim3(1), dim3(LZS_THREADS), lds, h->stream, n, w, (const double*)vj, vp, bp, Q, nq, dalpha + m, dbeta + m + 1, vj + n);
-            else if (n <= 8 * LZS_THREADS)
-                hipLaunchKernelGGL(k_lz_step_small<8>, dim3(1), dim3(LZS_THREADS), lds, h->stream, n, w, (const double*)vj, vp, bp, Q, nq, dalpha + m, dbeta + m + 1, vj + n);
-            else
-                hipLaunchKernelGGL(k_lz_step_small<16>, dim3(1), dim3(LZS_THREADS), lds, h->stream, n, w, (const double*)vj, vp, bp, Q, nq, dalpha + m, dbeta + m + 1, vj + n);
-            HIPCHK(hipGetLastError());
-        } else {
-        hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, n, w, vj, dalpha + m, 0);
-        hipLaunchKernelGGL(k_lanczos_update, gr, bl, 0, h->stream, n, w, vj, m > 0 ? vj - n : (const double*)nullptr,
-                           dalpha + m, m > 0 ? dbeta + m : (const double*)nullptr);
-        HIPCHK(hipGetLastError());
-        if ((rc = deflate(c, Q, nq, w, 1))) return rc;
-        hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, n, w, w, dbeta + m + 1, 1);
-        hipLaunchKernelGGL(k_normalize_to, gr, bl, 0, h->stream, n, w, dbeta + m + 1, vj + n);
-        HIPCHK(hipGetLastError());
-        }
-        ++m;
-        }
+        if ((rc = lanczos_advance(c, md, Q, nq, V, w, dalpha, dbeta, m, std::min(next_check, maxit)))) return rc;
         if (m == next_check || m == maxit) {
             a.resize(m); b.resize(m + 1);
             HIPCHK(hipMemcpyAsync(a.data(), dalpha, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -742,6 +844,12 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     if (k < 1) { msdp_set_error("escape_eigs: k >= 1"); return MSDP_EINVAL; }
     const int n = d.n, p = d.p;
     if (maxit < 8) maxit = 8;
+    // Sparse C: the block eigen-solver does the work (msdp_blockeig.hip); the Lanczos machinery below then only serves its
+    // short lambda_max run, and `maxit` is the budget of filter steps
+    const bool use_block = msdp_blockeig_eligible(h, Mdev, shard_dense) != 0;
+    const int maxdeg = maxit;
+    if (use_block && maxit > 2048) maxit = 2048;
+    h->esc_method_last = use_block ? 1 : 0;
     // Without re-orthogonalisation the process may need more than n steps for the extreme pairs (ghost copies use
     // up steps); small matrices are cheap, so allow 4 n there
     if (maxit > 4 * n) maxit = 4 * n;
@@ -822,6 +930,47 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     const dim3 gr((n + 255) / 256), bl(256);
 #define ESC_CHECK(x) do { rc = (x); if (rc) goto done; } while (0)
 #define ESC_HIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { msdp_set_error("%s: %s", #x, hipGetErrorString(_e)); rc = MSDP_EHIP; goto done; } } while (0)
+    if (use_block) {
+        // "cold" = what the independent check of the host loops asks for (escape_deflate = 0, escape_warm = 0): hashed noise
+        // only -- no column of Y unless escape_start_y says so, nothing read from or left for other calls
+        const bool cold = !h->tune.escape_deflate && !h->tune.escape_warm;
+        const bool use_y = cold ? (h->tune.escape_start_y != 0) : true;
+        const bool dbg = h->tune.esc_debug != 0;
+        const auto tb0 = std::chrono::steady_clock::now();
+        double lmx = 0.0, lres = 0.0, lmin_est = 0.0, err = 0.0, lower = -INFINITY;
+        int mtop = 0, deg = 0;
+        bool conv = false;
+        const double* warm_top = (!cold && h->tune.escape_warm && h->esc_top && h->esc_top_n == n) ? h->esc_top : nullptr;
+        rc = lanczos_top(c, V, w, dalpha, dbeta, maxit, 1e-7, 777u, warm_top, &lmx, &lres, &lmin_est, Z, &mtop);
+        if (!rc && !cold) {
+            if (!h->esc_top || h->esc_top_n != n) {
+                if (h->esc_top) (void)hipFree(h->esc_top);
+                h->esc_top = nullptr; h->esc_top_n = 0;
+                if (hipMalloc((void**)&h->esc_top, (size_t)n * sizeof(double)) == hipSuccess) h->esc_top_n = n; else (void)hipGetLastError();
+            }
+            if (h->esc_top) (void)hipMemcpyAsync(h->esc_top, Z, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+        }
+        const auto tb1 = std::chrono::steady_clock::now();
+        if (!rc) rc = msdp_blockeig_run(h, n, c.rp, c.ci, c.cv, c.z, !rep_sparse, c.Ypt, c.ld, c.p, k, tol, maxdeg, lmx, lres, lmin_est, cold, use_y,
+                                        lam_out, Q, &deg, &conv, &err, &lower);
+        if (!rc) {
+            hipError_t e2 = hipMemcpy(V_out, Q, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost);
+            if (e2 != hipSuccess) { msdp_set_error("escape_eigs: download of the eigenvectors failed: %s", hipGetErrorString(e2)); rc = MSDP_EHIP; }
+        }
+        if (!rc) {
+            int nvalid = 0;
+            for (int t = 0; t < k; ++t) if (std::isfinite(lam_out[t])) ++nvalid;
+            h->esc_nvalid = nvalid; h->esc_converged = conv ? 1 : 0; h->esc_maxres = conv ? 0.0 : err;
+            // honoured by the host loops only as the outcome of a cold, undeflated call: an estimate, not a certificate
+            h->esc_lower = (cold && conv) ? lower : -INFINITY;
+            if (lmax_out) *lmax_out = lmx;
+            if (iters_out) *iters_out = deg + mtop;
+            if (dbg) fprintf(stderr, "[escape] block path: lambda_max run %d steps (%.2f ms, %s start, residual %.1e), block iteration %.2f ms\n", mtop,
+                             1e3 * std::chrono::duration<double>(tb1 - tb0).count(), warm_top ? "warm" : "cold", lres,
+                             1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tb1).count());
+        }
+        goto done;
+    }
     {
         // Deflate span(Y) only where it IS the near-kernel of S, i.e. at (near-)stationary points:
         // |S*Y|_F is the Riemannian gradient norm.  Away from stationarity the spectrum has no cluster
@@ -895,10 +1044,11 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
         // ---- final Rayleigh-Ritz on Z = [Q_Y | X]: recouples the blocks when S*Y is only approximately zero
         const int nz = r;
         ESC_HIP(hipMemcpyAsync(Z, Q, (size_t)nz * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        // ... and measures how far span(Z) is from invariant: coupling = |(I - ZZ') S Z|_F, from which a LOWER bound of
+        // ... and measures how far span(Z) is from invariant: coupling = |(I - ZZ') S Z|_F, from which a lower ESTIMATE of
         // lambda_min follows (Weyl): S = [A E'; E B] in the basis [Z, complement], lambda_min(S) >= min(lambda_min(A),
-        // lambda_min(B)) - |E|_2, with A = Z'SZ known exactly, lambda_min(B) >= theta - res of the last (converged,
-        // non-negative) run, |E|_2 <= |E|_F.  The bound is what lets a caller declare dinf < tol without another run.
+        // lambda_min(B)) - |E|_2, with A = Z'SZ known exactly and |E|_2 <= |E|_F; lambda_min(B) is taken as theta - res of
+        // the last (converged, non-negative) run -- an estimate: a converged Ritz pair proves that some eigenvalue of B lies
+        // within res of theta, not that none lies below.
         std::vector<double> M((size_t)nz * nz, 0.0), col(nz + 1);
         double coupling2 = 0.0;
         for (int j = 0; j < nz; ++j) {
@@ -939,7 +1089,9 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
             }
         }
         h->esc_nvalid = nout;
-        if (complement_nonneg && nz > 0)
+        // reported only for a cold-started, undeflated call (the independent check of the host loops): a deflated or
+        // warm-started run that missed the bottom of the spectrum would report a bound that is too high
+        if (complement_nonneg && nz > 0 && !h->tune.escape_deflate && !h->tune.escape_warm)
             h->esc_lower = std::min(ew[eo[0]], last_theta - last_res) - sqrt(coupling2);
         if (dbg) fprintf(stderr, "[escape] Rayleigh-Ritz bottom %.6e, complement theta %.6e (res %.1e), coupling %.3e -> lower bound %.6e\n",
                          nz > 0 ? ew[eo[0]] : 0.0, last_theta, last_res, sqrt(coupling2), h->esc_lower);

@@ -263,6 +263,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         const int rc = msdp_get_kind(h, &k);
         if (rc) fail("get_kind", rc);
         plhs[0] = mxCreateDoubleScalar((double)k);
+    } else if (cmd == "escape_method") {
+        int32_t mth = 0;
+        const int rc = msdp_escape_method(h, &mth);
+        if (rc) fail("escape_method", rc);
+        plhs[0] = mxCreateDoubleScalar((double)mth);
     } else if (cmd == "set_option") {
         need(nrhs == 4 && mxIsChar(prhs[2]), "manisdp_mex('set_option', h, name, value)");
         char name[64];

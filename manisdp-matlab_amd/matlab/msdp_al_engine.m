@@ -94,21 +94,21 @@ for iter = 1:opt.AL_maxiter
         y = y - sigma*resid;
         z = manisdp_mex('al_dual', h, y);
         by = bvec'*y + sum(z);                 % sum([]) = 0 for the generic kind
-        [lam, V, lam_top, okflag, lam_lower] = manisdp_mex('escape_eigs_dual', h, opt.delta, opt.eig_tol, opt.eig_maxit);
+        [lam, V, lam_top, okflag] = manisdp_mex('escape_eigs_dual', h, opt.delta, opt.eig_tol, opt.eig_maxit);
         gap = abs(obj - by)/(abs(by) + abs(obj) + 1);
     else
         z = manisdp_mex('get_z', h);
         obj = sum(z);
-        [lam, V, lam_top, okflag, lam_lower] = manisdp_mex('escape_eigs', h, opt.delta, opt.eig_tol, opt.eig_maxit);
+        [lam, V, lam_top, okflag] = manisdp_mex('escape_eigs', h, opt.delta, opt.eig_tol, opt.eig_maxit);
     end
     certified = (okflag ~= 0);                 % a Lanczos run that ran out of steps certifies nothing
     dinf = max(0, -lam(1))/(1 + lam_top);
     if T.affine, eta_now = max([gap, pinf, dinf]); else, eta_now = dinf; end
-    proven = eta_now < opt.tol && max(0, -lam_lower)/(1 + lam_top) < opt.tol;    % Weyl bound of the same call
-    if certified && ~proven && (eta_now < opt.tol || iter == opt.AL_maxiter)
-        % The regular escape call deflates span(Y) and starts from the previous call's vectors: fast, but only as
-        % accurate as S*Y is small.  Before dinf may end the solve (and on the last pass, so that the reported dinf
-        % is the true one) lambda_min is recomputed by plain Lanczos on S: no deflation, random start.
+    if certified && (eta_now < opt.tol || iter == opt.AL_maxiter)
+        % The regular escape call is warm-started (columns of Y and the previous call's vectors in its start block, or
+        % span(Y) deflated): fast, but its lambda_min is an estimate.  Before dinf may end the solve -- always; the
+        % estimate of the same call is never taken as a certificate -- and on the last pass, so that the reported dinf
+        % is the true one, lambda_min is recomputed by a cold-started, undeflated run on S.
         [lam1, v1, top1, okflag] = independent_lambda_min(h, T.affine, n, opt);
         certified = (okflag ~= 0);
         dcheck = max(0, -lam1)/(1 + top1);
@@ -261,8 +261,9 @@ end
 % -------------------------------------------------------------------------
 function [lam1, v1, top1, okflag] = independent_lambda_min(h, affine, n, opt)
 % Affine kinds with a dense S of moderate order: the reference's own eig(S) on the S the device holds.  Otherwise
-% plain Lanczos on the device (no deflation of span(Y), nothing reused from earlier calls, start vector = random
-% combination of the columns of Y plus noise; twice if the first budget runs out).
+% a cold-started run on the device: nothing deflated, nothing reused from earlier calls -- the block eigen-solver from
+% hashed noise (sparse C), or plain Lanczos from a random combination of the columns of Y plus noise; twice if the first
+% budget runs out.
 if ~isfield(opt, 'verify_dense_max'), opt.verify_dense_max = 4000; end
 if affine && n <= opt.verify_dense_max
     S = manisdp_mex('get_dual_slack', h);
@@ -272,7 +273,8 @@ if affine && n <= opt.verify_dense_max
 end
 manisdp_mex('set_option', h, 'escape_deflate', 0);
 manisdp_mex('set_option', h, 'escape_warm', 0);
-manisdp_mex('set_option', h, 'escape_start_y', 1);
+% block eigen-solver (sparse C): hashed noise only; Lanczos path: span(Y) + 5 % noise
+manisdp_mex('set_option', h, 'escape_start_y', double(manisdp_mex('escape_method', h) ~= 1));
 restore = onCleanup(@() cellfun(@(nm, v) manisdp_mex('set_option', h, nm, v), {'escape_deflate', 'escape_warm', 'escape_start_y'}, {1, 1, 0})); %#ok<NASGU>
 if affine, cmd = 'escape_eigs_dual'; else, cmd = 'escape_eigs'; end
 [lam1, v1, top1, okflag] = manisdp_mex(cmd, h, 1, opt.eig_tol, opt.eig_maxit);

@@ -1,0 +1,137 @@
+"""GPU tests of the block eigen-solver of the saddle escape (msdp_blockeig.hip: Chebyshev-filtered subspace iteration on a
+64- / 128-wide panel) against the reference's dense eig(full(S)) (ManiSDP_onlyunitdiag.m:49-51) computed with LAPACK on the
+same S = C - diag(z), through the C ABI (msdp_escape_eigs)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from manisdp_matlab_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def _reference(C, h):
+    z = h.get_z()
+    S = (C - sp.diags(z)).toarray()
+    w, U = np.linalg.eigh(S)
+    return S, w, U
+
+
+def _check_pairs(S, w, lam, V, lmax, k, tol_val, tol_res):
+    scale = max(abs(w[0]), abs(w[-1]))
+    assert abs(lmax - w[-1]) <= 1e-6 * scale
+    assert abs(lam[0] - w[0]) <= tol_val * scale
+    for t in range(k):
+        if lam[t] < -1e-9 * scale or t == 0:
+            v = V[:, t]
+            assert abs(np.linalg.norm(v) - 1.0) < 1e-8
+            assert np.min(np.abs(w - lam[t])) <= 10 * tol_val * scale
+            assert np.linalg.norm(S @ v - lam[t] * v) <= tol_res * scale
+    # the returned values are the BOTTOM of the spectrum, in order
+    assert np.all(np.diff(lam[np.isfinite(lam)]) >= -1e-12 * scale)
+    nneg = int(np.sum(w < -1e-7 * scale))
+    assert int(np.sum(lam < -1e-7 * scale)) == min(nneg, k)
+
+
+@pytest.mark.parametrize("p", [6, 30, 60])
+def test_block_escape_matches_lapack_on_a_grid(lib, p):
+    """Toroidal grid (ELL rows, the G81 family), n = 6000: a random point (S*Y != 0), then a near-stationary one; warm
+    calls and the cold-started check; p = 60 takes the 128-wide panel."""
+    from manisdp_matlab_amd import problems
+    C = problems.toroidal_grid_maxcut(60, 100, seed=9)
+    n = C.shape[0]
+    rng = np.random.default_rng(p)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    h = lib.Handle.onlyunitdiag(C, pcap=64)
+    h.set_point(Y)
+    S, w, _ = _reference(C, h)
+    lam, V, lmax, deg = h.escape_eigs(8, tol=1e-9, maxit=60000)
+    assert h.escape_method() == 1
+    nvalid, conv, _ = h.escape_info()
+    assert conv and nvalid == 8
+    assert h.escape_lower_bound() == -np.inf                   # a warm call never reports a bound
+    _check_pairs(S, w, lam, V, lmax, 8, 2e-3, 2e-2)            # escape directions: 2 % of |theta| asked
+    h.rtr(lib.default_opts(maxiter=60, maxinner=200, tolgradnorm=1e-9))
+    S, w, _ = _reference(C, h)
+    lam, V, lmax, deg2 = h.escape_eigs(8, tol=1e-9, maxit=60000)
+    _, conv, _ = h.escape_info()
+    assert conv
+    _check_pairs(S, w, lam, V, lmax, 8, 2e-3, 2e-2)
+    # the independent check: cold start, nothing of Y, four times tighter
+    h.set_option("escape_deflate", 0); h.set_option("escape_warm", 0); h.set_option("escape_start_y", 0)
+    lam1, V1, lmax1, deg3 = h.escape_eigs(1, tol=1e-9, maxit=60000)
+    _, conv, _ = h.escape_info()
+    assert conv
+    scale = max(abs(w[0]), abs(w[-1]))
+    assert abs(lam1[0] - w[0]) <= 1e-9 * scale
+    assert np.linalg.norm(S @ V1[:, 0] - lam1[0] * V1[:, 0]) <= 1e-5 * scale
+    lb = h.escape_lower_bound()
+    assert np.isfinite(lb) and lb <= lam1[0] and lam1[0] - lb <= 1e-8 * scale
+    h.close()
+
+
+def test_block_escape_long_rows_and_small_n(lib):
+    """G1 (n = 800, ~48 entries per row: the CSR gather, no ELL copy), forced onto the block path."""
+    from manisdp_matlab_amd import problems
+    C = problems.maxcut_cost_matrix(golden_path("G1.txt.gz"))
+    n = C.shape[0]
+    rng = np.random.default_rng(0)
+    for p in (2, 10):
+        Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+        h = lib.Handle.onlyunitdiag(C)
+        h.set_option("escape_method", 2)
+        h.set_point(Y)
+        h.rtr(lib.default_opts(maxiter=40, maxinner=100, tolgradnorm=1e-8))
+        S, w, _ = _reference(C, h)
+        lam, V, lmax, deg = h.escape_eigs(8, tol=1e-9, maxit=60000)
+        assert h.escape_method() == 1
+        _, conv, _ = h.escape_info()
+        assert conv
+        _check_pairs(S, w, lam, V, lmax, 8, 2e-3, 2e-2)
+        assert lam[0] < 0                                       # rank-p stationary points of G1 are saddles for small p
+        h.close()
+
+
+def test_block_and_lanczos_paths_agree(lib):
+    """The two eigen-solvers on the same S at a near-stationary point: same lambda_min / lambda_max / dinf."""
+    from manisdp_matlab_amd import problems
+    C = problems.toroidal_grid_maxcut(50, 80, seed=2)
+    n, p = C.shape[0], 12
+    rng = np.random.default_rng(5)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    out = []
+    for method in (1, 2):
+        h = lib.Handle.onlyunitdiag(C)
+        h.set_option("escape_method", method)
+        h.set_point(Y)
+        h.rtr(lib.default_opts(maxiter=40, maxinner=100, tolgradnorm=1e-8))
+        h.set_option("escape_deflate", 0); h.set_option("escape_warm", 0)
+        lam, V, lmax, _ = h.escape_eigs(1, tol=1e-10, maxit=60000)
+        assert h.escape_method() == method - 1
+        out.append((lam[0], lmax))
+        h.close()
+    assert abs(out[0][0] - out[1][0]) <= 1e-8 * out[0][1]
+    assert abs(out[0][1] - out[1][1]) <= 1e-6 * out[0][1]
+
+
+def test_block_escape_budget_exhausted_is_reported(lib):
+    from manisdp_matlab_amd import problems
+    C = problems.toroidal_grid_maxcut(60, 100, seed=9)
+    n, p = C.shape[0], 8
+    rng = np.random.default_rng(4)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    h = lib.Handle.onlyunitdiag(C)
+    h.set_point(Y)
+    h.set_option("escape_deflate", 0); h.set_option("escape_warm", 0)
+    lam, V, lmax, deg = h.escape_eigs(4, tol=1e-13, maxit=64)     # 64 filter steps cannot reach 1e-13
+    nvalid, conv, res = h.escape_info()
+    assert not conv and res > 1e-13 and nvalid == 4
+    assert h.escape_lower_bound() == -np.inf
+    h.close()

@@ -102,6 +102,7 @@ def test_onesync_lanczos_matches_twosync_kernel(lib):
     out = []
     for one in (1, 0):
         h = lib.Handle.onlyunitdiag(C)
+        h.set_option("escape_method", 1)                      # the Lanczos path (n = 6000 would take the block eigen-solver)
         h.set_option("lanczos_onesync", one)
         h.set_option("escape_deflate", 0)
         h.set_option("escape_warm", 0)
@@ -134,6 +135,7 @@ def test_deflation_columns_read_in_place_are_bit_identical(lib):
     out = []
     for inplace in (0, 1):
         h = lib.Handle.onlyunitdiag(C)
+        h.set_option("escape_method", 1)
         h.set_option("lanczos_qglobal", inplace)
         h.set_option("escape_warm", 0)
         h.set_point(Y)
