@@ -14,7 +14,8 @@ all-gather of the thin n x p direction before every S*U and an all-reduce of the
 sums; the instance is the same toroidal-grid family scaled to n = 20000 * N rows so the
 per-GPU work is fixed ("weak" scaling); value counts 20000-row-equivalent Hess-vecs.  The same K steps are then timed once
 more with the halo exchange (option halo_exchange: only the rows a rank's rows of C reference travel, bit-identical results);
-both figures are in the line under "row_exchange", `value` is the faster one and config.row_exchange names it.
+both figures are in the line under "row_exchange"; `value` is the all-gather figure unless --row-exchange halo asks for the
+other one (fixed by configuration, never best-of), and config.row_exchange names it.
 
 One JSON line is printed by rank 0.
 """
@@ -30,6 +31,10 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# every cpu_baseline entry is the build's own CPU restatement of the reference's .m logic: MATLAB / Octave exist neither here
+# nor on the GPU box, so the reference's interpreter path itself cannot be timed
+PORT_DETAIL = "port (C/OpenMP restatement, oracle/oracle_core.c; MATLAB unavailable)"
+PORT_DETAIL_NUMPY = "port (NumPy/SciPy restatement, oracle/manisdp_ref.py; MATLAB unavailable)"
 
 
 def cpu_baseline(C, Y0, budget_s=15.0):
@@ -47,7 +52,7 @@ def cpu_baseline(C, Y0, budget_s=15.0):
         if time.time() - t1 > budget_s / 2:       # one call already uses most of the budget
             break
     dt = time.time() - t0
-    return {"value": hv / dt, "unit": "Hess-vec/s", "cores": core.num_threads(), "kind": "port",
+    return {"value": hv / dt, "unit": "Hess-vec/s", "cores": core.num_threads(), "kind": "port", "kind_detail": PORT_DETAIL,
             "sample": f"{reps} full RTR calls ({hv} Hess-vecs incl. all tCG vector work, retractions and cost "
                       f"evaluations) of the same G81 p={Y0.shape[1]} step in the C/OpenMP oracle, {dt:.1f} s"}
 
@@ -71,7 +76,7 @@ def cpu_dense_hessvec(n, p, budget_s=3.0):
         cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
     except Exception:                                     # pragma: no cover
         cores = os.cpu_count()
-    return {"value": 1.0 / dt, "unit": "Hess-vec/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / dt, "unit": "Hess-vec/s", "cores": cores, "kind": "port", "kind_detail": PORT_DETAIL_NUMPY,
             "sample": "%d NumPy (BLAS dgemm) Hess-vecs of the oracle, dense C n=%d p=%d" % (reps, n, p)}
 
 
@@ -96,7 +101,7 @@ def affine_shapes(_lib, problems, with_cpu):
             cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
         except Exception:                                     # pragma: no cover
             cores = os.cpu_count()
-        return {"value": 1.0 / dt, "unit": "Hess-vec/s", "cores": cores, "kind": "port",
+        return {"value": 1.0 / dt, "unit": "Hess-vec/s", "cores": cores, "kind": "port", "kind_detail": PORT_DETAIL_NUMPY,
                 "sample": "%d Hess-vecs of the oracle's %s closures (NumPy BLAS threads; the SciPy sparse products are serial)" % (reps, label)}
 
     for name in ("bqp60", "theta5000"):
@@ -155,6 +160,9 @@ def main():
     ap.add_argument("--no-kkt", action="store_true", help="skip the full G81 solve to KKT 1e-8")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-C (fp64 MFMA) Hess-vec figure")
     ap.add_argument("--no-affine", action="store_true", help="skip the Hess-vec figures of the affine configurations (BQP d = 60, theta n = 5000)")
+    ap.add_argument("--row-exchange", choices=("allgather", "halo"), default="allgather",
+                    help="N > 1: which exchange in front of S*U `value` is quoted on (both legs are timed and reported): the "
+                         "all-gather of the whole direction north_star prescribes (default), or the halo exchange")
     ap.add_argument("--force-comm", action="store_true",
                     help="diagnostic: run the N = 1 workload through the RCCL code path of the multi-GPU run "
                          "(size-1 communicator: all-gather + all-reduces per trip, chunked tCG)")
@@ -285,14 +293,21 @@ def main():
         for name in names:
             f = os.path.join(ROOT, "profiles", name)
             if N == 1 and p == 32 and os.path.exists(f):
-                return json.load(open(f))
+                rec = json.load(open(f))
+                rec["_source"] = "profiles/" + name
+                return rec
         return None
-    pm_h = pmc("r2_pmc_hess_g81_p32.json", "r1_pmc_hess_g81_p32.json")
-    pm_t = pmc("r2_pmc_persist_g81_p32.json", "r1_pmc_persist_g81_p32.json")
+    # HBM traffic comes from rocprofv3 --pmc passes (their own runs: counters cannot be collected inside a timed run);
+    # the line carries the committed summary's value together with the file it was read from
+    pm_h = pmc("r3_pmc_hess_g81_p32.json", "r2_pmc_hess_g81_p32.json", "r1_pmc_hess_g81_p32.json")
+    pm_t = pmc("r3_pmc_persist_g81_p32.json", "r2_pmc_persist_g81_p32.json", "r1_pmc_persist_g81_p32.json")
     if persistent:
         traffic = (pm_t or {}).get("hbm_bytes_per_trip")
         roofline = {"bound": "hbm", "achieved": trip_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": trip_achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": (pm_t or {}).get("_source"),
+                    "traffic_note": "replayed from the committed rocprofv3 --pmc summary of the same kernel and workload, not "
+                                    "measured in this run",
                     "kernel": "k_tcg_persist_obl", "kernel_us": trip_ms * 1e3, "per": "tCG trip (one Hess-vec)",
                     "algorithmic_bytes_per_launch": abytes,
                     "streaming_formulation_bytes_per_trip": streaming_trip_bytes,
@@ -304,10 +319,11 @@ def main():
     else:
         roofline = {"bound": "hbm", "achieved": hess_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hess_achieved / HBM_PEAK_GBS, "traffic": (pm_h or {}).get("hbm_bytes_per_launch"),
+                    "traffic_source": (pm_h or {}).get("_source"),
                     "kernel": "k_hess_ell_obl", "kernel_us": ms * 1e3, "algorithmic_bytes_per_launch": abytes}
     hess_kernel = {"kernel": "k_hess_ell_obl", "kernel_us": ms * 1e3, "algorithmic_bytes_per_launch": abytes,
                    "achieved_GBps": hess_achieved, "frac_of_hbm_peak": hess_achieved / HBM_PEAK_GBS,
-                   "traffic": (pm_h or {}).get("hbm_bytes_per_launch")}
+                   "traffic": (pm_h or {}).get("hbm_bytes_per_launch"), "traffic_source": (pm_h or {}).get("_source")}
 
     out = {
         "metric": "tCG Hess-vec prods/sec (n,p), G81 MaxCut",
@@ -369,6 +385,7 @@ def main():
                           "note": "dinf is confirmed by a plain Lanczos run (no deflation, nothing reused from earlier calls) before the solve "
                                   "stops; that run is inside seconds_to_dinf_1e-8 and escape_seconds"}
     h.close()
+    _lib.release_cache()         # the parked escape workspace: the dense shapes below allocate up to 160 GB of their own
     if not args.no_dense and N == 1 and rank == 0 and not args.force_comm:
         # The dense tall-skinny contraction S*U is the one place the path uses the matrix cores (north_star): report its
         # fp64 MFMA and HBM fractions on the dense-C shapes of BASELINE configs 4 / 5 (synthetic symmetric C, seed 0).
@@ -434,17 +451,13 @@ def main():
             # travel before S*U -- 400 of 20000*N rows on this family -- instead of the all-gather of the whole direction).
             # Results are bit-identical (tests/test_gpu_local_ranks.py); the all-gather figure above was taken first and
             # stays in the line, so a failure of this leg costs nothing.
-            try:
-                hl = halo_leg(_lib, join, sync, allmax, N, rank, C, Y0, p, opts, args.steps, args.warmup)
-                out["row_exchange"] = {"all_gather": {"value": out["value"], "ms_per_step": out["ms_per_step"]}, "halo": hl}
-                if hl["hessvecs"] == hv and hl["value"] > out["value"]:
-                    out["value"], out["ms_per_step"] = hl["value"], hl["ms_per_step"]
-                    out["config"]["row_exchange"] = "halo (option halo_exchange): grouped ncclSend/ncclRecv of the referenced rows"
-                else:
-                    out["config"]["row_exchange"] = "all-gather"
-            except Exception as e:  # noqa: BLE001
-                out["row_exchange"] = {"error": "%s: %s" % (type(e).__name__, e)}
-                out["config"]["row_exchange"] = "all-gather"
+            # Which of the two is `value` is fixed by --row-exchange, never chosen after the fact.
+            hl = halo_leg(_lib, join, sync, allmax, N, rank, C, Y0, p, opts, args.steps, args.warmup)
+            out["row_exchange"] = {"all_gather": {"value": out["value"], "ms_per_step": out["ms_per_step"]}, "halo": hl}
+            out["config"]["row_exchange"] = "all-gather"
+            if args.row_exchange == "halo" and "error" not in hl and hl["hessvecs"] == hv:
+                out["value"], out["ms_per_step"] = hl["value"], hl["ms_per_step"]
+                out["config"]["row_exchange"] = "halo (option halo_exchange): grouped ncclSend/ncclRecv of the referenced rows"
         if not args.no_dense:
             try:
                 out["k5_dense_sharded"] = k5_dense_sharded(_lib, join, sync, allmax, N, rank)
@@ -463,11 +476,27 @@ def halo_leg(_lib, join, sync, allmax, N, rank, C, Y0, p, opts, steps, warmup):
     """The timed region of main() once more on a fresh handle with the halo exchange in front of S*U.  `join(h)` makes the handle
     a member of the job's communicator, `sync()` is the barrier + device synchronisation of main(), `allmax(x)` the maximum
     of x over the ranks (closures, so that tests can drive this on in-process ranks)."""
-    h = _lib.Handle.onlyunitdiag(C, pcap=p)
-    join(h)
-    h.set_option("halo_exchange", 1)
-    h.set_point(Y0)
-    h.point_snapshot()
+    # Set-up (allocations, the halo lists and buffers) may fail on ONE rank only: every rank reports its outcome and all of
+    # them skip the timed collectives together -- a rank that raised alone would leave the others waiting in ncclSend/ncclRecv.
+    h, err = None, None
+    try:
+        h = _lib.Handle.onlyunitdiag(C, pcap=p)
+    except Exception as e:  # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+    if allmax(0.0 if err is None else 1.0) > 0.0:           # communicator set-up is a collective itself: only if everybody has a handle
+        if h is not None:
+            h.close()
+        return {"error": err or "another rank failed to create its handle"}
+    try:
+        join(h)
+        h.set_option("halo_exchange", 1)
+        h.set_point(Y0)
+        h.point_snapshot()
+    except Exception as e:  # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+    if allmax(0.0 if err is None else 1.0) > 0.0:
+        h.close()
+        return {"error": err or "another rank failed to set the halo exchange up"}
     for _ in range(max(1, warmup)):
         h.point_restore()
         h.rtr(opts)

@@ -301,7 +301,8 @@ int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const void* id12
  * row offsets, replicated operator state, lock-step tCG, order and number of collective calls -- with the three
  * collectives carried out by a host barrier and device copies / a summation kernel between the members' buffers, so a
  * single GPU executes the N-rank paths.  A member that never makes the matching call breaks the group after 120 s
- * (MSDP_ECOMM) instead of hanging the process. */
+ * (MSDP_ECOMM; environment variable MSDP_LOCAL_BARRIER_TIMEOUT = seconds, for legitimately slow members on a loaded GPU)
+ * instead of hanging the process; a member that detects an error itself breaks the group at once. */
 int msdp_comm_init_local(msdp_handle h, int32_t nranks, int32_t rank, int32_t group_id);
 /* Local row range [row0, row1) of this rank. */
 int msdp_local_rows(msdp_handle h, int64_t* row0, int64_t* row1);

@@ -133,7 +133,16 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # the library parks one escape workspace per process between handles (msdp_release_cache): give it back when the
+    # interpreter exits, and let callers do so earlier (release_cache()) before large allocations of their own
+    import atexit
+    atexit.register(lambda: lib.msdp_release_cache())
     return lib
+
+
+def release_cache():
+    """Free the device memory the library keeps between handles (the parked Lanczos workspace of the escape)."""
+    _check(load().msdp_release_cache())
 
 
 def _check(rc):

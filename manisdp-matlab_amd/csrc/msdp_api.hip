@@ -844,14 +844,30 @@ struct LocalGroup {
 };
 static std::mutex g_groups_mutex;
 static std::map<int, LocalGroup*> g_groups;
-// false: a member did not arrive within 120 s (it failed or never made the matching call) -- the group is broken and every
-// later collective fails at once instead of hanging the process
+// false: a member did not arrive within the time limit (it failed or never made the matching call) -- the group is broken and
+// every later collective fails at once instead of hanging the process.  The limit is 120 s unless MSDP_LOCAL_BARRIER_TIMEOUT
+// (seconds) says otherwise: eight replicated 60000-step verification runs sharing one loaded GPU are legitimately slow.
+static double local_barrier_timeout() {
+    static const double t = [] {
+        const char* e = getenv("MSDP_LOCAL_BARRIER_TIMEOUT");
+        const double v = e ? atof(e) : 0.0;
+        return v > 0.0 ? v : 120.0;
+    }();
+    return t;
+}
+// a member that fails between two barriers marks the group broken at once, so that its peers do not wait out the time limit
+static void local_break(LocalGroup* g) {
+    if (!g) return;
+    std::lock_guard<std::mutex> lk(g->m);
+    g->broken = true;
+    g->cv.notify_all();
+}
 static bool local_barrier(LocalGroup* g) {
     std::unique_lock<std::mutex> lk(g->m);
     if (g->broken) return false;
     const unsigned long long my = g->gen;
     if (++g->arrived == g->n) { g->arrived = 0; ++g->gen; g->cv.notify_all(); return true; }
-    if (!g->cv.wait_for(lk, std::chrono::seconds(120), [&] { return g->gen != my || g->broken; }) || g->broken) {
+    if (!g->cv.wait_for(lk, std::chrono::duration<double>(local_barrier_timeout()), [&] { return g->gen != my || g->broken; }) || g->broken) {
         g->broken = true;
         g->cv.notify_all();
         return false;
@@ -908,7 +924,11 @@ static int local_halo(msdp_handle h, Halo* ha, int ld) {
     for (int q = 0; q < g->n; ++q) {
         if (q == h->rank || ha->recv_cnt[q] == 0) continue;
         const Halo* pq = g->halo[q];
-        if (pq->send_cnt[h->rank] != ha->recv_cnt[q]) { msdp_set_error("halo exchange: rank %d sends %d rows, rank %d expects %d", q, pq->send_cnt[h->rank], h->rank, ha->recv_cnt[q]); return MSDP_ECOMM; }
+        if (pq->send_cnt[h->rank] != ha->recv_cnt[q]) {
+            msdp_set_error("halo exchange: rank %d sends %d rows, rank %d expects %d", q, pq->send_cnt[h->rank], h->rank, ha->recv_cnt[q]);
+            local_break(g);                                    // the peers learn at once, not after the barrier's time limit
+            return MSDP_ECOMM;
+        }
         HIPCHK(hipMemcpyAsync(ha->recvbuf + (size_t)ha->recv_off[q] * ld, g->ptr[q] + (size_t)pq->send_off[h->rank] * ld,
                               (size_t)ha->recv_cnt[q] * ld * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }

@@ -776,6 +776,13 @@ void msdp_escape_workspace_park(double* ptr, size_t cap_doubles) {
     if (!ptr) return;
     int dev = -1;
     (void)hipGetDevice(&dev);
+    // Nothing larger than an eighth of the device memory (36 GB of 288) is kept beyond the life of its handle: other users of
+    // the GPU in the same process (torch in bench.py, MATLAB's own gpuArrays) must not find the memory gone
+    {
+        size_t freeb = 0, totb = 0;
+        if (hipMemGetInfo(&freeb, &totb) != hipSuccess) { (void)hipGetLastError(); totb = 0; }
+        if (totb && cap_doubles * sizeof(double) > totb / 8) { (void)hipFree(ptr); return; }
+    }
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     if (g_ws_ptr && g_ws_cap >= cap_doubles && g_ws_dev == dev) { (void)hipFree(ptr); return; }    // keep the larger one
     if (g_ws_ptr) (void)hipFree(g_ws_ptr);

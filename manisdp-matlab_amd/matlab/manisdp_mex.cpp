@@ -170,6 +170,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (mxGetString(prhs[0], cmdbuf, sizeof(cmdbuf))) mexErrMsgIdAndTxt("ManiSDP:hip:cmd", "command string too long");
     const std::string cmd(cmdbuf);
 
+    if (cmd == "release_cache") {              // device memory the library keeps between handles (the parked escape workspace)
+        msdp_release_cache();
+        return;
+    }
     // ---------------------------------------------------------------- construction
     if (cmd == "create_onlyunitdiag") {
         need(nrhs == 2, "h = manisdp_mex('create_onlyunitdiag', C)");
