@@ -119,6 +119,10 @@ int msdp_debug_set_full_rows(msdp_handle h, const double* rows_host);
  * buffers.  Lets a single-GPU box run the RCCL half of the exchange; the send / receive lists are covered by the
  * in-process ranks (tests/test_gpu_local_ranks.py). */
 int msdp_debug_p2p_self(msdp_handle h, int64_t count, const double* in_host, double* out_host);
+/* Test-only: eta and Heta of the last tCG solve of msdp_rtr (reference layout), valid after a call with maxiter = 1 on the
+ * chunked path or on the persistent path with option fused_rtr = 0.  Lets a test check tCG's invariant Heta = Hess(eta)
+ * (tCG.m:192-220) on the device, i.e. bound what the persistent kernel's linearity trick for C*mdelta may drift. */
+int msdp_debug_get_tcg_step(msdp_handle h, double* eta, double* Heta);
 /* Test-only, host code only (no GPU touched): the dense symmetric eigen-solver (Householder + implicit QL; w ascending, row i
  * of Z = eigenvector i) and the generalised Rayleigh-Ritz problem H c = theta G c (theta ascending, +inf beyond *rank; W b x b
  * row-major, column j = coefficients of Ritz vector j, W'GW = I on the first *rank columns) of the block eigen-solver. */
@@ -338,6 +342,8 @@ int msdp_get_dual_slack_block(msdp_handle h, int64_t row0, int64_t nb, double* S
  *   "escape_deflate" 1/0 escape: deflate span(Y) at near-stationary points (default 1).  Fast, but only as accurate as
  *                       S*Y is small; a caller about to DECLARE optimality re-checks lambda_min with 0 (see solvers.py)
  *   "escape_warm"  1/0  escape: start from what the previous call found (default 1; 0 = hashed random start vector)
+ *   "trip2"        1/0  chunked path, sparse C / oblique manifold / one rank: two launches per tCG trip (12 vector passes,
+ *                       msdp_trip2.hip) instead of three (17 passes) (default 1; 0 for A/B timing and tests)
  *   "escape_method" 0 = block eigen-solver where it applies (sparse C, n >= 2048), Lanczos otherwise (default); 1 = Lanczos
  *                       always; 2 = block also for small n (tests)
  *   "be_width" 0/32/64/128, "be_degree", "be_grid", "be_lpr"  block eigen-solver: panel width, filter degree per round,

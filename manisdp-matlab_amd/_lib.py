@@ -83,6 +83,7 @@ SIGNATURES = {
     "msdp_escape_info": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _dp]),
     "msdp_escape_lower_bound": (C.c_int, [C.c_void_p, _dp]),
     "msdp_escape_method": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "msdp_debug_get_tcg_step": (C.c_int, [C.c_void_p, _dp, _dp]),
     "msdp_debug_sym_eig": (C.c_int, [C.c_int32, _dp, _dp, _dp]),
     "msdp_debug_ritz": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _P(C.c_int32)]),
     "msdp_get_dual_slack": (C.c_int, [C.c_void_p, _dp]),
@@ -408,6 +409,12 @@ class Handle:
 
     def retr(self, U):
         return self._vec_op(self._lib.msdp_retr, U)
+
+    def debug_get_tcg_step(self):
+        """(eta, Heta) of the last tCG solve (test hook, see msdp_debug_get_tcg_step)."""
+        eta, heta = self._empty(), self._empty()
+        _check(self._lib.msdp_debug_get_tcg_step(self._h, _dptr(eta), _dptr(heta)))
+        return np.ascontiguousarray(eta), np.ascontiguousarray(heta)
 
     def get_z(self):
         z = np.zeros(self.n)

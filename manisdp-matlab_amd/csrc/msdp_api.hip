@@ -117,7 +117,7 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
     const size_t rows = (size_t)rows_capacity(h);
     const size_t cnt = rows * (size_t)ldcap;
     double** vecs[] = {&d.Y[0], &d.Y[1], &d.Gr[0], &d.Gr[1], &d.eta[0], &d.eta[1], &d.Heta[0], &d.Heta[1],
-                       &d.r, &d.md, &d.md2, &d.Hmd, &d.W0, &d.W1};
+                       &d.r, &d.r2, &d.md, &d.md2, &d.Hmd, &d.W0, &d.W1};
     if (h->full_buf) dev_free(h, h->full_buf);
     h->full_buf = nullptr;
     d.full = nullptr;
@@ -745,6 +745,22 @@ extern "C" int msdp_get_point(msdp_handle h, double* Y) {
     return download_rows(h, h->d.Y[host_cur(h)], Y);
 }
 
+// Test-only: eta and Heta as the LAST tCG solve of msdp_rtr left them (tCG.m:95: [eta, Heta, ...] = tCG(...)); meaningful after
+// a call with maxiter = 1 on the paths that hand the step over through global memory (chunked path, persistent kernel with the
+// option fused_rtr = 0).  tCG keeps Heta = Hess(eta) by linearity (tCG.m:192-220); tests/test_gpu_onlyunitdiag.py bounds the
+// deviation of the persistent kernel, whose Hess-vecs are assembled as C*r_new + beta*C*mdelta_old (msdp_persist.hip, TWOSYNC).
+extern "C" int msdp_debug_get_tcg_step(msdp_handle h, double* eta, double* Heta) {
+    CHECK_H(h);
+    if (!h->have_point || !eta || !Heta) { msdp_set_error("debug_get_tcg_step: no resident point / null out"); return MSDP_ESTATE; }
+    Frame f;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(&f, &h->d.F[0], sizeof(Frame), hipMemcpyDeviceToHost));
+    const int ix = f.eta_idx ? 1 : 0;
+    int rc = download_rows(h, h->d.eta[ix], eta);
+    if (!rc) rc = download_rows(h, h->d.Heta[ix], Heta);
+    return rc;
+}
+
 // Every row of the resident point on every rank (one all-gather, then the download): the host loops of the row-sharded
 // affine kinds run replicated on all ranks and need identical inputs for their rank / escape decisions.
 extern "C" int msdp_get_point_all(msdp_handle h, double* Y) {
@@ -785,6 +801,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "escape_deflate")) t.escape_deflate = value != 0;
     else if (!strcmp(name, "escape_warm")) t.escape_warm = value != 0;
     else if (!strcmp(name, "escape_start_y")) t.escape_start_y = value != 0;
+    else if (!strcmp(name, "trip2")) { t.trip2 = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "escape_method")) { if (value < 0 || value > 2) { msdp_set_error("escape_method: 0 auto, 1 lanczos, 2 block"); return MSDP_EINVAL; } t.escape_method = value; }
     else if (!strcmp(name, "be_width")) { if (value != 0 && value != 32 && value != 64 && value != 128) { msdp_set_error("be_width: 0, 32, 64 or 128"); return MSDP_EINVAL; } t.be_width = value; }
     else if (!strcmp(name, "be_degree")) t.be_degree = value > 0 ? value : 0;
@@ -1286,8 +1303,24 @@ static void fill_ctl(msdp_handle h, const msdp_rtr_opts* o) {
 #define TCG_CHUNK 8           // tCG trips per enqueued chunk (one hipGraph of 3 x 8 kernel nodes)
 static bool use_graphs(msdp_handle h) { return h->tune.graph && !h->use_comm; }
 
+// Start of a tCG (tCG.m:102-157).  Two-launch trips (msdp_trip2.hip): the Hess-vec of trip j+1 rides in the launch that closes
+// trip j, so the first one is issued here, behind the initialisation.
+static int tcg_begin(msdp_handle h) {
+    if (msdp_trip2_ok(h)) {
+        int rc = msdp_launch_trip2_init(h);
+        return rc ? rc : msdp_launch_trip2_head(h);
+    }
+    return msdp_launch_tcg_init(h);
+}
 static int enqueue_trips(msdp_handle h, int cnt) {
     int rc;
+    if (msdp_trip2_ok(h)) {
+        for (int t = 0; t < cnt; ++t) {
+            if ((rc = msdp_launch_trip2_upd(h))) return rc;    // tCG.m:166-241
+            if ((rc = msdp_launch_trip2_head(h))) return rc;   // tCG.m:227-287, then tCG.m:163 of the next trip
+        }
+        return 0;
+    }
     for (int t = 0; t < cnt; ++t) {
         if ((rc = msdp_launch_hess(h))) return rc;        // tCG.m:163
         if ((rc = msdp_launch_upd1(h))) return rc;        // tCG.m:166-241
@@ -1343,7 +1376,7 @@ static int run_tcg_lockstep(msdp_handle h, int maxinner) {
     const int nchunks = (maxinner + CH - 1) / CH;
     int rc;
     h->d.status = nullptr;                                         // no host-mapped progress word on this path
-    if ((rc = msdp_launch_tcg_init(h))) return rc;                 // trustregions.m:484-496
+    if ((rc = tcg_begin(h))) return rc;                            // trustregions.m:484-496
     int enq = 0;
     auto push_chunk = [&]() -> int {
         int r2 = enqueue_trips(h, CH);
@@ -1371,7 +1404,7 @@ static int run_tcg(msdp_handle h, int maxinner, int k, bool* done_out = nullptr)
     const bool graph = use_graphs(h);
     int rc;
     if (graph && (rc = ensure_chunk_graph(h, CH))) return rc;
-    if ((rc = msdp_launch_tcg_init(h))) return rc;                // trustregions.m:484-496
+    if ((rc = tcg_begin(h))) return rc;                           // trustregions.m:484-496
     int enq = 0;
     if ((rc = launch_chunk(h, CH, graph))) return rc;
     enq = 1;
@@ -2071,7 +2104,7 @@ extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms) 
     if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
     if ((rc = msdp_launch_rtr_begin(h))) return rc;
     h->h_ctl->done = 0;
-    if ((rc = msdp_launch_tcg_init(h))) return rc;
+    if ((rc = tcg_begin(h))) return rc;
     if ((rc = enqueue_trips(h, 2))) return rc;
     const int CH = TCG_CHUNK;
     const bool graph = use_graphs(h);

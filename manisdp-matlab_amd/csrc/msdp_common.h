@@ -76,6 +76,7 @@ struct Dev {
     double* eta[2];
     double* Heta[2];
     double* r;
+    double* r2;       // second residual buffer (two-launch trips, msdp_trip2.hip: eta and r ping-pong together)
     double* md;       // mdelta, local rows
     double* md2;      // second direction buffer (fused two-launch trips)
     double* mdx;      // persistent tCG: exchange buffer of the direction rows (uncached memory, sc1 accesses only)
@@ -133,6 +134,7 @@ struct Tuning {
     int lanczos_onesync = 1;  // undeflated persistent Lanczos runs: one grid synchronisation per step (0: two)
     int dense_pack = 1;    // dense C*U reads the fragment-ordered copy of C (0: the row-major one; same results)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
+    int trip2 = 1;           // chunked path, sparse C / oblique / one rank: two launches per tCG trip (msdp_trip2.hip) instead of three
     int escape_method = 0;   // 0: block Chebyshev-filtered subspace iteration where it applies (msdp_blockeig.hip), else Lanczos;
                              //   1: Lanczos always (msdp_escape.hip); 2: block also below its size threshold (tests)
     int be_width = 0;        // block eigen-solver: panel width 32 / 64 / 128 (0: 64, or 128 when the start block needs it)
@@ -223,6 +225,10 @@ int msdp_launch_hess(msdp_handle h);
 int msdp_launch_tcg_init(msdp_handle h);
 int msdp_launch_upd1(msdp_handle h);
 int msdp_launch_upd2(msdp_handle h);
+int msdp_trip2_ok(msdp_handle h);                             // msdp_trip2.hip: two-launch trip applies to this handle
+int msdp_launch_trip2_init(msdp_handle h);
+int msdp_launch_trip2_head(msdp_handle h);
+int msdp_launch_trip2_upd(msdp_handle h);
 int msdp_launch_retract(msdp_handle h);                       // Y[cur]+eta -> Y[1-cur], P_RD
 int msdp_launch_rtr_begin(msdp_handle h);
 int msdp_launch_rtr_decide(msdp_handle h);

@@ -239,6 +239,8 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
         _join_comm(h, comm)
         if o.get("halo_exchange"):                         # only the rows this rank's rows of C reference travel before S*U
             h.set_option("halo_exchange", 1)
+    if "escape_method" in o:                               # 0 auto, 1 Lanczos, 2 block eigen-solver also below its size threshold
+        h.set_option("escape_method", int(o["escape_method"]))
     topts = _rtr_opts(o)
     p = int(o["p0"])
     Y = o.get("Y0", None)
@@ -300,6 +302,7 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
                 lam_min = lam[0]
                 nneg = int(np.sum(lam < 0))            # missing pairs come back as +inf
                 S = None
+                data["escape_method"] = h.escape_method()      # 1: block eigen-solver, 0: Lanczos
             data["eig_seconds"] += time.time() - t1
             dinf = max(0.0, -lam_min) / (1.0 + lam_max)    # :51
             last_verified = eig_mode != "device"

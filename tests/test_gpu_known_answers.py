@@ -1,0 +1,74 @@
+"""GPU solves (all through the C ABI) against every optimal value the reference ships for the three entry points of this
+path: data/sdplib/README:39-51 (gpp -> ManiSDP_unitdiag), :71-88 (maxG*, mcp* -> ManiSDP_onlyunitdiag), :98-105 (theta ->
+ManiSDP_unittrace).  The README prints 5-7 significant digits; a value must agree to exactly those digits (conftest.within_print)
+-- that is the accuracy of the pin, 1e-7 relative for the 7-digit families.  The oracle passes the same assertions on the CPU
+(tests/test_oracle_known_answers.py)."""
+import json
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import golden_path, within_print
+
+pytestmark = pytest.mark.gpu
+
+PRINTED = json.load(open(golden_path("known_answers_printed.json")))
+THETA_OPTS = dict(tol=1e-8, TR_maxiter=30, TR_maxinner=200)       # tests/test_oracle_known_answers.py: the budget under which the family converges
+GPP_OPTS = dict(sigma0=1e-1, sigma_min=1e-1, tau1=1e-2, tau2=1e-1, TR_maxinner=40, TR_maxiter=6)
+
+
+def _sdpa(name):
+    from manisdp_matlab_amd import problems
+    At, b, c, K = problems.from_sdpa(golden_path(name + ".dat-s.gz"))
+    c = np.asarray(c.todense()).ravel() if hasattr(c, "todense") else np.asarray(c, float).ravel()
+    b = np.asarray(b.todense()).ravel() if hasattr(b, "todense") else np.asarray(b, float).ravel()
+    return At, b, c, K
+
+
+@pytest.mark.parametrize("name", ["mcp100", "mcp124-1", "mcp124-2", "mcp124-3", "mcp124-4", "mcp250-1", "mcp250-2", "mcp250-3",
+                                  "mcp250-4", "mcp500-1", "mcp500-2", "mcp500-3", "mcp500-4"])
+@pytest.mark.parametrize("eig", ["host", "device"])
+def test_onlyunitdiag_mcp(name, eig):
+    from manisdp_matlab_amd import solvers
+    At, b, c, K = _sdpa(name)
+    n = K["s"]
+    C = sp.csr_matrix(c.reshape(n, n, order="F"))
+    Y, obj, data = solvers.ManiSDP_onlyunitdiag(C, {"eig": eig}, verbose=False)
+    assert data["status"] == 0 and data["dinf"] < 1e-8
+    assert within_print(-obj, PRINTED[name])
+    assert np.abs(np.linalg.norm(Y, axis=1) - 1.0).max() < 1e-12
+
+
+@pytest.mark.parametrize("eig", ["host", "device"])
+def test_onlyunitdiag_maxG32(eig):
+    """Gset G32 (n = 2000): the device escape takes the block eigen-solver at this size (n >= 2048 is its default threshold;
+    forced here for n = 2000 so that a README value pins that path too)."""
+    from manisdp_matlab_amd import problems, solvers, _lib
+    C = problems.maxcut_cost_matrix(golden_path("G32.txt.gz"))
+    Y, obj, data = solvers.ManiSDP_onlyunitdiag(C, {"eig": eig, "escape_method": 2}, verbose=False)
+    assert data["status"] == 0 and data["dinf"] < 1e-8
+    assert within_print(-obj, PRINTED["maxG32"])
+    if eig == "device":
+        assert data.get("escape_method") == 1
+
+
+@pytest.mark.parametrize("name", ["gpp100", "gpp124-1", "gpp124-2", "gpp124-3", "gpp124-4", "gpp250-1"])
+def test_unitdiag_gpp(name):
+    from manisdp_matlab_amd import solvers
+    At, b, c, K = _sdpa(name)
+    Y, obj, data = solvers.ManiSDP_unitdiag(At, b, c, K, dict(GPP_OPTS), verbose=False)
+    assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-6
+    assert within_print(-obj, PRINTED[name])
+
+
+@pytest.mark.parametrize("name", ["theta1", "theta2", "theta3", "theta4"])
+@pytest.mark.parametrize("eig", ["host", "device"])
+def test_unittrace_theta(name, eig):
+    from manisdp_matlab_amd import solvers
+    At, b, c, K = _sdpa(name)
+    Y, obj, data = solvers.ManiSDP_unittrace(At, b, c, K, dict(THETA_OPTS, eig=eig), verbose=False)
+    assert data["status"] == 0 and max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
+    assert within_print(-obj, PRINTED[name])
+    assert abs(-obj - float(PRINTED[name])) < 1e-7 * float(PRINTED[name])
+    assert abs(np.linalg.norm(Y) - 1.0) < 1e-12

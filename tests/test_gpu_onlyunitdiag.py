@@ -265,3 +265,96 @@ def test_fused_rtr_kernel_matches_per_iteration_path(lib):
     assert a[:4] == b[:4]
     assert abs(a[4] - b[4]) < 1e-11 * max(1.0, abs(a[4])) and abs(a[5] - b[5]) < 1e-8 * max(1.0, a[5])
     assert abs(b[6] - b[4]) < 1e-10 * max(1.0, abs(b[4]))       # the resident point IS the accepted one
+
+
+@pytest.mark.parametrize("p", [16, 32, 40])
+def test_persistent_tcg_keeps_heta_equal_to_hess_eta_on_G81(lib, p):
+    """the persistent kernel assembles C*mdelta_new as C*r_new + beta*(C*mdelta_old)
+    (msdp_persist.hip, TWOSYNC) while mdelta_new is re-projected (tCG.m:273,283) -- exact only as far as the projection is a
+    no-op, and the assembled product is never refreshed.  tCG's invariant Heta = Hess(eta) (tCG.m:192-220: both are updated
+    with the same alpha from mdelta and Hess*mdelta) measures exactly what such a drift would do: every Hmdelta the kernel
+    uses enters Heta.  G81 (n = 20000, ill-conditioned) near a stationary point, ONE tCG of 50 and of 100 trips (the
+    reference's TR_maxinner): |Heta - Hess(eta)| / |Heta| must stay at rounding level for the persistent kernel, as it does
+    for the chunked path whose every product is a direct gather."""
+    from manisdp_matlab_amd import problems
+    C = problems.maxcut_cost_matrix(golden_path("G81.txt.gz"))
+    n = C.shape[0]
+    Y, _ = _rand_point(n, p, seed=0)
+    devs = {}
+    for persist in (1, 0):
+        h = lib.Handle.onlyunitdiag(C, pcap=p)
+        h.set_option("persist", persist)
+        h.set_option("fused_rtr", 0)                       # the step is handed over through global memory
+        h.set_point(Y)
+        h.rtr(lib.default_opts(maxiter=12, maxinner=100, tolgradnorm=1e-8))      # towards a stationary point
+        Yc = h.get_point()
+        assert h.tcg_path() == persist
+        for trips in (50, 100):
+            h.set_point(Yc)
+            o = lib.default_opts(maxiter=1, maxinner=trips, tolgradnorm=1e-14)
+            o.Delta0 = 1e3; o.Delta_bar = 1e6                  # no boundary exit: the tCG runs its full budget
+            st = h.rtr(o)
+            eta, heta = h.debug_get_tcg_step()
+            h.set_point(Yc)
+            h.cost()
+            He = h.hessvec(eta)
+            dev = np.linalg.norm(heta - He) / np.linalg.norm(heta)
+            devs[(persist, trips)] = (dev, st.hessvecs, st.last_stop_inner)
+        h.close()
+    for (persist, trips), (dev, hv, stop) in devs.items():
+        assert hv >= min(trips, 20), (persist, trips, hv, stop)     # a real multi-trip tCG, not an early exit
+        assert dev <= 1e-12, (persist, trips, dev, hv, stop)
+    # the persistent kernel drifts no more than an order of magnitude beyond the direct products
+    for trips in (50, 100):
+        assert devs[(1, trips)][0] <= 10.0 * max(devs[(0, trips)][0], 1e-15), devs
+
+
+@pytest.mark.parametrize("shape,p,k", [((20, 30), 3, 0), ((20, 30), 16, 0), ((33, 37), 20, 0), ((25, 40), 40, 0), ((20, 30), 80, 0),
+                                      ((12, 25), 150, 0), ((1, 997), 12, 3), ((0, 0), 24, -1)])
+def test_two_launch_trip_matches_oracle_and_three_launch_trip(lib, shape, p, k):
+    """The two-launch tCG trip of the chunked path (msdp_trip2.hip: Heta implied as r - grad, the new direction recomputed for
+    the gathered rows) against the oracle's tCG and against the three-launch trip it replaces: with maxiter = 1 a solve is ONE
+    tCG, so Hess-vec count, stop code, cost and the step itself (eta, Heta) must agree for every inner-iteration cap -- also
+    the caps that end exactly on a chunk boundary (8, 16).  ELL rows, CSR rows (ring lattice with 7 entries, G1 with ~48), pad
+    lanes (p = 3, 12, 20) and multi-chunk rows (p = 150)."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R, manopt_rtr
+    if k < 0:
+        C = problems.maxcut_cost_matrix(golden_path("G1.txt.gz"))
+    else:
+        C = problems.toroidal_grid_maxcut(shape[0], shape[1], seed=3) if k == 0 else _ring_lattice_cost(shape[1], k, seed=4)
+    n = C.shape[0]
+    Y, _ = _rand_point(n, p, seed=11)
+    prob = R._OnlyUnitDiagProblem(C, n, p, q1="correct")
+    hs = []
+    for trip2 in (1, 0):
+        h = lib.Handle.onlyunitdiag(C, pcap=p)
+        h.set_option("persist", 0)
+        h.set_option("trip2", trip2)
+        hs.append(h)
+    for maxinner in (1, 2, 7, 8, 16, 100):
+        _, f_ref, info = manopt_rtr.trustregions(prob, Y.copy(), 1, maxinner, 1e-8)
+        steps = []
+        for h in hs:
+            h.set_point(Y)
+            assert h.tcg_path() == 0
+            st = h.rtr(lib.default_opts(maxiter=1, maxinner=maxinner, tolgradnorm=1e-8))
+            assert st.hessvecs == info.hessvecs
+            assert st.last_stop_inner == info.stop_inner[-1]
+            assert abs(st.cost - f_ref) < 1e-11 * max(1.0, abs(f_ref))
+            assert abs(st.gradnorm - info.gradnorm) < 1e-8 * max(1.0, info.gradnorm)
+            steps.append(h.debug_get_tcg_step())
+        (e2, h2), (e3, h3) = steps
+        assert np.linalg.norm(e2 - e3) <= 1e-10 * max(1.0, np.linalg.norm(e3))
+        assert np.linalg.norm(h2 - h3) <= 1e-10 * max(1.0, np.linalg.norm(h3))
+    # full solves: same decisions all the way (iterations, Hess-vecs, accepted / rejected steps), same optimum
+    outs = []
+    for h in hs:
+        h.set_point(Y)
+        st = h.rtr(lib.default_opts(maxiter=40, maxinner=100, tolgradnorm=1e-8))
+        outs.append((st.iters, st.cost, st.hessvecs))
+        assert np.allclose(np.linalg.norm(h.get_point(), axis=1), 1.0, atol=1e-14)
+        h.close()
+    _, f_ref, info = manopt_rtr.trustregions(prob, Y.copy(), 40, 100, 1e-8)
+    for it, cost, hv in outs:
+        assert abs(cost - f_ref) < 1e-6 * max(1.0, abs(f_ref))

@@ -7,11 +7,17 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from conftest import golden_path
+from conftest import golden_path, within_print
 from manisdp_matlab_amd import problems
 from oracle import manisdp_ref as R
 
 KNOWN = json.load(open(golden_path("known_answers.json")))
+PRINTED = json.load(open(golden_path("known_answers_printed.json")))       # the same values as data/sdplib/README prints them
+
+# Option sets under which the reference's algorithm reaches KKT 1e-8 on the SDPLIB families whose defaults are tuned for
+# other problems (found on the oracle, tools/theta_ref_opts.py): a larger trust-region budget per outer iteration.
+THETA_OPTS = dict(tol=1e-8, TR_maxiter=30, TR_maxinner=200)
+GPP_OPTS = dict(sigma0=1e-1, sigma_min=1e-1, tau1=1e-2, tau2=1e-1, TR_maxinner=40, TR_maxiter=6)
 
 
 def _mcp(name):
@@ -20,20 +26,29 @@ def _mcp(name):
     return sp.csr_matrix(c.toarray().reshape(n, n, order="F"))
 
 
-@pytest.mark.parametrize("name", ["mcp100", "mcp124-1", "mcp250-1"])
+@pytest.mark.parametrize("name", ["mcp100", "mcp124-1", "mcp124-2", "mcp124-3", "mcp124-4", "mcp250-1", "mcp250-2", "mcp250-3",
+                                  "mcp250-4", "mcp500-1", "mcp500-2", "mcp500-3", "mcp500-4"])
 def test_onlyunitdiag_sdplib_mcp(name):
-    """max <F0,X>, X_ii = 1  ->  ManiSDP_onlyunitdiag with C = -F0 returns -value (7 printed digits)."""
+    """max <F0,X>, X_ii = 1  ->  ManiSDP_onlyunitdiag with C = -F0 returns -value: every mcp instance of
+    data/sdplib/README:76-88, to the 7 digits printed there."""
     Y, obj, data = R.ManiSDP_onlyunitdiag(_mcp(name), {})
     assert data["status"] == 0 and data["dinf"] < 1e-8
-    assert abs(-obj - KNOWN[name]) < 1e-6 * abs(KNOWN[name])
+    assert within_print(-obj, PRINTED[name])
     assert np.allclose(np.linalg.norm(Y, axis=1), 1.0, atol=1e-12)
+
+
+def test_onlyunitdiag_maxG32():
+    """maxG32 == Gset G32 (n = 2000) with C = -L/4: data/sdplib/README:72, 7 digits."""
+    Y, obj, data = R.ManiSDP_onlyunitdiag(problems.maxcut_cost_matrix(golden_path("G32.txt.gz")), {})
+    assert data["status"] == 0 and data["dinf"] < 1e-8
+    assert within_print(-obj, PRINTED["maxG32"])
 
 
 def test_onlyunitdiag_gset():
     """maxG11 == Gset G11 with C = -L/4 (example_maxcut.m:10-11); G1 against the survey probe."""
     Y, obj, data = R.ManiSDP_onlyunitdiag(problems.maxcut_cost_matrix(golden_path("G11.txt.gz")), {})
     assert data["dinf"] < 1e-8
-    assert abs(-obj - KNOWN["maxG11"]) < 1e-6 * KNOWN["maxG11"]
+    assert within_print(-obj, PRINTED["maxG11"])
     Y, obj, data = R.ManiSDP_onlyunitdiag(problems.maxcut_cost_matrix(golden_path("G1.txt.gz")), {})
     assert data["dinf"] < 1e-8
     assert abs(obj - (-12083.19765455)) < 1e-6 * 12083.2
@@ -50,14 +65,16 @@ def test_quirk_q1_variants_agree_at_optimum():
     assert abs(o1 - o2) < 1e-7 * abs(o1)
 
 
-def test_unitdiag_gpp100():
-    """gpp100 through fromsdpa: constraint 1 is <J,X> = 0, the rest X_ii = 1; README gives 6 digits.
-    Option set of SURVEY.md section 4 (the defaults are tuned for BQP)."""
-    At, b, c, K = problems.from_sdpa(golden_path("gpp100.dat-s.gz"))
-    opts = dict(sigma0=1e-1, sigma_min=1e-1, tau1=1e-2, tau2=1e-1, TR_maxinner=40, TR_maxiter=6)
-    Y, obj, data = R.ManiSDP_unitdiag(At, b, c, K, opts)
+@pytest.mark.parametrize("name", ["gpp100", "gpp124-1", "gpp124-2", "gpp124-3", "gpp124-4"])
+def test_unitdiag_gpp(name):
+    """gpp* through fromsdpa: constraint 1 is <J,X> = 0, the rest X_ii = 1 (data/sdplib/README:39-43, 5-6 digits printed:
+    the value must agree to exactly those digits).  Option set of SURVEY.md section 4 (the defaults are tuned for BQP); the
+    family crawls at KKT residues of 1e-7 (no strictly feasible point: <J,X> = 0 with X psd), so the run ends on the
+    reference's iteration limit -- the value is converged to the printed digits long before."""
+    At, b, c, K = problems.from_sdpa(golden_path(name + ".dat-s.gz"))
+    Y, obj, data = R.ManiSDP_unitdiag(At, b, c, K, dict(GPP_OPTS))
     assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-6
-    assert abs(-obj - KNOWN["gpp100"]) < 2e-5 * abs(KNOWN["gpp100"])
+    assert within_print(-obj, PRINTED[name])
 
 
 def test_unitdiag_bqp_kkt_self_certification():
@@ -74,13 +91,25 @@ def test_unitdiag_bqp_kkt_self_certification():
     assert np.linalg.norm(At.T @ X.ravel(order="F") - b) / (1 + np.linalg.norm(b)) < 1e-8
 
 
-def test_unittrace_theta1():
-    """theta1: constraint 1 is tr X = 1, F0 = J; options of example/example_theta.m:50-53."""
+@pytest.mark.parametrize("name", ["theta1", "theta2", "theta3", "theta4"])
+def test_unittrace_theta(name):
+    """theta1..theta4 (data/sdplib/README:98-101, 7 digits): constraint 1 is tr X = 1, F0 = J.  With the default trust-region
+    budget (3 x 40) the reference's algorithm leaves through "Slow progress" at KKT residues of 1e-5..1e-4 with the value right
+    to 2e-6 only; with 30 x 200 it converges to tol = 1e-8 in ~20 outer iterations and the value matches all printed digits."""
+    At, b, c, K = problems.from_sdpa(golden_path(name + ".dat-s.gz"))
+    Y, obj, data = R.ManiSDP_unittrace(At, b, c, K, dict(THETA_OPTS))
+    assert data["status"] == 0 and max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
+    assert within_print(-obj, PRINTED[name])
+    assert abs(-obj - KNOWN[name]) < 1e-7 * KNOWN[name]
+    assert abs(np.linalg.norm(Y) - 1.0) < 1e-12
+
+
+def test_unittrace_theta1_reference_example_options():
+    """theta1 with the options of example/example_theta.m:50-53 (tol 1e-6): converges for this start."""
     At, b, c, K = problems.from_sdpa(golden_path("theta1.dat-s.gz"))
     Y, obj, data = R.ManiSDP_unittrace(At, b, c, K, dict(tol=1e-6, sigma0=1e5, sigma_max=1e8))
     assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-5
     assert abs(-obj - KNOWN["theta1"]) < 1e-5 * KNOWN["theta1"]
-    assert abs(np.linalg.norm(Y) - 1.0) < 1e-12
 
 
 @pytest.mark.parametrize("name", ["mcp100", "mcp124-1"])
@@ -91,7 +120,7 @@ def test_generic_sdplib_mcp(name):
     Y, obj, data = R.ManiSDP(At, b, c, K, {})
     assert data["status"] == 0
     assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
-    assert abs(-obj - KNOWN[name]) < 1e-6 * abs(KNOWN[name])
+    assert within_print(-obj, PRINTED[name])
 
 
 def test_generic_quartic_on_sphere_kkt_self_certification():
