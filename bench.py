@@ -37,6 +37,34 @@ PORT_DETAIL = "port (C/OpenMP restatement, oracle/oracle_core.c; MATLAB unavaila
 PORT_DETAIL_NUMPY = "port (NumPy/SciPy restatement, oracle/manisdp_ref.py; MATLAB unavailable)"
 
 
+MFMA_F64_PEAK_TFLOPS = 78.6    # MI355X_MICROARCH.md: dense fp64 matrix peak
+RIDGE_P = 39                   # dense tall-skinny contraction is HBM bound up to p ~ 4 * (78.6 TF / 8 TB/s)
+
+
+def secondary_roofline(kernel, us, algo_bytes, algo_flops, pmc_names=(), bound=None, per="Hess-vec"):
+    """The roofline object of the headline line for a secondary workload: achieved = algorithmic bytes (or flops) of SURVEY.md
+    8(d) / the measured time of one Hess-vec (HIP events over graph replays, steady state); traffic = HBM bytes per Hess-vec of
+    the committed rocprofv3 --pmc summary (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md), with the file it came from."""
+    if bound is None:
+        bound = "hbm"
+    rec, src = None, None
+    for name in pmc_names:
+        f = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(f):
+            rec, src = json.load(open(f)), "profiles/" + name
+            break
+    traffic = None if rec is None else rec.get("hbm_bytes_per_hessvec", rec.get("hbm_bytes_per_launch"))
+    if bound == "mfma":
+        achieved, peak, unit = algo_flops / (us * 1e-6) / 1e12, MFMA_F64_PEAK_TFLOPS, "TFLOP/s"
+    else:
+        achieved, peak, unit = algo_bytes / (us * 1e-6) / 1e9, HBM_PEAK_GBS, "GB/s"
+    return {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": traffic,
+            "traffic_source": src, "algorithmic_bytes": algo_bytes, "algorithmic_flops": algo_flops, "kernel": kernel,
+            "kernel_us": us, "per": per,
+            "frac_hbm_peak": algo_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "frac_mfma_f64_peak": algo_flops / (us * 1e-6) / 1e12 / MFMA_F64_PEAK_TFLOPS}
+
+
 def cpu_baseline(C, Y0, budget_s=15.0):
     """Oracle ("port": oracle/oracle_core.c, plain C + OpenMP over rows) timed on the host cores of this
     box on the SAME step (one full RTR call from Y0), repeated until ~budget_s of CPU work is done."""
@@ -127,11 +155,17 @@ def affine_shapes(_lib, problems, with_cpu):
                 h.set_point(np.ascontiguousarray(Y[:, :pp] / (np.linalg.norm(Y[:, :pp], axis=1, keepdims=True) if kind == _lib.KIND_UNITDIAG
                                                                 else np.linalg.norm(Y[:, :pp]))))
                 for _ in range(2):
-                    ms, _, _ = h.bench_hessvec(100)
+                    ms, aby, afl = h.bench_hessvec(100)
                 sweep["p%d" % pp] = ms * 1e3
+            h.set_option("affine_overlap", 0)                     # A/B: the same Hess-vec with every launch on one stream
+            for _ in range(2):
+                ms1, _, _ = h.bench_hessvec(100)
             h.close()
             ent = {"workload": name, "entry_point": label, "n": n, "m": int(b.size), "nnz_At": int(At.nnz), "p": p, "hessvec_us": ms * 1e3,
-                   "hessvec_per_s": 1e3 / ms, "hessvec_us_by_p": sweep}
+                   "hessvec_per_s": 1e3 / ms, "hessvec_us_by_p": sweep, "hessvec_us_one_stream": ms1 * 1e3,
+                   "roofline": secondary_roofline(
+                       "affine Hess-vec chain (A(YU') -> A'(w) -> contraction -> epilogue; 2*eS*U on a second stream)", ms * 1e3, aby, afl,
+                       ("r3_pmc_%s_p32.json" % name,))}
             if with_cpu:
                 from oracle import manisdp_ref
                 U = rng.standard_normal((n, p))
@@ -403,7 +437,10 @@ def main():
             ent = {"n": dn, "p": dp, "kernel": "k_dense_partial3 + k_dense_hess_epi_obl", "hessvec_us": msd * 1e3,
                    "algorithmic_bytes": byd, "algorithmic_flops": fld,
                    "TFLOPs_f64": fld / msd / 1e9, "frac_mfma_f64_peak": fld / msd / 1e9 / MFMA_F64_TFLOPS,
-                   "GBps": byd / msd / 1e6, "frac_hbm_peak": byd / msd / 1e6 / HBM_PEAK_GBS}
+                   "GBps": byd / msd / 1e6, "frac_hbm_peak": byd / msd / 1e6 / HBM_PEAK_GBS,
+                   "roofline": secondary_roofline("k_dense_partial3 + k_dense_hess_epi_obl", msd * 1e3, byd, fld,
+                                                  ("r3_pmc_dense%d_p%d.json" % (dn, dp), "r2_pmc_dense%d_p%d.json" % (dn, dp)),
+                                                  bound="hbm" if dp <= RIDGE_P else "mfma")}
             if dn == 5000 and not args.no_cpu_baseline:
                 ent["cpu_baseline"] = cpu_dense_hessvec(dn, dp)
             dense.append(ent)
@@ -421,7 +458,9 @@ def main():
             dense.append({"n": 100000, "rows_on_this_gpu": 12500, "p": 64, "shard": "rank 0 of 8 (BASELINE config 5)",
                           "kernel": "k_dense_partial3 + k_dense_hess_epi_obl", "hessvec_us": msk * 1e3,
                           "TFLOPs_f64": flk / msk / 1e9, "frac_mfma_f64_peak": flk / msk / 1e9 / MFMA_F64_TFLOPS,
-                          "GBps": byk / msk / 1e6, "frac_hbm_peak": byk / msk / 1e6 / HBM_PEAK_GBS})
+                          "GBps": byk / msk / 1e6, "frac_hbm_peak": byk / msk / 1e6 / HBM_PEAK_GBS,
+                          "roofline": secondary_roofline("k_dense_partial3 + k_dense_hess_epi_obl", msk * 1e3, byk, flk,
+                                                         ("r3_pmc_k5shard_p64.json",), bound="mfma")})
         except Exception as e:  # noqa: BLE001 -- secondary figure
             dense.append({"n": 100000, "p": 64, "error": "%s: %s" % (type(e).__name__, e)})
         out["dense_mfma"] = dense

@@ -342,8 +342,14 @@ int msdp_get_dual_slack_block(msdp_handle h, int64_t row0, int64_t nb, double* S
  *   "escape_deflate" 1/0 escape: deflate span(Y) at near-stationary points (default 1).  Fast, but only as accurate as
  *                       S*Y is small; a caller about to DECLARE optimality re-checks lambda_min with 0 (see solvers.py)
  *   "escape_warm"  1/0  escape: start from what the previous call found (default 1; 0 = hashed random start vector)
- *   "trip2"        1/0  chunked path, sparse C / oblique manifold / one rank: two launches per tCG trip (12 vector passes,
- *                       msdp_trip2.hip) instead of three (17 passes) (default 1; 0 for A/B timing and tests)
+ *   "persist_refresh" k  persistent tCG kernel: every k-th trip exchanges the rows of the new direction itself (one extra
+ *                       barrier) so that the product C*mdelta, otherwise assembled by linearity, starts afresh (default 16;
+ *                       0 = never: |Heta - Hess(eta)|/|Heta| then grows to 1e-8 over 100 trips on G81)
+ *   "affine_overlap" 1/0  affine kinds: the 2*eS*U contraction of a Hess-vec runs on a second stream beside the A(.) / A'(.)
+ *                       chain (default 1; 0 = everything on one stream, for A/B timing; results agree to rounding)
+ *   "trip2"        0/1/2  chunked path, sparse C / oblique manifold / one rank: two launches per tCG trip (12 vector passes,
+ *                       msdp_trip2.hip) instead of three (17 passes): 1 = where it pays, from 2^21 vector entries on (default);
+ *                       2 = always (tests); 0 = never
  *   "escape_method" 0 = block eigen-solver where it applies (sparse C, n >= 2048), Lanczos otherwise (default); 1 = Lanczos
  *                       always; 2 = block also for small n (tests)
  *   "be_width" 0/32/64/128, "be_degree", "be_grid", "be_lpr"  block eigen-solver: panel width, filter degree per round,

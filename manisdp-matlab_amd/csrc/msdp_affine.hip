@@ -684,6 +684,14 @@ struct AffineState {
     double* Cdense = nullptr;      // n x nS
     double* d_y = nullptr;
     struct DualState* dual = nullptr;   // MSDP_KIND_DUAL_UNITDIAG (below)
+    // second stream of the Hess-vec: 2*eS*U does not depend on the A(.) / A'(.) chain and runs beside it (msdp_affine_hess)
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    ~AffineState() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (s2) (void)hipStreamDestroy(s2);
+    }
 };
 static void msdp_dual_release(struct DualState* ds);
 static std::vector<std::pair<msdp_handle, AffineState*>> g_aff;
@@ -955,6 +963,10 @@ int msdp_affine_set_multipliers(msdp_handle h, const double* y, double sigma) {
     } while (0)
 
 int msdp_dense_hess_epilogue_obl(msdp_handle h, const double* slab, int64_t stride, int SK);   // msdp_dense.hip
+int msdp_dense_gemm_slabs(msdp_handle h, int nmat);
+int msdp_dense_gemm_at(msdp_handle h, hipStream_t stream, int slab_first, int slabs_reserve, int nmat, const double* const* M,
+                       const double* const* X, const double* scale, const int* active_flag, const double** slab_out,
+                       int64_t* stride_out, int* SK_out);
 int msdp_sphere_hess_raw(msdp_handle h, const double* slab, int64_t stride, int SK);           // below
 
 // k_sddmm has no reductions, so its grid follows the number of work items, not the number of rows
@@ -1124,6 +1136,20 @@ int msdp_affine_costgrad(msdp_handle h, int slot) {
     return 0;
 }
 
+// Algorithmic traffic / work of one Hess-vec of the affine kinds (SURVEY.md 8d, A-operator): At is read twice (w = A(Y U'),
+// A'(w): values + indices, 12 bytes per nonzero each), A'(w) is written and read once over the entries At touches (all n^2
+// of them for BQP, 55 276 of 25 M for the theta-like problem), eS is read once, the three n x p panels once each.
+void msdp_affine_algo_cost(msdp_handle h, double* bytes, double* flops) {
+    AffineState* st = astate(h);
+    *bytes = 0.0; *flops = 0.0;
+    if (!st || st->dual) return;
+    const AffineDev& a = st->a;
+    const double n = a.n, p = h->d.p, nnz = (double)st->nnz;
+    const double touched = a.nsup > 0 ? (double)a.nsup : n * n;
+    *bytes = 2.0 * nnz * 12.0 + 16.0 * touched + 8.0 * n * n + 24.0 * n * p;
+    *flops = 2.0 * n * n * p + 2.0 * touched * p + 2.0 * nnz * p + 4.0 * nnz;
+}
+
 int msdp_affine_hess(msdp_handle h) {
     AffineState* st = astate(h);
     if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
@@ -1138,10 +1164,48 @@ int msdp_affine_hess(msdp_handle h) {
     const double* Yf = kept_rows(h, cur);
     const double* Uf = sharded(h) ? (const double*)d.full : (const double*)d.md;
     const size_t roff = (size_t)d.row0 * a.nS;
-    // w = A(Y U') ; AyU = A'(w)
-    { int rc0 = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 0, (double*)nullptr, sigma); if (rc0) return rc0; }
     const double* slab; int64_t stride; int SK;
     int rc;
+    if (h->tune.affine_overlap && !sharded(h)) {
+        // Two branches of the Hess-vec are independent until the epilogue sums their slabs: 2*eS*U (one dense contraction, HBM
+        // bound) and the chain w = A(Y U') -> A'(w) -> 4 sigma A'(w)*Y (gathers and small launches, latency bound).  They run
+        // side by side on two streams (fork / join by events; inside a captured chunk the second stream joins the capture):
+        // BQP d = 60 spent 72 us on five launches in a row for 36 us worth of bytes, theta n = 5000 ran 25 us of small kernels
+        // in front of a 41-us contraction.
+        if (!st->s2) {
+            HIPCHK(hipStreamCreateWithFlags(&st->s2, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
+        }
+        const int sk1 = msdp_dense_gemm_slabs(h, 1);
+        const bool support = a.nsup > 0 && d.ld <= 512;
+        const int total = support ? sk1 + 1 : 2 * sk1;
+        int SKa = 0, SKb = 0;
+        HIPCHK(hipEventRecord(st->ev_fork, h->stream));
+        HIPCHK(hipStreamWaitEvent(st->s2, st->ev_fork, 0));
+        {
+            const double* M[1] = {d.eS[cur]}; const double* X[1] = {Uf}; const double sc[1] = {2.0};
+            if ((rc = msdp_dense_gemm_at(h, st->s2, 0, total, 1, M, X, sc, act, &slab, &stride, &SKa))) return rc;
+        }
+        HIPCHK(hipEventRecord(st->ev_join, st->s2));
+        if ((rc = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 0, (double*)nullptr, sigma))) return rc;
+        if (support) {
+            double* extra = const_cast<double*>(slab) + (int64_t)SKa * stride;
+            if ((rc = launch_support_spmm(h, a, (const double*)a.w, (const double*)d.Y[cur], 4.0 * sigma, extra, act, 0))) return rc;
+            SKb = 1;
+        } else {
+            if ((rc = launch_adjoint(h, a, (const double*)nullptr, a.w, 1.0, d.AyU, act, 0, true))) return rc;
+            const double* M[1] = {d.AyU}; const double* X[1] = {Yf}; const double sc[1] = {4.0 * sigma};
+            const double* slab2;
+            if ((rc = msdp_dense_gemm_at(h, h->stream, SKa, total, 1, M, X, sc, act, &slab2, &stride, &SKb))) return rc;
+        }
+        HIPCHK(hipStreamWaitEvent(h->stream, st->ev_join, 0));
+        SK = SKa + SKb;
+        if (d.manifold == MANI_OBLIQUE) return msdp_dense_hess_epilogue_obl(h, slab, stride, SK);
+        return msdp_sphere_hess_raw(h, slab, stride, SK);
+    }
+    // w = A(Y U') ; AyU = A'(w)
+    { int rc0 = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 0, (double*)nullptr, sigma); if (rc0) return rc0; }
     if (a.nsup > 0 && !sharded(h) && d.ld <= 512) {
         // At touches few entries: AyU*Y is a sparse product over those entries (appended as one more slab); only
         // 2*eS*U goes through the dense contraction

@@ -43,6 +43,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam, d
                      const double* Mdev);
 int msdp_dense_nS(int n);
 void msdp_blockeig_release(msdp_handle h);
+void msdp_affine_algo_cost(msdp_handle h, double* bytes, double* flops);
 
 #define CHECK_H(h)                                          \
     if (!(h)) { msdp_set_error("null handle"); return MSDP_EINVAL; }
@@ -801,7 +802,9 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "escape_deflate")) t.escape_deflate = value != 0;
     else if (!strcmp(name, "escape_warm")) t.escape_warm = value != 0;
     else if (!strcmp(name, "escape_start_y")) t.escape_start_y = value != 0;
-    else if (!strcmp(name, "trip2")) { t.trip2 = value != 0; h->chunk_len = 0; }
+    else if (!strcmp(name, "persist_refresh")) t.persist_refresh = value > 0 ? value : 0;
+    else if (!strcmp(name, "affine_overlap")) { t.affine_overlap = value != 0; h->chunk_len = 0; }
+    else if (!strcmp(name, "trip2")) { t.trip2 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
     else if (!strcmp(name, "escape_method")) { if (value < 0 || value > 2) { msdp_set_error("escape_method: 0 auto, 1 lanczos, 2 block"); return MSDP_EINVAL; } t.escape_method = value; }
     else if (!strcmp(name, "be_width")) { if (value != 0 && value != 32 && value != 64 && value != 128) { msdp_set_error("be_width: 0, 32, 64 or 128"); return MSDP_EINVAL; } t.be_width = value; }
     else if (!strcmp(name, "be_degree")) t.be_degree = value > 0 ? value : 0;
@@ -1292,6 +1295,7 @@ static void fill_ctl(msdp_handle h, const msdp_rtr_opts* o) {
     c->maxiter = o->maxiter; c->maxinner = o->maxinner; c->mininner = o->mininner;
     c->tolgradnorm = o->tolgradnorm; c->kappa = o->kappa; c->theta = o->theta;
     c->rho_prime = o->rho_prime; c->rho_reg = o->rho_regularization;
+    c->persist_refresh = h->tune.persist_refresh;
     // trustregions.m:363-372; typicaldist: pi*sqrt(n) (ManiSDP_onlyunitdiag.m:137) or pi (spherefactory.m:111)
     // ... or sqrt(n*p) (euclideanfactory.m:57)
     const double typical = (h->d.manifold == MANI_OBLIQUE) ? M_PI * sqrt((double)h->d.n)
@@ -1957,7 +1961,7 @@ static void algo_cost(msdp_handle h, double* bytes, double* flops) {
         *bytes = 8.0 * n * (double)d.n + 24.0 * n * p;
         *flops = 2.0 * n * (double)d.n * p;
     } else {
-        *bytes = 0.0; *flops = 0.0;
+        msdp_affine_algo_cost(h, bytes, flops);
     }
 }
 

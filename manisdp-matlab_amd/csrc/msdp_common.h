@@ -37,6 +37,8 @@ struct Ctl {
     int hessvecs, accepted, rejected, cost_evals, last_stop_inner;
     int bench_mode;              // 1: tCG exits disabled (throughput measurement)
     int tcg_running;             // mirror of Frame.active for host polling
+    int persist_refresh;         // persistent tCG (two-synchronisation trips): every this-many trips the product C*mdelta is
+                                 //   gathered directly instead of assembled by linearity (0: never); msdp_persist.hip
 };
 
 // tCG scalars (tCG.m:102-157, 286-287); two frames, each kernel reads one frame and
@@ -134,6 +136,8 @@ struct Tuning {
     int lanczos_onesync = 1;  // undeflated persistent Lanczos runs: one grid synchronisation per step (0: two)
     int dense_pack = 1;    // dense C*U reads the fragment-ordered copy of C (0: the row-major one; same results)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
+    int persist_refresh = 16;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
+    int affine_overlap = 1;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain (0: one stream, A/B and tests)
     int trip2 = 1;           // chunked path, sparse C / oblique / one rank: two launches per tCG trip (msdp_trip2.hip) instead of three
     int escape_method = 0;   // 0: block Chebyshev-filtered subspace iteration where it applies (msdp_blockeig.hip), else Lanczos;
                              //   1: Lanczos always (msdp_escape.hip); 2: block also below its size threshold (tests)

@@ -429,14 +429,32 @@ int msdp_dense_reserve(msdp_handle h, int nmat) {
         int SK, row_blocks; int64_t kslice;
         dense_plan(h, q, &row_blocks, &SK, &kslice);
         SKmax = std::max(SKmax, SK);
+        if (q == 1) SKmax = std::max(SKmax, nmat * SK);       // nmat one-matrix contractions side by side (msdp_dense_gemm_at)
     }
     const int64_t cap_rows = (h->d.n + h->nranks - 1) / h->nranks;
     return ensure_slab(h, (size_t)(SKmax + 1) * cap_rows * (size_t)h->d.ld);
 }
 
 // Launch the partial GEMM for up to two (matrix, panel, scale) pairs; returns slab info.
+// Number of split-K slabs a contraction of nmat (matrix, panel) pairs writes at the current factor width.
+int msdp_dense_gemm_slabs(msdp_handle h, int nmat) {
+    int SK; int64_t kslice; int row_blocks;
+    dense_plan(h, nmat, &row_blocks, &SK, &kslice);
+    return SK;
+}
+int msdp_dense_gemm_at(msdp_handle h, hipStream_t stream, int slab_first, int slabs_reserve, int nmat, const double* const* M,
+                       const double* const* X, const double* scale, const int* active_flag, const double** slab_out,
+                       int64_t* stride_out, int* SK_out);
 int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const double* const* X, const double* scale,
                     const int* active_flag, const double** slab_out, int64_t* stride_out, int* SK_out) {
+    return msdp_dense_gemm_at(h, h->stream, 0, 0, nmat, M, X, scale, active_flag, slab_out, stride_out, SK_out);
+}
+// The same on `stream`, writing its slabs behind the first `slab_first` ones of the handle's slab buffer.  slabs_reserve: how
+// many slabs the caller will fill in total (several contractions whose slabs one epilogue sums; the buffer must not be
+// re-allocated between them) -- 0: this call's own count.  *slab_out is the start of the WHOLE buffer.
+int msdp_dense_gemm_at(msdp_handle h, hipStream_t stream, int slab_first, int slabs_reserve, int nmat, const double* const* M,
+                       const double* const* X, const double* scale, const int* active_flag, const double** slab_out,
+                       int64_t* stride_out, int* SK_out) {
     Dev& d = h->d;
     DenseOp op;
     memset(&op, 0, sizeof(op));
@@ -455,9 +473,10 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
     op.kslice = (int)kslice;
     const int64_t cap_rows = (d.n + h->nranks - 1) / h->nranks;
     op.slab_stride = cap_rows * (int64_t)d.ld;
-    int rc = ensure_slab(h, (size_t)(SK + 1) * op.slab_stride);       // + 1: see msdp_dense_reserve
+    const int want_slabs = std::max(slab_first + SK, slabs_reserve) + 1;      // + 1: see msdp_dense_reserve
+    int rc = ensure_slab(h, (size_t)want_slabs * op.slab_stride);
     if (rc) return rc;
-    op.slab = h->slab;
+    op.slab = h->slab + (size_t)slab_first * op.slab_stride;
     if (h->tune.block_skip) { op.blk_lo = d.blk_lo; op.blk_hi = d.blk_hi; }
     // p > 128: column blocks of 128 (the matrix is re-streamed once per block; NT <= 8 accumulator tiles per wave)
     for (int colofs = 0; colofs < d.ld; colofs += 128) {
@@ -468,7 +487,7 @@ int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const doubl
         const int NT = (op.ncols + 15) / 16;
         const int rows_wg = dense3_waves(NT) * 16;
         dim3 grid((d.n_loc + rows_wg - 1) / rows_wg, SK), block(dense3_waves(NT) * 64);
-        hipLaunchKernelGGL(dense3_fn(NT, pk), grid, block, dense3_lds(NT, ldl), h->stream, op, active_flag);
+        hipLaunchKernelGGL(dense3_fn(NT, pk), grid, block, dense3_lds(NT, ldl), stream, op, active_flag);
     }
     HIPCHK(hipGetLastError());
     *slab_out = h->slab;

@@ -108,10 +108,20 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     // the rows of the new RESIDUAL (known before the second reduction) instead of the new direction (known only after
     // it), the stores complete before the workgroup posts its partial sums, so the second reduction doubles as the
     // barrier in front of the gathers; the product with the new direction follows from linearity,
-    //   C*mdelta_new = C*r_new + beta * C*mdelta_old      (mdelta_new = r_new + beta*mdelta_old, tCG.m:273)
+    //   C*mdelta_new = C*tangent(r_new) + beta * C*mdelta_old      (mdelta_new = tangent(r_new + beta*mdelta_old), tCG.m:273,283;
+    //                                                                mdelta_old is tangent to rounding, r_new is not quite)
     // with C*mdelta_old kept in registers (cmd).  Each workgroup's own rows of mdelta are still formed and
     // re-projected exactly as tCG.m:273,283 do.
     constexpr bool TWOSYNC = !LOWREG;
+    // Round 2 published the rows of r_new themselves: the normal component r accumulates (rounding of :238, never projected)
+    // stayed in cmd, and with it |Heta - Hess(eta)| / |Heta| reached 3e-9 after 100 trips on G81 where the direct products of the
+    // chunked path stay at 5e-14 (tools/tcg_invariant_probe.py).  Publishing tangent(r_new) removes the
+    // source; what the re-projection of mdelta_old + beta-scaling still leaves (1e-16 per trip) is reset by a direct exchange
+    // every `refresh`-th trip, which ends like a three-synchronisation trip: the workgroups
+    // publish the rows of the NEW DIRECTION after beta is known, a value-less barrier follows, and the next product is gathered
+    // directly (cmd starts afresh).  One extra barrier (1.5 us) per `refresh` trips; the schedule depends on the trip count only,
+    // so every workgroup takes the same branch.
+    const int refresh = c->persist_refresh;
     double2 eta[R], rr[R], md[LOWREG ? 1 : R], hmd[LOWREG ? 1 : R], cmd[TWOSYNC ? R : 1];
 #define VOFF(r) ((int64_t)ROW(r) * d.ld + 2 * sub)
 #define Y_GET(r) (LOWREG ? (OK(r) ? ld2(Yl + VOFF(r)) : zz) : Ys[(r) * PB + threadIdx.x])
@@ -173,6 +183,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     // stored with sc1 during this launch
     __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[1] : d.Gr[0], 0, vec_bytes, 0x00020000);
     bool first = true;
+    bool direct = false;             // TWOSYNC: the exchange buffer holds the rows of mdelta itself (a refresh trip preceded)
     // acc = sum_k C[row,k] * X[k, my columns] with X read through the agent-coherent resource rs
     auto gather_row = [&](int r, __amdgpu_buffer_rsrc_t rs) -> double2 {
             double2 acc = zz;
@@ -239,8 +250,8 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         auto hrow = [&](int r) {
             double2 acc = gather_row(r, first ? rs_g : rs_md);
             if (TWOSYNC) {
-                // the gathered rows are those of r_new (first trip: of the gradient = mdelta)
-                if (!first) { acc.x = fma(beta, cmd[TWOSYNC ? r : 0].x, acc.x); acc.y = fma(beta, cmd[TWOSYNC ? r : 0].y, acc.y); }
+                // the gathered rows are those of r_new (first trip: of the gradient = mdelta; after a refresh: of mdelta)
+                if (!first && !direct) { acc.x = fma(beta, cmd[TWOSYNC ? r : 0].x, acc.x); acc.y = fma(beta, cmd[TWOSYNC ? r : 0].y, acc.y); }
                 cmd[TWOSYNC ? r : 0] = acc;
             }
             const double2 y = Y_GET(r), mdr = MD_GET(r);
@@ -278,6 +289,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
             break;
         }
         // ---- trial step and its three inner products (tCG.m:215-241)
+        const bool refresh_now = TWOSYNC && refresh > 0 && ((j + 1) % refresh) == 0;   // this trip ends with a direct exchange
         double s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -288,7 +300,14 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
             s1 += ne.x * g.x + ne.y * g.y;
             s2 += ne.x * nh.x + ne.y * nh.y;
             s3 += nr.x * nr.x + nr.y * nr.y;
-            if (TWOSYNC && OK(r)) st2_sc1(rs_md, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, nr);
+            if (TWOSYNC && !refresh_now) {
+                // what the neighbours gather is the PROJECTED residual row: C*tangent(r_new) = C*r_new - C*(Y.*rowdot(Y, r_new)).
+                // r itself keeps the bits tCG.m gives it (:238 does not project); its rounding-level normal component is what
+                // the re-projection of mdelta removes (:283) and what the assembled product would otherwise keep and amplify
+                const double2 y = Y_GET(r);
+                const double dn = msdp_group_sum<LPR>(nr.x * y.x + nr.y * y.y);
+                if (OK(r)) st2_sc1(rs_md, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, make_double2(nr.x - y.x * dn, nr.y - y.y * dn));
+            }
         }
         if (TWOSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my residual rows are performed before I post
         if (!psync(slots, gen++, d.G, 3, s1, s2, s3, sh, shb, err)) { failed = true; break; }
@@ -324,12 +343,13 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
             dot = msdp_group_sum<LPR>(dot);
             const double2 mnew = make_double2(v.x - y.x * dot, v.y - y.y * dot);
             MD_SET(r, mnew);
-            if (!TWOSYNC && OK(r)) st2_sc1(rs_md, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, mnew);
+            if ((!TWOSYNC || refresh_now) && OK(r)) st2_sc1(rs_md, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, mnew);
         }
-        if (!TWOSYNC) {
+        if (!TWOSYNC || refresh_now) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my rows are performed before my workgroup posts
             if (!pbarrier(slots, nbar++, d.G, shb, err)) { failed = true; break; }
         }
+        direct = refresh_now;
         first = false;
     }
     if (failed) return;
@@ -456,6 +476,9 @@ static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
     while (lpr < half && lpr < 64) lpr <<= 1;
     if (half > 32) return false;                       // p <= 64: the resident rows must fit the register budget
     if (lpr < 8) lpr = 8;
+    // (p <= 8 runs the eight-lane instances with half of their lanes masked.  A four-lane instance -- one row slot of 128 rows
+    // per workgroup -- was measured in round 3 and is no faster: 7.29 against 7.20 us per trip on G81 at p = 8; its gathers
+    // touch sixteen 64-byte row segments per wave instruction instead of eight 128-byte ones.)
     pl.lpr = lpr;
     pl.ew = (d.ellW < 1 || d.ellW > 8) ? 0 : (d.ellW <= 5 ? 5 : 8);      // 0: CSR rows of any length
     pl.r = lpr / 4;                                    // 128 row slots per workgroup

@@ -1,0 +1,38 @@
+"""Block eigen-solver on the final S of the G81 solve: wall time of the cold check and of a warm call against the lanes per row /
+grid / width / degree of the filter step."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from manisdp_matlab_amd import _lib, problems, solvers
+C = problems.maxcut_cost_matrix(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "G81.txt.gz"))
+Y, obj, data = solvers.ManiSDP_onlyunitdiag(C, {"p0": 40}, verbose=False)
+print("solve: %.3f s, escape %.3f s, dinf %.2e, p %d" % (data["time"], data["eig_seconds"], data["dinf"], Y.shape[1]), flush=True)
+h = _lib.Handle.onlyunitdiag(C, pcap=64)
+h.set_point(Y)
+h.cost()
+def run(cold, **opts):
+    for k, v in opts.items():
+        h.set_option(k, v)
+    h.set_option("escape_deflate", 0 if cold else 1); h.set_option("escape_warm", 0 if cold else 1)
+    best = None
+    for _ in range(3):
+        t = time.perf_counter()
+        lam, V, lmax, deg = h.escape_eigs(1 if cold else 8, tol=1e-9, maxit=60000)
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    for k in opts:
+        h.set_option(k, 0)
+    return best, deg, lam[0], h.escape_info()[1]
+for cold in (1, 0):
+    print("cold" if cold else "warm", "default", "%.2f ms deg %d lam %.4e conv %s" % ((lambda r: (r[0] * 1e3, r[1], r[2], r[3]))(run(cold))), flush=True)
+    for lpr in (8, 16, 32):
+        for grid in (128, 256, 512):
+            r = run(cold, be_lpr=lpr, be_grid=grid)
+            print("   lpr %2d grid %3d: %.2f ms deg %d lam %.4e conv %s" % (lpr, grid, r[0] * 1e3, r[1], r[2], r[3]), flush=True)
+    for deg in (100, 200, 300, 400, 600, 800):
+        r = run(cold, be_degree=deg)
+        print("   degree/round %3d: %.2f ms deg %d lam %.4e conv %s" % (deg, r[0] * 1e3, r[1], r[2], r[3]), flush=True)
+    for w in (32, 128):
+        r = run(cold, be_width=w)
+        print("   width %3d: %.2f ms deg %d lam %.4e conv %s" % (w, r[0] * 1e3, r[1], r[2], r[3]), flush=True)
+h.close()

@@ -10,7 +10,7 @@ for p in (16, 32, 40):
     Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
     for name, persist, trip2 in (("persistent", 1, 1), ("two-launch", 0, 1), ("three-launch", 0, 0)):
         h = _lib.Handle.onlyunitdiag(C, pcap=p)
-        h.set_option("persist", persist); h.set_option("fused_rtr", 0); h.set_option("trip2", trip2)
+        h.set_option("persist", persist); h.set_option("fused_rtr", 0); h.set_option("trip2", 2 * trip2)
         h.set_point(Y)
         for warm in (12, 40):
             st0 = h.rtr(_lib.default_opts(maxiter=warm, maxinner=100, tolgradnorm=1e-8))
