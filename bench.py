@@ -157,14 +157,14 @@ def affine_shapes(_lib, problems, with_cpu):
                 for _ in range(2):
                     ms, aby, afl = h.bench_hessvec(100)
                 sweep["p%d" % pp] = ms * 1e3
-            h.set_option("affine_overlap", 0)                     # A/B: the same Hess-vec with every launch on one stream
+            h.set_option("affine_overlap", 1)                     # A/B: 2*eS*U forked onto a second stream (default off: slower)
             for _ in range(2):
                 ms1, _, _ = h.bench_hessvec(100)
             h.close()
             ent = {"workload": name, "entry_point": label, "n": n, "m": int(b.size), "nnz_At": int(At.nnz), "p": p, "hessvec_us": ms * 1e3,
-                   "hessvec_per_s": 1e3 / ms, "hessvec_us_by_p": sweep, "hessvec_us_one_stream": ms1 * 1e3,
+                   "hessvec_per_s": 1e3 / ms, "hessvec_us_by_p": sweep, "hessvec_us_two_streams": ms1 * 1e3,
                    "roofline": secondary_roofline(
-                       "affine Hess-vec chain (A(YU') -> A'(w) -> contraction -> epilogue; 2*eS*U on a second stream)", ms * 1e3, aby, afl,
+                       "affine Hess-vec chain (A(YU') -> A'(w) -> two-matrix contraction -> epilogue)", ms * 1e3, aby, afl,
                        ("r3_pmc_%s_p32.json" % name,))}
             if with_cpu:
                 from oracle import manisdp_ref

@@ -346,7 +346,7 @@ int msdp_get_dual_slack_block(msdp_handle h, int64_t row0, int64_t nb, double* S
  *                       barrier) so that the product C*mdelta, otherwise assembled by linearity, starts afresh (default 16;
  *                       0 = never: |Heta - Hess(eta)|/|Heta| then grows to 1e-8 over 100 trips on G81)
  *   "affine_overlap" 1/0  affine kinds: the 2*eS*U contraction of a Hess-vec runs on a second stream beside the A(.) / A'(.)
- *                       chain (default 1; 0 = everything on one stream, for A/B timing; results agree to rounding)
+ *                       chain (default 0: measured slower than one stream; kept for A/B timing; results agree to rounding)
  *   "trip2"        0/1/2  chunked path, sparse C / oblique manifold / one rank: two launches per tCG trip (12 vector passes,
  *                       msdp_trip2.hip) instead of three (17 passes): 1 = where it pays, from 2^21 vector entries on (default);
  *                       2 = always (tests); 0 = never

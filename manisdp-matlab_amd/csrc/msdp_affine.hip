@@ -1166,25 +1166,25 @@ int msdp_affine_hess(msdp_handle h) {
     const size_t roff = (size_t)d.row0 * a.nS;
     const double* slab; int64_t stride; int SK;
     int rc;
-    if (h->tune.affine_overlap && !sharded(h)) {
-        // Two branches of the Hess-vec are independent until the epilogue sums their slabs: 2*eS*U (one dense contraction, HBM
-        // bound) and the chain w = A(Y U') -> A'(w) -> 4 sigma A'(w)*Y (gathers and small launches, latency bound).  They run
-        // side by side on two streams (fork / join by events; inside a captured chunk the second stream joins the capture):
-        // BQP d = 60 spent 72 us on five launches in a row for 36 us worth of bytes, theta n = 5000 ran 25 us of small kernels
-        // in front of a 41-us contraction.
+    if (h->tune.affine_overlap) {
+        // A/B switch, default OFF.  Two branches of the Hess-vec are independent until the epilogue sums their slabs: 2*eS*U (one
+        // dense contraction) and the chain w = A(Y U') -> A'(w) -> 4 sigma A'(w)*Y.  Here they run side by side on two streams
+        // (fork / join by events; inside a captured chunk the second stream joins the capture).  Measured in round 3: slower than
+        // one stream (BQP d = 60: 85 against 73 us, theta n = 5000: 83 against 74 us) -- each launch of the chain fills the chip by
+        // itself, the split contraction loses its two-matrix launch, and the fork / join adds graph dependencies.
         if (!st->s2) {
             HIPCHK(hipStreamCreateWithFlags(&st->s2, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
         }
         const int sk1 = msdp_dense_gemm_slabs(h, 1);
-        const bool support = a.nsup > 0 && d.ld <= 512;
+        const bool support = a.nsup > 0 && d.ld <= 512 && !sharded(h);
         const int total = support ? sk1 + 1 : 2 * sk1;
         int SKa = 0, SKb = 0;
         HIPCHK(hipEventRecord(st->ev_fork, h->stream));
         HIPCHK(hipStreamWaitEvent(st->s2, st->ev_fork, 0));
         {
-            const double* M[1] = {d.eS[cur]}; const double* X[1] = {Uf}; const double sc[1] = {2.0};
+            const double* M[1] = {d.eS[cur] + roff}; const double* X[1] = {Uf}; const double sc[1] = {2.0};
             if ((rc = msdp_dense_gemm_at(h, st->s2, 0, total, 1, M, X, sc, act, &slab, &stride, &SKa))) return rc;
         }
         HIPCHK(hipEventRecord(st->ev_join, st->s2));
@@ -1195,7 +1195,7 @@ int msdp_affine_hess(msdp_handle h) {
             SKb = 1;
         } else {
             if ((rc = launch_adjoint(h, a, (const double*)nullptr, a.w, 1.0, d.AyU, act, 0, true))) return rc;
-            const double* M[1] = {d.AyU}; const double* X[1] = {Yf}; const double sc[1] = {4.0 * sigma};
+            const double* M[1] = {d.AyU + roff}; const double* X[1] = {Yf}; const double sc[1] = {4.0 * sigma};
             const double* slab2;
             if ((rc = msdp_dense_gemm_at(h, h->stream, SKa, total, 1, M, X, sc, act, &slab2, &stride, &SKb))) return rc;
         }

@@ -137,7 +137,9 @@ struct Tuning {
     int dense_pack = 1;    // dense C*U reads the fragment-ordered copy of C (0: the row-major one; same results)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
     int persist_refresh = 16;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
-    int affine_overlap = 1;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain (0: one stream, A/B and tests)
+    int affine_overlap = 0;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain.  Measured SLOWER (round 3: BQP d = 60
+                             //   85 against 73 us, theta n = 5000 83 against 74 us per Hess-vec inside graph replays): every launch of the chain
+                             //   already fills the chip, the fork / join only adds dependencies.  Kept as an A/B switch, default off.
     int trip2 = 1;           // chunked path, sparse C / oblique / one rank: two launches per tCG trip (msdp_trip2.hip) instead of three
     int escape_method = 0;   // 0: block Chebyshev-filtered subspace iteration where it applies (msdp_blockeig.hip), else Lanczos;
                              //   1: Lanczos always (msdp_escape.hip); 2: block also below its size threshold (tests)
