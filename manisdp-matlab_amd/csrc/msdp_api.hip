@@ -64,12 +64,55 @@ static int dev_alloc(msdp_handle h, T** out, size_t count) {
 // Uncached (MTYPE UC) device memory for the words that workgroups on different XCDs exchange inside one launch:
 // sc1 accesses to it skip the L2 look-up on both ends (tools/microbench_sync.hip: grid reduction 1.99 -> 1.24 us;
 // 12.8 -> 10.0 us per tCG trip).  Falls back to plain hipMalloc where the flag is not supported.
+// Uncached blocks come from a per-process pool and go back to it, never to the driver, while the process lives
+// (msdp_release_cache frees the pool).  Round 3: uncached memory that was allocated and hipFree'd per handle left LATER handles
+// of the process with corrupted buffers (a fresh handle's eG read back as garbage in two runs out of three of
+// tests/test_gpu_blockeig.py once the block eigen-solver added a 20-MB uncached allocation per handle; the same tests pass with
+// plain memory, and with this pool) -- memory whose caching attribute changes between owners is not safe to recycle here.
+#include <mutex>
+#include <map>
+struct UcBlock { void* p; size_t bytes; int dev; };
+static std::mutex g_uc_mutex;
+static std::vector<UcBlock> g_uc_free;                        // blocks waiting for their next owner
+static std::map<void*, UcBlock> g_uc_live;                    // blocks handed out
+void* msdp_uc_alloc(size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_uc_mutex);
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < g_uc_free.size(); ++i)            // smallest parked block that is large enough (and not more than twice the size)
+        if (g_uc_free[i].dev == dev && g_uc_free[i].bytes >= bytes && g_uc_free[i].bytes <= 2 * bytes + 4096 &&
+            (best == (size_t)-1 || g_uc_free[i].bytes < g_uc_free[best].bytes)) best = i;
+    UcBlock b;
+    if (best != (size_t)-1) { b = g_uc_free[best]; g_uc_free.erase(g_uc_free.begin() + best); }
+    else {
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        b.p = p; b.bytes = bytes; b.dev = dev;
+    }
+    g_uc_live[b.p] = b;
+    return b.p;
+}
+bool msdp_uc_free(void* p) {                                  // true: p was an uncached block (now parked)
+    if (!p) return false;
+    std::lock_guard<std::mutex> lk(g_uc_mutex);
+    auto it = g_uc_live.find(p);
+    if (it == g_uc_live.end()) return false;
+    g_uc_free.push_back(it->second);
+    g_uc_live.erase(it);
+    return true;
+}
+void msdp_uc_release_pool() {
+    std::lock_guard<std::mutex> lk(g_uc_mutex);
+    for (auto& b : g_uc_free) (void)hipFree(b.p);
+    g_uc_free.clear();
+}
 template <typename T>
 static int dev_alloc_uncached(msdp_handle h, T** out, size_t count) {
-    void* p = nullptr;
     if (count == 0) count = 1;
-    hipError_t e = hipExtMallocWithFlags(&p, count * sizeof(T), hipDeviceMallocUncached);
-    if (e != hipSuccess) { (void)hipGetLastError(); return dev_alloc<T>(h, out, count); }
+    void* p = msdp_uc_alloc(count * sizeof(T));
+    if (!p) return dev_alloc<T>(h, out, count);
     h->allocs.push_back(p);
     *out = (T*)p;
     return 0;
@@ -84,7 +127,7 @@ static void dev_free(msdp_handle h, void* p) {
     if (!p) return;
     for (size_t i = 0; i < h->allocs.size(); ++i)
         if (h->allocs[i] == p) { h->allocs.erase(h->allocs.begin() + i); break; }
-    (void)hipFree(p);
+    if (!msdp_uc_free(p)) (void)hipFree(p);
 }
 
 static bool boundary_colmajor(msdp_handle h) { return h->kind == MSDP_KIND_UNITTRACE || h->kind == MSDP_KIND_GENERIC; }
@@ -515,7 +558,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     if (!h) return 0;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) (void)ncclCommDestroy((ncclComm_t)h->comm);
-    for (void* p : h->allocs) (void)hipFree(p);
+    for (void* p : h->allocs) if (!msdp_uc_free(p)) (void)hipFree(p);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
     if (h->h_frame) (void)hipHostFree(h->h_frame);
     if (h->h_status) (void)hipHostFree((void*)h->h_status);
@@ -531,7 +574,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     if (h->esc_cv) (void)hipFree(h->esc_cv);
     if (h->esc_z) (void)hipFree(h->esc_z);
     msdp_escape_workspace_park(h->esc_mem, h->esc_cap);      // esc_prev lives inside it; kept for the next handle of the process
-    if (h->lz_slots) (void)hipFree(h->lz_slots);
+    if (h->lz_slots && !msdp_uc_free(h->lz_slots)) (void)hipFree(h->lz_slots);
     msdp_blockeig_release(h);
     if (h->esc_top) (void)hipFree(h->esc_top);
     if (h->ev0) (void)hipEventDestroy(h->ev0);

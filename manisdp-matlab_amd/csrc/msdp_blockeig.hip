@@ -115,6 +115,10 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_be_step(BeOp a, const double* __
     }
 }
 
+// (A persistent form of the filter -- panels of the recurrence in registers, neighbour rows through an exchange buffer with sc1
+// accesses, one grid barrier per step, a whole round per launch -- was built and measured in round 3: 7.2 us per step against
+// 8.1 us for one launch per step on G81.  At b = 64 a step exchanges 10 MB and gathers 51 MB through the coherent path, which
+// the launch-per-step form serves from each XCD's L2; the 5 % did not justify a second co-residency-dependent kernel.)
 // Partial Gram matrices of one row chunk: part[blk][0] = X'X, part[blk][1] = X'(SX) over the rows of workgroup blk.
 // 1024 threads as a TB x TB grid (TB = B/TI), thread (ti, tj) owns the TI x TI outputs (ti*TI + u, tj*TI + v); the rows are
 // staged through LDS 2048/B at a time.  Summed over the workgroups in index order by k_be_gram_sum: deterministic.
@@ -627,13 +631,12 @@ int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const 
     a.ellW = 0; a.ell_stride = 0; a.ellc = nullptr; a.ellv = nullptr;
     if (own_rows && h->d.ellW > 0 && h->d.n_loc == n) { a.ellW = h->d.ellW; a.ell_stride = h->d.ell_stride; a.ellc = h->d.ellc; a.ellv = h->d.ellv; }
     {
-        // grid: whole passes of 16 waves; one or two workgroups per CU (choose_grid of msdp_api.hip for width b)
-        const int lpr0 = std::max(8, std::min(b / 2, 32));
-        const int rows_per_step = MSDP_WAVES * (64 / lpr0);
-        int G = (((n + rows_per_step - 1) / rows_per_step + 7) / 8) * 8;
+        // grid: one workgroup per CU while its rows fit one pass of eight lanes per row (16 waves x 8 rows = 128 rows), two
+        // beyond; measured on G81 (tools/blockeig_tune.py): 256 workgroups x 8 lanes 19.2 ms for the cold check, 512 x 16 lanes
+        // 21.8, 128 x 8 lanes 24.1
+        int G = (((n + 15) / 16 + 7) / 8) * 8;
+        if (G > 256) G = (n > 256 * 128) ? 512 : 256;
         if (G < 8) G = 8;
-        if (G > 256 && G < 512) G = 256;
-        if (G > MSDP_MAX_GRID) G = MSDP_MAX_GRID;
         if (h->tune.be_grid > 0) G = ((h->tune.be_grid + 7) / 8) * 8;
         a.G = G;
     }

@@ -26,6 +26,8 @@
 #include <vector>
 
 int msdp_dense_nS(int n);
+void* msdp_uc_alloc(size_t bytes);                                           // msdp_api.hip: per-process pool of uncached blocks
+void msdp_uc_release_pool();
 int msdp_allgather_rows(msdp_handle h, const double* local_rows);          // msdp_api.hip
 int msdp_allgather_vec(msdp_handle h, const double* local, double* all, size_t count_per_rank);
 // msdp_lanczos.hip: persistent kernel for the recurrence (sparse C, single rank)
@@ -789,6 +791,7 @@ void msdp_escape_workspace_park(double* ptr, size_t cap_doubles) {
     g_ws_ptr = ptr; g_ws_cap = cap_doubles; g_ws_dev = dev;
 }
 extern "C" int msdp_release_cache(void) {
+    msdp_uc_release_pool();
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     if (g_ws_ptr) (void)hipFree(g_ws_ptr);
     g_ws_ptr = nullptr; g_ws_cap = 0; g_ws_dev = -1;
@@ -926,9 +929,7 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
     // the slots proper live in uncached device memory (sc1 accesses skip the L2 look-up: -0.75 us per grid reduction,
     // tools/microbench_sync.hip); the workspace copy above is the fallback
     if (!h->lz_slots) {
-        void* pu = nullptr;
-        if (hipExtMallocWithFlags(&pu, msdp_lanczos_slot_bytes(), hipDeviceMallocUncached) == hipSuccess) h->lz_slots = (unsigned long long*)pu;
-        else (void)hipGetLastError();
+        h->lz_slots = (unsigned long long*)msdp_uc_alloc(msdp_lanczos_slot_bytes());       // per-process pool (msdp_api.hip)
     }
     if (h->lz_slots) c.slots = h->lz_slots;
     c.err = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(c.X + 4 * (size_t)n) + slot_doubles);   // always in the workspace

@@ -45,7 +45,7 @@ python3 tools/pmc_to_json.py k_tcg_persist_obl "$OUT/pmc_persist_g81_p32.json" -
 python3 tools/pmc_to_json.py k_be_step "$OUT/pmc_be_step_g81.json" "$OUT/g81_kkt_fetch" "$OUT/g81_kkt_write"
 python3 tools/pmc_to_json.py k_dense_partial3 "$OUT/pmc_dense20000_p32.json" "$OUT/dense20000_fetch" "$OUT/dense20000_write"
 python3 tools/pmc_to_json.py k_dense_partial3 "$OUT/pmc_k5shard_p64.json" "$OUT/k5shard_fetch" "$OUT/k5shard_write"
-python3 tools/pmc_sum.py "$OUT/pmc_bqp60_p32.json" k_dense_hess_epi hbm_bytes_per_hessvec "$OUT/bqp60_fetch" "$OUT/bqp60_write"
-python3 tools/pmc_sum.py "$OUT/pmc_theta5000_p32.json" k_sph_hess_finish hbm_bytes_per_hessvec "$OUT/theta5000_fetch" "$OUT/theta5000_write"
-python3 tools/pmc_sum.py "$OUT/pmc_chunked_n1e6_p32.json" k_tcg2_upd hbm_bytes_per_trip "$OUT/chunked1e6_fetch" "$OUT/chunked1e6_write"
+python3 tools/pmc_sum.py "$OUT/pmc_bqp60_p32.json" k_dense_hess_epi hbm_bytes_per_hessvec --only k_gram_mfma,k_gram_apply,k_adjoint_tiled,k_dense_partial3,k_dense_hess_epi "$OUT/bqp60_fetch" "$OUT/bqp60_write"
+python3 tools/pmc_sum.py "$OUT/pmc_theta5000_p32.json" k_sph_hess_finish hbm_bytes_per_hessvec --only k_sddmm,k_support_spmm,k_dense_partial3,k_sph_hess_raw,k_sph_hess_finish "$OUT/theta5000_fetch" "$OUT/theta5000_write"
+python3 tools/pmc_sum.py "$OUT/pmc_chunked_n1e6_p32.json" k_tcg2_upd hbm_bytes_per_trip --only k_tcg2_head,k_tcg2_upd "$OUT/chunked1e6_fetch" "$OUT/chunked1e6_write"
 ls "$OUT" | grep -v "^[a-z0-9_]*$"
