@@ -343,7 +343,7 @@ int msdp_get_dual_slack_block(msdp_handle h, int64_t row0, int64_t nb, double* S
  *                       S*Y is small; a caller about to DECLARE optimality re-checks lambda_min with 0 (see solvers.py)
  *   "escape_warm"  1/0  escape: start from what the previous call found (default 1; 0 = hashed random start vector)
  *   "persist_refresh" k  persistent tCG kernel: every k-th trip exchanges the rows of the new direction itself (one extra
- *                       barrier) so that the product C*mdelta, otherwise assembled by linearity, starts afresh (default 16;
+ *                       barrier) so that the product C*mdelta, otherwise assembled by linearity, starts afresh (default 32;
  *                       0 = never: |Heta - Hess(eta)|/|Heta| then grows to 1e-8 over 100 trips on G81)
  *   "affine_overlap" 1/0  affine kinds: the 2*eS*U contraction of a Hess-vec runs on a second stream beside the A(.) / A'(.)
  *                       chain (default 0: measured slower than one stream; kept for A/B timing; results agree to rounding)

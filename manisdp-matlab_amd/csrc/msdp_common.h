@@ -136,7 +136,7 @@ struct Tuning {
     int lanczos_onesync = 1;  // undeflated persistent Lanczos runs: one grid synchronisation per step (0: two)
     int dense_pack = 1;    // dense C*U reads the fragment-ordered copy of C (0: the row-major one; same results)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
-    int persist_refresh = 16;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
+    int persist_refresh = 32;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
     int affine_overlap = 0;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain.  Measured SLOWER (round 3: BQP d = 60
                              //   85 against 73 us, theta n = 5000 83 against 74 us per Hess-vec inside graph replays): every launch of the chain
                              //   already fills the chip, the fork / join only adds dependencies.  Kept as an A/B switch, default off.

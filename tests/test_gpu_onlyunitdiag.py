@@ -273,7 +273,7 @@ def test_persistent_tcg_keeps_heta_equal_to_hess_eta_on_G81(lib, p):
     beta*(C*mdelta_old) (msdp_persist.hip, TWOSYNC) while mdelta_new is re-projected (tCG.m:273,283), and the assembled
     product used to drift: tCG's invariant Heta = Hess(eta) (tCG.m:192-220: both are updated with the same alpha from mdelta
     and Hess*mdelta -- every Hmdelta the kernel uses enters Heta) was off by 3e-9 after 100 trips on G81 where the direct
-    products of the chunked path stay at 1e-13.  Round 3: the neighbours gather tangent(r_new) and every 16th trip exchanges
+    products of the chunked path stay at 1e-13.  Round 3: the neighbours gather tangent(r_new) and every 32nd trip exchanges
     the direction itself (option persist_refresh).  G81 (n = 20000, ill-conditioned) near a stationary point, ONE tCG of 50
     and of 100 trips (the reference's TR_maxinner): |Heta - Hess(eta)| / |Heta| for the persistent kernel and for both chunked
     trips (every product a direct gather; the cancellation inside Heta = sum of alpha*Hmdelta sets their 1e-13)."""
