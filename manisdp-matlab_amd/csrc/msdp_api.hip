@@ -165,12 +165,19 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
     if (h->full_buf) dev_free(h, h->full_buf);
     h->full_buf = nullptr;
     d.full = nullptr;
-    for (double** v : vecs) {
-        if (*v) dev_free(h, *v);
-        *v = nullptr;
-        int rc = dev_alloc<double>(h, v, cnt);
+    {
+        // ONE allocation for the fifteen factor-sized vectors (15 hipMalloc calls were 15 of the 19 ms the first set_point of
+        // a G81 solve took -- 7 % of the 0.22-s solve, tools/g81_host_profile.py); each vector starts on a 256-byte boundary
+        const size_t nvec = sizeof(vecs) / sizeof(vecs[0]);
+        const size_t stride = (cnt + 31) / 32 * 32;
+        if (h->vec_pool) dev_free(h, h->vec_pool);
+        h->vec_pool = nullptr;
+        for (double** v : vecs) *v = nullptr;
+        int rc = dev_alloc<double>(h, &h->vec_pool, stride * nvec);
         if (rc) return rc;
-        HIPCHK(hipMemsetAsync(*v, 0, cnt * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(h->vec_pool, 0, stride * nvec * sizeof(double), h->stream));
+        size_t i = 0;
+        for (double** v : vecs) *v = h->vec_pool + stride * (i++);
     }
     if (d.mdx) dev_free(h, d.mdx);
     d.mdx = nullptr;

@@ -32,10 +32,11 @@
 #include <vector>
 
 // ---------------------------------------------------------------- device side
-struct BeOp {                            // S = C - diag(z), sparse C, all n rows
+struct BeOp {                            // S = C - diag(z) with sparse C (all n rows), or S = M - diag(z) with a dense M
     int n, b, G;                         // b: block width = row stride of the panels (doubles)
-    const int* rp; const int* ci; const double* cv; const double* z;
+    const int* rp; const int* ci; const double* cv; const double* z;     // z may be null (explicit S of the affine kinds)
     int ellW; int64_t ell_stride; const int* ellc; const double* ellv;   // optional ELL copy of the same rows
+    const double* M;                     // dense operand (n x nS row-major, msdp_dense.hip layout) or null
 };
 
 #define BE_ELL_MAXW 8
@@ -114,6 +115,26 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_be_step(BeOp a, const double* __
         }
     }
 }
+
+// Dense S: the panel product M*Xin comes out of the split-K fp64-MFMA contraction of msdp_dense.hip as SK slabs; this epilogue
+// sums them (slab order: deterministic) and applies the recurrence,  Xio <- f1*(sum slabs) - f1*(z + cs)*Xin - f2*Xio.
+__global__ __launch_bounds__(256) void k_be_dense_epi(int n, int b, const double* __restrict__ slab, int64_t stride, int SK,
+                                                       const double* __restrict__ z, const double* __restrict__ Xin, double* __restrict__ Xio,
+                                                       double f1, double cs, double f2, int prev) {
+    const int64_t tot = (int64_t)n * b / 2;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = 2 * e;
+        const int row = (int)(o / b);
+        const double2 acc = msdp_sum_slabs(slab, stride, SK, o);
+        const double2 x = ld2(Xin + o);
+        const double2 pv = prev ? ld2(Xio + o) : make_double2(0.0, 0.0);
+        const double g = -f1 * ((z ? z[row] : 0.0) + cs);
+        st2(Xio + o, make_double2(fma(f1, acc.x, fma(g, x.x, -f2 * pv.x)), fma(f1, acc.y, fma(g, x.y, -f2 * pv.y))));
+    }
+}
+int msdp_dense_gemm_at(msdp_handle h, hipStream_t stream, int slab_first, int slabs_reserve, int nmat, const double* const* M,
+                       const double* const* X, const double* scale, const int* active_flag, const double** slab_out,
+                       int64_t* stride_out, int* SK_out);          // msdp_dense.hip
 
 // (A persistent form of the filter -- panels of the recurrence in registers, neighbour rows through an exchange buffer with sc1
 // accesses, one grid barrier per step, a whole round per launch -- was built and measured in round 3: 7.2 us per step against
@@ -491,6 +512,23 @@ static void be_launch_step(msdp_handle h, const BeOp& a, const double* Xin, doub
 }
 // lanes per row: the fewest (>= 8) that put a workgroup's rows into one pass of its 16 waves, cf. lpr_rebalance
 static int be_step(msdp_handle h, const BeOp& a, const double* Xin, double* Xio, double f1, double cs, double f2, bool prev) {
+    if (a.M) {
+        // the contraction kernels take the panel geometry from the handle: borrow it for the launch (single rank, no graph)
+        Dev& d = h->d;
+        const int ld0 = d.ld, p0 = d.p;
+        d.ld = a.b; d.p = a.b;
+        const double* Mm[1] = {a.M}; const double* Xx[1] = {Xin}; const double sc[1] = {1.0};
+        const double* slab = nullptr; int64_t stride = 0; int SK = 0;
+        const double* slab_before = h->slab;
+        int rc = msdp_dense_gemm_at(h, h->stream, 0, 0, 1, Mm, Xx, sc, nullptr, &slab, &stride, &SK);
+        d.ld = ld0; d.p = p0;
+        if (h->slab != slab_before) h->chunk_len = 0;      // the slab buffer grew: captured tCG chunks hold the old pointer
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_be_dense_epi, dim3(std::min<int64_t>(2048, ((int64_t)a.n * a.b / 2 + 255) / 256)), dim3(256), 0, h->stream, a.n, a.b, slab, stride, SK,
+                           a.z, Xin, Xio, f1, cs, f2, prev ? 1 : 0);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     const int rows_wg = (a.n + a.G - 1) / a.G;
     int lpr = a.b / 2;                                   // one double2 per lane
     if (h->tune.be_lpr > 0) lpr = h->tune.be_lpr;
@@ -565,8 +603,20 @@ static int be_rayleigh_ritz(msdp_handle h, const BeOp& a, BeMem& m, const double
 
 int msdp_blockeig_eligible(msdp_handle h, const double* Mdev, bool w_loc) {
     if (h->tune.escape_method == 1) return 0;
-    if (Mdev || w_loc) return 0;                                          // explicit dense S / sharded dense product: Lanczos path
-    if (h->d.costkind != COST_SPARSE) return 0;
+    if (w_loc) return 0;                                                  // sharded dense product: Lanczos path
+    if (Mdev || h->d.costkind != COST_SPARSE) {
+        // dense operand (explicit S of the affine kinds, dense C): the filter step is the fp64-MFMA panel product; single rank,
+        // matrix order a multiple of nothing in particular (the contraction pads), panels of 64 columns
+        if (h->nranks != 1 || h->use_comm || h->lgroup) return 0;
+        if (!Mdev && (h->d.costkind != COST_DENSE || !h->d.Cd)) return 0;
+        // The explicit S of the affine kinds keeps the Lanczos path unless asked (escape_method = 2): the outer loop of those
+        // kinds is chaotic in its end game ("Trajectory sensitivity"), any change of the escape's last digits
+        // moves which starts converge, and BQP d = 60 from the reference's default start -- a pinned test -- converges with the
+        // Lanczos vectors and ends in "Slow progress" with the block solver's (equally valid) ones.
+        if (Mdev && h->tune.escape_method != 2) return 0;
+        if (h->d.n < 1024 && h->tune.escape_method != 2) return 0;
+        return h->d.n >= 256;
+    }
     if (h->lgroup) return 0;                                              // in-process ranks share one GPU and one set of tests: Lanczos path
     if (h->d.n < 2048 && h->tune.escape_method != 2) return 0;           // small problems: a Lanczos run is a few hundred steps
     if (h->d.n < 256) return 0;
@@ -583,7 +633,7 @@ int msdp_blockeig_eligible(msdp_handle h, const double* Mdev, bool w_loc) {
 int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const double* cv, const double* z, bool own_rows,
                       const double* Ypt, int ld, int p, int k, double tol, int maxdeg, double lmax, double lmax_res, double lmin_est,
                       bool cold, bool use_y, double* lam, double* V_dev, int* degree_out, bool* conv_out, double* err_out,
-                      double* lower_out) {
+                      double* lower_out, const double* Mdense) {
     if (!h->be) h->be = new BeMem();
     BeMem& m = *(BeMem*)h->be;
     const bool dbg = h->tune.esc_debug != 0;
@@ -593,8 +643,9 @@ int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const 
     int nprev = (!cold && h->tune.escape_warm && m.prevV && m.prev_n == n) ? m.prev_k : 0;
     int b = h->tune.be_width > 0 ? h->tune.be_width : 64;
     if (b != 32 && b != 64 && b != 128) b = 64;
-    if (h->tune.be_width <= 0 && ny + nprev + 8 > b) b = 128;
-    if (k + 8 > b) b = 128;
+    if (h->tune.be_width <= 0 && ny + nprev + 8 > b && !Mdense) b = 128;
+    if (k + 8 > b && !Mdense) b = 128;
+    if (Mdense) b = 64;
     if (k > 64) { msdp_set_error("block eigen-solver: at most 64 eigenpairs per call"); return MSDP_EINVAL; }
     if (ny > b - 8 - std::min(nprev, 8)) ny = b - 8 - std::min(nprev, 8);     // leave room for noise columns (and some warm ones)
     if (ny + nprev > b - 8) nprev = b - 8 - ny;
@@ -629,7 +680,9 @@ int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const 
     BeOp a;
     a.n = n; a.b = b; a.rp = rp; a.ci = ci; a.cv = cv; a.z = z;
     a.ellW = 0; a.ell_stride = 0; a.ellc = nullptr; a.ellv = nullptr;
-    if (own_rows && h->d.ellW > 0 && h->d.n_loc == n) { a.ellW = h->d.ellW; a.ell_stride = h->d.ell_stride; a.ellc = h->d.ellc; a.ellv = h->d.ellv; }
+    a.M = Mdense;
+    if (Mdense && b != 64) { msdp_set_error("block eigen-solver: the dense route works on 64-wide panels"); return MSDP_EUNSUPPORTED; }
+    if (!Mdense && own_rows && h->d.ellW > 0 && h->d.n_loc == n) { a.ellW = h->d.ellW; a.ell_stride = h->d.ell_stride; a.ellc = h->d.ellc; a.ellv = h->d.ellv; }
     {
         // grid: one workgroup per CU while its rows fit one pass of eight lanes per row (16 waves x 8 rows = 128 rows), two
         // beyond; measured on G81 (tools/blockeig_tune.py): 256 workgroups x 8 lanes 19.2 ms for the cold check, 512 x 16 lanes

@@ -164,6 +164,7 @@ struct msdp_handle_s {
     bool state_valid = false;      // cost/grad state computed at the resident point
     bool gradnorm_valid = false;   // h_ctl->norm_grad / fx describe the resident point
     bool dual_valid = false;       // d.Sdual holds the dual slack S of the last msdp_al_dual call
+    double* vec_pool = nullptr;    // the one allocation behind Y, Gr, eta, Heta, r, md, Hmd, W0, W1 (msdp_alloc_vectors)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Ctl* h_ctl = nullptr;          // pinned host mirror

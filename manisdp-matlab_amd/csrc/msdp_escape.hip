@@ -42,7 +42,7 @@ int msdp_blockeig_eligible(msdp_handle h, const double* Mdev, bool w_loc);
 int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const double* cv, const double* z, bool own_rows,
                       const double* Ypt, int ld, int p, int k, double tol, int maxdeg, double lmax, double lmax_res, double lmin_est,
                       bool cold, bool use_y, double* lam, double* V_dev, int* degree_out, bool* conv_out, double* err_out,
-                      double* lower_out);
+                      double* lower_out, const double* Mdense);
 
 // ---------------------------------------------------------------- kernels
 // w = S*v for S = C - diag(z), sparse C (one thread per row; rows are short)
@@ -959,8 +959,10 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
             if (h->esc_top) (void)hipMemcpyAsync(h->esc_top, Z, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
         }
         const auto tb1 = std::chrono::steady_clock::now();
+        // dense operand: the explicit S of the affine kinds (no z), or the dense cost matrix of onlyunitdiag (S = C - diag(z))
+        const double* Mdense = Mdev ? Mdev : (d.costkind == COST_DENSE ? (const double*)d.Cd : (const double*)nullptr);
         if (!rc) rc = msdp_blockeig_run(h, n, c.rp, c.ci, c.cv, c.z, !rep_sparse, c.Ypt, c.ld, c.p, k, tol, maxdeg, lmx, lres, lmin_est, cold, use_y,
-                                        lam_out, Q, &deg, &conv, &err, &lower);
+                                        lam_out, Q, &deg, &conv, &err, &lower, Mdense);
         if (!rc) {
             hipError_t e2 = hipMemcpy(V_out, Q, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost);
             if (e2 != hipSuccess) { msdp_set_error("escape_eigs: download of the eigenvectors failed: %s", hipGetErrorString(e2)); rc = MSDP_EHIP; }

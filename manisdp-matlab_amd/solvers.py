@@ -442,6 +442,8 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
     comm = o.get("comm")
     if comm is not None:
         _join_comm(h, comm)
+    if "escape_method" in o:                               # 0 auto (Lanczos on the explicit S of these kinds), 1 Lanczos, 2 block eigen-solver
+        h.set_option("escape_method", int(o["escape_method"]))
     topts = _rtr_opts(o)
     p = int(o["p0"])
     sigma = float(o["sigma0"])

@@ -135,3 +135,51 @@ def test_block_escape_budget_exhausted_is_reported(lib):
     assert not conv and res > 1e-13 and nvalid == 4
     assert h.escape_lower_bound() == -np.inf
     h.close()
+
+
+@pytest.mark.parametrize("kind", ["dense_C", "explicit_S"])
+def test_block_escape_on_a_dense_operand_matches_lapack(lib, kind):
+    """The dense route of the block eigen-solver (filter step = fp64-MFMA panel product + epilogue): S = C - diag(z) with a dense C
+    (onlyunitdiag, n = 1500) and an explicit dense S handed over by the AL loop of the affine kinds (msdp_escape_eigs_matrix),
+    against LAPACK on the same matrix; warm call and the cold-started check."""
+    from manisdp_matlab_amd import problems
+    rng = np.random.default_rng(3)
+    if kind == "dense_C":
+        n, p = 1500, 12
+        C = problems.dense_unitdiag_cost(n, seed=1)
+        Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+        h = lib.Handle.onlyunitdiag(C, pcap=p)
+        h.set_point(Y)
+        h.rtr(lib.default_opts(maxiter=30, maxinner=60, tolgradnorm=1e-9))
+        S = C - np.diag(h.get_z())
+        run = lambda k: h.escape_eigs(k, tol=1e-9, maxit=60000)
+    else:
+        At, b, c, K = problems.theta_problem(1200, ndraws=6000, seed=2)
+        c = np.asarray(c.todense()).ravel() if hasattr(c, "todense") else np.asarray(c, float).ravel()
+        n, p = K["s"], 6
+        Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y)
+        h = lib.Handle.affine(lib.KIND_UNITTRACE, At, np.asarray(b, float), c, n, pcap=p)
+        h.set_option("escape_method", 2)                       # explicit S: the Lanczos path unless asked
+        h.set_multipliers(np.zeros(len(b)), 10.0)
+        h.set_point(Y)
+        h.rtr(lib.default_opts(maxiter=10, maxinner=40, tolgradnorm=1e-9))
+        G = rng.standard_normal((n, n)); S = (G + G.T) / np.sqrt(n)
+        S[:40, :40] += -0.5 * np.eye(40)                       # a few well separated negative directions
+        S = 0.5 * (S + S.T)
+        run = lambda k: h.escape_eigs_matrix(S, k, tol=1e-9, maxit=60000)
+    w = np.linalg.eigvalsh(S)
+    scale = max(abs(w[0]), abs(w[-1]))
+    lam, V, lmax, deg = run(8)
+    assert h.escape_method() == 1                               # n >= 1024: the block path
+    nvalid, conv, _ = h.escape_info()
+    assert conv and nvalid == 8
+    assert abs(lmax - w[-1]) <= 1e-6 * scale
+    assert np.abs(lam - w[:8]).max() <= 2e-3 * scale and abs(lam[0] - w[0]) <= 1e-6 * scale
+    for t in range(8):
+        assert np.linalg.norm(S @ V[:, t] - lam[t] * V[:, t]) <= 2e-2 * scale
+    h.set_option("escape_deflate", 0); h.set_option("escape_warm", 0); h.set_option("escape_start_y", 0)
+    lam1, V1, lmax1, _ = run(1)
+    _, conv, _ = h.escape_info()
+    assert conv and abs(lam1[0] - w[0]) <= 1e-8 * scale
+    assert np.linalg.norm(S @ V1[:, 0] - lam1[0] * V1[:, 0]) <= 1e-4 * scale
+    h.close()
