@@ -615,8 +615,13 @@ int msdp_blockeig_eligible(msdp_handle h, const double* Mdev, bool w_loc) {
         // Lanczos vectors and ends in "Slow progress" with the block solver's (equally valid) ones.
         if (Mdev && h->tune.escape_method != 2) return 0;
         if (h->d.n < 1024 && h->tune.escape_method != 2) return 0;
+        // the panel has to hold span(Y) -- the near-kernel of S at a stationary point -- and noise columns beside it: a factor
+        // wider than 48 columns takes the Lanczos path (n = 50000, p = 64..78: the block sat INSIDE the 70-dimensional kernel
+        // and every call ran its budget out, round 3)
+        if (h->d.p + 16 > 64 && h->tune.escape_method != 2) return 0;
         return h->d.n >= 256;
     }
+    if (h->d.p + 16 > 128 && h->tune.escape_method != 2) return 0;           // same, 128-wide panels
     if (h->lgroup) return 0;                                              // in-process ranks share one GPU and one set of tests: Lanczos path
     if (h->d.n < 2048 && h->tune.escape_method != 2) return 0;           // small problems: a Lanczos run is a few hundred steps
     if (h->d.n < 256) return 0;
@@ -716,6 +721,8 @@ int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const 
     const double abstol = (cold ? 0.25 : 1.0) * tol * scale_top;
     bool converged = false;
     double worst = INFINITY;
+    std::vector<double> hist;
+    if (maxdeg > 20000) maxdeg = 20000;                    // (the callers' budgets are Lanczos-sized; G81's cold check takes 2400 steps)
     while (degree < maxdeg) {
         const int r = rr.rank;
         // lower edge: the largest Ritz value of the block; a block that was cut short (rank < b) uses its own top
@@ -762,12 +769,25 @@ int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const 
         bool ok = rk >= std::min(k, b);
         for (int i = 0; i < std::min(k, rk) && ok; ++i) {
             if (i > 0 && !(rr.theta[i] < 0.0)) break;
+            // Beyond index 0 only SIGNIFICANTLY negative values are waited for.  The near-kernel of S can be wider than the block
+            // (dense C at n = 50000, p = 64: one eigenvalue at -1.3e-3, then more than 64 within 1e-8 of zero): Ritz values inside
+            // such a cluster have no gap to the outside of the block and never pass a gap-based test -- and as escape directions
+            // (ManiSDP_onlyunitdiag.m:74: nne = min(#negative, delta)) they are as good as they will get.  Round 3: that call
+            // crawled through its whole 60 000-step budget, four times over.
+            if (i > 0 && rr.theta[i] > -10.0 * abstol) continue;
             const double dth = (i < rr_prev.rank) ? fabs(rr.theta[i] - rr_prev.theta[i]) : INFINITY;
             const double gap = std::max(gap_ref - rr.theta[i], 1e-300);
-            const double err = std::max(dth, rr.res[i] * rr.res[i] / gap);
+            // |theta - lambda| <= res always (some eigenvalue lies within the residual), <= res^2/gap when the rest of the spectrum is a gap away
+            const double err = std::max(dth, std::min(rr.res[i], rr.res[i] * rr.res[i] / gap));
             const double thr = std::max(abstol, relacc * fabs(rr.theta[i]));
             worst = std::max(worst, err / std::max(scale_top, 1e-300));
             if (!(err <= thr)) ok = false;
+        }
+        // a call that stopped making progress ends as "not converged" (msdp_escape_info) instead of walking its whole budget
+        hist.push_back(ok ? 0.0 : worst);
+        if (!ok && hist.size() > 12 && worst > 0.5 * hist[hist.size() - 13]) {
+            if (dbg) fprintf(stderr, "[blockeig] no progress over twelve rounds (worst %.2e): giving up\n", worst);
+            break;
         }
         if (dbg) fprintf(stderr, "[blockeig] round %d deg %d: a=%.3e a0=%.3e theta0=%.9e theta[k-1]=%.3e top=%.3e res0=%.2e rank=%d worst=%.2e %s\n",
                          rounds, degree, aedge, a0, rr.theta[0], rr.theta[std::min(k, rk) - 1], rr.theta[rk - 1], rr.res[0], rk, worst, ok ? "converged" : "");

@@ -808,7 +808,7 @@ double* msdp_escape_workspace_take(size_t need_doubles, size_t* cap_out) {
     return p;
 }
 
-int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_out, double* V_out, double* lmax_out,
+static int escape_impl_once(msdp_handle h, int k, double tol, int maxit, double* lam_out, double* V_out, double* lmax_out,
                      int* iters_out, const double* Mdev) {
     Dev& d = h->d;
     if (!Mdev && h->kind != MSDP_KIND_ONLYUNITDIAG) { msdp_set_error("escape_eigs: affine handles pass S explicitly (msdp_escape_eigs_matrix)"); return MSDP_EUNSUPPORTED; }
@@ -1117,5 +1117,26 @@ int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_ou
 done:
     (void)hipStreamSynchronize(h->stream);
     (void)mem;                                       // kept in the handle for the next call
+    return rc;
+}
+
+
+// The escape call proper.  A block-eigen-solver call that ends unconverged (msdp_blockeig.hip gives up when its error estimate
+// stops moving: the near-kernel of S wider than the panel and no gap behind it) is repeated on the Lanczos path -- span(Y)
+// deflated vector by vector, whatever its width -- inside the same call, so that no host loop has to know the difference.
+int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam_out, double* V_out, double* lmax_out,
+                     int* iters_out, const double* Mdev) {
+    int total = 0;
+    int rc = escape_impl_once(h, k, tol, maxit, lam_out, V_out, lmax_out, &total, Mdev);
+    if (!rc && h->esc_method_last == 1 && !h->esc_converged && h->tune.escape_method != 2) {
+        if (h->tune.esc_debug) fprintf(stderr, "[escape] block path did not converge (%d steps): Lanczos path\n", total);
+        const int keep = h->tune.escape_method;
+        h->tune.escape_method = 1;
+        int more = 0;
+        rc = escape_impl_once(h, k, tol, maxit, lam_out, V_out, lmax_out, &more, Mdev);
+        h->tune.escape_method = keep;
+        total += more;
+    }
+    if (iters_out) *iters_out = total;
     return rc;
 }

@@ -129,6 +129,7 @@ def test_block_escape_budget_exhausted_is_reported(lib):
     Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
     h = lib.Handle.onlyunitdiag(C)
     h.set_point(Y)
+    h.set_option("escape_method", 2)                              # (0 would repeat an unconverged block call on the Lanczos path)
     h.set_option("escape_deflate", 0); h.set_option("escape_warm", 0)
     lam, V, lmax, deg = h.escape_eigs(4, tol=1e-13, maxit=64)     # 64 filter steps cannot reach 1e-13
     nvalid, conv, res = h.escape_info()
