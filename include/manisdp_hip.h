@@ -274,6 +274,15 @@ int msdp_escape_eigs_matrix(msdp_handle h, const double* S, int32_t k, double to
  * few hundred steps), 0 = deflated single-vector Lanczos runs (msdp_escape.hip: dense S, pre-sharded dense C, small n). */
 int msdp_escape_method(msdp_handle h, int32_t* method);
 
+/* Collective calls this handle has issued on its communicator so far (row exchange, all-reduce, all-gather; operations grouped
+ * into one RCCL launch count once).  A row-sharded tCG trip of onlyunitdiag with sparse C costs two (msdp_trip1.hip: the rows
+ * of the projected residual with every rank's partial sums riding along, then the all-reduce of <mdelta, H mdelta> -- tCG.m:166),
+ * three with option trip1 = 0; tests/test_gpu_local_ranks.py asserts it. */
+int msdp_debug_collective_calls(msdp_handle h, int64_t* calls);
+/* Measurement only: average stream time (us) of one collective call: which = 0 row exchange, 1 all-reduce of one partial-sum
+ * array, 2 row exchange with the sums riding along, 3 all-reduce of three arrays, 4 rows and sums as two separate all-gathers. */
+int msdp_debug_time_collective(msdp_handle h, int32_t which, int32_t reps, double* avg_us);
+
 /* Outcome of the LAST msdp_escape_eigs / _matrix / _dual call on this handle.  The reference's eig(S) is exact;
  * a Lanczos run that reaches `maxit` without passing a stop test only yields an UPPER bound of lambda_min, so
  * dinf = max(0,-lambda_min)/(1+lambda_max) (ManiSDP_onlyunitdiag.m:51) would be under-estimated: the AL loop

@@ -83,6 +83,8 @@ SIGNATURES = {
     "msdp_escape_info": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32), _dp]),
     "msdp_escape_lower_bound": (C.c_int, [C.c_void_p, _dp]),
     "msdp_escape_method": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "msdp_debug_collective_calls": (C.c_int, [C.c_void_p, _P(C.c_int64)]),
+    "msdp_debug_time_collective": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_double)]),
     "msdp_debug_get_tcg_step": (C.c_int, [C.c_void_p, _dp, _dp]),
     "msdp_debug_sym_eig": (C.c_int, [C.c_int32, _dp, _dp, _dp]),
     "msdp_debug_ritz": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _P(C.c_int32)]),
@@ -467,6 +469,18 @@ class Handle:
     def set_option(self, name, value):
         """Run-time switch of this handle (see msdp_set_option in include/manisdp_hip.h)."""
         _check(self._lib.msdp_set_option(self._h, name.encode(), int(value)))
+
+    def time_collective(self, which, reps=200):
+        """Average stream time (us) of one collective call (msdp_debug_time_collective)."""
+        v = C.c_double(0)
+        _check(self._lib.msdp_debug_time_collective(self._h, which, reps, C.byref(v)))
+        return v.value
+
+    def collective_calls(self):
+        """Collective calls issued on this handle's communicator so far (a grouped RCCL launch counts once)."""
+        v = C.c_int64(0)
+        _check(self._lib.msdp_debug_collective_calls(self._h, C.byref(v)))
+        return int(v.value)
 
     def escape_method(self):
         """Which eigen-solver the last escape call ran: 1 = block Chebyshev-filtered subspace iteration, 0 = Lanczos."""

@@ -215,10 +215,16 @@ static int alloc_common(msdp_handle h) {
     if (h->psync_err) { dev_free(h, h->psync_err); h->psync_err = nullptr; }
     if ((rc = dev_alloc<Ctl>(h, &d.ctl, 1))) return rc;
     if ((rc = dev_alloc<Frame>(h, &d.F, 2))) return rc;
-    if ((rc = dev_alloc<double>(h, &d.P, (size_t)MSDP_NPART * MSDP_MAX_GRID))) return rc;
+    // behind the partial-sum arrays: the sums of the sharded one-all-reduce trip (msdp_trip1.hip) and its arrival counter
+    const size_t p_doubles = (size_t)MSDP_NPART * MSDP_MAX_GRID + 4 + 4 * MSDP_XS_MAX_RANKS + 2;
+    if ((rc = dev_alloc<double>(h, &d.P, p_doubles))) return rc;
     HIPCHK(hipMemset(d.ctl, 0, sizeof(Ctl)));
     HIPCHK(hipMemset(d.F, 0, 2 * sizeof(Frame)));
-    HIPCHK(hipMemset(d.P, 0, (size_t)MSDP_NPART * MSDP_MAX_GRID * sizeof(double)));
+    HIPCHK(hipMemset(d.P, 0, p_doubles * sizeof(double)));
+    d.xs = d.P + (size_t)MSDP_NPART * MSDP_MAX_GRID;
+    d.xs_all = d.xs + 4;
+    d.xcount = reinterpret_cast<unsigned*>(d.xs_all + 4 * MSDP_XS_MAX_RANKS);
+    d.xn = h->nranks;
     {
         char* ps = nullptr;
         if ((rc = dev_alloc_uncached<char>(h, &ps, msdp_psync_bytes()))) return rc;
@@ -854,6 +860,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "escape_start_y")) t.escape_start_y = value != 0;
     else if (!strcmp(name, "persist_refresh")) t.persist_refresh = value > 0 ? value : 0;
     else if (!strcmp(name, "affine_overlap")) { t.affine_overlap = value != 0; h->chunk_len = 0; }
+    else if (!strcmp(name, "trip1")) t.trip1 = value != 0;
     else if (!strcmp(name, "trip2")) { t.trip2 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
     else if (!strcmp(name, "escape_method")) { if (value < 0 || value > 2) { msdp_set_error("escape_method: 0 auto, 1 lanczos, 2 block"); return MSDP_EINVAL; } t.escape_method = value; }
     else if (!strcmp(name, "be_width")) { if (value != 0 && value != 32 && value != 64 && value != 128) { msdp_set_error("be_width: 0, 32, 64 or 128"); return MSDP_EINVAL; } t.be_width = value; }
@@ -1101,9 +1108,10 @@ static int halo_setup(msdp_handle h) {
 }
 static int local_halo(msdp_handle h, Halo* ha, int ld);      // in-process stand-in, below the LocalGroup definition
 // rows of `local` the other ranks reference -> their gather buffers; mine + what I reference -> my gather buffer
-static int halo_exchange(msdp_handle h, const double* local_rows) {
+static int halo_exchange(msdp_handle h, const double* local_rows, bool with_sums = false) {
     Halo* ha = h->halo;
     const int ld = h->d.ld;
+    ++h->coll_calls;
     if (ld > ha->ldcap) {                                  // the vectors were re-allocated for a wider factor: follow
         const int cap = h->ldcap;
         if (ha->sendbuf) (void)hipFree(ha->sendbuf);
@@ -1124,11 +1132,15 @@ static int halo_exchange(msdp_handle h, const double* local_rows) {
     }
     if (h->lgroup) { int rc = local_halo(h, ha, ld); if (rc) return rc; }
     else {
+        // with_sums (msdp_trip1.hip): every pair of ranks also swaps its four sums in the same group
+        if (with_sums) HIPCHK(hipMemcpyAsync(h->d.xs_all + 4 * (size_t)h->rank, h->d.xs, 4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         ncclResult_t r = ncclGroupStart();
         for (int q = 0; q < ha->N && r == ncclSuccess; ++q) {
             if (q == h->rank) continue;
             if (ha->send_cnt[q] > 0) r = ncclSend(ha->sendbuf + (size_t)ha->send_off[q] * ld, (size_t)ha->send_cnt[q] * ld, ncclDouble, q, (ncclComm_t)h->comm, h->stream);
             if (r == ncclSuccess && ha->recv_cnt[q] > 0) r = ncclRecv(ha->recvbuf + (size_t)ha->recv_off[q] * ld, (size_t)ha->recv_cnt[q] * ld, ncclDouble, q, (ncclComm_t)h->comm, h->stream);
+            if (with_sums && r == ncclSuccess) r = ncclSend(h->d.xs, 4, ncclDouble, q, (ncclComm_t)h->comm, h->stream);
+            if (with_sums && r == ncclSuccess) r = ncclRecv(h->d.xs_all + 4 * (size_t)q, 4, ncclDouble, q, (ncclComm_t)h->comm, h->stream);
         }
         ncclResult_t r2 = ncclGroupEnd();
         if (r != ncclSuccess || r2 != ncclSuccess) { msdp_set_error("halo exchange: ncclSend/ncclRecv failed: %s", ncclGetErrorString(r != ncclSuccess ? r : r2)); return MSDP_ECOMM; }
@@ -1168,9 +1180,34 @@ int msdp_exchange_rows(msdp_handle h, const double* local_rows) {
     return msdp_allgather_rows(h, local_rows);
 }
 
+// The exchange of msdp_trip1.hip: the rows as above AND d.xs (4 doubles) of every rank into d.xs_all, in ONE grouped
+// collective call -- RCCL fuses the operations between ncclGroupStart / ncclGroupEnd into one launch.
+int msdp_exchange_rows_sums(msdp_handle h, const double* local_rows) {
+    if (!h->use_comm) { msdp_set_error("exchange_rows_sums: no communicator"); return MSDP_ESTATE; }
+    Dev& d = h->d;
+    const bool halo = h->halo && h->tune.halo_exchange && h->nranks > 1;
+    if (h->lgroup) {
+        // in-process stand-in: the two parts one after the other, counted as the one call they are under RCCL
+        int rc = halo ? halo_exchange(h, local_rows) : msdp_allgather_rows(h, local_rows);      // (counted there)
+        if (!rc) rc = local_allgather(h, d.xs, d.xs_all, 4);
+        return rc;
+    }
+    if (halo) return halo_exchange(h, local_rows, true);
+    ++h->coll_calls;
+    const size_t cnt = (size_t)rows_capacity(h) * d.ld;
+    d.full = h->full_buf;
+    ncclResult_t r = ncclGroupStart();
+    if (r == ncclSuccess) r = ncclAllGather(local_rows, h->full_buf, cnt, ncclDouble, (ncclComm_t)h->comm, h->stream);
+    if (r == ncclSuccess) r = ncclAllGather(d.xs, d.xs_all, 4, ncclDouble, (ncclComm_t)h->comm, h->stream);
+    ncclResult_t r2 = ncclGroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess) { msdp_set_error("grouped ncclAllGather failed: %s", ncclGetErrorString(r != ncclSuccess ? r : r2)); return MSDP_ECOMM; }
+    return 0;
+}
+
 // ------------------------------------------------------------------ collectives
 int msdp_allreduce_partials(msdp_handle h, int first, int count) {
     if (!h->use_comm) return 0;
+    ++h->coll_calls;
     if (h->lgroup) return local_allreduce(h, h->d.P + (size_t)first * MSDP_MAX_GRID, (size_t)count * MSDP_MAX_GRID);
     double* buf = h->d.P + (size_t)first * MSDP_MAX_GRID;
     ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count * MSDP_MAX_GRID, ncclDouble, ncclSum,
@@ -1197,6 +1234,7 @@ int msdp_allgather_rows(msdp_handle h, const double* local_rows) {
     const size_t cnt = (size_t)rows_capacity(h) * h->d.ld;
     // slabs are packed with the CURRENT ld so the full buffer is n_pad x ld row-major
     h->d.full = h->full_buf;
+    ++h->coll_calls;
     if (h->lgroup) return local_allgather(h, local_rows, h->full_buf, cnt);
     ncclResult_t r = ncclAllGather(local_rows, h->full_buf, cnt, ncclDouble, (ncclComm_t)h->comm, h->stream);
     if (r != ncclSuccess) { msdp_set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return MSDP_ECOMM; }
@@ -1211,6 +1249,7 @@ int msdp_allreduce_array(msdp_handle h, double* buf, size_t count) {
 // count_per_rank doubles from every rank, in rank order
 int msdp_allgather_vec(msdp_handle h, const double* local, double* all, size_t count_per_rank) {
     if (!h->use_comm) { msdp_set_error("allgather_vec: no communicator"); return MSDP_ESTATE; }
+    ++h->coll_calls;
     if (h->lgroup) return local_allgather(h, local, all, count_per_rank);
     ncclResult_t r = ncclAllGather(local, all, count_per_rank, ncclDouble, (ncclComm_t)h->comm, h->stream);
     if (r != ncclSuccess) { msdp_set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return MSDP_ECOMM; }
@@ -1360,6 +1399,16 @@ static bool use_graphs(msdp_handle h) { return h->tune.graph && !h->use_comm; }
 // Start of a tCG (tCG.m:102-157).  Two-launch trips (msdp_trip2.hip): the Hess-vec of trip j+1 rides in the launch that closes
 // trip j, so the first one is issued here, behind the initialisation.
 static int tcg_begin(msdp_handle h) {
+    if (msdp_trip1_ok(h)) {
+        // sharded trip with one all-reduce (msdp_trip1.hip): the first product is a direct one on the gradient rows
+        int rc;
+        h->d.xn = h->nranks;
+        h->trip1_count = 0;
+        if ((rc = msdp_launch_trip1_init(h))) return rc;
+        if ((rc = msdp_exchange_rows(h, h->d.md))) return rc;
+        if ((rc = msdp_launch_trip1_head(h, true))) return rc;
+        return msdp_allreduce_partials(h, P_DHD, 1);
+    }
     if (msdp_trip2_ok(h)) {
         int rc = msdp_launch_trip2_init(h);
         return rc ? rc : msdp_launch_trip2_head(h);
@@ -1368,6 +1417,20 @@ static int tcg_begin(msdp_handle h) {
 }
 static int enqueue_trips(msdp_handle h, int cnt) {
     int rc;
+    if (msdp_trip1_ok(h)) {
+        const int refresh = h->tune.persist_refresh;
+        for (int t = 0; t < cnt; ++t) {
+            if ((rc = msdp_launch_trip1_upd(h))) return rc;                         // tCG.m:166-241
+            if ((rc = msdp_exchange_rows_sums(h, h->d.md2))) return rc;             // rows of tangent(r') + every rank's three sums
+            if ((rc = msdp_launch_trip1_head(h, false))) return rc;                 // tCG.m:227-287, tCG.m:163 by linearity
+            if (refresh > 0 && (++h->trip1_count % refresh) == 0) {                 // every refresh-th trip multiplies directly once more
+                if ((rc = msdp_exchange_rows(h, h->d.md))) return rc;
+                if ((rc = msdp_launch_trip1_head(h, true))) return rc;
+            }
+            if ((rc = msdp_allreduce_partials(h, P_DHD, 1))) return rc;             // <mdelta, H mdelta> over all ranks (tCG.m:166)
+        }
+        return 0;
+    }
     if (msdp_trip2_ok(h)) {
         for (int t = 0; t < cnt; ++t) {
             if ((rc = msdp_launch_trip2_upd(h))) return rc;    // tCG.m:166-241
@@ -1959,6 +2022,45 @@ extern "C" int msdp_escape_info(msdp_handle h, int32_t* nvalid, int32_t* converg
     if (nvalid) *nvalid = h->esc_nvalid;
     if (converged) *converged = h->esc_converged;
     if (residual) *residual = h->esc_maxres;
+    return 0;
+}
+
+// Test / measurement only: average time of one collective call of the given kind on the handle's stream (reps back to back).
+//   0 exchange of the direction rows, 1 all-reduce of one partial-sum array, 2 exchange + sums (msdp_trip1.hip), 3 all-reduce of
+//   three arrays, 4 rows then sums as two ungrouped all-gathers
+extern "C" int msdp_debug_time_collective(msdp_handle h, int32_t which, int32_t reps, double* avg_us) {
+    CHECK_H(h);
+    if (!avg_us || reps < 1 || which < 0 || which > 4) return MSDP_EINVAL;
+    if (!h->use_comm) { msdp_set_error("debug_time_collective: no communicator"); return MSDP_ESTATE; }
+    int rc = 0;
+    auto one = [&]() -> int {
+        switch (which) {
+            case 0: return msdp_exchange_rows(h, h->d.md);
+            case 1: return msdp_allreduce_partials(h, P_DHD, 1);
+            case 2: return msdp_exchange_rows_sums(h, h->d.md);
+            case 3: return msdp_allreduce_partials(h, P_S1, 3);
+            default: { int r = msdp_exchange_rows(h, h->d.md); return r ? r : msdp_allgather_vec(h, h->d.xs, h->d.xs_all, 4); }
+        }
+    };
+    const long long keep = h->coll_calls;
+    for (int i = 0; i < 3 && !rc; ++i) rc = one();
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < reps && !rc; ++i) rc = one();
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    h->coll_calls = keep;
+    if (rc) return rc;
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *avg_us = 1e3 * (double)ms / reps;
+    return 0;
+}
+
+extern "C" int msdp_debug_collective_calls(msdp_handle h, int64_t* calls) {
+    CHECK_H(h);
+    if (!calls) return MSDP_EINVAL;
+    *calls = h->coll_calls;
     return 0;
 }
 

@@ -84,8 +84,11 @@ struct Dev {
     double* mdx;      // persistent tCG: exchange buffer of the direction rows (uncached memory, sc1 accesses only)
     double* Hmd;
     double* full;     // gather source of n x ld (== local buffer when nranks == 1)
-    double* W0;       // scratch n_loc x ld
+    double* W0;       // scratch n_loc x ld (sharded one-all-reduce trip, msdp_trip1.hip: C*mdelta of the own rows)
     double* W1;
+    // msdp_trip1.hip: this rank's three sums of a trip (xs[0..2]), all ranks' (xs_all[4*q + 0..2], filled by the exchange), the
+    // arrival counter of the launch that forms xs, the number of ranks
+    double* xs; double* xs_all; unsigned* xcount; int xn;
     // sparse C (local rows, global column indices)
     const int* rowptr;
     const int* colind;
@@ -140,6 +143,7 @@ struct Tuning {
     int affine_overlap = 0;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain.  Measured SLOWER (round 3: BQP d = 60
                              //   85 against 73 us, theta n = 5000 83 against 74 us per Hess-vec inside graph replays): every launch of the chain
                              //   already fills the chip, the fork / join only adds dependencies.  Kept as an A/B switch, default off.
+    int trip1 = 1;           // row-sharded handles, sparse C / oblique: one exchange + one all-reduce per tCG trip (msdp_trip1.hip) instead of one + two
     int trip2 = 1;           // chunked path, sparse C / oblique / one rank: two launches per tCG trip (msdp_trip2.hip) instead of three
     int escape_method = 0;   // 0: block Chebyshev-filtered subspace iteration where it applies (msdp_blockeig.hip), else Lanczos;
                              //   1: Lanczos always (msdp_escape.hip); 2: block also below its size threshold (tests)
@@ -218,6 +222,8 @@ struct msdp_handle_s {
     void* be = nullptr;               // workspace and warm-start state of the block eigen-solver (msdp_blockeig.hip)
     double* esc_top = nullptr;        // top eigenvector of the previous escape call (warm start of the lambda_max run), esc_top_n entries
     int esc_top_n = 0;
+    long long coll_calls = 0;         // collective calls issued so far (exchange, all-reduce, all-gather; a grouped call counts once)
+    int trip1_count = 0;              // msdp_trip1.hip: trips enqueued since the tCG began (refresh schedule)
     int esc_method_last = 0;          // what the last escape call ran: 0 Lanczos, 1 block
     // persistent tCG kernel (msdp_persist.hip): grid-sync slots, error flag, cached eligibility
     unsigned long long* psync_slots = nullptr;
@@ -232,6 +238,12 @@ int msdp_launch_hess(msdp_handle h);
 int msdp_launch_tcg_init(msdp_handle h);
 int msdp_launch_upd1(msdp_handle h);
 int msdp_launch_upd2(msdp_handle h);
+#define MSDP_XS_MAX_RANKS 64
+int msdp_exchange_rows_sums(msdp_handle h, const double* local_rows);    // msdp_api.hip
+int msdp_trip1_ok(msdp_handle h);                             // msdp_trip1.hip: sharded trip with one all-reduce applies to this handle
+int msdp_launch_trip1_init(msdp_handle h);
+int msdp_launch_trip1_head(msdp_handle h, bool direct);
+int msdp_launch_trip1_upd(msdp_handle h);
 int msdp_trip2_ok(msdp_handle h);                             // msdp_trip2.hip: two-launch trip applies to this handle
 int msdp_launch_trip2_init(msdp_handle h);
 int msdp_launch_trip2_head(msdp_handle h);

@@ -199,3 +199,60 @@ __device__ __forceinline__ double2 msdp_sum_slabs(const double* __restrict__ sla
     }
     return acc;
 }
+
+// ------------------------------------------------------------------ sparse gather
+// acc[ch] += sum_k C[row,k] * X[k, cols of this lane]; the LPR lanes of a row each
+// fetch one (col,val) pair of the CSR row (coalesced) and broadcast it by shuffle.
+#define MSDP_ELL_MAXW 8
+template <int LPR, int NCH, bool ELL>
+__device__ __forceinline__ void spmm_row(const Dev& d, int row, int sub, const double* __restrict__ X,
+                                         double2 (&acc)[NCH]) {
+    if (ELL) {
+        // ELL slices ([w][row], padded with (row, 0.0)): no rowptr in the dependency chain, all (col,val)
+        // loads of a row are independent and coalesced across the rows of a wave, and all W neighbour-row
+        // gathers are in flight together: two dependent memory round trips instead of three.
+        int c[MSDP_ELL_MAXW];
+        double v[MSDP_ELL_MAXW];
+#pragma unroll
+        for (int w = 0; w < MSDP_ELL_MAXW; ++w) {
+            const bool ok = w < d.ellW;
+            c[w] = ok ? d.ellc[(int64_t)w * d.ell_stride + row] : row;
+            v[w] = ok ? d.ellv[(int64_t)w * d.ell_stride + row] : 0.0;
+        }
+#pragma unroll
+        for (int w = 0; w < MSDP_ELL_MAXW; ++w) {
+            if (w < d.ellW) {
+                const double* src = X + (int64_t)c[w] * d.ld + 2 * sub;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    if (2 * sub + ch * 2 * LPR < d.ld) {
+                        const double2 x = ld2(src + ch * 2 * LPR);
+                        acc[ch].x = fma(v[w], x.x, acc[ch].x);
+                        acc[ch].y = fma(v[w], x.y, acc[ch].y);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // CSR: all LPR lanes of a row read the same (col,val) pair: one L1 line per row serves the
+    // whole group, the loads are independent of each other (no shuffle in the chain) and
+    // the compiler can keep 4 neighbour rows in flight per lane.
+    const int start = d.rowptr[row], end = d.rowptr[row + 1];
+    const int* __restrict__ ci = d.colind;
+    const double* __restrict__ cv = d.cval;
+#pragma unroll 4
+    for (int k = start; k < end; ++k) {
+        const int c = ci[k];
+        const double v = cv[k];
+        const double* src = X + (int64_t)c * d.ld + 2 * sub;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (2 * sub + ch * 2 * LPR < d.ld) {
+                const double2 x = ld2(src + ch * 2 * LPR);
+                acc[ch].x = fma(v, x.x, acc[ch].x);
+                acc[ch].y = fma(v, x.y, acc[ch].y);
+            }
+        }
+    }
+}

@@ -20,21 +20,28 @@ def test_size1_communicator_is_bit_identical(monkeypatch):
     Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
     U = rng.standard_normal((n, p))
     res = []
-    for use_comm in (False, True):
+    for use_comm, trip1 in ((False, 0), (True, 0), (True, 1)):
         h = _lib.Handle.onlyunitdiag(C)
         if use_comm:
             h.comm_init(1, 0, _lib.Handle.comm_unique_id())
             assert h.local_rows() == (0, n)
+            h.set_option("trip1", trip1)                  # 0: the three-launch trip, the kernels of the communicator-free path
         h.set_point(Y)
         H = h.hessvec(U)
         G = h.rgrad()
         st = h.rtr(_lib.default_opts(maxiter=10, maxinner=30, tolgradnorm=1e-8))
         res.append((H, G, st.cost, st.gradnorm, st.hessvecs, st.accepted, h.get_point()))
         h.close()
-    a, b = res
+    a, b, c = res
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and a[5] == b[5]
     assert np.array_equal(a[6], b[6])
+    # the default sharded trip (msdp_trip1.hip: one exchange with the sums riding along through a grouped ncclAllGather, one
+    # all-reduce) forms C*mdelta by linearity: same decisions, results equal to rounding
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    assert a[4] == c[4] and a[5] == c[5]
+    assert abs(a[2] - c[2]) <= 1e-12 * abs(a[2]) and abs(a[3] - c[3]) <= 1e-9 * abs(a[3])
+    assert np.linalg.norm(a[6] - c[6]) <= 1e-9 * np.linalg.norm(a[6])
 
 
 def test_rccl_point_to_point_calls_of_the_halo_exchange():

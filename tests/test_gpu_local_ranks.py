@@ -442,3 +442,52 @@ def test_bench_multi_rank_legs_on_in_process_ranks(N):
     for hl, k5 in res:
         assert hl["hessvecs"] == hv and hl["value"] > 0 and hl == res[0][0]
         assert k5["n"] == 300 * N and k5["S_times_X_products"] > 0 and k5["aggregate_TFLOPs_f64"] > 0 and k5 == res[0][1]
+
+
+@pytest.mark.parametrize("halo", [0, 1])
+@pytest.mark.parametrize("N", [1, 2, 4])
+def test_sharded_trip_issues_one_exchange_and_one_allreduce(N, halo):
+    """Collective calls per tCG trip of the row-sharded onlyunitdiag path with sparse C (msdp_trip1.hip): the exchange of the
+    projected residual rows carries every rank's three sums of tCG.m:227,241, the product with the new direction follows by
+    linearity, and only <mdelta, H mdelta> (tCG.m:166) takes an all-reduce of its own -- 2 calls per trip plus one exchange
+    every 32nd trip (the direct refresh), against 3 with option trip1 = 0.  Same Hess-vec counts and stop reasons as the
+    three-launch trip, end points equal to rounding, every rank holds the same bits."""
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    C = problems.toroidal_grid_maxcut(40, 50, seed=81)
+    n, p = C.shape[0], 16
+    rng = np.random.default_rng(0)
+    Y0 = rng.standard_normal((n, p)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    opts = _lib.default_opts(maxiter=12, maxinner=80, tolgradnorm=1e-9)
+    reps = 64                                                  # bench_tcg_trip: cost/grad (2 calls), tCG start (2 / 0), 2 + reps trips
+
+    def one_rank(trip1):
+        def body(r, group):
+            h = _lib.Handle.onlyunitdiag(C, pcap=p)
+            h.comm_init_local(N, r, group)
+            h.set_option("halo_exchange", halo)
+            h.set_option("trip1", trip1)
+            h.set_point(Y0)
+            c0 = h.collective_calls()
+            h.bench_tcg_trip(reps)
+            calls = h.collective_calls() - c0
+            h.set_point(Y0)
+            st = h.rtr(opts)
+            Yall = h.get_point_all()
+            h.close()
+            return calls, (st.hessvecs, st.accepted, st.rejected, st.iters), st.cost, Yall
+        return body
+
+    new = run_ranks(N, one_rank(1))
+    old = run_ranks(N, one_rank(0))
+    trips = reps + 2
+    setup = old[0][0] - 3 * trips                                # cost / gradient evaluations in front of the tCG: the same on both paths
+    assert 0 <= setup <= 6
+    for q in old:
+        assert q[0] == setup + 3 * trips                         # exchange, all-reduce (tCG.m:166), all-reduce (tCG.m:227,241)
+    for q in new:
+        assert q[0] == setup + 2 + 2 * trips + trips // 32       # first direct product, trips, refreshes
+        assert q[1] == new[0][1] and np.array_equal(q[3], new[0][3])
+    assert new[0][1] == old[0][1]
+    assert abs(new[0][2] - old[0][2]) <= 1e-11 * abs(old[0][2])
+    assert rel(new[0][3], old[0][3]) < 1e-8
