@@ -71,3 +71,67 @@ def halo_lists(C, nranks, rank):
         else:
             send[q] = (need[(need >= m0) & (need < m1)] - m0).astype(np.int64)
     return send, recv
+
+
+def tcg_one_allreduce(Cl, Yl, gl, eGl, Delta, maxinner, exchange, allreduce, kappa=0.1, theta=1.0, mininner=1, refresh=32):
+    """Host-side statement of the row-sharded tCG trip of ``csrc/msdp_trip1.hip`` (tCG.m:95-292 on the oblique manifold of
+    ManiSDP_onlyunitdiag.m, Hess-vec :127-130): ONE exchange and ONE all-reduce per trip.
+
+    ``Cl``: this rank's rows of C (global columns); ``Yl, gl, eGl``: its rows of the point, of the Riemannian gradient and of
+    eG.  ``exchange(rows, sums)`` returns (all n rows, the list of every rank's ``sums`` in rank order) -- one collective;
+    ``allreduce(x)`` sums a scalar over the ranks -- the other.  The residual rows travel projected, the product with the new
+    direction follows by linearity, C*mdelta' = C*tangent(r') + beta * C*mdelta, and every ``refresh``-th trip exchanges the
+    direction itself once more.  Returns (eta rows, Heta rows, inner iterations, stop code) like the oracle's tCG."""
+    import math
+
+    def tangent(v):                                         # obliquefactory: v - Y .* rowdot(Y, v)
+        return v - Yl * np.sum(Yl * v, axis=1, keepdims=True)
+
+    def hess_rows(cmd, md):                                 # ManiSDP_onlyunitdiag.m:128-130 on the own rows
+        return cmd - Yl * np.sum(Yl * cmd, axis=1, keepdims=True) - md * eGl
+
+    eta = np.zeros_like(gl)
+    r = gl.copy()
+    md = gl.copy()
+    r_r = allreduce(float(np.sum(gl * gl)))                 # (the library holds |grad|^2 from the gradient evaluation)
+    norm_r0 = math.sqrt(r_r)
+    z_r, d_Pd, e_Pd, e_Pe, model_value = r_r, r_r, 0.0, 0.0, 0.0
+    full, _ = exchange(md, [0.0, 0.0, 0.0])                 # first trip: direct product with the gradient rows
+    cmd = Cl @ full
+    Hmd = hess_rows(cmd, md)
+    d_Hd = allreduce(float(np.sum(md * Hmd)))               # tCG.m:166
+    stop, j = 5, 0
+    for j in range(1, maxinner + 1):
+        alpha = z_r / d_Hd if d_Hd != 0.0 else math.copysign(math.inf, z_r)
+        e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd          # :173
+        if d_Hd <= 0 or e_Pe_new >= Delta ** 2:                               # :183
+            tau = (-e_Pd + math.sqrt(e_Pd * e_Pd + d_Pd * (Delta ** 2 - e_Pe))) / d_Pd
+            return eta - tau * md, (r - tau * Hmd) - gl, j, (1 if d_Hd <= 0 else 2)      # Heta = r - grad (:198,220,238)
+        new_eta = eta - alpha * md                                            # :215
+        new_r = r - alpha * Hmd                                               # :238
+        new_Heta = new_r - gl
+        sums = [float(np.sum(new_eta * gl)), float(np.sum(new_eta * new_Heta)), float(np.sum(new_r * new_r))]
+        full, all_sums = exchange(tangent(new_r), sums)                       # THE exchange: rows + every rank's sums
+        s1 = s2 = r_r = 0.0
+        for q in all_sums:                                                    # rank order: the same bits on every rank
+            s1 += q[0]; s2 += q[1]; r_r += q[2]
+        new_model = s1 + 0.5 * s2                                             # :227
+        if new_model >= model_value:                                          # :228
+            return eta, r - gl, j, 6
+        eta, r, model_value, e_Pe = new_eta, new_r, new_model, e_Pe_new
+        if j >= mininner and math.sqrt(r_r) <= norm_r0 * min(norm_r0 ** theta, kappa):   # :249
+            return eta, r - gl, j, (3 if kappa < norm_r0 ** theta else 4)
+        if j >= maxinner:
+            break
+        beta = r_r / z_r                                                      # :272
+        md = tangent(r + beta * md)                                           # :273,283
+        cmd = Cl @ full + beta * cmd                                          # linearity
+        if refresh > 0 and j % refresh == 0:                                  # direct product every refresh-th trip
+            full, _ = exchange(md, [0.0, 0.0, 0.0])
+            cmd = Cl @ full
+        Hmd = hess_rows(cmd, md)
+        e_Pd = beta * (e_Pd + alpha * d_Pd)                                   # :286
+        d_Pd = r_r + beta * beta * d_Pd                                       # :287
+        z_r = r_r
+        d_Hd = allreduce(float(np.sum(md * Hmd)))                             # THE all-reduce (tCG.m:166)
+    return eta, r - gl, j, stop

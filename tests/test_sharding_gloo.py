@@ -230,3 +230,95 @@ def test_halo_exchange_protocol(tmp_path, kind, world):
                 assert np.array_equal(lists[a][0][bq] + a0, lists[bq][1][a])        # what a sends to b is what b expects from a
     if kind == "grid":
         assert got[-1] < 0.5 * world * n                 # far fewer rows travel than an all-gather moves ((world-1) n per rank)
+
+
+def _trip1_start(C, Y, warm):
+    """`warm` trust-region iterations of the oracle from Y: near a stationary point a tCG runs its whole budget (at a random
+    point it leaves through negative curvature after a trip or two)."""
+    if not warm:
+        return Y
+    from oracle import manisdp_ref as R, manopt_rtr
+    prob = R._OnlyUnitDiagProblem(C, C.shape[0], Y.shape[1], q1="correct")
+    Y2, _, _ = manopt_rtr.trustregions(prob, Y.copy(), warm, 50, 1e-9)
+    return Y2
+
+
+def _trip1_worker(rank, world, port, shape, p, maxinner, warm, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    C = problems.toroidal_grid_maxcut(shape[0], shape[1], seed=7)
+    n = C.shape[0]
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    Y = _trip1_start(C, Y, warm)
+    r0, r1 = sharding.row_range(n, world, rank)
+    Cl = sharding.shard_rows_csr(C, n, world, rank)
+    calls = {"exchange": 0, "allreduce": 0}
+
+    def allgather(local):
+        slab = torch.from_numpy(sharding.pad_slab(local, n, world))
+        outs = [torch.empty_like(slab) for _ in range(world)]
+        dist.all_gather(outs, slab)
+        return sharding.unpad_gathered([o.numpy() for o in outs], n)
+
+    def exchange(rows, sums):
+        # rows and sums in one message per rank: the sums ride in a pad row of the slab
+        calls["exchange"] += 1
+        tail = np.zeros((1, p)); tail[0, :3] = sums
+        t = torch.from_numpy(np.vstack([sharding.pad_slab(rows, n, world), tail]))
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        full = sharding.unpad_gathered([o.numpy()[:-1] for o in outs], n)
+        return full, [list(o.numpy()[-1, :3]) for o in outs]
+
+    def allreduce(x):
+        calls["allreduce"] += 1
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t.item())
+
+    Yl = Y[r0:r1]
+    YC = Cl @ Y
+    eGl = np.sum(YC * Yl, axis=1, keepdims=True)              # ManiSDP_onlyunitdiag.m:118-119
+    gl = YC - Yl * eGl                                         # :123-124
+    eta, Heta, j, stop = sharding.tcg_one_allreduce(Cl, Yl, gl, eGl, 1e3, maxinner, exchange, allreduce)
+    E = allgather(eta); H = allgather(Heta)
+    if rank == 0:
+        np.save(out, np.concatenate([E.ravel(), H.ravel(), [j, stop, calls["exchange"], calls["allreduce"]]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("maxinner,warm", [(40, 0), (40, 10), (5, 15), (80, 15)])
+def test_tcg_with_one_exchange_and_one_allreduce_per_trip(tmp_path, world, maxinner, warm):
+    """The protocol of the row-sharded tCG trip (csrc/msdp_trip1.hip; host statement: sharding.tcg_one_allreduce) between
+    gloo processes: the exchange of the projected residual rows carries every rank's partial sums, the product with the new
+    direction follows by linearity, only <mdelta, H mdelta> is all-reduced.  Same step, same trip count and stop code as the
+    oracle's tCG (oracle/manopt_rtr.py, tCG.m:95-292); 1 exchange + 1 all-reduce per trip plus the direct refresh every 32nd."""
+    from oracle import manisdp_ref as R, manopt_rtr
+    shape, p = (12, 11), 5
+    out = str(tmp_path / "t.npy")
+    mp.spawn(_trip1_worker, args=(world, _free_port(), shape, p, maxinner, warm, out), nprocs=world, join=True)
+    got = np.load(out)
+    C = problems.toroidal_grid_maxcut(shape[0], shape[1], seed=7)
+    n = C.shape[0]
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    Y = _trip1_start(C, Y, warm)
+    prob = R._OnlyUnitDiagProblem(C, n, p, q1="correct")
+    prob.cost(Y)
+    g = prob.grad(Y)
+    eta, Heta, j, stop = manopt_rtr.tCG(prob, Y, g, 1e3, maxinner)
+    E, H = got[:n * p].reshape(n, p), got[n * p:2 * n * p].reshape(n, p)
+    jj, sstop, nex, nar = (int(v) for v in got[2 * n * p:])
+    assert (jj, sstop) == (j, stop)
+    assert np.linalg.norm(E - eta) <= 1e-10 * np.linalg.norm(eta)
+    assert np.linalg.norm(H - Heta) <= 1e-10 * max(np.linalg.norm(Heta), 1e-300)
+    if warm == 15:
+        assert (j, stop) == (maxinner, 5)                        # the whole budget: two refreshes at maxinner = 80
+    cont = j - 1                                                 # trips that went on to a next one
+    reached = cont if stop in (1, 2) else j                      # negative curvature / boundary (tCG.m:183) leave before the exchange
+    assert nex == 1 + reached + cont // 32                       # gradient rows, one per trip, the direct refresh every 32nd
+    assert nar == 2 + cont                                       # |grad|^2, the first product, one per further trip
