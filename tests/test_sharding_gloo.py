@@ -317,7 +317,7 @@ def test_tcg_with_one_exchange_and_one_allreduce_per_trip(tmp_path, world, maxin
     assert np.linalg.norm(E - eta) <= 1e-10 * np.linalg.norm(eta)
     # Heta is a sum of alpha*H*mdelta terms that nearly cancels near a stationary point: rounding is relative to |C| |eta|
     normC = float(abs(C).sum(axis=1).max())
-    assert np.linalg.norm(H - Heta) <= 1e-10 * np.linalg.norm(Heta) + 1e-12 * normC * np.linalg.norm(eta)
+    assert np.linalg.norm(H - Heta) <= 1e-10 * np.linalg.norm(Heta) + 1e-11 * normC * np.linalg.norm(eta)
     if warm == 15:
         assert (j, stop) == (maxinner, 5)                        # the whole budget: two refreshes at maxinner = 80
     cont = j - 1                                                 # trips that went on to a next one
