@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kkt", action="store_true", help="skip the full G81 solve to KKT 1e-8")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-C (fp64 MFMA) Hess-vec figure")
+    ap.add_argument("--no-large-sparse", action="store_true", help="skip the n = 10^6 chunked-trip figure")
     ap.add_argument("--no-affine", action="store_true", help="skip the Hess-vec figures of the affine configurations (BQP d = 60, theta n = 5000)")
     ap.add_argument("--row-exchange", choices=("allgather", "halo"), default="allgather",
                     help="N > 1: which exchange in front of S*U `value` is quoted on (both legs are timed and reported): the "
@@ -464,6 +465,33 @@ def main():
         except Exception as e:  # noqa: BLE001 -- secondary figure
             dense.append({"n": 100000, "p": 64, "error": "%s: %s" % (type(e).__name__, e)})
         out["dense_mfma"] = dense
+    if not args.no_large_sparse and N == 1 and rank == 0 and not args.force_comm:
+        # The chunked tCG path -- what every sparse problem beyond the persistent kernel's reach takes -- at n = 10^6, p = 32
+        # (toroidal grid MaxCut, the G81 family scaled up): the two launches of msdp_trip1.hip move 14 vectors per trip.
+        try:
+            ln, lp = 1000, 32
+            Cl = problems.toroidal_grid_maxcut(ln, ln, seed=3)
+            rngl = np.random.default_rng(0)
+            Yl = rngl.standard_normal((ln * ln, lp)); Yl /= np.linalg.norm(Yl, axis=1, keepdims=True)
+            hl = _lib.Handle.onlyunitdiag(Cl, pcap=lp)
+            hl.set_point(Yl)
+            trip_us = min(hl.bench_tcg_trip(64) for _ in range(3)) * 1e3
+            msl, byl, fll = hl.bench_hessvec(50)
+            path = hl.tcg_path()
+            hl.close()
+            vec = ln * ln * lp * 8.0
+            algo = 14 * vec + Cl.nnz * 12.0              # 14 vector passes + the (index, value) slices of C the head reads
+            out["large_sparse_trip"] = {
+                "workload": "toroidal grid MaxCut n=%d, p=%d, one tCG trip (tCG.m:160-287) of the chunked path" % (ln * ln, lp),
+                "n": ln * ln, "p": lp, "tcg_path": path, "trip_us": trip_us, "hessvec_kernel_us": msl * 1e3,
+                "vector_passes_per_trip": 14,
+                "roofline": secondary_roofline("k_tcg1_upd + k_tcg1_head", trip_us, algo, 0.0,
+                                               ("r3_pmc_linear_n1e6_p32.json",), bound="hbm", per="tCG trip")}
+            rec = out["large_sparse_trip"]["roofline"]
+            if rec.get("traffic") is None and rec.get("traffic_source"):
+                rec["traffic"] = json.load(open(os.path.join(ROOT, rec["traffic_source"]))).get("hbm_bytes_per_trip")
+        except Exception as e:  # noqa: BLE001 -- secondary figure
+            out["large_sparse_trip"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if not args.no_affine and N == 1 and rank == 0 and not args.force_comm:
         out["affine_hessvec"] = affine_shapes(_lib, problems, not args.no_cpu_baseline)
     if N > 1 or args.force_comm:

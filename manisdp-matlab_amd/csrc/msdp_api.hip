@@ -152,6 +152,7 @@ static void choose_grid(msdp_handle h) {
     if (G > 256 && G < 512) G = 256;
     if (G > gmax) G = (gmax / 8) * 8;
     d.G = G;
+    d.sweep = (h->tune.sweep >= 2 || (h->tune.sweep == 1 && (int64_t)rows_capacity(h) * d.ld >= ((int64_t)1 << 21))) ? 1 : 0;
 }
 
 // (Re)allocate every n_loc x ld vector for factor widths up to pcap.
@@ -860,7 +861,8 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "escape_start_y")) t.escape_start_y = value != 0;
     else if (!strcmp(name, "persist_refresh")) t.persist_refresh = value > 0 ? value : 0;
     else if (!strcmp(name, "affine_overlap")) { t.affine_overlap = value != 0; h->chunk_len = 0; }
-    else if (!strcmp(name, "trip1")) t.trip1 = value != 0;
+    else if (!strcmp(name, "trip1")) { t.trip1 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
+    else if (!strcmp(name, "sweep")) { t.sweep = value < 0 ? 0 : (value > 2 ? 2 : value); choose_grid(h); h->chunk_len = 0; }
     else if (!strcmp(name, "trip2")) { t.trip2 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
     else if (!strcmp(name, "escape_method")) { if (value < 0 || value > 2) { msdp_set_error("escape_method: 0 auto, 1 lanczos, 2 block"); return MSDP_EINVAL; } t.escape_method = value; }
     else if (!strcmp(name, "be_width")) { if (value != 0 && value != 32 && value != 64 && value != 128) { msdp_set_error("be_width: 0, 32, 64 or 128"); return MSDP_EINVAL; } t.be_width = value; }
@@ -1183,8 +1185,13 @@ int msdp_exchange_rows(msdp_handle h, const double* local_rows) {
 // The exchange of msdp_trip1.hip: the rows as above AND d.xs (4 doubles) of every rank into d.xs_all, in ONE grouped
 // collective call -- RCCL fuses the operations between ncclGroupStart / ncclGroupEnd into one launch.
 int msdp_exchange_rows_sums(msdp_handle h, const double* local_rows) {
-    if (!h->use_comm) { msdp_set_error("exchange_rows_sums: no communicator"); return MSDP_ESTATE; }
     Dev& d = h->d;
+    if (!h->use_comm) {                                   // one rank, no communicator: the kernels read the rows and the sums in place
+        if (h->nranks != 1) { msdp_set_error("exchange_rows_sums: no communicator"); return MSDP_ESTATE; }
+        d.full = const_cast<double*>(local_rows);
+        d.xs_all = d.xs;
+        return 0;
+    }
     const bool halo = h->halo && h->tune.halo_exchange && h->nranks > 1;
     if (h->lgroup) {
         // in-process stand-in: the two parts one after the other, counted as the one call they are under RCCL
@@ -1403,6 +1410,7 @@ static int tcg_begin(msdp_handle h) {
         // sharded trip with one all-reduce (msdp_trip1.hip): the first product is a direct one on the gradient rows
         int rc;
         h->d.xn = h->nranks;
+        if (!h->use_comm) h->d.xs_all = h->d.xs;
         h->trip1_count = 0;
         if ((rc = msdp_launch_trip1_init(h))) return rc;
         if ((rc = msdp_exchange_rows(h, h->d.md))) return rc;
@@ -1421,9 +1429,15 @@ static int enqueue_trips(msdp_handle h, int cnt) {
         const int refresh = h->tune.persist_refresh;
         for (int t = 0; t < cnt; ++t) {
             if ((rc = msdp_launch_trip1_upd(h))) return rc;                         // tCG.m:166-241
-            if ((rc = msdp_exchange_rows_sums(h, h->d.md2))) return rc;             // rows of tangent(r') + every rank's three sums
+            // eta and r ping-pong: trip t (counted from 0) of a running tCG writes r' into r2 when t is even (after the end of
+            // a tCG the launches are no-ops and the buffer does not matter)
+            const double* rnew = (h->trip1_count & 1) ? h->d.r : h->d.r2;
+            if ((rc = msdp_exchange_rows_sums(h, rnew))) return rc;                 // rows of r' + every rank's three sums
             if ((rc = msdp_launch_trip1_head(h, false))) return rc;                 // tCG.m:227-287, tCG.m:163 by linearity
-            if (refresh > 0 && (++h->trip1_count % refresh) == 0) {                 // every refresh-th trip multiplies directly once more
+            ++h->trip1_count;
+            // every refresh-th trip multiplies directly once more (inside a graph capture the count is not the replay's: there
+            // launch_chunk appends the refresh behind the graph -- one rank, no collective in between)
+            if (!h->trip1_capture && refresh > 0 && (h->trip1_count % refresh) == 0) {
                 if ((rc = msdp_exchange_rows(h, h->d.md))) return rc;
                 if ((rc = msdp_launch_trip1_head(h, true))) return rc;
             }
@@ -1465,7 +1479,11 @@ static int ensure_chunk_graph(msdp_handle h, int CH) {
     if (!h->chunk_execs[slot]) {
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        const int count_keep = h->trip1_count;
+        h->trip1_capture = true;
         int rc = enqueue_trips(h, CH);
+        h->trip1_capture = false;
+        h->trip1_count = count_keep;
         hipError_t e = hipStreamEndCapture(h->stream, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) { msdp_set_error("graph capture failed: %s", hipGetErrorString(e)); return MSDP_EHIP; }
@@ -1478,7 +1496,20 @@ static int ensure_chunk_graph(msdp_handle h, int CH) {
 }
 
 static int launch_chunk(msdp_handle h, int CH, bool graph) {
-    if (graph) { HIPCHK(hipGraphLaunch(h->chunk_exec, h->stream)); return 0; }
+    if (graph) {
+        HIPCHK(hipGraphLaunch(h->chunk_exec, h->stream));
+        if (msdp_trip1_ok(h)) {
+            // msdp_trip1.hip on one rank: the refresh schedule of the linear products, behind every (refresh / CH)-th replay
+            const int refresh = h->tune.persist_refresh, before = h->trip1_count;
+            h->trip1_count += CH;
+            if (refresh > 0 && h->trip1_count / refresh != before / refresh) {
+                int rc = msdp_exchange_rows(h, h->d.md);
+                if (!rc) rc = msdp_launch_trip1_head(h, true);
+                if (rc) return rc;
+            }
+        }
+        return 0;
+    }
     return enqueue_trips(h, CH);
 }
 

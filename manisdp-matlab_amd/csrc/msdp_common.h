@@ -89,6 +89,7 @@ struct Dev {
     // msdp_trip1.hip: this rank's three sums of a trip (xs[0..2]), all ranks' (xs_all[4*q + 0..2], filled by the exchange), the
     // arrival counter of the launch that forms xs, the number of ranks
     double* xs; double* xs_all; unsigned* xcount; int xn;
+    int sweep;        // gather kernels walk the rows window by window (msdp_sweep_rows, msdp_device.h) instead of chunk by chunk
     // sparse C (local rows, global column indices)
     const int* rowptr;
     const int* colind;
@@ -143,7 +144,9 @@ struct Tuning {
     int affine_overlap = 0;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain.  Measured SLOWER (round 3: BQP d = 60
                              //   85 against 73 us, theta n = 5000 83 against 74 us per Hess-vec inside graph replays): every launch of the chain
                              //   already fills the chip, the fork / join only adds dependencies.  Kept as an A/B switch, default off.
-    int trip1 = 1;           // row-sharded handles, sparse C / oblique: one exchange + one all-reduce per tCG trip (msdp_trip1.hip) instead of one + two
+    int sweep = 1;           // windowed row traversal of the large-vector gather kernels: 1 = from 2^21 vector entries per rank on, 2 always, 0 never
+    int trip1 = 1;           // msdp_trip1.hip (sparse C / oblique): row-sharded handles -- one exchange + one all-reduce per tCG trip instead of one + two;
+                             // one rank, chunked path -- the same two launches (14 vector passes, one gathered vector) from 2^21 vector entries on; 2: always; 0: never
     int trip2 = 1;           // chunked path, sparse C / oblique / one rank: two launches per tCG trip (msdp_trip2.hip) instead of three
     int escape_method = 0;   // 0: block Chebyshev-filtered subspace iteration where it applies (msdp_blockeig.hip), else Lanczos;
                              //   1: Lanczos always (msdp_escape.hip); 2: block also below its size threshold (tests)
@@ -223,6 +226,7 @@ struct msdp_handle_s {
     double* esc_top = nullptr;        // top eigenvector of the previous escape call (warm start of the lambda_max run), esc_top_n entries
     int esc_top_n = 0;
     long long coll_calls = 0;         // collective calls issued so far (exchange, all-reduce, all-gather; a grouped call counts once)
+    bool trip1_capture = false;       // enqueue_trips runs inside a graph capture (no count-dependent launches)
     int trip1_count = 0;              // msdp_trip1.hip: trips enqueued since the tCG began (refresh schedule)
     int esc_method_last = 0;          // what the last escape call ran: 0 Lanczos, 1 block
     // persistent tCG kernel (msdp_persist.hip): grid-sync slots, error flag, cached eligibility

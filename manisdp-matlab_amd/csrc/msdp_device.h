@@ -7,6 +7,26 @@
 #pragma once
 #include "msdp_common.h"
 
+// Windowed row traversal for gather kernels on vectors larger than the L2s (sweep != 0).  With msdp_chunk_rows every workgroup
+// streams through its own chunk: the 64 workgroups of an XCD walk 64 windows that lie one chunk apart, and a row a neighbour
+// row's gather brought into the L2 is gone long before its owner reaches it -- the two-launch tCG head, which gathers three
+// vectors, fetched 2.66 GB for 1.28 GB of vectors at n = 10^6 (profiles/r3_pmc_chunked_n1e6_p32.json).  Here the workgroups of
+// an XCD that are resident TOGETHER (32: one 1024-thread workgroup per CU; a grid of 512 runs as two phases, each on its own
+// half of the XCD's rows) take consecutive blocks of BR rows and advance by 32 blocks: one window of 32*BR rows plus the
+// graph's halo per XCD, which its 4-MB L2 holds.  Loop shape: for (row0 = lo + wave*RPW; row0 < hi; row0 += stride).
+__device__ __forceinline__ void msdp_sweep_rows(int n_loc, int G, int BR, int& lo, int& hi, int& stride) {
+    const int X = blockIdx.x & 7, s = blockIdx.x >> 3, S = G >> 3;
+    const int W = S < 32 ? S : 32, P = (S + W - 1) / W;
+    const int phase = s / W, sp = s - phase * W;
+    const int xlo = (int)((int64_t)n_loc * X / 8), xhi = (int)((int64_t)n_loc * (X + 1) / 8);
+    // phases split the XCD's rows at multiples of BR so that no block straddles two phases
+    const int nb = (xhi - xlo + BR - 1) / BR;
+    const int b0 = (int)((int64_t)nb * phase / P), b1 = (int)((int64_t)nb * (phase + 1) / P);
+    lo = xlo + (b0 + sp) * BR;
+    hi = xlo + b1 * BR < xhi ? xlo + b1 * BR : xhi;
+    stride = W * BR;
+}
+
 // Workgroup b -> row chunk.  Workgroups b and b+8 share an XCD (round-robin
 // dispatch, observed; a pure speed heuristic), so XCD x gets the contiguous
 // chunk range [x*G/8, (x+1)*G/8): its L2 then serves one contiguous 1/8 of the

@@ -5,15 +5,16 @@
 // update.  Both reductions are needed -- alpha depends on the first, beta on the second -- but only one has to be a collective
 // of its own: the second rides in the exchange.
 //
-//   k_tcg1_upd   (tCG.m:166-241)  alpha, exits, trial eta and r'; writes the rows of tangent(r') into the exchange buffer and
-//                                  this rank's three sums (<eta',grad>, <eta',Heta'>, <r',r'>) next to it
-//   exchange                       rows of tangent(r') (all-gather or halo) + every rank's three sums, ONE grouped collective
+//   k_tcg1_upd   (tCG.m:166-241)  alpha, exits, trial eta and r' (kept projected: r' = tangent(r - alpha*H mdelta)), this rank's
+//                                  three sums (<eta',grad>, <eta',Heta'>, <r',r'>)
+//   exchange                       rows of r' (all-gather or halo) + every rank's three sums, ONE grouped collective
 //   k_tcg1_head  (tCG.m:227-287, then tCG.m:163 of the next trip)
 //                                  adds the N triples in rank order (every rank: same bits, same decisions), model check, stop
-//                                  tests, beta, mdelta' = tangent(r' + beta*mdelta) for its own rows, and the product by
-//                                  linearity (the trick of the persistent kernel, msdp_persist.hip:107-123):
-//                                      C*mdelta' = C*tangent(r') + beta * C*mdelta        (mdelta is tangent to rounding)
-//                                  with C*mdelta of its rows kept from the previous trip; H mdelta' and the partial <mdelta', H mdelta'>
+//                                  tests, beta, mdelta' = tangent(r' + beta*mdelta) for its own rows, and the Hess-vec by
+//                                  linearity (the trick of the persistent kernel, msdp_persist.hip:107-123, applied to the
+//                                  Hessian itself -- a linear map on the tangent space):
+//                                      H mdelta' = H r' + beta * H mdelta          (r', mdelta tangent)
+//                                  with H mdelta of its rows from the previous trip; the partial <mdelta', H mdelta'>
 //   all-reduce                     of those partials
 //
 // What linearity leaves out -- the re-projection of the old direction, 1e-16 per trip -- is reset every `persist_refresh`-th trip
@@ -22,8 +23,13 @@
 // trip count only, which the host knows: every rank issues the same collectives.
 //
 // eta and r ping-pong as in msdp_trip2.hip (tCG.m:228: a trial step whose model value went up is dropped); Heta is not
-// stored (Heta = r - grad, tCG.m:220,238), the step's Heta is written when the tCG ends.  Buffers: exchange source = d.md2,
-// C*mdelta of the own rows = d.W0 (both idle on this path).
+// stored (Heta = r - grad, tCG.m:220,238), the step's Heta is written when the tCG ends.
+//
+// Vector passes per trip: upd reads eta, mdelta, H mdelta, r, grad, Y and writes eta', r' (8); head reads r', mdelta, H mdelta, Y
+// and writes mdelta', H mdelta' (6), its gather reads ONE vector (r') -- 14 passes, against 17 of the three-launch trip and 12 of
+// the two-launch trip of msdp_trip2.hip, whose head gathers three vectors and is bound by the L2s instead (17 row loads per row:
+// 530 us of its 830 at n = 10^6, p = 32).  With option trip1 = 2 a single rank without communicator runs this trip as well
+// (the exchange is a no-op: the kernels read r' and the sums in place).
 #include "msdp_device.h"
 #include <math.h>
 
@@ -99,38 +105,43 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg1_upd(Dev d) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RPW = 64 / LPR;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
-    double* __restrict__ xr = d.md2;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
     for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
         const int row = row0 + rsub;
         if (row < hi) {
-            double2 nr[NCH], y[NCH];
+            double2 nr[NCH], y[NCH], ne[NCH], gv[NCH];
             double dot = 0.0;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int col = 2 * sub + ch * 2 * LPR;
-                nr[ch] = make_double2(0.0, 0.0); y[ch] = nr[ch];
+                nr[ch] = make_double2(0.0, 0.0); y[ch] = nr[ch]; ne[ch] = nr[ch]; gv[ch] = nr[ch];
                 if (col < d.ld) {
                     const int64_t o = (int64_t)row * d.ld + col;
-                    const double2 e = ld2(eta + o), m = ld2(d.md + o), hm = ld2(d.Hmd + o), rr = ld2(rold + o), gv = ld2(g + o);
+                    const double2 e = ld2(eta + o), m = ld2(d.md + o), hm = ld2(d.Hmd + o), rr = ld2(rold + o);
+                    gv[ch] = ld2(g + o);
                     y[ch] = ld2(Yl + o);
-                    const double2 ne = make_double2(e.x - alpha * m.x, e.y - alpha * m.y);         // :215
+                    ne[ch] = make_double2(e.x - alpha * m.x, e.y - alpha * m.y);                   // :215
                     nr[ch] = make_double2(rr.x - alpha * hm.x, rr.y - alpha * hm.y);               // :238
-                    const double2 nh = make_double2(nr[ch].x - gv.x, nr[ch].y - gv.y);             // new_Heta (:220)
-                    st2(neta + o, ne);
-                    st2(rnew + o, nr[ch]);
-                    s1 += ne.x * gv.x + ne.y * gv.y;      // <new_eta, grad>     :227
-                    s2 += ne.x * nh.x + ne.y * nh.y;      // <new_eta, new_Heta>
-                    s3 += nr[ch].x * nr[ch].x + nr[ch].y * nr[ch].y;      // r_r :241
                     dot += nr[ch].x * y[ch].x + nr[ch].y * y[ch].y;
                 }
             }
             dot = msdp_group_sum<LPR>(dot);
-            // what the other ranks gather: the PROJECTED residual row (msdp_persist.hip:117-123)
+            // the residual is kept PROJECTED: r and H*mdelta are tangent, so this removes rounding only (1e-16 |r| per trip) -- but
+            // the neighbours' products are assembled from these rows by linearity, where a normal component would stay for good
+            // (msdp_persist.hip:117-123 publishes a projected copy; here the row is the exchange buffer)
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int col = 2 * sub + ch * 2 * LPR;
-                if (col < d.ld) st2(xr + (int64_t)row * d.ld + col, make_double2(nr[ch].x - y[ch].x * dot, nr[ch].y - y[ch].y * dot));
+                if (col < d.ld) {
+                    const int64_t o = (int64_t)row * d.ld + col;
+                    nr[ch].x -= y[ch].x * dot; nr[ch].y -= y[ch].y * dot;
+                    const double2 nh = make_double2(nr[ch].x - gv[ch].x, nr[ch].y - gv[ch].y);     // new_Heta (:220) = r' - grad
+                    st2(neta + o, ne[ch]);
+                    st2(rnew + o, nr[ch]);
+                    s1 += ne[ch].x * gv[ch].x + ne[ch].y * gv[ch].y;      // <new_eta, grad>     :227
+                    s2 += ne[ch].x * nh.x + ne[ch].y * nh.y;              // <new_eta, new_Heta>
+                    s3 += nr[ch].x * nr[ch].x + nr[ch].y * nr[ch].y;      // r_r                 :241
+                }
             }
         }
     }
@@ -241,13 +252,14 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg1_head(Dev d) {
     }
     const double* __restrict__ rn = nix ? d.r2 : d.r;
     const double* __restrict__ Xf = d.full;
-    double* __restrict__ cmd = d.W0;
     double* __restrict__ H = d.Hmd;
     double pd = 0.0;
-    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
+    int stride = MSDP_WAVES * RPW;
+    if (d.sweep) msdp_sweep_rows(d.n_loc, d.G, MSDP_WAVES * RPW, lo, hi, stride);     // (the streaming loop above keeps the chunks)
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += stride) {
         const int row = row0 + rsub;
         if (row < hi) {
-            double2 acc[NCH], y[NCH], u[NCH];
+            double2 acc[NCH], y[NCH], u[NCH], x[NCH];
             double udot = 0.0;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
@@ -257,41 +269,36 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg1_head(Dev d) {
                 const int64_t o = (int64_t)row * d.ld + col;
                 y[ch] = ok ? ld2(Yl + o) : make_double2(0.0, 0.0);
                 u[ch] = ok ? ld2(d.md + o) : make_double2(0.0, 0.0);
+                x[ch] = u[ch];                                                          // the row the product is taken of
                 if (!DIRECT) {
-                    const double2 rr = ok ? ld2(rn + o) : make_double2(0.0, 0.0);
-                    u[ch] = make_double2(rr.x + beta * u[ch].x, rr.y + beta * u[ch].y);     // :273
+                    x[ch] = ok ? ld2(rn + o) : make_double2(0.0, 0.0);                  // r' (tangent)
+                    u[ch] = make_double2(x[ch].x + beta * u[ch].x, x[ch].y + beta * u[ch].y);     // :273
                     udot += u[ch].x * y[ch].x + u[ch].y * y[ch].y;
                 }
             }
             const double eg = eG[row];
             spmm_row<LPR, NCH, ELL>(d, row, sub, Xf, acc);
-            if (!DIRECT) {
-                udot = msdp_group_sum<LPR>(udot);
-#pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) {
-                    const int col = 2 * sub + ch * 2 * LPR;
-                    u[ch].x -= y[ch].x * udot; u[ch].y -= y[ch].y * udot;                    // :283
-                    if (col < d.ld) {
-                        const int64_t o = (int64_t)row * d.ld + col;
-                        st2(d.md + o, u[ch]);
-                        const double2 co = ld2(cmd + o);
-                        acc[ch].x = fma(beta, co.x, acc[ch].x); acc[ch].y = fma(beta, co.y, acc[ch].y);
-                    }
-                }
-            }
             double dot = 0.0;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) dot += acc[ch].x * y[ch].x + acc[ch].y * y[ch].y;
             dot = msdp_group_sum<LPR>(dot);                 // sum(Y.*eH)
+            if (!DIRECT) udot = msdp_group_sum<LPR>(udot);
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int col = 2 * sub + ch * 2 * LPR;
                 if (col < d.ld) {
                     const int64_t o = (int64_t)row * d.ld + col;
-                    st2(cmd + o, acc[ch]);
+                    // Hess(x) of the gathered vector (ManiSDP_onlyunitdiag.m:128-129)
                     double2 hq;
-                    hq.x = acc[ch].x - y[ch].x * dot - u[ch].x * eg;
-                    hq.y = acc[ch].y - y[ch].y * dot - u[ch].y * eg;
+                    hq.x = acc[ch].x - y[ch].x * dot - x[ch].x * eg;
+                    hq.y = acc[ch].y - y[ch].y * dot - x[ch].y * eg;
+                    if (!DIRECT) {
+                        // Hess is linear on the tangent space: Hess(mdelta') = Hess(r') + beta * Hess(mdelta)
+                        const double2 ho = ld2(H + o);
+                        hq.x = fma(beta, ho.x, hq.x); hq.y = fma(beta, ho.y, hq.y);
+                        u[ch].x -= y[ch].x * udot; u[ch].y -= y[ch].y * udot;            // :283
+                        st2(d.md + o, u[ch]);
+                    }
                     st2(H + o, hq);
                     pd += u[ch].x * hq.x + u[ch].y * hq.y;
                 }
@@ -310,11 +317,16 @@ static inline void t1_lpr_for(int ld, int& lpr, int& nch) {
     if (nch < 1) nch = 1;
 }
 
-// trip1 = 1 (default): every row-sharded handle with sparse C on the oblique manifold; 0: the three-launch trip with its two all-reduces
+// trip1 = 1 (default): every row-sharded handle with sparse C on the oblique manifold, and a single rank from 2^21 vector entries
+// on (measured, tools/trip1_single_probe.py: n = 10^6, p = 32: 773 us per trip against 889 two-launch and 943 three-launch;
+// n = 250 000, p = 32: 190 / 227 / 216; below that the persistent kernel runs anyway); 2: always; 0: never
 int msdp_trip1_ok(msdp_handle h) {
     const Dev& d = h->d;
-    return h->tune.trip1 && h->use_comm && d.costkind == COST_SPARSE && d.manifold == MANI_OBLIQUE && d.r2 && d.md2 && d.W0 && d.xs
-           && d.xs_all && d.xcount && !d.rowfree && d.ld <= 1024 && h->nranks <= MSDP_XS_MAX_RANKS;
+    if (!(h->tune.trip1 && d.costkind == COST_SPARSE && d.manifold == MANI_OBLIQUE && d.r2 && d.xs && d.xs_all && d.xcount && !d.rowfree
+          && d.ld <= 1024 && h->nranks <= MSDP_XS_MAX_RANKS)) return 0;
+    if (h->use_comm) return 1;
+    if (h->nranks != 1) return 0;
+    return h->tune.trip1 >= 2 || (int64_t)d.n_loc * d.ld >= ((int64_t)1 << 21);
 }
 
 int msdp_launch_trip1_init(msdp_handle h) {

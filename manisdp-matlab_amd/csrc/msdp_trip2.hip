@@ -162,7 +162,9 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg2_head(Dev d) {
     double* __restrict__ mdn = mi ? d.md : d.md2;                          // new direction: the other buffer
     double* __restrict__ H = d.Hmd;
     double pd = 0.0;
-    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
+    int stride = MSDP_WAVES * RPW;
+    if (d.sweep) msdp_sweep_rows(d.n_loc, d.G, MSDP_WAVES * RPW, lo, hi, stride);     // (the streaming loops above keep the chunks)
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += stride) {
         const int row = row0 + rsub;
         if (row < hi) {
             double2 acc[NCH], y[NCH], u[NCH];

@@ -282,13 +282,16 @@ def test_persistent_tcg_keeps_heta_equal_to_hess_eta_on_G81(lib, p):
     n = C.shape[0]
     Y, _ = _rand_point(n, p, seed=0)
     devs = {}
-    for name, persist, trip2 in (("persistent", 1, 1), ("two-launch", 0, 1), ("three-launch", 0, 0), ("sharded", 0, 0)):
+    for name, persist, trip2 in (("persistent", 1, 1), ("two-launch", 0, 1), ("three-launch", 0, 0), ("sharded", 0, 0), ("linear", 0, 0)):
         h = lib.Handle.onlyunitdiag(C, pcap=p)
         if name == "sharded":
             # the row-sharded trip with one all-reduce (msdp_trip1.hip) assembles its products by the same linearity, with the
             # same refresh schedule; a communicator of one in-process member runs exactly that code
             h.comm_init_local(1, 0, 7700 + p)
         h.set_option("persist", persist)
+        # "linear": the same trip on one rank without communicator (the chunked path's default from 2^21 vector entries on),
+        # replayed from hipGraphs with the refresh launches appended behind every fourth replay
+        h.set_option("trip1", 2 if name == "linear" else (1 if name == "sharded" else 0))
         h.set_option("trip2", 2 * trip2)
         h.set_option("fused_rtr", 0)                       # the step is handed over through global memory
         h.set_point(Y)
@@ -317,7 +320,7 @@ def test_persistent_tcg_keeps_heta_equal_to_hess_eta_on_G81(lib, p):
         h.close()
     for (name, trips), (dev, hv, stop) in devs.items():
         assert hv == trips, (name, trips, hv, stop)                 # the whole budget, not an early exit
-        assert dev <= (2e-11 if name in ("persistent", "sharded") else 2e-12), (name, trips, dev, hv, stop)
+        assert dev <= (2e-11 if name in ("persistent", "sharded", "linear") else 2e-12), (name, trips, dev, hv, stop)
 
 
 @pytest.mark.parametrize("shape,p,k", [((20, 30), 3, 0), ((20, 30), 16, 0), ((33, 37), 20, 0), ((25, 40), 40, 0), ((20, 30), 80, 0),
@@ -338,10 +341,11 @@ def test_two_launch_trip_matches_oracle_and_three_launch_trip(lib, shape, p, k):
     Y, _ = _rand_point(n, p, seed=11)
     prob = R._OnlyUnitDiagProblem(C, n, p, q1="correct")
     hs = []
-    for trip2 in (1, 0):
+    for trip2, trip1 in ((1, 0), (0, 0), (0, 2)):
         h = lib.Handle.onlyunitdiag(C, pcap=p)
         h.set_option("persist", 0)
         h.set_option("trip2", 2 * trip2)                    # 2: also below the size from which it is the default
+        h.set_option("trip1", trip1)                        # 2: the linear-product trip of msdp_trip1.hip on one rank
         hs.append(h)
     for maxinner in (1, 2, 7, 8, 16, 100):
         _, f_ref, info = manopt_rtr.trustregions(prob, Y.copy(), 1, maxinner, 1e-8)
@@ -355,9 +359,11 @@ def test_two_launch_trip_matches_oracle_and_three_launch_trip(lib, shape, p, k):
             assert abs(st.cost - f_ref) < 1e-11 * max(1.0, abs(f_ref))
             assert abs(st.gradnorm - info.gradnorm) < 1e-8 * max(1.0, info.gradnorm)
             steps.append(h.debug_get_tcg_step())
-        (e2, h2), (e3, h3) = steps
+        (e2, h2), (e3, h3), (e1, h1) = steps
         assert np.linalg.norm(e2 - e3) <= 1e-10 * max(1.0, np.linalg.norm(e3))
         assert np.linalg.norm(h2 - h3) <= 1e-10 * max(1.0, np.linalg.norm(h3))
+        assert np.linalg.norm(e1 - e3) <= 1e-10 * max(1.0, np.linalg.norm(e3))
+        assert np.linalg.norm(h1 - h3) <= 1e-10 * max(1.0, np.linalg.norm(h3))
     # full solves: same decisions all the way (iterations, Hess-vecs, accepted / rejected steps), same optimum
     outs = []
     for h in hs:
