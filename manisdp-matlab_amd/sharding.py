@@ -79,16 +79,16 @@ def tcg_one_allreduce(Cl, Yl, gl, eGl, Delta, maxinner, exchange, allreduce, kap
 
     ``Cl``: this rank's rows of C (global columns); ``Yl, gl, eGl``: its rows of the point, of the Riemannian gradient and of
     eG.  ``exchange(rows, sums)`` returns (all n rows, the list of every rank's ``sums`` in rank order) -- one collective;
-    ``allreduce(x)`` sums a scalar over the ranks -- the other.  The residual rows travel projected, the product with the new
-    direction follows by linearity, C*mdelta' = C*tangent(r') + beta * C*mdelta, and every ``refresh``-th trip exchanges the
-    direction itself once more.  Returns (eta rows, Heta rows, inner iterations, stop code) like the oracle's tCG."""
+    ``allreduce(x)`` sums a scalar over the ranks -- the other.  The residual is kept projected, the Hess-vec of the new
+    direction follows by linearity, H mdelta' = H r' + beta * H mdelta (the Hessian is a linear map on the tangent space), and
+    every ``refresh``-th trip exchanges the direction itself once more.  Returns (eta rows, Heta rows, inner iterations, stop code) like the oracle's tCG."""
     import math
 
     def tangent(v):                                         # obliquefactory: v - Y .* rowdot(Y, v)
         return v - Yl * np.sum(Yl * v, axis=1, keepdims=True)
 
-    def hess_rows(cmd, md):                                 # ManiSDP_onlyunitdiag.m:128-130 on the own rows
-        return cmd - Yl * np.sum(Yl * cmd, axis=1, keepdims=True) - md * eGl
+    def hess_rows(cx, x):                                   # ManiSDP_onlyunitdiag.m:128-130 on the own rows, cx = rows of C*x
+        return cx - Yl * np.sum(Yl * cx, axis=1, keepdims=True) - x * eGl
 
     eta = np.zeros_like(gl)
     r = gl.copy()
@@ -97,8 +97,7 @@ def tcg_one_allreduce(Cl, Yl, gl, eGl, Delta, maxinner, exchange, allreduce, kap
     norm_r0 = math.sqrt(r_r)
     z_r, d_Pd, e_Pd, e_Pe, model_value = r_r, r_r, 0.0, 0.0, 0.0
     full, _ = exchange(md, [0.0, 0.0, 0.0])                 # first trip: direct product with the gradient rows
-    cmd = Cl @ full
-    Hmd = hess_rows(cmd, md)
+    Hmd = hess_rows(Cl @ full, md)
     d_Hd = allreduce(float(np.sum(md * Hmd)))               # tCG.m:166
     stop, j = 5, 0
     for j in range(1, maxinner + 1):
@@ -108,10 +107,10 @@ def tcg_one_allreduce(Cl, Yl, gl, eGl, Delta, maxinner, exchange, allreduce, kap
             tau = (-e_Pd + math.sqrt(e_Pd * e_Pd + d_Pd * (Delta ** 2 - e_Pe))) / d_Pd
             return eta - tau * md, (r - tau * Hmd) - gl, j, (1 if d_Hd <= 0 else 2)      # Heta = r - grad (:198,220,238)
         new_eta = eta - alpha * md                                            # :215
-        new_r = r - alpha * Hmd                                               # :238
+        new_r = tangent(r - alpha * Hmd)                                      # :238, kept projected (rounding only)
         new_Heta = new_r - gl
         sums = [float(np.sum(new_eta * gl)), float(np.sum(new_eta * new_Heta)), float(np.sum(new_r * new_r))]
-        full, all_sums = exchange(tangent(new_r), sums)                       # THE exchange: rows + every rank's sums
+        full, all_sums = exchange(new_r, sums)                                # THE exchange: rows + every rank's sums
         s1 = s2 = r_r = 0.0
         for q in all_sums:                                                    # rank order: the same bits on every rank
             s1 += q[0]; s2 += q[1]; r_r += q[2]
@@ -125,11 +124,10 @@ def tcg_one_allreduce(Cl, Yl, gl, eGl, Delta, maxinner, exchange, allreduce, kap
             break
         beta = r_r / z_r                                                      # :272
         md = tangent(r + beta * md)                                           # :273,283
-        cmd = Cl @ full + beta * cmd                                          # linearity
+        Hmd = hess_rows(Cl @ full, r) + beta * Hmd                            # linearity: H mdelta' = H r' + beta * H mdelta
         if refresh > 0 and j % refresh == 0:                                  # direct product every refresh-th trip
             full, _ = exchange(md, [0.0, 0.0, 0.0])
-            cmd = Cl @ full
-        Hmd = hess_rows(cmd, md)
+            Hmd = hess_rows(Cl @ full, md)
         e_Pd = beta * (e_Pd + alpha * d_Pd)                                   # :286
         d_Pd = r_r + beta * beta * d_Pd                                       # :287
         z_r = r_r
