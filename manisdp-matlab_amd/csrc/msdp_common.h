@@ -146,7 +146,7 @@ struct Tuning {
                              //   already fills the chip, the fork / join only adds dependencies.  Kept as an A/B switch, default off.
     int sweep = 1;           // windowed row traversal of the large-vector gather kernels: 1 = from 2^21 vector entries per rank on, 2 always, 0 never
     int trip1 = 1;           // msdp_trip1.hip (sparse C / oblique): row-sharded handles -- one exchange + one all-reduce per tCG trip instead of one + two;
-                             // one rank, chunked path -- the same two launches (14 vector passes, one gathered vector) from 2^21 vector entries on; 2: always; 0: never
+                             // one rank, chunked path -- the same two launches (14 vector passes, one gathered vector); 0: never
     int trip2 = 1;           // chunked path, sparse C / oblique / one rank: two launches per tCG trip (msdp_trip2.hip) instead of three
     int escape_method = 0;   // 0: block Chebyshev-filtered subspace iteration where it applies (msdp_blockeig.hip), else Lanczos;
                              //   1: Lanczos always (msdp_escape.hip); 2: block also below its size threshold (tests)

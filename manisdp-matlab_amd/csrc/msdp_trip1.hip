@@ -317,16 +317,17 @@ static inline void t1_lpr_for(int ld, int& lpr, int& nch) {
     if (nch < 1) nch = 1;
 }
 
-// trip1 = 1 (default): every row-sharded handle with sparse C on the oblique manifold, and a single rank from 2^21 vector entries
-// on (measured, tools/trip1_single_probe.py: n = 10^6, p = 32: 773 us per trip against 889 two-launch and 943 three-launch;
-// n = 250 000, p = 32: 190 / 227 / 216; below that the persistent kernel runs anyway); 2: always; 0: never
+// trip1 = 1 (default): every row-sharded handle with sparse C on the oblique manifold, and the chunked path of a single rank
+// (measured, tools/trip1_single_probe.py and trip1_small_probe.py, linear / two-launch / three-launch: n = 10^6, p = 32: 773 /
+// 889 / 943 us per trip; n = 250 000, p = 32: 190 / 227 / 216; n = 40 000, p = 40: 51 / 63 / 57; G81 with the persistent kernel
+// off, p = 32: 21.7 / 25.4 / 23.7, p = 128: 62 / 67 / 75; G1 (CSR rows), p = 40: 34.4 / 48.2 / 34.7); 0: the two- / three-launch
+// trips (msdp_trip2.hip, msdp_kernels.hip)
 int msdp_trip1_ok(msdp_handle h) {
     const Dev& d = h->d;
     if (!(h->tune.trip1 && d.costkind == COST_SPARSE && d.manifold == MANI_OBLIQUE && d.r2 && d.xs && d.xs_all && d.xcount && !d.rowfree
           && d.ld <= 1024 && h->nranks <= MSDP_XS_MAX_RANKS)) return 0;
     if (h->use_comm) return 1;
-    if (h->nranks != 1) return 0;
-    return h->tune.trip1 >= 2 || (int64_t)d.n_loc * d.ld >= ((int64_t)1 << 21);
+    return h->nranks == 1;
 }
 
 int msdp_launch_trip1_init(msdp_handle h) {

@@ -25,7 +25,7 @@ def test_size1_communicator_is_bit_identical(monkeypatch):
         if use_comm:
             h.comm_init(1, 0, _lib.Handle.comm_unique_id())
             assert h.local_rows() == (0, n)
-            h.set_option("trip1", trip1)                  # 0: the three-launch trip, the kernels of the communicator-free path
+        h.set_option("trip1", trip1)                      # 0: the three-launch trip on both sides, the same kernels
         h.set_point(Y)
         H = h.hessvec(U)
         G = h.rgrad()

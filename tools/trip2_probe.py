@@ -15,7 +15,7 @@ for name, C, p in cases:
     res = []
     for trip2 in (1, 0):
         h = _lib.Handle.onlyunitdiag(C, pcap=p)
-        h.set_option("persist", 0); h.set_option("trip2", 2 * trip2)
+        h.set_option("persist", 0); h.set_option("trip1", 0); h.set_option("trip2", 2 * trip2)
         h.set_point(Y)
         t = min(h.bench_tcg_trip(64) for _ in range(3))
         ms, by, fl = h.bench_hessvec(50)
