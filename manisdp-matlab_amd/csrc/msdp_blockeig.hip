@@ -722,6 +722,7 @@ int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const 
     bool converged = false;
     double worst = INFINITY;
     std::vector<double> hist;
+    std::vector<int> hist_deg;
     if (maxdeg > 20000) maxdeg = 20000;                    // (the callers' budgets are Lanczos-sized; G81's cold check takes 2400 steps)
     while (degree < maxdeg) {
         const int r = rr.rank;
@@ -738,7 +739,13 @@ int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const 
         // at a near-stationary point (G81: x0 - 1 = 5e-5) the cap is 1600 and d_round decides.
         const double x0 = 1.0 + 2.0 * (aedge - a0) / std::max(bup - aedge, 1e-300);
         const int d_cond = (int)std::max(4.0, std::floor(16.0 / std::max(acosh(x0), 1e-6)));
-        const int d = std::min(std::min(d_round, d_cond), std::max(2, maxdeg - degree));
+        // A restarted filter only compounds what each round gains, and cosh is flat near 0: where the usual degree amplifies a0 by
+        // less than cosh(1) = 1.5 per round (n = 160 000 of the G81 family: 64 eigenvalues within 1e-6 of the spectrum's width,
+        // acosh(x0) = 1.9e-3 -- twelve rounds of 200 steps gained a factor 2.3 and the call gave up) the round is made long enough
+        // for cosh(3) = 10
+        int d_want = d_round;
+        if ((double)d_round * acosh(x0) < 1.0) d_want = (int)std::min(2500.0, std::ceil(3.0 / std::max(acosh(x0), 1e-6)));
+        const int d = std::min(std::min(d_want, d_cond), std::max(2, maxdeg - degree));
         // scaled Chebyshev recurrence (Zhou & Saad, 2007): the value at a0 stays 1 whatever the degree
         const double e = 0.5 * (bup - aedge), c = 0.5 * (bup + aedge);
         double sigma = e / (a0 - c);
@@ -784,10 +791,16 @@ int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const 
             if (!(err <= thr)) ok = false;
         }
         // a call that stopped making progress ends as "not converged" (msdp_escape_info) instead of walking its whole budget
+        // (measured against the last round that lies at least eight rounds and 2400 filter steps back: less than a factor two since)
         hist.push_back(ok ? 0.0 : worst);
-        if (!ok && hist.size() > 12 && worst > 0.5 * hist[hist.size() - 13]) {
-            if (dbg) fprintf(stderr, "[blockeig] no progress over twelve rounds (worst %.2e): giving up\n", worst);
-            break;
+        hist_deg.push_back(degree);
+        if (!ok) {
+            int j = (int)hist.size() - 9;
+            while (j >= 0 && degree - hist_deg[j] < 2400) --j;
+            if (j >= 0 && worst > 0.5 * hist[j]) {
+                if (dbg) fprintf(stderr, "[blockeig] no progress over %d rounds / %d steps (worst %.2e, was %.2e): giving up\n", (int)hist.size() - 1 - j, degree - hist_deg[j], worst, hist[j]);
+                break;
+            }
         }
         if (dbg) fprintf(stderr, "[blockeig] round %d deg %d: a=%.3e a0=%.3e theta0=%.9e theta[k-1]=%.3e top=%.3e res0=%.2e rank=%d worst=%.2e %s\n",
                          rounds, degree, aedge, a0, rr.theta[0], rr.theta[std::min(k, rk) - 1], rr.theta[rk - 1], rr.res[0], rk, worst, ok ? "converged" : "");

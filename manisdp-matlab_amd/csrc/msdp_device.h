@@ -207,15 +207,29 @@ __device__ __forceinline__ void frame_store(Frame* o, double z_r, double d_Pd, d
 __device__ __forceinline__ double2 msdp_sum_slabs(const double* __restrict__ slab, int64_t slab_stride, int SK, int64_t o) {
     double2 acc = make_double2(0.0, 0.0);
     int s = 0;
-    for (; s + 4 <= SK; s += 4) {
-        const double2 v0 = ld2(slab + (int64_t)s * slab_stride + o), v1 = ld2(slab + (int64_t)(s + 1) * slab_stride + o);
-        const double2 v2 = ld2(slab + (int64_t)(s + 2) * slab_stride + o), v3 = ld2(slab + (int64_t)(s + 3) * slab_stride + o);
-        acc.x += v0.x; acc.y += v0.y; acc.x += v1.x; acc.y += v1.y;
-        acc.x += v2.x; acc.y += v2.y; acc.x += v3.x; acc.y += v3.y;
+    // eight, then four, then the last <= 3 loads in flight together; the additions stay in slab order (same bits as a plain loop).
+    // Round 3: the affine Hess-vec of BQP d = 60 sums 26 slabs -- seven dependent round trips with batches of four.
+    for (; s + 8 <= SK; s += 8) {
+        double2 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = ld2(slab + (int64_t)(s + q) * slab_stride + o);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { acc.x += v[q].x; acc.y += v[q].y; }
     }
-    for (; s < SK; ++s) {
-        const double2 v = ld2(slab + (int64_t)s * slab_stride + o);
-        acc.x += v.x; acc.y += v.y;
+    if (s + 4 <= SK) {
+        double2 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ld2(slab + (int64_t)(s + q) * slab_stride + o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc.x += v[q].x; acc.y += v[q].y; }
+        s += 4;
+    }
+    if (s < SK) {
+        double2 v[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[q] = (s + q < SK) ? ld2(slab + (int64_t)(s + q) * slab_stride + o) : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) if (s + q < SK) { acc.x += v[q].x; acc.y += v[q].y; }
     }
     return acc;
 }
