@@ -184,3 +184,18 @@ def test_block_escape_on_a_dense_operand_matches_lapack(lib, kind):
     assert conv and abs(lam1[0] - w[0]) <= 1e-8 * scale
     assert np.linalg.norm(S @ V1[:, 0] - lam1[0] * V1[:, 0]) <= 1e-4 * scale
     h.close()
+
+
+def test_block_escape_lengthens_its_rounds_on_a_dense_bottom_cluster(lib):
+    """The G81 family at n = 80 000 (toroidal 400 x 200 grid; bench.py --gpus 4 solves it sharded): near its optimum the bottom
+    of the spectrum of S is a cluster of more than 64 eigenvalues within a few 1e-6 of the width.  Rounds of 200 filter steps
+    gain cosh(200 acosh x0) ~ 1.1 there and the calls used to stall (the Lanczos path took over: 12-57 k steps each at
+    n = 160 000); with the rounds lengthened to cosh(3) every call converges on the block path.  Whole solve: KKT 1e-8, no
+    escape call needed a second attempt or ended unconverged."""
+    from manisdp_matlab_amd import problems, solvers
+    C = problems.toroidal_grid_maxcut(400, 200, seed=81)
+    Y, obj, data = solvers.ManiSDP_onlyunitdiag(C, {"p0": 40}, verbose=False)
+    assert data["status"] == 0 and data["dinf"] < 1e-8
+    assert data.get("eig_retries", 0) == 0 and data.get("eig_unconverged", 0) == 0
+    assert data["escape_method"] == 1                      # the last regular escape call ran the block eigen-solver
+    assert abs(obj + 62417.9192527) <= 1e-6 * 62417.9      # the value both rounds' builds and the Lanczos escape reach
