@@ -47,5 +47,7 @@ python3 tools/pmc_to_json.py k_dense_partial3 "$OUT/pmc_dense20000_p32.json" "$O
 python3 tools/pmc_to_json.py k_dense_partial3 "$OUT/pmc_k5shard_p64.json" "$OUT/k5shard_fetch" "$OUT/k5shard_write"
 python3 tools/pmc_sum.py "$OUT/pmc_bqp60_p32.json" k_dense_hess_epi hbm_bytes_per_hessvec --only k_gram_mfma,k_gram_apply,k_adjoint_tiled,k_dense_partial3,k_dense_hess_epi "$OUT/bqp60_fetch" "$OUT/bqp60_write"
 python3 tools/pmc_sum.py "$OUT/pmc_theta5000_p32.json" k_sph_hess_finish hbm_bytes_per_hessvec --only k_sddmm,k_support_spmm,k_dense_partial3,k_sph_hess_raw,k_sph_hess_finish "$OUT/theta5000_fetch" "$OUT/theta5000_write"
-python3 tools/pmc_sum.py "$OUT/pmc_chunked_n1e6_p32.json" k_tcg2_upd hbm_bytes_per_trip --only k_tcg2_head,k_tcg2_upd "$OUT/chunked1e6_fetch" "$OUT/chunked1e6_write"
+# (the chunked path's default trip is the linear-product one of msdp_trip1.hip; profiles/r3_pmc_chunked_n1e6_p32.json -- the two-launch trip
+#  of msdp_trip2.hip -- was collected the same way before it became the default, i.e. with option trip1 = 0)
+python3 tools/pmc_sum.py "$OUT/pmc_linear_n1e6_p32.json" k_tcg1_upd hbm_bytes_per_trip --only k_tcg1_upd,k_tcg1_head "$OUT/chunked1e6_fetch" "$OUT/chunked1e6_write"
 ls "$OUT" | grep -v "^[a-z0-9_]*$"
