@@ -91,7 +91,7 @@ def test_unitdiag_bqp_kkt_self_certification():
     assert np.linalg.norm(At.T @ X.ravel(order="F") - b) / (1 + np.linalg.norm(b)) < 1e-8
 
 
-@pytest.mark.parametrize("name", ["theta1", "theta2", "theta3", "theta4"])
+@pytest.mark.parametrize("name", ["theta1", "theta2", "theta3", "theta4", "theta5"])
 def test_unittrace_theta(name):
     """theta1..theta4 (data/sdplib/README:98-101, 7 digits): constraint 1 is tr X = 1, F0 = J.  With the default trust-region
     budget (3 x 40) the reference's algorithm leaves through "Slow progress" at KKT residues of 1e-5..1e-4 with the value right
