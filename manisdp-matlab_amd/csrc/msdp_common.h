@@ -84,7 +84,7 @@ struct Dev {
     double* mdx;      // persistent tCG: exchange buffer of the direction rows (uncached memory, sc1 accesses only)
     double* Hmd;
     double* full;     // gather source of n x ld (== local buffer when nranks == 1)
-    double* W0;       // scratch n_loc x ld (sharded one-all-reduce trip, msdp_trip1.hip: C*mdelta of the own rows)
+    double* W0;       // scratch n_loc x ld
     double* W1;
     // msdp_trip1.hip: this rank's three sums of a trip (xs[0..2]), all ranks' (xs_all[4*q + 0..2], filled by the exchange), the
     // arrival counter of the launch that forms xs, the number of ranks
