@@ -467,6 +467,7 @@ def test_sharded_trip_issues_one_exchange_and_one_allreduce(N, halo):
             h.comm_init_local(N, r, group)
             h.set_option("halo_exchange", halo)
             h.set_option("trip1", trip1)
+            h.set_option("sweep", 2 if halo else 0)            # the windowed row traversal of the gather launch, on every rank's rows
             h.set_point(Y0)
             c0 = h.collective_calls()
             h.bench_tcg_trip(reps)

@@ -375,3 +375,32 @@ def test_two_launch_trip_matches_oracle_and_three_launch_trip(lib, shape, p, k):
     _, f_ref, info = manopt_rtr.trustregions(prob, Y.copy(), 40, 100, 1e-8)
     for it, cost, hv in outs:
         assert abs(cost - f_ref) < 1e-6 * max(1.0, abs(f_ref))
+
+
+@pytest.mark.parametrize("shape,p", [((223, 227), 12), ((97, 531), 40), ((1, 4099), 6)])
+def test_windowed_row_traversal_covers_every_row_once(lib, shape, p):
+    """Option sweep (msdp_sweep_rows, msdp_device.h): from 2^21 vector entries on, the gather launch of the chunked tCG trip walks
+    the rows window by window -- the co-resident workgroups of an XCD take consecutive 64-row blocks -- instead of chunk by chunk.
+    Forced here at sizes whose row counts are no multiple of anything (50 621 = 223 x 227, 51 507, 4099 rows; p = 6, 12, 40:
+    4, 8 and 32 lanes per row) against the chunk traversal: the same rows get the same numbers, only the per-workgroup partial
+    sums are formed over different row sets -- Hess-vec counts and stop codes equal, costs and points equal to rounding --
+    with the linear-product trip (the default) and the two-launch trip."""
+    from manisdp_matlab_amd import problems
+    C = problems.toroidal_grid_maxcut(shape[0], shape[1], seed=5) if shape[0] > 1 else _ring_lattice_cost(shape[1], 3, seed=6)
+    n = C.shape[0]
+    Y, _ = _rand_point(n, p, seed=2)
+    for trip1, trip2 in ((1, 0), (0, 2)):
+        out = []
+        for sweep in (2, 0):
+            h = lib.Handle.onlyunitdiag(C, pcap=p)
+            h.set_option("persist", 0)
+            h.set_option("trip1", trip1); h.set_option("trip2", trip2)
+            h.set_option("sweep", sweep)
+            h.set_point(Y)
+            st = h.rtr(lib.default_opts(maxiter=6, maxinner=40, tolgradnorm=1e-9))
+            out.append((st.hessvecs, st.accepted, st.rejected, st.last_stop_inner, st.cost, h.get_point()))
+            h.close()
+        a, b = out
+        assert a[:4] == b[:4]
+        assert abs(a[4] - b[4]) <= 1e-12 * abs(b[4])
+        assert np.linalg.norm(a[5] - b[5]) <= 1e-9 * np.linalg.norm(b[5])
