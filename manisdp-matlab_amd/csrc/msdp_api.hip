@@ -875,6 +875,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "halo_exchange")) { t.halo_exchange = value != 0; h->state_valid = false; }
     else if (!strcmp(name, "dense_pack")) { t.dense_pack = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "debug_fail_persist")) t.fail_persist = value != 0;
+    else if (!strcmp(name, "debug_fail_block")) t.fail_block = value != 0;
     else { msdp_set_error("set_option: unknown option '%s'", name); return MSDP_EINVAL; }
     return 0;
 }

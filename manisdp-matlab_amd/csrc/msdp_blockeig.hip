@@ -826,6 +826,7 @@ int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const 
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     if (degree_out) *degree_out = degree;
+    if (h->tune.fail_block) { h->tune.fail_block = 0; converged = false; }      // test hook: report this call as unconverged
     if (conv_out) *conv_out = converged;
     if (err_out) *err_out = worst;
     if (lower_out) *lower_out = rr.theta[0] - worst * scale_top;

@@ -199,3 +199,57 @@ def test_block_escape_lengthens_its_rounds_on_a_dense_bottom_cluster(lib):
     assert data.get("eig_retries", 0) == 0 and data.get("eig_unconverged", 0) == 0
     assert data["escape_method"] == 1                      # the last regular escape call ran the block eigen-solver
     assert abs(obj + 62417.9192527) <= 1e-6 * 62417.9      # the value both rounds' builds and the Lanczos escape reach
+
+
+def test_unconverged_block_call_is_repeated_on_the_lanczos_path(lib):
+    """msdp_escape_eigs never hands an unconverged block result to the host loops when the Lanczos path can do better: a block
+    call that ends without passing its stop test (forced here by the test hook debug_fail_block; in the field: a bottom cluster
+    wider than the panel with no gap behind it) is repeated on the Lanczos path inside the same C call.  The outcome is the
+    Lanczos run's: converged, lambda_min right against LAPACK, msdp_escape_method = 0, both attempts counted in the steps; with
+    escape_method = 2 (block only) the same call reports the failure instead."""
+    from manisdp_matlab_amd import problems
+    C = problems.toroidal_grid_maxcut(50, 60, seed=9)            # n = 3000: the block eigen-solver's default territory
+    n, p = C.shape[0], 6
+    rng = np.random.default_rng(4)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    out = {}
+    for method in (0, 2):
+        h = lib.Handle.onlyunitdiag(C)
+        h.set_option("escape_method", method)
+        h.set_option("escape_deflate", 0); h.set_option("escape_warm", 0)
+        h.set_point(Y)
+        lam_b, _, _, steps_b = h.escape_eigs(1, tol=1e-10, maxit=2000)       # the block path, undisturbed
+        assert h.escape_method() == 1 and h.escape_info()[1]
+        h.set_option("debug_fail_block", 1)
+        lam, V, lmax, steps = h.escape_eigs(1, tol=1e-10, maxit=2000)
+        nvalid, conv, res = h.escape_info()
+        out[method] = (lam[0], V[:, 0].copy(), lmax, conv, h.escape_method(), steps, steps_b, lam_b[0])
+        if method == 0:
+            S, w, U = _reference(C, h)
+        h.close()
+    lam0, v, lmax, conv, ran, steps, steps_b, lam_b = out[0]
+    assert conv and ran == 0 and steps > steps_b                 # the Lanczos run's outcome; both attempts are counted
+    scale = max(abs(w[0]), abs(w[-1]))
+    assert abs(lam0 - w[0]) <= 1e-8 * scale and abs(lam_b - w[0]) <= 1e-8 * scale and abs(lmax - w[-1]) <= 1e-6 * scale
+    assert np.linalg.norm(S @ v - lam0 * v) <= 1e-6 * scale
+    assert not out[2][3] and out[2][4] == 1                      # block only: unconverged, and said so
+
+
+def test_factor_wider_than_the_panel_takes_the_lanczos_path(lib):
+    """The panel must hold span(Y) and noise columns beside it (msdp_blockeig_eligible): a factor of more than 112 columns takes
+    the Lanczos path (sparse C, 128-wide panel); 100 columns still run on the block path.  Same lambda_min either way."""
+    from manisdp_matlab_amd import problems
+    C = problems.toroidal_grid_maxcut(50, 50, seed=2)            # n = 2500
+    n = C.shape[0]
+    rng = np.random.default_rng(1)
+    vals = {}
+    for p in (100, 120):
+        Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+        h = lib.Handle.onlyunitdiag(C, pcap=p)
+        h.set_point(Y)
+        lam, V, lmax, steps = h.escape_eigs(2, tol=1e-9, maxit=20000)
+        _, conv, _ = h.escape_info()
+        S, w, U = _reference(C, h)
+        assert conv and h.escape_method() == (1 if p == 100 else 0)
+        assert abs(lam[0] - w[0]) <= 1e-8 * max(abs(w[0]), abs(w[-1]))
+        h.close()
