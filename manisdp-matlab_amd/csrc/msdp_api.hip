@@ -143,14 +143,16 @@ static void choose_grid(msdp_handle h) {
     while (lpr < half && lpr < 64) lpr <<= 1;
     const int rows_per_step = MSDP_WAVES * (64 / lpr);
     int want = (rows_capacity(h) + rows_per_step - 1) / rows_per_step;
-    // One or two workgroups per CU, never a fraction in between: with 256 < G < 512 some CUs get two
-    // 1024-thread workgroups and the launch waits for them (measured on G81 p=32: G=320 -> 27.4 us per tCG
-    // trip, G=256 -> 24.1 us).
+    // At most one workgroup per CU: beyond 256 some CUs get a second 1024-thread workgroup and the launch waits for it
+    // (measured on G81 p=32: G=320 -> 27.4 us per tCG trip, G=256 -> 24.1 us).  Round 3 (tools/grid_probe.py, option grid):
+    // 512 workgroups -- two full rounds -- lose as well, at every size: n = 40 000, p = 40: 50.6 us per trip against 43.1 with
+    // 256; n = 80 000, p = 40: 79.0 / 71.3; n = 250 000, p = 64: 390 / 378; n = 10^6, p = 32: 770 / 766 (the stand-alone S*U
+    // kernel alone gains 8 % from 512 at n = 10^6 and loses 8 % at n = 40 000).
     const int gmax = MSDP_MAX_GRID;
     int G = ((want + 7) / 8) * 8;
     if (G < 8) G = 8;
-    if (G > 256 && G < 512) G = 256;
-    if (G > gmax) G = (gmax / 8) * 8;
+    if (G > 256) G = 256;
+    if (h->tune.grid > 0) G = std::min((gmax / 8) * 8, std::max(8, ((h->tune.grid + 7) / 8) * 8));    // A/B switch
     d.G = G;
     d.sweep = (h->tune.sweep >= 2 || (h->tune.sweep == 1 && (int64_t)rows_capacity(h) * d.ld >= ((int64_t)1 << 21))) ? 1 : 0;
 }
@@ -876,6 +878,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "dense_pack")) { t.dense_pack = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "debug_fail_persist")) t.fail_persist = value != 0;
     else if (!strcmp(name, "debug_fail_block")) t.fail_block = value != 0;
+    else if (!strcmp(name, "grid")) { t.grid = value > 0 ? value : 0; choose_grid(h); h->chunk_len = 0; }
     else { msdp_set_error("set_option: unknown option '%s'", name); return MSDP_EINVAL; }
     return 0;
 }

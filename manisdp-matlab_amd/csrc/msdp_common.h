@@ -154,6 +154,7 @@ struct Tuning {
     int be_degree = 0;       // ... filter degree per round (0: 200 warm, 400 cold)
     int be_grid = 0;         // ... workgroups of the filter step (0: by rows)
     int be_lpr = 0;          // ... lanes per row of the filter step (0: by rows per workgroup)
+    int grid = 0;          // workgroups of the row-parallel launches (0: choose_grid; A/B switch)
     int fail_block = 0;    // test hook (msdp_set_option "debug_fail_block"): the next block eigen-solver call reports itself unconverged
     int fail_persist = 0;  // test hook (msdp_set_option "debug_fail_persist"): the next persistent launch reports a
                            //   grid-synchronisation time-out without running, to exercise the recovery path

@@ -396,6 +396,8 @@ def test_windowed_row_traversal_covers_every_row_once(lib, shape, p):
             h.set_option("persist", 0)
             h.set_option("trip1", trip1); h.set_option("trip2", trip2)
             h.set_option("sweep", sweep)
+            if p == 40:
+                h.set_option("grid", 512)                   # two rounds of workgroups: the two-phase form of the traversal
             h.set_point(Y)
             st = h.rtr(lib.default_opts(maxiter=6, maxinner=40, tolgradnorm=1e-9))
             out.append((st.hessvecs, st.accepted, st.rejected, st.last_stop_inner, st.cost, h.get_point()))
