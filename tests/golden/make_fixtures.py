@@ -30,6 +30,9 @@ FILES = [
     "bqp_Q_10_1.txt", "bqp_e_10_1.txt", "bqp_Q_20_1.txt", "bqp_e_20_1.txt",
     "bqp_Q_30_1.txt", "bqp_e_30_1.txt", "qs_c_10_1.txt",
     "bqp_Q_60_1.txt", "bqp_e_60_1.txt",          # BASELINE.json configs[2] (n = 1831, m = 1 155 281)
+    # data/sdplib/README:104-105.  Listed with the theta family, but NOT unit-trace problems: constraints 1..n are X_ii = 1
+    # (n = 801 / 1001 = |V| + 1), the others tie a 3 x 3 all-ones pattern per edge to 1 -> ManiSDP_unitdiag instances
+    "sdplib/thetaG11.dat-s", "sdplib/thetaG51.dat-s",
 ]
 
 # data/sdplib/README:39-51 (gpp), :71-88 (maxG/mcp), :98-105 (theta): optimal objective values, AS PRINTED there (the number
@@ -46,6 +49,7 @@ PRINTED = {
     "gpp500-4": "-1.56702e+03",
     "theta1": "2.300000e+01", "theta2": "3.287917e+01", "theta3": "4.216698e+01", "theta4": "5.032122e+01",
     "theta5": "5.723231e+01", "theta6": "6.347709e+01",
+    "thetaG11": "4.000000e+02", "thetaG51": "3.49000e+02",
 }
 # Not used as a pin: maxG51.  data/sdplib/maxG51.dat-s is Gset G51 (same matrix as data/Gset/G51.txt through either reader);
 # the oracle certifies 4006.2555 for it (dinf 5e-12) where README:73 prints 4.003809e+03 -- the file and the printed value

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from conftest import golden_path, within_print
+from conftest import bqp_bruteforce_min, golden_path, within_print
 
 pytestmark = pytest.mark.gpu
 
@@ -97,3 +97,40 @@ def test_unittrace_theta6_as_far_as_it_gets():
     assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-3
     assert abs(-obj - float(PRINTED["theta6"])) < 5e-7 * float(PRINTED["theta6"])
 
+
+
+@pytest.mark.parametrize("d", [10, 20])
+@pytest.mark.parametrize("eig", ["host", "device"])
+def test_bqp_relaxation_is_bounded_by_the_bruteforce_minimum(d, eig):
+    """Generator + ManiSDP_unitdiag pinned WITHOUT the oracle (src/basicfunction/bqpmom.m:1-5, example/example_bqp.m:36-43):
+    the relaxation value is a lower bound of min over {-1,1}^d of x'Qx + e'x (2^d points enumerated on the host), with
+    equality when the returned X has rank one -- then its first column is a sign vector that attains the value."""
+    from manisdp_matlab_amd import problems, solvers
+    Q = np.loadtxt(golden_path(f"bqp_Q_{d}_1.txt.gz"), delimiter=",")
+    e = np.loadtxt(golden_path(f"bqp_e_{d}_1.txt.gz"), delimiter=",")
+    fmin, xmin = bqp_bruteforce_min(Q, e)
+    At, b, c, K = problems.bqpmom(d, Q, e)
+    c = np.asarray(c.todense()).ravel()
+    maxc = np.abs(c).max()
+    Y, obj, data = solvers.ManiSDP_unitdiag(At, b, c / maxc, K, {"tol": 1e-8, "eig": eig}, verbose=False)
+    assert data["status"] == 0 and max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
+    val = obj * maxc
+    assert val <= fmin + 1e-6 * max(1.0, abs(fmin))
+    sv = np.linalg.svd(Y, compute_uv=False)
+    if sv[1] < 1e-6 * sv[0]:
+        assert abs(val - fmin) <= 1e-6 * max(1.0, abs(fmin))
+        X = Y @ Y.T
+        x = np.sign(X[1:d + 1, 0])
+        assert abs(x @ Q @ x + e @ x - fmin) <= 1e-9 * max(1.0, abs(fmin))
+
+
+@pytest.mark.parametrize("eig", ["host", "device"])
+def test_unitdiag_thetaG11(eig):
+    """data/sdplib/README:104: thetaG11 (n = 801, m = 2401) is a unit-diagonal instance (tests/test_oracle_known_answers.py checks
+    the structure) -> ManiSDP_unitdiag, default options, 7 printed digits."""
+    from manisdp_matlab_amd import solvers
+    At, b, c, K = _sdpa("thetaG11")
+    Y, obj, data = solvers.ManiSDP_unitdiag(At, b, c, K, {"tol": 1e-8, "eig": eig}, verbose=False)
+    assert data["status"] == 0 and max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
+    assert within_print(-obj, PRINTED["thetaG11"])
+    assert np.abs(np.linalg.norm(Y, axis=1) - 1.0).max() < 1e-12

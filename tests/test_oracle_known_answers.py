@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from conftest import golden_path, within_print
+from conftest import bqp_bruteforce_min, golden_path, within_print
 from manisdp_matlab_amd import problems
 from oracle import manisdp_ref as R
 
@@ -178,3 +178,44 @@ def test_dual_oracle_agrees_with_primal_oracle():
             _, fd, dd = R.ManiDSDP_unitdiag(A, bs, cs, Ks, {"tol": 1e-8, "dAAt": dAAt, "line_search": ls}, rng=np.random.default_rng(0))
             assert dd["status"] == 0 and max(dd["gap"], dd["pinf"], dd["dinf"]) < 1e-8
             assert abs(fd * maxb - fp) <= 1e-6 * max(1.0, abs(fp))
+
+
+@pytest.mark.parametrize("d", [10])
+def test_bqp_relaxation_is_bounded_by_the_bruteforce_minimum(d):
+    """A pin of bqpmom + ManiSDP_unitdiag that is independent of any restatement: the second-order moment relaxation
+    (src/basicfunction/bqpmom.m:1-5: Min x'Qx + x'e, x_i^2 = 1) is a LOWER bound of the minimum over the 2^d sign vectors,
+    and when the returned X has rank one its first column IS a sign vector attaining the value, so the two are equal.
+    Instance: data/bqp_Q_10_1.txt / bqp_e_10_1.txt, scaled as example/example_bqp.m:39-41 does."""
+    Q = np.loadtxt(golden_path(f"bqp_Q_{d}_1.txt.gz"), delimiter=",")
+    e = np.loadtxt(golden_path(f"bqp_e_{d}_1.txt.gz"), delimiter=",")
+    fmin, xmin = bqp_bruteforce_min(Q, e)
+    At, b, c, K = problems.bqpmom(d, Q, e)
+    c = np.asarray(c.todense()).ravel()
+    maxc = np.abs(c).max()
+    Y, obj, data = R.ManiSDP_unitdiag(At, b, c / maxc, K, {"tol": 1e-8})
+    assert data["status"] == 0 and max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
+    val = obj * maxc
+    assert val <= fmin + 1e-6 * max(1.0, abs(fmin))
+    sv = np.linalg.svd(Y, compute_uv=False)
+    if sv[1] < 1e-6 * sv[0]:                                   # rank one: the relaxation is tight
+        assert abs(val - fmin) <= 1e-6 * max(1.0, abs(fmin))
+        X = Y @ Y.T
+        x = np.sign(X[1:d + 1, 0])
+        assert abs(x @ Q @ x + e @ x - fmin) <= 1e-9 * max(1.0, abs(fmin))
+
+
+def test_unitdiag_thetaG11():
+    """data/sdplib/README:104 (thetaG11: m = 2401, n = 801, 4.000000e+02).  Listed with the theta family, but the instance is
+    a unit-DIAGONAL problem -- constraints 1..801 are X_ii = 1, the other 1600 tie one 3 x 3 all-ones pattern per edge of
+    Gset G11 to 1 -- so it pins ManiSDP_unitdiag (default options) at n = 801, to the 7 printed digits."""
+    At, b, c, K = problems.from_sdpa(golden_path("thetaG11.dat-s.gz"))
+    At = At.tocsc()
+    n = K["s"]
+    assert (n, At.shape[1]) == (801, 2401)
+    for k in range(n):                                        # the structure the choice of entry point rests on
+        col = At[:, k].tocoo()
+        assert col.nnz == 1 and col.row[0] == k * n + k and col.data[0] == 1.0
+    c = np.asarray(c.todense()).ravel()
+    Y, obj, data = R.ManiSDP_unitdiag(At, np.asarray(b).ravel(), c, K, {"tol": 1e-8})
+    assert data["status"] == 0 and max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
+    assert within_print(-obj, PRINTED["thetaG11"])
