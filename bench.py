@@ -374,7 +374,8 @@ def main():
         "config": {"workload": workload, "n": n, "p": p, "nnz_C": int(C.nnz),
                    "TR_maxiter": 40, "TR_maxinner": 100, "hessvecs_per_step": hv / args.steps,
                    "parallelism": "rows%d" % N,
-                   "tcg_path": "persistent single-launch kernel" if persistent else "chunked hipGraph, 3 kernels per trip"},
+                   "tcg_path": "persistent single-launch kernel" if persistent else
+                               "chunked hipGraph, two launches per trip (linear-product trip, msdp_trip1.hip)"},
         "roofline": roofline,
         "hessvec_kernel": hess_kernel,
         "tcg_trip_us": trip_ms * 1e3,
@@ -405,7 +406,8 @@ def main():
         # setting options.p0 = 40 (example/example_maxcut.m:32), everything else default
         from manisdp_matlab_amd import solvers
         # two solves, each on a fresh handle: the first pays the process's one-time costs (code objects of the escape
-        # kernels, first allocation of the 10-GB Lanczos workspace); the second is the figure, like the warmed-up steps above
+        # kernels, first allocation of the block eigen-solver's 0.35-GB workspace); the second is the figure, like the
+        # warmed-up steps above
         t1 = time.perf_counter()
         solvers.ManiSDP_onlyunitdiag(C, {"p0": 40}, verbose=False)
         first_s = time.perf_counter() - t1
@@ -478,16 +480,25 @@ def main():
             trip_us = min(hl.bench_tcg_trip(64) for _ in range(3)) * 1e3
             msl, byl, fll = hl.bench_hessvec(50)
             path = hl.tcg_path()
+            hl_passes = 14
             hl.close()
             vec = ln * ln * lp * 8.0
-            algo = 14 * vec + Cl.nnz * 12.0              # 14 vector passes + the (index, value) slices of C the head reads
+            npass = hl_passes
+            formulation = npass * vec + Cl.nnz * 12.0    # what the two launches stream: their vector passes + the (index, value) slices of C
+            # the ALGORITHMIC traffic of a trip is that of its one Hess-vec -- nnz*12 + 4(n+1) + 3*8*n*p + 8n
+            algo = Cl.nnz * 12.0 + 4.0 * (ln * ln + 1) + 3.0 * vec + 8.0 * ln * ln
             out["large_sparse_trip"] = {
                 "workload": "toroidal grid MaxCut n=%d, p=%d, one tCG trip (tCG.m:160-287) of the chunked path" % (ln * ln, lp),
                 "n": ln * ln, "p": lp, "tcg_path": path, "trip_us": trip_us, "hessvec_kernel_us": msl * 1e3,
-                "vector_passes_per_trip": 14,
+                "vector_passes_per_trip": npass,
                 "roofline": secondary_roofline("k_tcg1_upd + k_tcg1_head", trip_us, algo, 0.0,
-                                               ("r3_pmc_linear_n1e6_p32.json",), bound="hbm", per="tCG trip")}
+                                               ("r4_pmc_linear_n1e6_p32.json", "r3_pmc_linear_n1e6_p32.json"), bound="hbm", per="tCG trip")}
             rec = out["large_sparse_trip"]["roofline"]
+            rec["formulation_bytes"] = formulation
+            rec["formulation_GBps"] = formulation / (trip_us * 1e-6) / 1e9
+            rec["formulation_frac_of_hbm_peak"] = rec["formulation_GBps"] / HBM_PEAK_GBS
+            rec["note"] = ("algorithmic_bytes = the Hess-vec of SURVEY.md 8(d) (one per trip); formulation_bytes = the %d vector passes "
+                           "the two launches of the trip actually stream -- the gap between the two fractions is the pass count, not the kernels" % npass)
             if rec.get("traffic") is None and rec.get("traffic_source"):
                 rec["traffic"] = json.load(open(os.path.join(ROOT, rec["traffic_source"]))).get("hbm_bytes_per_trip")
         except Exception as e:  # noqa: BLE001 -- secondary figure

@@ -75,12 +75,28 @@ struct AffineDev {
     const int* ls0;        // its range in trk / trv
     const int* ls1;
     int nlong_e;
+    // fused SDDMM (k_sddmm1): short constraints are summed whole by one lane group; the items of the long ones go through
+    // ival and are summed by the workgroup that arrives last
+    int nshort; const int* sk;         // short constraints (<= FIN_SHORT items)
+    int nlit; const int* lit0; const int* lit1;   // items of the long constraints
+    const int* lkit;                   // nlong + 1: items of long constraint q (= longk[q]) are lkit[q] .. lkit[q+1]-1
+    unsigned* cnt;                     // arrival counter
+    // B route of the Hess-vec (symmetric data, every constraint short): A'(A(M)) on the upper entries as ONE sparse matrix applied
+    // to the Gram matrix, B[e][e'] = sum_k a_k[e] * c_k[e'] (k_adjoint_gram): no m-vector, no second pass over At
+    int bW;                // ELL width of B (0: route not built)
+    const int* bidx;       // [ntp][bW][1024]: position i'*nS + j' (i' <= j') in Wsym; padding = position 0 with coefficient 0
+    const double* bval;    // [ntp][bW][1024]
+    const unsigned char* blong;   // [ntp][1024]: row longer than bW (summed by one wave each, like the long entries of the tiled adjoint)
+    const int* blpos; const int* blmir; const int* bls0; const int* bls1; int bnlong;
+    const int* blk; const double* blv;       // (position, coefficient) pairs of the long rows
+    double* Wg;            // Gram matrix of the B route (n x nS): AyU is written while it is read
     const int* sup;        // entries r = i*n + j that occur in some constraint (nsup > 0: At touches few entries)
     const int* suprow;     // n+1: the entries of matrix row i are sup[suprow[i] .. suprow[i+1])
     int nsup;
 };
 
 #define SDDMM_CHUNK 16
+#define SPB 4                   // panel rows requested together by the sparse A'(w)*Y products
 #define FIN_SHORT 8           // constraints with more items than this are summed by a whole wave (k_sddmm_finish)
 // item value = sum over the item's nonzeros (i,j,val) of val * <Ya_i, Yb_j>   (one LPR-lane group per item)
 template <int LPR, int NCH>
@@ -172,6 +188,219 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm_finish(AffineDev a, int mo
         }
     }
     if (mode == 1) msdp_put_partial(P, P_AXB, pss, sh);
+}
+
+// k_sddmm + k_sddmm_finish in ONE launch (one rank).  A lane group sums a short constraint whole (its nonzeros are contiguous)
+// and writes w_k; the items of the long constraints (trace rows) go to ival with agent-coherent stores and the workgroup that
+// arrives last sums them per constraint in item order -- the same order whichever workgroup it is.
+//   mode 0: w.   mode 1 (cost): also Axb = w - b - y/sigma -> axb_out and the partial sums of Axb^2 -> P_AXB: launch with
+//   MSDP_MAX_GRID - 1 workgroups, slot MSDP_MAX_GRID - 1 takes the long constraints.   mode 2 (sphere Hess-vec, Ya = Y, Yb = U):
+//   also the partial sums of w_k (A x)_k -> P_T3 (slot gridDim.x: the long constraints) with (A x)_k = Axb_k + b_k + y_k/sigma of
+//   the current point, and of <U, G>, <U, Y> over this workgroup's rows -> P_T1, P_T2: together they give the sphere's
+//   tr(H Y') without a pass over H (k_sph_hess_fused).
+template <int LPR, int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm1(AffineDev a, Dev d, const double* __restrict__ Ya, const double* __restrict__ Yb,
+                                                     int mode, double* axb_out, double sigma, const int* skip_flag, int skip_when) {
+    __shared__ double sh[3 * MSDP_WAVES + 8];
+    __shared__ int lastflag;
+    if (skip_flag && *skip_flag == skip_when) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int CPW = 64 / LPR;
+    const int sub = lane & (LPR - 1), csub = lane / LPR;
+    const int64_t nunits = (int64_t)a.nshort + a.nlit;
+    const int cur = mode == 2 ? d.ctl->cur : 0;
+    const double* __restrict__ axc = cur ? a.Axb[1] : a.Axb[0];
+    const int slotL = mode == 1 ? MSDP_MAX_GRID - 1 : (int)gridDim.x;
+    double pacc = 0.0;
+    const int64_t ustride = (int64_t)gridDim.x * MSDP_WAVES * CPW;
+    for (int64_t u = ((int64_t)blockIdx.x * MSDP_WAVES + wave) * CPW + csub; u < nunits; u += ustride) {
+        int s0, s1, k = -1, lq = 0;
+        if (u < a.nshort) { k = a.sk[u]; s0 = a.cjc[k]; s1 = a.cjc[k + 1]; }
+        else { lq = (int)(u - a.nshort); s0 = a.lit0[lq]; s1 = a.lit1[lq]; }
+        double acc = 0.0;
+        constexpr int U = NCH == 1 ? 4 : 2;
+        for (int t = s0; t < s1; t += U) {
+            int ii[U], jj[U];
+            double vv[U], dd[U];
+#pragma unroll
+            for (int u2 = 0; u2 < U; ++u2) {
+                const bool in = t + u2 < s1;
+                const int tt = in ? t + u2 : s1 - 1;
+                ii[u2] = a.ci[tt]; jj[u2] = a.cj[tt];
+                vv[u2] = in ? a.cv[tt] : 0.0;
+                dd[u2] = 0.0;
+            }
+#pragma unroll
+            for (int u2 = 0; u2 < U; ++u2) {
+                const double* ya = Ya + (int64_t)ii[u2] * a.ld + 2 * sub;
+                const double* yb = Yb + (int64_t)jj[u2] * a.ld + 2 * sub;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    if (2 * sub + ch * 2 * LPR < a.ld) {
+                        const double2 x = ld2(ya + ch * 2 * LPR), z = ld2(yb + ch * 2 * LPR);
+                        dd[u2] += x.x * z.x + x.y * z.y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u2 = 0; u2 < U; ++u2) acc = fma(vv[u2], dd[u2], acc);
+        }
+        acc = msdp_group_sum<LPR>(acc);
+        if (sub == 0) {
+            if (k >= 0) {
+                a.w[k] = acc;
+                if (mode == 1) { const double r = acc - a.b[k] - a.y[k] / sigma; axb_out[k] = r; pacc += r * r; }
+                else if (mode == 2) pacc += acc * (axc[k] + a.b[k] + a.y[k] / sigma);
+            } else {
+                __hip_atomic_store(a.ival + lq, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (mode == 2) {
+        // <U, G> and <U, Y> over the rows of this workgroup (plain contiguous chunks; U = Yb, Y = Ya)
+        int lo, hi;
+        {
+            const unsigned q = (unsigned)d.n_loc / gridDim.x, r = (unsigned)d.n_loc - q * gridDim.x, c = blockIdx.x;
+            lo = (int)(c * q + (c < r ? c : r)); hi = lo + (int)q + (c < r ? 1 : 0);
+        }
+        const double* __restrict__ Gr = cur ? d.Gr[1] : d.Gr[0];
+        const int64_t e0 = (int64_t)lo * d.ld, e1 = (int64_t)hi * d.ld;
+        double p1 = 0.0, p2 = 0.0;
+        for (int64_t i = e0 + 2 * threadIdx.x; i < e1; i += 2 * MSDP_BLOCK) {
+            const double2 u = ld2(Yb + i), g = ld2(Gr + i), y = ld2(Ya + i);
+            p1 += u.x * g.x + u.y * g.y;
+            p2 += u.x * y.x + u.y * y.y;
+        }
+        msdp_put_partials3(d.P, P_T1, p1, P_T2, p2, P_T3, pacc, sh);
+    } else if (mode == 1) {
+        msdp_put_partial(d.P, P_AXB, pacc, sh);
+    }
+    // ---- long constraints: the last workgroup to arrive sums their items
+    if (a.nlit == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && mode != 0) d.P[(mode == 1 ? P_AXB : P_T3) * MSDP_MAX_GRID + slotL] = 0.0;
+        return;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) lastflag = (__hip_atomic_fetch_add(a.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!lastflag) return;
+    double pl = 0.0;
+    for (int q = wave; q < a.nlong; q += MSDP_WAVES) {
+        const int k = a.longk[q];
+        const int i0 = a.lkit[q], i1 = a.lkit[q + 1];
+        double a0 = 0.0, a1 = 0.0;
+        int it = i0 + lane;
+        for (; it + 64 < i1; it += 128) {
+            a0 += __hip_atomic_load(a.ival + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a1 += __hip_atomic_load(a.ival + it + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (it < i1) a0 += __hip_atomic_load(a.ival + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double acc = msdp_wave_sum(a0 + a1);
+        if (lane == 0) {
+            a.w[k] = acc;
+            if (mode == 1) { const double r = acc - a.b[k] - a.y[k] / sigma; axb_out[k] = r; pl += r * r; }
+            else if (mode == 2) pl += acc * (axc[k] + a.b[k] + a.y[k] / sigma);
+        }
+    }
+    __syncthreads();                                       // sh is free again (msdp_put_partials3 above has finished)
+    if (lane == 0) sh[wave] = pl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < MSDP_WAVES; ++i) s += sh[i];
+        if (mode != 0) d.P[(mode == 1 ? P_AXB : P_T3) * MSDP_MAX_GRID + slotL] = s;
+        *a.cnt = 0u;
+    }
+}
+
+// Sphere Hess-vec, everything behind the dense contraction in ONE launch (ManiSDP_unittrace.m:173-176, ManiSDP.m:160-162):
+//   H_raw(i,:) = sum of the split-K slabs (2*eS*U, or 2*eS*U + 4 sigma AyU*Y when AyU is dense)
+//              + 4 sigma * sum_j A'(w)_ij Y(j,:) over the entries At touches (k_support_spmm's sparse product, when nsup > 0)
+//   H = H_raw - t*Y - 2 z U,  t = tr(H_raw Y'),   partial sums of <U, H> -> P_DHD.
+// t needs no pass over H_raw: <2 eS U, Y> = <U, 2 eS Y> = <U, G> + 2 z <U, Y> (G = 2 eS Y - 2 z Y is the stored gradient, eS is
+// symmetric) and <4 sigma A'(w) Y, Y> = 4 sigma <w, A(Y Y')> -- the three sums k_sddmm1 (mode 2) left in P_T1..P_T3.
+// One wave per row; replaces k_support_spmm + k_sph_hess_raw + k_sph_hess_finish (20 us of launches at n = 5000).
+template <int NCH>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev a, const double* slab, int64_t slab_stride, int SK,
+                                                             double sigma, int G2, int support) {
+    __shared__ double sh[3 * MSDP_WAVES + 8];
+    if (!d.F[0].active) return;
+    const bool euc = d.manifold == MANI_EUCLID;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cur = d.ctl->cur;
+    double t = 0.0, z = 0.0;
+    if (!euc) {
+        if (threadIdx.x < 64) {
+            const double s1 = msdp_sum_partials(d.P, P_T1, G2), s2 = msdp_sum_partials(d.P, P_T2, G2), s3 = msdp_sum_partials(d.P, P_T3, G2 + 1);
+            if (threadIdx.x == 0) { sh[0] = s1; sh[1] = s2; sh[2] = s3; }
+        }
+        __syncthreads();
+        z = d.ctl->z_sphere[cur];
+        t = (sh[0] + 2.0 * z * sh[1]) + 4.0 * sigma * sh[2];
+        __syncthreads();
+    }
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
+    const double* __restrict__ w = a.w;
+    const double s4 = 4.0 * sigma;
+    double pd = 0.0;
+    for (int i = lo + wave; i < hi; i += MSDP_WAVES) {
+        double2 acc[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) acc[ch] = make_double2(0.0, 0.0);
+        if (support) {
+            const int q1 = a.suprow[i + 1];
+            for (int q0 = a.suprow[i]; q0 < q1; q0 += 64) {
+                const int cnt = min(64, q1 - q0);
+                int jl = 0;
+                double vl = 0.0;
+                if (lane < cnt) {
+                    const int r = a.sup[q0 + lane];
+                    jl = r - i * a.n;
+                    const int s0 = a.rp[r], s1 = a.rp[r + 1];
+                    for (int tt = s0; tt < s1; ++tt) vl = fma(a.rv[tt], w[a.rk[tt]], vl);
+                }
+                for (int e0 = 0; e0 < cnt; e0 += SPB) {
+                    int jj[SPB];
+                    double v[SPB];
+#pragma unroll
+                    for (int u = 0; u < SPB; ++u) {
+                        const int e = min(e0 + u, cnt - 1);
+                        jj[u] = __shfl(jl, e);
+                        v[u] = (e0 + u < cnt) ? __shfl(vl, e) : 0.0;
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) {
+                        const int c = 2 * lane + 128 * ch;
+                        if (c < d.ld) {
+                            double2 y[SPB];
+#pragma unroll
+                            for (int u = 0; u < SPB; ++u) y[u] = ld2(Yl + (int64_t)jj[u] * d.ld + c);
+#pragma unroll
+                            for (int u = 0; u < SPB; ++u) { acc[ch].x = fma(v[u], y[u].x, acc[ch].x); acc[ch].y = fma(v[u], y[u].y, acc[ch].y); }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = 2 * lane + 128 * ch;
+            if (c < d.ld) {
+                const int64_t o = (int64_t)i * d.ld + c;
+                const double2 ds = msdp_sum_slabs(slab, slab_stride, SK, o);
+                const double2 y = ld2(Yl + o), u = ld2(d.md + o);
+                double2 hq;
+                hq.x = (ds.x + s4 * acc[ch].x) - t * y.x - 2.0 * z * u.x;
+                hq.y = (ds.y + s4 * acc[ch].y) - t * y.y - 2.0 * z * u.y;
+                st2(d.Hmd + o, hq);
+                pd += u.x * hq.x + u.y * hq.y;
+            }
+        }
+    }
+    msdp_put_partial(d.P, P_DHD, pd, sh + 8);
 }
 
 // fp64-MFMA version of k_gram (default): W = Ya * Yb' as 64 x 64 tiles, four waves per tile in a 2 x 2 arrangement,
@@ -464,6 +693,75 @@ __global__ __launch_bounds__(256) void k_adjoint_tiled(AffineDev a, const double
     }
 }
 
+
+// B route: out = scale * B * Wsym on the 32 x 32 tiles on and above the diagonal, mirrored like k_adjoint_tiled.  Wsym = Ya*Yb' +
+// Yb*Ya' comes from k_gram_mfma (upper 64 x 64 tiles).  Replaces k_gram_apply (one gather per nonzero of the upper At, writes w)
+// + k_adjoint_tiled (one gather of w per nonzero): for BQP d = 60 4.2 M coefficients instead of 2 x 2.4 M, two dependent round
+// trips (ELL slice -> gather) instead of three + three, and no 9-MB m-vector in between.
+template <int BW>
+__global__ __launch_bounds__(256) void k_adjoint_gram(AffineDev a, const double* __restrict__ Wsym, double scale, double* __restrict__ out,
+                                                      const int* skip_flag, int skip_when) {
+    __shared__ double tile[ADJ_T][ADJ_T + 1];
+    if (skip_flag && *skip_flag == skip_when) return;
+    if ((int)blockIdx.x >= a.ntp) {
+        const int lane = threadIdx.x & 63;
+        const int q = ((int)blockIdx.x - a.ntp) * 4 + (threadIdx.x >> 6);
+        if (q >= a.bnlong) return;
+        const int t0 = a.bls0[q], t1 = a.bls1[q];
+        double acc = 0.0;
+        for (int t = t0 + lane; t < t1; t += 64) acc = fma(a.blv[t], Wsym[a.blk[t]], acc);
+        acc = msdp_wave_sum(acc);
+        if (lane == 0) {
+            const int o = a.blpos[q], om = a.blmir[q];
+            const double v = scale * acc;
+            out[o] = v;
+            if (om != o) out[om] = v;
+        }
+        return;
+    }
+    const int bi = a.tp_i[blockIdx.x], bj = a.tp_j[blockIdx.x];
+    const int lj = threadIdx.x & 31, li0 = threadIdx.x >> 5;
+    const size_t tb = (size_t)blockIdx.x * BW * (ADJ_T * ADJ_T);
+    int idx[4][BW];
+    double val[4][BW];
+    bool lng[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = (li0 + 8 * q) * ADJ_T + lj;
+        lng[q] = a.blong[(size_t)blockIdx.x * (ADJ_T * ADJ_T) + e] != 0;
+#pragma unroll
+        for (int w = 0; w < BW; ++w) { idx[q][w] = a.bidx[tb + (size_t)w * (ADJ_T * ADJ_T) + e]; val[q][w] = a.bval[tb + (size_t)w * (ADJ_T * ADJ_T) + e]; }
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int w = 0; w < BW; ++w)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = fma(val[q][w], Wsym[idx[q][w]], acc[q]);
+    const int j = bj * ADJ_T + lj;
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = bi * ADJ_T + li0 + 8 * q;
+        v[q] = 0.0;
+        if (i < a.n && j < a.nS && !lng[q]) {
+            const size_t o = (size_t)i * a.nS + j;
+            if (j < a.n) v[q] = scale * acc[q];
+            out[o] = v[q];
+        }
+    }
+    if (bi == bj) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tile[li0 + 8 * q][lj] = lng[q] ? __longlong_as_double(0x7ff8000000000000LL) : v[q];
+    __syncthreads();
+    const int jm = bi * ADJ_T + lj;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int im = bj * ADJ_T + li0 + 8 * q;
+        const double tv = tile[lj][li0 + 8 * q];
+        if (im < a.n && jm < a.nS && tv == tv) out[(size_t)im * a.nS + jm] = (jm < a.n) ? tv : 0.0;
+    }
+}
+
 // The same update restricted to the entries that occur in some constraint.  For the SDPLIB-type problems (theta, gpp:
 // m = O(n) constraints of a few entries each) At touches a fraction of a percent of the n^2 entries, and `out` keeps
 // its value everywhere else from one call to the next (eS = C there, AyU = 0 there), so the full sweep above moves
@@ -485,7 +783,6 @@ __global__ __launch_bounds__(256) void k_adjoint_support(AffineDev a, const doub
 // out(i,:) = scale * sum_j (A'(w))_ij * Yp(j,:) over the entries (i,j) At touches: the product AyU*Y of the Hess-vec
 // without forming AyU (ManiSDP_unitdiag.m:168-169, ManiSDP_unittrace.m:173-174).  One wave per matrix row; the
 // adjoint values of the entries of a row are computed one per lane, the panel rows are read 16 bytes per lane.  The result is handed to the epilogue as one more split-K slab.
-#define SPB 4
 template <int NCH>
 __global__ __launch_bounds__(256) void k_support_spmm(AffineDev a, const double* __restrict__ w, const double* __restrict__ Yp,
                                                       double scale, double* __restrict__ out, const int* skip_flag, int skip_when) {
@@ -773,6 +1070,25 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
         if ((rc = msdp_dev_alloc_bytes(h, &pv, (size_t)std::max<int64_t>(a.nitems, 1) * sizeof(double)))) return rc;
         a.ival = (double*)pv;
     }
+    {
+        // k_sddmm1: short constraints by id, the items of the long ones with their offsets per long constraint
+        std::vector<int> sk, lit0, lit1, lkit;
+        for (int64_t k = 0; k < m; ++k) {
+            if (kit[k + 1] - kit[k] > FIN_SHORT) {
+                lkit.push_back((int)lit0.size());
+                for (int q = kit[k]; q < kit[k + 1]; ++q) { lit0.push_back(it0[q]); lit1.push_back(it1[q]); }
+            } else sk.push_back((int)k);
+        }
+        lkit.push_back((int)lit0.size());
+        a.nshort = (int)sk.size(); a.nlit = (int)lit0.size();
+        if (sk.empty()) sk.push_back(0);
+        if (lit0.empty()) { lit0.push_back(0); lit1.push_back(0); }
+        if ((rc = up(h, sk, &a.sk)) || (rc = up(h, lit0, &a.lit0)) || (rc = up(h, lit1, &a.lit1)) || (rc = up(h, lkit, &a.lkit))) return rc;
+        void* pv = nullptr;
+        if ((rc = msdp_dev_alloc_bytes(h, &pv, 64))) return rc;
+        HIPCHK(hipMemset(pv, 0, 64));
+        a.cnt = (unsigned*)pv;
+    }
     if ((rc = up(h, cjc, &a.cjc)) || (rc = up(h, ci, &a.ci)) || (rc = up(h, cj, &a.cj)) || (rc = up(h, cv, &a.cv)) ||
         (rc = up(h, rp, &a.rp)) || (rc = up(h, rk, &a.rk)) || (rc = up(h, rv, &a.rv)) || (rc = up(h, cidx, &a.cidx)))
         return rc;
@@ -790,7 +1106,10 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
             }
         a.trp = nullptr; a.trk = nullptr; a.trv = nullptr; a.tp_i = nullptr; a.tp_j = nullptr; a.ntp = 0;
         a.lpos = nullptr; a.lmir = nullptr; a.ls0 = nullptr; a.ls1 = nullptr; a.nlong_e = 0;
+        a.bW = 0; a.bnlong = 0; a.bidx = nullptr; a.bval = nullptr; a.blong = nullptr; a.Wg = nullptr;
         a.usym = 0; a.unitems = 0; a.uit0 = a.uit1 = a.ukit = a.ulongk = a.ucidx = a.ucjc = nullptr; a.ucv = nullptr; a.unlong = 0;
+        std::vector<int> ucidx_h, ucjc_h;
+        std::vector<double> ucv_h;
         if (sym) {
             std::vector<int> ucidx, uit0, uit1, ukit(m + 1), ulongk, ucjc(m + 1);
             std::vector<double> ucv;
@@ -819,6 +1138,8 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
                 (rc = up(h, uit1, &a.uit1)) || (rc = up(h, ukit, &a.ukit)) || (rc = up(h, ulongk, &a.ulongk)) ||
                 (rc = up(h, ucjc, &a.ucjc))) return rc;
             a.usym = 1;
+            ucidx_h = ucidx; ucjc_h = ucjc; ucv_h = ucv;             // kept for the B route below
+            h->dense_symmetric = true;                       // c and every A_k are symmetric: so are eS and A'(w) (msdp_densesym.hip)
         }
         const int ntile = (a.nS + ADJ_T - 1) / ADJ_T;
         if (sym && ntile < 32768) {
@@ -860,6 +1181,68 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
             if ((rc = up(h, trp, &a.trp)) || (rc = up(h, trk, &a.trk)) || (rc = up(h, trv, &a.trv)) ||
                 (rc = up(h, tpi, &a.tp_i)) || (rc = up(h, tpj, &a.tp_j)) || (rc = up(h, lpos, &a.lpos)) ||
                 (rc = up(h, lmir, &a.lmir)) || (rc = up(h, ls0, &a.ls0)) || (rc = up(h, ls1, &a.ls1))) return rc;
+            // ---- B route (k_adjoint_gram): B[e][e'] = sum_k a_k[e] * c_k[e'] over the upper entries, when every constraint is
+            // short (a long one -- a trace row -- would fill B: its square) and At is dense in its rows (the Gram route's case)
+            a.bW = 0;
+            int maxcol = 0;
+            for (int64_t k = 0; k < m; ++k) maxcol = std::max(maxcol, ucjc_h[k + 1] - ucjc_h[k]);
+            if (maxcol > 0 && maxcol <= 8 && (int64_t)nnz * 8 >= nn) {
+                const size_t TE = (size_t)ADJ_T * ADJ_T;
+                std::vector<std::vector<std::pair<int, double>>> rows(tpi.size() * TE);
+                std::vector<int> hist(16, 0);
+                size_t nonempty = 0;
+                std::vector<std::pair<int, double>> acc;
+                for (size_t tp = 0; tp < tpi.size(); ++tp)
+                    for (size_t e = 0; e < TE; ++e) {
+                        const int i = tpi[tp] * ADJ_T + (int)(e / ADJ_T), j = tpj[tp] * ADJ_T + (int)(e % ADJ_T);
+                        if (i >= n || j >= n) continue;
+                        const int64_t r = (int64_t)std::min(i, j) * n + std::max(i, j);
+                        acc.clear();
+                        for (int t = rp[r]; t < rp[r + 1]; ++t) {
+                            const int k = rk[t];
+                            for (int u = ucjc_h[k]; u < ucjc_h[k + 1]; ++u) acc.push_back({ucidx_h[u], rv[t] * ucv_h[u]});
+                        }
+                        std::sort(acc.begin(), acc.end(), [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; });
+                        auto& row = rows[tp * TE + e];
+                        for (size_t q = 0; q < acc.size(); ++q) {
+                            if (!row.empty() && row.back().first == acc[q].first) row.back().second += acc[q].second;
+                            else row.push_back(acc[q]);
+                        }
+                        if (!row.empty()) { ++nonempty; hist[std::min<size_t>(15, row.size())]++; }
+                    }
+                int BW = 4;
+                { size_t cum = 0; for (int w = 1; w <= 4; ++w) { cum += hist[w]; if (cum * 1000 >= nonempty * 990) { BW = w; break; } } }
+                std::vector<int> bidx(tpi.size() * TE * BW, 0);
+                std::vector<double> bval(tpi.size() * TE * BW, 0.0);
+                std::vector<unsigned char> blong(tpi.size() * TE, 0);
+                std::vector<int> blpos, blmir, bls0, bls1, blk;
+                std::vector<double> blv;
+                for (size_t tp = 0; tp < tpi.size(); ++tp)
+                    for (size_t e = 0; e < TE; ++e) {
+                        const auto& row = rows[tp * TE + e];
+                        if ((int)row.size() <= BW) {
+                            for (size_t q = 0; q < row.size(); ++q) {
+                                bidx[(tp * BW + q) * TE + e] = row[q].first;
+                                bval[(tp * BW + q) * TE + e] = row[q].second;
+                            }
+                            continue;
+                        }
+                        blong[tp * TE + e] = 1;
+                        const int i = tpi[tp] * ADJ_T + (int)(e / ADJ_T), j = tpj[tp] * ADJ_T + (int)(e % ADJ_T);
+                        if (i > j) continue;                         // diagonal tile: the upper copy stores both
+                        blpos.push_back(i * a.nS + j); blmir.push_back(j * a.nS + i);
+                        bls0.push_back((int)blk.size());
+                        for (const auto& pr : row) { blk.push_back(pr.first); blv.push_back(pr.second); }
+                        bls1.push_back((int)blk.size());
+                    }
+                a.bnlong = (int)blpos.size();
+                if (blpos.empty()) { blpos.push_back(0); blmir.push_back(0); bls0.push_back(0); bls1.push_back(0); }
+                if (blk.empty()) { blk.push_back(0); blv.push_back(0.0); }
+                if ((rc = up(h, bidx, &a.bidx)) || (rc = up(h, bval, &a.bval)) || (rc = up(h, blong, &a.blong)) ||
+                    (rc = up(h, blpos, &a.blpos)) || (rc = up(h, blmir, &a.blmir)) || (rc = up(h, bls0, &a.bls0)) ||
+                    (rc = up(h, bls1, &a.bls1)) || (rc = up(h, blk, &a.blk)) || (rc = up(h, blv, &a.blv))) return rc;
+                a.bW = BW;
+            }
         }
     }
     {
@@ -912,6 +1295,11 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
     // touches, so the Gram scratch and the dual slack of msdp_al_dual get buffers of their own.
     a.W = d.AyU;
     d.Sdual = d.AyU;
+    if (a.bW > 0) {
+        if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
+        a.Wg = (double*)p;
+        HIPCHK(hipMemset(a.Wg, 0, msz));
+    }
     if (a.nsup > 0) {
         if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
         a.W = (double*)p;
@@ -997,11 +1385,31 @@ static void upper_view(AffineDev& a) {
 // w = A(Ya Yb') (mode 0), or additionally Axb = w - b - y/sigma into axb_out and the partial sums of Axb^2 -> P_AXB
 // (mode 1: exactly MSDP_MAX_GRID workgroups, the count the consumers re-reduce).  `a` is the caller's copy: on the
 // symmetric Gram route it is switched to the upper view.
+static bool sharded(msdp_handle h);
+// mode 2 (k_sddmm1 only, see there): *G2_out = the number of workgroups whose partial sums P_T1..P_T3 carry
+static bool sddmm1_ok(msdp_handle h, const AffineDev& a, int64_t nnz) {
+    return h->tune.affine_fuse && !sharded(h) && !use_gram_route(h, a, nnz, a.ld);
+}
 static int launch_A(msdp_handle h, AffineDev& a, int64_t nnz, const double* Ya, const double* Yb, const int* flag, int when,
-                    int mode, double* axb_out, double sigma) {
+                    int mode, double* axb_out, double sigma, int* G2_out = nullptr) {
     int64_t gm = (a.m + MSDP_BLOCK - 1) / MSDP_BLOCK;           // mode 0: no reduction, size the grid by m
     if (gm > 2048) gm = 2048;
     const int G = mode == 1 ? MSDP_MAX_GRID : (int)gm;
+    if (sddmm1_ok(h, a, nnz)) {
+        int half = a.ld / 2, lpr = 1;
+        while (lpr < half && lpr < 64) lpr <<= 1;
+        const int64_t per_block = (int64_t)MSDP_WAVES * (64 / lpr);
+        int64_t g1 = ((int64_t)a.nshort + a.nlit + per_block - 1) / per_block;
+        if (g1 < 1) g1 = 1;
+        if (g1 > MSDP_MAX_GRID - 1) g1 = MSDP_MAX_GRID - 1;
+        if (mode == 1) g1 = MSDP_MAX_GRID - 1;
+        if (mode == 2 && g1 > h->d.n_loc) g1 = std::max(1, h->d.n_loc);
+        if (G2_out) *G2_out = (int)g1;
+        DISPATCH_LPR_A(k_sddmm1, h, (int)g1, a, h->d, Ya, Yb, mode, axb_out, sigma, flag, when);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    if (mode == 2) { msdp_set_error("launch_A: mode 2 needs the fused SDDMM"); return MSDP_ESTATE; }
     if (use_gram_route(h, a, nnz, a.ld)) {
         dim3 grid((a.nS + 63) / 64, (a.n + 63) / 64);
         const int sym = a.usym ? 1 : 0;
@@ -1068,7 +1476,7 @@ static int launch_support_spmm(msdp_handle h, const AffineDev& a, const double* 
 // (each rank multiplies ITS rows of eS / AyU with the gathered panel) and every row-parallel kernel; their partial sums
 // are all-reduced like those of the other kinds.  The operators read all rows of the point: yfull[slot] keeps the
 // gathered copy of Y[slot] (the Hess-vec needs it next to the gathered direction).
-static bool sharded(msdp_handle h) { return h->use_comm || h->nranks > 1; }
+static bool sharded(msdp_handle h) { return h->use_comm || h->nranks > 1; }   // (declared above launch_A)
 // All n rows of Y[slot].  `gathered`: d.full holds them right now (the caller's all-gather) -> refresh the copy.
 static int full_rows(msdp_handle h, int slot, const double* local, bool gathered, const double** out) {
     if (!sharded(h)) { *out = local; return 0; }
@@ -1203,6 +1611,51 @@ int msdp_affine_hess(msdp_handle h) {
         SK = SKa + SKb;
         if (d.manifold == MANI_OBLIQUE) return msdp_dense_hess_epilogue_obl(h, slab, stride, SK);
         return msdp_sphere_hess_raw(h, slab, stride, SK);
+    }
+    if (a.bW > 0 && h->tune.affine_broute && !sharded(h) && !(a.nsup > 0 && d.ld <= 512) && use_gram_route(h, a, st->nnz, a.ld)) {
+        // B route: AyU = B * (Y U' + U Y') in one sparse pass over the upper entries (k_adjoint_gram) -- no w, At read once
+        dim3 grid((a.nS + 63) / 64, (a.n + 63) / 64);
+        hipLaunchKernelGGL(k_gram_mfma, grid, dim3(512), 0, h->stream, a.n, a.nS, a.ld, Yf, Uf, a.Wg, act, 0, 1);
+        HIPCHK(hipGetLastError());
+        const dim3 ga(a.ntp + (a.bnlong + 3) / 4), ba(256);
+        switch (a.bW) {
+            case 1: hipLaunchKernelGGL(k_adjoint_gram<1>, ga, ba, 0, h->stream, a, (const double*)a.Wg, 1.0, d.AyU, act, 0); break;
+            case 2: hipLaunchKernelGGL(k_adjoint_gram<2>, ga, ba, 0, h->stream, a, (const double*)a.Wg, 1.0, d.AyU, act, 0); break;
+            case 3: hipLaunchKernelGGL(k_adjoint_gram<3>, ga, ba, 0, h->stream, a, (const double*)a.Wg, 1.0, d.AyU, act, 0); break;
+            default: hipLaunchKernelGGL(k_adjoint_gram<4>, ga, ba, 0, h->stream, a, (const double*)a.Wg, 1.0, d.AyU, act, 0); break;
+        }
+        HIPCHK(hipGetLastError());
+        const double* M[2] = {d.eS[cur] + roff, d.AyU + roff};
+        const double* X[2] = {Uf, Yf};
+        const double sc[2] = {2.0, 4.0 * sigma};
+        if ((rc = msdp_dense_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
+        if (d.manifold == MANI_OBLIQUE) return msdp_dense_hess_epilogue_obl(h, slab, stride, SK);
+        return msdp_sphere_hess_raw(h, slab, stride, SK);
+    }
+    if (d.manifold != MANI_OBLIQUE && a.usym && d.ld <= 512 && sddmm1_ok(h, a, st->nnz)) {
+        // sphere / Euclidean factor, SDDMM route, one rank: three launches + the contraction (k_sddmm1 mode 2, [adjoint,]
+        // contraction, k_sph_hess_fused) instead of six
+        int G2 = 0;
+        if ((rc = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 2, (double*)nullptr, sigma, &G2))) return rc;
+        const bool support = a.nsup > 0;
+        if (support) {
+            const double* M[1] = {d.eS[cur]}; const double* X[1] = {d.md}; const double sc[1] = {2.0};
+            if ((rc = msdp_dense_gemm(h, 1, M, X, sc, act, &slab, &stride, &SK))) return rc;
+        } else {
+            if ((rc = launch_adjoint(h, a, (const double*)nullptr, a.w, 1.0, d.AyU, act, 0, true))) return rc;
+            const double* M[2] = {d.eS[cur], d.AyU}; const double* X[2] = {Uf, Yf}; const double sc[2] = {2.0, 4.0 * sigma};
+            if ((rc = msdp_dense_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
+        }
+        const int nch = (d.ld + 127) / 128;
+        const dim3 g(d.G), b(MSDP_BLOCK);
+        switch (nch) {
+            case 1: hipLaunchKernelGGL(k_sph_hess_fused<1>, g, b, 0, h->stream, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0); break;
+            case 2: hipLaunchKernelGGL(k_sph_hess_fused<2>, g, b, 0, h->stream, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0); break;
+            case 3: hipLaunchKernelGGL(k_sph_hess_fused<3>, g, b, 0, h->stream, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0); break;
+            default: hipLaunchKernelGGL(k_sph_hess_fused<4>, g, b, 0, h->stream, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0); break;
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
     }
     // w = A(Y U') ; AyU = A'(w)
     { int rc0 = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 0, (double*)nullptr, sigma); if (rc0) return rc0; }

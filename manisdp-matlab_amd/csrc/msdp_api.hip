@@ -39,6 +39,7 @@ int msdp_dense_setup(msdp_handle h, const double* C);
 int msdp_dense_reserve(msdp_handle h, int nmat);
 int msdp_dense_setup_synthetic(msdp_handle h, uint64_t seed);
 void msdp_affine_release(msdp_handle h);
+void msdp_densesym_release(msdp_handle h);                  // msdp_densesym.hip
 int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam, double* V, double* lmax, int* iters,
                      const double* Mdev);
 int msdp_dense_nS(int n);
@@ -582,6 +583,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     for (int s2 = 0; s2 < 2; ++s2) if (h->ev_flag[s2]) (void)hipEventDestroy(h->ev_flag[s2]);
     for (int s2 = 0; s2 < 2; ++s2) if (h->chunk_execs[s2]) (void)hipGraphExecDestroy(h->chunk_execs[s2]);
     msdp_affine_release(h);
+    msdp_densesym_release(h);
     halo_release(h);
     local_leave(h);
     if (h->lc_tmp) (void)hipFree(h->lc_tmp);
@@ -876,6 +878,12 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "block_skip")) t.block_skip = value != 0;
     else if (!strcmp(name, "halo_exchange")) { t.halo_exchange = value != 0; h->state_valid = false; }
     else if (!strcmp(name, "dense_pack")) { t.dense_pack = value != 0; h->chunk_len = 0; }
+    else if (!strcmp(name, "affine_fuse")) { t.affine_fuse = value != 0; h->chunk_len = 0; h->state_valid = false; }
+    else if (!strcmp(name, "affine_broute")) { t.affine_broute = value != 0; h->chunk_len = 0; }
+    else if (!strcmp(name, "dense_sym")) { t.dense_sym = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
+    else if (!strcmp(name, "dense_sym_min")) { t.dense_sym_min = value > 0 ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
+    else if (!strcmp(name, "dense_sym_rt")) { t.dense_sym_rt = (value >= 1 && value <= 3) ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
+    else if (!strcmp(name, "dense_sym_len")) { t.dense_sym_len = value > 0 ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
     else if (!strcmp(name, "debug_fail_persist")) t.fail_persist = value != 0;
     else if (!strcmp(name, "debug_fail_block")) t.fail_block = value != 0;
     else if (!strcmp(name, "grid")) { t.grid = value > 0 ? value : 0; choose_grid(h); h->chunk_len = 0; }

@@ -10,7 +10,7 @@
 #define MSDP_BLOCK 1024           // threads per workgroup (16 waves: one row step per wave, latency hidden by occupancy)
 #define MSDP_WAVES (MSDP_BLOCK / 64)
 #define MSDP_MAX_GRID 512         // <= 512 partial sums per reduction (2 per CU)
-#define MSDP_NPART 9              // number of partial-sum arrays
+#define MSDP_NPART 12             // number of partial-sum arrays
 
 void msdp_set_error(const char* fmt, ...);
 
@@ -54,7 +54,9 @@ struct Frame {
 // Partial-sum array ids
 // P_AXB: |A x - b - y/sigma|^2 of the affine kinds, summed over the constraints by MSDP_MAX_GRID workgroups (every other
 // array is filled by the d.G workgroups of a row-parallel launch)
-enum { P_F = 0, P_GG = 1, P_DHD = 2, P_S1 = 3, P_S2 = 4, P_S3 = 5, P_RD = 6, P_AUX = 7, P_AXB = 8 };
+enum { P_F = 0, P_GG = 1, P_DHD = 2, P_S1 = 3, P_S2 = 4, P_S3 = 5, P_RD = 6, P_AUX = 7, P_AXB = 8,
+       // sphere Hess-vec, fused form (msdp_affine.hip, k_sddmm1 mode 2): <U, G>, <U, Y>, sum_k w_k (A x)_k
+       P_T1 = 9, P_T2 = 10, P_T3 = 11 };
 
 enum { MANI_OBLIQUE = 0, MANI_SPHERE = 1, MANI_EUCLID = 2 };
 enum { COST_SPARSE = 0, COST_DENSE = 1, COST_AFFINE = 2 };
@@ -139,6 +141,15 @@ struct Tuning {
     int lanczos_qglobal = 0;  // tests: deflated persistent Lanczos reads the deflation columns in place even where they fit the LDS
     int lanczos_onesync = 1;  // undeflated persistent Lanczos runs: one grid synchronisation per step (0: two)
     int dense_pack = 1;    // dense C*U reads the fragment-ordered copy of C (0: the row-major one; same results)
+    int affine_fuse = 1;   // affine kinds, SDDMM route, one rank: A(Ya Yb') and its finish in ONE launch (k_sddmm1); sphere Hess-vec: the
+                           //   sparse A'(w)*Y product, the slab sum and the projection in ONE launch (k_sph_hess_fused) (0: A/B, tests)
+    int affine_broute = 1; // affine Hess-vec, Gram route, symmetric data with short constraints: A'(A(.)) as one sparse matrix on the Gram matrix
+                           //   (k_adjoint_gram) instead of k_gram_apply + k_adjoint_tiled (0: A/B, tests)
+    int dense_sym = 1;     // symmetric dense operands (p <= 32, one rank): the contraction reads the upper triangle only
+                           //   (msdp_densesym.hip); 1 = from dense_sym_min rows on, 2 = always, 0 = never
+    int dense_sym_min = 3000;   // see dense_sym
+    int dense_sym_rt = 0;       // A/B: 16-row tiles per wave of k_dense_sym (0: by n; 1 or 2)
+    int dense_sym_len = 0;      // A/B: slice length of a work item in 16-column steps (0: planned)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
     int persist_refresh = 32;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
     int affine_overlap = 0;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain.  Measured SLOWER (round 3: BQP d = 60
@@ -211,6 +222,8 @@ struct msdp_handle_s {
     size_t snap_cap = 0;
     int snap_p = 0;
     double* slab = nullptr;        // split-K partial slabs of the dense MFMA path
+    bool dense_symmetric = false;  // every dense operand of the contraction (C, eS, AyU) is symmetric (checked at set-up)
+    void* symplans = nullptr;      // work-item plans of the symmetric contraction (msdp_densesym.hip)
     size_t slab_cap = 0;
     // escape workspace, kept between calls (freeing 3 GB after every call stalled the NEXT kernels on the stream
     // for ~60 ms while the driver unmapped it: gaps seen in the kernel trace of the G81 solve)

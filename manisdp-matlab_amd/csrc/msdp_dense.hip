@@ -342,6 +342,12 @@ static int ensure_slab(msdp_handle h, size_t need) {
     return 0;
 }
 
+int msdp_dense_ensure_slab(msdp_handle h, size_t need) { return ensure_slab(h, need); }
+int msdp_densesym_eligible(msdp_handle h, int nmat);                   // msdp_densesym.hip
+int msdp_densesym_reserve(msdp_handle h, int nmat, size_t* slabs_out);
+int msdp_densesym_gemm(msdp_handle h, hipStream_t stream, int nmat, const double* const* M, const double* const* X,
+                       const double* scale, const int* active_flag);
+
 int msdp_dense_nS(int n) { return ((n + 15) / 16) * 16; }
 
 typedef void (*dense3_fn_t)(DenseOp, const int*);
@@ -432,7 +438,14 @@ int msdp_dense_reserve(msdp_handle h, int nmat) {
         if (q == 1) SKmax = std::max(SKmax, nmat * SK);       // nmat one-matrix contractions side by side (msdp_dense_gemm_at)
     }
     const int64_t cap_rows = (h->d.n + h->nranks - 1) / h->nranks;
-    return ensure_slab(h, (size_t)(SKmax + 1) * cap_rows * (size_t)h->d.ld);
+    size_t slabs = (size_t)(SKmax + 1);
+    if (msdp_densesym_eligible(h, nmat)) {
+        size_t sym_slabs = 0;
+        int rc = msdp_densesym_reserve(h, nmat, &sym_slabs);
+        if (rc) return rc;
+        slabs = std::max(slabs, sym_slabs);
+    }
+    return ensure_slab(h, slabs * cap_rows * (size_t)h->d.ld);
 }
 
 // Launch the partial GEMM for up to two (matrix, panel, scale) pairs; returns slab info.
@@ -456,6 +469,15 @@ int msdp_dense_gemm_at(msdp_handle h, hipStream_t stream, int slab_first, int sl
                        const double* const* X, const double* scale, const int* active_flag, const double** slab_out,
                        int64_t* stride_out, int* SK_out) {
     Dev& d = h->d;
+    if (slab_first == 0 && slabs_reserve == 0 && msdp_densesym_eligible(h, nmat)) {
+        // symmetric operands: the upper triangle only; the sum of all partial slabs arrives in slab 0
+        int rc = msdp_densesym_gemm(h, stream, nmat, M, X, scale, active_flag);
+        if (rc) return rc;
+        *slab_out = h->slab;
+        *stride_out = (int64_t)d.n * d.ld;
+        *SK_out = 1;
+        return 0;
+    }
     DenseOp op;
     memset(&op, 0, sizeof(op));
     op.nmat = nmat;
@@ -562,6 +584,13 @@ int msdp_dense_setup(msdp_handle h, const double* C) {
     HIPCHK(hipMemset(d.Cd, 0, (size_t)d.n * nS * sizeof(double)));
     HIPCHK(hipMemcpy2D(d.Cd, (size_t)nS * sizeof(double), C, (size_t)d.n * sizeof(double), (size_t)d.n * sizeof(double),
                        d.n, hipMemcpyHostToDevice));
+    {
+        bool sym = true;
+        for (int i = 0; i < d.n && sym; ++i)
+            for (int j = i + 1; j < d.n; ++j)
+                if (C[(size_t)i * d.n + j] != C[(size_t)j * d.n + i]) { sym = false; break; }
+        h->dense_symmetric = sym;
+    }
     return dense_pack(h);
 }
 
@@ -600,6 +629,7 @@ int msdp_dense_setup_synthetic(msdp_handle h, uint64_t seed) {
     hipLaunchKernelGGL(k_fill_dense_sym, dim3(4096), dim3(256), 0, h->stream, d.Cd, d.n, nS, d.row0, d.n_loc, seed);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->dense_symmetric = true;                                // entry (i,j) depends on (min, max) only
     return dense_pack(h);
 }
 

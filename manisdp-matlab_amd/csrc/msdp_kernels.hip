@@ -36,7 +36,9 @@ __device__ __forceinline__ void costgrad_sparse_obl_body(const Dev& d, int slot)
     double* __restrict__ Gr = slot ? d.Gr[1] : d.Gr[0];
     double* __restrict__ eG = slot ? d.eG[1] : d.eG[0];
     double pf = 0.0, pgg = 0.0;
-    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
+    int stride = MSDP_WAVES * RPW;
+    if (d.sweep) msdp_sweep_rows(d.n_loc, d.G, MSDP_WAVES * RPW, lo, hi, stride);      // windowed traversal, see hess_sparse_obl_body
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += stride) {
         const int row = row0 + rsub;
         if (row < hi) {
             double2 acc[NCH];
@@ -86,7 +88,12 @@ __device__ __forceinline__ void hess_sparse_obl_body(const Dev& d) {
     const double* __restrict__ Ul = d.md;
     double* __restrict__ H = d.Hmd;
     double pd = 0.0;
-    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
+    // vectors beyond the L2s (option sweep): the workgroups of an XCD walk ONE window of rows together, so that a row fetched
+    // as somebody's neighbour is still in the L2 when its owner reaches it (msdp_sweep_rows; round 3 measured 1.32 x the
+    // algorithmic bytes at n = 10^6 with the chunked order -- the far grid neighbours' rows were fetched twice)
+    int stride = MSDP_WAVES * RPW;
+    if (d.sweep) msdp_sweep_rows(d.n_loc, d.G, MSDP_WAVES * RPW, lo, hi, stride);
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += stride) {
         const int row = row0 + rsub;
         if (row < hi) {
             double2 acc[NCH], y[NCH], u[NCH];

@@ -410,3 +410,121 @@ def test_theta1_with_the_reference_examples_options(lib):
             assert max(d["gap"], d["pinf"], d["dinf"]) < 1e-6
             assert abs(obj + 23.0) <= 1e-6 * 23.0, (seed, obj)
     assert converged >= 2, converged
+
+
+@pytest.mark.parametrize("kind_name,case,p,shape", [("unitdiag", "bqp20", 16, 1), ("unitdiag", "bqp20", 32, 2), ("unitdiag", "gpp124-1", 9, 3),
+                                                   ("unittrace", "theta2", 20, 1), ("unittrace", "theta1", 6, 2), ("generic", "mcp124-1", 5, 3)])
+def test_affine_operators_through_the_symmetric_contraction(lib, kind_name, case, p, shape):
+    """The dense products of the affine closures (C*Y, eS*Y, 2*eS*U + 4*sigma*AyU*Y: ManiSDP_unitdiag.m:160-170,
+    ManiSDP_unittrace.m:160-176, ManiSDP.m:153-162) through msdp_densesym.hip -- forced at these small sizes with option
+    dense_sym = 2, one- and two-matrix launches, every workgroup shape -- against the oracle."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R
+    if case.startswith("bqp"):
+        At, b, c, K = _bqp(int(case[3:]))
+    else:
+        At, b, c, K = problems.from_sdpa(golden_path(case + ".dat-s.gz"))
+        c = np.asarray(c.todense()).ravel()
+    n = K["s"]
+    rng = np.random.default_rng(p)
+    Y = rng.standard_normal((n, p))
+    if kind_name == "unitdiag":
+        Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+        prob = R._UnitDiagProblem(At, np.asarray(b, float), c, n, p); kind = lib.KIND_UNITDIAG
+    elif kind_name == "unittrace":
+        Y /= np.linalg.norm(Y)
+        prob = R._UnitTraceProblem(At, np.asarray(b, float), c, n, p); kind = lib.KIND_UNITTRACE
+    else:
+        prob = R._GenericProblem(At, np.asarray(b, float), c, n, p); kind = lib.KIND_GENERIC
+    U = rng.standard_normal((n, p))
+    y = rng.standard_normal(np.asarray(b).size) * 0.1
+    sigma = 0.9
+    prob.y, prob.sigma = y, sigma
+    f_ref = prob.cost(Y); G_ref = prob.grad(Y); H_ref = prob.hess(Y, U)
+    h = lib.Handle.affine(kind, At, b, c, n)
+    h.set_option("dense_sym", 2); h.set_option("dense_sym_rt", shape)
+    h.set_multipliers(y, sigma)
+    h.set_point(Y)
+    assert abs(h.cost() - f_ref) <= 1e-11 * max(1.0, abs(f_ref))
+    assert _relerr(h.rgrad(), G_ref) < 1e-11
+    H = h.hessvec(U)
+    assert _relerr(H, H_ref) < 1e-11
+    assert np.array_equal(H, h.hessvec(U))
+    h.close()
+
+
+@pytest.mark.parametrize("case,p", [("bqp10", 3), ("bqp20", 32), ("bqp30", 20), ("bqp20", 70)])
+def test_unitdiag_hessvec_b_route_matches_the_two_pass_route(lib, monkeypatch, case, p):
+    """Hess-vec of ManiSDP_unitdiag.m:166-171 on the Gram route with A'(A(.)) applied as ONE sparse matrix to Y'U + U'Y
+    (k_adjoint_gram, option affine_broute, default) against the two-pass form (k_gram_apply -> w -> k_adjoint_tiled) and the oracle."""
+    from oracle import manisdp_ref as R
+    monkeypatch.setenv("MSDP_AFFINE_ROUTE", "gram")
+    At, b, c, K = _bqp(int(case[3:]))
+    n = K["s"]
+    rng = np.random.default_rng(7 + p)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    y = rng.standard_normal(b.size) * 0.1
+    prob = R._UnitDiagProblem(At, np.asarray(b, float), c, n, p)
+    prob.y, prob.sigma = y, 1.7
+    H_ref = prob.hess(Y, U)
+    out = []
+    for broute in (1, 0):
+        h = lib.Handle.affine(lib.KIND_UNITDIAG, At, b, c, n)
+        h.set_option("affine_broute", broute)
+        h.set_multipliers(y, 1.7)
+        h.set_point(Y)
+        out.append(h.hessvec(U))
+        assert _relerr(out[-1], H_ref) < 1e-11
+        h.close()
+    assert _relerr(out[0], out[1]) < 1e-12
+
+
+@pytest.mark.parametrize("kind_name,case,p", [("unittrace", "theta1", 6), ("unittrace", "theta3", 17), ("unittrace", "theta3", 140),
+                                              ("unitdiag", "gpp100", 7), ("unitdiag", "gpp124-1", 33), ("generic", "mcp124-1", 5),
+                                              ("generic", "theta3", 12)])
+def test_fused_sddmm_and_sphere_epilogue_match_the_separate_launches(lib, monkeypatch, kind_name, case, p):
+    """Option affine_fuse (default 1): A(Ya Yb') and its finish in one launch (k_sddmm1; long constraints -- the trace row of
+    theta3, the all-ones constraint of gpp -- summed by the workgroup that arrives last), and for the sphere / Euclidean factor
+    the sparse A'(w)*Y product, the slab sum and the projection in one launch with tr(H Y') assembled from <U,G>, <U,Y> and
+    <w, A(YY')> (k_sph_hess_fused; ManiSDP_unittrace.m:171-177, ManiSDP.m:158-162).  Against the separate launches and the oracle."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R
+    monkeypatch.setenv("MSDP_AFFINE_ROUTE", "sddmm")
+    At, b, c, K = problems.from_sdpa(golden_path(case + ".dat-s.gz"))
+    c = np.asarray(c.todense()).ravel()
+    b = np.asarray(b, float).ravel()
+    n = K["s"]
+    rng = np.random.default_rng(3 * p)
+    Y = rng.standard_normal((n, p))
+    if kind_name == "unitdiag":
+        Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+        prob = R._UnitDiagProblem(At, b, c, n, p); kind = lib.KIND_UNITDIAG
+    elif kind_name == "unittrace":
+        Y /= np.linalg.norm(Y)
+        prob = R._UnitTraceProblem(At, b, c, n, p); kind = lib.KIND_UNITTRACE
+    else:
+        prob = R._GenericProblem(At, b, c, n, p); kind = lib.KIND_GENERIC
+    U = rng.standard_normal((n, p))
+    if kind_name != "generic":
+        U = prob.M.proj(Y, U)                                  # tCG only ever multiplies tangent vectors
+    y = rng.standard_normal(b.size) * 0.1
+    sigma = 2.3
+    prob.y, prob.sigma = y, sigma
+    f_ref = prob.cost(Y); G_ref = prob.grad(Y); H_ref = prob.hess(Y, U)
+    out = []
+    for fuse in (1, 0):
+        h = lib.Handle.affine(kind, At, b, c, n)
+        h.set_option("affine_fuse", fuse)
+        h.set_multipliers(y, sigma)
+        h.set_point(Y)
+        f, G, H = h.cost(), h.rgrad(), h.hessvec(U)
+        assert abs(f - f_ref) <= 1e-11 * max(1.0, abs(f_ref))
+        assert _relerr(G, G_ref) < 1e-11
+        assert _relerr(H, H_ref) < 1e-11
+        assert np.array_equal(H, h.hessvec(U))               # the arrival counter is back at zero, same bits
+        out.append((f, G, H))
+        h.close()
+    assert abs(out[0][0] - out[1][0]) <= 1e-13 * max(1.0, abs(f_ref))
+    assert _relerr(out[0][1], out[1][1]) < 1e-13
+    assert _relerr(out[0][2], out[1][2]) < 1e-12

@@ -120,3 +120,66 @@ def test_synthetic_dense_shards_match_full_matrix(lib):
         H = h.hessvec(U)
         assert _relerr(H[r0:r1], H_ref[r0:r1]) < 1e-12
         h.close()
+
+
+@pytest.mark.parametrize("n,p,shape", [(17, 1, 1), (33, 5, 2), (130, 2, 3), (257, 16, 1), (300, 17, 2), (500, 31, 3), (1000, 32, 1),
+                                       (1000, 32, 2), (1000, 32, 3), (2050, 20, 1), (2050, 7, 2), (3000, 32, 0)])
+def test_symmetric_contraction_matches_oracle_and_full_kernel(lib, n, p, shape):
+    """msdp_densesym.hip (upper triangle only, direct + transposed MFMA product per tile) against the oracle and against the
+    full kernel of msdp_dense.hip, for the three workgroup shapes (dense_sym_rt: 8 x 16, 8 x 32, 16 x 16 rows; 0 = planned) and
+    sizes around the tile / row-block edges; two runs give the same bits (no atomics, fixed summation orders)."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R
+    C = problems.dense_unitdiag_cost(n, seed=n + 7)
+    rng = np.random.default_rng(p)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    prob = R._OnlyUnitDiagProblem(C, n, p)
+    h = lib.Handle.onlyunitdiag(C)
+    h.set_option("dense_sym", 2); h.set_option("dense_sym_rt", shape)
+    h.set_point(Y)
+    f, G, H = h.cost(), h.rgrad(), h.hessvec(U)
+    assert abs(f - prob.cost(Y)) <= 1e-12 * max(1.0, abs(prob.cost(Y)))
+    assert _relerr(G, prob.grad(Y)) < 1e-12
+    assert _relerr(H, prob.hess(Y, U)) < 1e-12
+    assert np.array_equal(H, h.hessvec(U))
+    h.set_option("dense_sym", 0)
+    h.set_point(Y)
+    assert _relerr(H, h.hessvec(U)) < 1e-13
+    h.close()
+
+
+def test_symmetric_contraction_short_slices(lib):
+    """Work items of two steps (dense_sym_len): many D slabs per row block, slices that end inside the block on the diagonal."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R
+    n, p = 700, 24
+    C = problems.dense_unitdiag_cost(n, seed=3)
+    rng = np.random.default_rng(5)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    prob = R._OnlyUnitDiagProblem(C, n, p)
+    for shape in (1, 2, 3):
+        h = lib.Handle.onlyunitdiag(C)
+        h.set_option("dense_sym", 2); h.set_option("dense_sym_rt", shape); h.set_option("dense_sym_len", 2)
+        h.set_point(Y)
+        assert _relerr(h.hessvec(U), prob.hess(Y, U)) < 1e-12
+        assert _relerr(h.rgrad(), prob.grad(Y)) < 1e-12
+        h.close()
+
+
+def test_asymmetric_dense_cost_keeps_the_full_kernel(lib):
+    """A dense C that is not symmetric entry by entry must not take the upper-triangle route (the reference's U*C uses all of C)."""
+    n, p = 300, 8
+    rng = np.random.default_rng(0)
+    C = rng.standard_normal((n, n))
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    U = rng.standard_normal((n, p))
+    out = []
+    for sym in (2, 0):
+        h = lib.Handle.onlyunitdiag(C)
+        h.set_option("dense_sym", sym)
+        h.set_point(Y)
+        out.append(h.hessvec(U))
+        h.close()
+    assert np.array_equal(out[0], out[1])

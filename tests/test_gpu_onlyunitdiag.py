@@ -406,3 +406,31 @@ def test_windowed_row_traversal_covers_every_row_once(lib, shape, p):
         assert a[:4] == b[:4]
         assert abs(a[4] - b[4]) <= 1e-12 * abs(b[4])
         assert np.linalg.norm(a[5] - b[5]) <= 1e-9 * np.linalg.norm(b[5])
+
+
+@pytest.mark.parametrize("shape,p", [((223, 227), 6), ((1, 51507), 12), ((1, 4099), 40), ((61, 67), 32)])
+def test_windowed_row_traversal_of_the_standalone_operators(lib, shape, p):
+    """The stand-alone cost / gradient and Hess-vec kernels (k_costgrad_*_obl, k_hess_*_obl: ManiSDP_onlyunitdiag.m:117-130) walk
+    the rows with the same windowed order when option sweep applies (round 4): every row gets the same bits as with the chunk
+    order -- a row's result does not depend on which workgroup computes it -- and the sums over the rows agree to rounding."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R
+    C = problems.toroidal_grid_maxcut(shape[0], shape[1], seed=5) if shape[0] > 1 else _ring_lattice_cost(shape[1], 3, seed=6)
+    n = C.shape[0]
+    Y, _ = _rand_point(n, p, seed=4)
+    U = np.random.default_rng(9).standard_normal((n, p))
+    out = []
+    for sweep in (2, 0):
+        h = lib.Handle.onlyunitdiag(C, pcap=p)
+        h.set_option("sweep", sweep)
+        if p == 40:
+            h.set_option("grid", 512)
+        h.set_point(Y)
+        out.append((h.cost(), h.rgrad(), h.hessvec(U), h.get_z()))
+        h.close()
+    a, b = out
+    assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0])
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    prob = R._OnlyUnitDiagProblem(C, n, p)
+    prob.cost(Y)
+    assert np.linalg.norm(a[2] - prob.hess(Y, U)) <= 1e-12 * np.linalg.norm(a[2])

@@ -1,0 +1,23 @@
+"""Stand-alone sparse S*U (k_hess_ell_obl) and cost/gradient at n = 10^6 (toroidal grid), chunk order against the windowed order
+(option sweep).  argv: [side=1000] [p ...]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from manisdp_matlab_amd import _lib, problems
+side = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+ps = [int(x) for x in sys.argv[2:]] or [32]
+C = problems.toroidal_grid_maxcut(side, side, seed=3)
+n = C.shape[0]
+for p in ps:
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    for sweep in (0, 2):
+        h = _lib.Handle.onlyunitdiag(C, pcap=p)
+        h.set_option("sweep", sweep)
+        if "--nograph" in sys.argv:
+            h.set_option("graph", 0)
+        h.set_point(Y)
+        h.bench_hessvec(20)
+        ms, by, fl = h.bench_hessvec(100)
+        print("n=%d p=%d sweep=%d: Hess-vec kernel %.1f us, %.2f TB/s algorithmic = %.3f of HBM" % (n, p, sweep, ms * 1e3, by / ms / 1e9, by / ms / 8e9), flush=True)
+        h.close()

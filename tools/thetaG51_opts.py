@@ -11,6 +11,12 @@ At, b, c, K = problems.from_sdpa(os.path.join(ROOT, "tests/golden/thetaG51.dat-s
 c = np.asarray(c.todense()).ravel() if hasattr(c, "todense") else np.asarray(c, float).ravel()
 b = np.asarray(b.todense()).ravel() if hasattr(b, "todense") else np.asarray(b, float).ravel()
 SETS = {
+    "b10x200": dict(tol=1e-8, TR_maxiter=10, TR_maxinner=200),
+    "b30x100": dict(tol=1e-8, TR_maxiter=30, TR_maxinner=100),
+    "b30x200s": dict(tol=1e-8, TR_maxiter=30, TR_maxinner=200, sigma0=1e-1, sigma_min=1e-1),
+    "b30x200t": dict(tol=1e-8, TR_maxiter=30, TR_maxinner=200, tau1=1e-1, tau2=1e-1),
+    "b60x400": dict(tol=1e-8, TR_maxiter=60, TR_maxinner=400),
+    "gpp6": dict(tol=1e-6, sigma0=1e-1, sigma_min=1e-1, tau1=1e-2, tau2=1e-1, TR_maxinner=40, TR_maxiter=6),
     "default": dict(tol=1e-8),
     "gpp": dict(sigma0=1e-1, sigma_min=1e-1, tau1=1e-2, tau2=1e-1, TR_maxinner=40, TR_maxiter=6),
     "budget": dict(tol=1e-8, TR_maxiter=30, TR_maxinner=200),
@@ -25,6 +31,6 @@ for name in which:
         try:
             Y, obj, d = solvers.ManiSDP_unitdiag(At, b, c, K, dict(SETS[name], eig=eig), verbose=False)
             print(f"{name:10s} eig={eig}: obj {-obj:.7f} status {d['status']} gap {d['gap']:.1e} pinf {d['pinf']:.1e} dinf {d['dinf']:.1e} "
-                  f"{time.time() - t:.1f}s", flush=True)
+                  f"{time.time() - t:.1f}s iters {d.get('iters')} hessvecs {d.get('hessvecs')} rtr {d.get('rtr_seconds', 0):.1f}s eig {d.get('eig_seconds', 0):.1f}s", flush=True)
         except Exception as ex:
             print(name, eig, "failed:", ex, flush=True)
