@@ -181,6 +181,11 @@ int msdp_destroy(msdp_handle h);
  * n = 20000; allocating it costs 0.05-0.5 s) is parked by msdp_destroy for the next handle of the process.  This call
  * frees it (a long-lived host such as MATLAB calls it when it unloads the binding). */
 int msdp_release_cache(void);
+/* The uncached device memory behind the grid synchronisations and row exchanges comes from per-process arenas with a coalescing
+ * sub-allocator (msdp_api.hip): bytes the arenas hold, bytes handed out to live handles, number of arenas.  The pool grows to
+ * the high-water mark of what was live together; arenas return to the driver only while no uncached block of the process is
+ * live (beyond MSDP_UC_POOL_CAP bytes -- default 1 GiB -- when the last one is freed, all of them in msdp_release_cache). */
+int msdp_debug_pool_stats(int64_t* pool_bytes, int64_t* live_bytes, int64_t* arenas);
 
 /* AL state that changes between trustregions() calls: y and sigma
  * (ManiSDP_unitdiag.m:64,108-112).  No-op error for onlyunitdiag handles. */
@@ -282,6 +287,13 @@ int msdp_debug_collective_calls(msdp_handle h, int64_t* calls);
 /* Measurement only: average stream time (us) of one collective call: which = 0 row exchange, 1 all-reduce of one partial-sum
  * array, 2 row exchange with the sums riding along, 3 all-reduce of three arrays, 4 rows and sums as two separate all-gathers. */
 int msdp_debug_time_collective(msdp_handle h, int32_t which, int32_t reps, double* avg_us);
+/* Measurement only: the phases of a persistent tCG trip (tCG.m:160-289 inside k_tcg_persist_obl).  Runs `reps` trips with the
+ * exits disabled on the traced instance of the kernel (17 <= p <= 32, rows of <= 5 entries: the G81 shape) and returns thread 0's
+ * s_memtime stamps of every workgroup at 7 phase boundaries -- 0 top of the trip, 1 gathers + row arithmetic done, 2 first grid
+ * reduction returned, 3 trial step formed and residual rows stored, 4 those stores performed, 5 second grid reduction returned,
+ * 6 new direction formed -- for the trips dims[2] .. dims[2] + dims[1] - 1: out[(g * dims[1] + t) * 8 + phase], g < dims[0].
+ * avg_ms = the average trip time of the same launch (HIP events).  tools/persist_timeline.py turns it into profiles/r4_persist_timeline.md. */
+int msdp_debug_persist_trace(msdp_handle h, int32_t reps, uint64_t* out, int64_t cap, int32_t* dims, double* avg_ms);
 
 /* Outcome of the LAST msdp_escape_eigs / _matrix / _dual call on this handle.  The reference's eig(S) is exact;
  * a Lanczos run that reaches `maxit` without passing a stop test only yields an UPPER bound of lambda_min, so

@@ -84,6 +84,7 @@ SIGNATURES = {
     "msdp_escape_lower_bound": (C.c_int, [C.c_void_p, _dp]),
     "msdp_escape_method": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "msdp_debug_collective_calls": (C.c_int, [C.c_void_p, _P(C.c_int64)]),
+    "msdp_debug_persist_trace": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_uint64), C.c_int64, _P(C.c_int32), _dp]),
     "msdp_debug_time_collective": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_double)]),
     "msdp_debug_get_tcg_step": (C.c_int, [C.c_void_p, _dp, _dp]),
     "msdp_debug_sym_eig": (C.c_int, [C.c_int32, _dp, _dp, _dp]),
@@ -91,6 +92,7 @@ SIGNATURES = {
     "msdp_get_dual_slack": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_dual_slack_block": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
     "msdp_release_cache": (C.c_int, []),
+    "msdp_debug_pool_stats": (C.c_int, [_P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
     "msdp_comm_init_local": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "msdp_get_point_all": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_z_all": (C.c_int, [C.c_void_p, _dp]),
@@ -144,8 +146,16 @@ def load():
 
 
 def release_cache():
-    """Free the device memory the library keeps between handles (the parked Lanczos workspace of the escape)."""
+    """Free the device memory the library keeps between handles (the parked Lanczos workspace of the escape; the arenas of
+    uncached memory, when no handle of the process holds a block of them)."""
     _check(load().msdp_release_cache())
+
+
+def pool_stats():
+    """(bytes the uncached-memory arenas hold, bytes handed out to live handles, number of arenas) -- msdp_debug_pool_stats."""
+    a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+    _check(load().msdp_debug_pool_stats(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
 
 
 def _check(rc):
@@ -578,6 +588,17 @@ class Handle:
         return v.value
 
     # ---- measurement
+    def persist_trace(self, reps=256):
+        """Phase stamps of the persistent tCG trip: (array [G, nj, 8] of s_memtime ticks, first traced trip, trip time in ms)."""
+        cap = 512 * 64 * 8
+        buf = (C.c_uint64 * cap)()
+        dims = (C.c_int32 * 3)()
+        ms = C.c_double()
+        _check(self._lib.msdp_debug_persist_trace(self._h, reps, buf, cap, dims, C.byref(ms)))
+        G, nj, j0 = dims[0], dims[1], dims[2]
+        a = np.frombuffer(buf, dtype=np.uint64, count=G * nj * 8).reshape(G, nj, 8).astype(np.int64)
+        return a, j0, ms.value
+
     def bench_hessvec(self, reps):
         ms, by, fl = C.c_double(), C.c_double(), C.c_double()
         _check(self._lib.msdp_bench_hessvec(self._h, reps, C.byref(ms), C.byref(by), C.byref(fl)))

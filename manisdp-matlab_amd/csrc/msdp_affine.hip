@@ -321,13 +321,15 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm1(AffineDev a, Dev d, const
 // t needs no pass over H_raw: <2 eS U, Y> = <U, 2 eS Y> = <U, G> + 2 z <U, Y> (G = 2 eS Y - 2 z Y is the stored gradient, eS is
 // symmetric) and <4 sigma A'(w) Y, Y> = 4 sigma <w, A(Y Y')> -- the three sums k_sddmm1 (mode 2) left in P_T1..P_T3.
 // One wave per row; replaces k_support_spmm + k_sph_hess_raw + k_sph_hess_finish (20 us of launches at n = 5000).
-template <int NCH>
+template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev a, const double* slab, int64_t slab_stride, int SK,
                                                              double sigma, int G2, int support) {
     __shared__ double sh[3 * MSDP_WAVES + 8];
     if (!d.F[0].active) return;
     const bool euc = d.manifold == MANI_EUCLID;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RPW = 64 / LPR;
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
     const int cur = d.ctl->cur;
     double t = 0.0, z = 0.0;
     if (!euc) {
@@ -346,34 +348,40 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev 
     const double* __restrict__ w = a.w;
     const double s4 = 4.0 * sigma;
     double pd = 0.0;
-    for (int i = lo + wave; i < hi; i += MSDP_WAVES) {
+    // LPR lanes per row (one double2 each, NCH column chunks), 64 / LPR rows per wave: the lanes of a row take one touched entry
+    // each (its chain of dependent loads: entry -> row pointer -> (coefficient, constraint) -> w), then the values and column
+    // indices are broadcast inside the group and all its lanes accumulate v * Y(j, :)
+    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
+        const int i = row0 + rsub;
+        const bool rok = i < hi;
         double2 acc[NCH];
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) acc[ch] = make_double2(0.0, 0.0);
         if (support) {
-            const int q1 = a.suprow[i + 1];
-            for (int q0 = a.suprow[i]; q0 < q1; q0 += 64) {
-                const int cnt = min(64, q1 - q0);
+            const int qb = rok ? a.suprow[i] : 0, qe = rok ? a.suprow[i + 1] : 0;
+            for (int q0 = qb; __builtin_amdgcn_ballot_w64(q0 < qe) != 0ULL; q0 += LPR) {
+                const int cnt = min(LPR, max(qe - q0, 0));
                 int jl = 0;
                 double vl = 0.0;
-                if (lane < cnt) {
-                    const int r = a.sup[q0 + lane];
+                if (sub < cnt) {
+                    const int r = a.sup[q0 + sub];
                     jl = r - i * a.n;
                     const int s0 = a.rp[r], s1 = a.rp[r + 1];
                     for (int tt = s0; tt < s1; ++tt) vl = fma(a.rv[tt], w[a.rk[tt]], vl);
                 }
-                for (int e0 = 0; e0 < cnt; e0 += SPB) {
+                for (int e0 = 0; __builtin_amdgcn_ballot_w64(e0 < cnt) != 0ULL; e0 += SPB) {      // until the longest row of the wave is done
                     int jj[SPB];
                     double v[SPB];
 #pragma unroll
                     for (int u = 0; u < SPB; ++u) {
-                        const int e = min(e0 + u, cnt - 1);
-                        jj[u] = __shfl(jl, e);
-                        v[u] = (e0 + u < cnt) ? __shfl(vl, e) : 0.0;
+                        const int e = min(e0 + u, max(cnt - 1, 0));
+                        jj[u] = __shfl(jl, e, LPR);
+                        const double vv = __shfl(vl, e, LPR);
+                        v[u] = (e0 + u < cnt) ? vv : 0.0;
                     }
 #pragma unroll
                     for (int ch = 0; ch < NCH; ++ch) {
-                        const int c = 2 * lane + 128 * ch;
+                        const int c = 2 * sub + ch * 2 * LPR;
                         if (c < d.ld) {
                             double2 y[SPB];
 #pragma unroll
@@ -385,18 +393,20 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev 
                 }
             }
         }
+        if (rok) {
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int c = 2 * lane + 128 * ch;
-            if (c < d.ld) {
-                const int64_t o = (int64_t)i * d.ld + c;
-                const double2 ds = msdp_sum_slabs(slab, slab_stride, SK, o);
-                const double2 y = ld2(Yl + o), u = ld2(d.md + o);
-                double2 hq;
-                hq.x = (ds.x + s4 * acc[ch].x) - t * y.x - 2.0 * z * u.x;
-                hq.y = (ds.y + s4 * acc[ch].y) - t * y.y - 2.0 * z * u.y;
-                st2(d.Hmd + o, hq);
-                pd += u.x * hq.x + u.y * hq.y;
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c = 2 * sub + ch * 2 * LPR;
+                if (c < d.ld) {
+                    const int64_t o = (int64_t)i * d.ld + c;
+                    const double2 ds = msdp_sum_slabs(slab, slab_stride, SK, o);
+                    const double2 y = ld2(Yl + o), u = ld2(d.md + o);
+                    double2 hq;
+                    hq.x = (ds.x + s4 * acc[ch].x) - t * y.x - 2.0 * z * u.x;
+                    hq.y = (ds.y + s4 * acc[ch].y) - t * y.y - 2.0 * z * u.y;
+                    st2(d.Hmd + o, hq);
+                    pd += u.x * hq.x + u.y * hq.y;
+                }
             }
         }
     }
@@ -1646,14 +1656,7 @@ int msdp_affine_hess(msdp_handle h) {
             const double* M[2] = {d.eS[cur], d.AyU}; const double* X[2] = {Uf, Yf}; const double sc[2] = {2.0, 4.0 * sigma};
             if ((rc = msdp_dense_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
         }
-        const int nch = (d.ld + 127) / 128;
-        const dim3 g(d.G), b(MSDP_BLOCK);
-        switch (nch) {
-            case 1: hipLaunchKernelGGL(k_sph_hess_fused<1>, g, b, 0, h->stream, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0); break;
-            case 2: hipLaunchKernelGGL(k_sph_hess_fused<2>, g, b, 0, h->stream, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0); break;
-            case 3: hipLaunchKernelGGL(k_sph_hess_fused<3>, g, b, 0, h->stream, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0); break;
-            default: hipLaunchKernelGGL(k_sph_hess_fused<4>, g, b, 0, h->stream, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0); break;
-        }
+        DISPATCH_LPR_A(k_sph_hess_fused, h, d.G, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0);
         HIPCHK(hipGetLastError());
         return 0;
     }

@@ -72,42 +72,100 @@ static int dev_alloc(msdp_handle h, T** out, size_t count) {
 // plain memory, and with this pool) -- memory whose caching attribute changes between owners is not safe to recycle here.
 #include <mutex>
 #include <map>
-struct UcBlock { void* p; size_t bytes; int dev; };
+// Round 4: the pool is a set of ARENAS with a coalescing first-fit sub-allocator instead of one driver block per request.  A
+// long-lived host (MATLAB) that cycles handles of varying sizes re-uses the same arenas -- freed blocks merge with their
+// neighbours, so the pool grows to the high-water mark of what was live together, not with the number of distinct sizes
+// (the per-request pool matched sizes within 2 x only and grew without bound).  Arenas go back to the driver only when NO
+// uncached block of the process is live any more: then, beyond MSDP_UC_POOL_CAP bytes, largest first (msdp_destroy of the last
+// handle), or all of them (msdp_release_cache) -- uncached pages never change owner while a handle that could be handed
+// them lives.  tests/test_gpu_edge_cases.py::test_handle_churn_keeps_results_and_pool_bounded.
+struct UcArena { char* base; size_t bytes; int dev; std::map<size_t, size_t> freemap; size_t live; };   // freemap: offset -> size
 static std::mutex g_uc_mutex;
-static std::vector<UcBlock> g_uc_free;                        // blocks waiting for their next owner
-static std::map<void*, UcBlock> g_uc_live;                    // blocks handed out
+static std::vector<UcArena> g_uc_arenas;
+static std::map<void*, std::pair<int, size_t>> g_uc_live;     // block -> (arena index, size)
+static const size_t UC_ALIGN = 256, UC_ARENA_MIN = (size_t)32 << 20;
+static size_t g_uc_cap = (size_t)1 << 30;                     // pool bytes kept when nothing is live (MSDP_UC_POOL_CAP, bytes)
+static size_t uc_pool_bytes_locked() { size_t t = 0; for (auto& a : g_uc_arenas) t += a.bytes; return t; }
+static int g_uc_direct = 0;                                   // MSDP_UC_POOL=0: one driver block per request, hipFree'd at once (the round-3
+                                                              //   arrangement that corrupted later handles; kept for tools/uc_pool_stress.py only)
 void* msdp_uc_alloc(size_t bytes) {
     if (bytes == 0) bytes = 8;
+    bytes = (bytes + UC_ALIGN - 1) / UC_ALIGN * UC_ALIGN;
     int dev = -1;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_uc_mutex);
-    size_t best = (size_t)-1;
-    for (size_t i = 0; i < g_uc_free.size(); ++i)            // smallest parked block that is large enough (and not more than twice the size)
-        if (g_uc_free[i].dev == dev && g_uc_free[i].bytes >= bytes && g_uc_free[i].bytes <= 2 * bytes + 4096 &&
-            (best == (size_t)-1 || g_uc_free[i].bytes < g_uc_free[best].bytes)) best = i;
-    UcBlock b;
-    if (best != (size_t)-1) { b = g_uc_free[best]; g_uc_free.erase(g_uc_free.begin() + best); }
-    else {
+    static bool env_read = false;
+    if (!env_read) {
+        env_read = true;
+        const char* e = getenv("MSDP_UC_POOL_CAP"); if (e && *e) g_uc_cap = (size_t)strtoull(e, nullptr, 10);
+        e = getenv("MSDP_UC_POOL"); if (e && *e == '0') g_uc_direct = 1;
+    }
+    if (g_uc_direct) {
         void* p = nullptr;
         if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        b.p = p; b.bytes = bytes; b.dev = dev;
+        return p;                                             // not registered: msdp_uc_free returns false and the caller hipFree's it
     }
-    g_uc_live[b.p] = b;
-    return b.p;
+    for (int pass = 0; pass < 2; ++pass) {
+        // best fit over the free ranges of this device's arenas
+        int ba = -1; size_t boff = 0, bsz = (size_t)-1;
+        for (size_t ai = 0; ai < g_uc_arenas.size(); ++ai) {
+            UcArena& a = g_uc_arenas[ai];
+            if (a.dev != dev) continue;
+            for (auto& fr : a.freemap)
+                if (fr.second >= bytes && fr.second < bsz) { ba = (int)ai; boff = fr.first; bsz = fr.second; }
+        }
+        if (ba >= 0) {
+            UcArena& a = g_uc_arenas[ba];
+            a.freemap.erase(boff);
+            if (bsz > bytes) a.freemap[boff + bytes] = bsz - bytes;
+            a.live += bytes;
+            void* p = a.base + boff;
+            g_uc_live[p] = {ba, bytes};
+            return p;
+        }
+        if (pass == 1) break;
+        void* p = nullptr;
+        const size_t ab = std::max(bytes, UC_ARENA_MIN);
+        if (hipExtMallocWithFlags(&p, ab, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        UcArena a; a.base = (char*)p; a.bytes = ab; a.dev = dev; a.live = 0; a.freemap[0] = ab;
+        g_uc_arenas.push_back(a);
+    }
+    return nullptr;
 }
-bool msdp_uc_free(void* p) {                                  // true: p was an uncached block (now parked)
+static void uc_trim_locked(size_t keep) {                     // only ever called with no live block anywhere
+    std::sort(g_uc_arenas.begin(), g_uc_arenas.end(), [](const UcArena& x, const UcArena& y) { return x.bytes > y.bytes; });
+    while (!g_uc_arenas.empty() && uc_pool_bytes_locked() > keep) { (void)hipFree(g_uc_arenas.front().base); g_uc_arenas.erase(g_uc_arenas.begin()); }
+}
+bool msdp_uc_free(void* p) {                                  // true: p was an uncached block (now back in its arena)
     if (!p) return false;
     std::lock_guard<std::mutex> lk(g_uc_mutex);
     auto it = g_uc_live.find(p);
     if (it == g_uc_live.end()) return false;
-    g_uc_free.push_back(it->second);
+    UcArena& a = g_uc_arenas[it->second.first];
+    size_t off = (size_t)((char*)p - a.base), sz = it->second.second;
+    a.live -= sz;
+    auto nx = a.freemap.lower_bound(off);
+    if (nx != a.freemap.end() && off + sz == nx->first) { sz += nx->second; nx = a.freemap.erase(nx); }
+    if (nx != a.freemap.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == off) { off = pv->first; sz += pv->second; a.freemap.erase(pv); } }
+    a.freemap[off] = sz;
     g_uc_live.erase(it);
+    if (g_uc_live.empty() && uc_pool_bytes_locked() > g_uc_cap) uc_trim_locked(g_uc_cap);   // indices are free to change: nothing is live
     return true;
 }
 void msdp_uc_release_pool() {
     std::lock_guard<std::mutex> lk(g_uc_mutex);
-    for (auto& b : g_uc_free) (void)hipFree(b.p);
-    g_uc_free.clear();
+    if (!g_uc_live.empty()) return;                           // a live handle owns uncached blocks: its arenas stay
+    uc_trim_locked(0);
+}
+// Pool statistics: bytes the arenas hold, bytes handed out, number of arenas (tests)
+extern "C" int msdp_debug_pool_stats(int64_t* pool_bytes, int64_t* live_bytes, int64_t* arenas) {
+    std::lock_guard<std::mutex> lk(g_uc_mutex);
+    size_t live = 0;
+    for (auto& a : g_uc_arenas) live += a.live;
+    if (pool_bytes) *pool_bytes = (int64_t)uc_pool_bytes_locked();
+    if (live_bytes) *live_bytes = (int64_t)live;
+    if (arenas) *arenas = (int64_t)g_uc_arenas.size();
+    return 0;
 }
 template <typename T>
 static int dev_alloc_uncached(msdp_handle h, T** out, size_t count) {
@@ -863,6 +921,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "escape_deflate")) t.escape_deflate = value != 0;
     else if (!strcmp(name, "escape_warm")) t.escape_warm = value != 0;
     else if (!strcmp(name, "escape_start_y")) t.escape_start_y = value != 0;
+    else if (!strcmp(name, "xpersist")) t.xpersist = value != 0;
     else if (!strcmp(name, "persist_refresh")) t.persist_refresh = value > 0 ? value : 0;
     else if (!strcmp(name, "affine_overlap")) { t.affine_overlap = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "trip1")) { t.trip1 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
@@ -885,6 +944,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "dense_sym_rt")) { t.dense_sym_rt = (value >= 1 && value <= 3) ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
     else if (!strcmp(name, "dense_sym_len")) { t.dense_sym_len = value > 0 ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
     else if (!strcmp(name, "debug_fail_persist")) t.fail_persist = value != 0;
+    else if (!strcmp(name, "debug_xr_skip")) t.fail_xr = value != 0;
     else if (!strcmp(name, "debug_fail_block")) t.fail_block = value != 0;
     else if (!strcmp(name, "grid")) { t.grid = value > 0 ? value : 0; choose_grid(h); h->chunk_len = 0; }
     else { msdp_set_error("set_option: unknown option '%s'", name); return MSDP_EINVAL; }
@@ -932,6 +992,13 @@ struct LocalGroup {
     const double* ptr[LOCAL_MAX_RANKS] = {nullptr};
     const Halo* halo[LOCAL_MAX_RANKS] = {nullptr};
     int members = 0;
+    int vote[LOCAL_MAX_RANKS] = {0};
+    // cross-rank persistent tCG (msdp_persist.hip XR): what the members' launches share -- two slot regions of the grid
+    // synchronisation, the error word, the exchange buffer of all n rows (uncached device memory)
+    unsigned long long* xr_slots = nullptr;
+    int* xr_err = nullptr;
+    double* xr_mdx = nullptr;
+    size_t xr_mdx_doubles = 0;
 };
 static std::mutex g_groups_mutex;
 static std::map<int, LocalGroup*> g_groups;
@@ -966,6 +1033,63 @@ static bool local_barrier(LocalGroup* g) {
     return true;
 }
 #define LOCAL_BARRIER(g) do { if (!local_barrier(g)) { msdp_set_error("in-process communicator: a member did not reach the collective (group broken)"); return MSDP_ECOMM; } } while (0)
+// minimum of one int per member (an agreement: every member takes the branch only if all of them can)
+static int local_vote_min(msdp_handle h, int v, int* out) {
+    LocalGroup* g = h->lgroup;
+    { std::lock_guard<std::mutex> lk(g->m); g->vote[h->rank] = v; }
+    LOCAL_BARRIER(g);
+    int m = v;
+    for (int r = 0; r < g->n; ++r) m = std::min(m, g->vote[r]);
+    LOCAL_BARRIER(g);                                      // nobody overwrites its vote before everyone has read it
+    *out = m;
+    return 0;
+}
+int msdp_xpersist_eligible(msdp_handle h, int nranks);                          // msdp_persist.hip
+size_t msdp_xpersist_slot_bytes();
+int msdp_xpersist_reset(hipStream_t stream, unsigned long long* slots, int* err);
+int msdp_launch_tcg_xpersist(msdp_handle h, int nranks, int rank, unsigned long long* slots, int* err, double* mdx);
+// The shared block of the group: allocated by member 0 the first time (and again when the factor outgrows the exchange buffer)
+static int xr_ensure_shared(msdp_handle h) {
+    LocalGroup* g = h->lgroup;
+    const size_t need = (size_t)rows_capacity(h) * h->nranks * (size_t)std::max(h->ldcap, 64);
+    LOCAL_BARRIER(g);
+    int rc = 0;
+    if (h->rank == 0 && (!g->xr_slots || g->xr_mdx_doubles < need)) {
+        if (!g->xr_slots) {
+            g->xr_slots = (unsigned long long*)msdp_uc_alloc(msdp_xpersist_slot_bytes() + 64);
+            if (g->xr_slots) g->xr_err = (int*)((char*)g->xr_slots + msdp_xpersist_slot_bytes());
+        }
+        if (g->xr_mdx) { if (!msdp_uc_free(g->xr_mdx)) (void)hipFree(g->xr_mdx); g->xr_mdx = nullptr; g->xr_mdx_doubles = 0; }
+        g->xr_mdx = (double*)msdp_uc_alloc(need * sizeof(double));
+        if (g->xr_mdx) { g->xr_mdx_doubles = need; if (hipMemset(g->xr_mdx, 0, need * sizeof(double)) != hipSuccess) rc = MSDP_EHIP; }
+        if (!g->xr_slots || !g->xr_mdx) rc = MSDP_ENOMEM;
+    }
+    LOCAL_BARRIER(g);
+    if (!g->xr_slots || !g->xr_mdx || g->xr_mdx_doubles < need) { msdp_set_error("cross-rank persistent tCG: shared buffers unavailable"); return rc ? rc : MSDP_ENOMEM; }
+    return 0;
+}
+// Start of a trustregions() call on the cross-rank path: member 0 clears both slot regions and the error word; nobody launches before
+static int xr_begin(msdp_handle h) {
+    LocalGroup* g = h->lgroup;
+    int rc = xr_ensure_shared(h);
+    if (rc) return rc;
+    if (h->rank == 0) {
+        if ((rc = msdp_xpersist_reset(h->stream, g->xr_slots, g->xr_err))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    LOCAL_BARRIER(g);
+    return 0;
+}
+static int xr_check(msdp_handle h) {
+    int e = 0;
+    HIPCHK(hipMemcpy(&e, h->lgroup->xr_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) {
+        msdp_set_error("cross-rank persistent tCG: a grid synchronisation timed out (a member's launch did not arrive or the workgroups were not co-resident)");
+        local_break(h->lgroup);                              // the other members' host-side collectives fail at once instead of waiting for this one
+        return MSDP_ECOMM;
+    }
+    return 0;
+}
 struct LocalPtrs { const double* p[LOCAL_MAX_RANKS]; };
 __global__ void k_local_sum(LocalPtrs src, int n, size_t count, double* __restrict__ out) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
@@ -1034,6 +1158,8 @@ static void local_leave(msdp_handle h) {
     h->lgroup = nullptr;
     if (--g->members == 0) {
         for (auto it = g_groups.begin(); it != g_groups.end(); ++it) if (it->second == g) { g_groups.erase(it); break; }
+        if (g->xr_slots && !msdp_uc_free(g->xr_slots)) (void)hipFree(g->xr_slots);
+        if (g->xr_mdx && !msdp_uc_free(g->xr_mdx)) (void)hipFree(g->xr_mdx);
         delete g;
     }
 }
@@ -1378,7 +1504,7 @@ extern "C" int msdp_tcg_path(msdp_handle h, int32_t* path) {
     CHECK_H(h);
     if (!path) return MSDP_EINVAL;
     if (!h->have_point) { msdp_set_error("tcg_path: no resident point"); return MSDP_ESTATE; }
-    *path = msdp_persist_eligible(h) ? 1 : 0;
+    *path = msdp_persist_eligible(h) ? 1 : ((h->use_comm && h->lgroup && h->xpersist_last) ? 2 : 0);   // 2: the last call ran the cross-rank persistent tCG
     return 0;
 }
 
@@ -1759,10 +1885,26 @@ static int rtr_core(msdp_handle h, const msdp_rtr_opts* opts, bool* timed_out) {
     } else {
         // One host synchronisation per TR iteration (dense / affine kinds bake the slot into their launches; with a
         // communicator the tCG runs in lock-step, see run_tcg_lockstep)
+        // in-process ranks, sparse C: ONE persistent tCG spans the ranks' launches (msdp_persist.hip XR) -- no collective per trip;
+        // every member must be able to (a vote), otherwise all of them take the lock-step chunks
+        bool xp = false;
+        if (h->use_comm && h->lgroup && h->nranks > 1 && h->d.costkind == COST_SPARSE) {
+            int agreed = 0;
+            if ((rc = local_vote_min(h, msdp_xpersist_eligible(h, h->nranks), &agreed))) return rc;
+            xp = agreed != 0;
+            if (xp && (rc = xr_begin(h))) return rc;
+        }
+        h->xpersist_last = xp;
         while (!h->h_ctl->done) {                                     // trustregions.m:441
             cur = h->h_ctl->cur;
             const auto ta = std::chrono::steady_clock::now();
-            if (h->use_comm) rc = run_tcg_lockstep(h, opts->maxinner);
+            if (xp) {
+                h->d.status = nullptr;
+                if (h->tune.fail_xr) { h->tune.fail_xr = 0; rc = 0; }     // test hook: this member's launch never arrives
+                else rc = msdp_launch_tcg_xpersist(h, h->nranks, h->rank, h->lgroup->xr_slots, h->lgroup->xr_err, h->lgroup->xr_mdx);
+                restore_status_ptr(h);
+            }
+            else if (h->use_comm) rc = run_tcg_lockstep(h, opts->maxinner);
             else rc = run_tcg(h, opts->maxinner, h->h_ctl->k);        // :495
             if (rc) return rc;
             const auto tb = std::chrono::steady_clock::now();
@@ -1770,6 +1912,7 @@ static int rtr_core(msdp_handle h, const msdp_rtr_opts* opts, bool* timed_out) {
             if ((rc = msdp_launch_costgrad(h, cur ^ 1))) return rc;   // :544
             if ((rc = msdp_launch_rtr_decide(h))) return rc;          // :548-729
             if ((rc = pull_ctl(h))) return rc;
+            if (xp && (rc = xr_check(h))) return rc;
             const auto tc = std::chrono::steady_clock::now();
             t_tcg += std::chrono::duration<double>(tb - ta).count();
             t_rest += std::chrono::duration<double>(tc - tb).count();
@@ -2257,6 +2400,35 @@ extern "C" int msdp_bench_kernel(msdp_handle h, int32_t which, int32_t reps, dou
     return 0;
 }
 
+int msdp_persist_trace_dims(msdp_handle h, int* G, int* nj, int* j0);        // msdp_persist.hip
+// Measurement only: where the time of a persistent tCG trip goes.  Runs msdp_bench_tcg_trip(reps) on the traced instance of the
+// persistent kernel and returns thread 0's s_memtime stamps of 7 phase boundaries (see msdp_persist.hip, TSTAMP) for every
+// workgroup and the trips j0 .. j0 + nj - 1: out[((g * nj + t) * 8 + phase)], cap >= G * nj * 8 entries; dims = {G, nj, j0}.
+extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms);
+extern "C" int msdp_debug_persist_trace(msdp_handle h, int32_t reps, uint64_t* out, int64_t cap, int32_t* dims, double* avg_ms) {
+    CHECK_H(h);
+    if (!out || !dims || !avg_ms) return MSDP_EINVAL;
+    if (!msdp_persist_eligible(h)) { msdp_set_error("persist_trace: the persistent kernel does not apply to this handle"); return MSDP_EUNSUPPORTED; }
+    int G = 0, nj = 0, j0 = 0;
+    msdp_persist_trace_dims(h, &G, &nj, &j0);
+    dims[0] = G; dims[1] = nj; dims[2] = j0;
+    const size_t cnt = (size_t)G * nj * 8;
+    if (cap < (int64_t)cnt || reps < j0 + nj) { msdp_set_error("persist_trace: cap >= %zu entries and reps >= %d needed", cnt, j0 + nj); return MSDP_EINVAL; }
+    if (!h->trace_buf) {
+        void* p = nullptr;
+        int rc = msdp_dev_alloc_bytes(h, &p, (size_t)MSDP_MAX_GRID * nj * 8 * sizeof(unsigned long long));
+        if (rc) return rc;
+        h->trace_buf = (unsigned long long*)p;
+    }
+    HIPCHK(hipMemset(h->trace_buf, 0, cnt * sizeof(unsigned long long)));
+    h->d.trace = h->trace_buf;
+    int rc = msdp_bench_tcg_trip(h, reps, avg_ms);
+    h->d.trace = nullptr;
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out, h->trace_buf, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms) {
     CHECK_H(h);
     if (reps < 1 || !avg_ms) return MSDP_EINVAL;
@@ -2298,6 +2470,39 @@ extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms) 
         HIPCHK(hipMemcpy(&perr, h->psync_err, sizeof(int), hipMemcpyDeviceToHost));
         if (perr) { msdp_set_error("persistent tCG: grid synchronisation timed out"); return MSDP_EHIP; }
         return rc ? rc : rc2;
+    }
+    if (h->use_comm && h->lgroup && h->nranks > 1 && h->d.costkind == COST_SPARSE) {
+        // in-process ranks: the cross-rank persistent tCG when every member can run it (`reps` trips, exits disabled, one launch per
+        // member; run twice, time the second) -- every member calls this function together
+        int agreed = 0;
+        if ((rc = local_vote_min(h, msdp_xpersist_eligible(h, h->nranks), &agreed))) return rc;
+        if (agreed) {
+            h->h_ctl->maxinner = reps;
+            if ((rc = push_ctl(h))) return rc;
+            if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
+            if ((rc = msdp_launch_rtr_begin(h))) return rc;
+            h->d.status = nullptr;
+            float ms = 0.f;
+            for (int pass = 0; pass < 2 && !rc; ++pass) {
+                if ((rc = xr_begin(h))) break;
+                HIPCHK(hipEventRecord(h->ev0, h->stream));
+                rc = msdp_launch_tcg_xpersist(h, h->nranks, h->rank, h->lgroup->xr_slots, h->lgroup->xr_err, h->lgroup->xr_mdx);
+                HIPCHK(hipEventRecord(h->ev1, h->stream));
+                HIPCHK(hipEventSynchronize(h->ev1));
+                HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+                if (!rc) rc = xr_check(h);
+                LOCAL_BARRIER(h->lgroup);
+            }
+            *avg_ms = (double)ms / reps;
+            restore_status_ptr(h);
+            h->h_ctl->bench_mode = 0;
+            h->h_ctl->done = 0;
+            int rc2 = push_ctl(h);
+            HIPCHK(hipStreamSynchronize(h->stream));
+            h->state_valid = false;
+            h->xpersist_last = true;
+            return rc ? rc : rc2;
+        }
     }
     if ((rc = push_ctl(h))) return rc;
     if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;

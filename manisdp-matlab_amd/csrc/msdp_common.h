@@ -122,6 +122,12 @@ struct Dev {
     // n x n operand of that kind (cost, eS, AyU, S) is block diagonal: the contraction skips the k range outside a row
     // tile's blocks (exact zeros there).  nullptr for every other kind.
     const int* blk_lo; const int* blk_hi;
+    // msdp_debug_persist_trace: s_memtime stamps of the phases of the persistent tCG trip (traced kernel instance only), else null
+    unsigned long long* trace;
+    // cross-rank persistent tCG (msdp_persist.hip, XR): this rank's first workgroup index among all ranks' workgroups, their total,
+    // the exchange buffer all ranks share (all n rows; uncached memory, sc1 accesses only)
+    int xr_gid0, xr_gtot;
+    double* xr_mdx;
 };
 
 // Run-time switches of a handle (msdp_set_option; the environment variables of the same meaning are read ONCE, when
@@ -151,6 +157,8 @@ struct Tuning {
     int dense_sym_rt = 0;       // A/B: 16-row tiles per wave of k_dense_sym (0: by n; 1 or 2)
     int dense_sym_len = 0;      // A/B: slice length of a work item in 16-column steps (0: planned)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
+    int xpersist = 1;        // in-process ranks (msdp_comm_init_local), sparse C, oblique: ONE persistent tCG spanning the ranks' launches -- grid
+                             //   reductions and row exchange through shared uncached memory, no collective per trip (msdp_persist.hip XR); 0: lock-step chunks
     int persist_refresh = 32;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
     int affine_overlap = 0;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain.  Measured SLOWER (round 3: BQP d = 60
                              //   85 against 73 us, theta n = 5000 83 against 74 us per Hess-vec inside graph replays): every launch of the chain
@@ -167,6 +175,7 @@ struct Tuning {
     int be_lpr = 0;          // ... lanes per row of the filter step (0: by rows per workgroup)
     int grid = 0;          // workgroups of the row-parallel launches (0: choose_grid; A/B switch)
     int fail_block = 0;    // test hook (msdp_set_option "debug_fail_block"): the next block eigen-solver call reports itself unconverged
+    int fail_xr = 0;       // test hook ("debug_xr_skip"): this member skips its next cross-rank persistent launch
     int fail_persist = 0;  // test hook (msdp_set_option "debug_fail_persist"): the next persistent launch reports a
                            //   grid-synchronisation time-out without running, to exercise the recovery path
 };
@@ -223,6 +232,7 @@ struct msdp_handle_s {
     int snap_p = 0;
     double* slab = nullptr;        // split-K partial slabs of the dense MFMA path
     bool dense_symmetric = false;  // every dense operand of the contraction (C, eS, AyU) is symmetric (checked at set-up)
+    unsigned long long* trace_buf = nullptr;   // device buffer behind Dev::trace (msdp_debug_persist_trace)
     void* symplans = nullptr;      // work-item plans of the symmetric contraction (msdp_densesym.hip)
     size_t slab_cap = 0;
     // escape workspace, kept between calls (freeing 3 GB after every call stalled the NEXT kernels on the stream
@@ -241,6 +251,7 @@ struct msdp_handle_s {
     double* esc_top = nullptr;        // top eigenvector of the previous escape call (warm start of the lambda_max run), esc_top_n entries
     int esc_top_n = 0;
     long long coll_calls = 0;         // collective calls issued so far (exchange, all-reduce, all-gather; a grouped call counts once)
+    bool xpersist_last = false;       // the last trustregions() call ran the cross-rank persistent tCG (msdp_tcg_path reports 2)
     bool trip1_capture = false;       // enqueue_trips runs inside a graph capture (no count-dependent launches)
     int trip1_count = 0;              // msdp_trip1.hip: trips enqueued since the tCG began (refresh schedule)
     int esc_method_last = 0;          // what the last escape call ran: 0 Lanczos, 1 block

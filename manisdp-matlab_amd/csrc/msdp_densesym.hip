@@ -260,7 +260,7 @@ static void sym_shape(msdp_handle h, int NT, int* RT, int* WV) {
 int msdp_densesym_eligible(msdp_handle h, int nmat) {
     const Dev& d = h->d;
     if (!h->tune.dense_sym || !h->dense_symmetric) return 0;
-    if (h->nranks != 1 || h->use_comm || h->presharded || d.n_loc != d.n) return 0;
+    if (h->nranks != 1 || h->use_comm || d.n_loc != d.n || d.row0 != 0) return 0;          // all rows on this rank
     if (d.blk_lo && h->tune.block_skip) return 0;
     if (nmat < 1 || nmat > 2 || d.ld > 32 || d.ld < 2) return 0;
     if (h->tune.dense_sym == 1 && d.n < h->tune.dense_sym_min) return 0;

@@ -39,7 +39,21 @@ __global__ void k_psync_reset(unsigned long long* slots, int* err) {
 }
 
 // LPR lanes per row (one double2 per lane), EW = stored ELL width, R = row slots per lane group.
-template <int LPR, int EW, int R, bool FUSE>
+// TRACE (one instance, msdp_debug_persist_trace): thread 0 of every workgroup stamps s_memtime at the phase boundaries of the
+// trips MSDP_TRACE_J0 .. J0 + MSDP_TRACE_NJ - 1 into d.trace[((workgroup * NJ + trip) * 8 + phase)]:
+//   0 top of the trip (gathers about to be issued)   1 gathers + row arithmetic done   2 first grid reduction returned (d_Hd)
+//   3 trial step formed, residual rows stored        4 those stores performed          5 second grid reduction returned
+//   6 new direction formed (end of the trip)
+#define MSDP_TRACE_J0 16
+#define MSDP_TRACE_NJ 32
+#define TSTAMP(ph) do { if (TRACE && threadIdx.x == 0 && j >= MSDP_TRACE_J0 && j < MSDP_TRACE_J0 + MSDP_TRACE_NJ) \
+        d.trace[((size_t)blockIdx.x * MSDP_TRACE_NJ + (j - MSDP_TRACE_J0)) * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
+// XR (cross-rank, round 4): the launches of N ranks -- N x d.G workgroups, all co-resident -- run ONE tCG together: the grid
+// reductions span the ranks (shared slot regions, workgroup index d.xr_gid0 + blockIdx.x of d.xr_gtot), the residual / direction rows
+// travel through one exchange buffer of all n rows (d.xr_mdx, global row indices), and no collective is issued per trip.  Same
+// arithmetic per row as the one-rank kernel; the sums are formed over d.xr_gtot partials in index order on every rank (same bits on
+// every rank -> same decisions).  Two slot regions alternate with the TR iteration; each launch clears the other one at its start.
+template <int LPR, int EW, int R, bool FUSE, bool TRACE = false, bool XR = false>
 __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long long* slots, int* err) {
     extern __shared__ double lds[];
     __shared__ double sh[3 * PWAVES];
@@ -69,7 +83,14 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         return;
     }
     if (lead && !FUSE) msdp_publish(d, k_tr, 0, 1);                // "TR iteration k_tr has started" (host pipelining)
-    if (!FUSE) psync_reset_other(slots + PSYNC_REGION);            // region B belongs to the TR-iteration tail kernel
+    const int bid = XR ? d.xr_gid0 + (int)blockIdx.x : (int)blockIdx.x;
+    const int GS = XR ? d.xr_gtot : d.G;                           // workgroups that synchronise
+    if (XR) {
+        unsigned long long* other = slots + (size_t)((k_tr & 1) ^ 1) * PSYNC_REGION;
+        slots += (size_t)(k_tr & 1) * PSYNC_REGION;
+        psync_reset_other(other, bid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // performed before this workgroup's first post of this launch
+    } else if (!FUSE) psync_reset_other(slots + PSYNC_REGION);     // region B belongs to the TR-iteration tail kernel
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -162,7 +183,9 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
 
     unsigned gen = 0, nbar = 0;
     const unsigned vec_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
-    __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, vec_bytes, 0x00020000);
+    const unsigned xrow0 = XR ? (unsigned)d.row0 : 0u;             // my rows inside the exchange buffer
+    __amdgpu_buffer_rsrc_t rs_md = XR ? __builtin_amdgcn_make_buffer_rsrc(d.xr_mdx, 0, (unsigned)((size_t)d.n * d.ld * sizeof(double)), 0x00020000)
+                                      : __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, vec_bytes, 0x00020000);
     bool failed = false;
     bool first_tr = true;
   for (;;) {   // ---- trust-region iterations (exactly one pass when !FUSE)
@@ -181,7 +204,14 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     // first direction = gradient: already in global memory (written by an earlier launch, or with sc1 stores by
     // the cost/gradient phase of the previous TR iteration); later trips gather the rows the other workgroups
     // stored with sc1 during this launch
-    __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[1] : d.Gr[0], 0, vec_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_g = XR ? rs_md : __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[1] : d.Gr[0], 0, vec_bytes, 0x00020000);
+    if (XR) {
+        // the first direction = the gradient, whose rows live in every rank's own buffer: hand them to the other ranks first
+#pragma unroll
+        for (int r = 0; r < R; ++r) if (OK(r)) st2_sc1(rs_md, ((xrow0 + (unsigned)ROW(r)) * (unsigned)d.ld + 2 * sub) * 8u, MD_GET(r));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!pbarrier(slots, nbar++, GS, shb, err, bid)) return;
+    }
     bool first = true;
     bool direct = false;             // TWOSYNC: the exchange buffer holds the rows of mdelta itself (a refresh trip preceded)
     // acc = sum_k C[row,k] * X[k, my columns] with X read through the agent-coherent resource rs
@@ -213,7 +243,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
                 for (int u = 0; u < 8; ++u) {
                     const bool in = s0 + u < s1;
                     const int k = in ? s0 + u : (s1 > s0 ? s1 - 1 : 0);
-                    cn[u] = (s1 > s0) ? d.colind[k] : ROW(r);
+                    cn[u] = (s1 > s0) ? d.colind[k] : (int)xrow0 + ROW(r);
                     vn[u] = in ? d.cval[k] : 0.0;
                 }
                 for (int k0 = s0; k0 < s1; k0 += 8) {
@@ -247,6 +277,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     for (;;) {
         // ---- Hmdelta = proj(C*mdelta) - mdelta.*eG   (tCG.m:163, ManiSDP_onlyunitdiag.m:127-130)
         double pd = 0.0, u1 = 0.0, u2 = 0.0;
+        TSTAMP(0);
         auto hrow = [&](int r) {
             double2 acc = gather_row(r, first ? rs_g : rs_md);
             if (TWOSYNC) {
@@ -272,7 +303,9 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
 #pragma unroll
             for (int r = 0; r < R; ++r) hrow(r);
         }
-        if (!psync(slots, gen++, d.G, 1, pd, u1, u2, sh, shb, err)) { failed = true; break; }
+        TSTAMP(1);
+        if (!psync(slots, gen++, GS, 1, pd, u1, u2, sh, shb, err, bid)) { failed = true; break; }
+        TSTAMP(2);
         const double d_Hd = pd;                                                        // :166
         alpha = z_r / d_Hd;                                                            // :170
         const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;      // :173
@@ -306,11 +339,15 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
                 // the re-projection of mdelta removes (:283) and what the assembled product would otherwise keep and amplify
                 const double2 y = Y_GET(r);
                 const double dn = msdp_group_sum<LPR>(nr.x * y.x + nr.y * y.y);
-                if (OK(r)) st2_sc1(rs_md, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, make_double2(nr.x - y.x * dn, nr.y - y.y * dn));
+                if (OK(r)) st2_sc1(rs_md, ((xrow0 + (unsigned)ROW(r)) * (unsigned)d.ld + 2 * sub) * 8u, make_double2(nr.x - y.x * dn, nr.y - y.y * dn));
             }
         }
+        TSTAMP(3);
         if (TWOSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my residual rows are performed before I post
-        if (!psync(slots, gen++, d.G, 3, s1, s2, s3, sh, shb, err)) { failed = true; break; }
+        TSTAMP(4);
+        if (!psync(slots, gen++, GS, 3, s1, s2, s3, sh, shb, err, bid)) { failed = true; break; }
+        { const int jsave = j; (void)jsave; }
+        TSTAMP(5);
         e_Pe = e_Pe_new;
         const double new_model = s1 + 0.5 * s2;                                        // :227
         const double r_r = s3;
@@ -343,14 +380,15 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
             dot = msdp_group_sum<LPR>(dot);
             const double2 mnew = make_double2(v.x - y.x * dot, v.y - y.y * dot);
             MD_SET(r, mnew);
-            if ((!TWOSYNC || refresh_now) && OK(r)) st2_sc1(rs_md, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, mnew);
+            if ((!TWOSYNC || refresh_now) && OK(r)) st2_sc1(rs_md, ((xrow0 + (unsigned)ROW(r)) * (unsigned)d.ld + 2 * sub) * 8u, mnew);
         }
         if (!TWOSYNC || refresh_now) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my rows are performed before my workgroup posts
-            if (!pbarrier(slots, nbar++, d.G, shb, err)) { failed = true; break; }
+            if (!pbarrier(slots, nbar++, GS, shb, err, bid)) { failed = true; break; }
         }
         direct = refresh_now;
         first = false;
+        { --j; TSTAMP(6); ++j; }                                    // (j was advanced above: stamp under the trip's own index)
     }
     if (failed) return;
     if (!FUSE) {
@@ -390,7 +428,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         if (OK(r)) st2_sc1(rs_yp, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, ypr);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!pbarrier(slots, nbar++, d.G, shb, err)) return;
+    if (!pbarrier(slots, nbar++, GS, shb, err, bid)) return;
     // cost and gradient at the proposal (ManiSDP_onlyunitdiag.m:117-125): YC = Y*C, eG = sum(YC.*Y), G = YC - Y.*eG.
     // Rolled loop over the row slots (LDS in, LDS out): this phase runs once per TR iteration and must not add
     // register pressure to the tCG loop above.
@@ -409,7 +447,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         if (OK(r)) st2_sc1(rs_gp, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, gpr);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the proposal's gradient rows are in place before the post
-    if (!psync(slots, gen++, d.G, 3, pf, pgg, prd, sh, shb, err)) return;
+    if (!psync(slots, gen++, GS, 3, pf, pgg, prd, sh, shb, err, bid)) return;
     {   // trustregions.m:548-729, identical in every workgroup (same bits in, same decision out)
         const double fp = pf, ggp = pgg;
         double rhonum = fx - fp;                                             // :548
@@ -493,6 +531,9 @@ static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
     // p = 17..32 beyond 128 rows per workgroup (n > 32768 on 256 CUs): eight row slots in the LOWREG form (mdelta / Hmdelta in
     // LDS, three synchronisations) instead of falling back to the chunked path
     if (lpr == 16 && need > 4 * rstep && need <= 8 * rstep) pl.r = 8;
+    // ... but up to 160 rows per workgroup (n <= 40960 on 256 CUs) five slots still keep every vector in registers: the
+    // two-synchronisation trip instead of LOWREG's three (round 4)
+    if (lpr == 16 && need > 4 * rstep && need <= 5 * rstep) pl.r = 5;
     // p <= 16 (64 rows per slot): four slots (all in registers, two synchronisations) up to 256 rows per workgroup, i.e.
     // n <= 65536 on 256 CUs (eight slots would need 163 KB of LDS with the ELL rows)
     if (lpr == 8 && need > 2 * rstep && need <= 4 * rstep) pl.r = 4;
@@ -525,6 +566,11 @@ static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false) {
         if (pl.ew == 5) return k_tcg_persist_obl<16, 5, 8, false>;
         if (pl.ew == 8) return k_tcg_persist_obl<16, 8, 8, false>;
         if (pl.ew == 0) return k_tcg_persist_obl<16, 0, 8, false>;
+    }
+    if (!fuse && pl.lpr == 16 && pl.r == 5) {
+        if (pl.ew == 5) return k_tcg_persist_obl<16, 5, 5, false>;
+        if (pl.ew == 8) return k_tcg_persist_obl<16, 8, 5, false>;
+        if (pl.ew == 0) return k_tcg_persist_obl<16, 0, 5, false>;
     }
     if (!fuse && pl.lpr == 32 && pl.r == 5) {
         if (pl.ew == 5) return k_tcg_persist_obl<32, 5, 5, false>;
@@ -606,10 +652,16 @@ int msdp_launch_tcg_persist(msdp_handle h, int reset_slots) {
         hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, h->stream, h->psync_slots, h->psync_err);
         HIPCHK(hipGetLastError());
     }
+    if (dp.trace) {
+        if (!(pl.lpr == 16 && pl.ew == 5 && pl.r == 3)) { msdp_set_error("persistent trace: only the <16, 5, 3> instance (17 <= p <= 32, rows of <= 5 entries) is traced"); return MSDP_EUNSUPPORTED; }
+        fn = k_tcg_persist_obl<16, 5, 3, false, true>;
+        HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    }
     hipLaunchKernelGGL(fn, dim3(G), dim3(PB), pl.lds, h->stream, dp, h->psync_slots, h->psync_err);
     HIPCHK(hipGetLastError());
     return 0;
 }
+int msdp_persist_trace_dims(msdp_handle h, int* G, int* nj, int* j0) { *G = persist_grid(h->d); *nj = MSDP_TRACE_NJ; *j0 = MSDP_TRACE_J0; return 0; }
 
 int msdp_tr_tail_grid(msdp_handle h) { return persist_grid(h->d); }
 
@@ -655,6 +707,67 @@ int msdp_launch_rtr_fused(msdp_handle h) {
     hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, h->stream, h->psync_slots, h->psync_err);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(fn, dim3(G), dim3(PB), pl.lds, h->stream, dp, h->psync_slots, h->psync_err);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+
+// ------------------------------------------------------------------ cross-rank persistent tCG (XR)
+// N in-process ranks (msdp_comm_init_local) run k_tcg_persist_obl<..., XR> side by side: N x G workgroups, G = (256 / N) rounded
+// down to a multiple of 8, all co-resident (one per CU).  The plan follows the LARGEST row count of a rank (cap), so every
+// rank picks the same synchronisation scheme; the ELL width may differ between ranks (a different instance, same protocol).
+static persist_fn xr_kernel(const PersistPlan& pl) {
+#define XK(L, E, RR) if (pl.lpr == L && pl.ew == E && pl.r == RR) return k_tcg_persist_obl<L, E, RR, false, false, true>;
+    XK(8, 5, 2) XK(8, 0, 2) XK(8, 5, 4) XK(8, 0, 4) XK(16, 5, 3) XK(16, 0, 3) XK(16, 5, 5) XK(16, 0, 5) XK(32, 5, 5) XK(32, 0, 5)
+#undef XK
+    return nullptr;
+}
+static bool xr_plan(msdp_handle h, int nranks, PersistPlan& pl, int* G_out) {
+    const Dev& d = h->d;
+    if (!h->tune.persist || !h->tune.xpersist || h->persist_failed || d.costkind != COST_SPARSE || d.manifold != MANI_OBLIQUE || d.rowfree) return false;
+    int G = (256 / nranks) & ~7;
+    if (G < 8 || nranks < 2) return false;
+    Dev dc = d;
+    dc.n_loc = (d.n + nranks - 1) / nranks;                // the plan of the rank with the most rows
+    if (!persist_plan(dc, G, pl)) return false;
+    if (pl.r > 5) return false;                            // LOWREG instances are not built for XR
+    if (pl.ew > 0 && d.ellW != pl.ew) pl.ew = 0;           // this rank's rows are longer than the ELL width of the plan: CSR instance
+    if (pl.ew == 8) pl.ew = 0;
+    if (!xr_kernel(pl)) return false;
+    const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr);
+    pl.lds = (size_t)2 * pl.r * PB * sizeof(double2) + rows * sizeof(double) + (size_t)pl.ew * rows * (sizeof(double) + sizeof(int));
+    *G_out = G;
+    return true;
+}
+int msdp_xpersist_eligible(msdp_handle h, int nranks) {
+    PersistPlan pl; int G = 0;
+    if (!xr_plan(h, nranks, pl, &G)) return 0;
+    persist_fn fn = xr_kernel(pl);
+    int dev = 0, cus = 0, per_cu = 0, ok = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, PB, pl.lds) == hipSuccess)
+        ok = (per_cu >= 1 && cus >= G * nranks) ? 1 : 0;
+    (void)hipGetLastError();
+    return ok;
+}
+// Bytes of the shared synchronisation block: two slot regions (they alternate with the TR iteration)
+size_t msdp_xpersist_slot_bytes() { return 2 * PSYNC_REGION * sizeof(unsigned long long); }
+int msdp_xpersist_reset(hipStream_t stream, unsigned long long* slots, int* err) {
+    hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, stream, slots, err);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int msdp_launch_tcg_xpersist(msdp_handle h, int nranks, int rank, unsigned long long* slots, int* err, double* mdx) {
+    PersistPlan pl; int G = 0;
+    if (!xr_plan(h, nranks, pl, &G)) { msdp_set_error("cross-rank persistent tCG: not eligible"); return MSDP_ESTATE; }
+    persist_fn fn = xr_kernel(pl);
+    Dev dp = h->d;
+    dp.G = G;
+    dp.xr_gid0 = rank * G; dp.xr_gtot = nranks * G; dp.xr_mdx = mdx;
+    HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    hipLaunchKernelGGL(fn, dim3(G), dim3(PB), pl.lds, h->stream, dp, slots, err);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -41,8 +41,11 @@ __device__ __forceinline__ void st2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte
 
 // Reduce (a, b, c) over the whole grid; nv = number of meaningful values (1 or 3).  Returns false when the
 // spin bound was hit (error flag set; the caller leaves the kernel).
+// bid: this workgroup's index among the G that synchronise -- blockIdx.x, or rank * (workgroups per rank) + blockIdx.x when the
+// launches of several ranks share one slot region (cross-rank persistent tCG, msdp_persist.hip XR)
 __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, int G, int nv, double& a, double& b,
-                                      double& c, double* sh, double* shb, int* err) {
+                                      double& c, double* sh, double* shb, int* err, int bid_in = -1) {
+    const int bid = bid_in < 0 ? (int)blockIdx.x : bid_in;
     a = msdp_wave_sum(a);
     if (nv > 1) { b = msdp_wave_sum(b); c = msdp_wave_sum(c); }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -57,11 +60,11 @@ __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, i
                 for (int i = 0; i < PWAVES; ++i) s += sh[vi * PWAVES + i];
                 // the reset store of this slot's other generations (issued one sync ago) must have been performed
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(gbase + ((size_t)rep * PSYNC_NV + vi) * MSDP_MAX_GRID + blockIdx.x,
+                __hip_atomic_store(gbase + ((size_t)rep * PSYNC_NV + vi) * MSDP_MAX_GRID + bid,
                                    (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        unsigned long long* base = gbase + (size_t)(blockIdx.x & (PSYNC_REP - 1)) * PSYNC_NV * MSDP_MAX_GRID;
+        unsigned long long* base = gbase + (size_t)(bid & (PSYNC_REP - 1)) * PSYNC_NV * MSDP_MAX_GRID;
         double r0, r1 = 0.0, r2 = 0.0;
         int spins = 0;
         bool fail = false;
@@ -130,7 +133,7 @@ __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, i
         // everybody has finished reading the previous generation (they all posted this one): reset my slots of it
         if (lane < PSYNC_REP * PSYNC_NV)
             __hip_atomic_store(slots + (size_t)((gen + PSYNC_GEN - 1) % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID +
-                                   (size_t)lane * MSDP_MAX_GRID + blockIdx.x,
+                                   (size_t)lane * MSDP_MAX_GRID + bid,
                                PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
@@ -141,12 +144,13 @@ __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, i
 
 // Barrier without a value (the new direction rows are in place): workgroup b adds to counter b & 7, everybody
 // polls the 8 counters (64 B apart).  nbar = number of barriers passed before this one.  G is a multiple of 8.
-__device__ __forceinline__ bool pbarrier(unsigned long long* slots, unsigned nbar, int G, double* shb, int* err) {
+__device__ __forceinline__ bool pbarrier(unsigned long long* slots, unsigned nbar, int G, double* shb, int* err, int bid_in = -1) {
+    const int bid = bid_in < 0 ? (int)blockIdx.x : bid_in;
     __syncthreads();
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         unsigned long long* cnt = slots + PSYNC_CNT_OFF;
-        if (lane == 0) __hip_atomic_fetch_add(cnt + 8 * (blockIdx.x & 7), 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_add(cnt + 8 * (bid & 7), 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long want = (unsigned long long)(nbar + 1) * (unsigned)(G / 8);
         int spins = 0;
         bool fail = false;
@@ -172,8 +176,9 @@ __device__ __forceinline__ bool pbarrier(unsigned long long* slots, unsigned nba
 // Two kernels alternate on a stream (persistent tCG, TR-iteration tail), each with its own region; a kernel may
 // not reset its own region while its workgroups poll it, so each one resets the OTHER kernel's region at its start:
 // workgroup b clears column b of every slot array, workgroup 0 the counters (completed at the kernel boundary).
-__device__ __forceinline__ void psync_reset_other(unsigned long long* other) {
+__device__ __forceinline__ void psync_reset_other(unsigned long long* other, int bid_in = -1) {
+    const int bid = bid_in < 0 ? (int)blockIdx.x : bid_in;
     const int t = threadIdx.x;
-    if (t < PSYNC_GEN * PSYNC_REP * PSYNC_NV) other[(size_t)t * MSDP_MAX_GRID + blockIdx.x] = PSYNC_SENT;
-    if (blockIdx.x == 0 && t >= 128 && t < 192) other[PSYNC_CNT_OFF + (t - 128)] = 0ULL;
+    if (t < PSYNC_GEN * PSYNC_REP * PSYNC_NV) other[(size_t)t * MSDP_MAX_GRID + bid] = PSYNC_SENT;
+    if (bid == 0 && t >= 128 && t < 192) other[PSYNC_CNT_OFF + (t - 128)] = 0ULL;
 }

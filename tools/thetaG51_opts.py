@@ -11,6 +11,8 @@ At, b, c, K = problems.from_sdpa(os.path.join(ROOT, "tests/golden/thetaG51.dat-s
 c = np.asarray(c.todense()).ravel() if hasattr(c, "todense") else np.asarray(c, float).ravel()
 b = np.asarray(b.todense()).ravel() if hasattr(b, "todense") else np.asarray(b, float).ravel()
 SETS = {
+    "gpp_al60": dict(tol=1e-6, sigma0=1e-1, sigma_min=1e-1, tau1=1e-2, tau2=1e-1, TR_maxinner=40, TR_maxiter=6, AL_maxiter=60),
+    "gpp_al120": dict(tol=1e-6, sigma0=1e-1, sigma_min=1e-1, tau1=1e-2, tau2=1e-1, TR_maxinner=40, TR_maxiter=6, AL_maxiter=120),
     "b10x200": dict(tol=1e-8, TR_maxiter=10, TR_maxinner=200),
     "b30x100": dict(tol=1e-8, TR_maxiter=30, TR_maxinner=100),
     "b30x200s": dict(tol=1e-8, TR_maxiter=30, TR_maxinner=200, sigma0=1e-1, sigma_min=1e-1),
