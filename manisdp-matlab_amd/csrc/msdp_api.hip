@@ -98,12 +98,15 @@ void* msdp_uc_alloc(size_t bytes) {
     if (!env_read) {
         env_read = true;
         const char* e = getenv("MSDP_UC_POOL_CAP"); if (e && *e) g_uc_cap = (size_t)strtoull(e, nullptr, 10);
-        e = getenv("MSDP_UC_POOL"); if (e && *e == '0') g_uc_direct = 1;
+        // probes of tools/uc_pool_stress.py: 0 = direct (hipFree at destroy), 2 = direct + hipDeviceSynchronize before every free,
+        // 3 = direct, uncached blocks never freed
+        e = getenv("MSDP_UC_POOL"); if (e && (*e == '0' || *e == '2' || *e == '3')) g_uc_direct = *e == '0' ? 1 : (*e - '0');
     }
     if (g_uc_direct) {
         void* p = nullptr;
         if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        return p;                                             // not registered: msdp_uc_free returns false and the caller hipFree's it
+        if (g_uc_direct == 3) g_uc_live[p] = {-1, bytes};     // registered with no arena: msdp_uc_free keeps it for ever
+        return p;                                             // else not registered: msdp_uc_free returns false and the caller hipFree's it
     }
     for (int pass = 0; pass < 2; ++pass) {
         // best fit over the free ranges of this device's arenas
@@ -140,7 +143,8 @@ bool msdp_uc_free(void* p) {                                  // true: p was an 
     if (!p) return false;
     std::lock_guard<std::mutex> lk(g_uc_mutex);
     auto it = g_uc_live.find(p);
-    if (it == g_uc_live.end()) return false;
+    if (it == g_uc_live.end()) { if (g_uc_direct == 2) (void)hipDeviceSynchronize(); return false; }
+    if (it->second.first < 0) return true;                    // probe mode 3: leaked on purpose
     UcArena& a = g_uc_arenas[it->second.first];
     size_t off = (size_t)((char*)p - a.base), sz = it->second.second;
     a.live -= sz;

@@ -153,7 +153,7 @@ struct Tuning {
                            //   (k_adjoint_gram) instead of k_gram_apply + k_adjoint_tiled (0: A/B, tests)
     int dense_sym = 1;     // symmetric dense operands (p <= 32, one rank): the contraction reads the upper triangle only
                            //   (msdp_densesym.hip); 1 = from dense_sym_min rows on, 2 = always, 0 = never
-    int dense_sym_min = 3000;   // see dense_sym
+    int dense_sym_min = 8192;   // see dense_sym (below, the partial slabs of the transposed products cost what the halved matrix saves: measured)
     int dense_sym_rt = 0;       // A/B: 16-row tiles per wave of k_dense_sym (0: by n; 1 or 2)
     int dense_sym_len = 0;      // A/B: slice length of a work item in 16-column steps (0: planned)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)

@@ -726,7 +726,9 @@ static bool xr_plan(msdp_handle h, int nranks, PersistPlan& pl, int* G_out) {
     const Dev& d = h->d;
     if (!h->tune.persist || !h->tune.xpersist || h->persist_failed || d.costkind != COST_SPARSE || d.manifold != MANI_OBLIQUE || d.rowfree) return false;
     int G = (256 / nranks) & ~7;
-    if (G < 8 || nranks < 2) return false;
+    // more than four members cannot run side by side: the launches of in-process ranks sit on streams of one process, which the
+    // runtime maps onto at most four hardware queues (GPU_MAX_HW_QUEUES) -- a fifth launch waits for a queue and the others for it
+    if (G < 8 || nranks < 2 || nranks > 4) return false;
     Dev dc = d;
     dc.n_loc = (d.n + nranks - 1) / nranks;                // the plan of the rank with the most rows
     if (!persist_plan(dc, G, pl)) return false;

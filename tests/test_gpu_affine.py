@@ -467,6 +467,7 @@ def test_unitdiag_hessvec_b_route_matches_the_two_pass_route(lib, monkeypatch, c
     y = rng.standard_normal(b.size) * 0.1
     prob = R._UnitDiagProblem(At, np.asarray(b, float), c, n, p)
     prob.y, prob.sigma = y, 1.7
+    prob.cost(Y); prob.grad(Y)                                # the closures share Axb and eS (ManiSDP_unitdiag.m:152-164)
     H_ref = prob.hess(Y, U)
     out = []
     for broute in (1, 0):

@@ -8,6 +8,7 @@ from manisdp_matlab_amd import _lib, problems
 gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 args = sys.argv[1:]
 profile = "--profile" in args
+nofuse = "--nofuse" in args
 names = [a for a in args if not a.startswith("--")] or ["bqp60", "theta5000"]
 for name in names:
     t0 = time.time()
@@ -32,6 +33,8 @@ for name in names:
         h.set_option("dense_sym", sym); h.set_option("affine_broute", br); h.set_option("dense_sym_rt", rt)
         if profile:
             h.set_option("graph", 0)
+        if nofuse:
+            h.set_option("affine_fuse", 0)
         h.set_point(Y)
         H = h.hessvec(U)
         if ref is None:

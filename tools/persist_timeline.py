@@ -39,18 +39,17 @@ for k in range(7):
     lines.append("| %d %s | %.0f ns | %.0f ns | %.0f ns (wg %d) | %.0f ns | %.1f %% |" % (k, names[k], col[0], np.median(col), col.max(), int(col.argmax()), col.min(), 100 * col.mean() / tot))
 lines.append("| sum | %.0f ns | | | | |" % per_wg[0].sum())
 # arrival skew at the two reductions (stamps 1 and 4 are taken right before the post); only meaningful if s_memtime is one clock for the chip
-skew1 = (st[:, :, 1].max(axis=0) - st[:, :, 1].min(axis=0)).mean() * ns
-skew2 = (st[:, :, 4].max(axis=0) - st[:, :, 4].min(axis=0)).mean() * ns
-lines.append("\nArrival skew (last minus first workgroup to reach the post, mean over the trips): reduction 1 %.0f ns, reduction 2 %.0f ns" % (skew1, skew2))
 xcd = np.arange(G) % 8
+# arrival skew at the two reductions, per XCD (s_memtime is one counter per XCD, not per chip: stamps of different XCDs do not compare)
+sk1 = np.mean([(st[xcd == x][:, :, 1].max(axis=0) - st[xcd == x][:, :, 1].min(axis=0)).mean() for x in range(8)]) * ns
+sk2 = np.mean([(st[xcd == x][:, :, 4].max(axis=0) - st[xcd == x][:, :, 4].min(axis=0)).mean() for x in range(8)]) * ns
+lines.append("\nArrival skew inside an XCD (last minus first of its workgroups to reach the post, mean over trips and XCDs): reduction 1 %.0f ns, reduction 2 %.0f ns" % (sk1, sk2))
 lines.append("Per-XCD mean of the gather phase (workgroup b runs on XCD b mod 8): " + ", ".join("%.0f" % per_wg[xcd == x, 0].mean() for x in range(8)) + " ns")
 lines.append("Per-XCD mean wait in reduction 1: " + ", ".join("%.0f" % per_wg[xcd == x, 1].mean() for x in range(8)) + " ns")
 lines.append("Per-XCD mean wait in reduction 2: " + ", ".join("%.0f" % per_wg[xcd == x, 4].mean() for x in range(8)) + " ns")
 # the reduction itself = the wait of the LAST workgroup to arrive (it finds all other slots filled)
-last1 = st[:, :-1, 1].argmax(axis=0); last2 = st[:, :-1, 4].argmax(axis=0)
-r1 = np.array([dur[last1[t], t, 1] for t in range(nj - 1)]).mean() * ns
-r2 = np.array([dur[last2[t], t, 4] for t in range(nj - 1)]).mean() * ns
-lines.append("Cost of a reduction proper = the wait of the workgroup that arrives LAST: reduction 1 %.0f ns, reduction 2 %.0f ns" % (r1, r2))
+r1 = dur[:, :, 1].min(axis=0).mean() * ns; r2 = dur[:, :, 4].min(axis=0).mean() * ns
+lines.append("Cost of a reduction proper = the SHORTEST wait among the workgroups of a trip (the one that arrives last finds the other slots filled): reduction 1 %.0f ns, reduction 2 %.0f ns" % (r1, r2))
 out = "\n".join(lines) + "\n"
 print(out)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
