@@ -200,7 +200,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm_finish(AffineDev a, int mo
 //   tr(H Y') without a pass over H (k_sph_hess_fused).
 template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm1(AffineDev a, Dev d, const double* __restrict__ Ya, const double* __restrict__ Yb,
-                                                     int mode, double* axb_out, double sigma, const int* skip_flag, int skip_when) {
+                                                     int mode, double* axb_out, double sigma, const int* skip_flag, int skip_when, int nbl) {
     __shared__ double sh[3 * MSDP_WAVES + 8];
     __shared__ int lastflag;
     if (skip_flag && *skip_flag == skip_when) return;
@@ -212,11 +212,12 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm1(AffineDev a, Dev d, const
     const double* __restrict__ axc = cur ? a.Axb[1] : a.Axb[0];
     const int slotL = mode == 1 ? MSDP_MAX_GRID - 1 : (int)gridDim.x;
     double pacc = 0.0;
+    int haslong = 0;
     const int64_t ustride = (int64_t)gridDim.x * MSDP_WAVES * CPW;
     for (int64_t u = ((int64_t)blockIdx.x * MSDP_WAVES + wave) * CPW + csub; u < nunits; u += ustride) {
         int s0, s1, k = -1, lq = 0;
         if (u < a.nshort) { k = a.sk[u]; s0 = a.cjc[k]; s1 = a.cjc[k + 1]; }
-        else { lq = (int)(u - a.nshort); s0 = a.lit0[lq]; s1 = a.lit1[lq]; }
+        else { lq = (int)(u - a.nshort); s0 = a.lit0[lq]; s1 = a.lit1[lq]; haslong = 1; }
         double acc = 0.0;
         constexpr int U = NCH == 1 ? 4 : 2;
         for (int t = s0; t < s1; t += U) {
@@ -280,9 +281,10 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm1(AffineDev a, Dev d, const
         if (blockIdx.x == 0 && threadIdx.x == 0 && mode != 0) d.P[(mode == 1 ? P_AXB : P_T3) * MSDP_MAX_GRID + slotL] = 0.0;
         return;
     }
+    // only the `nbl` workgroups that summed items of long constraints (a host-known count: the items are consecutive units) take part
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) lastflag = (__hip_atomic_fetch_add(a.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+    if (!__syncthreads_or(haslong)) return;
+    if (threadIdx.x == 0) lastflag = (__hip_atomic_fetch_add(a.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nbl - 1u) ? 1 : 0;
     __syncthreads();
     if (!lastflag) return;
     double pl = 0.0;
@@ -1415,7 +1417,13 @@ static int launch_A(msdp_handle h, AffineDev& a, int64_t nnz, const double* Ya, 
         if (mode == 1) g1 = MSDP_MAX_GRID - 1;
         if (mode == 2 && g1 > h->d.n_loc) g1 = std::max(1, h->d.n_loc);
         if (G2_out) *G2_out = (int)g1;
-        DISPATCH_LPR_A(k_sddmm1, h, (int)g1, a, h->d, Ya, Yb, mode, axb_out, sigma, flag, when);
+        // workgroups that hold items of long constraints: unit u belongs to workgroup (u / per_block) mod g1
+        int nbl = 0;
+        if (a.nlit > 0) {
+            const int64_t b0 = (int64_t)a.nshort / per_block, b1 = ((int64_t)a.nshort + a.nlit - 1) / per_block;
+            nbl = (int)std::min<int64_t>(g1, b1 - b0 + 1);
+        }
+        DISPATCH_LPR_A(k_sddmm1, h, (int)g1, a, h->d, Ya, Yb, mode, axb_out, sigma, flag, when, nbl);
         HIPCHK(hipGetLastError());
         return 0;
     }

@@ -657,6 +657,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     if (h->lz_slots && !msdp_uc_free(h->lz_slots)) (void)hipFree(h->lz_slots);
     msdp_blockeig_release(h);
     if (h->esc_top) (void)hipFree(h->esc_top);
+    if (h->xr_ev) (void)hipEventDestroy(h->xr_ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -946,6 +947,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "dense_sym")) { t.dense_sym = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
     else if (!strcmp(name, "dense_sym_min")) { t.dense_sym_min = value > 0 ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
     else if (!strcmp(name, "dense_sym_rt")) { t.dense_sym_rt = (value >= 1 && value <= 3) ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
+    else if (!strcmp(name, "dense_sym_db")) { t.dense_sym_db = (value >= 0 && value <= 2) ? value : 0; h->chunk_len = 0; }
     else if (!strcmp(name, "dense_sym_len")) { t.dense_sym_len = value > 0 ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
     else if (!strcmp(name, "debug_fail_persist")) t.fail_persist = value != 0;
     else if (!strcmp(name, "debug_xr_skip")) t.fail_xr = value != 0;
@@ -1001,6 +1003,12 @@ struct LocalGroup {
     // synchronisation, the error word, the exchange buffer of all n rows (uncached device memory)
     unsigned long long* xr_slots = nullptr;
     int* xr_err = nullptr;
+    // the combined launch (member 0 issues it for everybody): every member's Dev and plan, the events that order it behind the
+    // members' streams and the members' streams behind it
+    Dev xr_dev[LOCAL_MAX_RANKS];
+    int xr_plan[3 * LOCAL_MAX_RANKS] = {0};
+    hipEvent_t xr_ready[LOCAL_MAX_RANKS] = {nullptr};
+    hipEvent_t xr_done = nullptr;
     double* xr_mdx = nullptr;
     size_t xr_mdx_doubles = 0;
 };
@@ -1051,7 +1059,6 @@ static int local_vote_min(msdp_handle h, int v, int* out) {
 int msdp_xpersist_eligible(msdp_handle h, int nranks);                          // msdp_persist.hip
 size_t msdp_xpersist_slot_bytes();
 int msdp_xpersist_reset(hipStream_t stream, unsigned long long* slots, int* err);
-int msdp_launch_tcg_xpersist(msdp_handle h, int nranks, int rank, unsigned long long* slots, int* err, double* mdx);
 // The shared block of the group: allocated by member 0 the first time (and again when the factor outgrows the exchange buffer)
 static int xr_ensure_shared(msdp_handle h) {
     LocalGroup* g = h->lgroup;
@@ -1060,8 +1067,12 @@ static int xr_ensure_shared(msdp_handle h) {
     int rc = 0;
     if (h->rank == 0 && (!g->xr_slots || g->xr_mdx_doubles < need)) {
         if (!g->xr_slots) {
-            g->xr_slots = (unsigned long long*)msdp_uc_alloc(msdp_xpersist_slot_bytes() + 64);
-            if (g->xr_slots) g->xr_err = (int*)((char*)g->xr_slots + msdp_xpersist_slot_bytes());
+            g->xr_slots = (unsigned long long*)msdp_uc_alloc(msdp_xpersist_slot_bytes() + 256);
+            if (g->xr_slots) {
+                g->xr_err = (int*)((char*)g->xr_slots + msdp_xpersist_slot_bytes());
+                if (hipMemset(g->xr_err, 0, 256) != hipSuccess) rc = MSDP_EHIP;
+                if (hipEventCreateWithFlags(&g->xr_done, hipEventDisableTiming) != hipSuccess) rc = MSDP_EHIP;
+            }
         }
         if (g->xr_mdx) { if (!msdp_uc_free(g->xr_mdx)) (void)hipFree(g->xr_mdx); g->xr_mdx = nullptr; g->xr_mdx_doubles = 0; }
         g->xr_mdx = (double*)msdp_uc_alloc(need * sizeof(double));
@@ -1072,16 +1083,49 @@ static int xr_ensure_shared(msdp_handle h) {
     if (!g->xr_slots || !g->xr_mdx || g->xr_mdx_doubles < need) { msdp_set_error("cross-rank persistent tCG: shared buffers unavailable"); return rc ? rc : MSDP_ENOMEM; }
     return 0;
 }
-// Start of a trustregions() call on the cross-rank path: member 0 clears both slot regions and the error word; nobody launches before
-static int xr_begin(msdp_handle h) {
+int msdp_xpersist_member(msdp_handle h, int nranks, int rank, double* mdx, Dev* out, int* plan3);        // msdp_persist.hip
+int msdp_launch_tcg_xpersist_all(hipStream_t stream, int nranks, const Dev* devs, const int* plans, unsigned long long* slots, int* err);
+// Start of a trustregions() call on the cross-rank path: member 0 clears both slot regions and the error word; nobody goes on before
+static int xr_begin(msdp_handle h, bool* use) {
     LocalGroup* g = h->lgroup;
+    *use = false;
     int rc = xr_ensure_shared(h);
     if (rc) return rc;
+    if (!h->xr_ev) HIPCHK(hipEventCreateWithFlags(&h->xr_ev, hipEventDisableTiming));
+    *use = true;
     if (h->rank == 0) {
         if ((rc = msdp_xpersist_reset(h->stream, g->xr_slots, g->xr_err))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     LOCAL_BARRIER(g);
+    return 0;
+}
+// One tCG for all members: each hands its Dev and plan to the group and marks its stream; member 0 makes its stream wait for
+// the others', launches the combined kernel and marks its end; the others' streams wait for that mark.
+static int xr_launch(msdp_handle h) {
+    LocalGroup* g = h->lgroup;
+    int rc;
+    {
+        Dev dv; int pl[3];
+        if ((rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_mdx, &dv, pl))) { local_break(g); return rc; }
+        HIPCHK(hipEventRecord(h->xr_ev, h->stream));
+        std::lock_guard<std::mutex> lk(g->m);
+        g->xr_dev[h->rank] = dv;
+        for (int q = 0; q < 3; ++q) g->xr_plan[3 * h->rank + q] = pl[q];
+        g->xr_ready[h->rank] = h->xr_ev;
+    }
+    LOCAL_BARRIER(g);
+    if (h->rank == 0) {
+        for (int q = 1; q < g->n; ++q) HIPCHK(hipStreamWaitEvent(h->stream, g->xr_ready[q], 0));
+        if (h->tune.fail_xr) {                                 // test hook: the workgroups wait for eight more than exist -> bounded spin -> error word
+            h->tune.fail_xr = 0;
+            for (int q = 0; q < g->n; ++q) g->xr_dev[q].xr_gtot += 8;
+        }
+        if ((rc = msdp_launch_tcg_xpersist_all(h->stream, g->n, g->xr_dev, g->xr_plan, g->xr_slots, g->xr_err))) { local_break(g); return rc; }
+        HIPCHK(hipEventRecord(g->xr_done, h->stream));
+    }
+    LOCAL_BARRIER(g);
+    if (h->rank != 0) HIPCHK(hipStreamWaitEvent(h->stream, g->xr_done, 0));
     return 0;
 }
 static int xr_check(msdp_handle h) {
@@ -1164,6 +1208,7 @@ static void local_leave(msdp_handle h) {
         for (auto it = g_groups.begin(); it != g_groups.end(); ++it) if (it->second == g) { g_groups.erase(it); break; }
         if (g->xr_slots && !msdp_uc_free(g->xr_slots)) (void)hipFree(g->xr_slots);
         if (g->xr_mdx && !msdp_uc_free(g->xr_mdx)) (void)hipFree(g->xr_mdx);
+        if (g->xr_done) (void)hipEventDestroy(g->xr_done);
         delete g;
     }
 }
@@ -1896,7 +1941,7 @@ static int rtr_core(msdp_handle h, const msdp_rtr_opts* opts, bool* timed_out) {
             int agreed = 0;
             if ((rc = local_vote_min(h, msdp_xpersist_eligible(h, h->nranks), &agreed))) return rc;
             xp = agreed != 0;
-            if (xp && (rc = xr_begin(h))) return rc;
+            if (xp && (rc = xr_begin(h, &xp))) return rc;
         }
         h->xpersist_last = xp;
         while (!h->h_ctl->done) {                                     // trustregions.m:441
@@ -1904,8 +1949,7 @@ static int rtr_core(msdp_handle h, const msdp_rtr_opts* opts, bool* timed_out) {
             const auto ta = std::chrono::steady_clock::now();
             if (xp) {
                 h->d.status = nullptr;
-                if (h->tune.fail_xr) { h->tune.fail_xr = 0; rc = 0; }     // test hook: this member's launch never arrives
-                else rc = msdp_launch_tcg_xpersist(h, h->nranks, h->rank, h->lgroup->xr_slots, h->lgroup->xr_err, h->lgroup->xr_mdx);
+                rc = xr_launch(h);
                 restore_status_ptr(h);
             }
             else if (h->use_comm) rc = run_tcg_lockstep(h, opts->maxinner);
@@ -2480,7 +2524,9 @@ extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms) 
         // member; run twice, time the second) -- every member calls this function together
         int agreed = 0;
         if ((rc = local_vote_min(h, msdp_xpersist_eligible(h, h->nranks), &agreed))) return rc;
-        if (agreed) {
+        bool xuse = false;
+        if (agreed && (rc = xr_begin(h, &xuse))) return rc;
+        if (xuse) {
             h->h_ctl->maxinner = reps;
             if ((rc = push_ctl(h))) return rc;
             if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
@@ -2488,9 +2534,9 @@ extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms) 
             h->d.status = nullptr;
             float ms = 0.f;
             for (int pass = 0; pass < 2 && !rc; ++pass) {
-                if ((rc = xr_begin(h))) break;
+                if (pass && (rc = xr_begin(h, &xuse))) break;
                 HIPCHK(hipEventRecord(h->ev0, h->stream));
-                rc = msdp_launch_tcg_xpersist(h, h->nranks, h->rank, h->lgroup->xr_slots, h->lgroup->xr_err, h->lgroup->xr_mdx);
+                rc = xr_launch(h);
                 HIPCHK(hipEventRecord(h->ev1, h->stream));
                 HIPCHK(hipEventSynchronize(h->ev1));
                 HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));

@@ -155,6 +155,7 @@ struct Tuning {
                            //   (msdp_densesym.hip); 1 = from dense_sym_min rows on, 2 = always, 0 = never
     int dense_sym_min = 8192;   // see dense_sym (below, the partial slabs of the transposed products cost what the halved matrix saves: measured)
     int dense_sym_rt = 0;       // A/B: 16-row tiles per wave of k_dense_sym (0: by n; 1 or 2)
+    int dense_sym_db = 0;       // A/B: double-buffered reduction, one barrier per step (0: by shape, 1: never, 2: always)
     int dense_sym_len = 0;      // A/B: slice length of a work item in 16-column steps (0: planned)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
     int xpersist = 1;        // in-process ranks (msdp_comm_init_local), sparse C, oblique: ONE persistent tCG spanning the ranks' launches -- grid
@@ -251,6 +252,7 @@ struct msdp_handle_s {
     double* esc_top = nullptr;        // top eigenvector of the previous escape call (warm start of the lambda_max run), esc_top_n entries
     int esc_top_n = 0;
     long long coll_calls = 0;         // collective calls issued so far (exchange, all-reduce, all-gather; a grouped call counts once)
+    hipEvent_t xr_ev = nullptr;       // marks this member's stream in front of the combined cross-rank launch
     bool xpersist_last = false;       // the last trustregions() call ran the cross-rank persistent tCG (msdp_tcg_path reports 2)
     bool trip1_capture = false;       // enqueue_trips runs inside a graph capture (no count-dependent launches)
     int trip1_count = 0;              // msdp_trip1.hip: trips enqueued since the tCG began (refresh schedule)

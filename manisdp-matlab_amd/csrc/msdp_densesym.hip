@@ -50,13 +50,15 @@ template <int NT> struct SymCfg {
     static constexpr int RSLOT = (16 * RS > 16 * SYM_TS) ? 16 * RS : 16 * SYM_TS;   // the transposition tile lives in the same slot
 };
 static int sym_ldl(int NT) { int ldl = 16 * NT; while ((ldl & 7) != 4) ldl += 2; return ldl; }
-static size_t sym_lds_bytes(int NT, int waves) {
+static size_t sym_lds_bytes(int NT, int waves, bool db) {
     const int RS = 16 * NT + 4;
     const int rslot = std::max(16 * RS, 16 * SYM_TS);
-    return ((size_t)2 * SYM_KT * sym_ldl(NT) + (size_t)waves * rslot + 128) * sizeof(double);
+    return ((size_t)2 * SYM_KT * sym_ldl(NT) + (size_t)(db ? 2 : 1) * waves * rslot + 128) * sizeof(double);
 }
 
-template <int NT, int RT, int SYM_WAVES>
+// DB: the reduction buffer is double-buffered and a step needs ONE workgroup barrier instead of two (the reduction of step s runs
+// beside the products of step s + 1 of the faster waves) -- for the shapes that leave one workgroup per CU anyway
+template <int NT, int RT, int SYM_WAVES, bool DB>
 __global__ __launch_bounds__(SYM_WAVES * 64, (SYM_WAVES == 16 ? 4 : (NT * RT >= 4 ? 3 : 4))) void k_dense_sym(SymOp op, const int* active_flag) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (active_flag && !*active_flag) return;
@@ -72,9 +74,8 @@ __global__ __launch_bounds__(SYM_WAVES * 64, (SYM_WAVES == 16 ? 4 : (NT * RT >= 
     const int rbase = it.rb * op.RB + wave * (16 * RT);
     const int kdiag_end = (it.rb + 1) * op.RB;                // columns before this: the block on the diagonal, direct only
     double* stage = lds;                                      // 2 x KT x ldl panel tiles
-    double* red = lds + 2 * KT * ldl;                         // SYM_WAVES x RSLOT
-    double* myred = red + wave * RSLOT;
-    double* dummy = red + SYM_WAVES * RSLOT;                  // 128 doubles: store target of the threads that stage nothing
+    double* red = lds + 2 * KT * ldl;                         // (DB ? 2 : 1) x SYM_WAVES x RSLOT
+    double* dummy = red + (DB ? 2 : 1) * SYM_WAVES * RSLOT;   // 128 doubles: store target of the threads that stage nothing
     for (int e = threadIdx.x; e < 2 * KT * ldl; e += NTHR) stage[e] = 0.0;
 
     // X[I] as the B operand of the transposed product: lane (g, i) holds X[I0 + 4g + t][16 nt + i]
@@ -119,10 +120,13 @@ __global__ __launch_bounds__(SYM_WAVES * 64, (SYM_WAVES == 16 ? 4 : (NT * RT >= 
     };
     double* tslab = op.slab + (int64_t)(op.tslab0[it.m ? 1 : 0] + it.rb) * op.stride;
 
-    auto step = [&](const double* bt, double* stg_dst, int k0, const double2 (&F)[RT][2], const double2 stg_next) {
+    // products of one step: direct into accD, transposed into this wave's slot of `redb` (which also serves as the
+    // wave-private tile the fragment is turned through); the staged panel tile of the NEXT step is stored at the end
+    auto compute = [&](const double* bt, double* stg_dst, int k0, const double2 (&F)[RT][2], const double2 stg_next, double* redb) -> bool {
         const bool valid = k0 < it.k1;
         const double s = valid ? sc : 0.0;
         const bool tr = valid && k0 >= kdiag_end;             // workgroup-uniform
+        double* myred = redb + wave * RSLOT;
         sym_d4 accT[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) accT[nt] = (sym_d4){0.0, 0.0, 0.0, 0.0};
@@ -161,31 +165,38 @@ __global__ __launch_bounds__(SYM_WAVES * 64, (SYM_WAVES == 16 ? 4 : (NT * RT >= 
                 for (int r = 0; r < 4; ++r) myred[(g + 4 * r) * RS + 16 * nt + i] = accT[nt][r];
         }
         *reinterpret_cast<double2*>(stg_dst) = stg_next;       // the tile of step k0 + KT; its buffer was last read in step k0 - KT
-        __syncthreads();
-        if (tr) {
-            for (int e = threadIdx.x; e < 16 * NC; e += NTHR) {
-                const int j = e / NC, c = e - j * NC;
-                double v = 0.0;
+        return tr;
+    };
+    // the 8 (16) waves' contributions to out[k0 .. k0+15], added in wave order, written once
+    auto reduce = [&](int k0, const double* redb) {
+        for (int e = threadIdx.x; e < 16 * NC; e += NTHR) {
+            const int j = e / NC, c = e - j * NC;
+            double v = 0.0;
 #pragma unroll
-                for (int w = 0; w < SYM_WAVES; ++w) v += red[w * RSLOT + j * RS + c];
-                if (k0 + j < n && c < ld) tslab[(int64_t)(k0 + j) * ld + c] = v;
-            }
+            for (int w = 0; w < SYM_WAVES; ++w) v += redb[w * RSLOT + j * RS + c];
+            if (k0 + j < n && c < ld) tslab[(int64_t)(k0 + j) * ld + c] = v;
         }
     };
 
     double2 F0[RT][2], F1[RT][2];
+    double* red1 = DB ? red + SYM_WAVES * RSLOT : red;
     __syncthreads();                                          // zero fill done
     load_F(it.k0, F0);
     { const double2 v = load_stg(it.k0); *reinterpret_cast<double2*>(stg_dst0) = v; }
+    if (DB) __syncthreads();                                  // first tile staged
     for (int k0 = it.k0; k0 < it.k1; k0 += 2 * KT) {
-        __syncthreads();                                      // tile k0 staged; the reduction of the previous step has read `red`
+        if (!DB) __syncthreads();                             // tile k0 staged; the reduction of the previous step has read `red`
         double2 sn = load_stg(k0 + KT);
         load_F(k0 + KT, F1);
-        step(stage, stg_dst1, k0, F0, sn);
+        bool tr = compute(stage, stg_dst1, k0, F0, sn, red);
         __syncthreads();
+        if (tr) reduce(k0, red);
+        if (!DB) __syncthreads();
         sn = load_stg(k0 + 2 * KT);
         load_F(k0 + 2 * KT, F0);
-        step(stage + KT * ldl, stg_dst0, k0 + KT, F1, sn);
+        tr = compute(stage + KT * ldl, stg_dst0, k0 + KT, F1, sn, red1);
+        __syncthreads();
+        if (tr) reduce(k0 + KT, red1);
     }
     double* dsl = op.slab + (int64_t)(op.dslab0 + it.dslot) * op.stride;
 #pragma unroll
@@ -244,10 +255,15 @@ struct SymPlan {
 struct SymPlans { SymPlan p[2][2]; };      // [NT - 1][nmat - 1]
 
 typedef void (*sym_fn_t)(SymOp, const int*);
-static sym_fn_t sym_fn(int NT, int RT, int WV) {
-    if (WV == 16) return NT == 1 ? k_dense_sym<1, 1, 16> : k_dense_sym<2, 1, 16>;
-    if (NT == 1) return RT == 2 ? k_dense_sym<1, 2, 8> : k_dense_sym<1, 1, 8>;
-    return RT == 2 ? k_dense_sym<2, 2, 8> : k_dense_sym<2, 1, 8>;
+static sym_fn_t sym_fn(int NT, int RT, int WV, bool db) {
+    if (db) {
+        if (WV == 16) return NT == 1 ? k_dense_sym<1, 1, 16, true> : k_dense_sym<2, 1, 16, true>;
+        if (NT == 1) return RT == 2 ? k_dense_sym<1, 2, 8, true> : k_dense_sym<1, 1, 8, true>;
+        return RT == 2 ? k_dense_sym<2, 2, 8, true> : k_dense_sym<2, 1, 8, true>;
+    }
+    if (WV == 16) return NT == 1 ? k_dense_sym<1, 1, 16, false> : k_dense_sym<2, 1, 16, false>;
+    if (NT == 1) return RT == 2 ? k_dense_sym<1, 2, 8, false> : k_dense_sym<1, 1, 8, false>;
+    return RT == 2 ? k_dense_sym<2, 2, 8, false> : k_dense_sym<2, 1, 8, false>;
 }
 // shape of a workgroup: dense_sym_rt = 1: 8 waves x 16 rows (RB = 128); 2: 8 waves x 32 rows (RB = 256); 3: 16 waves x 16 rows (RB = 256)
 static void sym_shape(msdp_handle h, int NT, int* RT, int* WV) {
@@ -394,7 +410,12 @@ int msdp_densesym_gemm(msdp_handle h, hipStream_t stream, int nmat, const double
     op.tslab0[0] = P->tslab0[0]; op.tslab0[1] = P->tslab0[1]; op.dslab0 = P->dslab0;
     op.slab = h->slab; op.stride = stride;
     op.items = P->d_items;
-    hipLaunchKernelGGL(sym_fn(P->NT, P->RT, P->WV), dim3(P->nitems), dim3(P->WV * 64), sym_lds_bytes(P->NT, P->WV), stream, op, active_flag);
+    // one barrier per step (double-buffered reduction) where the shape leaves one workgroup per CU anyway; dense_sym_db: 1 never, 2 always
+    const bool db = h->tune.dense_sym_db == 2 || (h->tune.dense_sym_db == 0 && (P->WV == 16 || P->NT * P->RT >= 4 || P->NT == 1));
+    sym_fn_t fn = sym_fn(P->NT, P->RT, P->WV, db);
+    const size_t ldsb = sym_lds_bytes(P->NT, P->WV, db);
+    if (ldsb > 65536) HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    hipLaunchKernelGGL(fn, dim3(P->nitems), dim3(P->WV * 64), ldsb, stream, op, active_flag);
     HIPCHK(hipGetLastError());
     SymFold f;
     memset(&f, 0, sizeof(f));

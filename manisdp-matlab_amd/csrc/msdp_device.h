@@ -31,8 +31,8 @@ __device__ __forceinline__ void msdp_sweep_rows(int n_loc, int G, int BR, int& l
 // dispatch, observed; a pure speed heuristic), so XCD x gets the contiguous
 // chunk range [x*G/8, (x+1)*G/8): its L2 then serves one contiguous 1/8 of the
 // rows of every vector.  G is a multiple of 8.
-__device__ __forceinline__ void msdp_chunk_rows(int n_loc, int G, int& lo, int& hi, int plain = 0) {
-    const int b = blockIdx.x;
+__device__ __forceinline__ void msdp_chunk_rows(int n_loc, int G, int& lo, int& hi, int plain = 0, int bx = -1) {
+    const int b = bx < 0 ? (int)blockIdx.x : bx;            // bx: the workgroup's index inside ITS rank's share of a combined launch
     const int c = plain ? b : (b & 7) * (G >> 3) + (b >> 3);
     // balanced split with one 32-bit division (a 64-bit n_loc*c/G costs ~350 instructions of preamble in
     // every launch): the first n_loc % G chunks get one extra row

@@ -47,17 +47,17 @@ __global__ void k_psync_reset(unsigned long long* slots, int* err) {
 #define MSDP_TRACE_J0 16
 #define MSDP_TRACE_NJ 32
 #define TSTAMP(ph) do { if (TRACE && threadIdx.x == 0 && j >= MSDP_TRACE_J0 && j < MSDP_TRACE_J0 + MSDP_TRACE_NJ) \
-        d.trace[((size_t)blockIdx.x * MSDP_TRACE_NJ + (j - MSDP_TRACE_J0)) * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
+        d.trace[((size_t)bx * MSDP_TRACE_NJ + (j - MSDP_TRACE_J0)) * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
 // XR (cross-rank, round 4): the launches of N ranks -- N x d.G workgroups, all co-resident -- run ONE tCG together: the grid
 // reductions span the ranks (shared slot regions, workgroup index d.xr_gid0 + blockIdx.x of d.xr_gtot), the residual / direction rows
 // travel through one exchange buffer of all n rows (d.xr_mdx, global row indices), and no collective is issued per trip.  Same
 // arithmetic per row as the one-rank kernel; the sums are formed over d.xr_gtot partials in index order on every rank (same bits on
 // every rank -> same decisions).  Two slot regions alternate with the TR iteration; each launch clears the other one at its start.
-template <int LPR, int EW, int R, bool FUSE, bool TRACE = false, bool XR = false>
-__global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long long* slots, int* err) {
+template <int LPR, int EW, int R, bool FUSE, bool TRACE, bool XR>
+__device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long long* slots, int* err, const int bx) {
     extern __shared__ double lds[];
     __shared__ double sh[3 * PWAVES];
-    __shared__ double shb[4];
+    __shared__ double shb[8];
     constexpr int RPW = 64 / LPR;
     constexpr int RSTEP = PWAVES * RPW;       // rows per pass of the workgroup
     constexpr int ROWS = R * RSTEP;               // row slots of the workgroup
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     double* EGPs = reinterpret_cast<double*>(GPs + R * PB);        // [ROWS]
 
     const Ctl* c = d.ctl;
-    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    const bool lead = bx == 0 && threadIdx.x == 0;
     const int k_tr = c->k;
     if (c->done) {                                                 // same as k_tcg_init on a finished solve
         if (lead) {
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         return;
     }
     if (lead && !FUSE) msdp_publish(d, k_tr, 0, 1);                // "TR iteration k_tr has started" (host pipelining)
-    const int bid = XR ? d.xr_gid0 + (int)blockIdx.x : (int)blockIdx.x;
+    const int bid = XR ? d.xr_gid0 + bx : bx;
     const int GS = XR ? d.xr_gtot : d.G;                           // workgroups that synchronise
     if (XR) {
         unsigned long long* other = slots + (size_t)((k_tr & 1) ^ 1) * PSYNC_REGION;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // performed before this workgroup's first post of this launch
     } else if (!FUSE) psync_reset_other(slots + PSYNC_REGION);     // region B belongs to the TR-iteration tail kernel
     int lo, hi;
-    msdp_chunk_rows(d.n_loc, d.G, lo, hi);
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi, 0, bx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
     const bool colok = 2 * sub < d.ld;
@@ -493,6 +493,32 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long lon
     }
 }
 
+template <int LPR, int EW, int R, bool FUSE, bool TRACE = false, bool XR = false>
+__global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long long* slots, int* err) {
+    tcg_persist_body<LPR, EW, R, FUSE, TRACE, XR>(d, slots, err, (int)blockIdx.x);
+}
+// In-process ranks: ONE launch carries the workgroups of all members (member q owns the blocks [q*G, (q+1)*G)), so that their
+// co-residency does not depend on how the runtime maps the members' streams onto hardware queues (two launches on one queue
+// would wait for each other for ever).  Same body, same protocol as separate launches on separate devices would run.
+struct XrDevs2 { Dev d[2]; };
+struct XrDevs4 { Dev d[4]; };
+template <int LPR, int EW, int R>
+__global__ __launch_bounds__(PB) void k_tcg_persist_xr2(XrDevs2 ds, unsigned long long* slots, int* err) {
+    const int G = ds.d[0].G;
+    if ((int)blockIdx.x < G) tcg_persist_body<LPR, EW, R, false, false, true>(ds.d[0], slots, err, (int)blockIdx.x);
+    else tcg_persist_body<LPR, EW, R, false, false, true>(ds.d[1], slots, err, (int)blockIdx.x - G);
+}
+template <int LPR, int EW, int R>
+__global__ __launch_bounds__(PB) void k_tcg_persist_xr4(XrDevs4 ds, unsigned long long* slots, int* err) {
+    const int G = ds.d[0].G, q = (int)blockIdx.x / G, bx = (int)blockIdx.x - q * G;
+    switch (q) {
+        case 0: tcg_persist_body<LPR, EW, R, false, false, true>(ds.d[0], slots, err, bx); break;
+        case 1: tcg_persist_body<LPR, EW, R, false, false, true>(ds.d[1], slots, err, bx); break;
+        case 2: tcg_persist_body<LPR, EW, R, false, false, true>(ds.d[2], slots, err, bx); break;
+        default: tcg_persist_body<LPR, EW, R, false, false, true>(ds.d[3], slots, err, bx); break;
+    }
+}
+
 #undef VOFF
 #undef Y_GET
 #undef G_GET
@@ -713,11 +739,27 @@ int msdp_launch_rtr_fused(msdp_handle h) {
 
 
 // ------------------------------------------------------------------ cross-rank persistent tCG (XR)
-// N in-process ranks (msdp_comm_init_local) run k_tcg_persist_obl<..., XR> side by side: N x G workgroups, G = (256 / N) rounded
-// down to a multiple of 8, all co-resident (one per CU).  The plan follows the LARGEST row count of a rank (cap), so every
-// rank picks the same synchronisation scheme; the ELL width may differ between ranks (a different instance, same protocol).
-static persist_fn xr_kernel(const PersistPlan& pl) {
-#define XK(L, E, RR) if (pl.lpr == L && pl.ew == E && pl.r == RR) return k_tcg_persist_obl<L, E, RR, false, false, true>;
+// N in-process ranks (msdp_comm_init_local) run the persistent tCG TOGETHER: N x G workgroups, G = (256 / N) rounded down to a
+// multiple of 8, all co-resident (one per CU), in ONE launch that member 0 issues for everybody (k_tcg_persist_xr2 / _xr4: member q
+// owns the blocks [q*G, (q+1)*G) and its own Dev) -- separate launches of one process share a handful of hardware queues and may
+// end up behind each other.  The plan follows the LARGEST row count of a rank (cap), so every member has the same row slots and
+// the same synchronisation scheme; the ELL width is the members' common one, or the CSR form.
+typedef void (*xr2_fn)(XrDevs2, unsigned long long*, int*);
+typedef void (*xr4_fn)(XrDevs4, unsigned long long*, int*);
+static bool xr_instance(int lpr, int ew, int r) {
+#define XK(L, E, RR) if (lpr == L && ew == E && r == RR) return true;
+    XK(8, 5, 2) XK(8, 0, 2) XK(8, 5, 4) XK(8, 0, 4) XK(16, 5, 3) XK(16, 0, 3) XK(16, 5, 5) XK(16, 0, 5) XK(32, 5, 5) XK(32, 0, 5)
+#undef XK
+    return false;
+}
+static xr2_fn xr2_kernel(int lpr, int ew, int r) {
+#define XK(L, E, RR) if (lpr == L && ew == E && r == RR) return k_tcg_persist_xr2<L, E, RR>;
+    XK(8, 5, 2) XK(8, 0, 2) XK(8, 5, 4) XK(8, 0, 4) XK(16, 5, 3) XK(16, 0, 3) XK(16, 5, 5) XK(16, 0, 5) XK(32, 5, 5) XK(32, 0, 5)
+#undef XK
+    return nullptr;
+}
+static xr4_fn xr4_kernel(int lpr, int ew, int r) {
+#define XK(L, E, RR) if (lpr == L && ew == E && r == RR) return k_tcg_persist_xr4<L, E, RR>;
     XK(8, 5, 2) XK(8, 0, 2) XK(8, 5, 4) XK(8, 0, 4) XK(16, 5, 3) XK(16, 0, 3) XK(16, 5, 5) XK(16, 0, 5) XK(32, 5, 5) XK(32, 0, 5)
 #undef XK
     return nullptr;
@@ -726,33 +768,26 @@ static bool xr_plan(msdp_handle h, int nranks, PersistPlan& pl, int* G_out) {
     const Dev& d = h->d;
     if (!h->tune.persist || !h->tune.xpersist || h->persist_failed || d.costkind != COST_SPARSE || d.manifold != MANI_OBLIQUE || d.rowfree) return false;
     int G = (256 / nranks) & ~7;
-    // more than four members cannot run side by side: the launches of in-process ranks sit on streams of one process, which the
-    // runtime maps onto at most four hardware queues (GPU_MAX_HW_QUEUES) -- a fifth launch waits for a queue and the others for it
     if (G < 8 || nranks < 2 || nranks > 4) return false;
     Dev dc = d;
     dc.n_loc = (d.n + nranks - 1) / nranks;                // the plan of the rank with the most rows
     if (!persist_plan(dc, G, pl)) return false;
     if (pl.r > 5) return false;                            // LOWREG instances are not built for XR
-    if (pl.ew > 0 && d.ellW != pl.ew) pl.ew = 0;           // this rank's rows are longer than the ELL width of the plan: CSR instance
-    if (pl.ew == 8) pl.ew = 0;
-    if (!xr_kernel(pl)) return false;
-    const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr);
-    pl.lds = (size_t)2 * pl.r * PB * sizeof(double2) + rows * sizeof(double) + (size_t)pl.ew * rows * (sizeof(double) + sizeof(int));
+    if (pl.ew == 8) pl.ew = 0;                             // rows of 6..8 entries: the CSR form
+    if (!xr_instance(pl.lpr, pl.ew, pl.r)) return false;
     *G_out = G;
     return true;
+}
+static size_t xr_lds(int lpr, int ew, int r) {
+    const size_t rows = (size_t)r * PWAVES * (64 / lpr);
+    return (size_t)2 * r * PB * sizeof(double2) + rows * sizeof(double) + (size_t)ew * rows * (sizeof(double) + sizeof(int));
 }
 int msdp_xpersist_eligible(msdp_handle h, int nranks) {
     PersistPlan pl; int G = 0;
     if (!xr_plan(h, nranks, pl, &G)) return 0;
-    persist_fn fn = xr_kernel(pl);
-    int dev = 0, cus = 0, per_cu = 0, ok = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-        hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) == hipSuccess &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, PB, pl.lds) == hipSuccess)
-        ok = (per_cu >= 1 && cus >= G * nranks) ? 1 : 0;
-    (void)hipGetLastError();
-    return ok;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return cus >= G * nranks ? 1 : 0;
 }
 // Bytes of the shared synchronisation block: two slot regions (they alternate with the TR iteration)
 size_t msdp_xpersist_slot_bytes() { return 2 * PSYNC_REGION * sizeof(unsigned long long); }
@@ -761,15 +796,39 @@ int msdp_xpersist_reset(hipStream_t stream, unsigned long long* slots, int* err)
     HIPCHK(hipGetLastError());
     return 0;
 }
-int msdp_launch_tcg_xpersist(msdp_handle h, int nranks, int rank, unsigned long long* slots, int* err, double* mdx) {
+// This member's Dev for the combined launch and its plan {lanes per row, ELL width (0: CSR), row slots}
+int msdp_xpersist_member(msdp_handle h, int nranks, int rank, double* mdx, Dev* out, int* plan3) {
     PersistPlan pl; int G = 0;
     if (!xr_plan(h, nranks, pl, &G)) { msdp_set_error("cross-rank persistent tCG: not eligible"); return MSDP_ESTATE; }
-    persist_fn fn = xr_kernel(pl);
-    Dev dp = h->d;
-    dp.G = G;
-    dp.xr_gid0 = rank * G; dp.xr_gtot = nranks * G; dp.xr_mdx = mdx;
-    HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
-    hipLaunchKernelGGL(fn, dim3(G), dim3(PB), pl.lds, h->stream, dp, slots, err);
+    *out = h->d;
+    out->G = G; out->xr_gid0 = rank * G; out->xr_gtot = nranks * G; out->xr_mdx = mdx; out->status = nullptr; out->trace = nullptr;
+    plan3[0] = pl.lpr; plan3[1] = pl.ew; plan3[2] = pl.r;
+    return 0;
+}
+// Member 0: one launch for all members.  devs[q] / plans[3q..] as filled by msdp_xpersist_member on every member.
+int msdp_launch_tcg_xpersist_all(hipStream_t stream, int nranks, const Dev* devs, const int* plans, unsigned long long* slots, int* err) {
+    const int lpr = plans[0], r = plans[2];
+    int ew = plans[1];
+    for (int q = 1; q < nranks; ++q) {
+        if (plans[3 * q] != lpr || plans[3 * q + 2] != r) { msdp_set_error("cross-rank persistent tCG: the members' plans differ"); return MSDP_ESTATE; }
+        if (plans[3 * q + 1] != ew) ew = 0;                // different ELL widths: everybody walks its CSR rows
+    }
+    const int G = devs[0].G;
+    const size_t lds = xr_lds(lpr, ew, r);
+    if (nranks == 2) {
+        xr2_fn fn = xr2_kernel(lpr, ew, r);
+        if (!fn) { msdp_set_error("cross-rank persistent tCG: no kernel instance"); return MSDP_ESTATE; }
+        XrDevs2 ds; ds.d[0] = devs[0]; ds.d[1] = devs[1];
+        HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fn, dim3(2 * G), dim3(PB), lds, stream, ds, slots, err);
+    } else {
+        xr4_fn fn = xr4_kernel(lpr, ew, r);
+        if (!fn) { msdp_set_error("cross-rank persistent tCG: no kernel instance"); return MSDP_ESTATE; }
+        XrDevs4 ds;
+        for (int q = 0; q < 4; ++q) ds.d[q] = devs[q < nranks ? q : nranks - 1];
+        HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fn, dim3(nranks * G), dim3(PB), lds, stream, ds, slots, err);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

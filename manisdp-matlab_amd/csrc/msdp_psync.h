@@ -43,6 +43,9 @@ __device__ __forceinline__ void st2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte
 // spin bound was hit (error flag set; the caller leaves the kernel).
 // bid: this workgroup's index among the G that synchronise -- blockIdx.x, or rank * (workgroups per rank) + blockIdx.x when the
 // launches of several ranks share one slot region (cross-rank persistent tCG, msdp_persist.hip XR)
+// Round 4: with three values, three WAVES poll side by side, one value array each (wave 0 posts all of them): the s_memtime
+// trace of the trip (profiles/r4_persist_timeline_p32.md) showed the three-value reduction at 2.75 us against 1.94 us for the
+// one-value one -- a poll of twelve loads per lane by one wave against four.  shb needs 8 doubles.
 __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, int G, int nv, double& a, double& b,
                                       double& c, double* sh, double* shb, int* err, int bid_in = -1) {
     const int bid = bid_in < 0 ? (int)blockIdx.x : bid_in;
@@ -51,9 +54,9 @@ __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, i
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) { sh[w] = a; sh[PWAVES + w] = b; sh[2 * PWAVES + w] = c; }
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (w < nv) {                                                   // polling wave w takes value array w
         unsigned long long* gbase = slots + (size_t)(gen % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID;
-        if (lane < PSYNC_REP * PSYNC_NV) {
+        if (w == 0 && lane < PSYNC_REP * PSYNC_NV) {
             const int rep = lane / PSYNC_NV, vi = lane % PSYNC_NV;
             if (vi < nv) {
                 double s = 0.0;
@@ -64,74 +67,46 @@ __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, i
                                    (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        unsigned long long* base = gbase + (size_t)(bid & (PSYNC_REP - 1)) * PSYNC_NV * MSDP_MAX_GRID;
-        double r0, r1 = 0.0, r2 = 0.0;
+        const unsigned long long* p0 = gbase + ((size_t)(bid & (PSYNC_REP - 1)) * PSYNC_NV + w) * MSDP_MAX_GRID + lane;
+        double r0;
         int spins = 0;
         bool fail = false;
-        const unsigned long long* p0 = base + lane;
         for (;;) {
             // all slot loads of one poll are issued back to back with ONE wait (the compiler puts a full
-            // s_waitcnt after every atomic load: 12 serialized round trips per poll, measured 20 us per sync)
-            unsigned long long b0[4], b1[4], b2[4];
-            if (nv > 1) {
-                const unsigned long long* p1 = p0 + MSDP_MAX_GRID;
-                const unsigned long long* p2 = p0 + 2 * MSDP_MAX_GRID;
-                asm volatile(
-                    "global_load_dwordx2 %0, %12, off sc1\n\t"
-                    "global_load_dwordx2 %1, %12, off offset:512 sc1\n\t"
-                    "global_load_dwordx2 %2, %12, off offset:1024 sc1\n\t"
-                    "global_load_dwordx2 %3, %12, off offset:1536 sc1\n\t"
-                    "global_load_dwordx2 %4, %13, off sc1\n\t"
-                    "global_load_dwordx2 %5, %13, off offset:512 sc1\n\t"
-                    "global_load_dwordx2 %6, %13, off offset:1024 sc1\n\t"
-                    "global_load_dwordx2 %7, %13, off offset:1536 sc1\n\t"
-                    "global_load_dwordx2 %8, %14, off sc1\n\t"
-                    "global_load_dwordx2 %9, %14, off offset:512 sc1\n\t"
-                    "global_load_dwordx2 %10, %14, off offset:1024 sc1\n\t"
-                    "global_load_dwordx2 %11, %14, off offset:1536 sc1\n\t"
-                    "s_waitcnt vmcnt(0)"
-                    : "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3]), "=&v"(b1[0]), "=&v"(b1[1]), "=&v"(b1[2]),
-                      "=&v"(b1[3]), "=&v"(b2[0]), "=&v"(b2[1]), "=&v"(b2[2]), "=&v"(b2[3])
-                    : "v"(p0), "v"(p1), "v"(p2)
-                    : "memory");
-            } else {
-                asm volatile(
-                    "global_load_dwordx2 %0, %4, off sc1\n\t"
-                    "global_load_dwordx2 %1, %4, off offset:512 sc1\n\t"
-                    "global_load_dwordx2 %2, %4, off offset:1024 sc1\n\t"
-                    "global_load_dwordx2 %3, %4, off offset:1536 sc1\n\t"
-                    "s_waitcnt vmcnt(0)"
-                    : "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3])
-                    : "v"(p0)
-                    : "memory");
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { b1[q] = 0ULL; b2[q] = 0ULL; }
-            }
+            // s_waitcnt after every atomic load: serialized round trips, measured 20 us per sync)
+            unsigned long long b0[4];
+            asm volatile(
+                "global_load_dwordx2 %0, %4, off sc1\n\t"
+                "global_load_dwordx2 %1, %4, off offset:512 sc1\n\t"
+                "global_load_dwordx2 %2, %4, off offset:1024 sc1\n\t"
+                "global_load_dwordx2 %3, %4, off offset:1536 sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3])
+                : "v"(p0)
+                : "memory");
             bool ok = true;
-            double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+            double t0 = 0.0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (lane + 64 * q < G) {                                   // slots >= G hold the sentinel for ever
-                    ok = ok && b0[q] != PSYNC_SENT && b1[q] != PSYNC_SENT && b2[q] != PSYNC_SENT;
+                    ok = ok && b0[q] != PSYNC_SENT;
                     t0 += __longlong_as_double((long long)b0[q]);         // same order as msdp_sum_partials
-                    t1 += __longlong_as_double((long long)b1[q]);
-                    t2 += __longlong_as_double((long long)b2[q]);
                 }
             }
-            r0 = t0; r1 = t1; r2 = t2;
+            r0 = t0;
             if (__builtin_amdgcn_ballot_w64(!ok) == 0ULL) break;
             ++spins;
             if (spins > PSYNC_SPIN_LIMIT ||
                 ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
         }
         r0 = msdp_wave_sum(r0);
-        if (nv > 1) { r1 = msdp_wave_sum(r1); r2 = msdp_wave_sum(r2); }
         if (lane == 0) {
-            shb[0] = r0; shb[1] = r1; shb[2] = r2; shb[3] = fail ? 1.0 : 0.0;
+            shb[w] = r0; shb[4 + w] = fail ? 1.0 : 0.0;
+            if (nv == 1) { shb[1] = 0.0; shb[2] = 0.0; shb[5] = 0.0; shb[6] = 0.0; }
             if (fail) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // everybody has finished reading the previous generation (they all posted this one): reset my slots of it
-        if (lane < PSYNC_REP * PSYNC_NV)
+        if (w == 0 && lane < PSYNC_REP * PSYNC_NV)
             __hip_atomic_store(slots + (size_t)((gen + PSYNC_GEN - 1) % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID +
                                    (size_t)lane * MSDP_MAX_GRID + bid,
                                PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -139,7 +114,7 @@ __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, i
     __syncthreads();
     // wave-uniform results: readlane moves them to scalar registers (they live across the whole solve)
     a = msdp_readlane(shb[0], 0); b = msdp_readlane(shb[1], 0); c = msdp_readlane(shb[2], 0);
-    return msdp_readlane(shb[3], 0) == 0.0;
+    return msdp_readlane(shb[4], 0) + msdp_readlane(shb[5], 0) + msdp_readlane(shb[6], 0) == 0.0;
 }
 
 // Barrier without a value (the new direction rows are in place): workgroup b adds to counter b & 7, everybody

@@ -16,7 +16,7 @@ template <int LPR>
 __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* slots, int* err, int rcap) {
     extern __shared__ double lds[];
     __shared__ double sh[3 * PWAVES];
-    __shared__ double shb[4];
+    __shared__ double shb[8];
     constexpr int RPW = 64 / LPR;
     constexpr int RSTEP = PWAVES * RPW;
     double2* YPs = reinterpret_cast<double2*>(lds);            // [rcap][PB] proposal rows of this workgroup

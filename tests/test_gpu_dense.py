@@ -161,12 +161,17 @@ def test_symmetric_contraction_short_slices(lib):
     prob = R._OnlyUnitDiagProblem(C, n, p)
     prob.cost(Y)                                              # the closures share eG (ManiSDP_onlyunitdiag.m:118-119)
     for shape in (1, 2, 3):
-        h = lib.Handle.onlyunitdiag(C)
-        h.set_option("dense_sym", 2); h.set_option("dense_sym_rt", shape); h.set_option("dense_sym_len", 2)
-        h.set_point(Y)
-        assert _relerr(h.hessvec(U), prob.hess(Y, U)) < 1e-12
-        assert _relerr(h.rgrad(), prob.grad(Y)) < 1e-12
-        h.close()
+        for db in (1, 2):                                      # two barriers per step / one (double-buffered reduction)
+            for length in (2, 0):
+                h = lib.Handle.onlyunitdiag(C)
+                h.set_option("dense_sym", 2); h.set_option("dense_sym_rt", shape); h.set_option("dense_sym_len", length)
+                h.set_option("dense_sym_db", db)
+                h.set_point(Y)
+                H = h.hessvec(U)
+                assert _relerr(H, prob.hess(Y, U)) < 1e-12
+                assert _relerr(h.rgrad(), prob.grad(Y)) < 1e-12
+                assert np.array_equal(H, h.hessvec(U))
+                h.close()
 
 
 def test_asymmetric_dense_cost_keeps_the_full_kernel(lib):

@@ -553,10 +553,10 @@ def test_cross_rank_persistent_tcg(N, shape, p):
     assert max(q["trip_us"] for q in res) < 40.0
 
 
-def test_cross_rank_persistent_tcg_reports_a_missing_member():
-    """A member whose launch never arrives must not hang the others: the bounded spins of the grid synchronisation turn it into an
-    error word, the member that reads it breaks the group, and every member's trustregions() call returns MSDP_ECOMM.  Member 1
-    skips its first cross-rank launch (test hook debug_xr_skip)."""
+def test_cross_rank_persistent_tcg_times_out_instead_of_hanging():
+    """Workgroups that never arrive must not hang the launch: the bounded spins of the grid synchronisation turn the wait into an
+    error word, the member that reads it breaks the group, and every member's trustregions() call returns MSDP_ECOMM.  Test hook
+    debug_xr_skip on member 0: the next combined launch waits for eight workgroups more than it has."""
     from manisdp_matlab_amd import _lib, problems
     _lib.load()
     C = problems.toroidal_grid_maxcut(50, 60, seed=2)
@@ -568,7 +568,7 @@ def test_cross_rank_persistent_tcg_reports_a_missing_member():
         h = _lib.Handle.onlyunitdiag(C, pcap=p)
         h.comm_init_local(2, r, group)
         h.set_point(Y0)
-        if r == 1:
+        if r == 0:
             h.set_option("debug_xr_skip", 1)
         try:
             h.rtr(_lib.default_opts(maxiter=3, maxinner=10, tolgradnorm=1e-9))

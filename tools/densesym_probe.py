@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from manisdp_matlab_amd import _lib
 n = int(sys.argv[1])
-modes = [("full", 0, 0, 0), ("sym rt1 (8x16)", 2, 1, 0), ("sym rt2 (8x32)", 2, 2, 0), ("sym rt3 (16x16)", 2, 3, 0)]
+modes = [("full", 0, 0, 0, 0), ("sym 8x16", 2, 1, 0, 1), ("sym 8x16 db", 2, 1, 0, 2), ("sym 8x32", 2, 2, 0, 1), ("sym 8x32 db", 2, 2, 0, 2),
+         ("sym 16x16", 2, 3, 0, 1), ("sym 16x16 db", 2, 3, 0, 2), ("default", 1, 0, 0, 0)]
 for p in [int(x) for x in sys.argv[2:]]:
     h = _lib.Handle.dense_synthetic(n, 0, pcap=p)
     rng = np.random.default_rng(0)
@@ -13,8 +14,8 @@ for p in [int(x) for x in sys.argv[2:]]:
     U = rng.standard_normal((n, p))
     h.set_point(Y)
     ref = None
-    for name, sym, rt, ln in modes:
-        h.set_option("dense_sym", sym); h.set_option("dense_sym_rt", rt); h.set_option("dense_sym_len", ln)
+    for name, sym, rt, ln, db in modes:
+        h.set_option("dense_sym", sym); h.set_option("dense_sym_rt", rt); h.set_option("dense_sym_len", ln); h.set_option("dense_sym_db", db)
         h.set_point(Y)
         H1 = h.hessvec(U); H2 = h.hessvec(U)
         G = h.rgrad()
