@@ -81,11 +81,19 @@ struct AffineDev {
     int nlit; const int* lit0; const int* lit1;   // items of the long constraints
     const int* lkit;                   // nlong + 1: items of long constraint q (= longk[q]) are lkit[q] .. lkit[q+1]-1
     unsigned* cnt;                     // arrival counter
+    // flattened records (one round trip instead of a chain of pointer loads): unit u of k_sddmm1 -> nonzero range and constraint
+    // (uk >= 0: short constraint; < 0: item -1 - uk of a long one); touched entry q of k_sph_hess_fused -> column, first
+    // (coefficient, constraint) pair, number of further pairs (they follow at rp[sup[q]] + 1)
+    const int* us0; const int* us1; const int* uk;
+    const int* sqj; const int* sqk; const double* sqv; const int* sqmore;
     // B route of the Hess-vec (symmetric data, every constraint short): A'(A(M)) on the upper entries as ONE sparse matrix applied
     // to the Gram matrix, B[e][e'] = sum_k a_k[e] * c_k[e'] (k_adjoint_gram): no m-vector, no second pass over At
     int bW;                // ELL width of B (0: route not built)
     const int* bidx;       // [ntp][bW][1024]: position i'*nS + j' (i' <= j') in Wsym; padding = position 0 with coefficient 0
     const double* bval;    // [ntp][bW][1024]
+    const unsigned* bpk;   // packed form of (bidx, bval) when it applies: position | code << 24, the coefficient = bdict[code] (SeDuMi
+                           //   moment data has a dozen distinct coefficients: 5 bytes less per nonzero of B); else null
+    const double* bdict;   // 256 coefficients
     const unsigned char* blong;   // [ntp][1024]: row longer than bW (summed by one wave each, like the long entries of the tiled adjoint)
     const int* blpos; const int* blmir; const int* bls0; const int* bls1; int bnlong;
     const int* blk; const double* blv;       // (position, coefficient) pairs of the long rows
@@ -214,10 +222,28 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm1(AffineDev a, Dev d, const
     double pacc = 0.0;
     int haslong = 0;
     const int64_t ustride = (int64_t)gridDim.x * MSDP_WAVES * CPW;
+    // mode 2: the rows of <U, G>, <U, Y> are requested FIRST -- they depend on nothing and their latency hides behind the units'
+    // chain (record -> nonzeros -> panel rows): every launch of this chain is a handful of dependent round trips, not bandwidth
+    int lo = 0, hi = 0;
+    double p1 = 0.0, p2 = 0.0;
+    if (mode == 2) {
+        const unsigned q = (unsigned)d.n_loc / gridDim.x, r = (unsigned)d.n_loc - q * gridDim.x, c = blockIdx.x;
+        lo = (int)(c * q + (c < r ? c : r)); hi = lo + (int)q + (c < r ? 1 : 0);
+        const double* __restrict__ Gr = cur ? d.Gr[1] : d.Gr[0];
+        const int64_t e0 = (int64_t)lo * d.ld, e1 = (int64_t)hi * d.ld;
+        for (int64_t i = e0 + 2 * threadIdx.x; i < e1; i += 2 * MSDP_BLOCK) {
+            const double2 u = ld2(Yb + i), g = ld2(Gr + i), y = ld2(Ya + i);
+            p1 += u.x * g.x + u.y * g.y;
+            p2 += u.x * y.x + u.y * y.y;
+        }
+    }
     for (int64_t u = ((int64_t)blockIdx.x * MSDP_WAVES + wave) * CPW + csub; u < nunits; u += ustride) {
-        int s0, s1, k = -1, lq = 0;
-        if (u < a.nshort) { k = a.sk[u]; s0 = a.cjc[k]; s1 = a.cjc[k + 1]; }
-        else { lq = (int)(u - a.nshort); s0 = a.lit0[lq]; s1 = a.lit1[lq]; haslong = 1; }
+        const int s0 = a.us0[u], s1 = a.us1[u], kk = a.uk[u];
+        const int k = kk >= 0 ? kk : -1, lq = kk >= 0 ? 0 : -1 - kk;
+        if (kk < 0) haslong = 1;
+        // what the constraint's value is combined with (known as soon as k is): requested together with the nonzeros
+        double eb = 0.0, ey = 0.0, ea = 0.0;
+        if (k >= 0 && mode != 0) { eb = a.b[k]; ey = a.y[k] / sigma; if (mode == 2) ea = axc[k]; }
         double acc = 0.0;
         constexpr int U = NCH == 1 ? 4 : 2;
         for (int t = s0; t < s1; t += U) {
@@ -250,28 +276,14 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm1(AffineDev a, Dev d, const
         if (sub == 0) {
             if (k >= 0) {
                 a.w[k] = acc;
-                if (mode == 1) { const double r = acc - a.b[k] - a.y[k] / sigma; axb_out[k] = r; pacc += r * r; }
-                else if (mode == 2) pacc += acc * (axc[k] + a.b[k] + a.y[k] / sigma);
+                if (mode == 1) { const double r = acc - eb - ey; axb_out[k] = r; pacc += r * r; }      // ManiSDP_unitdiag.m:154, same order
+                else if (mode == 2) pacc += acc * (ea + eb + ey);
             } else {
                 __hip_atomic_store(a.ival + lq, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
     if (mode == 2) {
-        // <U, G> and <U, Y> over the rows of this workgroup (plain contiguous chunks; U = Yb, Y = Ya)
-        int lo, hi;
-        {
-            const unsigned q = (unsigned)d.n_loc / gridDim.x, r = (unsigned)d.n_loc - q * gridDim.x, c = blockIdx.x;
-            lo = (int)(c * q + (c < r ? c : r)); hi = lo + (int)q + (c < r ? 1 : 0);
-        }
-        const double* __restrict__ Gr = cur ? d.Gr[1] : d.Gr[0];
-        const int64_t e0 = (int64_t)lo * d.ld, e1 = (int64_t)hi * d.ld;
-        double p1 = 0.0, p2 = 0.0;
-        for (int64_t i = e0 + 2 * threadIdx.x; i < e1; i += 2 * MSDP_BLOCK) {
-            const double2 u = ld2(Yb + i), g = ld2(Gr + i), y = ld2(Ya + i);
-            p1 += u.x * g.x + u.y * g.y;
-            p2 += u.x * y.x + u.y * y.y;
-        }
         msdp_put_partials3(d.P, P_T1, p1, P_T2, p2, P_T3, pacc, sh);
     } else if (mode == 1) {
         msdp_put_partial(d.P, P_AXB, pacc, sh);
@@ -291,14 +303,30 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm1(AffineDev a, Dev d, const
     for (int q = wave; q < a.nlong; q += MSDP_WAVES) {
         const int k = a.longk[q];
         const int i0 = a.lkit[q], i1 = a.lkit[q + 1];
-        double a0 = 0.0, a1 = 0.0;
-        int it = i0 + lane;
-        for (; it + 64 < i1; it += 128) {
-            a0 += __hip_atomic_load(a.ival + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a1 += __hip_atomic_load(a.ival + it + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // four agent-coherent loads in flight per lane and ONE wait (the compiler puts a full s_waitcnt behind every atomic load:
+        // the trace row of a theta problem -- 313 items -- cost 7 us of serialized round trips that way)
+        double a0 = 0.0;
+        for (int base = i0; base < i1; base += 256) {
+            const double* q0 = a.ival + min(base + lane, i1 - 1);
+            const double* q1 = a.ival + min(base + lane + 64, i1 - 1);
+            const double* q2 = a.ival + min(base + lane + 128, i1 - 1);
+            const double* q3 = a.ival + min(base + lane + 192, i1 - 1);
+            double v0, v1, v2, v3;
+            asm volatile(
+                "global_load_dwordx2 %0, %4, off sc1\n\t"
+                "global_load_dwordx2 %1, %5, off sc1\n\t"
+                "global_load_dwordx2 %2, %6, off sc1\n\t"
+                "global_load_dwordx2 %3, %7, off sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                : "v"(q0), "v"(q1), "v"(q2), "v"(q3)
+                : "memory");
+            if (base + lane < i1) a0 += v0;
+            if (base + lane + 64 < i1) a0 += v1;
+            if (base + lane + 128 < i1) a0 += v2;
+            if (base + lane + 192 < i1) a0 += v3;
         }
-        if (it < i1) a0 += __hip_atomic_load(a.ival + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double acc = msdp_wave_sum(a0 + a1);
+        const double acc = msdp_wave_sum(a0);
         if (lane == 0) {
             a.w[k] = acc;
             if (mode == 1) { const double r = acc - a.b[k] - a.y[k] / sigma; axb_out[k] = r; pl += r * r; }
@@ -325,24 +353,22 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm1(AffineDev a, Dev d, const
 // One wave per row; replaces k_support_spmm + k_sph_hess_raw + k_sph_hess_finish (20 us of launches at n = 5000).
 template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev a, const double* slab, int64_t slab_stride, int SK,
-                                                             double sigma, int G2, int support) {
+                                                             double sigma, int G2, int support, int cur) {
     __shared__ double sh[3 * MSDP_WAVES + 8];
     if (!d.F[0].active) return;
     const bool euc = d.manifold == MANI_EUCLID;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RPW = 64 / LPR;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
-    const int cur = d.ctl->cur;
-    double t = 0.0, z = 0.0;
+    // `cur` is the host's (the affine kinds bake the slot into their launches: one graph per slot).  The three sums of t are
+    // requested by the LAST wave up front and consumed behind the row work (one barrier there): nothing waits for them early
+    double z = 0.0;
     if (!euc) {
-        if (threadIdx.x < 64) {
-            const double s1 = msdp_sum_partials(d.P, P_T1, G2), s2 = msdp_sum_partials(d.P, P_T2, G2), s3 = msdp_sum_partials(d.P, P_T3, G2 + 1);
-            if (threadIdx.x == 0) { sh[0] = s1; sh[1] = s2; sh[2] = s3; }
-        }
-        __syncthreads();
         z = d.ctl->z_sphere[cur];
-        t = (sh[0] + 2.0 * z * sh[1]) + 4.0 * sigma * sh[2];
-        __syncthreads();
+        if (wave == MSDP_WAVES - 1) {
+            const double s1 = msdp_sum_partials(d.P, P_T1, G2), s2 = msdp_sum_partials(d.P, P_T2, G2), s3 = msdp_sum_partials(d.P, P_T3, G2 + 1);
+            if (lane == 0) { sh[0] = s1; sh[1] = s2; sh[2] = s3; }
+        }
     }
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi);
@@ -351,14 +377,20 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev 
     const double s4 = 4.0 * sigma;
     double pd = 0.0;
     // LPR lanes per row (one double2 each, NCH column chunks), 64 / LPR rows per wave: the lanes of a row take one touched entry
-    // each (its chain of dependent loads: entry -> row pointer -> (coefficient, constraint) -> w), then the values and column
-    // indices are broadcast inside the group and all its lanes accumulate v * Y(j, :)
-    for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
-        const int i = row0 + rsub;
-        const bool rok = i < hi;
+    // each (flattened record -> w), then the values and column indices are broadcast inside the group and all its lanes
+    // accumulate v * Y(j, :).  raw = slabs + 4 sigma * sparse part; y, u = the row of the point and of the direction.
+    auto rowwork = [&](int i, bool rok, double2 (&raw)[NCH], double2 (&y)[NCH], double2 (&u)[NCH]) {
         double2 acc[NCH];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) acc[ch] = make_double2(0.0, 0.0);
+        for (int ch = 0; ch < NCH; ++ch) {
+            acc[ch] = make_double2(0.0, 0.0); raw[ch] = acc[ch]; y[ch] = acc[ch]; u[ch] = acc[ch];
+            const int c = 2 * sub + ch * 2 * LPR;
+            if (rok && c < d.ld) {                                 // independent of the sparse part: requested first
+                const int64_t o = (int64_t)i * d.ld + c;
+                raw[ch] = msdp_sum_slabs(slab, slab_stride, SK, o);
+                y[ch] = ld2(Yl + o); u[ch] = ld2(d.md + o);
+            }
+        }
         if (support) {
             const int qb = rok ? a.suprow[i] : 0, qe = rok ? a.suprow[i + 1] : 0;
             for (int q0 = qb; __builtin_amdgcn_ballot_w64(q0 < qe) != 0ULL; q0 += LPR) {
@@ -366,52 +398,71 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev 
                 int jl = 0;
                 double vl = 0.0;
                 if (sub < cnt) {
-                    const int r = a.sup[q0 + sub];
-                    jl = r - i * a.n;
-                    const int s0 = a.rp[r], s1 = a.rp[r + 1];
-                    for (int tt = s0; tt < s1; ++tt) vl = fma(a.rv[tt], w[a.rk[tt]], vl);
+                    // flattened record of the entry: column, first (coefficient, constraint) pair; further pairs are rare
+                    jl = a.sqj[q0 + sub];
+                    const int k0 = a.sqk[q0 + sub], more = a.sqmore[q0 + sub];
+                    vl = a.sqv[q0 + sub] * w[k0];
+                    if (more > 0) {
+                        const int s0 = a.rp[a.sup[q0 + sub]] + 1;
+                        for (int tt = s0; tt < s0 + more; ++tt) vl = fma(a.rv[tt], w[a.rk[tt]], vl);
+                    }
                 }
                 for (int e0 = 0; __builtin_amdgcn_ballot_w64(e0 < cnt) != 0ULL; e0 += SPB) {      // until the longest row of the wave is done
                     int jj[SPB];
                     double v[SPB];
 #pragma unroll
-                    for (int u = 0; u < SPB; ++u) {
-                        const int e = min(e0 + u, max(cnt - 1, 0));
-                        jj[u] = __shfl(jl, e, LPR);
+                    for (int q = 0; q < SPB; ++q) {
+                        const int e = min(e0 + q, max(cnt - 1, 0));
+                        jj[q] = __shfl(jl, e, LPR);
                         const double vv = __shfl(vl, e, LPR);
-                        v[u] = (e0 + u < cnt) ? vv : 0.0;
+                        v[q] = (e0 + q < cnt) ? vv : 0.0;
                     }
 #pragma unroll
                     for (int ch = 0; ch < NCH; ++ch) {
                         const int c = 2 * sub + ch * 2 * LPR;
                         if (c < d.ld) {
-                            double2 y[SPB];
+                            double2 yy[SPB];
 #pragma unroll
-                            for (int u = 0; u < SPB; ++u) y[u] = ld2(Yl + (int64_t)jj[u] * d.ld + c);
+                            for (int q = 0; q < SPB; ++q) yy[q] = ld2(Yl + (int64_t)jj[q] * d.ld + c);
 #pragma unroll
-                            for (int u = 0; u < SPB; ++u) { acc[ch].x = fma(v[u], y[u].x, acc[ch].x); acc[ch].y = fma(v[u], y[u].y, acc[ch].y); }
+                            for (int q = 0; q < SPB; ++q) { acc[ch].x = fma(v[q], yy[q].x, acc[ch].x); acc[ch].y = fma(v[q], yy[q].y, acc[ch].y); }
                         }
                     }
                 }
             }
         }
-        if (rok) {
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int c = 2 * sub + ch * 2 * LPR;
-                if (c < d.ld) {
-                    const int64_t o = (int64_t)i * d.ld + c;
-                    const double2 ds = msdp_sum_slabs(slab, slab_stride, SK, o);
-                    const double2 y = ld2(Yl + o), u = ld2(d.md + o);
-                    double2 hq;
-                    hq.x = (ds.x + s4 * acc[ch].x) - t * y.x - 2.0 * z * u.x;
-                    hq.y = (ds.y + s4 * acc[ch].y) - t * y.y - 2.0 * z * u.y;
-                    st2(d.Hmd + o, hq);
-                    pd += u.x * hq.x + u.y * hq.y;
-                }
+        for (int ch = 0; ch < NCH; ++ch) { raw[ch].x += s4 * acc[ch].x; raw[ch].y += s4 * acc[ch].y; }
+    };
+    double t = 0.0;
+    auto finish = [&](int i, bool rok, const double2 (&raw)[NCH], const double2 (&y)[NCH], const double2 (&u)[NCH]) {
+        if (!rok) return;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = 2 * sub + ch * 2 * LPR;
+            if (c < d.ld) {
+                double2 hq;
+                hq.x = raw[ch].x - t * y[ch].x - 2.0 * z * u[ch].x;
+                hq.y = raw[ch].y - t * y[ch].y - 2.0 * z * u[ch].y;
+                st2(d.Hmd + (int64_t)i * d.ld + c, hq);
+                pd += u[ch].x * hq.x + u[ch].y * hq.y;
             }
         }
+    };
+    double2 raw[NCH], y[NCH], u[NCH];
+    int row0 = lo + wave * RPW;                                    // wave-uniform
+    const bool first = row0 < hi;
+    if (first) rowwork(row0 + rsub, row0 + rsub < hi, raw, y, u);  // first pass in front of the barrier that hands out t
+    if (!euc) {
+        __syncthreads();
+        t = (sh[0] + 2.0 * z * sh[1]) + 4.0 * sigma * sh[2];
     }
+    if (first) finish(row0 + rsub, row0 + rsub < hi, raw, y, u);
+    for (row0 += MSDP_WAVES * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
+        rowwork(row0 + rsub, row0 + rsub < hi, raw, y, u);
+        finish(row0 + rsub, row0 + rsub < hi, raw, y, u);
+    }
+    __syncthreads();                                               // sh[0..2] has been read by everybody
     msdp_put_partial(d.P, P_DHD, pd, sh + 8);
 }
 
@@ -710,11 +761,13 @@ __global__ __launch_bounds__(256) void k_adjoint_tiled(AffineDev a, const double
 // Yb*Ya' comes from k_gram_mfma (upper 64 x 64 tiles).  Replaces k_gram_apply (one gather per nonzero of the upper At, writes w)
 // + k_adjoint_tiled (one gather of w per nonzero): for BQP d = 60 4.2 M coefficients instead of 2 x 2.4 M, two dependent round
 // trips (ELL slice -> gather) instead of three + three, and no 9-MB m-vector in between.
-template <int BW>
+template <int BW, bool PK>
 __global__ __launch_bounds__(256) void k_adjoint_gram(AffineDev a, const double* __restrict__ Wsym, double scale, double* __restrict__ out,
                                                       const int* skip_flag, int skip_when) {
     __shared__ double tile[ADJ_T][ADJ_T + 1];
+    __shared__ double dict[PK ? 256 : 1];
     if (skip_flag && *skip_flag == skip_when) return;
+    if (PK && (int)blockIdx.x < a.ntp) { dict[threadIdx.x] = a.bdict[threadIdx.x]; __syncthreads(); }
     if ((int)blockIdx.x >= a.ntp) {
         const int lane = threadIdx.x & 63;
         const int q = ((int)blockIdx.x - a.ntp) * 4 + (threadIdx.x >> 6);
@@ -742,7 +795,12 @@ __global__ __launch_bounds__(256) void k_adjoint_gram(AffineDev a, const double*
         const int e = (li0 + 8 * q) * ADJ_T + lj;
         lng[q] = a.blong[(size_t)blockIdx.x * (ADJ_T * ADJ_T) + e] != 0;
 #pragma unroll
-        for (int w = 0; w < BW; ++w) { idx[q][w] = a.bidx[tb + (size_t)w * (ADJ_T * ADJ_T) + e]; val[q][w] = a.bval[tb + (size_t)w * (ADJ_T * ADJ_T) + e]; }
+        for (int w = 0; w < BW; ++w) {
+            if (PK) {
+                const unsigned pk = a.bpk[tb + (size_t)w * (ADJ_T * ADJ_T) + e];
+                idx[q][w] = (int)(pk & 0xffffffu); val[q][w] = dict[pk >> 24];
+            } else { idx[q][w] = a.bidx[tb + (size_t)w * (ADJ_T * ADJ_T) + e]; val[q][w] = a.bval[tb + (size_t)w * (ADJ_T * ADJ_T) + e]; }
+        }
     }
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1096,6 +1154,12 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
         if (sk.empty()) sk.push_back(0);
         if (lit0.empty()) { lit0.push_back(0); lit1.push_back(0); }
         if ((rc = up(h, sk, &a.sk)) || (rc = up(h, lit0, &a.lit0)) || (rc = up(h, lit1, &a.lit1)) || (rc = up(h, lkit, &a.lkit))) return rc;
+        {
+            std::vector<int> us0((size_t)a.nshort + a.nlit + 1, 0), us1(us0.size(), 0), uk(us0.size(), 0);
+            for (int u = 0; u < a.nshort; ++u) { us0[u] = cjc[sk[u]]; us1[u] = cjc[sk[u] + 1]; uk[u] = sk[u]; }
+            for (int q = 0; q < a.nlit; ++q) { us0[a.nshort + q] = lit0[q]; us1[a.nshort + q] = lit1[q]; uk[a.nshort + q] = -1 - q; }
+            if ((rc = up(h, us0, &a.us0)) || (rc = up(h, us1, &a.us1)) || (rc = up(h, uk, &a.uk))) return rc;
+        }
         void* pv = nullptr;
         if ((rc = msdp_dev_alloc_bytes(h, &pv, 64))) return rc;
         HIPCHK(hipMemset(pv, 0, 64));
@@ -1118,7 +1182,7 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
             }
         a.trp = nullptr; a.trk = nullptr; a.trv = nullptr; a.tp_i = nullptr; a.tp_j = nullptr; a.ntp = 0;
         a.lpos = nullptr; a.lmir = nullptr; a.ls0 = nullptr; a.ls1 = nullptr; a.nlong_e = 0;
-        a.bW = 0; a.bnlong = 0; a.bidx = nullptr; a.bval = nullptr; a.blong = nullptr; a.Wg = nullptr;
+        a.bW = 0; a.bnlong = 0; a.bidx = nullptr; a.bval = nullptr; a.blong = nullptr; a.Wg = nullptr; a.bpk = nullptr; a.bdict = nullptr;
         a.usym = 0; a.unitems = 0; a.uit0 = a.uit1 = a.ukit = a.ulongk = a.ucidx = a.ucjc = nullptr; a.ucv = nullptr; a.unlong = 0;
         std::vector<int> ucidx_h, ucjc_h;
         std::vector<double> ucv_h;
@@ -1250,6 +1314,27 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
                 a.bnlong = (int)blpos.size();
                 if (blpos.empty()) { blpos.push_back(0); blmir.push_back(0); bls0.push_back(0); bls1.push_back(0); }
                 if (blk.empty()) { blk.push_back(0); blv.push_back(0.0); }
+                // packed form: position (24 bits) | coefficient code (8 bits) when the data allows it
+                a.bpk = nullptr; a.bdict = nullptr;
+                {
+                    std::vector<double> dict;
+                    bool ok = (int64_t)n * a.nS < (1 << 24);
+                    std::vector<unsigned> bpk;
+                    if (ok) {
+                        bpk.resize(bidx.size());
+                        for (size_t q = 0; q < bidx.size() && ok; ++q) {
+                            size_t c = 0;
+                            for (; c < dict.size(); ++c) if (memcmp(&dict[c], &bval[q], sizeof(double)) == 0) break;
+                            if (c == dict.size()) { if (dict.size() >= 256) { ok = false; break; } dict.push_back(bval[q]); }
+                            bpk[q] = (unsigned)bidx[q] | ((unsigned)c << 24);
+                        }
+                    }
+                    if (ok) {
+                        dict.resize(256, 0.0);
+                        if ((rc = up(h, bpk, &a.bpk)) || (rc = up(h, dict, &a.bdict))) return rc;
+                        bidx.assign(1, 0); bval.assign(1, 0.0);          // the packed arrays replace them on the device
+                    }
+                }
                 if ((rc = up(h, bidx, &a.bidx)) || (rc = up(h, bval, &a.bval)) || (rc = up(h, blong, &a.blong)) ||
                     (rc = up(h, blpos, &a.blpos)) || (rc = up(h, blmir, &a.blmir)) || (rc = up(h, bls0, &a.bls0)) ||
                     (rc = up(h, bls1, &a.bls1)) || (rc = up(h, blk, &a.blk)) || (rc = up(h, blv, &a.blv))) return rc;
@@ -1261,7 +1346,7 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
         // entries touched by At; the restricted adjoint is used when they are few (<= 1/8 of the matrix)
         int64_t ns = 0;
         for (int64_t r = 0; r < nn; ++r) ns += rp[r + 1] > rp[r];
-        a.sup = nullptr; a.suprow = nullptr; a.nsup = 0;
+        a.sup = nullptr; a.suprow = nullptr; a.nsup = 0; a.sqj = a.sqk = a.sqmore = nullptr; a.sqv = nullptr;
         if (ns > 0 && ns * 8 <= nn) {
             std::vector<int> sup;
             sup.reserve((size_t)ns);
@@ -1270,6 +1355,15 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
             for (int r : sup) suprow[r / n + 1]++;
             for (int i = 0; i < n; ++i) suprow[i + 1] += suprow[i];
             if ((rc = up(h, sup, &a.sup)) || (rc = up(h, suprow, &a.suprow))) return rc;
+            {
+                std::vector<int> sqj(sup.size()), sqk(sup.size()), sqmore(sup.size());
+                std::vector<double> sqv(sup.size());
+                for (size_t q = 0; q < sup.size(); ++q) {
+                    const int64_t r = sup[q];
+                    sqj[q] = (int)(r % n); sqk[q] = rk[rp[r]]; sqv[q] = rv[rp[r]]; sqmore[q] = rp[r + 1] - rp[r] - 1;
+                }
+                if ((rc = up(h, sqj, &a.sqj)) || (rc = up(h, sqk, &a.sqk)) || (rc = up(h, sqv, &a.sqv)) || (rc = up(h, sqmore, &a.sqmore))) return rc;
+            }
             a.nsup = (int)ns;
         }
     }
@@ -1636,12 +1730,11 @@ int msdp_affine_hess(msdp_handle h) {
         hipLaunchKernelGGL(k_gram_mfma, grid, dim3(512), 0, h->stream, a.n, a.nS, a.ld, Yf, Uf, a.Wg, act, 0, 1);
         HIPCHK(hipGetLastError());
         const dim3 ga(a.ntp + (a.bnlong + 3) / 4), ba(256);
-        switch (a.bW) {
-            case 1: hipLaunchKernelGGL(k_adjoint_gram<1>, ga, ba, 0, h->stream, a, (const double*)a.Wg, 1.0, d.AyU, act, 0); break;
-            case 2: hipLaunchKernelGGL(k_adjoint_gram<2>, ga, ba, 0, h->stream, a, (const double*)a.Wg, 1.0, d.AyU, act, 0); break;
-            case 3: hipLaunchKernelGGL(k_adjoint_gram<3>, ga, ba, 0, h->stream, a, (const double*)a.Wg, 1.0, d.AyU, act, 0); break;
-            default: hipLaunchKernelGGL(k_adjoint_gram<4>, ga, ba, 0, h->stream, a, (const double*)a.Wg, 1.0, d.AyU, act, 0); break;
-        }
+        const bool pk = a.bpk != nullptr;
+#define AG(BW) do { if (pk) hipLaunchKernelGGL((k_adjoint_gram<BW, true>), ga, ba, 0, h->stream, a, (const double*)a.Wg, 1.0, d.AyU, act, 0); \
+                    else hipLaunchKernelGGL((k_adjoint_gram<BW, false>), ga, ba, 0, h->stream, a, (const double*)a.Wg, 1.0, d.AyU, act, 0); } while (0)
+        switch (a.bW) { case 1: AG(1); break; case 2: AG(2); break; case 3: AG(3); break; default: AG(4); break; }
+#undef AG
         HIPCHK(hipGetLastError());
         const double* M[2] = {d.eS[cur] + roff, d.AyU + roff};
         const double* X[2] = {Uf, Yf};
@@ -1654,17 +1747,33 @@ int msdp_affine_hess(msdp_handle h) {
         // sphere / Euclidean factor, SDDMM route, one rank: three launches + the contraction (k_sddmm1 mode 2, [adjoint,]
         // contraction, k_sph_hess_fused) instead of six
         int G2 = 0;
-        if ((rc = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 2, (double*)nullptr, sigma, &G2))) return rc;
         const bool support = a.nsup > 0;
-        if (support) {
+        if (support && h->tune.affine_overlap) {
+            // A/B (option affine_overlap): 2*eS*U needs neither w nor the sums -- it runs on a second stream beside k_sddmm1 and joins in
+            // front of the epilogue
+            if (!st->s2) {
+                HIPCHK(hipStreamCreateWithFlags(&st->s2, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
+            }
+            const double* M[1] = {d.eS[cur]}; const double* X[1] = {d.md}; const double sc[1] = {2.0};
+            HIPCHK(hipEventRecord(st->ev_fork, h->stream));
+            HIPCHK(hipStreamWaitEvent(st->s2, st->ev_fork, 0));
+            if ((rc = msdp_dense_gemm_at(h, st->s2, 0, 0, 1, M, X, sc, act, &slab, &stride, &SK))) return rc;
+            HIPCHK(hipEventRecord(st->ev_join, st->s2));
+            if ((rc = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 2, (double*)nullptr, sigma, &G2))) return rc;
+            HIPCHK(hipStreamWaitEvent(h->stream, st->ev_join, 0));
+        } else if (support) {
+            if ((rc = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 2, (double*)nullptr, sigma, &G2))) return rc;
             const double* M[1] = {d.eS[cur]}; const double* X[1] = {d.md}; const double sc[1] = {2.0};
             if ((rc = msdp_dense_gemm(h, 1, M, X, sc, act, &slab, &stride, &SK))) return rc;
         } else {
+            if ((rc = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 2, (double*)nullptr, sigma, &G2))) return rc;
             if ((rc = launch_adjoint(h, a, (const double*)nullptr, a.w, 1.0, d.AyU, act, 0, true))) return rc;
             const double* M[2] = {d.eS[cur], d.AyU}; const double* X[2] = {Uf, Yf}; const double sc[2] = {2.0, 4.0 * sigma};
             if ((rc = msdp_dense_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
         }
-        DISPATCH_LPR_A(k_sph_hess_fused, h, d.G, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0);
+        DISPATCH_LPR_A(k_sph_hess_fused, h, d.G, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0, cur);
         HIPCHK(hipGetLastError());
         return 0;
     }

@@ -27,7 +27,7 @@ import scipy.sparse as sp
 
 __all__ = [
     "read_gset", "gset_laplacian", "maxcut_cost_matrix", "toroidal_grid_maxcut",
-    "from_sdpa", "get_basis", "bqpmom", "qsmom", "theta_problem",
+    "from_sdpa", "get_basis", "bqpmom", "qsmom", "theta_problem", "generate_hamming",
     "dense_unitdiag_cost", "vec_index",
 ]
 
@@ -485,6 +485,41 @@ def theta_problem(n, ndraws=None, seed=1):
     b = np.zeros(m + 1)
     b[m] = 1.0
     c = -np.ones(n * n)
+    return At, b, c, {"s": n}
+
+
+def generate_hamming(k, d):
+    """Theta function of the Hamming graph H_{k,d} in SeDuMi format -- example/generate_hamming.m:24-59 (the SDPLIB ``hamming_*``
+    generator): vertices = the 2^k bit patterns, an edge where the Hamming distance is in ``d``; constraint 1 is ``tr X = 1``
+    (``b(1) = 1``), then one constraint ``X_ij + X_ji = 0`` per edge in the order the reference enumerates them (vertex
+    ``i`` ascending, its neighbours ``j > i`` in the order of the bit patterns); ``c = -vec(1 - Adj)``.  A unit-trace problem:
+    ``ManiSDP_unittrace(At, b, c, K)`` returns ``-theta(H_{k,d})``.  Returns ``At`` (the reference returns ``A``)."""
+    n = 1 << int(k)
+    bitpat = []
+    for dist in np.atleast_1d(d):
+        for comb_ in combinations(range(int(k)), int(dist)):       # nchoosek(1:k, i): rows in lexicographic order
+            bitpat.append(sum(1 << q for q in comb_))
+    bitpat = np.array(bitpat, dtype=np.int64)
+    Adj = sp.lil_matrix((n, n))
+    ai, aj = [], []
+    start = 0
+    for i in range(n):
+        nb = np.bitwise_xor(i, bitpat)
+        nb = nb[nb > i]
+        if nb.size:
+            Adj[i, nb] = 1.0
+            Adj[nb, i] = 1.0
+            rows = np.arange(start, start + nb.size)
+            ai += [rows, rows]
+            aj += [nb * n + i, nb + i * n]
+            start += nb.size
+    m = start + 1
+    rows = np.concatenate([np.arange(n) * n + np.arange(n)] + ([np.concatenate(aj)] if aj else []))
+    cols = np.concatenate([np.zeros(n, dtype=np.int64)] + ([np.concatenate(ai) + 1] if ai else []))
+    At = sp.coo_matrix((np.ones(rows.size), (rows, cols)), shape=(n * n, m)).tocsc()
+    c = -(1.0 - np.asarray(Adj.todense())).ravel(order="F")
+    b = np.zeros(m)
+    b[0] = 1.0
     return At, b, c, {"s": n}
 
 

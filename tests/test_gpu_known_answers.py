@@ -146,3 +146,14 @@ def test_unitdiag_thetaG51():
     Y, obj, data = solvers.ManiSDP_unitdiag(At, b, c, K, dict(GPP_OPTS, tol=1e-6, AL_maxiter=60, eig="host"), verbose=False)
     assert max(data["gap"], data["pinf"], data["dinf"]) < 1e-4
     assert within_print(-obj, PRINTED["thetaG51"])
+
+
+@pytest.mark.parametrize("k,d,theta", [(5, [1], 16.0), (7, [5, 6], 128.0 / 3.0), (8, [1], 128.0), (6, [6], 32.0)])
+def test_unittrace_hamming_graphs(k, d, theta):
+    """problems.generate_hamming (example/generate_hamming.m:24-59) through ManiSDP_unittrace on the GPU: hypercubes and the antipodal
+    matching (perfect graphs: theta = 2^(k-1)), and H_{7,{5,6}} -- SDPLIB's hamming_7_5_6, whose value is 128/3."""
+    from manisdp_matlab_amd import problems, solvers
+    At, b, c, K = problems.generate_hamming(k, d)
+    Y, obj, data = solvers.ManiSDP_unittrace(At, b, c, K, dict(THETA_OPTS, eig="host"), verbose=False)
+    assert data["status"] == 0 and max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
+    assert abs(-obj - theta) <= 1e-7 * theta

@@ -219,3 +219,19 @@ def test_unitdiag_thetaG11():
     Y, obj, data = R.ManiSDP_unitdiag(At, np.asarray(b).ravel(), c, K, {"tol": 1e-8})
     assert data["status"] == 0 and max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
     assert within_print(-obj, PRINTED["thetaG11"])
+
+
+@pytest.mark.parametrize("k,d,theta", [(3, [1, 2, 3], 1.0), (4, [1], 8.0), (4, [4], 8.0), (5, [1], 16.0)])
+def test_unittrace_hamming_graphs_with_known_theta(k, d, theta):
+    """example/generate_hamming.m (the generator of SDPLIB's hamming_* problems, restated in problems.generate_hamming) through
+    ManiSDP_unittrace on graphs whose theta number is known in closed form: the complete graph (distances 1..k: theta = 1) and
+    perfect graphs -- the hypercube (distance 1, bipartite) and the antipodal matching (distance k) -- where theta = the
+    independence number 2^(k-1).  A pin of generator + unit-trace solver that needs no stored optimum."""
+    At, b, c, K = problems.generate_hamming(k, d)
+    n = 1 << k
+    assert K["s"] == n and b[0] == 1.0 and np.count_nonzero(b) == 1
+    col0 = At[:, 0].tocoo()
+    assert col0.nnz == n and np.array_equal(np.sort(col0.row), np.arange(n) * (n + 1))          # constraint 1 = trace
+    Y, obj, data = R.ManiSDP_unittrace(At, b, c, K, dict(THETA_OPTS))
+    assert data["status"] == 0 and max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
+    assert abs(-obj - theta) <= 1e-7 * theta

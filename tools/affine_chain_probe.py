@@ -9,6 +9,7 @@ gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 args = sys.argv[1:]
 profile = "--profile" in args
 nofuse = "--nofuse" in args
+quick = "--quick" in args
 names = [a for a in args if not a.startswith("--")] or ["bqp60", "theta5000"]
 for name in names:
     t0 = time.time()
@@ -28,9 +29,10 @@ for name in names:
     print("%s: n=%d m=%d nnz=%d  (set-up %.1f s)" % (name, n, b.size, At.nnz, time.time() - t0), flush=True)
     h.set_multipliers(np.zeros(b.size), 1.0)
     ref = None
-    combos = [(1, 1, 0)] if profile else [(0, 0, 0), (0, 1, 0), (2, 0, 1), (2, 1, 1), (2, 1, 2), (2, 1, 3), (1, 1, 0)]
-    for sym, br, rt in combos:
-        h.set_option("dense_sym", sym); h.set_option("affine_broute", br); h.set_option("dense_sym_rt", rt)
+    combos = [(1, 1, 0, 0)] if profile else ([(1, 1, 0, 0), (1, 1, 0, 1), (1, 0, 0, 0)] if quick else
+                                             [(0, 0, 0, 0), (0, 1, 0, 0), (2, 0, 1, 0), (2, 1, 1, 0), (2, 1, 2, 0), (2, 1, 3, 0), (1, 1, 0, 0), (1, 1, 0, 1)])
+    for sym, br, rt, ov in combos:
+        h.set_option("dense_sym", sym); h.set_option("affine_broute", br); h.set_option("dense_sym_rt", rt); h.set_option("affine_overlap", ov)
         if profile:
             h.set_option("graph", 0)
         if nofuse:
@@ -42,6 +44,6 @@ for name in names:
         err = np.linalg.norm(H - ref) / np.linalg.norm(ref)
         for _ in range(2):
             ms, by, fl = h.bench_hessvec(100)
-        print("  dense_sym=%d broute=%d shape=%d: %.1f us  (%.2f TB/s algorithmic = %.3f of HBM)  diff vs first %.1e" %
-              (sym, br, rt, ms * 1e3, by / ms / 1e9, by / ms / 1e9 / 8.0, err), flush=True)
+        print("  dense_sym=%d broute=%d shape=%d overlap=%d: %.1f us  (%.2f TB/s algorithmic = %.3f of HBM)  diff vs first %.1e" %
+              (sym, br, rt, ov, ms * 1e3, by / ms / 1e9, by / ms / 1e9 / 8.0, err), flush=True)
     h.close()
