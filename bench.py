@@ -165,7 +165,7 @@ def affine_shapes(_lib, problems, with_cpu):
                    "hessvec_per_s": 1e3 / ms, "hessvec_us_by_p": sweep, "hessvec_us_two_streams": ms1 * 1e3,
                    "roofline": secondary_roofline(
                        "affine Hess-vec chain (A(YU') -> A'(w) -> two-matrix contraction -> epilogue)", ms * 1e3, aby, afl,
-                       ("r3_pmc_%s_p32.json" % name,))}
+                       ("r4_pmc_%s_p32.json" % name, "r3_pmc_%s_p32.json" % name))}
             if with_cpu:
                 from oracle import manisdp_ref
                 U = rng.standard_normal((n, p))
@@ -176,6 +176,56 @@ def affine_shapes(_lib, problems, with_cpu):
         except Exception as e:  # noqa: BLE001 -- secondary figures never cost the headline line
             out.append({"workload": name, "error": "%s: %s" % (type(e).__name__, e)})
     return out
+
+
+def cross_rank_trip(_lib, problems, N=2, p=32):
+    """Two in-process ranks on ONE GPU (msdp_comm_init_local), 20 000 rows each (the weak-scaled G81 family of --gpus N): the tCG
+    trip of the cross-rank persistent kernel (one combined launch, grid reductions and row exchange through shared uncached
+    memory, no collective per trip; msdp_persist.hip XR) against the lock-step chunked trips (one exchange + one all-reduce per
+    trip through the in-process stand-in of the communicator).  What a box with one GPU can say about the multi-GPU tCG."""
+    import threading
+    C = problems.toroidal_grid_maxcut(100 * N, 200, seed=81)
+    n = C.shape[0]
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    res = {}
+    gid = [9100]
+
+    def run(xp):
+        gid[0] += 1
+        out, err = [None] * N, [None] * N
+
+        def body(r):
+            try:
+                h = _lib.Handle.onlyunitdiag(C, pcap=p)
+                h.comm_init_local(N, r, gid[0])
+                h.set_option("xpersist", xp)
+                h.set_point(Y)
+                c0 = h.collective_calls()
+                t = min(h.bench_tcg_trip(256) for _ in range(3)) * 1e3
+                out[r] = (t, h.tcg_path(), h.collective_calls() - c0)
+                h.close()
+            except BaseException as e:  # noqa: BLE001
+                err[r] = e
+        th = [threading.Thread(target=body, args=(r,)) for r in range(N)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(300)
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+    a, b = run(1), run(0)
+    h = _lib.Handle.onlyunitdiag(C, pcap=p)
+    h.set_point(Y)
+    one = min(h.bench_tcg_trip(256) for _ in range(3)) * 1e3
+    h.close()
+    return {"workload": "toroidal grid MaxCut, %d in-process ranks x 20000 rows on one GPU, p = %d" % (N, p), "n": n, "p": p, "ranks": N,
+            "trip_us_cross_rank_persistent": max(q[0] for q in a), "tcg_path": a[0][1], "collective_calls_per_768_trips": a[0][2],
+            "trip_us_lockstep_chunks": max(q[0] for q in b), "collective_calls_per_768_trips_lockstep": b[0][2],
+            "trip_us_one_unsharded_handle": one,
+            "note": "the members' workgroups (2 x 128) run in ONE launch; on N GPUs the same protocol needs peer-mapped fine-grained memory over xGMI (not built)"}
 
 
 def main():
@@ -194,6 +244,7 @@ def main():
     ap.add_argument("--no-kkt", action="store_true", help="skip the full G81 solve to KKT 1e-8")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-C (fp64 MFMA) Hess-vec figure")
     ap.add_argument("--no-large-sparse", action="store_true", help="skip the n = 10^6 chunked-trip figure")
+    ap.add_argument("--no-xrank", action="store_true", help="skip the two-ranks-on-one-GPU cross-rank persistent trip")
     ap.add_argument("--no-affine", action="store_true", help="skip the Hess-vec figures of the affine configurations (BQP d = 60, theta n = 5000)")
     ap.add_argument("--row-exchange", choices=("allgather", "halo"), default="allgather",
                     help="N > 1: which exchange in front of S*U `value` is quoted on (both legs are timed and reported): the "
@@ -334,8 +385,8 @@ def main():
         return None
     # HBM traffic comes from rocprofv3 --pmc passes (their own runs: counters cannot be collected inside a timed run);
     # the line carries the committed summary's value together with the file it was read from
-    pm_h = pmc("r3_pmc_hess_g81_p32.json", "r2_pmc_hess_g81_p32.json", "r1_pmc_hess_g81_p32.json")
-    pm_t = pmc("r3_pmc_persist_g81_p32.json", "r2_pmc_persist_g81_p32.json", "r1_pmc_persist_g81_p32.json")
+    pm_h = pmc("r4_pmc_hess_g81_p32.json", "r3_pmc_hess_g81_p32.json", "r2_pmc_hess_g81_p32.json", "r1_pmc_hess_g81_p32.json")
+    pm_t = pmc("r4_pmc_persist_g81_p32.json", "r3_pmc_persist_g81_p32.json", "r2_pmc_persist_g81_p32.json", "r1_pmc_persist_g81_p32.json")
     if persistent:
         traffic = (pm_t or {}).get("hbm_bytes_per_trip")
         roofline = {"bound": "hbm", "achieved": trip_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -348,9 +399,11 @@ def main():
                     "streaming_formulation_bytes_per_trip": streaming_trip_bytes,
                     "streaming_equivalent_GBps": streaming_trip_bytes / (trip_ms * 1e-3) / 1e9,
                     "note": "one launch runs all trips of a solve; bytes, traffic and time are per trip.  The working "
-                            "set is register/LDS resident and the trip is bound by its two grid-wide synchronisations "
-                            "(~1.7 us each) and the coherent exchange of the residual rows, not by HBM: the fraction of "
-                            "the HBM roofline is low by construction at n*p*8 = 5 MB per vector"}
+                            "set is register/LDS resident; profiles/r4_persist_timeline_p32.md (s_memtime stamps of every workgroup) "
+                            "splits a trip into gathers + row arithmetic 1.6 us, grid reduction 1 1.9 us, trial step 0.5 us, wait for the "
+                            "residual-row stores 0.6 us, grid reduction 2 2.7 us, commit + new direction 0.6 us, loop 0.15 us: the two "
+                            "grid-wide reductions are 58 % of the trip, not HBM -- the fraction of the HBM roofline is low by "
+                            "construction at n*p*8 = 5 MB per vector"}
     else:
         roofline = {"bound": "hbm", "achieved": hess_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hess_achieved / HBM_PEAK_GBS, "traffic": (pm_h or {}).get("hbm_bytes_per_launch"),
@@ -437,12 +490,14 @@ def main():
             for _ in range(2):
                 msd, byd, fld = hd.bench_hessvec(100)
             hd.close()
-            ent = {"n": dn, "p": dp, "kernel": "k_dense_partial3 + k_dense_hess_epi_obl", "hessvec_us": msd * 1e3,
+            # symmetric C, p <= 32, n >= 8192: the upper-triangle contraction of msdp_densesym.hip (k_dense_sym + k_sym_fold) takes the product
+            kname = ("k_dense_sym + k_sym_fold + k_dense_hess_epi_obl" if (dp <= 32 and dn >= 8192) else "k_dense_partial3 + k_dense_hess_epi_obl")
+            ent = {"n": dn, "p": dp, "kernel": kname, "hessvec_us": msd * 1e3,
                    "algorithmic_bytes": byd, "algorithmic_flops": fld,
                    "TFLOPs_f64": fld / msd / 1e9, "frac_mfma_f64_peak": fld / msd / 1e9 / MFMA_F64_TFLOPS,
                    "GBps": byd / msd / 1e6, "frac_hbm_peak": byd / msd / 1e6 / HBM_PEAK_GBS,
-                   "roofline": secondary_roofline("k_dense_partial3 + k_dense_hess_epi_obl", msd * 1e3, byd, fld,
-                                                  ("r3_pmc_dense%d_p%d.json" % (dn, dp), "r2_pmc_dense%d_p%d.json" % (dn, dp)),
+                   "roofline": secondary_roofline(kname, msd * 1e3, byd, fld,
+                                                  ("r4_pmc_dense%d_p%d.json" % (dn, dp), "r3_pmc_dense%d_p%d.json" % (dn, dp), "r2_pmc_dense%d_p%d.json" % (dn, dp)),
                                                   bound="hbm" if dp <= RIDGE_P else "mfma")}
             if dn == 5000 and not args.no_cpu_baseline:
                 ent["cpu_baseline"] = cpu_dense_hessvec(dn, dp)
@@ -505,6 +560,11 @@ def main():
             out["large_sparse_trip"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if not args.no_affine and N == 1 and rank == 0 and not args.force_comm:
         out["affine_hessvec"] = affine_shapes(_lib, problems, not args.no_cpu_baseline)
+    if not args.no_xrank and N == 1 and rank == 0 and not args.force_comm:
+        try:
+            out["cross_rank_trip"] = cross_rank_trip(_lib, problems)
+        except Exception as e:  # noqa: BLE001 -- secondary figure
+            out["cross_rank_trip"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if N > 1 or args.force_comm:
         # BASELINE config 5 next to the headline metric: synthetic dense C generated per shard on the device
         # (12 500 rows per GPU, n = 12 500 * N, so N = 8 is exactly n = 100 000), p = 64, RCCL all-gather of the
