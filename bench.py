@@ -499,6 +499,10 @@ def main():
                    "roofline": secondary_roofline(kname, msd * 1e3, byd, fld,
                                                   ("r4_pmc_dense%d_p%d.json" % (dn, dp), "r3_pmc_dense%d_p%d.json" % (dn, dp), "r2_pmc_dense%d_p%d.json" % (dn, dp)),
                                                   bound="hbm" if dp <= RIDGE_P else "mfma")}
+            if "k_dense_sym" in kname:
+                ent["roofline"]["note"] = ("algorithmic_bytes is SURVEY.md 8(d)'s dense-C figure (the whole n x n matrix once + three panels); the symmetric "
+                                           "route reads the upper triangle only, so achieved / peak can exceed what streaming the whole matrix allows -- "
+                                           "`traffic` (rocprofv3 --pmc) is what the three launches move")
             if dn == 5000 and not args.no_cpu_baseline:
                 ent["cpu_baseline"] = cpu_dense_hessvec(dn, dp)
             dense.append(ent)
