@@ -164,7 +164,8 @@ def affine_shapes(_lib, problems, with_cpu):
             ent = {"workload": name, "entry_point": label, "n": n, "m": int(b.size), "nnz_At": int(At.nnz), "p": p, "hessvec_us": ms * 1e3,
                    "hessvec_per_s": 1e3 / ms, "hessvec_us_by_p": sweep, "hessvec_us_two_streams": ms1 * 1e3,
                    "roofline": secondary_roofline(
-                       "affine Hess-vec chain (A(YU') -> A'(w) -> two-matrix contraction -> epilogue)", ms * 1e3, aby, afl,
+                       ("affine Hess-vec chain (Gram matrix -> B route A'(A(.)) -> two-matrix contraction -> epilogue)" if name == "bqp60" else
+                        "affine Hess-vec chain (contraction with the SDDMM as a side job -> fused sparse A'(w)*Y + sphere epilogue)"), ms * 1e3, aby, afl,
                        ("r4_pmc_%s_p32.json" % name, "r3_pmc_%s_p32.json" % name))}
             if with_cpu:
                 from oracle import manisdp_ref

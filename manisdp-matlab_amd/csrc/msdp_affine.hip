@@ -14,6 +14,7 @@
 // CSR-by-entry SpMV that writes the dense n x nS matrix the MFMA kernel then contracts.
 // The constraint matrices A_k and C are symmetric (SeDuMi data), so row-major == column-major.
 #include "msdp_device.h"
+#include "msdp_affine_dev.h"
 #include <math.h>
 #include <algorithm>
 #include <cstring>
@@ -28,84 +29,6 @@ int msdp_allgather_vec(msdp_handle h, const double* local, double* all, size_t c
 int msdp_dense_gemm(msdp_handle h, int nmat, const double* const* M, const double* const* X, const double* scale,
                     const int* active_flag, const double** slab_out, int64_t* stride_out, int* SK_out);
 
-struct AffineDev {
-    int n, nS, p, ld;
-    int64_t m;
-    const int* cjc;        // m+1 column pointers (CSC by constraint)
-    // long columns are cut into work items of <= SDDMM_CHUNK nonzeros so that one constraint (e.g. the trace
-    // row of a theta problem: n nonzeros) cannot serialise a whole launch on a single lane group
-    int64_t nitems;
-    const int* it0;        // first nonzero of item
-    const int* it1;        // one past the last nonzero of item
-    const int* kit;        // m+1: items of constraint k are kit[k] .. kit[k+1]-1
-    const int* longk;      // constraints with more than FIN_SHORT items
-    int nlong;
-    double* ival;          // partial value per item
-    const int* ci;         // row i of each nonzero
-    const int* cj;         // col j of each nonzero
-    const double* cv;
-    const int* rp;         // n*n+1 row pointers (CSR by matrix entry r = i*n + j)
-    const int* cidx;       // i*nS + j of each nonzero: position in the dense Gram matrix W = Ya*Yb' (Gram route)
-    // symmetric data: the same constraints over their entries i <= j only (coefficient halved on the diagonal), for the
-    // Gram route on Wsym = Ya*Yb' + Yb*Ya' -- half the gathers (upper_view() swaps these in)
-    int usym;
-    int64_t unitems;
-    const int* uit0; const int* uit1; const int* ukit; const int* ulongk; int unlong;
-    const int* ucjc;       // m+1 column pointers of the upper view
-    const int* ucidx; const double* ucv;
-    double* W;             // n x nS scratch for the Gram route (aliases the AyU buffer)
-    const int* rk;         // constraint index
-    const double* rv;
-    const double* b;
-    const double* y;
-    double* w;             // A(.) result, length m
-    double* Axb[2];        // per slot
-    // tiled upper-triangle copy of the CSR-by-entry arrays (symmetric data only; k_adjoint_tiled): the entries of
-    // every 32 x 32 tile (bi <= bj) are stored together, row-major inside the tile
-    const int* trp;        // ntp*1024 + 1 offsets into trk / trv
-    const int* trk;
-    const double* trv;
-    const short* tp_i;     // tile pair -> (bi, bj)
-    const short* tp_j;
-    int ntp;               // number of tile pairs (0: data not symmetric, flat kernel)
-    // entries with more than ADJ_LONG nonzeros (the (x_i, x_j) block of a BQP moment matrix: 59 each) are left out
-    // by the tile workgroups and summed by one wave each in extra workgroups of the same launch
-    const int* lpos;       // i*nS + j of long entry q (i <= j)
-    const int* lmir;       // j*nS + i
-    const int* ls0;        // its range in trk / trv
-    const int* ls1;
-    int nlong_e;
-    // fused SDDMM (k_sddmm1): short constraints are summed whole by one lane group; the items of the long ones go through
-    // ival and are summed by the workgroup that arrives last
-    int nshort; const int* sk;         // short constraints (<= FIN_SHORT items)
-    int nlit; const int* lit0; const int* lit1;   // items of the long constraints
-    const int* lkit;                   // nlong + 1: items of long constraint q (= longk[q]) are lkit[q] .. lkit[q+1]-1
-    unsigned* cnt;                     // arrival counter
-    // flattened records (one round trip instead of a chain of pointer loads): unit u of k_sddmm1 -> nonzero range and constraint
-    // (uk >= 0: short constraint; < 0: item -1 - uk of a long one); touched entry q of k_sph_hess_fused -> column, first
-    // (coefficient, constraint) pair, number of further pairs (they follow at rp[sup[q]] + 1)
-    const int* us0; const int* us1; const int* uk;
-    const int* sqj; const int* sqk; const double* sqv; const int* sqmore;
-    // B route of the Hess-vec (symmetric data, every constraint short): A'(A(M)) on the upper entries as ONE sparse matrix applied
-    // to the Gram matrix, B[e][e'] = sum_k a_k[e] * c_k[e'] (k_adjoint_gram): no m-vector, no second pass over At
-    int bW;                // ELL width of B (0: route not built)
-    const int* bidx;       // [ntp][bW][1024]: position i'*nS + j' (i' <= j') in Wsym; padding = position 0 with coefficient 0
-    const double* bval;    // [ntp][bW][1024]
-    const unsigned* bpk;   // packed form of (bidx, bval) when it applies: position | code << 24, the coefficient = bdict[code] (SeDuMi
-                           //   moment data has a dozen distinct coefficients: 5 bytes less per nonzero of B); else null
-    const double* bdict;   // 256 coefficients
-    const unsigned char* blong;   // [ntp][1024]: row longer than bW (summed by one wave each, like the long entries of the tiled adjoint)
-    const int* blpos; const int* blmir; const int* bls0; const int* bls1; int bnlong;
-    const int* blk; const double* blv;       // (position, coefficient) pairs of the long rows
-    double* Wg;            // Gram matrix of the B route (n x nS): AyU is written while it is read
-    const int* sup;        // entries r = i*n + j that occur in some constraint (nsup > 0: At touches few entries)
-    const int* suprow;     // n+1: the entries of matrix row i are sup[suprow[i] .. suprow[i+1])
-    int nsup;
-};
-
-#define SDDMM_CHUNK 16
-#define SPB 4                   // panel rows requested together by the sparse A'(w)*Y products
-#define FIN_SHORT 8           // constraints with more items than this are summed by a whole wave (k_sddmm_finish)
 // item value = sum over the item's nonzeros (i,j,val) of val * <Ya_i, Yb_j>   (one LPR-lane group per item)
 template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm(AffineDev a, const double* __restrict__ Ya,
@@ -353,8 +276,9 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sddmm1(AffineDev a, Dev d, const
 // One wave per row; replaces k_support_spmm + k_sph_hess_raw + k_sph_hess_finish (20 us of launches at n = 5000).
 template <int LPR, int NCH>
 __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev a, const double* slab, int64_t slab_stride, int SK,
-                                                             double sigma, int G2, int support, int cur) {
+                                                             double sigma, int G2, int support, int cur, int hetero) {
     __shared__ double sh[3 * MSDP_WAVES + 8];
+    __shared__ double wl[MSDP_WAVES + 1];                      // values of the long constraints (<= 16), and their share of the third sum
     if (!d.F[0].active) return;
     const bool euc = d.manifold == MANI_EUCLID;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -369,6 +293,18 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev 
             const double s1 = msdp_sum_partials(d.P, P_T1, G2), s2 = msdp_sum_partials(d.P, P_T2, G2), s3 = msdp_sum_partials(d.P, P_T3, G2 + 1);
             if (lane == 0) { sh[0] = s1; sh[1] = s2; sh[2] = s3; }
         }
+    }
+    // Long constraints (a trace row): wave q provides the value of number q -- hetero (the SDDMM ran as a side job of the contraction
+    // launch, msdp_sddmm_side): the sum of its item values, in item order, the same in every workgroup; else what k_sddmm1 left in w
+    if (support && wave < a.nlong) {
+        const int k = a.longk[wave];
+        double v;
+        if (hetero) {
+            double a0 = 0.0;
+            for (int it = a.lkit[wave] + lane; it < a.lkit[wave + 1]; it += 64) a0 += a.ival[it];
+            v = msdp_wave_sum(a0);
+        } else v = a.w[k];
+        if (lane == 0) wl[wave] = v;
     }
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi);
@@ -401,10 +337,10 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev 
                     // flattened record of the entry: column, first (coefficient, constraint) pair; further pairs are rare
                     jl = a.sqj[q0 + sub];
                     const int k0 = a.sqk[q0 + sub], more = a.sqmore[q0 + sub];
-                    vl = a.sqv[q0 + sub] * w[k0];
+                    vl = a.sqv[q0 + sub] * (k0 >= 0 ? w[k0] : wl[-1 - k0]);
                     if (more > 0) {
                         const int s0 = a.rp[a.sup[q0 + sub]] + 1;
-                        for (int tt = s0; tt < s0 + more; ++tt) vl = fma(a.rv[tt], w[a.rk[tt]], vl);
+                        for (int tt = s0; tt < s0 + more; ++tt) { const int kx = a.rkx[tt]; vl = fma(a.rv[tt], kx >= 0 ? w[kx] : wl[-1 - kx], vl); }
                     }
                 }
                 for (int e0 = 0; __builtin_amdgcn_ballot_w64(e0 < cnt) != 0ULL; e0 += SPB) {      // until the longest row of the wave is done
@@ -449,13 +385,19 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev 
             }
         }
     };
+    if (support && a.nlong > 0) __syncthreads();                   // wl is in place
     double2 raw[NCH], y[NCH], u[NCH];
     int row0 = lo + wave * RPW;                                    // wave-uniform
     const bool first = row0 < hi;
     if (first) rowwork(row0 + rsub, row0 + rsub < hi, raw, y, u);  // first pass in front of the barrier that hands out t
     if (!euc) {
         __syncthreads();
-        t = (sh[0] + 2.0 * z * sh[1]) + 4.0 * sigma * sh[2];
+        double s3 = sh[2];
+        if (hetero && support) {                                   // the long constraints' share of <w, A(YY')>, in constraint order
+            const double* __restrict__ axc = cur ? a.Axb[1] : a.Axb[0];
+            for (int q = 0; q < a.nlong; ++q) { const int k = a.longk[q]; s3 += wl[q] * (axc[k] + a.b[k] + a.y[k] / sigma); }
+        }
+        t = (sh[0] + 2.0 * z * sh[1]) + 4.0 * sigma * s3;
     }
     if (first) finish(row0 + rsub, row0 + rsub < hi, raw, y, u);
     for (row0 += MSDP_WAVES * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
@@ -1346,7 +1288,7 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
         // entries touched by At; the restricted adjoint is used when they are few (<= 1/8 of the matrix)
         int64_t ns = 0;
         for (int64_t r = 0; r < nn; ++r) ns += rp[r + 1] > rp[r];
-        a.sup = nullptr; a.suprow = nullptr; a.nsup = 0; a.sqj = a.sqk = a.sqmore = nullptr; a.sqv = nullptr;
+        a.sup = nullptr; a.suprow = nullptr; a.nsup = 0; a.sqj = a.sqk = a.sqmore = nullptr; a.sqv = nullptr; a.rkx = nullptr;
         if (ns > 0 && ns * 8 <= nn) {
             std::vector<int> sup;
             sup.reserve((size_t)ns);
@@ -1358,11 +1300,18 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
             {
                 std::vector<int> sqj(sup.size()), sqk(sup.size()), sqmore(sup.size());
                 std::vector<double> sqv(sup.size());
+                std::vector<int> longno((size_t)m, -1);
+                { int ql = 0; for (int64_t k = 0; k < m; ++k) if (kit[k + 1] - kit[k] > FIN_SHORT) longno[k] = ql++; }
+                auto enc = [&](int k) { return longno[k] >= 0 ? -1 - longno[k] : k; };
                 for (size_t q = 0; q < sup.size(); ++q) {
                     const int64_t r = sup[q];
-                    sqj[q] = (int)(r % n); sqk[q] = rk[rp[r]]; sqv[q] = rv[rp[r]]; sqmore[q] = rp[r + 1] - rp[r] - 1;
+                    sqj[q] = (int)(r % n); sqk[q] = enc(rk[rp[r]]); sqv[q] = rv[rp[r]]; sqmore[q] = rp[r + 1] - rp[r] - 1;
                 }
-                if ((rc = up(h, sqj, &a.sqj)) || (rc = up(h, sqk, &a.sqk)) || (rc = up(h, sqv, &a.sqv)) || (rc = up(h, sqmore, &a.sqmore))) return rc;
+                std::vector<int> rkx(rk.size());
+                for (size_t t = 0; t < rk.size(); ++t) rkx[t] = enc(rk[t]);
+                if (rkx.empty()) rkx.push_back(0);
+                if ((rc = up(h, sqj, &a.sqj)) || (rc = up(h, sqk, &a.sqk)) || (rc = up(h, sqv, &a.sqv)) || (rc = up(h, sqmore, &a.sqmore)) ||
+                    (rc = up(h, rkx, &a.rkx))) return rc;
             }
             a.nsup = (int)ns;
         }
@@ -1462,6 +1411,8 @@ int msdp_dense_gemm_at(msdp_handle h, hipStream_t stream, int slab_first, int sl
                        const double* const* X, const double* scale, const int* active_flag, const double** slab_out,
                        int64_t* stride_out, int* SK_out);
 int msdp_sphere_hess_raw(msdp_handle h, const double* slab, int64_t stride, int SK);           // below
+int msdp_dense_gemm_side(msdp_handle h, const double* M, const double* X, double scale, const int* active_flag, SideJob sj,
+                         int* njobs_out, const double** slab_out, int64_t* stride_out, int* SK_out);   // msdp_dense.hip
 
 // k_sddmm has no reductions, so its grid follows the number of work items, not the number of rows
 static int sddmm_grid(const AffineDev& a, int ld) {
@@ -1746,7 +1697,7 @@ int msdp_affine_hess(msdp_handle h) {
     if (d.manifold != MANI_OBLIQUE && a.usym && d.ld <= 512 && sddmm1_ok(h, a, st->nnz)) {
         // sphere / Euclidean factor, SDDMM route, one rank: three launches + the contraction (k_sddmm1 mode 2, [adjoint,]
         // contraction, k_sph_hess_fused) instead of six
-        int G2 = 0;
+        int G2 = 0, hetero = 0;
         const bool support = a.nsup > 0;
         if (support && h->tune.affine_overlap) {
             // A/B (option affine_overlap): 2*eS*U needs neither w nor the sums -- it runs on a second stream beside k_sddmm1 and joins in
@@ -1764,16 +1715,28 @@ int msdp_affine_hess(msdp_handle h) {
             if ((rc = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 2, (double*)nullptr, sigma, &G2))) return rc;
             HIPCHK(hipStreamWaitEvent(h->stream, st->ev_join, 0));
         } else if (support) {
-            if ((rc = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 2, (double*)nullptr, sigma, &G2))) return rc;
-            const double* M[1] = {d.eS[cur]}; const double* X[1] = {d.md}; const double sc[1] = {2.0};
-            if ((rc = msdp_dense_gemm(h, 1, M, X, sc, act, &slab, &stride, &SK))) return rc;
+            // default: the SDDMM rides in the contraction launch as a side job (msdp_dense_gemm_side) -- where the shape allows it
+            rc = MSDP_EUNSUPPORTED;
+            if (h->tune.affine_side && a.nlong <= MSDP_WAVES) {
+                SideJob sj;
+                memset(&sj, 0, sizeof(sj));
+                sj.a = a; sj.Ya = Yf; sj.Yb = Uf; sj.Gr = d.Gr[cur]; sj.axc = a.Axb[cur]; sj.P = d.P; sj.sigma = sigma;
+                rc = msdp_dense_gemm_side(h, d.eS[cur], d.md, 2.0, act, sj, &G2, &slab, &stride, &SK);
+                if (rc == 0) hetero = 1;
+                else if (rc != MSDP_EUNSUPPORTED) return rc;
+            }
+            if (!hetero) {
+                if ((rc = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 2, (double*)nullptr, sigma, &G2))) return rc;
+                const double* M[1] = {d.eS[cur]}; const double* X[1] = {d.md}; const double sc[1] = {2.0};
+                if ((rc = msdp_dense_gemm(h, 1, M, X, sc, act, &slab, &stride, &SK))) return rc;
+            }
         } else {
             if ((rc = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 2, (double*)nullptr, sigma, &G2))) return rc;
             if ((rc = launch_adjoint(h, a, (const double*)nullptr, a.w, 1.0, d.AyU, act, 0, true))) return rc;
             const double* M[2] = {d.eS[cur], d.AyU}; const double* X[2] = {Uf, Yf}; const double sc[2] = {2.0, 4.0 * sigma};
             if ((rc = msdp_dense_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
         }
-        DISPATCH_LPR_A(k_sph_hess_fused, h, d.G, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0, cur);
+        DISPATCH_LPR_A(k_sph_hess_fused, h, d.G, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0, cur, hetero);
         HIPCHK(hipGetLastError());
         return 0;
     }

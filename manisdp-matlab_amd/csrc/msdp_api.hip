@@ -943,6 +943,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "halo_exchange")) { t.halo_exchange = value != 0; h->state_valid = false; }
     else if (!strcmp(name, "dense_pack")) { t.dense_pack = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "affine_fuse")) { t.affine_fuse = value != 0; h->chunk_len = 0; h->state_valid = false; }
+    else if (!strcmp(name, "affine_side")) { t.affine_side = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "affine_broute")) { t.affine_broute = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "dense_sym")) { t.dense_sym = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
     else if (!strcmp(name, "dense_sym_min")) { t.dense_sym_min = value > 0 ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }

@@ -149,6 +149,8 @@ struct Tuning {
     int dense_pack = 1;    // dense C*U reads the fragment-ordered copy of C (0: the row-major one; same results)
     int affine_fuse = 1;   // affine kinds, SDDMM route, one rank: A(Ya Yb') and its finish in ONE launch (k_sddmm1); sphere Hess-vec: the
                            //   sparse A'(w)*Y product, the slab sum and the projection in ONE launch (k_sph_hess_fused) (0: A/B, tests)
+    int affine_side = 1;   // sphere / Euclidean Hess-vec, SDDMM route, few touched entries: the SDDMM rides in the contraction launch as a side job
+                           //   (msdp_dense_gemm_side) instead of a launch of its own (0: A/B, tests)
     int affine_broute = 1; // affine Hess-vec, Gram route, symmetric data with short constraints: A'(A(.)) as one sparse matrix on the Gram matrix
                            //   (k_adjoint_gram) instead of k_gram_apply + k_adjoint_tiled (0: A/B, tests)
     int dense_sym = 1;     // symmetric dense operands (p <= 32, one rank): the contraction reads the upper triangle only

@@ -20,6 +20,7 @@
 // slice writes a partial slab with plain stores (deterministic, no fp64 atomics).
 // Kernel 2 (row-tiled epilogue): sums the slabs and applies the fused projection.
 #include "msdp_device.h"
+#include "msdp_affine_dev.h"
 #include <math.h>
 #include <algorithm>
 #include <cstdlib>
@@ -74,9 +75,8 @@ template <int NT> struct Dense3Cfg {
 // k-step reads one contiguous kilobyte per wave instead of sixteen 128-byte lines 8*nS bytes apart.  Same values into
 // the same MFMA sequence: results are bit-identical to the row-major form.
 template <int NT, bool PK>
-__global__ __launch_bounds__(Dense3Cfg<NT>::WAVES * 64, (NT <= 4 ? 3 : 1)) void k_dense_partial3(DenseOp op, const int* active_flag) {
+__device__ __forceinline__ void dense_partial3_body(const DenseOp& op, const int by) {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // 2 x KT x ldl + 128 (dummy slots)
-    if (active_flag && !*active_flag) return;
     typedef Dense3Cfg<NT> Cfg;
     constexpr int KT = Cfg::KT, HP = Cfg::HP, RPP = Cfg::RPP, NPASS = Cfg::NPASS, SS = Cfg::SS;
     constexpr int NTHR = Cfg::WAVES * 64;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(Dense3Cfg<NT>::WAVES * 64, (NT <= 4 ? 3 : 1)) void 
     const int arow = min(row0 + i, op.n_loc - 1);
     const int nS = op.nS;
     const int Ktot = op.nmat * nS;
-    int kbeg = blockIdx.y * op.kslice;
+    int kbeg = by * op.kslice;
     int kend = min(kbeg + op.kslice, Ktot);
     if (op.blk_lo) {
         // block-diagonal operands: outside the column range of the blocks this workgroup's rows belong to the matrices hold
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(Dense3Cfg<NT>::WAVES * 64, (NT <= 4 ? 3 : 1)) void 
         compute_tile(buf1, k0 + KT, A1);
         store_stg(buf0);
     }
-    double* out = op.slab + (int64_t)blockIdx.y * op.slab_stride;
+    double* out = op.slab + (int64_t)by * op.slab_stride;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = 16 * t + i;
@@ -220,6 +220,25 @@ __global__ __launch_bounds__(Dense3Cfg<NT>::WAVES * 64, (NT <= 4 ? 3 : 1)) void 
             if (row < op.n_loc && col < op.ncols) out[(int64_t)row * ld + op.colofs + col] = acc[t][r];
         }
     }
+}
+
+template <int NT, bool PK>
+__global__ __launch_bounds__(Dense3Cfg<NT>::WAVES * 64, (NT <= 4 ? 3 : 1)) void k_dense_partial3(DenseOp op, const int* active_flag) {
+    if (active_flag && !*active_flag) return;
+    dense_partial3_body<NT, PK>(op, (int)blockIdx.y);
+}
+// The same launch with a SIDE JOB in its first `side_rows` rows of workgroups (they are dispatched first): the SDDMM of the
+// sphere / Euclidean Hess-vec (msdp_affine_dev.h, msdp_sddmm_side) -- its chain of dependent round trips hides under the matrix
+// stream of the other workgroups instead of standing in front of it as a launch of its own.
+template <int NT, int LPR>
+__global__ __launch_bounds__(Dense3Cfg<NT>::WAVES * 64, 3) void k_dense_partial3_side(DenseOp op, const int* active_flag, SideJob sj, int side_rows) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (active_flag && !*active_flag) return;
+    if ((int)blockIdx.y < side_rows) {
+        msdp_sddmm_side<LPR, 1>(sj, (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, lds);
+        return;
+    }
+    dense_partial3_body<NT, false>(op, (int)blockIdx.y - side_rows);
 }
 
 // ---------------------------------------------------------------- epilogues (oblique)
@@ -515,6 +534,57 @@ int msdp_dense_gemm_at(msdp_handle h, hipStream_t stream, int slab_first, int sl
     *slab_out = h->slab;
     *stride_out = op.slab_stride;
     *SK_out = SK;
+    return 0;
+}
+
+// One-matrix contraction with the SDDMM side job (sphere Hess-vec on the SDDMM route; msdp_affine.hip).  *njobs_out = the number of
+// side workgroups (= entries of P_T1..P_T3).  MSDP_EUNSUPPORTED when the shape does not fit (p > 32, symmetric route, sharding):
+// the caller then launches k_sddmm1 and the plain contraction.
+int msdp_dense_gemm_side(msdp_handle h, const double* M, const double* X, double scale, const int* active_flag, SideJob sj,
+                         int* njobs_out, const double** slab_out, int64_t* stride_out, int* SK_out) {
+    Dev& d = h->d;
+    if (d.ld > 32 || h->nranks != 1 || h->use_comm || d.n_loc != d.n || msdp_densesym_eligible(h, 1) || (d.blk_lo && h->tune.block_skip)) return MSDP_EUNSUPPORTED;
+    DenseOp op;
+    memset(&op, 0, sizeof(op));
+    op.nmat = 1;
+    op.M[0] = M; op.X[0] = X; op.scale[0] = scale;
+    op.M[1] = M; op.X[1] = X; op.scale[1] = 0.0;
+    op.n = d.n; op.nS = msdp_dense_nS(d.n); op.n_loc = d.n_loc; op.ld = d.ld;
+    int SK; int64_t kslice; int row_blocks;
+    dense_plan(h, 1, &row_blocks, &SK, &kslice);
+    op.SK = SK; op.kslice = (int)kslice;
+    op.slab_stride = (int64_t)d.n * d.ld;
+    int rc = ensure_slab(h, (size_t)(SK + 1) * op.slab_stride);      // what msdp_dense_reserve has set aside (no allocation inside a capture)
+    if (rc) return rc;
+    op.slab = h->slab;
+    op.colofs = 0; op.ncols = d.ld;
+    const int ldl = dense_ldl(op.ncols);
+    op.ldl = ldl;
+    const int NT = (op.ncols + 15) / 16;
+    int half = d.ld / 2, lpr = 1;
+    while (lpr < half && lpr < 64) lpr <<= 1;
+    const int rows_wg = dense3_waves(NT) * 16;
+    const int gx = (d.n_loc + rows_wg - 1) / rows_wg;
+    // side workgroups: 4 waves x (64 / lpr) units per pass, about five passes each, at most 510 of them (partial-sum slots)
+    const int64_t nunits = (int64_t)sj.a.nshort + sj.a.nlit;
+    const int64_t per_job = (int64_t)4 * (64 / lpr) * 5;
+    int side_rows = (int)((nunits + per_job * gx - 1) / (per_job * gx));
+    if (side_rows < 1) side_rows = 1;
+    while (side_rows > 1 && side_rows * gx > 510) --side_rows;
+    if (side_rows * gx > 510) return MSDP_EUNSUPPORTED;
+    sj.njobs = side_rows * gx; sj.n_loc = d.n_loc; sj.ld = d.ld;
+    dim3 grid(gx, SK + side_rows), block(dense3_waves(NT) * 64);
+    const size_t lds = dense3_lds(NT, ldl);
+    if (NT == 2) hipLaunchKernelGGL((k_dense_partial3_side<2, 16>), grid, block, lds, h->stream, op, active_flag, sj, side_rows);
+    else switch (lpr) {
+        case 1: hipLaunchKernelGGL((k_dense_partial3_side<1, 1>), grid, block, lds, h->stream, op, active_flag, sj, side_rows); break;
+        case 2: hipLaunchKernelGGL((k_dense_partial3_side<1, 2>), grid, block, lds, h->stream, op, active_flag, sj, side_rows); break;
+        case 4: hipLaunchKernelGGL((k_dense_partial3_side<1, 4>), grid, block, lds, h->stream, op, active_flag, sj, side_rows); break;
+        default: hipLaunchKernelGGL((k_dense_partial3_side<1, 8>), grid, block, lds, h->stream, op, active_flag, sj, side_rows); break;
+    }
+    HIPCHK(hipGetLastError());
+    *njobs_out = sj.njobs;
+    *slab_out = h->slab; *stride_out = op.slab_stride; *SK_out = SK;
     return 0;
 }
 

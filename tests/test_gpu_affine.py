@@ -514,9 +514,9 @@ def test_fused_sddmm_and_sphere_epilogue_match_the_separate_launches(lib, monkey
     prob.y, prob.sigma = y, sigma
     f_ref = prob.cost(Y); G_ref = prob.grad(Y); H_ref = prob.hess(Y, U)
     out = []
-    for fuse in (1, 0):
+    for fuse, side in ((1, 1), (0, 0), (1, 0)):                # side: the SDDMM as a side job of the contraction launch (sphere, few touched entries)
         h = lib.Handle.affine(kind, At, b, c, n)
-        h.set_option("affine_fuse", fuse)
+        h.set_option("affine_fuse", fuse); h.set_option("affine_side", side)
         h.set_multipliers(y, sigma)
         h.set_point(Y)
         f, G, H = h.cost(), h.rgrad(), h.hessvec(U)
@@ -526,6 +526,7 @@ def test_fused_sddmm_and_sphere_epilogue_match_the_separate_launches(lib, monkey
         assert np.array_equal(H, h.hessvec(U))               # the arrival counter is back at zero, same bits
         out.append((f, G, H))
         h.close()
-    assert abs(out[0][0] - out[1][0]) <= 1e-13 * max(1.0, abs(f_ref))
-    assert _relerr(out[0][1], out[1][1]) < 1e-13
-    assert _relerr(out[0][2], out[1][2]) < 1e-12
+    for q in (1, 2):
+        assert abs(out[0][0] - out[q][0]) <= 1e-13 * max(1.0, abs(f_ref))
+        assert _relerr(out[0][1], out[q][1]) < 1e-13
+        assert _relerr(out[0][2], out[q][2]) < 1e-12

@@ -37,6 +37,8 @@ for name in names:
             h.set_option("graph", 0)
         if nofuse:
             h.set_option("affine_fuse", 0)
+        if "--noside" in args:
+            h.set_option("affine_side", 0)
         h.set_point(Y)
         H = h.hessvec(U)
         if ref is None:
