@@ -55,6 +55,10 @@ def test_size1_communicator_affine_is_bit_identical(kind_name):
         h = _lib.Handle.affine(kind, At, b, c, n)
         if use_comm:
             h.comm_init(1, 0, _lib.Handle.comm_unique_id())
+        else:
+            # round 4: a communicator-free handle takes the B route / the fused SDDMM (msdp_affine.hip), which a row-sharded one does
+            # not -- switched off here so that the comparison stays one of the communicator plumbing, bit for bit
+            h.set_option("affine_broute", 0); h.set_option("affine_fuse", 0)
         h.set_multipliers(y, 0.7)
         h.set_point(Y)
         f, G, H = h.cost(), h.rgrad(), h.hessvec(h.proj(U))
