@@ -928,6 +928,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "escape_start_y")) t.escape_start_y = value != 0;
     else if (!strcmp(name, "xpersist")) t.xpersist = value != 0;
     else if (!strcmp(name, "persist_refresh")) t.persist_refresh = value > 0 ? value : 0;
+    else if (!strcmp(name, "psync_backoff")) t.psync_backoff = value > 0 ? value : 0;
     else if (!strcmp(name, "affine_overlap")) { t.affine_overlap = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "trip1")) { t.trip1 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
     else if (!strcmp(name, "sweep")) { t.sweep = value < 0 ? 0 : (value > 2 ? 2 : value); choose_grid(h); h->chunk_len = 0; }
@@ -1580,6 +1581,7 @@ static void fill_ctl(msdp_handle h, const msdp_rtr_opts* o) {
     c->tolgradnorm = o->tolgradnorm; c->kappa = o->kappa; c->theta = o->theta;
     c->rho_prime = o->rho_prime; c->rho_reg = o->rho_regularization;
     c->persist_refresh = h->tune.persist_refresh;
+    c->psync_backoff = h->tune.psync_backoff;
     // trustregions.m:363-372; typicaldist: pi*sqrt(n) (ManiSDP_onlyunitdiag.m:137) or pi (spherefactory.m:111)
     // ... or sqrt(n*p) (euclideanfactory.m:57)
     const double typical = (h->d.manifold == MANI_OBLIQUE) ? M_PI * sqrt((double)h->d.n)

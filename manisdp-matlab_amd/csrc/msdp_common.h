@@ -37,6 +37,7 @@ struct Ctl {
     int hessvecs, accepted, rejected, cost_evals, last_stop_inner;
     int bench_mode;              // 1: tCG exits disabled (throughput measurement)
     int tcg_running;             // mirror of Frame.active for host polling
+    int psync_backoff;           // grid reductions of the persistent kernels: (s_sleep units of 64 cycles before the first poll) | (units after a failed poll) << 8
     int persist_refresh;         // persistent tCG (two-synchronisation trips): every this-many trips the product C*mdelta is
                                  //   gathered directly instead of assembled by linearity (0: never); msdp_persist.hip
 };
@@ -162,6 +163,7 @@ struct Tuning {
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
     int xpersist = 1;        // in-process ranks (msdp_comm_init_local), sparse C, oblique: ONE persistent tCG spanning the ranks' launches -- grid
                              //   reductions and row exchange through shared uncached memory, no collective per trip (msdp_persist.hip XR); 0: lock-step chunks
+    int psync_backoff = 0;   // see Ctl::psync_backoff (A/B)
     int persist_refresh = 32;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
     int affine_overlap = 0;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain.  Measured SLOWER (round 3: BQP d = 60
                              //   85 against 73 us, theta n = 5000 83 against 74 us per Hess-vec inside graph replays): every launch of the chain

@@ -143,6 +143,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     // directly (cmd starts afresh).  One extra barrier (1.5 us) per `refresh` trips; the schedule depends on the trip count only,
     // so every workgroup takes the same branch.
     const int refresh = c->persist_refresh;
+    const int backoff = c->psync_backoff;
     double2 eta[R], rr[R], md[LOWREG ? 1 : R], hmd[LOWREG ? 1 : R], cmd[TWOSYNC ? R : 1];
 #define VOFF(r) ((int64_t)ROW(r) * d.ld + 2 * sub)
 #define Y_GET(r) (LOWREG ? (OK(r) ? ld2(Yl + VOFF(r)) : zz) : Ys[(r) * PB + threadIdx.x])
@@ -304,7 +305,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             for (int r = 0; r < R; ++r) hrow(r);
         }
         TSTAMP(1);
-        if (!psync(slots, gen++, GS, 1, pd, u1, u2, sh, shb, err, bid)) { failed = true; break; }
+        if (!psync(slots, gen++, GS, 1, pd, u1, u2, sh, shb, err, bid, backoff)) { failed = true; break; }
         TSTAMP(2);
         const double d_Hd = pd;                                                        // :166
         alpha = z_r / d_Hd;                                                            // :170
@@ -345,7 +346,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         TSTAMP(3);
         if (TWOSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my residual rows are performed before I post
         TSTAMP(4);
-        if (!psync(slots, gen++, GS, 3, s1, s2, s3, sh, shb, err, bid)) { failed = true; break; }
+        if (!psync(slots, gen++, GS, 3, s1, s2, s3, sh, shb, err, bid, backoff)) { failed = true; break; }
         { const int jsave = j; (void)jsave; }
         TSTAMP(5);
         e_Pe = e_Pe_new;

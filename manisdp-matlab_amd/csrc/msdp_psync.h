@@ -47,7 +47,7 @@ __device__ __forceinline__ void st2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte
 // trace of the trip (profiles/r4_persist_timeline_p32.md) showed the three-value reduction at 2.75 us against 1.94 us for the
 // one-value one -- a poll of twelve loads per lane by one wave against four.  shb needs 8 doubles.
 __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, int G, int nv, double& a, double& b,
-                                      double& c, double* sh, double* shb, int* err, int bid_in = -1) {
+                                      double& c, double* sh, double* shb, int* err, int bid_in = -1, int backoff = 0) {
     const int bid = bid_in < 0 ? (int)blockIdx.x : bid_in;
     a = msdp_wave_sum(a);
     if (nv > 1) { b = msdp_wave_sum(b); c = msdp_wave_sum(c); }
@@ -71,6 +71,9 @@ __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, i
         double r0;
         int spins = 0;
         bool fail = false;
+        // A/B (option psync_backoff): nothing can be visible for the first half microsecond after the posts, and every poll of the 216
+        // workgroups is traffic the posts compete with -- sleep before the first poll and after a failed one
+        for (int q = 0; q < (backoff & 0xff); ++q) __builtin_amdgcn_s_sleep(1);
         for (;;) {
             // all slot loads of one poll are issued back to back with ONE wait (the compiler puts a full
             // s_waitcnt after every atomic load: serialized round trips, measured 20 us per sync)
@@ -98,6 +101,7 @@ __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, i
             ++spins;
             if (spins > PSYNC_SPIN_LIMIT ||
                 ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
+            for (int q = 0; q < ((backoff >> 8) & 0xff); ++q) __builtin_amdgcn_s_sleep(1);
         }
         r0 = msdp_wave_sum(r0);
         if (lane == 0) {

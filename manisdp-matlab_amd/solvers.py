@@ -444,6 +444,8 @@ def _affine_impl(kind, At, b, c, K, options, verbose, rng, defaults):
         _join_comm(h, comm)
     if "escape_method" in o:                               # 0 auto (Lanczos on the explicit S of these kinds), 1 Lanczos, 2 block eigen-solver
         h.set_option("escape_method", int(o["escape_method"]))
+    for name, value in (o.get("device_options") or {}).items():     # run-time switches of the handle (msdp_set_option): A/B runs, tests
+        h.set_option(name, int(value))
     topts = _rtr_opts(o)
     p = int(o["p0"])
     sigma = float(o["sigma0"])

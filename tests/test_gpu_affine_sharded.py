@@ -99,7 +99,9 @@ def test_size1_communicator_full_solve(kind_name):
     rng = np.random.default_rng(5)
     Y0 = _point(kind, n, 2 if kind_name == "unitdiag" else 1, rng)
     o = {"Y0": Y0, "tol": 1e-8, "AL_maxiter": 60}
-    Ya, obja, da = solve(At, b, c, K, dict(o), verbose=False)
+    # the communicator-free handle keeps the operator routes a row-sharded one takes (round 4's B route / fused SDDMM are one-rank
+    # forms): the comparison is one of the communicator plumbing, iterate for iterate
+    Ya, obja, da = solve(At, b, c, K, dict(o, device_options={"affine_broute": 0, "affine_fuse": 0}), verbose=False)
     Yb, objb, db = solve(At, b, c, K, dict(o, comm=(1, 0, _lib.Handle.comm_unique_id())), verbose=False)
     if kind_name == "unitdiag":
         assert da["iters"] == db["iters"] and da["hessvecs"] == db["hessvecs"]
