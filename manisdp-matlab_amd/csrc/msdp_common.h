@@ -163,7 +163,11 @@ struct Tuning {
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
     int xpersist = 1;        // in-process ranks (msdp_comm_init_local), sparse C, oblique: ONE persistent tCG spanning the ranks' launches -- grid
                              //   reductions and row exchange through shared uncached memory, no collective per trip (msdp_persist.hip XR); 0: lock-step chunks
-    int psync_backoff = 0;   // see Ctl::psync_backoff (A/B)
+    int psync_backoff = 19;  // grid reductions of the persistent kernels: s_sleep units (64 cycles) before the first poll | units after a
+                             //   failed poll << 8.  Round 4: nothing can be visible for the first half microsecond after the posts, and
+                             //   the polls of 216 workgroups are the traffic the posts compete with -- G81, p = 32: 8.03 us per trip
+                             //   with 0, 7.06 (14), 6.85 (18), 6.87 (20), 7.05 (24), 7.44 (32), 7.86 (40); p = 16: 6.87 -> 5.84
+                             //   (tools/psync_backoff_probe.py); sleeping between failed polls gains nothing
     int persist_refresh = 32;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
     int affine_overlap = 0;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain.  Measured SLOWER (round 3: BQP d = 60
                              //   85 against 73 us, theta n = 5000 83 against 74 us per Hess-vec inside graph replays): every launch of the chain

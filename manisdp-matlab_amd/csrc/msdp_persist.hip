@@ -448,7 +448,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         if (OK(r)) st2_sc1(rs_gp, ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, gpr);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the proposal's gradient rows are in place before the post
-    if (!psync(slots, gen++, GS, 3, pf, pgg, prd, sh, shb, err, bid)) return;
+    if (!psync(slots, gen++, GS, 3, pf, pgg, prd, sh, shb, err, bid, backoff)) return;
     {   // trustregions.m:548-729, identical in every workgroup (same bits in, same decision out)
         const double fp = pf, ggp = pgg;
         double rhonum = fx - fp;                                             // :548

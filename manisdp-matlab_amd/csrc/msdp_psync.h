@@ -8,7 +8,9 @@
 // Every workgroup posts its partials into PSYNC_REP replicas and polls replica (blockIdx & 7), i.e. the one of
 // its XCD under round-robin dispatch: 32 pollers per cache line instead of 256 (tools/microbench_sync.hip:
 // 3.03 -> 2.09 us per grid reduction at G = 256).  The barrier that carries no value uses 8 counters the same way.
+#ifndef PSYNC_REP
 #define PSYNC_REP 8
+#endif
 #define PSYNC_CNT_OFF ((size_t)PSYNC_GEN * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID)   // counters behind the slots, 64 B apart
 #define PSYNC_SENT 0xFFF8DEADBEEF0001ULL  // NaN payload no arithmetic produces
 #define PSYNC_SPIN_LIMIT (1 << 22)
@@ -73,7 +75,8 @@ __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, i
         bool fail = false;
         // A/B (option psync_backoff): nothing can be visible for the first half microsecond after the posts, and every poll of the 216
         // workgroups is traffic the posts compete with -- sleep before the first poll and after a failed one
-        for (int q = 0; q < (backoff & 0xff); ++q) __builtin_amdgcn_s_sleep(1);
+        const int first = (nv > 1 && ((backoff >> 16) & 0xff)) ? ((backoff >> 16) & 0xff) : (backoff & 0xff);     // bits 16..23: the three-value reductions' own figure
+        for (int q = 0; q < first; ++q) __builtin_amdgcn_s_sleep(1);
         for (;;) {
             // all slot loads of one poll are issued back to back with ONE wait (the compiler puts a full
             // s_waitcnt after every atomic load: serialized round trips, measured 20 us per sync)

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
             if (sub == 0 && rok) { pf += 0.5 * dot; eGp[row] = dot; }
         }
     }
-    if (!psync(sb, 0, d.G, 3, pf, pgg, prd, sh, shb, err)) return;
+    if (!psync(sb, 0, d.G, 3, pf, pgg, prd, sh, shb, err, -1, d.ctl->psync_backoff)) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) {                 // trustregions.m:548-729 (same arithmetic as k_rtr_decide)
         const int f_stop = d.F[0].stop, f_j = d.F[0].j;
         const double fp = pf, ggp = pgg;
