@@ -241,6 +241,8 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
             h.set_option("halo_exchange", 1)
     if "escape_method" in o:                               # 0 auto, 1 Lanczos, 2 block eigen-solver also below its size threshold
         h.set_option("escape_method", int(o["escape_method"]))
+    for name, value in (o.get("device_options") or {}).items():     # run-time switches of the handle (msdp_set_option): A/B runs, tests
+        h.set_option(name, int(value))
     topts = _rtr_opts(o)
     p = int(o["p0"])
     Y = o.get("Y0", None)

@@ -189,3 +189,34 @@ def test_asymmetric_dense_cost_keeps_the_full_kernel(lib):
         out.append(h.hessvec(U))
         h.close()
     assert np.array_equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2, 3])
+def test_trustregions_through_the_symmetric_contraction(lib, shape):
+    """A whole trustregions() call (graph-replayed tCG trips, retractions, cost evaluations) and a whole ManiSDP_onlyunitdiag solve with
+    every dense product on the upper-triangle route (forced below its size threshold) against the full kernel: same Hess-vec counts
+    and accept / reject sequence, costs and end points equal to rounding; the solve reaches the SDPLIB value of mcp250-1."""
+    import json
+    from conftest import golden_path
+    from manisdp_matlab_amd import problems, solvers
+    n, p = 1500, 24
+    C = problems.dense_unitdiag_cost(n, seed=11)
+    rng = np.random.default_rng(2)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    out = []
+    for sym in (2, 0):
+        h = lib.Handle.onlyunitdiag(C, pcap=p)
+        h.set_option("dense_sym", sym); h.set_option("dense_sym_rt", shape)
+        h.set_point(Y)
+        st = h.rtr(lib.default_opts(maxiter=8, maxinner=30, tolgradnorm=1e-9))
+        out.append(((st.hessvecs, st.accepted, st.rejected, st.iters), st.cost, h.get_point()))
+        h.close()
+    assert out[0][0] == out[1][0]
+    assert abs(out[0][1] - out[1][1]) <= 1e-11 * abs(out[1][1])
+    assert _relerr(out[0][2], out[1][2]) < 1e-8
+    if shape == 0:
+        known = json.load(open(golden_path("known_answers.json")))
+        At, b, c, K = problems.from_sdpa(golden_path("mcp250-1.dat-s.gz"))
+        Cm = c.toarray().reshape(K["s"], K["s"], order="F")
+        Yf, obj, data = solvers.ManiSDP_onlyunitdiag(Cm, {"device_options": {"dense_sym": 2}}, verbose=False)
+        assert data["dinf"] < 1e-8 and abs(-obj - known["mcp250-1"]) < 1e-6 * abs(known["mcp250-1"])
