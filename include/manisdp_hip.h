@@ -152,7 +152,10 @@ int msdp_create_affine(int32_t kind, int64_t n, int64_t m,
  * [N_i, N_i + n_i) and, when its own width p_i is smaller than p, rows p_i..p-1 of those columns are zero (zero
  * rows of a block stay zero under cost, gradient, Hess-vec, projection and retraction, so padding changes nothing).
  * Internally the problem is the unit-diagonal affine kind of order N whose constraint matrices are block diagonal,
- * with a per-row flag that switches the projection / normalisation terms off for the Euclidean blocks. */
+ * with a per-row flag that switches the projection / normalisation terms off for the Euclidean blocks.
+ * Storage: up to 15 blocks with N < 4096 the operands are embedded N x N arrays; beyond that every operand is the
+ * concatenation of its diagonal blocks (memory and work ~ sum n_i^2; environment MSDP_MULTIBLOCK_BLOCKED = 0 / 1 forces
+ * either form), msdp_get_dual_slack_block is then the way to read S and msdp_get_dual_slack returns MSDP_EUNSUPPORTED. */
 int msdp_create_multiblock(int32_t nb, const int64_t* block_n, int32_t nob, int64_t m,
                            const int64_t* at_jc, const int64_t* at_ir, const double* at_pr,
                            const double* b, const double* c, int32_t pcap, msdp_handle* out);
@@ -186,6 +189,9 @@ int msdp_release_cache(void);
  * the high-water mark of what was live together; arenas return to the driver only while no uncached block of the process is
  * live (beyond MSDP_UC_POOL_CAP bytes -- default 1 GiB -- when the last one is freed, all of them in msdp_release_cache). */
 int msdp_debug_pool_stats(int64_t* pool_bytes, int64_t* live_bytes, int64_t* arenas);
+/* Free and total bytes of the current device (hipMemGetInfo), for hosts and tests that size a problem or watch for leaks
+ * without a second HIP runtime in the process. */
+int msdp_debug_mem_info(int64_t* free_bytes, int64_t* total_bytes);
 
 /* AL state that changes between trustregions() calls: y and sigma
  * (ManiSDP_unitdiag.m:64,108-112).  No-op error for onlyunitdiag handles. */

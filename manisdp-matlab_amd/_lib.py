@@ -93,6 +93,7 @@ SIGNATURES = {
     "msdp_get_dual_slack_block": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
     "msdp_release_cache": (C.c_int, []),
     "msdp_debug_pool_stats": (C.c_int, [_P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
+    "msdp_debug_mem_info": (C.c_int, [_P(C.c_int64), _P(C.c_int64)]),
     "msdp_comm_init_local": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "msdp_get_point_all": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_z_all": (C.c_int, [C.c_void_p, _dp]),
@@ -160,6 +161,13 @@ def pool_stats():
     a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
     _check(load().msdp_debug_pool_stats(C.byref(a), C.byref(b), C.byref(c)))
     return a.value, b.value, c.value
+
+
+def mem_info():
+    """(free, total) bytes of the current device -- msdp_debug_mem_info."""
+    a, b = C.c_int64(), C.c_int64()
+    _check(load().msdp_debug_mem_info(C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def _check(rc):

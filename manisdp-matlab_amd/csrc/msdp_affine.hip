@@ -986,6 +986,85 @@ __global__ void k_cost_only(Dev d, double sigma, double* out) {
 }
 
 // ------------------------------------------------------------------ host side
+// ================================================================== multiblock kind, per-block storage (round 4)
+// ManiSDP_multiblock.m keeps X, S, C as cell arrays of blocks.  Rounds 2-3 embedded the direct sum into ONE dense N x N problem
+// (N = sum n_i): memory and work ~ N^2 -- 3.6 GB per operand at N = 21 100, impossible for thousands of small cliques.  Here
+// every dense operand (c, eS, A'(w), S) is the concatenation of its diagonal blocks, block i an n_i x nS_i row-major array
+// (nS_i = roundup(n_i, 16), zero pad columns): memory and work ~ sum n_i^2.  Row r of the direct sum lives at rbase[r]; its block
+// spans the rows [rlo[r], rhi[r]).  A(.) stays the SDDMM over (i, j) pairs; A'(.) walks the stored positions (CSR by position);
+// the contraction is one MFMA wave per 16-row tile of a block, no split-K, straight into slab 0 of the usual epilogues.
+struct BlockedDev {
+    int nb, N, ntile;
+    int64_t etot;                  // stored entries: sum n_i * nS_i
+    const int64_t* rbase;          // N: offset of the storage row of global row r
+    const int* rlo; const int* rhi; const int* rns;   // N: first / one-past-last row of r's block, its padded order
+    const int* prp;                // etot + 1: CSR by stored position -> (constraint, coefficient)
+    const int* prk; const double* prv;
+    const int* tile_row0;          // ntile: first row of every 16-row tile (tiles never straddle blocks)
+};
+struct BlockOp { const double* M[2]; const double* X[2]; double scale[2]; int nmat, ld, colofs, ncols; double* out; };
+
+// out[q] = (base ? base[q] : 0) + scale * sum_k At[(position q), k] * vec[k]   over all stored positions
+__global__ __launch_bounds__(256) void k_adjoint_blocked(BlockedDev bd, const double* __restrict__ base, const double* __restrict__ vec,
+                                                         double scale, double* __restrict__ out, const int* skip_flag, int skip_when) {
+    if (skip_flag && *skip_flag == skip_when) return;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < bd.etot; q += (int64_t)gridDim.x * blockDim.x) {
+        const int s0 = bd.prp[q], s1 = bd.prp[q + 1];
+        double acc = 0.0;
+        for (int t = s0; t < s1; ++t) acc = fma(bd.prv[t], vec[bd.prk[t]], acc);
+        out[q] = (base ? base[q] : 0.0) + scale * acc;
+    }
+}
+typedef double blk_d4 __attribute__((ext_vector_type(4)));
+// out(rows of a tile, :) = sum_m scale_m * M_m(block rows, block columns) * X_m(block rows, :): one wave per tile, A fragments
+// straight from the block's storage rows, B fragments straight from the panel rows (they stay in the L1 / L2 of the CU: a block's
+// panel is n_i x p doubles)
+template <int NT>
+__global__ __launch_bounds__(256) void k_block_contract(BlockedDev bd, BlockOp op, const int* active_flag) {
+    if (active_flag && !*active_flag) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= bd.ntile) return;
+    const int row0 = bd.tile_row0[tile];
+    const int lo = bd.rlo[row0], hi = bd.rhi[row0], ns = bd.rns[row0];
+    const int64_t abase = bd.rbase[min(row0 + i, hi - 1)] + 4 * g;
+    blk_d4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (blk_d4){0.0, 0.0, 0.0, 0.0};
+    for (int m = 0; m < op.nmat; ++m) {
+        const double* __restrict__ Mm = op.M[m] + abase;
+        const double* __restrict__ Xm = op.X[m];
+        const double sc = op.scale[m];
+        for (int k = 0; k < ns; k += 16) {
+            const double2 a01 = ld2(Mm + k), a23 = ld2(Mm + k + 2);
+            const double av[4] = {a01.x * sc, a01.y * sc, a23.x * sc, a23.y * sc};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int xr = lo + k + 4 * g + t;
+                const bool ok = xr < hi;                          // pad columns of the block hold zeros; keep the read inside the block
+                const double* xp = Xm + (int64_t)(ok ? xr : lo) * op.ld + op.colofs + i;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const double bv = (ok && 16 * nt + i < op.ncols) ? xp[16 * nt] : 0.0;
+                    acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = 16 * nt + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + g + 4 * r;
+            if (row < hi && col < op.ncols) op.out[(int64_t)row * op.ld + op.colofs + col] = acc[nt][r];
+        }
+    }
+}
+__global__ void k_sub_diag_blocked(BlockedDev bd, double* __restrict__ S, const double* __restrict__ zrow) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < bd.N; i += gridDim.x * blockDim.x) S[bd.rbase[i] + (i - bd.rlo[i])] -= zrow[i];
+}
+
 struct AffineState {
     AffineDev a{};
     int64_t nnz = 0;
@@ -993,6 +1072,8 @@ struct AffineState {
     double* Cdense = nullptr;      // n x nS
     double* d_y = nullptr;
     struct DualState* dual = nullptr;   // MSDP_KIND_DUAL_UNITDIAG (below)
+    BlockedDev* blk = nullptr;          // multiblock kind with per-block storage (msdp_affine_setup_blocked); host copies of the block offsets:
+    std::vector<int64_t> blk_r0, blk_off; std::vector<int> blk_n, blk_ns;
     // second stream of the Hess-vec: 2*eS*U does not depend on the A(.) / A'(.) chain and runs beside it (msdp_affine_hess)
     hipStream_t s2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -1000,6 +1081,7 @@ struct AffineState {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (s2) (void)hipStreamDestroy(s2);
+        delete blk;
     }
 };
 static void msdp_dual_release(struct DualState* ds);
@@ -1366,6 +1448,156 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
     return 0;
 }
 
+// Set-up of the multiblock kind with per-block storage.  jc / ir / pr: At over the CONCATENATED vecs of the blocks (ir = e0_i + a +
+// b*n_i, column-major inside block i); c likewise.  Nothing of size N^2 is built, on the host or on the device.
+int msdp_affine_setup_blocked(msdp_handle h, int nb, const int64_t* block_n, const int64_t* jc, const int64_t* ir, const double* pr,
+                              const double* b, const double* c) {
+    Dev& d = h->d;
+    const int N = d.n;
+    const int64_t m = d.m, nnz = jc[m];
+    if (nnz > 0x7fffffff) { msdp_set_error("nnz(At) too large"); return MSDP_EINVAL; }
+    AffineState* st = new AffineState();
+    g_aff.push_back({h, st});
+    AffineDev& a = st->a;
+    memset(&a, 0, sizeof(a));
+    a.n = N; a.nS = msdp_dense_nS(N); a.m = m;
+    st->nnz = nnz;
+    st->blk = new BlockedDev();
+    BlockedDev& bd = *st->blk;
+    std::vector<int64_t> r0((size_t)nb + 1, 0), e0((size_t)nb + 1, 0), off((size_t)nb + 1, 0);
+    std::vector<int> bn(nb), bns(nb);
+    for (int i = 0; i < nb; ++i) {
+        bn[i] = (int)block_n[i]; bns[i] = msdp_dense_nS(bn[i]);
+        r0[i + 1] = r0[i] + bn[i]; e0[i + 1] = e0[i] + (int64_t)bn[i] * bn[i]; off[i + 1] = off[i] + (int64_t)bn[i] * bns[i];
+    }
+    const int64_t etot = off[nb];
+    if (etot > 0x7fffffffLL) { msdp_set_error("multiblock: sum n_i^2 too large"); return MSDP_EUNSUPPORTED; }
+    st->blk_r0 = r0; st->blk_off = off; st->blk_n = bn; st->blk_ns = bns;
+    std::vector<int64_t> rbase(N);
+    std::vector<int> rlo(N), rhi(N), rns(N), tile_row0;
+    for (int i = 0; i < nb; ++i) {
+        for (int aa = 0; aa < bn[i]; ++aa) {
+            const int64_t r = r0[i] + aa;
+            rbase[r] = off[i] + (int64_t)aa * bns[i]; rlo[r] = (int)r0[i]; rhi[r] = (int)r0[i + 1]; rns[r] = bns[i];
+        }
+        for (int t = 0; t < bn[i]; t += 16) tile_row0.push_back((int)r0[i] + t);
+    }
+    // nonzeros: rows (i, j) of the direct sum, stored position
+    std::vector<int> cjc(m + 1), ci(nnz), cj(nnz), pos(nnz);
+    std::vector<double> cv(pr, pr + nnz);
+    for (int64_t k = 0; k <= m; ++k) cjc[k] = (int)jc[k];
+    std::vector<int> prp(etot + 1, 0);
+    for (int64_t t = 0; t < nnz; ++t) {
+        const int64_t e = ir[t];
+        if (e < 0 || e >= e0[nb]) { msdp_set_error("multiblock: At row index out of range"); return MSDP_EINVAL; }
+        const int i = (int)(std::upper_bound(e0.begin(), e0.end(), e) - e0.begin()) - 1;
+        const int64_t l = e - e0[i];
+        const int aa = (int)(l % bn[i]), bb = (int)(l / bn[i]);
+        ci[t] = (int)r0[i] + aa; cj[t] = (int)r0[i] + bb;
+        pos[t] = (int)(off[i] + (int64_t)aa * bns[i] + bb);
+        prp[pos[t] + 1]++;
+    }
+    for (int64_t q = 0; q < etot; ++q) prp[q + 1] += prp[q];
+    std::vector<int> prk(std::max<int64_t>(nnz, 1));
+    std::vector<double> prv(std::max<int64_t>(nnz, 1));
+    {
+        std::vector<int> fill(prp.begin(), prp.end() - 1);
+        for (int64_t k = 0; k < m; ++k)
+            for (int64_t t = jc[k]; t < jc[k + 1]; ++t) { const int q = fill[pos[t]]++; prk[q] = (int)k; prv[q] = pr[t]; }
+    }
+    // work items / units of the SDDMM (as msdp_affine_setup)
+    std::vector<int> it0, it1, kit(m + 1), longk, sk, lit0, lit1, lkit;
+    for (int64_t k = 0; k < m; ++k) {
+        kit[k] = (int)it0.size();
+        for (int t = cjc[k]; t < cjc[k + 1]; t += SDDMM_CHUNK) { it0.push_back(t); it1.push_back(std::min(t + SDDMM_CHUNK, cjc[k + 1])); }
+    }
+    kit[m] = (int)it0.size();
+    a.nitems = (int64_t)it0.size();
+    for (int64_t k = 0; k < m; ++k) {
+        if (kit[k + 1] - kit[k] > FIN_SHORT) {
+            longk.push_back((int)k);
+            lkit.push_back((int)lit0.size());
+            for (int q = kit[k]; q < kit[k + 1]; ++q) { lit0.push_back(it0[q]); lit1.push_back(it1[q]); }
+        } else sk.push_back((int)k);
+    }
+    lkit.push_back((int)lit0.size());
+    a.nlong = (int)longk.size(); a.nshort = (int)sk.size(); a.nlit = (int)lit0.size();
+    std::vector<int> us0((size_t)a.nshort + a.nlit + 1, 0), us1(us0.size(), 0), uk(us0.size(), 0);
+    for (int u = 0; u < a.nshort; ++u) { us0[u] = cjc[sk[u]]; us1[u] = cjc[sk[u] + 1]; uk[u] = sk[u]; }
+    for (int q = 0; q < a.nlit; ++q) { us0[a.nshort + q] = lit0[q]; us1[a.nshort + q] = lit1[q]; uk[a.nshort + q] = -1 - q; }
+    if (longk.empty()) longk.push_back(0);
+    if (sk.empty()) sk.push_back(0);
+    if (lit0.empty()) { lit0.push_back(0); lit1.push_back(0); }
+    if (it0.empty()) { it0.push_back(0); it1.push_back(0); }
+    if (ci.empty()) { ci.push_back(0); cj.push_back(0); cv.push_back(0.0); }
+    int rc;
+    if ((rc = up(h, it0, &a.it0)) || (rc = up(h, it1, &a.it1)) || (rc = up(h, kit, &a.kit)) || (rc = up(h, longk, &a.longk)) ||
+        (rc = up(h, sk, &a.sk)) || (rc = up(h, lit0, &a.lit0)) || (rc = up(h, lit1, &a.lit1)) || (rc = up(h, lkit, &a.lkit)) ||
+        (rc = up(h, us0, &a.us0)) || (rc = up(h, us1, &a.us1)) || (rc = up(h, uk, &a.uk)) ||
+        (rc = up(h, cjc, &a.cjc)) || (rc = up(h, ci, &a.ci)) || (rc = up(h, cj, &a.cj)) || (rc = up(h, cv, &a.cv)) ||
+        (rc = up(h, rbase, &bd.rbase)) || (rc = up(h, rlo, &bd.rlo)) || (rc = up(h, rhi, &bd.rhi)) || (rc = up(h, rns, &bd.rns)) ||
+        (rc = up(h, prp, &bd.prp)) || (rc = up(h, prk, &bd.prk)) || (rc = up(h, prv, &bd.prv)) || (rc = up(h, tile_row0, &bd.tile_row0)))
+        return rc;
+    bd.nb = nb; bd.N = N; bd.ntile = (int)tile_row0.size(); bd.etot = etot;
+    void* p = nullptr;
+    if ((rc = msdp_dev_alloc_bytes(h, &p, (size_t)std::max<int64_t>(a.nitems, 1) * sizeof(double)))) return rc;
+    a.ival = (double*)p;
+    if ((rc = msdp_dev_alloc_bytes(h, &p, 64))) return rc;
+    HIPCHK(hipMemset(p, 0, 64));
+    a.cnt = (unsigned*)p;
+    std::vector<double> bv(b, b + m);
+    if ((rc = up(h, bv, &a.b))) return rc;
+    if ((rc = msdp_dev_alloc_bytes(h, &p, m * sizeof(double)))) return rc;
+    st->d_y = (double*)p; a.y = st->d_y;
+    HIPCHK(hipMemset(st->d_y, 0, m * sizeof(double)));
+    if ((rc = msdp_dev_alloc_bytes(h, &p, m * sizeof(double)))) return rc;
+    a.w = (double*)p;
+    for (int s2 = 0; s2 < 2; ++s2) {
+        if ((rc = msdp_dev_alloc_bytes(h, &p, m * sizeof(double)))) return rc;
+        a.Axb[s2] = (double*)p;
+    }
+    // c, block by block, into the padded storage; eS, AyU start as zeros
+    const size_t msz = (size_t)etot * sizeof(double);
+    {
+        std::vector<double> cb((size_t)etot, 0.0);
+        for (int i = 0; i < nb; ++i)
+            for (int bb = 0; bb < bn[i]; ++bb)
+                for (int aa = 0; aa < bn[i]; ++aa) cb[(size_t)(off[i] + (int64_t)aa * bns[i] + bb)] = c[e0[i] + aa + (int64_t)bb * bn[i]];
+        if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
+        st->Cdense = (double*)p; d.Cd = st->Cdense;
+        HIPCHK(hipMemcpy(st->Cdense, cb.data(), msz, hipMemcpyHostToDevice));
+    }
+    for (int s2 = 0; s2 < 2; ++s2) {
+        if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
+        d.eS[s2] = (double*)p;
+        HIPCHK(hipMemset(d.eS[s2], 0, msz));
+    }
+    if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
+    d.AyU = (double*)p;
+    HIPCHK(hipMemset(d.AyU, 0, msz));
+    a.W = nullptr;
+    d.Sdual = d.AyU;
+    h->blocked = true;
+    h->dense_symmetric = false;
+    h->tune.affine_route = 1;                              // SDDMM: there is no N x N Gram matrix to form
+    h->h_ctl->sigma = 1.0;
+    return 0;
+}
+// One diagonal block of the dual slack (per-block storage): rows row0 .. row0 + nbk - 1 must be exactly one block
+int msdp_affine_get_block(msdp_handle h, int64_t row0, int64_t nbk, double* S) {
+    AffineState* st = astate(h);
+    if (!st || !st->blk) { msdp_set_error("get_block: not a handle with per-block storage"); return MSDP_ESTATE; }
+    for (size_t i = 0; i + 1 < st->blk_r0.size(); ++i)
+        if (st->blk_r0[i] == row0 && st->blk_n[i] == nbk) {
+            HIPCHK(hipMemcpy2DAsync(S, (size_t)nbk * sizeof(double), h->d.Sdual + st->blk_off[i], (size_t)st->blk_ns[i] * sizeof(double),
+                                    (size_t)nbk * sizeof(double), (size_t)nbk, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            return 0;
+        }
+    msdp_set_error("get_dual_slack_block: rows %lld..%lld are not one block of this handle", (long long)row0, (long long)(row0 + nbk));
+    return MSDP_EINVAL;
+}
+
 int msdp_affine_set_multipliers(msdp_handle h, const double* y, double sigma) {
     AffineState* st = astate(h);
     if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
@@ -1428,6 +1660,7 @@ static int sddmm_grid(const AffineDev& a, int ld) {
 // A(Ya Yb') -> item values.  SDDMM (gathers 2 p-wide rows per nonzero) or the Gram route (dense W = Ya*Yb' once,
 // one double per nonzero), whichever moves fewer bytes; the option affine_route (msdp_set_option) overrides.
 static bool use_gram_route(msdp_handle h, const AffineDev& a, int64_t nnz, int ld) {
+    if (AffineState* stb = astate(h)) if (stb->blk) return false;                 // per-block storage: there is no N x N Gram matrix
     if (h->tune.affine_route) return h->tune.affine_route == 2;
     const double sddmm_bytes = (double)nnz * ld * 16.0;
     const double gram_bytes = 2.0 * a.n * (double)a.nS * 8.0 + (double)nnz * 20.0;
@@ -1501,6 +1734,12 @@ static int adjoint_grid(const AffineDev& a) {
 // out = base + scale * At*vec.  `restricted_ok`: `out` already holds base (or 0) outside the entries At touches.
 static int launch_adjoint(msdp_handle h, const AffineDev& a, const double* base, const double* vec, double scale, double* out,
                           const int* flag, int when, bool restricted_ok) {
+    if (AffineState* stb = astate(h)) if (stb->blk) {
+        const int64_t g = std::min<int64_t>(4096, (stb->blk->etot + 255) / 256);
+        hipLaunchKernelGGL(k_adjoint_blocked, dim3((int)g), dim3(256), 0, h->stream, *stb->blk, base, vec, scale, out, flag, when);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (restricted_ok && a.nsup > 0) {
         int g = (a.nsup + 255) / 256;
         if (g > 4096) g = 4096;
@@ -1530,6 +1769,36 @@ static int launch_support_spmm(msdp_handle h, const AffineDev& a, const double* 
 }
 
 
+// The dense products of the closures: the MFMA contraction of msdp_dense.hip, or -- multiblock kind with per-block storage -- one
+// wave per 16-row tile of a block, written to slab 0 (SK = 1)
+int msdp_dense_ensure_slab(msdp_handle h, size_t need);
+static int affine_gemm(msdp_handle h, int nmat, const double* const* M, const double* const* X, const double* scale, const int* active_flag,
+                       const double** slab_out, int64_t* stride_out, int* SK_out) {
+    AffineState* st = astate(h);
+    if (!st || !st->blk) return msdp_dense_gemm(h, nmat, M, X, scale, active_flag, slab_out, stride_out, SK_out);
+    Dev& d = h->d;
+    const int64_t stride = (int64_t)d.n * d.ld;
+    int rc = msdp_dense_ensure_slab(h, (size_t)2 * stride);
+    if (rc) return rc;
+    BlockOp op;
+    memset(&op, 0, sizeof(op));
+    op.nmat = nmat; op.ld = d.ld; op.out = h->slab;
+    for (int m = 0; m < nmat; ++m) { op.M[m] = M[m]; op.X[m] = X[m]; op.scale[m] = scale[m]; }
+    const dim3 grid((st->blk->ntile + 3) / 4), block(256);
+    for (int colofs = 0; colofs < d.ld; colofs += 128) {
+        op.colofs = colofs; op.ncols = std::min(128, d.ld - colofs);
+        switch ((op.ncols + 15) / 16) {
+            case 1: hipLaunchKernelGGL(k_block_contract<1>, grid, block, 0, h->stream, *st->blk, op, active_flag); break;
+            case 2: hipLaunchKernelGGL(k_block_contract<2>, grid, block, 0, h->stream, *st->blk, op, active_flag); break;
+            case 3: hipLaunchKernelGGL(k_block_contract<3>, grid, block, 0, h->stream, *st->blk, op, active_flag); break;
+            case 4: hipLaunchKernelGGL(k_block_contract<4>, grid, block, 0, h->stream, *st->blk, op, active_flag); break;
+            default: hipLaunchKernelGGL(k_block_contract<8>, grid, block, 0, h->stream, *st->blk, op, active_flag); break;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    *slab_out = h->slab; *stride_out = stride; *SK_out = 1;
+    return 0;
+}
 // cost + gradient state at Y[slot]:  w = A(YY'), Axb, eS, eS*Y, C*Y  (see header comment)
 // ------------------------------------------------------------------ Row sharding of the affine kinds
 // The rows of Y, U, G, H are split over the ranks as for the other kinds; the OPERATOR state is replicated: every rank
@@ -1575,7 +1844,7 @@ int msdp_affine_costgrad(msdp_handle h, int slot) {
     const double* slab; int64_t stride; int SK;
     {
         const double* M[1] = {d.Cd + roff}; const double* X[1] = {Yf}; const double sc[1] = {1.0};
-        int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
+        int rc = affine_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
         if (rc) return rc;
         DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 1.0, (double*)nullptr, (double*)nullptr, P_S1);
         HIPCHK(hipGetLastError());
@@ -1592,7 +1861,7 @@ int msdp_affine_costgrad(msdp_handle h, int slot) {
         HIPCHK(hipGetLastError());
     } else {
         const double* M[1] = {d.eS[slot] + roff}; const double* X[1] = {Yf}; const double sc[1] = {1.0};
-        int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
+        int rc = affine_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
         if (rc) return rc;
         DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 2.0, d.Gr[slot], d.eG[slot], P_S2);
         HIPCHK(hipGetLastError());
@@ -1690,7 +1959,7 @@ int msdp_affine_hess(msdp_handle h) {
         const double* M[2] = {d.eS[cur] + roff, d.AyU + roff};
         const double* X[2] = {Uf, Yf};
         const double sc[2] = {2.0, 4.0 * sigma};
-        if ((rc = msdp_dense_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
+        if ((rc = affine_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
         if (d.manifold == MANI_OBLIQUE) return msdp_dense_hess_epilogue_obl(h, slab, stride, SK);
         return msdp_sphere_hess_raw(h, slab, stride, SK);
     }
@@ -1728,13 +1997,13 @@ int msdp_affine_hess(msdp_handle h) {
             if (!hetero) {
                 if ((rc = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 2, (double*)nullptr, sigma, &G2))) return rc;
                 const double* M[1] = {d.eS[cur]}; const double* X[1] = {d.md}; const double sc[1] = {2.0};
-                if ((rc = msdp_dense_gemm(h, 1, M, X, sc, act, &slab, &stride, &SK))) return rc;
+                if ((rc = affine_gemm(h, 1, M, X, sc, act, &slab, &stride, &SK))) return rc;
             }
         } else {
             if ((rc = launch_A(h, a, st->nnz, Yf, Uf, act, 0, 2, (double*)nullptr, sigma, &G2))) return rc;
             if ((rc = launch_adjoint(h, a, (const double*)nullptr, a.w, 1.0, d.AyU, act, 0, true))) return rc;
             const double* M[2] = {d.eS[cur], d.AyU}; const double* X[2] = {Uf, Yf}; const double sc[2] = {2.0, 4.0 * sigma};
-            if ((rc = msdp_dense_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
+            if ((rc = affine_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
         }
         DISPATCH_LPR_A(k_sph_hess_fused, h, d.G, d, a, slab, stride, SK, sigma, G2, support ? 1 : 0, cur, hetero);
         HIPCHK(hipGetLastError());
@@ -1748,7 +2017,7 @@ int msdp_affine_hess(msdp_handle h) {
         const double* M[1] = {d.eS[cur]};
         const double* X[1] = {d.md};
         const double sc[1] = {2.0};
-        if ((rc = msdp_dense_gemm(h, 1, M, X, sc, act, &slab, &stride, &SK))) return rc;
+        if ((rc = affine_gemm(h, 1, M, X, sc, act, &slab, &stride, &SK))) return rc;
         double* extra = const_cast<double*>(slab) + (int64_t)SK * stride;
         if ((rc = launch_support_spmm(h, a, (const double*)a.w, (const double*)d.Y[cur], 4.0 * sigma, extra, act, 0))) return rc;
         ++SK;
@@ -1757,7 +2026,7 @@ int msdp_affine_hess(msdp_handle h) {
         const double* M[2] = {d.eS[cur] + roff, d.AyU + roff};
         const double* X[2] = {Uf, Yf};
         const double sc[2] = {2.0, 4.0 * sigma};
-        if ((rc = msdp_dense_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
+        if ((rc = affine_gemm(h, 2, M, X, sc, act, &slab, &stride, &SK))) return rc;
     }
     if (d.manifold == MANI_OBLIQUE) return msdp_dense_hess_epilogue_obl(h, slab, stride, SK);
     return msdp_sphere_hess_raw(h, slab, stride, SK);
@@ -1808,7 +2077,7 @@ int msdp_affine_linesearch_cost(msdp_handle h, const double* Yt, double* val) {
     { int rc0 = launch_A(h, a, st->nnz, Yf, Yf, (const int*)nullptr, 0, 1, a.Axb[other], sigma); if (rc0) return rc0; }
     const double* slab; int64_t stride; int SK;
     const double* M[1] = {d.Cd + (size_t)d.row0 * a.nS}; const double* X[1] = {Yf}; const double sc[1] = {1.0};
-    int rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
+    int rc = affine_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK);
     if (rc) return rc;
     DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Yt, slab, stride, SK, 1.0, (double*)nullptr, (double*)nullptr, P_S1);
     HIPCHK(hipGetLastError());
@@ -1851,7 +2120,7 @@ int msdp_affine_al_primal(msdp_handle h, double* obj, double* Ax_host) {
     if ((rc = launch_A(h, a, st->nnz, Yf, Yf, (const int*)nullptr, 0, 0, (double*)nullptr, 1.0))) return rc;
     const double* slab; int64_t stride; int SK;
     const double* M[1] = {d.Cd + (size_t)d.row0 * a.nS}; const double* X[1] = {Yf}; const double sc[1] = {1.0};
-    if ((rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK))) return rc;
+    if ((rc = affine_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK))) return rc;
     DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 1.0, (double*)nullptr, (double*)nullptr, P_S1);
     HIPCHK(hipGetLastError());
     if ((rc = msdp_allreduce_partials(h, P_S1, 1))) return rc;
@@ -1883,7 +2152,7 @@ int msdp_affine_al_dual(msdp_handle h, const double* y_host, double* z_host) {
     if (rc) return rc;
     const double* slab; int64_t stride; int SK;
     const double* M[1] = {d.Sdual + (size_t)d.row0 * a.nS}; const double* X[1] = {Yf}; const double sc[1] = {1.0};
-    if ((rc = msdp_dense_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK))) return rc;
+    if ((rc = affine_gemm(h, 1, M, X, sc, nullptr, &slab, &stride, &SK))) return rc;
     DISPATCH_LPR_A(k_rowdot_slabs, h, d.G, d, Ys, slab, stride, SK, 1.0, (double*)nullptr, d.W0, P_S2);
     HIPCHK(hipGetLastError());
     if (d.manifold == MANI_OBLIQUE) {
@@ -1895,7 +2164,8 @@ int msdp_affine_al_dual(msdp_handle h, const double* y_host, double* z_host) {
             if ((rc = msdp_allgather_vec(h, d.W0, h->full_buf, cap))) return rc;
             zall = h->full_buf;
         }
-        hipLaunchKernelGGL(k_sub_diag, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, a.n, a.nS, d.Sdual, zall, (const double*)nullptr);
+        if (st->blk) hipLaunchKernelGGL(k_sub_diag_blocked, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, *st->blk, d.Sdual, zall);
+        else hipLaunchKernelGGL(k_sub_diag, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, a.n, a.nS, d.Sdual, zall, (const double*)nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(z_host, zall, (size_t)a.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     } else {

@@ -39,6 +39,9 @@ int msdp_dense_setup(msdp_handle h, const double* C);
 int msdp_dense_reserve(msdp_handle h, int nmat);
 int msdp_dense_setup_synthetic(msdp_handle h, uint64_t seed);
 void msdp_affine_release(msdp_handle h);
+int msdp_affine_setup_blocked(msdp_handle h, int nb, const int64_t* block_n, const int64_t* jc, const int64_t* ir, const double* pr,
+                              const double* b, const double* c);        // msdp_affine.hip: multiblock kind, per-block storage
+int msdp_affine_get_block(msdp_handle h, int64_t row0, int64_t nbk, double* S);
 void msdp_densesym_release(msdp_handle h);                  // msdp_densesym.hip
 int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam, double* V, double* lmax, int* iters,
                      const double* Mdev);
@@ -169,6 +172,13 @@ extern "C" int msdp_debug_pool_stats(int64_t* pool_bytes, int64_t* live_bytes, i
     if (pool_bytes) *pool_bytes = (int64_t)uc_pool_bytes_locked();
     if (live_bytes) *live_bytes = (int64_t)live;
     if (arenas) *arenas = (int64_t)g_uc_arenas.size();
+    return 0;
+}
+extern "C" int msdp_debug_mem_info(int64_t* free_bytes, int64_t* total_bytes) {
+    size_t f = 0, t = 0;
+    if (hipMemGetInfo(&f, &t) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("hipMemGetInfo failed"); return MSDP_EHIP; }
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
     return 0;
 }
 template <typename T>
@@ -539,6 +549,33 @@ extern "C" int msdp_create_multiblock(int32_t nb, const int64_t* block_n, int32_
         e0[i + 1] = e0[i] + block_n[i] * block_n[i];
     }
     const int64_t N = r0[nb], E = e0[nb], nnz = at_jc[m];
+    // Per-block storage (round 4): every dense operand is the concatenation of its diagonal blocks, memory and work ~ sum n_i^2.
+    // Default from 16 blocks or N >= 4096 on; MSDP_MULTIBLOCK_BLOCKED = 0 / 1 forces the embedded N x N form / this one (tests).
+    bool blocked = nb >= 16 || N >= 4096;
+    if (const char* e = getenv("MSDP_MULTIBLOCK_BLOCKED")) { if (*e == '0') blocked = false; else if (*e == '1') blocked = true; }
+    if (blocked) {
+        if (N > 0x3fffffff) { msdp_set_error("multiblock: total order too large"); return MSDP_EUNSUPPORTED; }
+        msdp_handle hb = nullptr;
+        int rcb = new_handle(MSDP_KIND_UNITDIAG, N, &hb);
+        if (rcb) return rcb;
+        hb->d.costkind = COST_AFFINE;
+        hb->d.m = m;
+        if ((rcb = alloc_common(hb)) || (rcb = msdp_affine_setup_blocked(hb, nb, block_n, at_jc, at_ir, at_pr, b, c)) ||
+            (rcb = msdp_alloc_vectors(hb, pcap > 0 ? pcap : 32))) { msdp_destroy(hb); return rcb; }
+        hb->kind = MSDP_KIND_MULTIBLOCK;
+        std::vector<unsigned char> rfb((size_t)N, 0);
+        bool anyb = false;
+        for (int i = nob; i < nb; ++i)
+            for (int64_t a = r0[i]; a < r0[i + 1]; ++a) { rfb[(size_t)a] = 1; anyb = true; }
+        if (anyb) {
+            unsigned char* drf = nullptr;
+            if ((rcb = dev_alloc<unsigned char>(hb, &drf, (size_t)N))) { msdp_destroy(hb); return rcb; }
+            if (hipMemcpy(drf, rfb.data(), (size_t)N, hipMemcpyHostToDevice) != hipSuccess) { msdp_set_error("multiblock: upload failed"); msdp_destroy(hb); return MSDP_EHIP; }
+            hb->d.rowfree = drf;
+        }
+        *out = hb;
+        return 0;
+    }
     if (N > 46000) { msdp_set_error("multiblock: total order %lld too large for the embedded dense representation", (long long)N); return MSDP_EUNSUPPORTED; }
     // embed: entry (a, b) of block i -> entry (r0_i + a, r0_i + b) of the N x N direct sum (column-major vec index)
     auto embed = [&](int64_t e, int64_t* g) -> bool {
@@ -2319,6 +2356,7 @@ extern "C" int msdp_get_dual_slack(msdp_handle h, double* S) {
     CHECK_H(h);
     if (!S) { msdp_set_error("get_dual_slack: null argument"); return MSDP_EINVAL; }
     if (h->d.costkind != COST_AFFINE || !h->dual_valid) { msdp_set_error("get_dual_slack: call msdp_al_dual first"); return MSDP_ESTATE; }
+    if (h->blocked) { msdp_set_error("get_dual_slack: this multiblock handle stores its blocks only (msdp_get_dual_slack_block)"); return MSDP_EUNSUPPORTED; }
     const int n = h->d.n, nS = msdp_dense_nS(n);
     HIPCHK(hipMemcpy2DAsync(S, (size_t)n * sizeof(double), h->d.Sdual, (size_t)nS * sizeof(double), (size_t)n * sizeof(double), n,
                             hipMemcpyDeviceToHost, h->stream));
@@ -2332,6 +2370,7 @@ extern "C" int msdp_get_dual_slack_block(msdp_handle h, int64_t row0, int64_t nb
     if (h->d.costkind != COST_AFFINE || !h->dual_valid) { msdp_set_error("get_dual_slack_block: call msdp_al_dual first"); return MSDP_ESTATE; }
     const int n = h->d.n, nS = msdp_dense_nS(n);
     if (row0 < 0 || nb < 1 || row0 + nb > n) { msdp_set_error("get_dual_slack_block: rows %lld..%lld outside 0..%d", (long long)row0, (long long)(row0 + nb), n); return MSDP_EINVAL; }
+    if (h->blocked) return msdp_affine_get_block(h, row0, nb, S);
     HIPCHK(hipMemcpy2DAsync(S, (size_t)nb * sizeof(double), h->d.Sdual + (size_t)row0 * nS + row0, (size_t)nS * sizeof(double),
                             (size_t)nb * sizeof(double), (size_t)nb, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -240,6 +240,7 @@ struct msdp_handle_s {
     size_t snap_cap = 0;
     int snap_p = 0;
     double* slab = nullptr;        // split-K partial slabs of the dense MFMA path
+    bool blocked = false;          // multiblock kind with per-block storage: no N x N operand exists (msdp_affine.hip)
     bool dense_symmetric = false;  // every dense operand of the contraction (C, eS, AyU) is symmetric (checked at set-up)
     unsigned long long* trace_buf = nullptr;   // device buffer behind Dev::trace (msdp_debug_persist_trace)
     void* symplans = nullptr;      // work-item plans of the symmetric contraction (msdp_densesym.hip)

@@ -447,6 +447,7 @@ static void dense_plan(msdp_handle h, int nmat, int* row_blocks_out, int* SK_out
 // Reserve the split-K slab for the current p BEFORE any graph capture (hipMalloc is illegal
 // while a stream is capturing).
 int msdp_dense_reserve(msdp_handle h, int nmat) {
+    if (h->blocked) return ensure_slab(h, (size_t)2 * h->d.n * (size_t)h->d.ld);      // per-block contraction: slab 0 only (msdp_affine.hip)
     // room for the plans of 1..nmat matrices plus one extra slab (the affine Hess-vec appends the sparse A'(w)*Y
     // product as one more slab when At touches few entries)
     int SKmax = 1;

@@ -26,6 +26,26 @@ def lib():
     return _lib
 
 
+@pytest.fixture(params=["embedded", "blocked"], autouse=True)
+def storage(request, monkeypatch):
+    """Every test of this module runs on both representations of the direct sum: the N x N embedding of rounds 2-3 and the
+    per-block storage of round 4 (msdp_affine_setup_blocked: memory and work ~ sum n_i^2), which is the default from 16 blocks
+    or N = 4096 on."""
+    monkeypatch.setenv("MSDP_MULTIBLOCK_BLOCKED", "1" if request.param == "blocked" else "0")
+    return request.param
+
+
+def _dual_slack(h, r0, nset, storage):
+    """S as a dense N x N array: in one piece from the embedded form, block by block from the per-block storage."""
+    if storage == "embedded":
+        return h.get_dual_slack()
+    N = int(r0[-1])
+    S = np.zeros((N, N))
+    for i, n in enumerate(nset):
+        S[r0[i]:r0[i + 1], r0[i]:r0[i + 1]] = h.get_dual_slack_block(int(r0[i]), int(n))
+    return S
+
+
 def _random_multiblock(nset, m, seed):
     """SeDuMi data over the concatenated vecs of the blocks: symmetric constraint matrices with a few entries each,
     some of them touching two blocks, dense symmetric costs."""
@@ -49,7 +69,7 @@ def _random_multiblock(nset, m, seed):
     return At, rng.standard_normal(m), np.concatenate(c)
 
 
-def test_multiblock_operators(lib):
+def test_multiblock_operators(lib, storage):
     from oracle import manisdp_ref as R
     from manisdp_matlab_amd.solvers import _pack_blocks
     nset, nob, p = [30, 17, 24], 2, [4, 3, 5]
@@ -85,7 +105,7 @@ def test_multiblock_operators(lib):
     x = prob._x(Y)
     assert abs(obj - c @ x) <= 1e-11 * max(1.0, abs(c @ x)) and _relerr(Ax, prob.A @ x) < 1e-11
     z = h.al_dual(y)
-    S = h.get_dual_slack()
+    S = _dual_slack(h, r0, nset, storage)
     cy = c - prob.At @ y
     for i, n in enumerate(nset):
         Si = cy[prob.off[i]:prob.off[i + 1]].reshape((n, n), order="F")
@@ -213,21 +233,42 @@ def test_multiblock_sparse_quartic_matches_oracle(lib, opts):
     assert abs(obj - objr) <= 10 * opts["tol"] * max(1.0, abs(objr))
 
 
-def test_dual_slack_block_getter(lib):
-    """msdp_get_dual_slack_block: the diagonal blocks the multiblock host loop reads, against the full N x N download."""
+def test_dual_slack_block_getter(lib, storage, monkeypatch):
+    """msdp_get_dual_slack_block: the diagonal blocks the multiblock host loop reads, against the full N x N download of the
+    embedded form (which the per-block storage does not offer: its blocks are checked against the embedded handle's)."""
     At, b, c = _random_multiblock([30, 17, 24], 40, seed=1)
     nset = [30, 17, 24]
-    h = lib.Handle.multiblock(At, b, c, nset, 2)
+    r0 = np.concatenate([[0], np.cumsum(nset)])
     rng = np.random.default_rng(0)
     Y = rng.standard_normal((sum(nset), 4)); Y[:47] /= np.linalg.norm(Y[:47], axis=1, keepdims=True)
-    h.set_multipliers(0.1 * rng.standard_normal(b.size), 0.5)
-    h.set_point(Y)
-    h.cost()
-    h.al_dual(0.1 * rng.standard_normal(b.size))
-    S = h.get_dual_slack()
-    r0 = np.concatenate([[0], np.cumsum(nset)])
-    for i, nb in enumerate(nset):
-        assert np.array_equal(h.get_dual_slack_block(r0[i], nb), S[r0[i]:r0[i + 1], r0[i]:r0[i + 1]])
+    y0, y1 = 0.1 * rng.standard_normal(b.size), 0.1 * rng.standard_normal(b.size)
+
+    def prepared():
+        h = lib.Handle.multiblock(At, b, c, nset, 2)
+        h.set_multipliers(y0, 0.5)
+        h.set_point(Y)
+        h.cost()
+        h.al_dual(y1)
+        return h
+
+    h = prepared()
+    blocks = [h.get_dual_slack_block(r0[i], nb) for i, nb in enumerate(nset)]
+    if storage == "embedded":
+        S = h.get_dual_slack()
+        for i, nb in enumerate(nset):
+            assert np.array_equal(blocks[i], S[r0[i]:r0[i + 1], r0[i]:r0[i + 1]])
+    else:
+        monkeypatch.setenv("MSDP_MULTIBLOCK_BLOCKED", "0")
+        he = prepared()
+        S = he.get_dual_slack()
+        he.close()
+        for i, nb in enumerate(nset):
+            ref = S[r0[i]:r0[i + 1], r0[i]:r0[i + 1]]
+            assert np.abs(blocks[i] - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max())
+        with pytest.raises(lib.MsdpError):
+            h.get_dual_slack()
+        with pytest.raises(lib.MsdpError):
+            h.get_dual_slack_block(10, 30)          # not a block of the direct sum
     with pytest.raises(lib.MsdpError):
         h.get_dual_slack_block(60, 20)
     h.close()
@@ -256,3 +297,79 @@ def test_block_skip_gives_the_same_results(lib):
         h.close()
     for x, yv in zip(*out):
         assert np.array_equal(np.asarray(x), np.asarray(yv))
+
+
+def _stacked_maxcut(nblk, n, seed):
+    """Direct sum of `nblk` scaled copies of one random MaxCut-like block of order n (unit diagonal everywhere, one trivial
+    constraint <E_00, X_1> = 1 as in _direct_sum): the optimum is sum s_i * opt(block)."""
+    rng = np.random.default_rng(seed)
+    C0 = rng.standard_normal((n, n)); C0 = (C0 + C0.T) / 2; np.fill_diagonal(C0, 0.0)
+    scale = 1.0 + (np.arange(nblk) % 2)
+    c = np.concatenate([(s * C0).reshape(-1) for s in scale])
+    At = sp.csc_matrix(([1.0], ([0], [0])), shape=(nblk * n * n, 1))
+    return C0, scale, At, np.array([1.0]), c
+
+
+def test_blocked_storage_matches_the_embedding(lib, storage, monkeypatch):
+    """The two representations of one direct sum: cost, gradient, Hess-vec, A(YY'), the dual step and a trustregions() call
+    agree to rounding (different summation orders, so not bit for bit)."""
+    if storage == "embedded":
+        pytest.skip("one comparison, run from the blocked leg")
+    rng = np.random.default_rng(2)
+    nset = [int(v) for v in rng.integers(5, 70, size=9)]
+    At, b, c = _random_multiblock(nset, 120, seed=4)
+    N, p = sum(nset), 5
+    nob = 6
+    r0 = np.concatenate([[0], np.cumsum(nset)])
+    Y = rng.standard_normal((N, p)); Y[:r0[nob]] /= np.linalg.norm(Y[:r0[nob]], axis=1, keepdims=True)
+    U = rng.standard_normal((N, p))
+    y = 0.1 * rng.standard_normal(b.size)
+    out = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MSDP_MULTIBLOCK_BLOCKED", mode)
+        h = lib.Handle.multiblock(At, b, c, nset, nob)
+        h.set_multipliers(y, 0.5)
+        h.set_point(Y)
+        f, G, H = h.cost(), h.rgrad(), h.hessvec(h.proj(U))
+        ax = h.al_primal(b.size)
+        z = h.al_dual(y)
+        Sb = [h.get_dual_slack_block(r0[i], n) for i, n in enumerate(nset)]
+        st = h.rtr(lib.default_opts(maxiter=3, maxinner=15, tolgradnorm=1e-9))
+        out.append([f, G, H, np.concatenate([[ax[0]], ax[1]]), z, np.concatenate([s.ravel() for s in Sb]),
+                    st.cost, h.get_point()])
+        h.close()
+    for i, (x, r) in enumerate(zip(*out)):
+        x, r = np.asarray(x, dtype=float), np.asarray(r, dtype=float)
+        tol = 1e-12 if i < 6 else 1e-8
+        assert np.abs(x - r).max() <= tol * max(1.0, np.abs(r).max()), i
+
+
+def test_thousand_blocks_of_order_60(lib, storage):
+    """N = 60 000 in 1000 blocks.  The embedding would need an N x N contraction (28.8 GB dense); the
+    per-block storage holds sum n_i^2 = 3.6e6 entries, is created in < 2 s, and the reference's multiblock loop solves it to
+    the sum of the per-block optima."""
+    if storage == "embedded":
+        pytest.skip("the embedding refuses N = 60 000 with a dense cost (N^2 doubles)")
+    import time
+    from manisdp_matlab_amd import solvers
+    nblk, n = 1000, 60
+    C0, scale, At, b, c = _stacked_maxcut(nblk, n, seed=0)
+    lib.load()
+    free0 = lib.mem_info()[0]
+    t0 = time.perf_counter()
+    h = lib.Handle.multiblock(At, b, c, [n] * nblk, nblk)
+    t_create = time.perf_counter() - t0
+    held = free0 - lib.mem_info()[0]
+    h.close()
+    assert t_create < 2.0, t_create
+    # sum n_i^2 doubles = 28.8 MB of S, plus the factor-sized work arrays and the slabs: two orders below the embedding's 28.8 GB
+    assert held < 1.5e9, held
+    opts = dict(tol=1e-7, p0=[4] * nblk, AL_maxiter=60, seed=0)
+    Y, obj, d = solvers.ManiSDP_multiblock(At, b, c, dict(s=[n] * nblk, nob=nblk), dict(opts), verbose=False)
+    # one block on its own: X_11 = 1 is implied by the unit diagonal, so the block optimum is the plain MaxCut-like SDP
+    _, obj1, d1 = solvers.ManiSDP_onlyunitdiag(C0, dict(tol=1e-9, p0=4, seed=0), verbose=False)
+    assert d1["status"] == 0
+    ref = scale.sum() * obj1
+    assert max(d["gap"], d["pinf"], d["dinf"]) < 1e-6, d
+    assert abs(obj - ref) <= 1e-5 * abs(ref), (obj, ref)
+    assert len(Y) == nblk and all(Yi.shape[0] == n for Yi in Y)
