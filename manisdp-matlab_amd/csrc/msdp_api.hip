@@ -228,6 +228,11 @@ static void choose_grid(msdp_handle h) {
     if (h->tune.grid > 0) G = std::min((gmax / 8) * 8, std::max(8, ((h->tune.grid + 7) / 8) * 8));    // A/B switch
     d.G = G;
     d.sweep = (h->tune.sweep >= 2 || (h->tune.sweep == 1 && (int64_t)rows_capacity(h) * d.ld >= ((int64_t)1 << 21))) ? 1 : 0;
+    // bit 1: streaming (nt) accesses for the operands a gather launch touches once -- from 3 * 2^22 vector entries on (96 MB:
+    // n = 250 000 at p = 32 loses 14 % with them, p = 64 and n = 10^6 at p = 16 gain 17 %), or with sweep = 3; bits 4-7: 64-row
+    // steps per workgroup and window of the stand-alone Hess-vec, minus one
+    if (d.sweep && (h->tune.sweep == 3 || (h->tune.sweep == 1 && (int64_t)rows_capacity(h) * d.ld >= ((int64_t)3 << 22)))) d.sweep |= 2;
+    if (d.sweep && h->tune.sweep_k > 1) d.sweep |= (std::min(h->tune.sweep_k, 16) - 1) << 4;
 }
 
 // (Re)allocate every n_loc x ld vector for factor widths up to pcap.
@@ -968,7 +973,8 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "psync_backoff")) t.psync_backoff = value > 0 ? value : 0;
     else if (!strcmp(name, "affine_overlap")) { t.affine_overlap = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "trip1")) { t.trip1 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
-    else if (!strcmp(name, "sweep")) { t.sweep = value < 0 ? 0 : (value > 2 ? 2 : value); choose_grid(h); h->chunk_len = 0; }
+    else if (!strcmp(name, "sweep_k")) { t.sweep_k = value < 1 ? 1 : value; choose_grid(h); h->chunk_len = 0; }
+    else if (!strcmp(name, "sweep")) { t.sweep = value < 0 ? 0 : (value > 3 ? 3 : value); choose_grid(h); h->chunk_len = 0; }
     else if (!strcmp(name, "trip2")) { t.trip2 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
     else if (!strcmp(name, "escape_method")) { if (value < 0 || value > 2) { msdp_set_error("escape_method: 0 auto, 1 lanczos, 2 block"); return MSDP_EINVAL; } t.escape_method = value; }
     else if (!strcmp(name, "be_width")) { if (value != 0 && value != 32 && value != 64 && value != 128) { msdp_set_error("be_width: 0, 32, 64 or 128"); return MSDP_EINVAL; } t.be_width = value; }

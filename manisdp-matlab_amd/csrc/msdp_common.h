@@ -172,7 +172,8 @@ struct Tuning {
     int affine_overlap = 0;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain.  Measured SLOWER (round 3: BQP d = 60
                              //   85 against 73 us, theta n = 5000 83 against 74 us per Hess-vec inside graph replays): every launch of the chain
                              //   already fills the chip, the fork / join only adds dependencies.  Kept as an A/B switch, default off.
-    int sweep = 1;           // windowed row traversal of the large-vector gather kernels: 1 = from 2^21 vector entries per rank on, 2 always, 0 never
+    int sweep_k = 2;         // 64-row steps a workgroup takes per window of the traversal (window = 32 * 64 * sweep_k rows per XCD)
+    int sweep = 1;           // windowed row traversal of the large-vector gather kernels: 1 = from 2^21 vector entries per rank on (streaming accesses from 3 * 2^22 on), 2 always / without streaming accesses, 3 always / with them, 0 never
     int trip1 = 1;           // msdp_trip1.hip (sparse C / oblique): row-sharded handles -- one exchange + one all-reduce per tCG trip instead of one + two;
                              // one rank, chunked path -- the same two launches (14 vector passes, one gathered vector); 0: never
     int trip2 = 1;           // chunked path, sparse C / oblique / one rank: two launches per tCG trip (msdp_trip2.hip) instead of three

@@ -178,6 +178,17 @@ __device__ __forceinline__ void msdp_sum_partials3_block(const double* P, int w0
 
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 __device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
+// streaming accesses (nt: the line is not kept by the L2 beyond its use) for the operands a gather kernel touches exactly once,
+// so that the rows other workgroups gather stay resident
+typedef double msdp_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld2_nt(const double* p) {
+    const msdp_d2v v = __builtin_nontemporal_load(reinterpret_cast<const msdp_d2v*>(p));
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void st2_nt(double* p, double2 v) {
+    const msdp_d2v w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<msdp_d2v*>(p));
+}
 
 // Publish tCG progress to the host-mapped status word (one relaxed system-scope store by
 // the lead thread): the host polls it to decide whether to enqueue another chunk.

@@ -90,36 +90,60 @@ __device__ __forceinline__ void hess_sparse_obl_body(const Dev& d) {
     double pd = 0.0;
     // vectors beyond the L2s (option sweep): the workgroups of an XCD walk ONE window of rows together, so that a row fetched
     // as somebody's neighbour is still in the L2 when its owner reaches it (msdp_sweep_rows; round 3 measured 1.32 x the
-    // algorithmic bytes at n = 10^6 with the chunked order -- the far grid neighbours' rows were fetched twice)
+    // algorithmic bytes at n = 10^6 with the chunked order -- the far grid neighbours' rows were fetched twice).  Round 4:
+    // the window alone left 1.30 x (PMC); with streaming (nt) accesses for what the launch touches once -- Y, the output --
+    // the L2 keeps the gathered rows and the launch moves 1.00 x the algorithmic bytes (0.841 GB at n = 10^6, p = 32), and with
+    // two 64-row steps per workgroup and window 242 -> 215 us.  What is left is not traffic: a software-pipelined form of this
+    // loop (next step's loads in flight during the gather wait) was SLOWER (263 us), four steps per window and four row steps in
+    // flight per wave change nothing -- the time follows the request count through the L2 (1.9 KB per row against 0.84 KB
+    // from HBM), not the bytes from HBM.
     int stride = MSDP_WAVES * RPW;
-    if (d.sweep) msdp_sweep_rows(d.n_loc, d.G, MSDP_WAVES * RPW, lo, hi, stride);
-    for (int row0 = lo + wave * RPW; row0 < hi; row0 += stride) {
-        const int row = row0 + rsub;
-        if (row < hi) {
-            double2 acc[NCH], y[NCH], u[NCH];
+    const int K = d.sweep ? ((d.sweep >> 4) & 15) + 1 : 1;       // 64-row steps per block of the windowed traversal
+    if (d.sweep) msdp_sweep_rows(d.n_loc, d.G, K * MSDP_WAVES * RPW, lo, hi, stride);
+    const bool nt = (d.sweep & 2) != 0;
+    // two row steps per trip of the loop: the loads of both are issued before either is consumed (the loop is a chain of two
+    // dependent round trips -- (col, val) -> neighbour rows -- and 16 waves per CU do not cover it at HBM latency)
+    constexpr int UN = 2;
+    auto step_row = [&](int t) { return lo + (K == 1 ? t * stride : (t / K) * stride + (t % K) * (MSDP_WAVES * RPW)) + wave * RPW; };
+    for (int t = 0; step_row(t) < hi; t += UN) {
+        double2 acc[UN][NCH], y[UN][NCH], u[UN][NCH];
+        double eg[UN];
+        int rows[UN];
+        bool rok[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int row = step_row(t + q) + rsub;
+            rok[q] = row < hi;
+            rows[q] = rok[q] ? row : lo;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                acc[ch] = make_double2(0.0, 0.0);
+                acc[q][ch] = make_double2(0.0, 0.0);
                 const int col = 2 * sub + ch * 2 * LPR;
                 const bool ok = col < d.ld;
-                y[ch] = ok ? ld2(Yl + (int64_t)row * d.ld + col) : make_double2(0.0, 0.0);
-                u[ch] = ok ? ld2(Ul + (int64_t)row * d.ld + col) : make_double2(0.0, 0.0);
+                const int64_t o = (int64_t)rows[q] * d.ld + (ok ? col : 0);
+                y[q][ch] = nt ? ld2_nt(Yl + o) : ld2(Yl + o);
+                u[q][ch] = ld2(Ul + o);
+                if (!ok) { y[q][ch] = make_double2(0.0, 0.0); u[q][ch] = make_double2(0.0, 0.0); }
             }
-            const double eg = eG[row];
-            spmm_row<LPR, NCH, ELL>(d, row, sub, Uf, acc);
+            eg[q] = eG[rows[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < UN; ++q) spmm_row<LPR, NCH, ELL>(d, rows[q], sub, Uf, acc[q]);
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
             double dot = 0.0;
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) dot += acc[ch].x * y[ch].x + acc[ch].y * y[ch].y;
+            for (int ch = 0; ch < NCH; ++ch) dot += acc[q][ch].x * y[q][ch].x + acc[q][ch].y * y[q][ch].y;
             dot = msdp_group_sum<LPR>(dot);          // sum(Y.*eH)
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int col = 2 * sub + ch * 2 * LPR;
-                if (col < d.ld) {
+                if (col < d.ld && rok[q]) {
                     double2 h;
-                    h.x = acc[ch].x - y[ch].x * dot - u[ch].x * eg;
-                    h.y = acc[ch].y - y[ch].y * dot - u[ch].y * eg;
-                    st2(H + (int64_t)row * d.ld + col, h);
-                    pd += u[ch].x * h.x + u[ch].y * h.y;
+                    h.x = acc[q][ch].x - y[q][ch].x * dot - u[q][ch].x * eg[q];
+                    h.y = acc[q][ch].y - y[q][ch].y * dot - u[q][ch].y * eg[q];
+                    if (nt) st2_nt(H + (int64_t)rows[q] * d.ld + col, h); else st2(H + (int64_t)rows[q] * d.ld + col, h);
+                    pd += u[q][ch].x * h.x + u[q][ch].y * h.y;
                 }
             }
         }

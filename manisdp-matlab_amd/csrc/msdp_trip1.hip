@@ -256,6 +256,9 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg1_head(Dev d) {
     double pd = 0.0;
     int stride = MSDP_WAVES * RPW;
     if (d.sweep) msdp_sweep_rows(d.n_loc, d.G, MSDP_WAVES * RPW, lo, hi, stride);     // (the streaming loop above keeps the chunks)
+    // streaming (nt) accesses for what this launch touches once -- Y, mdelta, H mdelta, eG -- so that the L2 keeps the rows of
+    // the gathered vector (hess_sparse_obl_body, msdp_kernels.hip)
+    const bool nt = (d.sweep & 2) != 0;
     for (int row0 = lo + wave * RPW; row0 < hi; row0 += stride) {
         const int row = row0 + rsub;
         if (row < hi) {
@@ -267,8 +270,8 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg1_head(Dev d) {
                 const int col = 2 * sub + ch * 2 * LPR;
                 const bool ok = col < d.ld;
                 const int64_t o = (int64_t)row * d.ld + col;
-                y[ch] = ok ? ld2(Yl + o) : make_double2(0.0, 0.0);
-                u[ch] = ok ? ld2(d.md + o) : make_double2(0.0, 0.0);
+                y[ch] = ok ? (nt ? ld2_nt(Yl + o) : ld2(Yl + o)) : make_double2(0.0, 0.0);
+                u[ch] = ok ? ((nt && !DIRECT) ? ld2_nt(d.md + o) : ld2(d.md + o)) : make_double2(0.0, 0.0);
                 x[ch] = u[ch];                                                          // the row the product is taken of
                 if (!DIRECT) {
                     x[ch] = ok ? ld2(rn + o) : make_double2(0.0, 0.0);                  // r' (tangent)
@@ -294,12 +297,12 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_tcg1_head(Dev d) {
                     hq.y = acc[ch].y - y[ch].y * dot - x[ch].y * eg;
                     if (!DIRECT) {
                         // Hess is linear on the tangent space: Hess(mdelta') = Hess(r') + beta * Hess(mdelta)
-                        const double2 ho = ld2(H + o);
+                        const double2 ho = nt ? ld2_nt(H + o) : ld2(H + o);
                         hq.x = fma(beta, ho.x, hq.x); hq.y = fma(beta, ho.y, hq.y);
                         u[ch].x -= y[ch].x * udot; u[ch].y -= y[ch].y * udot;            // :283
-                        st2(d.md + o, u[ch]);
+                        if (nt) st2_nt(d.md + o, u[ch]); else st2(d.md + o, u[ch]);
                     }
-                    st2(H + o, hq);
+                    if (nt) st2_nt(H + o, hq); else st2(H + o, hq);
                     pd += u[ch].x * hq.x + u[ch].y * hq.y;
                 }
             }

@@ -420,7 +420,7 @@ def test_windowed_row_traversal_of_the_standalone_operators(lib, shape, p):
     Y, _ = _rand_point(n, p, seed=4)
     U = np.random.default_rng(9).standard_normal((n, p))
     out = []
-    for sweep in (2, 0):
+    for sweep in (2, 3, 0):                # 3: the software-pipelined streaming form of the Hess-vec (k_hess_ell_stream*)
         h = lib.Handle.onlyunitdiag(C, pcap=p)
         h.set_option("sweep", sweep)
         if p == 40:
@@ -428,9 +428,10 @@ def test_windowed_row_traversal_of_the_standalone_operators(lib, shape, p):
         h.set_point(Y)
         out.append((h.cost(), h.rgrad(), h.hessvec(U), h.get_z()))
         h.close()
-    a, b = out
-    assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0])
-    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    a, a3, b = out
+    for a in (a, a3):
+        assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0])
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
     prob = R._OnlyUnitDiagProblem(C, n, p)
     prob.cost(Y)
     assert np.linalg.norm(a[2] - prob.hess(Y, U)) <= 1e-12 * np.linalg.norm(a[2])

@@ -13,7 +13,7 @@ for rows, cols, p in cases:
     rng = np.random.default_rng(p)
     Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
     out = {}
-    for sweep in (2, 0):
+    for sweep in (3, 2, 0):
         h = _lib.Handle.onlyunitdiag(C, pcap=p)
         h.set_option("persist", 0); h.set_option("sweep", sweep)
         h.set_point(Y)
@@ -21,5 +21,5 @@ for rows, cols, p in cases:
         ms, by, fl = h.bench_hessvec(50)
         out[sweep] = (t * 1e3, ms * 1e3)
         h.close()
-    print("grid %dx%d n=%d p=%d: trip windowed %.1f us / chunked %.1f us; S*U windowed %.1f / chunked %.1f us"
-          % (rows, cols, n, p, out[2][0], out[0][0], out[2][1], out[0][1]), flush=True)
+    print("grid %dx%d n=%d p=%d: trip windowed+nt %.1f us / windowed %.1f us / chunked %.1f us; S*U %.1f / %.1f / %.1f us"
+          % (rows, cols, n, p, out[3][0], out[2][0], out[0][0], out[3][1], out[2][1], out[0][1]), flush=True)
