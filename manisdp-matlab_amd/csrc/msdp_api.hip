@@ -973,6 +973,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "psync_backoff")) t.psync_backoff = value > 0 ? value : 0;
     else if (!strcmp(name, "affine_overlap")) { t.affine_overlap = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "trip1")) { t.trip1 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
+    else if (!strcmp(name, "dense_sk")) t.dense_sk = value < 0 ? 0 : value;
     else if (!strcmp(name, "sweep_k")) { t.sweep_k = value < 1 ? 1 : value; choose_grid(h); h->chunk_len = 0; }
     else if (!strcmp(name, "sweep")) { t.sweep = value < 0 ? 0 : (value > 3 ? 3 : value); choose_grid(h); h->chunk_len = 0; }
     else if (!strcmp(name, "trip2")) { t.trip2 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }

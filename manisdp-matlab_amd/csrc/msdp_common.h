@@ -172,6 +172,7 @@ struct Tuning {
     int affine_overlap = 0;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain.  Measured SLOWER (round 3: BQP d = 60
                              //   85 against 73 us, theta n = 5000 83 against 74 us per Hess-vec inside graph replays): every launch of the chain
                              //   already fills the chip, the fork / join only adds dependencies.  Kept as an A/B switch, default off.
+    int dense_sk = 0;        // A/B switch: number of k slices of the dense contraction (0 = the plan's choice)
     int sweep_k = 2;         // 64-row steps a workgroup takes per window of the traversal (window = 32 * 64 * sweep_k rows per XCD)
     int sweep = 1;           // windowed row traversal of the large-vector gather kernels: 1 = from 2^21 vector entries per rank on (streaming accesses from 3 * 2^22 on), 2 always / without streaming accesses, 3 always / with them, 0 never
     int trip1 = 1;           // msdp_trip1.hip (sparse C / oblique): row-sharded handles -- one exchange + one all-reduce per tCG trip instead of one + two;

@@ -424,13 +424,24 @@ static void dense_plan(msdp_handle h, int nmat, int* row_blocks_out, int* SK_out
     {
         const int ncols = std::min(128, d.ld);
         const int NT = (ncols + 15) / 16;
-        const double cap = (double)dense3_capacity(NT, dense_ldl(ncols));
+        double cap = (double)dense3_capacity(NT, dense_ldl(ncols));
+        // The affine kinds feed the slabs to epilogues that are chains of dependent launches and row sums (k_sph_hess_fused,
+        // k_dense_hess_epi_obl behind the adjoint): there every slab costs more than its bytes, and two workgroups per CU stream
+        // a 30-200 MB operand as fast as five.  Round 4, tools/affine_chain_probe.py --sk=..: theta n = 5000 16 slabs 67.5 us,
+        // 6-12 slabs 61-62 us; BQP d = 60 29 slabs 59.6 us, 16 slabs 56.5 us (the dense kinds keep the full-occupancy plan:
+        // tools/dense_sk_probe.py has it within 1-5 % of the best slice count at n = 1000..20000, p = 16..64)
+        if (d.costkind == COST_AFFINE) {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cus = 256; }
+            cap = std::min(cap, 2.0 * cus);
+        }
         double best = 1e300;
         SK = 1; kslice = ((Ktot + 15) / 16) * 16;
         for (int cand = 1; cand <= 32; ++cand) {
+            if (h->tune.dense_sk > 0 && cand != h->tune.dense_sk) continue;      // A/B switch: this many k slices
             int64_t ks = (Ktot + cand - 1) / cand;
             ks = ((ks + 63) / 64) * 64;                       // whole tile pairs
-            if (ks < 128 && cand > 1) break;
+            if (ks < 128 && cand > 1 && h->tune.dense_sk <= 0) break;
             const int sk = (int)((Ktot + ks - 1) / ks);
             const double W = (double)row_blocks * sk;
             const double rounds = ceil(W / cap);

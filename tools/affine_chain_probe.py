@@ -31,7 +31,13 @@ for name in names:
     ref = None
     combos = [(1, 1, 0, 0)] if profile else ([(1, 1, 0, 0), (1, 1, 0, 1), (1, 0, 0, 0)] if quick else
                                              [(0, 0, 0, 0), (0, 1, 0, 0), (2, 0, 1, 0), (2, 1, 1, 0), (2, 1, 2, 0), (2, 1, 3, 0), (1, 1, 0, 0), (1, 1, 0, 1)])
-    for sym, br, rt, ov in combos:
+    sks = [int(a[5:]) for a in args if a.startswith("--sk=")]
+    if sks:
+        combos = [(1, 1, 0, 0, k) for k in [0] + sks]
+    else:
+        combos = [c4 + (0,) for c4 in combos]
+    for sym, br, rt, ov, sk in combos:
+        h.set_option("dense_sk", sk)
         h.set_option("dense_sym", sym); h.set_option("affine_broute", br); h.set_option("dense_sym_rt", rt); h.set_option("affine_overlap", ov)
         if profile:
             h.set_option("graph", 0)
@@ -46,6 +52,6 @@ for name in names:
         err = np.linalg.norm(H - ref) / np.linalg.norm(ref)
         for _ in range(2):
             ms, by, fl = h.bench_hessvec(100)
-        print("  dense_sym=%d broute=%d shape=%d overlap=%d: %.1f us  (%.2f TB/s algorithmic = %.3f of HBM)  diff vs first %.1e" %
-              (sym, br, rt, ov, ms * 1e3, by / ms / 1e9, by / ms / 1e9 / 8.0, err), flush=True)
+        print("  dense_sym=%d broute=%d shape=%d overlap=%d sk=%d: %.1f us  (%.2f TB/s algorithmic = %.3f of HBM)  diff vs first %.1e" %
+              (sym, br, rt, ov, sk, ms * 1e3, by / ms / 1e9, by / ms / 1e9 / 8.0, err), flush=True)
     h.close()
