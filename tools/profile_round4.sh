@@ -4,7 +4,7 @@
 # own passes (--kernel-trace + --pmc only); graphs are off (rocprofv3 7.2 crashes on graph replay).
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof4
-rm -rf "$OUT"; mkdir -p "$OUT"
+mkdir -p "$OUT"
 export MSDP_NO_GRAPH=1
 cd /tmp && export TMPDIR=/tmp
 stats() {   # stats <tag> <timeout> python3 args...
@@ -23,25 +23,26 @@ both() {    # both <tag> <timeout> python3 args...   (FETCH_SIZE and WRITE_SIZE 
     pmc ${tag}_fetch $to FETCH_SIZE "$@"
     pmc ${tag}_write $to WRITE_SIZE "$@"
 }
-WHAT=${1:-all}
-if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
+WHAT=" ${*:-all} "     # one or more of: bench dense affine sparse (default: all)
+want() { [[ "$WHAT" == *" all "* || "$WHAT" == *" $1 "* ]]; }
+if want bench; then
 stats bench 400 python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-kkt --no-dense --no-affine --no-large-sparse
 both persist 120 python3 "$ROOT/tools/pmc_probe.py" 32
 fi
-if [ "$WHAT" = all ] || [ "$WHAT" = dense ]; then
+if want dense; then
 stats dense20000 300 python3 "$ROOT/tools/dense_probe.py" 20000 16 32 64
 both dense20000p16 300 python3 "$ROOT/tools/dense_probe.py" 20000 16
 both dense20000p32 300 python3 "$ROOT/tools/dense_probe.py" 20000 32
 fi
-if [ "$WHAT" = all ] || [ "$WHAT" = affine ]; then
+if want affine; then
 stats bqp60_p32 300 python3 "$ROOT/tools/gram_probe.py" 32
 both bqp60 300 python3 "$ROOT/tools/gram_probe.py" 32
 stats theta5000 300 python3 "$ROOT/tools/theta_probe.py" 32
 both theta5000 300 python3 "$ROOT/tools/theta_probe.py" 32
 fi
-if [ "$WHAT" = all ] || [ "$WHAT" = sparse ]; then
-stats hess1e6 300 python3 "$ROOT/tools/hess_large_probe.py" 1000 32
-both hess1e6 300 python3 "$ROOT/tools/hess_large_probe.py" 1000 32
+if want sparse; then
+stats hess1e6 300 python3 "$ROOT/tools/hess_large_probe.py" 1000 32 --sweep=1
+both hess1e6 300 python3 "$ROOT/tools/hess_large_probe.py" 1000 32 --sweep=1
 stats linear1e6 300 python3 "$ROOT/tools/pmc_probe_large.py" 1000 1000 32
 fi
 cd "$ROOT"
