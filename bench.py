@@ -553,6 +553,10 @@ def main():
                 "vector_passes_per_trip": npass,
                 "roofline": secondary_roofline("k_tcg1_upd + k_tcg1_head", trip_us, algo, 0.0,
                                                ("r4_pmc_linear_n1e6_p32.json", "r3_pmc_linear_n1e6_p32.json"), bound="hbm", per="tCG trip")}
+            # the stand-alone S*U launch of the same handle (k_hess_ell_obl: windowed traversal, streaming accesses for Y and the output)
+            out["large_sparse_trip"]["standalone_hessvec"] = {
+                "kernel_us": msl * 1e3,
+                "roofline": secondary_roofline("k_hess_ell_obl", msl * 1e3, byl, fll, ("r4_pmc_hess_n1e6_p32.json",), bound="hbm", per="launch")}
             rec = out["large_sparse_trip"]["roofline"]
             rec["formulation_bytes"] = formulation
             rec["formulation_GBps"] = formulation / (trip_us * 1e-6) / 1e9
