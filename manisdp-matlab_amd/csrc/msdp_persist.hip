@@ -279,8 +279,32 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         // ---- Hmdelta = proj(C*mdelta) - mdelta.*eG   (tCG.m:163, ManiSDP_onlyunitdiag.m:127-130)
         double pd = 0.0, u1 = 0.0, u2 = 0.0;
         TSTAMP(0);
+        // all R * EW gathers of the trip are requested before the first one is consumed (the compiler left to itself requests the
+        // gathers of one row slot, waits, does the row's arithmetic and only then turns to the next slot: R round trips)
+        constexpr bool ALLG = !LOWREG && EW > 0 && R * EW <= 25;
+        double2 X[ALLG ? R : 1][ALLG ? EW : 1];
+        if (ALLG) {
+            const __amdgpu_buffer_rsrc_t rs = first ? rs_g : rs_md;
+#pragma unroll
+            for (int r = 0; r < (ALLG ? R : 0); ++r)
+#pragma unroll
+                for (int w = 0; w < (ALLG ? EW : 0); ++w) {
+                    const int cidx = cs[w * ROWS + SLOT(r)];
+                    X[ALLG ? r : 0][ALLG ? w : 0] = ld2_sc1(rs, ((unsigned)cidx * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u);
+                }
+        }
         auto hrow = [&](int r) {
-            double2 acc = gather_row(r, first ? rs_g : rs_md);
+            double2 acc;
+            if (ALLG) {
+                acc = zz;
+#pragma unroll
+                for (int w = 0; w < (ALLG ? EW : 0); ++w) {
+                    const double v = vs[w * ROWS + SLOT(r)];
+                    acc.x = fma(v, X[ALLG ? r : 0][ALLG ? w : 0].x, acc.x);
+                    acc.y = fma(v, X[ALLG ? r : 0][ALLG ? w : 0].y, acc.y);
+                }
+                if (!colok) acc = zz;
+            } else acc = gather_row(r, first ? rs_g : rs_md);
             if (TWOSYNC) {
                 // the gathered rows are those of r_new (first trip: of the gradient = mdelta; after a refresh: of mdelta)
                 if (!first && !direct) { acc.x = fma(beta, cmd[TWOSYNC ? r : 0].x, acc.x); acc.y = fma(beta, cmd[TWOSYNC ? r : 0].y, acc.y); }
