@@ -401,10 +401,11 @@ def main():
                     "streaming_equivalent_GBps": streaming_trip_bytes / (trip_ms * 1e-3) / 1e9,
                     "note": "one launch runs all trips of a solve; bytes, traffic and time are per trip.  The working "
                             "set is register/LDS resident; profiles/r4_persist_timeline_p32.md (s_memtime stamps of every workgroup) "
-                            "splits a trip into gathers + row arithmetic 1.65 us, grid reduction 1 1.66 us, trial step 0.46 us, wait for "
-                            "the residual-row stores 0.66 us, grid reduction 2 1.95 us, commit + new direction 0.56 us, loop 0.14 us (with "
-                            "the polling back-off of round 4; 2.0 and 2.7 us for the reductions before): the two grid-wide reductions are "
-                            "half of the trip, not HBM -- the fraction of the HBM roofline is low by construction at n*p*8 = 5 MB per vector"}
+                            "splits a trip into gathers + row arithmetic 1.19 us (1.65 before all gathers of a trip were requested "
+                            "up front), grid reduction 1 1.92 us, trial step 0.52 us, wait for the residual-row stores 0.67 us, grid "
+                            "reduction 2 1.90 us, commit + new direction 0.54 us, loop 0.12 us (with the polling back-off of round 4; 2.0 "
+                            "and 2.7 us for the reductions before): the two grid-wide reductions are more than half of the trip, not HBM "
+                            "-- the fraction of the HBM roofline is low by construction at n*p*8 = 5 MB per vector"}
     else:
         roofline = {"bound": "hbm", "achieved": hess_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hess_achieved / HBM_PEAK_GBS, "traffic": (pm_h or {}).get("hbm_bytes_per_launch"),
