@@ -523,6 +523,108 @@ def generate_hamming(k, d):
     return At, b, c, {"s": n}
 
 
+def _quat_rotation(q):
+    """Rotation matrix of the unit quaternion q = (v, s), vector part first (the convention of the QUASAR papers)."""
+    v, s = np.asarray(q[:3], float), float(q[3])
+    V = np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+    return (s * s - v @ v) * np.eye(3) + 2.0 * np.outer(v, v) + 2.0 * s * V
+
+
+def wahba_with_outliers(N, outlier_rate=0.5, sigma=0.01, seed=1):
+    """Synthetic rotation-search data in the manner of example/example_rotationsearch.m:10-20 (its generator, createWahbaProblem,
+    belongs to the STRIDE package and is not in the reference tree; this is the set-up the example's parameters describe): N unit
+    vectors a_i, a random rotation R_gt, b_i = R_gt a_i + noise of covariance sigma^2 I for the inliers, random unit vectors for
+    round(N * outlier_rate) outliers; noise bound beta = sigma * sqrt(chi2inv(0.9999, 3)).  Returns (a, b, R_gt, beta, outlier mask)."""
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((N, 3)); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    q = rng.standard_normal(4); q /= np.linalg.norm(q)
+    R = _quat_rotation(q)
+    b = a @ R.T + sigma * rng.standard_normal((N, 3))
+    nout = int(round(N * outlier_rate))
+    out = np.zeros(N, dtype=bool)
+    out[rng.permutation(N)[:nout]] = True
+    bo = rng.standard_normal((nout, 3)); bo /= np.linalg.norm(bo, axis=1, keepdims=True)
+    b[out] = bo
+    beta = sigma * np.sqrt(21.10751347)                            # chi2inv(0.9999, 3)
+    return a, b, R, beta, out
+
+
+def quasar_cost_blocks(a, b, betasq, cbar2=1.0):
+    """The 4 x 4 matrices Q_i with ||b_i - R(q) a_i||^2 = q' Q_i q for a unit quaternion q = (v, s):
+    b'R(q)a = q' M q, M = [[a b' + b a' - (a'b) I, a x b], [(a x b)', a'b]], Q_i = (|a_i|^2 + |b_i|^2) I - 2 M_i."""
+    Q = []
+    for ai, bi in zip(a, b):
+        M = np.zeros((4, 4))
+        M[:3, :3] = np.outer(ai, bi) + np.outer(bi, ai) - (ai @ bi) * np.eye(3)
+        M[:3, 3] = M[3, :3] = np.cross(ai, bi)
+        M[3, 3] = ai @ bi
+        Q.append((ai @ ai + bi @ bi) * np.eye(4) - 2.0 * M)
+    return Q
+
+
+def quasar_problem(a, b, betasq, cbar2=1.0, redundant=True):
+    """QUASAR relaxation of the truncated-least-squares rotation search (Yang & Carlone, ICCV 2019: the SDP that
+    example/example_rotationsearch.m:26-28 builds with STRIDE's QUASAR_Problem) in SeDuMi format.
+        min_{R, theta_i = +-1}  sum_i (1 + theta_i)/2 * ||b_i - R a_i||^2 / beta^2 + (1 - theta_i)/2 * cbar^2
+    With x = [q; theta_1 q; ...; theta_N q] (4(N+1) entries) the cost is x'Cx and Z = xx' satisfies: tr Z_00 = 1; Z_ii = Z_00
+    (10 equalities per i); Z_0i symmetric (6 per i); and, redundant, Z_ij symmetric for 0 < i < j (6 per pair).
+    Blocks of C: C_00 = sum_i (Q_i / beta^2 + cbar^2 I) / 2, C_0i = C_i0 = (Q_i / beta^2 - cbar^2 I) / 4.
+    tr Z = N + 1: ManiSDP_unittrace(At, b / (N + 1), c, K) solves for X = Z / (N + 1), as the example does (:37).
+    Returns (At, b, c, K)."""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    N = a.shape[0]
+    n = 4 * (N + 1)
+    Q = quasar_cost_blocks(a, b, betasq, cbar2)
+    C = np.zeros((n, n))
+    for i, Qi in enumerate(Q, start=1):
+        C[:4, :4] += 0.5 * (Qi / betasq + cbar2 * np.eye(4))
+        blk = 0.25 * (Qi / betasq - cbar2 * np.eye(4))
+        C[:4, 4 * i:4 * i + 4] = blk
+        C[4 * i:4 * i + 4, :4] = blk.T
+    rows, cols, vals = [], [], []
+    k = 0
+
+    def put(r, c_, v):
+        rows.append(c_ * n + r); cols.append(k); vals.append(v)      # column-major vec, both triangles of a symmetric A_k
+
+    for d_ in range(4):                                              # tr Z_00 = 1
+        put(d_, d_, 1.0)
+    k += 1
+    for i in range(1, N + 1):                                        # Z_ii = Z_00
+        o = 4 * i
+        for p_ in range(4):
+            for q_ in range(p_, 4):
+                if p_ == q_:
+                    put(o + p_, o + p_, 1.0); put(p_, p_, -1.0)
+                else:
+                    put(o + p_, o + q_, 0.5); put(o + q_, o + p_, 0.5); put(p_, q_, -0.5); put(q_, p_, -0.5)
+                k += 1
+    pairs = [(0, i) for i in range(1, N + 1)]
+    if redundant:
+        pairs += [(i, j) for i in range(1, N + 1) for j in range(i + 1, N + 1)]
+    for i, j in pairs:                                               # Z_ij symmetric
+        oi, oj = 4 * i, 4 * j
+        for p_ in range(4):
+            for q_ in range(p_ + 1, 4):
+                put(oi + p_, oj + q_, 0.5); put(oj + q_, oi + p_, 0.5)
+                put(oi + q_, oj + p_, -0.5); put(oj + p_, oi + q_, -0.5)
+                k += 1
+    m = k
+    At = sp.coo_matrix((vals, (rows, cols)), shape=(n * n, m)).tocsc()
+    bvec = np.zeros(m)
+    bvec[0] = 1.0
+    return At, bvec, C.reshape(-1, order="F"), {"s": n}
+
+
+def quasar_recover(X, N):
+    """Rotation and inlier decisions from a (near) rank-one solution X ~ xx' / (N + 1): q = leading eigenvector of the 00 block,
+    theta_i = sign of tr X_0i."""
+    w, V = np.linalg.eigh(0.5 * (X[:4, :4] + X[:4, :4].T))
+    q = V[:, -1]
+    theta = np.array([np.sign(np.trace(X[:4, 4 * i:4 * i + 4])) for i in range(1, N + 1)])
+    return _quat_rotation(q / np.linalg.norm(q)), theta
+
+
 def chain_cliques(t, q):
     """``t`` cliques of ``q`` consecutive variables, neighbours sharing two (reference example/example_bqp_sparse.m:3-10):
     ``n = q + (q-2)(t-1)`` variables, clique i = {(q-2) i, ..., (q-2) i + q - 1} (0-based)."""

@@ -160,3 +160,20 @@ def test_unittrace_hamming_graphs(k, d, theta):
     Y, obj, data = solvers.ManiSDP_unittrace(At, b, c, K, dict(THETA_OPTS, eig="host"), verbose=False)
     assert data["status"] == 0 and max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
     assert abs(-obj - theta) <= 1e-7 * theta
+
+
+@pytest.mark.parametrize("N,seed", [(10, 1), (50, 1)])
+def test_unittrace_rotation_search(N, seed):
+    """example/example_rotationsearch.m (N = 50, half outliers: n = 204, m = 8151) on the GPU: tight relaxation, inliers and
+    rotation recovered (tests/test_oracle_known_answers.py::check_rotation_search); N = 10 also against the oracle's optimum."""
+    from manisdp_matlab_amd import solvers
+    from test_oracle_known_answers import check_rotation_search
+
+    def solve(At, b, c, K, o):
+        return solvers.ManiSDP_unittrace(At, b, c, K, dict(o, eig="host"), verbose=False)
+
+    fval = check_rotation_search(solve, N, seed)
+    if N == 10:
+        from oracle import manisdp_ref as R
+        assert abs(fval - check_rotation_search(R.ManiSDP_unittrace, N, seed)) <= 1e-7 * abs(fval)
+

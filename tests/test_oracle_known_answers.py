@@ -235,3 +235,34 @@ def test_unittrace_hamming_graphs_with_known_theta(k, d, theta):
     Y, obj, data = R.ManiSDP_unittrace(At, b, c, K, dict(THETA_OPTS))
     assert data["status"] == 0 and max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
     assert abs(-obj - theta) <= 1e-7 * theta
+
+
+QUASAR_OPTS = {"tol": 1e-8, "sigma0": 1.0, "sigma_min": 1.0, "sigma_max": 1e4}
+
+
+def check_rotation_search(solve, N, seed):
+    """Shared by the oracle and the GPU test: the QUASAR relaxation of a rotation search with 50 % outliers is tight -- the optimum
+    of the SDP equals the truncated-least-squares cost AT the rotation read off its rank-one solution (an independent evaluation:
+    3 x 3 rotation, N residuals), the inlier set comes back exactly, and the rotation is the ground truth to the noise level."""
+    a, b, Rgt, beta, out = problems.wahba_with_outliers(N, 0.5, seed=seed)
+    At, bv, c, K = problems.quasar_problem(a, b, beta ** 2)
+    Y, fval, data = solve(At, bv / (N + 1), c, K, dict(QUASAR_OPTS))          # example_rotationsearch.m:37: b / (N + 1)
+    assert data["status"] == 0 and max(data["gap"], data["pinf"], data["dinf"]) < 1e-8
+    X = Y @ Y.T
+    w = np.linalg.eigvalsh(X)
+    assert w[-2] <= 1e-8 * w[-1]                                               # rank one
+    Rr, theta = problems.quasar_recover(X, N)
+    assert np.array_equal(theta > 0, ~out)
+    tls = sum(min(np.sum((bi - Rr @ ai) ** 2) / beta ** 2, 1.0) for ai, bi in zip(a, b))
+    assert abs(fval * (N + 1) - tls) <= 1e-6 * tls
+    angle = np.degrees(np.arccos(np.clip((np.trace(Rr.T @ Rgt) - 1.0) / 2.0, -1.0, 1.0)))
+    assert angle < 1.0
+    return fval
+
+
+def test_unittrace_rotation_search_relaxation_is_tight():
+    """example/example_rotationsearch.m through the oracle's ManiSDP_unittrace (N = 10 measurements, half of them outliers).  The
+    reference's sigma schedule (sigma_min = 1e2, up to 1e7) leaves through "Slow progress" on this data (the example's own generator
+    is not in the tree, its scaling unknown); sigma0 = sigma_min = 1, sigma_max = 1e4 converges in ~50 outer iterations."""
+    check_rotation_search(R.ManiSDP_unittrace, 10, 1)
+

@@ -255,3 +255,36 @@ def test_matrix_completion_generator_and_oracle():
     Y, obj, d = R.ManiSDP(At, b, c, K, {"tol": 1e-8, "theta": 1e-2, "TR_maxinner": 6, "TR_maxiter": 8, "delta": 10, "alpha": 0.1})
     assert d["status"] == 0 and abs(obj - 2 * s.sum()) <= 1e-6 * obj
     assert np.linalg.norm(Y[:p] @ Y[p:].T - M) <= 1e-6 * np.linalg.norm(M)
+
+
+def test_quasar_relaxation_is_valid_on_feasible_points():
+    """problems.quasar_problem (the SDP of example/example_rotationsearch.m:26-28, whose generator belongs to STRIDE and is
+    restated here from the QUASAR paper): for every unit quaternion q and every sign pattern theta the matrix Z = xx',
+    x = [q; theta_1 q; ...], satisfies all constraints, and <C, Z> is the truncated-least-squares cost it stands for -- written
+    out with the rotation matrix of q, which also pins the quaternion convention.  Constraint count: 1 + 10 N + 6 N + 6 N(N-1)/2."""
+    N = 7
+    a, b, R, beta, out = P.wahba_with_outliers(N, 0.5, seed=3)
+    assert out.sum() == 4 and np.allclose(np.linalg.norm(a, axis=1), 1.0)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-14) and abs(np.linalg.det(R) - 1.0) < 1e-14
+    assert np.abs(b[~out] - a[~out] @ R.T).max() < 0.06                          # inliers: noise of sigma = 0.01
+    At, bv, c, K = P.quasar_problem(a, b, beta ** 2)
+    n = 4 * (N + 1)
+    assert K["s"] == n and At.shape == (n * n, 1 + 16 * N + 3 * N * (N - 1))
+    assert bv[0] == 1.0 and np.count_nonzero(bv) == 1
+    C = c.reshape(n, n, order="F")
+    assert np.array_equal(C, C.T)
+    for k in (0, 5, 80, At.shape[1] - 1):                                        # symmetric constraint matrices
+        Ak = np.asarray(At[:, k].todense()).reshape(n, n, order="F")
+        assert np.array_equal(Ak, Ak.T)
+    rng = np.random.default_rng(0)
+    for _ in range(4):
+        q = rng.standard_normal(4); q /= np.linalg.norm(q)
+        th = rng.choice([-1.0, 1.0], N)
+        x = np.concatenate([q] + [t * q for t in th])
+        z = np.outer(x, x).reshape(-1, order="F")
+        assert np.abs(At.T @ z - bv).max() < 1e-14
+        Rq = P._quat_rotation(q)
+        direct = sum((1 + t) / 2 * np.sum((bi - Rq @ ai) ** 2) / beta ** 2 + (1 - t) / 2 for ai, bi, t in zip(a, b, th))
+        assert abs(c @ z - direct) <= 1e-12 * abs(direct)
+    At2 = P.quasar_problem(a, b, beta ** 2, redundant=False)[0]
+    assert At2.shape[1] == 1 + 16 * N
