@@ -360,6 +360,14 @@ int msdp_get_dual_slack(msdp_handle h, double* S);
  * ManiSDP_multiblock.m:78-88 takes eig(S_i) block by block: with a hundred blocks the whole N x N matrix is 100 times what
  * the host reads (N = 21 100 for example_bqp_sparse.m with t = 100: 3.5 GB per outer iteration against 35 MB). */
 int msdp_get_dual_slack_block(msdp_handle h, int64_t row0, int64_t nb, double* S);
+/* eig of `nb` diagonal blocks of the same matrix on the device, in one launch: what ManiSDP_multiblock.m:78-88 computes block by
+ * block with eig(S{i}) -- all eigenvalues (dinf needs the extremes, the escape the count of negative ones, :129-133) and the
+ * eigenvectors of the `k` smallest (:137-147 take at most options.delta of them).  Block b = rows / columns row0[b] .. row0[b] +
+ * nblk[b] - 1 (a block of the handle when it stores per block); orders up to 256 (MSDP_EUNSUPPORTED beyond: the host loop over
+ * msdp_get_dual_slack_block remains).  w: the eigenvalues, block after block, ascending inside a block (sum nblk values);
+ * V: (sum nblk) x k row-major, row = position in the concatenation of the blocks, column c = eigenvector of the block's c-th
+ * smallest eigenvalue (zero columns beyond a block's order).  Cyclic Jacobi, one workgroup per block (msdp_blockjacobi.hip). */
+int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, const int64_t* nblk, int32_t k, double* w, double* V);
 
 /* Run-time switches of one handle (production = the defaults; the tests and the profiling scripts use them):
  *   "persist"      1/0  persistent single-launch tCG / Lanczos kernels where they fit (default 1; env MSDP_NO_PERSIST=1)

@@ -1629,6 +1629,16 @@ int msdp_affine_get_block(msdp_handle h, int64_t row0, int64_t nbk, double* S) {
     return MSDP_EINVAL;
 }
 
+// Where block (row0, n) of the per-block storage lives in d.Sdual (msdp_blockjacobi.hip)
+int msdp_affine_block_source(msdp_handle h, int64_t row0, int64_t n, int64_t* off, int64_t* ld) {
+    AffineState* st = astate(h);
+    if (!st || !st->blk) { msdp_set_error("block_source: not a handle with per-block storage"); return MSDP_ESTATE; }
+    for (size_t i = 0; i + 1 < st->blk_r0.size(); ++i)
+        if (st->blk_r0[i] == row0 && st->blk_n[i] == n) { *off = st->blk_off[i]; *ld = st->blk_ns[i]; return 0; }
+    msdp_set_error("block_eigs: rows %lld..%lld are not one block of this handle", (long long)row0, (long long)(row0 + n));
+    return MSDP_EINVAL;
+}
+
 int msdp_affine_set_multipliers(msdp_handle h, const double* y, double sigma) {
     AffineState* st = astate(h);
     if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }

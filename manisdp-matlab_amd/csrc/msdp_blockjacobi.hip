@@ -1,0 +1,222 @@
+// msdp_blockjacobi.hip -- eig(S_i) of every diagonal block of the dual slack, on the device, in one launch.
+//
+// ManiSDP_multiblock.m:78-88 takes [vS{i}, dS{i}] = eig(S{i}) of every block in every outer iteration (all eigenvalues: dinf needs the
+// smallest and the largest, the escape the number of negative ones; eigenvectors: the first `delta` columns, :129-147).  With
+// many small blocks that host loop is the solve: example_bqp_sparse.m's chain of 100 cliques spends 48 of its 69 s in 17 600
+// LAPACK calls of order 211 (profiles/r4_multiblock_times.log).  Here one workgroup per block runs a cyclic two-sided Jacobi
+// iteration on a copy of the block (A <- J'AJ, V <- VJ, rotations of one round in parallel: round-robin pairing, m/2 disjoint
+// pairs per round, m - 1 rounds per sweep), the matrix in global memory (n_i <= 256: it lives in the L2 of the workgroup's XCD),
+// until off(A)^2 <= 1e-30 |A|_F^2; eigenvalues sorted ascending, the first k eigenvectors returned.  Jacobi's eigenvalues are
+// accurate to |A| eps, its eigenvectors orthogonal to rounding; vectors of a multiple eigenvalue are one orthonormal basis of the
+// eigenspace, as with LAPACK, and their signs are whatever the rotations leave.
+#include "msdp_device.h"
+#include <vector>
+
+int msdp_affine_block_source(msdp_handle h, int64_t row0, int64_t n, int64_t* off, int64_t* ld);   // msdp_affine.hip (per-block storage)
+int msdp_dense_nS(int n);
+
+#define JAC_MAXN 256
+#define JAC_THREADS 1024
+
+struct JacArgs {
+    int nb, k;
+    const int64_t* soff; const int64_t* sld;      // block b: S_b(i, j) = S[soff[b] + i * sld[b] + j]
+    const int* n; const int64_t* woff;            // order; offset of the block's n x n workspaces
+    const int64_t* r0;                            // first row of the block in the output arrays
+    const double* S;
+    double* A; double* V;                         // workspaces (sum n_b^2 doubles each)
+    double* w; double* vec;                       // outputs: w[r0 + rank], vec[(r0 + i) * k + rank] for rank < k
+    int* sweeps;                                  // per block: sweeps used (diagnostic; -1: not converged in JAC_MAXSWEEP)
+};
+#define JAC_MAXSWEEP 40
+
+__global__ __launch_bounds__(JAC_THREADS) void k_block_jacobi(JacArgs a) {
+    __shared__ double cc[JAC_MAXN / 2], ss[JAC_MAXN / 2];
+    __shared__ int pp[JAC_MAXN / 2], qq[JAC_MAXN / 2];
+    __shared__ double red[2 * (JAC_THREADS / 64)];
+    __shared__ double dg[JAC_MAXN];
+    __shared__ int rk[JAC_MAXN];
+    __shared__ int done;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n[b];
+    const int m = n + (n & 1), half = m >> 1;
+    const int64_t so = a.soff[b], sl = a.sld[b];
+    double* __restrict__ A = a.A + a.woff[b];
+    double* __restrict__ V = a.V + a.woff[b];
+    for (int e = tid; e < n * n; e += JAC_THREADS) {
+        const int i = e / n, j = e - i * n;
+        A[e] = 0.5 * (a.S[so + (int64_t)i * sl + j] + a.S[so + (int64_t)j * sl + i]);      // ManiSDP_multiblock.m:86 symmetrises too
+        V[e] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    int sweep = 0;
+    for (; sweep < JAC_MAXSWEEP; ++sweep) {
+        // off(A)^2 and |A|_F^2
+        double off = 0.0, tot = 0.0;
+        for (int e = tid; e < n * n; e += JAC_THREADS) {
+            const int i = e / n, j = e - i * n;
+            const double v = A[e] * A[e];
+            tot += v;
+            if (i != j) off += v;
+        }
+        off = msdp_wave_sum(off); tot = msdp_wave_sum(tot);
+        if (lane == 0) { red[wave] = off; red[JAC_THREADS / 64 + wave] = tot; }
+        __syncthreads();
+        if (tid == 0) {
+            double o2 = 0.0, t2 = 0.0;
+            for (int q = 0; q < JAC_THREADS / 64; ++q) { o2 += red[q]; t2 += red[JAC_THREADS / 64 + q]; }
+            done = (o2 <= 1e-30 * t2) ? 1 : 0;
+        }
+        __syncthreads();
+        if (done) break;
+        for (int r = 0; r < m - 1; ++r) {
+            if (tid < half) {
+                // round-robin pairing of m players: player m - 1 stays, the others rotate
+                int p, q;
+                if (tid == 0) { p = m - 1; q = r; }
+                else { p = (r + tid) % (m - 1); q = (r - tid + (m - 1)) % (m - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                double c = 1.0, s = 0.0;
+                if (q < n) {                                              // (q == n: the dummy player of an odd order)
+                    const double apq = A[p * n + q];
+                    if (apq != 0.0) {
+                        const double app = A[p * n + p], aqq = A[q * n + q];
+                        const double tau = (aqq - app) / (2.0 * apq);
+                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        s = t * c;
+                    }
+                } else q = p;                                              // identity on (p, p)
+                pp[tid] = p; qq[tid] = q; cc[tid] = c; ss[tid] = s;
+            }
+            __syncthreads();
+            // columns p, q of A and V (threads of a wave share a row: its entries are one contiguous stretch).  Four items per trip,
+            // all their loads before the first store: the compiler cannot tell the stores of one item from the loads of the next
+            // (same array) and would otherwise run them one after the other, a memory round trip each
+            for (int e0 = tid; e0 < n * half; e0 += 4 * JAC_THREADS) {
+                double ap[4], aq[4], vp[4], vq[4], c[4], s[4];
+                int ip[4], iq[4];
+                bool on[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * JAC_THREADS;
+                    on[u] = e < n * half;
+                    const int ec = on[u] ? e : tid;
+                    const int i = ec / half, k2 = ec - i * half;
+                    const int p = pp[k2], q = qq[k2];
+                    on[u] = on[u] && p != q;
+                    c[u] = cc[k2]; s[u] = ss[k2];
+                    ip[u] = i * n + p; iq[u] = i * n + q;
+                    ap[u] = A[ip[u]]; aq[u] = A[iq[u]]; vp[u] = V[ip[u]]; vq[u] = V[iq[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (on[u]) {
+                        A[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; A[iq[u]] = s[u] * ap[u] + c[u] * aq[u];
+                        V[ip[u]] = c[u] * vp[u] - s[u] * vq[u]; V[iq[u]] = s[u] * vp[u] + c[u] * vq[u];
+                    }
+                }
+            }
+            __syncthreads();
+            // rows p, q of A
+            for (int e0 = tid; e0 < half * n; e0 += 4 * JAC_THREADS) {
+                double ap[4], aq[4], c[4], s[4];
+                int ip[4], iq[4];
+                bool on[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * JAC_THREADS;
+                    on[u] = e < half * n;
+                    const int ec = on[u] ? e : tid;
+                    const int k2 = ec / n, j = ec - k2 * n;
+                    const int p = pp[k2], q = qq[k2];
+                    on[u] = on[u] && p != q;
+                    c[u] = cc[k2]; s[u] = ss[k2];
+                    ip[u] = p * n + j; iq[u] = q * n + j;
+                    ap[u] = A[ip[u]]; aq[u] = A[iq[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (on[u]) { A[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; A[iq[u]] = s[u] * ap[u] + c[u] * aq[u]; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) a.sweeps[b] = sweep < JAC_MAXSWEEP ? sweep : -1;
+    // eigenvalues = diagonal; rank by counting (ties by index); the first k eigenvectors
+    if (tid < n) dg[tid] = A[tid * n + tid];
+    __syncthreads();
+    if (tid < n) {
+        const double v = dg[tid];
+        int rnk = 0;
+        for (int j = 0; j < n; ++j) rnk += (dg[j] < v || (dg[j] == v && j < tid)) ? 1 : 0;
+        rk[tid] = rnk;
+        a.w[a.r0[b] + rnk] = v;
+    }
+    __syncthreads();
+    const int k = a.k < n ? a.k : n;
+    for (int e = tid; e < n * n; e += JAC_THREADS) {
+        const int i = e / n, j = e - i * n;
+        const int rnk = rk[j];
+        if (rnk < k) a.vec[(a.r0[b] + i) * a.k + rnk] = V[e];
+    }
+    if (k < a.k) for (int e = tid; e < n * (a.k - k); e += JAC_THREADS) a.vec[(a.r0[b] + e / (a.k - k)) * a.k + k + e % (a.k - k)] = 0.0;
+}
+
+template <typename T>
+static int jac_up(const std::vector<T>& v, T** out, hipStream_t s) {
+    if (hipMalloc((void**)out, v.size() * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("block_eigs: device allocation failed"); return MSDP_ENOMEM; }
+    HIPCHK(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+extern "C" int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, const int64_t* nblk, int32_t k, double* w, double* V) {
+    if (!h) { msdp_set_error("null handle"); return MSDP_EINVAL; }
+    if (nb < 1 || !row0 || !nblk || !w || (k > 0 && !V) || k < 0 || k > 64) { msdp_set_error("block_eigs: bad argument"); return MSDP_EINVAL; }
+    if (h->d.costkind != COST_AFFINE || !h->dual_valid) { msdp_set_error("block_eigs: call msdp_al_dual first"); return MSDP_ESTATE; }
+    const int N = h->d.n, nS = msdp_dense_nS(N);
+    std::vector<int64_t> soff(nb), sld(nb), woff(nb), r0(nb);
+    std::vector<int> nn(nb);
+    int64_t tot = 0, rows = 0;
+    for (int b = 0; b < nb; ++b) {
+        if (nblk[b] < 1 || nblk[b] > JAC_MAXN) { msdp_set_error("block_eigs: block orders up to %d (block %d has %lld)", JAC_MAXN, b, (long long)nblk[b]); return MSDP_EUNSUPPORTED; }
+        if (row0[b] < 0 || row0[b] + nblk[b] > N) { msdp_set_error("block_eigs: block %d outside the matrix", b); return MSDP_EINVAL; }
+        if (h->blocked) {
+            int rc = msdp_affine_block_source(h, row0[b], nblk[b], &soff[b], &sld[b]);
+            if (rc) return rc;
+        } else { soff[b] = row0[b] * nS + row0[b]; sld[b] = nS; }
+        nn[b] = (int)nblk[b]; woff[b] = tot; r0[b] = rows;
+        tot += nblk[b] * nblk[b]; rows += nblk[b];
+    }
+    const int kk = k > 0 ? k : 1;
+    JacArgs a;
+    a.nb = nb; a.k = kk; a.S = h->d.Sdual;
+    int64_t *d_soff = nullptr, *d_sld = nullptr, *d_woff = nullptr, *d_r0 = nullptr;
+    int* d_n = nullptr; int* d_sw = nullptr;
+    double *d_A = nullptr, *d_V = nullptr, *d_w = nullptr, *d_vec = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        void* ps[] = {d_soff, d_sld, d_woff, d_r0, d_n, d_sw, d_A, d_V, d_w, d_vec};
+        for (void* p : ps) if (p) (void)hipFree(p);
+    };
+    if ((rc = jac_up(soff, &d_soff, h->stream)) || (rc = jac_up(sld, &d_sld, h->stream)) || (rc = jac_up(woff, &d_woff, h->stream)) ||
+        (rc = jac_up(r0, &d_r0, h->stream)) || (rc = jac_up(nn, &d_n, h->stream))) { cleanup(); return rc; }
+    if (hipMalloc((void**)&d_A, tot * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_V, tot * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&d_w, rows * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_vec, rows * kk * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&d_sw, nb * sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError(); cleanup(); msdp_set_error("block_eigs: device allocation failed"); return MSDP_ENOMEM;
+    }
+    a.soff = d_soff; a.sld = d_sld; a.n = d_n; a.woff = d_woff; a.r0 = d_r0; a.A = d_A; a.V = d_V; a.w = d_w; a.vec = d_vec; a.sweeps = d_sw;
+    hipLaunchKernelGGL(k_block_jacobi, dim3(nb), dim3(JAC_THREADS), 0, h->stream, a);
+    hipError_t e = hipGetLastError();
+    std::vector<int> sw(nb);
+    if (e == hipSuccess) e = hipMemcpyAsync(w, d_w, rows * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && k > 0) e = hipMemcpyAsync(V, d_vec, rows * k * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sw.data(), d_sw, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess) { msdp_set_error("block_eigs: %s", hipGetErrorString(e)); return MSDP_EHIP; }
+    for (int b = 0; b < nb; ++b)
+        if (sw[b] < 0) { msdp_set_error("block_eigs: Jacobi iteration of block %d did not converge in %d sweeps", b, JAC_MAXSWEEP); return MSDP_ESTATE; }
+    return 0;
+}

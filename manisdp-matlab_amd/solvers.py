@@ -686,6 +686,14 @@ def _multiblock_impl(At, b, c, K, options, verbose, rng):
     _say(verbose, f"SDP size: n = {max(nset)}, m = {b.size}")
     p = [p0[i] if nset[i] >= o["min_facsize"] else nset[i] for i in range(nb)]        # :34-39
     h = _lib.Handle.multiblock(Atc, b, c, nset, nob, pcap=max(32, max(p) + 2 * int(o["delta"])))
+    # options["block_eig"]: "host" = the reference's loop of eig(S{i}) on the host (LAPACK through NumPy), "device" = all blocks in
+    # one launch on the GPU (msdp_block_eigs: one workgroup per block, a Jacobi iteration bounded by ONE CU's path to the L2), "auto"
+    # (default) = device where that wins: from 64 blocks of order <= 128 or from 256 blocks of order <= 256 on (1000 x 60: solve
+    # 1.1 -> 0.35 s, 4000 x 60: 4.5 -> 0.96 s, 1000 x 200: 27 -> 8 s; 100 blocks of order 211: 277 ms per call against 280 on the
+    # host, 20 such blocks: slower) -- and never where the oracle-parity tests compare iterate by iterate: the eigenvectors of
+    # LAPACK and of a Jacobi iteration differ by signs / rotations inside eigenspaces
+    be = o.get("block_eig", "auto")
+    block_eig_device = be == "device" or (be == "auto" and max(nset) <= 256 and (nb >= 256 or (nb >= 64 and max(nset) <= 128)))
     sigma = float(o["sigma0"]); gama = float(o["gama"])
     y = np.zeros(b.size)
     normb = 1.0 + np.linalg.norm(b)
@@ -731,11 +739,26 @@ def _multiblock_impl(At, b, c, K, options, verbose, rng):
             z = h.al_dual(y)                                # :74-84 on the device: S = cy blocks - diag(z), z = 0 on free rows
             by = float(b @ y) + float(np.sum(z))            # :75,82
             S, vS, dS, dinfs = [], [], [], []
-            for i in range(nb):                             # :78-88 (only the diagonal blocks come to the host)
-                Si = h.get_dual_slack_block(r0[i], nset[i])
-                w, V = np.linalg.eigh(0.5 * (Si + Si.T))    # :86
-                S.append(Si); dS.append(w); vS.append(V)
-                dinfs.append(max(0.0, -w[0]) / (1.0 + abs(w[-1])))   # :87
+            if block_eig_device:
+                # eig(S{i}) of every block in one launch (msdp_block_eigs: cyclic Jacobi, one workgroup per block); what the loop
+                # below uses of it -- all eigenvalues, the eigenvectors of the `delta` smallest -- is what comes back
+                try:
+                    wall, Vall = h.block_eigs(r0[:-1], nset, int(o["delta"]))
+                except _lib.MsdpError:
+                    if o.get("block_eig", "auto") == "device":
+                        raise
+                    block_eig_device = False
+            if block_eig_device:
+                for i in range(nb):
+                    w = wall[r0[i]:r0[i + 1]]
+                    dS.append(w); vS.append(Vall[r0[i]:r0[i + 1], :])
+                    dinfs.append(max(0.0, -w[0]) / (1.0 + abs(w[-1])))   # :87
+            else:
+                for i in range(nb):                         # :78-88 (only the diagonal blocks come to the host)
+                    Si = h.get_dual_slack_block(r0[i], nset[i])
+                    w, V = np.linalg.eigh(0.5 * (Si + Si.T))    # :86
+                    S.append(Si); dS.append(w); vS.append(V)
+                    dinfs.append(max(0.0, -w[0]) / (1.0 + abs(w[-1])))   # :87
             data["eig_seconds"] += time.time() - t1
             dinf = max(dinfs)                               # :89
             gap = abs(obj - by) / (abs(by) + abs(obj) + 1.0)   # :90
@@ -782,6 +805,8 @@ def _multiblock_impl(At, b, c, K, options, verbose, rng):
                 sigma = max(sigma / gama, o["sigma_min"])
             elif pinf > o["tau2"] * gradnorm:
                 sigma = min(sigma * gama, o["sigma_max"])
+        if block_eig_device and Y_eval is not None:         # data.S (:158): the blocks of the last iterate, fetched once
+            S = [h.get_dual_slack_block(r0[i], nset[i]) for i in range(nb)]
     finally:
         h.close()
     if Y_eval is not None:

@@ -373,3 +373,62 @@ def test_thousand_blocks_of_order_60(lib, storage):
     assert max(d["gap"], d["pinf"], d["dinf"]) < 1e-6, d
     assert abs(obj - ref) <= 1e-5 * abs(ref), (obj, ref)
     assert len(Y) == nblk and all(Yi.shape[0] == n for Yi in Y)
+
+
+def test_block_eigs_match_lapack(lib, storage):
+    """msdp_block_eigs (cyclic Jacobi, one workgroup per block, msdp_blockjacobi.hip) against numpy.linalg.eigh on the blocks of a
+    dual slack: orders 1..97 incl. odd ones, 23 blocks; eigenvalues to 1e-13 |S_i|, eigenvectors as residuals and orthonormality
+    (a Jacobi basis and LAPACK's differ by signs)."""
+    rng = np.random.default_rng(11)
+    nset = [1, 2, 3, 97, 64, 31] + [int(v) for v in rng.integers(4, 60, size=17)]
+    At, b, c = _random_multiblock(nset, 200, seed=8)
+    N, p = sum(nset), 4
+    r0 = np.concatenate([[0], np.cumsum(nset)])
+    h = lib.Handle.multiblock(At, b, c, nset, 10)
+    Y = rng.standard_normal((N, p)); Y[:r0[10]] /= np.linalg.norm(Y[:r0[10]], axis=1, keepdims=True)
+    h.set_multipliers(0.1 * rng.standard_normal(b.size), 0.5)
+    h.set_point(Y)
+    h.cost()
+    h.al_dual(0.3 * rng.standard_normal(b.size))
+    k = 8
+    w, V = h.block_eigs(r0[:-1], nset, k)
+    assert w.shape == (N,) and V.shape == (N, k)
+    for i, n in enumerate(nset):
+        S = h.get_dual_slack_block(r0[i], n)
+        S = 0.5 * (S + S.T)
+        wr = np.linalg.eigvalsh(S)
+        scale = max(1.0, np.abs(wr).max())
+        wi = w[r0[i]:r0[i + 1]]
+        assert np.all(np.diff(wi) >= 0)
+        assert np.abs(wi - wr).max() <= 1e-13 * scale * n
+        kk = min(k, n)
+        Vi = V[r0[i]:r0[i + 1], :kk]
+        assert np.abs(S @ Vi - Vi * wi[:kk]).max() <= 1e-12 * scale * n
+        assert np.abs(Vi.T @ Vi - np.eye(kk)).max() <= 1e-12
+        assert not np.any(V[r0[i]:r0[i + 1], kk:])                       # columns beyond the block's order
+    w2, V2 = h.block_eigs(r0[:-1], nset, k)                              # deterministic
+    assert np.array_equal(w, w2) and np.array_equal(V, V2)
+    with pytest.raises(lib.MsdpError):
+        h.block_eigs([0], [N + 1], 1)
+    if storage == "blocked":
+        with pytest.raises(lib.MsdpError):
+            h.block_eigs([2], [2], 1)                                    # rows 2..3 straddle two blocks of the handle
+    h.close()
+
+
+def test_multiblock_solve_with_device_block_eigs(lib, storage):
+    """options.block_eig: the reference's host loop of eig(S{i}) against all blocks in one device launch -- same optimum and KKT
+    residuals within tol (the iterates differ: Jacobi's eigenvectors are LAPACK's up to signs), on a chain of 18 cliques of 5
+    variables (18 blocks of order 16; "auto" takes the device from 64 blocks on, the host here)."""
+    from manisdp_matlab_amd import problems as P, solvers
+    cl, n = P.chain_cliques(18, 5)
+    coe = np.random.default_rng(2).standard_normal(len(P.bqp_sparse_monomials(cl)))
+    At, b, c, K = P.bqpmom_sparse(n, cl, coe)
+    out = {}
+    for mode in ("host", "device", "auto"):
+        Y, obj, d = solvers.ManiSDP_multiblock(At, b, c, K, {"tol": 1e-8, "line_search": 1, "tau1": 1, "block_eig": mode}, verbose=False)
+        assert d["status"] == 0 and max(d["gap"], d["pinf"], d["dinf"]) < 1e-8
+        assert len(d["S"]) == len(K["s"]) and d["S"][0].shape == (K["s"][0], K["s"][0])
+        out[mode] = obj
+    assert abs(out["device"] - out["host"]) <= 1e-6 * abs(out["host"])
+    assert abs(out["auto"] - out["host"]) <= 1e-6 * abs(out["host"])
