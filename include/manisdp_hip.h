@@ -366,8 +366,9 @@ int msdp_get_dual_slack_block(msdp_handle h, int64_t row0, int64_t nb, double* S
  * nblk[b] - 1 (a block of the handle when it stores per block); orders up to 256 (MSDP_EUNSUPPORTED beyond: the host loop over
  * msdp_get_dual_slack_block remains).  w: the eigenvalues, block after block, ascending inside a block (sum nblk values);
  * V: (sum nblk) x k row-major, row = position in the concatenation of the blocks, column c = eigenvector of the block's c-th
- * smallest eigenvalue (zero columns beyond a block's order).  Cyclic Jacobi, one workgroup per block (msdp_blockjacobi.hip). */
-int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, const int64_t* nblk, int32_t k, double* w, double* V);
+ * smallest eigenvalue (zero columns beyond a block's order).  One workgroup per block (msdp_blockjacobi.hip); method 0 = Householder
+ * tridiagonalisation + bisection + inverse iteration when k <= 8 (the way of LAPACK's dsyevx), else 1 = cyclic Jacobi; 2 = the former or an error. */
+int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, const int64_t* nblk, int32_t k, int32_t method, double* w, double* V);
 
 /* Run-time switches of one handle (production = the defaults; the tests and the profiling scripts use them):
  *   "persist"      1/0  persistent single-launch tCG / Lanczos kernels where they fit (default 1; env MSDP_NO_PERSIST=1)

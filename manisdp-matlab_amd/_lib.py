@@ -91,7 +91,7 @@ SIGNATURES = {
     "msdp_debug_ritz": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _P(C.c_int32)]),
     "msdp_get_dual_slack": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_dual_slack_block": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
-    "msdp_block_eigs": (C.c_int, [C.c_void_p, C.c_int32, _i64p, _i64p, C.c_int32, _dp, _dp]),
+    "msdp_block_eigs": (C.c_int, [C.c_void_p, C.c_int32, _i64p, _i64p, C.c_int32, C.c_int32, _dp, _dp]),
     "msdp_release_cache": (C.c_int, []),
     "msdp_debug_pool_stats": (C.c_int, [_P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
     "msdp_debug_mem_info": (C.c_int, [_P(C.c_int64), _P(C.c_int64)]),
@@ -536,16 +536,17 @@ class Handle:
         return S
 
     # ---- AL bookkeeping on the device (affine handles)
-    def block_eigs(self, row0, nblk, k):
+    def block_eigs(self, row0, nblk, k, method=0):
         """eig of the diagonal blocks (row0[b], nblk[b]) of the dual slack of the last al_dual call, on the device (msdp_block_eigs):
         returns (w, V) -- all eigenvalues, block after block and ascending inside a block; V[(rows of block b), c] = eigenvector of
-        the block's c-th smallest eigenvalue, c < k."""
+        the block's c-th smallest eigenvalue, c < k.  method: 0 = tridiagonalisation + bisection + inverse iteration (k <= 8), else
+        Jacobi; 1 = Jacobi; 2 = the tridiagonal method."""
         r0 = np.ascontiguousarray(row0, dtype=np.int64)
         nb = np.ascontiguousarray(nblk, dtype=np.int64)
         tot = int(nb.sum())
         w = np.empty(tot)
         V = np.empty((tot, max(int(k), 1)))
-        _check(self._lib.msdp_block_eigs(self._h, len(nb), r0.ctypes.data_as(_i64p), nb.ctypes.data_as(_i64p), int(k), _dptr(w), _dptr(V)))
+        _check(self._lib.msdp_block_eigs(self._h, len(nb), r0.ctypes.data_as(_i64p), nb.ctypes.data_as(_i64p), int(k), int(method), _dptr(w), _dptr(V)))
         return w, V[:, :int(k)]
 
     def al_primal(self, m):

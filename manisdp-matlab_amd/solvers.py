@@ -687,13 +687,12 @@ def _multiblock_impl(At, b, c, K, options, verbose, rng):
     p = [p0[i] if nset[i] >= o["min_facsize"] else nset[i] for i in range(nb)]        # :34-39
     h = _lib.Handle.multiblock(Atc, b, c, nset, nob, pcap=max(32, max(p) + 2 * int(o["delta"])))
     # options["block_eig"]: "host" = the reference's loop of eig(S{i}) on the host (LAPACK through NumPy), "device" = all blocks in
-    # one launch on the GPU (msdp_block_eigs: one workgroup per block, a Jacobi iteration bounded by ONE CU's path to the L2), "auto"
-    # (default) = device where that wins: from 64 blocks of order <= 128 or from 256 blocks of order <= 256 on (1000 x 60: solve
-    # 1.1 -> 0.35 s, 4000 x 60: 4.5 -> 0.96 s, 1000 x 200: 27 -> 8 s; 100 blocks of order 211: 277 ms per call against 280 on the
-    # host, 20 such blocks: slower) -- and never where the oracle-parity tests compare iterate by iterate: the eigenvectors of
-    # LAPACK and of a Jacobi iteration differ by signs / rotations inside eigenspaces
+    # one launch on the GPU (msdp_block_eigs: one workgroup per block; Householder tridiagonalisation, bisection, inverse iteration
+    # for the `delta` <= 8 vectors the loop uses), "auto" (default) = device from 16 blocks of order <= 256 on, host below -- where the
+    # oracle-parity tests compare iterate by iterate: the eigenvectors of two eigen-solvers differ by signs / rotations inside
+    # eigenspaces
     be = o.get("block_eig", "auto")
-    block_eig_device = be == "device" or (be == "auto" and max(nset) <= 256 and (nb >= 256 or (nb >= 64 and max(nset) <= 128)))
+    block_eig_device = be == "device" or (be == "auto" and nb >= 16 and max(nset) <= 256)
     sigma = float(o["sigma0"]); gama = float(o["gama"])
     y = np.zeros(b.size)
     normb = 1.0 + np.linalg.norm(b)

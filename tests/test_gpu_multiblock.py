@@ -391,23 +391,28 @@ def test_block_eigs_match_lapack(lib, storage):
     h.cost()
     h.al_dual(0.3 * rng.standard_normal(b.size))
     k = 8
-    w, V = h.block_eigs(r0[:-1], nset, k)
-    assert w.shape == (N,) and V.shape == (N, k)
-    for i, n in enumerate(nset):
-        S = h.get_dual_slack_block(r0[i], n)
-        S = 0.5 * (S + S.T)
-        wr = np.linalg.eigvalsh(S)
-        scale = max(1.0, np.abs(wr).max())
-        wi = w[r0[i]:r0[i + 1]]
-        assert np.all(np.diff(wi) >= 0)
-        assert np.abs(wi - wr).max() <= 1e-13 * scale * n
-        kk = min(k, n)
-        Vi = V[r0[i]:r0[i + 1], :kk]
-        assert np.abs(S @ Vi - Vi * wi[:kk]).max() <= 1e-12 * scale * n
-        assert np.abs(Vi.T @ Vi - np.eye(kk)).max() <= 1e-12
-        assert not np.any(V[r0[i]:r0[i + 1], kk:])                       # columns beyond the block's order
-    w2, V2 = h.block_eigs(r0[:-1], nset, k)                              # deterministic
-    assert np.array_equal(w, w2) and np.array_equal(V, V2)
+    for method in (2, 1):                      # 2: tridiagonalisation + bisection + inverse iteration (the default up to k = 8); 1: Jacobi
+      w, V = h.block_eigs(r0[:-1], nset, k, method=method)
+      assert w.shape == (N,) and V.shape == (N, k)
+      for i, n in enumerate(nset):
+          S = h.get_dual_slack_block(r0[i], n)
+          S = 0.5 * (S + S.T)
+          wr = np.linalg.eigvalsh(S)
+          scale = max(1.0, np.abs(wr).max())
+          wi = w[r0[i]:r0[i + 1]]
+          assert np.all(np.diff(wi) >= 0)
+          assert np.abs(wi - wr).max() <= 1e-13 * scale * n
+          kk = min(k, n)
+          Vi = V[r0[i]:r0[i + 1], :kk]
+          assert np.abs(S @ Vi - Vi * wi[:kk]).max() <= 1e-12 * scale * n
+          assert np.abs(Vi.T @ Vi - np.eye(kk)).max() <= 1e-12
+          assert not np.any(V[r0[i]:r0[i + 1], kk:])                       # columns beyond the block's order
+      w2, V2 = h.block_eigs(r0[:-1], nset, k, method=method)             # deterministic
+      assert np.array_equal(w, w2) and np.array_equal(V, V2)
+    with pytest.raises(lib.MsdpError):
+        h.block_eigs(r0[:-1], nset, 9, method=2)                         # the tridiagonal method returns at most 8 vectors
+    w9, V9 = h.block_eigs(r0[:-1], nset, 9)                              # ... the default falls back to Jacobi
+    assert V9.shape == (N, 9) and np.abs(w9 - w).max() <= 1e-11 * max(1.0, np.abs(w).max())
     with pytest.raises(lib.MsdpError):
         h.block_eigs([0], [N + 1], 1)
     if storage == "blocked":
@@ -419,7 +424,7 @@ def test_block_eigs_match_lapack(lib, storage):
 def test_multiblock_solve_with_device_block_eigs(lib, storage):
     """options.block_eig: the reference's host loop of eig(S{i}) against all blocks in one device launch -- same optimum and KKT
     residuals within tol (the iterates differ: Jacobi's eigenvectors are LAPACK's up to signs), on a chain of 18 cliques of 5
-    variables (18 blocks of order 16; "auto" takes the device from 64 blocks on, the host here)."""
+    variables (18 blocks of order 16: "auto" takes the device from 16 blocks on)."""
     from manisdp_matlab_amd import problems as P, solvers
     cl, n = P.chain_cliques(18, 5)
     coe = np.random.default_rng(2).standard_normal(len(P.bqp_sparse_monomials(cl)))
