@@ -1004,6 +1004,40 @@ struct BlockedDev {
 };
 struct BlockOp { const double* M[2]; const double* X[2]; double scale[2]; int nmat, ld, colofs, ncols; double* out; };
 
+// W_b = Ya_b * Yb_b' for every block, in the per-block storage (row r of block b: W[rbase[r] + (c - rlo[r])]): the Gram route of
+// A(Ya Yb') for many blocks -- one 8-byte gather per nonzero of At (k_gram_apply) instead of two panel rows of ld doubles
+// (k_sddmm1: 6.8 GB through the L2 per call at ld = 128 for the 100 cliques of example_bqp_sparse.m, 795 us).  One wave per
+// 16-row tile, v_mfma_f64_16x16x4_f64 over the ld columns, column tile after column tile of the block.
+typedef double blkg_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_block_gram(BlockedDev bd, const double* __restrict__ Ya, const double* __restrict__ Yb, int ld,
+                                                    double* __restrict__ W, const int* skip_flag, int skip_when) {
+    if (skip_flag && *skip_flag == skip_when) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= bd.ntile) return;
+    const int row0 = bd.tile_row0[tile];
+    const int lo = bd.rlo[row0], hi = bd.rhi[row0];
+    const int ra = min(row0 + i, hi - 1);
+    const double* __restrict__ arow = Ya + (int64_t)ra * ld;
+    for (int c0 = lo; c0 < hi; c0 += 16) {
+        const int cb = min(c0 + i, hi - 1);
+        const double* __restrict__ brow = Yb + (int64_t)cb * ld;
+        blkg_d4 acc = (blkg_d4){0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < ld; k0 += 4) {
+            const int kk = k0 + g;
+            const double av = kk < ld ? arow[kk] : 0.0;               // A operand: lane (g, i) = Ya[row0 + i][k0 + g]
+            const double bv = kk < ld ? brow[kk] : 0.0;               // B operand: lane (g, i) = Yb[c0 + i][k0 + g]
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+        const int col = c0 + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                 // D: row g + 4r, column i
+            const int row = row0 + g + 4 * r;
+            if (row < hi && col < hi) W[bd.rbase[row] + (col - lo)] = acc[r];
+        }
+    }
+}
+
 // out[q] = (base ? base[q] : 0) + scale * sum_k At[(position q), k] * vec[k]   over all stored positions
 __global__ __launch_bounds__(256) void k_adjoint_blocked(BlockedDev bd, const double* __restrict__ base, const double* __restrict__ vec,
                                                          double scale, double* __restrict__ out, const int* skip_flag, int skip_when) {
@@ -1560,7 +1594,9 @@ int msdp_affine_setup_blocked(msdp_handle h, int nb, const int64_t* block_n, con
     if (sk.empty()) sk.push_back(0);
     if (lit0.empty()) { lit0.push_back(0); lit1.push_back(0); }
     if (it0.empty()) { it0.push_back(0); it1.push_back(0); }
+    if (pos.empty()) pos.push_back(0);
     if (ci.empty()) { ci.push_back(0); cj.push_back(0); cv.push_back(0.0); }
+    if (pos.empty()) pos.push_back(0);
     int rc;
     if ((rc = up(h, it0, &a.it0)) || (rc = up(h, it1, &a.it1)) || (rc = up(h, kit, &a.kit)) || (rc = up(h, longk, &a.longk)) ||
         (rc = up(h, sk, &a.sk)) || (rc = up(h, lit0, &a.lit0)) || (rc = up(h, lit1, &a.lit1)) || (rc = up(h, lkit, &a.lkit)) ||
@@ -1571,6 +1607,10 @@ int msdp_affine_setup_blocked(msdp_handle h, int nb, const int64_t* block_n, con
         return rc;
     bd.nb = nb; bd.N = N; bd.ntile = (int)tile_row0.size(); bd.etot = etot;
     void* p = nullptr;
+    // Gram route on the blocks (k_block_gram + k_gram_apply): the stored position of every nonzero, and room for W = Ya Yb' block by block
+    if ((rc = up(h, pos, &a.cidx))) return rc;
+    if ((rc = msdp_dev_alloc_bytes(h, &p, (size_t)std::max<int64_t>(etot, 1) * sizeof(double)))) return rc;
+    a.W = (double*)p;
     if ((rc = msdp_dev_alloc_bytes(h, &p, (size_t)std::max<int64_t>(a.nitems, 1) * sizeof(double)))) return rc;
     a.ival = (double*)p;
     if ((rc = msdp_dev_alloc_bytes(h, &p, 64))) return rc;
@@ -1606,11 +1646,11 @@ int msdp_affine_setup_blocked(msdp_handle h, int nb, const int64_t* block_n, con
     if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
     d.AyU = (double*)p;
     HIPCHK(hipMemset(d.AyU, 0, msz));
-    a.W = nullptr;
     d.Sdual = d.AyU;
     h->blocked = true;
     h->dense_symmetric = false;
-    h->tune.affine_route = 1;                              // SDDMM: there is no N x N Gram matrix to form
+    // (a.W: the blocks' own Gram storage, allocated above -- launch_A takes the Gram route on it once the panel is wide enough;
+    //  the N x N routes of use_gram_route / the B route never apply to this storage)
     h->h_ctl->sigma = 1.0;
     return 0;
 }
@@ -1726,6 +1766,19 @@ static int launch_A(msdp_handle h, AffineDev& a, int64_t nnz, const double* Ya, 
     int64_t gm = (a.m + MSDP_BLOCK - 1) / MSDP_BLOCK;           // mode 0: no reduction, size the grid by m
     if (gm > 2048) gm = 2048;
     const int G = mode == 1 ? MSDP_MAX_GRID : (int)gm;
+    if (AffineState* stb = astate(h)) {
+        // per-block storage: the Gram route on the blocks' own storage once the panel is wide enough for the row gathers of the
+        // SDDMM to cost four times the Gram matrix (the rule of use_gram_route, with sum n_i^2 in the place of n^2)
+        if (stb->blk && a.W && a.cidx && mode != 2 && h->tune.affine_route != 1 &&
+            ((double)nnz * a.ld * 16.0 > 4.0 * (2.0 * (double)stb->blk->etot * 8.0 + (double)nnz * 20.0) || h->tune.affine_route == 2)) {
+            hipLaunchKernelGGL(k_block_gram, dim3((stb->blk->ntile + 3) / 4), dim3(256), 0, h->stream, *stb->blk, Ya, Yb, a.ld, a.W, flag, when);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_gram_apply, dim3(G), dim3(MSDP_BLOCK), 0, h->stream, a, (const double*)a.W, mode, axb_out, sigma,
+                               h->d.P, flag, when);
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
+    }
     if (sddmm1_ok(h, a, nnz)) {
         int half = a.ld / 2, lpr = 1;
         while (lpr < half && lpr < 64) lpr <<= 1;

@@ -437,3 +437,33 @@ def test_multiblock_solve_with_device_block_eigs(lib, storage):
         out[mode] = obj
     assert abs(out["device"] - out["host"]) <= 1e-6 * abs(out["host"])
     assert abs(out["auto"] - out["host"]) <= 1e-6 * abs(out["host"])
+
+
+def test_blocked_gram_route_matches_the_sddmm(lib, storage):
+    """Per-block storage: A(Y U') through the Gram matrices of the blocks (k_block_gram + k_gram_apply, taken from a panel width on
+    where the row gathers of the SDDMM cost four times the Gram matrix) against the SDDMM (option affine_route = 1): cost, gradient,
+    Hess-vec, A(YY') at widths 4, 18 and 40."""
+    if storage == "embedded":
+        pytest.skip("the route of the per-block storage")
+    rng = np.random.default_rng(5)
+    nset = [int(v) for v in rng.integers(3, 50, size=20)]
+    At, b, c = _random_multiblock(nset, 400, seed=6)
+    N, nob = sum(nset), 12
+    r0 = np.concatenate([[0], np.cumsum(nset)])
+    y = 0.1 * rng.standard_normal(b.size)
+    for p in (4, 18, 40):
+        Y = rng.standard_normal((N, p)); Y[:r0[nob]] /= np.linalg.norm(Y[:r0[nob]], axis=1, keepdims=True)
+        U = rng.standard_normal((N, p))
+        out = []
+        for route in (2, 1):
+            h = lib.Handle.multiblock(At, b, c, nset, nob, pcap=p)
+            h.set_option("affine_route", route)
+            h.set_multipliers(y, 0.7)
+            h.set_point(Y)
+            f, G, H = h.cost(), h.rgrad(), h.hessvec(h.proj(U))
+            obj, Ax = h.al_primal(b.size)
+            out.append((f, G, H, Ax, obj))
+            h.close()
+        for x, r in zip(*out):
+            x, r = np.asarray(x, float), np.asarray(r, float)
+            assert np.abs(x - r).max() <= 1e-12 * max(1.0, np.abs(r).max())
