@@ -1000,6 +1000,7 @@ struct BlockedDev {
     const int* rlo; const int* rhi; const int* rns;   // N: first / one-past-last row of r's block, its padded order
     const int* prp;                // etot + 1: CSR by stored position -> (constraint, coefficient)
     const int* prk; const double* prv;
+    int nlongq; const int* longq;  // stored positions that occur in more than ADJB_LONG constraints (the entry of the monomial 1: in every 'x_i^2 = 1' row of its block): one wave each
     const int* tile_row0;          // ntile: first row of every 16-row tile (tiles never straddle blocks)
 };
 struct BlockOp { const double* M[2]; const double* X[2]; double scale[2]; int nmat, ld, colofs, ncols; double* out; };
@@ -1039,11 +1040,30 @@ __global__ __launch_bounds__(256) void k_block_gram(BlockedDev bd, const double*
 }
 
 // out[q] = (base ? base[q] : 0) + scale * sum_k At[(position q), k] * vec[k]   over all stored positions
+#define ADJB_LONG 16
 __global__ __launch_bounds__(256) void k_adjoint_blocked(BlockedDev bd, const double* __restrict__ base, const double* __restrict__ vec,
                                                          double scale, double* __restrict__ out, const int* skip_flag, int skip_when) {
     if (skip_flag && *skip_flag == skip_when) return;
-    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < bd.etot; q += (int64_t)gridDim.x * blockDim.x) {
+    // A position that occurs in hundreds of constraints (the (1, 1) entry of a moment block: every `x_i^2 = 1` row) would keep ONE
+    // thread in a chain of dependent gathers for the whole launch -- 362 us per call on the 100 cliques of example_bqp_sparse.m,
+    // half of a Hess-vec, whatever the order or layout of the short positions: those go to a wave each (workgroups behind the
+    // first `gmain`), lanes striding over the list.
+    const int gmain = (int)gridDim.x - (bd.nlongq + 3) / 4;
+    if ((int)blockIdx.x >= gmain) {
+        const int lane = threadIdx.x & 63;
+        const int lq = ((int)blockIdx.x - gmain) * 4 + (threadIdx.x >> 6);
+        if (lq >= bd.nlongq) return;
+        const int64_t q = bd.longq[lq];
         const int s0 = bd.prp[q], s1 = bd.prp[q + 1];
+        double acc = 0.0;
+        for (int t = s0 + lane; t < s1; t += 64) acc = fma(bd.prv[t], vec[bd.prk[t]], acc);
+        acc = msdp_wave_sum(acc);
+        if (lane == 0) out[q] = (base ? base[q] : 0.0) + scale * acc;
+        return;
+    }
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < bd.etot; q += (int64_t)gmain * blockDim.x) {
+        const int s0 = bd.prp[q], s1 = bd.prp[q + 1];
+        if (s1 - s0 > ADJB_LONG) continue;
         double acc = 0.0;
         for (int t = s0; t < s1; ++t) acc = fma(bd.prv[t], vec[bd.prk[t]], acc);
         out[q] = (base ? base[q] : 0.0) + scale * acc;
@@ -1595,6 +1615,10 @@ int msdp_affine_setup_blocked(msdp_handle h, int nb, const int64_t* block_n, con
     if (lit0.empty()) { lit0.push_back(0); lit1.push_back(0); }
     if (it0.empty()) { it0.push_back(0); it1.push_back(0); }
     if (pos.empty()) pos.push_back(0);
+    std::vector<int> longq;
+    for (int64_t q = 0; q < etot; ++q) if (prp[q + 1] - prp[q] > ADJB_LONG) longq.push_back((int)q);
+    bd.nlongq = (int)longq.size();
+    if (longq.empty()) longq.push_back(0);
     if (ci.empty()) { ci.push_back(0); cj.push_back(0); cv.push_back(0.0); }
     if (pos.empty()) pos.push_back(0);
     int rc;
@@ -1603,7 +1627,8 @@ int msdp_affine_setup_blocked(msdp_handle h, int nb, const int64_t* block_n, con
         (rc = up(h, us0, &a.us0)) || (rc = up(h, us1, &a.us1)) || (rc = up(h, uk, &a.uk)) ||
         (rc = up(h, cjc, &a.cjc)) || (rc = up(h, ci, &a.ci)) || (rc = up(h, cj, &a.cj)) || (rc = up(h, cv, &a.cv)) ||
         (rc = up(h, rbase, &bd.rbase)) || (rc = up(h, rlo, &bd.rlo)) || (rc = up(h, rhi, &bd.rhi)) || (rc = up(h, rns, &bd.rns)) ||
-        (rc = up(h, prp, &bd.prp)) || (rc = up(h, prk, &bd.prk)) || (rc = up(h, prv, &bd.prv)) || (rc = up(h, tile_row0, &bd.tile_row0)))
+        (rc = up(h, prp, &bd.prp)) || (rc = up(h, prk, &bd.prk)) || (rc = up(h, prv, &bd.prv)) || (rc = up(h, tile_row0, &bd.tile_row0)) ||
+        (rc = up(h, longq, &bd.longq)))
         return rc;
     bd.nb = nb; bd.N = N; bd.ntile = (int)tile_row0.size(); bd.etot = etot;
     void* p = nullptr;
@@ -1829,7 +1854,7 @@ static int adjoint_grid(const AffineDev& a) {
 static int launch_adjoint(msdp_handle h, const AffineDev& a, const double* base, const double* vec, double scale, double* out,
                           const int* flag, int when, bool restricted_ok) {
     if (AffineState* stb = astate(h)) if (stb->blk) {
-        const int64_t g = std::min<int64_t>(4096, (stb->blk->etot + 255) / 256);
+        const int64_t g = std::min<int64_t>(4096, (stb->blk->etot + 255) / 256) + (stb->blk->nlongq + 3) / 4;
         hipLaunchKernelGGL(k_adjoint_blocked, dim3((int)g), dim3(256), 0, h->stream, *stb->blk, base, vec, scale, out, flag, when);
         HIPCHK(hipGetLastError());
         return 0;
