@@ -69,6 +69,16 @@ def cpu_baseline(C, Y0, budget_s=15.0):
     """Oracle ("port": oracle/oracle_core.c, plain C + OpenMP over rows) timed on the host cores of this
     box on the SAME step (one full RTR call from Y0), repeated until ~budget_s of CPU work is done."""
     from oracle import core
+    # all host cores (BASELINE.md); one untimed call at that count and one at the parity tests' default of 16 decide which the
+    # bounded sample runs on -- a row-parallel OpenMP loop over 20000 rows does not always gain from 100+ threads
+    ncpu = core.host_cpus()
+    trial = {}
+    for nt in sorted({ncpu, min(16, ncpu)}):
+        core.set_threads(nt)
+        t1 = time.time()
+        _, st = core.rtr_onlyunitdiag(C, Y0, 40, 100, 1e-8)
+        trial[nt] = st.hessvecs / (time.time() - t1)
+    core.set_threads(max(trial, key=trial.get))
     t0 = time.time()
     hv = 0
     reps = 0
@@ -80,9 +90,11 @@ def cpu_baseline(C, Y0, budget_s=15.0):
         if time.time() - t1 > budget_s / 2:       # one call already uses most of the budget
             break
     dt = time.time() - t0
-    return {"value": hv / dt, "unit": "Hess-vec/s", "cores": core.num_threads(), "kind": "port", "kind_detail": PORT_DETAIL,
+    return {"value": hv / dt, "unit": "Hess-vec/s", "cores": core.num_threads(), "host_cpus": ncpu,
+            "threads_tried_hessvec_per_s": {str(k): v for k, v in trial.items()}, "kind": "port", "kind_detail": PORT_DETAIL,
             "sample": f"{reps} full RTR calls ({hv} Hess-vecs incl. all tCG vector work, retractions and cost "
-                      f"evaluations) of the same G81 p={Y0.shape[1]} step in the C/OpenMP oracle, {dt:.1f} s"}
+                      f"evaluations) of the same G81 p={Y0.shape[1]} step in the C/OpenMP oracle on {core.num_threads()} of "
+                      f"{ncpu} host CPUs (the faster of all-cores / 16 threads), {dt:.1f} s"}
 
 
 def cpu_dense_hessvec(n, p, budget_s=3.0):
@@ -493,18 +505,26 @@ def main():
                 msd, byd, fld = hd.bench_hessvec(100)
             hd.close()
             # symmetric C, p <= 32, n >= 8192: the upper-triangle contraction of msdp_densesym.hip (k_dense_sym + k_sym_fold) takes the product
-            kname = ("k_dense_sym + k_sym_fold + k_dense_hess_epi_obl" if (dp <= 32 and dn >= 8192) else "k_dense_partial3 + k_dense_hess_epi_obl")
+            sym = dp <= 32 and dn >= 8192
+            kname = ("k_dense_sym + k_sym_fold + k_dense_hess_epi_obl" if sym else "k_dense_partial3 + k_dense_hess_epi_obl")
+            survey_bytes = byd                       # 8 n^2 + 3 * 8 n p (the whole matrix once)
+            if sym:
+                # what the symmetric algorithm must move: the upper triangle incl. the diagonal once + three panels.  The bound follows
+                # from the arithmetic intensity against the ridge (fp64 MFMA peak / HBM peak = 9.8 flop/B), not from p alone
+                byd = 8.0 * dn * (dn + 1) / 2 + 3 * 8.0 * dn * dp
+            ridge = MFMA_F64_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+            bound = "mfma" if fld / byd > ridge else "hbm"
             ent = {"n": dn, "p": dp, "kernel": kname, "hessvec_us": msd * 1e3,
-                   "algorithmic_bytes": byd, "algorithmic_flops": fld,
+                   "algorithmic_bytes": byd, "algorithmic_flops": fld, "arithmetic_intensity_flop_per_byte": fld / byd,
                    "TFLOPs_f64": fld / msd / 1e9, "frac_mfma_f64_peak": fld / msd / 1e9 / MFMA_F64_TFLOPS,
                    "GBps": byd / msd / 1e6, "frac_hbm_peak": byd / msd / 1e6 / HBM_PEAK_GBS,
                    "roofline": secondary_roofline(kname, msd * 1e3, byd, fld,
-                                                  ("r4_pmc_dense%d_p%d.json" % (dn, dp), "r3_pmc_dense%d_p%d.json" % (dn, dp), "r2_pmc_dense%d_p%d.json" % (dn, dp)),
-                                                  bound="hbm" if dp <= RIDGE_P else "mfma")}
-            if "k_dense_sym" in kname:
-                ent["roofline"]["note"] = ("algorithmic_bytes is SURVEY.md 8(d)'s dense-C figure (the whole n x n matrix once + three panels); the symmetric "
-                                           "route reads the upper triangle only, so achieved / peak can exceed what streaming the whole matrix allows -- "
-                                           "`traffic` (rocprofv3 --pmc) is what the three launches move")
+                                                  ("r5_pmc_dense%d_p%d.json" % (dn, dp), "r4_pmc_dense%d_p%d.json" % (dn, dp), "r3_pmc_dense%d_p%d.json" % (dn, dp), "r2_pmc_dense%d_p%d.json" % (dn, dp)),
+                                                  bound=bound)}
+            if sym:
+                ent["survey_8d_bytes"] = survey_bytes
+                ent["roofline"]["note"] = ("symmetric route: algorithmic_bytes = 8 n (n + 1) / 2 + 3 * 8 n p (upper triangle once + three panels); "
+                                           "SURVEY.md 8(d)'s whole-matrix figure is kept as survey_8d_bytes and is not a bound for this kernel")
             if dn == 5000 and not args.no_cpu_baseline:
                 ent["cpu_baseline"] = cpu_dense_hessvec(dn, dp)
             dense.append(ent)

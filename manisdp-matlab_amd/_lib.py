@@ -134,10 +134,6 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise MsdpError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(or `make -C manisdp-matlab_amd/csrc`). There is no CPU fallback.")
-    # In-process ranks (msdp_comm_init_local) run one launch per member SIDE BY SIDE (cross-rank persistent tCG): each needs a
-    # hardware queue of its own, and the runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES of them (4 by default).
-    # Only effective if the HIP runtime has not been initialised yet; the library checks with a handshake and falls back anyway.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

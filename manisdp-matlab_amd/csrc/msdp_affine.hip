@@ -296,14 +296,12 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev 
     }
     // Long constraints (a trace row): wave q provides the value of number q -- hetero (the SDDMM ran as a side job of the contraction
     // launch, msdp_sddmm_side): the sum of its item values, in item order, the same in every workgroup; else what k_sddmm1 left in w
-    if (support && wave < a.nlong) {
-        const int k = a.longk[wave];
-        double v;
-        if (hetero) {
-            double a0 = 0.0;
-            for (int it = a.lkit[wave] + lane; it < a.lkit[wave + 1]; it += 64) a0 += a.ival[it];
-            v = msdp_wave_sum(a0);
-        } else v = a.w[k];
+    // (only the side-job route needs wl, and it is taken for nlong <= MSDP_WAVES only; otherwise k_sddmm1's last workgroup has written
+    // w[longk[q]] and the records below read it there -- any number of long constraints)
+    if (support && hetero && wave < a.nlong) {
+        double a0 = 0.0;
+        for (int it = a.lkit[wave] + lane; it < a.lkit[wave + 1]; it += 64) a0 += a.ival[it];
+        const double v = msdp_wave_sum(a0);
         if (lane == 0) wl[wave] = v;
     }
     int lo, hi;
@@ -337,10 +335,10 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev 
                     // flattened record of the entry: column, first (coefficient, constraint) pair; further pairs are rare
                     jl = a.sqj[q0 + sub];
                     const int k0 = a.sqk[q0 + sub], more = a.sqmore[q0 + sub];
-                    vl = a.sqv[q0 + sub] * (k0 >= 0 ? w[k0] : wl[-1 - k0]);
+                    vl = a.sqv[q0 + sub] * (k0 >= 0 ? w[k0] : (hetero ? wl[-1 - k0] : w[a.longk[-1 - k0]]));
                     if (more > 0) {
                         const int s0 = a.rp[a.sup[q0 + sub]] + 1;
-                        for (int tt = s0; tt < s0 + more; ++tt) { const int kx = a.rkx[tt]; vl = fma(a.rv[tt], kx >= 0 ? w[kx] : wl[-1 - kx], vl); }
+                        for (int tt = s0; tt < s0 + more; ++tt) { const int kx = a.rkx[tt]; vl = fma(a.rv[tt], kx >= 0 ? w[kx] : (hetero ? wl[-1 - kx] : w[a.longk[-1 - kx]]), vl); }
                     }
                 }
                 for (int e0 = 0; __builtin_amdgcn_ballot_w64(e0 < cnt) != 0ULL; e0 += SPB) {      // until the longest row of the wave is done
@@ -385,7 +383,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev 
             }
         }
     };
-    if (support && a.nlong > 0) __syncthreads();                   // wl is in place
+    if (support && hetero && a.nlong > 0) __syncthreads();         // wl is in place
     double2 raw[NCH], y[NCH], u[NCH];
     int row0 = lo + wave * RPW;                                    // wave-uniform
     const bool first = row0 < hi;

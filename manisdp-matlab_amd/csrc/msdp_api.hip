@@ -990,11 +990,11 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "affine_fuse")) { t.affine_fuse = value != 0; h->chunk_len = 0; h->state_valid = false; }
     else if (!strcmp(name, "affine_side")) { t.affine_side = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "affine_broute")) { t.affine_broute = value != 0; h->chunk_len = 0; }
-    else if (!strcmp(name, "dense_sym")) { t.dense_sym = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
-    else if (!strcmp(name, "dense_sym_min")) { t.dense_sym_min = value > 0 ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
-    else if (!strcmp(name, "dense_sym_rt")) { t.dense_sym_rt = (value >= 1 && value <= 3) ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
+    else if (!strcmp(name, "dense_sym")) { t.dense_sym = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE && !h->blocked) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
+    else if (!strcmp(name, "dense_sym_min")) { t.dense_sym_min = value > 0 ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE && !h->blocked) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
+    else if (!strcmp(name, "dense_sym_rt")) { t.dense_sym_rt = (value >= 1 && value <= 3) ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE && !h->blocked) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
     else if (!strcmp(name, "dense_sym_db")) { t.dense_sym_db = (value >= 0 && value <= 2) ? value : 0; h->chunk_len = 0; }
-    else if (!strcmp(name, "dense_sym_len")) { t.dense_sym_len = value > 0 ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
+    else if (!strcmp(name, "dense_sym_len")) { t.dense_sym_len = value > 0 ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE && !h->blocked) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
     else if (!strcmp(name, "debug_fail_persist")) t.fail_persist = value != 0;
     else if (!strcmp(name, "debug_xr_skip")) t.fail_xr = value != 0;
     else if (!strcmp(name, "debug_fail_block")) t.fail_block = value != 0;
@@ -2293,6 +2293,8 @@ extern "C" int msdp_escape_eigs_dual(msdp_handle h, int32_t k, double tol, int32
     CHECK_H(h);
     if (!lam_min || !V) { msdp_set_error("escape_eigs_dual: null argument"); return MSDP_EINVAL; }
     if (h->d.costkind != COST_AFFINE || !h->dual_valid) { msdp_set_error("escape_eigs_dual: call msdp_al_dual first"); return MSDP_ESTATE; }
+    // per-block storage: d.Sdual holds sum n_i * nS_i doubles, not an n x nS matrix -- the eigen-pairs come block by block
+    if (h->blocked) { msdp_set_error("escape_eigs_dual: this multiblock handle stores its blocks only (msdp_block_eigs)"); return MSDP_EUNSUPPORTED; }
     int rc = msdp_escape_impl(h, k, tol, maxit, lam_min, V, lam_max, iters, h->d.Sdual);
     (void)hipStreamSynchronize(h->stream);
     return rc;

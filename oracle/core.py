@@ -28,13 +28,24 @@ def load():
         os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _lib = C.CDLL(_PATH)
         _lib.oc_num_threads.restype = C.c_int
-        # at most 16 threads, never more than the CPUs this process may run on
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 1
-        _lib.oc_set_threads(max(1, min(16, avail)))
+        # default for the parity tests: at most 16 threads, never more than the CPUs this process may run on
+        # (bench.py's cpu_baseline calls set_threads(host_cpus()) -- all host cores)
+        _lib.oc_set_threads(max(1, min(16, host_cpus())))
     return _lib
+
+
+def host_cpus():
+    """CPUs this process may run on (nproc)."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def set_threads(n):
+    """OpenMP threads of the C restatement from now on; returns the count in force."""
+    load().oc_set_threads(max(1, int(n)))
+    return num_threads()
 
 
 def _csr(Cm):

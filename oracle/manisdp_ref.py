@@ -177,6 +177,21 @@ def hessvec_onlyunitdiag(C, Y, U):
     return eH - Y * np.sum(Y * eH, axis=1, keepdims=True) - U * eG
 
 
+def onlyunitdiag_rows(Crows, rows, Y, U=None):
+    """The closures of ManiSDP_onlyunitdiag.m:117-130 on a SUBSET of rows -- for checks at sizes where the whole dense C (3.2 GB at
+    n = 20000) is not wanted on the host: ``Crows = C[rows, :]``.  Returns (eG[rows], grad[rows], hess[rows] or None); the cost is
+    ``0.5 * sum(eG)`` over ALL rows (:120), i.e. the sum of the first output over a partition of the rows."""
+    Yr = Y[rows]
+    YC = Crows @ Y                                        # :118 (C symmetric)
+    eG = np.sum(YC * Yr, axis=1, keepdims=True)           # :119
+    G = YC - Yr * eG                                      # :124
+    H = None
+    if U is not None:
+        eH = Crows @ U                                    # :128
+        H = eH - Yr * np.sum(Yr * eH, axis=1, keepdims=True) - U[rows] * eG   # :129
+    return eG[:, 0], G, H
+
+
 def ManiSDP_onlyunitdiag(C, options=None, rng=None, verbose=False, eig_fn=None, q1="reference"):
     """``[X, obj, data] = ManiSDP_onlyunitdiag(C, options)``; returns (Y, obj, data)
     with ``X = Y @ Y.T`` (``data['X']`` is only formed when n <= 4000).

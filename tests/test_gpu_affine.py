@@ -530,3 +530,56 @@ def test_fused_sddmm_and_sphere_epilogue_match_the_separate_launches(lib, monkey
         assert abs(out[0][0] - out[q][0]) <= 1e-13 * max(1.0, abs(f_ref))
         assert _relerr(out[0][1], out[q][1]) < 1e-13
         assert _relerr(out[0][2], out[q][2]) < 1e-12
+
+
+@pytest.mark.parametrize("kind_name,p", [("unittrace", 6), ("unittrace", 40), ("generic", 9)])
+def test_sphere_hessvec_with_more_long_constraints_than_waves(lib, kind_name, p):
+    """k_sph_hess_fused kept the values of the long constraints (more than 128 nonzeros) in an LDS array of
+    MSDP_WAVES entries; only the side-job route was guarded by nlong <= MSDP_WAVES.  24 long constraints + the trace row, few
+    touched entries: every route (side job refused -> k_sddmm1 + fused epilogue, separate launches) against the oracle
+    (ManiSDP_unittrace.m:171-177, ManiSDP.m:158-162)."""
+    import scipy.sparse as sp
+    from oracle import manisdp_ref as R
+    n, nlong, nshort = 320, 24, 150
+    rng = np.random.default_rng(11)
+    cols = []
+    for k in range(nlong):
+        ii = rng.integers(0, n, 400); jj = rng.integers(0, n, 400)
+        keep = ii < jj
+        A = sp.coo_matrix((rng.choice([1.0, -0.5, 0.25], keep.sum()), (ii[keep], jj[keep])), shape=(n, n)).tocsr()
+        A = A + A.T
+        assert A.nnz > 2 * 128
+        cols.append(A.reshape((n * n, 1)).tocsc())
+    for k in range(nshort):
+        i, j = sorted(rng.choice(n, 2, replace=False))
+        A = sp.coo_matrix(([1.0, 1.0], ([i, j], [j, i])), shape=(n, n))
+        cols.append(A.reshape((n * n, 1)).tocsc())
+    cols.append(sp.identity(n, format="csr").reshape((n * n, 1)).tocsc())          # the trace row, last (example_theta.m:36-39)
+    At = sp.hstack(cols).tocsc()
+    m = At.shape[1]
+    b = np.zeros(m); b[-1] = 1.0
+    G0 = rng.standard_normal((n, n)); c = ((G0 + G0.T) / (2 * np.sqrt(n))).ravel()
+    Y = rng.standard_normal((n, p))
+    if kind_name == "unittrace":
+        Y /= np.linalg.norm(Y)
+        prob = R._UnitTraceProblem(At, b, c, n, p); kind = lib.KIND_UNITTRACE
+    else:
+        prob = R._GenericProblem(At, b, c, n, p); kind = lib.KIND_GENERIC
+    U = rng.standard_normal((n, p))
+    if kind_name != "generic":
+        U = prob.M.proj(Y, U)
+    y = rng.standard_normal(m) * 0.1
+    sigma = 3.7
+    prob.y, prob.sigma = y, sigma
+    f_ref = prob.cost(Y); G_ref = prob.grad(Y); H_ref = prob.hess(Y, U)
+    for fuse, side in ((1, 1), (1, 0), (0, 0)):
+        h = lib.Handle.affine(kind, At, b, c, n)
+        h.set_option("affine_fuse", fuse); h.set_option("affine_side", side)
+        h.set_multipliers(y, sigma)
+        h.set_point(Y)
+        assert abs(h.cost() - f_ref) <= 1e-11 * max(1.0, abs(f_ref))
+        assert _relerr(h.rgrad(), G_ref) < 1e-11
+        H = h.hessvec(U)
+        assert _relerr(H, H_ref) < 1e-11, (fuse, side)
+        assert np.array_equal(H, h.hessvec(U))
+        h.close()

@@ -220,3 +220,51 @@ def test_trustregions_through_the_symmetric_contraction(lib, shape):
         Cm = c.toarray().reshape(K["s"], K["s"], order="F")
         Yf, obj, data = solvers.ManiSDP_onlyunitdiag(Cm, {"device_options": {"dense_sym": 2}}, verbose=False)
         assert data["dinf"] < 1e-8 and abs(-obj - known["mcp250-1"]) < 1e-6 * abs(known["mcp250-1"])
+
+
+@pytest.mark.parametrize("n", [8192, 20000])
+def test_dense_operators_at_the_benchmarked_size(lib, n):
+    """bench.py quotes k_dense_sym at n = 20000 and the route switches on by default at n >= 8192, but no
+    test compared the one-GPU dense path with the oracle beyond n = 3000 (79 row blocks and a multi-round slice plan at 20000: a
+    different plan).  Synthetic dense C of bench.py (generated on the device; problems.SyntheticDenseC restates the generator on
+    the host row by row), p = 16 / 32 on the symmetric route (the default here) and p = 64 on the full kernel: Hess-vec and
+    gradient against the oracle's closures (ManiSDP_onlyunitdiag.m:117-130) on 96 sampled rows incl. the row-block edges, the cost
+    against the oracle's sum over ALL rows, two runs bit for bit, and the symmetric route against the full kernel on every row."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R
+    seed = 0
+    S = problems.SyntheticDenseC(n, seed)
+    rng = np.random.default_rng(n)
+    ps = (16, 32, 64)
+    Ys, Us = {}, {}
+    for p in ps:
+        Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+        Ys[p], Us[p] = Y, rng.standard_normal((n, p))
+    edge = [0, 1, 15, 16, 127, 128, 255, 256, 257, 511, 512, n // 2 - 1, n // 2, n - 257, n - 256, n - 17, n - 16, n - 2, n - 1]
+    rows = np.unique(np.concatenate([np.array(edge), rng.choice(n, 96 - len(edge), replace=False)]))
+    # oracle: eG over all rows (for the cost), in chunks of rows of the generator; gradient / Hess-vec on the sampled rows
+    f_ref = {p: 0.0 for p in ps}
+    for r0 in range(0, n, 512):
+        blk = np.arange(r0, min(n, r0 + 512))
+        Cb = S.rows(blk)
+        for p in ps:
+            f_ref[p] += 0.5 * float(np.sum(R.onlyunitdiag_rows(Cb, blk, Ys[p])[0]))
+    Cr = S.rows(rows)
+    h = lib.Handle.dense_synthetic(n, seed, pcap=64)
+    for p in ps:
+        Y, U = Ys[p], Us[p]
+        _, G_ref, H_ref = R.onlyunitdiag_rows(Cr, rows, Y, U)
+        h.set_option("dense_sym", 1)                               # default: symmetric route from 8192 rows on, p <= 32
+        h.set_point(Y)
+        f, G, H = h.cost(), h.rgrad(), h.hessvec(U)
+        assert abs(f - f_ref[p]) <= 1e-12 * max(1.0, abs(f_ref[p])), (p, f, f_ref[p])
+        assert _relerr(G[rows], G_ref) < 1e-12, p
+        assert _relerr(H[rows], H_ref) < 1e-12, p
+        assert np.array_equal(H, h.hessvec(U)), p                  # no atomics, fixed summation orders
+        assert np.array_equal(G, h.rgrad()), p
+        if p <= 32:
+            h.set_option("dense_sym", 0)                           # the full kernel on the same data: every row
+            h.set_point(Y)
+            assert abs(h.cost() - f) <= 1e-13 * max(1.0, abs(f))
+            assert _relerr(h.rgrad(), G) < 1e-13 and _relerr(h.hessvec(U), H) < 1e-13, p
+    h.close()

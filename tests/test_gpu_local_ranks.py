@@ -545,7 +545,6 @@ def test_cross_rank_persistent_tcg(N, shape, p):
         assert np.array_equal(q["Y"], res[0]["Y"])
         # collectives per TR iteration only (retraction, cost / gradient at the proposal, decision): the same number per iteration
         # whether a tCG makes 7 trips or 60
-        assert q["calls"] % max(q["iters"], 1) == 0 or True
         per_it = (q["calls"] - q["calls7"]) / max(q["iters"] - q["iters7"], 1) if q["iters"] != q["iters7"] else q["calls"] / max(q["iters"], 1)
         assert q["hv7"] < st.hessvecs
         assert abs(q["calls"] / max(q["iters"], 1) - q["calls7"] / max(q["iters7"], 1)) < 1.0 + 6.0 / max(q["iters7"], 1), (q["calls"], q["iters"], q["calls7"], q["iters7"], per_it)

@@ -310,6 +310,33 @@ def _stacked_maxcut(nblk, n, seed):
     return C0, scale, At, np.array([1.0]), c
 
 
+def test_dense_slack_entry_points_refuse_a_blocked_handle(lib, storage, monkeypatch):
+    """a per-block handle keeps S as the concatenation of its diagonal blocks (sum n_i * nS_i doubles); the entry
+    points that read an N x nS matrix must refuse it instead of reading past the buffer (msdp_block_eigs is the per-block call)."""
+    if storage == "embedded":
+        pytest.skip("per-block storage only")
+    monkeypatch.setenv("MSDP_MULTIBLOCK_BLOCKED", "1")
+    rng = np.random.default_rng(5)
+    nset = [12, 30, 7, 22]
+    At, b, c = _random_multiblock(nset, 40, seed=6)
+    N, p = sum(nset), 4
+    Y = rng.standard_normal((N, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    y = 0.1 * rng.standard_normal(b.size)
+    h = lib.Handle.multiblock(At, b, c, nset, len(nset))
+    h.set_multipliers(y, 0.5)
+    h.set_point(Y)
+    f0 = h.cost()
+    h.al_dual(y)
+    with pytest.raises(lib.MsdpError, match="msdp_block_eigs"):
+        h.escape_eigs_dual(2)
+    with pytest.raises(lib.MsdpError, match="get_dual_slack_block"):
+        h.get_dual_slack()
+    h.set_option("dense_sym", 2)                                    # must not reserve an N x N plan either
+    h.set_point(Y)
+    assert abs(h.cost() - f0) <= 1e-13 * max(1.0, abs(f0))
+    h.close()
+
+
 def test_blocked_storage_matches_the_embedding(lib, storage, monkeypatch):
     """The two representations of one direct sum: cost, gradient, Hess-vec, A(YY'), the dual step and a trustregions() call
     agree to rounding (different summation orders, so not bit for bit)."""
