@@ -263,9 +263,13 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
     if (d.mdx) dev_free(h, d.mdx);
     d.mdx = nullptr;
     {
-        int rc = dev_alloc_uncached<double>(h, &d.mdx, cnt);
+        // rows padded to whole 128-byte lines for the persistent kernels' lanes-per-row (2 x 8 / 16 / 32 doubles; msdp_persist.hip xld)
+        const size_t xcap = ldcap <= 16 ? 16 : (ldcap <= 32 ? 32 : (ldcap <= 64 ? 64 : (size_t)ldcap));
+        const size_t xcnt = rows * xcap;
+        int rc = dev_alloc_uncached<double>(h, &d.mdx, xcnt);
         if (rc) return rc;
-        HIPCHK(hipMemsetAsync(d.mdx, 0, cnt * sizeof(double), h->stream));
+        h->mdx_doubles = xcnt;
+        HIPCHK(hipMemsetAsync(d.mdx, 0, xcnt * sizeof(double), h->stream));
     }
     if (h->use_comm || h->nranks > 1) {
         int rc = dev_alloc<double>(h, &h->full_buf, cnt * (size_t)h->nranks);
@@ -970,6 +974,8 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "escape_start_y")) t.escape_start_y = value != 0;
     else if (!strcmp(name, "xpersist")) t.xpersist = value != 0;
     else if (!strcmp(name, "persist_refresh")) t.persist_refresh = value > 0 ? value : 0;
+    else if (!strcmp(name, "persist_early")) t.persist_early = value > 0 ? value : 0;
+    else if (!strcmp(name, "persist_xld")) t.persist_xld = value ? 1 : 0;
     else if (!strcmp(name, "psync_backoff")) t.psync_backoff = value > 0 ? value : 0;
     else if (!strcmp(name, "affine_overlap")) { t.affine_overlap = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "trip1")) { t.trip1 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
@@ -1625,6 +1631,7 @@ static void fill_ctl(msdp_handle h, const msdp_rtr_opts* o) {
     c->tolgradnorm = o->tolgradnorm; c->kappa = o->kappa; c->theta = o->theta;
     c->rho_prime = o->rho_prime; c->rho_reg = o->rho_regularization;
     c->persist_refresh = h->tune.persist_refresh;
+    c->persist_early = h->tune.persist_early;
     c->psync_backoff = h->tune.psync_backoff;
     // trustregions.m:363-372; typicaldist: pi*sqrt(n) (ManiSDP_onlyunitdiag.m:137) or pi (spherefactory.m:111)
     // ... or sqrt(n*p) (euclideanfactory.m:57)

@@ -29,12 +29,13 @@
 
 #include "msdp_psync.h"
 
-size_t msdp_psync_bytes() { return 2 * PSYNC_REGION * sizeof(double); }       // regions A (tCG) and B (TR tail)
+size_t msdp_psync_bytes() { return (2 * PSYNC_REGION + PFLAG_WORDS64) * sizeof(double); }       // regions A (tCG) and B (TR tail), row flags
 
 __global__ void k_psync_reset(unsigned long long* slots, int* err) {
     const int tot = (int)PSYNC_CNT_OFF;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += gridDim.x * blockDim.x) { slots[i] = PSYNC_SENT; slots[PSYNC_REGION + i] = PSYNC_SENT; }
     if (blockIdx.x == 0 && threadIdx.x < 64) { slots[PSYNC_CNT_OFF + threadIdx.x] = 0ULL; slots[PSYNC_REGION + PSYNC_CNT_OFF + threadIdx.x] = 0ULL; }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (int)PFLAG_WORDS64; i += gridDim.x * blockDim.x) slots[PFLAG_OFF64 + i] = 0ULL;
     if (blockIdx.x == 0 && threadIdx.x == 0) *err = 0;
 }
 
@@ -44,6 +45,8 @@ __global__ void k_psync_reset(unsigned long long* slots, int* err) {
 //   0 top of the trip (gathers about to be issued)   1 gathers + row arithmetic done   2 first grid reduction returned (d_Hd)
 //   3 trial step formed, residual rows stored        4 those stores performed          5 second grid reduction returned
 //   6 new direction formed (end of the trip)
+// EARLY trips (round 5): 3 = trial step formed, rows stored, reduction 2 POSTED; 4 = own stores performed, row flag raised;
+//   5 = the neighbours' flags seen; 6 = their rows gathered (C*tangent(r') formed); 7 = second grid reduction returned
 #define MSDP_TRACE_J0 16
 #define MSDP_TRACE_NJ 32
 #define TSTAMP(ph) do { if (TRACE && threadIdx.x == 0 && j >= MSDP_TRACE_J0 && j < MSDP_TRACE_J0 + MSDP_TRACE_NJ) \
@@ -53,11 +56,12 @@ __global__ void k_psync_reset(unsigned long long* slots, int* err) {
 // travel through one exchange buffer of all n rows (d.xr_mdx, global row indices), and no collective is issued per trip.  Same
 // arithmetic per row as the one-rank kernel; the sums are formed over d.xr_gtot partials in index order on every rank (same bits on
 // every rank -> same decisions).  Two slot regions alternate with the TR iteration; each launch clears the other one at its start.
-template <int LPR, int EW, int R, bool FUSE, bool TRACE, bool XR>
+template <int LPR, int EW, int R, bool FUSE, bool TRACE, bool XR, bool EARLYP>
 __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long long* slots, int* err, const int bx) {
     extern __shared__ double lds[];
     __shared__ double sh[3 * PWAVES];
     __shared__ double shb[8];
+    __shared__ int shfail;
     constexpr int RPW = 64 / LPR;
     constexpr int RSTEP = PWAVES * RPW;       // rows per pass of the workgroup
     constexpr int ROWS = R * RSTEP;               // row slots of the workgroup
@@ -144,6 +148,22 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     // so every workgroup takes the same branch.
     const int refresh = c->persist_refresh;
     const int backoff = c->psync_backoff;
+    // EARLY (round 5): the gather of tangent(r') leaves the critical path.  Its rows need only the neighbours' stores, not beta, so
+    // a workgroup (1) posts its partial sums of reduction 2 the moment they exist -- no longer behind the drain of its row stores --,
+    // (2) drains its stores and raises one flag per WAVE (the number of this publication), (3) watches the flags of the waves that
+    // own the rows it gathers, gathers them and forms C*tangent(r') while reduction 2 is in flight, (4) picks up reduction 2
+    // (polled in the shadow of the flag and gather waits), then beta, the new direction and C*mdelta' = C*tangent(r') + beta*C*mdelta
+    // as before.  Same row arithmetic, same summation orders, same decisions as the trip above: the oracle / drift tests are
+    // unchanged.  The rows are safe to overwrite one trip later: every gather is consumed before its workgroup posts reduction 1.
+    constexpr bool ALLG = !LOWREG && EW > 0 && R * EW <= 25;
+    constexpr bool EARLY = EARLYP && TWOSYNC && ALLG && !XR;
+    constexpr int NE = EARLY ? (R * RPW * EW + 63) / 64 : 1;       // flags a lane watches
+    const bool early = EARLY;                                       // (a compile-time choice: the instances without it are the round-4 kernels, register for register)
+    const int fbackoff = c->persist_early > 1 ? c->persist_early - 1 : 0;   // s_sleep units between raising the flag and the first look at the neighbours'
+    // the exchange buffer has its own row stride: 2*LPR doubles (whole 128-byte lines per row whatever p is) when the host says so
+    const unsigned xld = XR ? (unsigned)d.ld : (unsigned)d.xld;
+    const bool xfull = xld == 2u * LPR;
+    const bool xcol = colok || xfull;
     double2 eta[R], rr[R], md[LOWREG ? 1 : R], hmd[LOWREG ? 1 : R], cmd[TWOSYNC ? R : 1];
 #define VOFF(r) ((int64_t)ROW(r) * d.ld + 2 * sub)
 #define Y_GET(r) (LOWREG ? (OK(r) ? ld2(Yl + VOFF(r)) : zz) : Ys[(r) * PB + threadIdx.x])
@@ -180,13 +200,37 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             }
         }
     }
+    if (threadIdx.x == 0) shfail = 0;
     __syncthreads();
 
     unsigned gen = 0, nbar = 0;
     const unsigned vec_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
     const unsigned xrow0 = XR ? (unsigned)d.row0 : 0u;             // my rows inside the exchange buffer
     __amdgpu_buffer_rsrc_t rs_md = XR ? __builtin_amdgcn_make_buffer_rsrc(d.xr_mdx, 0, (unsigned)((size_t)d.n * d.ld * sizeof(double)), 0x00020000)
-                                      : __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, vec_bytes, 0x00020000);
+                                      : __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, (unsigned)((size_t)d.n_loc * xld * sizeof(double)), 0x00020000);
+    // EARLY: the flags this lane watches = the (workgroup, wave) pairs that own the rows this wave gathers -- entry e*64 + lane of the
+    // wave's R x RPW x EW column indices (duplicates cost nothing: one load instruction covers all of them)
+    unsigned foff[NE];
+    bool fself[NE];
+    __amdgpu_buffer_rsrc_t rs_fl = __builtin_amdgcn_make_buffer_rsrc(slots + PFLAG_OFF64, 0, (unsigned)(PFLAG_WORDS64 * 8), 0x00020000);
+    unsigned xgen = 0;                                             // publications through flags so far in this launch
+    if (EARLY) {
+        const unsigned q = (unsigned)d.n_loc / (unsigned)d.G, rem = (unsigned)d.n_loc - q * (unsigned)d.G, thr = rem * (q + 1);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = e * 64 + lane;
+            const int ii = idx < R * RPW * EW ? idx : 0;
+            const int r = ii / (RPW * EW), t = ii - r * (RPW * EW), rw = t / (EW > 0 ? EW : 1), w = t - rw * (EW > 0 ? EW : 1);
+            const unsigned cidx = (unsigned)cs[w * ROWS + r * RSTEP + wave * RPW + rw];
+            // inverse of msdp_chunk_rows: the chunk that holds row cidx, its first row, the workgroup that owns it
+            const unsigned ch = cidx < thr ? cidx / (q + 1) : rem + (cidx - thr) / (q > 0 ? q : 1u);
+            const unsigned olo = ch * q + (ch < rem ? ch : rem);
+            const unsigned S8 = (unsigned)d.G >> 3, ox = ch / S8, os = ch - ox * S8, ob = os * 8 + ox;
+            const unsigned owave = ((cidx - olo) % (unsigned)RSTEP) / (unsigned)RPW;
+            foff[e] = (ob * PWAVES + owave) * 4u;
+            fself[e] = (int)ob == bx && (int)owave == wave;         // my own rows: program order
+        }
+    }
     bool failed = false;
     bool first_tr = true;
   for (;;) {   // ---- trust-region iterations (exactly one pass when !FUSE)
@@ -214,10 +258,13 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         if (!pbarrier(slots, nbar++, GS, shb, err, bid)) return;
     }
     bool first = true;
+    bool have_early = false;         // EARLY: acc_e holds C*tangent(r') of my rows for the trip that starts
+    double2 acc_e[EARLY ? R : 1];
     bool direct = false;             // TWOSYNC: the exchange buffer holds the rows of mdelta itself (a refresh trip preceded)
     // acc = sum_k C[row,k] * X[k, my columns] with X read through the agent-coherent resource rs
-    auto gather_row = [&](int r, __amdgpu_buffer_rsrc_t rs) -> double2 {
+    auto gather_row = [&](int r, __amdgpu_buffer_rsrc_t rs, bool from_mdx) -> double2 {
             double2 acc = zz;
+            const unsigned gld = from_mdx ? xld : (unsigned)d.ld, gcol = (from_mdx ? xcol : colok) ? 2 * sub : 0;
             if (EW > 0) {
                 double2 x[EW > 0 ? EW : 1];
                 double v[EW > 0 ? EW : 1];
@@ -225,7 +272,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
                 for (int w = 0; w < EW; ++w) {
                     const int cidx = cs[w * ROWS + SLOT(r)];
                     v[w] = vs[w * ROWS + SLOT(r)];
-                    const unsigned off = ((unsigned)cidx * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u;
+                    const unsigned off = ((unsigned)cidx * gld + gcol) * 8u;
                     x[w] = ld2_sc1(rs, off);
                 }
 #pragma unroll
@@ -252,7 +299,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
                     double cvk[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const unsigned off = ((unsigned)cn[u] * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u;
+                        const unsigned off = ((unsigned)cn[u] * gld + gcol) * 8u;
                         cvk[u] = vn[u];
                         x[u] = ld2_sc1(rs, off);
                     }
@@ -281,30 +328,34 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         TSTAMP(0);
         // all R * EW gathers of the trip are requested before the first one is consumed (the compiler left to itself requests the
         // gathers of one row slot, waits, does the row's arithmetic and only then turns to the next slot: R round trips)
-        constexpr bool ALLG = !LOWREG && EW > 0 && R * EW <= 25;
-        double2 X[ALLG ? R : 1][ALLG ? EW : 1];
-        if (ALLG) {
+        // (EARLY instances gather here on the first trip of a tCG and after a refresh trip only: row slot by row slot, so that the
+        // R x EW row registers exist at ONE place of the loop -- the early gather below)
+        constexpr bool ALLGT = ALLG && !EARLY;
+        double2 X[ALLGT ? R : 1][ALLGT ? EW : 1];
+        if (ALLGT) {
             const __amdgpu_buffer_rsrc_t rs = first ? rs_g : rs_md;
+            const unsigned gld = first ? (unsigned)d.ld : xld, gcol = (first ? colok : xcol) ? 2 * sub : 0;
 #pragma unroll
-            for (int r = 0; r < (ALLG ? R : 0); ++r)
+            for (int r = 0; r < (ALLGT ? R : 0); ++r)
 #pragma unroll
-                for (int w = 0; w < (ALLG ? EW : 0); ++w) {
+                for (int w = 0; w < (ALLGT ? EW : 0); ++w) {
                     const int cidx = cs[w * ROWS + SLOT(r)];
-                    X[ALLG ? r : 0][ALLG ? w : 0] = ld2_sc1(rs, ((unsigned)cidx * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u);
+                    X[ALLGT ? r : 0][ALLGT ? w : 0] = ld2_sc1(rs, ((unsigned)cidx * gld + gcol) * 8u);
                 }
         }
         auto hrow = [&](int r) {
             double2 acc;
-            if (ALLG) {
+            if (EARLY && have_early) acc = acc_e[EARLY ? r : 0];          // C*tangent(r') of my rows, gathered during reduction 2 of the previous trip
+            else if (ALLGT) {
                 acc = zz;
 #pragma unroll
-                for (int w = 0; w < (ALLG ? EW : 0); ++w) {
+                for (int w = 0; w < (ALLGT ? EW : 0); ++w) {
                     const double v = vs[w * ROWS + SLOT(r)];
-                    acc.x = fma(v, X[ALLG ? r : 0][ALLG ? w : 0].x, acc.x);
-                    acc.y = fma(v, X[ALLG ? r : 0][ALLG ? w : 0].y, acc.y);
+                    acc.x = fma(v, X[ALLGT ? r : 0][ALLGT ? w : 0].x, acc.x);
+                    acc.y = fma(v, X[ALLGT ? r : 0][ALLGT ? w : 0].y, acc.y);
                 }
                 if (!colok) acc = zz;
-            } else acc = gather_row(r, first ? rs_g : rs_md);
+            } else acc = gather_row(r, first ? rs_g : rs_md, !first);
             if (TWOSYNC) {
                 // the gathered rows are those of r_new (first trip: of the gradient = mdelta; after a refresh: of mdelta)
                 if (!first && !direct) { acc.x = fma(beta, cmd[TWOSYNC ? r : 0].x, acc.x); acc.y = fma(beta, cmd[TWOSYNC ? r : 0].y, acc.y); }
@@ -364,24 +415,91 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
                 // the re-projection of mdelta removes (:283) and what the assembled product would otherwise keep and amplify
                 const double2 y = Y_GET(r);
                 const double dn = msdp_group_sum<LPR>(nr.x * y.x + nr.y * y.y);
-                if (OK(r)) st2_sc1(rs_md, ((xrow0 + (unsigned)ROW(r)) * (unsigned)d.ld + 2 * sub) * 8u, make_double2(nr.x - y.x * dn, nr.y - y.y * dn));
+                if (ROK(r) && xcol) st2_sc1(rs_md, ((xrow0 + (unsigned)ROW(r)) * xld + 2 * sub) * 8u, make_double2(nr.x - y.x * dn, nr.y - y.y * dn));
             }
         }
-        TSTAMP(3);
-        if (TWOSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my residual rows are performed before I post
-        TSTAMP(4);
-        if (!psync(slots, gen++, GS, 3, s1, s2, s3, sh, shb, err, bid, backoff)) { failed = true; break; }
-        { const int jsave = j; (void)jsave; }
-        TSTAMP(5);
+        if (EARLY && early && !refresh_now) {
+            // (1) reduction 2 goes out now; (2) my rows drain, my flag goes up
+            psync_post3(slots, gen, s1, s2, s3, sh, bid);
+            TSTAMP(3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned want = d.flag_base + (++xgen);
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(want, rs_fl, (unsigned)(bx * PWAVES + wave) * 4u, 0, MSDP_CPOL_SC1);
+            TSTAMP(4);
+            for (int q = 0; q < fbackoff; ++q) __builtin_amdgcn_s_sleep(1);
+            // (3) the neighbours' flags; waves 0..2 look at their value array of reduction 2 under the same wait
+            const unsigned long long* p0 = psync_poll_base(slots, gen, bid);
+            bool r2ok = wave >= 3, fail = false;
+            double r2t = 0.0;
+            int spins = 0;
+            for (;;) {
+                unsigned fv[NE];
+#pragma unroll
+                for (int e = 0; e < NE; ++e) fv[e] = __builtin_amdgcn_raw_buffer_load_b32(rs_fl, foff[e], 0, MSDP_CPOL_SC1);
+                if (!r2ok) r2ok = psync_poll_once(p0, GS, r2t);
+                bool ready = true;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) ready = ready && (fself[e] || (int)(fv[e] - want) >= 0);
+                if (__builtin_amdgcn_ballot_w64(!ready) == 0ULL) break;
+                ++spins;
+                if (spins > PSYNC_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
+            }
+            TSTAMP(5);
+            // the rows of tangent(r') my rows of C reference; C*tangent(r') stays in acc_e until the top of the next trip
+            {
+                double2 XE[EARLY ? R : 1][EARLY ? EW : 1];
+#pragma unroll
+                for (int r = 0; r < (EARLY ? R : 0); ++r)
+#pragma unroll
+                    for (int w = 0; w < (EARLY ? EW : 0); ++w) {
+                        const int cidx = cs[w * ROWS + SLOT(r)];
+                        XE[EARLY ? r : 0][EARLY ? w : 0] = ld2_sc1(rs_md, ((unsigned)cidx * xld + (xcol ? 2 * sub : 0)) * 8u);
+                    }
+                if (!r2ok && !fail) r2ok = psync_poll_once(p0, GS, r2t);
+#pragma unroll
+                for (int r = 0; r < (EARLY ? R : 0); ++r) {
+                    double2 acc = zz;
+#pragma unroll
+                    for (int w = 0; w < (EARLY ? EW : 0); ++w) {
+                        const double v = vs[w * ROWS + SLOT(r)];
+                        acc.x = fma(v, XE[EARLY ? r : 0][EARLY ? w : 0].x, acc.x);
+                        acc.y = fma(v, XE[EARLY ? r : 0][EARLY ? w : 0].y, acc.y);
+                    }
+                    if (!colok) acc = zz;
+                    acc_e[EARLY ? r : 0] = acc;
+                }
+            }
+            TSTAMP(6);
+            // (4) reduction 2
+            while (!r2ok && !fail) {
+                r2ok = psync_poll_once(p0, GS, r2t);
+                ++spins;
+                if (spins > PSYNC_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) fail = true;
+            }
+            if (!psync_finish3(slots, gen++, r2t, fail, s1, s2, s3, shb, &shfail, err, bid)) { failed = true; break; }
+            have_early = true;
+            TSTAMP(7);
+        } else {
+            TSTAMP(3);
+            if (TWOSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my residual rows are performed before I post
+            TSTAMP(4);
+            if (!psync(slots, gen++, GS, 3, s1, s2, s3, sh, shb, err, bid, backoff)) { failed = true; break; }
+            have_early = false;
+            TSTAMP(5);
+        }
         e_Pe = e_Pe_new;
         const double new_model = s1 + 0.5 * s2;                                        // :227
         const double r_r = s3;
         if (!bench && new_model >= model_value) { stop = 6; ++j; break; }              // :228 (eta, Heta stay)
+        // (EARLY: the step length through an opaque copy, so that the compiler recomputes the commit instead of carrying the trial's
+        // 2 x R row values across the gather of the neighbours' rows -- they were the spills of this instance)
+        double alpha_c = alpha;
+        if (EARLY) asm volatile("" : "+v"(alpha_c));
 #pragma unroll
         for (int r = 0; r < R; ++r) {                                                  // :233-238 commit (same bits as the trial)
             const double2 mdr = MD_GET(r), hq = HMD_GET(r);
-            eta[r].x -= alpha * mdr.x; eta[r].y -= alpha * mdr.y;
-            rr[r].x -= alpha * hq.x; rr[r].y -= alpha * hq.y;
+            eta[r].x -= alpha_c * mdr.x; eta[r].y -= alpha_c * mdr.y;
+            rr[r].x -= alpha_c * hq.x; rr[r].y -= alpha_c * hq.y;
         }
         model_value = new_model;
         ++j;
@@ -405,7 +523,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             dot = msdp_group_sum<LPR>(dot);
             const double2 mnew = make_double2(v.x - y.x * dot, v.y - y.y * dot);
             MD_SET(r, mnew);
-            if ((!TWOSYNC || refresh_now) && OK(r)) st2_sc1(rs_md, ((xrow0 + (unsigned)ROW(r)) * (unsigned)d.ld + 2 * sub) * 8u, mnew);
+            if ((!TWOSYNC || refresh_now) && ROK(r) && xcol) st2_sc1(rs_md, ((xrow0 + (unsigned)ROW(r)) * xld + 2 * sub) * 8u, mnew);
         }
         if (!TWOSYNC || refresh_now) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my rows are performed before my workgroup posts
@@ -413,7 +531,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         }
         direct = refresh_now;
         first = false;
-        { --j; TSTAMP(6); ++j; }                                    // (j was advanced above: stamp under the trip's own index)
+        if (!(EARLY && have_early)) { --j; TSTAMP(6); ++j; }        // (j was advanced above: stamp under the trip's own index)
     }
     if (failed) return;
     if (!FUSE) {
@@ -459,7 +577,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     // register pressure to the tCG loop above.
 #pragma unroll 1
     for (int r = 0; r < R; ++r) {
-        const double2 acc = gather_row(r, rs_yp);
+        const double2 acc = gather_row(r, rs_yp, false);
         const double2 ypr = YPs[r * PB + threadIdx.x];
         const double dot = msdp_group_sum<LPR>(acc.x * ypr.x + acc.y * ypr.y);
         const double2 gpr = OK(r) ? make_double2(acc.x - ypr.x * dot, acc.y - ypr.y * dot) : zz;
@@ -518,9 +636,9 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     }
 }
 
-template <int LPR, int EW, int R, bool FUSE, bool TRACE = false, bool XR = false>
+template <int LPR, int EW, int R, bool FUSE, bool TRACE = false, bool XR = false, bool EARLYP = false>
 __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long long* slots, int* err) {
-    tcg_persist_body<LPR, EW, R, FUSE, TRACE, XR>(d, slots, err, (int)blockIdx.x);
+    tcg_persist_body<LPR, EW, R, FUSE, TRACE, XR, EARLYP>(d, slots, err, (int)blockIdx.x);
 }
 // In-process ranks: ONE launch carries the workgroups of all members (member q owns the blocks [q*G, (q+1)*G)), so that their
 // co-residency does not depend on how the runtime maps the members' streams onto hardware queues (two launches on one queue
@@ -530,17 +648,17 @@ struct XrDevs4 { Dev d[4]; };
 template <int LPR, int EW, int R>
 __global__ __launch_bounds__(PB) void k_tcg_persist_xr2(XrDevs2 ds, unsigned long long* slots, int* err) {
     const int G = ds.d[0].G;
-    if ((int)blockIdx.x < G) tcg_persist_body<LPR, EW, R, false, false, true>(ds.d[0], slots, err, (int)blockIdx.x);
-    else tcg_persist_body<LPR, EW, R, false, false, true>(ds.d[1], slots, err, (int)blockIdx.x - G);
+    if ((int)blockIdx.x < G) tcg_persist_body<LPR, EW, R, false, false, true, false>(ds.d[0], slots, err, (int)blockIdx.x);
+    else tcg_persist_body<LPR, EW, R, false, false, true, false>(ds.d[1], slots, err, (int)blockIdx.x - G);
 }
 template <int LPR, int EW, int R>
 __global__ __launch_bounds__(PB) void k_tcg_persist_xr4(XrDevs4 ds, unsigned long long* slots, int* err) {
     const int G = ds.d[0].G, q = (int)blockIdx.x / G, bx = (int)blockIdx.x - q * G;
     switch (q) {
-        case 0: tcg_persist_body<LPR, EW, R, false, false, true>(ds.d[0], slots, err, bx); break;
-        case 1: tcg_persist_body<LPR, EW, R, false, false, true>(ds.d[1], slots, err, bx); break;
-        case 2: tcg_persist_body<LPR, EW, R, false, false, true>(ds.d[2], slots, err, bx); break;
-        default: tcg_persist_body<LPR, EW, R, false, false, true>(ds.d[3], slots, err, bx); break;
+        case 0: tcg_persist_body<LPR, EW, R, false, false, true, false>(ds.d[0], slots, err, bx); break;
+        case 1: tcg_persist_body<LPR, EW, R, false, false, true, false>(ds.d[1], slots, err, bx); break;
+        case 2: tcg_persist_body<LPR, EW, R, false, false, true, false>(ds.d[2], slots, err, bx); break;
+        default: tcg_persist_body<LPR, EW, R, false, false, true, false>(ds.d[3], slots, err, bx); break;
     }
 }
 
@@ -595,7 +713,17 @@ static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
 }
 
 typedef void (*persist_fn)(Dev, unsigned long long*, int*);
-static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false) {
+// EARLY instances (round 5): rows of <= 5 entries, everything in registers
+static persist_fn persist_kernel_early(const PersistPlan& pl, bool fuse) {
+    if (pl.ew != 5) return nullptr;
+    if (pl.lpr == 16 && pl.r == 3) return fuse ? k_tcg_persist_obl<16, 5, 3, true, false, false, true> : k_tcg_persist_obl<16, 5, 3, false, false, false, true>;
+    if (pl.lpr == 8 && pl.r == 2) return fuse ? k_tcg_persist_obl<8, 5, 2, true, false, false, true> : k_tcg_persist_obl<8, 5, 2, false, false, false, true>;
+    // (four and five row slots: the R x EW row registers of the early gather on top of five resident vectors spill 350-600 bytes per
+    // lane -- those sizes keep the round-4 trip)
+    return nullptr;
+}
+static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false, int early = 0) {
+    if (early) { persist_fn f = persist_kernel_early(pl, fuse); if (f) return f; }
 #define PK(L, E) if (pl.lpr == L && pl.ew == E && pl.r == L / 4) return k_tcg_persist_obl<L, E, L / 4, false>;
     if (pl.lpr == 16 && pl.r == 3) {
         if (fuse) {
@@ -663,6 +791,16 @@ static int persist_grid(const Dev& d) {
     return g;
 }
 
+// Row stride of the exchange buffer and the base of this launch's row-flag counts (EARLY trips, msdp_psync.h): every launch counts
+// from where the previous one could have ended at most (`adv` publications), k_psync_reset starts over.
+static void persist_exchange_layout(msdp_handle h, const PersistPlan& pl, Dev& dp, unsigned long long adv) {
+    const size_t rows = (size_t)dp.n_loc;
+    dp.xld = (h->tune.persist_xld && rows * (size_t)(2 * pl.lpr) <= h->mdx_doubles) ? 2 * pl.lpr : dp.ld;
+    dp.flag_base = h->flag_epoch;
+    const unsigned long long next = (unsigned long long)h->flag_epoch + adv;
+    h->flag_epoch = next > 0x7fff0000ULL ? 0x7fff0000u : (unsigned)next;     // (a fused launch of more than 2^31 trips would need a 64-bit count)
+}
+
 // 1: the persistent kernel can run this handle's tCG (and all its workgroups are co-resident); 0: use the chunked path
 int msdp_persist_eligible(msdp_handle h) {
     const Dev& d = h->d;
@@ -672,11 +810,11 @@ int msdp_persist_eligible(msdp_handle h) {
     if (G < 8) return 0;
     PersistPlan pl;
     if (!persist_plan(d, G, pl)) return 0;
-    persist_fn fn = persist_kernel(pl);
+    persist_fn fn = persist_kernel(pl, false, h->tune.persist_early);
     if (!fn) return 0;
     // the ELL copy must be stored with the width the kernel is instantiated for
     if (pl.ew > 0 && d.ellW != pl.ew) return 0;
-    if (h->persist_sig_lpr == pl.lpr && h->persist_sig_ew == pl.ew && h->persist_sig_r == pl.r && h->persist_sig_G == G)
+    if (h->persist_sig_lpr == pl.lpr && h->persist_sig_ew == pl.ew && h->persist_sig_r == pl.r && h->persist_sig_G == G && h->persist_sig_fn == (const void*)fn)
         return h->persist_sig_ok;
     int ok = 0;
     int dev = 0, cus = 0, per_cu = 0;
@@ -686,7 +824,7 @@ int msdp_persist_eligible(msdp_handle h) {
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, PB, pl.lds) == hipSuccess)
         ok = (per_cu >= 1 && cus >= G) ? 1 : 0;        // one workgroup per CU: never rely on two sharing a CU
     (void)hipGetLastError();
-    h->persist_sig_lpr = pl.lpr; h->persist_sig_ew = pl.ew; h->persist_sig_r = pl.r; h->persist_sig_G = G;
+    h->persist_sig_lpr = pl.lpr; h->persist_sig_ew = pl.ew; h->persist_sig_r = pl.r; h->persist_sig_G = G; h->persist_sig_fn = (const void*)fn;
     h->persist_sig_ok = ok;
     return ok;
 }
@@ -695,17 +833,20 @@ int msdp_launch_tcg_persist(msdp_handle h, int reset_slots) {
     const int G = persist_grid(h->d);
     PersistPlan pl;
     if (!persist_plan(h->d, G, pl)) { msdp_set_error("persistent tCG: not eligible"); return MSDP_ESTATE; }
-    persist_fn fn = persist_kernel(pl);
+    persist_fn fn = persist_kernel(pl, false, h->tune.persist_early);
     if (!fn) { msdp_set_error("persistent tCG: no kernel instance"); return MSDP_ESTATE; }
     Dev dp = h->d;
     dp.G = G;
-    if (reset_slots) {
+    const unsigned long long adv = (unsigned long long)(h->h_ctl->maxinner > 0 ? h->h_ctl->maxinner : 0) + 2ULL;
+    if (reset_slots || (unsigned long long)h->flag_epoch + adv > 0x7fff0000ULL) {
         hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, h->stream, h->psync_slots, h->psync_err);
         HIPCHK(hipGetLastError());
+        h->flag_epoch = 0;
     }
+    persist_exchange_layout(h, pl, dp, adv);
     if (dp.trace) {
         if (!(pl.lpr == 16 && pl.ew == 5 && pl.r == 3)) { msdp_set_error("persistent trace: only the <16, 5, 3> instance (17 <= p <= 32, rows of <= 5 entries) is traced"); return MSDP_EUNSUPPORTED; }
-        fn = k_tcg_persist_obl<16, 5, 3, false, true>;
+        fn = h->tune.persist_early ? k_tcg_persist_obl<16, 5, 3, false, true, false, true> : k_tcg_persist_obl<16, 5, 3, false, true>;
         HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     }
     hipLaunchKernelGGL(fn, dim3(G), dim3(PB), pl.lds, h->stream, dp, h->psync_slots, h->psync_err);
@@ -733,16 +874,16 @@ int msdp_persist_fused_ok(msdp_handle h) {
     PersistPlan pl;
     const int G = persist_grid(h->d);
     if (!persist_plan(h->d, G, pl)) return 0;
-    persist_fn fn = persist_kernel(pl, true);
+    persist_fn fn = persist_kernel(pl, true, h->tune.persist_early);
     if (!fn) return 0;
     pl.lds = fused_lds(pl);
-    if (h->fused_sig_lpr == pl.lpr && h->fused_sig_ew == pl.ew && h->fused_sig_G == G) return h->fused_sig_ok;
+    if (h->fused_sig_lpr == pl.lpr && h->fused_sig_ew == pl.ew && h->fused_sig_G == G && h->fused_sig_fn == (const void*)fn) return h->fused_sig_ok;
     int ok = 0, per_cu = 0;
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) == hipSuccess &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, PB, pl.lds) == hipSuccess)
         ok = per_cu >= 1 ? 1 : 0;
     (void)hipGetLastError();
-    h->fused_sig_lpr = pl.lpr; h->fused_sig_ew = pl.ew; h->fused_sig_G = G; h->fused_sig_ok = ok;
+    h->fused_sig_lpr = pl.lpr; h->fused_sig_ew = pl.ew; h->fused_sig_G = G; h->fused_sig_fn = (const void*)fn; h->fused_sig_ok = ok;
     return ok;
 }
 
@@ -750,13 +891,16 @@ int msdp_launch_rtr_fused(msdp_handle h) {
     const int G = persist_grid(h->d);
     PersistPlan pl;
     if (!persist_plan(h->d, G, pl)) { msdp_set_error("fused RTR: not eligible"); return MSDP_ESTATE; }
-    persist_fn fn = persist_kernel(pl, true);
+    persist_fn fn = persist_kernel(pl, true, h->tune.persist_early);
     if (!fn) { msdp_set_error("fused RTR: no kernel instance"); return MSDP_ESTATE; }
     pl.lds = fused_lds(pl);
     Dev dp = h->d;
     dp.G = G;
     hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, h->stream, h->psync_slots, h->psync_err);
     HIPCHK(hipGetLastError());
+    h->flag_epoch = 0;
+    persist_exchange_layout(h, pl, dp, ((unsigned long long)(h->h_ctl->maxinner > 0 ? h->h_ctl->maxinner : 0) + 2ULL) *
+                                           ((unsigned long long)(h->h_ctl->maxiter > 0 ? h->h_ctl->maxiter : 0) + 1ULL));
     hipLaunchKernelGGL(fn, dim3(G), dim3(PB), pl.lds, h->stream, dp, h->psync_slots, h->psync_err);
     HIPCHK(hipGetLastError());
     return 0;
@@ -827,6 +971,7 @@ int msdp_xpersist_member(msdp_handle h, int nranks, int rank, double* mdx, Dev* 
     if (!xr_plan(h, nranks, pl, &G)) { msdp_set_error("cross-rank persistent tCG: not eligible"); return MSDP_ESTATE; }
     *out = h->d;
     out->G = G; out->xr_gid0 = rank * G; out->xr_gtot = nranks * G; out->xr_mdx = mdx; out->status = nullptr; out->trace = nullptr;
+    out->xld = out->ld; out->flag_base = 0;
     plan3[0] = pl.lpr; plan3[1] = pl.ew; plan3[2] = pl.r;
     return 0;
 }

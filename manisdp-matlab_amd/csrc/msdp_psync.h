@@ -124,6 +124,83 @@ __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, i
     return msdp_readlane(shb[4], 0) + msdp_readlane(shb[5], 0) + msdp_readlane(shb[6], 0) == 0.0;
 }
 
+// ---- Split form of the three-value reduction (round 5, msdp_persist.hip EARLY): the posts go out first, the caller does other work
+// (waits for its neighbours' row flags, gathers their rows), polls the slots with the SAME loads and the same summation order as
+// psync() wherever it has a wait anyway, and ends with psync_finish3.  Same bits as psync(..., nv = 3, ...).
+__device__ __forceinline__ void psync_post3(unsigned long long* slots, unsigned gen, double a, double b, double c, double* sh, int bid) {
+    a = msdp_wave_sum(a); b = msdp_wave_sum(b); c = msdp_wave_sum(c);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sh[w] = a; sh[PWAVES + w] = b; sh[2 * PWAVES + w] = c; }
+    __syncthreads();
+    if (w == 0 && lane < PSYNC_REP * PSYNC_NV) {
+        unsigned long long* gbase = slots + (size_t)(gen % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID;
+        const int rep = lane / PSYNC_NV, vi = lane % PSYNC_NV;
+        if (vi < 3) {
+            double s = 0.0;
+            for (int i = 0; i < PWAVES; ++i) s += sh[vi * PWAVES + i];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the reset store of this slot's other generations has been performed
+            __hip_atomic_store(gbase + ((size_t)rep * PSYNC_NV + vi) * MSDP_MAX_GRID + bid,
+                               (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// Where wave w (< 3) polls value array w of generation gen
+__device__ __forceinline__ const unsigned long long* psync_poll_base(const unsigned long long* slots, unsigned gen, int bid) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    return slots + (size_t)(gen % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID +
+           ((size_t)(bid & (PSYNC_REP - 1)) * PSYNC_NV + (w < 3 ? w : 0)) * MSDP_MAX_GRID + lane;
+}
+// One poll (four slot loads, ONE wait -- which also covers whatever loads the caller issued in front of this call): true when all G
+// slots are filled; t0 = this lane's share of the sum (the order of psync / msdp_sum_partials).
+__device__ __forceinline__ bool psync_poll_once(const unsigned long long* p0, int G, double& t0) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long b0[4];
+    asm volatile(
+        "global_load_dwordx2 %0, %4, off sc1\n\t"
+        "global_load_dwordx2 %1, %4, off offset:512 sc1\n\t"
+        "global_load_dwordx2 %2, %4, off offset:1024 sc1\n\t"
+        "global_load_dwordx2 %3, %4, off offset:1536 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3])
+        : "v"(p0)
+        : "memory");
+    bool ok = true;
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (lane + 64 * q < G) {
+            ok = ok && b0[q] != PSYNC_SENT;
+            t += __longlong_as_double((long long)b0[q]);
+        }
+    }
+    t0 = t;
+    return __builtin_amdgcn_ballot_w64(!ok) == 0ULL;
+}
+// Closes the split reduction: the polling waves hand their sums over, wave 0 resets its slots of the previous generation.
+// `fail` (any wave): a bounded spin ran out.  Returns false in every thread if any wave failed.
+__device__ __forceinline__ bool psync_finish3(unsigned long long* slots, unsigned gen, double t0, bool fail, double& a, double& b, double& c,
+                                              double* shb, int* shfail, int* err, int bid) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (fail && lane == 0) { *shfail = 1; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (w < 3) {
+        const double r0 = msdp_wave_sum(t0);
+        if (lane == 0) shb[w] = r0;
+        if (w == 0 && lane < PSYNC_REP * PSYNC_NV)
+            __hip_atomic_store(slots + (size_t)((gen + PSYNC_GEN - 1) % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID +
+                                   (size_t)lane * MSDP_MAX_GRID + bid,
+                               PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    a = msdp_readlane(shb[0], 0); b = msdp_readlane(shb[1], 0); c = msdp_readlane(shb[2], 0);
+    return __builtin_amdgcn_readfirstlane(*shfail) == 0;
+}
+
+// Row flags (round 5): wave v of workgroup b raises flags[b * PWAVES + v] to the number of the publication once ITS rows of that
+// publication are performed; a consumer wave watches the flags of the waves that own the rows it gathers.  32-bit counters behind
+// the two slot regions, zeroed by k_psync_reset; sc1 accesses (uncached memory).
+#define PFLAG_OFF64 (2 * PSYNC_REGION)                                     // in 64-bit words from the slot base
+#define PFLAG_WORDS64 ((size_t)MSDP_MAX_GRID * PWAVES / 2)
+
 // Barrier without a value (the new direction rows are in place): workgroup b adds to counter b & 7, everybody
 // polls the 8 counters (64 B apart).  nbar = number of barriers passed before this one.  G is a multiple of 8.
 __device__ __forceinline__ bool pbarrier(unsigned long long* slots, unsigned nbar, int G, double* shb, int* err, int bid_in = -1) {
