@@ -382,10 +382,10 @@ int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, const int64_
  *                       barrier) so that the product C*mdelta, otherwise assembled by linearity, starts afresh (default 32;
  *                       0 = never: |Heta - Hess(eta)|/|Heta| then grows to 1e-8 over 100 trips on G81)
  *   "persist_early" k  persistent tCG kernel (rows of <= 5 entries, p <= 32): k >= 1 = the neighbours' rows of tangent(r') are
- *                       gathered behind per-wave row flags WHILE the second grid reduction of the trip is in flight (k - 1 = units
- *                       of 64 cycles a wave sleeps between raising its flag and its first look at the neighbours'); 0 = at the top
- *                       of the next trip, behind that reduction (the round-4 trip).  Same arithmetic, same decisions (default 1)
- *   "persist_xld"  1/0  persistent tCG kernel: rows of the exchange buffer padded to whole 128-byte lines (default 1)
+ *                       gathered WHILE the second grid reduction of the trip is in flight -- the exchange buffer's halves hold a NaN
+ *                       sentinel until a row is stored, so the rows are their own flags (k - 1 = units of 64 cycles a wave sleeps
+ *                       between posting the reduction and its first gather); 0 = at the top of the next trip, behind that
+ *                       reduction (the round-4 trip).  Same arithmetic, same decisions (default 1)
  *   "affine_overlap" 1/0  affine kinds: the 2*eS*U contraction of a Hess-vec runs on a second stream beside the A(.) / A'(.)
  *                       chain (default 0: measured slower than one stream; kept for A/B timing; results agree to rounding)
  *   "trip2"        0/1/2  chunked path, sparse C / oblique manifold / one rank: two launches per tCG trip (12 vector passes,

@@ -263,12 +263,10 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
     if (d.mdx) dev_free(h, d.mdx);
     d.mdx = nullptr;
     {
-        // rows padded to whole 128-byte lines for the persistent kernels' lanes-per-row (2 x 8 / 16 / 32 doubles; msdp_persist.hip xld)
-        const size_t xcap = ldcap <= 16 ? 16 : (ldcap <= 32 ? 32 : (ldcap <= 64 ? 64 : (size_t)ldcap));
-        const size_t xcnt = rows * xcap;
+        // two halves: the EARLY trips of the persistent tCG alternate between them (msdp_persist.hip)
+        const size_t xcnt = 2 * cnt;
         int rc = dev_alloc_uncached<double>(h, &d.mdx, xcnt);
         if (rc) return rc;
-        h->mdx_doubles = xcnt;
         HIPCHK(hipMemsetAsync(d.mdx, 0, xcnt * sizeof(double), h->stream));
     }
     if (h->use_comm || h->nranks > 1) {
@@ -975,7 +973,6 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "xpersist")) t.xpersist = value != 0;
     else if (!strcmp(name, "persist_refresh")) t.persist_refresh = value > 0 ? value : 0;
     else if (!strcmp(name, "persist_early")) t.persist_early = value > 0 ? value : 0;
-    else if (!strcmp(name, "persist_xld")) t.persist_xld = value ? 1 : 0;
     else if (!strcmp(name, "psync_backoff")) t.psync_backoff = value > 0 ? value : 0;
     else if (!strcmp(name, "affine_overlap")) { t.affine_overlap = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "trip1")) { t.trip1 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }

@@ -38,8 +38,8 @@ struct Ctl {
     int bench_mode;              // 1: tCG exits disabled (throughput measurement)
     int tcg_running;             // mirror of Frame.active for host polling
     int psync_backoff;           // grid reductions of the persistent kernels: (s_sleep units of 64 cycles before the first poll) | (units after a failed poll) << 8
-    int persist_early;           // persistent tCG: 0 = gather the neighbours' rows at the top of the trip (round 4), >= 1 = behind row flags while
-                                 //   reduction 2 is in flight (msdp_persist.hip EARLY), value - 1 = s_sleep units before the first look at the flags
+    int persist_early;           // persistent tCG: 0 = gather the neighbours' rows at the top of the trip (round 4), >= 1 = while reduction 2 is in
+                                 //   flight, the rows being their own flags (msdp_persist.hip EARLY); value - 1 = s_sleep units before the first gather
     int persist_refresh;         // persistent tCG (two-synchronisation trips): every this-many trips the product C*mdelta is
                                  //   gathered directly instead of assembled by linearity (0: never); msdp_persist.hip
 };
@@ -131,10 +131,6 @@ struct Dev {
     // the exchange buffer all ranks share (all n rows; uncached memory, sc1 accesses only)
     int xr_gid0, xr_gtot;
     double* xr_mdx;
-    // persistent tCG, round 5: row stride of the exchange buffer mdx (ld, or 2 x lanes-per-row: whole 128-byte lines per row), and
-    // the value the row flags of this launch count from (msdp_psync.h; the host advances it launch by launch)
-    int xld;
-    unsigned flag_base;
 };
 
 // Run-time switches of a handle (msdp_set_option; the environment variables of the same meaning are read ONCE, when
@@ -175,9 +171,9 @@ struct Tuning {
                              //   with 0, 7.06 (14), 6.85 (18), 6.87 (20), 7.05 (24), 7.44 (32), 7.86 (40); p = 16: 6.87 -> 5.84
                              //   (tools/psync_backoff_probe.py); sleeping between failed polls gains nothing
     int persist_refresh = 32;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
-    int persist_early = 1;     // persistent tCG: the neighbours' rows are gathered behind per-wave row flags while reduction 2 is in flight
-                               //   (0: at the top of the next trip, behind reduction 2 -- the round-4 trip; n >= 1: n - 1 s_sleep units before the first flag poll)
-    int persist_xld = 1;       // persistent tCG: the exchange buffer's rows are padded to whole 128-byte lines (2 x lanes-per-row doubles; 0: ld)
+    int persist_early = 1;     // persistent tCG: the neighbours' rows are gathered while reduction 2 is in flight -- sentinel-initialised exchange
+                               //   halves, the rows are their own flags (0: at the top of the next trip, behind reduction 2 -- the round-4 trip;
+                               //   n >= 1: n - 1 s_sleep units between the post of reduction 2 and the first gather)
     int affine_overlap = 0;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain.  Measured SLOWER (round 3: BQP d = 60
                              //   85 against 73 us, theta n = 5000 83 against 74 us per Hess-vec inside graph replays): every launch of the chain
                              //   already fills the chip, the fork / join only adds dependencies.  Kept as an A/B switch, default off.
@@ -204,8 +200,6 @@ struct msdp_handle_s {
     int kind = 0;
     Tuning tune{};
     bool persist_failed = false;   // a persistent launch timed out on this handle: stay on the chunked path
-    unsigned flag_epoch = 0;       // persistent tCG: what the row flags have counted up to (k_psync_reset zeroes both)
-    size_t mdx_doubles = 0;        // capacity of d.mdx
     double* rtr_start = nullptr;   // copy of the start point of the running msdp_rtr call (persistent path: recovery)
     size_t rtr_start_cap = 0;
     Dev d{};

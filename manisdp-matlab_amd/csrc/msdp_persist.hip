@@ -29,13 +29,12 @@
 
 #include "msdp_psync.h"
 
-size_t msdp_psync_bytes() { return (2 * PSYNC_REGION + PFLAG_WORDS64) * sizeof(double); }       // regions A (tCG) and B (TR tail), row flags
+size_t msdp_psync_bytes() { return 2 * PSYNC_REGION * sizeof(double); }       // regions A (tCG) and B (TR tail)
 
 __global__ void k_psync_reset(unsigned long long* slots, int* err) {
     const int tot = (int)PSYNC_CNT_OFF;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += gridDim.x * blockDim.x) { slots[i] = PSYNC_SENT; slots[PSYNC_REGION + i] = PSYNC_SENT; }
     if (blockIdx.x == 0 && threadIdx.x < 64) { slots[PSYNC_CNT_OFF + threadIdx.x] = 0ULL; slots[PSYNC_REGION + PSYNC_CNT_OFF + threadIdx.x] = 0ULL; }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (int)PFLAG_WORDS64; i += gridDim.x * blockDim.x) slots[PFLAG_OFF64 + i] = 0ULL;
     if (blockIdx.x == 0 && threadIdx.x == 0) *err = 0;
 }
 
@@ -45,8 +44,9 @@ __global__ void k_psync_reset(unsigned long long* slots, int* err) {
 //   0 top of the trip (gathers about to be issued)   1 gathers + row arithmetic done   2 first grid reduction returned (d_Hd)
 //   3 trial step formed, residual rows stored        4 those stores performed          5 second grid reduction returned
 //   6 new direction formed (end of the trip)
-// EARLY trips (round 5): 3 = trial step formed, rows stored, reduction 2 POSTED; 4 = own stores performed, row flag raised;
-//   5 = the neighbours' flags seen; 6 = their rows gathered (C*tangent(r') formed); 7 = second grid reduction returned
+// EARLY trips (round 5): 3 = trial step formed, rows stored, reduction 2 POSTED; 4 = last trip's half back to the sentinel, back-off
+//   slept; 5 = the neighbours' rows gathered, none holds the sentinel (C*tangent(r') formed); 6 = second grid reduction returned;
+//   7 = new direction formed (end of the trip)
 #define MSDP_TRACE_J0 16
 #define MSDP_TRACE_NJ 32
 #define TSTAMP(ph) do { if (TRACE && threadIdx.x == 0 && j >= MSDP_TRACE_J0 && j < MSDP_TRACE_J0 + MSDP_TRACE_NJ) \
@@ -61,7 +61,6 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     extern __shared__ double lds[];
     __shared__ double sh[3 * PWAVES];
     __shared__ double shb[8];
-    __shared__ int shfail;
     constexpr int RPW = 64 / LPR;
     constexpr int RSTEP = PWAVES * RPW;       // rows per pass of the workgroup
     constexpr int ROWS = R * RSTEP;               // row slots of the workgroup
@@ -148,23 +147,30 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     // so every workgroup takes the same branch.
     const int refresh = c->persist_refresh;
     const int backoff = c->psync_backoff;
-    // EARLY (round 5): the gather of tangent(r') leaves the critical path.  Its rows need only the neighbours' stores, not beta, so
-    // a workgroup (1) posts its partial sums of reduction 2 the moment they exist -- no longer behind the drain of its row stores --,
-    // (2) drains its stores and raises one flag per WAVE (the number of this publication), (3) watches the flags of the waves that
-    // own the rows it gathers, gathers them and forms C*tangent(r') while reduction 2 is in flight, (4) picks up reduction 2
-    // (polled in the shadow of the flag and gather waits), then beta, the new direction and C*mdelta' = C*tangent(r') + beta*C*mdelta
-    // as before.  Same row arithmetic, same summation orders, same decisions as the trip above: the oracle / drift tests are
-    // unchanged.  The rows are safe to overwrite one trip later: every gather is consumed before its workgroup posts reduction 1.
+    // EARLY (round 5): the gather of tangent(r') leaves the critical path.  Its rows need only the neighbours' stores, not beta.
+    // First form (kept in the history: per-wave row flags raised behind the drain of the stores, watched by the consumers):
+    // 8.6-8.7 us per trip against 7.8 -- drain (0.5 us) + flag store becoming visible and polled (1.4 us median, 2.2 us on three of
+    // the XCDs) + the gather (0.5 us) add up to MORE than the reduction they were to hide under, and the flag polls of 1700 waves
+    // slowed the reduction itself (profiles/r5_persist_timeline_p32_flags.md).  This form has no flags and no drain: THE ROWS ARE
+    // THEIR OWN FLAGS.  The exchange buffer has two halves that alternate trip by trip, and a half holds a NaN sentinel in every
+    // 16-byte element until its owner stores the row: a workgroup (1) stores its rows of tangent(r') and posts its partial sums of
+    // reduction 2 at once, (2) gathers the rows its rows of C reference and looks at what came back -- an element that still holds
+    // the sentinel means "not stored yet": the gather is repeated (a 16-byte element is written by one lane of one store, whole),
+    // (3) forms C*tangent(r') while reduction 2 is in flight, picks the reduction up (waves 0..2 poll it under the gather's wait),
+    // then beta, the new direction and C*mdelta' = C*tangent(r') + beta*C*mdelta as before.  The half filled at trip j is put back
+    // to the sentinel by its owner during trip j+1, behind reduction 1 of that trip (every gather of trip j was consumed before its
+    // workgroup posted that reduction), and filled again at trip j+2.  Same row arithmetic, same summation orders, same decisions
+    // as the trip above: the oracle / drift tests are unchanged.
     constexpr bool ALLG = !LOWREG && EW > 0 && R * EW <= 25;
     constexpr bool EARLY = EARLYP && TWOSYNC && ALLG && !XR;
-    constexpr int NE = EARLY ? (R * RPW * EW + 63) / 64 : 1;       // flags a lane watches
-    const bool early = EARLY;                                       // (a compile-time choice: the instances without it are the round-4 kernels, register for register)
-    const int fbackoff = c->persist_early > 1 ? c->persist_early - 1 : 0;   // s_sleep units between raising the flag and the first look at the neighbours'
-    // the exchange buffer has its own row stride: 2*LPR doubles (whole 128-byte lines per row whatever p is) when the host says so
-    const unsigned xld = XR ? (unsigned)d.ld : (unsigned)d.xld;
-    const bool xfull = xld == 2u * LPR;
-    const bool xcol = colok || xfull;
-    double2 eta[R], rr[R], md[LOWREG ? 1 : R], hmd[LOWREG ? 1 : R], cmd[TWOSYNC ? R : 1];
+    const int fbackoff = c->persist_early > 1 ? c->persist_early - 1 : 0;   // s_sleep units between the post of reduction 2 and the first gather
+    // EARLY: eta lives in LDS (read by the trial step, updated by the commit, nothing else touches it): R x 4 registers less next to the
+    // R x EW row registers of the early gather
+    constexpr bool ELDS = EARLY;
+    double2* Es = FUSE ? reinterpret_cast<double2*>(EGPs + ROWS) : YPs;   // [R][PB], behind everything else
+    double2 eta[ELDS ? 1 : R], rr[R], md[LOWREG ? 1 : R], hmd[LOWREG ? 1 : R], cmd[TWOSYNC ? R : 1];
+#define ETA_GET(r) (ELDS ? Es[(r) * PB + threadIdx.x] : eta[ELDS ? 0 : (r)])
+#define ETA_SET(r, val) do { if (ELDS) Es[(r) * PB + threadIdx.x] = (val); else eta[ELDS ? 0 : (r)] = (val); } while (0)
 #define VOFF(r) ((int64_t)ROW(r) * d.ld + 2 * sub)
 #define Y_GET(r) (LOWREG ? (OK(r) ? ld2(Yl + VOFF(r)) : zz) : Ys[(r) * PB + threadIdx.x])
 #define G_GET(r) (LOWREG ? (OK(r) ? ld2(gl + VOFF(r)) : zz) : Gs[(r) * PB + threadIdx.x])
@@ -182,7 +188,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         double2 y = ld2(Yl + o), g = ld2(gl + o);
         if (!OK(r)) { y = zz; g = zz; }
         if (!LOWREG) { Ys[r * PB + threadIdx.x] = y; Gs[r * PB + threadIdx.x] = g; }
-        eta[r] = zz; rr[r] = g; MD_SET(r, g); HMD_SET(r, zz);      // tCG.m:102-157
+        ETA_SET(r, zz); rr[r] = g; MD_SET(r, g); HMD_SET(r, zz);      // tCG.m:102-157
         const double egv = eGl[rc];
         int cw[EW > 0 ? EW : 1];
         double vw[EW > 0 ? EW : 1];
@@ -200,37 +206,25 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             }
         }
     }
-    if (threadIdx.x == 0) shfail = 0;
+    if (threadIdx.x == 0) shb[7] = 0.0;
     __syncthreads();
 
     unsigned gen = 0, nbar = 0;
-    const unsigned vec_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
     const unsigned xrow0 = XR ? (unsigned)d.row0 : 0u;             // my rows inside the exchange buffer
+    const unsigned vec_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
+    // (EARLY: two halves of n_loc x ld doubles each)
+    const unsigned half_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
     __amdgpu_buffer_rsrc_t rs_md = XR ? __builtin_amdgcn_make_buffer_rsrc(d.xr_mdx, 0, (unsigned)((size_t)d.n * d.ld * sizeof(double)), 0x00020000)
-                                      : __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, (unsigned)((size_t)d.n_loc * xld * sizeof(double)), 0x00020000);
-    // EARLY: the flags this lane watches = the (workgroup, wave) pairs that own the rows this wave gathers -- entry e*64 + lane of the
-    // wave's R x RPW x EW column indices (duplicates cost nothing: one load instruction covers all of them)
-    unsigned foff[NE];
-    bool fself[NE];
-    __amdgpu_buffer_rsrc_t rs_fl = __builtin_amdgcn_make_buffer_rsrc(slots + PFLAG_OFF64, 0, (unsigned)(PFLAG_WORDS64 * 8), 0x00020000);
-    unsigned xgen = 0;                                             // publications through flags so far in this launch
-    if (EARLY) {
-        const unsigned q = (unsigned)d.n_loc / (unsigned)d.G, rem = (unsigned)d.n_loc - q * (unsigned)d.G, thr = rem * (q + 1);
+                                      : __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, (EARLY ? 2u : 1u) * half_bytes, 0x00020000);
+    const double2 sent2 = make_double2(__longlong_as_double((long long)PSYNC_SENT), __longlong_as_double((long long)PSYNC_SENT));
+    // my rows of half q back to the sentinel
+    auto reset_half = [&](int q) {
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int idx = e * 64 + lane;
-            const int ii = idx < R * RPW * EW ? idx : 0;
-            const int r = ii / (RPW * EW), t = ii - r * (RPW * EW), rw = t / (EW > 0 ? EW : 1), w = t - rw * (EW > 0 ? EW : 1);
-            const unsigned cidx = (unsigned)cs[w * ROWS + r * RSTEP + wave * RPW + rw];
-            // inverse of msdp_chunk_rows: the chunk that holds row cidx, its first row, the workgroup that owns it
-            const unsigned ch = cidx < thr ? cidx / (q + 1) : rem + (cidx - thr) / (q > 0 ? q : 1u);
-            const unsigned olo = ch * q + (ch < rem ? ch : rem);
-            const unsigned S8 = (unsigned)d.G >> 3, ox = ch / S8, os = ch - ox * S8, ob = os * 8 + ox;
-            const unsigned owave = ((cidx - olo) % (unsigned)RSTEP) / (unsigned)RPW;
-            foff[e] = (ob * PWAVES + owave) * 4u;
-            fself[e] = (int)ob == bx && (int)owave == wave;         // my own rows: program order
-        }
-    }
+        for (int r = 0; r < R; ++r) if (OK(r)) st2_sc1(rs_md, (unsigned)q * half_bytes + ((unsigned)ROW(r) * (unsigned)d.ld + 2 * sub) * 8u, sent2);
+    };
+    int xq = 0;                      // EARLY: the half the next publication goes to
+    int pend = -1;                   // EARLY: the half to put back to the sentinel behind the next reduction 1 (-1: none)
+    if (EARLY) { reset_half(0); reset_half(1); }                   // (whatever an earlier launch left; the first look at them is behind reduction 1 of trip 1)
     bool failed = false;
     bool first_tr = true;
   for (;;) {   // ---- trust-region iterations (exactly one pass when !FUSE)
@@ -239,7 +233,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double2 g = Gs[r * PB + threadIdx.x];
-            eta[r] = zz; rr[r] = g; MD_SET(r, g); HMD_SET(r, zz);
+            ETA_SET(r, zz); rr[r] = g; MD_SET(r, g); HMD_SET(r, zz);
         }
     }
     first_tr = false;
@@ -259,12 +253,13 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     }
     bool first = true;
     bool have_early = false;         // EARLY: acc_e holds C*tangent(r') of my rows for the trip that starts
+    int lastq = 0;                   // EARLY: the half the last direct exchange (refresh trip) went to
     double2 acc_e[EARLY ? R : 1];
     bool direct = false;             // TWOSYNC: the exchange buffer holds the rows of mdelta itself (a refresh trip preceded)
     // acc = sum_k C[row,k] * X[k, my columns] with X read through the agent-coherent resource rs
-    auto gather_row = [&](int r, __amdgpu_buffer_rsrc_t rs, bool from_mdx) -> double2 {
+    auto gather_row = [&](int r, __amdgpu_buffer_rsrc_t rs, unsigned base) -> double2 {
             double2 acc = zz;
-            const unsigned gld = from_mdx ? xld : (unsigned)d.ld, gcol = (from_mdx ? xcol : colok) ? 2 * sub : 0;
+            const unsigned gld = (unsigned)d.ld, gcol = colok ? 2 * sub : 0;
             if (EW > 0) {
                 double2 x[EW > 0 ? EW : 1];
                 double v[EW > 0 ? EW : 1];
@@ -272,7 +267,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
                 for (int w = 0; w < EW; ++w) {
                     const int cidx = cs[w * ROWS + SLOT(r)];
                     v[w] = vs[w * ROWS + SLOT(r)];
-                    const unsigned off = ((unsigned)cidx * gld + gcol) * 8u;
+                    const unsigned off = base + ((unsigned)cidx * gld + gcol) * 8u;
                     x[w] = ld2_sc1(rs, off);
                 }
 #pragma unroll
@@ -299,7 +294,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
                     double cvk[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const unsigned off = ((unsigned)cn[u] * gld + gcol) * 8u;
+                        const unsigned off = base + ((unsigned)cn[u] * gld + gcol) * 8u;
                         cvk[u] = vn[u];
                         x[u] = ld2_sc1(rs, off);
                     }
@@ -334,7 +329,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         double2 X[ALLGT ? R : 1][ALLGT ? EW : 1];
         if (ALLGT) {
             const __amdgpu_buffer_rsrc_t rs = first ? rs_g : rs_md;
-            const unsigned gld = first ? (unsigned)d.ld : xld, gcol = (first ? colok : xcol) ? 2 * sub : 0;
+            const unsigned gld = (unsigned)d.ld, gcol = colok ? 2 * sub : 0;
 #pragma unroll
             for (int r = 0; r < (ALLGT ? R : 0); ++r)
 #pragma unroll
@@ -355,7 +350,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
                     acc.y = fma(v, X[ALLGT ? r : 0][ALLGT ? w : 0].y, acc.y);
                 }
                 if (!colok) acc = zz;
-            } else acc = gather_row(r, first ? rs_g : rs_md, !first);
+            } else acc = gather_row(r, first ? rs_g : rs_md, (!first && EARLY) ? (unsigned)lastq * half_bytes : 0u);
             if (TWOSYNC) {
                 // the gathered rows are those of r_new (first trip: of the gradient = mdelta; after a refresh: of mdelta)
                 if (!first && !direct) { acc.x = fma(beta, cmd[TWOSYNC ? r : 0].x, acc.x); acc.y = fma(beta, cmd[TWOSYNC ? r : 0].y, acc.y); }
@@ -390,7 +385,8 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const double2 mdr = MD_GET(r), hq = HMD_GET(r);
-                eta[r].x -= tau * mdr.x; eta[r].y -= tau * mdr.y;                      // :192
+                const double2 e0 = ETA_GET(r);
+                ETA_SET(r, make_double2(e0.x - tau * mdr.x, e0.y - tau * mdr.y));      // :192
                 rr[r].x -= tau * hq.x; rr[r].y -= tau * hq.y;                          // :198 (Heta = r - grad)
             }
             stop = (d_Hd <= 0.0) ? 1 : 2;
@@ -400,10 +396,15 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         // ---- trial step and its three inner products (tCG.m:215-241)
         const bool refresh_now = TWOSYNC && refresh > 0 && ((j + 1) % refresh) == 0;   // this trip ends with a direct exchange
         double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        // EARLY: this trip's rows go to half xq; every wave's earlier stores to it (the sentinel, one trip ago) have long been
+        // performed -- the wait makes the order of the two stores to one address explicit and costs nothing here
+        const unsigned qoff = EARLY ? (unsigned)xq * half_bytes : 0u;
+        if (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double2 g = G_GET(r), mdr = MD_GET(r), hq = HMD_GET(r);
-            const double2 ne = make_double2(eta[r].x - alpha * mdr.x, eta[r].y - alpha * mdr.y);         // :215
+            const double2 e0 = ETA_GET(r);
+            const double2 ne = make_double2(e0.x - alpha * mdr.x, e0.y - alpha * mdr.y);                 // :215
             const double2 nr = make_double2(rr[r].x - alpha * hq.x, rr[r].y - alpha * hq.y);             // :238
             const double2 nh = make_double2(nr.x - g.x, nr.y - g.y);                                     // new_Heta (:220)
             s1 += ne.x * g.x + ne.y * g.y;
@@ -415,70 +416,65 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
                 // the re-projection of mdelta removes (:283) and what the assembled product would otherwise keep and amplify
                 const double2 y = Y_GET(r);
                 const double dn = msdp_group_sum<LPR>(nr.x * y.x + nr.y * y.y);
-                if (ROK(r) && xcol) st2_sc1(rs_md, ((xrow0 + (unsigned)ROW(r)) * xld + 2 * sub) * 8u, make_double2(nr.x - y.x * dn, nr.y - y.y * dn));
+                if (OK(r)) st2_sc1(rs_md, qoff + ((xrow0 + (unsigned)ROW(r)) * (unsigned)d.ld + 2 * sub) * 8u, make_double2(nr.x - y.x * dn, nr.y - y.y * dn));
             }
         }
-        if (EARLY && early && !refresh_now) {
-            // (1) reduction 2 goes out now; (2) my rows drain, my flag goes up
+        if (EARLY && !refresh_now) {
+            // (1) reduction 2 goes out at once -- nothing waits for the row stores any more
             psync_post3(slots, gen, s1, s2, s3, sh, bid);
             TSTAMP(3);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned want = d.flag_base + (++xgen);
-            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(want, rs_fl, (unsigned)(bx * PWAVES + wave) * 4u, 0, MSDP_CPOL_SC1);
-            TSTAMP(4);
+            // the half of the PREVIOUS trip goes back to the sentinel now: reduction 1 of this trip has returned, so every workgroup has
+            // consumed its gather of it; these stores are performed long before the half is filled again (next trip, behind a reduction)
+            if (pend >= 0) reset_half(pend);
+            pend = xq;
             for (int q = 0; q < fbackoff; ++q) __builtin_amdgcn_s_sleep(1);
-            // (3) the neighbours' flags; waves 0..2 look at their value array of reduction 2 under the same wait
+            TSTAMP(4);
+            // (2) + (3): gather the rows of tangent(r') my rows of C reference until no element holds the sentinel; waves 0..2 look at
+            // their value array of reduction 2 under the same wait.  C*tangent(r') stays in acc_e until the top of the next trip.
             const unsigned long long* p0 = psync_poll_base(slots, gen, bid);
             bool r2ok = wave >= 3, fail = false;
             double r2t = 0.0;
             int spins = 0;
             for (;;) {
-                unsigned fv[NE];
-#pragma unroll
-                for (int e = 0; e < NE; ++e) fv[e] = __builtin_amdgcn_raw_buffer_load_b32(rs_fl, foff[e], 0, MSDP_CPOL_SC1);
-                if (!r2ok) r2ok = psync_poll_once(p0, GS, r2t);
-                bool ready = true;
-#pragma unroll
-                for (int e = 0; e < NE; ++e) ready = ready && (fself[e] || (int)(fv[e] - want) >= 0);
-                if (__builtin_amdgcn_ballot_w64(!ready) == 0ULL) break;
-                ++spins;
-                if (spins > PSYNC_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
-            }
-            TSTAMP(5);
-            // the rows of tangent(r') my rows of C reference; C*tangent(r') stays in acc_e until the top of the next trip
-            {
                 double2 XE[EARLY ? R : 1][EARLY ? EW : 1];
 #pragma unroll
                 for (int r = 0; r < (EARLY ? R : 0); ++r)
 #pragma unroll
                     for (int w = 0; w < (EARLY ? EW : 0); ++w) {
                         const int cidx = cs[w * ROWS + SLOT(r)];
-                        XE[EARLY ? r : 0][EARLY ? w : 0] = ld2_sc1(rs_md, ((unsigned)cidx * xld + (xcol ? 2 * sub : 0)) * 8u);
+                        XE[EARLY ? r : 0][EARLY ? w : 0] = ld2_sc1(rs_md, qoff + ((unsigned)cidx * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u);
                     }
-                if (!r2ok && !fail) r2ok = psync_poll_once(p0, GS, r2t);
+                if (!r2ok) r2ok = psync_poll_once(p0, GS, r2t);
+                bool ready = true;
 #pragma unroll
                 for (int r = 0; r < (EARLY ? R : 0); ++r) {
                     double2 acc = zz;
 #pragma unroll
                     for (int w = 0; w < (EARLY ? EW : 0); ++w) {
+                        const double2 x = XE[EARLY ? r : 0][EARLY ? w : 0];
+                        ready = ready && (unsigned long long)__double_as_longlong(x.x) != PSYNC_SENT && (unsigned long long)__double_as_longlong(x.y) != PSYNC_SENT;
                         const double v = vs[w * ROWS + SLOT(r)];
-                        acc.x = fma(v, XE[EARLY ? r : 0][EARLY ? w : 0].x, acc.x);
-                        acc.y = fma(v, XE[EARLY ? r : 0][EARLY ? w : 0].y, acc.y);
+                        acc.x = fma(v, x.x, acc.x);
+                        acc.y = fma(v, x.y, acc.y);
                     }
                     if (!colok) acc = zz;
                     acc_e[EARLY ? r : 0] = acc;
                 }
+                if (__builtin_amdgcn_ballot_w64(!ready) == 0ULL) break;
+                ++spins;
+                if (spins > PSYNC_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
             }
-            TSTAMP(6);
+            TSTAMP(5);
             // (4) reduction 2
             while (!r2ok && !fail) {
                 r2ok = psync_poll_once(p0, GS, r2t);
                 ++spins;
                 if (spins > PSYNC_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) fail = true;
             }
-            if (!psync_finish3(slots, gen++, r2t, fail, s1, s2, s3, shb, &shfail, err, bid)) { failed = true; break; }
+            if (!psync_finish3(slots, gen++, r2t, fail, s1, s2, s3, shb, err, bid)) { failed = true; break; }
             have_early = true;
-            TSTAMP(7);
+            xq ^= 1;
+            TSTAMP(6);
         } else {
             TSTAMP(3);
             if (TWOSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my residual rows are performed before I post
@@ -486,6 +482,8 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             if (!psync(slots, gen++, GS, 3, s1, s2, s3, sh, shb, err, bid, backoff)) { failed = true; break; }
             have_early = false;
             TSTAMP(5);
+            // (EARLY instance, refresh trip: reduction 1 of this trip has returned -- the pending half can go back to the sentinel)
+            if (EARLY && pend >= 0) { reset_half(pend); pend = -1; }
         }
         e_Pe = e_Pe_new;
         const double new_model = s1 + 0.5 * s2;                                        // :227
@@ -498,7 +496,8 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
 #pragma unroll
         for (int r = 0; r < R; ++r) {                                                  // :233-238 commit (same bits as the trial)
             const double2 mdr = MD_GET(r), hq = HMD_GET(r);
-            eta[r].x -= alpha_c * mdr.x; eta[r].y -= alpha_c * mdr.y;
+            const double2 e0 = ETA_GET(r);
+            ETA_SET(r, make_double2(e0.x - alpha_c * mdr.x, e0.y - alpha_c * mdr.y));
             rr[r].x -= alpha_c * hq.x; rr[r].y -= alpha_c * hq.y;
         }
         model_value = new_model;
@@ -523,15 +522,16 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             dot = msdp_group_sum<LPR>(dot);
             const double2 mnew = make_double2(v.x - y.x * dot, v.y - y.y * dot);
             MD_SET(r, mnew);
-            if ((!TWOSYNC || refresh_now) && ROK(r) && xcol) st2_sc1(rs_md, ((xrow0 + (unsigned)ROW(r)) * xld + 2 * sub) * 8u, mnew);
+            if ((!TWOSYNC || refresh_now) && OK(r)) st2_sc1(rs_md, qoff + ((xrow0 + (unsigned)ROW(r)) * (unsigned)d.ld + 2 * sub) * 8u, mnew);
         }
         if (!TWOSYNC || refresh_now) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my rows are performed before my workgroup posts
             if (!pbarrier(slots, nbar++, GS, shb, err, bid)) { failed = true; break; }
+            if (EARLY) { lastq = xq; pend = xq; xq ^= 1; }         // the direction rows sit in half lastq until the next trip has gathered them
         }
         direct = refresh_now;
         first = false;
-        if (!(EARLY && have_early)) { --j; TSTAMP(6); ++j; }        // (j was advanced above: stamp under the trip's own index)
+        { --j; TSTAMP(EARLY && have_early ? 7 : 6); ++j; }          // (j was advanced above: stamp under the trip's own index)
     }
     if (failed) return;
     if (!FUSE) {
@@ -541,7 +541,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             if (OK(r)) {
                 const int64_t o = (int64_t)ROW(r) * d.ld + 2 * sub;
                 const double2 g = G_GET(r);
-                st2(d.eta[0] + o, eta[r]);
+                st2(d.eta[0] + o, ETA_GET(r));
                 st2(d.Heta[0] + o, make_double2(rr[r].x - g.x, rr[r].y - g.y));
             }
         }
@@ -562,8 +562,9 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     for (int r = 0; r < R; ++r) {
         const double2 y = Ys[r * PB + threadIdx.x], g = Gs[r * PB + threadIdx.x];
         const double2 he = make_double2(rr[r].x - g.x, rr[r].y - g.y);
-        prd += eta[r].x * (g.x + 0.5 * he.x) + eta[r].y * (g.y + 0.5 * he.y);
-        const double2 x = make_double2(y.x + eta[r].x, y.y + eta[r].y);
+        const double2 e0 = ETA_GET(r);
+        prd += e0.x * (g.x + 0.5 * he.x) + e0.y * (g.y + 0.5 * he.y);
+        const double2 x = make_double2(y.x + e0.x, y.y + e0.y);
         double nn = sqrt(msdp_group_sum<LPR>(x.x * x.x + x.y * x.y));
         if (!(nn > 0.0)) nn = 1.0;                                  // empty row slot
         const double2 ypr = OK(r) ? make_double2(x.x / nn, x.y / nn) : zz;
@@ -572,12 +573,14 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!pbarrier(slots, nbar++, GS, shb, err, bid)) return;
+    // (EARLY: every workgroup has left the tCG -- the half its last trip published can go back to the sentinel)
+    if (EARLY && pend >= 0) { reset_half(pend); pend = -1; }
     // cost and gradient at the proposal (ManiSDP_onlyunitdiag.m:117-125): YC = Y*C, eG = sum(YC.*Y), G = YC - Y.*eG.
     // Rolled loop over the row slots (LDS in, LDS out): this phase runs once per TR iteration and must not add
     // register pressure to the tCG loop above.
 #pragma unroll 1
     for (int r = 0; r < R; ++r) {
-        const double2 acc = gather_row(r, rs_yp, false);
+        const double2 acc = gather_row(r, rs_yp, 0u);
         const double2 ypr = YPs[r * PB + threadIdx.x];
         const double dot = msdp_group_sum<LPR>(acc.x * ypr.x + acc.y * ypr.y);
         const double2 gpr = OK(r) ? make_double2(acc.x - ypr.x * dot, acc.y - ypr.y * dot) : zz;
@@ -663,6 +666,8 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_xr4(XrDevs4 ds, unsigned lon
 }
 
 #undef VOFF
+#undef ETA_GET
+#undef ETA_SET
 #undef Y_GET
 #undef G_GET
 #undef MD_GET
@@ -765,6 +770,9 @@ static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false, int e
     return nullptr;
 }
 
+static bool persist_is_early(msdp_handle h, const PersistPlan& pl, bool fuse) { return h->tune.persist_early && persist_kernel_early(pl, fuse) != nullptr; }
+static size_t early_lds(const PersistPlan& pl);
+
 // The persistent kernel has its own grid: at most one workgroup per CU (co-residency), independent of the grid
 // of the row-parallel kernels around it (those exchange data through global memory only).
 static int persist_grid(const Dev& d) {
@@ -791,16 +799,6 @@ static int persist_grid(const Dev& d) {
     return g;
 }
 
-// Row stride of the exchange buffer and the base of this launch's row-flag counts (EARLY trips, msdp_psync.h): every launch counts
-// from where the previous one could have ended at most (`adv` publications), k_psync_reset starts over.
-static void persist_exchange_layout(msdp_handle h, const PersistPlan& pl, Dev& dp, unsigned long long adv) {
-    const size_t rows = (size_t)dp.n_loc;
-    dp.xld = (h->tune.persist_xld && rows * (size_t)(2 * pl.lpr) <= h->mdx_doubles) ? 2 * pl.lpr : dp.ld;
-    dp.flag_base = h->flag_epoch;
-    const unsigned long long next = (unsigned long long)h->flag_epoch + adv;
-    h->flag_epoch = next > 0x7fff0000ULL ? 0x7fff0000u : (unsigned)next;     // (a fused launch of more than 2^31 trips would need a 64-bit count)
-}
-
 // 1: the persistent kernel can run this handle's tCG (and all its workgroups are co-resident); 0: use the chunked path
 int msdp_persist_eligible(msdp_handle h) {
     const Dev& d = h->d;
@@ -812,6 +810,7 @@ int msdp_persist_eligible(msdp_handle h) {
     if (!persist_plan(d, G, pl)) return 0;
     persist_fn fn = persist_kernel(pl, false, h->tune.persist_early);
     if (!fn) return 0;
+    if (persist_is_early(h, pl, false)) pl.lds += early_lds(pl);
     // the ELL copy must be stored with the width the kernel is instantiated for
     if (pl.ew > 0 && d.ellW != pl.ew) return 0;
     if (h->persist_sig_lpr == pl.lpr && h->persist_sig_ew == pl.ew && h->persist_sig_r == pl.r && h->persist_sig_G == G && h->persist_sig_fn == (const void*)fn)
@@ -835,15 +834,13 @@ int msdp_launch_tcg_persist(msdp_handle h, int reset_slots) {
     if (!persist_plan(h->d, G, pl)) { msdp_set_error("persistent tCG: not eligible"); return MSDP_ESTATE; }
     persist_fn fn = persist_kernel(pl, false, h->tune.persist_early);
     if (!fn) { msdp_set_error("persistent tCG: no kernel instance"); return MSDP_ESTATE; }
+    if (persist_is_early(h, pl, false)) pl.lds += early_lds(pl);
     Dev dp = h->d;
     dp.G = G;
-    const unsigned long long adv = (unsigned long long)(h->h_ctl->maxinner > 0 ? h->h_ctl->maxinner : 0) + 2ULL;
-    if (reset_slots || (unsigned long long)h->flag_epoch + adv > 0x7fff0000ULL) {
+    if (reset_slots) {
         hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, h->stream, h->psync_slots, h->psync_err);
         HIPCHK(hipGetLastError());
-        h->flag_epoch = 0;
     }
-    persist_exchange_layout(h, pl, dp, adv);
     if (dp.trace) {
         if (!(pl.lpr == 16 && pl.ew == 5 && pl.r == 3)) { msdp_set_error("persistent trace: only the <16, 5, 3> instance (17 <= p <= 32, rows of <= 5 entries) is traced"); return MSDP_EUNSUPPORTED; }
         fn = h->tune.persist_early ? k_tcg_persist_obl<16, 5, 3, false, true, false, true> : k_tcg_persist_obl<16, 5, 3, false, true>;
@@ -862,6 +859,8 @@ static size_t fused_lds(const PersistPlan& pl) {
     const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr);
     return pl.lds + 16 + (size_t)2 * pl.r * PB * sizeof(double2) + rows * sizeof(double);
 }
+// EARLY instances keep eta in LDS, behind everything else (R x PB double2)
+static size_t early_lds(const PersistPlan& pl) { return 16 + (size_t)pl.r * PB * sizeof(double2); }
 
 // Whole trustregions() loop in one launch (FUSE = true): tCG + retraction + cost/gradient at the proposal + the
 // accept/reject logic, iterated on the device until gradnorm < tol or maxiter.  Needs Y and grad in LDS (p <= 32).
@@ -876,7 +875,7 @@ int msdp_persist_fused_ok(msdp_handle h) {
     if (!persist_plan(h->d, G, pl)) return 0;
     persist_fn fn = persist_kernel(pl, true, h->tune.persist_early);
     if (!fn) return 0;
-    pl.lds = fused_lds(pl);
+    pl.lds = fused_lds(pl) + (persist_is_early(h, pl, true) ? early_lds(pl) : 0);
     if (h->fused_sig_lpr == pl.lpr && h->fused_sig_ew == pl.ew && h->fused_sig_G == G && h->fused_sig_fn == (const void*)fn) return h->fused_sig_ok;
     int ok = 0, per_cu = 0;
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) == hipSuccess &&
@@ -893,14 +892,11 @@ int msdp_launch_rtr_fused(msdp_handle h) {
     if (!persist_plan(h->d, G, pl)) { msdp_set_error("fused RTR: not eligible"); return MSDP_ESTATE; }
     persist_fn fn = persist_kernel(pl, true, h->tune.persist_early);
     if (!fn) { msdp_set_error("fused RTR: no kernel instance"); return MSDP_ESTATE; }
-    pl.lds = fused_lds(pl);
+    pl.lds = fused_lds(pl) + (persist_is_early(h, pl, true) ? early_lds(pl) : 0);
     Dev dp = h->d;
     dp.G = G;
     hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, h->stream, h->psync_slots, h->psync_err);
     HIPCHK(hipGetLastError());
-    h->flag_epoch = 0;
-    persist_exchange_layout(h, pl, dp, ((unsigned long long)(h->h_ctl->maxinner > 0 ? h->h_ctl->maxinner : 0) + 2ULL) *
-                                           ((unsigned long long)(h->h_ctl->maxiter > 0 ? h->h_ctl->maxiter : 0) + 1ULL));
     hipLaunchKernelGGL(fn, dim3(G), dim3(PB), pl.lds, h->stream, dp, h->psync_slots, h->psync_err);
     HIPCHK(hipGetLastError());
     return 0;
@@ -971,7 +967,6 @@ int msdp_xpersist_member(msdp_handle h, int nranks, int rank, double* mdx, Dev* 
     if (!xr_plan(h, nranks, pl, &G)) { msdp_set_error("cross-rank persistent tCG: not eligible"); return MSDP_ESTATE; }
     *out = h->d;
     out->G = G; out->xr_gid0 = rank * G; out->xr_gtot = nranks * G; out->xr_mdx = mdx; out->status = nullptr; out->trace = nullptr;
-    out->xld = out->ld; out->flag_base = 0;
     plan3[0] = pl.lpr; plan3[1] = pl.ew; plan3[2] = pl.r;
     return 0;
 }

@@ -138,7 +138,9 @@ __device__ __forceinline__ void psync_post3(unsigned long long* slots, unsigned 
         if (vi < 3) {
             double s = 0.0;
             for (int i = 0; i < PWAVES; ++i) s += sh[vi * PWAVES + i];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the reset store of this slot's other generations has been performed
+            // (no wait for the reset store of this generation's slots here: it was issued two synchronisations ago and the psync() of
+            // reduction 1 in between waited for everything in front of its own post -- a wait at this point would put the drain
+            // of the row stores the caller has just issued in front of the post)
             __hip_atomic_store(gbase + ((size_t)rep * PSYNC_NV + vi) * MSDP_MAX_GRID + bid,
                                (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -178,10 +180,12 @@ __device__ __forceinline__ bool psync_poll_once(const unsigned long long* p0, in
 }
 // Closes the split reduction: the polling waves hand their sums over, wave 0 resets its slots of the previous generation.
 // `fail` (any wave): a bounded spin ran out.  Returns false in every thread if any wave failed.
+// shb[7] = the workgroup's failure flag (0.0 at kernel start; no extra static LDS: the dynamic array behind sh / shb must stay
+// 16-byte aligned -- one more int had moved it to offset 264 and every ds_read_b128 of the resident rows went misaligned)
 __device__ __forceinline__ bool psync_finish3(unsigned long long* slots, unsigned gen, double t0, bool fail, double& a, double& b, double& c,
-                                              double* shb, int* shfail, int* err, int bid) {
+                                              double* shb, int* err, int bid) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (fail && lane == 0) { *shfail = 1; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (fail && lane == 0) { shb[7] = 1.0; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     if (w < 3) {
         const double r0 = msdp_wave_sum(t0);
         if (lane == 0) shb[w] = r0;
@@ -192,14 +196,8 @@ __device__ __forceinline__ bool psync_finish3(unsigned long long* slots, unsigne
     }
     __syncthreads();
     a = msdp_readlane(shb[0], 0); b = msdp_readlane(shb[1], 0); c = msdp_readlane(shb[2], 0);
-    return __builtin_amdgcn_readfirstlane(*shfail) == 0;
+    return msdp_readlane(shb[7], 0) == 0.0;
 }
-
-// Row flags (round 5): wave v of workgroup b raises flags[b * PWAVES + v] to the number of the publication once ITS rows of that
-// publication are performed; a consumer wave watches the flags of the waves that own the rows it gathers.  32-bit counters behind
-// the two slot regions, zeroed by k_psync_reset; sc1 accesses (uncached memory).
-#define PFLAG_OFF64 (2 * PSYNC_REGION)                                     // in 64-bit words from the slot base
-#define PFLAG_WORDS64 ((size_t)MSDP_MAX_GRID * PWAVES / 2)
 
 // Barrier without a value (the new direction rows are in place): workgroup b adds to counter b & 7, everybody
 // polls the 8 counters (64 B apart).  nbar = number of barriers passed before this one.  G is a multiple of 8.

@@ -1,6 +1,5 @@
 """Round 5: the persistent tCG trip with the neighbours' rows gathered behind per-wave row flags while reduction 2 is in flight
-(option persist_early) against the round-4 trip (persist_early = 0), and the exchange buffer padded to whole 128-byte lines
-(persist_xld).  G81, p in {8, 16, 32}: trip time (bench mode, 512 trips) and whole trustregions() calls (p = 32).
+(option persist_early) against the round-4 trip (persist_early = 0).  G81, p in {8, 16, 32}: trip time (bench mode, 512 trips) and whole trustregions() calls (p = 32).
 argv: [p list, comma separated]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,14 +14,11 @@ for p in ps:
     Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
     h = _lib.Handle.onlyunitdiag(C, pcap=p)
     h.set_point(Y)
-    for xld in (1, 0):
-        h.set_option("persist_xld", xld)
-        for early in (0, 1, 3, 5, 7, 9, 12, 16, 20):
-            h.set_option("persist_early", early)
-            t = min(h.bench_tcg_trip(512) for _ in range(4)) * 1e3
-            print("p %2d xld %d early %2d: trip %.3f us" % (p, xld, early, t), flush=True)
+    for early in (0, 1, 3, 5, 7, 9, 12, 16, 20):
+        h.set_option("persist_early", early)
+        t = min(h.bench_tcg_trip(512) for _ in range(4)) * 1e3
+        print("p %2d early %2d: trip %.3f us" % (p, early, t), flush=True)
     # psync_backoff interplay with the early trip
-    h.set_option("persist_xld", 1)
     for early in (1, 5):
         h.set_option("persist_early", early)
         for bo in (14, 17, 19, 22, 26):
