@@ -88,9 +88,25 @@ static std::vector<UcArena> g_uc_arenas;
 static std::map<void*, std::pair<int, size_t>> g_uc_live;     // block -> (arena index, size)
 static const size_t UC_ALIGN = 256, UC_ARENA_MIN = (size_t)32 << 20;
 static size_t g_uc_cap = (size_t)1 << 30;                     // pool bytes kept when nothing is live (MSDP_UC_POOL_CAP, bytes)
+static int g_uc_release = 0;                                  // MSDP_UC_RELEASE=1: arenas may go back to the driver (see msdp_uc_free)
 static size_t uc_pool_bytes_locked() { size_t t = 0; for (auto& a : g_uc_arenas) t += a.bytes; return t; }
 static int g_uc_direct = 0;                                   // MSDP_UC_POOL=0: one driver block per request, hipFree'd at once (the round-3
                                                               //   arrangement that corrupted later handles; kept for tools/uc_pool_stress.py only)
+// Round 5: the exchange memory is FINE-GRAINED device memory (hipDeviceMallocFinegrained), not uncached (hipDeviceMallocUncached) any more.
+// tools/uc_pool_stress.py, 300 handles per mode: uncached blocks that went back to the driver corrupt whoever receives their pages next --
+// the same three handles wrong whether the block was hipFree'd as it was (mode 0), hipMemset + synchronised first (4), or rewritten line
+// by line with cached stores and an L2 write-back / invalidate (5): a formerly-uncached page keeps something of its memory type that no
+// access from user space clears.  Fine-grained blocks freed the same way: 0 of 300 wrong (mode 6), and the persistent trip is FASTER on
+// them (G81, p = 32: 6.41 against 6.55 us; 146 100 against 142 500 Hess-vec/s per trustregions() call, profiles/r5_finegrained_vs_uncached.log).
+// MSDP_UC_MEM=uncached restores the old memory type (then the arenas never go back to the driver, as in round 4).
+static unsigned g_uc_flags = hipDeviceMallocFinegrained;     // MSDP_UC_MEM=uncached: hipDeviceMallocUncached; MSDP_UC_POOL=6 / 7: fine-grained (direct / arenas)
+// Round 5 probes (tools/uc_pool_stress.py): what has to happen to a formerly-uncached block before hipFree for its pages to be safe in
+// somebody else's hands?  4: hipMemset of the whole block + hipDeviceSynchronize; 5: every 128-byte line written by a kernel with plain
+// (cached) stores, then an L2 write-back + invalidate by every wave (buffer_wbl2 sc1 / buffer_inv sc1), then hipDeviceSynchronize.
+__global__ void k_uc_scrub(unsigned long long* p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0ULL;
+    asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)\n\tbuffer_inv sc1" ::: "memory");
+}
 void* msdp_uc_alloc(size_t bytes) {
     if (bytes == 0) bytes = 8;
     bytes = (bytes + UC_ALIGN - 1) / UC_ALIGN * UC_ALIGN;
@@ -101,14 +117,23 @@ void* msdp_uc_alloc(size_t bytes) {
     if (!env_read) {
         env_read = true;
         const char* e = getenv("MSDP_UC_POOL_CAP"); if (e && *e) g_uc_cap = (size_t)strtoull(e, nullptr, 10);
+        e = getenv("MSDP_UC_MEM"); if (e && !strcmp(e, "uncached")) g_uc_flags = hipDeviceMallocUncached;
+        e = getenv("MSDP_UC_POOL"); if (e && *e >= '0' && *e <= '5' && *e != '1') g_uc_flags = hipDeviceMallocUncached;   // the probes of the old memory type
+        e = getenv("MSDP_UC_RELEASE"); if (e && *e == '1') g_uc_release = 1; else if (e && *e == '0') g_uc_release = 0;
+        else g_uc_release = g_uc_flags == hipDeviceMallocFinegrained ? 1 : 0;   // fine-grained pages are safe in anybody's hands
         // probes of tools/uc_pool_stress.py: 0 = direct (hipFree at destroy), 2 = direct + hipDeviceSynchronize before every free,
         // 3 = direct, uncached blocks never freed
-        e = getenv("MSDP_UC_POOL"); if (e && (*e == '0' || *e == '2' || *e == '3')) g_uc_direct = *e == '0' ? 1 : (*e - '0');
+        // round 5: 4 / 5 = direct, the block scrubbed before hipFree (see k_uc_scrub); 6 = direct, fine-grained instead of uncached memory;
+        // 7 = the arenas, of fine-grained memory
+        e = getenv("MSDP_UC_POOL");
+        if (e && *e >= '0' && *e <= '7' && *e != '1') g_uc_direct = *e == '0' ? 1 : (*e == '7' ? 0 : *e - '0');
+        if (e && (*e == '6' || *e == '7')) g_uc_flags = hipDeviceMallocFinegrained;
     }
     if (g_uc_direct) {
         void* p = nullptr;
-        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipExtMallocWithFlags(&p, bytes, g_uc_flags) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         if (g_uc_direct == 3) g_uc_live[p] = {-1, bytes};     // registered with no arena: msdp_uc_free keeps it for ever
+        if (g_uc_direct == 4 || g_uc_direct == 5) g_uc_live[p] = {-2, bytes};   // registered for its size: scrubbed in msdp_uc_free, hipFree'd by the caller
         return p;                                             // else not registered: msdp_uc_free returns false and the caller hipFree's it
     }
     for (int pass = 0; pass < 2; ++pass) {
@@ -132,7 +157,7 @@ void* msdp_uc_alloc(size_t bytes) {
         if (pass == 1) break;
         void* p = nullptr;
         const size_t ab = std::max(bytes, UC_ARENA_MIN);
-        if (hipExtMallocWithFlags(&p, ab, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipExtMallocWithFlags(&p, ab, g_uc_flags) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         UcArena a; a.base = (char*)p; a.bytes = ab; a.dev = dev; a.live = 0; a.freemap[0] = ab;
         g_uc_arenas.push_back(a);
     }
@@ -147,6 +172,15 @@ bool msdp_uc_free(void* p) {                                  // true: p was an 
     std::lock_guard<std::mutex> lk(g_uc_mutex);
     auto it = g_uc_live.find(p);
     if (it == g_uc_live.end()) { if (g_uc_direct == 2) (void)hipDeviceSynchronize(); return false; }
+    if (it->second.first == -2) {                             // probe modes 4 / 5: scrub, then the caller hipFree's
+        const size_t sz = it->second.second;
+        (void)hipDeviceSynchronize();
+        if (g_uc_direct == 4) (void)hipMemset(p, 0, sz);
+        else hipLaunchKernelGGL(k_uc_scrub, dim3(256), dim3(256), 0, 0, (unsigned long long*)p, sz / 8);
+        (void)hipDeviceSynchronize();
+        g_uc_live.erase(it);
+        return false;
+    }
     if (it->second.first < 0) return true;                    // probe mode 3: leaked on purpose
     UcArena& a = g_uc_arenas[it->second.first];
     size_t off = (size_t)((char*)p - a.base), sz = it->second.second;
@@ -156,12 +190,15 @@ bool msdp_uc_free(void* p) {                                  // true: p was an 
     if (nx != a.freemap.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == off) { off = pv->first; sz += pv->second; a.freemap.erase(pv); } }
     a.freemap[off] = sz;
     g_uc_live.erase(it);
-    if (g_uc_live.empty() && uc_pool_bytes_locked() > g_uc_cap) uc_trim_locked(g_uc_cap);   // indices are free to change: nothing is live
+    // Round 5: arenas of UNCACHED memory are never handed back to the driver while the process lives -- such pages corrupt whoever
+    // receives them next (torch, a MATLAB gpuArray in the same process included), and no scrub of tools/uc_pool_stress.py is clean.
+    // Arenas of fine-grained memory (the default now) go back beyond MSDP_UC_POOL_CAP when nothing is live and on msdp_release_cache.
+    if (g_uc_release && g_uc_live.empty() && uc_pool_bytes_locked() > g_uc_cap) uc_trim_locked(g_uc_cap);   // indices are free to change: nothing is live
     return true;
 }
 void msdp_uc_release_pool() {
     std::lock_guard<std::mutex> lk(g_uc_mutex);
-    if (!g_uc_live.empty()) return;                           // a live handle owns uncached blocks: its arenas stay
+    if (!g_uc_release || !g_uc_live.empty()) return;          // a live handle owns uncached blocks: its arenas stay
     uc_trim_locked(0);
 }
 // Pool statistics: bytes the arenas hold, bytes handed out, number of arenas (tests)

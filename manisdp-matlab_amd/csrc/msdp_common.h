@@ -171,7 +171,7 @@ struct Tuning {
                              //   with 0, 7.06 (14), 6.85 (18), 6.87 (20), 7.05 (24), 7.44 (32), 7.86 (40); p = 16: 6.87 -> 5.84
                              //   (tools/psync_backoff_probe.py); sleeping between failed polls gains nothing
     int persist_refresh = 32;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
-    int persist_early = 1;     // persistent tCG: the neighbours' rows are gathered while reduction 2 is in flight -- sentinel-initialised exchange
+    int persist_early = 0;     // persistent tCG: the neighbours' rows are gathered while reduction 2 is in flight -- sentinel-initialised exchange
                                //   halves, the rows are their own flags (0: at the top of the next trip, behind reduction 2 -- the round-4 trip;
                                //   n >= 1: n - 1 s_sleep units between the post of reduction 2 and the first gather)
     int affine_overlap = 0;  // affine Hess-vec: 2*eS*U on a second stream beside the A(.) / A'(.) chain.  Measured SLOWER (round 3: BQP d = 60

@@ -374,6 +374,9 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
 #pragma unroll
             for (int r = 0; r < R; ++r) hrow(r);
         }
+        // EARLY: the sentinel stores of the last trip (issued a reduction ago) are performed before anything of this trip is stored to the
+        // same half -- explicit, and free at this point (a wait behind reduction 1 would sit on that reduction's own slot-reset store)
+        if (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TSTAMP(1);
         if (!psync(slots, gen++, GS, 1, pd, u1, u2, sh, shb, err, bid, backoff)) { failed = true; break; }
         TSTAMP(2);
@@ -396,10 +399,9 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         // ---- trial step and its three inner products (tCG.m:215-241)
         const bool refresh_now = TWOSYNC && refresh > 0 && ((j + 1) % refresh) == 0;   // this trip ends with a direct exchange
         double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        // EARLY: this trip's rows go to half xq; every wave's earlier stores to it (the sentinel, one trip ago) have long been
-        // performed -- the wait makes the order of the two stores to one address explicit and costs nothing here
+        // EARLY: this trip's rows go to half xq; every wave's earlier stores to it (the sentinel, one trip ago) were waited for at the
+        // end of the top phase of this trip
         const unsigned qoff = EARLY ? (unsigned)xq * half_bytes : 0u;
-        if (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double2 g = G_GET(r), mdr = MD_GET(r), hq = HMD_GET(r);
@@ -435,7 +437,10 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             bool r2ok = wave >= 3, fail = false;
             double r2t = 0.0;
             int spins = 0;
-            for (;;) {
+            {
+                // One full gather; afterwards only the elements that still held the sentinel are asked for again, by the lanes that
+                // miss them (a retry of everything would put the whole 5 x n x ld x 8 bytes on the fabric again -- the gather is
+                // bandwidth-bound there: two full attempts cost 1.5 us, profiles/r5_persist_timeline_p32_sentinel_full_retry.md)
                 double2 XE[EARLY ? R : 1][EARLY ? EW : 1];
 #pragma unroll
                 for (int r = 0; r < (EARLY ? R : 0); ++r)
@@ -445,24 +450,36 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
                         XE[EARLY ? r : 0][EARLY ? w : 0] = ld2_sc1(rs_md, qoff + ((unsigned)cidx * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u);
                     }
                 if (!r2ok) r2ok = psync_poll_once(p0, GS, r2t);
-                bool ready = true;
+                for (;;) {
+                    bool ready = true;
+#pragma unroll
+                    for (int r = 0; r < (EARLY ? R : 0); ++r)
+#pragma unroll
+                        for (int w = 0; w < (EARLY ? EW : 0); ++w) {
+                            const double2 x = XE[EARLY ? r : 0][EARLY ? w : 0];
+                            if ((unsigned long long)__double_as_longlong(x.x) == PSYNC_SENT || (unsigned long long)__double_as_longlong(x.y) == PSYNC_SENT) {
+                                const int cidx = cs[w * ROWS + SLOT(r)];
+                                XE[EARLY ? r : 0][EARLY ? w : 0] = ld2_sc1(rs_md, qoff + ((unsigned)cidx * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u);
+                                ready = false;
+                            }
+                        }
+                    if (__builtin_amdgcn_ballot_w64(!ready) == 0ULL) break;
+                    if (!r2ok) r2ok = psync_poll_once(p0, GS, r2t);
+                    ++spins;
+                    if (spins > PSYNC_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
+                }
 #pragma unroll
                 for (int r = 0; r < (EARLY ? R : 0); ++r) {
                     double2 acc = zz;
 #pragma unroll
                     for (int w = 0; w < (EARLY ? EW : 0); ++w) {
-                        const double2 x = XE[EARLY ? r : 0][EARLY ? w : 0];
-                        ready = ready && (unsigned long long)__double_as_longlong(x.x) != PSYNC_SENT && (unsigned long long)__double_as_longlong(x.y) != PSYNC_SENT;
                         const double v = vs[w * ROWS + SLOT(r)];
-                        acc.x = fma(v, x.x, acc.x);
-                        acc.y = fma(v, x.y, acc.y);
+                        acc.x = fma(v, XE[EARLY ? r : 0][EARLY ? w : 0].x, acc.x);
+                        acc.y = fma(v, XE[EARLY ? r : 0][EARLY ? w : 0].y, acc.y);
                     }
                     if (!colok) acc = zz;
                     acc_e[EARLY ? r : 0] = acc;
                 }
-                if (__builtin_amdgcn_ballot_w64(!ready) == 0ULL) break;
-                ++spins;
-                if (spins > PSYNC_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
             }
             TSTAMP(5);
             // (4) reduction 2

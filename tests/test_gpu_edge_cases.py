@@ -1,6 +1,8 @@
 """GPU edge cases through the C-ABI: ragged / empty rows, tiny and odd sizes, widths that exercise every lane
 mapping (p = 1 pad column ... p > 128 multi-chunk), dense orders that are not multiples of the MFMA tile,
 degenerate constraint sets, and the error paths (call-order violations, unsupported sizes)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -475,5 +477,7 @@ def test_handle_churn_keeps_results_and_pool_bounded(lib):
     pool, live, arenas = lib.pool_stats()
     assert live == 0
     assert peak_pool - base_pool <= 2 * peak_live + 2 * (32 << 20), (peak_pool, peak_live)
+    # round 5: the arenas are fine-grained memory (safe to hand back: tools/uc_pool_stress.py mode 6); with MSDP_UC_MEM=uncached
+    # they stay with the process for good (pages that were uncached are not safe in anybody else's hands)
     lib.release_cache()
-    assert lib.pool_stats()[0] == 0
+    assert lib.pool_stats()[0] == (pool if os.environ.get("MSDP_UC_MEM") == "uncached" else 0)

@@ -14,14 +14,14 @@ for p in ps:
     Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
     h = _lib.Handle.onlyunitdiag(C, pcap=p)
     h.set_point(Y)
-    for early in (0, 1, 3, 5, 7, 9, 12, 16, 20):
+    for early in (0, 1, 5, 9, 13, 17, 21, 25, 29, 33):
         h.set_option("persist_early", early)
         t = min(h.bench_tcg_trip(512) for _ in range(4)) * 1e3
         print("p %2d early %2d: trip %.3f us" % (p, early, t), flush=True)
     # psync_backoff interplay with the early trip
-    for early in (1, 5):
+    for early in (9, 17):
         h.set_option("persist_early", early)
-        for bo in (14, 17, 19, 22, 26):
+        for bo in (15, 19, 23):
             h.set_option("psync_backoff", bo)
             t = min(h.bench_tcg_trip(512) for _ in range(4)) * 1e3
             print("p %2d early %d psync_backoff %2d: trip %.3f us" % (p, early, bo, t), flush=True)
@@ -29,7 +29,7 @@ for p in ps:
     if p == 32:
         opts = _lib.default_opts(maxiter=40, maxinner=100, tolgradnorm=1e-8)
         h.point_snapshot()
-        for early in (0, 1, 5, 9):
+        for early in (0, 1, 9, 17, 25):
             h.set_option("persist_early", early)
             best, hv, cost = 1e9, 0, 0.0
             for _ in range(6):

@@ -24,11 +24,11 @@ if early:
     names = ["top of the trip: C*mdelta' = C*tangent(r') + beta*C*mdelta, projection, <d,Hd> partials (tCG.m:163)",
              "grid reduction 1: <d,Hd> (:166)",
              "trial step, projected residual rows stored, reduction 2 POSTED (:215-241)",
-             "drain of the row stores (s_waitcnt vmcnt(0)), row flag raised",
-             "wait for the neighbours' row flags (reduction 2 polled under the same waits)",
-             "gather of the neighbours' rows, C*tangent(r') formed",
+             "last trip's half back to the sentinel, back-off before the first gather",
+             "gather of the neighbours' rows until none holds the sentinel, C*tangent(r') formed (reduction 2 polled under the same waits)",
              "rest of grid reduction 2: model value, <r,r> (:227-241)",
-             "commit, beta, new direction, loop back (:233-287)"]
+             "commit, beta, new direction (:233-287)",
+             "loop back (stop tests, next trip's set-up)"]
     NP = 8
 else:
     names = ["gathers of C*x + row arithmetic (tCG.m:163)", "grid reduction 1: <d,Hd> (:166)", "trial step, projected residual rows stored (:215-241)",

@@ -1,5 +1,7 @@
 """Root-cause probe for the round-3 corruption of later handles by uncached device memory that was hipFree'd per handle.
-Run with MSDP_UC_POOL=0 (one driver block per request, hipFree at destroy: the round-3 arrangement) and without (arena pool):
+Run with MSDP_UC_POOL=0 (one driver block per request, hipFree at destroy: the round-3 arrangement) and without (arena pool);
+round 5: 4 = direct + hipMemset + device synchronisation before every hipFree, 5 = direct + every line rewritten with cached stores and
+an L2 write-back / invalidate before hipFree, 6 = direct with FINE-GRAINED instead of uncached memory, 7 = arenas of fine-grained memory:
 counts the handles whose cost / eG / gradient differ from NumPy.  argv: [iterations=300] [--sync] (hipDeviceSynchronize between handles
 via torch-free means: a blocking get_z) """
 import os, sys
