@@ -96,6 +96,7 @@ SIGNATURES = {
     "msdp_debug_pool_stats": (C.c_int, [_P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
     "msdp_debug_mem_info": (C.c_int, [_P(C.c_int64), _P(C.c_int64)]),
     "msdp_comm_init_local": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "msdp_comm_init_ipc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
     "msdp_get_point_all": (C.c_int, [C.c_void_p, _dp]),
     "msdp_get_z_all": (C.c_int, [C.c_void_p, _dp]),
     "msdp_factor_gram": (C.c_int, [C.c_void_p, _dp]),
@@ -591,6 +592,11 @@ class Handle:
         """Member `rank` of an in-process group of `nranks` handles on one GPU (one host thread per handle): the N-rank code
         paths with local stand-ins for the RCCL collectives."""
         _check(self._lib.msdp_comm_init_local(self._h, int(nranks), int(rank), int(group)))
+
+    def comm_init_ipc(self, nranks, rank, name):
+        """Member `rank` of a group of `nranks` PROCESSES (ranks on one GPU, or one per GPU with peer access): `name` is a POSIX
+        shared-memory name ("/..."), the same on every member, fresh per group (msdp_comm_init_ipc)."""
+        _check(self._lib.msdp_comm_init_ipc(self._h, int(nranks), int(rank), name.encode()))
 
     def local_rows(self):
         a, b = C.c_int64(), C.c_int64()

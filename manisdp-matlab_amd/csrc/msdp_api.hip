@@ -1074,7 +1074,35 @@ struct Halo {
 #include <map>
 #include <mutex>
 #define LOCAL_MAX_RANKS 8
+// Round 5: the same group, with its members in DIFFERENT PROCESSES (msdp_comm_init_ipc) -- ranks on one GPU, or one rank per GPU of a
+// node with peer access.  What the in-process members share through their common address space travels through two shared blocks here:
+// a POSIX shared-memory segment for the host side (barrier, votes, halo list sizes, the IPC handle) and ONE device allocation of rank 0
+// that every member maps through hipIpcOpenMemHandle (the ARENA: the slot regions and exchange buffer of the cross-rank persistent tCG,
+// and one staging slab per rank for the collectives: a member copies its contribution into its slab, the others read it there).  The
+// collectives, the lock-step driver and the cross-rank persistent tCG above them are the code of the in-process group, call for call.
+#include <atomic>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+struct IpcShared {
+    std::atomic<int> arrived; std::atomic<unsigned long long> gen; std::atomic<int> broken;
+    std::atomic<int> attached; std::atomic<int> arena_ready;
+    hipIpcMemHandle_t arena;
+    unsigned long long arena_bytes, stage_bytes, mdx_doubles, slot_bytes;
+    int vote[LOCAL_MAX_RANKS];
+    int plan[LOCAL_MAX_RANKS][4];
+    int halo_off[LOCAL_MAX_RANKS][LOCAL_MAX_RANKS], halo_cnt[LOCAL_MAX_RANKS][LOCAL_MAX_RANKS];
+};
 struct LocalGroup {
+    // members in other processes (msdp_comm_init_ipc): the host segment, the arena as this process maps it, this member's rank
+    bool ipc = false;
+    IpcShared* shm = nullptr;
+    std::string shm_name;
+    char* arena = nullptr;
+    char* stage = nullptr;         // arena + slots + exchange buffer: n slabs of stage_bytes
+    size_t stage_bytes = 0;
+    int my_rank = 0;
     int n = 0;
     std::mutex m;
     std::condition_variable cv;
@@ -1114,11 +1142,27 @@ static double local_barrier_timeout() {
 // a member that fails between two barriers marks the group broken at once, so that its peers do not wait out the time limit
 static void local_break(LocalGroup* g) {
     if (!g) return;
+    if (g->ipc) { g->shm->broken.store(1); return; }
     std::lock_guard<std::mutex> lk(g->m);
     g->broken = true;
     g->cv.notify_all();
 }
 static bool local_barrier(LocalGroup* g) {
+    if (g->ipc) {
+        // sense-reversing barrier on the shared segment; polite polling (a collective on this path lasts tens of microseconds at least)
+        IpcShared* sh = g->shm;
+        if (sh->broken.load()) return false;
+        const unsigned long long my = sh->gen.load();
+        if (sh->arrived.fetch_add(1) + 1 == g->n) { sh->arrived.store(0); sh->gen.fetch_add(1); return true; }
+        const auto t0 = std::chrono::steady_clock::now();
+        long spins = 0;
+        while (sh->gen.load() == my) {
+            if (sh->broken.load()) return false;
+            if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            if ((spins & 1023) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > local_barrier_timeout()) { sh->broken.store(1); return false; }
+        }
+        return true;
+    }
     std::unique_lock<std::mutex> lk(g->m);
     if (g->broken) return false;
     const unsigned long long my = g->gen;
@@ -1134,10 +1178,11 @@ static bool local_barrier(LocalGroup* g) {
 // minimum of one int per member (an agreement: every member takes the branch only if all of them can)
 static int local_vote_min(msdp_handle h, int v, int* out) {
     LocalGroup* g = h->lgroup;
-    { std::lock_guard<std::mutex> lk(g->m); g->vote[h->rank] = v; }
+    if (g->ipc) g->shm->vote[h->rank] = v;
+    else { std::lock_guard<std::mutex> lk(g->m); g->vote[h->rank] = v; }
     LOCAL_BARRIER(g);
     int m = v;
-    for (int r = 0; r < g->n; ++r) m = std::min(m, g->vote[r]);
+    for (int r = 0; r < g->n; ++r) m = std::min(m, g->ipc ? g->shm->vote[r] : g->vote[r]);
     LOCAL_BARRIER(g);                                      // nobody overwrites its vote before everyone has read it
     *out = m;
     return 0;
@@ -1149,6 +1194,10 @@ int msdp_xpersist_reset(hipStream_t stream, unsigned long long* slots, int* err)
 static int xr_ensure_shared(msdp_handle h) {
     LocalGroup* g = h->lgroup;
     const size_t need = (size_t)rows_capacity(h) * h->nranks * (size_t)std::max(h->ldcap, 64);
+    if (g->ipc) {                                            // the arena was cut at msdp_comm_init_ipc
+        if (g->xr_mdx_doubles < need) { msdp_set_error("cross-rank persistent tCG: the factor outgrew the arena of this communicator (ld %d)", h->ldcap); return MSDP_ENOMEM; }
+        return 0;
+    }
     LOCAL_BARRIER(g);
     int rc = 0;
     if (h->rank == 0 && (!g->xr_slots || g->xr_mdx_doubles < need)) {
@@ -1188,9 +1237,25 @@ static int xr_begin(msdp_handle h, bool* use) {
 }
 // One tCG for all members: each hands its Dev and plan to the group and marks its stream; member 0 makes its stream wait for
 // the others', launches the combined kernel and marks its end; the others' streams wait for that mark.
+int msdp_launch_tcg_xpersist_one(hipStream_t stream, const Dev& dv, const int* plan, unsigned long long* slots, int* err);   // msdp_persist.hip
 static int xr_launch(msdp_handle h) {
     LocalGroup* g = h->lgroup;
     int rc;
+    if (g->ipc) {
+        // members in different processes: every member launches ITS workgroups itself (separate processes have separate hardware
+        // queues; the launches meet in the first grid synchronisation, a bounded spin turns a member that never comes into MSDP_ECOMM)
+        Dev dv; int pl[3];
+        if ((rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_mdx, &dv, pl))) { local_break(g); return rc; }
+        for (int q = 0; q < 3; ++q) g->shm->plan[h->rank][q] = pl[q];
+        LOCAL_BARRIER(g);
+        for (int r = 1; r < g->n; ++r)
+            if (g->shm->plan[r][0] != g->shm->plan[0][0] || g->shm->plan[r][2] != g->shm->plan[0][2]) { msdp_set_error("cross-rank persistent tCG: the members' plans differ"); return MSDP_ESTATE; }
+        for (int r = 0; r < g->n; ++r) if (g->shm->plan[r][1] != pl[1]) pl[1] = 0;      // different ELL widths: everybody walks its CSR rows
+        if (h->tune.fail_xr) { h->tune.fail_xr = 0; dv.xr_gtot += 8; }
+        if ((rc = msdp_launch_tcg_xpersist_one(h->stream, dv, pl, g->xr_slots, g->xr_err))) { local_break(g); return rc; }
+        LOCAL_BARRIER(g);                                    // nobody overwrites its plan before everyone has read it
+        return 0;
+    }
     {
         Dev dv; int pl[3];
         if ((rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_mdx, &dv, pl))) { local_break(g); return rc; }
@@ -1232,6 +1297,17 @@ __global__ void k_local_sum(LocalPtrs src, int n, size_t count, double* __restri
         out[i] = acc;
     }
 }
+// A member's contribution to a collective: in one process the others read it where it lies; across processes it is copied into the
+// member's staging slab of the arena first (the caller has synchronised its stream: the source is complete)
+static int group_publish(msdp_handle h, const double* buf, size_t count) {
+    LocalGroup* g = h->lgroup;
+    if (!g->ipc) { std::lock_guard<std::mutex> lk(g->m); g->ptr[h->rank] = buf; return 0; }
+    if (count * sizeof(double) > g->stage_bytes) { msdp_set_error("inter-process communicator: a contribution of %zu bytes exceeds the staging slab (%zu)", count * sizeof(double), g->stage_bytes); local_break(g); return MSDP_ENOMEM; }
+    HIPCHK(hipMemcpyAsync(g->stage + (size_t)h->rank * g->stage_bytes, buf, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+static const double* group_peer(LocalGroup* g, int r) { return g->ipc ? (const double*)(g->stage + (size_t)r * g->stage_bytes) : g->ptr[r]; }
 static int local_allreduce(msdp_handle h, double* buf, size_t count) {
     LocalGroup* g = h->lgroup;
     if (h->lc_tmp_cap < count) {
@@ -1241,10 +1317,10 @@ static int local_allreduce(msdp_handle h, double* buf, size_t count) {
         h->lc_tmp_cap = count;
     }
     HIPCHK(hipStreamSynchronize(h->stream));               // my contribution is complete
-    { std::lock_guard<std::mutex> lk(g->m); g->ptr[h->rank] = buf; }
+    { int rcp = group_publish(h, buf, count); if (rcp) return rcp; }
     LOCAL_BARRIER(g);
     LocalPtrs src;
-    for (int r = 0; r < LOCAL_MAX_RANKS; ++r) src.p[r] = r < g->n ? g->ptr[r] : nullptr;
+    for (int r = 0; r < LOCAL_MAX_RANKS; ++r) src.p[r] = r < g->n ? group_peer(g, r) : nullptr;
     int blocks = (int)std::min<size_t>(1024, (count + 255) / 256);
     hipLaunchKernelGGL(k_local_sum, dim3(blocks), dim3(256), 0, h->stream, src, g->n, count, h->lc_tmp);
     HIPCHK(hipGetLastError());
@@ -1256,10 +1332,10 @@ static int local_allreduce(msdp_handle h, double* buf, size_t count) {
 static int local_allgather(msdp_handle h, const double* local, double* all, size_t count_per_rank) {
     LocalGroup* g = h->lgroup;
     HIPCHK(hipStreamSynchronize(h->stream));
-    { std::lock_guard<std::mutex> lk(g->m); g->ptr[h->rank] = local; }
+    { int rcp = group_publish(h, local, count_per_rank); if (rcp) return rcp; }
     LOCAL_BARRIER(g);
     for (int r = 0; r < g->n; ++r)
-        HIPCHK(hipMemcpyAsync(all + (size_t)r * count_per_rank, g->ptr[r], count_per_rank * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(all + (size_t)r * count_per_rank, group_peer(g, r), count_per_rank * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     LOCAL_BARRIER(g);                                      // nobody overwrites its slab before everyone has copied it
     return 0;
@@ -1268,17 +1344,21 @@ static int local_allgather(msdp_handle h, const double* local, double* all, size
 static int local_halo(msdp_handle h, Halo* ha, int ld) {
     LocalGroup* g = h->lgroup;
     HIPCHK(hipStreamSynchronize(h->stream));               // my send buffer is packed
-    { std::lock_guard<std::mutex> lk(g->m); g->ptr[h->rank] = ha->sendbuf; g->halo[h->rank] = ha; }
+    if (g->ipc) {
+        for (int q = 0; q < g->n; ++q) { g->shm->halo_cnt[h->rank][q] = ha->send_cnt[q]; g->shm->halo_off[h->rank][q] = ha->send_off[q]; }
+        int rcp = group_publish(h, ha->sendbuf, (size_t)ha->send_rows * ld); if (rcp) return rcp;
+    } else { std::lock_guard<std::mutex> lk(g->m); g->ptr[h->rank] = ha->sendbuf; g->halo[h->rank] = ha; }
     LOCAL_BARRIER(g);
     for (int q = 0; q < g->n; ++q) {
         if (q == h->rank || ha->recv_cnt[q] == 0) continue;
-        const Halo* pq = g->halo[q];
-        if (pq->send_cnt[h->rank] != ha->recv_cnt[q]) {
-            msdp_set_error("halo exchange: rank %d sends %d rows, rank %d expects %d", q, pq->send_cnt[h->rank], h->rank, ha->recv_cnt[q]);
+        const int q_cnt = g->ipc ? g->shm->halo_cnt[q][h->rank] : g->halo[q]->send_cnt[h->rank];
+        const int q_off = g->ipc ? g->shm->halo_off[q][h->rank] : g->halo[q]->send_off[h->rank];
+        if (q_cnt != ha->recv_cnt[q]) {
+            msdp_set_error("halo exchange: rank %d sends %d rows, rank %d expects %d", q, q_cnt, h->rank, ha->recv_cnt[q]);
             local_break(g);                                    // the peers learn at once, not after the barrier's time limit
             return MSDP_ECOMM;
         }
-        HIPCHK(hipMemcpyAsync(ha->recvbuf + (size_t)ha->recv_off[q] * ld, g->ptr[q] + (size_t)pq->send_off[h->rank] * ld,
+        HIPCHK(hipMemcpyAsync(ha->recvbuf + (size_t)ha->recv_off[q] * ld, group_peer(g, q) + (size_t)q_off * ld,
                               (size_t)ha->recv_cnt[q] * ld * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1290,6 +1370,14 @@ static void local_leave(msdp_handle h) {
     std::lock_guard<std::mutex> lk(g_groups_mutex);
     LocalGroup* g = h->lgroup;
     h->lgroup = nullptr;
+    if (g->ipc) {
+        // the arena belongs to rank 0 (the mappings of the others keep its memory alive until they close them)
+        if (g->arena) { if (g->my_rank == 0) (void)hipFree(g->arena); else (void)hipIpcCloseMemHandle(g->arena); }
+        if (g->shm) (void)munmap((void*)g->shm, sizeof(IpcShared));
+        if (g->my_rank == 0 && !g->shm_name.empty()) (void)shm_unlink(g->shm_name.c_str());
+        delete g;
+        return;
+    }
     if (--g->members == 0) {
         for (auto it = g_groups.begin(); it != g_groups.end(); ++it) if (it->second == g) { g_groups.erase(it); break; }
         if (g->xr_slots && !msdp_uc_free(g->xr_slots)) (void)hipFree(g->xr_slots);
@@ -1565,6 +1653,65 @@ extern "C" int msdp_comm_init_local(msdp_handle h, int32_t nranks, int32_t rank,
         h->lgroup = g;
     }
     return comm_partition(h, nranks, rank);
+}
+
+// Members in different processes (one per GPU of a node, or several on one GPU): `name` identifies the group (a POSIX shared-memory
+// name, e.g. "/msdp_<pid of the launcher>_<counter>"; every member passes the same one).  Rank 0 allocates the arena and exports it,
+// the others map it; with ranks on different devices the mapping goes over peer access (hipIpcMemLazyEnablePeerAccess).
+extern "C" int msdp_comm_init_ipc(msdp_handle h, int32_t nranks, int32_t rank, const char* name) {
+    CHECK_H(h);
+    if (nranks < 1 || nranks > LOCAL_MAX_RANKS || rank < 0 || rank >= nranks || !name || name[0] != '/') { msdp_set_error("comm_init_ipc: bad arguments (the name starts with '/')"); return MSDP_EINVAL; }
+    if (h->have_point || h->use_comm) { msdp_set_error("comm_init_ipc must precede set_point / comm_init"); return MSDP_ESTATE; }
+    if (h->presharded && (nranks != h->nranks || rank != h->rank)) { msdp_set_error("comm_init_ipc: shard was created as rank %d of %d", h->rank, h->nranks); return MSDP_EINVAL; }
+    if (h->kind == MSDP_KIND_MULTIBLOCK || h->kind == MSDP_KIND_DUAL_UNITDIAG) { msdp_set_error("row sharding is not implemented for the multiblock and dual kinds"); return MSDP_EUNSUPPORTED; }
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) { msdp_set_error("comm_init_ipc: shm_open(%s) failed", name); return MSDP_ECOMM; }
+    if (ftruncate(fd, (off_t)sizeof(IpcShared)) != 0) { (void)close(fd); msdp_set_error("comm_init_ipc: ftruncate failed"); return MSDP_ECOMM; }
+    void* mp = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    (void)close(fd);
+    if (mp == MAP_FAILED) { msdp_set_error("comm_init_ipc: mmap failed"); return MSDP_ECOMM; }
+    LocalGroup* g = new LocalGroup();
+    g->ipc = true; g->n = nranks; g->members = 1; g->my_rank = rank; g->shm = (IpcShared*)mp; g->shm_name = name;
+    h->lgroup = g;
+    int rc = comm_partition(h, nranks, rank);
+    if (rc) return rc;
+    IpcShared* sh = g->shm;
+    const size_t slot_bytes = msdp_xpersist_slot_bytes() + 256;
+    const size_t ldx = (size_t)std::max(h->ldcap, 64);
+    const size_t mdx_doubles = (size_t)rows_capacity(h) * nranks * ldx;
+    const size_t stage = std::max<size_t>(((size_t)rows_capacity(h) * ldx * sizeof(double) + 255) / 256 * 256, (size_t)1 << 16);
+    const size_t total = slot_bytes + mdx_doubles * sizeof(double) + (size_t)nranks * stage;
+    if (rank == 0) {
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, total, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("comm_init_ipc: arena allocation of %zu bytes failed", total); local_break(g); return MSDP_ENOMEM; }
+        HIPCHK(hipMemset(p, 0, total));
+        HIPCHK(hipDeviceSynchronize());
+        hipIpcMemHandle_t hd;
+        if (hipIpcGetMemHandle(&hd, p) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); msdp_set_error("comm_init_ipc: hipIpcGetMemHandle failed"); local_break(g); return MSDP_ECOMM; }
+        g->arena = (char*)p;
+        sh->arena = hd; sh->arena_bytes = total; sh->stage_bytes = stage; sh->mdx_doubles = mdx_doubles; sh->slot_bytes = slot_bytes;
+        sh->arena_ready.store(1);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!sh->arena_ready.load()) {
+            if (sh->broken.load() || std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > local_barrier_timeout()) { msdp_set_error("comm_init_ipc: rank 0 did not publish the arena"); return MSDP_ECOMM; }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        if (sh->arena_bytes != total || sh->stage_bytes != stage) { msdp_set_error("comm_init_ipc: the members disagree about the problem size"); local_break(g); return MSDP_EINVAL; }
+        void* p = nullptr;
+        hipIpcMemHandle_t hd = sh->arena;
+        if (hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("comm_init_ipc: hipIpcOpenMemHandle failed"); local_break(g); return MSDP_ECOMM; }
+        g->arena = (char*)p;
+    }
+    g->xr_slots = (unsigned long long*)g->arena;
+    g->xr_err = (int*)(g->arena + msdp_xpersist_slot_bytes());
+    g->xr_mdx = (double*)(g->arena + slot_bytes);
+    g->xr_mdx_doubles = mdx_doubles;
+    g->stage = g->arena + slot_bytes + mdx_doubles * sizeof(double);
+    g->stage_bytes = stage;
+    sh->attached.fetch_add(1);
+    LOCAL_BARRIER(g);                                        // everybody has mapped the arena
+    return 0;
 }
 
 extern "C" int msdp_comm_init(msdp_handle h, int32_t nranks, int32_t rank, const void* id128) {

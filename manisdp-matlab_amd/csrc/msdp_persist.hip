@@ -987,6 +987,22 @@ int msdp_xpersist_member(msdp_handle h, int nranks, int rank, double* mdx, Dev* 
     plan3[0] = pl.lpr; plan3[1] = pl.ew; plan3[2] = pl.r;
     return 0;
 }
+// Members in different processes (msdp_comm_init_ipc): every member launches its own G workgroups -- the same body, the same protocol;
+// the launches of different processes run side by side (tools/ipc_probe.hip: a barrier across two such launches costs 1.75 us).
+int msdp_launch_tcg_xpersist_one(hipStream_t stream, const Dev& dv, const int* plan, unsigned long long* slots, int* err) {
+    const int lpr = plan[0], ew = plan[1], r = plan[2];
+    persist_fn fn = nullptr;
+#define XK(L, E, RR) if (lpr == L && ew == E && r == RR) fn = k_tcg_persist_obl<L, E, RR, false, false, true>;
+    XK(8, 5, 2) XK(8, 0, 2) XK(8, 5, 4) XK(8, 0, 4) XK(16, 5, 3) XK(16, 0, 3) XK(16, 5, 5) XK(16, 0, 5) XK(32, 5, 5) XK(32, 0, 5)
+#undef XK
+    if (!fn) { msdp_set_error("cross-rank persistent tCG: no kernel instance"); return MSDP_ESTATE; }
+    const size_t lds = xr_lds(lpr, ew, r);
+    HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fn, dim3(dv.G), dim3(PB), lds, stream, dv, slots, err);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // Member 0: one launch for all members.  devs[q] / plans[3q..] as filled by msdp_xpersist_member on every member.
 int msdp_launch_tcg_xpersist_all(hipStream_t stream, int nranks, const Dev* devs, const int* plans, unsigned long long* slots, int* err) {
     const int lpr = plans[0], r = plans[2];

@@ -1,0 +1,99 @@
+"""Row-sharded ranks in DIFFERENT PROCESSES (msdp_comm_init_ipc): the N-GPU form of the cross-rank persistent tCG as far as one GPU can
+validate it -- N fresh processes share the GPU, the slot regions and the exchange buffer of the tCG live in one fine-grained device
+block that rank 0 exports with hipIpcGetMemHandle and the others map with hipIpcOpenMemHandle (the mapping goes over peer access when
+the ranks own different devices: the same code path), every process launches its own workgroups, and the collectives outside the tCG
+go through staging slabs of the same block.  Reference: one unsharded handle (tCG.m:160-289, trustregions.m:441-767)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_counter = [0]
+
+
+def _run_ranks(N, rows, cols, p, tmp_path, devices=None):
+    _counter[0] += 1
+    name = "/msdp_test_%d_%d" % (os.getpid(), _counter[0])
+    procs, outs = [], []
+    env = dict(os.environ)
+    env.setdefault("MSDP_LOCAL_BARRIER_TIMEOUT", "60")
+    for r in range(N):
+        out = str(tmp_path / ("rank%d.npz" % r))
+        outs.append(out)
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "ipc_rank_worker.py"), str(r), str(N), name, str(rows), str(cols), str(p), out]
+        if devices is not None:
+            cmd.append(str(devices[r]))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            o, _ = pr.communicate()
+        logs.append(o)
+    for r, pr in enumerate(procs):
+        assert pr.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-3000:])
+    return [np.load(o) for o in outs]
+
+
+def _reference(rows, cols, p):
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    C = problems.toroidal_grid_maxcut(rows, cols, seed=7)
+    n = C.shape[0]
+    rng = np.random.default_rng(3)
+    Y0 = rng.standard_normal((n, p)); Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True)
+    h = _lib.Handle.onlyunitdiag(C, pcap=p)
+    h.set_point(Y0)
+    f0, G0 = h.cost(), h.rgrad()
+    st = h.rtr(_lib.default_opts(maxiter=10, maxinner=60, tolgradnorm=1e-9))
+    Y1 = h.get_point()
+    h.close()
+    return f0, G0, st, Y1
+
+
+def _check(res, ref):
+    f0, G0, st, Y1 = ref
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    for q in res:
+        r0, r1 = q["rows"]
+        assert abs(float(q["f0"]) - f0) <= 1e-12 * abs(f0)
+        assert rel(q["G0"][r0:r1], G0[r0:r1]) < 1e-12
+        assert int(q["path"]) == 2                                 # the cross-rank persistent kernel ran
+        assert tuple(int(v) for v in q["stats"]) == (st.hessvecs, st.accepted, st.rejected, st.iters, st.last_stop_inner)
+        assert abs(float(q["cost"]) - st.cost) <= 1e-10 * abs(st.cost)
+        assert rel(q["Y"], Y1) < 1e-8
+        assert np.array_equal(q["Y"], res[0]["Y"])                 # every member ends with the same bits
+        # zero collectives per trip: the same number per TR iteration whether a tCG makes 7 trips or 60
+        assert int(q["hv7"]) < st.hessvecs
+        assert abs(int(q["calls"]) / max(int(q["iters"]), 1) - int(q["calls7"]) / max(int(q["iters7"]), 1)) < 1.0 + 6.0 / max(int(q["iters7"]), 1)
+        assert "timed out" in str(q["err"]) or "did not reach" in str(q["err"]) or "group broken" in str(q["err"]), str(q["err"])
+    print("process ranks: trip %.2f us" % max(float(q["trip_us"]) for q in res))
+
+
+@pytest.mark.parametrize("N,shape,p", [(2, (200, 200), 32), (2, (61, 50), 12), (4, (200, 200), 16)])
+def test_process_ranks_on_one_gpu_run_one_persistent_tcg(tmp_path, N, shape, p):
+    """N processes on ONE GPU, 256 / N workgroups each, separate launches: same counts / stop codes / end point as one handle, zero
+    collectives per trip, a launch that waits for workgroups that do not exist ends in MSDP_ECOMM instead of hanging."""
+    res = _run_ranks(N, shape[0], shape[1], p, tmp_path)
+    _check(res, _reference(shape[0], shape[1], p))
+    assert max(float(q["trip_us"]) for q in res) < 40.0
+
+
+@pytest.mark.parametrize("N", [2, 4, 8])
+def test_process_ranks_on_separate_gpus(tmp_path, N):
+    """The identical code path with one rank per GPU: the arena is mapped over peer access (skipped where fewer than N GPUs are visible)."""
+    from manisdp_matlab_amd import _lib
+    _lib.load()
+    if _lib.device_count() < N:
+        pytest.skip("needs %d GPUs" % N)
+    if N > 4:
+        pytest.skip("the cross-rank persistent kernel serves up to 4 members (256 / N workgroups per member)")
+    res = _run_ranks(N, 200, 200, 32, tmp_path, devices=list(range(N)))
+    _check(res, _reference(200, 200, 32))
