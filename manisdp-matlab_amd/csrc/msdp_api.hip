@@ -43,6 +43,8 @@ int msdp_affine_setup_blocked(msdp_handle h, int nb, const int64_t* block_n, con
                               const double* b, const double* c);        // msdp_affine.hip: multiblock kind, per-block storage
 int msdp_affine_get_block(msdp_handle h, int64_t row0, int64_t nbk, double* S);
 void msdp_densesym_release(msdp_handle h);                  // msdp_densesym.hip
+void msdp_window_release(msdp_handle h);                    // msdp_window.hip
+int msdp_window_eligible(msdp_handle h);
 int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam, double* V, double* lmax, int* iters,
                      const double* Mdev);
 int msdp_dense_nS(int n);
@@ -727,6 +729,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     for (int s2 = 0; s2 < 2; ++s2) if (h->chunk_execs[s2]) (void)hipGraphExecDestroy(h->chunk_execs[s2]);
     msdp_affine_release(h);
     msdp_densesym_release(h);
+    msdp_window_release(h);
     halo_release(h);
     local_leave(h);
     if (h->lc_tmp) (void)hipFree(h->lc_tmp);
@@ -1009,6 +1012,8 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "escape_start_y")) t.escape_start_y = value != 0;
     else if (!strcmp(name, "xpersist")) t.xpersist = value != 0;
     else if (!strcmp(name, "persist_refresh")) t.persist_refresh = value > 0 ? value : 0;
+    else if (!strcmp(name, "window")) { t.window = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
+    else if (!strcmp(name, "window_lds")) { t.window_lds = value < 16 ? 16 : (value > 144 ? 144 : value); h->chunk_len = 0; msdp_window_release(h); }
     else if (!strcmp(name, "persist_early")) t.persist_early = value > 0 ? value : 0;
     else if (!strcmp(name, "psync_backoff")) t.psync_backoff = value > 0 ? value : 0;
     else if (!strcmp(name, "affine_overlap")) { t.affine_overlap = value != 0; h->chunk_len = 0; }
@@ -2218,6 +2223,7 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
     if (opts->maxinner < 1 || opts->maxiter < 0) { msdp_set_error("rtr: maxinner >= 1 and maxiter >= 0 required"); return MSDP_EINVAL; }
     const auto t0 = std::chrono::steady_clock::now();
     h->last_opts = *opts;
+    (void)msdp_window_eligible(h);                                 // (builds the patch plan of the LDS-staged S*U outside any graph capture)
     // The persistent kernels assume that all their workgroups are resident together.  When the GPU is shared (a
     // second handle solving on another stream, another process) that can fail; the launch then gives up after a
     // bounded spin.  Keep a copy of the start point so that the call can be repeated on the chunked path.
@@ -2276,6 +2282,7 @@ extern "C" int msdp_rtr_host(msdp_handle h, int32_t p, double* Y, const msdp_rtr
 // ------------------------------------------------------------------ fine-grained ops
 static int ensure_state(msdp_handle h) {
     if (!h->have_point) { msdp_set_error("no resident point"); return MSDP_ESTATE; }
+    (void)msdp_window_eligible(h);                                 // (patch plan of the LDS-staged S*U: built here, outside any graph capture)
     if (h->state_valid) return 0;
     h->h_ctl->done = 0;
     h->h_ctl->bench_mode = 0;

@@ -170,6 +170,9 @@ struct Tuning {
                              //   the polls of 216 workgroups are the traffic the posts compete with -- G81, p = 32: 8.03 us per trip
                              //   with 0, 7.06 (14), 6.85 (18), 6.87 (20), 7.05 (24), 7.44 (32), 7.86 (40); p = 16: 6.87 -> 5.84
                              //   (tools/psync_backoff_probe.py); sleeping between failed polls gains nothing
+    int window = 1;            // stand-alone sparse S*U with the gathered rows staged once per workgroup in LDS (msdp_window.hip): 1 = for vectors
+                               //   far beyond the L2s (from 3 * 2^22 entries on), 2 = always (tests), 0 = never
+    int window_lds = 144;      // ... KB of LDS a window may take (A/B; one 1024-thread workgroup per CU)
     int persist_refresh = 32;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
     int persist_early = 0;     // persistent tCG: the neighbours' rows are gathered while reduction 2 is in flight -- sentinel-initialised exchange
                                //   halves, the rows are their own flags (0: at the top of the next trip, behind reduction 2 -- the round-4 trip;
@@ -224,6 +227,7 @@ struct msdp_handle_s {
     // its rows of C reference (msdp_api.hip, "Halo exchange")
     struct Halo* halo = nullptr;
     struct LocalGroup* lgroup = nullptr;   // in-process stand-in for the RCCL communicator (msdp_comm_init_local)
+    struct WinCache* win = nullptr;        // patch plans of the LDS-staged S*U (msdp_window.hip), one per lanes-per-row
     double* lc_tmp = nullptr; size_t lc_tmp_cap = 0;   // its reduction scratch
     // row-sharded onlyunitdiag (sparse C): the escape runs replicated on full copies of C's CSR arrays and of z
     int* esc_rp = nullptr; int* esc_ci = nullptr; double* esc_cv = nullptr; double* esc_z = nullptr;

@@ -620,6 +620,8 @@ static inline void lpr_rebalance(msdp_handle h, int& lpr, int& nch) {
         }                                                                                            \
     } while (0)
 
+int msdp_window_eligible(msdp_handle h);            // msdp_window.hip
+int msdp_window_hess(msdp_handle h);
 int msdp_dense_costgrad(msdp_handle h, int slot);   // msdp_dense.hip
 int msdp_dense_hess(msdp_handle h);
 int msdp_affine_costgrad(msdp_handle h, int slot);  // msdp_affine.hip
@@ -654,7 +656,8 @@ int msdp_launch_hess(msdp_handle h) {
     int rc = (h->d.costkind == COST_SPARSE) ? msdp_exchange_rows(h, h->d.md) : msdp_allgather_rows(h, h->d.md);
     if (rc) return rc;
     if (h->d.costkind == COST_SPARSE) {
-        if (h->d.ellW > 0) DISPATCH_LPR(k_hess_ell_obl, h, h->d);
+        if (msdp_window_eligible(h)) { if ((rc = msdp_window_hess(h))) return rc; }        // gathered rows staged in LDS (msdp_window.hip)
+        else if (h->d.ellW > 0) DISPATCH_LPR(k_hess_ell_obl, h, h->d);
         else DISPATCH_LPR(k_hess_sparse_obl, h, h->d);
     } else if (h->d.costkind == COST_DENSE) {
         rc = msdp_dense_hess(h);

@@ -1,0 +1,263 @@
+// msdp_window.hip -- S*U for vectors far beyond the L2s with the gathered rows staged ONCE per workgroup in LDS
+// (ManiSDP_onlyunitdiag.m:127-130: eH = U*C; H = eH - Y.*sum(Y.*eH) - U.*eG; north_star's "LDS-staged p-wide panels").
+//
+// Why: k_hess_ell_obl gathers, for every row, the rows of U its row of C references straight from the L2 -- on a grid graph five
+// 16-byte-per-lane row gathers per row, 1.9 KB per row through the L2 for 0.84 KB from HBM (n = 10^6, p = 32: 212 us = 0.49 of
+// HBM, traffic already 1.00 x the algorithmic bytes: profiles/r4_pmc_hess_n1e6_p32.json).  Here the rows are cut into PATCHES of B
+// rows that are close in the graph (breadth-first growth from the lowest unassigned row: on a 2-D grid a patch is a diamond-like
+// tile whose halo is ~ 25 % of its rows, where a block of B consecutive rows has a halo of 2B).  A workgroup loads the window of a
+// patch -- its own rows and the halo rows, each ONCE, whole 16-byte-per-lane rows, coalesced -- into LDS, and forms every row
+// product from LDS with patch-local column indices.  Per row through the L2: (1 + halo / B) rows of U + the rows of Y and H + 60
+// bytes of (index, value) pairs: 0.9 KB instead of 1.9.  The patches of the workgroups that run together on an XCD are consecutive
+// (the traversal of msdp_sweep_rows), so a halo row is in that XCD's L2 when the neighbouring patch asks for it.
+// Same fma order per row as spmm_row's ELL form: the result is bit-identical to k_hess_ell_obl (tests/test_gpu_onlyunitdiag.py).
+#include "msdp_device.h"
+#include <algorithm>
+#include <deque>
+#include <vector>
+
+struct WinPlan {
+    int npatch, EW, wmax;
+    int64_t own_total;
+    const int* poff;      // [npatch + 1]  offsets into wrows
+    const int* pown;      // [npatch]      own rows of the patch = the first pown[p] rows of its window
+    const int* ooff;      // [npatch + 1]  offsets of the patch's own rows into the (index, value) slices
+    const int* wrows;     // window rows, GLOBAL row numbers (gather source d.full / the local vector at row - row0)
+    const int* lidx;      // [EW][own_total]  patch-local position of the column
+    const double* lval;   // [EW][own_total]
+};
+
+struct WinCacheEntry { int lpr = 0; int ld_max = 0; WinPlan plan{}; std::vector<void*> dev; bool failed = false; };
+struct WinCache { WinCacheEntry e[4]; };
+
+// H = proj-fused (C*md - Y.*rowdot(Y, C*md) - md.*eG) with the rows of md the patch touches staged in LDS; partial <md, Hmd>.
+template <int LPR>
+__global__ __launch_bounds__(MSDP_BLOCK) void k_hess_win_obl(Dev d, WinPlan w) {
+    extern __shared__ double2 win[];                       // [wmax][LPR]
+    __shared__ double sh[3 * MSDP_WAVES];
+    if (!d.F[0].active) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RPW = 64 / LPR;
+    constexpr int RSTEP = MSDP_WAVES * RPW;
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    const bool colok = 2 * sub < d.ld;
+    const int cur = d.ctl->cur;
+    const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
+    const double* __restrict__ eG = cur ? d.eG[1] : d.eG[0];
+    const double* __restrict__ Uf = d.full;
+    double* __restrict__ H = d.Hmd;
+    const double2 zz = make_double2(0.0, 0.0);
+    double pd = 0.0;
+    // XCD x (workgroups b = x mod 8 under round-robin dispatch) walks the patches [x P / 8, (x + 1) P / 8); its G / 8 resident
+    // workgroups take consecutive patches and advance together
+    const int X = blockIdx.x & 7, s = blockIdx.x >> 3, S = (int)gridDim.x >> 3;
+    const int p0 = (int)((int64_t)w.npatch * X / 8), p1 = (int)((int64_t)w.npatch * (X + 1) / 8);
+    for (int p = p0 + s; p < p1; p += S) {
+        const int w0 = w.poff[p], W = w.poff[p + 1] - w0, nown = w.pown[p], o0 = w.ooff[p];
+        for (int i = wave * RPW + rsub; i < W; i += RSTEP) {
+            const int row = w.wrows[w0 + i];
+            win[i * LPR + sub] = colok ? ld2(Uf + (int64_t)row * d.ld + 2 * sub) : zz;
+        }
+        __syncthreads();
+        for (int i0 = wave * RPW; i0 < nown; i0 += RSTEP) {
+            const int i = i0 + rsub;
+            const bool rok = i < nown;
+            const int ic = rok ? i : 0;
+            const int row = w.wrows[w0 + ic] - d.row0;     // local row
+            int c[MSDP_ELL_MAXW];
+            double v[MSDP_ELL_MAXW];
+#pragma unroll
+            for (int k = 0; k < MSDP_ELL_MAXW; ++k) {
+                const bool ok = k < w.EW;
+                c[k] = ok ? w.lidx[(int64_t)k * w.own_total + o0 + ic] : ic;
+                v[k] = ok ? w.lval[(int64_t)k * w.own_total + o0 + ic] : 0.0;
+            }
+            const double2 y = colok ? ld2_nt(Yl + (int64_t)row * d.ld + 2 * sub) : zz;
+            const double eg = eG[row];
+            double2 acc = zz;
+#pragma unroll
+            for (int k = 0; k < MSDP_ELL_MAXW; ++k) {
+                if (k < w.EW) {
+                    const double2 x = win[c[k] * LPR + sub];
+                    acc.x = fma(v[k], x.x, acc.x);
+                    acc.y = fma(v[k], x.y, acc.y);
+                }
+            }
+            if (!colok) acc = zz;
+            const double2 u = win[ic * LPR + sub];
+            const double dot = msdp_group_sum<LPR>(acc.x * y.x + acc.y * y.y);
+            if (rok && colok) {
+                double2 hq;
+                hq.x = acc.x - y.x * dot - u.x * eg;
+                hq.y = acc.y - y.y * dot - u.y * eg;
+                st2_nt(H + (int64_t)row * d.ld + 2 * sub, hq);
+                pd += u.x * hq.x + u.y * hq.y;
+            }
+        }
+        __syncthreads();                                   // the window is free for the next patch
+    }
+    msdp_put_partial(d.P, P_DHD, pd, sh);
+}
+
+// ------------------------------------------------------------------ host: patches
+// Breadth-first patches of at most B rows over the LOCAL rows (h_rowptr / h_colind hold ALL rows of C with global numbers; columns
+// outside the rank's rows are halo by definition); a patch
+// whose window exceeds wmax rows is cut in two (its rows are in breadth-first order: both halves stay connected-ish).
+static void win_build_patches(msdp_handle h, int B, int wmax, std::vector<std::vector<int>>& own, std::vector<std::vector<int>>& halo) {
+    const int nl = h->d.n_loc, r0 = h->d.row0;
+    const std::vector<int>& rp = h->h_rowptr; const std::vector<int>& ci = h->h_colind;
+    std::vector<int> asg((size_t)nl, -1);
+    int nxt = 0;
+    std::vector<std::vector<int>> raw;
+    while (true) {
+        while (nxt < nl && asg[nxt] >= 0) ++nxt;
+        if (nxt >= nl) break;
+        const int p = (int)raw.size();
+        std::vector<int> o;
+        std::deque<int> q;
+        while ((int)o.size() < B) {
+            if (q.empty()) {
+                while (nxt < nl && asg[nxt] >= 0) ++nxt;
+                if (nxt >= nl) break;
+                asg[nxt] = p; o.push_back(nxt); q.push_back(nxt);
+                continue;
+            }
+            const int r = q.front(); q.pop_front();
+            for (int k = rp[r + r0]; k < rp[r + r0 + 1] && (int)o.size() < B; ++k) {
+                const int c = ci[k] - r0;
+                if (c >= 0 && c < nl && asg[c] < 0) { asg[c] = p; o.push_back(c); q.push_back(c); }
+            }
+        }
+        raw.push_back(std::move(o));
+    }
+    // halo of a patch = the distinct columns (global numbers) of its rows that are not rows of the patch
+    std::vector<int> mark((size_t)h->d.n, -1);
+    std::deque<std::vector<int>> work(raw.begin(), raw.end());
+    int stamp = 0;
+    while (!work.empty()) {
+        std::vector<int> o = std::move(work.front()); work.pop_front();
+        ++stamp;
+        for (int r : o) mark[r + r0] = stamp;
+        std::vector<int> hl;
+        for (int r : o)
+            for (int k = rp[r + r0]; k < rp[r + r0 + 1]; ++k) { const int c = ci[k]; if (mark[c] != stamp) { mark[c] = stamp; hl.push_back(c); } }
+        if ((int)(o.size() + hl.size()) > wmax && o.size() > 1) {
+            std::vector<int> a(o.begin(), o.begin() + o.size() / 2), b(o.begin() + o.size() / 2, o.end());
+            work.push_front(std::move(b)); work.push_front(std::move(a));
+            continue;
+        }
+        std::sort(hl.begin(), hl.end());
+        own.push_back(std::move(o)); halo.push_back(std::move(hl));
+    }
+}
+
+template <class T>
+static int win_upload(WinCacheEntry& e, const std::vector<T>& v, const T** out) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); return MSDP_ENOMEM; }
+    e.dev.push_back(p);
+    if (!v.empty() && hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return MSDP_EHIP; }
+    *out = (const T*)p;
+    return 0;
+}
+
+static const size_t WIN_LDS_BYTES = 144 * 1024;            // one 1024-thread workgroup per CU: the window may take most of the 160 KB
+
+static int win_get_plan(msdp_handle h, int lpr, WinCacheEntry** out) {
+    if (!h->win) h->win = new WinCache();
+    WinCacheEntry* e = nullptr;
+    for (auto& x : h->win->e) if (x.lpr == lpr) { e = &x; break; }
+    if (!e) for (auto& x : h->win->e) if (x.lpr == 0) { e = &x; break; }
+    if (!e) return MSDP_EUNSUPPORTED;
+    *out = e;
+    if (e->lpr == lpr) return e->failed ? MSDP_EUNSUPPORTED : 0;
+    e->lpr = lpr;
+    const int wmax = (int)(std::min(WIN_LDS_BYTES, (size_t)h->tune.window_lds * 1024) / ((size_t)lpr * sizeof(double2)));
+    // target patch size: on a 2-D grid the halo of a breadth-first patch of B rows is ~ 2.5 sqrt(B) + a few rows
+    const int B = std::max(32, (int)(wmax * 0.78) / 16 * 16);
+    std::vector<std::vector<int>> own, halo;
+    win_build_patches(h, B, wmax, own, halo);
+    const int EW = h->d.ellW, r0 = h->d.row0;
+    const int np = (int)own.size();
+    std::vector<int> poff((size_t)np + 1, 0), pown((size_t)np, 0), ooff((size_t)np + 1, 0), wrows;
+    int64_t own_total = 0, win_total = 0;
+    for (int p = 0; p < np; ++p) { own_total += (int64_t)own[p].size(); win_total += (int64_t)(own[p].size() + halo[p].size()); }
+    // a graph without locality (every row drags its own halo in) gains nothing from the staging: keep the direct gathers
+    if (win_total > 3 * own_total) { e->failed = true; return MSDP_EUNSUPPORTED; }
+    wrows.reserve((size_t)win_total);
+    std::vector<int> lidx((size_t)EW * own_total, 0);
+    std::vector<double> lval((size_t)EW * own_total, 0.0);
+    std::vector<int> pos((size_t)h->d.n, -1);
+    const std::vector<int>& rp = h->h_rowptr; const std::vector<int>& ci = h->h_colind; const std::vector<double>& cv = h->h_cval;
+    int64_t o0 = 0;
+    for (int p = 0; p < np; ++p) {
+        poff[p] = (int)wrows.size(); pown[p] = (int)own[p].size(); ooff[p] = (int)o0;
+        int i = 0;
+        for (int r : own[p]) { pos[r + r0] = i++; wrows.push_back(r + r0); }
+        for (int c : halo[p]) { pos[c] = i++; wrows.push_back(c); }
+        for (size_t q = 0; q < own[p].size(); ++q) {
+            const int r = own[p][q];
+            int k = 0;
+            for (int t = rp[r + r0]; t < rp[r + r0 + 1] && k < EW; ++t, ++k) { lidx[(size_t)k * own_total + o0 + q] = pos[ci[t]]; lval[(size_t)k * own_total + o0 + q] = cv[t]; }
+            for (; k < EW; ++k) { lidx[(size_t)k * own_total + o0 + q] = (int)q; lval[(size_t)k * own_total + o0 + q] = 0.0; }   // ELL padding: (row, 0.0)
+        }
+        o0 += (int64_t)own[p].size();
+    }
+    poff[np] = (int)wrows.size(); ooff[np] = (int)o0;
+    WinPlan& pl = e->plan;
+    pl.npatch = np; pl.EW = EW; pl.wmax = wmax; pl.own_total = own_total;
+    int rc = 0;
+    if ((rc = win_upload(*e, poff, &pl.poff)) || (rc = win_upload(*e, pown, &pl.pown)) || (rc = win_upload(*e, ooff, &pl.ooff)) ||
+        (rc = win_upload(*e, wrows, &pl.wrows)) || (rc = win_upload(*e, lidx, &pl.lidx)) || (rc = win_upload(*e, lval, &pl.lval))) {
+        e->failed = true;
+        msdp_set_error("windowed Hess-vec: plan upload failed");
+        return rc;
+    }
+    if (h->tune.timing) fprintf(stderr, "[msdp window] lpr %d: %d patches of <= %d rows, windows %.2f x the rows (wmax %d)\n", lpr, np, B, (double)win_total / (double)own_total, wmax);
+    return 0;
+}
+
+void msdp_window_release(msdp_handle h) {
+    if (!h->win) return;
+    for (auto& x : h->win->e) for (void* p : x.dev) (void)hipFree(p);
+    delete h->win;
+    h->win = nullptr;
+}
+
+// 1: the staged Hess-vec serves this handle at its current width (sparse C with ELL rows, oblique, p <= 64, and a plan whose windows
+// stay below three times the rows); the plan is built at the first call per lane count
+int msdp_window_eligible(msdp_handle h) {
+    const Dev& d = h->d;
+    if (!h->tune.window || d.costkind != COST_SPARSE || d.manifold != MANI_OBLIQUE || d.rowfree || d.ellW < 1 || d.ellW > MSDP_ELL_MAXW || h->h_rowptr.empty()) return 0;
+    if (h->tune.window == 1 && !(d.sweep & 2)) return 0;   // from 3 * 2^22 vector entries on (where the streaming accesses start), or always (2)
+    if (d.ld > 64) return 0;
+    int lpr = 8;
+    while (2 * lpr < d.ld) lpr <<= 1;
+    WinCacheEntry* e = nullptr;
+    return win_get_plan(h, lpr, &e) == 0 ? 1 : 0;
+}
+
+int msdp_window_hess(msdp_handle h) {
+    const Dev& d = h->d;
+    int lpr = 8;
+    while (2 * lpr < d.ld) lpr <<= 1;
+    WinCacheEntry* e = nullptr;
+    int rc = win_get_plan(h, lpr, &e);
+    if (rc) return rc;
+    const size_t lds = (size_t)e->plan.wmax * lpr * sizeof(double2);
+    dim3 grid(d.G), block(MSDP_BLOCK);
+    static bool attr_set = false;                          // (not a stream operation: once per process, outside any graph capture)
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_hess_win_obl<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIN_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_hess_win_obl<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIN_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute((const void*)k_hess_win_obl<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIN_LDS_BYTES));
+        attr_set = true;
+    }
+    switch (lpr) {
+        case 8: hipLaunchKernelGGL(k_hess_win_obl<8>, grid, block, lds, h->stream, d, e->plan); break;
+        case 16: hipLaunchKernelGGL(k_hess_win_obl<16>, grid, block, lds, h->stream, d, e->plan); break;
+        default: hipLaunchKernelGGL(k_hess_win_obl<32>, grid, block, lds, h->stream, d, e->plan); break;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}

@@ -435,3 +435,54 @@ def test_windowed_row_traversal_of_the_standalone_operators(lib, shape, p):
     prob = R._OnlyUnitDiagProblem(C, n, p)
     prob.cost(Y)
     assert np.linalg.norm(a[2] - prob.hess(Y, U)) <= 1e-12 * np.linalg.norm(a[2])
+
+
+@pytest.mark.parametrize("shape,p", [((200, 300), 32), ((100, 100), 16), ((141, 142), 5), ((300, 300), 40), ((60, 50), 64), ((1, 4000), 12), ((0, 3000), 8)])
+def test_lds_staged_hessvec_is_bit_identical(lib, shape, p):
+    """Round 5 (north_star's "LDS-staged p-wide panels"): option window = 2 routes the stand-alone Hess-vec
+    (ManiSDP_onlyunitdiag.m:127-130) through k_hess_win_obl -- breadth-first patches of rows, the rows of U a patch touches loaded
+    ONCE per workgroup into LDS, products formed from LDS with patch-local indices in the fma order of the direct gathers.  Every
+    row must get the same bits as from k_hess_ell_obl, on grids, on a ring lattice (rows of 7 entries) and on a random graph without
+    locality (there the plan is refused and the direct kernel serves the call); sharded handles take their rows of the same plan."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R
+    if shape[0] > 1:
+        C = problems.toroidal_grid_maxcut(shape[0], shape[1], seed=5)
+    elif shape[0] == 1:
+        C = _ring_lattice_cost(shape[1], 3, seed=6)
+    else:
+        import scipy.sparse as sp
+        n0 = shape[1]
+        rng0 = np.random.default_rng(2)
+        ii = rng0.integers(0, n0, 2 * n0); jj = rng0.integers(0, n0, 2 * n0)
+        A = sp.coo_matrix((rng0.choice([1.0, -1.0], ii.size), (ii, jj)), shape=(n0, n0)).tocsr()
+        A = A + A.T
+        A.setdiag(0); A.eliminate_zeros()
+        C = (sp.diags(np.asarray(abs(A).sum(axis=1)).ravel()) - A).tocsr() * -0.25
+    n = C.shape[0]
+    Y, _ = _rand_point(n, p, seed=4)
+    U = np.random.default_rng(9).standard_normal((n, p))
+    out = []
+    for window in (2, 0):
+        h = lib.Handle.onlyunitdiag(C, pcap=p)
+        h.set_option("window", window)
+        h.set_point(Y)
+        H = h.hessvec(U)
+        assert np.array_equal(H, h.hessvec(U))
+        out.append(H)
+        h.close()
+    assert np.array_equal(out[0], out[1])
+    prob = R._OnlyUnitDiagProblem(C, n, p)
+    prob.cost(Y)
+    assert np.linalg.norm(out[0] - prob.hess(Y, U)) <= 1e-12 * np.linalg.norm(out[0])
+    if shape[0] > 1:
+        for N in (2, 3):
+            for r in range(N):
+                h = lib.Handle.onlyunitdiag(C, pcap=p)
+                h.debug_shard(N, r)
+                h.set_option("window", 2)
+                h.set_point(Y)
+                r0, r1 = h.local_rows()
+                h.debug_set_full_rows(U)
+                assert np.array_equal(h.hessvec(U)[r0:r1], out[1][r0:r1])
+                h.close()
