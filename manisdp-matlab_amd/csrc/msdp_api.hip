@@ -1012,6 +1012,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "escape_start_y")) t.escape_start_y = value != 0;
     else if (!strcmp(name, "xpersist")) t.xpersist = value != 0;
     else if (!strcmp(name, "persist_refresh")) t.persist_refresh = value > 0 ? value : 0;
+    else if (!strcmp(name, "xtail")) t.xtail = value ? 1 : 0;
     else if (!strcmp(name, "window")) { t.window = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
     else if (!strcmp(name, "window_lds")) { t.window_lds = value < 16 ? 16 : (value > 144 ? 144 : value); h->chunk_len = 0; msdp_window_release(h); }
     else if (!strcmp(name, "persist_early")) t.persist_early = value > 0 ? value : 0;
@@ -1283,6 +1284,15 @@ static int xr_launch(msdp_handle h) {
     LOCAL_BARRIER(g);
     if (h->rank != 0) HIPCHK(hipStreamWaitEvent(h->stream, g->xr_done, 0));
     return 0;
+}
+int msdp_launch_tr_tail_xr(hipStream_t stream, const Dev& dv, unsigned long long* slots, int* err);     // msdp_trtail.hip
+static int xr_tail(msdp_handle h) {
+    LocalGroup* g = h->lgroup;
+    Dev dv; int pl[3];
+    int rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_mdx, &dv, pl);
+    if (!rc) rc = msdp_launch_tr_tail_xr(h->stream, dv, g->xr_slots, g->xr_err);
+    if (rc) local_break(g);
+    return rc;
 }
 static int xr_check(msdp_handle h) {
     int e = 0;
@@ -2196,9 +2206,15 @@ static int rtr_core(msdp_handle h, const msdp_rtr_opts* opts, bool* timed_out) {
             else rc = run_tcg(h, opts->maxinner, h->h_ctl->k);        // :495
             if (rc) return rc;
             const auto tb = std::chrono::steady_clock::now();
-            if ((rc = msdp_launch_retract(h))) return rc;             // :540
-            if ((rc = msdp_launch_costgrad(h, cur ^ 1))) return rc;   // :544
-            if ((rc = msdp_launch_rtr_decide(h))) return rc;          // :548-729
+            if (xp && h->lgroup->ipc && h->tune.xtail) {
+                // members in different processes: the rest of the iteration is ONE launch per member too (k_tr_tail_obl<.., XR>) -- the
+                // proposal rows through the group's exchange buffer, barrier and reduction over its slots, no collective
+                if ((rc = xr_tail(h))) return rc;
+            } else {
+                if ((rc = msdp_launch_retract(h))) return rc;             // :540
+                if ((rc = msdp_launch_costgrad(h, cur ^ 1))) return rc;   // :544
+                if ((rc = msdp_launch_rtr_decide(h))) return rc;          // :548-729
+            }
             if ((rc = pull_ctl(h))) return rc;
             if (xp && (rc = xr_check(h))) return rc;
             const auto tc = std::chrono::steady_clock::now();

@@ -165,6 +165,8 @@ struct Tuning {
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
     int xpersist = 1;        // in-process ranks (msdp_comm_init_local), sparse C, oblique: ONE persistent tCG spanning the ranks' launches -- grid
                              //   reductions and row exchange through shared uncached memory, no collective per trip (msdp_persist.hip XR); 0: lock-step chunks
+    int xtail = 1;           // process ranks (msdp_comm_init_ipc): the rest of a TR iteration behind the cross-rank tCG is one launch per member as well
+                             //   (retraction, cost / gradient at the proposal, decision; msdp_trtail.hip XR); 0: sharded kernels with their collectives
     int psync_backoff = 19;  // grid reductions of the persistent kernels: s_sleep units (64 cycles) before the first poll | units after a
                              //   failed poll << 8.  Round 4: nothing can be visible for the first half microsecond after the posts, and
                              //   the polls of 216 workgroups are the traffic the posts compete with -- G81, p = 32: 8.03 us per trip

@@ -972,9 +972,10 @@ int msdp_xpersist_eligible(msdp_handle h, int nranks) {
     return cus >= G * nranks ? 1 : 0;
 }
 // Bytes of the shared synchronisation block: two slot regions (they alternate with the TR iteration)
-size_t msdp_xpersist_slot_bytes() { return 2 * PSYNC_REGION * sizeof(unsigned long long); }
+size_t msdp_xpersist_slot_bytes() { return 4 * PSYNC_REGION * sizeof(unsigned long long); }   // tCG: regions 0 / 1, cross-rank TR tail: 2 / 3
 int msdp_xpersist_reset(hipStream_t stream, unsigned long long* slots, int* err) {
     hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, stream, slots, err);
+    hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, stream, slots + 2 * PSYNC_REGION, err);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -12,7 +12,12 @@
 #include <math.h>
 #include <cstdlib>
 
-template <int LPR>
+// XR (round 5): the members of a row-sharded group run the tail TOGETHER, like the cross-rank persistent tCG in front of it
+// (msdp_persist.hip): the proposal rows travel through the group's exchange buffer of all n rows (global row numbers; the tCG does
+// not touch it between its last reduction and its next launch), the barrier and the reduction run over the N x G slots of a slot
+// region of the group (regions 2 and 3 of the shared block, alternating with the TR iteration; every launch clears the other one),
+// and every member takes the decision of trustregions.m:548-729 from the same sums in the same order -- no collective.
+template <int LPR, bool XR = false>
 __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* slots, int* err, int rcap) {
     extern __shared__ double lds[];
     __shared__ double sh[3 * PWAVES];
@@ -22,8 +27,17 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
     double2* YPs = reinterpret_cast<double2*>(lds);            // [rcap][PB] proposal rows of this workgroup
     Ctl* c = d.ctl;
     if (c->done) return;
-    psync_reset_other(slots);                                  // region A belongs to the persistent tCG kernel
-    unsigned long long* sb = slots + PSYNC_REGION;
+    const int bid = XR ? d.xr_gid0 + (int)blockIdx.x : (int)blockIdx.x;
+    const int GS = XR ? d.xr_gtot : d.G;
+    unsigned long long* sb;
+    if (XR) {
+        sb = slots + (size_t)(2 + (c->k & 1)) * PSYNC_REGION;
+        psync_reset_other(slots + (size_t)(2 + ((c->k & 1) ^ 1)) * PSYNC_REGION, bid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        psync_reset_other(slots);                              // region A belongs to the persistent tCG kernel
+        sb = slots + PSYNC_REGION;
+    }
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi);
     constexpr int RMAX = (LPR / 4 < 4) ? LPR / 4 : 4;            // row slots processed together (their loads overlap)
@@ -38,7 +52,10 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
     const double* __restrict__ eta = ix ? d.eta[1] : d.eta[0];
     const double* __restrict__ Heta = ix ? d.Heta[1] : d.Heta[0];
     const unsigned vec_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
-    __amdgpu_buffer_rsrc_t rs_yp = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Y[0] : d.Y[1], 0, vec_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_yp = XR ? __builtin_amdgcn_make_buffer_rsrc(d.xr_mdx, 0, (unsigned)((size_t)d.n * d.ld * sizeof(double)), 0x00020000)
+                                      : __builtin_amdgcn_make_buffer_rsrc(cur ? d.Y[0] : d.Y[1], 0, vec_bytes, 0x00020000);
+    double* __restrict__ Ypl = cur ? d.Y[0] : d.Y[1];          // XR: the member's own copy of its proposal rows
+    const unsigned xrow0 = XR ? (unsigned)d.row0 : 0u;
     double* __restrict__ Gp = cur ? d.Gr[0] : d.Gr[1];
     double* __restrict__ eGp = cur ? d.eG[0] : d.eG[1];
     const double2 zz = make_double2(0.0, 0.0);
@@ -66,11 +83,12 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
             if (!(nn > 0.0)) nn = 1.0;
             const double2 ypr = ok ? make_double2(x.x / nn, x.y / nn) : zz;
             if (r < rcap) YPs[r * PB + threadIdx.x] = ypr;
-            if (ok) st2_sc1(rs_yp, ((unsigned)row * (unsigned)d.ld + 2 * sub) * 8u, ypr);
+            if (ok) st2_sc1(rs_yp, ((xrow0 + (unsigned)row) * (unsigned)d.ld + 2 * sub) * 8u, ypr);
+            if (XR && ok) st2(Ypl + (int64_t)row * d.ld + 2 * sub, ypr);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my proposal rows are performed before my workgroup arrives
-    if (!pbarrier(sb, 0, d.G, shb, err)) return;
+    if (!pbarrier(sb, 0, GS, shb, err, bid)) return;
     for (int r0 = 0; r0 < R; r0 += RMAX) {
         int s0[RMAX], s1[RMAX];
         double2 acc[RMAX];
@@ -97,7 +115,7 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
                     const bool in = s0[q] + kb + u < s1[q];
                     const int k = in ? s0[q] + kb + u : (s1[q] > s0[q] ? s1[q] - 1 : 0);
                     cv[q][u] = in ? d.cval[k] : 0.0;
-                    const int col = (s1[q] > s0[q]) ? d.colind[k] : lo;
+                    const int col = (s1[q] > s0[q]) ? d.colind[k] : lo + (int)xrow0;
                     x[q][u] = ld2_sc1(rs_yp, ((unsigned)col * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u);
                 }
             }
@@ -120,7 +138,7 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
             if (sub == 0 && rok) { pf += 0.5 * dot; eGp[row] = dot; }
         }
     }
-    if (!psync(sb, 0, d.G, 3, pf, pgg, prd, sh, shb, err, -1, d.ctl->psync_backoff)) return;
+    if (!psync(sb, 0, GS, 3, pf, pgg, prd, sh, shb, err, bid, d.ctl->psync_backoff)) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) {                 // trustregions.m:548-729 (same arithmetic as k_rtr_decide)
         const int f_stop = d.F[0].stop, f_j = d.F[0].j;
         const double fp = pf, ggp = pgg;
@@ -182,6 +200,29 @@ int msdp_launch_tr_tail(msdp_handle h) {
         attr_set[ai] = true;
     }
     hipLaunchKernelGGL(fn, dim3(G), dim3(PB), lds, h->stream, dp, h->psync_slots, h->psync_err, rcap);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// XR: this member's launch of the tail the group runs together (separate processes: msdp_comm_init_ipc).  `dv` = the member's Dev as
+// msdp_xpersist_member filled it (G, xr_gid0, xr_gtot, xr_mdx), slots = the group's shared block (regions 2 / 3).
+int msdp_launch_tr_tail_xr(hipStream_t stream, const Dev& dv, unsigned long long* slots, int* err) {
+    const int lpr = tail_lpr(dv);
+    if (lpr > 32) { msdp_set_error("cross-rank TR tail: not eligible"); return MSDP_ESTATE; }
+    const int rstep = PWAVES * (64 / lpr);
+    int rcap = ((dv.n_loc + dv.G - 1) / dv.G + rstep - 1) / rstep;
+    if (rcap < 1) rcap = 1;
+    const size_t lds = (size_t)rcap * PB * sizeof(double2);
+    if (lds > 128 * 1024) { msdp_set_error("cross-rank TR tail: %d row slots do not fit the LDS", rcap); return MSDP_ESTATE; }
+    typedef void (*fn_t)(Dev, unsigned long long*, int*, int);
+    fn_t fn = lpr == 8 ? k_tr_tail_obl<8, true> : (lpr == 16 ? k_tr_tail_obl<16, true> : k_tr_tail_obl<32, true>);
+    static bool attr_set[3] = {false, false, false};
+    const int ai = lpr == 8 ? 0 : (lpr == 16 ? 1 : 2);
+    if (!attr_set[ai]) {
+        HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set[ai] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(dv.G), dim3(PB), lds, stream, dv, slots, err, rcap);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -26,10 +26,23 @@ def main():
     h.set_point(Y0)
     f0, G0 = h.cost(), h.rgrad()                                   # sharded operators through the staging slabs
     c0 = h.collective_calls()
+    import time
+    t0 = time.perf_counter()
     st = h.rtr(opts)
+    rtr_us_per_hv = (time.perf_counter() - t0) * 1e6 / max(st.hessvecs, 1)
     c1 = h.collective_calls()
     path = h.tcg_path()
     Yall = h.get_point_all()
+    # the same call with the rest of every TR iteration on the sharded kernels and their collectives (option xtail = 0)
+    h.set_option("xtail", 0)
+    h.set_point(Y0)
+    cc0 = h.collective_calls()
+    t0 = time.perf_counter()
+    stc = h.rtr(opts)
+    rtr_us_per_hv_coll = (time.perf_counter() - t0) * 1e6 / max(stc.hessvecs, 1)
+    calls_coll = h.collective_calls() - cc0
+    Ycoll = h.get_point_all()
+    h.set_option("xtail", 1)
     h.set_point(Y0)
     c2 = h.collective_calls()
     st7 = h.rtr(short)
@@ -47,7 +60,8 @@ def main():
     r0, r1 = h.local_rows()
     np.savez(out, path=path, stats=np.array([st.hessvecs, st.accepted, st.rejected, st.iters, st.last_stop_inner]), cost=st.cost, Y=Yall,
              calls=c1 - c0, iters=st.iters, calls7=c3 - c2, iters7=st7.iters, hv7=st7.hessvecs, trip_us=trip_us, f0=f0, G0=G0, rows=np.array([r0, r1]),
-             err=np.array(err))
+             err=np.array(err), rtr_us_per_hv=rtr_us_per_hv, rtr_us_per_hv_coll=rtr_us_per_hv_coll, calls_coll=calls_coll, Ycoll=Ycoll,
+             stats_coll=np.array([stc.hessvecs, stc.accepted, stc.rejected, stc.iters, stc.last_stop_inner]))
     # (no h.close(): the group is broken after the provoked time-out; the process ends here)
 
 

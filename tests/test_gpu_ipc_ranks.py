@@ -70,11 +70,17 @@ def _check(res, ref):
         assert abs(float(q["cost"]) - st.cost) <= 1e-10 * abs(st.cost)
         assert rel(q["Y"], Y1) < 1e-8
         assert np.array_equal(q["Y"], res[0]["Y"])                 # every member ends with the same bits
-        # zero collectives per trip: the same number per TR iteration whether a tCG makes 7 trips or 60
+        # zero collectives per trip AND per TR iteration (cross-rank TR tail): a trustregions() call issues the set-up exchanges only,
+        # whether its tCGs make 7 trips or 60 and however many iterations it runs; with xtail = 0 the iterations pay their collectives
+        # and reach the same point
         assert int(q["hv7"]) < st.hessvecs
-        assert abs(int(q["calls"]) / max(int(q["iters"]), 1) - int(q["calls7"]) / max(int(q["iters7"]), 1)) < 1.0 + 6.0 / max(int(q["iters7"]), 1)
+        assert int(q["calls"]) <= 6 and int(q["calls"]) == int(q["calls7"]), (int(q["calls"]), int(q["calls7"]))
+        assert int(q["calls_coll"]) >= 3 * int(q["iters"])
+        assert tuple(int(v) for v in q["stats_coll"]) == tuple(int(v) for v in q["stats"])
+        assert rel(q["Ycoll"], q["Y"]) < 1e-9
         assert "timed out" in str(q["err"]) or "did not reach" in str(q["err"]) or "group broken" in str(q["err"]), str(q["err"])
-    print("process ranks: trip %.2f us" % max(float(q["trip_us"]) for q in res))
+    print("process ranks: trip %.2f us; trustregions() %.2f us per Hess-vec with the cross-rank tail, %.2f with per-iteration collectives"
+          % (max(float(q["trip_us"]) for q in res), max(float(q["rtr_us_per_hv"]) for q in res), max(float(q["rtr_us_per_hv_coll"]) for q in res)))
 
 
 @pytest.mark.parametrize("N,shape,p", [(2, (200, 200), 32), (2, (61, 50), 12), (4, (200, 200), 16)])
