@@ -238,7 +238,67 @@ def cross_rank_trip(_lib, problems, N=2, p=32):
             "trip_us_cross_rank_persistent": max(q[0] for q in a), "tcg_path": a[0][1], "collective_calls_per_768_trips": a[0][2],
             "trip_us_lockstep_chunks": max(q[0] for q in b), "collective_calls_per_768_trips_lockstep": b[0][2],
             "trip_us_one_unsharded_handle": one,
-            "note": "the members' workgroups (2 x 128) run in ONE launch; on N GPUs the same protocol needs peer-mapped fine-grained memory over xGMI (not built)"}
+            "note": "in-process ranks: the members' workgroups (2 x 128) run in ONE launch; members in different processes / on different GPUs: process_rank_trip"}
+
+
+def process_rank_worker(argv):
+    """bench.py --ipc-worker rank N name p out.json: one member of a group of PROCESSES sharing the GPU (msdp_comm_init_ipc)."""
+    rank, N, name, p, out = int(argv[0]), int(argv[1]), argv[2], int(argv[3]), argv[4]
+    from manisdp_matlab_amd import _lib, problems
+    _lib.load()
+    C = problems.toroidal_grid_maxcut(100 * N, 200, seed=81)
+    n = C.shape[0]
+    rng = np.random.default_rng(0)
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+    h = _lib.Handle.onlyunitdiag(C, pcap=p)
+    h.comm_init_ipc(N, rank, name)
+    h.set_point(Y)
+    trip = min(h.bench_tcg_trip(256) for _ in range(3)) * 1e3
+    opts = _lib.default_opts(maxiter=40, maxinner=100, tolgradnorm=1e-8)
+    res = {}
+    for xtail in (1, 0):
+        h.set_option("xtail", xtail)
+        best, hv, calls = 1e9, 0, 0
+        for _ in range(3):
+            h.set_point(Y)
+            c0 = h.collective_calls()
+            t0 = time.perf_counter(); st = h.rtr(opts); dt = time.perf_counter() - t0
+            best, hv, calls = min(best, dt), st.hessvecs, h.collective_calls() - c0
+        res[xtail] = (best, hv, calls, st.iters)
+    json.dump({"trip_us": trip, "tcg_path": h.tcg_path(), "rtr_seconds": res[1][0], "hessvecs": res[1][1], "collective_calls_per_rtr_call": res[1][2],
+               "iters": res[1][3], "rtr_seconds_with_per_iteration_collectives": res[0][0], "collective_calls_with_them": res[0][2]}, open(out, "w"))
+    h.close()
+
+
+def process_rank_trip(N=2, p=32):
+    """N PROCESSES on ONE GPU (msdp_comm_init_ipc), 20 000 rows each: the group's slot regions and exchange buffer live in one
+    fine-grained device block exported / mapped through HIP IPC (the mapping goes over peer access when the ranks own different
+    devices: the same code path), every process launches its own workgroups of the cross-rank persistent tCG and of the cross-rank TR
+    tail -- a trustregions() call issues no collective per trip and none per iteration."""
+    import subprocess, tempfile
+    name = "/msdp_bench_%d" % os.getpid()
+    tmp = tempfile.mkdtemp()
+    procs = []
+    for r in range(N):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--ipc-worker", str(r), str(N), name, str(p), os.path.join(tmp, "r%d.json" % r)],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+    errs = []
+    for pr in procs:
+        try:
+            _, e = pr.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            pr.kill(); _, e = pr.communicate()
+        errs.append(e)
+    if any(pr.returncode != 0 for pr in procs):
+        raise RuntimeError("a member failed: " + " | ".join(e[-300:] for e in errs if e))
+    res = [json.load(open(os.path.join(tmp, "r%d.json" % r))) for r in range(N)]
+    hv, sec, sec_c = res[0]["hessvecs"], max(q["rtr_seconds"] for q in res), max(q["rtr_seconds_with_per_iteration_collectives"] for q in res)
+    return {"workload": "toroidal grid MaxCut, %d process ranks x 20000 rows on one GPU (HIP IPC), p = %d" % (N, p), "ranks": N, "p": p,
+            "trip_us_cross_rank_persistent": max(q["trip_us"] for q in res), "tcg_path": res[0]["tcg_path"],
+            "trustregions_us_per_hessvec": sec * 1e6 / hv, "hessvec_per_s": hv / sec, "hessvecs": hv, "tr_iterations": res[0]["iters"],
+            "collective_calls_per_trustregions_call": res[0]["collective_calls_per_rtr_call"],
+            "trustregions_us_per_hessvec_with_per_iteration_collectives": sec_c * 1e6 / hv,
+            "collective_calls_with_per_iteration_collectives": res[0]["collective_calls_with_them"]}
 
 
 def main():
@@ -595,6 +655,10 @@ def main():
             out["cross_rank_trip"] = cross_rank_trip(_lib, problems)
         except Exception as e:  # noqa: BLE001 -- secondary figure
             out["cross_rank_trip"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            out["process_rank_trip"] = process_rank_trip()
+        except Exception as e:  # noqa: BLE001 -- secondary figure
+            out["process_rank_trip"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if N > 1 or args.force_comm:
         # BASELINE config 5 next to the headline metric: synthetic dense C generated per shard on the device
         # (12 500 rows per GPU, n = 12 500 * N, so N = 8 is exactly n = 100 000), p = 64, RCCL all-gather of the
@@ -713,4 +777,7 @@ def k5_dense_sharded(_lib, join, sync, allmax, N, rank, rows_per_gpu=12500, p=64
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--ipc-worker":
+        process_rank_worker(sys.argv[2:])
+    else:
+        main()

@@ -44,6 +44,7 @@ int msdp_affine_setup_blocked(msdp_handle h, int nb, const int64_t* block_n, con
 int msdp_affine_get_block(msdp_handle h, int64_t row0, int64_t nbk, double* S);
 void msdp_densesym_release(msdp_handle h);                  // msdp_densesym.hip
 void msdp_window_release(msdp_handle h);                    // msdp_window.hip
+void msdp_block_eigs_release(msdp_handle h);                // msdp_blockjacobi.hip
 int msdp_window_eligible(msdp_handle h);
 int msdp_escape_impl(msdp_handle h, int k, double tol, int maxit, double* lam, double* V, double* lmax, int* iters,
                      const double* Mdev);
@@ -730,6 +731,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     msdp_affine_release(h);
     msdp_densesym_release(h);
     msdp_window_release(h);
+    msdp_block_eigs_release(h);
     halo_release(h);
     local_leave(h);
     if (h->lc_tmp) (void)hipFree(h->lc_tmp);
@@ -1199,12 +1201,18 @@ int msdp_xpersist_reset(hipStream_t stream, unsigned long long* slots, int* err)
 // The shared block of the group: allocated by member 0 the first time (and again when the factor outgrows the exchange buffer)
 static int xr_ensure_shared(msdp_handle h) {
     LocalGroup* g = h->lgroup;
-    const size_t need = (size_t)rows_capacity(h) * h->nranks * (size_t)std::max(h->ldcap, 64);
+    size_t need = (size_t)rows_capacity(h) * h->nranks * (size_t)std::max(h->ldcap, 64);
     if (g->ipc) {                                            // the arena was cut at msdp_comm_init_ipc
         if (g->xr_mdx_doubles < need) { msdp_set_error("cross-rank persistent tCG: the factor outgrew the arena of this communicator (ld %d)", h->ldcap); return MSDP_ENOMEM; }
         return 0;
     }
-    LOCAL_BARRIER(g);
+    // the members agree on the LARGEST need (member 0's alone decided, a member with a wider factor failed)
+    {
+        int m = 0;
+        int rcv = local_vote_min(h, -(int)((need + 1023) / 1024), &m);
+        if (rcv) return rcv;
+        need = (size_t)(-m) * 1024;
+    }
     int rc = 0;
     if (h->rank == 0 && (!g->xr_slots || g->xr_mdx_doubles < need)) {
         if (!g->xr_slots) {

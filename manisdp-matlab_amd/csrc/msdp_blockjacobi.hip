@@ -377,13 +377,13 @@ __global__ __launch_bounds__(JAC_THREADS) void k_block_tridiag(TriArgs ta) {
     if (tid == 0) a.sweeps[b] = 0;
 }
 
-template <typename T>
-static int jac_up(const std::vector<T>& v, T** out, hipStream_t s) {
-    if (hipMalloc((void**)out, v.size() * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("block_eigs: device allocation failed"); return MSDP_ENOMEM; }
-    HIPCHK(hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
-    return 0;
+// Workspace of msdp_block_eigs, kept on the handle (ten hipMalloc / hipFree pairs per outer iteration, each hipFree a
+// device synchronisation; an upload that failed half-way leaked the earlier allocations): one block, grown when a call needs more,
+// released with the handle.
+void msdp_block_eigs_release(msdp_handle h) {
+    if (h->blk_ws) (void)hipFree(h->blk_ws);
+    h->blk_ws = nullptr; h->blk_ws_cap = 0;
 }
-
 extern "C" int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, const int64_t* nblk, int32_t k, int32_t method, double* w, double* V) {
     if (!h) { msdp_set_error("null handle"); return MSDP_EINVAL; }
     if (nb < 1 || !row0 || !nblk || !w || (k > 0 && !V) || k < 0 || k > 64 || method < 0 || method > 2) { msdp_set_error("block_eigs: bad argument"); return MSDP_EINVAL; }
@@ -408,22 +408,30 @@ extern "C" int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, c
     const int kk = k > 0 ? k : 1;
     JacArgs a;
     a.nb = nb; a.k = kk; a.S = h->d.Sdual;
-    int64_t *d_soff = nullptr, *d_sld = nullptr, *d_woff = nullptr, *d_r0 = nullptr;
-    int* d_n = nullptr; int* d_sw = nullptr;
-    double *d_A = nullptr, *d_V = nullptr, *d_w = nullptr, *d_vec = nullptr, *d_ws = nullptr;
-    int rc = 0;
-    auto cleanup = [&]() {
-        void* ps[] = {d_soff, d_sld, d_woff, d_r0, d_n, d_sw, d_A, d_V, d_w, d_vec, d_ws};
-        for (void* p : ps) if (p) (void)hipFree(p);
-    };
-    if ((rc = jac_up(soff, &d_soff, h->stream)) || (rc = jac_up(sld, &d_sld, h->stream)) || (rc = jac_up(woff, &d_woff, h->stream)) ||
-        (rc = jac_up(r0, &d_r0, h->stream)) || (rc = jac_up(nn, &d_n, h->stream))) { cleanup(); return rc; }
-    if (hipMalloc((void**)&d_A, tot * sizeof(double)) != hipSuccess || (!tri && hipMalloc((void**)&d_V, tot * sizeof(double)) != hipSuccess) ||
-        (tri && hipMalloc((void**)&d_ws, (size_t)nb * 5 * 8 * JAC_MAXN * sizeof(double)) != hipSuccess) ||
-        hipMalloc((void**)&d_w, rows * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_vec, rows * kk * sizeof(double)) != hipSuccess ||
-        hipMalloc((void**)&d_sw, nb * sizeof(int)) != hipSuccess) {
-        (void)hipGetLastError(); cleanup(); msdp_set_error("block_eigs: device allocation failed"); return MSDP_ENOMEM;
+    // one workspace, carved into 256-byte aligned pieces
+    size_t need = 0;
+    auto piece = [&](size_t bytes) { const size_t o = need; need += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_soff = piece(nb * sizeof(int64_t)), o_sld = piece(nb * sizeof(int64_t)), o_woff = piece(nb * sizeof(int64_t)), o_r0 = piece(nb * sizeof(int64_t));
+    const size_t o_n = piece(nb * sizeof(int)), o_sw = piece(nb * sizeof(int));
+    const size_t o_A = piece((size_t)tot * sizeof(double)), o_V = tri ? 0 : piece((size_t)tot * sizeof(double));
+    const size_t o_ws = tri ? piece((size_t)nb * 5 * 8 * JAC_MAXN * sizeof(double)) : 0;
+    const size_t o_w = piece((size_t)rows * sizeof(double)), o_vec = piece((size_t)rows * kk * sizeof(double));
+    if (h->blk_ws_cap < need) {
+        msdp_block_eigs_release(h);
+        if (hipMalloc(&h->blk_ws, need) != hipSuccess) { (void)hipGetLastError(); h->blk_ws = nullptr; msdp_set_error("block_eigs: device allocation of %zu bytes failed", need); return MSDP_ENOMEM; }
+        h->blk_ws_cap = need;
     }
+    char* base = (char*)h->blk_ws;
+    int64_t *d_soff = (int64_t*)(base + o_soff), *d_sld = (int64_t*)(base + o_sld), *d_woff = (int64_t*)(base + o_woff), *d_r0 = (int64_t*)(base + o_r0);
+    int* d_n = (int*)(base + o_n); int* d_sw = (int*)(base + o_sw);
+    double *d_A = (double*)(base + o_A), *d_V = tri ? nullptr : (double*)(base + o_V), *d_w = (double*)(base + o_w), *d_vec = (double*)(base + o_vec);
+    double* d_ws = tri ? (double*)(base + o_ws) : nullptr;
+    HIPCHK(hipMemcpyAsync(d_soff, soff.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_sld, sld.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_woff, woff.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_r0, r0.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_n, nn.data(), nb * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));                 // (the index vectors are locals of this call)
     a.soff = d_soff; a.sld = d_sld; a.n = d_n; a.woff = d_woff; a.r0 = d_r0; a.A = d_A; a.V = d_V; a.w = d_w; a.vec = d_vec; a.sweeps = d_sw;
     if (tri) {
         TriArgs ta; ta.j = a; ta.ws = d_ws;
@@ -435,7 +443,6 @@ extern "C" int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, c
     if (e == hipSuccess && k > 0) e = hipMemcpyAsync(V, d_vec, rows * k * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(sw.data(), d_sw, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    cleanup();
     if (e != hipSuccess) { msdp_set_error("block_eigs: %s", hipGetErrorString(e)); return MSDP_EHIP; }
     for (int b = 0; b < nb; ++b)
         if (sw[b] < 0) { msdp_set_error("block_eigs: Jacobi iteration of block %d did not converge in %d sweeps", b, JAC_MAXSWEEP); return MSDP_ESTATE; }

@@ -230,6 +230,7 @@ struct msdp_handle_s {
     struct Halo* halo = nullptr;
     struct LocalGroup* lgroup = nullptr;   // in-process stand-in for the RCCL communicator (msdp_comm_init_local)
     struct WinCache* win = nullptr;        // patch plans of the LDS-staged S*U (msdp_window.hip), one per lanes-per-row
+    void* blk_ws = nullptr; size_t blk_ws_cap = 0;   // workspace of msdp_block_eigs (msdp_blockjacobi.hip)
     double* lc_tmp = nullptr; size_t lc_tmp_cap = 0;   // its reduction scratch
     // row-sharded onlyunitdiag (sparse C): the escape runs replicated on full copies of C's CSR arrays and of z
     int* esc_rp = nullptr; int* esc_ci = nullptr; double* esc_cv = nullptr; double* esc_z = nullptr;

@@ -31,9 +31,14 @@ struct WinCacheEntry { int lpr = 0; int ld_max = 0; WinPlan plan{}; std::vector<
 struct WinCache { WinCacheEntry e[4]; };
 
 // H = proj-fused (C*md - Y.*rowdot(Y, C*md) - md.*eG) with the rows of md the patch touches staged in LDS; partial <md, Hmd>.
-template <int LPR>
+// Software pipeline over the patches of a workgroup: the window of the NEXT patch is requested into registers (NW row loads per
+// lane group, all in flight) before the products of the current patch are formed from LDS buffer `cur`, and goes into the other
+// buffer behind them -- the first version (load, barrier, compute, barrier, one row per trip of either loop) spent 35 us per patch
+// in chains of dependent round trips: 306 us at n = 10^6, p = 32 against 208 us for the direct gathers.
+#define WIN_NW 5                                               // window rows per lane group: wmax <= WIN_NW * MSDP_WAVES * 64 / LPR
+template <int LPR, int EWC>                                   // EWC: the stored ELL width (5 or 8)
 __global__ __launch_bounds__(MSDP_BLOCK) void k_hess_win_obl(Dev d, WinPlan w) {
-    extern __shared__ double2 win[];                       // [wmax][LPR]
+    extern __shared__ double2 win[];                       // 2 x [wmax][LPR]
     __shared__ double sh[3 * MSDP_WAVES];
     if (!d.F[0].active) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -41,6 +46,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_hess_win_obl(Dev d, WinPlan w) {
     constexpr int RSTEP = MSDP_WAVES * RPW;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
     const bool colok = 2 * sub < d.ld;
+    const int csub = colok ? 2 * sub : 0;
     const int cur = d.ctl->cur;
     const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
     const double* __restrict__ eG = cur ? d.eG[1] : d.eG[0];
@@ -52,52 +58,82 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_hess_win_obl(Dev d, WinPlan w) {
     // workgroups take consecutive patches and advance together
     const int X = blockIdx.x & 7, s = blockIdx.x >> 3, S = (int)gridDim.x >> 3;
     const int p0 = (int)((int64_t)w.npatch * X / 8), p1 = (int)((int64_t)w.npatch * (X + 1) / 8);
-    for (int p = p0 + s; p < p1; p += S) {
-        const int w0 = w.poff[p], W = w.poff[p + 1] - w0, nown = w.pown[p], o0 = w.ooff[p];
-        for (int i = wave * RPW + rsub; i < W; i += RSTEP) {
-            const int row = w.wrows[w0 + i];
-            win[i * LPR + sub] = colok ? ld2(Uf + (int64_t)row * d.ld + 2 * sub) : zz;
-        }
-        __syncthreads();
-        for (int i0 = wave * RPW; i0 < nown; i0 += RSTEP) {
-            const int i = i0 + rsub;
-            const bool rok = i < nown;
-            const int ic = rok ? i : 0;
-            const int row = w.wrows[w0 + ic] - d.row0;     // local row
-            int c[MSDP_ELL_MAXW];
-            double v[MSDP_ELL_MAXW];
+    const int slot0 = wave * RPW + rsub;
+    // (plain locals for what the lambdas below touch: a by-reference capture of a kernel-argument struct puts the struct into scratch)
+    const int* __restrict__ poff = w.poff; const int* __restrict__ wrows = w.wrows;
+    const int ld = d.ld, wmax = w.wmax;
+    double2 nx[WIN_NW];
+    // the rows of patch P this lane group stages: requested by GET_WINDOW, stored by PUT_WINDOW (macros, not lambdas: an array that
+    // two lambdas capture by reference stays in scratch memory)
+#define GET_WINDOW(P) do { \
+        const int w0_ = poff[P], W_ = poff[(P) + 1] - w0_; \
+        int rows_[WIN_NW]; \
+        _Pragma("unroll") for (int q = 0; q < WIN_NW; ++q) { const int i_ = slot0 + q * RSTEP; rows_[q] = wrows[w0_ + (i_ < W_ ? i_ : 0)]; } \
+        _Pragma("unroll") for (int q = 0; q < WIN_NW; ++q) nx[q] = ld2(Uf + (int64_t)rows_[q] * ld + csub); \
+    } while (0)
+#define PUT_WINDOW(BUF) do { \
+        double2* dst_ = win + (size_t)(BUF) * wmax * LPR; \
+        _Pragma("unroll") for (int q = 0; q < WIN_NW; ++q) { const int i_ = slot0 + q * RSTEP; double2 t_ = nx[q]; if (!colok) { t_.x = 0.0; t_.y = 0.0; } if (i_ < wmax) dst_[i_ * LPR + sub] = t_; } \
+    } while (0)
+    int p = p0 + s, buf = 0;
+    if (p < p1) { GET_WINDOW(p); PUT_WINDOW(0); }
+    __syncthreads();
+    for (; p < p1; p += S) {
+        const int pn = p + S;
+        if (pn < p1) GET_WINDOW(pn);                           // in flight during the products of patch p
+        const double2* wb = win + (size_t)buf * w.wmax * LPR;
+        const int w0 = w.poff[p], nown = w.pown[p], o0 = w.ooff[p];
+        constexpr int UN = 2;
+        for (int i0 = wave * RPW; i0 < nown; i0 += UN * RSTEP) {
+            int ic[UN], row[UN];
+            bool rok[UN];
+            int c[UN][EWC];
+            double v[UN][EWC];
+            double2 y[UN];
+            double eg[UN];
 #pragma unroll
-            for (int k = 0; k < MSDP_ELL_MAXW; ++k) {
-                const bool ok = k < w.EW;
-                c[k] = ok ? w.lidx[(int64_t)k * w.own_total + o0 + ic] : ic;
-                v[k] = ok ? w.lval[(int64_t)k * w.own_total + o0 + ic] : 0.0;
-            }
-            const double2 y = colok ? ld2_nt(Yl + (int64_t)row * d.ld + 2 * sub) : zz;
-            const double eg = eG[row];
-            double2 acc = zz;
+            for (int u = 0; u < UN; ++u) {
+                const int i = i0 + u * RSTEP + rsub;
+                rok[u] = i < nown;
+                ic[u] = rok[u] ? i : 0;
+                row[u] = w.wrows[w0 + ic[u]] - d.row0;     // local row
 #pragma unroll
-            for (int k = 0; k < MSDP_ELL_MAXW; ++k) {
-                if (k < w.EW) {
-                    const double2 x = win[c[k] * LPR + sub];
-                    acc.x = fma(v[k], x.x, acc.x);
-                    acc.y = fma(v[k], x.y, acc.y);
+                for (int k = 0; k < EWC; ++k) {
+                    c[u][k] = w.lidx[(int64_t)k * w.own_total + o0 + ic[u]];
+                    v[u][k] = w.lval[(int64_t)k * w.own_total + o0 + ic[u]];
                 }
             }
-            if (!colok) acc = zz;
-            const double2 u = win[ic * LPR + sub];
-            const double dot = msdp_group_sum<LPR>(acc.x * y.x + acc.y * y.y);
-            if (rok && colok) {
-                double2 hq;
-                hq.x = acc.x - y.x * dot - u.x * eg;
-                hq.y = acc.y - y.y * dot - u.y * eg;
-                st2_nt(H + (int64_t)row * d.ld + 2 * sub, hq);
-                pd += u.x * hq.x + u.y * hq.y;
+#pragma unroll
+            for (int u = 0; u < UN; ++u) { y[u] = ld2_nt(Yl + (int64_t)row[u] * d.ld + csub); eg[u] = eG[row[u]]; }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                double2 acc = zz;
+#pragma unroll
+                for (int k = 0; k < EWC; ++k) {
+                    const double2 x = wb[c[u][k] * LPR + sub];
+                    acc.x = fma(v[u][k], x.x, acc.x);
+                    acc.y = fma(v[u][k], x.y, acc.y);
+                }
+                if (!colok) { acc = zz; y[u] = zz; }
+                const double2 uu = wb[ic[u] * LPR + sub];
+                const double dot = msdp_group_sum<LPR>(acc.x * y[u].x + acc.y * y[u].y);
+                if (rok[u] && colok) {
+                    double2 hq;
+                    hq.x = acc.x - y[u].x * dot - uu.x * eg[u];
+                    hq.y = acc.y - y[u].y * dot - uu.y * eg[u];
+                    st2_nt(H + (int64_t)row[u] * d.ld + 2 * sub, hq);
+                    pd += uu.x * hq.x + uu.y * hq.y;
+                }
             }
         }
-        __syncthreads();                                   // the window is free for the next patch
+        if (pn < p1) PUT_WINDOW(buf ^ 1);                      // (nobody reads that buffer: its patch was finished one barrier ago)
+        __syncthreads();
+        buf ^= 1;
     }
     msdp_put_partial(d.P, P_DHD, pd, sh);
 }
+#undef GET_WINDOW
+#undef PUT_WINDOW
 
 // ------------------------------------------------------------------ host: patches
 // Breadth-first patches of at most B rows over the LOCAL rows (h_rowptr / h_colind hold ALL rows of C with global numbers; columns
@@ -161,7 +197,7 @@ static int win_upload(WinCacheEntry& e, const std::vector<T>& v, const T** out) 
     return 0;
 }
 
-static const size_t WIN_LDS_BYTES = 144 * 1024;            // one 1024-thread workgroup per CU: the window may take most of the 160 KB
+static const size_t WIN_LDS_BYTES = 144 * 1024;            // one 1024-thread workgroup per CU: the two window buffers may take most of the 160 KB
 
 static int win_get_plan(msdp_handle h, int lpr, WinCacheEntry** out) {
     if (!h->win) h->win = new WinCache();
@@ -172,7 +208,9 @@ static int win_get_plan(msdp_handle h, int lpr, WinCacheEntry** out) {
     *out = e;
     if (e->lpr == lpr) return e->failed ? MSDP_EUNSUPPORTED : 0;
     e->lpr = lpr;
-    const int wmax = (int)(std::min(WIN_LDS_BYTES, (size_t)h->tune.window_lds * 1024) / ((size_t)lpr * sizeof(double2)));
+    // two buffers of wmax rows; a lane group stages at most WIN_NW rows of a window
+    int wmax = (int)(std::min(WIN_LDS_BYTES, (size_t)h->tune.window_lds * 1024) / 2 / ((size_t)lpr * sizeof(double2)));
+    wmax = std::min(wmax, WIN_NW * MSDP_WAVES * (64 / lpr));
     // target patch size: on a 2-D grid the halo of a breadth-first patch of B rows is ~ 2.5 sqrt(B) + a few rows
     const int B = std::max(32, (int)(wmax * 0.78) / 16 * 16);
     std::vector<std::vector<int>> own, halo;
@@ -244,20 +282,15 @@ int msdp_window_hess(msdp_handle h) {
     WinCacheEntry* e = nullptr;
     int rc = win_get_plan(h, lpr, &e);
     if (rc) return rc;
-    const size_t lds = (size_t)e->plan.wmax * lpr * sizeof(double2);
+    const size_t lds = (size_t)2 * e->plan.wmax * lpr * sizeof(double2);
     dim3 grid(d.G), block(MSDP_BLOCK);
-    static bool attr_set = false;                          // (not a stream operation: once per process, outside any graph capture)
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_hess_win_obl<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIN_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_hess_win_obl<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIN_LDS_BYTES));
-        HIPCHK(hipFuncSetAttribute((const void*)k_hess_win_obl<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIN_LDS_BYTES));
-        attr_set = true;
-    }
-    switch (lpr) {
-        case 8: hipLaunchKernelGGL(k_hess_win_obl<8>, grid, block, lds, h->stream, d, e->plan); break;
-        case 16: hipLaunchKernelGGL(k_hess_win_obl<16>, grid, block, lds, h->stream, d, e->plan); break;
-        default: hipLaunchKernelGGL(k_hess_win_obl<32>, grid, block, lds, h->stream, d, e->plan); break;
-    }
+    typedef void (*fn_t)(Dev, WinPlan);
+    const bool e5 = e->plan.EW == 5;
+    fn_t fn = lpr == 8 ? (e5 ? k_hess_win_obl<8, 5> : k_hess_win_obl<8, 8>) : (lpr == 16 ? (e5 ? k_hess_win_obl<16, 5> : k_hess_win_obl<16, 8>) : (e5 ? k_hess_win_obl<32, 5> : k_hess_win_obl<32, 8>));
+    static bool attr_set[6] = {false, false, false, false, false, false};      // (not a stream operation: once per process and kernel, outside any graph capture)
+    const int ai = (lpr == 8 ? 0 : (lpr == 16 ? 1 : 2)) * 2 + (e5 ? 0 : 1);
+    if (!attr_set[ai]) { HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIN_LDS_BYTES)); attr_set[ai] = true; }
+    hipLaunchKernelGGL(fn, grid, block, lds, h->stream, d, e->plan);
     HIPCHK(hipGetLastError());
     return 0;
 }
