@@ -1111,6 +1111,7 @@ struct LocalGroup {
     char* stage = nullptr;         // arena + slots + exchange buffer: n slabs of stage_bytes
     size_t stage_bytes = 0;
     int my_rank = 0;
+    int ipc_ew = 0;                // the ELL width the members agreed on for the running call (0: CSR form)
     int n = 0;
     std::mutex m;
     std::condition_variable cv;
@@ -1242,6 +1243,18 @@ static int xr_begin(msdp_handle h, bool* use) {
     if (rc) return rc;
     if (!h->xr_ev) HIPCHK(hipEventCreateWithFlags(&h->xr_ev, hipEventDisableTiming));
     *use = true;
+    if (g->ipc) {
+        // the plan of the call: lanes per row and row slots must agree, a differing ELL width sends everybody to the CSR form
+        Dev dv; int pl[3];
+        if ((rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_mdx, &dv, pl))) { local_break(g); return rc; }
+        for (int q = 0; q < 3; ++q) g->shm->plan[h->rank][q] = pl[q];
+        LOCAL_BARRIER(g);
+        g->ipc_ew = pl[1];
+        for (int r = 0; r < g->n; ++r) {
+            if (g->shm->plan[r][0] != pl[0] || g->shm->plan[r][2] != pl[2]) { msdp_set_error("cross-rank persistent tCG: the members' plans differ"); local_break(g); return MSDP_ESTATE; }
+            if (g->shm->plan[r][1] != pl[1]) g->ipc_ew = 0;
+        }
+    }
     if (h->rank == 0) {
         if ((rc = msdp_xpersist_reset(h->stream, g->xr_slots, g->xr_err))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1257,17 +1270,13 @@ static int xr_launch(msdp_handle h) {
     int rc;
     if (g->ipc) {
         // members in different processes: every member launches ITS workgroups itself (separate processes have separate hardware
-        // queues; the launches meet in the first grid synchronisation, a bounded spin turns a member that never comes into MSDP_ECOMM)
+        // queues; the launches meet in the first grid synchronisation, a bounded spin turns a member that never comes into MSDP_ECOMM).
+        // The members agreed on the plan in xr_begin: no host exchange per launch.
         Dev dv; int pl[3];
         if ((rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_mdx, &dv, pl))) { local_break(g); return rc; }
-        for (int q = 0; q < 3; ++q) g->shm->plan[h->rank][q] = pl[q];
-        LOCAL_BARRIER(g);
-        for (int r = 1; r < g->n; ++r)
-            if (g->shm->plan[r][0] != g->shm->plan[0][0] || g->shm->plan[r][2] != g->shm->plan[0][2]) { msdp_set_error("cross-rank persistent tCG: the members' plans differ"); return MSDP_ESTATE; }
-        for (int r = 0; r < g->n; ++r) if (g->shm->plan[r][1] != pl[1]) pl[1] = 0;      // different ELL widths: everybody walks its CSR rows
+        pl[1] = g->ipc_ew;
         if (h->tune.fail_xr) { h->tune.fail_xr = 0; dv.xr_gtot += 8; }
         if ((rc = msdp_launch_tcg_xpersist_one(h->stream, dv, pl, g->xr_slots, g->xr_err))) { local_break(g); return rc; }
-        LOCAL_BARRIER(g);                                    // nobody overwrites its plan before everyone has read it
         return 0;
     }
     {
