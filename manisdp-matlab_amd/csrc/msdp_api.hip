@@ -1018,6 +1018,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "window")) { t.window = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
     else if (!strcmp(name, "window_lds")) { t.window_lds = value < 16 ? 16 : (value > 144 ? 144 : value); h->chunk_len = 0; msdp_window_release(h); }
     else if (!strcmp(name, "persist_early")) t.persist_early = value > 0 ? value : 0;
+    else if (!strcmp(name, "persist_goff")) t.persist_goff = value ? 1 : 0;
     else if (!strcmp(name, "psync_backoff")) t.psync_backoff = value > 0 ? value : 0;
     else if (!strcmp(name, "affine_overlap")) { t.affine_overlap = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "trip1")) { t.trip1 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
@@ -1845,6 +1846,7 @@ static void fill_ctl(msdp_handle h, const msdp_rtr_opts* o) {
     c->rho_prime = o->rho_prime; c->rho_reg = o->rho_regularization;
     c->persist_refresh = h->tune.persist_refresh;
     c->persist_early = h->tune.persist_early;
+    c->persist_goff = h->tune.persist_goff;
     c->psync_backoff = h->tune.psync_backoff;
     // trustregions.m:363-372; typicaldist: pi*sqrt(n) (ManiSDP_onlyunitdiag.m:137) or pi (spherefactory.m:111)
     // ... or sqrt(n*p) (euclideanfactory.m:57)

@@ -225,6 +225,17 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     int xq = 0;                      // EARLY: the half the next publication goes to
     int pend = -1;                   // EARLY: the half to put back to the sentinel behind the next reduction 1 (-1: none)
     if (EARLY) { reset_half(0); reset_half(1); }                   // (whatever an earlier launch left; the first look at them is behind reduction 1 of trip 1)
+    // byte offsets of the R x EW gathers of a trip (the same in the gradient buffer and in the exchange buffer: both have row stride ld)
+    constexpr bool GOFF = ALLG && !EARLY && R * EW <= 15;        // (more row slots: the extra registers spill)
+    const bool use_goff = GOFF && c->persist_goff != 0;
+    unsigned goff[GOFF ? R : 1][GOFF ? EW : 1];
+    if (GOFF) {
+#pragma unroll
+        for (int r = 0; r < (GOFF ? R : 0); ++r)
+#pragma unroll
+            for (int w = 0; w < (GOFF ? EW : 0); ++w)
+                goff[GOFF ? r : 0][GOFF ? w : 0] = ((unsigned)cs[w * ROWS + SLOT(r)] * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u;
+    }
     bool failed = false;
     bool first_tr = true;
   for (;;) {   // ---- trust-region iterations (exactly one pass when !FUSE)
@@ -334,8 +345,12 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             for (int r = 0; r < (ALLGT ? R : 0); ++r)
 #pragma unroll
                 for (int w = 0; w < (ALLGT ? EW : 0); ++w) {
-                    const int cidx = cs[w * ROWS + SLOT(r)];
-                    X[ALLGT ? r : 0][ALLGT ? w : 0] = ld2_sc1(rs, ((unsigned)cidx * gld + gcol) * 8u);
+                    // (round 5, option persist_goff: the byte offset of every gather kept in a register from kernel start instead of an
+                    // LDS read + a quarter-rate 32-bit multiply + an add per gather and trip)
+                    unsigned off;
+                    if (GOFF && use_goff) off = goff[GOFF ? r : 0][GOFF ? w : 0];
+                    else { const int cidx = cs[w * ROWS + SLOT(r)]; off = ((unsigned)cidx * gld + gcol) * 8u; }
+                    X[ALLGT ? r : 0][ALLGT ? w : 0] = ld2_sc1(rs, off);
                 }
         }
         auto hrow = [&](int r) {

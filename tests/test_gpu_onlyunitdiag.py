@@ -484,6 +484,8 @@ def test_lds_staged_hessvec_matches_the_direct_gathers(lib, shape, p):
                 h.set_option("window", 2)
                 h.set_point(Y)
                 r0, r1 = h.local_rows()
-                h.debug_set_full_rows(U)
+                h.debug_set_full_rows(Y)                           # stands in for the all-gather of the point ...
+                h.rgrad()
+                h.debug_set_full_rows(U)                           # ... and of the direction
                 assert np.abs(h.hessvec(U)[r0:r1] - out[1][r0:r1]).max() <= 1e-13 * np.abs(out[1]).max()
                 h.close()
