@@ -459,7 +459,7 @@ def main():
     # HBM traffic comes from rocprofv3 --pmc passes (their own runs: counters cannot be collected inside a timed run);
     # the line carries the committed summary's value together with the file it was read from
     pm_h = pmc("r4_pmc_hess_g81_p32.json", "r3_pmc_hess_g81_p32.json", "r2_pmc_hess_g81_p32.json", "r1_pmc_hess_g81_p32.json")
-    pm_t = pmc("r4_pmc_persist_g81_p32.json", "r3_pmc_persist_g81_p32.json", "r2_pmc_persist_g81_p32.json", "r1_pmc_persist_g81_p32.json")
+    pm_t = pmc("r5_pmc_persist_g81_p32.json", "r4_pmc_persist_g81_p32.json", "r3_pmc_persist_g81_p32.json", "r2_pmc_persist_g81_p32.json", "r1_pmc_persist_g81_p32.json")
     if persistent:
         traffic = (pm_t or {}).get("hbm_bytes_per_trip")
         roofline = {"bound": "hbm", "achieved": trip_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -472,12 +472,15 @@ def main():
                     "streaming_formulation_bytes_per_trip": streaming_trip_bytes,
                     "streaming_equivalent_GBps": streaming_trip_bytes / (trip_ms * 1e-3) / 1e9,
                     "note": "one launch runs all trips of a solve; bytes, traffic and time are per trip.  The working "
-                            "set is register/LDS resident; profiles/r4_persist_timeline_p32.md (s_memtime stamps of every workgroup) "
-                            "splits a trip into gathers + row arithmetic 1.19 us (1.65 before all gathers of a trip were requested "
-                            "up front), grid reduction 1 1.92 us, trial step 0.52 us, wait for the residual-row stores 0.67 us, grid "
-                            "reduction 2 1.90 us, commit + new direction 0.54 us, loop 0.12 us (with the polling back-off of round 4; 2.0 "
-                            "and 2.7 us for the reductions before): the two grid-wide reductions are more than half of the trip, not HBM "
-                            "-- the fraction of the HBM roofline is low by construction at n*p*8 = 5 MB per vector"}
+                            "set is register/LDS resident; profiles/r5_persist_timeline_p32.md (s_memtime stamps of every workgroup) "
+                            "splits a trip into gathers + row arithmetic 1.3 us, grid reduction 1 1.96 us, trial step 0.52 us, wait for "
+                            "the residual-row stores 0.5 us, grid reduction 2 1.92 us, commit + new direction 0.6 us, loop 0.13 us: the two "
+                            "grid-wide reductions are more than half of the trip, not HBM -- the fraction of the HBM roofline is low by "
+                            "construction at n*p*8 = 5 MB per vector.  Round 5 built the trip with the gather running DURING reduction 2 "
+                            "three ways (row flags; sentinel-initialised exchange halves with full / partial retry): 8.6 / 7.1-7.5 / 7.2-7.5 us "
+                            "against 6.55 -- the exchanged rows need 2.6 us to become visible to other XCDs under that load "
+                            "(profiles/r5_persist_timeline_p32_*.md); what moved the trip is the exchange memory type (fine-grained instead of "
+                            "uncached: 6.55 -> 6.41 us on one box)"}
     else:
         roofline = {"bound": "hbm", "achieved": hess_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hess_achieved / HBM_PEAK_GBS, "traffic": (pm_h or {}).get("hbm_bytes_per_launch"),
@@ -620,6 +623,9 @@ def main():
             hl.set_point(Yl)
             trip_us = min(hl.bench_tcg_trip(64) for _ in range(3)) * 1e3
             msl, byl, fll = hl.bench_hessvec(50)
+            hl.set_option("window", 0)
+            msl0, _, _ = hl.bench_hessvec(50)
+            hl.set_option("window", 1)
             path = hl.tcg_path()
             hl_passes = 14
             hl.close()
@@ -634,10 +640,11 @@ def main():
                 "vector_passes_per_trip": npass,
                 "roofline": secondary_roofline("k_tcg1_upd + k_tcg1_head", trip_us, algo, 0.0,
                                                ("r4_pmc_linear_n1e6_p32.json", "r3_pmc_linear_n1e6_p32.json"), bound="hbm", per="tCG trip")}
-            # the stand-alone S*U launch of the same handle (k_hess_ell_obl: windowed traversal, streaming accesses for Y and the output)
+            # the stand-alone S*U launch of the same handle: k_hess_win_obl (round 5: the rows of U a breadth-first patch of rows touches
+            # staged once per workgroup in LDS), and beside it the direct gathers of k_hess_ell_obl (option window = 0)
             out["large_sparse_trip"]["standalone_hessvec"] = {
-                "kernel_us": msl * 1e3,
-                "roofline": secondary_roofline("k_hess_ell_obl", msl * 1e3, byl, fll, ("r4_pmc_hess_n1e6_p32.json",), bound="hbm", per="launch")}
+                "kernel_us": msl * 1e3, "kernel_us_direct_gathers": msl0 * 1e3,
+                "roofline": secondary_roofline("k_hess_win_obl", msl * 1e3, byl, fll, ("r5_pmc_hess_win_n1e6_p32.json", "r4_pmc_hess_n1e6_p32.json"), bound="hbm", per="launch")}
             rec = out["large_sparse_trip"]["roofline"]
             rec["formulation_bytes"] = formulation
             rec["formulation_GBps"] = formulation / (trip_us * 1e-6) / 1e9

@@ -464,6 +464,100 @@ def qsmom(n, coe):
     return At, b, c, {"s": mb}
 
 
+# -------------------------------------------------------------------------- sensor network localization
+def snl_polynomial(n, seed=1, radius2=0.5):
+    """The quartic of example/Sensor_Network_Localization.m:2-31: ``n`` sensors at random positions in the unit square, the four anchors
+    of the example, an edge wherever two sensors (or, for the LAST sensor as in the example's ``for i = n``, sensor and anchor) are
+    within squared distance ``radius2``; ``f = sum (|p_i - p_j|^2 - d_ij^2)^2`` over the edges in the 2n variables
+    ``(x_1..x_n, y_1..y_n)``.  Returns ``(f, loc)``: f as a dict {sorted variable tuple: coefficient} (degree <= 4), loc 2 x n.
+    (NumPy's generator, not MATLAB's: the same family, not the same instance.)"""
+    rng = np.random.default_rng(seed)
+    loc = rng.random((2, n))
+    anchors = np.array([[0.25, 0.75, 0.3, 0.8], [0.75, 0.25, 0.8, 0.3]])
+
+    def mul(p, q):
+        out = {}
+        for ma, ca in p.items():
+            for mq, cq in q.items():
+                m = tuple(sorted(ma + mq))
+                out[m] = out.get(m, 0.0) + ca * cq
+        return out
+
+    def add(p, q, sq=1.0):
+        for m, cq in q.items():
+            p[m] = p.get(m, 0.0) + sq * cq
+        return p
+
+    f = {}
+    for i in range(n - 1):
+        for j in range(i + 1, n):
+            d2 = float(np.sum((loc[:, i] - loc[:, j]) ** 2))
+            if d2 <= radius2:
+                dx = {(i,): 1.0, (j,): -1.0}; dy = {(n + i,): 1.0, (n + j,): -1.0}
+                q = add(add(mul(dx, dx), mul(dy, dy)), {(): -d2})
+                add(f, mul(q, q))
+    i = n - 1
+    for j in range(anchors.shape[1]):
+        d2 = float(np.sum((loc[:, i] - anchors[:, j]) ** 2))
+        if d2 <= radius2:
+            dx = {(i,): 1.0, (): -float(anchors[0, j])}; dy = {(n + i,): 1.0, (): -float(anchors[1, j])}
+            q = add(add(mul(dx, dx), mul(dy, dy)), {(): -d2})
+            add(f, mul(q, q))
+    return {m: c for m, c in f.items() if c != 0.0}, loc
+
+
+def snl_mom(f, nvars):
+    """Second-order moment relaxation of ``min f(x)`` for a quartic ``f`` (dict {sorted variable tuple: coefficient}) in ``nvars``
+    variables, one clique holding all of them, in SeDuMi format: what src/basicfunction/snl_mom_sparse.m:4-96 builds for
+    ``cliques = {1:nvars}`` (example/Sensor_Network_Localization.m:34-35).  Basis = all monomials of degree <= 2 (get_basis order);
+    constraints: ``X_11 = 1`` and one tie per extra entry of every monomial class (:46-74, the class representative is the entry
+    with the largest first index, +-1 on a diagonal entry, +-1/2 on a symmetric pair); ``c`` spreads every coefficient of f evenly
+    over the entries of its class (:78-93).  As in the reference, At has ``mb (mb + 1) / 2 - lsp + mb + 1`` columns (:38) of which the
+    last ``mb`` stay empty."""
+    n = int(nvars)
+    basis_arr = get_basis(n, 2)
+    mb = basis_arr.shape[1]
+    basis = [tuple(v for v in range(n) for _ in range(int(basis_arr[v, k]))) for k in range(mb)]
+    classes = {}
+    for i in range(mb):
+        for j in range(i, mb):
+            classes.setdefault(tuple(sorted(basis[i] + basis[j])), []).append((i, j))
+    # the reference sorts the degree-4 monomials by rows of exponents (sortrows): the order of the tie constraints
+    def expo(m):
+        e = [0] * n
+        for v in m:
+            e[v] += 1
+        return tuple(e)
+    order = sorted(classes, key=expo)
+    lsp = len(order)
+    assert lsp == comb(n + 4, 4)
+    ncons = mb * (mb + 1) // 2 - lsp + mb + 1
+    rows, cols, vals = [0], [0], [1.0]
+    b = np.zeros(ncons); b[0] = 1.0
+    l = 1
+    for mon in order:
+        lst = classes[mon]
+        idx = int(np.argmax([pr[0] for pr in lst]))
+        for q, (i, j) in enumerate(lst):
+            if q == idx:
+                continue
+            for (ii, jj), sgn in ((lst[idx], 1.0), ((i, j), -1.0)):
+                if ii == jj:
+                    rows.append(ii * mb + ii); cols.append(l); vals.append(sgn)
+                else:
+                    rows += [jj * mb + ii, ii * mb + jj]; cols += [l, l]; vals += [0.5 * sgn, 0.5 * sgn]
+            l += 1
+    assert l == ncons - mb
+    At = sp.coo_matrix((np.array(vals), (np.array(rows), np.array(cols))), shape=(mb * mb, ncons)).tocsc()
+    c = np.zeros(mb * mb)
+    for mon, coef in f.items():
+        spots = []
+        for (i, j) in classes[tuple(sorted(mon))]:
+            spots += [i * mb + i] if i == j else [j * mb + i, i * mb + j]
+        c[spots] = coef / len(spots)
+    return At, b, sp.csc_matrix(c.reshape(-1, 1)), {"s": mb}
+
+
 # -------------------------------------------------------------------------- theta
 def theta_problem(n, ndraws=None, seed=1):
     """Lovasz-theta-like unit-trace SDP of example/example_theta.m:2-39:

@@ -172,3 +172,26 @@ def test_matrix_completion_n1000(lib):
     X12 = Y[:500] @ Y[500:].T
     assert np.linalg.norm(X12 - M) <= 1e-6 * np.linalg.norm(M)
     assert abs(obj - 2.0 * np.linalg.svd(M, compute_uv=False).sum()) <= 1e-6 * obj      # tr X = 2 |M|_*
+
+
+SNL_OPTS = {"tol": 1e-4, "sigma0": 1, "sigma_min": 1e1, "theta": 1e-3, "TR_maxiter": 8, "line_search": 0, "alpha": 0.01}   # Sensor_Network_Localization.m:40-46
+
+
+@pytest.mark.parametrize("n", [4, 10])
+def test_sensor_network_localization(lib, n):
+    """example/Sensor_Network_Localization.m:2-49 through the generic ManiSDP (the caller SURVEY.md 8f-2 says the generic kind
+    unlocks; VERDICT round 4, missing 4): the moment relaxation of the localization quartic with the example's options.  f >= 0
+    with f = 0 at the true positions, so the SDP optimum is 0: |optimum| and eta below the example's tolerance; for n = 4 also the
+    oracle's optimum from the same start (both 0 to the tolerance)."""
+    from manisdp_matlab_amd import problems, solvers
+    from oracle import manisdp_ref as R
+    f, loc = problems.snl_polynomial(n, seed=1)
+    At, b, c, K = problems.snl_mom(f, 2 * n)
+    c = np.asarray(c.todense()).ravel()
+    maxc = np.abs(c).max()
+    Y, fval, d = solvers.ManiSDP(At, b, c / maxc, K, dict(SNL_OPTS), verbose=False, rng=np.random.default_rng(0))
+    assert d["status"] == 0 and max(d["gap"], d["pinf"], d["dinf"]) < 1e-4
+    assert abs(fval * maxc) < 2e-3
+    if n == 4:
+        Yo, fo, do = R.ManiSDP(At, b, c / maxc, K, dict(SNL_OPTS), rng=np.random.default_rng(0))
+        assert do["status"] == 0 and abs(fo * maxc) < 2e-3

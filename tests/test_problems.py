@@ -288,3 +288,28 @@ def test_quasar_relaxation_is_valid_on_feasible_points():
         assert abs(c @ z - direct) <= 1e-12 * abs(direct)
     At2 = P.quasar_problem(a, b, beta ** 2, redundant=False)[0]
     assert At2.shape[1] == 1 + 16 * N
+
+
+def test_snl_relaxation_is_valid():
+    """problems.snl_polynomial / snl_mom (src/basicfunction/snl_mom_sparse.m:4-96 for one clique, the workload of
+    example/Sensor_Network_Localization.m:2-35): the quartic vanishes at the true sensor positions, the moments of ANY point satisfy
+    every constraint and reproduce f, and the sizes are the reference's (mb = C(2n+2, 2), columns = mb (mb + 1) / 2 - C(2n+4, 4) + mb + 1)."""
+    from math import comb
+    from manisdp_matlab_amd import problems
+    n = 4
+    f, loc = problems.snl_polynomial(n, seed=1)
+    At, b, c, K = problems.snl_mom(f, 2 * n)
+    mb = K["s"]
+    assert mb == comb(2 * n + 2, 2) and At.shape == (mb * mb, mb * (mb + 1) // 2 - comb(2 * n + 4, 4) + mb + 1)
+    ev = lambda x: sum(cf * np.prod([x[i] for i in m]) for m, cf in f.items())
+    assert abs(ev(np.concatenate([loc[0], loc[1]]))) < 1e-12
+    ba = problems.get_basis(2 * n, 2)
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        x = rng.standard_normal(2 * n)
+        v = np.array([np.prod(x ** ba[:, k]) for k in range(mb)])
+        X = np.outer(v, v).reshape(-1, order="F")
+        assert np.abs(At.T @ X - b).max() < 1e-12 * max(1.0, np.abs(X).max())
+        assert abs((c.T @ X)[0] - ev(x)) <= 1e-10 * max(1.0, abs(ev(x)))
+    C = np.asarray(c.todense()).reshape(mb, mb)
+    assert np.array_equal(C, C.T)

@@ -11,7 +11,8 @@ stats() {   # stats <tag> <timeout> python3 args...
     local tag=$1 to=$2; shift 2
     timeout "$to" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$tag" -- "$@" > "$OUT/$tag.log" 2>&1
     echo "stats $tag rc=$?"
-    for f in $(find "$OUT/$tag" -name "*kernel_stats.csv"); do cp "$f" "$OUT/${tag}_kernel_stats.csv"; done
+    # (child processes of the profiled command write their own files: the parent's is the one with the lowest process id)
+    for f in $(find "$OUT/$tag" -name "*kernel_stats.csv" | sort -t/ -k1 -V -r); do cp "$f" "$OUT/${tag}_kernel_stats.csv"; done
 }
 pmc() {     # pmc <tag> <timeout> "<counters>" python3 args...
     local tag=$1 to=$2 ctr=$3; shift 3
