@@ -816,9 +816,12 @@ static int persist_grid(const Dev& d) {
         else cus = 0;
         (void)hipGetLastError();
     }
-    int g = d.G;
+    // (round 5: NOT d.G -- the grid of the row-parallel kernels follows THEIR lanes per row: 4 lanes at p <= 8, i.e. 256 rows per
+    // pass and 80 workgroups for G81, on which this kernel (8 lanes per row at least) needed its four-slot instance and left two
+    // thirds of the CUs idle: p = 8 6.8 us per trip against 5.5 at p = 16, p = 4 not eligible at all (12.6 us on the chunked path);
+    // tools/p_sweep_probe.py)
+    int g = 256;                                       // psync polls 4 x 64 slots
     if (g > cus) g = (cus / 8) * 8;
-    if (g > 256) g = 256;                              // psync polls 4 x 64 slots
     // the fewest workgroups that need the same number of row slots: a workgroup with 93 rows in three slots of 32 takes as
     // long as one with 79, and the grid synchronisation has fewer slots to poll
     PersistPlan pl;

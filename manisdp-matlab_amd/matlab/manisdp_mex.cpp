@@ -35,6 +35,7 @@
 //   S = manisdp_mex('get_dual_slack', h)
 //   k = manisdp_mex('kind', h)
 //       manisdp_mex('set_option', h, name, value)        run-time switch of the handle (msdp_set_option)
+//       manisdp_mex('comm_init_ipc', h, nranks, rank, name)   this MATLAB worker is member `rank` of a group of processes (row sharding)
 //       manisdp_mex('destroy', h)
 //
 // Handles travel as uint64 scalars and are remembered here together with (kind, n, m), so the factor layout is
@@ -278,6 +279,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (mxGetString(prhs[2], name, sizeof(name))) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "option name too long");
         const int rc = msdp_set_option(h, name, (int32_t)mxGetScalar(prhs[3]));
         if (rc) fail("set_option", rc);
+    } else if (cmd == "comm_init_ipc") {
+        // row sharding over MATLAB workers (one per GPU, or several on one GPU): member `rank` of `nranks` processes; `name` is a POSIX
+        // shared-memory name, the same on every worker (msdp_comm_init_ipc); call right after create, before any point is set
+        need(nrhs == 5 && mxIsChar(prhs[4]), "manisdp_mex('comm_init_ipc', h, nranks, rank, name)");
+        char name[128];
+        if (mxGetString(prhs[4], name, sizeof(name))) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "group name too long");
+        const int rc = msdp_comm_init_ipc(h, (int32_t)mxGetScalar(prhs[2]), (int32_t)mxGetScalar(prhs[3]), name);
+        if (rc) fail("comm_init_ipc", rc);
     } else if (cmd == "set_multipliers") {
         need(nrhs == 4, "manisdp_mex('set_multipliers', h, y, sigma)");
         if ((int64_t)mxGetNumberOfElements(prhs[2]) != me.m) mexErrMsgIdAndTxt("ManiSDP:hip:arg", "y must have m entries");
