@@ -1019,6 +1019,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "window_lds")) { t.window_lds = value < 16 ? 16 : (value > 144 ? 144 : value); h->chunk_len = 0; msdp_window_release(h); }
     else if (!strcmp(name, "persist_early")) t.persist_early = value > 0 ? value : 0;
     else if (!strcmp(name, "persist_goff")) t.persist_goff = value ? 1 : 0;
+    else if (!strcmp(name, "persist_slots")) { t.persist_slots = (value == 3 || value == 4) ? value : 0; h->d.persist_slots = t.persist_slots; }
     else if (!strcmp(name, "psync_backoff")) t.psync_backoff = value > 0 ? value : 0;
     else if (!strcmp(name, "affine_overlap")) { t.affine_overlap = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "trip1")) { t.trip1 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }

@@ -132,6 +132,7 @@ struct Dev {
     // the exchange buffer all ranks share (all n rows; uncached memory, sc1 accesses only)
     int xr_gid0, xr_gtot;
     double* xr_mdx;
+    int persist_slots;    // A/B: row slots of the persistent tCG plan at p = 17..32 (0: planned)
 };
 
 // Run-time switches of a handle (msdp_set_option; the environment variables of the same meaning are read ONCE, when
@@ -177,6 +178,7 @@ struct Tuning {
                                //   far beyond the L2s (from 3 * 2^22 entries on), 2 = always (tests), 0 = never
     int window_lds = 144;      // ... KB of LDS a window may take (A/B; one 1024-thread workgroup per CU)
     int persist_refresh = 32;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
+    int persist_slots = 0;     // A/B: row slots per lane group of the persistent tCG at p = 17..32 (0: planned; 3 or 4)
     int persist_goff = 1;      // persistent tCG: the byte offsets of the R x EW gathers of a trip live in registers (0: recomputed per trip from the LDS copy of the column indices)
     int persist_early = 0;     // persistent tCG: the neighbours' rows are gathered while reduction 2 is in flight -- sentinel-initialised exchange
                                //   halves, the rows are their own flags (0: at the top of the next trip, behind reduction 2 -- the round-4 trip;

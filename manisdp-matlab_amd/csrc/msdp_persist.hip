@@ -743,6 +743,8 @@ static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
     // p <= 16 (64 rows per slot): four slots (all in registers, two synchronisations) up to 256 rows per workgroup, i.e.
     // n <= 65536 on 256 CUs (eight slots would need 163 KB of LDS with the ELL rows)
     if (lpr == 8 && need > 2 * rstep && need <= 4 * rstep) pl.r = 4;
+    // A/B (option persist_slots): force the number of row slots of the p = 17..32 plan (3 -> 96 rows, 4 -> 128 rows per workgroup)
+    if (d.persist_slots > 0 && lpr == 16 && (d.persist_slots == 3 || d.persist_slots == 4) && need <= d.persist_slots * rstep) pl.r = d.persist_slots;
     if (need > pl.r * rstep) return false;
     const size_t rows = (size_t)pl.r * rstep;
     pl.lds = (size_t)2 * pl.r * PB * sizeof(double2) + rows * sizeof(double) + (size_t)pl.ew * rows * (sizeof(double) + sizeof(int));
