@@ -2230,6 +2230,15 @@ static int rtr_core(msdp_handle h, const msdp_rtr_opts* opts, bool* timed_out) {
                 // members in different processes: the rest of the iteration is ONE launch per member too (k_tr_tail_obl<.., XR>) -- the
                 // proposal rows through the group's exchange buffer, barrier and reduction over its slots, no collective
                 if ((rc = xr_tail(h))) return rc;
+                // ... and the decision stays on the device: three more iterations are enqueued before the host looks (both kernels
+                // return at once when the solve is done, on every member alike), one host synchronisation per FOUR iterations
+                for (int ahead = 0; ahead < 3 && !rc; ++ahead) {
+                    h->d.status = nullptr;
+                    rc = xr_launch(h);
+                    restore_status_ptr(h);
+                    if (!rc) rc = xr_tail(h);
+                }
+                if (rc) return rc;
             } else {
                 if ((rc = msdp_launch_retract(h))) return rc;             // :540
                 if ((rc = msdp_launch_costgrad(h, cur ^ 1))) return rc;   // :544
