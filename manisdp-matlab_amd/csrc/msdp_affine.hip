@@ -313,16 +313,20 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev 
     // LPR lanes per row (one double2 each, NCH column chunks), 64 / LPR rows per wave: the lanes of a row take one touched entry
     // each (flattened record -> w), then the values and column indices are broadcast inside the group and all its lanes
     // accumulate v * Y(j, :).  raw = slabs + 4 sigma * sparse part; y, u = the row of the point and of the direction.
-    auto rowwork = [&](int i, bool rok, double2 (&raw)[NCH], double2 (&y)[NCH], double2 (&u)[NCH]) {
+    // (eight column chunks per lane, p = 513..1024: only the sparse part is held across the row work; the slab sums and the rows of Y
+    // and U are read in `finish` -- holding all four sets took 128 registers per lane and spilled 640 bytes)
+    constexpr bool HOLD = NCH < 8;
+    auto rowwork = [&](int i, bool rok, double2 (&raw)[NCH], double2 (&y)[HOLD ? NCH : 1], double2 (&u)[HOLD ? NCH : 1]) {
         double2 acc[NCH];
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-            acc[ch] = make_double2(0.0, 0.0); raw[ch] = acc[ch]; y[ch] = acc[ch]; u[ch] = acc[ch];
+            acc[ch] = make_double2(0.0, 0.0); raw[ch] = acc[ch];
+            if (HOLD) { y[HOLD ? ch : 0] = acc[ch]; u[HOLD ? ch : 0] = acc[ch]; }
             const int c = 2 * sub + ch * 2 * LPR;
-            if (rok && c < d.ld) {                                 // independent of the sparse part: requested first
+            if (HOLD && rok && c < d.ld) {                         // independent of the sparse part: requested first
                 const int64_t o = (int64_t)i * d.ld + c;
                 raw[ch] = msdp_sum_slabs(slab, slab_stride, SK, o);
-                y[ch] = ld2(Yl + o); u[ch] = ld2(d.md + o);
+                y[HOLD ? ch : 0] = ld2(Yl + o); u[HOLD ? ch : 0] = ld2(d.md + o);
             }
         }
         if (support) {
@@ -369,22 +373,26 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_sph_hess_fused(Dev d, AffineDev 
         for (int ch = 0; ch < NCH; ++ch) { raw[ch].x += s4 * acc[ch].x; raw[ch].y += s4 * acc[ch].y; }
     };
     double t = 0.0;
-    auto finish = [&](int i, bool rok, const double2 (&raw)[NCH], const double2 (&y)[NCH], const double2 (&u)[NCH]) {
+    auto finish = [&](int i, bool rok, const double2 (&raw)[NCH], const double2 (&y)[HOLD ? NCH : 1], const double2 (&u)[HOLD ? NCH : 1]) {
         if (!rok) return;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int c = 2 * sub + ch * 2 * LPR;
             if (c < d.ld) {
+                const int64_t o = (int64_t)i * d.ld + c;
+                double2 rw = raw[ch];
+                if (!HOLD) { const double2 sl = msdp_sum_slabs(slab, slab_stride, SK, o); rw.x += sl.x; rw.y += sl.y; }
+                const double2 yy = HOLD ? y[HOLD ? ch : 0] : ld2(Yl + o), uu = HOLD ? u[HOLD ? ch : 0] : ld2(d.md + o);
                 double2 hq;
-                hq.x = raw[ch].x - t * y[ch].x - 2.0 * z * u[ch].x;
-                hq.y = raw[ch].y - t * y[ch].y - 2.0 * z * u[ch].y;
-                st2(d.Hmd + (int64_t)i * d.ld + c, hq);
-                pd += u[ch].x * hq.x + u[ch].y * hq.y;
+                hq.x = rw.x - t * yy.x - 2.0 * z * uu.x;
+                hq.y = rw.y - t * yy.y - 2.0 * z * uu.y;
+                st2(d.Hmd + o, hq);
+                pd += uu.x * hq.x + uu.y * hq.y;
             }
         }
     };
     if (support && hetero && a.nlong > 0) __syncthreads();         // wl is in place
-    double2 raw[NCH], y[NCH], u[NCH];
+    double2 raw[NCH], y[HOLD ? NCH : 1], u[HOLD ? NCH : 1];
     int row0 = lo + wave * RPW;                                    // wave-uniform
     const bool first = row0 < hi;
     if (first) rowwork(row0 + rsub, row0 + rsub < hi, raw, y, u);  // first pass in front of the barrier that hands out t

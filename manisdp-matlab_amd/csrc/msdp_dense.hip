@@ -259,17 +259,22 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_dense_hess_epi_obl(Dev d, const 
     for (int row0 = lo + wave * RPW; row0 < hi; row0 += MSDP_WAVES * RPW) {
         const int row = row0 + rsub;
         if (row < hi) {
-            double2 acc[NCH], y[NCH], u[NCH];
+            // (eight column chunks per lane, p = 513..1024: the rows of Y and U are read a second time in the second loop instead of
+            // being held -- 64 registers per lane, which spilled 140 bytes at the 128-register budget of a 1024-thread workgroup)
+            constexpr bool HOLD = NCH < 8;
+            double2 acc[NCH], y[HOLD ? NCH : 1], u[HOLD ? NCH : 1];
             double dot = 0.0;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int col = 2 * sub + ch * 2 * LPR;
-                acc[ch] = make_double2(0.0, 0.0); y[ch] = acc[ch]; u[ch] = acc[ch];
+                acc[ch] = make_double2(0.0, 0.0);
+                if (HOLD) { y[HOLD ? ch : 0] = acc[ch]; u[HOLD ? ch : 0] = acc[ch]; }
                 if (col < d.ld) {
                     const int64_t o = (int64_t)row * d.ld + col;
                     acc[ch] = msdp_sum_slabs(slab, slab_stride, SK, o);
-                    y[ch] = ld2(Yl + o); u[ch] = ld2(d.md + o);
-                    dot += acc[ch].x * y[ch].x + acc[ch].y * y[ch].y;
+                    const double2 yy = ld2(Yl + o);
+                    if (HOLD) { y[HOLD ? ch : 0] = yy; u[HOLD ? ch : 0] = ld2(d.md + o); }
+                    dot += acc[ch].x * yy.x + acc[ch].y * yy.y;
                 }
             }
             dot = msdp_group_sum<LPR>(dot);
@@ -279,11 +284,13 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_dense_hess_epi_obl(Dev d, const 
             for (int ch = 0; ch < NCH; ++ch) {
                 const int col = 2 * sub + ch * 2 * LPR;
                 if (col < d.ld) {
+                    const int64_t o = (int64_t)row * d.ld + col;
+                    const double2 yy = HOLD ? y[HOLD ? ch : 0] : ld2(Yl + o), uu = HOLD ? u[HOLD ? ch : 0] : ld2(d.md + o);
                     double2 h;
-                    h.x = acc[ch].x - y[ch].x * dot - u[ch].x * eg;
-                    h.y = acc[ch].y - y[ch].y * dot - u[ch].y * eg;
-                    st2(d.Hmd + (int64_t)row * d.ld + col, h);
-                    pd += u[ch].x * h.x + u[ch].y * h.y;
+                    h.x = acc[ch].x - yy.x * dot - uu.x * eg;
+                    h.y = acc[ch].y - yy.y * dot - uu.y * eg;
+                    st2(d.Hmd + o, h);
+                    pd += uu.x * h.x + uu.y * h.y;
                 }
             }
         }

@@ -400,6 +400,22 @@ def test_wide_factors_up_to_1024(p):
     with pytest.raises(_lib.MsdpError, match="maximum of 1024"):
         h.set_point(np.ones((n, 1030)) / np.sqrt(1030.0))
     h.close()
+    # unit-trace affine kind (theta1): the fused sphere epilogue with eight column chunks per lane (round 5: holds the sparse part only)
+    At, b, c, K = problems.from_sdpa(golden_path("theta1.dat-s.gz"))
+    c = np.asarray(c.todense()).ravel(); b = np.asarray(b, float).ravel()
+    n = K["s"]
+    Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y)
+    pt = R._UnitTraceProblem(At, b, c, n, p)
+    U = pt.M.proj(Y, rng.standard_normal((n, p)))
+    y = 0.1 * rng.standard_normal(b.size)
+    pt.y, pt.sigma = y, 2.5
+    ft, Gt, Ht = pt.cost(Y), pt.grad(Y), pt.hess(Y, U)
+    h = _lib.Handle.affine(_lib.KIND_UNITTRACE, At, b, c, n, pcap=p)
+    h.set_multipliers(y, 2.5)
+    h.set_point(Y)
+    assert abs(h.cost() - ft) <= 1e-10 * max(1.0, abs(ft))
+    assert rel(h.rgrad(), Gt) < 1e-10 and rel(h.hessvec(U), Ht) < 1e-10
+    h.close()
 
 
 def test_handle_churn_keeps_results_and_pool_bounded(lib):
