@@ -1015,7 +1015,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "xpersist")) t.xpersist = value != 0;
     else if (!strcmp(name, "persist_refresh")) t.persist_refresh = value > 0 ? value : 0;
     else if (!strcmp(name, "xtail")) t.xtail = value ? 1 : 0;
-    else if (!strcmp(name, "window")) { t.window = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
+    else if (!strcmp(name, "window")) { t.window = value < 0 ? 0 : (value > 3 ? 3 : value); h->chunk_len = 0; }
     else if (!strcmp(name, "window_lds")) { t.window_lds = value < 16 ? 16 : (value > 144 ? 144 : value); h->chunk_len = 0; msdp_window_release(h); }
     else if (!strcmp(name, "persist_early")) t.persist_early = value > 0 ? value : 0;
     else if (!strcmp(name, "persist_goff")) t.persist_goff = value ? 1 : 0;

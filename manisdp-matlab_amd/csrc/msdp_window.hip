@@ -28,7 +28,7 @@ struct WinPlan {
 };
 
 struct WinCacheEntry { int lpr = 0; int ld_max = 0; WinPlan plan{}; std::vector<void*> dev; bool failed = false; };
-struct WinCache { WinCacheEntry e[4]; };
+struct WinCache { WinCacheEntry e[8]; };
 
 // H = proj-fused (C*md - Y.*rowdot(Y, C*md) - md.*eG) with the rows of md the patch touches staged in LDS; partial <md, Hmd>.
 // Software pipeline over the patches of a workgroup: the window of the NEXT patch is requested into registers (NW row loads per
@@ -36,9 +36,12 @@ struct WinCache { WinCacheEntry e[4]; };
 // buffer behind them -- the first version (load, barrier, compute, barrier, one row per trip of either loop) spent 35 us per patch
 // in chains of dependent round trips: 306 us at n = 10^6, p = 32 against 208 us for the direct gathers.
 #define WIN_NW 5                                               // window rows per lane group: wmax <= WIN_NW * MSDP_WAVES * 64 / LPR
-template <int LPR, int EWC>                                   // EWC: the stored ELL width (5 or 8)
+// TWO (round 5, second form): two workgroups per CU, each with ONE window buffer (the next window waits in registers until the
+// products of the current one are done: two barriers per patch, and the other resident workgroup's products fill the gaps); the
+// launch has 2 x d.G workgroups and k_win_fold adds the partial sums of workgroup b + G to those of b (the consumers read d.G slots).
+template <int LPR, int EWC, bool TWO>                         // EWC: the stored ELL width (5 or 8)
 __global__ __launch_bounds__(MSDP_BLOCK) void k_hess_win_obl(Dev d, WinPlan w) {
-    extern __shared__ double2 win[];                       // 2 x [wmax][LPR]
+    extern __shared__ double2 win[];                       // (TWO ? 1 : 2) x [wmax][LPR]
     __shared__ double sh[3 * MSDP_WAVES];
     if (!d.F[0].active) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -62,6 +65,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_hess_win_obl(Dev d, WinPlan w) {
     // (plain locals for what the lambdas below touch: a by-reference capture of a kernel-argument struct puts the struct into scratch)
     const int* __restrict__ poff = w.poff; const int* __restrict__ wrows = w.wrows;
     const int ld = d.ld, wmax = w.wmax;
+    const bool nt = (d.sweep & 2) != 0;                    // streaming accesses for what the launch touches once (Y, the output), as in the direct kernel
     double2 nx[WIN_NW];
     // the rows of patch P this lane group stages: requested by GET_WINDOW, stored by PUT_WINDOW (macros, not lambdas: an array that
     // two lambdas capture by reference stays in scratch memory)
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_hess_win_obl(Dev d, WinPlan w) {
                 }
             }
 #pragma unroll
-            for (int u = 0; u < UN; ++u) { y[u] = ld2_nt(Yl + (int64_t)row[u] * d.ld + csub); eg[u] = eG[row[u]]; }
+            for (int u = 0; u < UN; ++u) { y[u] = nt ? ld2_nt(Yl + (int64_t)row[u] * d.ld + csub) : ld2(Yl + (int64_t)row[u] * d.ld + csub); eg[u] = eG[row[u]]; }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 double2 acc = zz;
@@ -121,19 +125,31 @@ __global__ __launch_bounds__(MSDP_BLOCK) void k_hess_win_obl(Dev d, WinPlan w) {
                     double2 hq;
                     hq.x = acc.x - y[u].x * dot - uu.x * eg[u];
                     hq.y = acc.y - y[u].y * dot - uu.y * eg[u];
-                    st2_nt(H + (int64_t)row[u] * d.ld + 2 * sub, hq);
+                    if (nt) st2_nt(H + (int64_t)row[u] * d.ld + 2 * sub, hq); else st2(H + (int64_t)row[u] * d.ld + 2 * sub, hq);
                     pd += uu.x * hq.x + uu.y * hq.y;
                 }
             }
         }
-        if (pn < p1) PUT_WINDOW(buf ^ 1);                      // (nobody reads that buffer: its patch was finished one barrier ago)
-        __syncthreads();
-        buf ^= 1;
+        if (TWO) {
+            __syncthreads();                                   // everybody is done with the window
+            if (pn < p1) PUT_WINDOW(0);
+            __syncthreads();
+        } else {
+            if (pn < p1) PUT_WINDOW(buf ^ 1);                  // (nobody reads that buffer: its patch was finished one barrier ago)
+            __syncthreads();
+            buf ^= 1;
+        }
     }
     msdp_put_partial(d.P, P_DHD, pd, sh);
 }
 #undef GET_WINDOW
 #undef PUT_WINDOW
+// the partial sums of the second round of workgroups onto those of the first (deterministic: one fixed pair per slot)
+__global__ void k_win_fold(Dev d, int G) {
+    if (!d.F[0].active) return;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < G) d.P[(size_t)P_DHD * MSDP_MAX_GRID + b] += d.P[(size_t)P_DHD * MSDP_MAX_GRID + b + G];
+}
 
 // ------------------------------------------------------------------ host: patches
 // Breadth-first patches of at most B rows over the LOCAL rows (h_rowptr / h_colind hold ALL rows of C with global numbers; columns
@@ -183,6 +199,7 @@ static void win_build_patches(msdp_handle h, int B, int wmax, std::vector<std::v
             continue;
         }
         std::sort(hl.begin(), hl.end());
+        std::sort(o.begin(), o.end());                         // consecutive lane groups take ascending rows: runs of consecutive rows stay together in memory
         own.push_back(std::move(o)); halo.push_back(std::move(hl));
     }
 }
@@ -199,16 +216,18 @@ static int win_upload(WinCacheEntry& e, const std::vector<T>& v, const T** out) 
 
 static const size_t WIN_LDS_BYTES = 144 * 1024;            // one 1024-thread workgroup per CU: the two window buffers may take most of the 160 KB
 
+static bool win_two(msdp_handle h) { return h->tune.window == 3 && 2 * h->d.G <= MSDP_MAX_GRID; }
 static int win_get_plan(msdp_handle h, int lpr, WinCacheEntry** out) {
     if (!h->win) h->win = new WinCache();
     WinCacheEntry* e = nullptr;
-    for (auto& x : h->win->e) if (x.lpr == lpr) { e = &x; break; }
+    const int key = lpr + (win_two(h) ? 1000 : 0);
+    for (auto& x : h->win->e) if (x.lpr == key) { e = &x; break; }
     if (!e) for (auto& x : h->win->e) if (x.lpr == 0) { e = &x; break; }
     if (!e) return MSDP_EUNSUPPORTED;
     *out = e;
-    if (e->lpr == lpr) return e->failed ? MSDP_EUNSUPPORTED : 0;
-    e->lpr = lpr;
-    // two buffers of wmax rows; a lane group stages at most WIN_NW rows of a window
+    if (e->lpr == key) return e->failed ? MSDP_EUNSUPPORTED : 0;
+    e->lpr = key;
+    // two buffers of wmax rows in one workgroup per CU, or one buffer in each of two; a lane group stages at most WIN_NW rows of a window
     int wmax = (int)(std::min(WIN_LDS_BYTES, (size_t)h->tune.window_lds * 1024) / 2 / ((size_t)lpr * sizeof(double2)));
     wmax = std::min(wmax, WIN_NW * MSDP_WAVES * (64 / lpr));
     // target patch size: on a 2-D grid the halo of a breadth-first patch of B rows is ~ 2.5 sqrt(B) + a few rows
@@ -284,15 +303,19 @@ int msdp_window_hess(msdp_handle h) {
     WinCacheEntry* e = nullptr;
     int rc = win_get_plan(h, lpr, &e);
     if (rc) return rc;
-    const size_t lds = (size_t)2 * e->plan.wmax * lpr * sizeof(double2);
-    dim3 grid(d.G), block(MSDP_BLOCK);
+    const bool two = win_two(h);
+    const size_t lds = (size_t)(two ? 1 : 2) * e->plan.wmax * lpr * sizeof(double2);
+    dim3 grid(two ? 2 * d.G : d.G), block(MSDP_BLOCK);
     typedef void (*fn_t)(Dev, WinPlan);
     const bool e5 = e->plan.EW == 5;
-    fn_t fn = lpr == 8 ? (e5 ? k_hess_win_obl<8, 5> : k_hess_win_obl<8, 8>) : (lpr == 16 ? (e5 ? k_hess_win_obl<16, 5> : k_hess_win_obl<16, 8>) : (e5 ? k_hess_win_obl<32, 5> : k_hess_win_obl<32, 8>));
-    static bool attr_set[6] = {false, false, false, false, false, false};      // (not a stream operation: once per process and kernel, outside any graph capture)
-    const int ai = (lpr == 8 ? 0 : (lpr == 16 ? 1 : 2)) * 2 + (e5 ? 0 : 1);
+    fn_t fn;
+    if (two) fn = lpr == 8 ? (e5 ? k_hess_win_obl<8, 5, true> : k_hess_win_obl<8, 8, true>) : (lpr == 16 ? (e5 ? k_hess_win_obl<16, 5, true> : k_hess_win_obl<16, 8, true>) : (e5 ? k_hess_win_obl<32, 5, true> : k_hess_win_obl<32, 8, true>));
+    else fn = lpr == 8 ? (e5 ? k_hess_win_obl<8, 5, false> : k_hess_win_obl<8, 8, false>) : (lpr == 16 ? (e5 ? k_hess_win_obl<16, 5, false> : k_hess_win_obl<16, 8, false>) : (e5 ? k_hess_win_obl<32, 5, false> : k_hess_win_obl<32, 8, false>));
+    static bool attr_set[12] = {false};                    // (not a stream operation: once per process and kernel, outside any graph capture)
+    const int ai = ((lpr == 8 ? 0 : (lpr == 16 ? 1 : 2)) * 2 + (e5 ? 0 : 1)) * 2 + (two ? 1 : 0);
     if (!attr_set[ai]) { HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIN_LDS_BYTES)); attr_set[ai] = true; }
     hipLaunchKernelGGL(fn, grid, block, lds, h->stream, d, e->plan);
+    if (two) hipLaunchKernelGGL(k_win_fold, dim3((d.G + 255) / 256), dim3(256), 0, h->stream, d, d.G);
     HIPCHK(hipGetLastError());
     return 0;
 }

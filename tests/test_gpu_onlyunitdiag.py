@@ -463,14 +463,20 @@ def test_lds_staged_hessvec_matches_the_direct_gathers(lib, shape, p):
     Y, _ = _rand_point(n, p, seed=4)
     U = np.random.default_rng(9).standard_normal((n, p))
     out = []
-    for window in (2, 0):
+    for window in (2, 0, 3):               # 3: two workgroups per CU with one window buffer each, partial sums folded by k_win_fold
         h = lib.Handle.onlyunitdiag(C, pcap=p)
         h.set_option("window", window)
         h.set_point(Y)
         H = h.hessvec(U)
         assert np.array_equal(H, h.hessvec(U))
         out.append(H)
+        if window:                         # the partial sums <U, H U> reach the tCG kernels: one trustregions() step must agree with the direct form
+            st = h.rtr(lib.default_opts(maxiter=2, maxinner=6, tolgradnorm=1e-9))
+            out.append((st.hessvecs, st.cost))
         h.close()
+    assert out[1][0] == out[4][0] and abs(out[1][1] - out[4][1]) <= 1e-12 * abs(out[1][1])
+    assert np.array_equal(out[0], out[3])
+    out = [out[0], out[2]]
     # (same fma order in the row products; the row dot <Y, C*U> is summed over 8 or 16 lanes depending on the direct kernel's lane plan)
     assert np.abs(out[0] - out[1]).max() <= 1e-13 * np.abs(out[1]).max()
     prob = R._OnlyUnitDiagProblem(C, n, p)
