@@ -271,9 +271,10 @@ def process_rank_worker(argv):
 
 
 def process_rank_trip(N=2, p=32):
-    """N PROCESSES on ONE GPU (msdp_comm_init_ipc), 20 000 rows each: the group's slot regions and exchange buffer live in one
-    fine-grained device block exported / mapped through HIP IPC (the mapping goes over peer access when the ranks own different
-    devices: the same code path), every process launches its own workgroups of the cross-rank persistent tCG and of the cross-rank TR
+    """N PROCESSES on ONE GPU (msdp_comm_init_ipc), 20 000 rows each: the group's slot regions live in one fine-grained device
+    block of rank 0, every member's exchange buffer (its rows + a slot per foreign row it references) in its own memory, all
+    exported / mapped through HIP IPC (the mapping goes over peer access when the ranks own different devices: the same code
+    path); the owner of a boundary row stores it into the neighbour's buffer, gathers are local.  Every process launches its own workgroups of the cross-rank persistent tCG and of the cross-rank TR
     tail -- a trustregions() call issues no collective per trip and none per iteration."""
     import subprocess, tempfile
     name = "/msdp_bench_%d" % os.getpid()

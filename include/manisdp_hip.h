@@ -338,8 +338,9 @@ int msdp_comm_init_local(msdp_handle h, int32_t nranks, int32_t rank, int32_t gr
 /* The same group with its members in DIFFERENT PROCESSES -- several ranks on one GPU, or one rank per GPU of a node with peer
  * access (replaces nothing in the reference, whose MATLAB path is one process).  `name` is a POSIX shared-memory
  * name ("/..."), the same on every member and fresh for every group.  Rank 0 allocates one fine-grained device block (the slot
- * regions and the exchange buffer of the cross-rank persistent tCG, one staging slab per rank for the collectives), exports it
- * with hipIpcGetMemHandle; the others map it with hipIpcOpenMemHandle (peer access between devices).  With sparse C the whole
+ * regions of the cross-rank persistent tCG, one staging slab per rank for the collectives) and EVERY member an exchange buffer
+ * for its own rows plus a slot per foreign row it references, on its own device; the blocks are exported with hipIpcGetMemHandle
+ * and mapped by the others with hipIpcOpenMemHandle (peer access between devices).  With sparse C the whole
  * tCG of a trust-region iteration then runs as ONE grid-synchronised computation across the members' launches -- no collective
  * per trip; a member whose launch never arrives turns the others' bounded spins into MSDP_ECOMM.  Collectives outside the tCG
  * (cost / gradient at the proposal, AL bookkeeping) go through the staging slabs behind a barrier on the shared segment. */

@@ -733,6 +733,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     msdp_window_release(h);
     msdp_block_eigs_release(h);
     halo_release(h);
+    if (h->xr_paddr) (void)hipFree(h->xr_paddr);
     local_leave(h);
     if (h->lc_tmp) (void)hipFree(h->lc_tmp);
     if (h->esc_rp) (void)hipFree(h->esc_rp);
@@ -1070,6 +1071,14 @@ struct Halo {
     double* sendbuf = nullptr;     // device: send_rows x ldcap
     double* recvbuf = nullptr;     // device: recv_rows x ldcap
     int ldcap = 0;
+    // cross-rank persistent kernels, round 5 ("push" exchange): every member's exchange buffer = [its own rows (cap)] [a slot for
+    // every foreign row its rows of C reference, in the order of recv_idx].  A member stores its rows into its own buffer AND into the
+    // halo slots of the members that reference them, so every gather is a local load with buffer-local indices:
+    int* xr_colind = nullptr;      // device: the local CSR column indices remapped to buffer positions (c - row0, or cap + halo slot)
+    int* xr_ellc = nullptr;        // device: the same for the ELL copy ([w][cap])
+    int* xr_pq = nullptr;          // device: [2][n_loc] member that needs local row i (-1: none), up to two per row
+    int* xr_pidx = nullptr;        // device: [2][n_loc] its buffer position there (cap_of_that_member + slot)
+    bool xr_ok = false;            // false: some row is referenced by more than two other members -> lock-step trips
 };
 
 // ------------------------------------------------------------------ in-process stand-in for the communicator
@@ -1099,7 +1108,8 @@ struct IpcShared {
     std::atomic<int> arrived; std::atomic<unsigned long long> gen; std::atomic<int> broken;
     std::atomic<int> attached; std::atomic<int> arena_ready;
     hipIpcMemHandle_t arena;
-    unsigned long long arena_bytes, stage_bytes, mdx_doubles, slot_bytes;
+    unsigned long long arena_bytes, stage_bytes, rows_doubles, slot_bytes;
+    hipIpcMemHandle_t rows_handle[LOCAL_MAX_RANKS];          // every member's exchange buffer (its own allocation, on its own device)
     int vote[LOCAL_MAX_RANKS];
     int plan[LOCAL_MAX_RANKS][4];
     int halo_off[LOCAL_MAX_RANKS][LOCAL_MAX_RANKS], halo_cnt[LOCAL_MAX_RANKS][LOCAL_MAX_RANKS];
@@ -1125,7 +1135,7 @@ struct LocalGroup {
     int members = 0;
     int vote[LOCAL_MAX_RANKS] = {0};
     // cross-rank persistent tCG (msdp_persist.hip XR): what the members' launches share -- two slot regions of the grid
-    // synchronisation, the error word, the exchange buffer of all n rows (uncached device memory)
+    // synchronisation, the error word (fine-grained device memory); the exchange buffers: xr_rows below
     unsigned long long* xr_slots = nullptr;
     int* xr_err = nullptr;
     // the combined launch (member 0 issues it for everybody): every member's Dev and plan, the events that order it behind the
@@ -1134,8 +1144,11 @@ struct LocalGroup {
     int xr_plan[3 * LOCAL_MAX_RANKS] = {0};
     hipEvent_t xr_ready[LOCAL_MAX_RANKS] = {nullptr};
     hipEvent_t xr_done = nullptr;
-    double* xr_mdx = nullptr;
-    size_t xr_mdx_doubles = 0;
+    // the members' exchange buffers of the cross-rank kernels: xr_rows[q] = member q's rows (in-process: all in this address space;
+    // process group: this process's own allocation for q = my_rank, the IPC mappings of the others'), xr_rows_doubles each
+    double* xr_rows[LOCAL_MAX_RANKS] = {nullptr};
+    size_t xr_rows_doubles = 0;
+    int xr_halo_max = 0;          // halo slots behind a member's rows in every buffer (the largest halo of the group)
 };
 static std::mutex g_groups_mutex;
 static std::map<int, LocalGroup*> g_groups;
@@ -1204,20 +1217,25 @@ int msdp_xpersist_reset(hipStream_t stream, unsigned long long* slots, int* err)
 // The shared block of the group: allocated by member 0 the first time (and again when the factor outgrows the exchange buffer)
 static int xr_ensure_shared(msdp_handle h) {
     LocalGroup* g = h->lgroup;
-    size_t need = (size_t)rows_capacity(h) * h->nranks * (size_t)std::max(h->ldcap, 64);
-    if (g->ipc) {                                            // the arena was cut at msdp_comm_init_ipc
-        if (g->xr_mdx_doubles < need) { msdp_set_error("cross-rank persistent tCG: the factor outgrew the arena of this communicator (ld %d)", h->ldcap); return MSDP_ENOMEM; }
+    size_t need = ((size_t)rows_capacity(h) + (size_t)(g->ipc ? g->xr_halo_max : h->xr_halo_rows)) * (size_t)std::max(h->ldcap, 64);   // per member: its rows + halo slots
+    if (g->ipc) {                                            // the buffers were cut at msdp_comm_init_ipc
+        if (g->xr_rows_doubles < need) { msdp_set_error("cross-rank persistent tCG: the factor outgrew the exchange buffers of this communicator (ld %d)", h->ldcap); return MSDP_ENOMEM; }
         return 0;
     }
-    // the members agree on the LARGEST need (member 0's alone decided, a member with a wider factor failed)
+    // the members agree on the LARGEST halo and the largest need (member 0's alone decided, a member with a wider
+    // factor failed)
     {
         int m = 0;
-        int rcv = local_vote_min(h, -(int)((need + 1023) / 1024), &m);
+        int rcv = local_vote_min(h, -h->xr_halo_rows, &m);
         if (rcv) return rcv;
+        const int hmax = -m;
+        need = ((size_t)rows_capacity(h) + (size_t)hmax) * (size_t)std::max(h->ldcap, 64);
+        if ((rcv = local_vote_min(h, -(int)((need + 1023) / 1024), &m))) return rcv;
         need = (size_t)(-m) * 1024;
+        if (h->rank == 0) g->xr_halo_max = hmax;
     }
     int rc = 0;
-    if (h->rank == 0 && (!g->xr_slots || g->xr_mdx_doubles < need)) {
+    if (h->rank == 0 && (!g->xr_slots || g->xr_rows_doubles < need)) {
         if (!g->xr_slots) {
             g->xr_slots = (unsigned long long*)msdp_uc_alloc(msdp_xpersist_slot_bytes() + 256);
             if (g->xr_slots) {
@@ -1226,16 +1244,21 @@ static int xr_ensure_shared(msdp_handle h) {
                 if (hipEventCreateWithFlags(&g->xr_done, hipEventDisableTiming) != hipSuccess) rc = MSDP_EHIP;
             }
         }
-        if (g->xr_mdx) { if (!msdp_uc_free(g->xr_mdx)) (void)hipFree(g->xr_mdx); g->xr_mdx = nullptr; g->xr_mdx_doubles = 0; }
-        g->xr_mdx = (double*)msdp_uc_alloc(need * sizeof(double));
-        if (g->xr_mdx) { g->xr_mdx_doubles = need; if (hipMemset(g->xr_mdx, 0, need * sizeof(double)) != hipSuccess) rc = MSDP_EHIP; }
-        if (!g->xr_slots || !g->xr_mdx) rc = MSDP_ENOMEM;
+        g->xr_rows_doubles = 0;
+        for (int q = 0; q < g->n; ++q) {
+            if (g->xr_rows[q]) { if (!msdp_uc_free(g->xr_rows[q])) (void)hipFree(g->xr_rows[q]); g->xr_rows[q] = nullptr; }
+            g->xr_rows[q] = (double*)msdp_uc_alloc(need * sizeof(double));
+            if (!g->xr_rows[q]) { rc = MSDP_ENOMEM; break; }
+            if (hipMemset(g->xr_rows[q], 0, need * sizeof(double)) != hipSuccess) rc = MSDP_EHIP;
+        }
+        if (!rc) g->xr_rows_doubles = need;
+        if (!g->xr_slots) rc = MSDP_ENOMEM;
     }
     LOCAL_BARRIER(g);
-    if (!g->xr_slots || !g->xr_mdx || g->xr_mdx_doubles < need) { msdp_set_error("cross-rank persistent tCG: shared buffers unavailable"); return rc ? rc : MSDP_ENOMEM; }
+    if (!g->xr_slots || g->xr_rows_doubles < need) { msdp_set_error("cross-rank persistent tCG: shared buffers unavailable"); return rc ? rc : MSDP_ENOMEM; }
     return 0;
 }
-int msdp_xpersist_member(msdp_handle h, int nranks, int rank, double* mdx, Dev* out, int* plan3);        // msdp_persist.hip
+int msdp_xpersist_member(msdp_handle h, int nranks, int rank, double* const* rows, int halo_rows, Dev* out, int* plan3);        // msdp_persist.hip
 int msdp_launch_tcg_xpersist_all(hipStream_t stream, int nranks, const Dev* devs, const int* plans, unsigned long long* slots, int* err);
 // Start of a trustregions() call on the cross-rank path: member 0 clears both slot regions and the error word; nobody goes on before
 static int xr_begin(msdp_handle h, bool* use) {
@@ -1248,7 +1271,7 @@ static int xr_begin(msdp_handle h, bool* use) {
     if (g->ipc) {
         // the plan of the call: lanes per row and row slots must agree, a differing ELL width sends everybody to the CSR form
         Dev dv; int pl[3];
-        if ((rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_mdx, &dv, pl))) { local_break(g); return rc; }
+        if ((rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_rows, g->xr_halo_max, &dv, pl))) { local_break(g); return rc; }
         for (int q = 0; q < 3; ++q) g->shm->plan[h->rank][q] = pl[q];
         LOCAL_BARRIER(g);
         g->ipc_ew = pl[1];
@@ -1275,7 +1298,7 @@ static int xr_launch(msdp_handle h) {
         // queues; the launches meet in the first grid synchronisation, a bounded spin turns a member that never comes into MSDP_ECOMM).
         // The members agreed on the plan in xr_begin: no host exchange per launch.
         Dev dv; int pl[3];
-        if ((rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_mdx, &dv, pl))) { local_break(g); return rc; }
+        if ((rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_rows, g->xr_halo_max, &dv, pl))) { local_break(g); return rc; }
         pl[1] = g->ipc_ew;
         if (h->tune.fail_xr) { h->tune.fail_xr = 0; dv.xr_gtot += 8; }
         if ((rc = msdp_launch_tcg_xpersist_one(h->stream, dv, pl, g->xr_slots, g->xr_err))) { local_break(g); return rc; }
@@ -1283,7 +1306,7 @@ static int xr_launch(msdp_handle h) {
     }
     {
         Dev dv; int pl[3];
-        if ((rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_mdx, &dv, pl))) { local_break(g); return rc; }
+        if ((rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_rows, g->xr_halo_max, &dv, pl))) { local_break(g); return rc; }
         HIPCHK(hipEventRecord(h->xr_ev, h->stream));
         std::lock_guard<std::mutex> lk(g->m);
         g->xr_dev[h->rank] = dv;
@@ -1308,7 +1331,7 @@ int msdp_launch_tr_tail_xr(hipStream_t stream, const Dev& dv, unsigned long long
 static int xr_tail(msdp_handle h) {
     LocalGroup* g = h->lgroup;
     Dev dv; int pl[3];
-    int rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_mdx, &dv, pl);
+    int rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_rows, g->xr_halo_max, &dv, pl);
     if (!rc) rc = msdp_launch_tr_tail_xr(h->stream, dv, g->xr_slots, g->xr_err);
     if (rc) local_break(g);
     return rc;
@@ -1407,6 +1430,7 @@ static void local_leave(msdp_handle h) {
     if (g->ipc) {
         // the arena belongs to rank 0 (the mappings of the others keep its memory alive until they close them)
         if (g->arena) { if (g->my_rank == 0) (void)hipFree(g->arena); else (void)hipIpcCloseMemHandle(g->arena); }
+        for (int q = 0; q < g->n; ++q) if (g->xr_rows[q]) { if (q == g->my_rank) (void)hipFree(g->xr_rows[q]); else (void)hipIpcCloseMemHandle(g->xr_rows[q]); }
         if (g->shm) (void)munmap((void*)g->shm, sizeof(IpcShared));
         if (g->my_rank == 0 && !g->shm_name.empty()) (void)shm_unlink(g->shm_name.c_str());
         delete g;
@@ -1415,7 +1439,7 @@ static void local_leave(msdp_handle h) {
     if (--g->members == 0) {
         for (auto it = g_groups.begin(); it != g_groups.end(); ++it) if (it->second == g) { g_groups.erase(it); break; }
         if (g->xr_slots && !msdp_uc_free(g->xr_slots)) (void)hipFree(g->xr_slots);
-        if (g->xr_mdx && !msdp_uc_free(g->xr_mdx)) (void)hipFree(g->xr_mdx);
+        for (int q = 0; q < LOCAL_MAX_RANKS; ++q) if (g->xr_rows[q] && !msdp_uc_free(g->xr_rows[q])) (void)hipFree(g->xr_rows[q]);
         if (g->xr_done) (void)hipEventDestroy(g->xr_done);
         delete g;
     }
@@ -1452,8 +1476,14 @@ static void halo_release(msdp_handle h) {
     if (ha->recv_idx) (void)hipFree(ha->recv_idx);
     if (ha->sendbuf) (void)hipFree(ha->sendbuf);
     if (ha->recvbuf) (void)hipFree(ha->recvbuf);
+    if (ha->xr_colind) (void)hipFree(ha->xr_colind);
+    if (ha->xr_ellc) (void)hipFree(ha->xr_ellc);
+    if (ha->xr_pq) (void)hipFree(ha->xr_pq);
+    if (ha->xr_pidx) (void)hipFree(ha->xr_pidx);
     delete ha;
     h->halo = nullptr;
+    h->d.xr_colind = h->d.xr_ellc = h->d.xr_pq = h->d.xr_pidx = nullptr; h->xr_ok = false; h->xr_halo_rows = 0;
+    h->xr_paddr_pq = nullptr; h->d.xr_paddr = nullptr;   // (the push addresses are rebuilt from the next partition's lists)
 }
 // Lists for the current partition (called by comm_partition for sparse C); buffers follow the vectors' capacity
 static int halo_setup(msdp_handle h) {
@@ -1467,6 +1497,9 @@ static int halo_setup(msdp_handle h) {
     std::vector<std::vector<int>> send_rows(N);          // what I send to q (local indices), in the order q will unpack
     std::vector<int> recv_rows;
     std::vector<char> mark((size_t)n, 0);
+    const int my0 = std::min(n, me * cap), my1 = std::min(n, my0 + cap), nloc = my1 - my0;
+    std::vector<int> pq((size_t)2 * std::max(nloc, 1), -1), pidx((size_t)2 * std::max(nloc, 1), 0);
+    bool push_ok = true;
     for (int q = 0; q < N; ++q) {
         const int q0 = std::min(n, q * cap), q1 = std::min(n, q0 + cap);
         std::vector<int> need;
@@ -1484,6 +1517,15 @@ static int halo_setup(msdp_handle h) {
             const int m0 = std::min(n, me * cap), m1 = std::min(n, m0 + cap);
             for (int c : need) if (c >= m0 && c < m1) send_rows[q].push_back(c - m0);
             ha->send_cnt[q] = (int)send_rows[q].size();
+            // push exchange: my row c sits at position cap + (index of c in q's sorted need list) of q's buffer
+            for (size_t k = 0; k < need.size(); ++k) {
+                const int c = need[k];
+                if (c < m0 || c >= m1) continue;
+                const int i = c - m0;
+                if (pq[i] < 0) { pq[i] = q; pidx[i] = cap + (int)k; }
+                else if (pq[(size_t)nloc + i] < 0) { pq[(size_t)nloc + i] = q; pidx[(size_t)nloc + i] = cap + (int)k; }
+                else push_ok = false;
+            }
         }
     }
     std::vector<int> sidx;
@@ -1497,6 +1539,30 @@ static int halo_setup(msdp_handle h) {
     };
     int rc = upi(sidx, &ha->send_idx);
     if (!rc) rc = upi(recv_rows, &ha->recv_idx);
+    // push exchange: buffer-local column indices of my rows (CSR and ELL copies), push targets
+    if (!rc) {
+        std::vector<int> gmap((size_t)n, -1);
+        for (int c = my0; c < my1; ++c) gmap[c] = c - my0;
+        for (size_t k = 0; k < recv_rows.size(); ++k) gmap[recv_rows[k]] = cap + (int)k;
+        const int base = nloc > 0 ? h->h_rowptr[my0] : 0, nnzl = nloc > 0 ? h->h_rowptr[my1] - base : 0;
+        std::vector<int> xcol((size_t)std::max(nnzl, 1), 0);
+        for (int t = 0; t < nnzl; ++t) xcol[t] = gmap[h->h_colind[base + t]];
+        rc = upi(xcol, &ha->xr_colind);
+        if (!rc && h->d.ellW > 0) {
+            const int W = h->d.ellW;
+            std::vector<int> ec((size_t)W * cap);
+            for (int w = 0; w < W; ++w) for (int i = 0; i < cap; ++i) ec[(size_t)w * cap + i] = std::min(i, nloc > 0 ? nloc - 1 : 0);    // padding: (own row, 0.0)
+            for (int i = 0; i < nloc; ++i)
+                for (int t = h->h_rowptr[my0 + i]; t < h->h_rowptr[my0 + i + 1] && t - h->h_rowptr[my0 + i] < W; ++t)
+                    ec[(size_t)(t - h->h_rowptr[my0 + i]) * cap + i] = gmap[h->h_colind[t]];
+            rc = upi(ec, &ha->xr_ellc);
+        }
+        if (!rc) rc = upi(pq, &ha->xr_pq);
+        if (!rc) rc = upi(pidx, &ha->xr_pidx);
+        ha->xr_ok = push_ok && !rc;
+        h->d.xr_colind = ha->xr_colind; h->d.xr_ellc = ha->xr_ellc; h->d.xr_pq = ha->xr_pq; h->d.xr_pidx = ha->xr_pidx;
+        h->xr_ok = ha->xr_ok; h->xr_halo_rows = (int)recv_rows.size();
+    }
     if (!rc && hipMalloc((void**)&ha->sendbuf, (size_t)std::max(ha->send_rows, 1) * ha->ldcap * sizeof(double)) != hipSuccess) rc = MSDP_ENOMEM;
     if (!rc && hipMalloc((void**)&ha->recvbuf, (size_t)std::max(ha->recv_rows, 1) * ha->ldcap * sizeof(double)) != hipSuccess) rc = MSDP_ENOMEM;
     h->halo = ha;
@@ -1712,9 +1778,11 @@ extern "C" int msdp_comm_init_ipc(msdp_handle h, int32_t nranks, int32_t rank, c
     IpcShared* sh = g->shm;
     const size_t slot_bytes = msdp_xpersist_slot_bytes() + 256;
     const size_t ldx = (size_t)std::max(h->ldcap, 64);
-    const size_t mdx_doubles = (size_t)rows_capacity(h) * nranks * ldx;
+    // every member's own exchange buffer: its rows + a slot for every foreign row it references (the largest halo of the group: the
+    // members vote below, through the segment)
+    sh->vote[rank] = h->xr_halo_rows;
     const size_t stage = std::max<size_t>(((size_t)rows_capacity(h) * ldx * sizeof(double) + 255) / 256 * 256, (size_t)1 << 16);
-    const size_t total = slot_bytes + mdx_doubles * sizeof(double) + (size_t)nranks * stage;
+    const size_t total = slot_bytes + (size_t)nranks * stage;
     if (rank == 0) {
         void* p = nullptr;
         if (hipExtMallocWithFlags(&p, total, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("comm_init_ipc: arena allocation of %zu bytes failed", total); local_break(g); return MSDP_ENOMEM; }
@@ -1723,7 +1791,7 @@ extern "C" int msdp_comm_init_ipc(msdp_handle h, int32_t nranks, int32_t rank, c
         hipIpcMemHandle_t hd;
         if (hipIpcGetMemHandle(&hd, p) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); msdp_set_error("comm_init_ipc: hipIpcGetMemHandle failed"); local_break(g); return MSDP_ECOMM; }
         g->arena = (char*)p;
-        sh->arena = hd; sh->arena_bytes = total; sh->stage_bytes = stage; sh->mdx_doubles = mdx_doubles; sh->slot_bytes = slot_bytes;
+        sh->arena = hd; sh->arena_bytes = total; sh->stage_bytes = stage; sh->slot_bytes = slot_bytes;
         sh->arena_ready.store(1);
     } else {
         const auto t0 = std::chrono::steady_clock::now();
@@ -1739,12 +1807,35 @@ extern "C" int msdp_comm_init_ipc(msdp_handle h, int32_t nranks, int32_t rank, c
     }
     g->xr_slots = (unsigned long long*)g->arena;
     g->xr_err = (int*)(g->arena + msdp_xpersist_slot_bytes());
-    g->xr_mdx = (double*)(g->arena + slot_bytes);
-    g->xr_mdx_doubles = mdx_doubles;
-    g->stage = g->arena + slot_bytes + mdx_doubles * sizeof(double);
+    g->stage = g->arena + slot_bytes;
     g->stage_bytes = stage;
     sh->attached.fetch_add(1);
-    LOCAL_BARRIER(g);                                        // everybody has mapped the arena
+    LOCAL_BARRIER(g);                                        // everybody has mapped the arena; the halo sizes are in the segment
+    size_t hmax = 0;
+    for (int q = 0; q < nranks; ++q) hmax = std::max<size_t>(hmax, (size_t)sh->vote[q]);
+    const size_t rows_doubles = ((size_t)rows_capacity(h) + hmax) * ldx;
+    g->xr_halo_max = (int)hmax;
+    // the exchange buffer of MY rows (+ my halo slots): my own allocation (on my device), exported; then the others', mapped
+    {
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, rows_doubles * sizeof(double), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("comm_init_ipc: exchange buffer allocation failed"); local_break(g); return MSDP_ENOMEM; }
+        HIPCHK(hipMemset(p, 0, rows_doubles * sizeof(double)));
+        HIPCHK(hipDeviceSynchronize());
+        hipIpcMemHandle_t hd;
+        if (hipIpcGetMemHandle(&hd, p) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); msdp_set_error("comm_init_ipc: hipIpcGetMemHandle (exchange buffer) failed"); local_break(g); return MSDP_ECOMM; }
+        g->xr_rows[rank] = (double*)p;
+        sh->rows_handle[rank] = hd;
+    }
+    LOCAL_BARRIER(g);                                        // everybody has exported its buffer
+    for (int q = 0; q < nranks; ++q) {
+        if (q == rank) continue;
+        void* p = nullptr;
+        hipIpcMemHandle_t hd = sh->rows_handle[q];
+        if (hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("comm_init_ipc: hipIpcOpenMemHandle (exchange buffer of rank %d) failed", q); local_break(g); return MSDP_ECOMM; }
+        g->xr_rows[q] = (double*)p;
+    }
+    g->xr_rows_doubles = rows_doubles;
+    LOCAL_BARRIER(g);
     return 0;
 }
 

@@ -129,9 +129,19 @@ struct Dev {
     // msdp_debug_persist_trace: s_memtime stamps of the phases of the persistent tCG trip (traced kernel instance only), else null
     unsigned long long* trace;
     // cross-rank persistent tCG (msdp_persist.hip, XR): this rank's first workgroup index among all ranks' workgroups, their total,
-    // the exchange buffer all ranks share (all n rows; uncached memory, sc1 accesses only)
+    // the members' exchange buffers (sc1 accesses only)
     int xr_gid0, xr_gtot;
-    double* xr_mdx;
+    // round 5: every member keeps the exchanged rows of ITS rows in its OWN buffer (local HBM on its device; the others map it through
+    // HIP IPC / peer access, or simply share the address space): xr_rows[q] = member q's buffer as this process sees it, xr_cap rows each
+    // (the row capacity of a rank), xr_me = this member.  A gather of row c goes to member c / xr_cap -- its own for most rows of a
+    // partition with locality.
+    double* xr_rows[4];
+    int xr_cap, xr_me, xr_halo;
+    // "push" exchange (msdp_api.hip halo_setup): a member's buffer = [its rows (xr_cap)] [one slot per foreign row its rows of C
+    // reference]; buffer-local column indices of its rows (ELL copy [w][xr_cap] and CSR), and for every local row up to two
+    // (member, position there) pairs it has to be stored to as well ([2][n_loc], member -1 = none)
+    const int* xr_ellc; const int* xr_colind; const int* xr_pq; const int* xr_pidx;
+    const unsigned long long* xr_paddr;   // [2][n_loc] address of local row i's slot in the buffer of a member that references it (0: none); built by msdp_xpersist_member
     int persist_slots;    // A/B: row slots of the persistent tCG plan at p = 17..32 (0: planned)
 };
 
@@ -233,6 +243,8 @@ struct msdp_handle_s {
     // its rows of C reference (msdp_api.hip, "Halo exchange")
     struct Halo* halo = nullptr;
     struct LocalGroup* lgroup = nullptr;   // in-process stand-in for the RCCL communicator (msdp_comm_init_local)
+    unsigned long long* xr_paddr = nullptr; size_t xr_paddr_cap = 0; double* xr_paddr_key[4] = {nullptr, nullptr, nullptr, nullptr}; int xr_paddr_ld = 0, xr_paddr_n = 0; const int* xr_paddr_pq = nullptr;   // cross-rank push addresses and what they were built from
+    bool xr_ok = false; int xr_halo_rows = 0;   // push exchange of the cross-rank kernels: usable (no row needed by more than two members), foreign rows referenced
     struct WinCache* win = nullptr;        // patch plans of the LDS-staged S*U (msdp_window.hip), one per lanes-per-row
     void* blk_ws = nullptr; size_t blk_ws_cap = 0;   // workspace of msdp_block_eigs (msdp_blockjacobi.hip)
     double* lc_tmp = nullptr; size_t lc_tmp_cap = 0;   // its reduction scratch

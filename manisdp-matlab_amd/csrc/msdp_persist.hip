@@ -53,7 +53,7 @@ __global__ void k_psync_reset(unsigned long long* slots, int* err) {
         d.trace[((size_t)bx * MSDP_TRACE_NJ + (j - MSDP_TRACE_J0)) * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
 // XR (cross-rank, round 4): the launches of N ranks -- N x d.G workgroups, all co-resident -- run ONE tCG together: the grid
 // reductions span the ranks (shared slot regions, workgroup index d.xr_gid0 + blockIdx.x of d.xr_gtot), the residual / direction rows
-// travel through one exchange buffer of all n rows (d.xr_mdx, global row indices), and no collective is issued per trip.  Same
+// travel through the members' exchange buffers (d.xr_rows[q]: member q's rows, in q's own memory), and no collective is issued per trip.  Same
 // arithmetic per row as the one-rank kernel; the sums are formed over d.xr_gtot partials in index order on every rank (same bits on
 // every rank -> same decisions).  Two slot regions alternate with the TR iteration; each launch clears the other one at its start.
 template <int LPR, int EW, int R, bool FUSE, bool TRACE, bool XR, bool EARLYP>
@@ -194,8 +194,13 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         double vw[EW > 0 ? EW : 1];
 #pragma unroll
         for (int w = 0; w < EW; ++w) {
-            cw[w] = d.ellc[(int64_t)w * d.ell_stride + rc];
+            cw[w] = XR ? d.xr_ellc[(int64_t)w * d.ell_stride + rc] : d.ellc[(int64_t)w * d.ell_stride + rc];
             vw[w] = d.ellv[(int64_t)w * d.ell_stride + rc];
+        }
+        if (XR && sub == 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)                            // push targets of this row (slot addresses, 0: none)
+                reinterpret_cast<unsigned long long*>(YPs)[t * ROWS + SLOT(r)] = rok ? d.xr_paddr[(int64_t)t * d.n_loc + rc] : 0ULL;
         }
         if (sub == 0) {
             eGs[SLOT(r)] = rok ? egv : 0.0;
@@ -210,12 +215,36 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     __syncthreads();
 
     unsigned gen = 0, nbar = 0;
-    const unsigned xrow0 = XR ? (unsigned)d.row0 : 0u;             // my rows inside the exchange buffer
+    const unsigned xrow0 = 0u;                                     // (stores into the exchange buffer use local row numbers on every path)
+    const unsigned xglob0 = 0u;                                    // (XR: the column indices are buffer-local, d.xr_ellc / d.xr_colind)
     const unsigned vec_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
     // (EARLY: two halves of n_loc x ld doubles each)
     const unsigned half_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
-    __amdgpu_buffer_rsrc_t rs_md = XR ? __builtin_amdgcn_make_buffer_rsrc(d.xr_mdx, 0, (unsigned)((size_t)d.n * d.ld * sizeof(double)), 0x00020000)
+    // XR ("push" exchange, round 5): rs_md = this member's own exchange buffer -- its rows followed by a slot for every foreign row its
+    // rows of C reference; ALL gathers are local loads with buffer-local indices (d.xr_ellc / d.xr_colind).  The owner of a row stores
+    // it into its own buffer and into the halo slots of the members that reference it (d.xr_paddr: the slots' addresses).
+    const unsigned xr_bytes = XR ? (unsigned)(((size_t)d.xr_cap + (size_t)d.xr_halo) * d.ld * sizeof(double)) : 0u;
+    double* xr_own = d.xr_rows[0];                                 // (selects, not a dynamic index: that would put the kernel-argument array into scratch)
+    if (XR) { if (d.xr_me == 1) xr_own = d.xr_rows[1]; if (d.xr_me == 2) xr_own = d.xr_rows[2]; if (d.xr_me == 3) xr_own = d.xr_rows[3]; }
+    __amdgpu_buffer_rsrc_t rs_md = XR ? __builtin_amdgcn_make_buffer_rsrc(xr_own, 0, xr_bytes, 0x00020000)
                                       : __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, (EARLY ? 2u : 1u) * half_bytes, 0x00020000);
+    // XR: this lane's 16 bytes of local row slot r also go to the members that reference the row: plain address arithmetic on a
+    // descriptor held in LDS, no branch per member (the boundary waves are on the critical path of the reduction that follows)
+    unsigned long long* pds = reinterpret_cast<unsigned long long*>(YPs);   // [2][ROWS] slot address (0: none)   (XR is never FUSE: the region is free)
+    bool xr_has_push = false, xr_has_push2 = false;                // wave-uniform: some row of this wave is referenced by another member / by two (set below)
+    auto xr_push = [&](int r, double2 v) {
+        if (!xr_has_push) return;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t == 1 && !xr_has_push2) continue;
+            const unsigned long long a = pds[t * ROWS + SLOT(r)];
+            if (a != 0ULL && OK(r)) {
+                double* ptr = reinterpret_cast<double*>(a) + 2 * sub;
+                __hip_atomic_store(ptr, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ptr + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
     const double2 sent2 = make_double2(__longlong_as_double((long long)PSYNC_SENT), __longlong_as_double((long long)PSYNC_SENT));
     // my rows of half q back to the sentinel
     auto reset_half = [&](int q) {
@@ -225,8 +254,15 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     int xq = 0;                      // EARLY: the half the next publication goes to
     int pend = -1;                   // EARLY: the half to put back to the sentinel behind the next reduction 1 (-1: none)
     if (EARLY) { reset_half(0); reset_half(1); }                   // (whatever an earlier launch left; the first look at them is behind reduction 1 of trip 1)
+    if (XR) {
+        bool any = false, any2 = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { any = any || pds[SLOT(r)] != 0ULL; any2 = any2 || pds[ROWS + SLOT(r)] != 0ULL; }
+        xr_has_push2 = __builtin_amdgcn_ballot_w64(any2) != 0ULL;
+        xr_has_push = xr_has_push2 || __builtin_amdgcn_ballot_w64(any) != 0ULL;
+    }
     // byte offsets of the R x EW gathers of a trip (the same in the gradient buffer and in the exchange buffer: both have row stride ld)
-    constexpr bool GOFF = ALLG && !EARLY && R * EW <= 15;        // (more row slots: the extra registers spill)
+    constexpr bool GOFF = ALLG && !EARLY && !XR && R * EW <= 15;        // (more row slots: the extra registers spill)
     const bool use_goff = GOFF && c->persist_goff != 0;
     unsigned goff[GOFF ? R : 1][GOFF ? EW : 1];
     if (GOFF) {
@@ -258,7 +294,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     if (XR) {
         // the first direction = the gradient, whose rows live in every rank's own buffer: hand them to the other ranks first
 #pragma unroll
-        for (int r = 0; r < R; ++r) if (OK(r)) st2_sc1(rs_md, ((xrow0 + (unsigned)ROW(r)) * (unsigned)d.ld + 2 * sub) * 8u, MD_GET(r));
+        for (int r = 0; r < R; ++r) { if (OK(r)) st2_sc1(rs_md, ((xrow0 + (unsigned)ROW(r)) * (unsigned)d.ld + 2 * sub) * 8u, MD_GET(r)); xr_push(r, MD_GET(r)); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!pbarrier(slots, nbar++, GS, shb, err, bid)) return;
     }
@@ -297,7 +333,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
                 for (int u = 0; u < 8; ++u) {
                     const bool in = s0 + u < s1;
                     const int k = in ? s0 + u : (s1 > s0 ? s1 - 1 : 0);
-                    cn[u] = (s1 > s0) ? d.colind[k] : (int)xrow0 + ROW(r);
+                    cn[u] = (s1 > s0) ? (XR ? d.xr_colind[k] : d.colind[k]) : (XR ? ROW(r) : (int)xglob0 + ROW(r));
                     vn[u] = in ? d.cval[k] : 0.0;
                 }
                 for (int k0 = s0; k0 < s1; k0 += 8) {
@@ -314,7 +350,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
                         for (int u = 0; u < 8; ++u) {
                             const bool in = k0 + 8 + u < s1;
                             const int k = in ? k0 + 8 + u : s1 - 1;
-                            cn[u] = d.colind[k];
+                            cn[u] = XR ? d.xr_colind[k] : d.colind[k];
                             vn[u] = in ? d.cval[k] : 0.0;
                         }
                     }
@@ -433,7 +469,9 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
                 // the re-projection of mdelta removes (:283) and what the assembled product would otherwise keep and amplify
                 const double2 y = Y_GET(r);
                 const double dn = msdp_group_sum<LPR>(nr.x * y.x + nr.y * y.y);
-                if (OK(r)) st2_sc1(rs_md, qoff + ((xrow0 + (unsigned)ROW(r)) * (unsigned)d.ld + 2 * sub) * 8u, make_double2(nr.x - y.x * dn, nr.y - y.y * dn));
+                const double2 tr = make_double2(nr.x - y.x * dn, nr.y - y.y * dn);
+                if (OK(r)) st2_sc1(rs_md, qoff + ((xrow0 + (unsigned)ROW(r)) * (unsigned)d.ld + 2 * sub) * 8u, tr);
+                if (XR) xr_push(r, tr);
             }
         }
         if (EARLY && !refresh_now) {
@@ -555,6 +593,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             const double2 mnew = make_double2(v.x - y.x * dot, v.y - y.y * dot);
             MD_SET(r, mnew);
             if ((!TWOSYNC || refresh_now) && OK(r)) st2_sc1(rs_md, qoff + ((xrow0 + (unsigned)ROW(r)) * (unsigned)d.ld + 2 * sub) * 8u, mnew);
+            if (XR && (!TWOSYNC || refresh_now)) xr_push(r, mnew);
         }
         if (!TWOSYNC || refresh_now) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my rows are performed before my workgroup posts
@@ -969,6 +1008,7 @@ static xr4_fn xr4_kernel(int lpr, int ew, int r) {
 static bool xr_plan(msdp_handle h, int nranks, PersistPlan& pl, int* G_out) {
     const Dev& d = h->d;
     if (!h->tune.persist || !h->tune.xpersist || h->persist_failed || d.costkind != COST_SPARSE || d.manifold != MANI_OBLIQUE || d.rowfree) return false;
+    if (!h->xr_ok || !d.xr_colind || !d.xr_pq) return false;     // a row referenced by more than two other members: lock-step trips
     int G = (256 / nranks) & ~7;
     if (G < 8 || nranks < 2 || nranks > 4) return false;
     Dev dc = d;
@@ -982,7 +1022,7 @@ static bool xr_plan(msdp_handle h, int nranks, PersistPlan& pl, int* G_out) {
 }
 static size_t xr_lds(int lpr, int ew, int r) {
     const size_t rows = (size_t)r * PWAVES * (64 / lpr);
-    return (size_t)2 * r * PB * sizeof(double2) + rows * sizeof(double) + (size_t)ew * rows * (sizeof(double) + sizeof(int));
+    return (size_t)2 * r * PB * sizeof(double2) + rows * sizeof(double) + (size_t)ew * rows * (sizeof(double) + sizeof(int)) + 16 + 4 * rows * sizeof(int);   // + the push descriptors
 }
 int msdp_xpersist_eligible(msdp_handle h, int nranks) {
     PersistPlan pl; int G = 0;
@@ -1000,11 +1040,41 @@ int msdp_xpersist_reset(hipStream_t stream, unsigned long long* slots, int* err)
     return 0;
 }
 // This member's Dev for the combined launch and its plan {lanes per row, ELL width (0: CSR), row slots}
-int msdp_xpersist_member(msdp_handle h, int nranks, int rank, double* mdx, Dev* out, int* plan3) {
+// slot addresses of the push exchange: row i of this member -> &rows[q][(position there) * ld] for each member q that references it
+__global__ void k_xr_paddr(const int* __restrict__ pq, const int* __restrict__ pidx, double* r0, double* r1, double* r2, double* r3, int ld, int n_loc,
+                           unsigned long long* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n_loc) return;
+    const int q = pq[i];
+    double* base = q == 1 ? r1 : q == 2 ? r2 : q == 3 ? r3 : r0;
+    out[i] = q < 0 ? 0ULL : (unsigned long long)(base + (int64_t)pidx[i] * ld);
+}
+int msdp_xpersist_member(msdp_handle h, int nranks, int rank, double* const* rows, int halo_rows, Dev* out, int* plan3) {
     PersistPlan pl; int G = 0;
     if (!xr_plan(h, nranks, pl, &G)) { msdp_set_error("cross-rank persistent tCG: not eligible"); return MSDP_ESTATE; }
     *out = h->d;
-    out->G = G; out->xr_gid0 = rank * G; out->xr_gtot = nranks * G; out->xr_mdx = mdx; out->status = nullptr; out->trace = nullptr;
+    out->G = G; out->xr_gid0 = rank * G; out->xr_gtot = nranks * G; out->status = nullptr; out->trace = nullptr;
+    for (int q = 0; q < 4; ++q) out->xr_rows[q] = rows[q < nranks ? q : rank];
+    out->xr_cap = (h->d.n + nranks - 1) / nranks; out->xr_me = rank; out->xr_halo = halo_rows;
+    {   // the push addresses follow the members' buffers, the leading dimension and the partition
+        bool same = h->xr_paddr && h->xr_paddr_ld == h->d.ld && h->xr_paddr_n == h->d.n_loc && h->xr_paddr_pq == h->d.xr_pq;
+        for (int q = 0; q < 4; ++q) same = same && h->xr_paddr_key[q] == out->xr_rows[q];
+        if (!same) {
+            const size_t need = (size_t)2 * (size_t)h->d.n_loc;
+            if (h->xr_paddr_cap < need) {
+                if (h->xr_paddr) (void)hipFree(h->xr_paddr);
+                h->xr_paddr = nullptr; h->xr_paddr_cap = 0;
+                if (hipMalloc(&h->xr_paddr, need * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("cross-rank persistent tCG: out of device memory"); return MSDP_ENOMEM; }
+                h->xr_paddr_cap = need;
+            }
+            if (need) hipLaunchKernelGGL(k_xr_paddr, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, h->stream, h->d.xr_pq, h->d.xr_pidx,
+                                         out->xr_rows[0], out->xr_rows[1], out->xr_rows[2], out->xr_rows[3], h->d.ld, h->d.n_loc, h->xr_paddr);
+            if (hipGetLastError() != hipSuccess) { msdp_set_error("cross-rank persistent tCG: launch failed"); return MSDP_EHIP; }
+            for (int q = 0; q < 4; ++q) h->xr_paddr_key[q] = out->xr_rows[q];
+            h->xr_paddr_ld = h->d.ld; h->xr_paddr_n = h->d.n_loc; h->xr_paddr_pq = h->d.xr_pq;
+        }
+        out->xr_paddr = h->xr_paddr;
+    }
     plan3[0] = pl.lpr; plan3[1] = pl.ew; plan3[2] = pl.r;
     return 0;
 }

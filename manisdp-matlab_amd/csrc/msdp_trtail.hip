@@ -13,8 +13,8 @@
 #include <cstdlib>
 
 // XR (round 5): the members of a row-sharded group run the tail TOGETHER, like the cross-rank persistent tCG in front of it
-// (msdp_persist.hip): the proposal rows travel through the group's exchange buffer of all n rows (global row numbers; the tCG does
-// not touch it between its last reduction and its next launch), the barrier and the reduction run over the N x G slots of a slot
+// (msdp_persist.hip): the proposal rows travel through the members' exchange buffers (every member writes its rows into its own; the
+// tCG does not touch them between its last reduction and its next launch), the barrier and the reduction run over the N x G slots of a slot
 // region of the group (regions 2 and 3 of the shared block, alternating with the TR iteration; every launch clears the other one),
 // and every member takes the decision of trustregions.m:548-729 from the same sums in the same order -- no collective.
 template <int LPR, bool XR = false>
@@ -52,10 +52,24 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
     const double* __restrict__ eta = ix ? d.eta[1] : d.eta[0];
     const double* __restrict__ Heta = ix ? d.Heta[1] : d.Heta[0];
     const unsigned vec_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
-    __amdgpu_buffer_rsrc_t rs_yp = XR ? __builtin_amdgcn_make_buffer_rsrc(d.xr_mdx, 0, (unsigned)((size_t)d.n * d.ld * sizeof(double)), 0x00020000)
+    // XR ("push" exchange, msdp_persist.hip): the proposal rows go to this member's own exchange buffer and to the halo slots of the
+    // members that reference them; every gather is a local load with the buffer-local column indices d.xr_colind
+    const unsigned xr_bytes = XR ? (unsigned)(((size_t)d.xr_cap + (size_t)d.xr_halo) * d.ld * sizeof(double)) : 0u;
+    double* xr_own = d.xr_rows[0];
+    if (XR) { if (d.xr_me == 1) xr_own = d.xr_rows[1]; if (d.xr_me == 2) xr_own = d.xr_rows[2]; if (d.xr_me == 3) xr_own = d.xr_rows[3]; }
+    __amdgpu_buffer_rsrc_t rs_yp = XR ? __builtin_amdgcn_make_buffer_rsrc(xr_own, 0, xr_bytes, 0x00020000)
                                       : __builtin_amdgcn_make_buffer_rsrc(cur ? d.Y[0] : d.Y[1], 0, vec_bytes, 0x00020000);
+    auto xr_push = [&](int row, bool ok, double2 v) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned long long a = ok ? d.xr_paddr[(int64_t)t * d.n_loc + row] : 0ULL;
+            if (a == 0ULL) continue;
+            double* ptr = reinterpret_cast<double*>(a) + 2 * sub;
+            __hip_atomic_store(ptr, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ptr + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     double* __restrict__ Ypl = cur ? d.Y[0] : d.Y[1];          // XR: the member's own copy of its proposal rows
-    const unsigned xrow0 = XR ? (unsigned)d.row0 : 0u;
     double* __restrict__ Gp = cur ? d.Gr[0] : d.Gr[1];
     double* __restrict__ eGp = cur ? d.eG[0] : d.eG[1];
     const double2 zz = make_double2(0.0, 0.0);
@@ -83,7 +97,8 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
             if (!(nn > 0.0)) nn = 1.0;
             const double2 ypr = ok ? make_double2(x.x / nn, x.y / nn) : zz;
             if (r < rcap) YPs[r * PB + threadIdx.x] = ypr;
-            if (ok) st2_sc1(rs_yp, ((xrow0 + (unsigned)row) * (unsigned)d.ld + 2 * sub) * 8u, ypr);
+            if (ok) st2_sc1(rs_yp, ((unsigned)row * (unsigned)d.ld + 2 * sub) * 8u, ypr);
+            if (XR) xr_push(row < hi ? row : lo, ok, ypr);
             if (XR && ok) st2(Ypl + (int64_t)row * d.ld + 2 * sub, ypr);
         }
     }
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
                     const bool in = s0[q] + kb + u < s1[q];
                     const int k = in ? s0[q] + kb + u : (s1[q] > s0[q] ? s1[q] - 1 : 0);
                     cv[q][u] = in ? d.cval[k] : 0.0;
-                    const int col = (s1[q] > s0[q]) ? d.colind[k] : lo + (int)xrow0;
+                    const int col = (s1[q] > s0[q]) ? (XR ? d.xr_colind[k] : d.colind[k]) : lo;
                     x[q][u] = ld2_sc1(rs_yp, ((unsigned)col * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u);
                 }
             }
@@ -205,7 +220,7 @@ int msdp_launch_tr_tail(msdp_handle h) {
 }
 
 // XR: this member's launch of the tail the group runs together (separate processes: msdp_comm_init_ipc).  `dv` = the member's Dev as
-// msdp_xpersist_member filled it (G, xr_gid0, xr_gtot, xr_mdx), slots = the group's shared block (regions 2 / 3).
+// msdp_xpersist_member filled it (G, xr_gid0, xr_gtot, xr_rows), slots = the group's shared block (regions 2 / 3).
 int msdp_launch_tr_tail_xr(hipStream_t stream, const Dev& dv, unsigned long long* slots, int* err) {
     const int lpr = tail_lpr(dv);
     if (lpr > 32) { msdp_set_error("cross-rank TR tail: not eligible"); return MSDP_ESTATE; }
