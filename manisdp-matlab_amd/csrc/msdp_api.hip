@@ -303,8 +303,9 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
     if (d.mdx) dev_free(h, d.mdx);
     d.mdx = nullptr;
     {
-        // two halves: the EARLY trips of the persistent tCG alternate between them (msdp_persist.hip)
-        const size_t xcnt = 2 * cnt;
+        // four regions of one vector each: the EARLY trips of the persistent tCG alternate between the first two (msdp_persist.hip), the
+        // one-reduction trips too and use the other two for their direct exchanges (msdp_pipe.h)
+        const size_t xcnt = 4 * cnt;
         int rc = dev_alloc_uncached<double>(h, &d.mdx, xcnt);
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(d.mdx, 0, xcnt * sizeof(double), h->stream));
@@ -1019,6 +1020,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "window")) { t.window = value < 0 ? 0 : (value > 3 ? 3 : value); h->chunk_len = 0; }
     else if (!strcmp(name, "window_lds")) { t.window_lds = value < 16 ? 16 : (value > 144 ? 144 : value); h->chunk_len = 0; msdp_window_release(h); }
     else if (!strcmp(name, "persist_early")) t.persist_early = value > 0 ? value : 0;
+    else if (!strcmp(name, "persist_pipe")) t.persist_pipe = value > 0 ? 1 : 0;
     else if (!strcmp(name, "persist_goff")) t.persist_goff = value ? 1 : 0;
     else if (!strcmp(name, "persist_slots")) { t.persist_slots = (value == 3 || value == 4) ? value : 0; h->d.persist_slots = t.persist_slots; }
     else if (!strcmp(name, "psync_backoff")) t.psync_backoff = value > 0 ? value : 0;

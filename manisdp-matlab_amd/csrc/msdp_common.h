@@ -190,6 +190,7 @@ struct Tuning {
     int persist_refresh = 32;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
     int persist_slots = 0;     // A/B: row slots per lane group of the persistent tCG at p = 17..32 (0: planned; 3 or 4)
     int persist_goff = 1;      // persistent tCG: the byte offsets of the R x EW gathers of a trip live in registers (0: recomputed per trip from the LDS copy of the column indices)
+    int persist_pipe = 0;      // persistent tCG: ONE grid reduction per trip (msdp_pipe.h) where an instance exists (rows of <= 8 entries, p <= 32)
     int persist_early = 0;     // persistent tCG: the neighbours' rows are gathered while reduction 2 is in flight -- sentinel-initialised exchange
                                //   halves, the rows are their own flags (0: at the top of the next trip, behind reduction 2 -- the round-4 trip;
                                //   n >= 1: n - 1 s_sleep units between the post of reduction 2 and the first gather)

@@ -91,9 +91,9 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     if (XR) {
         unsigned long long* other = slots + (size_t)((k_tr & 1) ^ 1) * PSYNC_REGION;
         slots += (size_t)(k_tr & 1) * PSYNC_REGION;
-        psync_reset_other(other, bid);
+        psync_reset_other(other, bid, GS);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // performed before this workgroup's first post of this launch
-    } else if (!FUSE) psync_reset_other(slots + PSYNC_REGION);     // region B belongs to the TR-iteration tail kernel
+    } else if (!FUSE) psync_reset_other(slots + PSYNC_REGION, bid, GS);     // region B belongs to the TR-iteration tail kernel
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi, 0, bx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -750,6 +750,8 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_xr4(XrDevs4 ds, unsigned lon
 #undef ROK
 #undef OK
 
+#include "msdp_pipe.h"
+
 // ------------------------------------------------------------------ host side
 struct PersistPlan { int lpr, ew, r; size_t lds; };
 
@@ -800,8 +802,19 @@ static persist_fn persist_kernel_early(const PersistPlan& pl, bool fuse) {
     // lane -- those sizes keep the round-4 trip)
     return nullptr;
 }
+// One-reduction instances (round 5, msdp_pipe.h): rows of <= 5 entries, every vector in registers
+static persist_fn persist_kernel_pipe(const PersistPlan& pl) {
+    if (pl.ew != 5) return nullptr;
+    if (pl.lpr == 16 && pl.r == 3) return k_tcg_pipe_obl<16, 5, 3>;
+    if (pl.lpr == 16 && pl.r == 4) return k_tcg_pipe_obl<16, 5, 4>;
+    if (pl.lpr == 8 && pl.r == 2) return k_tcg_pipe_obl<8, 5, 2>;
+    if (pl.lpr == 8 && pl.r == 4) return k_tcg_pipe_obl<8, 5, 4>;
+    return nullptr;
+}
+// early: 0 none, 1 the EARLY trip, 2 the one-reduction trip
 static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false, int early = 0) {
-    if (early) { persist_fn f = persist_kernel_early(pl, fuse); if (f) return f; }
+    if (early == 2 && !fuse) { persist_fn f = persist_kernel_pipe(pl); if (f) return f; }
+    if (early == 1) { persist_fn f = persist_kernel_early(pl, fuse); if (f) return f; }
 #define PK(L, E) if (pl.lpr == L && pl.ew == E && pl.r == L / 4) return k_tcg_persist_obl<L, E, L / 4, false>;
     if (pl.lpr == 16 && pl.r == 3) {
         if (fuse) {
@@ -843,7 +856,9 @@ static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false, int e
     return nullptr;
 }
 
-static bool persist_is_early(msdp_handle h, const PersistPlan& pl, bool fuse) { return h->tune.persist_early && persist_kernel_early(pl, fuse) != nullptr; }
+static int persist_mode(msdp_handle h) { return h->tune.persist_pipe ? 2 : (h->tune.persist_early ? 1 : 0); }
+static bool persist_is_pipe(msdp_handle h, const PersistPlan& pl, bool fuse) { return !fuse && h->tune.persist_pipe && persist_kernel_pipe(pl) != nullptr; }
+static bool persist_is_early(msdp_handle h, const PersistPlan& pl, bool fuse) { return !persist_is_pipe(h, pl, fuse) && h->tune.persist_early && persist_kernel_early(pl, fuse) != nullptr; }
 static size_t early_lds(const PersistPlan& pl);
 
 // The persistent kernel has its own grid: at most one workgroup per CU (co-residency), independent of the grid
@@ -884,7 +899,7 @@ int msdp_persist_eligible(msdp_handle h) {
     if (G < 8) return 0;
     PersistPlan pl;
     if (!persist_plan(d, G, pl)) return 0;
-    persist_fn fn = persist_kernel(pl, false, h->tune.persist_early);
+    persist_fn fn = persist_kernel(pl, false, persist_mode(h));
     if (!fn) return 0;
     if (persist_is_early(h, pl, false)) pl.lds += early_lds(pl);
     // the ELL copy must be stored with the width the kernel is instantiated for
@@ -908,7 +923,7 @@ int msdp_launch_tcg_persist(msdp_handle h, int reset_slots) {
     const int G = persist_grid(h->d);
     PersistPlan pl;
     if (!persist_plan(h->d, G, pl)) { msdp_set_error("persistent tCG: not eligible"); return MSDP_ESTATE; }
-    persist_fn fn = persist_kernel(pl, false, h->tune.persist_early);
+    persist_fn fn = persist_kernel(pl, false, persist_mode(h));
     if (!fn) { msdp_set_error("persistent tCG: no kernel instance"); return MSDP_ESTATE; }
     if (persist_is_early(h, pl, false)) pl.lds += early_lds(pl);
     Dev dp = h->d;
@@ -919,7 +934,7 @@ int msdp_launch_tcg_persist(msdp_handle h, int reset_slots) {
     }
     if (dp.trace) {
         if (!(pl.lpr == 16 && pl.ew == 5 && pl.r == 3)) { msdp_set_error("persistent trace: only the <16, 5, 3> instance (17 <= p <= 32, rows of <= 5 entries) is traced"); return MSDP_EUNSUPPORTED; }
-        fn = h->tune.persist_early ? k_tcg_persist_obl<16, 5, 3, false, true, false, true> : k_tcg_persist_obl<16, 5, 3, false, true>;
+        fn = h->tune.persist_pipe ? k_tcg_pipe_obl<16, 5, 3, true> : h->tune.persist_early ? k_tcg_persist_obl<16, 5, 3, false, true, false, true> : k_tcg_persist_obl<16, 5, 3, false, true>;
         HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     }
     hipLaunchKernelGGL(fn, dim3(G), dim3(PB), pl.lds, h->stream, dp, h->psync_slots, h->psync_err);
@@ -949,7 +964,7 @@ int msdp_persist_fused_ok(msdp_handle h) {
     PersistPlan pl;
     const int G = persist_grid(h->d);
     if (!persist_plan(h->d, G, pl)) return 0;
-    persist_fn fn = persist_kernel(pl, true, h->tune.persist_early);
+    persist_fn fn = persist_kernel(pl, true, h->tune.persist_early ? 1 : 0);
     if (!fn) return 0;
     pl.lds = fused_lds(pl) + (persist_is_early(h, pl, true) ? early_lds(pl) : 0);
     if (h->fused_sig_lpr == pl.lpr && h->fused_sig_ew == pl.ew && h->fused_sig_G == G && h->fused_sig_fn == (const void*)fn) return h->fused_sig_ok;
@@ -966,7 +981,7 @@ int msdp_launch_rtr_fused(msdp_handle h) {
     const int G = persist_grid(h->d);
     PersistPlan pl;
     if (!persist_plan(h->d, G, pl)) { msdp_set_error("fused RTR: not eligible"); return MSDP_ESTATE; }
-    persist_fn fn = persist_kernel(pl, true, h->tune.persist_early);
+    persist_fn fn = persist_kernel(pl, true, h->tune.persist_early ? 1 : 0);
     if (!fn) { msdp_set_error("fused RTR: no kernel instance"); return MSDP_ESTATE; }
     pl.lds = fused_lds(pl) + (persist_is_early(h, pl, true) ? early_lds(pl) : 0);
     Dev dp = h->d;

@@ -1,0 +1,367 @@
+// msdp_pipe.h -- ONE grid synchronisation per tCG trip (round 5, option persist_pipe): the persistent kernel of msdp_persist.hip with
+// the two reductions of a trip (tCG.m:166 <delta, H delta>; :227-241 model value and <r', r'>) folded into one.
+//
+// Why: a trip of k_tcg_persist_obl is latency -- two grid reductions of 1.9 us each, the drain of the published rows (0.7) and the
+// gather (1.2) in front of 0.7 us of arithmetic (profiles/r4_persist_timeline_p32.md); taking the gather off the critical path was
+// tried three ways in round 5 and lost to the visibility latency of the exchanged rows.  What can go is one of the reductions:
+// everything the second one carries is a polynomial in the step length alpha whose coefficients are inner products of vectors known
+// BEFORE alpha (tCG.m:215-241 with eta' = eta - alpha md, r' = r - alpha Hmd):
+//     <r', r'>            = <r, r> - 2 alpha <r, Hmd> + alpha^2 <Hmd, Hmd>
+//     <eta', g>           = <eta, g> - alpha <md, g>
+//     <eta', r' - g>      = <eta, r - g> - alpha (<eta, Hmd> + <md, r - g>) + alpha^2 <md, Hmd>
+// so ONE reduction of eight values -- <md, Hmd>, <r, Hmd>, <Hmd, Hmd>, <md, g>, <eta, Hmd>, <md, r - g>, and <r, r> and the model value
+// of the point committed one trip ago, summed DIRECTLY (they replace the values the formulas gave: nothing is carried by recurrence
+// for more than one trip) -- decides the whole trip: alpha, the boundary / negative-curvature test (:183), the model test (:228),
+// the stopping test (:249), beta (:272).  The rows the neighbours need must then be stored BEFORE that reduction (it is the only
+// barrier left), i.e. before alpha and beta are known: the workgroups publish the rows of Hmd, and the products follow from linearity
+//     C tangent(r') = C tangent(r) - alpha C Hmd          (Hmd is tangent: it is a projection minus a multiple of md)
+//     C md'         = C tangent(r') + beta C md           (md' = tangent(r' + beta md), tCG.m:273,283)
+// with C tangent(r) (ctr) and C md (cmd) kept in registers -- one more resident vector than the two-reduction trip.  The published
+// rows alternate between two halves of the exchange buffer (a workgroup that has passed the reduction of trip j may store its rows
+// of trip j+1 while a neighbour still gathers those of trip j).  Every `refresh`-th trip ends with a direct exchange, as in the
+// two-reduction kernel: the rows of md' and of tangent(r') go to two further regions of the buffer behind a value-less barrier and
+// the next trip gathers both products directly (ctr and cmd start afresh).
+// Per-row arithmetic of eta, r, md and Hmd: the statements of the two-reduction kernel (same reference lines).  What differs from
+// tCG.m in floating point: C md is assembled (as in the two-reduction kernel), and <r', r'> / the model value that decide the
+// stopping and model tests of a trip are the expanded forms above (relative error eps <r, r> / <r', r'>); the values that enter
+// alpha and the next test are the directly summed ones.  Parity: tests/test_gpu_persistent_tcg.py (pipe cases) against the oracle.
+#pragma once
+#include "msdp_psync.h"
+
+// Eight-value grid reduction: wave w polls value array w (PSYNC_NV = 8 arrays per generation); same slot protocol and layout as psync().
+// (A layout with the eight values of a workgroup in ONE 64-byte line per replica -- 8 lines per post instead of 64, polled with
+// 16-byte loads -- was measured too: 5.99 us per trip against 5.83; the cross-wave sum of its 64 partials costs more than the posts save.)
+// The eight per-lane partials are reduced over the wave TOGETHER: a butterfly that halves the number of values a lane carries at each
+// of its first three steps (10 exchanges and additions instead of the 48 of eight separate wave sums; lane 8 i ends with value i).
+// sh8: 8 x PWAVES doubles, shb8: 16 doubles.  Returns false when a bounded spin ran out.
+__device__ __forceinline__ bool psync8(unsigned long long* slots, unsigned gen, int G, double (&v)[8], double* sh8, double* shb8, int* err,
+                                       int bid, int backoff, unsigned long long* tr = nullptr) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        const bool h32 = (lane & 32) != 0, h16 = (lane & 16) != 0, h8 = (lane & 8) != 0;
+        double a[4], b[2], x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = (h32 ? v[4 + k] : v[k]) + __shfl_xor(h32 ? v[k] : v[4 + k], 32);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) b[k] = (h16 ? a[2 + k] : a[k]) + __shfl_xor(h16 ? a[k] : a[2 + k], 16);
+        x = (h8 ? b[1] : b[0]) + __shfl_xor(h8 ? b[0] : b[1], 8);
+        x += __shfl_xor(x, 4); x += __shfl_xor(x, 2); x += __shfl_xor(x, 1);
+        if ((lane & 7) == 0) sh8[(lane >> 3) * PWAVES + w] = x;     // value lane / 8 of this wave
+    }
+    __syncthreads();
+    if (tr && threadIdx.x == 0) tr[2] = __builtin_readcyclecounter();
+    {
+        unsigned long long* gbase = slots + (size_t)(gen % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID;
+        if (w == 0) {
+            const int rep = lane / PSYNC_NV, vi = lane % PSYNC_NV;
+            double s = 0.0;
+            for (int i = 0; i < PWAVES; ++i) s += sh8[vi * PWAVES + i];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the reset store of this slot's other generations has been performed
+            __hip_atomic_store(gbase + ((size_t)rep * PSYNC_NV + vi) * MSDP_MAX_GRID + bid,
+                               (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned long long* p0 = gbase + ((size_t)(bid & (PSYNC_REP - 1)) * PSYNC_NV + w) * MSDP_MAX_GRID + lane;
+        double r0;
+        int spins = 0;
+        bool fail = false;
+        const int first = ((backoff >> 16) & 0xff) ? ((backoff >> 16) & 0xff) : (backoff & 0xff);
+        for (int q = 0; q < first; ++q) __builtin_amdgcn_s_sleep(1);
+        if (tr && threadIdx.x == 0) tr[3] = __builtin_readcyclecounter();
+        for (;;) {
+            unsigned long long b0[4];
+            asm volatile(
+                "global_load_dwordx2 %0, %4, off sc1\n\t"
+                "global_load_dwordx2 %1, %4, off offset:512 sc1\n\t"
+                "global_load_dwordx2 %2, %4, off offset:1024 sc1\n\t"
+                "global_load_dwordx2 %3, %4, off offset:1536 sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3])
+                : "v"(p0)
+                : "memory");
+            bool ok = true;
+            double t0 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (lane + 64 * q < G) {
+                    ok = ok && b0[q] != PSYNC_SENT;
+                    t0 += __longlong_as_double((long long)b0[q]);
+                }
+            }
+            r0 = t0;
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ULL) break;
+            ++spins;
+            if (spins > PSYNC_SPIN_LIMIT ||
+                ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
+            for (int q = 0; q < ((backoff >> 8) & 0xff); ++q) __builtin_amdgcn_s_sleep(1);
+        }
+        if (tr && threadIdx.x == 0) tr[7] = (__builtin_readcyclecounter() << 4) + (unsigned long long)(spins < 15 ? spins : 15);
+        r0 = msdp_wave_sum(r0);
+        if (lane == 0) {
+            shb8[w] = r0; shb8[8 + w] = fail ? 1.0 : 0.0;
+            if (fail) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // every workgroup has posted value array 0 of this generation, i.e. has finished reading the previous one: my slots of it back
+        // to the sentinel
+        if (w == 0)
+            __hip_atomic_store(slots + (size_t)((gen + PSYNC_GEN - 1) % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID +
+                                   (size_t)lane * MSDP_MAX_GRID + bid,
+                               PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    double bad = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = msdp_readlane(shb8[i], 0); bad += msdp_readlane(shb8[8 + i], 0); }
+    return bad == 0.0;
+}
+
+// TRACE stamps of this form: 0 top of the trip (gather about to be issued), 1 products, Hmd and the eight partial sums formed, rows of
+// Hmd stored, 4 those stores performed, 5 the reduction returned, 6 new direction formed (end of the trip)
+template <int LPR, int EW, int R, bool TRACE>
+__device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* slots, int* err, const int bx) {
+    static_assert(EW > 0 && R <= 5, "pipelined trip: ELL rows, every vector in registers");
+    static_assert(PSYNC_NV == 8 && PSYNC_REP * PSYNC_NV == 64, "psync8 posts one slot per lane of wave 0");
+    extern __shared__ double lds[];
+    __shared__ double sh8[8 * PWAVES];
+    __shared__ double shb8[16];
+    constexpr int RPW = 64 / LPR;
+    constexpr int RSTEP = PWAVES * RPW;
+    constexpr int ROWS = R * RSTEP;
+    double2* Ys = reinterpret_cast<double2*>(lds);                 // [R][PB]
+    double2* Gs = Ys + R * PB;                                     // [R][PB]
+    double* eGs = reinterpret_cast<double*>(Gs + R * PB);          // [ROWS]
+    double* vs = eGs + ROWS;                                       // [EW][ROWS]
+    int* cs = reinterpret_cast<int*>(vs + EW * ROWS);              // [EW][ROWS]
+
+    const Ctl* c = d.ctl;
+    const bool lead = bx == 0 && threadIdx.x == 0;
+    const int k_tr = c->k;
+    if (c->done) {
+        if (lead) {
+            frame_store(&d.F[0], c->gg, c->gg, 0.0, 0.0, 0.0, sqrt(c->gg), 0.0, 0.0, 0, 0, 5, 0, 0, 1);
+            d.ctl->tcg_running = 0;
+            msdp_publish(d, k_tr, 0, 0);
+        }
+        return;
+    }
+    if (lead) msdp_publish(d, k_tr, 0, 1);
+    const int bid = bx, GS = d.G;
+    psync_reset_other(slots + PSYNC_REGION, bid, GS);
+    int lo, hi;
+    msdp_chunk_rows(d.n_loc, d.G, lo, hi, 0, bx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    const bool colok = 2 * sub < d.ld;
+    const int cur = c->cur;
+    const bool bench = c->bench_mode != 0;
+    const double Delta = c->Delta;
+    const double kappa = c->kappa, theta = c->theta;
+    const int mininner = c->mininner, maxinner = c->maxinner;
+    const double gg = c->gg;
+    const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
+    const double* __restrict__ gl = cur ? d.Gr[1] : d.Gr[0];
+    const double* __restrict__ eGl = cur ? d.eG[1] : d.eG[0];
+    const int slot0 = wave * RPW + rsub;
+#define SLOT(r) ((r) * RSTEP + slot0)
+#define ROW(r) (lo + SLOT(r))
+#define ROK(r) (ROW(r) < hi)
+#define OK(r) (ROK(r) && colok)
+    const int refresh = c->persist_refresh;
+    const int backoff = c->psync_backoff;
+    const double2 zz = make_double2(0.0, 0.0);
+    double2 eta[R], rr[R], md[R], hmd[R], cmd[R], ctr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool rok = ROK(r);
+        const int rc = rok ? ROW(r) : lo;
+        const int64_t o = (int64_t)rc * d.ld + (colok ? 2 * sub : 0);
+        double2 y = ld2(Yl + o), g = ld2(gl + o);
+        if (!OK(r)) { y = zz; g = zz; }
+        Ys[r * PB + threadIdx.x] = y; Gs[r * PB + threadIdx.x] = g;
+        eta[r] = zz; rr[r] = g; md[r] = g; hmd[r] = zz; cmd[r] = zz; ctr[r] = zz;       // tCG.m:102-157
+        const double egv = eGl[rc];
+        int cw[EW];
+        double vw[EW];
+#pragma unroll
+        for (int w = 0; w < EW; ++w) {
+            cw[w] = d.ellc[(int64_t)w * d.ell_stride + rc];
+            vw[w] = d.ellv[(int64_t)w * d.ell_stride + rc];
+        }
+        if (sub == 0) {
+            eGs[SLOT(r)] = rok ? egv : 0.0;
+#pragma unroll
+            for (int w = 0; w < EW; ++w) {
+                cs[w * ROWS + SLOT(r)] = cw[w];
+                vs[w * ROWS + SLOT(r)] = rok ? vw[w] : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+
+    unsigned gen = 0, nbar = 0;
+    const unsigned half_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
+    // exchange buffer: halves 0 / 1 = the rows of Hmd (alternating trips), 2 = the rows of md' and 3 = those of tangent(r') of a refresh trip
+    const __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, 4u * half_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[1] : d.Gr[0], 0, half_bytes, 0x00020000);
+    const unsigned gld = (unsigned)d.ld, gcol = colok ? 2 * sub : 0;
+
+    double z_r = gg, d_Pd = gg, e_Pd = 0.0, e_Pe = 0.0, model_value = 0.0, alpha = 0.0, beta = 0.0;
+    const double norm_r0 = sqrt(gg);
+    int j = 0, stop = 5;
+    bool first = true, direct = false, failed = false;
+    unsigned xq = 0;                                               // the half this trip's rows of Hmd go to
+    for (;;) {
+        TSTAMP(0);
+        // ---- the products: C md of this trip (cmd) and C tangent(r) (ctr)
+        double2 X[R][EW];
+#define PIPE_ISSUE(rs, base) do { \
+            _Pragma("unroll") for (int r = 0; r < R; ++r) \
+            _Pragma("unroll") for (int w = 0; w < EW; ++w) { \
+                const int cidx = cs[w * ROWS + SLOT(r)]; \
+                X[r][w] = ld2_sc1((rs), (base) + ((unsigned)cidx * gld + gcol) * 8u); } } while (0)
+#define PIPE_FOLD(r, acc) do { \
+            (acc) = zz; \
+            _Pragma("unroll") for (int w = 0; w < EW; ++w) { \
+                const double vv = vs[w * ROWS + SLOT(r)]; \
+                (acc).x = fma(vv, X[r][w].x, (acc).x); (acc).y = fma(vv, X[r][w].y, (acc).y); } \
+            if (!colok) (acc) = zz; } while (0)
+        if (first) {
+            // the first direction = the gradient (tangent, in global memory since an earlier launch): r = md = grad
+            PIPE_ISSUE(rs_g, 0u);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { double2 a; PIPE_FOLD(r, a); cmd[r] = a; ctr[r] = a; }
+        } else if (direct) {
+            PIPE_ISSUE(rs_md, 2u * half_bytes);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { double2 a; PIPE_FOLD(r, a); cmd[r] = a; }
+            PIPE_ISSUE(rs_md, 3u * half_bytes);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { double2 a; PIPE_FOLD(r, a); ctr[r] = a; }
+        } else {
+            PIPE_ISSUE(rs_md, (xq ^ 1u) * half_bytes);              // the neighbours' rows of last trip's Hmd
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double2 a; PIPE_FOLD(r, a);
+                ctr[r].x = fma(-alpha, a.x, ctr[r].x); ctr[r].y = fma(-alpha, a.y, ctr[r].y);      // C tangent(r') = C tangent(r) - alpha C Hmd
+                cmd[r].x = fma(beta, cmd[r].x, ctr[r].x); cmd[r].y = fma(beta, cmd[r].y, ctr[r].y);  // C md' = C tangent(r') + beta C md
+            }
+        }
+        // ---- Hmd = proj(C*md) - md.*eG (tCG.m:163, ManiSDP_onlyunitdiag.m:127-130), its rows to the neighbours, the eight partial sums
+        double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double2 acc = cmd[r];
+            const double2 y = Ys[r * PB + threadIdx.x], g = Gs[r * PB + threadIdx.x], mdr = md[r], e0 = eta[r], rv = rr[r];
+            const double dot = msdp_group_sum<LPR>(acc.x * y.x + acc.y * y.y);
+            const double eg = eGs[SLOT(r)];
+            double2 hq = make_double2(acc.x - y.x * dot - mdr.x * eg, acc.y - y.y * dot - mdr.y * eg);
+            if (!OK(r)) hq = zz;
+            hmd[r] = hq;
+            if (OK(r)) st2_sc1(rs_md, xq * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, hq);
+            const double2 rg = make_double2(rv.x - g.x, rv.y - g.y);                      // Heta (:220)
+            v[0] += mdr.x * hq.x + mdr.y * hq.y;                                          // <md, Hmd>   (:166)
+            v[1] += rv.x * hq.x + rv.y * hq.y;                                            // <r, Hmd>
+            v[2] += hq.x * hq.x + hq.y * hq.y;                                            // <Hmd, Hmd>
+            v[3] += mdr.x * g.x + mdr.y * g.y;                                            // <md, g>
+            v[4] += e0.x * hq.x + e0.y * hq.y;                                            // <eta, Hmd>
+            v[5] += mdr.x * rg.x + mdr.y * rg.y;                                          // <md, Heta>
+            v[6] += rv.x * rv.x + rv.y * rv.y;                                            // <r, r>      (:241 of the trip before)
+            v[7] += (e0.x * g.x + e0.y * g.y) + 0.5 * (e0.x * rg.x + e0.y * rg.y);        // model value (:227 of the trip before)
+        }
+        TSTAMP(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my rows of Hmd are performed before I post
+        TSTAMP(4);
+        if (!psync8(slots, gen++, GS, v, sh8, shb8, err, bid, backoff, (TRACE && j >= MSDP_TRACE_J0 && j < MSDP_TRACE_J0 + MSDP_TRACE_NJ) ? d.trace + ((size_t)bx * MSDP_TRACE_NJ + (j - MSDP_TRACE_J0)) * 8 : nullptr)) { failed = true; break; }
+        TSTAMP(5);
+        const double d_Hd = v[0];                                                         // :166
+        z_r = v[6];
+        model_value = v[7];
+        alpha = z_r / d_Hd;                                                               // :170
+        const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;         // :173
+        if (!bench && (d_Hd <= 0.0 || e_Pe_new >= Delta * Delta)) {                       // :183
+            const double tau = (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta * Delta - e_Pe))) / d_Pd;   // :188
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                eta[r].x -= tau * md[r].x; eta[r].y -= tau * md[r].y;                     // :192
+                rr[r].x -= tau * hmd[r].x; rr[r].y -= tau * hmd[r].y;                     // :198 (Heta = r - grad)
+            }
+            stop = (d_Hd <= 0.0) ? 1 : 2;
+            ++j;
+            break;
+        }
+        // the trial step's three inner products (tCG.m:215-241), expanded in alpha
+        const double new_model = model_value - alpha * v[3] - 0.5 * alpha * (v[4] + v[5]) + 0.5 * alpha * alpha * d_Hd;   // :227
+        const double r_r = fmax(z_r - 2.0 * alpha * v[1] + alpha * alpha * v[2], 0.0);                                    // :241
+        e_Pe = e_Pe_new;
+        if (!bench && new_model >= model_value) { stop = 6; ++j; break; }                 // :228 (eta, Heta stay)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {                                                     // :233-238
+            eta[r].x -= alpha * md[r].x; eta[r].y -= alpha * md[r].y;
+            rr[r].x -= alpha * hmd[r].x; rr[r].y -= alpha * hmd[r].y;
+        }
+        model_value = new_model;
+        ++j;
+        const double norm_r = sqrt(r_r);
+        const double nr0t = (theta == 1.0) ? norm_r0 : pow(norm_r0, theta);
+        if (!bench && j >= mininner && norm_r <= norm_r0 * fmin(nr0t, kappa)) {           // :249
+            stop = (kappa < nr0t) ? 3 : 4;
+            break;
+        }
+        if (j >= maxinner) break;                                                         // :160 (stop stays 5)
+        beta = r_r / z_r;                                                                 // :272
+        e_Pd = beta * (e_Pd + alpha * d_Pd);                                              // :286
+        d_Pd = r_r + beta * beta * d_Pd;                                                  // :287
+        z_r = r_r;
+        // ---- mdelta = tangent(r + beta*mdelta)  (:273,283)
+        const bool refresh_now = refresh > 0 && (j % refresh) == 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double2 y = Ys[r * PB + threadIdx.x];
+            const double2 vv = make_double2(rr[r].x + beta * md[r].x, rr[r].y + beta * md[r].y);
+            const double dot = msdp_group_sum<LPR>(vv.x * y.x + vv.y * y.y);
+            const double2 mnew = make_double2(vv.x - y.x * dot, vv.y - y.y * dot);
+            md[r] = mnew;
+            if (refresh_now) {
+                const double dn = msdp_group_sum<LPR>(rr[r].x * y.x + rr[r].y * y.y);
+                if (OK(r)) {
+                    st2_sc1(rs_md, 2u * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, mnew);
+                    st2_sc1(rs_md, 3u * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, make_double2(rr[r].x - y.x * dn, rr[r].y - y.y * dn));
+                }
+            }
+        }
+        if (refresh_now) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!pbarrier(slots, nbar++, GS, shb8, err, bid)) { failed = true; break; }
+        }
+        direct = refresh_now;
+        first = false;
+        xq ^= 1u;
+        { --j; TSTAMP(6); ++j; }
+    }
+#undef PIPE_ISSUE
+#undef PIPE_FOLD
+    if (failed) return;
+    // ---- hand eta, Heta = r - grad and the final scalars to the RTR kernels (trustregions.m:540-550)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (OK(r)) {
+            const int64_t o = (int64_t)ROW(r) * d.ld + 2 * sub;
+            const double2 g = Gs[r * PB + threadIdx.x];
+            st2(d.eta[0] + o, eta[r]);
+            st2(d.Heta[0] + o, make_double2(rr[r].x - g.x, rr[r].y - g.y));
+        }
+    }
+    if (lead) {
+        frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha, beta, 0, j, stop, 0, 0, 0);
+        d.ctl->tcg_running = 0;
+        msdp_publish(d, k_tr, j, 0);
+    }
+#undef SLOT
+#undef ROW
+#undef ROK
+#undef OK
+}
+
+template <int LPR, int EW, int R, bool TRACE = false>
+__global__ __launch_bounds__(PB) void k_tcg_pipe_obl(Dev d, unsigned long long* slots, int* err) {
+    tcg_pipe_body<LPR, EW, R, TRACE>(d, slots, err, (int)blockIdx.x);
+}

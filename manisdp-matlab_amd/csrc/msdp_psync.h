@@ -3,7 +3,7 @@
 #pragma once
 #include "msdp_device.h"
 
-#define PSYNC_NV 4                       // value arrays per generation
+#define PSYNC_NV 8                       // value arrays per generation (round 5: eight, for the one-reduction trip of msdp_pipe.h)
 #define PSYNC_GEN 3
 // Every workgroup posts its partials into PSYNC_REP replicas and polls replica (blockIdx & 7), i.e. the one of
 // its XCD under round-robin dispatch: 32 pollers per cache line instead of 256 (tools/microbench_sync.hip:
@@ -232,10 +232,11 @@ __device__ __forceinline__ bool pbarrier(unsigned long long* slots, unsigned nba
 
 // Two kernels alternate on a stream (persistent tCG, TR-iteration tail), each with its own region; a kernel may
 // not reset its own region while its workgroups poll it, so each one resets the OTHER kernel's region at its start:
-// workgroup b clears column b of every slot array, workgroup 0 the counters (completed at the kernel boundary).
-__device__ __forceinline__ void psync_reset_other(unsigned long long* other, int bid_in = -1) {
+// the workgroups share the slots out among themselves, workgroup 0 clears the counters (completed at the kernel boundary).
+__device__ __forceinline__ void psync_reset_other(unsigned long long* other, int bid_in = -1, int G_in = -1) {
     const int bid = bid_in < 0 ? (int)blockIdx.x : bid_in;
-    const int t = threadIdx.x;
-    if (t < PSYNC_GEN * PSYNC_REP * PSYNC_NV) other[(size_t)t * MSDP_MAX_GRID + bid] = PSYNC_SENT;
-    if (bid == 0 && t >= 128 && t < 192) other[PSYNC_CNT_OFF + (t - 128)] = 0ULL;
+    const int G = G_in < 0 ? (int)gridDim.x : G_in;                // the workgroups that share the region (all of them call this)
+    // (round 5: every slot of the region, whatever layout the other kernel gives it -- psync() arrays or the lines of psync8())
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < PSYNC_CNT_OFF; i += (size_t)G * blockDim.x) other[i] = PSYNC_SENT;
+    if (bid == 0 && threadIdx.x >= 128 && threadIdx.x < 192) other[PSYNC_CNT_OFF + (threadIdx.x - 128)] = 0ULL;
 }

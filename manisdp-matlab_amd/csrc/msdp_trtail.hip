@@ -32,10 +32,10 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
     unsigned long long* sb;
     if (XR) {
         sb = slots + (size_t)(2 + (c->k & 1)) * PSYNC_REGION;
-        psync_reset_other(slots + (size_t)(2 + ((c->k & 1) ^ 1)) * PSYNC_REGION, bid);
+        psync_reset_other(slots + (size_t)(2 + ((c->k & 1) ^ 1)) * PSYNC_REGION, bid, GS);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-        psync_reset_other(slots);                              // region A belongs to the persistent tCG kernel
+        psync_reset_other(slots, bid, GS);                     // region A belongs to the persistent tCG kernel
         sb = slots + PSYNC_REGION;
     }
     int lo, hi;
