@@ -395,7 +395,16 @@ int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, const int64_
  *                       gathered WHILE the second grid reduction of the trip is in flight -- the exchange buffer's halves hold a NaN
  *                       sentinel until a row is stored, so the rows are their own flags (k - 1 = units of 64 cycles a wave sleeps
  *                       between posting the reduction and its first gather); 0 = at the top of the next trip, behind that
- *                       reduction (the round-4 trip).  Same arithmetic, same decisions (default 1)
+ *                       reduction (the round-4 trip).  Same arithmetic, same decisions; measured slower (default 0)
+ *   "persist_pipe" 1/0  persistent tCG kernel (rows of <= 5 entries, p <= 32): ONE grid reduction per trip instead of two -- the
+ *                       values of tCG.m:227-241 (model value, <r', r'>) follow from eight inner products formed BEFORE the step length
+ *                       is known, the neighbours gather the rows of H*mdelta, and C*tangent(r), C*mdelta follow by linearity.
+ *                       Same tests and decisions as tCG.m; <r', r'> and the model value that decide a trip carry a rounding error of
+ *                       eps <r, r> / <r', r'> (the directly summed values replace them one trip later).  G81, p = 32: 6.6 -> 4.9 us
+ *                       per trip (default 1; 0 = the two-reduction trip)
+ *   "pipe_refresh" k   one-reduction trip: every k-th trip also publishes tangent(r) and mdelta, and the next one forms both
+ *                       products from direct gathers (default 16: |Heta - Hess(eta)|/|Heta| <= 1.2e-11 after 100 trips on G81;
+ *                       32: 6e-11, 8: 2.5e-12; the recurrences lose accuracy with the SQUARE of k)
  *   "affine_overlap" 1/0  affine kinds: the 2*eS*U contraction of a Hess-vec runs on a second stream beside the A(.) / A'(.)
  *                       chain (default 0: measured slower than one stream; kept for A/B timing; results agree to rounding)
  *   "trip2"        0/1/2  chunked path, sparse C / oblique manifold / one rank: two launches per tCG trip (12 vector passes,
@@ -428,6 +437,10 @@ int msdp_set_option(msdp_handle h, const char* name, int32_t value);
  * one rank, n and p small enough to stay on chip), 0 = chunked hipGraph of three kernels
  * per trip.  Both follow tCG.m:95-292; the choice is a speed matter only. */
 int msdp_tcg_path(msdp_handle h, int32_t* path);
+/* (test / diagnostic) The trip form of the persistent kernel at the resident point: 2 = ONE grid reduction per trip (option
+ * "persist_pipe", rows of <= 5 entries, p <= 32, every vector in registers), 1 = the "persist_early" form, 0 = two reductions per
+ * trip (tCG.m:166 and :227-241 separately); -1 = the tCG is not persistent.  All forms follow tCG.m:95-292. */
+int msdp_debug_persist_form(msdp_handle h, int32_t* form);
 
 /* ------------------------------------------------------------ measurement */
 

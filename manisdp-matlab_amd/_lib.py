@@ -112,6 +112,7 @@ SIGNATURES = {
     "msdp_local_rows": (C.c_int, [C.c_void_p, _i64p, _i64p]),
     "msdp_debug_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "msdp_tcg_path": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "msdp_debug_persist_form": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "msdp_point_snapshot": (C.c_int, [C.c_void_p]),
     "msdp_point_restore": (C.c_int, [C.c_void_p]),
     "msdp_al_primal": (C.c_int, [C.c_void_p, _dp, _dp]),
@@ -613,6 +614,12 @@ class Handle:
         """1: persistent single-launch tCG kernel, 0: chunked hipGraph (three kernels per trip)."""
         v = C.c_int32()
         _check(self._lib.msdp_tcg_path(self._h, C.byref(v)))
+        return v.value
+
+    def persist_form(self):
+        """Trip form of the persistent tCG kernel: 2 one grid reduction per trip, 1 early gather, 0 two reductions, -1 not persistent."""
+        v = C.c_int32()
+        _check(self._lib.msdp_debug_persist_form(self._h, C.byref(v)))
         return v.value
 
     # ---- measurement

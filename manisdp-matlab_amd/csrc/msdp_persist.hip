@@ -941,6 +941,17 @@ int msdp_launch_tcg_persist(msdp_handle h, int reset_slots) {
     HIPCHK(hipGetLastError());
     return 0;
 }
+// Which trip the persistent kernel of this handle runs: 0 two reductions per trip (round 4), 1 the EARLY form, 2 one reduction per trip
+// (msdp_pipe.h); -1: the handle's tCG is not persistent
+extern "C" int msdp_debug_persist_form(msdp_handle h, int32_t* form) {
+    if (!h || !form) return MSDP_EINVAL;
+    *form = -1;
+    if (!msdp_persist_eligible(h)) return 0;
+    PersistPlan pl;
+    if (!persist_plan(h->d, persist_grid(h->d), pl)) return 0;
+    *form = persist_is_pipe(h, pl, false) ? 2 : (persist_is_early(h, pl, false) ? 1 : 0);
+    return 0;
+}
 int msdp_persist_trace_dims(msdp_handle h, int* G, int* nj, int* j0) { *G = persist_grid(h->d); *nj = MSDP_TRACE_NJ; *j0 = MSDP_TRACE_J0; return 0; }
 
 int msdp_tr_tail_grid(msdp_handle h) { return persist_grid(h->d); }

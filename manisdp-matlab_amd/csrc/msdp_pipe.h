@@ -18,9 +18,13 @@
 //     C md'         = C tangent(r') + beta C md           (md' = tangent(r' + beta md), tCG.m:273,283)
 // with C tangent(r) (ctr) and C md (cmd) kept in registers -- one more resident vector than the two-reduction trip.  The published
 // rows alternate between two halves of the exchange buffer (a workgroup that has passed the reduction of trip j may store its rows
-// of trip j+1 while a neighbour still gathers those of trip j).  Every `refresh`-th trip ends with a direct exchange, as in the
-// two-reduction kernel: the rows of md' and of tangent(r') go to two further regions of the buffer behind a value-less barrier and
-// the next trip gathers both products directly (ctr and cmd start afresh).
+// of trip j+1 while a neighbour still gathers those of trip j).  ctr and cmd are recurrences where the two-reduction trip gathers
+// C tangent(r') directly, and what they lose grows with the SQUARE of the trips since they were last formed from gathers (the error of
+// ctr grows by a rounding per trip and feeds cmd every trip): |Heta - Hess(eta)| / |Heta| on G81 after 50 trips 4.2e-11 with a
+// refresh every 32 trips, 1.0e-11 every 16, 2.2e-12 every 8 (1.4e-13 for the two-reduction trip; tools/pipe_drift_probe.py).  The
+// refresh needs no barrier here: every `pipe_refresh`-th trip publishes the rows of tangent(r) and md of ITS START next to those of
+// Hmd (regions 3 and 2 of the buffer, in front of the same reduction) and the next trip gathers all three -- C tangent(r) and C md
+// direct, then the step of the recurrences as on every trip.
 // Per-row arithmetic of eta, r, md and Hmd: the statements of the two-reduction kernel (same reference lines).  What differs from
 // tCG.m in floating point: C md is assembled (as in the two-reduction kernel), and <r', r'> / the model value that decide the
 // stopping and model tests of a trip are the expanded forms above (relative error eps <r, r> / <r', r'>); the values that enter
@@ -34,20 +38,45 @@
 // The eight per-lane partials are reduced over the wave TOGETHER: a butterfly that halves the number of values a lane carries at each
 // of its first three steps (10 exchanges and additions instead of the 48 of eight separate wave sums; lane 8 i ends with value i).
 // sh8: 8 x PWAVES doubles, shb8: 16 doubles.  Returns false when a bounded spin ran out.
+// (a', b') = v_permlane<W>_swap(a, b): a' = a in the even rows of W lanes and b's even-row copy in the odd ones, b' = a's odd-row copy in
+// the even rows and b in the odd ones; a' + b' = a summed over the row pair (even rows) / b summed over the row pair (odd rows)
+template <int W>
+__device__ __forceinline__ double msdp_swap_add(double a, double b) {
+    const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const unsigned alo = (unsigned)(ba & 0xffffffffLL), ahi = (unsigned)((unsigned long long)ba >> 32);
+    const unsigned blo = (unsigned)(bb & 0xffffffffLL), bhi = (unsigned)((unsigned long long)bb >> 32);
+    unsigned l0, l1, h0, h1;
+    if (W == 16) {
+        const auto rl = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        l0 = rl[0]; l1 = rl[1]; h0 = rh[0]; h1 = rh[1];
+    } else {
+        const auto rl = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        l0 = rl[0]; l1 = rl[1]; h0 = rh[0]; h1 = rh[1];
+    }
+    return __longlong_as_double((long long)(((unsigned long long)h0 << 32) | l0)) + __longlong_as_double((long long)(((unsigned long long)h1 << 32) | l1));
+}
 __device__ __forceinline__ bool psync8(unsigned long long* slots, unsigned gen, int G, double (&v)[8], double* sh8, double* shb8, int* err,
                                        int bid, int backoff, unsigned long long* tr = nullptr) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     {
-        const bool h32 = (lane & 32) != 0, h16 = (lane & 16) != 0, h8 = (lane & 8) != 0;
+        // v_permlane32_swap / v_permlane16_swap (gfx950) hand the lower half's copy of value 4 + k to the upper half and the upper
+        // half's copy of value k to the lower one in ONE VALU instruction per dword -- no selects, no LDS crossbar (the first version,
+        // six __shfl_xor stages, took 0.47 us of the trip)
+        const bool h8 = (lane & 8) != 0;
         double a[4], b[2], x;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a[k] = (h32 ? v[4 + k] : v[k]) + __shfl_xor(h32 ? v[k] : v[4 + k], 32);
+        for (int k = 0; k < 4; ++k) a[k] = msdp_swap_add<32>(v[k], v[4 + k]);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) b[k] = (h16 ? a[2 + k] : a[k]) + __shfl_xor(h16 ? a[k] : a[2 + k], 16);
-        x = (h8 ? b[1] : b[0]) + __shfl_xor(h8 ? b[0] : b[1], 8);
-        x += __shfl_xor(x, 4); x += __shfl_xor(x, 2); x += __shfl_xor(x, 1);
+        for (int k = 0; k < 2; ++k) b[k] = msdp_swap_add<16>(a[k], a[2 + k]);
+        x = (h8 ? b[1] : b[0]) + msdp_dpp<0x128>(h8 ? b[0] : b[1]);          // row_ror:8 = lane ^ 8 inside a row of 16
+        x += msdp_dpp<MSDP_DPP_XOR1>(x); x += msdp_dpp<MSDP_DPP_XOR2>(x); x += msdp_dpp<MSDP_DPP_HALF_MIRROR>(x);
         if ((lane & 7) == 0) sh8[(lane >> 3) * PWAVES + w] = x;     // value lane / 8 of this wave
     }
+    if (tr && threadIdx.x == 0) tr[4] = __builtin_readcyclecounter();
+    // the caller's row stores (issued in front of the butterfly, draining under it) are performed before the workgroup posts
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tr && threadIdx.x == 0) tr[2] = __builtin_readcyclecounter();
     {
@@ -115,7 +144,8 @@ __device__ __forceinline__ bool psync8(unsigned long long* slots, unsigned gen, 
 }
 
 // TRACE stamps of this form: 0 top of the trip (gather about to be issued), 1 products, Hmd and the eight partial sums formed, rows of
-// Hmd stored, 4 those stores performed, 5 the reduction returned, 6 new direction formed (end of the trip)
+// Hmd stored; inside the reduction 4 wave butterfly done, 2 stores performed + workgroup barrier, 3 posted + slept, 7 wave 0's poll
+// returned; 5 the reduction returned, 6 new direction formed (end of the trip)
 template <int LPR, int EW, int R, bool TRACE>
 __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* slots, int* err, const int bx) {
     static_assert(EW > 0 && R <= 5, "pipelined trip: ELL rows, every vector in registers");
@@ -165,7 +195,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
 #define ROW(r) (lo + SLOT(r))
 #define ROK(r) (ROW(r) < hi)
 #define OK(r) (ROK(r) && colok)
-    const int refresh = c->persist_refresh;
+    const int refresh = c->pipe_refresh;
     const int backoff = c->psync_backoff;
     const double2 zz = make_double2(0.0, 0.0);
     double2 eta[R], rr[R], md[R], hmd[R], cmd[R], ctr[R];
@@ -197,7 +227,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     }
     __syncthreads();
 
-    unsigned gen = 0, nbar = 0;
+    unsigned gen = 0;
     const unsigned half_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
     // exchange buffer: halves 0 / 1 = the rows of Hmd (alternating trips), 2 = the rows of md' and 3 = those of tangent(r') of a refresh trip
     const __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, 4u * half_bytes, 0x00020000);
@@ -229,14 +259,16 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
             PIPE_ISSUE(rs_g, 0u);
 #pragma unroll
             for (int r = 0; r < R; ++r) { double2 a; PIPE_FOLD(r, a); cmd[r] = a; ctr[r] = a; }
-        } else if (direct) {
-            PIPE_ISSUE(rs_md, 2u * half_bytes);
-#pragma unroll
-            for (int r = 0; r < R; ++r) { double2 a; PIPE_FOLD(r, a); cmd[r] = a; }
-            PIPE_ISSUE(rs_md, 3u * half_bytes);
-#pragma unroll
-            for (int r = 0; r < R; ++r) { double2 a; PIPE_FOLD(r, a); ctr[r] = a; }
         } else {
+            if (direct) {
+                // the trip before published tangent(r) and md next to Hmd: both products start afresh from direct gathers
+                PIPE_ISSUE(rs_md, 3u * half_bytes);
+#pragma unroll
+                for (int r = 0; r < R; ++r) { double2 a; PIPE_FOLD(r, a); ctr[r] = a; }
+                PIPE_ISSUE(rs_md, 2u * half_bytes);
+#pragma unroll
+                for (int r = 0; r < R; ++r) { double2 a; PIPE_FOLD(r, a); cmd[r] = a; }
+            }
             PIPE_ISSUE(rs_md, (xq ^ 1u) * half_bytes);              // the neighbours' rows of last trip's Hmd
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -245,6 +277,9 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
                 cmd[r].x = fma(beta, cmd[r].x, ctr[r].x); cmd[r].y = fma(beta, cmd[r].y, ctr[r].y);  // C md' = C tangent(r') + beta C md
             }
         }
+        // every `refresh`-th trip publishes tangent(r) and md of ITS start next to Hmd (no barrier of its own: the reduction orders them
+        // like the rows of Hmd); the next trip gathers all three
+        const bool pub = !first && refresh > 0 && ((j + 1) % refresh) == 0;
         // ---- Hmd = proj(C*md) - md.*eG (tCG.m:163, ManiSDP_onlyunitdiag.m:127-130), its rows to the neighbours, the eight partial sums
         double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -257,6 +292,13 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
             if (!OK(r)) hq = zz;
             hmd[r] = hq;
             if (OK(r)) st2_sc1(rs_md, xq * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, hq);
+            if (pub) {
+                const double dn = msdp_group_sum<LPR>(rv.x * y.x + rv.y * y.y);
+                if (OK(r)) {
+                    st2_sc1(rs_md, 2u * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, mdr);
+                    st2_sc1(rs_md, 3u * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, make_double2(rv.x - y.x * dn, rv.y - y.y * dn));
+                }
+            }
             const double2 rg = make_double2(rv.x - g.x, rv.y - g.y);                      // Heta (:220)
             v[0] += mdr.x * hq.x + mdr.y * hq.y;                                          // <md, Hmd>   (:166)
             v[1] += rv.x * hq.x + rv.y * hq.y;                                            // <r, Hmd>
@@ -268,8 +310,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
             v[7] += (e0.x * g.x + e0.y * g.y) + 0.5 * (e0.x * rg.x + e0.y * rg.y);        // model value (:227 of the trip before)
         }
         TSTAMP(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my rows of Hmd are performed before I post
-        TSTAMP(4);
+        // (my rows of Hmd are performed before I post: the wait sits inside psync8, behind the wave reduction)
         if (!psync8(slots, gen++, GS, v, sh8, shb8, err, bid, backoff, (TRACE && j >= MSDP_TRACE_J0 && j < MSDP_TRACE_J0 + MSDP_TRACE_NJ) ? d.trace + ((size_t)bx * MSDP_TRACE_NJ + (j - MSDP_TRACE_J0)) * 8 : nullptr)) { failed = true; break; }
         TSTAMP(5);
         const double d_Hd = v[0];                                                         // :166
@@ -312,27 +353,14 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         d_Pd = r_r + beta * beta * d_Pd;                                                  // :287
         z_r = r_r;
         // ---- mdelta = tangent(r + beta*mdelta)  (:273,283)
-        const bool refresh_now = refresh > 0 && (j % refresh) == 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double2 y = Ys[r * PB + threadIdx.x];
             const double2 vv = make_double2(rr[r].x + beta * md[r].x, rr[r].y + beta * md[r].y);
             const double dot = msdp_group_sum<LPR>(vv.x * y.x + vv.y * y.y);
-            const double2 mnew = make_double2(vv.x - y.x * dot, vv.y - y.y * dot);
-            md[r] = mnew;
-            if (refresh_now) {
-                const double dn = msdp_group_sum<LPR>(rr[r].x * y.x + rr[r].y * y.y);
-                if (OK(r)) {
-                    st2_sc1(rs_md, 2u * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, mnew);
-                    st2_sc1(rs_md, 3u * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, make_double2(rr[r].x - y.x * dn, rr[r].y - y.y * dn));
-                }
-            }
+            md[r] = make_double2(vv.x - y.x * dot, vv.y - y.y * dot);
         }
-        if (refresh_now) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!pbarrier(slots, nbar++, GS, shb8, err, bid)) { failed = true; break; }
-        }
-        direct = refresh_now;
+        direct = pub;
         first = false;
         xq ^= 1u;
         { --j; TSTAMP(6); ++j; }

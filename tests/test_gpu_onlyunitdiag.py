@@ -176,20 +176,32 @@ def test_persistent_tcg_matches_oracle(lib, shape, p, k):
     h.set_point(Y)
     assert h.tcg_path() == 1, "persistent kernel not selected"
     prob = R._OnlyUnitDiagProblem(C, n, p, q1="correct")
-    for maxinner in (1, 2, 7, 100):
+    # both trip forms of the kernel (round 5): ONE grid reduction per trip (msdp_pipe.h: rows of <= 5 entries, p <= 32; the default
+    # there) and the two-reduction trip (everything else, and persist_pipe = 0)
+    one_reduction = p <= 32 and 2 * k + 1 <= 5
+    refs = {}
+    for pipe in (1, 0):
+        h.set_option("persist_pipe", pipe)
         h.set_point(Y)
-        st = h.rtr(lib.default_opts(maxiter=1, maxinner=maxinner, tolgradnorm=1e-8))
-        _, f_ref, info = manopt_rtr.trustregions(prob, Y.copy(), 1, maxinner, 1e-8)
-        assert st.hessvecs == info.hessvecs
-        assert st.last_stop_inner == info.stop_inner[-1]
-        assert abs(st.cost - f_ref) < 1e-11 * max(1.0, abs(f_ref))
-        assert abs(st.gradnorm - info.gradnorm) < 1e-8 * max(1.0, info.gradnorm)
-    # a full solve lands on the same optimum as the chunked path's oracle
-    h.set_point(Y)
-    st = h.rtr(lib.default_opts(maxiter=40, maxinner=100, tolgradnorm=1e-8))
-    _, f_ref, info = manopt_rtr.trustregions(prob, Y.copy(), 40, 100, 1e-8)
-    assert abs(st.cost - f_ref) < 1e-6 * max(1.0, abs(f_ref))
-    assert np.allclose(np.linalg.norm(h.get_point(), axis=1), 1.0, atol=1e-14)
+        assert h.persist_form() == (2 if pipe and one_reduction else 0)
+        for maxinner in (1, 2, 7, 100):
+            h.set_point(Y)
+            st = h.rtr(lib.default_opts(maxiter=1, maxinner=maxinner, tolgradnorm=1e-8))
+            if maxinner not in refs:
+                refs[maxinner] = manopt_rtr.trustregions(prob, Y.copy(), 1, maxinner, 1e-8)
+            _, f_ref, info = refs[maxinner]
+            assert st.hessvecs == info.hessvecs
+            assert st.last_stop_inner == info.stop_inner[-1]
+            assert abs(st.cost - f_ref) < 1e-11 * max(1.0, abs(f_ref))
+            assert abs(st.gradnorm - info.gradnorm) < 1e-8 * max(1.0, info.gradnorm)
+        # a full solve lands on the same optimum as the chunked path's oracle
+        h.set_point(Y)
+        st = h.rtr(lib.default_opts(maxiter=40, maxinner=100, tolgradnorm=1e-8))
+        if "full" not in refs:
+            refs["full"] = manopt_rtr.trustregions(prob, Y.copy(), 40, 100, 1e-8)
+        _, f_ref, info = refs["full"]
+        assert abs(st.cost - f_ref) < 1e-6 * max(1.0, abs(f_ref))
+        assert np.allclose(np.linalg.norm(h.get_point(), axis=1), 1.0, atol=1e-14)
     h.close()
 
 
@@ -282,8 +294,13 @@ def test_persistent_tcg_keeps_heta_equal_to_hess_eta_on_G81(lib, p):
     n = C.shape[0]
     Y, _ = _rand_point(n, p, seed=0)
     devs = {}
-    for name, persist, trip2 in (("persistent", 1, 1), ("two-launch", 0, 1), ("three-launch", 0, 0), ("sharded", 0, 0), ("linear", 0, 0)):
+    # "persistent": the kernel's default trip -- ONE grid reduction per trip at p <= 32 (msdp_pipe.h: two products by recurrence, afresh
+    # from direct gathers every 16th trip), two reductions at p = 40; "persistent-two": the two-reduction trip everywhere
+    for name, persist, trip2 in (("persistent", 1, 1), ("persistent-two", 1, 1), ("two-launch", 0, 1), ("three-launch", 0, 0), ("sharded", 0, 0), ("linear", 0, 0)):
+        if name == "persistent-two" and p > 32:
+            continue
         h = lib.Handle.onlyunitdiag(C, pcap=p)
+        h.set_option("persist_pipe", 0 if name == "persistent-two" else 1)
         if name == "sharded":
             # the row-sharded trip with one all-reduce (msdp_trip1.hip) assembles its products by the same linearity, with the
             # same refresh schedule; a communicator of one in-process member runs exactly that code
@@ -307,6 +324,8 @@ def test_persistent_tcg_keeps_heta_equal_to_hess_eta_on_G81(lib, p):
             if full:
                 break
         assert h.tcg_path() == persist
+        if persist:
+            assert h.persist_form() == (2 if name == "persistent" and p <= 32 else 0)
         for trips in (50, 100):
             h.set_point(Yc)
             o.maxinner = trips
@@ -321,6 +340,40 @@ def test_persistent_tcg_keeps_heta_equal_to_hess_eta_on_G81(lib, p):
     for (name, trips), (dev, hv, stop) in devs.items():
         assert hv == trips, (name, trips, hv, stop)                 # the whole budget, not an early exit
         assert dev <= (2e-11 if name in ("persistent", "sharded", "linear") else 2e-12), (name, trips, dev, hv, stop)
+
+
+@pytest.mark.parametrize("p", [8, 16, 32])
+def test_one_reduction_trip_solves_G81_like_the_two_reduction_trip(lib, p):
+    """Round 5 (msdp_pipe.h): the persistent tCG with ONE grid reduction per trip -- the values of tCG.m:227-241 expanded in the step
+    length, the rows of H*mdelta published before the reduction, C*tangent(r) and C*mdelta by linearity -- against the two-reduction
+    trip on whole trustregions() calls on G81 (40 iterations, inner cap 100: negative-curvature / boundary exits, model and residual
+    stops all occur): same iteration, Hess-vec, accept / reject counts and last stop code, cost and gradient norm to rounding, the
+    end point within the tolerance of the north star; two runs of the one-reduction trip bit for bit; every refresh interval."""
+    from manisdp_matlab_amd import problems
+    C = problems.maxcut_cost_matrix(golden_path("G81.txt.gz"))
+    n = C.shape[0]
+    Y, _ = _rand_point(n, p, seed=0)
+    h = lib.Handle.onlyunitdiag(C, pcap=p)
+    h.set_option("fused_rtr", 0)
+    opts = lib.default_opts(maxiter=40, maxinner=100, tolgradnorm=1e-8)
+    out = {}
+    for name, pipe, refresh in (("two", 0, 16), ("one", 1, 16), ("one again", 1, 16), ("one/4", 1, 4), ("one/64", 1, 64)):
+        h.set_option("persist_pipe", pipe)
+        h.set_option("pipe_refresh", refresh)
+        h.set_point(Y)
+        assert h.tcg_path() == 1 and h.persist_form() == (2 if pipe else 0)
+        st = h.rtr(opts)
+        out[name] = (st, h.get_point())
+    ref, Yref = out["two"]
+    for name in ("one", "one/4", "one/64"):
+        st, Yo = out[name]
+        assert (st.iters, st.hessvecs, st.accepted, st.rejected, st.last_stop_inner) == (ref.iters, ref.hessvecs, ref.accepted, ref.rejected, ref.last_stop_inner), name
+        assert abs(st.cost - ref.cost) <= 1e-11 * abs(ref.cost), (name, st.cost, ref.cost)
+        assert abs(st.gradnorm - ref.gradnorm) <= 1e-6 * ref.gradnorm, (name, st.gradnorm, ref.gradnorm)
+        assert np.abs(Yo - Yref).max() <= 1e-6, name
+        assert np.allclose(np.linalg.norm(Yo, axis=1), 1.0, atol=1e-14)
+    assert np.array_equal(out["one"][1], out["one again"][1]) and out["one"][0].cost == out["one again"][0].cost
+    h.close()
 
 
 @pytest.mark.parametrize("shape,p,k", [((20, 30), 3, 0), ((20, 30), 16, 0), ((33, 37), 20, 0), ((25, 40), 40, 0), ((20, 30), 80, 0),

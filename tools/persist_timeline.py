@@ -29,8 +29,8 @@ if pipe:
     a = a.copy(); a[:, :, 7] >>= 4
     a = a[:, :, [0, 1, 4, 2, 3, 7, 5, 6]]
     names = ["gather of the neighbours' rows of Hmd, C*tangent(r') and C*mdelta' by linearity, Hmd, its rows stored, eight partial sums (tCG.m:163)",
-             "wait for those stores (s_waitcnt vmcnt(0))",
-             "reduction: eight partial sums over the wave (butterfly), LDS, workgroup barrier",
+             "reduction: the eight partial sums over the wave (joint butterfly), to LDS",
+             "reduction: wait for the row stores (s_waitcnt vmcnt(0)) + workgroup barrier",
              "reduction: sum over the waves, post, back-off sleep",
              "reduction: wave 0 polls its value array until all workgroups have posted (failed polls of wave 0 per trip: %.2f)" % polls.mean(),
              "reduction: wave sum, workgroup barrier (= the slowest polling wave), results to registers",

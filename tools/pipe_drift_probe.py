@@ -23,7 +23,8 @@ for _ in range(12):
         break
 for pipe, refresh in ((0, 32), (1, 32), (1, 16), (1, 8), (1, 4), (1, 0)):
     h.set_option("persist_pipe", pipe)
-    h.set_option("persist_refresh", refresh)
+    h.set_option("persist_refresh", refresh if not pipe else 32)
+    h.set_option("pipe_refresh", refresh)
     t = min(h.bench_tcg_trip(512) for _ in range(4)) * 1e3
     out = []
     for trips in (50, 100, 200):
