@@ -1022,6 +1022,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "persist_early")) t.persist_early = value > 0 ? value : 0;
     else if (!strcmp(name, "persist_pipe")) t.persist_pipe = value > 0 ? 1 : 0;
     else if (!strcmp(name, "pipe_refresh")) t.pipe_refresh = value > 0 ? value : 0;
+    else if (!strcmp(name, "pipe_local")) t.pipe_local = value > 0 ? 1 : 0;
     else if (!strcmp(name, "persist_goff")) t.persist_goff = value ? 1 : 0;
     else if (!strcmp(name, "persist_slots")) { t.persist_slots = (value == 3 || value == 4) ? value : 0; h->d.persist_slots = t.persist_slots; }
     else if (!strcmp(name, "psync_backoff")) t.psync_backoff = value > 0 ? value : 0;
@@ -1942,6 +1943,7 @@ static void fill_ctl(msdp_handle h, const msdp_rtr_opts* o) {
     c->persist_refresh = h->tune.persist_refresh;
     c->persist_early = h->tune.persist_early;
     c->pipe_refresh = h->tune.pipe_refresh;
+    c->pipe_local = h->tune.pipe_local;
     c->persist_goff = h->tune.persist_goff;
     c->psync_backoff = h->tune.psync_backoff;
     // trustregions.m:363-372; typicaldist: pi*sqrt(n) (ManiSDP_onlyunitdiag.m:137) or pi (spherefactory.m:111)

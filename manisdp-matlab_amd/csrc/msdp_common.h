@@ -39,6 +39,7 @@ struct Ctl {
     int tcg_running;             // mirror of Frame.active for host polling
     int psync_backoff;           // grid reductions of the persistent kernels: (s_sleep units of 64 cycles before the first poll) | (units after a failed poll) << 8
     int persist_goff;            // persistent tCG: gather offsets kept in registers (A/B)
+    int pipe_local;              // one-reduction trip: 1 = rows of the own workgroup from LDS / registers, 0 = every row through the exchange buffer
     int pipe_refresh;            // one-reduction trip (msdp_pipe.h): every pipe_refresh-th trip the products start afresh from direct gathers
     int persist_early;           // persistent tCG: 0 = gather the neighbours' rows at the top of the trip (round 4), >= 1 = while reduction 2 is in
                                  //   flight, the rows being their own flags (msdp_persist.hip EARLY); value - 1 = s_sleep units before the first gather
@@ -191,6 +192,7 @@ struct Tuning {
     int persist_refresh = 32;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
     int persist_slots = 0;     // A/B: row slots per lane group of the persistent tCG at p = 17..32 (0: planned; 3 or 4)
     int persist_goff = 1;      // persistent tCG: the byte offsets of the R x EW gathers of a trip live in registers (0: recomputed per trip from the LDS copy of the column indices)
+    int pipe_local = 1;        // one-reduction trip: neighbours that belong to the same workgroup are read from LDS, the diagonal from registers
     int pipe_refresh = 16;     // one-reduction trip: trips between two direct exchanges (its recurrences drift with the square of this)
     int persist_pipe = 1;      // persistent tCG: ONE grid reduction per trip (msdp_pipe.h) where an instance exists (rows of <= 8 entries, p <= 32)
     int persist_early = 0;     // persistent tCG: the neighbours' rows are gathered while reduction 2 is in flight -- sentinel-initialised exchange

@@ -806,9 +806,9 @@ static persist_fn persist_kernel_early(const PersistPlan& pl, bool fuse) {
 static persist_fn persist_kernel_pipe(const PersistPlan& pl) {
     if (pl.ew != 5) return nullptr;
     if (pl.lpr == 16 && pl.r == 3) return k_tcg_pipe_obl<16, 5, 3>;
-    if (pl.lpr == 16 && pl.r == 4) return k_tcg_pipe_obl<16, 5, 4>;
     if (pl.lpr == 8 && pl.r == 2) return k_tcg_pipe_obl<8, 5, 2>;
-    if (pl.lpr == 8 && pl.r == 4) return k_tcg_pipe_obl<8, 5, 4>;
+    // (four row slots -- 97..128 rows per workgroup at p = 17..32, 129..256 at p <= 16: the sixth resident vector spills, measured
+    // 9.6 us per trip against 8.2 for the two-reduction trip on a 180 x 180 grid at p = 32; tools/pipe_sizes_probe.py)
     return nullptr;
 }
 // early: 0 none, 1 the EARLY trip, 2 the one-reduction trip
@@ -860,6 +860,7 @@ static int persist_mode(msdp_handle h) { return h->tune.persist_pipe ? 2 : (h->t
 static bool persist_is_pipe(msdp_handle h, const PersistPlan& pl, bool fuse) { return !fuse && h->tune.persist_pipe && persist_kernel_pipe(pl) != nullptr; }
 static bool persist_is_early(msdp_handle h, const PersistPlan& pl, bool fuse) { return !persist_is_pipe(h, pl, fuse) && h->tune.persist_early && persist_kernel_early(pl, fuse) != nullptr; }
 static size_t early_lds(const PersistPlan& pl);
+static size_t pipe_lds(const PersistPlan& pl) { const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr); return (size_t)pl.ew * rows * sizeof(int) + (size_t)2 * pl.r * PB * sizeof(double2); }   // + ls, HQs
 
 // The persistent kernel has its own grid: at most one workgroup per CU (co-residency), independent of the grid
 // of the row-parallel kernels around it (those exchange data through global memory only).
@@ -902,6 +903,7 @@ int msdp_persist_eligible(msdp_handle h) {
     persist_fn fn = persist_kernel(pl, false, persist_mode(h));
     if (!fn) return 0;
     if (persist_is_early(h, pl, false)) pl.lds += early_lds(pl);
+    if (persist_is_pipe(h, pl, false)) pl.lds += pipe_lds(pl);
     // the ELL copy must be stored with the width the kernel is instantiated for
     if (pl.ew > 0 && d.ellW != pl.ew) return 0;
     if (h->persist_sig_lpr == pl.lpr && h->persist_sig_ew == pl.ew && h->persist_sig_r == pl.r && h->persist_sig_G == G && h->persist_sig_fn == (const void*)fn)
@@ -926,6 +928,7 @@ int msdp_launch_tcg_persist(msdp_handle h, int reset_slots) {
     persist_fn fn = persist_kernel(pl, false, persist_mode(h));
     if (!fn) { msdp_set_error("persistent tCG: no kernel instance"); return MSDP_ESTATE; }
     if (persist_is_early(h, pl, false)) pl.lds += early_lds(pl);
+    if (persist_is_pipe(h, pl, false)) pl.lds += pipe_lds(pl);
     Dev dp = h->d;
     dp.G = G;
     if (reset_slots) {

@@ -30,6 +30,7 @@
 // stopping and model tests of a trip are the expanded forms above (relative error eps <r, r> / <r', r'>); the values that enter
 // alpha and the next test are the directly summed ones.  Parity: tests/test_gpu_persistent_tcg.py (pipe cases) against the oracle.
 #pragma once
+#include <type_traits>
 #include "msdp_psync.h"
 
 // Eight-value grid reduction: wave w polls value array w (PSYNC_NV = 8 arrays per generation); same slot protocol and layout as psync().
@@ -57,8 +58,13 @@ __device__ __forceinline__ double msdp_swap_add(double a, double b) {
     }
     return __longlong_as_double((long long)(((unsigned long long)h0 << 32) | l0)) + __longlong_as_double((long long)(((unsigned long long)h1 << 32) | l1));
 }
+// on_ready(): called by every wave as soon as ITS poll has returned -- all workgroups have posted, so everything they stored in front
+// of their posts is visible: the caller issues the next trip's gather there, under the rest of the reduction (wave sum, workgroup
+// barrier, results to registers) and the trip's arithmetic.  The barrier behind it is a bare s_barrier (LDS traffic waited for
+// explicitly): __syncthreads() carries a fence that would wait for those loads.
+template <class F>
 __device__ __forceinline__ bool psync8(unsigned long long* slots, unsigned gen, int G, double (&v)[8], double* sh8, double* shb8, int* err,
-                                       int bid, int backoff, unsigned long long* tr = nullptr) {
+                                       int bid, int backoff, unsigned long long* tr, F on_ready) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     {
         // v_permlane32_swap / v_permlane16_swap (gfx950) hand the lower half's copy of value 4 + k to the upper half and the upper
@@ -93,7 +99,7 @@ __device__ __forceinline__ bool psync8(unsigned long long* slots, unsigned gen, 
         double r0;
         int spins = 0;
         bool fail = false;
-        const int first = ((backoff >> 16) & 0xff) ? ((backoff >> 16) & 0xff) : (backoff & 0xff);
+        const int first = ((backoff >> 16) & 0xff) ? ((backoff >> 16) & 0xff) : 27;     // (this reduction's own figure: tools/pipe_probe.py)
         for (int q = 0; q < first; ++q) __builtin_amdgcn_s_sleep(1);
         if (tr && threadIdx.x == 0) tr[3] = __builtin_readcyclecounter();
         for (;;) {
@@ -124,6 +130,7 @@ __device__ __forceinline__ bool psync8(unsigned long long* slots, unsigned gen, 
             for (int q = 0; q < ((backoff >> 8) & 0xff); ++q) __builtin_amdgcn_s_sleep(1);
         }
         if (tr && threadIdx.x == 0) tr[7] = (__builtin_readcyclecounter() << 4) + (unsigned long long)(spins < 15 ? spins : 15);
+        if (!fail) on_ready();
         r0 = msdp_wave_sum(r0);
         if (lane == 0) {
             shb8[w] = r0; shb8[8 + w] = fail ? 1.0 : 0.0;
@@ -136,7 +143,7 @@ __device__ __forceinline__ bool psync8(unsigned long long* slots, unsigned gen, 
                                    (size_t)lane * MSDP_MAX_GRID + bid,
                                PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     double bad = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { v[i] = msdp_readlane(shb8[i], 0); bad += msdp_readlane(shb8[8 + i], 0); }
@@ -161,6 +168,13 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     double* eGs = reinterpret_cast<double*>(Gs + R * PB);          // [ROWS]
     double* vs = eGs + ROWS;                                       // [EW][ROWS]
     int* cs = reinterpret_cast<int*>(vs + EW * ROWS);              // [EW][ROWS]
+    // Where an entry's row lives (round 5): most neighbours of a row belong to the SAME workgroup when C is banded / a grid in its
+    // natural order, and the diagonal entry is the lane's own row -- those need no trip through the texture path, which is what bounds
+    // the gather (a 16-byte-per-lane load occupies it for 16 cycles: 8 waves x R x EW loads = 0.8 us of a 4.9-us trip at p = 32).
+    // ls = LDS element of the row in HQs (+ class in bits 24..25: 0 in this workgroup, 1 the lane's own row, 2 empty slot) or -1 (another
+    // workgroup's row: exchange buffer); HQs = this workgroup's own rows of Hmd, two halves alternating like the buffer's.
+    int* ls = cs + EW * ROWS;                                      // [EW][ROWS]
+    double2* HQs = reinterpret_cast<double2*>(ls + EW * ROWS);     // [2][R][PB]
 
     const Ctl* c = d.ctl;
     const bool lead = bx == 0 && threadIdx.x == 0;
@@ -198,6 +212,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     const int refresh = c->pipe_refresh;
     const int backoff = c->psync_backoff;
     const double2 zz = make_double2(0.0, 0.0);
+    constexpr bool LOC = R * EW <= 15;                             // (four row slots: the source selection costs registers that spill)
     double2 eta[R], rr[R], md[R], hmd[R], cmd[R], ctr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -216,17 +231,52 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
             cw[w] = d.ellc[(int64_t)w * d.ell_stride + rc];
             vw[w] = d.ellv[(int64_t)w * d.ell_stride + rc];
         }
+        // the entries of the row ordered own row, rows of this workgroup, other rows, empty slots: a column of the ELL block then
+        // holds ONE kind for (nearly) all rows of a wave, and the wave picks the source per column, not per lane
+        int kw[EW];
+#pragma unroll
+        for (int w = 0; w < EW; ++w) {
+            if (!rok) vw[w] = 0.0;
+            kw[w] = vw[w] == 0.0 ? 3 : (cw[w] == rc ? 0 : ((cw[w] >= lo && cw[w] < hi) ? 1 : 2));
+        }
+#pragma unroll
+        for (int a = 0; a < (LOC ? EW - 1 : 0); ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < EW - 1 - a; ++b2)
+                if (kw[b2] > kw[b2 + 1]) {
+                    const int tk = kw[b2]; kw[b2] = kw[b2 + 1]; kw[b2 + 1] = tk;
+                    const int tc = cw[b2]; cw[b2] = cw[b2 + 1]; cw[b2 + 1] = tc;
+                    const double tv = vw[b2]; vw[b2] = vw[b2 + 1]; vw[b2 + 1] = tv;
+                }
         if (sub == 0) {
             eGs[SLOT(r)] = rok ? egv : 0.0;
 #pragma unroll
             for (int w = 0; w < EW; ++w) {
                 cs[w * ROWS + SLOT(r)] = cw[w];
-                vs[w * ROWS + SLOT(r)] = rok ? vw[w] : 0.0;
+                vs[w * ROWS + SLOT(r)] = vw[w];
+                const int li = cw[w] - lo;
+                const int el = (li / RSTEP) * PB + (li % RSTEP) * LPR;          // element of row li's lane 0 in a half of HQs
+                ls[w * ROWS + SLOT(r)] = kw[w] == 2 ? -1 : (kw[w] == 3 ? (2 << 24) : ((kw[w] == 0 ? (1 << 24) : 0) | el));
             }
         }
     }
     __syncthreads();
-
+    // nl = the leading columns whose rows ALL live in this workgroup for every row of this WAVE (own row, neighbour in the chunk, or an
+    // empty slot): read from LDS; the columns behind them go through the exchange buffer (which holds every row: also right for a column
+    // that mixes kinds).  Three instances of the trip loop: nl = 3 (a grid row away from the chunk's ends: own row, two neighbours in
+    // the chunk, two far ones), 2 (a wave that holds an end of the chunk), 0 (everything else, pipe_local = 0, four row slots).
+    int nl = 0;
+    if (LOC && c->pipe_local != 0) {
+        bool lead_ok = true;
+#pragma unroll
+        for (int w = 0; w < EW; ++w) {
+            bool glob = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) glob = glob || ls[w * ROWS + SLOT(r)] < 0;
+            lead_ok = lead_ok && __builtin_amdgcn_ballot_w64(glob) == 0ULL;
+            if (lead_ok) nl = w + 1;
+        }
+    }
     unsigned gen = 0;
     const unsigned half_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
     // exchange buffer: halves 0 / 1 = the rows of Hmd (alternating trips), 2 = the rows of md' and 3 = those of tangent(r') of a refresh trip
@@ -239,44 +289,64 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     int j = 0, stop = 5;
     bool first = true, direct = false, failed = false;
     unsigned xq = 0;                                               // the half this trip's rows of Hmd go to
+    bool have_x = false;
+    constexpr bool PREF = R * EW <= 15;                            // (four row slots: the rows in flight across the trip's arithmetic spill)
+  auto trips = [&](auto nlc) {
+    constexpr int NL = decltype(nlc)::value;                       // columns [0, NL) from LDS, [NL, EW) through the buffer
+    constexpr int NG = EW - NL;
+    double2 X[R][NG];                                              // the gathered rows (in flight across the end of a trip)
     for (;;) {
         TSTAMP(0);
         // ---- the products: C md of this trip (cmd) and C tangent(r) (ctr)
-        double2 X[R][EW];
-#define PIPE_ISSUE(rs, base) do { \
+        // columns [w0, w0 + NG) of the rows my rows reference, requested from (rs, base) / folded into acc
+#define PIPE_ISSUE(rs, base, w0) do { \
             _Pragma("unroll") for (int r = 0; r < R; ++r) \
-            _Pragma("unroll") for (int w = 0; w < EW; ++w) { \
-                const int cidx = cs[w * ROWS + SLOT(r)]; \
-                X[r][w] = ld2_sc1((rs), (base) + ((unsigned)cidx * gld + gcol) * 8u); } } while (0)
-#define PIPE_FOLD(r, acc) do { \
-            (acc) = zz; \
-            _Pragma("unroll") for (int w = 0; w < EW; ++w) { \
+            _Pragma("unroll") for (int w = 0; w < NG; ++w) { \
+                if ((w0) + w < EW) { \
+                    const int cidx = cs[((w0) + w) * ROWS + SLOT(r)]; \
+                    X[r][w] = ld2_sc1((rs), (base) + ((unsigned)cidx * gld + gcol) * 8u); } } } while (0)
+#define PIPE_FOLDX(r, acc, w0) do { \
+            _Pragma("unroll") for (int w = 0; w < NG; ++w) { \
+                if ((w0) + w < EW) { \
+                    const double vv = vs[((w0) + w) * ROWS + SLOT(r)]; \
+                    (acc).x = fma(vv, X[r][w].x, (acc).x); (acc).y = fma(vv, X[r][w].y, (acc).y); } } } while (0)
+        // the leading NL columns from the workgroup's own rows in LDS (half hq_half of HQs)
+#define PIPE_FOLDL(r, acc, hq_half) do { \
+            _Pragma("unroll") for (int w = 0; w < NL; ++w) { \
                 const double vv = vs[w * ROWS + SLOT(r)]; \
-                (acc).x = fma(vv, X[r][w].x, (acc).x); (acc).y = fma(vv, X[r][w].y, (acc).y); } \
-            if (!colok) (acc) = zz; } while (0)
+                const double2 xx = HQs[(hq_half) * R * PB + (ls[w * ROWS + SLOT(r)] & 0xffffff) + sub]; \
+                (acc).x = fma(vv, xx.x, (acc).x); (acc).y = fma(vv, xx.y, (acc).y); } } while (0)
+        // all EW columns through the buffer (the gradient / the refresh vectors are not in LDS): passes of NG columns
+#define PIPE_GATHER_ALL(rs, base, dst) do { \
+            _Pragma("unroll") for (int r = 0; r < R; ++r) (dst)[r] = zz; \
+            _Pragma("unroll") for (int w0 = 0; w0 < EW; w0 += NG) { \
+                PIPE_ISSUE(rs, base, w0); \
+                _Pragma("unroll") for (int r = 0; r < R; ++r) PIPE_FOLDX(r, (dst)[r], w0); } \
+            if (!colok) { _Pragma("unroll") for (int r = 0; r < R; ++r) (dst)[r] = zz; } } while (0)
         if (first) {
             // the first direction = the gradient (tangent, in global memory since an earlier launch): r = md = grad
-            PIPE_ISSUE(rs_g, 0u);
+            PIPE_GATHER_ALL(rs_g, 0u, cmd);
 #pragma unroll
-            for (int r = 0; r < R; ++r) { double2 a; PIPE_FOLD(r, a); cmd[r] = a; ctr[r] = a; }
+            for (int r = 0; r < R; ++r) ctr[r] = cmd[r];
         } else {
             if (direct) {
                 // the trip before published tangent(r) and md next to Hmd: both products start afresh from direct gathers
-                PIPE_ISSUE(rs_md, 3u * half_bytes);
-#pragma unroll
-                for (int r = 0; r < R; ++r) { double2 a; PIPE_FOLD(r, a); ctr[r] = a; }
-                PIPE_ISSUE(rs_md, 2u * half_bytes);
-#pragma unroll
-                for (int r = 0; r < R; ++r) { double2 a; PIPE_FOLD(r, a); cmd[r] = a; }
+                PIPE_GATHER_ALL(rs_md, 3u * half_bytes, ctr);
+                PIPE_GATHER_ALL(rs_md, 2u * half_bytes, cmd);
             }
-            PIPE_ISSUE(rs_md, (xq ^ 1u) * half_bytes);              // the neighbours' rows of last trip's Hmd
+            // the neighbours' rows of last trip's Hmd: requested inside that trip's reduction already (have_x), except behind a refresh
+            if (!have_x) PIPE_ISSUE(rs_md, (xq ^ 1u) * half_bytes, NL);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                double2 a; PIPE_FOLD(r, a);
+                double2 a = zz;
+                PIPE_FOLDL(r, a, (xq ^ 1u));
+                PIPE_FOLDX(r, a, NL);
+                if (!colok) a = zz;
                 ctr[r].x = fma(-alpha, a.x, ctr[r].x); ctr[r].y = fma(-alpha, a.y, ctr[r].y);      // C tangent(r') = C tangent(r) - alpha C Hmd
                 cmd[r].x = fma(beta, cmd[r].x, ctr[r].x); cmd[r].y = fma(beta, cmd[r].y, ctr[r].y);  // C md' = C tangent(r') + beta C md
             }
         }
+        have_x = false;
         // every `refresh`-th trip publishes tangent(r) and md of ITS start next to Hmd (no barrier of its own: the reduction orders them
         // like the rows of Hmd); the next trip gathers all three
         const bool pub = !first && refresh > 0 && ((j + 1) % refresh) == 0;
@@ -291,6 +361,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
             double2 hq = make_double2(acc.x - y.x * dot - mdr.x * eg, acc.y - y.y * dot - mdr.y * eg);
             if (!OK(r)) hq = zz;
             hmd[r] = hq;
+            if (LOC) HQs[xq * R * PB + r * PB + threadIdx.x] = hq;
             if (OK(r)) st2_sc1(rs_md, xq * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, hq);
             if (pub) {
                 const double dn = msdp_group_sum<LPR>(rv.x * y.x + rv.y * y.y);
@@ -311,7 +382,11 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         }
         TSTAMP(1);
         // (my rows of Hmd are performed before I post: the wait sits inside psync8, behind the wave reduction)
-        if (!psync8(slots, gen++, GS, v, sh8, shb8, err, bid, backoff, (TRACE && j >= MSDP_TRACE_J0 && j < MSDP_TRACE_J0 + MSDP_TRACE_NJ) ? d.trace + ((size_t)bx * MSDP_TRACE_NJ + (j - MSDP_TRACE_J0)) * 8 : nullptr)) { failed = true; break; }
+        // (the next trip's gather goes out as soon as this wave has seen every workgroup's post: its latency runs under the rest of the
+        // reduction and the arithmetic behind it.  Not behind a refresh trip: that one's two direct gathers come first.)
+        if (!psync8(slots, gen++, GS, v, sh8, shb8, err, bid, backoff,
+                    (TRACE && j >= MSDP_TRACE_J0 && j < MSDP_TRACE_J0 + MSDP_TRACE_NJ) ? d.trace + ((size_t)bx * MSDP_TRACE_NJ + (j - MSDP_TRACE_J0)) * 8 : nullptr,
+                    [&]() { if (PREF && !pub) { PIPE_ISSUE(rs_md, xq * half_bytes, NL); have_x = true; } })) { failed = true; break; }
         TSTAMP(5);
         const double d_Hd = v[0];                                                         // :166
         z_r = v[6];
@@ -366,7 +441,13 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         { --j; TSTAMP(6); ++j; }
     }
 #undef PIPE_ISSUE
-#undef PIPE_FOLD
+#undef PIPE_FOLDX
+#undef PIPE_FOLDL
+#undef PIPE_GATHER_ALL
+  };
+    if (LOC && nl >= 3) trips(std::integral_constant<int, LOC ? 3 : 0>());
+    else if (LOC && nl == 2) trips(std::integral_constant<int, LOC ? 2 : 0>());
+    else trips(std::integral_constant<int, 0>());
     if (failed) return;
     // ---- hand eta, Heta = r - grad and the final scalars to the RTR kernels (trustregions.m:540-550)
 #pragma unroll
