@@ -441,6 +441,13 @@ def main():
     ms, abytes, aflops = h.bench_hessvec(200)
     trip_ms = h.bench_tcg_trip(512)
     persistent = (N == 1 and h.tcg_path() == 1)
+    # round 5: the persistent kernel's default trip has ONE grid reduction (msdp_pipe.h); the two-reduction trip timed beside it
+    one_reduction = persistent and h.persist_form() == 2
+    trip2_ms = None
+    if one_reduction:
+        h.set_option("persist_pipe", 0)
+        trip2_ms = h.bench_tcg_trip(512)
+        h.set_option("persist_pipe", 1)
     hess_achieved = abytes / (ms * 1e-3) / 1e9
     # the algorithmic traffic of the path is that of the S*U (ehess) product, `abytes` per Hess-vec;
     # one tCG trip = one Hess-vec.  For the persistent kernel (one launch = all trips of a solve) bytes and time are
@@ -460,7 +467,8 @@ def main():
     # HBM traffic comes from rocprofv3 --pmc passes (their own runs: counters cannot be collected inside a timed run);
     # the line carries the committed summary's value together with the file it was read from
     pm_h = pmc("r4_pmc_hess_g81_p32.json", "r3_pmc_hess_g81_p32.json", "r2_pmc_hess_g81_p32.json", "r1_pmc_hess_g81_p32.json")
-    pm_t = pmc("r5_pmc_persist_g81_p32.json", "r4_pmc_persist_g81_p32.json", "r3_pmc_persist_g81_p32.json", "r2_pmc_persist_g81_p32.json", "r1_pmc_persist_g81_p32.json")
+    pm_t = (pmc("r5_pmc_pipe_g81_p32.json") if one_reduction else
+            pmc("r5_pmc_persist_g81_p32.json", "r4_pmc_persist_g81_p32.json", "r3_pmc_persist_g81_p32.json", "r2_pmc_persist_g81_p32.json", "r1_pmc_persist_g81_p32.json"))
     if persistent:
         traffic = (pm_t or {}).get("hbm_bytes_per_trip")
         roofline = {"bound": "hbm", "achieved": trip_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -468,20 +476,23 @@ def main():
                     "traffic_source": (pm_t or {}).get("_source"),
                     "traffic_note": "replayed from the committed rocprofv3 --pmc summary of the same kernel and workload, not "
                                     "measured in this run",
-                    "kernel": "k_tcg_persist_obl", "kernel_us": trip_ms * 1e3, "per": "tCG trip (one Hess-vec)",
+                    "kernel": "k_tcg_pipe_obl" if one_reduction else "k_tcg_persist_obl", "kernel_us": trip_ms * 1e3, "per": "tCG trip (one Hess-vec)",
                     "algorithmic_bytes_per_launch": abytes,
                     "streaming_formulation_bytes_per_trip": streaming_trip_bytes,
                     "streaming_equivalent_GBps": streaming_trip_bytes / (trip_ms * 1e-3) / 1e9,
-                    "note": "one launch runs all trips of a solve; bytes, traffic and time are per trip.  The working "
-                            "set is register/LDS resident; profiles/r5_persist_timeline_p32.md (s_memtime stamps of every workgroup) "
-                            "splits a trip into gathers + row arithmetic 1.3 us, grid reduction 1 1.96 us, trial step 0.52 us, wait for "
-                            "the residual-row stores 0.5 us, grid reduction 2 1.92 us, commit + new direction 0.6 us, loop 0.13 us: the two "
-                            "grid-wide reductions are more than half of the trip, not HBM -- the fraction of the HBM roofline is low by "
-                            "construction at n*p*8 = 5 MB per vector.  Round 5 built the trip with the gather running DURING reduction 2 "
-                            "three ways (row flags; sentinel-initialised exchange halves with full / partial retry): 8.6 / 7.1-7.5 / 7.2-7.5 us "
-                            "against 6.55 -- the exchanged rows need 2.6 us to become visible to other XCDs under that load "
-                            "(profiles/r5_persist_timeline_p32_*.md); what moved the trip is the exchange memory type (fine-grained instead of "
-                            "uncached: 6.55 -> 6.41 us on one box)"}
+                    "two_reduction_trip_us": None if trip2_ms is None else trip2_ms * 1e3,
+                    "note": "one launch runs all trips of a solve; bytes, traffic and time are per trip.  The working set is register / LDS "
+                            "resident and a trip is LATENCY, not HBM (n*p*8 = 5 MB per vector: the fraction of the HBM roofline is low by "
+                            "construction).  Round 4's trip had two grid reductions (profiles/r5_persist_timeline_p32.md: gathers + row "
+                            "arithmetic 1.3 us, reduction 1 1.96, trial step 0.52, wait for the row stores 0.5, reduction 2 1.92, commit + new "
+                            "direction 0.6, loop 0.13).  Round 5: (a) the gather DURING reduction 2, three ways (row flags; sentinel-initialised "
+                            "exchange halves with full / partial retry): 8.6 / 7.1-7.5 / 7.2-7.5 us against 6.55 -- the exchanged rows need 2.6 us "
+                            "to become visible to other XCDs under that load (profiles/r5_persist_timeline_p32_{flags,sentinel_*}.md); (b) "
+                            "fine-grained instead of uncached exchange memory: 6.55 -> 6.41; (c) ONE reduction per trip (msdp_pipe.h, the "
+                            "default: what reduction 2 carried is a polynomial in the step length whose coefficients are inner products known "
+                            "before it; the neighbours gather H*mdelta, C*tangent(r) and C*mdelta follow by linearity; eight values in one "
+                            "reduction, joint wave butterfly, next gather requested inside the reduction, own-workgroup rows from LDS): "
+                            "`two_reduction_trip_us` -> `kernel_us` in this run; phases in profiles/r5_persist_timeline_p32_pipe.md"}
     else:
         roofline = {"bound": "hbm", "achieved": hess_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hess_achieved / HBM_PEAK_GBS, "traffic": (pm_h or {}).get("hbm_bytes_per_launch"),
@@ -505,7 +516,7 @@ def main():
         "config": {"workload": workload, "n": n, "p": p, "nnz_C": int(C.nnz),
                    "TR_maxiter": 40, "TR_maxinner": 100, "hessvecs_per_step": hv / args.steps,
                    "parallelism": "rows%d" % N,
-                   "tcg_path": "persistent single-launch kernel" if persistent else
+                   "tcg_path": ("persistent single-launch kernel, one grid reduction per trip" if one_reduction else "persistent single-launch kernel") if persistent else
                                "chunked hipGraph, two launches per trip (linear-product trip, msdp_trip1.hip)"},
         "roofline": roofline,
         "hessvec_kernel": hess_kernel,

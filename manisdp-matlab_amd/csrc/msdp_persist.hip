@@ -803,17 +803,17 @@ static persist_fn persist_kernel_early(const PersistPlan& pl, bool fuse) {
     return nullptr;
 }
 // One-reduction instances (round 5, msdp_pipe.h): rows of <= 5 entries, every vector in registers
-static persist_fn persist_kernel_pipe(const PersistPlan& pl) {
+static persist_fn persist_kernel_pipe(const PersistPlan& pl, bool fuse = false) {
     if (pl.ew != 5) return nullptr;
-    if (pl.lpr == 16 && pl.r == 3) return k_tcg_pipe_obl<16, 5, 3>;
-    if (pl.lpr == 8 && pl.r == 2) return k_tcg_pipe_obl<8, 5, 2>;
+    if (pl.lpr == 16 && pl.r == 3) return fuse ? k_tcg_pipe_obl<16, 5, 3, false, true> : k_tcg_pipe_obl<16, 5, 3>;
+    if (pl.lpr == 8 && pl.r == 2) return fuse ? k_tcg_pipe_obl<8, 5, 2, false, true> : k_tcg_pipe_obl<8, 5, 2>;
     // (four row slots -- 97..128 rows per workgroup at p = 17..32, 129..256 at p <= 16: the sixth resident vector spills, measured
     // 9.6 us per trip against 8.2 for the two-reduction trip on a 180 x 180 grid at p = 32; tools/pipe_sizes_probe.py)
     return nullptr;
 }
 // early: 0 none, 1 the EARLY trip, 2 the one-reduction trip
 static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false, int early = 0) {
-    if (early == 2 && !fuse) { persist_fn f = persist_kernel_pipe(pl); if (f) return f; }
+    if (early == 2) { persist_fn f = persist_kernel_pipe(pl, fuse); if (f) return f; }
     if (early == 1) { persist_fn f = persist_kernel_early(pl, fuse); if (f) return f; }
 #define PK(L, E) if (pl.lpr == L && pl.ew == E && pl.r == L / 4) return k_tcg_persist_obl<L, E, L / 4, false>;
     if (pl.lpr == 16 && pl.r == 3) {
@@ -856,8 +856,8 @@ static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false, int e
     return nullptr;
 }
 
-static int persist_mode(msdp_handle h) { return h->tune.persist_pipe ? 2 : (h->tune.persist_early ? 1 : 0); }
-static bool persist_is_pipe(msdp_handle h, const PersistPlan& pl, bool fuse) { return !fuse && h->tune.persist_pipe && persist_kernel_pipe(pl) != nullptr; }
+static int persist_mode(msdp_handle h) { return h->tune.persist_early ? 1 : (h->tune.persist_pipe ? 2 : 0); }   // (persist_early is off by default: asking for it wins)
+static bool persist_is_pipe(msdp_handle h, const PersistPlan& pl, bool fuse) { return !h->tune.persist_early && h->tune.persist_pipe && persist_kernel_pipe(pl, fuse) != nullptr; }
 static bool persist_is_early(msdp_handle h, const PersistPlan& pl, bool fuse) { return !persist_is_pipe(h, pl, fuse) && h->tune.persist_early && persist_kernel_early(pl, fuse) != nullptr; }
 static size_t early_lds(const PersistPlan& pl);
 static size_t pipe_lds(const PersistPlan& pl) { const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr); return (size_t)pl.ew * rows * sizeof(int) + (size_t)2 * pl.r * PB * sizeof(double2); }   // + ls, HQs
@@ -937,7 +937,7 @@ int msdp_launch_tcg_persist(msdp_handle h, int reset_slots) {
     }
     if (dp.trace) {
         if (!(pl.lpr == 16 && pl.ew == 5 && pl.r == 3)) { msdp_set_error("persistent trace: only the <16, 5, 3> instance (17 <= p <= 32, rows of <= 5 entries) is traced"); return MSDP_EUNSUPPORTED; }
-        fn = h->tune.persist_pipe ? k_tcg_pipe_obl<16, 5, 3, true> : h->tune.persist_early ? k_tcg_persist_obl<16, 5, 3, false, true, false, true> : k_tcg_persist_obl<16, 5, 3, false, true>;
+        fn = h->tune.persist_early ? k_tcg_persist_obl<16, 5, 3, false, true, false, true> : h->tune.persist_pipe ? k_tcg_pipe_obl<16, 5, 3, true> : k_tcg_persist_obl<16, 5, 3, false, true>;
         HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     }
     hipLaunchKernelGGL(fn, dim3(G), dim3(PB), pl.lds, h->stream, dp, h->psync_slots, h->psync_err);
@@ -978,9 +978,13 @@ int msdp_persist_fused_ok(msdp_handle h) {
     PersistPlan pl;
     const int G = persist_grid(h->d);
     if (!persist_plan(h->d, G, pl)) return 0;
-    persist_fn fn = persist_kernel(pl, true, h->tune.persist_early ? 1 : 0);
+    persist_fn fn = persist_kernel(pl, true, persist_mode(h));
     if (!fn) return 0;
-    pl.lds = fused_lds(pl) + (persist_is_early(h, pl, true) ? early_lds(pl) : 0);
+    {   // (the one-reduction form: + ls; its HQs share the space of the proposal point and gradient)
+        const bool pipe = persist_is_pipe(h, pl, true), early = persist_is_early(h, pl, true);
+        const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr);
+        pl.lds = fused_lds(pl) + (early ? early_lds(pl) : 0) + (pipe ? (size_t)pl.ew * rows * sizeof(int) : 0);
+    }
     if (h->fused_sig_lpr == pl.lpr && h->fused_sig_ew == pl.ew && h->fused_sig_G == G && h->fused_sig_fn == (const void*)fn) return h->fused_sig_ok;
     int ok = 0, per_cu = 0;
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) == hipSuccess &&
@@ -995,9 +999,13 @@ int msdp_launch_rtr_fused(msdp_handle h) {
     const int G = persist_grid(h->d);
     PersistPlan pl;
     if (!persist_plan(h->d, G, pl)) { msdp_set_error("fused RTR: not eligible"); return MSDP_ESTATE; }
-    persist_fn fn = persist_kernel(pl, true, h->tune.persist_early ? 1 : 0);
+    persist_fn fn = persist_kernel(pl, true, persist_mode(h));
     if (!fn) { msdp_set_error("fused RTR: no kernel instance"); return MSDP_ESTATE; }
-    pl.lds = fused_lds(pl) + (persist_is_early(h, pl, true) ? early_lds(pl) : 0);
+    {   // (the one-reduction form: + ls; its HQs share the space of the proposal point and gradient)
+        const bool pipe = persist_is_pipe(h, pl, true), early = persist_is_early(h, pl, true);
+        const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr);
+        pl.lds = fused_lds(pl) + (early ? early_lds(pl) : 0) + (pipe ? (size_t)pl.ew * rows * sizeof(int) : 0);
+    }
     Dev dp = h->d;
     dp.G = G;
     hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, h->stream, h->psync_slots, h->psync_err);

@@ -153,7 +153,9 @@ __device__ __forceinline__ bool psync8(unsigned long long* slots, unsigned gen, 
 // TRACE stamps of this form: 0 top of the trip (gather about to be issued), 1 products, Hmd and the eight partial sums formed, rows of
 // Hmd stored; inside the reduction 4 wave butterfly done, 2 stores performed + workgroup barrier, 3 posted + slept, 7 wave 0's poll
 // returned; 5 the reduction returned, 6 new direction formed (end of the trip)
-template <int LPR, int EW, int R, bool TRACE>
+// FUSE: the whole trustregions() loop in this launch (trustregions.m:441-767), as in k_tcg_persist_obl<..., FUSE = true>: tCG, retraction,
+// cost / gradient at the proposal, the accept / reject decision, iterated until the gradient norm or the iteration cap stops it.
+template <int LPR, int EW, int R, bool TRACE, bool FUSE>
 __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* slots, int* err, const int bx) {
     static_assert(EW > 0 && R <= 5, "pipelined trip: ELL rows, every vector in registers");
     static_assert(PSYNC_NV == 8 && PSYNC_REP * PSYNC_NV == 64, "psync8 posts one slot per lane of wave 0");
@@ -175,6 +177,10 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     // workgroup's row: exchange buffer); HQs = this workgroup's own rows of Hmd, two halves alternating like the buffer's.
     int* ls = cs + EW * ROWS;                                      // [EW][ROWS]
     double2* HQs = reinterpret_cast<double2*>(ls + EW * ROWS);     // [2][R][PB]
+    // FUSE only: the proposal point, its gradient and eG.  They share the space of HQs: that one lives inside a tCG, these between two
+    double2* YPs = HQs;                                            // [R][PB]
+    double2* GPs = YPs + R * PB;                                   // [R][PB]
+    double* EGPs = reinterpret_cast<double*>(GPs + R * PB);        // [ROWS]
 
     const Ctl* c = d.ctl;
     const bool lead = bx == 0 && threadIdx.x == 0;
@@ -187,20 +193,23 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         }
         return;
     }
-    if (lead) msdp_publish(d, k_tr, 0, 1);
+    if (lead && !FUSE) msdp_publish(d, k_tr, 0, 1);
     const int bid = bx, GS = d.G;
-    psync_reset_other(slots + PSYNC_REGION, bid, GS);
+    if (!FUSE) psync_reset_other(slots + PSYNC_REGION, bid, GS);   // region B belongs to the TR-iteration tail kernel
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi, 0, bx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
     const bool colok = 2 * sub < d.ld;
-    const int cur = c->cur;
+    int cur = c->cur;
     const bool bench = c->bench_mode != 0;
-    const double Delta = c->Delta;
+    double Delta = c->Delta;
     const double kappa = c->kappa, theta = c->theta;
     const int mininner = c->mininner, maxinner = c->maxinner;
-    const double gg = c->gg;
+    double gg = c->gg;
+    // trust-region level state (FUSE; the statistics are kept in d.ctl by the lead thread, not in registers)
+    double fx = c->fx;
+    int k_it = c->k;
     const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
     const double* __restrict__ gl = cur ? d.Gr[1] : d.Gr[0];
     const double* __restrict__ eGl = cur ? d.eG[1] : d.eG[0];
@@ -277,23 +286,24 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
             if (lead_ok) nl = w + 1;
         }
     }
-    unsigned gen = 0;
+    unsigned gen = 0, nbar = 0;
     const unsigned half_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
     // exchange buffer: halves 0 / 1 = the rows of Hmd (alternating trips), 2 = the rows of md' and 3 = those of tangent(r') of a refresh trip
     const __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, 4u * half_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[1] : d.Gr[0], 0, half_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[1] : d.Gr[0], 0, half_bytes, 0x00020000);
     const unsigned gld = (unsigned)d.ld, gcol = colok ? 2 * sub : 0;
 
     double z_r = gg, d_Pd = gg, e_Pd = 0.0, e_Pe = 0.0, model_value = 0.0, alpha = 0.0, beta = 0.0;
-    const double norm_r0 = sqrt(gg);
+    double norm_r0 = sqrt(gg);
     int j = 0, stop = 5;
     bool first = true, direct = false, failed = false;
     unsigned xq = 0;                                               // the half this trip's rows of Hmd go to
     bool have_x = false;
-    constexpr bool PREF = R * EW <= 15;                            // (four row slots: the rows in flight across the trip's arithmetic spill)
   auto trips = [&](auto nlc) {
     constexpr int NL = decltype(nlc)::value;                       // columns [0, NL) from LDS, [NL, EW) through the buffer
     constexpr int NG = EW - NL;
+    // the next trip's rows requested inside the reduction: where they are few enough to stay in flight across the trip's arithmetic
+    constexpr bool PREF = R * NG <= (FUSE ? 9 : 15);
     double2 X[R][NG];                                              // the gathered rows (in flight across the end of a trip)
     for (;;) {
         TSTAMP(0);
@@ -445,24 +455,140 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
 #undef PIPE_FOLDL
 #undef PIPE_GATHER_ALL
   };
-    if (LOC && nl >= 3) trips(std::integral_constant<int, LOC ? 3 : 0>());
-    else if (LOC && nl == 2) trips(std::integral_constant<int, LOC ? 2 : 0>());
+  bool first_tr = true;
+  for (;;) {   // ---- trust-region iterations (exactly one pass when !FUSE)
+    if (FUSE && !first_tr) {
+        // tCG.m:102-157 at the (possibly new) current point: eta = 0, r = mdelta = grad
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double2 g = Gs[r * PB + threadIdx.x];
+            eta[r] = zz; rr[r] = g; md[r] = g; hmd[r] = zz; cmd[r] = zz; ctr[r] = zz;   // (cmd / ctr: dead across the tail, said so)
+        }
+        z_r = gg; d_Pd = gg; e_Pd = 0.0; e_Pe = 0.0; model_value = 0.0; alpha = 0.0; beta = 0.0;
+        norm_r0 = sqrt(gg);
+        j = 0; stop = 5; first = true; direct = false; have_x = false;
+        rs_g = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[1] : d.Gr[0], 0, half_bytes, 0x00020000);
+    }
+    first_tr = false;
+    // (FUSE at 16 lanes per row: ONE instance of the trip loop -- with three of them inside the loop over the TR iterations the
+    // register allocation spills 400 bytes per lane into the trips, 103 000 Hess-vec/s on G81 at p = 32 against 170 000 with one)
+    constexpr bool MULTI = LOC && !(FUSE && LPR >= 16);
+    if (MULTI && nl >= 3) trips(std::integral_constant<int, MULTI ? 3 : 0>());
+    else if (MULTI && nl == 2) trips(std::integral_constant<int, MULTI ? 2 : 0>());
     else trips(std::integral_constant<int, 0>());
     if (failed) return;
-    // ---- hand eta, Heta = r - grad and the final scalars to the RTR kernels (trustregions.m:540-550)
+    if (!FUSE) {
+        // ---- hand eta, Heta = r - grad and the final scalars to the RTR kernels (trustregions.m:540-550)
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (OK(r)) {
-            const int64_t o = (int64_t)ROW(r) * d.ld + 2 * sub;
-            const double2 g = Gs[r * PB + threadIdx.x];
-            st2(d.eta[0] + o, eta[r]);
-            st2(d.Heta[0] + o, make_double2(rr[r].x - g.x, rr[r].y - g.y));
+        for (int r = 0; r < R; ++r) {
+            if (OK(r)) {
+                const int64_t o = (int64_t)ROW(r) * d.ld + 2 * sub;
+                const double2 g = Gs[r * PB + threadIdx.x];
+                st2(d.eta[0] + o, eta[r]);
+                st2(d.Heta[0] + o, make_double2(rr[r].x - g.x, rr[r].y - g.y));
+            }
         }
+        if (lead) {
+            frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha, beta, 0, j, stop, 0, 0, 0);
+            d.ctl->tcg_running = 0;
+            msdp_publish(d, k_tr, j, 0);
+        }
+        return;
     }
+    // ================= rest of the TR iteration (FUSE): trustregions.m:540-729 =================
+    // x_prop = retr(x, eta) (ManiSDP_onlyunitdiag.m:142-145), <eta, grad + .5*Heta> (trustregions.m:549-550)
+    double tv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};          // [0] cost, [1] |grad|^2 at the proposal, [2] <eta, grad + .5 Heta>
+    const __amdgpu_buffer_rsrc_t rs_yp = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Y[0] : d.Y[1], 0, half_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_gp = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[0] : d.Gr[1], 0, half_bytes, 0x00020000);
+    double* eGp = cur ? d.eG[0] : d.eG[1];
+    __syncthreads();                                               // (every wave has left the tCG: YPs / GPs take the place of HQs)
+    // (the step leaves the registers first: the rest of the iteration is rolled loops over LDS)
+#pragma unroll
+    for (int r = 0; r < R; ++r) { YPs[r * PB + threadIdx.x] = eta[r]; GPs[r * PB + threadIdx.x] = rr[r]; }
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+        const double2 y = Ys[r * PB + threadIdx.x], g = Gs[r * PB + threadIdx.x];
+        const double2 rq = GPs[r * PB + threadIdx.x];
+        const double2 he = make_double2(rq.x - g.x, rq.y - g.y);
+        const double2 e0 = YPs[r * PB + threadIdx.x];
+        tv[2] += e0.x * (g.x + 0.5 * he.x) + e0.y * (g.y + 0.5 * he.y);
+        const double2 x = make_double2(y.x + e0.x, y.y + e0.y);
+        double nn = sqrt(msdp_group_sum<LPR>(x.x * x.x + x.y * x.y));
+        if (!(nn > 0.0)) nn = 1.0;                                  // empty row slot
+        const double2 ypr = OK(r) ? make_double2(x.x / nn, x.y / nn) : zz;
+        YPs[r * PB + threadIdx.x] = ypr;
+        if (OK(r)) st2_sc1(rs_yp, ((unsigned)ROW(r) * gld + 2 * sub) * 8u, ypr);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!pbarrier(slots, nbar++, GS, shb8, err, bid)) return;
+    // cost and gradient at the proposal (ManiSDP_onlyunitdiag.m:117-125): YC = Y*C, eG = sum(YC.*Y), G = YC - Y.*eG.
+    // Rolled loop over the row slots (LDS in, LDS out): once per TR iteration, no register pressure on the tCG loop
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+        double2 xw[EW];
+#pragma unroll
+        for (int w = 0; w < EW; ++w) xw[w] = ld2_sc1(rs_yp, ((unsigned)cs[w * ROWS + SLOT(r)] * gld + gcol) * 8u);
+        double2 acc = zz;
+#pragma unroll
+        for (int w = 0; w < EW; ++w) { const double vv = vs[w * ROWS + SLOT(r)]; acc.x = fma(vv, xw[w].x, acc.x); acc.y = fma(vv, xw[w].y, acc.y); }
+        if (!colok) acc = zz;
+        const double2 ypr = YPs[r * PB + threadIdx.x];
+        const double dot = msdp_group_sum<LPR>(acc.x * ypr.x + acc.y * ypr.y);
+        const double2 gpr = OK(r) ? make_double2(acc.x - ypr.x * dot, acc.y - ypr.y * dot) : zz;
+        GPs[r * PB + threadIdx.x] = gpr;
+        tv[1] += gpr.x * gpr.x + gpr.y * gpr.y;
+        if (sub == 0) {
+            EGPs[SLOT(r)] = ROK(r) ? dot : 0.0;
+            if (ROK(r)) { tv[0] += 0.5 * dot; eGp[ROW(r)] = dot; }
+        }
+        if (OK(r)) st2_sc1(rs_gp, ((unsigned)ROW(r) * gld + 2 * sub) * 8u, gpr);
+    }
+    // (the proposal's gradient rows are in place before the post: psync8 waits for the stores)
+    if (!psync8(slots, gen++, GS, tv, sh8, shb8, err, bid, backoff, nullptr, []() {})) return;
+    {   // trustregions.m:548-729, identical in every workgroup (same bits in, same decision out)
+        // (the options are read here, once per TR iteration, not kept in scalar registers across the tCG loop)
+        const double Delta_bar = c->Delta_bar, rho_prime = c->rho_prime, rho_reg_opt = c->rho_reg;
+        const double fp = tv[0], ggp = tv[1], prd = tv[2];
+        double rhonum = fx - fp;                                             // :548
+        double rhoden = -prd;                                                // :550
+        const double rreg = fmax(1.0, fabs(fx)) * 2.220446049250313e-16 * rho_reg_opt;   // :579
+        rhonum += rreg;
+        rhoden += rreg;
+        const bool model_decreased = rhoden >= 0.0;                          // :614
+        const double rho = rhonum / rhoden;                                  // :621
+        if (rho < 0.25 || !model_decreased || isnan(rho)) Delta = Delta / 4.0;            // :653
+        else if (rho > 0.75 && (stop == 1 || stop == 2)) Delta = fmin(2.0 * Delta, Delta_bar);   // :669
+        const bool accept = model_decreased && rho > rho_prime;              // :688
+        if (lead) {
+            Ctl* cw = d.ctl;
+            cw->rho = rho; cw->rhonum = rhonum; cw->rhoden = rhoden; cw->fx_prop = fp; cw->gg_prop = ggp;
+            if (accept) cw->accepted++; else cw->rejected++;
+            cw->hessvecs += j;
+            cw->cost_evals++;
+            cw->last_stop_inner = stop;
+        }
+        if (accept) {
+            cur ^= 1;
+            fx = fp; gg = ggp;
+#pragma unroll 1
+            for (int r = 0; r < R; ++r) {
+                Ys[r * PB + threadIdx.x] = YPs[r * PB + threadIdx.x];
+                Gs[r * PB + threadIdx.x] = GPs[r * PB + threadIdx.x];
+                if (sub == 0) eGs[SLOT(r)] = EGPs[SLOT(r)];
+            }
+        }
+        ++k_it;                                                              // :729
+    }
+    __syncthreads();                                                         // eGs / Ys / Gs updates visible to the whole workgroup
+    if (sqrt(gg) < c->tolgradnorm || k_it >= c->maxiter) break;                    // stoppingcriterion.m:51-72
+  }
     if (lead) {
-        frame_store(&d.F[0], z_r, d_Pd, e_Pd, e_Pe, model_value, norm_r0, alpha, beta, 0, j, stop, 0, 0, 0);
-        d.ctl->tcg_running = 0;
-        msdp_publish(d, k_tr, j, 0);
+        Ctl* cw = d.ctl;
+        cw->fx = fx; cw->gg = gg; cw->norm_grad = sqrt(gg); cw->Delta = Delta;
+        cw->k = k_it; cw->cur = cur;
+        cw->done = 1;
+        cw->tcg_running = 0;
+        frame_store(&d.F[0], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, cw->last_stop_inner, 0, 0, 0);
     }
 #undef SLOT
 #undef ROW
@@ -470,7 +596,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
 #undef OK
 }
 
-template <int LPR, int EW, int R, bool TRACE = false>
+template <int LPR, int EW, int R, bool TRACE = false, bool FUSE = false>
 __global__ __launch_bounds__(PB) void k_tcg_pipe_obl(Dev d, unsigned long long* slots, int* err) {
-    tcg_pipe_body<LPR, EW, R, TRACE>(d, slots, err, (int)blockIdx.x);
+    tcg_pipe_body<LPR, EW, R, TRACE, FUSE>(d, slots, err, (int)blockIdx.x);
 }

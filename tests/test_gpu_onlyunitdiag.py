@@ -180,8 +180,10 @@ def test_persistent_tcg_matches_oracle(lib, shape, p, k):
     # there) and the two-reduction trip (everything else, and persist_pipe = 0)
     one_reduction = p <= 32 and 2 * k + 1 <= 5
     refs = {}
-    for pipe in (1, 0):
+    # ... each as per-iteration launches (tCG kernel + TR tail kernel) and, at p <= 32, with the whole trustregions() loop in one launch
+    for pipe, fused in ((1, 1), (1, 0), (0, 1)):
         h.set_option("persist_pipe", pipe)
+        h.set_option("fused_rtr", fused)
         h.set_point(Y)
         assert h.persist_form() == (2 if pipe and one_reduction else 0)
         for maxinner in (1, 2, 7, 100):
@@ -354,18 +356,20 @@ def test_one_reduction_trip_solves_G81_like_the_two_reduction_trip(lib, p):
     n = C.shape[0]
     Y, _ = _rand_point(n, p, seed=0)
     h = lib.Handle.onlyunitdiag(C, pcap=p)
-    h.set_option("fused_rtr", 0)
     opts = lib.default_opts(maxiter=40, maxinner=100, tolgradnorm=1e-8)
     out = {}
-    for name, pipe, refresh in (("two", 0, 16), ("one", 1, 16), ("one again", 1, 16), ("one/4", 1, 4), ("one/64", 1, 64)):
+    for name, pipe, refresh, fused in (("two", 0, 16, 0), ("one", 1, 16, 0), ("one again", 1, 16, 0), ("one/4", 1, 4, 0), ("one/64", 1, 64, 0),
+                                       ("one fused", 1, 16, 1), ("one fused again", 1, 16, 1), ("one all rows through the buffer", 1, 16, 0)):
         h.set_option("persist_pipe", pipe)
         h.set_option("pipe_refresh", refresh)
+        h.set_option("fused_rtr", fused)                       # 1: the whole trustregions() loop in the one launch (k_tcg_pipe_obl<.., FUSE>)
+        h.set_option("pipe_local", 0 if "buffer" in name else 1)
         h.set_point(Y)
         assert h.tcg_path() == 1 and h.persist_form() == (2 if pipe else 0)
         st = h.rtr(opts)
         out[name] = (st, h.get_point())
     ref, Yref = out["two"]
-    for name in ("one", "one/4", "one/64"):
+    for name in ("one", "one/4", "one/64", "one fused", "one all rows through the buffer"):
         st, Yo = out[name]
         assert (st.iters, st.hessvecs, st.accepted, st.rejected, st.last_stop_inner) == (ref.iters, ref.hessvecs, ref.accepted, ref.rejected, ref.last_stop_inner), name
         assert abs(st.cost - ref.cost) <= 1e-11 * abs(ref.cost), (name, st.cost, ref.cost)
@@ -373,6 +377,7 @@ def test_one_reduction_trip_solves_G81_like_the_two_reduction_trip(lib, p):
         assert np.abs(Yo - Yref).max() <= 1e-6, name
         assert np.allclose(np.linalg.norm(Yo, axis=1), 1.0, atol=1e-14)
     assert np.array_equal(out["one"][1], out["one again"][1]) and out["one"][0].cost == out["one again"][0].cost
+    assert np.array_equal(out["one fused"][1], out["one fused again"][1]) and out["one fused"][0].cost == out["one fused again"][0].cost
     h.close()
 
 

@@ -28,7 +28,8 @@ WHAT=" ${*:-all} "     # one or more of: bench dense sparse (default: all)
 want() { [[ "$WHAT" == *" all "* || "$WHAT" == *" $1 "* ]]; }
 if want bench; then
 stats bench 400 python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-kkt --no-dense --no-affine --no-large-sparse
-both persist 120 python3 "$ROOT/tools/pmc_probe.py" 32
+both persist 120 python3 "$ROOT/tools/pmc_probe.py" 32 0
+both pipe 120 python3 "$ROOT/tools/pmc_probe.py" 32 1
 fi
 if want dense; then
 stats dense20000 300 python3 "$ROOT/tools/dense_probe.py" 20000 16 32 64
@@ -43,6 +44,7 @@ both hess1e6win 300 python3 "$ROOT/tools/hess_large_probe.py" 1000 32 --sweep=3 
 fi
 cd "$ROOT"
 [ -d "$OUT/persist_fetch" ] && python3 tools/pmc_to_json.py k_tcg_persist_obl "$OUT/pmc_persist_g81_p32.json" --per 64 "$OUT/persist_fetch" "$OUT/persist_write"
+[ -d "$OUT/pipe_fetch" ] && python3 tools/pmc_to_json.py k_tcg_pipe_obl "$OUT/pmc_pipe_g81_p32.json" --per 64 "$OUT/pipe_fetch" "$OUT/pipe_write"
 for p in 16 32; do
   [ -d "$OUT/dense20000p${p}_fetch" ] && python3 tools/pmc_sum.py "$OUT/pmc_dense20000_p$p.json" k_dense_hess_epi hbm_bytes_per_hessvec --only k_dense_sym,k_sym_fold,k_dense_partial3,k_dense_hess_epi "$OUT/dense20000p${p}_fetch" "$OUT/dense20000p${p}_write"
 done
