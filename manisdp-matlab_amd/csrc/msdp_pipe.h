@@ -34,8 +34,7 @@
 #include "msdp_psync.h"
 
 // Eight-value grid reduction: wave w polls value array w (PSYNC_NV = 8 arrays per generation); same slot protocol and layout as psync().
-// (A layout with the eight values of a workgroup in ONE 64-byte line per replica -- 8 lines per post instead of 64, polled with
-// 16-byte loads -- was measured too: 5.99 us per trip against 5.83; the cross-wave sum of its 64 partials costs more than the posts save.)
+// (The layout with the eight values of a workgroup in ONE 64-byte line per replica is psync8_lines below.)
 // The eight per-lane partials are reduced over the wave TOGETHER: a butterfly that halves the number of values a lane carries at each
 // of its first three steps (10 exchanges and additions instead of the 48 of eight separate wave sums; lane 8 i ends with value i).
 // sh8: 8 x PWAVES doubles, shb8: 16 doubles.  Returns false when a bounded spin ran out.
@@ -150,17 +149,122 @@ __device__ __forceinline__ bool psync8(unsigned long long* slots, unsigned gen, 
     return bad == 0.0;
 }
 
+// The same reduction with the eight values of a workgroup in ONE 64-byte line per replica (option pipe_lines):
+//     slot(gen, rep, b, vi) = (gen * PSYNC_REP + rep) * PSYNC_NV * MSDP_MAX_GRID + b * 8 + vi,            b < 256
+// a post is 8 lines instead of 64, and wave w polls the lines of the workgroups 32 w .. 32 w + 31 with two 16-byte loads per lane
+// (lane l: workgroup 32 w + 16 q + l / 4, values 2 (l % 4) and 2 (l % 4) + 1).  Sums: over q, over the sixteen lanes of a value
+// pair (DPP rotations inside a row, permlane swaps across rows), over the waves in index order -- the same order in every workgroup.
+// shp: PWAVES x 8 doubles.
+typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
+template <class F>
+__device__ __forceinline__ bool psync8_lines(unsigned long long* slots, unsigned gen, int G, double (&v)[8], double* sh8, double* shp, double* shb8,
+                                             int* err, int bid, int backoff, unsigned long long* tr, F on_ready) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        const bool h8 = (lane & 8) != 0;
+        double a[4], b[2], x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = msdp_swap_add<32>(v[k], v[4 + k]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) b[k] = msdp_swap_add<16>(a[k], a[2 + k]);
+        x = (h8 ? b[1] : b[0]) + msdp_dpp<0x128>(h8 ? b[0] : b[1]);
+        x += msdp_dpp<MSDP_DPP_XOR1>(x); x += msdp_dpp<MSDP_DPP_XOR2>(x); x += msdp_dpp<MSDP_DPP_HALF_MIRROR>(x);
+        if ((lane & 7) == 0) sh8[(lane >> 3) * PWAVES + w] = x;
+    }
+    if (tr && threadIdx.x == 0) tr[4] = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tr && threadIdx.x == 0) tr[2] = __builtin_readcyclecounter();
+    unsigned long long* gbase = slots + (size_t)(gen % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID;
+    if (w == 0) {
+        const int rep = lane >> 3, vi = lane & 7;
+        double s = 0.0;
+        for (int i = 0; i < PWAVES; ++i) s += sh8[vi * PWAVES + i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(gbase + (size_t)rep * PSYNC_NV * MSDP_MAX_GRID + (size_t)bid * 8 + vi,
+                           (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const unsigned long long* p0 = gbase + (size_t)(bid & (PSYNC_REP - 1)) * PSYNC_NV * MSDP_MAX_GRID + (size_t)(32 * w + (lane >> 2)) * 8 + 2 * (lane & 3);
+    const bool in0 = 32 * w + (lane >> 2) < G, in1 = 32 * w + 16 + (lane >> 2) < G;   // lines >= G hold the sentinel for ever
+    double t0 = 0.0, t1 = 0.0;
+    int spins = 0;
+    bool fail = false;
+    const int first = ((backoff >> 16) & 0xff) ? ((backoff >> 16) & 0xff) : (backoff & 0xff);   // (19 units by default: tools/pipe_ab_probe.py)
+    for (int q = 0; q < first; ++q) __builtin_amdgcn_s_sleep(1);
+    if (tr && threadIdx.x == 0) tr[3] = __builtin_readcyclecounter();
+    if (__builtin_amdgcn_ballot_w64(in0) != 0ULL) {               // (a wave whose 32 workgroups do not exist has nothing to wait for)
+        for (;;) {
+            v2ul a0, a1;
+            asm volatile(
+                "global_load_dwordx4 %0, %2, off sc1\n\t"
+                "global_load_dwordx4 %1, %2, off offset:1024 sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(a0), "=&v"(a1)
+                : "v"(p0)
+                : "memory");
+            bool ok = true;
+            t0 = 0.0; t1 = 0.0;
+            if (in0) { ok = a0.x != PSYNC_SENT && a0.y != PSYNC_SENT; t0 = __longlong_as_double((long long)a0.x); t1 = __longlong_as_double((long long)a0.y); }
+            if (in1) { ok = ok && a1.x != PSYNC_SENT && a1.y != PSYNC_SENT; t0 += __longlong_as_double((long long)a1.x); t1 += __longlong_as_double((long long)a1.y); }
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ULL) break;
+            ++spins;
+            if (spins > PSYNC_SPIN_LIMIT ||
+                ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
+            for (int q = 0; q < ((backoff >> 8) & 0xff); ++q) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    if (tr && threadIdx.x == 0) tr[7] = (__builtin_readcyclecounter() << 4) + (unsigned long long)(spins < 15 ? spins : 15);
+    // lanes l, l ^ 4, l ^ 8, l ^ 12 of a row, then the four rows: the sixteen lanes that hold the same value pair
+    t0 += msdp_dpp<0x124>(t0); t1 += msdp_dpp<0x124>(t1);         // row_ror:4
+    t0 += msdp_dpp<0x128>(t0); t1 += msdp_dpp<0x128>(t1);         // row_ror:8
+    t0 = msdp_rowpair_sum<16>(t0); t1 = msdp_rowpair_sum<16>(t1);
+    t0 = msdp_rowpair_sum<32>(t0); t1 = msdp_rowpair_sum<32>(t1);
+    if (lane < 4) { shp[w * 8 + 2 * lane] = t0; shp[w * 8 + 2 * lane + 1] = t1; }
+    if (lane == 0) {
+        shb8[8 + w] = fail ? 1.0 : 0.0;
+        if (fail) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // every wave's poll has returned: ALL workgroups have posted this generation (a wave alone has only seen the posts of its 32
+    // workgroups: on_ready() -- whatever needs every workgroup's stores -- must not run before this barrier), i.e. finished reading
+    // the previous one -- my lines of it back to the sentinel
+    on_ready();
+    if (w == 0)
+        __hip_atomic_store(slots + (size_t)((gen + PSYNC_GEN - 1) % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID +
+                               (size_t)(lane >> 3) * PSYNC_NV * MSDP_MAX_GRID + (size_t)bid * 8 + (lane & 7),
+                           PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // value i = the sum over the waves, formed by lane i (every wave does the same), then broadcast
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < PWAVES; ++k) s += shp[k * 8 + (lane & 7)];
+    const double fl = shb8[8 + (lane & 7)];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = msdp_readlane(s, i);
+    return __builtin_amdgcn_ballot_w64(fl != 0.0) == 0ULL;
+}
+
 // TRACE stamps of this form: 0 top of the trip (gather about to be issued), 1 products, Hmd and the eight partial sums formed, rows of
 // Hmd stored; inside the reduction 4 wave butterfly done, 2 stores performed + workgroup barrier, 3 posted + slept, 7 wave 0's poll
 // returned; 5 the reduction returned, 6 new direction formed (end of the trip)
 // FUSE: the whole trustregions() loop in this launch (trustregions.m:441-767), as in k_tcg_persist_obl<..., FUSE = true>: tCG, retraction,
 // cost / gradient at the proposal, the accept / reject decision, iterated until the gradient norm or the iteration cap stops it.
+// Which of the two reductions: the line layout (default; G81 p = 32 4.82 us per trip against 4.99, p = 16 3.54 against 3.74, with the
+// cross-wave sum formed by eight lanes instead of every thread reading 64 partials -- the first version of it lost to the arrays)
+#ifndef MSDP_PIPE_LINES
+#define MSDP_PIPE_LINES 1
+#endif
+#if MSDP_PIPE_LINES
+#define PSYNC8(slots, gen, G, v, sh8, shb8, err, bid, backoff, tr, f) psync8_lines(slots, gen, G, v, sh8, shp, shb8, err, bid, backoff, tr, f)
+#else
+#define PSYNC8(slots, gen, G, v, sh8, shb8, err, bid, backoff, tr, f) psync8(slots, gen, G, v, sh8, shb8, err, bid, backoff, tr, f)
+#endif
 template <int LPR, int EW, int R, bool TRACE, bool FUSE>
 __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* slots, int* err, const int bx) {
     static_assert(EW > 0 && R <= 5, "pipelined trip: ELL rows, every vector in registers");
     static_assert(PSYNC_NV == 8 && PSYNC_REP * PSYNC_NV == 64, "psync8 posts one slot per lane of wave 0");
     extern __shared__ double lds[];
     __shared__ double sh8[8 * PWAVES];
+    __shared__ double shp[8 * PWAVES];
     __shared__ double shb8[16];
     constexpr int RPW = 64 / LPR;
     constexpr int RSTEP = PWAVES * RPW;
@@ -394,7 +498,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         // (my rows of Hmd are performed before I post: the wait sits inside psync8, behind the wave reduction)
         // (the next trip's gather goes out as soon as this wave has seen every workgroup's post: its latency runs under the rest of the
         // reduction and the arithmetic behind it.  Not behind a refresh trip: that one's two direct gathers come first.)
-        if (!psync8(slots, gen++, GS, v, sh8, shb8, err, bid, backoff,
+        if (!PSYNC8(slots, gen++, GS, v, sh8, shb8, err, bid, backoff,
                     (TRACE && j >= MSDP_TRACE_J0 && j < MSDP_TRACE_J0 + MSDP_TRACE_NJ) ? d.trace + ((size_t)bx * MSDP_TRACE_NJ + (j - MSDP_TRACE_J0)) * 8 : nullptr,
                     [&]() { if (PREF && !pub) { PIPE_ISSUE(rs_md, xq * half_bytes, NL); have_x = true; } })) { failed = true; break; }
         TSTAMP(5);
@@ -544,7 +648,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         if (OK(r)) st2_sc1(rs_gp, ((unsigned)ROW(r) * gld + 2 * sub) * 8u, gpr);
     }
     // (the proposal's gradient rows are in place before the post: psync8 waits for the stores)
-    if (!psync8(slots, gen++, GS, tv, sh8, shb8, err, bid, backoff, nullptr, []() {})) return;
+    if (!PSYNC8(slots, gen++, GS, tv, sh8, shb8, err, bid, backoff, nullptr, []() {})) return;
     {   // trustregions.m:548-729, identical in every workgroup (same bits in, same decision out)
         // (the options are read here, once per TR iteration, not kept in scalar registers across the tCG loop)
         const double Delta_bar = c->Delta_bar, rho_prime = c->rho_prime, rho_reg_opt = c->rho_reg;
