@@ -401,7 +401,7 @@ int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, const int64_
  *                       is known, the neighbours gather the rows of H*mdelta, and C*tangent(r), C*mdelta follow by linearity.
  *                       Same tests and decisions as tCG.m; <r', r'> and the model value that decide a trip carry a rounding error of
  *                       eps <r, r> / <r', r'> (the directly summed values replace them one trip later).  G81, p = 32: 6.6 -> 4.9 us
- *                       per trip (default 1; 0 = the two-reduction trip)
+ *                       per trip (default 1; 0 = the two-reduction trip; env MSDP_NO_PERSIST_PIPE=1)
  *   "pipe_refresh" k   one-reduction trip: every k-th trip also publishes tangent(r) and mdelta, and the next one forms both
  *                       products from direct gathers (default 16: |Heta - Hess(eta)|/|Heta| <= 1.2e-11 after 100 trips on G81;
  *                       32: 6e-11, 8: 2.5e-12; the recurrences lose accuracy with the SQUARE of k)

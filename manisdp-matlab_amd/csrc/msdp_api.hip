@@ -384,6 +384,7 @@ static int new_handle(int kind, int64_t n, msdp_handle* out) {
         auto on = [](const char* name) { const char* e = getenv(name); return e && atoi(e) != 0; };
         if (on("MSDP_NO_PERSIST")) h->tune.persist = 0;
         if (on("MSDP_NO_FUSED_RTR")) h->tune.fused_rtr = 0;
+        if (on("MSDP_NO_PERSIST_PIPE")) h->tune.persist_pipe = 0;
         if (on("MSDP_NO_GRAPH")) h->tune.graph = 0;
         if (on("MSDP_TIMING")) h->tune.timing = 1;
         if (on("MSDP_ESC_DEBUG")) h->tune.esc_debug = 1;
