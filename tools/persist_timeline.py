@@ -32,8 +32,8 @@ if pipe:
              "reduction: the eight partial sums over the wave (joint butterfly), to LDS",
              "reduction: wait for the row stores (s_waitcnt vmcnt(0)) + workgroup barrier",
              "reduction: sum over the waves, post, back-off sleep",
-             "reduction: wave 0 polls its value array until all workgroups have posted (failed polls of wave 0 per trip: %.2f)" % polls.mean(),
-             "reduction: wave sum, workgroup barrier (= the slowest polling wave), results to registers",
+             "reduction: wave 0 polls the lines of its 32 workgroups until they have posted (failed polls of wave 0 per trip: %.2f)" % polls.mean(),
+             "reduction: sum over the lanes of a value pair, workgroup barrier (= the slowest polling wave), next gather requested, sum over the waves",
              "alpha, tests, commit, beta, new direction (:170-287)",
              "loop back (next trip's set-up)"]
     NP = 8
