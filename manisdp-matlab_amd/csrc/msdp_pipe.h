@@ -627,7 +627,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     if (!pbarrier(slots, nbar++, GS, shb8, err, bid)) return;
     // cost and gradient at the proposal (ManiSDP_onlyunitdiag.m:117-125): YC = Y*C, eG = sum(YC.*Y), G = YC - Y.*eG.
     // Rolled loop over the row slots (LDS in, LDS out): once per TR iteration, no register pressure on the tCG loop
-#pragma unroll 1
+#pragma unroll
     for (int r = 0; r < R; ++r) {
         double2 xw[EW];
 #pragma unroll
