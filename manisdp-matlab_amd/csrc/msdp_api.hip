@@ -2228,20 +2228,38 @@ static int rtr_core(msdp_handle h, const msdp_rtr_opts* opts, bool* timed_out) {
             first_iter = false;
             return msdp_launch_tr_tail(h);                                // :540-729
         };
-        int enq = 0;
+        // (round 5: up to AHEAD iterations beyond the last one known to have started -- with ONE the device waited for the host
+        // whenever an iteration was shorter than the host's polling sleep + two launches: 78 us per TR iteration whatever its tCG
+        // (tools/fused_overhead_probe.py).  What is enqueued behind a finished solve returns at once: at most AHEAD - 1 pairs of
+        // empty launches per call.)
+        const int AHEAD = 3;
+        int enq = 0, started = 0;
         bool done = false;
         const auto ta = std::chrono::steady_clock::now();
         auto last_query = ta;
-        if (opts->maxiter > 0) { if ((rc = enqueue_iter())) return rc; enq = 1; }
-        while (enq > 0 && !done) {
-            const unsigned long long want = (unsigned long long)(unsigned)enq;
+        while (!done) {
+            while (enq < opts->maxiter && enq < started + AHEAD) {
+                const auto te = std::chrono::steady_clock::now();
+                if ((rc = enqueue_iter())) return rc;
+                if (timing) {
+                    const double de = std::chrono::duration<double>(std::chrono::steady_clock::now() - te).count();
+                    t_enq_sum += de; if (de > t_enq_max) t_enq_max = de;
+                }
+                ++enq;
+                last_query = std::chrono::steady_clock::now();
+            }
+            if (started >= enq) break;                           // every iteration of the budget has started (or maxiter = 0)
             long spins = 0;
             for (;;) {
                 const unsigned long long s = *h->h_status;
-                if ((s >> 32) == want) { if (((s & 0xffffffffULL) >> 1) & 0x40000000) done = true; break; }
-                // a TR iteration lasts 0.3-2 ms and the host only has to stay one iteration ahead: poll politely
-                // (a hard spin burns a full core; under a container CPU quota that got this thread throttled
-                // for tens of ms at a time, seen as 60 ms holes in the kernel trace of the G81 solve)
+                const int it = (int)(s >> 32);
+                if (it > started && it <= enq) {
+                    started = it;
+                    if (((s & 0xffffffffULL) >> 1) & 0x40000000) done = true;
+                    break;
+                }
+                // a TR iteration lasts 0.02-2 ms: poll politely (a hard spin burns a full core; under a container CPU quota that
+                // got this thread throttled for tens of ms at a time, seen as 60 ms holes in the kernel trace of the G81 solve)
                 std::this_thread::sleep_for(std::chrono::microseconds(20));
                 if ((++spins & 0xff) == 0) {
                     // hipStreamQuery is NOT a cheap poll (every call makes the runtime touch the queue; called every
@@ -2253,12 +2271,13 @@ static int rtr_core(msdp_handle h, const msdp_rtr_opts* opts, bool* timed_out) {
                         last_query = now;
                         if (hipStreamQuery(h->stream) == hipSuccess) {
                             const unsigned long long s2 = *h->h_status;
-                            if ((s2 >> 32) == want) { if (((s2 & 0xffffffffULL) >> 1) & 0x40000000) done = true; break; }
+                            const int it2 = (int)(s2 >> 32);
+                            if (it2 > started && it2 <= enq) { started = it2; if (((s2 & 0xffffffffULL) >> 1) & 0x40000000) done = true; break; }
                             // everything enqueued has run and the word never arrived: a launch that gave up on a grid
                             // synchronisation exits without publishing
                             if ((rc = persist_timed_out(h, timed_out))) return rc;
                             if (*timed_out) return 0;
-                            msdp_set_error("persistent tCG: progress word inconsistent (status %llx, expected iteration %d)", s2, enq);
+                            msdp_set_error("persistent tCG: progress word inconsistent (status %llx, expected iteration %d..%d)", s2, started + 1, enq);
                             return MSDP_EHIP;
                         }
                     }
@@ -2268,14 +2287,6 @@ static int rtr_core(msdp_handle h, const msdp_rtr_opts* opts, bool* timed_out) {
                     }
                 }
             }
-            if (done || enq >= opts->maxiter) break;
-            last_query = std::chrono::steady_clock::now();
-            if ((rc = enqueue_iter())) return rc;
-            if (timing) {
-                const double de = std::chrono::duration<double>(std::chrono::steady_clock::now() - last_query).count();
-                t_enq_sum += de; if (de > t_enq_max) t_enq_max = de;
-            }
-            ++enq;
         }
         if ((rc = pull_ctl(h))) return rc;
         if ((rc = persist_timed_out(h, timed_out))) return rc;
