@@ -547,9 +547,9 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             TSTAMP(6);
         } else {
             TSTAMP(3);
-            if (TWOSYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my residual rows are performed before I post
+            // (TWOSYNC: my residual rows are performed before I post -- the wait sits inside psync, behind the wave sums)
             TSTAMP(4);
-            if (!psync(slots, gen++, GS, 3, s1, s2, s3, sh, shb, err, bid, backoff)) { failed = true; break; }
+            if (!psync(slots, gen++, GS, 3, s1, s2, s3, sh, shb, err, bid, backoff, TWOSYNC)) { failed = true; break; }
             have_early = false;
             TSTAMP(5);
             // (EARLY instance, refresh trip: reduction 1 of this trip has returned -- the pending half can go back to the sentinel)

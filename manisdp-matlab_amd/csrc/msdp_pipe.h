@@ -38,25 +38,6 @@
 // The eight per-lane partials are reduced over the wave TOGETHER: a butterfly that halves the number of values a lane carries at each
 // of its first three steps (10 exchanges and additions instead of the 48 of eight separate wave sums; lane 8 i ends with value i).
 // sh8: 8 x PWAVES doubles, shb8: 16 doubles.  Returns false when a bounded spin ran out.
-// (a', b') = v_permlane<W>_swap(a, b): a' = a in the even rows of W lanes and b's even-row copy in the odd ones, b' = a's odd-row copy in
-// the even rows and b in the odd ones; a' + b' = a summed over the row pair (even rows) / b summed over the row pair (odd rows)
-template <int W>
-__device__ __forceinline__ double msdp_swap_add(double a, double b) {
-    const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
-    const unsigned alo = (unsigned)(ba & 0xffffffffLL), ahi = (unsigned)((unsigned long long)ba >> 32);
-    const unsigned blo = (unsigned)(bb & 0xffffffffLL), bhi = (unsigned)((unsigned long long)bb >> 32);
-    unsigned l0, l1, h0, h1;
-    if (W == 16) {
-        const auto rl = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-        const auto rh = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-        l0 = rl[0]; l1 = rl[1]; h0 = rh[0]; h1 = rh[1];
-    } else {
-        const auto rl = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-        const auto rh = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-        l0 = rl[0]; l1 = rl[1]; h0 = rh[0]; h1 = rh[1];
-    }
-    return __longlong_as_double((long long)(((unsigned long long)h0 << 32) | l0)) + __longlong_as_double((long long)(((unsigned long long)h1 << 32) | l1));
-}
 // on_ready(): called by every wave as soon as ITS poll has returned -- all workgroups have posted, so everything they stored in front
 // of their posts is visible: the caller issues the next trip's gather there, under the rest of the reduction (wave sum, workgroup
 // barrier, results to registers) and the trip's arithmetic.  The barrier behind it is a bare s_barrier (LDS traffic waited for

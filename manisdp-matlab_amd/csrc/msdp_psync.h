@@ -48,13 +48,43 @@ __device__ __forceinline__ void st2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte
 // Round 4: with three values, three WAVES poll side by side, one value array each (wave 0 posts all of them): the s_memtime
 // trace of the trip (profiles/r4_persist_timeline_p32.md) showed the three-value reduction at 2.75 us against 1.94 us for the
 // one-value one -- a poll of twelve loads per lane by one wave against four.  shb needs 8 doubles.
+// (a', b') = v_permlane<W>_swap(a, b): a' = a in the even rows of W lanes and b's even-row copy in the odd ones, b' = a's odd-row copy in
+// the even rows and b in the odd ones; a' + b' = a summed over the row pair (even rows) / b summed over the row pair (odd rows)
+template <int W>
+__device__ __forceinline__ double msdp_swap_add(double a, double b) {
+    const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const unsigned alo = (unsigned)(ba & 0xffffffffLL), ahi = (unsigned)((unsigned long long)ba >> 32);
+    const unsigned blo = (unsigned)(bb & 0xffffffffLL), bhi = (unsigned)((unsigned long long)bb >> 32);
+    unsigned l0, l1, h0, h1;
+    if (W == 16) {
+        const auto rl = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        l0 = rl[0]; l1 = rl[1]; h0 = rh[0]; h1 = rh[1];
+    } else {
+        const auto rl = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        l0 = rl[0]; l1 = rl[1]; h0 = rh[0]; h1 = rh[1];
+    }
+    return __longlong_as_double((long long)(((unsigned long long)h0 << 32) | l0)) + __longlong_as_double((long long)(((unsigned long long)h1 << 32) | l1));
+}
+// drain (round 5): the caller has row stores in flight that must be performed before the workgroup posts -- the wait sits here, behind
+// the wave sums, instead of in front of the call (the stores drain while the sums are formed)
 __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, int G, int nv, double& a, double& b,
-                                      double& c, double* sh, double* shb, int* err, int bid_in = -1, int backoff = 0) {
+                                      double& c, double* sh, double* shb, int* err, int bid_in = -1, int backoff = 0, bool drain = false) {
     const int bid = bid_in < 0 ? (int)blockIdx.x : bid_in;
-    a = msdp_wave_sum(a);
-    if (nv > 1) { b = msdp_wave_sum(b); c = msdp_wave_sum(c); }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { sh[w] = a; sh[PWAVES + w] = b; sh[2 * PWAVES + w] = c; }
+    if (nv > 1) {
+        // the three values over the wave TOGETHER (round 5): two permlane swaps leave value k in row k of 16 lanes (row 3: zero), one
+        // row reduction finishes all of them -- a third of the instructions of three separate wave sums
+        double x = msdp_swap_add<16>(msdp_swap_add<32>(a, c), msdp_swap_add<32>(b, 0.0));
+        x += msdp_dpp<MSDP_DPP_XOR1>(x); x += msdp_dpp<MSDP_DPP_XOR2>(x);
+        x += msdp_dpp<MSDP_DPP_HALF_MIRROR>(x); x += msdp_dpp<MSDP_DPP_MIRROR>(x);
+        if ((lane & 15) == 0 && lane < 48) sh[(lane >> 4) * PWAVES + w] = x;
+    } else {
+        a = msdp_wave_sum(a);
+        if (lane == 0) { sh[w] = a; sh[PWAVES + w] = b; sh[2 * PWAVES + w] = c; }
+    }
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (w < nv) {                                                   // polling wave w takes value array w
         unsigned long long* gbase = slots + (size_t)(gen % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID;
