@@ -28,7 +28,10 @@
 // Per-row arithmetic of eta, r, md and Hmd: the statements of the two-reduction kernel (same reference lines).  What differs from
 // tCG.m in floating point: C md is assembled (as in the two-reduction kernel), and <r', r'> / the model value that decide the
 // stopping and model tests of a trip are the expanded forms above (relative error eps <r, r> / <r', r'>); the values that enter
-// alpha and the next test are the directly summed ones.  Parity: tests/test_gpu_persistent_tcg.py (pipe cases) against the oracle.
+// alpha and the next test are the directly summed ones.  Parity: tests/test_one_reduction_algebra.py (the trip restated in NumPy
+// against the oracle's tCG: same trip counts and stop codes over radii, inner caps and refresh intervals -- no GPU), and on the GPU
+// tests/test_gpu_onlyunitdiag.py (test_persistent_tcg_matches_oracle over both trip forms, fused and per-iteration launches;
+// test_one_reduction_trip_solves_G81_like_the_two_reduction_trip; test_persistent_tcg_keeps_heta_equal_to_hess_eta_on_G81).
 #pragma once
 #include <type_traits>
 #include "msdp_psync.h"
