@@ -8,6 +8,7 @@
 // next to the persistent tCG kernel; now 1.  The kernel needs one grid barrier (the proposal rows must be
 // in place before the S*Y_prop gathers) and one grid reduction (f, |grad|^2, model decrease), for which it
 // uses region B of the synchronisation slots; it clears region A for the next tCG launch.
+#include <type_traits>
 #include "msdp_psync.h"
 #include <math.h>
 #include <cstdlib>
@@ -118,6 +119,34 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
         int len = 0;
 #pragma unroll
         for (int q = 0; q < RMAX; ++q) len = max(len, s1[q] - s0[q]);
+        // Round 5: rows stored in ELL form too (width 5 or 8: the persistent kernels' copy) take ONE dependent load level -- column
+        // index, then the row -- with all RMAX x width gathers in flight; the CSR walk below pays row pointer -> (column, value)
+        // -> row per batch of four entries (k_tr_tail_obl<32>: 31.7 us per launch on G81 at p = 40, most of it these round trips)
+        const int ellw = (d.ellW == 5 || d.ellW == 8) && d.ellc && (!XR || d.xr_ellc) ? d.ellW : 0;
+        if (ellw) {
+            len = 0;                                            // (skips the CSR walk)
+            auto ell_rows = [&](auto wc) {
+                constexpr int W = decltype(wc)::value;
+                double2 x[RMAX][W];
+                double cv[RMAX][W];
+#pragma unroll
+                for (int q = 0; q < RMAX; ++q) {
+                    const int row = lo + (r0 + q) * RSTEP + slot0;
+                    const int rc = row < hi ? row : lo;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        const int col = XR ? d.xr_ellc[(int64_t)w * d.ell_stride + rc] : d.ellc[(int64_t)w * d.ell_stride + rc];
+                        cv[q][w] = row < hi ? d.ellv[(int64_t)w * d.ell_stride + rc] : 0.0;
+                        x[q][w] = ld2_sc1(rs_yp, ((unsigned)col * (unsigned)d.ld + (colok ? 2 * sub : 0)) * 8u);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < RMAX; ++q)
+#pragma unroll
+                    for (int w = 0; w < W; ++w) { acc[q].x = fma(cv[q][w], x[q][w].x, acc[q].x); acc[q].y = fma(cv[q][w], x[q][w].y, acc[q].y); }
+            };
+            if (ellw == 5) ell_rows(std::integral_constant<int, 5>()); else ell_rows(std::integral_constant<int, 8>());
+        }
         // CSR rows of C (static data: plain loads); the proposal rows of other workgroups through sc1.  The RMAX
         // rows advance together, 4 entries each per batch, so 4*RMAX gathers are in flight.
         for (int kb = 0; kb < len; kb += 4) {
