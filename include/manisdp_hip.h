@@ -396,7 +396,7 @@ int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, const int64_
  *                       sentinel until a row is stored, so the rows are their own flags (k - 1 = units of 64 cycles a wave sleeps
  *                       between posting the reduction and its first gather); 0 = at the top of the next trip, behind that
  *                       reduction (the round-4 trip).  Same arithmetic, same decisions; measured slower (default 0)
- *   "persist_pipe" 1/0  persistent tCG kernel (rows of <= 5 entries, p <= 32): ONE grid reduction per trip instead of two -- the
+ *   "persist_pipe" 1/0  persistent tCG kernel (rows of <= 8 entries, p <= 32): ONE grid reduction per trip instead of two -- the
  *                       values of tCG.m:227-241 (model value, <r', r'>) follow from eight inner products formed BEFORE the step length
  *                       is known, the neighbours gather the rows of H*mdelta, and C*tangent(r), C*mdelta follow by linearity.
  *                       Same tests and decisions as tCG.m; <r', r'> and the model value that decide a trip carry a rounding error of
@@ -438,7 +438,7 @@ int msdp_set_option(msdp_handle h, const char* name, int32_t value);
  * per trip.  Both follow tCG.m:95-292; the choice is a speed matter only. */
 int msdp_tcg_path(msdp_handle h, int32_t* path);
 /* (test / diagnostic) The trip form of the persistent kernel at the resident point: 2 = ONE grid reduction per trip (option
- * "persist_pipe", rows of <= 5 entries, p <= 32, every vector in registers), 1 = the "persist_early" form, 0 = two reductions per
+ * "persist_pipe", rows of <= 8 entries, p <= 32, every vector in registers), 1 = the "persist_early" form, 0 = two reductions per
  * trip (tCG.m:166 and :227-241 separately); -1 = the tCG is not persistent.  All forms follow tCG.m:95-292. */
 int msdp_debug_persist_form(msdp_handle h, int32_t* form);
 

@@ -804,6 +804,9 @@ static persist_fn persist_kernel_early(const PersistPlan& pl, bool fuse) {
 }
 // One-reduction instances (round 5, msdp_pipe.h): rows of <= 5 entries, every vector in registers
 static persist_fn persist_kernel_pipe(const PersistPlan& pl, bool fuse = false) {
+    // rows of 6..8 entries (3-D grids: six neighbours + the diagonal): every row through the buffer, per-iteration launches
+    if (pl.ew == 8 && pl.lpr == 8 && pl.r == 2) return fuse ? k_tcg_pipe_obl<8, 8, 2, false, true> : k_tcg_pipe_obl<8, 8, 2>;
+    if (pl.ew == 8 && pl.lpr == 16 && pl.r == 3) return fuse ? nullptr : k_tcg_pipe_obl<16, 8, 3>;   // (fused: 290 bytes of scratch)
     if (pl.ew != 5) return nullptr;
     if (pl.lpr == 16 && pl.r == 3) return fuse ? k_tcg_pipe_obl<16, 5, 3, false, true> : k_tcg_pipe_obl<16, 5, 3>;
     if (pl.lpr == 8 && pl.r == 2) return fuse ? k_tcg_pipe_obl<8, 5, 2, false, true> : k_tcg_pipe_obl<8, 5, 2>;
@@ -978,6 +981,9 @@ int msdp_persist_fused_ok(msdp_handle h) {
     PersistPlan pl;
     const int G = persist_grid(h->d);
     if (!persist_plan(h->d, G, pl)) return 0;
+    // where the one-reduction trip exists for per-iteration launches only, those beat the fused two-reduction launch (G81 p = 32:
+    // 164 000 against 143 000 Hess-vec/s)
+    if (persist_is_pipe(h, pl, false) && !persist_is_pipe(h, pl, true)) return 0;
     persist_fn fn = persist_kernel(pl, true, persist_mode(h));
     if (!fn) return 0;
     {   // (the one-reduction form: + ls; its HQs share the space of the proposal point and gradient)

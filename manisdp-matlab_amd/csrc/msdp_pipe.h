@@ -611,8 +611,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     if (!pbarrier(slots, nbar++, GS, shb8, err, bid)) return;
     // cost and gradient at the proposal (ManiSDP_onlyunitdiag.m:117-125): YC = Y*C, eG = sum(YC.*Y), G = YC - Y.*eG.
     // Rolled loop over the row slots (LDS in, LDS out): once per TR iteration, no register pressure on the tCG loop
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
+    auto prop_row = [&](int r) {
         double2 xw[EW];
 #pragma unroll
         for (int w = 0; w < EW; ++w) xw[w] = ld2_sc1(rs_yp, ((unsigned)cs[w * ROWS + SLOT(r)] * gld + gcol) * 8u);
@@ -630,6 +629,13 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
             if (ROK(r)) { tv[0] += 0.5 * dot; eGp[ROW(r)] = dot; }
         }
         if (OK(r)) st2_sc1(rs_gp, ((unsigned)ROW(r) * gld + 2 * sub) * 8u, gpr);
+    };
+    if (R * EW <= 15) {                                            // all gathers in flight (wider rows: a row slot at a time, registers)
+#pragma unroll
+        for (int r = 0; r < R; ++r) prop_row(r);
+    } else {
+#pragma unroll 1
+        for (int r = 0; r < R; ++r) prop_row(r);
     }
     // (the proposal's gradient rows are in place before the post: psync8 waits for the stores)
     if (!PSYNC8(slots, gen++, GS, tv, sh8, shb8, err, bid, backoff, nullptr, []() {})) return;

@@ -161,7 +161,7 @@ def _ring_lattice_cost(n, k, seed):
 
 
 @pytest.mark.parametrize("shape,p,k", [((20, 30), 4, 0), ((20, 30), 16, 0), ((33, 37), 20, 0), ((20, 30), 32, 0),
-                                      ((25, 40), 40, 0), ((20, 30), 64, 0), ((1, 997), 12, 3), ((1, 2500), 32, 2)])
+                                      ((25, 40), 40, 0), ((20, 30), 64, 0), ((1, 997), 12, 3), ((1, 2500), 32, 2), ((1, 1201), 24, 3), ((1, 700), 10, 4)])
 def test_persistent_tcg_matches_oracle(lib, shape, p, k):
     """The single-launch persistent tCG kernel (msdp_persist.hip) against the oracle's tCG: with maxiter = 1
     the solve is ONE tCG, so the Hess-vec count, the stop reason and the cost after the step must agree to
@@ -178,7 +178,7 @@ def test_persistent_tcg_matches_oracle(lib, shape, p, k):
     prob = R._OnlyUnitDiagProblem(C, n, p, q1="correct")
     # both trip forms of the kernel (round 5): ONE grid reduction per trip (msdp_pipe.h: rows of <= 5 entries, p <= 32; the default
     # there) and the two-reduction trip (everything else, and persist_pipe = 0)
-    one_reduction = p <= 32 and 2 * k + 1 <= 5
+    one_reduction = p <= 32 and 2 * k + 1 <= 8               # (rows of <= 5 entries, and of 6..8 in the stored width 8; nine entries: CSR rows)
     refs = {}
     # ... each as per-iteration launches (tCG kernel + TR tail kernel) and, at p <= 32, with the whole trustregions() loop in one launch
     for pipe, fused in ((1, 1), (1, 0), (0, 1)):
