@@ -304,6 +304,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     double2 acc_e[EARLY ? R : 1];
     bool direct = false;             // TWOSYNC: the exchange buffer holds the rows of mdelta itself (a refresh trip preceded)
     // acc = sum_k C[row,k] * X[k, my columns] with X read through the agent-coherent resource rs
+    constexpr int CB = 8;                                          // gathers of a CSR row in flight together (16 at eight lanes per row: measured, no gain)
     auto gather_row = [&](int r, __amdgpu_buffer_rsrc_t rs, unsigned base) -> double2 {
             double2 acc = zz;
             const unsigned gld = (unsigned)d.ld, gcol = colok ? 2 * sub : 0;
@@ -325,37 +326,37 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             } else if (ROK(r)) {
                 // CSR rows of any length: (col, val) are static (plain loads, L2 resident), the direction rows are not
                 const int s0 = d.rowptr[ROW(r)], s1 = d.rowptr[ROW(r) + 1];
-                // batches of 8 gathers in flight, software pipelined: the (col, val) pairs of batch b+1 are loaded
+                // batches of CB gathers in flight, software pipelined: the (col, val) pairs of batch b+1 are loaded
                 // while the gathers of batch b are outstanding; the tail is clamped (weight 0), not peeled
-                int cn[8];
-                double vn[8];
+                int cn[CB];
+                double vn[CB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < CB; ++u) {
                     const bool in = s0 + u < s1;
                     const int k = in ? s0 + u : (s1 > s0 ? s1 - 1 : 0);
                     cn[u] = (s1 > s0) ? (XR ? d.xr_colind[k] : d.colind[k]) : (XR ? ROW(r) : (int)xglob0 + ROW(r));
                     vn[u] = in ? d.cval[k] : 0.0;
                 }
-                for (int k0 = s0; k0 < s1; k0 += 8) {
-                    double2 x[8];
-                    double cvk[8];
+                for (int k0 = s0; k0 < s1; k0 += CB) {
+                    double2 x[CB];
+                    double cvk[CB];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < CB; ++u) {
                         const unsigned off = base + ((unsigned)cn[u] * gld + gcol) * 8u;
                         cvk[u] = vn[u];
                         x[u] = ld2_sc1(rs, off);
                     }
-                    if (k0 + 8 < s1) {
+                    if (k0 + CB < s1) {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const bool in = k0 + 8 + u < s1;
-                            const int k = in ? k0 + 8 + u : s1 - 1;
+                        for (int u = 0; u < CB; ++u) {
+                            const bool in = k0 + CB + u < s1;
+                            const int k = in ? k0 + CB + u : s1 - 1;
                             cn[u] = XR ? d.xr_colind[k] : d.colind[k];
                             vn[u] = in ? d.cval[k] : 0.0;
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < CB; ++u) {
                         acc.x = fma(cvk[u], x[u].x, acc.x);
                         acc.y = fma(cvk[u], x[u].y, acc.y);
                     }
@@ -886,7 +887,10 @@ static int persist_grid(const Dev& d) {
     // long as one with 79, and the grid synchronisation has fewer slots to poll
     PersistPlan pl;
     if (g >= 8 && persist_plan(d, g, pl)) {
-        const int cap = pl.r * PWAVES * (64 / pl.lpr);
+        // (CSR rows, round 5: the row slots of a workgroup are walked one after the other, each a chain of gather batches as long as
+        // its longest row, and an empty slot is skipped -- ONE slot per workgroup while the CUs last: G1, 800 rows of ~49 entries,
+        // 8 workgroups x 2 slots 20.7 us per trip, 16 x 1 12.8; tools/g1_trip_probe.py)
+        const int cap = (pl.ew == 0 ? 1 : pl.r) * PWAVES * (64 / pl.lpr);
         int gmin = (((d.n_loc + cap - 1) / cap + 7) / 8) * 8;
         if (gmin < 8) gmin = 8;
         if (gmin < g) g = gmin;
