@@ -49,7 +49,7 @@ elif early:
     NP = 8
 else:
     names = ["gathers of C*x + row arithmetic (tCG.m:163)", "grid reduction 1: <d,Hd> (:166)", "trial step, projected residual rows stored (:215-241)",
-             "wait for those stores (s_waitcnt vmcnt(0))", "grid reduction 2: model value, <r,r> (:227-241)", "commit, beta, new direction (:233-287)",
+             "(the wait for those stores sits inside reduction 2 since round 5, behind its wave sums)", "grid reduction 2: model value, <r,r> (:227-241), incl. the drain of the row stores", "commit, beta, new direction (:233-287)",
              "loop back (stop tests, next trip's set-up)"]
     NP = 7
 st = a[:, :, :NP].astype(np.float64)
