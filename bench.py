@@ -276,23 +276,41 @@ def process_rank_trip(N=2, p=32):
     exported / mapped through HIP IPC (the mapping goes over peer access when the ranks own different devices: the same code
     path); the owner of a boundary row stores it into the neighbour's buffer, gathers are local.  Every process launches its own workgroups of the cross-rank persistent tCG and of the cross-rank TR
     tail -- a trustregions() call issues no collective per trip and none per iteration."""
-    import subprocess, tempfile
+    import shutil, subprocess, tempfile
     name = "/msdp_bench_%d" % os.getpid()
     tmp = tempfile.mkdtemp()
-    procs = []
-    for r in range(N):
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--ipc-worker", str(r), str(N), name, str(p), os.path.join(tmp, "r%d.json" % r)],
-                                      stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
-    errs = []
-    for pr in procs:
+    procs, logs = [], []
+    try:
+        # (every member's stderr goes to a file of its own: a pipe that nobody drains while the members wait for each other in the
+        # group's barrier would stall all of them -- ADVICE round 5)
+        for r in range(N):
+            log = open(os.path.join(tmp, "r%d.err" % r), "w")
+            logs.append(log)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--ipc-worker", str(r), str(N), name, str(p), os.path.join(tmp, "r%d.json" % r)],
+                                          stdout=subprocess.DEVNULL, stderr=log))
+        for pr in procs:
+            try:
+                pr.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                pr.kill(); pr.wait()
+        for log in logs:
+            log.close()
+        if any(pr.returncode != 0 for pr in procs):
+            errs = [open(os.path.join(tmp, "r%d.err" % r)).read() for r in range(N)]
+            raise RuntimeError("a member failed: " + " | ".join(e[-300:] for e in errs if e))
+        res = [json.load(open(os.path.join(tmp, "r%d.json" % r))) for r in range(N)]
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill(); pr.wait()
+        for log in logs:
+            if not log.closed:
+                log.close()
+        shutil.rmtree(tmp, ignore_errors=True)
         try:
-            _, e = pr.communicate(timeout=240)
-        except subprocess.TimeoutExpired:
-            pr.kill(); _, e = pr.communicate()
-        errs.append(e)
-    if any(pr.returncode != 0 for pr in procs):
-        raise RuntimeError("a member failed: " + " | ".join(e[-300:] for e in errs if e))
-    res = [json.load(open(os.path.join(tmp, "r%d.json" % r))) for r in range(N)]
+            os.unlink("/dev/shm" + name)          # (rank 0 unlinks it when it closes its handle; this covers a member that was killed)
+        except OSError:
+            pass
     hv, sec, sec_c = res[0]["hessvecs"], max(q["rtr_seconds"] for q in res), max(q["rtr_seconds_with_per_iteration_collectives"] for q in res)
     return {"workload": "toroidal grid MaxCut, %d process ranks x 20000 rows on one GPU (HIP IPC), p = %d" % (N, p), "ranks": N, "p": p,
             "trip_us_cross_rank_persistent": max(q["trip_us"] for q in res), "tcg_path": res[0]["tcg_path"],

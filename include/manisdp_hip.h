@@ -298,7 +298,11 @@ int msdp_debug_time_collective(msdp_handle h, int32_t which, int32_t reps, doubl
  * s_memtime stamps of every workgroup at 7 phase boundaries -- 0 top of the trip, 1 gathers + row arithmetic done, 2 first grid
  * reduction returned, 3 trial step formed and residual rows stored, 4 those stores performed, 5 second grid reduction returned,
  * 6 new direction formed -- for the trips dims[2] .. dims[2] + dims[1] - 1: out[(g * dims[1] + t) * 8 + phase], g < dims[0].
- * avg_ms = the average trip time of the same launch (HIP events).  tools/persist_timeline.py turns it into profiles/r4_persist_timeline.md. */
+ * avg_ms = the average trip time of the same launch (HIP events).  tools/persist_timeline.py turns it into profiles/r4_persist_timeline.md.
+ * reps <= 0 (round 6): the FUSED launch instead -- one trustregions() call (trustregions.m:441-767) with the options of the handle's last
+ * msdp_rtr, stamps of the first dims[1] TR iterations (dims[2] = 0): 0 iteration starts, 1 first trip's products formed, 2 tCG ended
+ * (bits 56..63: its trips), 3 proposal rows stored and performed, 4 barrier returned, 5 cost / gradient rows of the proposal formed,
+ * 6 the iteration's reduction returned, 7 decision taken; avg_ms = the call's time.  tools/fused_timeline.py. */
 int msdp_debug_persist_trace(msdp_handle h, int32_t reps, uint64_t* out, int64_t cap, int32_t* dims, double* avg_ms);
 
 /* Outcome of the LAST msdp_escape_eigs / _matrix / _dual call on this handle.  The reference's eig(S) is exact;

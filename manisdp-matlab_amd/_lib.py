@@ -624,7 +624,8 @@ class Handle:
 
     # ---- measurement
     def persist_trace(self, reps=256):
-        """Phase stamps of the persistent tCG trip: (array [G, nj, 8] of s_memtime ticks, first traced trip, trip time in ms)."""
+        """Phase stamps of the persistent tCG trip: (array [G, nj, 8] of s_memtime ticks, first traced trip, trip time in ms).
+        reps <= 0: the fused launch -- ((stamps of the TR iterations, stamps of the trips of one iteration), 0, call time in ms)."""
         cap = 512 * 64 * 8
         buf = (C.c_uint64 * cap)()
         dims = (C.c_int32 * 3)()
@@ -632,6 +633,10 @@ class Handle:
         _check(self._lib.msdp_debug_persist_trace(self._h, reps, buf, cap, dims, C.byref(ms)))
         G, nj, j0 = dims[0], dims[1], dims[2]
         a = np.frombuffer(buf, dtype=np.uint64, count=G * nj * 8).reshape(G, nj, 8).astype(np.int64)
+        if reps <= 0:
+            # the fused launch: stamps of the TR iterations, then the trips of one of them (msdp_pipe.h MSDP_TRACE_KSEL)
+            b = np.frombuffer(buf, dtype=np.uint64, count=2 * G * nj * 8)[G * nj * 8:].reshape(G, nj, 8).astype(np.int64)
+            return (a, b), j0, ms.value
         return a, j0, ms.value
 
     def bench_hessvec(self, reps):

@@ -303,9 +303,11 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
     if (d.mdx) dev_free(h, d.mdx);
     d.mdx = nullptr;
     {
-        // four regions of one vector each: the EARLY trips of the persistent tCG alternate between the first two (msdp_persist.hip), the
-        // one-reduction trips too and use the other two for their direct exchanges (msdp_pipe.h)
-        const size_t xcnt = 4 * cnt;
+        // regions of one vector each: the EARLY trips of the persistent tCG alternate between the first two (msdp_persist.hip), the
+        // one-reduction trips too and use the next two for their direct exchanges; the fused launch of msdp_pipe.h exchanges the
+        // proposal's rows and the gradient rows of the two point slots through three more (round 6) -- where the persistent kernels can
+        // apply at all (rows per rank within their reach)
+        const size_t xcnt = (rows_capacity(h) <= 65536 ? 7 : 4) * cnt;
         int rc = dev_alloc_uncached<double>(h, &d.mdx, xcnt);
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(d.mdx, 0, xcnt * sizeof(double), h->stream));
@@ -1022,7 +1024,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "window_lds")) { t.window_lds = value < 16 ? 16 : (value > 144 ? 144 : value); h->chunk_len = 0; msdp_window_release(h); }
     else if (!strcmp(name, "persist_early")) t.persist_early = value > 0 ? value : 0;
     else if (!strcmp(name, "persist_pipe")) t.persist_pipe = value > 0 ? 1 : 0;
-    else if (!strcmp(name, "pipe_refresh")) t.pipe_refresh = value > 0 ? value : 0;
+    else if (!strcmp(name, "pipe_refresh")) t.pipe_refresh = value > 0 ? (value < 2 ? 2 : value) : 0;   // (1 would store the refresh rows of trip j + 1 into the regions a slower workgroup still gathers those of trip j from: msdp_pipe.h)
     else if (!strcmp(name, "pipe_local")) t.pipe_local = value > 0 ? 1 : 0;
     else if (!strcmp(name, "persist_goff")) t.persist_goff = value ? 1 : 0;
     else if (!strcmp(name, "persist_slots")) { t.persist_slots = (value == 3 || value == 4) ? value : 0; h->d.persist_slots = t.persist_slots; }
@@ -1109,7 +1111,9 @@ struct Halo {
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#define IPC_MAGIC 0x4d53445049504331ULL   // "MSDPIPC1": written by rank 0 when the cleared segment is ready
 struct IpcShared {
+    std::atomic<unsigned long long> magic;
     std::atomic<int> arrived; std::atomic<unsigned long long> gen; std::atomic<int> broken;
     std::atomic<int> attached; std::atomic<int> arena_ready;
     hipIpcMemHandle_t arena;
@@ -1763,21 +1767,67 @@ extern "C" int msdp_comm_init_local(msdp_handle h, int32_t nranks, int32_t rank,
 // Members in different processes (one per GPU of a node, or several on one GPU): `name` identifies the group (a POSIX shared-memory
 // name, e.g. "/msdp_<pid of the launcher>_<counter>"; every member passes the same one).  Rank 0 allocates the arena and exports it,
 // the others map it; with ranks on different devices the mapping goes over peer access (hipIpcMemLazyEnablePeerAccess).
+static int comm_init_ipc_attach(msdp_handle h, int32_t nranks, int32_t rank, unsigned long long my_ino);
 extern "C" int msdp_comm_init_ipc(msdp_handle h, int32_t nranks, int32_t rank, const char* name) {
     CHECK_H(h);
     if (nranks < 1 || nranks > LOCAL_MAX_RANKS || rank < 0 || rank >= nranks || !name || name[0] != '/') { msdp_set_error("comm_init_ipc: bad arguments (the name starts with '/')"); return MSDP_EINVAL; }
     if (h->have_point || h->use_comm) { msdp_set_error("comm_init_ipc must precede set_point / comm_init"); return MSDP_ESTATE; }
     if (h->presharded && (nranks != h->nranks || rank != h->rank)) { msdp_set_error("comm_init_ipc: shard was created as rank %d of %d", h->rank, h->nranks); return MSDP_EINVAL; }
     if (h->kind == MSDP_KIND_MULTIBLOCK || h->kind == MSDP_KIND_DUAL_UNITDIAG) { msdp_set_error("row sharding is not implemented for the multiblock and dual kinds"); return MSDP_EUNSUPPORTED; }
-    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-    if (fd < 0) { msdp_set_error("comm_init_ipc: shm_open(%s) failed", name); return MSDP_ECOMM; }
-    if (ftruncate(fd, (off_t)sizeof(IpcShared)) != 0) { (void)close(fd); msdp_set_error("comm_init_ipc: ftruncate failed"); return MSDP_ECOMM; }
-    void* mp = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    (void)close(fd);
-    if (mp == MAP_FAILED) { msdp_set_error("comm_init_ipc: mmap failed"); return MSDP_ECOMM; }
+    // The host segment: rank 0 removes whatever a crashed run left under this name, creates the segment anew (O_EXCL),
+    // clears it and writes the magic word LAST; the others open it without O_CREAT, wait for the magic word and check that the name
+    // still leads to the segment they mapped (a stale one that rank 0 has replaced meanwhile does not).
+    void* mp = MAP_FAILED;
+    unsigned long long my_ino = 0;
+    if (rank == 0) {
+        (void)shm_unlink(name);
+        const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) { msdp_set_error("comm_init_ipc: shm_open(%s, O_EXCL) failed", name); return MSDP_ECOMM; }
+        if (ftruncate(fd, (off_t)sizeof(IpcShared)) != 0) { (void)close(fd); (void)shm_unlink(name); msdp_set_error("comm_init_ipc: ftruncate failed"); return MSDP_ECOMM; }
+        mp = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        (void)close(fd);
+        if (mp == MAP_FAILED) { (void)shm_unlink(name); msdp_set_error("comm_init_ipc: mmap failed"); return MSDP_ECOMM; }
+        memset(mp, 0, sizeof(IpcShared));
+        ((IpcShared*)mp)->magic.store(IPC_MAGIC);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const bool late = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > local_barrier_timeout();
+            const int fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(IpcShared)) {
+                void* q = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                (void)close(fd);
+                if (q != MAP_FAILED) {
+                    if (((IpcShared*)q)->magic.load() == IPC_MAGIC) {
+                        // the name still leads here?  (rank 0 unlinks a stale segment before it creates the group's)
+                        const int fd2 = shm_open(name, O_RDWR, 0600);
+                        struct stat st2;
+                        const bool same = fd2 >= 0 && fstat(fd2, &st2) == 0 && st2.st_ino == st.st_ino;
+                        if (fd2 >= 0) (void)close(fd2);
+                        if (same) { mp = q; my_ino = (unsigned long long)st.st_ino; break; }
+                    }
+                    (void)munmap(q, sizeof(IpcShared));
+                }
+            } else if (fd >= 0) (void)close(fd);
+            if (late) { msdp_set_error("comm_init_ipc: rank 0 did not create the segment %s", name); return MSDP_ECOMM; }
+            std::this_thread::sleep_for(std::chrono::microseconds(500));
+        }
+    }
     LocalGroup* g = new LocalGroup();
     g->ipc = true; g->n = nranks; g->members = 1; g->my_rank = rank; g->shm = (IpcShared*)mp; g->shm_name = name;
     h->lgroup = g;
+    int rc = comm_init_ipc_attach(h, nranks, rank, my_ino);
+    if (rc) {
+        // (a member that fails here tells the others, and leaves nothing behind: mapping, group record and -- rank 0 -- the name)
+        local_break(g);
+        local_leave(h);
+    }
+    return rc;
+}
+static int comm_init_ipc_attach(msdp_handle h, int32_t nranks, int32_t rank, unsigned long long my_ino) {
+    LocalGroup* g = h->lgroup;
+    const char* name = g->shm_name.c_str();
     int rc = comm_partition(h, nranks, rank);
     if (rc) return rc;
     IpcShared* sh = g->shm;
@@ -1816,6 +1866,14 @@ extern "C" int msdp_comm_init_ipc(msdp_handle h, int32_t nranks, int32_t rank, c
     g->stage_bytes = stage;
     sh->attached.fetch_add(1);
     LOCAL_BARRIER(g);                                        // everybody has mapped the arena; the halo sizes are in the segment
+    if (rank != 0) {
+        // (once more behind the first barrier: a segment of an earlier run that passed every wait above on stale values)
+        const int fd2 = shm_open(name, O_RDWR, 0600);
+        struct stat st2;
+        const bool same = fd2 >= 0 && fstat(fd2, &st2) == 0 && (unsigned long long)st2.st_ino == my_ino;
+        if (fd2 >= 0) (void)close(fd2);
+        if (!same) { msdp_set_error("comm_init_ipc: attached to a stale segment %s", name); return MSDP_ECOMM; }
+    }
     size_t hmax = 0;
     for (int q = 0; q < nranks; ++q) hmax = std::max<size_t>(hmax, (size_t)sh->vote[q]);
     const size_t rows_doubles = ((size_t)rows_capacity(h) + hmax) * ldx;
@@ -1943,7 +2001,7 @@ static void fill_ctl(msdp_handle h, const msdp_rtr_opts* o) {
     c->rho_prime = o->rho_prime; c->rho_reg = o->rho_regularization;
     c->persist_refresh = h->tune.persist_refresh;
     c->persist_early = h->tune.persist_early;
-    c->pipe_refresh = h->tune.pipe_refresh;
+    c->pipe_refresh = h->tune.pipe_refresh == 1 ? 2 : h->tune.pipe_refresh;   // never 1 (see msdp_set_option)
     c->pipe_local = h->tune.pipe_local;
     c->persist_goff = h->tune.persist_goff;
     c->psync_backoff = h->tune.psync_backoff;
@@ -2860,17 +2918,28 @@ extern "C" int msdp_debug_persist_trace(msdp_handle h, int32_t reps, uint64_t* o
     int G = 0, nj = 0, j0 = 0;
     msdp_persist_trace_dims(h, &G, &nj, &j0);
     dims[0] = G; dims[1] = nj; dims[2] = j0;
-    const size_t cnt = (size_t)G * nj * 8;
-    if (cap < (int64_t)cnt || reps < j0 + nj) { msdp_set_error("persist_trace: cap >= %zu entries and reps >= %d needed", cnt, j0 + nj); return MSDP_EINVAL; }
+    const bool fused = reps <= 0;                                  // the TR iterations of one trustregions() call in the fused launch
+    const size_t cnt = (size_t)G * nj * 8 * (fused ? 2 : 1);       // (fused: + the trips of one TR iteration, msdp_pipe.h MSDP_TRACE_KSEL)
+    if (fused) { j0 = 0; dims[2] = 0; }
+    if (cap < (int64_t)cnt || (!fused && reps < j0 + nj)) { msdp_set_error("persist_trace: cap >= %zu entries and reps >= %d needed", cnt, j0 + nj); return MSDP_EINVAL; }
     if (!h->trace_buf) {
         void* p = nullptr;
-        int rc = msdp_dev_alloc_bytes(h, &p, (size_t)MSDP_MAX_GRID * nj * 8 * sizeof(unsigned long long));
+        int rc = msdp_dev_alloc_bytes(h, &p, (size_t)2 * MSDP_MAX_GRID * nj * 8 * sizeof(unsigned long long));
         if (rc) return rc;
         h->trace_buf = (unsigned long long*)p;
     }
     HIPCHK(hipMemset(h->trace_buf, 0, cnt * sizeof(unsigned long long)));
     h->d.trace = h->trace_buf;
-    int rc = msdp_bench_tcg_trip(h, reps, avg_ms);
+    int rc;
+    if (fused) {
+        // one call with the options of the handle's last msdp_rtr (the reference's inner-solver defaults before any): avg_ms = its time
+        msdp_rtr_opts o = h->last_opts;
+        if (o.maxinner < 1) { msdp_rtr_default_opts(&o); o.maxiter = 40; o.maxinner = 100; }
+        if (!msdp_persist_fused_ok(h)) { h->d.trace = nullptr; msdp_set_error("persist_trace: the fused launch does not apply to this handle"); return MSDP_EUNSUPPORTED; }
+        msdp_rtr_stats st;
+        rc = msdp_rtr(h, &o, &st);
+        *avg_ms = st.seconds * 1e3;
+    } else rc = msdp_bench_tcg_trip(h, reps, avg_ms);
     h->d.trace = nullptr;
     if (rc) return rc;
     HIPCHK(hipMemcpy(out, h->trace_buf, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -990,10 +990,10 @@ int msdp_persist_fused_ok(msdp_handle h) {
     if (persist_is_pipe(h, pl, false) && !persist_is_pipe(h, pl, true)) return 0;
     persist_fn fn = persist_kernel(pl, true, persist_mode(h));
     if (!fn) return 0;
-    {   // (the one-reduction form: + ls; its HQs share the space of the proposal point and gradient)
+    {   // (the one-reduction form: + ls and HQs)
         const bool pipe = persist_is_pipe(h, pl, true), early = persist_is_early(h, pl, true);
         const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr);
-        pl.lds = fused_lds(pl) + (early ? early_lds(pl) : 0) + (pipe ? (size_t)pl.ew * rows * sizeof(int) : 0);
+        pl.lds = fused_lds(pl) + (early ? early_lds(pl) : 0) + (pipe ? (size_t)pl.ew * rows * sizeof(int) + (size_t)2 * pl.r * PB * sizeof(double2) : 0);   // (+ ls, + HQs: the proposal's buffers are their own since round 6)
     }
     if (h->fused_sig_lpr == pl.lpr && h->fused_sig_ew == pl.ew && h->fused_sig_G == G && h->fused_sig_fn == (const void*)fn) return h->fused_sig_ok;
     int ok = 0, per_cu = 0;
@@ -1011,13 +1011,21 @@ int msdp_launch_rtr_fused(msdp_handle h) {
     if (!persist_plan(h->d, G, pl)) { msdp_set_error("fused RTR: not eligible"); return MSDP_ESTATE; }
     persist_fn fn = persist_kernel(pl, true, persist_mode(h));
     if (!fn) { msdp_set_error("fused RTR: no kernel instance"); return MSDP_ESTATE; }
-    {   // (the one-reduction form: + ls; its HQs share the space of the proposal point and gradient)
+    if (h->tune.timing) fprintf(stderr, "[msdp_rtr] fused launch: <%d, %d, %d>, %s, G = %d\n", pl.lpr, pl.ew, pl.r,
+                                persist_is_pipe(h, pl, true) ? "one reduction per trip" : "two reductions per trip", G);
+    {   // (the one-reduction form: + ls and HQs)
         const bool pipe = persist_is_pipe(h, pl, true), early = persist_is_early(h, pl, true);
         const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr);
-        pl.lds = fused_lds(pl) + (early ? early_lds(pl) : 0) + (pipe ? (size_t)pl.ew * rows * sizeof(int) : 0);
+        pl.lds = fused_lds(pl) + (early ? early_lds(pl) : 0) + (pipe ? (size_t)pl.ew * rows * sizeof(int) + (size_t)2 * pl.r * PB * sizeof(double2) : 0);   // (+ ls, + HQs: the proposal's buffers are their own since round 6)
     }
     Dev dp = h->d;
     dp.G = G;
+    if (dp.trace) {
+        // (msdp_debug_persist_trace with reps <= 0: the phases of the TR iterations around the tCGs, FSTAMP in msdp_pipe.h)
+        if (!(pl.lpr == 16 && pl.ew == 5 && pl.r == 3 && persist_is_pipe(h, pl, true))) { msdp_set_error("fused trace: only the one-reduction <16, 5, 3> instance (17 <= p <= 32, rows of <= 5 entries) is traced"); return MSDP_EUNSUPPORTED; }
+        fn = k_tcg_pipe_obl<16, 5, 3, true, true>;
+        HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    }
     hipLaunchKernelGGL(k_psync_reset, dim3(8), dim3(256), 0, h->stream, h->psync_slots, h->psync_err);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(fn, dim3(G), dim3(PB), pl.lds, h->stream, dp, h->psync_slots, h->psync_err);

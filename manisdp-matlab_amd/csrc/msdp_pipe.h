@@ -24,7 +24,9 @@
 // refresh every 32 trips, 1.0e-11 every 16, 2.2e-12 every 8 (1.4e-13 for the two-reduction trip; tools/pipe_drift_probe.py).  The
 // refresh needs no barrier here: every `pipe_refresh`-th trip publishes the rows of tangent(r) and md of ITS START next to those of
 // Hmd (regions 3 and 2 of the buffer, in front of the same reduction) and the next trip gathers all three -- C tangent(r) and C md
-// direct, then the step of the recurrences as on every trip.
+// direct, then the step of the recurrences as on every trip.  (pipe_refresh >= 2, enforced by msdp_set_option / fill_ctl: with 1 every trip
+// would both gather regions 2 / 3 at its top and store into them before its reduction -- no reduction between one workgroup's store and a
+// slower one's gather; with >= 2 the reduction of the trip in between separates them.)
 // Per-row arithmetic of eta, r, md and Hmd: the statements of the two-reduction kernel (same reference lines).  What differs from
 // tCG.m in floating point: C md is assembled (as in the two-reduction kernel), and <r', r'> / the model value that decide the
 // stopping and model tests of a trip are the expanded forms above (relative error eps <r, r> / <r', r'>); the values that enter
@@ -227,6 +229,58 @@ __device__ __forceinline__ bool psync8_lines(unsigned long long* slots, unsigned
     return __builtin_amdgcn_ballot_w64(fl != 0.0) == 0ULL;
 }
 
+// A barrier on the slots of psync8_lines -- a post without values (round 6, the TR tail of the fused launch): one generation of the same
+// ring, so posts, polls and sentinel resets interleave with the reductions around it.  The counter barrier of msdp_psync.h costs 3.3 us
+// on 216 workgroups (profiles/r6_fused_timeline_p32_before.md: 27 read-modify-writes per counter, one behind the other at the memory
+// side), this one what a reduction costs minus its sums.  The caller's stores are performed before the post (the wait is in here).
+__device__ __forceinline__ bool pbar8_lines(unsigned long long* slots, unsigned gen, int G, double* shb8, int* err, int bid, int backoff) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned long long* gbase = slots + (size_t)(gen % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID;
+    if (w == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(gbase + (size_t)(lane >> 3) * PSYNC_NV * MSDP_MAX_GRID + (size_t)bid * 8 + (lane & 7), 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const unsigned long long* p0 = gbase + (size_t)(bid & (PSYNC_REP - 1)) * PSYNC_NV * MSDP_MAX_GRID + (size_t)(32 * w + (lane >> 2)) * 8 + 2 * (lane & 3);
+    const bool in0 = 32 * w + (lane >> 2) < G, in1 = 32 * w + 16 + (lane >> 2) < G;
+    int spins = 0;
+    bool fail = false;
+    const int first = ((backoff >> 16) & 0xff) ? ((backoff >> 16) & 0xff) : (backoff & 0xff);
+    for (int q = 0; q < first; ++q) __builtin_amdgcn_s_sleep(1);
+    if (__builtin_amdgcn_ballot_w64(in0) != 0ULL) {
+        for (;;) {
+            v2ul a0, a1;
+            asm volatile(
+                "global_load_dwordx4 %0, %2, off sc1\n\t"
+                "global_load_dwordx4 %1, %2, off offset:1024 sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(a0), "=&v"(a1)
+                : "v"(p0)
+                : "memory");
+            bool ok = true;
+            if (in0) ok = a0.x != PSYNC_SENT && a0.y != PSYNC_SENT;
+            if (in1) ok = ok && a1.x != PSYNC_SENT && a1.y != PSYNC_SENT;
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ULL) break;
+            ++spins;
+            if (spins > PSYNC_SPIN_LIMIT ||
+                ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
+            for (int q = 0; q < ((backoff >> 8) & 0xff); ++q) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    if (lane == 0) {
+        shb8[8 + w] = fail ? 1.0 : 0.0;
+        if (fail) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (w == 0)
+        __hip_atomic_store(slots + (size_t)((gen + PSYNC_GEN - 1) % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID +
+                               (size_t)(lane >> 3) * PSYNC_NV * MSDP_MAX_GRID + (size_t)bid * 8 + (lane & 7),
+                           PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double fl = shb8[8 + (lane & 7)];
+    return __builtin_amdgcn_ballot_w64(fl != 0.0) == 0ULL;
+}
+
 // TRACE stamps of this form: 0 top of the trip (gather about to be issued), 1 products, Hmd and the eight partial sums formed, rows of
 // Hmd stored; inside the reduction 4 wave butterfly done, 2 stores performed + workgroup barrier, 3 posted + slept, 7 wave 0's poll
 // returned; 5 the reduction returned, 6 new direction formed (end of the trip)
@@ -253,6 +307,8 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     constexpr int RPW = 64 / LPR;
     constexpr int RSTEP = PWAVES * RPW;
     constexpr int ROWS = R * RSTEP;
+    // (FUSE: Ys / Gs / eGs and YPs / GPs / EGPs are the CURRENT point and the PROPOSAL -- two sets of LDS buffers that change roles when a
+    // step is accepted, round 6; the names are pointers, not fixed addresses)
     double2* Ys = reinterpret_cast<double2*>(lds);                 // [R][PB]
     double2* Gs = Ys + R * PB;                                     // [R][PB]
     double* eGs = reinterpret_cast<double*>(Gs + R * PB);          // [ROWS]
@@ -265,8 +321,9 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     // workgroup's row: exchange buffer); HQs = this workgroup's own rows of Hmd, two halves alternating like the buffer's.
     int* ls = cs + EW * ROWS;                                      // [EW][ROWS]
     double2* HQs = reinterpret_cast<double2*>(ls + EW * ROWS);     // [2][R][PB]
-    // FUSE only: the proposal point, its gradient and eG.  They share the space of HQs: that one lives inside a tCG, these between two
-    double2* YPs = HQs;                                            // [R][PB]
+    // FUSE only: the proposal point, its gradient and eG (round 6: buffers of their own behind HQs -- sharing its space meant a copy of
+    // 2 x R x PB double2 per accepted step, 1.1 us of every TR iteration)
+    double2* YPs = HQs + 2 * R * PB;                               // [R][PB]
     double2* GPs = YPs + R * PB;                                   // [R][PB]
     double* EGPs = reinterpret_cast<double*>(GPs + R * PB);        // [ROWS]
 
@@ -295,9 +352,14 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     const double kappa = c->kappa, theta = c->theta;
     const int mininner = c->mininner, maxinner = c->maxinner;
     double gg = c->gg;
-    // trust-region level state (FUSE; the statistics are kept in d.ctl by the lead thread, not in registers)
+    // trust-region level state (FUSE).  Round 6: the options and the counters are workgroup-uniform values (scalar registers) read ONCE --
+    // read per TR iteration they were a chain of scalar loads and, for the counters, read-modify-writes of global memory by the lead
+    // thread on the critical path between the iteration's reduction and the next tCG
     double fx = c->fx;
     int k_it = c->k;
+    const double Delta_bar = c->Delta_bar, rho_prime = c->rho_prime, rho_reg_opt = c->rho_reg, tolgradnorm = c->tolgradnorm;
+    const int maxiter = c->maxiter;
+    int n_acc = c->accepted, n_rej = c->rejected, n_hv = c->hessvecs, n_ce = c->cost_evals;
     const double* __restrict__ Yl = cur ? d.Y[1] : d.Y[0];
     const double* __restrict__ gl = cur ? d.Gr[1] : d.Gr[0];
     const double* __restrict__ eGl = cur ? d.eG[1] : d.eG[0];
@@ -310,6 +372,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     const int backoff = c->psync_backoff;
     const double2 zz = make_double2(0.0, 0.0);
     constexpr bool LOC = R * EW <= 15;                             // (four row slots: the source selection costs registers that spill)
+    constexpr bool MULTI = LOC && !(FUSE && LPR >= 16);            // three instances of the trip loop (per-wave local columns), see below
     double2 eta[R], rr[R], md[R], hmd[R], cmd[R], ctr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -374,19 +437,38 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
             if (lead_ok) nl = w + 1;
         }
     }
-    unsigned gen = 0, nbar = 0;
+    unsigned gen = 0;
     const unsigned half_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
-    // exchange buffer: halves 0 / 1 = the rows of Hmd (alternating trips), 2 = the rows of md' and 3 = those of tangent(r') of a refresh trip
-    const __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, 4u * half_bytes, 0x00020000);
+    // exchange buffer: halves 0 / 1 = the rows of Hmd (alternating trips), 2 = the rows of md' and 3 = those of tangent(r') of a refresh trip;
+    // FUSE (round 6): 4 = the rows of the proposal point, 5 / 6 = the gradient rows of the point in slot 0 / 1 -- the TR tail's exchanges
+    // went through d.Y / d.Gr of the proposal slot (ordinary device memory, sc1 accesses) and its two cold gathers took 4.2 and 2.8 us
+    // where a trip's gather from this buffer (fine-grained memory) is done in 1.4 with its arithmetic (profiles/r6_fused_timeline_p32_*.md)
+    const __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, (FUSE ? 7u : 4u) * half_bytes, 0x00020000);
+    // the gradient rows of the current point: where an earlier launch left them (d.Gr) until a step has been accepted in THIS launch
     __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[1] : d.Gr[0], 0, half_bytes, 0x00020000);
+    unsigned g_base = 0u;
     const unsigned gld = (unsigned)d.ld, gcol = colok ? 2 * sub : 0;
 
     double z_r = gg, d_Pd = gg, e_Pd = 0.0, e_Pe = 0.0, model_value = 0.0, alpha = 0.0, beta = 0.0;
     double norm_r0 = sqrt(gg);
     int j = 0, stop = 5;
+    // TRACE && FUSE (msdp_debug_persist_trace with reps <= 0): thread 0 of every workgroup stamps the phases of the first MSDP_TRACE_NJ TR
+    // iterations of the call into d.trace[(workgroup * NJ + iteration) * 8 + phase]: 0 iteration starts (tCG.m:102-157), 1 first trip's
+    // products and partial sums formed, 2 the tCG has ended (bits 56..63: its trips), 3 proposal rows stored and performed, 4 barrier
+    // returned, 5 cost / gradient rows of the proposal formed, 6 the iteration's reduction returned, 7 decision taken, point committed
+    const int k_it0 = c->k;
+#define FSTAMP(ph) do { if (TRACE && FUSE && threadIdx.x == 0 && k_it - k_it0 < MSDP_TRACE_NJ) \
+        d.trace[((size_t)bx * MSDP_TRACE_NJ + (k_it - k_it0)) * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
     bool first = true, direct = false, failed = false;
     unsigned xq = 0;                                               // the half this trip's rows of Hmd go to
     bool have_x = false;
+  // TRACE with FUSE (round 6): the stamps are those of the TR iteration around the tCG, not of the trips (FSTAMP below)
+// (... plus, in a second block of the trace buffer behind the G x NJ x 8 stamps of the iterations, the trips' own phase stamps -- those of
+// the per-iteration instance -- for the trips 0 .. NJ - 1 of ONE TR iteration, MSDP_TRACE_KSEL)
+#define MSDP_TRACE_KSEL 7
+#define FTRIP_ON (TRACE && FUSE && k_it - k_it0 == MSDP_TRACE_KSEL && j < MSDP_TRACE_NJ)
+#define FTRIP_PTR (d.trace + (size_t)GS * MSDP_TRACE_NJ * 8 + ((size_t)bx * MSDP_TRACE_NJ + j) * 8)
+#define PTSTAMP(ph) do { if (!FUSE) { TSTAMP(ph); } else if (FTRIP_ON && threadIdx.x == 0) FTRIP_PTR[ph] = __builtin_readcyclecounter(); } while (0)
   auto trips = [&](auto nlc) {
     constexpr int NL = decltype(nlc)::value;                       // columns [0, NL) from LDS, [NL, EW) through the buffer
     constexpr int NG = EW - NL;
@@ -394,7 +476,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     constexpr bool PREF = R * NG <= (FUSE ? 9 : 15);
     double2 X[R][NG];                                              // the gathered rows (in flight across the end of a trip)
     for (;;) {
-        TSTAMP(0);
+        PTSTAMP(0);
         // ---- the products: C md of this trip (cmd) and C tangent(r) (ctr)
         // columns [w0, w0 + NG) of the rows my rows reference, requested from (rs, base) / folded into acc
 #define PIPE_ISSUE(rs, base, w0) do { \
@@ -408,11 +490,11 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
                 if ((w0) + w < EW) { \
                     const double vv = vs[((w0) + w) * ROWS + SLOT(r)]; \
                     (acc).x = fma(vv, X[r][w].x, (acc).x); (acc).y = fma(vv, X[r][w].y, (acc).y); } } } while (0)
-        // the leading NL columns from the workgroup's own rows in LDS (half hq_half of HQs)
-#define PIPE_FOLDL(r, acc, hq_half) do { \
+        // the leading NL columns from the workgroup's own rows in LDS (src: a [R][PB] array -- a half of HQs, Gs, YPs)
+#define PIPE_FOLDL(r, acc, src) do { \
             _Pragma("unroll") for (int w = 0; w < NL; ++w) { \
                 const double vv = vs[w * ROWS + SLOT(r)]; \
-                const double2 xx = HQs[(hq_half) * R * PB + (ls[w * ROWS + SLOT(r)] & 0xffffff) + sub]; \
+                const double2 xx = (src)[(ls[w * ROWS + SLOT(r)] & 0xffffff) + sub]; \
                 (acc).x = fma(vv, xx.x, (acc).x); (acc).y = fma(vv, xx.y, (acc).y); } } while (0)
         // all EW columns through the buffer (the gradient / the refresh vectors are not in LDS): passes of NG columns
 #define PIPE_GATHER_ALL(rs, base, dst) do { \
@@ -422,8 +504,9 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
                 _Pragma("unroll") for (int r = 0; r < R; ++r) PIPE_FOLDX(r, (dst)[r], w0); } \
             if (!colok) { _Pragma("unroll") for (int r = 0; r < R; ++r) (dst)[r] = zz; } } while (0)
         if (first) {
-            // the first direction = the gradient (tangent, in global memory since an earlier launch): r = md = grad
-            PIPE_GATHER_ALL(rs_g, 0u, cmd);
+            // the first direction = the gradient (tangent): r = md = grad.  Its rows: in global memory since an earlier launch, in the
+            // exchange buffer since the TR tail that proposed this point
+            PIPE_GATHER_ALL(rs_g, g_base, cmd);
 #pragma unroll
             for (int r = 0; r < R; ++r) ctr[r] = cmd[r];
         } else {
@@ -437,7 +520,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 double2 a = zz;
-                PIPE_FOLDL(r, a, (xq ^ 1u));
+                PIPE_FOLDL(r, a, HQs + (xq ^ 1u) * R * PB);
                 PIPE_FOLDX(r, a, NL);
                 if (!colok) a = zz;
                 ctr[r].x = fma(-alpha, a.x, ctr[r].x); ctr[r].y = fma(-alpha, a.y, ctr[r].y);      // C tangent(r') = C tangent(r) - alpha C Hmd
@@ -459,7 +542,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
             double2 hq = make_double2(acc.x - y.x * dot - mdr.x * eg, acc.y - y.y * dot - mdr.y * eg);
             if (!OK(r)) hq = zz;
             hmd[r] = hq;
-            if (LOC) HQs[xq * R * PB + r * PB + threadIdx.x] = hq;
+            if (MULTI) HQs[xq * R * PB + r * PB + threadIdx.x] = hq;    // (read by the instances with local columns only)
             if (OK(r)) st2_sc1(rs_md, xq * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, hq);
             if (pub) {
                 const double dn = msdp_group_sum<LPR>(rv.x * y.x + rv.y * y.y);
@@ -478,14 +561,16 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
             v[6] += rv.x * rv.x + rv.y * rv.y;                                            // <r, r>      (:241 of the trip before)
             v[7] += (e0.x * g.x + e0.y * g.y) + 0.5 * (e0.x * rg.x + e0.y * rg.y);        // model value (:227 of the trip before)
         }
-        TSTAMP(1);
+        PTSTAMP(1);
+        if (TRACE && FUSE && j == 0) { FSTAMP(1); }
         // (my rows of Hmd are performed before I post: the wait sits inside psync8, behind the wave reduction)
         // (the next trip's gather goes out as soon as this wave has seen every workgroup's post: its latency runs under the rest of the
         // reduction and the arithmetic behind it.  Not behind a refresh trip: that one's two direct gathers come first.)
         if (!PSYNC8(slots, gen++, GS, v, sh8, shb8, err, bid, backoff,
-                    (TRACE && j >= MSDP_TRACE_J0 && j < MSDP_TRACE_J0 + MSDP_TRACE_NJ) ? d.trace + ((size_t)bx * MSDP_TRACE_NJ + (j - MSDP_TRACE_J0)) * 8 : nullptr,
+                    (TRACE && !FUSE && j >= MSDP_TRACE_J0 && j < MSDP_TRACE_J0 + MSDP_TRACE_NJ) ? d.trace + ((size_t)bx * MSDP_TRACE_NJ + (j - MSDP_TRACE_J0)) * 8 :
+                    (FTRIP_ON ? FTRIP_PTR : nullptr),
                     [&]() { if (PREF && !pub) { PIPE_ISSUE(rs_md, xq * half_bytes, NL); have_x = true; } })) { failed = true; break; }
-        TSTAMP(5);
+        PTSTAMP(5);
         const double d_Hd = v[0];                                                         // :166
         z_r = v[6];
         model_value = v[7];
@@ -536,15 +621,19 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         direct = pub;
         first = false;
         xq ^= 1u;
-        { --j; TSTAMP(6); ++j; }
+        { --j; PTSTAMP(6); ++j; }
     }
 #undef PIPE_ISSUE
 #undef PIPE_FOLDX
 #undef PIPE_FOLDL
 #undef PIPE_GATHER_ALL
+#undef PTSTAMP
+#undef FTRIP_ON
+#undef FTRIP_PTR
   };
   bool first_tr = true;
   for (;;) {   // ---- trust-region iterations (exactly one pass when !FUSE)
+    FSTAMP(0);
     if (FUSE && !first_tr) {
         // tCG.m:102-157 at the (possibly new) current point: eta = 0, r = mdelta = grad
 #pragma unroll
@@ -555,16 +644,27 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         z_r = gg; d_Pd = gg; e_Pd = 0.0; e_Pe = 0.0; model_value = 0.0; alpha = 0.0; beta = 0.0;
         norm_r0 = sqrt(gg);
         j = 0; stop = 5; first = true; direct = false; have_x = false;
-        rs_g = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[1] : d.Gr[0], 0, half_bytes, 0x00020000);
     }
     first_tr = false;
     // (FUSE at 16 lanes per row: ONE instance of the trip loop -- with three of them inside the loop over the TR iterations the
-    // register allocation spills 400 bytes per lane into the trips, 103 000 Hess-vec/s on G81 at p = 32 against 170 000 with one)
-    constexpr bool MULTI = LOC && !(FUSE && LPR >= 16);
+    // register allocation spills 400 bytes per lane into the trips, 103 000 Hess-vec/s on G81 at p = 32 against 170 000 with one.
+    // Round 6: an instance with its local columns fixed for the whole KERNEL -- two columns of every row from LDS, three through the
+    // buffer, one overflow column for the 1 to 4 rows of G81 that need it, the next gather requested inside the reduction -- was built
+    // and measured: 12 420 ticks per trip against 12 365, i.e. nothing; a trip is its reduction chain (3.3 us) and 2.2 us of fp64
+    // VALU work at 2 waves per SIMD, not its gather.  Removed.)
+    // RELIANCE: `nl` is per WAVE, so the waves of one workgroup may sit in different instances of `trips` and meet
+    // in the workgroup barriers of PSYNC8 (`__syncthreads()` / `s_barrier`) from different program counters.  gfx950's s_barrier counts
+    // arrivals per workgroup regardless of the PC and every instance executes the SAME sequence of barriers per trip (PSYNC8 is the
+    // only place with barriers; an instance leaves the loop on workgroup-uniform values only), so the counts pair up -- this is
+    // hardware behaviour, not the HIP model's guarantee.  Making `nl` workgroup-uniform would send every workgroup of a grid in natural
+    // order to NL = 2 (each holds the two ends of its chunk).  Covered on the device by the G81 tests: a workgroup there mixes NL = 3
+    // waves (interior), NL = 2 (the two waves at the chunk's ends) and NL = 0 (the waves with the wrap-around columns of a grid row).
     if (MULTI && nl >= 3) trips(std::integral_constant<int, MULTI ? 3 : 0>());
     else if (MULTI && nl == 2) trips(std::integral_constant<int, MULTI ? 2 : 0>());
     else trips(std::integral_constant<int, 0>());
     if (failed) return;
+    if (TRACE && FUSE && threadIdx.x == 0 && k_it - k_it0 < MSDP_TRACE_NJ)
+        d.trace[((size_t)bx * MSDP_TRACE_NJ + (k_it - k_it0)) * 8 + 2] = (__builtin_readcyclecounter() & 0x00ffffffffffffffULL) | ((unsigned long long)(j & 0xff) << 56);
     if (!FUSE) {
         // ---- hand eta, Heta = r - grad and the final scalars to the RTR kernels (trustregions.m:540-550)
 #pragma unroll
@@ -584,40 +684,34 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         return;
     }
     // ================= rest of the TR iteration (FUSE): trustregions.m:540-729 =================
+    // Round 6 (profiles/r6_fused_timeline_p32_before.md: 14 us per iteration outside its trips).  What changed: the step stays in its
+    // registers (it went through LDS and a rolled loop); the barrier in front of the gathers is a post on the reduction's slot lines
+    // (the counter barrier: 3.3 us); the proposal's rows and its gradient's rows travel through the fine-grained exchange buffer like
+    // the rows of a trip, not through d.Y / d.Gr; the neighbours' rows of the proposal's gradient -- the first gather of the next tCG if
+    // the step is accepted, as it mostly is -- are requested inside the iteration's reduction; an accepted step swaps the roles of the
+    // two sets of LDS buffers instead of copying one into the other; the point goes back to global memory once, when the launch ends.
     // x_prop = retr(x, eta) (ManiSDP_onlyunitdiag.m:142-145), <eta, grad + .5*Heta> (trustregions.m:549-550)
     double tv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};          // [0] cost, [1] |grad|^2 at the proposal, [2] <eta, grad + .5 Heta>
-    const __amdgpu_buffer_rsrc_t rs_yp = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Y[0] : d.Y[1], 0, half_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_gp = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[0] : d.Gr[1], 0, half_bytes, 0x00020000);
-    double* eGp = cur ? d.eG[0] : d.eG[1];
-    __syncthreads();                                               // (every wave has left the tCG: YPs / GPs take the place of HQs)
-    // (the step leaves the registers first: the rest of the iteration is rolled loops over LDS)
+    const unsigned yx_base = 4u * half_bytes, gx_base = (5u + (unsigned)(cur ^ 1)) * half_bytes;   // the proposal's rows / its gradient's rows
 #pragma unroll
-    for (int r = 0; r < R; ++r) { YPs[r * PB + threadIdx.x] = eta[r]; GPs[r * PB + threadIdx.x] = rr[r]; }
-#pragma unroll 1
     for (int r = 0; r < R; ++r) {
         const double2 y = Ys[r * PB + threadIdx.x], g = Gs[r * PB + threadIdx.x];
-        const double2 rq = GPs[r * PB + threadIdx.x];
-        const double2 he = make_double2(rq.x - g.x, rq.y - g.y);
-        const double2 e0 = YPs[r * PB + threadIdx.x];
+        const double2 e0 = eta[r];
+        const double2 he = make_double2(rr[r].x - g.x, rr[r].y - g.y);
         tv[2] += e0.x * (g.x + 0.5 * he.x) + e0.y * (g.y + 0.5 * he.y);
         const double2 x = make_double2(y.x + e0.x, y.y + e0.y);
         double nn = sqrt(msdp_group_sum<LPR>(x.x * x.x + x.y * x.y));
         if (!(nn > 0.0)) nn = 1.0;                                  // empty row slot
         const double2 ypr = OK(r) ? make_double2(x.x / nn, x.y / nn) : zz;
         YPs[r * PB + threadIdx.x] = ypr;
-        if (OK(r)) st2_sc1(rs_yp, ((unsigned)ROW(r) * gld + 2 * sub) * 8u, ypr);
+        if (OK(r)) st2_sc1(rs_md, yx_base + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, ypr);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!pbarrier(slots, nbar++, GS, shb8, err, bid)) return;
-    // cost and gradient at the proposal (ManiSDP_onlyunitdiag.m:117-125): YC = Y*C, eG = sum(YC.*Y), G = YC - Y.*eG.
-    // Rolled loop over the row slots (LDS in, LDS out): once per TR iteration, no register pressure on the tCG loop
-    auto prop_row = [&](int r) {
-        double2 xw[EW];
-#pragma unroll
-        for (int w = 0; w < EW; ++w) xw[w] = ld2_sc1(rs_yp, ((unsigned)cs[w * ROWS + SLOT(r)] * gld + gcol) * 8u);
-        double2 acc = zz;
-#pragma unroll
-        for (int w = 0; w < EW; ++w) { const double vv = vs[w * ROWS + SLOT(r)]; acc.x = fma(vv, xw[w].x, acc.x); acc.y = fma(vv, xw[w].y, acc.y); }
+    FSTAMP(3);
+    // (my proposal rows are performed before the post: the wait is inside)
+    if (!pbar8_lines(slots, gen++, GS, shb8, err, bid, backoff)) return;
+    FSTAMP(4);
+    // cost and gradient at the proposal (ManiSDP_onlyunitdiag.m:117-125): YC = Y*C, eG = sum(YC.*Y), G = YC - Y.*eG
+    auto prop_finish = [&](int r, double2 acc) {
         if (!colok) acc = zz;
         const double2 ypr = YPs[r * PB + threadIdx.x];
         const double dot = msdp_group_sum<LPR>(acc.x * ypr.x + acc.y * ypr.y);
@@ -626,22 +720,43 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         tv[1] += gpr.x * gpr.x + gpr.y * gpr.y;
         if (sub == 0) {
             EGPs[SLOT(r)] = ROK(r) ? dot : 0.0;
-            if (ROK(r)) { tv[0] += 0.5 * dot; eGp[ROW(r)] = dot; }
+            if (ROK(r)) tv[0] += 0.5 * dot;
         }
-        if (OK(r)) st2_sc1(rs_gp, ((unsigned)ROW(r) * gld + 2 * sub) * 8u, gpr);
+        if (OK(r)) st2_sc1(rs_md, gx_base + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, gpr);
     };
-    if (R * EW <= 15) {                                            // all gathers in flight (wider rows: a row slot at a time, registers)
+    if (R * EW <= 16) {                                            // all gathers in flight (wider rows: a row slot at a time, registers)
+        double2 XG[R][EW];
 #pragma unroll
-        for (int r = 0; r < R; ++r) prop_row(r);
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int w = 0; w < EW; ++w) XG[r][w] = ld2_sc1(rs_md, yx_base + ((unsigned)cs[w * ROWS + SLOT(r)] * gld + gcol) * 8u);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double2 acc = zz;
+#pragma unroll
+            for (int w = 0; w < EW; ++w) { const double vv = vs[w * ROWS + SLOT(r)]; acc.x = fma(vv, XG[r][w].x, acc.x); acc.y = fma(vv, XG[r][w].y, acc.y); }
+            prop_finish(r, acc);
+        }
     } else {
 #pragma unroll 1
-        for (int r = 0; r < R; ++r) prop_row(r);
+        for (int r = 0; r < R; ++r) {
+            double2 xw[EW];
+#pragma unroll
+            for (int w = 0; w < EW; ++w) xw[w] = ld2_sc1(rs_md, yx_base + ((unsigned)cs[w * ROWS + SLOT(r)] * gld + gcol) * 8u);
+            double2 acc = zz;
+#pragma unroll
+            for (int w = 0; w < EW; ++w) { const double vv = vs[w * ROWS + SLOT(r)]; acc.x = fma(vv, xw[w].x, acc.x); acc.y = fma(vv, xw[w].y, acc.y); }
+            prop_finish(r, acc);
+        }
     }
-    // (the proposal's gradient rows are in place before the post: psync8 waits for the stores)
+    FSTAMP(5);
+    // (the proposal's gradient rows are in place before the post: psync8 waits for the stores.  Requesting the neighbours' rows of that
+    // gradient inside this reduction -- the first gather of the next tCG when the step is accepted -- was built and measured: the R x EW
+    // row registers do not survive the decision block, the compiler parks them in scratch and WAITS for the loads to do so: the
+    // reduction went from 6 300 to 15 500 ticks.  The first trip gathers them itself.)
     if (!PSYNC8(slots, gen++, GS, tv, sh8, shb8, err, bid, backoff, nullptr, []() {})) return;
+    FSTAMP(6);
     {   // trustregions.m:548-729, identical in every workgroup (same bits in, same decision out)
-        // (the options are read here, once per TR iteration, not kept in scalar registers across the tCG loop)
-        const double Delta_bar = c->Delta_bar, rho_prime = c->rho_prime, rho_reg_opt = c->rho_reg;
         const double fp = tv[0], ggp = tv[1], prd = tv[2];
         double rhonum = fx - fp;                                             // :548
         double rhoden = -prd;                                                // :550
@@ -653,37 +768,54 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         if (rho < 0.25 || !model_decreased || isnan(rho)) Delta = Delta / 4.0;            // :653
         else if (rho > 0.75 && (stop == 1 || stop == 2)) Delta = fmin(2.0 * Delta, Delta_bar);   // :669
         const bool accept = model_decreased && rho > rho_prime;              // :688
+        if (accept) ++n_acc; else ++n_rej;
+        n_hv += j;
+        ++n_ce;
         if (lead) {
             Ctl* cw = d.ctl;
             cw->rho = rho; cw->rhonum = rhonum; cw->rhoden = rhoden; cw->fx_prop = fp; cw->gg_prop = ggp;
-            if (accept) cw->accepted++; else cw->rejected++;
-            cw->hessvecs += j;
-            cw->cost_evals++;
+            cw->accepted = n_acc; cw->rejected = n_rej; cw->hessvecs = n_hv; cw->cost_evals = n_ce;
             cw->last_stop_inner = stop;
         }
         if (accept) {
+            // the proposal becomes the point: the two sets of LDS buffers change roles, and its gradient's rows are where the
+            // neighbours (and later tCGs at this point) find them -- slot cur of the exchange buffer
             cur ^= 1;
             fx = fp; gg = ggp;
-#pragma unroll 1
-            for (int r = 0; r < R; ++r) {
-                Ys[r * PB + threadIdx.x] = YPs[r * PB + threadIdx.x];
-                Gs[r * PB + threadIdx.x] = GPs[r * PB + threadIdx.x];
-                if (sub == 0) eGs[SLOT(r)] = EGPs[SLOT(r)];
-            }
+            { double2* t = Ys; Ys = YPs; YPs = t; }
+            { double2* t = Gs; Gs = GPs; GPs = t; }
+            { double* t = eGs; eGs = EGPs; EGPs = t; }
+            rs_g = rs_md; g_base = gx_base;
         }
+        FSTAMP(7);
         ++k_it;                                                              // :729
     }
-    __syncthreads();                                                         // eGs / Ys / Gs updates visible to the whole workgroup
-    if (sqrt(gg) < c->tolgradnorm || k_it >= c->maxiter) break;                    // stoppingcriterion.m:51-72
+    if (sqrt(gg) < tolgradnorm || k_it >= maxiter) break;                    // stoppingcriterion.m:51-72
   }
+    // the point the solve ends at goes back to global memory (its rows lived in LDS and in the exchange buffer since the launch began)
+    {
+        double* Yo = cur ? d.Y[1] : d.Y[0];
+        double* Go = cur ? d.Gr[1] : d.Gr[0];
+        double* eo = cur ? d.eG[1] : d.eG[0];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (OK(r)) {
+                const int64_t o = (int64_t)ROW(r) * d.ld + 2 * sub;
+                st2(Yo + o, Ys[r * PB + threadIdx.x]);
+                st2(Go + o, Gs[r * PB + threadIdx.x]);
+            }
+            if (sub == 0 && ROK(r)) eo[ROW(r)] = eGs[SLOT(r)];
+        }
+    }
     if (lead) {
         Ctl* cw = d.ctl;
         cw->fx = fx; cw->gg = gg; cw->norm_grad = sqrt(gg); cw->Delta = Delta;
         cw->k = k_it; cw->cur = cur;
         cw->done = 1;
         cw->tcg_running = 0;
-        frame_store(&d.F[0], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, cw->last_stop_inner, 0, 0, 0);
+        frame_store(&d.F[0], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, stop, 0, 0, 0);
     }
+#undef FSTAMP
 #undef SLOT
 #undef ROW
 #undef ROK

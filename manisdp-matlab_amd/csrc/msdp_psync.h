@@ -67,20 +67,24 @@ __device__ __forceinline__ double msdp_swap_add(double a, double b) {
     }
     return __longlong_as_double((long long)(((unsigned long long)h0 << 32) | l0)) + __longlong_as_double((long long)(((unsigned long long)h1 << 32) | l1));
 }
+// Three per-lane partials summed over the wave TOGETHER (round 5): two permlane swaps leave value k in row k of 16 lanes (row 3: zero),
+// one row reduction finishes all of them -- a third of the instructions of three separate wave sums.  sh[k * PWAVES + wave] = value k.
+// ONE helper for psync(nv = 3) and psync_post3: the split reduction promises the bits of the unsplit one.
+__device__ __forceinline__ void psync_wave3(double a, double b, double c, double* sh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double x = msdp_swap_add<16>(msdp_swap_add<32>(a, c), msdp_swap_add<32>(b, 0.0));
+    x += msdp_dpp<MSDP_DPP_XOR1>(x); x += msdp_dpp<MSDP_DPP_XOR2>(x);
+    x += msdp_dpp<MSDP_DPP_HALF_MIRROR>(x); x += msdp_dpp<MSDP_DPP_MIRROR>(x);
+    if ((lane & 15) == 0 && lane < 48) sh[(lane >> 4) * PWAVES + w] = x;
+}
 // drain (round 5): the caller has row stores in flight that must be performed before the workgroup posts -- the wait sits here, behind
 // the wave sums, instead of in front of the call (the stores drain while the sums are formed)
 __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, int G, int nv, double& a, double& b,
                                       double& c, double* sh, double* shb, int* err, int bid_in = -1, int backoff = 0, bool drain = false) {
     const int bid = bid_in < 0 ? (int)blockIdx.x : bid_in;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (nv > 1) {
-        // the three values over the wave TOGETHER (round 5): two permlane swaps leave value k in row k of 16 lanes (row 3: zero), one
-        // row reduction finishes all of them -- a third of the instructions of three separate wave sums
-        double x = msdp_swap_add<16>(msdp_swap_add<32>(a, c), msdp_swap_add<32>(b, 0.0));
-        x += msdp_dpp<MSDP_DPP_XOR1>(x); x += msdp_dpp<MSDP_DPP_XOR2>(x);
-        x += msdp_dpp<MSDP_DPP_HALF_MIRROR>(x); x += msdp_dpp<MSDP_DPP_MIRROR>(x);
-        if ((lane & 15) == 0 && lane < 48) sh[(lane >> 4) * PWAVES + w] = x;
-    } else {
+    if (nv > 1) psync_wave3(a, b, c, sh);
+    else {
         a = msdp_wave_sum(a);
         if (lane == 0) { sh[w] = a; sh[PWAVES + w] = b; sh[2 * PWAVES + w] = c; }
     }
@@ -158,9 +162,8 @@ __device__ __forceinline__ bool psync(unsigned long long* slots, unsigned gen, i
 // (waits for its neighbours' row flags, gathers their rows), polls the slots with the SAME loads and the same summation order as
 // psync() wherever it has a wait anyway, and ends with psync_finish3.  Same bits as psync(..., nv = 3, ...).
 __device__ __forceinline__ void psync_post3(unsigned long long* slots, unsigned gen, double a, double b, double c, double* sh, int bid) {
-    a = msdp_wave_sum(a); b = msdp_wave_sum(b); c = msdp_wave_sum(c);
+    psync_wave3(a, b, c, sh);                                      // (the wave sums of psync(nv = 3): same instructions, same bits)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { sh[w] = a; sh[PWAVES + w] = b; sh[2 * PWAVES + w] = c; }
     __syncthreads();
     if (w == 0 && lane < PSYNC_REP * PSYNC_NV) {
         unsigned long long* gbase = slots + (size_t)(gen % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID;

@@ -28,15 +28,23 @@ def _run_ranks(N, rows, cols, p, tmp_path, devices=None):
         cmd = [sys.executable, os.path.join(ROOT, "tests", "ipc_rank_worker.py"), str(r), str(N), name, str(rows), str(cols), str(p), out]
         if devices is not None:
             cmd.append(str(devices[r]))
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        # (output to a file per worker: a pipe nobody drains while the members wait for each other in a barrier would stall all of them)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=open(str(tmp_path / ("rank%d.log" % r)), "w"), stderr=subprocess.STDOUT, text=True))
     logs = []
-    for pr in procs:
+    try:
+        for pr in procs:
+            try:
+                pr.wait(timeout=300)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                pr.wait()
+        logs = [open(str(tmp_path / ("rank%d.log" % r))).read() for r in range(N)]
+    finally:
+        # the worker ends with a provoked time-out and skips h.close(): rank 0 never unlinks the group's segment -- the harness does
         try:
-            o, _ = pr.communicate(timeout=300)
-        except subprocess.TimeoutExpired:
-            pr.kill()
-            o, _ = pr.communicate()
-        logs.append(o)
+            os.unlink("/dev/shm" + name)
+        except OSError:
+            pass
     for r, pr in enumerate(procs):
         assert pr.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-3000:])
     return [np.load(o) for o in outs]

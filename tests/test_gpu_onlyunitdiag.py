@@ -358,7 +358,7 @@ def test_one_reduction_trip_solves_G81_like_the_two_reduction_trip(lib, p):
     h = lib.Handle.onlyunitdiag(C, pcap=p)
     opts = lib.default_opts(maxiter=40, maxinner=100, tolgradnorm=1e-8)
     out = {}
-    for name, pipe, refresh, fused in (("two", 0, 16, 0), ("one", 1, 16, 0), ("one again", 1, 16, 0), ("one/4", 1, 4, 0), ("one/64", 1, 64, 0),
+    for name, pipe, refresh, fused in (("two", 0, 16, 0), ("one", 1, 16, 0), ("one again", 1, 16, 0), ("one/1", 1, 1, 0), ("one/2", 1, 2, 0), ("one/4", 1, 4, 0), ("one/64", 1, 64, 0),
                                        ("one fused", 1, 16, 1), ("one fused again", 1, 16, 1), ("one all rows through the buffer", 1, 16, 0)):
         h.set_option("persist_pipe", pipe)
         h.set_option("pipe_refresh", refresh)
@@ -369,7 +369,10 @@ def test_one_reduction_trip_solves_G81_like_the_two_reduction_trip(lib, p):
         st = h.rtr(opts)
         out[name] = (st, h.get_point())
     ref, Yref = out["two"]
-    for name in ("one", "one/4", "one/64", "one fused", "one all rows through the buffer"):
+    # ("one/1": a refresh interval of 1 is raised to 2 by msdp_set_option -- with 1 a workgroup would publish the refresh rows of trip
+    # j + 1 into the regions a slower one still gathers those of trip j from)
+    assert np.array_equal(out["one/1"][1], out["one/2"][1])
+    for name in ("one", "one/1", "one/2", "one/4", "one/64", "one fused", "one all rows through the buffer"):
         st, Yo = out[name]
         assert (st.iters, st.hessvecs, st.accepted, st.rejected, st.last_stop_inner) == (ref.iters, ref.hessvecs, ref.accepted, ref.rejected, ref.last_stop_inner), name
         assert abs(st.cost - ref.cost) <= 1e-11 * abs(ref.cost), (name, st.cost, ref.cost)
