@@ -14,8 +14,10 @@ all-gather of the thin n x p direction before every S*U and an all-reduce of the
 sums; the instance is the same toroidal-grid family scaled to n = 20000 * N rows so the
 per-GPU work is fixed ("weak" scaling); value counts 20000-row-equivalent Hess-vecs.  The same K steps are then timed once
 more with the halo exchange (option halo_exchange: only the rows a rank's rows of C reference travel, bit-identical results);
-both figures are in the line under "row_exchange"; `value` is the all-gather figure unless --row-exchange halo asks for the
-other one (fixed by configuration, never best-of), and config.row_exchange names it.
+both figures are in the line under "row_exchange".  Round 6: `value` at N > 1 is quoted on the cross-rank persistent kernels
+(--multi-gpu-path xr, the default: one process group over HIP IPC / peer access, two-level grid reductions, no collective per trip or TR
+iteration; "cross_rank_persistent" in the line) where the node offers peer access between the ranks' devices, and on the RCCL leg
+--row-exchange names otherwise (fixed by configuration, never best-of); config.multi_gpu_path says which.
 
 One JSON line is printed by rank 0.
 """
@@ -265,8 +267,19 @@ def process_rank_worker(argv):
             t0 = time.perf_counter(); st = h.rtr(opts); dt = time.perf_counter() - t0
             best, hv, calls = min(best, dt), st.hessvecs, h.collective_calls() - c0
         res[xtail] = (best, hv, calls, st.iters)
-    json.dump({"trip_us": trip, "tcg_path": h.tcg_path(), "rtr_seconds": res[1][0], "hessvecs": res[1][1], "collective_calls_per_rtr_call": res[1][2],
-               "iters": res[1][3], "rtr_seconds_with_per_iteration_collectives": res[0][0], "collective_calls_with_them": res[0][2]}, open(out, "w"))
+    path = h.tcg_path()
+    # the same with the two-level grid reductions (msdp_psync.h psync2: what ranks on different GPUs run; here both members share the device)
+    h.set_option("xtail", 1)
+    h.set_option("xr_twolevel", 1)
+    h.set_point(Y)
+    trip2 = min(h.bench_tcg_trip(256) for _ in range(3)) * 1e3
+    best2 = 1e9
+    for _ in range(3):
+        h.set_point(Y)
+        t0 = time.perf_counter(); st2 = h.rtr(opts); best2 = min(best2, time.perf_counter() - t0)
+    json.dump({"trip_us": trip, "tcg_path": path, "rtr_seconds": res[1][0], "hessvecs": res[1][1], "collective_calls_per_rtr_call": res[1][2],
+               "iters": res[1][3], "rtr_seconds_with_per_iteration_collectives": res[0][0], "collective_calls_with_them": res[0][2],
+               "trip_us_two_level": trip2, "rtr_seconds_two_level": best2, "hessvecs_two_level": st2.hessvecs}, open(out, "w"))
     h.close()
 
 
@@ -317,7 +330,30 @@ def process_rank_trip(N=2, p=32):
             "trustregions_us_per_hessvec": sec * 1e6 / hv, "hessvec_per_s": hv / sec, "hessvecs": hv, "tr_iterations": res[0]["iters"],
             "collective_calls_per_trustregions_call": res[0]["collective_calls_per_rtr_call"],
             "trustregions_us_per_hessvec_with_per_iteration_collectives": sec_c * 1e6 / hv,
-            "collective_calls_with_per_iteration_collectives": res[0]["collective_calls_with_them"]}
+            "collective_calls_with_per_iteration_collectives": res[0]["collective_calls_with_them"],
+            "two_level_reductions": {"trip_us": max(q["trip_us_two_level"] for q in res),
+                                     "trustregions_us_per_hessvec": max(q["rtr_seconds_two_level"] for q in res) * 1e6 / max(res[0]["hessvecs_two_level"], 1),
+                                     "hessvecs": res[0]["hessvecs_two_level"],
+                                     "note": "the N-GPU form of the reductions (each member over its own grid, the members' sums pushed into every member's block) "
+                                             "run by two processes on ONE device; on N devices the second level crosses xGMI"}}
+
+
+def xr_unavailable(N, local_rank):
+    """None when the process-group path can serve this job: every rank on this node, one device each, peer access between them."""
+    try:
+        import torch
+        if int(os.environ.get("LOCAL_WORLD_SIZE", str(N))) != N:
+            return "the ranks span more than one node"
+        if N > 8:
+            return "more than 8 ranks"
+        if torch.cuda.device_count() < N:
+            return "fewer than %d devices visible" % N
+        for q in range(N):
+            if q != local_rank and not torch.cuda.can_device_access_peer(local_rank, q):
+                return "no peer access between devices %d and %d" % (local_rank, q)
+        return None
+    except Exception as e:  # noqa: BLE001
+        return "%s: %s" % (type(e).__name__, e)
 
 
 def main():
@@ -341,6 +377,9 @@ def main():
     ap.add_argument("--row-exchange", choices=("allgather", "halo"), default="allgather",
                     help="N > 1: which exchange in front of S*U `value` is quoted on (both legs are timed and reported): the "
                          "all-gather of the whole direction north_star prescribes (default), or the halo exchange")
+    ap.add_argument("--multi-gpu-path", choices=("xr", "rccl"), default="xr",
+                    help="N > 1: the path `value` is quoted on -- xr: the cross-rank persistent kernels over HIP IPC / xGMI where the node "
+                         "offers peer access between the ranks' devices (RCCL lock-step trips otherwise); rccl: the RCCL lock-step trips")
     ap.add_argument("--force-comm", action="store_true",
                     help="diagnostic: run the N = 1 workload through the RCCL code path of the multi-GPU run "
                          "(size-1 communicator: all-gather + all-reduces per trip, chunked tCG)")
@@ -727,6 +766,28 @@ def main():
             if args.row_exchange == "halo" and "error" not in hl and hl["hessvecs"] == hv:
                 out["value"], out["ms_per_step"] = hl["value"], hl["ms_per_step"]
                 out["config"]["row_exchange"] = "halo (option halo_exchange): grouped ncclSend/ncclRecv of the referenced rows"
+            # Round 6: the N-GPU form of the persistent kernels -- one PROCESS group over HIP IPC / peer access, the cross-rank tCG
+            # and TR tail with two-level grid reductions (each member over its own grid, eight sums per member over xGMI), boundary
+            # rows pushed into the neighbours' buffers: no collective per trip, none per iteration.  `value` is quoted on THIS path
+            # when --multi-gpu-path xr (the default) and it ran; the RCCL legs above stay in the line beside it.  Whether the path is
+            # available is a property of the node (every rank on it, peer access between the devices), decided before any timing.
+            out["config"]["multi_gpu_path"] = "rccl (%s)" % out["config"]["row_exchange"]
+            why_not = xr_unavailable(N, local_rank)
+            if args.multi_gpu_path != "xr":
+                out["cross_rank_persistent"] = {"skipped": "--multi-gpu-path rccl"}
+            elif allmax(0.0 if why_not is None else 1.0) > 0.0:
+                out["cross_rank_persistent"] = {"skipped": why_not or "unavailable on another rank"}
+            else:
+                os.environ.setdefault("MSDP_LOCAL_BARRIER_TIMEOUT", "60")
+                ident = ["/msdp_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getpid()) if rank == 0 else None]
+                dist.broadcast_object_list(ident, src=0)
+                xl = xr_leg(_lib, lambda hh: hh.comm_init_ipc(N, rank, ident[0]), sync, allmax, N, rank, C, Y0, p, opts, args.steps, args.warmup)
+                out["cross_rank_persistent"] = xl
+                if "error" not in xl and xl.get("tcg_path") == 2 and xl["hessvecs"] == hv:
+                    out["value"], out["ms_per_step"] = xl["value"], xl["ms_per_step"]
+                    out["config"]["multi_gpu_path"] = ("cross-rank persistent tCG + TR tail over HIP IPC / xGMI, two-level grid reductions "
+                                                       "(msdp_comm_init_ipc); RCCL legs: row_exchange")
+                    out["config"]["tcg_path"] = "persistent kernels spanning the ranks: no collective per trip or TR iteration"
         if not args.no_dense:
             try:
                 out["k5_dense_sharded"] = k5_dense_sharded(_lib, join, sync, allmax, N, rank)
@@ -741,44 +802,83 @@ def main():
         result_out.flush()
 
 
-def halo_leg(_lib, join, sync, allmax, N, rank, C, Y0, p, opts, steps, warmup):
-    """The timed region of main() once more on a fresh handle with the halo exchange in front of S*U.  `join(h)` makes the handle
-    a member of the job's communicator, `sync()` is the barrier + device synchronisation of main(), `allmax(x)` the maximum
-    of x over the ranks (closures, so that tests can drive this on in-process ranks)."""
-    # Set-up (allocations, the halo lists and buffers) may fail on ONE rank only: every rank reports its outcome and all of
-    # them skip the timed collectives together -- a rank that raised alone would leave the others waiting in ncclSend/ncclRecv.
+def _sharded_leg(_lib, join, sync, allmax, N, rank, C, Y0, p, opts, steps, warmup, options, what, probe=None):
+    """The timed region of main() once more on a fresh handle.  `join(h)` makes the handle a member of the job's group (RCCL
+    communicator or process group over HIP IPC), `sync()` is the barrier + device synchronisation of main(), `allmax(x)` the
+    maximum of x over the ranks (closures, so that tests can drive this on in-process ranks).  options: set on the handle behind
+    the join; probe(h): extra figures taken behind the timed loop (a collective call: every rank makes it)."""
+    # Set-up may fail on ONE rank only: every rank reports its outcome and all of them skip the timed region together -- a rank
+    # that raised alone would leave the others waiting in a collective / a grid reduction.
     h, err = None, None
     try:
         h = _lib.Handle.onlyunitdiag(C, pcap=p)
     except Exception as e:  # noqa: BLE001
         err = "%s: %s" % (type(e).__name__, e)
-    if allmax(0.0 if err is None else 1.0) > 0.0:           # communicator set-up is a collective itself: only if everybody has a handle
+    if allmax(0.0 if err is None else 1.0) > 0.0:           # group set-up is a collective itself: only if everybody has a handle
         if h is not None:
             h.close()
         return {"error": err or "another rank failed to create its handle"}
     try:
         join(h)
-        h.set_option("halo_exchange", 1)
+        for k, v in options.items():
+            h.set_option(k, v)
         h.set_point(Y0)
         h.point_snapshot()
     except Exception as e:  # noqa: BLE001
         err = "%s: %s" % (type(e).__name__, e)
     if allmax(0.0 if err is None else 1.0) > 0.0:
         h.close()
-        return {"error": err or "another rank failed to set the halo exchange up"}
-    for _ in range(max(1, warmup)):
-        h.point_restore()
-        h.rtr(opts)
+        return {"error": err or "another rank failed to set %s up" % what}
+    # (from here on a failure -- a grid reduction of the cross-rank kernels that times out -- is raised on every rank by the library
+    # itself; the barriers and maxima below are still entered by everybody, in the same order)
+    try:
+        for _ in range(max(1, warmup)):
+            h.point_restore()
+            h.rtr(opts)
+    except Exception as e:  # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
     sync()
     t0 = time.perf_counter()
     hv = 0
-    for _ in range(steps):
-        h.point_restore()
-        hv += h.rtr(opts).hessvecs
+    if err is None:
+        try:
+            for _ in range(steps):
+                h.point_restore()
+                hv += h.rtr(opts).hessvecs
+        except Exception as e:  # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
     sync()
     dt = allmax(time.perf_counter() - t0)
-    h.close()
-    return {"value": hv * N / dt, "ms_per_step": dt / steps * 1e3, "hessvecs": hv}
+    bad = allmax(0.0 if err is None else 1.0) > 0.0
+    res = {"value": hv * N / dt, "ms_per_step": dt / steps * 1e3, "hessvecs": hv}
+    if bad:
+        res = {"error": err or "another rank failed in the timed region of %s" % what}
+    elif probe is not None:
+        try:
+            res.update(probe(h))
+        except Exception as e:  # noqa: BLE001
+            res["probe_error"] = "%s: %s" % (type(e).__name__, e)
+    try:
+        h.close()
+    except Exception:  # noqa: BLE001 -- a broken group refuses its collectives; the process ends soon
+        pass
+    return res
+
+
+def halo_leg(_lib, join, sync, allmax, N, rank, C, Y0, p, opts, steps, warmup):
+    """The K steps on a fresh handle with the halo exchange in front of S*U (RCCL: grouped ncclSend / ncclRecv of the referenced rows)."""
+    return _sharded_leg(_lib, join, sync, allmax, N, rank, C, Y0, p, opts, steps, warmup, {"halo_exchange": 1}, "the halo exchange")
+
+
+def xr_leg(_lib, join_ipc, sync, allmax, N, rank, C, Y0, p, opts, steps, warmup):
+    """The K steps on a fresh handle whose group is a PROCESS group over HIP IPC (msdp_comm_init_ipc, one rank per GPU): the
+    cross-rank persistent tCG and TR tail -- every member reduces over its own grid, the members' sums travel over xGMI (two-level
+    reductions, msdp_psync.h), boundary rows are pushed into the neighbours' exchange buffers; no collective per trip or iteration."""
+    def probe(h):
+        path = h.tcg_path()
+        return {"tcg_path": path, "collective_calls_total": h.collective_calls(),
+                "trip_us_cross_rank_persistent": min(h.bench_tcg_trip(256) for _ in range(2)) * 1e3 if path == 2 else None}
+    return _sharded_leg(_lib, join_ipc, sync, allmax, N, rank, C, Y0, p, opts, steps, warmup, {}, "the process group", probe)
 
 
 def k5_dense_sharded(_lib, join, sync, allmax, N, rank, rows_per_gpu=12500, p=64):

@@ -1020,6 +1020,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "xpersist")) t.xpersist = value != 0;
     else if (!strcmp(name, "persist_refresh")) t.persist_refresh = value > 0 ? value : 0;
     else if (!strcmp(name, "xtail")) t.xtail = value ? 1 : 0;
+    else if (!strcmp(name, "xr_twolevel")) t.xr_twolevel = value ? 1 : 0;
     else if (!strcmp(name, "window")) { t.window = value < 0 ? 0 : (value > 3 ? 3 : value); h->chunk_len = 0; }
     else if (!strcmp(name, "window_lds")) { t.window_lds = value < 16 ? 16 : (value > 144 ? 144 : value); h->chunk_len = 0; msdp_window_release(h); }
     else if (!strcmp(name, "persist_early")) t.persist_early = value > 0 ? value : 0;
@@ -1119,6 +1120,8 @@ struct IpcShared {
     hipIpcMemHandle_t arena;
     unsigned long long arena_bytes, stage_bytes, rows_doubles, slot_bytes;
     hipIpcMemHandle_t rows_handle[LOCAL_MAX_RANKS];          // every member's exchange buffer (its own allocation, on its own device)
+    hipIpcMemHandle_t blk_handle[LOCAL_MAX_RANKS];           // every member's two-level synchronisation block (msdp_psync.h psync2; round 6)
+    char devid[LOCAL_MAX_RANKS][32];                         // the PCI bus id of every member's device
     int vote[LOCAL_MAX_RANKS];
     int plan[LOCAL_MAX_RANKS][4];
     int halo_off[LOCAL_MAX_RANKS][LOCAL_MAX_RANKS], halo_cnt[LOCAL_MAX_RANKS][LOCAL_MAX_RANKS];
@@ -1158,6 +1161,10 @@ struct LocalGroup {
     double* xr_rows[LOCAL_MAX_RANKS] = {nullptr};
     size_t xr_rows_doubles = 0;
     int xr_halo_max = 0;          // halo slots behind a member's rows in every buffer (the largest halo of the group)
+    // two-level reductions (process group): the members' blocks as this process maps them (mine: my own allocation), the device copy of
+    // that table
+    unsigned long long* xr2_blk[LOCAL_MAX_RANKS] = {nullptr};
+    unsigned long long** xr2_table = nullptr;
 };
 static std::mutex g_groups_mutex;
 static std::map<int, LocalGroup*> g_groups;
@@ -1221,6 +1228,9 @@ static int local_vote_min(msdp_handle h, int v, int* out) {
     return 0;
 }
 int msdp_xpersist_eligible(msdp_handle h, int nranks);                          // msdp_persist.hip
+size_t msdp_xr2_block_bytes();
+size_t msdp_xr2_err_offset();
+int msdp_xr2_reset(hipStream_t stream, unsigned long long* blk);
 size_t msdp_xpersist_slot_bytes();
 int msdp_xpersist_reset(hipStream_t stream, unsigned long long* slots, int* err);
 // The shared block of the group: allocated by member 0 the first time (and again when the factor outgrows the exchange buffer)
@@ -1293,9 +1303,15 @@ static int xr_begin(msdp_handle h, bool* use) {
         if ((rc = msdp_xpersist_reset(h->stream, g->xr_slots, g->xr_err))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
     }
+    if (g->ipc && h->xr2_blk) {
+        // two-level form: every member clears ITS block (slots, member lines, error word); nobody posts before everybody has
+        if ((rc = msdp_xr2_reset(h->stream, h->xr2_blk))) { local_break(g); return rc; }
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     LOCAL_BARRIER(g);
     return 0;
 }
+static int* xr2_err(msdp_handle h) { return reinterpret_cast<int*>(reinterpret_cast<char*>(h->xr2_blk) + msdp_xr2_err_offset()); }
 // One tCG for all members: each hands its Dev and plan to the group and marks its stream; member 0 makes its stream wait for
 // the others', launches the combined kernel and marks its end; the others' streams wait for that mark.
 int msdp_launch_tcg_xpersist_one(hipStream_t stream, const Dev& dv, const int* plan, unsigned long long* slots, int* err);   // msdp_persist.hip
@@ -1309,8 +1325,8 @@ static int xr_launch(msdp_handle h) {
         Dev dv; int pl[3];
         if ((rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_rows, g->xr_halo_max, &dv, pl))) { local_break(g); return rc; }
         pl[1] = g->ipc_ew;
-        if (h->tune.fail_xr) { h->tune.fail_xr = 0; dv.xr_gtot += 8; }
-        if ((rc = msdp_launch_tcg_xpersist_one(h->stream, dv, pl, g->xr_slots, g->xr_err))) { local_break(g); return rc; }
+        if (h->tune.fail_xr) { h->tune.fail_xr = 0; dv.xr_gtot += 8; dv.xr2_skip = 8; }
+        if ((rc = msdp_launch_tcg_xpersist_one(h->stream, dv, pl, g->xr_slots, dv.xr2_on ? xr2_err(h) : g->xr_err))) { local_break(g); return rc; }
         return 0;
     }
     {
@@ -1341,13 +1357,14 @@ static int xr_tail(msdp_handle h) {
     LocalGroup* g = h->lgroup;
     Dev dv; int pl[3];
     int rc = msdp_xpersist_member(h, h->nranks, h->rank, g->xr_rows, g->xr_halo_max, &dv, pl);
-    if (!rc) rc = msdp_launch_tr_tail_xr(h->stream, dv, g->xr_slots, g->xr_err);
+    if (!rc) rc = msdp_launch_tr_tail_xr(h->stream, dv, g->xr_slots, dv.xr2_on ? xr2_err(h) : g->xr_err);
     if (rc) local_break(g);
     return rc;
 }
 static int xr_check(msdp_handle h) {
     int e = 0;
     HIPCHK(hipMemcpy(&e, h->lgroup->xr_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (!e && h->xr2_blk) HIPCHK(hipMemcpy(&e, xr2_err(h), sizeof(int), hipMemcpyDeviceToHost));    // (the two-level form's word lives in the member's own block)
     if (e) {
         msdp_set_error("cross-rank persistent tCG: a grid synchronisation timed out (a member's launch did not arrive or the workgroups were not co-resident)");
         local_break(h->lgroup);                              // the other members' host-side collectives fail at once instead of waiting for this one
@@ -1440,6 +1457,9 @@ static void local_leave(msdp_handle h) {
         // the arena belongs to rank 0 (the mappings of the others keep its memory alive until they close them)
         if (g->arena) { if (g->my_rank == 0) (void)hipFree(g->arena); else (void)hipIpcCloseMemHandle(g->arena); }
         for (int q = 0; q < g->n; ++q) if (g->xr_rows[q]) { if (q == g->my_rank) (void)hipFree(g->xr_rows[q]); else (void)hipIpcCloseMemHandle(g->xr_rows[q]); }
+        for (int q = 0; q < g->n; ++q) if (g->xr2_blk[q]) { if (q == g->my_rank) (void)hipFree(g->xr2_blk[q]); else (void)hipIpcCloseMemHandle(g->xr2_blk[q]); }
+        if (g->xr2_table) (void)hipFree(g->xr2_table);
+        h->xr2_blk = nullptr; h->xr2_peers = nullptr; h->lgroup_is_ipc = false;
         if (g->shm) (void)munmap((void*)g->shm, sizeof(IpcShared));
         if (g->my_rank == 0 && !g->shm_name.empty()) (void)shm_unlink(g->shm_name.c_str());
         delete g;
@@ -1898,6 +1918,53 @@ static int comm_init_ipc_attach(msdp_handle h, int32_t nranks, int32_t rank, uns
         g->xr_rows[q] = (double*)p;
     }
     g->xr_rows_doubles = rows_doubles;
+    // Round 6, the two-level reductions of msdp_psync.h (psync2): every member's own block -- its local slot regions, the member lines the
+    // others' leaders push into, its error word -- fine-grained memory of ITS device, exported like the exchange buffer; and where the
+    // members sit: the PCI bus ids tell how many share a device (their workgroups must be resident together) and whether any two own
+    // different ones (then the reductions are two-level and the pushed rows cross devices)
+    {
+        void* p = nullptr;
+        const size_t bb = msdp_xr2_block_bytes();
+        if (hipExtMallocWithFlags(&p, bb, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("comm_init_ipc: synchronisation block allocation failed"); return MSDP_ENOMEM; }
+        g->xr2_blk[rank] = (unsigned long long*)p;
+        int rc2 = msdp_xr2_reset(h->stream, g->xr2_blk[rank]);
+        if (rc2) return rc2;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        hipIpcMemHandle_t hd;
+        if (hipIpcGetMemHandle(&hd, p) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("comm_init_ipc: hipIpcGetMemHandle (synchronisation block) failed"); return MSDP_ECOMM; }
+        sh->blk_handle[rank] = hd;
+        int dev = 0;
+        char bus[32] = {0};
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof(bus), "device-%d", dev); }
+        memcpy(sh->devid[rank], bus, sizeof(bus));
+    }
+    LOCAL_BARRIER(g);                                        // every block is exported, every device id is in the segment
+    for (int q = 0; q < nranks; ++q) {
+        if (q == rank) continue;
+        void* p = nullptr;
+        hipIpcMemHandle_t hd = sh->blk_handle[q];
+        if (hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("comm_init_ipc: hipIpcOpenMemHandle (synchronisation block of rank %d) failed", q); return MSDP_ECOMM; }
+        g->xr2_blk[q] = (unsigned long long*)p;
+    }
+    {
+        if (hipMalloc((void**)&g->xr2_table, LOCAL_MAX_RANKS * sizeof(unsigned long long*)) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("comm_init_ipc: out of device memory"); return MSDP_ENOMEM; }
+        unsigned long long* tab[LOCAL_MAX_RANKS];
+        for (int q = 0; q < LOCAL_MAX_RANKS; ++q) tab[q] = g->xr2_blk[q < nranks ? q : rank];
+        HIPCHK(hipMemcpy(g->xr2_table, tab, sizeof(tab), hipMemcpyHostToDevice));
+        int share = 1;
+        bool multi = false;
+        for (int q = 0; q < nranks; ++q) {
+            int cnt = 0;
+            for (int t = 0; t < nranks; ++t) cnt += strncmp(sh->devid[q], sh->devid[t], sizeof(sh->devid[q])) == 0 ? 1 : 0;
+            share = std::max(share, cnt);
+            if (strncmp(sh->devid[q], sh->devid[rank], sizeof(sh->devid[q])) != 0) multi = true;
+        }
+        // (`multi` as every member sees it: true on all of them as soon as two devices are involved)
+        bool any_multi = false;
+        for (int q = 0; q < nranks; ++q) for (int t = 0; t < nranks; ++t) if (strncmp(sh->devid[q], sh->devid[t], sizeof(sh->devid[q])) != 0) any_multi = true;
+        (void)multi;
+        h->xr2_blk = g->xr2_blk[rank]; h->xr2_peers = g->xr2_table; h->xr2_share = share; h->xr2_multi = any_multi; h->lgroup_is_ipc = true;
+    }
     LOCAL_BARRIER(g);
     return 0;
 }

@@ -144,6 +144,12 @@ struct Dev {
     // (member, position there) pairs it has to be stored to as well ([2][n_loc], member -1 = none)
     const int* xr_ellc; const int* xr_colind; const int* xr_pq; const int* xr_pidx;
     const unsigned long long* xr_paddr;   // [2][n_loc] address of local row i's slot in the buffer of a member that references it (0: none); built by msdp_xpersist_member
+    // round 6, two-level grid reductions between members that own a device each (msdp_psync.h psync2): xr2_on, this member's block
+    // (fine-grained memory of its device), the members' blocks as this process maps them (device array of xr2_n pointers), this member's
+    // index among the xr2_n members; xr_sys: the pushed rows cross devices (system-scope stores)
+    int xr2_on, xr2_n, xr2_me, xr_sys, xr2_skip;   // (xr2_skip: test hook -- the leader waits for this many local workgroups that do not exist)
+    unsigned long long* xr2_blk;
+    unsigned long long* const* xr2_peers;
     int persist_slots;    // A/B: row slots of the persistent tCG plan at p = 17..32 (0: planned)
 };
 
@@ -193,6 +199,7 @@ struct Tuning {
     int persist_slots = 0;     // A/B: row slots per lane group of the persistent tCG at p = 17..32 (0: planned; 3 or 4)
     int persist_goff = 1;      // persistent tCG: the byte offsets of the R x EW gathers of a trip live in registers (0: recomputed per trip from the LDS copy of the column indices)
     int pipe_local = 1;        // one-reduction trip: neighbours that belong to the same workgroup are read from LDS, the diagonal from registers
+    int xr_twolevel = 0;       // process ranks: 1 = two-level grid reductions (msdp_psync.h psync2) also where the flat ones would do (one device, <= 4 members); A/B, tests
     int pipe_refresh = 16;     // one-reduction trip: trips between two direct exchanges (its recurrences drift with the square of this)
     int persist_pipe = 1;      // persistent tCG: ONE grid reduction per trip (msdp_pipe.h) where an instance exists (rows of <= 8 entries, p <= 32)
     int persist_early = 0;     // persistent tCG: the neighbours' rows are gathered while reduction 2 is in flight -- sentinel-initialised exchange
@@ -248,7 +255,11 @@ struct msdp_handle_s {
     // its rows of C reference (msdp_api.hip, "Halo exchange")
     struct Halo* halo = nullptr;
     struct LocalGroup* lgroup = nullptr;   // in-process stand-in for the RCCL communicator (msdp_comm_init_local)
-    unsigned long long* xr_paddr = nullptr; size_t xr_paddr_cap = 0; double* xr_paddr_key[4] = {nullptr, nullptr, nullptr, nullptr}; int xr_paddr_ld = 0, xr_paddr_n = 0; const int* xr_paddr_pq = nullptr;   // cross-rank push addresses and what they were built from
+    unsigned long long* xr_paddr = nullptr; size_t xr_paddr_cap = 0; double* xr_paddr_key[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int xr_paddr_ld = 0, xr_paddr_n = 0; const int* xr_paddr_pq = nullptr;   // cross-rank push addresses and what they were built from
+    bool lgroup_is_ipc = false;                  // the handle's group is a process group (msdp_comm_init_ipc)
+    unsigned long long* xr2_blk = nullptr;       // this member's two-level block (its own allocation), the members' blocks as mapped here (device array)
+    unsigned long long** xr2_peers = nullptr;
+    int xr2_share = 1; bool xr2_multi = false;   // process ranks (msdp_comm_init_ipc): the most members on one device, members on different devices
     bool xr_ok = false; int xr_halo_rows = 0;   // push exchange of the cross-rank kernels: usable (no row needed by more than two members), foreign rows referenced
     struct WinCache* win = nullptr;        // patch plans of the LDS-staged S*U (msdp_window.hip), one per lanes-per-row
     void* blk_ws = nullptr; size_t blk_ws_cap = 0;   // workspace of msdp_block_eigs (msdp_blockjacobi.hip)

@@ -56,7 +56,7 @@ __global__ void k_psync_reset(unsigned long long* slots, int* err) {
 // travel through the members' exchange buffers (d.xr_rows[q]: member q's rows, in q's own memory), and no collective is issued per trip.  Same
 // arithmetic per row as the one-rank kernel; the sums are formed over d.xr_gtot partials in index order on every rank (same bits on
 // every rank -> same decisions).  Two slot regions alternate with the TR iteration; each launch clears the other one at its start.
-template <int LPR, int EW, int R, bool FUSE, bool TRACE, bool XR, bool EARLYP>
+template <int LPR, int EW, int R, bool FUSE, bool TRACE, bool XR, bool EARLYP, bool XR2 = false>
 __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long long* slots, int* err, const int bx) {
     extern __shared__ double lds[];
     __shared__ double sh[3 * PWAVES];
@@ -86,14 +86,28 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         return;
     }
     if (lead && !FUSE) msdp_publish(d, k_tr, 0, 1);                // "TR iteration k_tr has started" (host pipelining)
-    const int bid = XR ? d.xr_gid0 + bx : bx;
-    const int GS = XR ? d.xr_gtot : d.G;                           // workgroups that synchronise
-    if (XR) {
+    // XR, two-level form (round 6, d.xr2_on: members that own a device each, up to 8): the reductions run over THIS member's workgroups
+    // in its own block and over the members' sums (psync2, msdp_psync.h) -- `slots` is not used, bid / GS are local
+    // (a template parameter: as a run-time flag the second form cost the flat <16, 5, 5> instance 16 scratch loads per trip, 10.6 -> 12.4 us)
+    constexpr bool two = XR && XR2;
+    __shared__ unsigned long long* shpeer[two ? 8 : 1];
+    const int bid = (XR && !two) ? d.xr_gid0 + bx : bx;
+    const int GS = (XR && !two) ? d.xr_gtot : d.G;                 // workgroups that synchronise
+    const int xri = k_tr & 1;                                      // two-level: the region of this launch
+    if (two) {
+        if (threadIdx.x < 8) shpeer[threadIdx.x] = threadIdx.x < d.xr2_n ? d.xr2_peers[threadIdx.x] : d.xr2_blk;
+        psync2_reset_other(d.xr2_blk, xri ^ 1, bid, GS);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (XR) {
         unsigned long long* other = slots + (size_t)((k_tr & 1) ^ 1) * PSYNC_REGION;
         slots += (size_t)(k_tr & 1) * PSYNC_REGION;
         psync_reset_other(other, bid, GS);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // performed before this workgroup's first post of this launch
     } else if (!FUSE) psync_reset_other(slots + PSYNC_REGION, bid, GS);     // region B belongs to the TR-iteration tail kernel
+    // the grid reduction / barrier of this launch, in whichever form
+#define XSYNC(nv, a, b, c, dr) (two ? psync2(d.xr2_blk, shpeer, d.xr2_n, d.xr2_me, xri, gen++, GS + d.xr2_skip, (nv), (a), (b), (c), sh, shb, err, bid, backoff, (dr)) \
+                                    : psync(slots, gen++, GS, (nv), (a), (b), (c), sh, shb, err, bid, backoff, (dr)))
+#define XBAR() (two ? xbar2() : pbarrier(slots, nbar++, GS, shb, err, bid))
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi, 0, bx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -215,6 +229,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     __syncthreads();
 
     unsigned gen = 0, nbar = 0;
+    auto xbar2 = [&]() { double z0 = 0.0, z1 = 0.0, z2 = 0.0; return psync2(d.xr2_blk, shpeer, d.xr2_n, d.xr2_me, xri, gen++, GS + d.xr2_skip, 0, z0, z1, z2, sh, shb, err, bid, backoff, false); };
     const unsigned xrow0 = 0u;                                     // (stores into the exchange buffer use local row numbers on every path)
     const unsigned xglob0 = 0u;                                    // (XR: the column indices are buffer-local, d.xr_ellc / d.xr_colind)
     const unsigned vec_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
@@ -240,8 +255,13 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             const unsigned long long a = pds[t * ROWS + SLOT(r)];
             if (a != 0ULL && OK(r)) {
                 double* ptr = reinterpret_cast<double*>(a) + 2 * sub;
-                __hip_atomic_store(ptr, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ptr + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (two) {                                         // the slot may live on another device: system scope
+                    __hip_atomic_store(ptr, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(ptr + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    __hip_atomic_store(ptr, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ptr + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     };
@@ -296,7 +316,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
 #pragma unroll
         for (int r = 0; r < R; ++r) { if (OK(r)) st2_sc1(rs_md, ((xrow0 + (unsigned)ROW(r)) * (unsigned)d.ld + 2 * sub) * 8u, MD_GET(r)); xr_push(r, MD_GET(r)); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!pbarrier(slots, nbar++, GS, shb, err, bid)) return;
+        if (!XBAR()) return;
     }
     bool first = true;
     bool have_early = false;         // EARLY: acc_e holds C*tangent(r') of my rows for the trip that starts
@@ -430,7 +450,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         // same half -- explicit, and free at this point (a wait behind reduction 1 would sit on that reduction's own slot-reset store)
         if (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TSTAMP(1);
-        if (!psync(slots, gen++, GS, 1, pd, u1, u2, sh, shb, err, bid, backoff)) { failed = true; break; }
+        if (!XSYNC(1, pd, u1, u2, false)) { failed = true; break; }
         TSTAMP(2);
         const double d_Hd = pd;                                                        // :166
         alpha = z_r / d_Hd;                                                            // :170
@@ -550,7 +570,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
             TSTAMP(3);
             // (TWOSYNC: my residual rows are performed before I post -- the wait sits inside psync, behind the wave sums)
             TSTAMP(4);
-            if (!psync(slots, gen++, GS, 3, s1, s2, s3, sh, shb, err, bid, backoff, TWOSYNC)) { failed = true; break; }
+            if (!XSYNC(3, s1, s2, s3, TWOSYNC)) { failed = true; break; }
             have_early = false;
             TSTAMP(5);
             // (EARLY instance, refresh trip: reduction 1 of this trip has returned -- the pending half can go back to the sentinel)
@@ -598,7 +618,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         }
         if (!TWOSYNC || refresh_now) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my rows are performed before my workgroup posts
-            if (!pbarrier(slots, nbar++, GS, shb, err, bid)) { failed = true; break; }
+            if (!XBAR()) { failed = true; break; }
             if (EARLY) { lastq = xq; pend = xq; xq ^= 1; }         // the direction rows sit in half lastq until the next trip has gathered them
         }
         direct = refresh_now;
@@ -711,9 +731,9 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     }
 }
 
-template <int LPR, int EW, int R, bool FUSE, bool TRACE = false, bool XR = false, bool EARLYP = false>
+template <int LPR, int EW, int R, bool FUSE, bool TRACE = false, bool XR = false, bool EARLYP = false, bool XR2 = false>
 __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long long* slots, int* err) {
-    tcg_persist_body<LPR, EW, R, FUSE, TRACE, XR, EARLYP>(d, slots, err, (int)blockIdx.x);
+    tcg_persist_body<LPR, EW, R, FUSE, TRACE, XR, EARLYP, XR2>(d, slots, err, (int)blockIdx.x);
 }
 // In-process ranks: ONE launch carries the workgroups of all members (member q owns the blocks [q*G, (q+1)*G)), so that their
 // co-residency does not depend on how the runtime maps the members' streams onto hardware queues (two launches on one queue
@@ -737,6 +757,8 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_xr4(XrDevs4 ds, unsigned lon
     }
 }
 
+#undef XSYNC
+#undef XBAR
 #undef VOFF
 #undef ETA_GET
 #undef ETA_SET
@@ -1060,14 +1082,29 @@ static xr4_fn xr4_kernel(int lpr, int ew, int r) {
 #undef XK
     return nullptr;
 }
+// two-level reductions (msdp_psync.h psync2): process ranks on different devices, or more than four of them, or on request (option
+// xr_twolevel); the in-process group (one launch for everybody) keeps the flat ones
+static bool xr_two_level(msdp_handle h, int nranks) {
+    return h->lgroup_is_ipc && (h->xr2_multi || nranks > 4 || h->tune.xr_twolevel);
+}
 static bool xr_plan(msdp_handle h, int nranks, PersistPlan& pl, int* G_out) {
     const Dev& d = h->d;
     if (!h->tune.persist || !h->tune.xpersist || h->persist_failed || d.costkind != COST_SPARSE || d.manifold != MANI_OBLIQUE || d.rowfree) return false;
     if (!h->xr_ok || !d.xr_colind || !d.xr_pq) return false;     // a row referenced by more than two other members: lock-step trips
-    int G = (256 / nranks) & ~7;
-    if (G < 8 || nranks < 2 || nranks > 4) return false;
+    const bool two = xr_two_level(h, nranks);
+    if (nranks < 2 || nranks > (two ? 8 : 4)) return false;
     Dev dc = d;
     dc.n_loc = (d.n + nranks - 1) / nranks;                // the plan of the rank with the most rows
+    int G;
+    if (two) {
+        // every member synchronises over ITS OWN grid: a whole device's when it owns one (the one-rank grid for its rows), a share of
+        // the 256 workgroups when several members sit on one device (the single-GPU tests: 8 processes x 32 workgroups)
+        const int share = h->xr2_share > 0 ? h->xr2_share : 1;
+        G = persist_grid(dc);
+        const int gcap = (256 / share) & ~7;
+        if (G > gcap) G = gcap;
+    } else G = (256 / nranks) & ~7;
+    if (G < 8) return false;
     if (!persist_plan(dc, G, pl)) return false;
     if (pl.r > 5) return false;                            // LOWREG instances are not built for XR
     if (pl.ew == 8) pl.ew = 0;                             // rows of 6..8 entries: the CSR form
@@ -1084,7 +1121,9 @@ int msdp_xpersist_eligible(msdp_handle h, int nranks) {
     if (!xr_plan(h, nranks, pl, &G)) return 0;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return cus >= G * nranks ? 1 : 0;
+    // every workgroup of the members that share this device must be resident at once
+    const int here = xr_two_level(h, nranks) ? (h->xr2_share > 0 ? h->xr2_share : 1) : nranks;
+    return cus >= G * here ? 1 : 0;
 }
 // Bytes of the shared synchronisation block: two slot regions (they alternate with the TR iteration)
 size_t msdp_xpersist_slot_bytes() { return 4 * PSYNC_REGION * sizeof(unsigned long long); }   // tCG: regions 0 / 1, cross-rank TR tail: 2 / 3
@@ -1096,24 +1135,33 @@ int msdp_xpersist_reset(hipStream_t stream, unsigned long long* slots, int* err)
 }
 // This member's Dev for the combined launch and its plan {lanes per row, ELL width (0: CSR), row slots}
 // slot addresses of the push exchange: row i of this member -> &rows[q][(position there) * ld] for each member q that references it
-__global__ void k_xr_paddr(const int* __restrict__ pq, const int* __restrict__ pidx, double* r0, double* r1, double* r2, double* r3, int ld, int n_loc,
+struct XrRows8 { double* r[8]; };
+__global__ void k_xr_paddr(const int* __restrict__ pq, const int* __restrict__ pidx, XrRows8 rows, int ld, int n_loc,
                            unsigned long long* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * n_loc) return;
     const int q = pq[i];
-    double* base = q == 1 ? r1 : q == 2 ? r2 : q == 3 ? r3 : r0;
+    double* base = rows.r[0];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) if (q == t) base = rows.r[t];
     out[i] = q < 0 ? 0ULL : (unsigned long long)(base + (int64_t)pidx[i] * ld);
 }
 int msdp_xpersist_member(msdp_handle h, int nranks, int rank, double* const* rows, int halo_rows, Dev* out, int* plan3) {
     PersistPlan pl; int G = 0;
     if (!xr_plan(h, nranks, pl, &G)) { msdp_set_error("cross-rank persistent tCG: not eligible"); return MSDP_ESTATE; }
+    const bool two = xr_two_level(h, nranks);
     *out = h->d;
-    out->G = G; out->xr_gid0 = rank * G; out->xr_gtot = nranks * G; out->status = nullptr; out->trace = nullptr;
-    for (int q = 0; q < 4; ++q) out->xr_rows[q] = rows[q < nranks ? q : rank];
-    out->xr_cap = (h->d.n + nranks - 1) / nranks; out->xr_me = rank; out->xr_halo = halo_rows;
+    out->G = G; out->xr_gid0 = two ? 0 : rank * G; out->xr_gtot = two ? G : nranks * G; out->status = nullptr; out->trace = nullptr;
+    // (the kernels address this member's own buffer only -- the others' slots through the push addresses below)
+    for (int q = 0; q < 4; ++q) out->xr_rows[q] = rows[rank];
+    out->xr_cap = (h->d.n + nranks - 1) / nranks; out->xr_me = 0; out->xr_halo = halo_rows;
+    out->xr2_on = two ? 1 : 0; out->xr2_n = nranks; out->xr2_me = rank; out->xr2_skip = 0;
+    out->xr_sys = h->xr2_multi ? 1 : 0;
+    out->xr2_blk = h->xr2_blk; out->xr2_peers = h->xr2_peers;
+    if (two && (!h->xr2_blk || !h->xr2_peers)) { msdp_set_error("cross-rank persistent tCG: the two-level blocks are missing"); return MSDP_ESTATE; }
     {   // the push addresses follow the members' buffers, the leading dimension and the partition
         bool same = h->xr_paddr && h->xr_paddr_ld == h->d.ld && h->xr_paddr_n == h->d.n_loc && h->xr_paddr_pq == h->d.xr_pq;
-        for (int q = 0; q < 4; ++q) same = same && h->xr_paddr_key[q] == out->xr_rows[q];
+        for (int q = 0; q < 8; ++q) same = same && h->xr_paddr_key[q] == rows[q < nranks ? q : rank];
         if (!same) {
             const size_t need = (size_t)2 * (size_t)h->d.n_loc;
             if (h->xr_paddr_cap < need) {
@@ -1122,10 +1170,12 @@ int msdp_xpersist_member(msdp_handle h, int nranks, int rank, double* const* row
                 if (hipMalloc(&h->xr_paddr, need * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("cross-rank persistent tCG: out of device memory"); return MSDP_ENOMEM; }
                 h->xr_paddr_cap = need;
             }
+            XrRows8 r8;
+            for (int q = 0; q < 8; ++q) r8.r[q] = rows[q < nranks ? q : rank];
             if (need) hipLaunchKernelGGL(k_xr_paddr, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, h->stream, h->d.xr_pq, h->d.xr_pidx,
-                                         out->xr_rows[0], out->xr_rows[1], out->xr_rows[2], out->xr_rows[3], h->d.ld, h->d.n_loc, h->xr_paddr);
+                                         r8, h->d.ld, h->d.n_loc, h->xr_paddr);
             if (hipGetLastError() != hipSuccess) { msdp_set_error("cross-rank persistent tCG: launch failed"); return MSDP_EHIP; }
-            for (int q = 0; q < 4; ++q) h->xr_paddr_key[q] = out->xr_rows[q];
+            for (int q = 0; q < 8; ++q) h->xr_paddr_key[q] = r8.r[q];
             h->xr_paddr_ld = h->d.ld; h->xr_paddr_n = h->d.n_loc; h->xr_paddr_pq = h->d.xr_pq;
         }
         out->xr_paddr = h->xr_paddr;
@@ -1133,12 +1183,27 @@ int msdp_xpersist_member(msdp_handle h, int nranks, int rank, double* const* row
     plan3[0] = pl.lpr; plan3[1] = pl.ew; plan3[2] = pl.r;
     return 0;
 }
+// this member's two-level block back to its start state (every slot and member line the sentinel, the error word clear)
+__global__ void k_xr2_reset(unsigned long long* blk) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < XR2_ERR_OFF; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = i % XR2_REGION;
+        blk[i] = (o >= PSYNC_CNT_OFF && o < PSYNC_REGION) ? 0ULL : PSYNC_SENT;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) blk[XR2_ERR_OFF + threadIdx.x] = 0ULL;
+}
+size_t msdp_xr2_block_bytes() { return XR2_BLOCK_U64 * sizeof(unsigned long long); }
+size_t msdp_xr2_err_offset() { return XR2_ERR_OFF * sizeof(unsigned long long); }
+int msdp_xr2_reset(hipStream_t stream, unsigned long long* blk) {
+    hipLaunchKernelGGL(k_xr2_reset, dim3(64), dim3(256), 0, stream, blk);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 // Members in different processes (msdp_comm_init_ipc): every member launches its own G workgroups -- the same body, the same protocol;
 // the launches of different processes run side by side (tools/ipc_probe.hip: a barrier across two such launches costs 1.75 us).
 int msdp_launch_tcg_xpersist_one(hipStream_t stream, const Dev& dv, const int* plan, unsigned long long* slots, int* err) {
     const int lpr = plan[0], ew = plan[1], r = plan[2];
     persist_fn fn = nullptr;
-#define XK(L, E, RR) if (lpr == L && ew == E && r == RR) fn = k_tcg_persist_obl<L, E, RR, false, false, true>;
+#define XK(L, E, RR) if (lpr == L && ew == E && r == RR) fn = dv.xr2_on ? k_tcg_persist_obl<L, E, RR, false, false, true, false, true> : k_tcg_persist_obl<L, E, RR, false, false, true>;
     XK(8, 5, 2) XK(8, 0, 2) XK(8, 5, 4) XK(8, 0, 4) XK(16, 5, 3) XK(16, 0, 3) XK(16, 5, 5) XK(16, 0, 5) XK(32, 5, 5) XK(32, 0, 5)
 #undef XK
     if (!fn) { msdp_set_error("cross-rank persistent tCG: no kernel instance"); return MSDP_ESTATE; }

@@ -12,6 +12,8 @@
 #define PSYNC_REP 8
 #endif
 #define PSYNC_CNT_OFF ((size_t)PSYNC_GEN * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID)   // counters behind the slots, 64 B apart
+// One region = the slots of psync (3 generations x 8 replicas x PSYNC_NV values x MSDP_MAX_GRID) + 8 barrier counters.
+#define PSYNC_REGION (PSYNC_CNT_OFF + 64)
 #define PSYNC_SENT 0xFFF8DEADBEEF0001ULL  // NaN payload no arithmetic produces
 #define PSYNC_SPIN_LIMIT (1 << 22)
 // 512 threads per workgroup, one workgroup per CU: 2 waves per SIMD, i.e. a 256-register budget per lane
@@ -232,6 +234,138 @@ __device__ __forceinline__ bool psync_finish3(unsigned long long* slots, unsigne
     return msdp_readlane(shb[7], 0) == 0.0;
 }
 
+// ---- Two-level reduction across MEMBERS that own a device each (round 6, the N-GPU form of the cross-rank kernels; N <= 8).
+// The flat protocol above lets every workgroup of every member poll one slot region: fine on one device, but between devices every poll
+// would cross xGMI and N x G workgroups would have to fit 256 slots.  Here a member reduces over ITS OWN grid in ITS OWN memory and only
+// eight sums per member travel:
+//   level 1   every workgroup posts its partials into the member's local slot array (one replica: only the leader polls it);
+//             the member's LEADER workgroup (local index 0) polls the G local slots -- wave w takes value array w, the order of psync() --
+//             and stores the member's sum of value w into line `me` of generation gen in EVERY member's block (its own included):
+//             N stores of 8 bytes per value over the peer mappings, system scope;
+//   level 2   wave 0 of EVERY workgroup of every member polls the N lines of its OWN block (local memory: one 8-byte load per lane,
+//             lane = 8 member + value) until none holds the sentinel and adds the members' sums in one fixed order -- the same lanes,
+//             the same instructions on every member: the same bits, the same decisions everywhere.
+// Block of a member (fine-grained memory of its device, mapped by the others): XR2_REGIONS regions (tCG 0 / 1, TR tail 2 / 3, alternating
+// with the TR iteration like the flat regions), each [the slots of psync (PSYNC_CNT_OFF + 64)] [PSYNC_GEN x 8 members x 8 values] [pad];
+// behind them the error word.  Generations rotate as above: a workgroup puts its local slots of generation gen - 1 back to the sentinel
+// when it has passed gen, the leader does the same for the member lines in its own block (at that point every workgroup of every
+// member has posted gen, i.e. finished reading gen - 1; the next writes into those lines are the pushes of gen + 2, which a peer's leader
+// issues only after it has passed gen + 1 -- behind this member's push of gen + 1, in front of which the reset store was waited for).
+// nv = 0: a barrier (one dummy value).  peers[q] = member q's block as THIS process maps it (the caller keeps the N pointers in LDS).
+#define XR2_LINES (PSYNC_GEN * 8 * 8)
+#define XR2_REGION (PSYNC_REGION + XR2_LINES + 64)
+#define XR2_REGIONS 4
+#define XR2_ERR_OFF ((size_t)XR2_REGIONS * XR2_REGION)            // (u64 units) the member's error word
+#define XR2_BLOCK_U64 (XR2_ERR_OFF + 64)
+#define MSDP_CPOL_SYS 17                                          // sc0 | sc1: system scope
+__device__ __forceinline__ unsigned long long ld_u64_sys(const unsigned long long* p) {
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void xr2_fail(unsigned long long* blk, unsigned long long* const* peers, int N, int* err) {   // (peers: the table in LDS)
+    // this member's error word, and every peer's: their bounded spins look at it every 1024 polls and give up at once
+    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int lane = threadIdx.x & 63;
+    if (lane < N) __hip_atomic_store(reinterpret_cast<int*>(peers[lane] + XR2_ERR_OFF), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool psync2(unsigned long long* blk, unsigned long long* const* peers, int N, int me, int ri, unsigned gen, int G, int nv,
+                                       double& a, double& b, double& c, double* sh, double* shb, int* err, int bid, int backoff, bool drain = false) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nvp = nv > 0 ? nv : 1;
+    if (nv > 1) psync_wave3(a, b, c, sh);
+    else if (nv == 1) { a = msdp_wave_sum(a); if (lane == 0) sh[w] = a; }
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned long long* ls = blk + (size_t)ri * XR2_REGION;
+    unsigned long long* ml = ls + PSYNC_REGION;
+    unsigned long long* gbase = ls + (size_t)(gen % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID;   // replica 0
+    if (w == 0 && lane < nvp) {
+        double s = 0.0;
+        if (nv > 0) for (int i = 0; i < PWAVES; ++i) s += sh[lane * PWAVES + i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the reset store of this slot's other generations has been performed
+        __hip_atomic_store(gbase + (size_t)lane * MSDP_MAX_GRID + bid, (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool fail = false;
+    if (bid == 0 && w < nvp) {
+        // the member's leader: value array w of the local slots, summed in the order of psync(); the sum goes to every member's block
+        const unsigned long long* p0 = gbase + (size_t)w * MSDP_MAX_GRID + lane;
+        double r0 = 0.0;
+        int spins = 0;
+        for (;;) {
+            unsigned long long b0[4];
+            asm volatile(
+                "global_load_dwordx2 %0, %4, off sc1\n\t"
+                "global_load_dwordx2 %1, %4, off offset:512 sc1\n\t"
+                "global_load_dwordx2 %2, %4, off offset:1024 sc1\n\t"
+                "global_load_dwordx2 %3, %4, off offset:1536 sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3])
+                : "v"(p0)
+                : "memory");
+            bool ok = true;
+            double t0 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (lane + 64 * q < G) {
+                    ok = ok && b0[q] != PSYNC_SENT;
+                    t0 += __longlong_as_double((long long)b0[q]);
+                }
+            }
+            r0 = t0;
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ULL) break;
+            ++spins;
+            if (spins > PSYNC_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
+        }
+        r0 = msdp_wave_sum(r0);
+        if (!fail && lane < N)
+            __hip_atomic_store(peers[lane] + (size_t)ri * XR2_REGION + PSYNC_REGION + ((size_t)(gen % PSYNC_GEN) * 8 + me) * 8 + w,
+                               (unsigned long long)__double_as_longlong(r0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (fail) xr2_fail(blk, peers, N, err);
+    }
+    if (w == 0) {
+        // everybody: the N member lines of this generation in my own block
+        const unsigned long long* p = ml + (size_t)(gen % PSYNC_GEN) * 64 + lane;
+        const bool need = (lane >> 3) < N && (lane & 7) < nvp;
+        const int first = bid == 0 ? 0 : (backoff & 0xff);          // (the leader comes from its level-1 poll: nothing to sleep for)
+        for (int q = 0; q < first; ++q) __builtin_amdgcn_s_sleep(1);
+        unsigned long long x = 0ULL;
+        int spins = 0;
+        for (;;) {
+            x = ld_u64_sys(p);
+            if (__builtin_amdgcn_ballot_w64(need && x == PSYNC_SENT) == 0ULL) break;
+            ++spins;
+            if (spins > PSYNC_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
+            for (int q = 0; q < ((backoff >> 8) & 0xff); ++q) __builtin_amdgcn_s_sleep(1);
+        }
+        // value v = the sum over the members, lanes v, v + 8, ..., v + 56: one fixed butterfly, the same on every member
+        double t = need ? __longlong_as_double((long long)x) : 0.0;
+        t += msdp_dpp<0x128>(t);                                   // row_ror:8 = lane ^ 8 inside a row of 16
+        t = msdp_rowpair_sum<16>(t);
+        t = msdp_rowpair_sum<32>(t);
+        if (lane < 3) shb[lane] = nv > lane ? t : 0.0;
+        if (lane == 0) { shb[4] = fail ? 1.0 : 0.0; if (bid != 0 || nvp < 2) shb[5] = 0.0; if (bid != 0 || nvp < 3) shb[6] = 0.0; }
+        if (fail) xr2_fail(blk, peers, N, err);
+        // my local slots of the previous generation back to the sentinel; the leader: the member lines of it in this member's block
+        if (lane < PSYNC_NV)
+            __hip_atomic_store(ls + (size_t)((gen + PSYNC_GEN - 1) % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID + (size_t)lane * MSDP_MAX_GRID + bid,
+                               PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bid == 0)
+            __hip_atomic_store(ml + (size_t)((gen + PSYNC_GEN - 1) % PSYNC_GEN) * 64 + lane, PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (bid == 0 && w < nvp && lane == 0) shb[4 + w] = fail ? 1.0 : 0.0;     // (the leader's other polling waves)
+    __syncthreads();
+    a = msdp_readlane(shb[0], 0); b = msdp_readlane(shb[1], 0); c = msdp_readlane(shb[2], 0);
+    return msdp_readlane(shb[4], 0) + msdp_readlane(shb[5], 0) + msdp_readlane(shb[6], 0) == 0.0;
+}
+// the member's OTHER region (the one the next launch of the alternating pair will use): local slots by all workgroups, the member lines by
+// the leader -- performed before this launch ends, long before a peer's push into them can arrive (a peer reaches the launch that uses
+// this region only through a reduction this member takes part in first)
+__device__ __forceinline__ void psync2_reset_other(unsigned long long* blk, int ri_other, int bid, int G) {
+    unsigned long long* ls = blk + (size_t)ri_other * XR2_REGION;
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < PSYNC_CNT_OFF; i += (size_t)G * blockDim.x) ls[i] = PSYNC_SENT;
+    if (bid == 0 && threadIdx.x < XR2_LINES) ls[PSYNC_REGION + threadIdx.x] = PSYNC_SENT;
+}
+
 // Barrier without a value (the new direction rows are in place): workgroup b adds to counter b & 7, everybody
 // polls the 8 counters (64 B apart).  nbar = number of barriers passed before this one.  G is a multiple of 8.
 __device__ __forceinline__ bool pbarrier(unsigned long long* slots, unsigned nbar, int G, double* shb, int* err, int bid_in = -1) {
@@ -260,8 +394,6 @@ __device__ __forceinline__ bool pbarrier(unsigned long long* slots, unsigned nba
     return shb[3] == 0.0;
 }
 
-// One region = the slots of psync (3 generations x 8 replicas x PSYNC_NV values x MSDP_MAX_GRID) + 8 barrier counters.
-#define PSYNC_REGION (PSYNC_CNT_OFF + 64)
 
 // Two kernels alternate on a stream (persistent tCG, TR-iteration tail), each with its own region; a kernel may
 // not reset its own region while its workgroups poll it, so each one resets the OTHER kernel's region at its start:

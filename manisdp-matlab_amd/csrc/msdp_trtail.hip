@@ -18,7 +18,7 @@
 // tCG does not touch them between its last reduction and its next launch), the barrier and the reduction run over the N x G slots of a slot
 // region of the group (regions 2 and 3 of the shared block, alternating with the TR iteration; every launch clears the other one),
 // and every member takes the decision of trustregions.m:548-729 from the same sums in the same order -- no collective.
-template <int LPR, bool XR = false>
+template <int LPR, bool XR = false, bool XR2 = false>
 __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* slots, int* err, int rcap) {
     extern __shared__ double lds[];
     __shared__ double sh[3 * PWAVES];
@@ -28,10 +28,18 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
     double2* YPs = reinterpret_cast<double2*>(lds);            // [rcap][PB] proposal rows of this workgroup
     Ctl* c = d.ctl;
     if (c->done) return;
-    const int bid = XR ? d.xr_gid0 + (int)blockIdx.x : (int)blockIdx.x;
-    const int GS = XR ? d.xr_gtot : d.G;
-    unsigned long long* sb;
-    if (XR) {
+    // two-level form (round 6, d.xr2_on: members on devices of their own, up to 8; msdp_psync.h psync2): regions 2 / 3 of the member's block
+    constexpr bool two = XR && XR2;
+    __shared__ unsigned long long* shpeer[two ? 8 : 1];
+    const int bid = (XR && !two) ? d.xr_gid0 + (int)blockIdx.x : (int)blockIdx.x;
+    const int GS = (XR && !two) ? d.xr_gtot : d.G;
+    const int xri = 2 + (c->k & 1);
+    unsigned long long* sb = slots;
+    if (two) {
+        if (threadIdx.x < 8) shpeer[threadIdx.x] = threadIdx.x < d.xr2_n ? d.xr2_peers[threadIdx.x] : d.xr2_blk;
+        psync2_reset_other(d.xr2_blk, 2 + ((c->k & 1) ^ 1), bid, GS);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (XR) {
         sb = slots + (size_t)(2 + (c->k & 1)) * PSYNC_REGION;
         psync_reset_other(slots + (size_t)(2 + ((c->k & 1) ^ 1)) * PSYNC_REGION, bid, GS);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -66,8 +74,13 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
             const unsigned long long a = ok ? d.xr_paddr[(int64_t)t * d.n_loc + row] : 0ULL;
             if (a == 0ULL) continue;
             double* ptr = reinterpret_cast<double*>(a) + 2 * sub;
-            __hip_atomic_store(ptr, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ptr + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (two) {                                             // the slot may live on another device: system scope
+                __hip_atomic_store(ptr, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(ptr + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                __hip_atomic_store(ptr, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ptr + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     };
     double* __restrict__ Ypl = cur ? d.Y[0] : d.Y[1];          // XR: the member's own copy of its proposal rows
@@ -104,7 +117,11 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my proposal rows are performed before my workgroup arrives
-    if (!pbarrier(sb, 0, GS, shb, err, bid)) return;
+    const int backoff = d.ctl->psync_backoff;
+    if (two) {
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+        if (!psync2(d.xr2_blk, shpeer, d.xr2_n, d.xr2_me, xri, 0, GS, 0, z0, z1, z2, sh, shb, err, bid, backoff)) return;
+    } else if (!pbarrier(sb, 0, GS, shb, err, bid)) return;
     for (int r0 = 0; r0 < R; r0 += RMAX) {
         int s0[RMAX], s1[RMAX];
         double2 acc[RMAX];
@@ -182,7 +199,8 @@ __global__ __launch_bounds__(PB) void k_tr_tail_obl(Dev d, unsigned long long* s
             if (sub == 0 && rok) { pf += 0.5 * dot; eGp[row] = dot; }
         }
     }
-    if (!psync(sb, 0, GS, 3, pf, pgg, prd, sh, shb, err, bid, d.ctl->psync_backoff)) return;
+    if (two) { if (!psync2(d.xr2_blk, shpeer, d.xr2_n, d.xr2_me, xri, 1, GS, 3, pf, pgg, prd, sh, shb, err, bid, backoff)) return; }
+    else if (!psync(sb, 0, GS, 3, pf, pgg, prd, sh, shb, err, bid, backoff)) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) {                 // trustregions.m:548-729 (same arithmetic as k_rtr_decide)
         const int f_stop = d.F[0].stop, f_j = d.F[0].j;
         const double fp = pf, ggp = pgg;
@@ -260,8 +278,9 @@ int msdp_launch_tr_tail_xr(hipStream_t stream, const Dev& dv, unsigned long long
     if (lds > 128 * 1024) { msdp_set_error("cross-rank TR tail: %d row slots do not fit the LDS", rcap); return MSDP_ESTATE; }
     typedef void (*fn_t)(Dev, unsigned long long*, int*, int);
     fn_t fn = lpr == 8 ? k_tr_tail_obl<8, true> : (lpr == 16 ? k_tr_tail_obl<16, true> : k_tr_tail_obl<32, true>);
-    static bool attr_set[3] = {false, false, false};
-    const int ai = lpr == 8 ? 0 : (lpr == 16 ? 1 : 2);
+    if (dv.xr2_on) fn = lpr == 8 ? k_tr_tail_obl<8, true, true> : (lpr == 16 ? k_tr_tail_obl<16, true, true> : k_tr_tail_obl<32, true, true>);
+    static bool attr_set[6] = {false, false, false, false, false, false};
+    const int ai = (lpr == 8 ? 0 : (lpr == 16 ? 1 : 2)) + (dv.xr2_on ? 3 : 0);
     if (!attr_set[ai]) {
         HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set[ai] = true;

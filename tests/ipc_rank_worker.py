@@ -23,6 +23,8 @@ def main():
     short = _lib.default_opts(maxiter=10, maxinner=7, tolgradnorm=1e-9)
     h = _lib.Handle.onlyunitdiag(C, pcap=p)
     h.comm_init_ipc(N, rank, name)
+    if os.environ.get("MSDP_TEST_XR_TWOLEVEL"):                    # the two-level grid reductions also where the flat ones would do
+        h.set_option("xr_twolevel", 1)
     h.set_point(Y0)
     f0, G0 = h.cost(), h.rgrad()                                   # sharded operators through the staging slabs
     c0 = h.collective_calls()
