@@ -56,15 +56,29 @@ def secondary_roofline(kernel, us, algo_bytes, algo_flops, pmc_names=(), bound=N
             rec, src = json.load(open(f)), "profiles/" + name
             break
     traffic = None if rec is None else rec.get("hbm_bytes_per_hessvec", rec.get("hbm_bytes_per_launch"))
+    # (a summary carries the hash of the kernel sources it was measured on; one that does not, or whose sources changed since, is marked)
+    stale = None if rec is None else (not rec.get("sources_sha16") or rec["sources_sha16"] != sources_sha16(rec.get("sources", [])))
     if bound == "mfma":
         achieved, peak, unit = algo_flops / (us * 1e-6) / 1e12, MFMA_F64_PEAK_TFLOPS, "TFLOP/s"
     else:
         achieved, peak, unit = algo_bytes / (us * 1e-6) / 1e9, HBM_PEAK_GBS, "GB/s"
     return {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": traffic,
-            "traffic_source": src, "algorithmic_bytes": algo_bytes, "algorithmic_flops": algo_flops, "kernel": kernel,
+            "traffic_source": src, "traffic_stale": stale, "algorithmic_bytes": algo_bytes, "algorithmic_flops": algo_flops, "kernel": kernel,
             "kernel_us": us, "per": per,
             "frac_hbm_peak": algo_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "frac_mfma_f64_peak": algo_flops / (us * 1e-6) / 1e12 / MFMA_F64_PEAK_TFLOPS}
+
+
+def sources_sha16(files):
+    """Hash of the named source files (paths relative to the repository) -- what a committed counter summary was measured on."""
+    import hashlib
+    hh = hashlib.sha256()
+    for f in files:
+        try:
+            hh.update(open(os.path.join(ROOT, f), "rb").read())
+        except OSError:
+            return None
+    return hh.hexdigest()[:16] if files else None
 
 
 def cpu_baseline(C, Y0, budget_s=15.0):
@@ -179,7 +193,7 @@ def affine_shapes(_lib, problems, with_cpu):
                    "roofline": secondary_roofline(
                        ("affine Hess-vec chain (Gram matrix -> B route A'(A(.)) -> two-matrix contraction -> epilogue)" if name == "bqp60" else
                         "affine Hess-vec chain (contraction with the SDDMM as a side job -> fused sparse A'(w)*Y + sphere epilogue)"), ms * 1e3, aby, afl,
-                       ("r4_pmc_%s_p32.json" % name, "r3_pmc_%s_p32.json" % name))}
+                       ("r6_pmc_%s_p32.json" % name, "r4_pmc_%s_p32.json" % name, "r3_pmc_%s_p32.json" % name))}
             if with_cpu:
                 from oracle import manisdp_ref
                 U = rng.standard_normal((n, p))
@@ -246,9 +260,10 @@ def cross_rank_trip(_lib, problems, N=2, p=32):
 def process_rank_worker(argv):
     """bench.py --ipc-worker rank N name p out.json: one member of a group of PROCESSES sharing the GPU (msdp_comm_init_ipc)."""
     rank, N, name, p, out = int(argv[0]), int(argv[1]), argv[2], int(argv[3]), argv[4]
+    grid_rows = int(argv[5]) if len(argv) > 5 else 100            # grid rows of 200 vertices per rank
     from manisdp_matlab_amd import _lib, problems
     _lib.load()
-    C = problems.toroidal_grid_maxcut(100 * N, 200, seed=81)
+    C = problems.toroidal_grid_maxcut(grid_rows * N, 200, seed=81)
     n = C.shape[0]
     rng = np.random.default_rng(0)
     Y = rng.standard_normal((n, p)); Y /= np.linalg.norm(Y, axis=1, keepdims=True)
@@ -283,7 +298,7 @@ def process_rank_worker(argv):
     h.close()
 
 
-def process_rank_trip(N=2, p=32):
+def process_rank_trip(N=2, p=32, grid_rows=100):
     """N PROCESSES on ONE GPU (msdp_comm_init_ipc), 20 000 rows each: the group's slot regions live in one fine-grained device
     block of rank 0, every member's exchange buffer (its rows + a slot per foreign row it references) in its own memory, all
     exported / mapped through HIP IPC (the mapping goes over peer access when the ranks own different devices: the same code
@@ -299,7 +314,7 @@ def process_rank_trip(N=2, p=32):
         for r in range(N):
             log = open(os.path.join(tmp, "r%d.err" % r), "w")
             logs.append(log)
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--ipc-worker", str(r), str(N), name, str(p), os.path.join(tmp, "r%d.json" % r)],
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--ipc-worker", str(r), str(N), name, str(p), os.path.join(tmp, "r%d.json" % r), str(grid_rows)],
                                           stdout=subprocess.DEVNULL, stderr=log))
         for pr in procs:
             try:
@@ -325,7 +340,7 @@ def process_rank_trip(N=2, p=32):
         except OSError:
             pass
     hv, sec, sec_c = res[0]["hessvecs"], max(q["rtr_seconds"] for q in res), max(q["rtr_seconds_with_per_iteration_collectives"] for q in res)
-    return {"workload": "toroidal grid MaxCut, %d process ranks x 20000 rows on one GPU (HIP IPC), p = %d" % (N, p), "ranks": N, "p": p,
+    return {"workload": "toroidal grid MaxCut, %d process ranks x %d rows on one GPU (HIP IPC), p = %d" % (N, 200 * grid_rows, p), "ranks": N, "p": p,
             "trip_us_cross_rank_persistent": max(q["trip_us"] for q in res), "tcg_path": res[0]["tcg_path"],
             "trustregions_us_per_hessvec": sec * 1e6 / hv, "hessvec_per_s": hv / sec, "hessvecs": hv, "tr_iterations": res[0]["iters"],
             "collective_calls_per_trustregions_call": res[0]["collective_calls_per_rtr_call"],
@@ -476,10 +491,12 @@ def main():
     t0 = time.perf_counter()
     hv = 0
     rtr_s = 0.0
+    dev_ms = []                                     # the step's device time by HIP events on the library's stream (msdp_debug_last_rtr_device_ms)
     for _ in range(args.steps):
         st = step()
         hv += st.hessvecs
         rtr_s += st.seconds
+        dev_ms.append(h.last_rtr_device_ms())
     sync()
     dt = time.perf_counter() - t0
     if N > 1:
@@ -514,50 +531,71 @@ def main():
     streaming_trip_bytes = abytes + 10.0 * n * p * 8
 
     def pmc(*names):
+        """A committed rocprofv3 --pmc summary (profiles/), with a mark when the kernel's sources changed after it was taken: a summary
+        carries the hash of the sources it was measured on (tools/pmc_to_json.py --sources); one without is of unknown generation."""
         for name in names:
             f = os.path.join(ROOT, "profiles", name)
             if N == 1 and p == 32 and os.path.exists(f):
                 rec = json.load(open(f))
                 rec["_source"] = "profiles/" + name
+                rec["_stale"] = not rec.get("sources_sha16") or rec["sources_sha16"] != sources_sha16(rec.get("sources", []))
                 return rec
         return None
     # HBM traffic comes from rocprofv3 --pmc passes (their own runs: counters cannot be collected inside a timed run);
     # the line carries the committed summary's value together with the file it was read from
-    pm_h = pmc("r4_pmc_hess_g81_p32.json", "r3_pmc_hess_g81_p32.json", "r2_pmc_hess_g81_p32.json", "r1_pmc_hess_g81_p32.json")
-    pm_t = (pmc("r5_pmc_pipe_g81_p32.json") if one_reduction else
-            pmc("r5_pmc_persist_g81_p32.json", "r4_pmc_persist_g81_p32.json", "r3_pmc_persist_g81_p32.json", "r2_pmc_persist_g81_p32.json", "r1_pmc_persist_g81_p32.json"))
+    pm_h = pmc("r6_pmc_hess_g81_p32.json", "r4_pmc_hess_g81_p32.json", "r3_pmc_hess_g81_p32.json")
+    pm_t = pmc("r6_pmc_pipe_g81_p32.json", "r5_pmc_pipe_g81_p32.json") if one_reduction else pmc("r6_pmc_persist_g81_p32.json", "r5_pmc_persist_g81_p32.json")
+    pm_f = pmc("r6_pmc_fused_g81_p32.json")
     if persistent:
-        traffic = (pm_t or {}).get("hbm_bytes_per_trip")
-        roofline = {"bound": "hbm", "achieved": trip_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": trip_achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": (pm_t or {}).get("_source"),
-                    "traffic_note": "replayed from the committed rocprofv3 --pmc summary of the same kernel and workload, not "
-                                    "measured in this run",
-                    "kernel": "k_tcg_pipe_obl" if one_reduction else "k_tcg_persist_obl", "kernel_us": trip_ms * 1e3, "per": "tCG trip (one Hess-vec)",
-                    "algorithmic_bytes_per_launch": abytes,
+        # The DOMINANT kernel of the timed step: on the fused path ONE launch of k_tcg_pipe_obl<.., FUSE> runs the whole trustregions() call
+        # (every trip, retraction, cost evaluation, decision) -- roofline.achieved = algorithmic bytes of that launch (its Hess-vecs x
+        # SURVEY.md 8(d)'s bytes per Hess-vec; the 40 cost / gradient evaluations it also makes are not counted) / its duration by HIP
+        # events on the library's stream over the timed steps.  `trip_only` = the trip microbenchmark (bench_tcg_trip: the per-iteration
+        # instance, 512 trips, exits disabled) that earlier rounds quoted as `frac`; `frac_of_value` = the same bytes x `value` / peak,
+        # i.e. with the host side of the step inside.
+        hv_step = hv / args.steps
+        fused_ms = sum(dev_ms) / len(dev_ms) if dev_ms and min(dev_ms) > 0 else None
+        trip_only = {"kernel": "k_tcg_pipe_obl" if one_reduction else "k_tcg_persist_obl", "kernel_us": trip_ms * 1e3, "per": "tCG trip (one Hess-vec)",
+                     "achieved": trip_achieved, "frac": trip_achieved / HBM_PEAK_GBS,
+                     "traffic": (pm_t or {}).get("hbm_bytes_per_trip"), "traffic_source": (pm_t or {}).get("_source"),
+                     "traffic_stale": (pm_t or {}).get("_stale"),
+                     "two_reduction_trip_us": None if trip2_ms is None else trip2_ms * 1e3}
+        if fused_ms is not None:
+            achieved = hv_step * abytes / (fused_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": (pm_f or {}).get("hbm_bytes_per_launch"), "traffic_source": (pm_f or {}).get("_source"),
+                        "traffic_stale": (pm_f or {}).get("_stale"),
+                        "traffic_note": "replayed from the committed rocprofv3 --pmc summary of the same kernel and workload, not measured in this run",
+                        "kernel": ("k_tcg_pipe_obl<.., FUSE>" if one_reduction else "k_tcg_persist_obl<.., FUSE>") + " (one launch = one trustregions() call)",
+                        "kernel_us": fused_ms * 1e3, "per": "launch (%d Hess-vecs)" % round(hv_step),
+                        "algorithmic_bytes_per_launch": hv_step * abytes, "algorithmic_bytes_per_hessvec": abytes,
+                        "frac_is": "algorithmic bytes of the fused launch / its HIP-event duration / peak",
+                        "frac_of_value": hv / dt * abytes / 1e9 / HBM_PEAK_GBS,
+                        "us_per_hessvec_in_the_launch": fused_ms * 1e3 / hv_step,
+                        "trip_only": trip_only}
+        else:
+            roofline = {"bound": "hbm", "achieved": trip_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": trip_achieved / HBM_PEAK_GBS,
+                        "traffic": trip_only["traffic"], "traffic_source": trip_only["traffic_source"], "traffic_stale": trip_only["traffic_stale"],
+                        "kernel": trip_only["kernel"], "kernel_us": trip_ms * 1e3, "per": "tCG trip (one Hess-vec)",
+                        "algorithmic_bytes_per_launch": abytes, "frac_is": "algorithmic bytes of one trip / trip time of the trip microbenchmark / peak",
+                        "frac_of_value": hv / dt * abytes / 1e9 / HBM_PEAK_GBS}
+        roofline.update({
                     "streaming_formulation_bytes_per_trip": streaming_trip_bytes,
-                    "streaming_equivalent_GBps": streaming_trip_bytes / (trip_ms * 1e-3) / 1e9,
-                    "two_reduction_trip_us": None if trip2_ms is None else trip2_ms * 1e3,
-                    "note": "one launch runs all trips of a solve; bytes, traffic and time are per trip.  The working set is register / LDS "
-                            "resident and a trip is LATENCY, not HBM (n*p*8 = 5 MB per vector: the fraction of the HBM roofline is low by "
-                            "construction).  Round 4's trip had two grid reductions (profiles/r5_persist_timeline_p32.md: gathers + row "
-                            "arithmetic 1.3 us, reduction 1 1.96, trial step 0.52, wait for the row stores 0.5, reduction 2 1.92, commit + new "
-                            "direction 0.6, loop 0.13).  Round 5: (a) the gather DURING reduction 2, three ways (row flags; sentinel-initialised "
-                            "exchange halves with full / partial retry): 8.6 / 7.1-7.5 / 7.2-7.5 us against 6.55 -- the exchanged rows need 2.6 us "
-                            "to become visible to other XCDs under that load (profiles/r5_persist_timeline_p32_{flags,sentinel_*}.md); (b) "
-                            "fine-grained instead of uncached exchange memory: 6.55 -> 6.41; (c) ONE reduction per trip (msdp_pipe.h, the "
-                            "default: what reduction 2 carried is a polynomial in the step length whose coefficients are inner products known "
-                            "before it; the neighbours gather H*mdelta, C*tangent(r) and C*mdelta follow by linearity; eight values in one "
-                            "reduction, joint wave butterfly, next gather requested inside the reduction, own-workgroup rows from LDS): "
-                            "`two_reduction_trip_us` -> `kernel_us` in this run; phases in profiles/r5_persist_timeline_p32_pipe.md"}
+                    "note": "the working set is register / LDS resident and a trip is LATENCY, not HBM (n*p*8 = 5 MB per vector: the fraction of the "
+                            "HBM roofline is low by construction): one grid reduction per trip (msdp_pipe.h) -- profiles/r6_fused_timeline_p32.md: "
+                            "products + partial sums 1.4 us (fp64 VALU at two waves per SIMD), the reduction chain 3.3 us (wave butterfly, store "
+                            "drain + barrier, post + back-off, poll, sums), alpha .. new direction 0.5 us; a TR iteration costs 13 us outside "
+                            "its trips (round 5: 14; retraction, slot-line barrier, gather of the proposal rows through the fine-grained exchange "
+                            "buffer, the iteration's reduction, decision with an LDS role swap)"})
     else:
         roofline = {"bound": "hbm", "achieved": hess_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hess_achieved / HBM_PEAK_GBS, "traffic": (pm_h or {}).get("hbm_bytes_per_launch"),
-                    "traffic_source": (pm_h or {}).get("_source"),
+                    "traffic_source": (pm_h or {}).get("_source"), "traffic_stale": (pm_h or {}).get("_stale"),
                     "kernel": "k_hess_ell_obl", "kernel_us": ms * 1e3, "algorithmic_bytes_per_launch": abytes}
     hess_kernel = {"kernel": "k_hess_ell_obl", "kernel_us": ms * 1e3, "algorithmic_bytes_per_launch": abytes,
                    "achieved_GBps": hess_achieved, "frac_of_hbm_peak": hess_achieved / HBM_PEAK_GBS,
-                   "traffic": (pm_h or {}).get("hbm_bytes_per_launch"), "traffic_source": (pm_h or {}).get("_source")}
+                   "traffic": (pm_h or {}).get("hbm_bytes_per_launch"), "traffic_source": (pm_h or {}).get("_source"),
+                   "traffic_stale": (pm_h or {}).get("_stale")}
 
     out = {
         "metric": "tCG Hess-vec prods/sec (n,p), G81 MaxCut",
@@ -651,7 +689,7 @@ def main():
                    "TFLOPs_f64": fld / msd / 1e9, "frac_mfma_f64_peak": fld / msd / 1e9 / MFMA_F64_TFLOPS,
                    "GBps": byd / msd / 1e6, "frac_hbm_peak": byd / msd / 1e6 / HBM_PEAK_GBS,
                    "roofline": secondary_roofline(kname, msd * 1e3, byd, fld,
-                                                  ("r5_pmc_dense%d_p%d.json" % (dn, dp), "r4_pmc_dense%d_p%d.json" % (dn, dp), "r3_pmc_dense%d_p%d.json" % (dn, dp), "r2_pmc_dense%d_p%d.json" % (dn, dp)),
+                                                  ("r6_pmc_dense%d_p%d.json" % (dn, dp), "r5_pmc_dense%d_p%d.json" % (dn, dp), "r4_pmc_dense%d_p%d.json" % (dn, dp), "r3_pmc_dense%d_p%d.json" % (dn, dp), "r2_pmc_dense%d_p%d.json" % (dn, dp)),
                                                   bound=bound)}
             if sym:
                 ent["survey_8d_bytes"] = survey_bytes
@@ -708,12 +746,12 @@ def main():
                 "n": ln * ln, "p": lp, "tcg_path": path, "trip_us": trip_us, "hessvec_kernel_us": msl * 1e3,
                 "vector_passes_per_trip": npass,
                 "roofline": secondary_roofline("k_tcg1_upd + k_tcg1_head", trip_us, algo, 0.0,
-                                               ("r4_pmc_linear_n1e6_p32.json", "r3_pmc_linear_n1e6_p32.json"), bound="hbm", per="tCG trip")}
+                                               ("r6_pmc_linear_n1e6_p32.json", "r4_pmc_linear_n1e6_p32.json", "r3_pmc_linear_n1e6_p32.json"), bound="hbm", per="tCG trip")}
             # the stand-alone S*U launch of the same handle: k_hess_win_obl (round 5: the rows of U a breadth-first patch of rows touches
             # staged once per workgroup in LDS), and beside it the direct gathers of k_hess_ell_obl (option window = 0)
             out["large_sparse_trip"]["standalone_hessvec"] = {
                 "kernel_us": msl * 1e3, "kernel_us_direct_gathers": msl0 * 1e3,
-                "roofline": secondary_roofline("k_hess_win_obl", msl * 1e3, byl, fll, ("r5_pmc_hess_win_n1e6_p32.json", "r4_pmc_hess_n1e6_p32.json"), bound="hbm", per="launch")}
+                "roofline": secondary_roofline("k_hess_win_obl", msl * 1e3, byl, fll, ("r6_pmc_hess_win_n1e6_p32.json", "r5_pmc_hess_win_n1e6_p32.json", "r4_pmc_hess_n1e6_p32.json"), bound="hbm", per="launch")}
             rec = out["large_sparse_trip"]["roofline"]
             rec["formulation_bytes"] = formulation
             rec["formulation_GBps"] = formulation / (trip_us * 1e-6) / 1e9
@@ -735,6 +773,19 @@ def main():
             out["process_rank_trip"] = process_rank_trip()
         except Exception as e:  # noqa: BLE001 -- secondary figure
             out["process_rank_trip"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            # 2 x 10 000 rows: 79 rows per workgroup on the members' 128 workgroups each -- the shape every member of an N-GPU run has on
+            # its own 216 (20 000 rows), where the cross-rank kernels run the ONE-reduction trip (msdp_pipe.h XRM; round 6); at 2 x 20 000
+            # rows on one device a workgroup owns 157 rows and the two-reduction trip runs
+            out["process_rank_trip_10000"] = process_rank_trip(grid_rows=50)
+            hq = _lib.Handle.onlyunitdiag(problems.toroidal_grid_maxcut(100, 200, seed=81), pcap=p)
+            rq = np.random.default_rng(0)
+            Yq = rq.standard_normal((20000, p)); Yq /= np.linalg.norm(Yq, axis=1, keepdims=True)
+            hq.set_point(Yq)
+            out["process_rank_trip_10000"]["trip_us_one_unsharded_handle"] = min(hq.bench_tcg_trip(256) for _ in range(3)) * 1e3
+            hq.close()
+        except Exception as e:  # noqa: BLE001 -- secondary figure
+            out["process_rank_trip_10000"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if N > 1 or args.force_comm:
         # BASELINE config 5 next to the headline metric: synthetic dense C generated per shard on the device
         # (12 500 rows per GPU, n = 12 500 * N, so N = 8 is exactly n = 100 000), p = 64, RCCL all-gather of the

@@ -290,6 +290,11 @@ int msdp_escape_method(msdp_handle h, int32_t* method);
  * of the projected residual with every rank's partial sums riding along, then the all-reduce of <mdelta, H mdelta> -- tCG.m:166),
  * three with option trip1 = 0; tests/test_gpu_local_ranks.py asserts it. */
 int msdp_debug_collective_calls(msdp_handle h, int64_t* calls);
+/* (new, measurement only) Device time of the LAST msdp_rtr call on this handle, by HIP events on the handle's stream around what the
+ * call enqueued behind the cost / gradient evaluation of its start point (trustregions.m:441-767): on the fused path exactly the ONE launch
+ * that runs every tCG trip, retraction, cost evaluation and decision of the call -- bench.py's dominant kernel, whose roofline figure is
+ * algorithmic bytes of the launch / this time.  *ms < 0: no call yet. */
+int msdp_debug_last_rtr_device_ms(msdp_handle h, double* ms);
 /* Measurement only: average stream time (us) of one collective call: which = 0 row exchange, 1 all-reduce of one partial-sum
  * array, 2 row exchange with the sums riding along, 3 all-reduce of three arrays, 4 rows and sums as two separate all-gathers. */
 int msdp_debug_time_collective(msdp_handle h, int32_t which, int32_t reps, double* avg_us);

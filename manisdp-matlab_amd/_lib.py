@@ -84,6 +84,7 @@ SIGNATURES = {
     "msdp_escape_lower_bound": (C.c_int, [C.c_void_p, _dp]),
     "msdp_escape_method": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
     "msdp_debug_collective_calls": (C.c_int, [C.c_void_p, _P(C.c_int64)]),
+    "msdp_debug_last_rtr_device_ms": (C.c_int, [C.c_void_p, _dp]),
     "msdp_debug_persist_trace": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_uint64), C.c_int64, _P(C.c_int32), _dp]),
     "msdp_debug_time_collective": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_double)]),
     "msdp_debug_get_tcg_step": (C.c_int, [C.c_void_p, _dp, _dp]),
@@ -609,6 +610,12 @@ class Handle:
 
     def point_restore(self):
         _check(self._lib.msdp_point_restore(self._h))
+
+    def last_rtr_device_ms(self):
+        """Device time of the last rtr() call (HIP events on the library's stream; the fused launch on the fused path)."""
+        v = C.c_double()
+        _check(self._lib.msdp_debug_last_rtr_device_ms(self._h, C.byref(v)))
+        return v.value
 
     def tcg_path(self):
         """1: persistent single-launch tCG kernel, 0: chunked hipGraph (three kernels per trip)."""

@@ -1236,7 +1236,7 @@ int msdp_xpersist_reset(hipStream_t stream, unsigned long long* slots, int* err)
 // The shared block of the group: allocated by member 0 the first time (and again when the factor outgrows the exchange buffer)
 static int xr_ensure_shared(msdp_handle h) {
     LocalGroup* g = h->lgroup;
-    size_t need = ((size_t)rows_capacity(h) + (size_t)(g->ipc ? g->xr_halo_max : h->xr_halo_rows)) * (size_t)std::max(h->ldcap, 64);   // per member: its rows + halo slots
+    size_t need = (g->ipc ? 4 : 1) * ((size_t)rows_capacity(h) + (size_t)(g->ipc ? g->xr_halo_max : h->xr_halo_rows)) * (size_t)std::max(h->ldcap, 64);   // per member: its rows + halo slots (process group: four regions)
     if (g->ipc) {                                            // the buffers were cut at msdp_comm_init_ipc
         if (g->xr_rows_doubles < need) { msdp_set_error("cross-rank persistent tCG: the factor outgrew the exchange buffers of this communicator (ld %d)", h->ldcap); return MSDP_ENOMEM; }
         return 0;
@@ -1896,7 +1896,9 @@ static int comm_init_ipc_attach(msdp_handle h, int32_t nranks, int32_t rank, uns
     }
     size_t hmax = 0;
     for (int q = 0; q < nranks; ++q) hmax = std::max<size_t>(hmax, (size_t)sh->vote[q]);
-    const size_t rows_doubles = ((size_t)rows_capacity(h) + hmax) * ldx;
+    // (four regions of rows + halo slots each: the one-reduction trip of msdp_pipe.h publishes H md alternately in two and its refresh
+    // rows in two more; the two-reduction trip and the TR tail use the first)
+    const size_t rows_doubles = 4 * ((size_t)rows_capacity(h) + hmax) * ldx;
     g->xr_halo_max = (int)hmax;
     // the exchange buffer of MY rows (+ my halo slots): my own allocation (on my device), exported; then the others', mapped
     {
@@ -2034,6 +2036,13 @@ extern "C" int msdp_local_rows(msdp_handle h, int64_t* row0, int64_t* row1) {
     CHECK_H(h);
     if (row0) *row0 = h->d.row0;
     if (row1) *row1 = h->d.row0 + h->d.n_loc;
+    return 0;
+}
+
+extern "C" int msdp_debug_last_rtr_device_ms(msdp_handle h, double* ms) {
+    CHECK_H(h);
+    if (!ms) return MSDP_EINVAL;
+    *ms = h->last_rtr_device_ms;
     return 0;
 }
 
@@ -2323,6 +2332,8 @@ static int rtr_core(msdp_handle h, const msdp_rtr_opts* opts, bool* timed_out) {
     // the fused launch reads ctl on the device (a solve that is already done is a no-op there): the host needs the state of
     // the start point only on the other paths -- one host round trip less per call (20-100 us, host to host)
     if (!fused && (rc = pull_ctl(h))) return rc;
+    if (!fused) HIPCHK(hipEventRecord(h->ev0, h->stream));       // (msdp_debug_last_rtr_device_ms: closed in msdp_rtr)
+    h->last_rtr_fused = fused;
     if (persist && h->tune.fail_persist) {                       // test hook: behave as if the launch had timed out
         h->tune.fail_persist = 0;
         *timed_out = true;
@@ -2333,10 +2344,16 @@ static int rtr_core(msdp_handle h, const msdp_rtr_opts* opts, bool* timed_out) {
         // accept/reject logic) runs in ONE launch; the host only waits for it (msdp_persist.hip, FUSE = true).
         const auto ta = std::chrono::steady_clock::now();
         h->d.status = nullptr;                                            // no progress word needed
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
         rc = msdp_launch_rtr_fused(h);
         restore_status_ptr(h);
         if (rc) return rc;
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
         if ((rc = pull_ctl_and_err(h, timed_out))) return rc;
+        {   // (the stream is idle: the events are complete)
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_rtr_device_ms = (double)ms; else (void)hipGetLastError();
+        }
         if (*timed_out) return 0;
         t_tcg = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
     } else if (persist) {
@@ -2539,6 +2556,12 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
     }
     h->state_valid = true;
     h->gradnorm_valid = true;
+    if (!h->last_rtr_fused) {
+        // (the other paths: the stream time of everything the call enqueued behind the evaluation of its start point, host gaps included)
+        float ms = 0.f;
+        if (hipEventRecord(h->ev1, h->stream) == hipSuccess && hipEventSynchronize(h->ev1) == hipSuccess &&
+            hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_rtr_device_ms = (double)ms; else (void)hipGetLastError();
+    }
     if (stats) {
         const Ctl* c = h->h_ctl;
         memset(stats, 0, sizeof(*stats));

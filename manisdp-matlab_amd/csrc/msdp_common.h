@@ -147,6 +147,7 @@ struct Dev {
     // round 6, two-level grid reductions between members that own a device each (msdp_psync.h psync2): xr2_on, this member's block
     // (fine-grained memory of its device), the members' blocks as this process maps them (device array of xr2_n pointers), this member's
     // index among the xr2_n members; xr_sys: the pushed rows cross devices (system-scope stores)
+    int xr_pipe;          // the members' launches run the one-reduction trip (msdp_pipe.h XRM) -- process ranks, rows of <= 5 entries, <16,5,3> / <8,5,2> plans
     int xr2_on, xr2_n, xr2_me, xr_sys, xr2_skip;   // (xr2_skip: test hook -- the leader waits for this many local workgroups that do not exist)
     unsigned long long* xr2_blk;
     unsigned long long* const* xr2_peers;
@@ -274,6 +275,7 @@ struct msdp_handle_s {
     int* d_rowptr = nullptr; int* d_colind = nullptr; double* d_cval = nullptr;
     int* d_ellc = nullptr; double* d_ellv = nullptr;
     msdp_rtr_opts last_opts{};
+    double last_rtr_device_ms = -1.0; bool last_rtr_fused = false;   // msdp_debug_last_rtr_device_ms
     // tCG chunk graph (CH x {hess, upd1, upd2}) and its validity signature
     hipGraphExec_t chunk_exec = nullptr;          // the one to launch now (alias into chunk_execs)
     hipGraphExec_t chunk_execs[2] = {nullptr, nullptr};

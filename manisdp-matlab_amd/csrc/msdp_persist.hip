@@ -1156,6 +1156,10 @@ int msdp_xpersist_member(msdp_handle h, int nranks, int rank, double* const* row
     for (int q = 0; q < 4; ++q) out->xr_rows[q] = rows[rank];
     out->xr_cap = (h->d.n + nranks - 1) / nranks; out->xr_me = 0; out->xr_halo = halo_rows;
     out->xr2_on = two ? 1 : 0; out->xr2_n = nranks; out->xr2_me = rank; out->xr2_skip = 0;
+    // the one-reduction trip across the members (round 6): process ranks, the two shapes it is instantiated for (the launcher also wants
+    // the members' common ELL width to be 5)
+    out->xr_pipe = (h->lgroup_is_ipc && h->tune.persist_pipe && !h->tune.persist_early && pl.ew == 5 &&
+                    ((pl.lpr == 16 && pl.r == 3) || (pl.lpr == 8 && pl.r == 2))) ? 1 : 0;
     out->xr_sys = h->xr2_multi ? 1 : 0;
     out->xr2_blk = h->xr2_blk; out->xr2_peers = h->xr2_peers;
     if (two && (!h->xr2_blk || !h->xr2_peers)) { msdp_set_error("cross-rank persistent tCG: the two-level blocks are missing"); return MSDP_ESTATE; }
@@ -1207,7 +1211,18 @@ int msdp_launch_tcg_xpersist_one(hipStream_t stream, const Dev& dv, const int* p
     XK(8, 5, 2) XK(8, 0, 2) XK(8, 5, 4) XK(8, 0, 4) XK(16, 5, 3) XK(16, 0, 3) XK(16, 5, 5) XK(16, 0, 5) XK(32, 5, 5) XK(32, 0, 5)
 #undef XK
     if (!fn) { msdp_set_error("cross-rank persistent tCG: no kernel instance"); return MSDP_ESTATE; }
-    const size_t lds = xr_lds(lpr, ew, r);
+    size_t lds = xr_lds(lpr, ew, r);
+    if (dv.xr_pipe && ew == 5) {
+        // ONE grid reduction per trip across the members (msdp_pipe.h, XRM = 1 flat / 2 two-level)
+        persist_fn fp = nullptr;
+        if (lpr == 16 && r == 3) fp = dv.xr2_on ? k_tcg_pipe_obl<16, 5, 3, false, false, 2> : k_tcg_pipe_obl<16, 5, 3, false, false, 1>;
+        if (lpr == 8 && r == 2) fp = dv.xr2_on ? k_tcg_pipe_obl<8, 5, 2, false, false, 2> : k_tcg_pipe_obl<8, 5, 2, false, false, 1>;
+        if (fp) {
+            const size_t rows = (size_t)r * PWAVES * (64 / lpr);
+            fn = fp;
+            lds += (size_t)ew * rows * sizeof(int) + (size_t)2 * r * PB * sizeof(double2);      // + ls, HQs
+        }
+    }
     HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fn, dim3(dv.G), dim3(PB), lds, stream, dv, slots, err);
     HIPCHK(hipGetLastError());

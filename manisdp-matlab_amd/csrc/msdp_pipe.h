@@ -281,6 +281,108 @@ __device__ __forceinline__ bool pbar8_lines(unsigned long long* slots, unsigned 
     return __builtin_amdgcn_ballot_w64(fl != 0.0) == 0ULL;
 }
 
+// The eight-value reduction in its two-level form (msdp_psync.h psync2, members that own a device each): the wave butterfly of psync8,
+// the member's leader polls the eight local value arrays with its eight waves and pushes the member's eight sums -- ONE 64-byte line --
+// into every member's block; everybody polls the N lines of its own block.  One cross-device hop per trip.
+template <class F>
+__device__ __forceinline__ bool psync2_8(unsigned long long* blk, unsigned long long* const* peers, int N, int me, int ri, unsigned gen, int G,
+                                         double (&v)[8], double* sh8, double* shb8, int* err, int bid, int backoff, F on_ready) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        const bool h8 = (lane & 8) != 0;
+        double a[4], b[2], x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = msdp_swap_add<32>(v[k], v[4 + k]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) b[k] = msdp_swap_add<16>(a[k], a[2 + k]);
+        x = (h8 ? b[1] : b[0]) + msdp_dpp<0x128>(h8 ? b[0] : b[1]);
+        x += msdp_dpp<MSDP_DPP_XOR1>(x); x += msdp_dpp<MSDP_DPP_XOR2>(x); x += msdp_dpp<MSDP_DPP_HALF_MIRROR>(x);
+        if ((lane & 7) == 0) sh8[(lane >> 3) * PWAVES + w] = x;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the caller's row stores (and pushes) are performed before the post
+    __syncthreads();
+    unsigned long long* ls = blk + (size_t)ri * XR2_REGION;
+    unsigned long long* ml = ls + PSYNC_REGION;
+    unsigned long long* gbase = ls + (size_t)(gen % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID;   // replica 0
+    if (w == 0 && lane < 8) {
+        double s = 0.0;
+        for (int i = 0; i < PWAVES; ++i) s += sh8[lane * PWAVES + i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(gbase + (size_t)lane * MSDP_MAX_GRID + bid, (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool fail = false;
+    if (bid == 0) {
+        // the member's leader: wave w takes value array w of the local slots (the order of psync8) and hands the sum to every member
+        const unsigned long long* p0 = gbase + (size_t)w * MSDP_MAX_GRID + lane;
+        double r0 = 0.0;
+        int spins = 0;
+        for (;;) {
+            unsigned long long b0[4];
+            asm volatile(
+                "global_load_dwordx2 %0, %4, off sc1\n\t"
+                "global_load_dwordx2 %1, %4, off offset:512 sc1\n\t"
+                "global_load_dwordx2 %2, %4, off offset:1024 sc1\n\t"
+                "global_load_dwordx2 %3, %4, off offset:1536 sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3])
+                : "v"(p0)
+                : "memory");
+            bool ok = true;
+            double t0 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (lane + 64 * q < G) {
+                    ok = ok && b0[q] != PSYNC_SENT;
+                    t0 += __longlong_as_double((long long)b0[q]);
+                }
+            }
+            r0 = t0;
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ULL) break;
+            ++spins;
+            if (spins > PSYNC_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
+        }
+        r0 = msdp_wave_sum(r0);
+        if (!fail && lane < N)
+            __hip_atomic_store(peers[lane] + (size_t)ri * XR2_REGION + PSYNC_REGION + ((size_t)(gen % PSYNC_GEN) * 8 + me) * 8 + w,
+                               (unsigned long long)__double_as_longlong(r0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (fail) xr2_fail(blk, peers, N, err);
+        if (w > 0 && lane == 0) shb8[8 + w] = fail ? 1.0 : 0.0;
+    }
+    if (w == 0) {
+        const unsigned long long* p = ml + (size_t)(gen % PSYNC_GEN) * 64 + lane;
+        const bool need = (lane >> 3) < N;
+        const int first = bid == 0 ? 0 : (((backoff >> 16) & 0xff) ? ((backoff >> 16) & 0xff) : (backoff & 0xff));
+        for (int q = 0; q < first; ++q) __builtin_amdgcn_s_sleep(1);
+        unsigned long long x = 0ULL;
+        int spins = 0;
+        for (;;) {
+            x = ld_u64_sys(p);
+            if (__builtin_amdgcn_ballot_w64(need && x == PSYNC_SENT) == 0ULL) break;
+            ++spins;
+            if (spins > PSYNC_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { fail = true; break; }
+            for (int q = 0; q < ((backoff >> 8) & 0xff); ++q) __builtin_amdgcn_s_sleep(1);
+        }
+        double t = need ? __longlong_as_double((long long)x) : 0.0;
+        t += msdp_dpp<0x128>(t);
+        t = msdp_rowpair_sum<16>(t);
+        t = msdp_rowpair_sum<32>(t);
+        if (lane < 8) { shb8[lane] = t; if (bid != 0 && lane > 0) shb8[8 + lane] = 0.0; }
+        if (lane == 0) shb8[8] = fail ? 1.0 : 0.0;
+        if (fail) xr2_fail(blk, peers, N, err);
+        if (lane < PSYNC_NV)
+            __hip_atomic_store(ls + (size_t)((gen + PSYNC_GEN - 1) % PSYNC_GEN) * PSYNC_REP * PSYNC_NV * MSDP_MAX_GRID + (size_t)lane * MSDP_MAX_GRID + bid,
+                               PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bid == 0)
+            __hip_atomic_store(ml + (size_t)((gen + PSYNC_GEN - 1) % PSYNC_GEN) * 64 + lane, PSYNC_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    on_ready();
+    double bad = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = msdp_readlane(shb8[i], 0); bad += msdp_readlane(shb8[8 + i], 0); }
+    return bad == 0.0;
+}
+
 // TRACE stamps of this form: 0 top of the trip (gather about to be issued), 1 products, Hmd and the eight partial sums formed, rows of
 // Hmd stored; inside the reduction 4 wave butterfly done, 2 stores performed + workgroup barrier, 3 posted + slept, 7 wave 0's poll
 // returned; 5 the reduction returned, 6 new direction formed (end of the trip)
@@ -296,8 +398,16 @@ __device__ __forceinline__ bool pbar8_lines(unsigned long long* slots, unsigned 
 #else
 #define PSYNC8(slots, gen, G, v, sh8, shb8, err, bid, backoff, tr, f) psync8(slots, gen, G, v, sh8, shb8, err, bid, backoff, tr, f)
 #endif
-template <int LPR, int EW, int R, bool TRACE, bool FUSE>
+// XRM (round 6): 0 one rank; 1 / 2 = a member of a group of ranks whose launches run ONE tCG together (the cross-rank form of
+// msdp_persist.hip XR with this trip): 1 the flat reductions over all members' workgroups (members that share a device, N <= 4),
+// 2 the two-level ones (psync2_8: members on devices of their own, N <= 8).  The rows travel as there: every member's exchange buffer holds
+// its rows and a slot per foreign row its rows of C reference (buffer-local column indices d.xr_ellc), the owner of a boundary row
+// stores it into the slots of the members that reference it (d.xr_paddr) -- here in four regions (H md alternating, the refresh rows),
+// and the first direction (the gradient, which every member keeps to itself) is published behind one barrier.
+template <int LPR, int EW, int R, bool TRACE, bool FUSE, int XRM = 0>
 __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* slots, int* err, const int bx) {
+    constexpr bool XR = XRM != 0, XTWO = XRM == 2;
+    static_assert(!XR || (!FUSE && !TRACE), "cross-rank instances: per-iteration launches");
     static_assert(EW > 0 && R <= 5, "pipelined trip: ELL rows, every vector in registers");
     static_assert(PSYNC_NV == 8 && PSYNC_REP * PSYNC_NV == 64, "psync8 posts one slot per lane of wave 0");
     extern __shared__ double lds[];
@@ -323,6 +433,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     double2* HQs = reinterpret_cast<double2*>(ls + EW * ROWS);     // [2][R][PB]
     // FUSE only: the proposal point, its gradient and eG (round 6: buffers of their own behind HQs -- sharing its space meant a copy of
     // 2 x R x PB double2 per accepted step, 1.1 us of every TR iteration)
+    unsigned long long* pds = reinterpret_cast<unsigned long long*>(HQs + 2 * R * PB);   // XR: [2][ROWS] (never FUSE: the space is free)
     double2* YPs = HQs + 2 * R * PB;                               // [R][PB]
     double2* GPs = YPs + R * PB;                                   // [R][PB]
     double* EGPs = reinterpret_cast<double*>(GPs + R * PB);        // [ROWS]
@@ -339,8 +450,20 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         return;
     }
     if (lead && !FUSE) msdp_publish(d, k_tr, 0, 1);
-    const int bid = bx, GS = d.G;
-    if (!FUSE) psync_reset_other(slots + PSYNC_REGION, bid, GS);   // region B belongs to the TR-iteration tail kernel
+    const int bid = (XR && !XTWO) ? d.xr_gid0 + bx : bx;
+    const int GS = (XR && !XTWO) ? d.xr_gtot : d.G;                // the workgroups that synchronise (two-level: this member's)
+    const int xri = k_tr & 1;                                      // XR: the slot region of this launch (they alternate with the TR iteration)
+    __shared__ unsigned long long* shpeer[XTWO ? 8 : 1];
+    if (XTWO) {
+        if (threadIdx.x < 8) shpeer[threadIdx.x] = threadIdx.x < d.xr2_n ? d.xr2_peers[threadIdx.x] : d.xr2_blk;
+        psync2_reset_other(d.xr2_blk, xri ^ 1, bid, GS);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (XR) {
+        unsigned long long* other = slots + (size_t)(xri ^ 1) * PSYNC_REGION;
+        slots += (size_t)xri * PSYNC_REGION;
+        psync_reset_other(other, bid, GS);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // performed before this workgroup's first post of this launch
+    } else if (!FUSE) psync_reset_other(slots + PSYNC_REGION, bid, GS);   // region B belongs to the TR-iteration tail kernel
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi, 0, bx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -388,7 +511,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         double vw[EW];
 #pragma unroll
         for (int w = 0; w < EW; ++w) {
-            cw[w] = d.ellc[(int64_t)w * d.ell_stride + rc];
+            cw[w] = XR ? d.xr_ellc[(int64_t)w * d.ell_stride + rc] : d.ellc[(int64_t)w * d.ell_stride + rc];
             vw[w] = d.ellv[(int64_t)w * d.ell_stride + rc];
         }
         // the entries of the row ordered own row, rows of this workgroup, other rows, empty slots: a column of the ELL block then
@@ -408,6 +531,11 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
                     const int tc = cw[b2]; cw[b2] = cw[b2 + 1]; cw[b2 + 1] = tc;
                     const double tv = vw[b2]; vw[b2] = vw[b2 + 1]; vw[b2 + 1] = tv;
                 }
+        if (XR && sub == 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)                            // push targets of this row (the slot's address in region 0 of that member's buffer; 0: none)
+                pds[t * ROWS + SLOT(r)] = rok ? d.xr_paddr[(int64_t)t * d.n_loc + rc] : 0ULL;
+        }
         if (sub == 0) {
             eGs[SLOT(r)] = rok ? egv : 0.0;
 #pragma unroll
@@ -438,12 +566,41 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         }
     }
     unsigned gen = 0;
-    const unsigned half_bytes = (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
+    // (XR: a region of a member's buffer = its rows + the slots of the foreign rows it references)
+    const unsigned half_bytes = XR ? (unsigned)(((size_t)d.xr_cap + (size_t)d.xr_halo) * d.ld * sizeof(double)) : (unsigned)((size_t)d.n_loc * d.ld * sizeof(double));
     // exchange buffer: halves 0 / 1 = the rows of Hmd (alternating trips), 2 = the rows of md' and 3 = those of tangent(r') of a refresh trip;
     // FUSE (round 6): 4 = the rows of the proposal point, 5 / 6 = the gradient rows of the point in slot 0 / 1 -- the TR tail's exchanges
     // went through d.Y / d.Gr of the proposal slot (ordinary device memory, sc1 accesses) and its two cold gathers took 4.2 and 2.8 us
     // where a trip's gather from this buffer (fine-grained memory) is done in 1.4 with its arithmetic (profiles/r6_fused_timeline_p32_*.md)
-    const __amdgpu_buffer_rsrc_t rs_md = __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, (FUSE ? 7u : 4u) * half_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_md = XR ? __builtin_amdgcn_make_buffer_rsrc(d.xr_rows[0], 0, 4u * half_bytes, 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc(d.mdx, 0, (FUSE ? 7u : 4u) * half_bytes, 0x00020000);
+    // XR: this lane's 16 bytes of local row slot r of region `reg` also go to the members that reference the row
+    bool xr_has_push = false, xr_has_push2 = false;                // wave-uniform: some row of this wave is referenced by another member / by two
+    if (XR) {
+        bool any = false, any2 = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { any = any || pds[SLOT(r)] != 0ULL; any2 = any2 || pds[ROWS + SLOT(r)] != 0ULL; }
+        xr_has_push2 = __builtin_amdgcn_ballot_w64(any2) != 0ULL;
+        xr_has_push = xr_has_push2 || __builtin_amdgcn_ballot_w64(any) != 0ULL;
+    }
+    auto xr_push = [&](int r, unsigned reg, double2 val) {
+        if (!XR || !xr_has_push) return;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t == 1 && !xr_has_push2) continue;
+            const unsigned long long a = pds[t * ROWS + SLOT(r)];
+            if (a != 0ULL && OK(r)) {
+                double* ptr = reinterpret_cast<double*>(a + (unsigned long long)reg * half_bytes) + 2 * sub;
+                if (XTWO) {                                        // the slot may live on another device: system scope
+                    __hip_atomic_store(ptr, val.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(ptr + 1, val.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    __hip_atomic_store(ptr, val.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ptr + 1, val.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    };
     // the gradient rows of the current point: where an earlier launch left them (d.Gr) until a step has been accepted in THIS launch
     __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[1] : d.Gr[0], 0, half_bytes, 0x00020000);
     unsigned g_base = 0u;
@@ -544,12 +701,15 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
             hmd[r] = hq;
             if (MULTI) HQs[xq * R * PB + r * PB + threadIdx.x] = hq;    // (read by the instances with local columns only)
             if (OK(r)) st2_sc1(rs_md, xq * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, hq);
+            xr_push(r, xq, hq);
             if (pub) {
                 const double dn = msdp_group_sum<LPR>(rv.x * y.x + rv.y * y.y);
                 if (OK(r)) {
                     st2_sc1(rs_md, 2u * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, mdr);
                     st2_sc1(rs_md, 3u * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, make_double2(rv.x - y.x * dn, rv.y - y.y * dn));
                 }
+                xr_push(r, 2u, mdr);
+                xr_push(r, 3u, make_double2(rv.x - y.x * dn, rv.y - y.y * dn));
             }
             const double2 rg = make_double2(rv.x - g.x, rv.y - g.y);                      // Heta (:220)
             v[0] += mdr.x * hq.x + mdr.y * hq.y;                                          // <md, Hmd>   (:166)
@@ -566,10 +726,14 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         // (my rows of Hmd are performed before I post: the wait sits inside psync8, behind the wave reduction)
         // (the next trip's gather goes out as soon as this wave has seen every workgroup's post: its latency runs under the rest of the
         // reduction and the arithmetic behind it.  Not behind a refresh trip: that one's two direct gathers come first.)
+        auto next_gather = [&]() { if (PREF && !pub) { PIPE_ISSUE(rs_md, xq * half_bytes, NL); have_x = true; } };
+        if (XTWO) {
+            if (!psync2_8(d.xr2_blk, shpeer, d.xr2_n, d.xr2_me, xri, gen++, GS + d.xr2_skip, v, sh8, shb8, err, bid, backoff, next_gather)) { failed = true; break; }
+        } else
         if (!PSYNC8(slots, gen++, GS, v, sh8, shb8, err, bid, backoff,
                     (TRACE && !FUSE && j >= MSDP_TRACE_J0 && j < MSDP_TRACE_J0 + MSDP_TRACE_NJ) ? d.trace + ((size_t)bx * MSDP_TRACE_NJ + (j - MSDP_TRACE_J0)) * 8 :
                     (FTRIP_ON ? FTRIP_PTR : nullptr),
-                    [&]() { if (PREF && !pub) { PIPE_ISSUE(rs_md, xq * half_bytes, NL); have_x = true; } })) { failed = true; break; }
+                    next_gather)) { failed = true; break; }
         PTSTAMP(5);
         const double d_Hd = v[0];                                                         // :166
         z_r = v[6];
@@ -631,6 +795,24 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
 #undef FTRIP_ON
 #undef FTRIP_PTR
   };
+  // (test hook debug_xr_skip, flat form: the first workgroup of the group never posts -- everybody else's bounded spin runs out; the
+  // two-level form waits for local workgroups that do not exist, GS + d.xr2_skip)
+  if (XR && !XTWO && d.xr2_skip && bid == 0) return;
+  if (XR) {
+    // the first direction = the gradient, whose rows every member keeps to itself: hand them to the others first (region 2: the refresh
+    // trips use it from trip `refresh` on, long behind the first trip's gather)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (OK(r)) st2_sc1(rs_md, 2u * half_bytes + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, md[r]);
+        xr_push(r, 2u, md[r]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (XTWO) {
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+        if (!psync2(d.xr2_blk, shpeer, d.xr2_n, d.xr2_me, xri, gen++, GS + d.xr2_skip, 0, z0, z1, z2, sh8, shb8, err, bid, backoff, false)) return;
+    } else if (!pbar8_lines(slots, gen++, GS, shb8, err, bid, backoff)) return;
+    rs_g = rs_md; g_base = 2u * half_bytes;
+  }
   bool first_tr = true;
   for (;;) {   // ---- trust-region iterations (exactly one pass when !FUSE)
     FSTAMP(0);
@@ -822,7 +1004,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
 #undef OK
 }
 
-template <int LPR, int EW, int R, bool TRACE = false, bool FUSE = false>
+template <int LPR, int EW, int R, bool TRACE = false, bool FUSE = false, int XRM = 0>
 __global__ __launch_bounds__(PB) void k_tcg_pipe_obl(Dev d, unsigned long long* slots, int* err) {
-    tcg_pipe_body<LPR, EW, R, TRACE, FUSE>(d, slots, err, (int)blockIdx.x);
+    tcg_pipe_body<LPR, EW, R, TRACE, FUSE, XRM>(d, slots, err, (int)blockIdx.x);
 }

@@ -6,6 +6,11 @@ The dispatches of the kernels whose names contain one of the --only substrings (
 and divided by the number of dispatches of the unit kernel; the per-kernel split is kept in the record.  The x2 of FETCH_SIZE
 is the guide's correction for 16-B-per-lane streams; for the 8-byte gathers of the affine operators it is an upper bound."""
 import csv, glob, json, sys, collections
+import hashlib, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sources = []
+if "--sources" in sys.argv:            # the kernels' source files (relative to the repository): their hash goes into the summary
+    i = sys.argv.index("--sources"); sources = [x for x in sys.argv[i + 1].split(",") if x]; del sys.argv[i:i + 2]
 out, unit_kernel, field = sys.argv[1], sys.argv[2], sys.argv[3]
 rest = sys.argv[4:]
 only = None
@@ -31,5 +36,10 @@ for c, scale in (("FETCH_SIZE", 2 * 1024.0), ("WRITE_SIZE", 1024.0)):
         rec["per_kernel_bytes_per_unit"].setdefault(k, {})[c] = b
         total += b
 rec[field] = total
+if sources:
+    hh = hashlib.sha256()
+    for f in sources:
+        hh.update(open(os.path.join(ROOT, f), "rb").read())
+    rec["sources"] = sources; rec["sources_sha16"] = hh.hexdigest()[:16]
 json.dump(rec, open(out, "w"), indent=1)
 print(json.dumps({k: rec[k] for k in ("unit_kernel", "units", field)}))
