@@ -660,9 +660,29 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
                 PIPE_ISSUE(rs, base, w0); \
                 _Pragma("unroll") for (int r = 0; r < R; ++r) PIPE_FOLDX(r, (dst)[r], w0); } \
             if (!colok) { _Pragma("unroll") for (int r = 0; r < R; ++r) (dst)[r] = zz; } } while (0)
+        // the eight partial sums of this trip's reduction.  Round 6, the instances that do NOT have the next gather requested inside the
+        // reduction (!PREF: the fused launch at 16 lanes per row): four sums -- <md, g>, <md, Heta>, <r, r>, the model value -- do not
+        // involve H md and are formed while the gathers of this trip are in flight, the other four behind the rows of H md and their
+        // stores (whose drain they run under): G81 p = 32, the fused launch 5 426 -> 5 137 us per call, 182 100 -> 192 400 Hess-vec/s.
+        // With the gather prefetched the same order LOSES (the per-iteration <16, 5, 3> instance 4.82 -> 4.98 us per trip, <8, 5, 2>
+        // 3.59 -> 3.77): those keep the one loop of round 5.
+        double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        auto pre_sums = [&]() {
+            if (PREF) return;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double2 g = Gs[r * PB + threadIdx.x], mdr = md[r], e0 = eta[r], rv = rr[r];
+                const double2 rg = make_double2(rv.x - g.x, rv.y - g.y);                  // Heta (:220)
+                v[3] += mdr.x * g.x + mdr.y * g.y;                                        // <md, g>
+                v[5] += mdr.x * rg.x + mdr.y * rg.y;                                      // <md, Heta>
+                v[6] += rv.x * rv.x + rv.y * rv.y;                                        // <r, r>      (:241 of the trip before)
+                v[7] += (e0.x * g.x + e0.y * g.y) + 0.5 * (e0.x * rg.x + e0.y * rg.y);    // model value (:227 of the trip before)
+            }
+        };
         if (first) {
             // the first direction = the gradient (tangent): r = md = grad.  Its rows: in global memory since an earlier launch, in the
             // exchange buffer since the TR tail that proposed this point
+            pre_sums();
             PIPE_GATHER_ALL(rs_g, g_base, cmd);
 #pragma unroll
             for (int r = 0; r < R; ++r) ctr[r] = cmd[r];
@@ -674,6 +694,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
             }
             // the neighbours' rows of last trip's Hmd: requested inside that trip's reduction already (have_x), except behind a refresh
             if (!have_x) PIPE_ISSUE(rs_md, (xq ^ 1u) * half_bytes, NL);
+            pre_sums();
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 double2 a = zz;
@@ -689,11 +710,10 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         // like the rows of Hmd); the next trip gathers all three
         const bool pub = !first && refresh > 0 && ((j + 1) % refresh) == 0;
         // ---- Hmd = proj(C*md) - md.*eG (tCG.m:163, ManiSDP_onlyunitdiag.m:127-130), its rows to the neighbours, the eight partial sums
-        double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double2 acc = cmd[r];
-            const double2 y = Ys[r * PB + threadIdx.x], g = Gs[r * PB + threadIdx.x], mdr = md[r], e0 = eta[r], rv = rr[r];
+            const double2 y = Ys[r * PB + threadIdx.x], mdr = md[r], rv = rr[r];
             const double dot = msdp_group_sum<LPR>(acc.x * y.x + acc.y * y.y);
             const double eg = eGs[SLOT(r)];
             double2 hq = make_double2(acc.x - y.x * dot - mdr.x * eg, acc.y - y.y * dot - mdr.y * eg);
@@ -711,15 +731,29 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
                 xr_push(r, 2u, mdr);
                 xr_push(r, 3u, make_double2(rv.x - y.x * dn, rv.y - y.y * dn));
             }
-            const double2 rg = make_double2(rv.x - g.x, rv.y - g.y);                      // Heta (:220)
-            v[0] += mdr.x * hq.x + mdr.y * hq.y;                                          // <md, Hmd>   (:166)
-            v[1] += rv.x * hq.x + rv.y * hq.y;                                            // <r, Hmd>
-            v[2] += hq.x * hq.x + hq.y * hq.y;                                            // <Hmd, Hmd>
-            v[3] += mdr.x * g.x + mdr.y * g.y;                                            // <md, g>
-            v[4] += e0.x * hq.x + e0.y * hq.y;                                            // <eta, Hmd>
-            v[5] += mdr.x * rg.x + mdr.y * rg.y;                                          // <md, Heta>
-            v[6] += rv.x * rv.x + rv.y * rv.y;                                            // <r, r>      (:241 of the trip before)
-            v[7] += (e0.x * g.x + e0.y * g.y) + 0.5 * (e0.x * rg.x + e0.y * rg.y);        // model value (:227 of the trip before)
+            if (PREF) {                                                                   // (round 5's order: all eight sums row by row)
+                const double2 g = Gs[r * PB + threadIdx.x], e0 = eta[r];
+                const double2 rg = make_double2(rv.x - g.x, rv.y - g.y);                  // Heta (:220)
+                v[0] += mdr.x * hq.x + mdr.y * hq.y;                                      // <md, Hmd>   (:166)
+                v[1] += rv.x * hq.x + rv.y * hq.y;                                        // <r, Hmd>
+                v[2] += hq.x * hq.x + hq.y * hq.y;                                        // <Hmd, Hmd>
+                v[3] += mdr.x * g.x + mdr.y * g.y;                                        // <md, g>
+                v[4] += e0.x * hq.x + e0.y * hq.y;                                        // <eta, Hmd>
+                v[5] += mdr.x * rg.x + mdr.y * rg.y;                                      // <md, Heta>
+                v[6] += rv.x * rv.x + rv.y * rv.y;                                        // <r, r>      (:241 of the trip before)
+                v[7] += (e0.x * g.x + e0.y * g.y) + 0.5 * (e0.x * rg.x + e0.y * rg.y);    // model value (:227 of the trip before)
+            }
+        }
+        if (!PREF) {
+            // (every row store of the trip is on its way: the sums that need H md run under their drain)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double2 hq = hmd[r], mdr = md[r], e0 = eta[r], rv = rr[r];
+                v[0] += mdr.x * hq.x + mdr.y * hq.y;                                      // <md, Hmd>   (:166)
+                v[1] += rv.x * hq.x + rv.y * hq.y;                                        // <r, Hmd>
+                v[2] += hq.x * hq.x + hq.y * hq.y;                                        // <Hmd, Hmd>
+                v[4] += e0.x * hq.x + e0.y * hq.y;                                        // <eta, Hmd>
+            }
         }
         PTSTAMP(1);
         if (TRACE && FUSE && j == 0) { FSTAMP(1); }
