@@ -630,7 +630,13 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     constexpr int NL = decltype(nlc)::value;                       // columns [0, NL) from LDS, [NL, EW) through the buffer
     constexpr int NG = EW - NL;
     // the next trip's rows requested inside the reduction: where they are few enough to stay in flight across the trip's arithmetic
-    constexpr bool PREF = R * NG <= (FUSE ? 9 : 15);
+#ifndef MSDP_PIPE_VARIANT
+#define MSDP_PIPE_VARIANT 0
+#endif
+    constexpr bool PREF = R * NG <= ((FUSE && MSDP_PIPE_VARIANT == 0) ? 9 : 15);
+    // SPLIT: the four sums without H md under the gather, the other four behind the row stores (A/B builds: variant 1 = the gather
+    // prefetched in the fused launch too, round 5's order; variant 2 = prefetched AND split)
+    constexpr bool SPLIT = (MSDP_PIPE_VARIANT == 2 && FUSE) ? true : !PREF;
     double2 X[R][NG];                                              // the gathered rows (in flight across the end of a trip)
     for (;;) {
         PTSTAMP(0);
@@ -668,7 +674,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         // 3.59 -> 3.77): those keep the one loop of round 5.
         double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         auto pre_sums = [&]() {
-            if (PREF) return;
+            if (!SPLIT) return;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const double2 g = Gs[r * PB + threadIdx.x], mdr = md[r], e0 = eta[r], rv = rr[r];
@@ -731,7 +737,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
                 xr_push(r, 2u, mdr);
                 xr_push(r, 3u, make_double2(rv.x - y.x * dn, rv.y - y.y * dn));
             }
-            if (PREF) {                                                                   // (round 5's order: all eight sums row by row)
+            if (!SPLIT) {                                                                 // (round 5's order: all eight sums row by row)
                 const double2 g = Gs[r * PB + threadIdx.x], e0 = eta[r];
                 const double2 rg = make_double2(rv.x - g.x, rv.y - g.y);                  // Heta (:220)
                 v[0] += mdr.x * hq.x + mdr.y * hq.y;                                      // <md, Hmd>   (:166)
@@ -744,7 +750,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
                 v[7] += (e0.x * g.x + e0.y * g.y) + 0.5 * (e0.x * rg.x + e0.y * rg.y);    // model value (:227 of the trip before)
             }
         }
-        if (!PREF) {
+        if (SPLIT) {
             // (every row store of the trip is on its way: the sums that need H md run under their drain)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
