@@ -257,7 +257,7 @@ static void choose_grid(msdp_handle h) {
     const int rows_per_step = MSDP_WAVES * (64 / lpr);
     int want = (rows_capacity(h) + rows_per_step - 1) / rows_per_step;
     // At most one workgroup per CU: beyond 256 some CUs get a second 1024-thread workgroup and the launch waits for it
-    // (measured on G81 p=32: G=320 -> 27.4 us per tCG trip, G=256 -> 24.1 us).  Round 3 (tools/grid_probe.py, option grid):
+    // (measured on G81 p=32: G=320 -> 27.4 us per tCG trip, G=256 -> 24.1 us).  Round 3 (tools/archive/grid_probe.py, option grid):
     // 512 workgroups -- two full rounds -- lose as well, at every size: n = 40 000, p = 40: 50.6 us per trip against 43.1 with
     // 256; n = 80 000, p = 40: 79.0 / 71.3; n = 250 000, p = 64: 390 / 378; n = 10^6, p = 32: 770 / 766 (the stand-alone S*U
     // kernel alone gains 8 % from 512 at n = 10^6 and loses 8 % at n = 40 000).
@@ -288,7 +288,7 @@ int msdp_alloc_vectors(msdp_handle h, int pcap) {
     d.full = nullptr;
     {
         // ONE allocation for the fifteen factor-sized vectors (15 hipMalloc calls were 15 of the 19 ms the first set_point of
-        // a G81 solve took -- 7 % of the 0.22-s solve, tools/g81_host_profile.py); each vector starts on a 256-byte boundary
+        // a G81 solve took -- 7 % of the 0.22-s solve, tools/archive/g81_host_profile.py); each vector starts on a 256-byte boundary
         const size_t nvec = sizeof(vecs) / sizeof(vecs[0]);
         const size_t stride = (cnt + 31) / 32 * 32;
         if (h->vec_pool) dev_free(h, h->vec_pool);

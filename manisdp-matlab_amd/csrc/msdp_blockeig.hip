@@ -690,7 +690,7 @@ int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const 
     if (!Mdense && own_rows && h->d.ellW > 0 && h->d.n_loc == n) { a.ellW = h->d.ellW; a.ell_stride = h->d.ell_stride; a.ellc = h->d.ellc; a.ellv = h->d.ellv; }
     {
         // grid: one workgroup per CU while its rows fit one pass of eight lanes per row (16 waves x 8 rows = 128 rows), two
-        // beyond; measured on G81 (tools/blockeig_tune.py): 256 workgroups x 8 lanes 19.2 ms for the cold check, 512 x 16 lanes
+        // beyond; measured on G81 (tools/archive/blockeig_tune.py): 256 workgroups x 8 lanes 19.2 ms for the cold check, 512 x 16 lanes
         // 21.8, 128 x 8 lanes 24.1
         int G = (((n + 15) / 16 + 7) / 8) * 8;
         if (G > 256) G = (n > 256 * 128) ? 512 : 256;

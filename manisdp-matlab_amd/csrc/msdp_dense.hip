@@ -436,7 +436,7 @@ static void dense_plan(msdp_handle h, int nmat, int* row_blocks_out, int* SK_out
         // k_dense_hess_epi_obl behind the adjoint): there every slab costs more than its bytes, and two workgroups per CU stream
         // a 30-200 MB operand as fast as five.  Round 4, tools/affine_chain_probe.py --sk=..: theta n = 5000 16 slabs 67.5 us,
         // 6-12 slabs 61-62 us; BQP d = 60 29 slabs 59.6 us, 16 slabs 56.5 us (the dense kinds keep the full-occupancy plan:
-        // tools/dense_sk_probe.py has it within 1-5 % of the best slice count at n = 1000..20000, p = 16..64)
+        // tools/archive/dense_sk_probe.py has it within 1-5 % of the best slice count at n = 1000..20000, p = 16..64)
         if (d.costkind == COST_AFFINE) {
             int dev = 0, cus = 256;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cus = 256; }

@@ -268,7 +268,7 @@ static sym_fn_t sym_fn(int NT, int RT, int WV, bool db) {
 // shape of a workgroup: dense_sym_rt = 1: 8 waves x 16 rows (RB = 128); 2: 8 waves x 32 rows (RB = 256); 3: 16 waves x 16 rows (RB = 256)
 static void sym_shape(msdp_handle h, int NT, int* RT, int* WV) {
     int mode = h->tune.dense_sym_rt;
-    // measured (tools/densesym_probe.py, n = 20000: p = 16 551 us full / 414 / 384 / 444 for the shapes 1 / 2 / 3; p = 32: 613 /
+    // measured (tools/archive/densesym_probe.py, n = 20000: p = 16 551 us full / 414 / 384 / 444 for the shapes 1 / 2 / 3; p = 32: 613 /
     // 650 / 594 / 607; n = 10000, p = 32: 177 / 182 / 173 / 166)
     if (!mode) mode = NT == 1 ? 2 : (h->d.n >= 16000 ? 2 : 3);
     *RT = mode == 2 ? 2 : 1;

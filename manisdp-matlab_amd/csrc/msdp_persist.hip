@@ -153,7 +153,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     constexpr bool TWOSYNC = !LOWREG;
     // Round 2 published the rows of r_new themselves: the normal component r accumulates (rounding of :238, never projected)
     // stayed in cmd, and with it |Heta - Hess(eta)| / |Heta| reached 3e-9 after 100 trips on G81 where the direct products of the
-    // chunked path stay at 5e-14 (tools/tcg_invariant_probe.py).  Publishing tangent(r_new) removes the
+    // chunked path stay at 5e-14 (tools/archive/tcg_invariant_probe.py).  Publishing tangent(r_new) removes the
     // source; what the re-projection of mdelta_old + beta-scaling still leaves (1e-16 per trip) is reset by a direct exchange
     // every `refresh`-th trip, which ends like a three-synchronisation trip: the workgroups
     // publish the rows of the NEW DIRECTION after beta is known, a value-less barrier follows, and the next product is gathered
@@ -834,7 +834,7 @@ static persist_fn persist_kernel_pipe(const PersistPlan& pl, bool fuse = false) 
     if (pl.lpr == 16 && pl.r == 3) return fuse ? k_tcg_pipe_obl<16, 5, 3, false, true> : k_tcg_pipe_obl<16, 5, 3>;
     if (pl.lpr == 8 && pl.r == 2) return fuse ? k_tcg_pipe_obl<8, 5, 2, false, true> : k_tcg_pipe_obl<8, 5, 2>;
     // (four row slots -- 97..128 rows per workgroup at p = 17..32, 129..256 at p <= 16: the sixth resident vector spills, measured
-    // 9.6 us per trip against 8.2 for the two-reduction trip on a 180 x 180 grid at p = 32; tools/pipe_sizes_probe.py)
+    // 9.6 us per trip against 8.2 for the two-reduction trip on a 180 x 180 grid at p = 32; tools/archive/pipe_sizes_probe.py)
     return nullptr;
 }
 // early: 0 none, 1 the EARLY trip, 2 the one-reduction trip
@@ -902,7 +902,7 @@ static int persist_grid(const Dev& d) {
     // (round 5: NOT d.G -- the grid of the row-parallel kernels follows THEIR lanes per row: 4 lanes at p <= 8, i.e. 256 rows per
     // pass and 80 workgroups for G81, on which this kernel (8 lanes per row at least) needed its four-slot instance and left two
     // thirds of the CUs idle: p = 8 6.8 us per trip against 5.5 at p = 16, p = 4 not eligible at all (12.6 us on the chunked path);
-    // tools/p_sweep_probe.py)
+    // tools/archive/p_sweep_probe.py)
     int g = 256;                                       // psync polls 4 x 64 slots
     if (g > cus) g = (cus / 8) * 8;
     // the fewest workgroups that need the same number of row slots: a workgroup with 93 rows in three slots of 32 takes as
@@ -911,7 +911,7 @@ static int persist_grid(const Dev& d) {
     if (g >= 8 && persist_plan(d, g, pl)) {
         // (CSR rows, round 5: the row slots of a workgroup are walked one after the other, each a chain of gather batches as long as
         // its longest row, and an empty slot is skipped -- ONE slot per workgroup while the CUs last: G1, 800 rows of ~49 entries,
-        // 8 workgroups x 2 slots 20.7 us per trip, 16 x 1 12.8; tools/g1_trip_probe.py)
+        // 8 workgroups x 2 slots 20.7 us per trip, 16 x 1 12.8; tools/archive/g1_trip_probe.py)
         const int cap = (pl.ew == 0 ? 1 : pl.r) * PWAVES * (64 / pl.lpr);
         int gmin = (((d.n_loc + cap - 1) / cap + 7) / 8) * 8;
         if (gmin < 8) gmin = 8;

@@ -175,7 +175,7 @@ __device__ __forceinline__ bool psync8_lines(unsigned long long* slots, unsigned
     double t0 = 0.0, t1 = 0.0;
     int spins = 0;
     bool fail = false;
-    const int first = ((backoff >> 16) & 0xff) ? ((backoff >> 16) & 0xff) : (backoff & 0xff);   // (19 units by default: tools/pipe_ab_probe.py)
+    const int first = ((backoff >> 16) & 0xff) ? ((backoff >> 16) & 0xff) : (backoff & 0xff);   // (19 units by default: tools/archive/pipe_ab_probe.py)
     for (int q = 0; q < first; ++q) __builtin_amdgcn_s_sleep(1);
     if (tr && threadIdx.x == 0) tr[3] = __builtin_readcyclecounter();
     if (__builtin_amdgcn_ballot_w64(in0) != 0ULL) {               // (a wave whose 32 workgroups do not exist has nothing to wait for)

@@ -321,7 +321,7 @@ static inline void t1_lpr_for(int ld, int& lpr, int& nch) {
 }
 
 // trip1 = 1 (default): every row-sharded handle with sparse C on the oblique manifold, and the chunked path of a single rank
-// (measured, tools/trip1_single_probe.py and trip1_small_probe.py, linear / two-launch / three-launch: n = 10^6, p = 32: 773 /
+// (measured, tools/archive/trip1_single_probe.py and trip1_small_probe.py, linear / two-launch / three-launch: n = 10^6, p = 32: 773 /
 // 889 / 943 us per trip; n = 250 000, p = 32: 190 / 227 / 216; n = 40 000, p = 40: 51 / 63 / 57; G81 with the persistent kernel
 // off, p = 32: 21.7 / 25.4 / 23.7, p = 128: 62 / 67 / 75; G1 (CSR rows), p = 40: 34.4 / 48.2 / 34.7); 0: the two- / three-launch
 // trips (msdp_trip2.hip, msdp_kernels.hip)

@@ -339,7 +339,7 @@ static inline void t2_lpr_for(int ld, int& lpr, int& nch) {
 
 // Where it pays: the head kernel recomputes the direction of every gathered row from three vectors (15 row gathers per row on a
 // grid graph instead of 5), which costs more than the five saved vector passes until the vectors are large -- measured
-// (tools/trip2_probe.py): G81 (n = 20000) p = 32: 23.6 against 23.9 us, p = 64: 49 against 45; n = 250 000, p = 64: 406 against 459;
+// (tools/archive/trip2_probe.py): G81 (n = 20000) p = 32: 23.6 against 23.9 us, p = 64: 49 against 45; n = 250 000, p = 64: 406 against 459;
 // n = 10^6, p = 32: 858 against 940 us.  trip2 = 1 (default): from 2^21 vector entries on; 2: always (tests); 0: never.
 int msdp_trip2_ok(msdp_handle h) {
     const Dev& d = h->d;

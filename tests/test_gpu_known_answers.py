@@ -143,7 +143,7 @@ def test_unitdiag_thetaG51():
     """data/sdplib/README:105: thetaG51 (n = 1001, m = 6910, printed 3.49000e+02), a unit-diagonal instance like thetaG11.  With the
     reference's defaults the algorithm stops at 349.0074 (status 1; the oracle likewise, 300 s on the CPU); with the option set of
     the gpp family (tests above) the value reaches the six printed digits within 60 outer iterations while the residues crawl
-    (pinf 2e-5 at iteration 60, 4e-6 at 120: tools/thetaG51_opts.py) -- as for gpp, the digits are the pin."""
+    (pinf 2e-5 at iteration 60, 4e-6 at 120: tools/archive/thetaG51_opts.py) -- as for gpp, the digits are the pin."""
     from manisdp_matlab_amd import solvers
     At, b, c, K = _sdpa("thetaG51")
     Y, obj, data = solvers.ManiSDP_unitdiag(At, b, c, K, dict(GPP_OPTS, tol=1e-6, AL_maxiter=60, eig="host"), verbose=False)

@@ -15,7 +15,7 @@ KNOWN = json.load(open(golden_path("known_answers.json")))
 PRINTED = json.load(open(golden_path("known_answers_printed.json")))       # the same values as data/sdplib/README prints them
 
 # Option sets under which the reference's algorithm reaches KKT 1e-8 on the SDPLIB families whose defaults are tuned for
-# other problems (found on the oracle, tools/theta_ref_opts.py): a larger trust-region budget per outer iteration.
+# other problems (found on the oracle, tools/archive/theta_ref_opts.py): a larger trust-region budget per outer iteration.
 THETA_OPTS = dict(tol=1e-8, TR_maxiter=30, TR_maxinner=200)
 GPP_OPTS = dict(sigma0=1e-1, sigma_min=1e-1, tau1=1e-2, tau2=1e-1, TR_maxinner=40, TR_maxiter=6)
 
