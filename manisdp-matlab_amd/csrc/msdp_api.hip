@@ -1030,6 +1030,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "persist_goff")) t.persist_goff = value ? 1 : 0;
     else if (!strcmp(name, "persist_slots")) { t.persist_slots = (value == 3 || value == 4) ? value : 0; h->d.persist_slots = t.persist_slots; }
     else if (!strcmp(name, "psync_backoff")) t.psync_backoff = value > 0 ? value : 0;
+    else if (!strcmp(name, "psync8_backoff")) t.psync8_backoff = value > 0 ? (value > 255 ? 255 : value) : 0;
     else if (!strcmp(name, "affine_overlap")) { t.affine_overlap = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "trip1")) { t.trip1 = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; }
     else if (!strcmp(name, "dense_sk")) t.dense_sk = value < 0 ? 0 : value;
@@ -2081,6 +2082,7 @@ static void fill_ctl(msdp_handle h, const msdp_rtr_opts* o) {
     c->pipe_local = h->tune.pipe_local;
     c->persist_goff = h->tune.persist_goff;
     c->psync_backoff = h->tune.psync_backoff;
+    c->psync8_backoff = h->tune.psync8_backoff;
     // trustregions.m:363-372; typicaldist: pi*sqrt(n) (ManiSDP_onlyunitdiag.m:137) or pi (spherefactory.m:111)
     // ... or sqrt(n*p) (euclideanfactory.m:57)
     const double typical = (h->d.manifold == MANI_OBLIQUE) ? M_PI * sqrt((double)h->d.n)

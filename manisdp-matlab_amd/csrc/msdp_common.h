@@ -37,6 +37,7 @@ struct Ctl {
     int hessvecs, accepted, rejected, cost_evals, last_stop_inner;
     int bench_mode;              // 1: tCG exits disabled (throughput measurement)
     int tcg_running;             // mirror of Frame.active for host polling
+    int psync8_backoff;          // the eight-value reduction of the one-reduction trip (msdp_pipe.h): units before its first poll where bits 16..23 of psync_backoff are 0
     int psync_backoff;           // grid reductions of the persistent kernels: (s_sleep units of 64 cycles before the first poll) | (units after a failed poll) << 8
     int persist_goff;            // persistent tCG: gather offsets kept in registers (A/B)
     int pipe_local;              // one-reduction trip: 1 = rows of the own workgroup from LDS / registers, 0 = every row through the exchange buffer
@@ -188,6 +189,7 @@ struct Tuning {
                              //   reductions and row exchange through shared uncached memory, no collective per trip (msdp_persist.hip XR); 0: lock-step chunks
     int xtail = 1;           // process ranks (msdp_comm_init_ipc): the rest of a TR iteration behind the cross-rank tCG is one launch per member as well
                              //   (retraction, cost / gradient at the proposal, decision; msdp_trtail.hip XR); 0: sharded kernels with their collectives
+    int psync8_backoff = 16;   // eight-value reduction of the one-reduction trip: units slept before the first poll (round 6: 16 against 19, 0.8 % of a G81 call)
     int psync_backoff = 19;  // grid reductions of the persistent kernels: s_sleep units (64 cycles) before the first poll | units after a
                              //   failed poll << 8.  Round 4: nothing can be visible for the first half microsecond after the posts, and
                              //   the polls of 216 workgroups are the traffic the posts compete with -- G81, p = 32: 8.03 us per trip

@@ -492,7 +492,8 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
 #define ROK(r) (ROW(r) < hi)
 #define OK(r) (ROK(r) && colok)
     const int refresh = c->pipe_refresh;
-    const int backoff = c->psync_backoff;
+    // (bits 16..23 = this reduction's own figure; the option psync8_backoff fills them where psync_backoff leaves them empty)
+    const int backoff = (c->psync_backoff & 0xff00ffff) | ((((c->psync_backoff >> 16) & 0xff) ? ((c->psync_backoff >> 16) & 0xff) : (c->psync8_backoff & 0xff)) << 16);
     const double2 zz = make_double2(0.0, 0.0);
     constexpr bool LOC = R * EW <= 15;                             // (four row slots: the source selection costs registers that spill)
     constexpr bool MULTI = LOC && !(FUSE && LPR >= 16);            // three instances of the trip loop (per-wave local columns), see below
