@@ -507,6 +507,13 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         if (!OK(r)) { y = zz; g = zz; }
         Ys[r * PB + threadIdx.x] = y; Gs[r * PB + threadIdx.x] = g;
         eta[r] = zz; rr[r] = g; md[r] = g; hmd[r] = zz; cmd[r] = zz; ctr[r] = zz;       // tCG.m:102-157
+    }
+    // (the ELL rows in a loop of their own, NOT unrolled: nothing in it is indexed by the row slot but LDS, and unrolled next to the
+    // register set-up above its sort was where the kernel's first spills came from)
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+        const bool rok = ROK(r);
+        const int rc = rok ? ROW(r) : lo;
         const double egv = eGl[rc];
         int cw[EW];
         double vw[EW];

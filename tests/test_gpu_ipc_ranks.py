@@ -24,6 +24,8 @@ def _run_ranks(N, rows, cols, p, tmp_path, devices=None, two_level=False):
     env.setdefault("MSDP_LOCAL_BARRIER_TIMEOUT", "60")
     if two_level:
         env["MSDP_TEST_XR_TWOLEVEL"] = "1"
+    if N > 4 and devices is None:
+        env["MSDP_TEST_LIGHT"] = "1"                # (eight processes share one device: see the worker)
     for r in range(N):
         out = str(tmp_path / ("rank%d.npz" % r))
         outs.append(out)
