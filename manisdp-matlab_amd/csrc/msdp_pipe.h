@@ -403,7 +403,8 @@ __device__ __forceinline__ bool psync2_8(unsigned long long* blk, unsigned long 
 // 2 the two-level ones (psync2_8: members on devices of their own, N <= 8).  The rows travel as there: every member's exchange buffer holds
 // its rows and a slot per foreign row its rows of C reference (buffer-local column indices d.xr_ellc), the owner of a boundary row
 // stores it into the slots of the members that reference it (d.xr_paddr) -- here in four regions (H md alternating, the refresh rows),
-// and the first direction (the gradient, which every member keeps to itself) is published behind one barrier.
+// and the first direction (the gradient, which every member keeps to itself) is published behind one barrier.  XRM = 2: the gathers are
+// system-scope loads (a halo slot may have been stored by another device), the pushed rows and member sums system-scope stores.
 template <int LPR, int EW, int R, bool TRACE, bool FUSE, int XRM = 0>
 __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* slots, int* err, const int bx) {
     constexpr bool XR = XRM != 0, XTWO = XRM == 2;
@@ -655,7 +656,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
             _Pragma("unroll") for (int w = 0; w < NG; ++w) { \
                 if ((w0) + w < EW) { \
                     const int cidx = cs[((w0) + w) * ROWS + SLOT(r)]; \
-                    X[r][w] = ld2_sc1((rs), (base) + ((unsigned)cidx * gld + gcol) * 8u); } } } while (0)
+                    X[r][w] = ld2_cp<XTWO ? 17 : MSDP_CPOL_SC1>((rs), (base) + ((unsigned)cidx * gld + gcol) * 8u); } } } while (0)
 #define PIPE_FOLDX(r, acc, w0) do { \
             _Pragma("unroll") for (int w = 0; w < NG; ++w) { \
                 if ((w0) + w < EW) { \

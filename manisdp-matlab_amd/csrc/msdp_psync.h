@@ -34,6 +34,16 @@ __device__ __forceinline__ double2 ld2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned b
     o.y = __longlong_as_double(((long long)v.w << 32) | (long long)v.z);
     return o;
 }
+// the same gather with the cache policy as a template argument: MSDP_CPOL_SC1 (agent scope) on one device, 17 = sc0 | sc1 (system scope)
+// where the row may have been stored by another device (the two-level cross-rank instances)
+template <int CPOL>
+__device__ __forceinline__ double2 ld2_cp(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, CPOL);
+    double2 o;
+    o.x = __longlong_as_double(((long long)v.y << 32) | (long long)v.x);
+    o.y = __longlong_as_double(((long long)v.w << 32) | (long long)v.z);
+    return o;
+}
 __device__ __forceinline__ void st2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, double2 d2) {
     const long long a = __double_as_longlong(d2.x), b = __double_as_longlong(d2.y);
     v4u v;

@@ -21,7 +21,7 @@ def _run_ranks(N, rows, cols, p, tmp_path, devices=None, two_level=False):
     name = "/msdp_test_%d_%d" % (os.getpid(), _counter[0])
     procs, outs = [], []
     env = dict(os.environ)
-    env.setdefault("MSDP_LOCAL_BARRIER_TIMEOUT", "60")
+    env.setdefault("MSDP_LOCAL_BARRIER_TIMEOUT", "180")     # (a fresh box pages the libraries in: eight processes starting at once can be a minute apart)
     if two_level:
         env["MSDP_TEST_XR_TWOLEVEL"] = "1"
     if N > 4 and devices is None:
@@ -38,7 +38,7 @@ def _run_ranks(N, rows, cols, p, tmp_path, devices=None, two_level=False):
     try:
         for pr in procs:
             try:
-                pr.wait(timeout=300)
+                pr.wait(timeout=600)
             except subprocess.TimeoutExpired:
                 pr.kill()
                 pr.wait()
