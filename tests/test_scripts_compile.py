@@ -7,7 +7,7 @@ import py_compile
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCRIPTS = sorted(glob.glob(os.path.join(ROOT, "examples", "*.py")) + glob.glob(os.path.join(ROOT, "tools", "*.py")) +
+SCRIPTS = sorted(glob.glob(os.path.join(ROOT, "examples", "*.py")) + glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "tools", "archive", "*.py")) +
                  glob.glob(os.path.join(ROOT, "tests", "diagnostics", "*.py")) + glob.glob(os.path.join(ROOT, "tests", "golden", "*.py")) +
                  [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")])
 
