@@ -1160,7 +1160,7 @@ static int up(msdp_handle h, const std::vector<T>& v, const T** out) {
     void* p = nullptr;
     int rc = msdp_dev_alloc_bytes(h, &p, v.size() * sizeof(T));
     if (rc) return rc;
-    if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!v.empty()) HIPCHK(msdp_memcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = (const T*)p;
     return 0;
 }
@@ -1506,13 +1506,13 @@ int msdp_affine_setup(msdp_handle h, const int64_t* jc, const int64_t* ir, const
     if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
     st->Cdense = (double*)p; d.Cd = st->Cdense;
     HIPCHK(hipMemset(st->Cdense, 0, msz));
-    HIPCHK(hipMemcpy2D(st->Cdense, (size_t)a.nS * sizeof(double), c, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n,
+    HIPCHK(msdp_memcpy2d(st->Cdense, (size_t)a.nS * sizeof(double), c, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n,
                        hipMemcpyHostToDevice));
     for (int s = 0; s < 2; ++s) {
         if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
         d.eS[s] = (double*)p;
         // restricted adjoint: eS = C outside the entries At touches, from the start
-        if (a.nsup > 0) HIPCHK(hipMemcpy(d.eS[s], st->Cdense, msz, hipMemcpyDeviceToDevice));
+        if (a.nsup > 0) HIPCHK(msdp_memcpy(d.eS[s], st->Cdense, msz, hipMemcpyDeviceToDevice));
         else HIPCHK(hipMemset(d.eS[s], 0, msz));
     }
     if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
@@ -1667,7 +1667,7 @@ int msdp_affine_setup_blocked(msdp_handle h, int nb, const int64_t* block_n, con
                 for (int aa = 0; aa < bn[i]; ++aa) cb[(size_t)(off[i] + (int64_t)aa * bns[i] + bb)] = c[e0[i] + aa + (int64_t)bb * bn[i]];
         if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
         st->Cdense = (double*)p; d.Cd = st->Cdense;
-        HIPCHK(hipMemcpy(st->Cdense, cb.data(), msz, hipMemcpyHostToDevice));
+        HIPCHK(msdp_memcpy(st->Cdense, cb.data(), msz, hipMemcpyHostToDevice));
     }
     for (int s2 = 0; s2 < 2; ++s2) {
         if ((rc = msdp_dev_alloc_bytes(h, &p, msz))) return rc;
@@ -1691,7 +1691,7 @@ int msdp_affine_get_block(msdp_handle h, int64_t row0, int64_t nbk, double* S) {
     if (!st || !st->blk) { msdp_set_error("get_block: not a handle with per-block storage"); return MSDP_ESTATE; }
     for (size_t i = 0; i + 1 < st->blk_r0.size(); ++i)
         if (st->blk_r0[i] == row0 && st->blk_n[i] == nbk) {
-            HIPCHK(hipMemcpy2DAsync(S, (size_t)nbk * sizeof(double), h->d.Sdual + st->blk_off[i], (size_t)st->blk_ns[i] * sizeof(double),
+            HIPCHK(msdp_memcpy2d_async(S, (size_t)nbk * sizeof(double), h->d.Sdual + st->blk_off[i], (size_t)st->blk_ns[i] * sizeof(double),
                                     (size_t)nbk * sizeof(double), (size_t)nbk, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
             return 0;
@@ -1714,7 +1714,7 @@ int msdp_affine_set_multipliers(msdp_handle h, const double* y, double sigma) {
     AffineState* st = astate(h);
     if (!st) { msdp_set_error("affine state missing"); return MSDP_ESTATE; }
     if (!(sigma > 0)) { msdp_set_error("sigma must be positive"); return MSDP_EINVAL; }
-    HIPCHK(hipMemcpyAsync(st->d_y, y, st->a.m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(st->d_y, y, st->a.m * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     st->sigma = sigma;
     h->h_ctl->sigma = sigma;
@@ -1940,7 +1940,7 @@ static int full_rows(msdp_handle h, int slot, const double* local, bool gathered
     if (!h->yfull[slot]) { msdp_set_error("row-sharded affine handle without gather buffers"); return MSDP_ESTATE; }
     if (!gathered) { int rc = msdp_allgather_rows(h, local); if (rc) return rc; }
     const size_t cap = (size_t)((h->d.n + h->nranks - 1) / h->nranks);
-    HIPCHK(hipMemcpyAsync(h->yfull[slot], h->d.full, cap * h->nranks * (size_t)h->d.ld * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(h->yfull[slot], h->d.full, cap * h->nranks * (size_t)h->d.ld * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     *out = h->yfull[slot];
     return 0;
 }
@@ -2210,7 +2210,7 @@ int msdp_affine_linesearch_cost(msdp_handle h, const double* Yt, double* val) {
     hipLaunchKernelGGL(k_cost_only, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, d, sigma, &d.ctl->fx_prop);
     HIPCHK(hipGetLastError());
     double v = 0.0;
-    HIPCHK(hipMemcpyAsync(&v, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(&v, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     *val = v;
     return 0;
@@ -2251,8 +2251,8 @@ int msdp_affine_al_primal(msdp_handle h, double* obj, double* Ax_host) {
     if ((rc = msdp_allreduce_partials(h, P_S1, 1))) return rc;
     if ((rc = msdp_k_sum_to_fwd(h, P_S1, &d.ctl->fx_prop))) return rc;
     double v = 0.0;
-    HIPCHK(hipMemcpyAsync(&v, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(Ax_host, a.w, (size_t)a.m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(&v, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(Ax_host, a.w, (size_t)a.m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     *obj = v;
     return 0;
@@ -2267,7 +2267,7 @@ int msdp_affine_al_dual(msdp_handle h, const double* y_host, double* z_host) {
     a.p = d.p; a.ld = d.ld;
     const int cur = h->h_ctl->cur;
     const double* Ys = d.Y[cur];
-    HIPCHK(hipMemcpyAsync(a.w, y_host, (size_t)a.m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(a.w, y_host, (size_t)a.m * sizeof(double), hipMemcpyHostToDevice, h->stream));
     // full sweep: the diagonal of Sdual was modified by k_sub_diag after the previous call
     { int rca = launch_adjoint(h, a, d.Cd, (const double*)a.w, -1.0, d.Sdual, (const int*)nullptr, 0, false); if (rca) return rca; }
     if (d.manifold == MANI_EUCLID) { HIPCHK(hipStreamSynchronize(h->stream)); return 0; }
@@ -2292,13 +2292,13 @@ int msdp_affine_al_dual(msdp_handle h, const double* y_host, double* z_host) {
         if (st->blk) hipLaunchKernelGGL(k_sub_diag_blocked, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, *st->blk, d.Sdual, zall);
         else hipLaunchKernelGGL(k_sub_diag, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, a.n, a.nS, d.Sdual, zall, (const double*)nullptr);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(z_host, zall, (size_t)a.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(msdp_memcpy_async(z_host, zall, (size_t)a.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     } else {
         if ((rc = msdp_allreduce_partials(h, P_S2, 1))) return rc;
         if ((rc = msdp_k_sum_to_fwd(h, P_S2, &d.ctl->fx_prop))) return rc;
         hipLaunchKernelGGL(k_sub_diag, dim3((a.n + 255) / 256), dim3(256), 0, h->stream, a.n, a.nS, d.Sdual, (const double*)nullptr, (const double*)&d.ctl->fx_prop);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(z_host, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(msdp_memcpy_async(z_host, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
@@ -2571,7 +2571,7 @@ static int dual_linesearch_cost(msdp_handle h, AffineState* st, const double* Yt
     const int other = h->h_ctl->cur ^ 1;
     if ((rc = dual_cost_state(h, st, Yt, d.eS[other], (const int*)nullptr, 0))) return rc;
     double v = 0.0;
-    HIPCHK(hipMemcpyAsync(&v, ds->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(&v, ds->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     *val = v;
     return 0;
@@ -2623,7 +2623,7 @@ int msdp_dual_setup(msdp_handle h, const int64_t* at_jc, const int64_t* at_ir, c
         *mats[q] = (double*)p;
         HIPCHK(hipMemset(p, 0, msz));
     }
-    HIPCHK(hipMemcpy(ds->bA, bA.data(), msz, hipMemcpyHostToDevice));
+    HIPCHK(msdp_memcpy(ds->bA, bA.data(), msz, hipMemcpyHostToDevice));
     const size_t ppsz = (size_t)DUAL_PP_MAXLD * DUAL_PP_MAXLD * sizeof(double);
     double** pps[3] = {&ds->G2[0], &ds->G2[1], &ds->M1};
     for (int q = 0; q < 3; ++q) {
@@ -2652,7 +2652,7 @@ int msdp_dual_set_penalty_impl(msdp_handle h, double sigma, const double* wf_hos
     DualState* ds = st->dual;
     if (ds->nf > 0) {
         if (!wf_host) { msdp_set_error("dual_set_penalty: w is null"); return MSDP_EINVAL; }
-        HIPCHK(hipMemcpyAsync(ds->wf, wf_host, (size_t)ds->nf * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(msdp_memcpy_async(ds->wf, wf_host, (size_t)ds->nf * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
     st->sigma = sigma;
     h->h_ctl->sigma = sigma;
@@ -2695,9 +2695,9 @@ int msdp_dual_outer_step_impl(msdp_handle h, double* scal_host, double* Af_host,
                        (const double*)ds->bA, (const double*)d.Cd, sigma, d.W0);
     HIPCHK(hipGetLastError());
     if ((rc = msdp_k_sum_to_fwd(h, P_S2, ds->scal + 2)) || (rc = msdp_k_sum_to_fwd(h, P_S3, ds->scal + 3))) return rc;
-    HIPCHK(hipMemcpyAsync(scal_host, ds->scal + 1, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (ds->nf > 0) HIPCHK(hipMemcpyAsync(Af_host, ds->Af, (size_t)ds->nf * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(z_host, d.W0, (size_t)a.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(scal_host, ds->scal + 1, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (ds->nf > 0) HIPCHK(msdp_memcpy_async(Af_host, ds->Af, (size_t)ds->nf * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(z_host, d.W0, (size_t)a.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     ds->T_valid = false;
     return 0;
@@ -2706,7 +2706,7 @@ int msdp_dual_outer_step_impl(msdp_handle h, double* scal_host, double* Af_host,
 int msdp_dual_get_y_impl(msdp_handle h, double* y_host) {
     AffineState* st = astate(h);
     if (!st || !st->dual) { msdp_set_error("dual_get_y: not a dual handle"); return MSDP_ESTATE; }
-    HIPCHK(hipMemcpyAsync(y_host, st->a.w, (size_t)st->a.m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(y_host, st->a.w, (size_t)st->a.m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }

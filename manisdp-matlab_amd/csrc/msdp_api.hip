@@ -432,10 +432,10 @@ static int upload_sparse_rows(msdp_handle h) {
     if ((rc = dev_alloc<int>(h, &h->d_rowptr, rp.size()))) return rc;
     if ((rc = dev_alloc<int>(h, &h->d_colind, (size_t)nnz))) return rc;
     if ((rc = dev_alloc<double>(h, &h->d_cval, (size_t)nnz))) return rc;
-    HIPCHK(hipMemcpy(h->d_rowptr, rp.data(), rp.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(msdp_memcpy(h->d_rowptr, rp.data(), rp.size() * sizeof(int), hipMemcpyHostToDevice));
     if (nnz) {
-        HIPCHK(hipMemcpy(h->d_colind, h->h_colind.data() + base, nnz * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(h->d_cval, h->h_cval.data() + base, nnz * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(msdp_memcpy(h->d_colind, h->h_colind.data() + base, nnz * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(msdp_memcpy(h->d_cval, h->h_cval.data() + base, nnz * sizeof(double), hipMemcpyHostToDevice));
     }
     d.rowptr = h->d_rowptr; d.colind = h->d_colind; d.cval = h->d_cval; d.nnz = nnz;
     // ELL copy when every row is short (fixed-degree graphs such as G81: W = 5)
@@ -461,8 +461,8 @@ static int upload_sparse_rows(msdp_handle h) {
         if (h->d_ellv) dev_free(h, h->d_ellv);
         if ((rc = dev_alloc<int>(h, &h->d_ellc, ec.size()))) return rc;
         if ((rc = dev_alloc<double>(h, &h->d_ellv, ev.size()))) return rc;
-        HIPCHK(hipMemcpy(h->d_ellc, ec.data(), ec.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(h->d_ellv, ev.data(), ev.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(msdp_memcpy(h->d_ellc, ec.data(), ec.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(msdp_memcpy(h->d_ellv, ev.data(), ev.size() * sizeof(double), hipMemcpyHostToDevice));
         d.ellW = W; d.ell_stride = (int64_t)cap; d.ellc = h->d_ellc; d.ellv = h->d_ellv;
     }
     return 0;
@@ -559,7 +559,7 @@ extern "C" int msdp_debug_set_full_rows(msdp_handle h, const double* rows_host) 
     const size_t cnt = (size_t)d.n * d.p;
     double* stage = nullptr;
     if (hipMalloc((void**)&stage, cnt * sizeof(double)) != hipSuccess) { msdp_set_error("staging alloc failed"); return MSDP_ENOMEM; }
-    hipError_t e = hipMemcpyAsync(stage, rows_host, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    hipError_t e = msdp_memcpy_async(stage, rows_host, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream);
     int rc = 0;
     if (e != hipSuccess) { msdp_set_error("H2D failed"); rc = MSDP_EHIP; }
     if (!rc) rc = msdp_k_pack(h, stage, h->full_buf, d.n, d.p, d.ld, false);
@@ -621,7 +621,7 @@ extern "C" int msdp_create_multiblock(int32_t nb, const int64_t* block_n, int32_
         if (anyb) {
             unsigned char* drf = nullptr;
             if ((rcb = dev_alloc<unsigned char>(hb, &drf, (size_t)N))) { msdp_destroy(hb); return rcb; }
-            if (hipMemcpy(drf, rfb.data(), (size_t)N, hipMemcpyHostToDevice) != hipSuccess) { msdp_set_error("multiblock: upload failed"); msdp_destroy(hb); return MSDP_EHIP; }
+            if (msdp_memcpy(drf, rfb.data(), (size_t)N, hipMemcpyHostToDevice) != hipSuccess) { msdp_set_error("multiblock: upload failed"); msdp_destroy(hb); return MSDP_EHIP; }
             hb->d.rowfree = drf;
         }
         *out = hb;
@@ -655,7 +655,7 @@ extern "C" int msdp_create_multiblock(int32_t nb, const int64_t* block_n, int32_
     if (any) {
         unsigned char* drf = nullptr;
         if ((rc = dev_alloc<unsigned char>(h, &drf, (size_t)N))) { msdp_destroy(h); return rc; }
-        if (hipMemcpy(drf, rf.data(), (size_t)N, hipMemcpyHostToDevice) != hipSuccess) { msdp_set_error("multiblock: upload failed"); msdp_destroy(h); return MSDP_EHIP; }
+        if (msdp_memcpy(drf, rf.data(), (size_t)N, hipMemcpyHostToDevice) != hipSuccess) { msdp_set_error("multiblock: upload failed"); msdp_destroy(h); return MSDP_EHIP; }
         h->d.rowfree = drf;
     }
     if (nb > 1) {                                          // block ranges per row: the dense contraction skips the zero off-diagonal blocks
@@ -664,8 +664,8 @@ extern "C" int msdp_create_multiblock(int32_t nb, const int64_t* block_n, int32_
             for (int64_t a = r0[i]; a < r0[i + 1]; ++a) { lo[(size_t)a] = (int)r0[i]; hi[(size_t)a] = (int)r0[i + 1]; }
         int *dlo = nullptr, *dhi = nullptr;
         if ((rc = dev_alloc<int>(h, &dlo, (size_t)N)) || (rc = dev_alloc<int>(h, &dhi, (size_t)N))) { msdp_destroy(h); return rc; }
-        if (hipMemcpy(dlo, lo.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dhi, hi.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { msdp_set_error("multiblock: upload failed"); msdp_destroy(h); return MSDP_EHIP; }
+        if (msdp_memcpy(dlo, lo.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+            msdp_memcpy(dhi, hi.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { msdp_set_error("multiblock: upload failed"); msdp_destroy(h); return MSDP_EHIP; }
         h->d.blk_lo = dlo; h->d.blk_hi = dhi;
     }
     *out = h;
@@ -779,13 +779,13 @@ static int upload_rows(msdp_handle h, const double* host, double* dst) {
     if (boundary_colmajor(h)) {
         // n x p column-major; each rank reads its row block of every column
         if (h->nranks == 1) {
-            e = hipMemcpyAsync(stage, host, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream);
+            e = msdp_memcpy_async(stage, host, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream);
         } else {
-            e = hipMemcpy2DAsync(stage, (size_t)d.n_loc * sizeof(double), host + d.row0, (size_t)d.n * sizeof(double),
+            e = msdp_memcpy2d_async(stage, (size_t)d.n_loc * sizeof(double), host + d.row0, (size_t)d.n * sizeof(double),
                                  (size_t)d.n_loc * sizeof(double), d.p, hipMemcpyHostToDevice, h->stream);
         }
     } else {
-        e = hipMemcpyAsync(stage, host + (size_t)d.row0 * d.p, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream);
+        e = msdp_memcpy_async(stage, host + (size_t)d.row0 * d.p, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream);
     }
     if (e != hipSuccess) { msdp_set_error("H2D copy failed: %s", hipGetErrorString(e)); rc = MSDP_EHIP; }
     if (!rc) rc = msdp_k_pack(h, stage, dst, d.n_loc, d.p, d.ld, boundary_colmajor(h));
@@ -803,10 +803,10 @@ static int download_rows(msdp_handle h, const double* src, double* host) {
     int rc = msdp_k_unpack(h, src, stage, d.n_loc, d.p, d.ld, boundary_colmajor(h));
     if (!rc) {
         if (boundary_colmajor(h) && h->nranks > 1)
-            e = hipMemcpy2DAsync(host + d.row0, (size_t)d.n * sizeof(double), stage, (size_t)d.n_loc * sizeof(double),
+            e = msdp_memcpy2d_async(host + d.row0, (size_t)d.n * sizeof(double), stage, (size_t)d.n_loc * sizeof(double),
                                  (size_t)d.n_loc * sizeof(double), d.p, hipMemcpyDeviceToHost, h->stream);
         else
-            e = hipMemcpyAsync(host + (boundary_colmajor(h) ? 0 : (size_t)d.row0 * d.p), stage, cnt * sizeof(double),
+            e = msdp_memcpy_async(host + (boundary_colmajor(h) ? 0 : (size_t)d.row0 * d.p), stage, cnt * sizeof(double),
                                hipMemcpyDeviceToHost, h->stream);
         if (e != hipSuccess) { msdp_set_error("D2H copy failed: %s", hipGetErrorString(e)); rc = MSDP_EHIP; }
     }
@@ -881,7 +881,7 @@ extern "C" int msdp_factor_gram(msdp_handle h, double* G) {
         ncclResult_t r = ncclAllReduce(out, out, (size_t)ld * ld, ncclDouble, ncclSum, (ncclComm_t)h->comm, h->stream);
         if (r != ncclSuccess) { msdp_set_error("ncclAllReduce failed: %s", ncclGetErrorString(r)); rc = MSDP_ECOMM; }
     }
-    if (!rc && hipMemcpy2DAsync(G, (size_t)p * sizeof(double), out, (size_t)ld * sizeof(double), (size_t)p * sizeof(double), p,
+    if (!rc && msdp_memcpy2d_async(G, (size_t)p * sizeof(double), out, (size_t)ld * sizeof(double), (size_t)p * sizeof(double), p,
                                 hipMemcpyDeviceToHost, h->stream) != hipSuccess) { msdp_set_error("factor_gram: D2H failed"); rc = MSDP_EHIP; }
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(buf);
@@ -897,7 +897,7 @@ extern "C" int msdp_factor_rotate(msdp_handle h, int32_t r, const double* Q) {
     double* qd = nullptr;
     if (hipMalloc((void**)&qd, (size_t)d.p * r * sizeof(double)) != hipSuccess) { msdp_set_error("factor_rotate: scratch alloc failed"); return MSDP_ENOMEM; }
     int rc = 0;
-    if (hipMemcpyAsync(qd, Q, (size_t)d.p * r * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) { msdp_set_error("factor_rotate: H2D failed"); rc = MSDP_EHIP; }
+    if (msdp_memcpy_async(qd, Q, (size_t)d.p * r * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) { msdp_set_error("factor_rotate: H2D failed"); rc = MSDP_EHIP; }
     if (!rc) rc = msdp_k_frotate(h, rows_capacity(h), r, ldn, d.Y[cur], qd, d.Y[cur ^ 1]);
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(qd);
@@ -917,7 +917,7 @@ extern "C" int msdp_factor_append(msdp_handle h, int32_t k, const double* V, dou
     if (hipMalloc((void**)&vd, (size_t)std::max(d.n_loc, 1) * k * sizeof(double)) != hipSuccess) { msdp_set_error("factor_append: scratch alloc failed"); return MSDP_ENOMEM; }
     int rc = 0;
     // my rows of every column of the n x k column-major V
-    if (hipMemcpy2DAsync(vd, (size_t)d.n_loc * sizeof(double), V + d.row0, (size_t)d.n * sizeof(double), (size_t)d.n_loc * sizeof(double), k,
+    if (msdp_memcpy2d_async(vd, (size_t)d.n_loc * sizeof(double), V + d.row0, (size_t)d.n * sizeof(double), (size_t)d.n_loc * sizeof(double), k,
                          hipMemcpyHostToDevice, h->stream) != hipSuccess) { msdp_set_error("factor_append: H2D failed"); rc = MSDP_EHIP; }
     if (!rc) rc = msdp_k_fappend(h, rows_capacity(h), k, ldn, d.Y[cur], vd, alpha, normalize, d.Y[cur ^ 1]);
     (void)hipStreamSynchronize(h->stream);
@@ -939,7 +939,7 @@ extern "C" int msdp_point_snapshot(msdp_handle h) {
         if (rc) return rc;
         h->snap_cap = cnt;
     }
-    HIPCHK(hipMemcpyAsync(h->snap, h->d.Y[host_cur(h)], cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(h->snap, h->d.Y[host_cur(h)], cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->snap_p = h->d.p;
     return 0;
@@ -949,7 +949,7 @@ extern "C" int msdp_point_restore(msdp_handle h) {
     if (!h->snap || h->snap_p != h->d.p || !h->have_point) { msdp_set_error("point_restore: no snapshot of the current width"); return MSDP_ESTATE; }
     const size_t cnt = (size_t)rows_capacity(h) * h->ldcap;
     h->h_ctl->cur = 0;
-    HIPCHK(hipMemcpyAsync(h->d.Y[0], h->snap, cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(h->d.Y[0], h->snap, cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     h->state_valid = false;
     h->gradnorm_valid = false;
     return 0;
@@ -970,7 +970,7 @@ extern "C" int msdp_debug_get_tcg_step(msdp_handle h, double* eta, double* Heta)
     if (!h->have_point || !eta || !Heta) { msdp_set_error("debug_get_tcg_step: no resident point / null out"); return MSDP_ESTATE; }
     Frame f;
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(&f, &h->d.F[0], sizeof(Frame), hipMemcpyDeviceToHost));
+    HIPCHK(msdp_memcpy(&f, &h->d.F[0], sizeof(Frame), hipMemcpyDeviceToHost));
     const int ix = f.eta_idx ? 1 : 0;
     int rc = download_rows(h, h->d.eta[ix], eta);
     if (!rc) rc = download_rows(h, h->d.Heta[ix], Heta);
@@ -991,7 +991,7 @@ extern "C" int msdp_get_point_all(msdp_handle h, double* Y) {
     double* stage = nullptr;
     if (hipMalloc((void**)&stage, (cnt ? cnt : 1) * sizeof(double)) != hipSuccess) { msdp_set_error("staging alloc failed"); return MSDP_ENOMEM; }
     rc = msdp_k_unpack(h, h->full_buf, stage, d.n, d.p, d.ld, boundary_colmajor(h));
-    if (!rc && hipMemcpyAsync(Y, stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess) { msdp_set_error("D2H copy failed"); rc = MSDP_EHIP; }
+    if (!rc && msdp_memcpy_async(Y, stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess) { msdp_set_error("D2H copy failed"); rc = MSDP_EHIP; }
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(stage);
     return rc;
@@ -1364,8 +1364,8 @@ static int xr_tail(msdp_handle h) {
 }
 static int xr_check(msdp_handle h) {
     int e = 0;
-    HIPCHK(hipMemcpy(&e, h->lgroup->xr_err, sizeof(int), hipMemcpyDeviceToHost));
-    if (!e && h->xr2_blk) HIPCHK(hipMemcpy(&e, xr2_err(h), sizeof(int), hipMemcpyDeviceToHost));    // (the two-level form's word lives in the member's own block)
+    HIPCHK(msdp_memcpy(&e, h->lgroup->xr_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (!e && h->xr2_blk) HIPCHK(msdp_memcpy(&e, xr2_err(h), sizeof(int), hipMemcpyDeviceToHost));    // (the two-level form's word lives in the member's own block)
     if (e) {
         msdp_set_error("cross-rank persistent tCG: a grid synchronisation timed out (a member's launch did not arrive or the workgroups were not co-resident)");
         local_break(h->lgroup);                              // the other members' host-side collectives fail at once instead of waiting for this one
@@ -1387,7 +1387,7 @@ static int group_publish(msdp_handle h, const double* buf, size_t count) {
     LocalGroup* g = h->lgroup;
     if (!g->ipc) { std::lock_guard<std::mutex> lk(g->m); g->ptr[h->rank] = buf; return 0; }
     if (count * sizeof(double) > g->stage_bytes) { msdp_set_error("inter-process communicator: a contribution of %zu bytes exceeds the staging slab (%zu)", count * sizeof(double), g->stage_bytes); local_break(g); return MSDP_ENOMEM; }
-    HIPCHK(hipMemcpyAsync(g->stage + (size_t)h->rank * g->stage_bytes, buf, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(g->stage + (size_t)h->rank * g->stage_bytes, buf, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -1410,7 +1410,7 @@ static int local_allreduce(msdp_handle h, double* buf, size_t count) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     LOCAL_BARRIER(g);                                      // every member has read every contribution
-    HIPCHK(hipMemcpyAsync(buf, h->lc_tmp, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(buf, h->lc_tmp, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return 0;
 }
 static int local_allgather(msdp_handle h, const double* local, double* all, size_t count_per_rank) {
@@ -1419,7 +1419,7 @@ static int local_allgather(msdp_handle h, const double* local, double* all, size
     { int rcp = group_publish(h, local, count_per_rank); if (rcp) return rcp; }
     LOCAL_BARRIER(g);
     for (int r = 0; r < g->n; ++r)
-        HIPCHK(hipMemcpyAsync(all + (size_t)r * count_per_rank, group_peer(g, r), count_per_rank * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(msdp_memcpy_async(all + (size_t)r * count_per_rank, group_peer(g, r), count_per_rank * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     LOCAL_BARRIER(g);                                      // nobody overwrites its slab before everyone has copied it
     return 0;
@@ -1442,7 +1442,7 @@ static int local_halo(msdp_handle h, Halo* ha, int ld) {
             local_break(g);                                    // the peers learn at once, not after the barrier's time limit
             return MSDP_ECOMM;
         }
-        HIPCHK(hipMemcpyAsync(ha->recvbuf + (size_t)ha->recv_off[q] * ld, group_peer(g, q) + (size_t)q_off * ld,
+        HIPCHK(msdp_memcpy_async(ha->recvbuf + (size_t)ha->recv_off[q] * ld, group_peer(g, q) + (size_t)q_off * ld,
                               (size_t)ha->recv_cnt[q] * ld * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1564,7 +1564,7 @@ static int halo_setup(msdp_handle h) {
     ha->ldcap = h->ldcap > 0 ? h->ldcap : ((h->pcap + 1) / 2) * 2;
     auto upi = [&](const std::vector<int>& v, int** out) -> int {
         if (hipMalloc((void**)out, (v.size() ? v.size() : 1) * sizeof(int)) != hipSuccess) return MSDP_ENOMEM;
-        if (!v.empty() && hipMemcpy(*out, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return MSDP_EHIP;
+        if (!v.empty() && msdp_memcpy(*out, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return MSDP_EHIP;
         return 0;
     };
     int rc = upi(sidx, &ha->send_idx);
@@ -1616,7 +1616,7 @@ static int halo_exchange(msdp_handle h, const double* local_rows, bool with_sums
     }
     h->d.full = h->full_buf;
     const size_t own = (size_t)rows_capacity(h) * ld;
-    HIPCHK(hipMemcpyAsync(h->full_buf + (size_t)h->rank * own, local_rows, own * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(h->full_buf + (size_t)h->rank * own, local_rows, own * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     if (ha->send_rows > 0) {
         const int64_t tot = (int64_t)ha->send_rows * ld;
         hipLaunchKernelGGL(k_halo_pack, dim3((int)std::min<int64_t>(1024, (tot + 255) / 256)), dim3(256), 0, h->stream, ha->send_rows, ld,
@@ -1626,7 +1626,7 @@ static int halo_exchange(msdp_handle h, const double* local_rows, bool with_sums
     if (h->lgroup) { int rc = local_halo(h, ha, ld); if (rc) return rc; }
     else {
         // with_sums (msdp_trip1.hip): every pair of ranks also swaps its four sums in the same group
-        if (with_sums) HIPCHK(hipMemcpyAsync(h->d.xs_all + 4 * (size_t)h->rank, h->d.xs, 4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (with_sums) HIPCHK(msdp_memcpy_async(h->d.xs_all + 4 * (size_t)h->rank, h->d.xs, 4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         ncclResult_t r = ncclGroupStart();
         for (int q = 0; q < ha->N && r == ncclSuccess; ++q) {
             if (q == h->rank) continue;
@@ -1654,7 +1654,7 @@ extern "C" int msdp_debug_p2p_self(msdp_handle h, int64_t count, const double* i
         msdp_set_error("debug_p2p_self: allocation failed"); return MSDP_ENOMEM;
     }
     int rc = 0;
-    if (hipMemcpyAsync(a, in_host, count * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = MSDP_EHIP;
+    if (msdp_memcpy_async(a, in_host, count * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = MSDP_EHIP;
     if (!rc) {
         ncclResult_t r = ncclGroupStart();
         if (r == ncclSuccess) r = ncclSend(a, (size_t)count, ncclDouble, h->rank, (ncclComm_t)h->comm, h->stream);
@@ -1662,7 +1662,7 @@ extern "C" int msdp_debug_p2p_self(msdp_handle h, int64_t count, const double* i
         ncclResult_t r2 = ncclGroupEnd();
         if (r != ncclSuccess || r2 != ncclSuccess) { msdp_set_error("debug_p2p_self: %s", ncclGetErrorString(r != ncclSuccess ? r : r2)); rc = MSDP_ECOMM; }
     }
-    if (!rc && hipMemcpyAsync(out_host, b, count * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = MSDP_EHIP;
+    if (!rc && msdp_memcpy_async(out_host, b, count * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = MSDP_EHIP;
     if (hipStreamSynchronize(h->stream) != hipSuccess && !rc) rc = MSDP_EHIP;
     (void)hipFree(a); (void)hipFree(b);
     return rc;
@@ -1721,7 +1721,7 @@ int msdp_allgather_rows(msdp_handle h, const double* local_rows) {
     if (!h->use_comm) {
         if (h->nranks > 1) {        // a lone process standing in for one shard (tests / per-shard measurement)
             const size_t cnt1 = (size_t)rows_capacity(h) * h->d.ld;
-            HIPCHK(hipMemcpyAsync(h->full_buf + (size_t)h->rank * cnt1, local_rows, cnt1 * sizeof(double),
+            HIPCHK(msdp_memcpy_async(h->full_buf + (size_t)h->rank * cnt1, local_rows, cnt1 * sizeof(double),
                                   hipMemcpyDeviceToDevice, h->stream));
             h->d.full = h->full_buf;
             return 0;
@@ -1953,7 +1953,7 @@ static int comm_init_ipc_attach(msdp_handle h, int32_t nranks, int32_t rank, uns
         if (hipMalloc((void**)&g->xr2_table, LOCAL_MAX_RANKS * sizeof(unsigned long long*)) != hipSuccess) { (void)hipGetLastError(); msdp_set_error("comm_init_ipc: out of device memory"); return MSDP_ENOMEM; }
         unsigned long long* tab[LOCAL_MAX_RANKS];
         for (int q = 0; q < LOCAL_MAX_RANKS; ++q) tab[q] = g->xr2_blk[q < nranks ? q : rank];
-        HIPCHK(hipMemcpy(g->xr2_table, tab, sizeof(tab), hipMemcpyHostToDevice));
+        HIPCHK(msdp_memcpy(g->xr2_table, tab, sizeof(tab), hipMemcpyHostToDevice));
         int share = 1;
         bool multi = false;
         for (int q = 0; q < nranks; ++q) {
@@ -2057,11 +2057,11 @@ extern "C" int msdp_tcg_path(msdp_handle h, int32_t* path) {
 
 // ------------------------------------------------------------------ RTR driver
 static int push_ctl(msdp_handle h) {
-    HIPCHK(hipMemcpyAsync(h->d.ctl, h->h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(h->d.ctl, h->h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, h->stream));
     return 0;
 }
 static int pull_ctl(msdp_handle h) {
-    HIPCHK(hipMemcpyAsync(h->h_ctl, h->d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(h->h_ctl, h->d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -2220,7 +2220,7 @@ static int run_tcg_lockstep(msdp_handle h, int maxinner) {
     auto push_chunk = [&]() -> int {
         int r2 = enqueue_trips(h, CH);
         if (r2) return r2;
-        HIPCHK(hipMemcpyAsync((void*)&h->h_flags[enq & 1], &h->d.ctl->tcg_running, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(msdp_memcpy_async((void*)&h->h_flags[enq & 1], &h->d.ctl->tcg_running, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipEventRecord(h->ev_flag[enq & 1], h->stream));
         ++enq;
         return 0;
@@ -2300,14 +2300,14 @@ static void restore_status_ptr(msdp_handle h) {
 // workgroups of the launch not all resident because something else occupies CUs -- into this flag.)
 static int persist_timed_out(msdp_handle h, bool* out) {
     int perr = 0;
-    HIPCHK(hipMemcpy(&perr, h->psync_err, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(msdp_memcpy(&perr, h->psync_err, sizeof(int), hipMemcpyDeviceToHost));
     *out = perr != 0;
     return 0;
 }
 
 // ctl and the persistent kernels' error word with ONE host synchronisation (the word lands in a pinned slot of h_flags)
 static int pull_ctl_and_err(msdp_handle h, bool* timed_out) {
-    HIPCHK(hipMemcpyAsync((void*)&h->h_flags[8], h->psync_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async((void*)&h->h_flags[8], h->psync_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     int rc = pull_ctl(h);
     if (rc) return rc;
     *timed_out = h->h_flags[8] != 0;
@@ -2536,7 +2536,7 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
             if (rc0) return rc0;
             h->rtr_start_cap = cnt;
         }
-        HIPCHK(hipMemcpyAsync(h->rtr_start, h->d.Y[cur0], cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(msdp_memcpy_async(h->rtr_start, h->d.Y[cur0], cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
     bool timed_out = false;
     int rc = rtr_core(h, opts, &timed_out);
@@ -2549,7 +2549,7 @@ extern "C" int msdp_rtr(msdp_handle h, const msdp_rtr_opts* opts, msdp_rtr_stats
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipMemset(h->psync_err, 0, sizeof(int)));
         h->h_ctl->cur = cur0;
-        HIPCHK(hipMemcpyAsync(h->d.Y[cur0], h->rtr_start, cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(msdp_memcpy_async(h->d.Y[cur0], h->rtr_start, cnt * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         restore_status_ptr(h);
         h->chunk_len = 0;                                          // re-capture the chunk graph against the current Dev
         rc = rtr_core(h, opts, &timed_out);
@@ -2609,7 +2609,7 @@ extern "C" int msdp_cost(msdp_handle h, double* f) {
     if ((rc = msdp_launch_costgrad(h, host_cur(h)))) return rc;
     if ((rc = msdp_k_sum_to(h, P_F, &h->d.ctl->fx))) return rc;
     double v = 0.0;
-    HIPCHK(hipMemcpyAsync(&v, &h->d.ctl->fx, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(&v, &h->d.ctl->fx, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     *f = v;
     return 0;
@@ -2660,7 +2660,7 @@ extern "C" int msdp_get_z(msdp_handle h, double* z) {
     if (h->kind != MSDP_KIND_ONLYUNITDIAG) { msdp_set_error("get_z: only for onlyunitdiag handles"); return MSDP_EUNSUPPORTED; }
     int rc = ensure_state(h);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(z + h->d.row0, h->d.eG[host_cur(h)], (size_t)h->d.n_loc * sizeof(double),
+    HIPCHK(msdp_memcpy_async(z + h->d.row0, h->d.eG[host_cur(h)], (size_t)h->d.n_loc * sizeof(double),
                           hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
@@ -2675,7 +2675,7 @@ extern "C" int msdp_get_z_all(msdp_handle h, double* z) {
     if (rc) return rc;
     const size_t cap = (size_t)rows_capacity(h);
     if ((rc = msdp_allgather_vec(h, h->d.eG[host_cur(h)], h->full_buf, cap))) return rc;     // the gather buffer is free here
-    HIPCHK(hipMemcpyAsync(z, h->full_buf, (size_t)h->d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(z, h->full_buf, (size_t)h->d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -2693,7 +2693,7 @@ extern "C" int msdp_linesearch_cost(msdp_handle h, const double* U, double alpha
         else rc = msdp_sphere_retr(h, d.Y[cur], d.W0, d.Y[cur ^ 1], alpha);
         if (rc) return rc;
     } else {
-        HIPCHK(hipMemcpyAsync(d.Y[cur ^ 1], d.Y[cur], (size_t)rows_capacity(h) * d.ld * sizeof(double),
+        HIPCHK(msdp_memcpy_async(d.Y[cur ^ 1], d.Y[cur], (size_t)rows_capacity(h) * d.ld * sizeof(double),
                               hipMemcpyDeviceToDevice, h->stream));
     }
     if (d.costkind == COST_AFFINE) return msdp_affine_linesearch_cost(h, d.Y[cur ^ 1], val);
@@ -2702,7 +2702,7 @@ extern "C" int msdp_linesearch_cost(msdp_handle h, const double* U, double alpha
     if ((rc = msdp_launch_costgrad(h, cur ^ 1))) return rc;
     if ((rc = msdp_k_sum_to(h, P_F, &d.ctl->fx_prop))) return rc;
     double v = 0.0;
-    HIPCHK(hipMemcpyAsync(&v, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(&v, &d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     *val = 2.0 * v;
     return 0;
@@ -2730,8 +2730,8 @@ extern "C" int msdp_escape_eigs(msdp_handle h, int32_t k, double tol, int32_t ma
         if ((rc = msdp_k_sum_to(h, P_GG, &h->d.ctl->gg_prop))) return rc;
         if ((rc = msdp_k_sum_to(h, P_F, &h->d.ctl->fx_prop))) return rc;
         double v[2] = {0.0, 0.0};
-        HIPCHK(hipMemcpyAsync(&v[0], &h->d.ctl->gg_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(&v[1], &h->d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(msdp_memcpy_async(&v[0], &h->d.ctl->gg_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(msdp_memcpy_async(&v[1], &h->d.ctl->fx_prop, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->h_ctl->norm_grad = sqrt(v[0] > 0 ? v[0] : 0.0);
         h->h_ctl->fx = v[1];
@@ -2754,7 +2754,7 @@ extern "C" int msdp_escape_eigs_matrix(msdp_handle h, const double* S, int32_t k
     if (hipMalloc((void**)&M, (size_t)n * nS * sizeof(double)) != hipSuccess) { msdp_set_error("escape_eigs_matrix: allocation failed"); return MSDP_ENOMEM; }
     hipError_t e = hipMemsetAsync(M, 0, (size_t)n * nS * sizeof(double), h->stream);
     if (e == hipSuccess)
-        e = hipMemcpy2DAsync(M, (size_t)nS * sizeof(double), S, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n,
+        e = msdp_memcpy2d_async(M, (size_t)nS * sizeof(double), S, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n,
                              hipMemcpyHostToDevice, h->stream);
     int rc = 0;
     if (e != hipSuccess) { msdp_set_error("escape_eigs_matrix: upload failed: %s", hipGetErrorString(e)); rc = MSDP_EHIP; }
@@ -2866,7 +2866,7 @@ extern "C" int msdp_get_dual_slack(msdp_handle h, double* S) {
     if (h->d.costkind != COST_AFFINE || !h->dual_valid) { msdp_set_error("get_dual_slack: call msdp_al_dual first"); return MSDP_ESTATE; }
     if (h->blocked) { msdp_set_error("get_dual_slack: this multiblock handle stores its blocks only (msdp_get_dual_slack_block)"); return MSDP_EUNSUPPORTED; }
     const int n = h->d.n, nS = msdp_dense_nS(n);
-    HIPCHK(hipMemcpy2DAsync(S, (size_t)n * sizeof(double), h->d.Sdual, (size_t)nS * sizeof(double), (size_t)n * sizeof(double), n,
+    HIPCHK(msdp_memcpy2d_async(S, (size_t)n * sizeof(double), h->d.Sdual, (size_t)nS * sizeof(double), (size_t)n * sizeof(double), n,
                             hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
@@ -2879,7 +2879,7 @@ extern "C" int msdp_get_dual_slack_block(msdp_handle h, int64_t row0, int64_t nb
     const int n = h->d.n, nS = msdp_dense_nS(n);
     if (row0 < 0 || nb < 1 || row0 + nb > n) { msdp_set_error("get_dual_slack_block: rows %lld..%lld outside 0..%d", (long long)row0, (long long)(row0 + nb), n); return MSDP_EINVAL; }
     if (h->blocked) return msdp_affine_get_block(h, row0, nb, S);
-    HIPCHK(hipMemcpy2DAsync(S, (size_t)nb * sizeof(double), h->d.Sdual + (size_t)row0 * nS + row0, (size_t)nS * sizeof(double),
+    HIPCHK(msdp_memcpy2d_async(S, (size_t)nb * sizeof(double), h->d.Sdual + (size_t)row0 * nS + row0, (size_t)nS * sizeof(double),
                             (size_t)nb * sizeof(double), (size_t)nb, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
@@ -2907,7 +2907,7 @@ extern "C" int msdp_bench_hessvec(msdp_handle h, int32_t reps, double* avg_ms, d
     int rc = ensure_state(h);
     if (rc) return rc;
     // direction: the Riemannian gradient at the resident point
-    HIPCHK(hipMemcpyAsync(h->d.md, h->d.Gr[host_cur(h)], (size_t)rows_capacity(h) * h->d.ld * sizeof(double),
+    HIPCHK(msdp_memcpy_async(h->d.md, h->d.Gr[host_cur(h)], (size_t)rows_capacity(h) * h->d.ld * sizeof(double),
                           hipMemcpyDeviceToDevice, h->stream));
     if ((rc = msdp_k_set_active(h, 1))) return rc;
     for (int i = 0; i < 3; ++i) if ((rc = msdp_launch_hess(h))) return rc;
@@ -3034,7 +3034,7 @@ extern "C" int msdp_debug_persist_trace(msdp_handle h, int32_t reps, uint64_t* o
     } else rc = msdp_bench_tcg_trip(h, reps, avg_ms);
     h->d.trace = nullptr;
     if (rc) return rc;
-    HIPCHK(hipMemcpy(out, h->trace_buf, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(msdp_memcpy(out, h->trace_buf, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -3076,7 +3076,7 @@ extern "C" int msdp_bench_tcg_trip(msdp_handle h, int32_t reps, double* avg_ms) 
         HIPCHK(hipStreamSynchronize(h->stream));
         h->state_valid = false;
         int perr = 0;
-        HIPCHK(hipMemcpy(&perr, h->psync_err, sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(msdp_memcpy(&perr, h->psync_err, sizeof(int), hipMemcpyDeviceToHost));
         if (perr) { msdp_set_error("persistent tCG: grid synchronisation timed out"); return MSDP_EHIP; }
         return rc ? rc : rc2;
     }

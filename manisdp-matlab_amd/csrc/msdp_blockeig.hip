@@ -567,7 +567,7 @@ static int be_rayleigh_ritz(msdp_handle h, const BeOp& a, BeMem& m, const double
     hipLaunchKernelGGL(k_be_gram_sum, dim3((2 * b * b + 255) / 256), dim3(256), 0, h->stream, 2 * b * b, BE_GRAM_BLOCKS, (const double*)gpart, gout);
     HIPCHK(hipGetLastError());
     double* hp = m.hpin;
-    HIPCHK(hipMemcpyAsync(hp, gout, (size_t)2 * b * b * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(hp, gout, (size_t)2 * b * b * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<double> Gm(hp, hp + (size_t)b * b), Hm(hp + (size_t)b * b, hp + (size_t)2 * b * b), W;
@@ -578,7 +578,7 @@ static int be_rayleigh_ritz(msdp_handle h, const BeOp& a, BeMem& m, const double
     double* hw = hp + (size_t)2 * b * b;                 // W, then theta (finite values only: +inf -> 0 for the residual pass)
     memcpy(hw, W.data(), (size_t)b * b * sizeof(double));
     for (int j = 0; j < b; ++j) hw[(size_t)b * b + j] = j < r ? out.theta[j] : 0.0;
-    HIPCHK(hipMemcpyAsync(Wd, hw, ((size_t)b * b + b) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(Wd, hw, ((size_t)b * b + b) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     // theta sits right behind W on the device (Wd + b*b)
     const size_t lds = ((size_t)b * b + (size_t)(256 / (b / 4)) * b) * sizeof(double);
     if (b == 32) hipLaunchKernelGGL((k_be_rotate<32>), dim3(BE_ROT_BLOCKS), dim3(256), lds, h->stream, n, X, (const double*)SX, (const double*)Wd, (const double*)(Wd + (size_t)b * b), Xn, rpart);
@@ -590,7 +590,7 @@ static int be_rayleigh_ritz(msdp_handle h, const BeOp& a, BeMem& m, const double
         HIPCHK(hipGetLastError());
     }
     double* hr = hw + (size_t)b * b + b;
-    HIPCHK(hipMemcpyAsync(hr, rpart, (size_t)BE_ROT_BLOCKS * b * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(hr, rpart, (size_t)BE_ROT_BLOCKS * b * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     out.res.assign(b, INFINITY);
     for (int j = 0; j < r; ++j) {
@@ -820,7 +820,7 @@ int msdp_blockeig_run(msdp_handle h, int n, const int* rp, const int* ci, const 
             if (hipMalloc((void**)&m.prevV, (size_t)n * 16 * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); m.prevV = nullptr; m.prev_n = 0; m.prev_k = 0; }
         }
         if (m.prevV) {
-            HIPCHK(hipMemcpyAsync(m.prevV, V_dev, (size_t)n * kp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(msdp_memcpy_async(m.prevV, V_dev, (size_t)n * kp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
             m.prev_n = n; m.prev_k = kp; m.prev_a = rr.theta[rk - 1];
         }
     }

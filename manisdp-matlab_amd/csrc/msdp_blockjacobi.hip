@@ -426,11 +426,11 @@ extern "C" int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, c
     int* d_n = (int*)(base + o_n); int* d_sw = (int*)(base + o_sw);
     double *d_A = (double*)(base + o_A), *d_V = tri ? nullptr : (double*)(base + o_V), *d_w = (double*)(base + o_w), *d_vec = (double*)(base + o_vec);
     double* d_ws = tri ? (double*)(base + o_ws) : nullptr;
-    HIPCHK(hipMemcpyAsync(d_soff, soff.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d_sld, sld.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d_woff, woff.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d_r0, r0.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d_n, nn.data(), nb * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(d_soff, soff.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(d_sld, sld.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(d_woff, woff.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(d_r0, r0.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(msdp_memcpy_async(d_n, nn.data(), nb * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));                 // (the index vectors are locals of this call)
     a.soff = d_soff; a.sld = d_sld; a.n = d_n; a.woff = d_woff; a.r0 = d_r0; a.A = d_A; a.V = d_V; a.w = d_w; a.vec = d_vec; a.sweeps = d_sw;
     if (tri) {
@@ -439,9 +439,9 @@ extern "C" int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, c
     } else hipLaunchKernelGGL(k_block_jacobi, dim3(nb), dim3(JAC_THREADS), 0, h->stream, a);
     hipError_t e = hipGetLastError();
     std::vector<int> sw(nb);
-    if (e == hipSuccess) e = hipMemcpyAsync(w, d_w, rows * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess && k > 0) e = hipMemcpyAsync(V, d_vec, rows * k * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(sw.data(), d_sw, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = msdp_memcpy_async(w, d_w, rows * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && k > 0) e = msdp_memcpy_async(V, d_vec, rows * k * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = msdp_memcpy_async(sw.data(), d_sw, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { msdp_set_error("block_eigs: %s", hipGetErrorString(e)); return MSDP_EHIP; }
     for (int b = 0; b < nb; ++b)

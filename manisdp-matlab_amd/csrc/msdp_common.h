@@ -14,6 +14,14 @@
 
 void msdp_set_error(const char* fmt, ...);
 
+// Host <-> device copies (msdp_xfer.hip): signatures of hipMemcpy / hipMemcpyAsync / hipMemcpy2D / hipMemcpy2DAsync.  Unpinned caller
+// memory goes through a pinned staging buffer of the process -- no msdp_*.hip file calls the hipMemcpy family itself.
+hipError_t msdp_memcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+hipError_t msdp_memcpy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
+hipError_t msdp_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind);
+hipError_t msdp_memcpy2d_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind, hipStream_t s);
+void msdp_xfer_release();
+
 #define HIPCHK(expr)                                                              \
     do {                                                                          \
         hipError_t _e = (expr);                                                   \

@@ -671,7 +671,7 @@ int msdp_dense_setup(msdp_handle h, const double* C) {
     if (rc) return rc;
     d.Cd = (double*)p;
     HIPCHK(hipMemset(d.Cd, 0, (size_t)d.n * nS * sizeof(double)));
-    HIPCHK(hipMemcpy2D(d.Cd, (size_t)nS * sizeof(double), C, (size_t)d.n * sizeof(double), (size_t)d.n * sizeof(double),
+    HIPCHK(msdp_memcpy2d(d.Cd, (size_t)nS * sizeof(double), C, (size_t)d.n * sizeof(double), (size_t)d.n * sizeof(double),
                        d.n, hipMemcpyHostToDevice));
     {
         bool sym = true;

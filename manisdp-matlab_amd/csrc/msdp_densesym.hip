@@ -349,13 +349,13 @@ static int sym_build(msdp_handle h, SymPlan& P, int NT, int nmat) {
     int rc;
     if ((rc = msdp_dev_alloc_bytes(h, &p, items.size() * sizeof(SymItem)))) return rc;
     P.d_items = (SymItem*)p;
-    HIPCHK(hipMemcpy(P.d_items, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
+    HIPCHK(msdp_memcpy(P.d_items, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice));
     if ((rc = msdp_dev_alloc_bytes(h, &p, qd.size() * sizeof(int)))) return rc;
     P.d_qd = (int*)p;
-    HIPCHK(hipMemcpy(P.d_qd, qd.data(), qd.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(msdp_memcpy(P.d_qd, qd.data(), qd.size() * sizeof(int), hipMemcpyHostToDevice));
     if ((rc = msdp_dev_alloc_bytes(h, &p, frow.size() * sizeof(int)))) return rc;
     P.d_frow = (int*)p;
-    HIPCHK(hipMemcpy(P.d_frow, frow.data(), frow.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(msdp_memcpy(P.d_frow, frow.data(), frow.size() * sizeof(int), hipMemcpyHostToDevice));
     return 0;
 }
 

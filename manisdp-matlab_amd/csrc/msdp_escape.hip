@@ -409,7 +409,7 @@ static int sapply(EscCtx& c, const double* v, double* w) {
         HIPCHK(hipGetLastError());
         int rc = msdp_allgather_vec(h, c.w_loc, c.w_all, (size_t)c.cap);
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(w, c.w_all, (size_t)c.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(msdp_memcpy_async(w, c.w_all, (size_t)c.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         return 0;
     }
     if (c.M)
@@ -439,7 +439,7 @@ static int dev_norm(EscCtx& c, const double* w, double* out) {
     hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, c.n, w, w, c.hbuf, 1);
     HIPCHK(hipGetLastError());
     double v = 0.0;
-    HIPCHK(hipMemcpyAsync(&v, c.hbuf, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(msdp_memcpy_async(&v, c.hbuf, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     *out = v;
     return 0;
@@ -521,7 +521,7 @@ static int lanczos_top(EscCtx& c, double* V, double* w, double* dalpha, double* 
     const dim3 gr((n + 255) / 256), bl(256);
     int rc;
     if (warm) {
-        HIPCHK(hipMemcpyAsync(w, warm, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(msdp_memcpy_async(w, warm, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         // the stored vector has unit norm: entries ~ 1/sqrt(n); 10 % of that as noise keeps every eigen-direction alive
         hipLaunchKernelGGL(k_add_hash, gr, bl, 0, h->stream, n, seed, 0.35 / sqrt((double)n), w);
     } else {
@@ -537,12 +537,12 @@ static int lanczos_top(EscCtx& c, double* V, double* w, double* dalpha, double* 
     while (m < maxit) {
         if ((rc = lanczos_advance(c, md, nullptr, 0, V, w, dalpha, dbeta, m, std::min(next_check, maxit)))) return rc;
         a.resize(m); b.resize(m + 1);
-        HIPCHK(hipMemcpyAsync(a.data(), dalpha, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(b.data(), dbeta, (m + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(msdp_memcpy_async(a.data(), dalpha, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(msdp_memcpy_async(b.data(), dbeta, (m + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         if (md.persist) {
             int perr = 0;
-            HIPCHK(hipMemcpy(&perr, c.err, sizeof(int), hipMemcpyDeviceToHost));
+            HIPCHK(msdp_memcpy(&perr, c.err, sizeof(int), hipMemcpyDeviceToHost));
             if (perr) { msdp_set_error("persistent Lanczos: grid synchronisation timed out"); return MSDP_EHIP; }
         }
         off.assign(m, 0.0);
@@ -564,7 +564,7 @@ static int lanczos_top(EscCtx& c, double* V, double* w, double* dalpha, double* 
     if (top_out) {
         double* sdev = nullptr;
         HIPCHK(hipMalloc((void**)&sdev, (size_t)m * sizeof(double)));
-        hipError_t e = hipMemcpyAsync(sdev, s.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, h->stream);
+        hipError_t e = msdp_memcpy_async(sdev, s.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, h->stream);
         if (e == hipSuccess) e = hipMemsetAsync(top_out, 0, (size_t)n * sizeof(double), h->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_multiaxpy, gr, bl, 0, h->stream, n, m, V, (int64_t)n, sdev, 1.0, top_out);
@@ -597,7 +597,7 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
     // else a hashed pseudo-random vector
     bool warm = false;
     if (xstart && have_xstart && *have_xstart) {
-        HIPCHK(hipMemcpyAsync(w, xstart, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(msdp_memcpy_async(w, xstart, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         if ((rc = deflate(c, Q, nq, w, 2))) return rc;
         double nw = 0.0;
         if ((rc = dev_norm(c, w, &nw))) return rc;
@@ -624,12 +624,12 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
         if ((rc = lanczos_advance(c, md, Q, nq, V, w, dalpha, dbeta, m, std::min(next_check, maxit)))) return rc;
         if (m == next_check || m == maxit) {
             a.resize(m); b.resize(m + 1);
-            HIPCHK(hipMemcpyAsync(a.data(), dalpha, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(b.data(), dbeta, (m + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(msdp_memcpy_async(a.data(), dalpha, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(msdp_memcpy_async(b.data(), dbeta, (m + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
             if (persist) {
                 int perr = 0;
-                HIPCHK(hipMemcpy(&perr, c.err, sizeof(int), hipMemcpyDeviceToHost));
+                HIPCHK(msdp_memcpy(&perr, c.err, sizeof(int), hipMemcpyDeviceToHost));
                 if (perr) { msdp_set_error("persistent Lanczos: grid synchronisation timed out"); return MSDP_EHIP; }
             }
             const auto t_an0 = std::chrono::steady_clock::now();
@@ -666,7 +666,7 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
     double* sdev = nullptr;
     HIPCHK(hipMalloc((void**)&sdev, (size_t)m * sizeof(double)));
     auto assemble = [&](const std::vector<double>& sv, double* dst) -> int {
-        hipError_t e = hipMemcpyAsync(sdev, sv.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, h->stream);
+        hipError_t e = msdp_memcpy_async(sdev, sv.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, h->stream);
         const int NCH = 32;
         if (e == hipSuccess && m >= 256 && m + 2 + NCH <= maxit + 2) {
             double* part = V + (size_t)(m + 2) * n;              // unused tail of the Lanczos basis as scratch
@@ -725,7 +725,7 @@ static int lanczos_smallest(EscCtx& c, const double* Q, int nq, double* V /* max
                 hipLaunchKernelGGL(k_lanczos_update, gr, bl, 0, h->stream, n, w, xk, (const double*)nullptr, c.hbuf + 8, (const double*)nullptr);
                 double rq = 0.0, rn = 0.0;
                 if ((rc = dev_norm(c, w, &rn))) break;
-                if (hipMemcpy(&rq, c.hbuf + 8, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { msdp_set_error("escape: memcpy failed"); rc = MSDP_EHIP; break; }
+                if (msdp_memcpy(&rq, c.hbuf + 8, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { msdp_set_error("escape: memcpy failed"); rc = MSDP_EHIP; break; }
                 if (!(rn <= 1e-6 * scale) || !(rq < -tol * scale)) break;
                 if (thetas_out) thetas_out[nacc] = rq;
                 ++nacc;
@@ -792,6 +792,7 @@ void msdp_escape_workspace_park(double* ptr, size_t cap_doubles) {
 }
 extern "C" int msdp_release_cache(void) {
     msdp_uc_release_pool();
+    msdp_xfer_release();                                      // the pinned staging buffer of msdp_xfer.hip
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     if (g_ws_ptr) (void)hipFree(g_ws_ptr);
     g_ws_ptr = nullptr; g_ws_cap = 0; g_ws_dev = -1;
@@ -843,9 +844,9 @@ static int escape_impl_once(msdp_handle h, int k, double tol, int maxit, double*
                 hipMalloc((void**)&h->esc_cv, (nnz ? nnz : 1) * sizeof(double)) != hipSuccess || hipMalloc((void**)&h->esc_z, cap * h->nranks * sizeof(double)) != hipSuccess) {
                 msdp_set_error("escape_eigs: allocation of the replicated copy of C failed"); return MSDP_ENOMEM;
             }
-            HIPCHK(hipMemcpy(h->esc_rp, h->h_rowptr.data(), ((size_t)d.n + 1) * sizeof(int), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(h->esc_ci, h->h_colind.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(h->esc_cv, h->h_cval.data(), nnz * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK(msdp_memcpy(h->esc_rp, h->h_rowptr.data(), ((size_t)d.n + 1) * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHK(msdp_memcpy(h->esc_ci, h->h_colind.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHK(msdp_memcpy(h->esc_cv, h->h_cval.data(), nnz * sizeof(double), hipMemcpyHostToDevice));
         }
         int rcg = msdp_allgather_vec(h, d.eG[h->h_ctl->cur], h->esc_z, cap);
         if (!rcg) rcg = msdp_allgather_rows(h, d.Y[h->h_ctl->cur]);        // all rows of the point in the gather buffer
@@ -909,7 +910,7 @@ static int escape_impl_once(msdp_handle h, int k, double tol, int maxit, double*
             if (me != hipSuccess) { (void)hipGetLastError(); me = hipMalloc((void**)&nm, total * sizeof(double)); if (me == hipSuccess) want = total; }
             if (me != hipSuccess) { msdp_set_error("escape_eigs: workspace allocation (%zu MB) failed", total * 8 >> 20); return MSDP_ENOMEM; }
         }
-        if (h->esc_mem && h->esc_prev_n == n) (void)hipMemcpy(nm, h->esc_mem, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice);
+        if (h->esc_mem && h->esc_prev_n == n) (void)msdp_memcpy(nm, h->esc_mem, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice);
         else h->esc_prev_n = 0;
         if (h->esc_mem) (void)hipFree(h->esc_mem);
         h->esc_mem = nm;
@@ -956,7 +957,7 @@ static int escape_impl_once(msdp_handle h, int k, double tol, int maxit, double*
                 h->esc_top = nullptr; h->esc_top_n = 0;
                 if (hipMalloc((void**)&h->esc_top, (size_t)n * sizeof(double)) == hipSuccess) h->esc_top_n = n; else (void)hipGetLastError();
             }
-            if (h->esc_top) (void)hipMemcpyAsync(h->esc_top, Z, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+            if (h->esc_top) (void)msdp_memcpy_async(h->esc_top, Z, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
         }
         const auto tb1 = std::chrono::steady_clock::now();
         // dense operand: the explicit S of the affine kinds (no z), or the dense cost matrix of onlyunitdiag (S = C - diag(z))
@@ -964,7 +965,7 @@ static int escape_impl_once(msdp_handle h, int k, double tol, int maxit, double*
         if (!rc) rc = msdp_blockeig_run(h, n, c.rp, c.ci, c.cv, c.z, !rep_sparse, c.Ypt, c.ld, c.p, k, tol, maxdeg, lmx, lres, lmin_est, cold, use_y,
                                         lam_out, Q, &deg, &conv, &err, &lower, Mdense);
         if (!rc) {
-            hipError_t e2 = hipMemcpy(V_out, Q, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost);
+            hipError_t e2 = msdp_memcpy(V_out, Q, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost);
             if (e2 != hipSuccess) { msdp_set_error("escape_eigs: download of the eigenvectors failed: %s", hipGetErrorString(e2)); rc = MSDP_EHIP; }
         }
         if (!rc) {
@@ -1013,7 +1014,7 @@ static int escape_impl_once(msdp_handle h, int k, double tol, int maxit, double*
         // Across calls: S changes little from one outer iteration to the next, so the first run starts from the
         // bottom eigenvectors the previous call found (deflated against the current Q inside lanczos_smallest)
         if (h->tune.escape_warm && h->esc_prev && h->esc_prev_n == n) {
-            ESC_HIP(hipMemcpyAsync(Z, h->esc_prev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            ESC_HIP(msdp_memcpy_async(Z, h->esc_prev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
             have_xstart = true;
         }
         h->esc_converged = 1; h->esc_maxres = 0.0; h->esc_nvalid = 0; h->esc_lower = -INFINITY;
@@ -1044,7 +1045,7 @@ static int escape_impl_once(msdp_handle h, int k, double tol, int maxit, double*
         if (r > ry) {
             if (h->esc_prev) {
                 std::vector<double> ones(r - ry, 1.0);
-                ESC_HIP(hipMemcpyAsync(c.hbuf, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                ESC_HIP(msdp_memcpy_async(c.hbuf, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
                 ESC_HIP(hipMemsetAsync(h->esc_prev, 0, (size_t)n * sizeof(double), h->stream));
                 hipLaunchKernelGGL(k_multiaxpy, gr, bl, 0, h->stream, n, r - ry, Q + (size_t)ry * n, (int64_t)n, c.hbuf, 1.0, h->esc_prev);
                 ESC_HIP(hipStreamSynchronize(h->stream));
@@ -1053,7 +1054,7 @@ static int escape_impl_once(msdp_handle h, int k, double tol, int maxit, double*
         }
         // ---- final Rayleigh-Ritz on Z = [Q_Y | X]: recouples the blocks when S*Y is only approximately zero
         const int nz = r;
-        ESC_HIP(hipMemcpyAsync(Z, Q, (size_t)nz * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        ESC_HIP(msdp_memcpy_async(Z, Q, (size_t)nz * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         // ... and measures how far span(Z) is from invariant: coupling = |(I - ZZ') S Z|_F, from which a lower ESTIMATE of
         // lambda_min follows (Weyl): S = [A E'; E B] in the basis [Z, complement], lambda_min(S) >= min(lambda_min(A),
         // lambda_min(B)) - |E|_2, with A = Z'SZ known exactly and |E|_2 <= |E|_F; lambda_min(B) is taken as theta - res of
@@ -1065,7 +1066,7 @@ static int escape_impl_once(msdp_handle h, int k, double tol, int maxit, double*
             ESC_CHECK(sapply(c, Z + (size_t)j * n, w));
             hipLaunchKernelGGL(k_multidot, dim3(nz), dim3(MSDP_BLOCK), 0, h->stream, n, Z, (int64_t)n, w, c.hbuf);
             hipLaunchKernelGGL(k_dot1, dim3(1), dim3(MSDP_BLOCK), 0, h->stream, n, w, w, c.hbuf + nz, 0);
-            ESC_HIP(hipMemcpyAsync(col.data(), c.hbuf, (nz + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            ESC_HIP(msdp_memcpy_async(col.data(), c.hbuf, (nz + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             ESC_HIP(hipStreamSynchronize(h->stream));
             double inside = 0.0;
             for (int i = 0; i < nz; ++i) { M[(size_t)i * nz + j] = col[i]; inside += col[i] * col[i]; }
@@ -1086,10 +1087,10 @@ static int escape_impl_once(msdp_handle h, int k, double tol, int maxit, double*
             if (t < nout) {
                 lam_out[t] = ew[eo[t]];
                 for (int i = 0; i < nz; ++i) cz[i] = EV[(size_t)i * nz + eo[t]];
-                ESC_HIP(hipMemcpyAsync(c.hbuf, cz.data(), nz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                ESC_HIP(msdp_memcpy_async(c.hbuf, cz.data(), nz * sizeof(double), hipMemcpyHostToDevice, h->stream));
                 ESC_HIP(hipMemsetAsync(w, 0, n * sizeof(double), h->stream));
                 hipLaunchKernelGGL(k_multiaxpy, gr, bl, 0, h->stream, n, nz, Z, (int64_t)n, c.hbuf, 1.0, w);
-                ESC_HIP(hipMemcpyAsync(V_out + (size_t)t * n, w, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+                ESC_HIP(msdp_memcpy_async(V_out + (size_t)t * n, w, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
                 ESC_HIP(hipStreamSynchronize(h->stream));
             } else {
                 // fewer than k Ritz pairs exist: +inf marks the missing values (never counted as negative) and the

@@ -209,7 +209,7 @@ static int win_upload(WinCacheEntry& e, const std::vector<T>& v, const T** out) 
     void* p = nullptr;
     if (hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); return MSDP_ENOMEM; }
     e.dev.push_back(p);
-    if (!v.empty() && hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return MSDP_EHIP; }
+    if (!v.empty() && msdp_memcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return MSDP_EHIP; }
     *out = (const T*)p;
     return 0;
 }

@@ -45,3 +45,19 @@ def test_no_gpu_means_loud_failure():
     C = problems.toroidal_grid_maxcut(4, 4)
     with pytest.raises(_lib.MsdpError):
         _lib.Handle.onlyunitdiag(C)
+
+
+def test_caller_memory_never_reaches_the_runtime_copy_calls():
+    """Every host <-> device copy of the library goes through msdp_xfer.hip (pinned staging of unpinned caller memory): no other
+    source file calls the hipMemcpy family (round 6: the runtime registers pageable ranges it copies from, and the process stalls for
+    20 - 35 ms when their owner frees them -- msdp_xfer.hip's header has the measurements)."""
+    import glob
+    csrc = os.path.join(ROOT, "manisdp-matlab_amd", "csrc")
+    bad = []
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        if os.path.basename(path) == "msdp_xfer.hip":
+            continue
+        txt = re.sub(r"//[^\n]*", "", open(path).read())
+        for m in re.finditer(r"\bhipMemcpy\w*\s*\(", txt):
+            bad.append((os.path.basename(path), m.group(0)))
+    assert not bad, bad
