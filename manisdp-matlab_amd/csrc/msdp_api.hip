@@ -243,6 +243,53 @@ static void dev_free(msdp_handle h, void* p) {
     if (!msdp_uc_free(p)) (void)hipFree(p);
 }
 
+// The stream and the four pinned control blocks of a handle come from a small cache of the process (round 6): hipStreamCreate 2.8 ms,
+// hipStreamDestroy 3.9 - 4.5 ms and the hipHostMalloc / hipHostFree pairs were 8 of the 163 ms of a G81 solve to KKT 1e-8, paid by every
+// handle a host opens (rocprofv3 --hip-trace, tools/hip_api_totals.py).  A kit goes back when its handle is destroyed (the stream
+// synchronised), at most HOST_KIT_MAX per process are kept, msdp_release_cache frees them.
+struct HostKit { int dev; hipStream_t stream; Ctl* h_ctl; Frame* h_frame; volatile int* h_flags; volatile unsigned long long* h_status; };
+static std::mutex g_kit_mutex;
+static std::vector<HostKit> g_kits;
+static const size_t HOST_KIT_MAX = 8;
+static void host_kit_free(HostKit& k) {
+    if (k.h_ctl) (void)hipHostFree(k.h_ctl);
+    if (k.h_frame) (void)hipHostFree(k.h_frame);
+    if (k.h_status) (void)hipHostFree((void*)k.h_status);
+    if (k.h_flags) (void)hipHostFree((void*)k.h_flags);
+    if (k.stream) (void)hipStreamDestroy(k.stream);
+}
+static bool host_kit_take(msdp_handle h) {
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_kit_mutex);
+    for (size_t i = 0; i < g_kits.size(); ++i) {
+        if (g_kits[i].dev != dev) continue;
+        HostKit k = g_kits[i];
+        g_kits.erase(g_kits.begin() + i);
+        h->stream = k.stream; h->h_ctl = k.h_ctl; h->h_frame = k.h_frame; h->h_flags = k.h_flags; h->h_status = k.h_status;
+        memset(h->h_ctl, 0, sizeof(Ctl)); memset(h->h_frame, 0, 2 * sizeof(Frame)); memset((void*)h->h_flags, 0, 64); memset((void*)h->h_status, 0, 64);
+        return true;
+    }
+    return false;
+}
+static void host_kit_give(msdp_handle h) {
+    HostKit k = {-1, h->stream, h->h_ctl, h->h_frame, h->h_flags, h->h_status};
+    h->stream = nullptr; h->h_ctl = nullptr; h->h_frame = nullptr; h->h_flags = nullptr; h->h_status = nullptr;
+    (void)hipGetDevice(&k.dev);
+    const bool whole = k.stream && k.h_ctl && k.h_frame && k.h_flags && k.h_status;
+    if (whole && hipStreamSynchronize(k.stream) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_kit_mutex);
+        if (g_kits.size() < HOST_KIT_MAX) { g_kits.push_back(k); return; }
+    }
+    (void)hipGetLastError();
+    host_kit_free(k);
+}
+void msdp_host_kits_release() {                               // msdp_release_cache
+    std::lock_guard<std::mutex> lk(g_kit_mutex);
+    for (auto& k : g_kits) host_kit_free(k);
+    g_kits.clear();
+}
+
 static bool boundary_colmajor(msdp_handle h) { return h->kind == MSDP_KIND_UNITTRACE || h->kind == MSDP_KIND_GENERIC; }
 
 static int rows_capacity(msdp_handle h) {
@@ -392,15 +439,18 @@ static int new_handle(int kind, int64_t n, msdp_handle* out) {
         if (on("MSDP_ESC_DEBUG")) h->tune.esc_debug = 1;
         if (const char* e = getenv("MSDP_AFFINE_ROUTE")) h->tune.affine_route = !strcmp(e, "gram") ? 2 : (!strcmp(e, "sddmm") ? 1 : 0);
     }
-    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    hipError_t e = hipSuccess;
+    if (!host_kit_take(h)) {
+        e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_ctl, sizeof(Ctl), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_frame, 2 * sizeof(Frame), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_flags, 64, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_status, 64, hipHostMallocMapped);
+    }
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_ctl, sizeof(Ctl), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_frame, 2 * sizeof(Frame), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_flags, 64, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_flag[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_flag[1], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_status, 64, hipHostMallocMapped);
     if (e == hipSuccess) {
         *h->h_status = 0;
         void* dp = nullptr;
@@ -726,10 +776,6 @@ extern "C" int msdp_destroy(msdp_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) (void)ncclCommDestroy((ncclComm_t)h->comm);
     for (void* p : h->allocs) if (!msdp_uc_free(p)) (void)hipFree(p);
-    if (h->h_ctl) (void)hipHostFree(h->h_ctl);
-    if (h->h_frame) (void)hipHostFree(h->h_frame);
-    if (h->h_status) (void)hipHostFree((void*)h->h_status);
-    if (h->h_flags) (void)hipHostFree((void*)h->h_flags);
     for (int s2 = 0; s2 < 2; ++s2) if (h->ev_flag[s2]) (void)hipEventDestroy(h->ev_flag[s2]);
     for (int s2 = 0; s2 < 2; ++s2) if (h->chunk_execs[s2]) (void)hipGraphExecDestroy(h->chunk_execs[s2]);
     msdp_affine_release(h);
@@ -751,7 +797,7 @@ extern "C" int msdp_destroy(msdp_handle h) {
     if (h->xr_ev) (void)hipEventDestroy(h->xr_ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    host_kit_give(h);                                         // the stream and the pinned control blocks: to the next handle of the process
     delete h;
     return 0;
 }

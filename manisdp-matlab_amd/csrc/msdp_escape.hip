@@ -28,6 +28,7 @@
 int msdp_dense_nS(int n);
 void* msdp_uc_alloc(size_t bytes);                                           // msdp_api.hip: per-process pool of uncached blocks
 void msdp_uc_release_pool();
+void msdp_host_kits_release();
 int msdp_allgather_rows(msdp_handle h, const double* local_rows);          // msdp_api.hip
 int msdp_allgather_vec(msdp_handle h, const double* local, double* all, size_t count_per_rank);
 // msdp_lanczos.hip: persistent kernel for the recurrence (sparse C, single rank)
@@ -793,6 +794,7 @@ void msdp_escape_workspace_park(double* ptr, size_t cap_doubles) {
 extern "C" int msdp_release_cache(void) {
     msdp_uc_release_pool();
     msdp_xfer_release();                                      // the pinned staging buffer of msdp_xfer.hip
+    msdp_host_kits_release();                                 // cached streams + pinned control blocks (msdp_api.hip)
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     if (g_ws_ptr) (void)hipFree(g_ws_ptr);
     g_ws_ptr = nullptr; g_ws_cap = 0; g_ws_dev = -1;
