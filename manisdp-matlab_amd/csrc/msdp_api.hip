@@ -1098,7 +1098,8 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "affine_broute")) { t.affine_broute = value != 0; h->chunk_len = 0; }
     else if (!strcmp(name, "dense_sym")) { t.dense_sym = value < 0 ? 0 : (value > 2 ? 2 : value); h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE && !h->blocked) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
     else if (!strcmp(name, "dense_sym_min")) { t.dense_sym_min = value > 0 ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE && !h->blocked) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
-    else if (!strcmp(name, "dense_sym_rt")) { t.dense_sym_rt = (value >= 1 && value <= 3) ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE && !h->blocked) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
+    else if (!strcmp(name, "dense_sym_res")) { t.dense_sym_res = value > 0 ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE && !h->blocked) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
+    else if (!strcmp(name, "dense_sym_rt")) { t.dense_sym_rt = (value >= 1 && value <= 4) ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE && !h->blocked) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
     else if (!strcmp(name, "dense_sym_db")) { t.dense_sym_db = (value >= 0 && value <= 2) ? value : 0; h->chunk_len = 0; }
     else if (!strcmp(name, "dense_sym_len")) { t.dense_sym_len = value > 0 ? value : 0; h->chunk_len = 0; if (h->have_point && h->d.costkind != COST_SPARSE && !h->blocked) { int rc = msdp_dense_reserve(h, h->d.costkind == COST_AFFINE ? 2 : 1); if (rc) return rc; } }
     else if (!strcmp(name, "debug_fail_persist")) t.fail_persist = value != 0;

@@ -192,6 +192,7 @@ struct Tuning {
     int dense_sym_rt = 0;       // A/B: 16-row tiles per wave of k_dense_sym (0: by n; 1 or 2)
     int dense_sym_db = 0;       // A/B: double-buffered reduction, one barrier per step (0: by shape, 1: never, 2: always)
     int dense_sym_len = 0;      // A/B: slice length of a work item in 16-column steps (0: planned)
+    int dense_sym_res = 0;         // workgroups of the symmetric contraction assumed resident at a time when its slices are cut (0: by shape)
     int escape_warm = 1;     // escape: start the Lanczos runs from what the previous call found (0: hashed random vector)
     int xpersist = 1;        // in-process ranks (msdp_comm_init_local), sparse C, oblique: ONE persistent tCG spanning the ranks' launches -- grid
                              //   reductions and row exchange through shared uncached memory, no collective per trip (msdp_persist.hip XR); 0: lock-step chunks

@@ -58,6 +58,10 @@ static size_t sym_lds_bytes(int NT, int waves, bool db) {
 
 // DB: the reduction buffer is double-buffered and a step needs ONE workgroup barrier instead of two (the reduction of step s runs
 // beside the products of step s + 1 of the faster waves) -- for the shapes that leave one workgroup per CU anyway
+// (__launch_bounds__' second figure is waves per SIMD: NT x RT = 4 holds 166 registers per lane -- three waves per SIMD, i.e. ONE 8-wave
+// workgroup per CU, or one of 12 waves: round 6's shape.  Two 8-wave workgroups per CU need 128: with the fragments requested at the top
+// of their step instead of a step ahead the kernel fits them with 92 bytes of scratch and runs 806 us where this one takes 596; two
+// 6-wave workgroups per CU: 746 us; three of 4 waves (RB = 128: three times the T slabs of RB = 384): 630-635 us.)
 template <int NT, int RT, int SYM_WAVES, bool DB>
 __global__ __launch_bounds__(SYM_WAVES * 64, (SYM_WAVES == 16 ? 4 : (NT * RT >= 4 ? 3 : 4))) void k_dense_sym(SymOp op, const int* active_flag) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -178,12 +182,18 @@ __global__ __launch_bounds__(SYM_WAVES * 64, (SYM_WAVES == 16 ? 4 : (NT * RT >= 
         }
     };
 
-    double2 F0[RT][2], F1[RT][2];
     double* red1 = DB ? red + SYM_WAVES * RSLOT : red;
     __syncthreads();                                          // zero fill done
+    double2 F0[RT][2], F1[RT][2];
     load_F(it.k0, F0);
     { const double2 v = load_stg(it.k0); *reinterpret_cast<double2*>(stg_dst0) = v; }
     if (DB) __syncthreads();                                  // first tile staged
+    // Round 6, what this loop was measured against at n = 20000, p = 32 (tools/densesym_shapes.py; whole Hess-vec, twelve waves 565-577 us
+    // by box): without the transposed products 390 us, without the reductions 543, without the barriers 550 -- the direct half alone
+    // streams its 1.6 GB at 4.8 TB/s (what the full kernel reaches on 3.2 GB) and the transposed half adds its 163 us of matrix
+    // instructions nearly in full: the waves of the ONE workgroup a CU holds wait for their fragments together and multiply together.
+    // Tried and not kept: the reduction of step s inside step s + 1, behind the first direct products (580 us); the fragments of three
+    // steps in flight instead of one (eight waves, 215 registers: 606 against 607 us), requested as 256 contiguous bytes per row (629).
     for (int k0 = it.k0; k0 < it.k1; k0 += 2 * KT) {
         if (!DB) __syncthreads();                             // tile k0 staged; the reduction of the previous step has read `red`
         double2 sn = load_stg(k0 + KT);
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(SYM_WAVES * 64, (SYM_WAVES == 16 ? 4 : (NT * RT >= 
 // rows sum nrb slabs, the first ones a handful).
 struct SymFold {
     const double* slab; int64_t stride;
-    int ld, nmat, rb_shift;
+    int ld, nmat, RB;
     int tslab0[2], dslab0;
     const int* qd; const int* frow;
     double* out;
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(256) void k_sym_fold(SymFold f, const int* active_f
         const int rl = e / half, cp = e - rl * half;
         const int row = r0 + rl;
         const int64_t o = (int64_t)row * f.ld + 2 * cp;
-        const int rbk = row >> f.rb_shift;
+        const int rbk = row / f.RB;
         double2 acc = msdp_sum_slabs(f.slab + (int64_t)f.tslab0[0] * f.stride, f.stride, rbk, o);
         if (f.nmat == 2) {
             const double2 t = msdp_sum_slabs(f.slab + (int64_t)f.tslab0[1] * f.stride, f.stride, rbk, o);
@@ -247,7 +257,7 @@ struct SymPlan {
     int NT = 0, nmat = 0, RT = 0, WV = 0, RB = 0, nrb = 0, n = 0;
     int nitems = 0, QDmax = 0, nslabs = 0, Gf = 0;
     int tslab0[2] = {0, 0}, dslab0 = 0;
-    int len_opt = 0;
+    int len_opt = 0, res_opt = 0;
     SymItem* d_items = nullptr;
     int* d_qd = nullptr;
     int* d_frow = nullptr;
@@ -256,6 +266,10 @@ struct SymPlans { SymPlan p[2][2]; };      // [NT - 1][nmat - 1]
 
 typedef void (*sym_fn_t)(SymOp, const int*);
 static sym_fn_t sym_fn(int NT, int RT, int WV, bool db) {
+    if (WV == 12) {
+        if (db) return NT == 1 ? k_dense_sym<1, 2, 12, true> : k_dense_sym<2, 2, 12, true>;
+        return NT == 1 ? k_dense_sym<1, 2, 12, false> : k_dense_sym<2, 2, 12, false>;
+    }
     if (db) {
         if (WV == 16) return NT == 1 ? k_dense_sym<1, 1, 16, true> : k_dense_sym<2, 1, 16, true>;
         if (NT == 1) return RT == 2 ? k_dense_sym<1, 2, 8, true> : k_dense_sym<1, 1, 8, true>;
@@ -265,14 +279,17 @@ static sym_fn_t sym_fn(int NT, int RT, int WV, bool db) {
     if (NT == 1) return RT == 2 ? k_dense_sym<1, 2, 8, false> : k_dense_sym<1, 1, 8, false>;
     return RT == 2 ? k_dense_sym<2, 2, 8, false> : k_dense_sym<2, 1, 8, false>;
 }
-// shape of a workgroup: dense_sym_rt = 1: 8 waves x 16 rows (RB = 128); 2: 8 waves x 32 rows (RB = 256); 3: 16 waves x 16 rows (RB = 256)
+// shape of a workgroup: dense_sym_rt = 1: 8 waves x 16 rows (RB = 128); 2: 8 waves x 32 rows (RB = 256); 3: 16 waves x 16 rows (RB = 256);
+// round 6: 4: 12 waves x 32 rows (RB = 384: three waves per SIMD -- what 166 registers per lane allow -- in ONE workgroup per CU)
 static void sym_shape(msdp_handle h, int NT, int* RT, int* WV) {
     int mode = h->tune.dense_sym_rt;
     // measured (tools/archive/densesym_probe.py, n = 20000: p = 16 551 us full / 414 / 384 / 444 for the shapes 1 / 2 / 3; p = 32: 613 /
     // 650 / 594 / 607; n = 10000, p = 32: 177 / 182 / 173 / 166)
-    if (!mode) mode = NT == 1 ? 2 : (h->d.n >= 16000 ? 2 : 3);
-    *RT = mode == 2 ? 2 : 1;
-    *WV = mode == 3 ? 16 : 8;
+    // (round 6, p = 32: n = 10000 164.6 / 167.3 / 153.4 us for the shapes 2 / 3 / 4, n = 20000 595.7 / 619.6 / 568.4, n = 40000 2401 / 2500 / 2236;
+    // p = 16 keeps shape 2: 388.8 against 401.6 at n = 20000; tools/densesym_shapes.py)
+    if (!mode) mode = NT == 1 ? 2 : (h->d.n >= 9000 ? 4 : 3);
+    *RT = (mode == 2 || mode == 4) ? 2 : 1;
+    *WV = mode == 3 ? 16 : (mode == 4 ? 12 : 8);
 }
 
 int msdp_densesym_eligible(msdp_handle h, int nmat) {
@@ -292,8 +309,13 @@ static int sym_build(msdp_handle h, SymPlan& P, int NT, int nmat) {
     sym_shape(h, NT, &P.RT, &P.WV);
     P.RB = P.WV * 16 * P.RT;
     P.nrb = (n + P.RB - 1) / P.RB;
-    // slice length L (steps of 16 columns, even): the fewest rounds of resident workgroups, then the shortest slices
-    const int resident = P.WV == 16 ? 256 : 512;
+    // slice length L (steps of 16 columns, even): the fewest rounds of resident workgroups, then the shortest slices.  (Round 6 tried slices
+    // of EQUAL length per row block, the target length chosen by simulating the longest-first schedule on the resident workgroups: 501 ->
+    // 510 items and 146 -> 140 steps on the busiest CU for n = 20000 in the model; measured 565 -> 560 us there, 153 -> 163 us at n = 10000 and
+    // 595 -> 611 for the 8 x 32-row shape -- an item costs more than the model's three steps, D slabs and fold work included.  Not kept.)
+    // workgroups resident at a time: one per CU for 12 / 16 waves, two for 8 (dense_sym_res overrides: the 8 x 32-row shape at p > 16 holds
+    // 166 registers per lane, i.e. ONE workgroup per CU)
+    const int resident = h->tune.dense_sym_res > 0 ? h->tune.dense_sym_res : ((P.WV >= 12 || NT * P.RT >= 4) ? 256 : 512);
     std::vector<int> steps_rb(P.nrb);
     for (int rb = 0; rb < P.nrb; ++rb) { steps_rb[rb] = (nS - rb * P.RB) / 16; }
     int bestL = 0; double bestcost = 1e300;
@@ -366,10 +388,11 @@ static int sym_plan(msdp_handle h, int nmat, SymPlan** out) {
     SymPlan& P = S->p[NT - 1][nmat - 1];
     int want_rt, want_wv;
     sym_shape(h, NT, &want_rt, &want_wv);
-    if (P.NT != NT || P.n != h->d.n || P.RT != want_rt || P.WV != want_wv || P.len_opt != h->tune.dense_sym_len) {
+    if (P.NT != NT || P.n != h->d.n || P.RT != want_rt || P.WV != want_wv || P.len_opt != h->tune.dense_sym_len || P.res_opt != h->tune.dense_sym_res) {
         int rc = sym_build(h, P, NT, nmat);
         if (rc) return rc;
         P.len_opt = h->tune.dense_sym_len;
+        P.res_opt = h->tune.dense_sym_res;
     }
     *out = &P;
     return 0;
@@ -411,8 +434,9 @@ int msdp_densesym_gemm(msdp_handle h, hipStream_t stream, int nmat, const double
     op.slab = h->slab; op.stride = stride;
     op.items = P->d_items;
     // one barrier per step (double-buffered reduction) where the shape leaves one workgroup per CU anyway; dense_sym_db: 1 never, 2 always
-    const bool db = h->tune.dense_sym_db == 2 || (h->tune.dense_sym_db == 0 && (P->WV == 16 || P->NT * P->RT >= 4 || P->NT == 1));
+    const bool db = h->tune.dense_sym_db == 2 || (h->tune.dense_sym_db == 0 && (P->WV >= 12 || P->NT * P->RT >= 4 || P->NT == 1));
     sym_fn_t fn = sym_fn(P->NT, P->RT, P->WV, db);
+    if (!fn) { msdp_set_error("symmetric contraction: no kernel instance"); return MSDP_ESTATE; }
     const size_t ldsb = sym_lds_bytes(P->NT, P->WV, db);
     if (ldsb > 65536) HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     hipLaunchKernelGGL(fn, dim3(P->nitems), dim3(P->WV * 64), ldsb, stream, op, active_flag);
@@ -420,8 +444,7 @@ int msdp_densesym_gemm(msdp_handle h, hipStream_t stream, int nmat, const double
     SymFold f;
     memset(&f, 0, sizeof(f));
     f.slab = h->slab; f.stride = stride; f.ld = d.ld; f.nmat = nmat;
-    int sh = 0; while ((1 << sh) < P->RB) ++sh;
-    f.rb_shift = sh;
+    f.RB = P->RB;
     f.tslab0[0] = P->tslab0[0]; f.tslab0[1] = P->tslab0[1]; f.dslab0 = P->dslab0;
     f.qd = P->d_qd; f.frow = P->d_frow; f.out = h->slab;
     hipLaunchKernelGGL(k_sym_fold, dim3(P->Gf), dim3(256), 0, stream, f, active_flag);
