@@ -193,7 +193,12 @@ __global__ __launch_bounds__(SYM_WAVES * 64, (SYM_WAVES == 16 ? 4 : (NT * RT >= 
     // streams its 1.6 GB at 4.8 TB/s (what the full kernel reaches on 3.2 GB) and the transposed half adds its 163 us of matrix
     // instructions nearly in full: the waves of the ONE workgroup a CU holds wait for their fragments together and multiply together.
     // Tried and not kept: the reduction of step s inside step s + 1, behind the first direct products (580 us); the fragments of three
-    // steps in flight instead of one (eight waves, 215 registers: 606 against 607 us), requested as 256 contiguous bytes per row (629).
+    // steps in flight instead of one (eight waves, 215 registers: 606 against 607 us), requested as 256 contiguous bytes per row (629);
+    // the barrier of step s in the MIDDLE of step s + 1 (behind its direct products; the panel tile staged two steps ahead in a third LDS
+    // tile): by the cycle counter the first wave of a SIMD waits 3 700 of 9 500 cycles at the end-of-step barrier, with the barrier moved it
+    // waits as long in the middle -- 575 against 567-577 us; the direct products with t outermost (a B fragment read once for both row
+    // tiles, four accumulators rotating): no change.  The 48 direct matrix instructions of a SIMD's three waves take 4 400-4 800 cycles
+    // (64 each at peak), the 48 transposed ones 3 000-4 000.
     for (int k0 = it.k0; k0 < it.k1; k0 += 2 * KT) {
         if (!DB) __syncthreads();                             // tile k0 staged; the reduction of the previous step has read `red`
         double2 sn = load_stg(k0 + KT);
