@@ -437,6 +437,7 @@ static int new_handle(int kind, int64_t n, msdp_handle* out) {
         if (on("MSDP_NO_GRAPH")) h->tune.graph = 0;
         if (on("MSDP_TIMING")) h->tune.timing = 1;
         if (on("MSDP_ESC_DEBUG")) h->tune.esc_debug = 1;
+        h->d.persist_ep = h->tune.persist_ep;
         if (const char* e = getenv("MSDP_AFFINE_ROUTE")) h->tune.affine_route = !strcmp(e, "gram") ? 2 : (!strcmp(e, "sddmm") ? 1 : 0);
     }
     hipError_t e = hipSuccess;
@@ -1074,6 +1075,7 @@ extern "C" int msdp_set_option(msdp_handle h, const char* name, int32_t value) {
     else if (!strcmp(name, "pipe_refresh")) t.pipe_refresh = value > 0 ? (value < 2 ? 2 : value) : 0;   // (1 would store the refresh rows of trip j + 1 into the regions a slower workgroup still gathers those of trip j from: msdp_pipe.h)
     else if (!strcmp(name, "pipe_local")) t.pipe_local = value > 0 ? 1 : 0;
     else if (!strcmp(name, "persist_goff")) t.persist_goff = value ? 1 : 0;
+    else if (!strcmp(name, "persist_ep")) { t.persist_ep = value ? 1 : 0; h->d.persist_ep = t.persist_ep; h->persist_sig_fn = nullptr; }
     else if (!strcmp(name, "persist_slots")) { t.persist_slots = (value == 3 || value == 4) ? value : 0; h->d.persist_slots = t.persist_slots; }
     else if (!strcmp(name, "psync_backoff")) t.psync_backoff = value > 0 ? value : 0;
     else if (!strcmp(name, "psync8_backoff")) t.psync8_backoff = value > 0 ? (value > 255 ? 255 : value) : 0;

@@ -161,6 +161,7 @@ struct Dev {
     unsigned long long* xr2_blk;
     unsigned long long* const* xr2_peers;
     int persist_slots;    // A/B: row slots of the persistent tCG plan at p = 17..32 (0: planned)
+    int persist_ep;       // CSR rows: the lane groups of a wave share a row and split its entries where the grid allows (1, default) or never (0)
 };
 
 // Run-time switches of a handle (msdp_set_option; the environment variables of the same meaning are read ONCE, when
@@ -209,6 +210,7 @@ struct Tuning {
     int window_lds = 144;      // ... KB of LDS a window may take (A/B; one 1024-thread workgroup per CU)
     int persist_refresh = 32;  // persistent tCG: direct (three-synchronisation) trip every this-many trips, bounds the drift of C*mdelta
     int persist_slots = 0;     // A/B: row slots per lane group of the persistent tCG at p = 17..32 (0: planned; 3 or 4)
+    int persist_ep = 1;        // CSR rows of the persistent tCG: entry-parallel lanes where the rows leave lanes free (A/B: 0 never)
     int persist_goff = 1;      // persistent tCG: the byte offsets of the R x EW gathers of a trip live in registers (0: recomputed per trip from the LDS copy of the column indices)
     int pipe_local = 1;        // one-reduction trip: neighbours that belong to the same workgroup are read from LDS, the diagonal from registers
     int xr_twolevel = 0;       // process ranks: 1 = two-level grid reductions (msdp_psync.h psync2) also where the flat ones would do (one device, <= 4 members); A/B, tests

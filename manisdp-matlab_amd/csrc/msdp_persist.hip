@@ -56,12 +56,17 @@ __global__ void k_psync_reset(unsigned long long* slots, int* err) {
 // travel through the members' exchange buffers (d.xr_rows[q]: member q's rows, in q's own memory), and no collective is issued per trip.  Same
 // arithmetic per row as the one-rank kernel; the sums are formed over d.xr_gtot partials in index order on every rank (same bits on
 // every rank -> same decisions).  Two slot regions alternate with the TR iteration; each launch clears the other one at its start.
-template <int LPR, int EW, int R, bool FUSE, bool TRACE, bool XR, bool EARLYP, bool XR2 = false>
+// EP (round 6, CSR rows only): EP lane groups share a row.  The group with epi = 0 owns the row (its registers, its sums, its stores); all EP
+// groups walk the row's entries with stride EP and their partial products are added across the groups -- a row of 48 entries is ONE
+// round trip of six gathers per lane instead of six round trips of eight.  For the sizes where the rows do not fill the chip's lanes
+// anyway (G1: 800 rows on 256 CUs).
+template <int LPR, int EW, int R, bool FUSE, bool TRACE, bool XR, bool EARLYP, bool XR2 = false, int EP = 1>
 __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long long* slots, int* err, const int bx) {
+    static_assert(EP == 1 || (EW == 0 && !XR), "entry-parallel lanes: CSR rows of one rank");
     extern __shared__ double lds[];
     __shared__ double sh[3 * PWAVES];
     __shared__ double shb[8];
-    constexpr int RPW = 64 / LPR;
+    constexpr int RPW = 64 / (LPR * EP);
     constexpr int RSTEP = PWAVES * RPW;       // rows per pass of the workgroup
     constexpr int ROWS = R * RSTEP;               // row slots of the workgroup
     double2* Ys = reinterpret_cast<double2*>(lds);                 // [R][PB]
@@ -111,8 +116,10 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi, 0, bx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane & (LPR - 1), rsub = lane / LPR;
-    const bool colok = 2 * sub < d.ld;
+    const int sub = lane & (LPR - 1), rsub = lane / (LPR * EP);
+    const int epi = (lane / LPR) & (EP - 1);                       // EP > 1: which of the row's lane groups (0 owns the row)
+    const bool colok_g = 2 * sub < d.ld;                           // the lane has columns (gathers)
+    const bool colok = colok_g && epi == 0;                        // ... and owns them (registers, sums, stores)
     int cur = c->cur;
     const bool bench = c->bench_mode != 0;
     double Delta = c->Delta;
@@ -342,6 +349,35 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
                 for (int w = 0; w < EW; ++w) {
                     acc.x = fma(v[w], x[w].x, acc.x);
                     acc.y = fma(v[w], x[w].y, acc.y);
+                }
+            } else if (EP > 1) {
+                // entry-parallel: lane group epi takes the entries s0 + epi, s0 + epi + EP, ... -- all of them in flight together for rows of
+                // up to CBE * EP entries -- and the groups' partial products are added (every group ends with the row's sum)
+                constexpr int CBE = CB;                                // (sixteen in flight: 7.9 against 7.8 us per trip on G1 -- no gain)
+                const bool rok = ROK(r);
+                const int s0 = rok ? d.rowptr[ROW(r)] : 0, s1 = rok ? d.rowptr[ROW(r) + 1] : 0;
+                const unsigned gcg = colok_g ? 2 * sub : 0;
+                for (int k0 = s0 + epi; __builtin_amdgcn_ballot_w64(k0 < s1) != 0ULL; k0 += CBE * EP) {
+                    double2 x[CBE];
+                    double cvk[CBE];
+#pragma unroll
+                    for (int u = 0; u < CBE; ++u) {
+                        const int k = k0 + u * EP;
+                        const bool in = k < s1;
+                        const int cidx = in ? d.colind[k] : (int)xglob0 + (rok ? ROW(r) : lo);
+                        cvk[u] = in ? d.cval[k] : 0.0;
+                        x[u] = ld2_sc1(rs, base + ((unsigned)cidx * gld + gcg) * 8u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < CBE; ++u) {
+                        acc.x = fma(cvk[u], x[u].x, acc.x);
+                        acc.y = fma(cvk[u], x[u].y, acc.y);
+                    }
+                }
+#pragma unroll
+                for (int m = LPR; m < LPR * EP; m <<= 1) {
+                    acc.x += __shfl_xor(acc.x, m);
+                    acc.y += __shfl_xor(acc.y, m);
                 }
             } else if (ROK(r)) {
                 // CSR rows of any length: (col, val) are static (plain loads, L2 resident), the direction rows are not
@@ -678,7 +714,7 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
         const double2 gpr = OK(r) ? make_double2(acc.x - ypr.x * dot, acc.y - ypr.y * dot) : zz;
         GPs[r * PB + threadIdx.x] = gpr;
         pgg += gpr.x * gpr.x + gpr.y * gpr.y;
-        if (sub == 0) {
+        if (sub == 0 && epi == 0) {                               // (EP > 1: the lane group that owns the row)
             EGPs[SLOT(r)] = ROK(r) ? dot : 0.0;
             if (ROK(r)) { pf += 0.5 * dot; eGp[ROW(r)] = dot; }
         }
@@ -731,9 +767,9 @@ __device__ __forceinline__ void tcg_persist_body(const Dev& d, unsigned long lon
     }
 }
 
-template <int LPR, int EW, int R, bool FUSE, bool TRACE = false, bool XR = false, bool EARLYP = false, bool XR2 = false>
+template <int LPR, int EW, int R, bool FUSE, bool TRACE = false, bool XR = false, bool EARLYP = false, bool XR2 = false, int EP = 1>
 __global__ __launch_bounds__(PB) void k_tcg_persist_obl(Dev d, unsigned long long* slots, int* err) {
-    tcg_persist_body<LPR, EW, R, FUSE, TRACE, XR, EARLYP, XR2>(d, slots, err, (int)blockIdx.x);
+    tcg_persist_body<LPR, EW, R, FUSE, TRACE, XR, EARLYP, XR2, EP>(d, slots, err, (int)blockIdx.x);
 }
 // In-process ranks: ONE launch carries the workgroups of all members (member q owns the blocks [q*G, (q+1)*G)), so that their
 // co-residency does not depend on how the runtime maps the members' streams onto hardware queues (two launches on one queue
@@ -776,9 +812,10 @@ __global__ __launch_bounds__(PB) void k_tcg_persist_xr4(XrDevs4 ds, unsigned lon
 #include "msdp_pipe.h"
 
 // ------------------------------------------------------------------ host side
-struct PersistPlan { int lpr, ew, r; size_t lds; };
+struct PersistPlan { int lpr, ew, r; size_t lds; int ep; };
+static int plan_rstep(const PersistPlan& pl) { return PWAVES * (64 / (pl.lpr * (pl.ep > 1 ? pl.ep : 1))); }   // rows per pass of a workgroup
 
-static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
+static bool persist_plan(const Dev& d, int G, PersistPlan& pl, bool allow_ep = true) {
     if (!d.rowptr) return false;
     int half = d.ld / 2, lpr = 1;
     while (lpr < half && lpr < 64) lpr <<= 1;
@@ -790,8 +827,21 @@ static bool persist_plan(const Dev& d, int G, PersistPlan& pl) {
     pl.lpr = lpr;
     pl.ew = (d.ellW < 1 || d.ellW > 8) ? 0 : (d.ellW <= 5 ? 5 : 8);      // 0: CSR rows of any length
     pl.r = lpr / 4;                                    // 128 row slots per workgroup
+    pl.ep = 1;
     const int rstep = PWAVES * (64 / lpr);
     const int need = (d.n_loc + G - 1) / G;
+    // CSR rows on a grid that leaves most lanes without a row (round 6): all 64 / lpr lane groups of a wave share ONE row and split its
+    // entries (EP instances: 8 rows per pass, R = 2 / 3 / 5 passes at 8 / 16 / 32 lanes per row) -- G1 (800 rows of ~48 entries) 12.5 us
+    // per trip on 16 workgroups -> one gather round trip on 104
+    if (pl.ew == 0 && allow_ep && d.persist_ep != 0) {
+        const int rr = lpr == 8 ? 2 : (lpr == 16 ? 3 : 5);
+        if (need <= rr * PWAVES) {
+            pl.r = rr; pl.ep = 64 / lpr;
+            const size_t rows = (size_t)pl.r * PWAVES;
+            pl.lds = (size_t)2 * pl.r * PB * sizeof(double2) + rows * sizeof(double);
+            return true;
+        }
+    }
     // p = 33..64: five row slots (80 rows per workgroup: n <= 20480 on 256 CUs) keep every vector in registers and take
     // the two-synchronisation trip; eight slots (LOWREG: mdelta / Hmdelta in LDS, three synchronisations) beyond that
     if (lpr == 32 && need <= 5 * rstep) pl.r = 5;
@@ -839,6 +889,12 @@ static persist_fn persist_kernel_pipe(const PersistPlan& pl, bool fuse = false) 
 }
 // early: 0 none, 1 the EARLY trip, 2 the one-reduction trip
 static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false, int early = 0) {
+    if (pl.ep > 1) {                                   // CSR rows, entry-parallel lanes (two-reduction trip)
+        if (pl.lpr == 8 && pl.r == 2) return fuse ? k_tcg_persist_obl<8, 0, 2, true, false, false, false, false, 8> : k_tcg_persist_obl<8, 0, 2, false, false, false, false, false, 8>;
+        if (pl.lpr == 16 && pl.r == 3) return fuse ? k_tcg_persist_obl<16, 0, 3, true, false, false, false, false, 4> : k_tcg_persist_obl<16, 0, 3, false, false, false, false, false, 4>;
+        if (pl.lpr == 32 && pl.r == 5) return fuse ? nullptr : k_tcg_persist_obl<32, 0, 5, false, false, false, false, false, 2>;
+        return nullptr;
+    }
     if (early == 2) { persist_fn f = persist_kernel_pipe(pl, fuse); if (f) return f; }
     if (early == 1) { persist_fn f = persist_kernel_early(pl, fuse); if (f) return f; }
 #define PK(L, E) if (pl.lpr == L && pl.ew == E && pl.r == L / 4) return k_tcg_persist_obl<L, E, L / 4, false>;
@@ -886,7 +942,7 @@ static int persist_mode(msdp_handle h) { return h->tune.persist_early ? 1 : (h->
 static bool persist_is_pipe(msdp_handle h, const PersistPlan& pl, bool fuse) { return !h->tune.persist_early && h->tune.persist_pipe && persist_kernel_pipe(pl, fuse) != nullptr; }
 static bool persist_is_early(msdp_handle h, const PersistPlan& pl, bool fuse) { return !persist_is_pipe(h, pl, fuse) && h->tune.persist_early && persist_kernel_early(pl, fuse) != nullptr; }
 static size_t early_lds(const PersistPlan& pl);
-static size_t pipe_lds(const PersistPlan& pl) { const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr); return (size_t)pl.ew * rows * sizeof(int) + (size_t)2 * pl.r * PB * sizeof(double2); }   // + ls, HQs
+static size_t pipe_lds(const PersistPlan& pl) { const size_t rows = (size_t)pl.r * plan_rstep(pl); return (size_t)pl.ew * rows * sizeof(int) + (size_t)2 * pl.r * PB * sizeof(double2); }   // + ls, HQs
 
 // The persistent kernel has its own grid: at most one workgroup per CU (co-residency), independent of the grid
 // of the row-parallel kernels around it (those exchange data through global memory only).
@@ -912,7 +968,7 @@ static int persist_grid(const Dev& d) {
         // (CSR rows, round 5: the row slots of a workgroup are walked one after the other, each a chain of gather batches as long as
         // its longest row, and an empty slot is skipped -- ONE slot per workgroup while the CUs last: G1, 800 rows of ~49 entries,
         // 8 workgroups x 2 slots 20.7 us per trip, 16 x 1 12.8; tools/archive/g1_trip_probe.py)
-        const int cap = (pl.ew == 0 ? 1 : pl.r) * PWAVES * (64 / pl.lpr);
+        const int cap = (pl.ew == 0 ? 1 : pl.r) * plan_rstep(pl);
         int gmin = (((d.n_loc + cap - 1) / cap + 7) / 8) * 8;
         if (gmin < 8) gmin = 8;
         if (gmin < g) g = gmin;
@@ -990,7 +1046,7 @@ int msdp_tr_tail_grid(msdp_handle h) { return persist_grid(h->d); }
 
 // LDS of the fused form: + the proposal point, its gradient (R x PB double2 each) and eG
 static size_t fused_lds(const PersistPlan& pl) {
-    const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr);
+    const size_t rows = (size_t)pl.r * plan_rstep(pl);
     return pl.lds + 16 + (size_t)2 * pl.r * PB * sizeof(double2) + rows * sizeof(double);
 }
 // EARLY instances keep eta in LDS, behind everything else (R x PB double2)
@@ -1014,7 +1070,7 @@ int msdp_persist_fused_ok(msdp_handle h) {
     if (!fn) return 0;
     {   // (the one-reduction form: + ls and HQs)
         const bool pipe = persist_is_pipe(h, pl, true), early = persist_is_early(h, pl, true);
-        const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr);
+        const size_t rows = (size_t)pl.r * plan_rstep(pl);
         pl.lds = fused_lds(pl) + (early ? early_lds(pl) : 0) + (pipe ? (size_t)pl.ew * rows * sizeof(int) + (size_t)2 * pl.r * PB * sizeof(double2) : 0);   // (+ ls, + HQs: the proposal's buffers are their own since round 6)
     }
     if (h->fused_sig_lpr == pl.lpr && h->fused_sig_ew == pl.ew && h->fused_sig_G == G && h->fused_sig_fn == (const void*)fn) return h->fused_sig_ok;
@@ -1037,7 +1093,7 @@ int msdp_launch_rtr_fused(msdp_handle h) {
                                 persist_is_pipe(h, pl, true) ? "one reduction per trip" : "two reductions per trip", G);
     {   // (the one-reduction form: + ls and HQs)
         const bool pipe = persist_is_pipe(h, pl, true), early = persist_is_early(h, pl, true);
-        const size_t rows = (size_t)pl.r * PWAVES * (64 / pl.lpr);
+        const size_t rows = (size_t)pl.r * plan_rstep(pl);
         pl.lds = fused_lds(pl) + (early ? early_lds(pl) : 0) + (pipe ? (size_t)pl.ew * rows * sizeof(int) + (size_t)2 * pl.r * PB * sizeof(double2) : 0);   // (+ ls, + HQs: the proposal's buffers are their own since round 6)
     }
     Dev dp = h->d;
@@ -1105,7 +1161,7 @@ static bool xr_plan(msdp_handle h, int nranks, PersistPlan& pl, int* G_out) {
         if (G > gcap) G = gcap;
     } else G = (256 / nranks) & ~7;
     if (G < 8) return false;
-    if (!persist_plan(dc, G, pl)) return false;
+    if (!persist_plan(dc, G, pl, false)) return false;
     if (pl.r > 5) return false;                            // LOWREG instances are not built for XR
     if (pl.ew == 8) pl.ew = 0;                             // rows of 6..8 entries: the CSR form
     if (!xr_instance(pl.lpr, pl.ew, pl.r)) return false;

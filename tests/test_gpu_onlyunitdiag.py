@@ -97,6 +97,35 @@ def test_rtr_matches_oracle_small(lib):
     h.close()
 
 
+@pytest.mark.parametrize("p", [4, 12, 20])
+def test_csr_rows_entry_parallel_lanes_match_the_row_per_lane_group_form(lib, p):
+    """G1 (800 rows of ~48 entries: CSR rows in the persistent tCG).  Round 6: the lane groups of a wave share a row and split its
+    entries (option persist_ep, default on where the rows leave lanes free).  Same step as with one lane group per row (persist_ep = 0),
+    and as the oracle (tCG.m:160-289 inside trustregions.m:441-767): counts and stop code equal, cost to 1e-11."""
+    from manisdp_matlab_amd import problems
+    from oracle import manisdp_ref as R, manopt_rtr
+    C = problems.maxcut_cost_matrix(golden_path("G1.txt.gz"))
+    n = C.shape[0]
+    Y, _ = _rand_point(n, p, seed=11)
+    prob = R._OnlyUnitDiagProblem(C, n, p, q1="correct")
+    _, f_ref, info = manopt_rtr.trustregions(prob, Y.copy(), 3, 20, 1e-8)
+    h = lib.Handle.onlyunitdiag(C, pcap=p)
+    got = []
+    for ep in (1, 0):
+        h.set_option("persist_ep", ep)
+        for fused in (1, 0):
+            h.set_option("fused_rtr", fused)
+            h.set_point(Y)
+            assert h.tcg_path() == 1
+            st = h.rtr(lib.default_opts(maxiter=3, maxinner=20, tolgradnorm=1e-8))
+            assert (st.iters, st.hessvecs, st.last_stop_inner) == (info.iters, info.hessvecs, info.stop_inner[-1]), (ep, fused)
+            assert abs(st.cost - f_ref) < 1e-11 * max(1.0, abs(f_ref)), (ep, fused)
+            got.append(h.get_point())
+    for Yg in got[1:]:
+        assert np.abs(Yg - got[0]).max() < 1e-9
+    h.close()
+
+
 def test_rtr_first_iteration_trace(lib):
     """With maxiter = 1 the solve is a single tCG: Hess-vec count and cost must agree with the
     oracle to rounding (no accumulated divergence yet)."""
