@@ -658,6 +658,27 @@ def main():
                           "options": {"p0": 40},
                           "note": "dinf is confirmed by a plain Lanczos run (no deflation, nothing reused from earlier calls) before the solve "
                                   "stops; that run is inside seconds_to_dinf_1e-8 and escape_seconds"}
+        # BASELINE config 0 beside it: Gset G1 (n = 800, rows of ~48 entries: CSR rows in the persistent tCG), the reference's default options
+        g1 = os.path.join(ROOT, "tests", "golden", "G1.txt.gz")
+        if os.path.exists(g1):
+            try:
+                C1 = problems.maxcut_cost_matrix(g1)
+                solvers.ManiSDP_onlyunitdiag(C1, {}, verbose=False)
+                t1 = time.perf_counter()
+                _, obj1, d1 = solvers.ManiSDP_onlyunitdiag(C1, {}, verbose=False)
+                sec1 = time.perf_counter() - t1
+                h1 = _lib.Handle.onlyunitdiag(C1, pcap=16)
+                r1 = np.random.default_rng(0)
+                Y1 = r1.standard_normal((C1.shape[0], 16)); Y1 /= np.linalg.norm(Y1, axis=1, keepdims=True)
+                h1.set_point(Y1)
+                trip1 = min(h1.bench_tcg_trip(256) for _ in range(3)) * 1e3
+                h1.close()
+                out["g1_config0"] = {"seconds_to_dinf_1e-8": sec1, "obj": obj1, "dinf": d1["dinf"], "status": d1["status"], "AL_iters": d1["iters"],
+                                     "hessvecs": d1["hessvecs"], "rtr_seconds": d1["rtr_seconds"], "eig_seconds_host": d1["eig_seconds"],
+                                     "tcg_trip_us_p16": trip1,
+                                     "note": "default options (p0 = 2); the saddle escape of this size is the reference's own eig(S) on the host (800 x 800)"}
+            except Exception as e:  # noqa: BLE001 -- secondary figure
+                out["g1_config0"] = {"error": "%s: %s" % (type(e).__name__, e)}
     h.close()
     _lib.release_cache()         # the parked escape workspace: the dense shapes below allocate up to 160 GB of their own
     if not args.no_dense and N == 1 and rank == 0 and not args.force_comm:
