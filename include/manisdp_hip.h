@@ -436,6 +436,14 @@ int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, const int64_
  *                       0 = stream the whole N x N matrices; same results, for A/B timing)
  *   "dense_pack"   1/0  dense C*U reads the MFMA-fragment-ordered copy of C (default 1; 0 = the row-major one;
  *                       bit-identical results, for A/B timing)
+ *   "persist_ep"   1/0  persistent tCG kernel on CSR rows (rows of more than 8 entries): the 64 / lanes-per-row lane groups of a
+ *                       wave share ONE row and split its entries where the grid leaves lanes free (G1: 12.5 -> 7.8 us per trip;
+ *                       default 1; 0 = one lane group per row).  Same row arithmetic; the row's products are summed in another order
+ *   "dense_sym", "dense_sym_min", "dense_sym_rt", "dense_sym_db", "dense_sym_len", "dense_sym_res"  symmetric dense contraction
+ *                       (msdp_densesym.hip): on from dense_sym_min rows (1, default) / always (2) / never (0); workgroup shape 1..4 =
+ *                       8 x 16, 8 x 32, 16 x 16, 12 x 32 rows (0 = by p and n); one or two barriers per step; slice length; workgroups
+ *                       assumed resident when the slices are cut (A/B timing and tests; results agree to rounding, every shape is
+ *                       bit-reproducible run to run)
  *   "timing", "esc_debug"  1/0  diagnostics on stderr                                (env MSDP_TIMING, MSDP_ESC_DEBUG)
  *   "debug_fail_persist"   1    test hook: the next persistent launch reports a synchronisation time-out
  * The environment variables are read once, when the handle is created.  Unknown names -> MSDP_EINVAL. */
