@@ -877,6 +877,12 @@ static persist_fn persist_kernel_early(const PersistPlan& pl, bool fuse) {
 }
 // One-reduction instances (round 5, msdp_pipe.h): rows of <= 5 entries, every vector in registers
 static persist_fn persist_kernel_pipe(const PersistPlan& pl, bool fuse = false) {
+    if (pl.ep > 1) {                                   // CSR rows, entry-parallel lanes (round 6)
+        if (pl.ew != 0) return nullptr;
+        if (pl.lpr == 8 && pl.r == 2) return fuse ? k_tcg_pipe_obl<8, 0, 2, false, true, 0, 8> : k_tcg_pipe_obl<8, 0, 2, false, false, 0, 8>;
+        if (pl.lpr == 16 && pl.r == 3) return fuse ? k_tcg_pipe_obl<16, 0, 3, false, true, 0, 4> : k_tcg_pipe_obl<16, 0, 3, false, false, 0, 4>;
+        return nullptr;
+    }
     // rows of 6..8 entries (3-D grids: six neighbours + the diagonal): every row through the buffer, per-iteration launches
     if (pl.ew == 8 && pl.lpr == 8 && pl.r == 2) return fuse ? k_tcg_pipe_obl<8, 8, 2, false, true> : k_tcg_pipe_obl<8, 8, 2>;
     if (pl.ew == 8 && pl.lpr == 16 && pl.r == 3) return fuse ? nullptr : k_tcg_pipe_obl<16, 8, 3>;   // (fused: 290 bytes of scratch)
@@ -889,6 +895,7 @@ static persist_fn persist_kernel_pipe(const PersistPlan& pl, bool fuse = false) 
 }
 // early: 0 none, 1 the EARLY trip, 2 the one-reduction trip
 static persist_fn persist_kernel(const PersistPlan& pl, bool fuse = false, int early = 0) {
+    if (pl.ep > 1 && early == 2) { persist_fn f = persist_kernel_pipe(pl, fuse); if (f) return f; }
     if (pl.ep > 1) {                                   // CSR rows, entry-parallel lanes (two-reduction trip)
         if (pl.lpr == 8 && pl.r == 2) return fuse ? k_tcg_persist_obl<8, 0, 2, true, false, false, false, false, 8> : k_tcg_persist_obl<8, 0, 2, false, false, false, false, false, 8>;
         if (pl.lpr == 16 && pl.r == 3) return fuse ? k_tcg_persist_obl<16, 0, 3, true, false, false, false, false, 4> : k_tcg_persist_obl<16, 0, 3, false, false, false, false, false, 4>;

@@ -405,17 +405,22 @@ __device__ __forceinline__ bool psync2_8(unsigned long long* blk, unsigned long 
 // stores it into the slots of the members that reference it (d.xr_paddr) -- here in four regions (H md alternating, the refresh rows),
 // and the first direction (the gradient, which every member keeps to itself) is published behind one barrier.  XRM = 2: the gathers are
 // system-scope loads (a halo slot may have been stored by another device), the pushed rows and member sums system-scope stores.
-template <int LPR, int EW, int R, bool TRACE, bool FUSE, int XRM = 0>
+// EW = 0, EP > 1 (round 6): CSR rows with entry-parallel lanes -- the 64 / LPR lane groups of a wave share ONE row (group epi = 0 owns it:
+// registers, sums, stores) and split its entries (msdp_persist.hip, option persist_ep); no ELL copy, no local columns, no gather requested
+// inside the reduction: a trip's products come from ONE batch of gathers per lane for rows of up to 8 x EP entries.
+template <int LPR, int EW, int R, bool TRACE, bool FUSE, int XRM = 0, int EP = 1>
 __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* slots, int* err, const int bx) {
     constexpr bool XR = XRM != 0, XTWO = XRM == 2;
+    constexpr bool CSR = EW == 0;
     static_assert(!XR || (!FUSE && !TRACE), "cross-rank instances: per-iteration launches");
-    static_assert(EW > 0 && R <= 5, "pipelined trip: ELL rows, every vector in registers");
+    static_assert(R <= 5, "pipelined trip: every vector in registers");
+    static_assert(CSR ? (EP == 64 / LPR && !XR && !TRACE) : EP == 1, "CSR rows: one row per wave, one rank");
     static_assert(PSYNC_NV == 8 && PSYNC_REP * PSYNC_NV == 64, "psync8 posts one slot per lane of wave 0");
     extern __shared__ double lds[];
     __shared__ double sh8[8 * PWAVES];
     __shared__ double shp[8 * PWAVES];
     __shared__ double shb8[16];
-    constexpr int RPW = 64 / LPR;
+    constexpr int RPW = 64 / (LPR * EP);
     constexpr int RSTEP = PWAVES * RPW;
     constexpr int ROWS = R * RSTEP;
     // (FUSE: Ys / Gs / eGs and YPs / GPs / EGPs are the CURRENT point and the PROPOSAL -- two sets of LDS buffers that change roles when a
@@ -468,8 +473,10 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     int lo, hi;
     msdp_chunk_rows(d.n_loc, d.G, lo, hi, 0, bx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane & (LPR - 1), rsub = lane / LPR;
-    const bool colok = 2 * sub < d.ld;
+    const int sub = lane & (LPR - 1), rsub = lane / (LPR * EP);
+    const int epi = (lane / LPR) & (EP - 1);                       // CSR: which of the row's lane groups (0 owns the row)
+    const bool colok_g = 2 * sub < d.ld;                           // the lane has columns (gathers)
+    const bool colok = colok_g && epi == 0;                        // ... and owns them (registers, sums, stores)
     int cur = c->cur;
     const bool bench = c->bench_mode != 0;
     double Delta = c->Delta;
@@ -496,7 +503,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     // (bits 16..23 = this reduction's own figure; the option psync8_backoff fills them where psync_backoff leaves them empty)
     const int backoff = (c->psync_backoff & 0xff00ffff) | ((((c->psync_backoff >> 16) & 0xff) ? ((c->psync_backoff >> 16) & 0xff) : (c->psync8_backoff & 0xff)) << 16);
     const double2 zz = make_double2(0.0, 0.0);
-    constexpr bool LOC = R * EW <= 15;                             // (four row slots: the source selection costs registers that spill)
+    constexpr bool LOC = !CSR && R * EW <= 15;                     // (four row slots: the source selection costs registers that spill)
     constexpr bool MULTI = LOC && !(FUSE && LPR >= 16);            // three instances of the trip loop (per-wave local columns), see below
     double2 eta[R], rr[R], md[R], hmd[R], cmd[R], ctr[R];
 #pragma unroll
@@ -512,12 +519,12 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     // (the ELL rows in a loop of their own, NOT unrolled: nothing in it is indexed by the row slot but LDS, and unrolled next to the
     // register set-up above its sort was where the kernel's first spills came from)
 #pragma unroll 1
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < (CSR ? 0 : R); ++r) {
         const bool rok = ROK(r);
         const int rc = rok ? ROW(r) : lo;
         const double egv = eGl[rc];
-        int cw[EW];
-        double vw[EW];
+        int cw[EW > 0 ? EW : 1];
+        double vw[EW > 0 ? EW : 1];
 #pragma unroll
         for (int w = 0; w < EW; ++w) {
             cw[w] = XR ? d.xr_ellc[(int64_t)w * d.ell_stride + rc] : d.ellc[(int64_t)w * d.ell_stride + rc];
@@ -525,7 +532,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         }
         // the entries of the row ordered own row, rows of this workgroup, other rows, empty slots: a column of the ELL block then
         // holds ONE kind for (nearly) all rows of a wave, and the wave picks the source per column, not per lane
-        int kw[EW];
+        int kw[EW > 0 ? EW : 1];
 #pragma unroll
         for (int w = 0; w < EW; ++w) {
             if (!rok) vw[w] = 0.0;
@@ -556,6 +563,11 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
                 ls[w * ROWS + SLOT(r)] = kw[w] == 2 ? -1 : (kw[w] == 3 ? (2 << 24) : ((kw[w] == 0 ? (1 << 24) : 0) | el));
             }
         }
+    }
+    if (CSR) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (sub == 0 && epi == 0) eGs[SLOT(r)] = ROK(r) ? eGl[ROW(r)] : 0.0;
     }
     __syncthreads();
     // nl = the leading columns whose rows ALL live in this workgroup for every row of this WAVE (own row, neighbour in the chunk, or an
@@ -614,6 +626,33 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(cur ? d.Gr[1] : d.Gr[0], 0, half_bytes, 0x00020000);
     unsigned g_base = 0u;
     const unsigned gld = (unsigned)d.ld, gcol = colok ? 2 * sub : 0;
+    // CSR rows: C[row, :] * X[:, my columns] with X read through rs at byte offset base -- lane group epi takes the entries s0 + epi,
+    // s0 + epi + EP, ..., eight of them in flight per lane; the groups' partial products are added, the owner keeps the sum
+    auto csr_gather = [&](int r, __amdgpu_buffer_rsrc_t rs, unsigned base) -> double2 {
+        constexpr int CB = 8;
+        double2 acc = make_double2(0.0, 0.0);
+        const bool rok = ROK(r);
+        const int s0 = (CSR && rok) ? d.rowptr[ROW(r)] : 0, s1 = (CSR && rok) ? d.rowptr[ROW(r) + 1] : 0;
+        const unsigned gcg = colok_g ? 2 * sub : 0;
+        for (int k0 = s0 + epi; __builtin_amdgcn_ballot_w64(k0 < s1) != 0ULL; k0 += CB * EP) {
+            double2 x[CB];
+            double cvk[CB];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int k = k0 + u * EP;
+                const bool in = k < s1;
+                const int cidx = in ? d.colind[k] : (rok ? ROW(r) : lo);
+                cvk[u] = in ? d.cval[k] : 0.0;
+                x[u] = ld2_sc1(rs, base + ((unsigned)cidx * gld + gcg) * 8u);
+            }
+#pragma unroll
+            for (int u = 0; u < CB; ++u) { acc.x = fma(cvk[u], x[u].x, acc.x); acc.y = fma(cvk[u], x[u].y, acc.y); }
+        }
+#pragma unroll
+        for (int m = LPR; m < LPR * EP; m <<= 1) { acc.x += __shfl_xor(acc.x, m); acc.y += __shfl_xor(acc.y, m); }
+        if (!colok) acc = make_double2(0.0, 0.0);
+        return acc;
+    };
 
     double z_r = gg, d_Pd = gg, e_Pd = 0.0, e_Pe = 0.0, model_value = 0.0, alpha = 0.0, beta = 0.0;
     double norm_r0 = sqrt(gg);
@@ -642,11 +681,11 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
 #ifndef MSDP_PIPE_VARIANT
 #define MSDP_PIPE_VARIANT 0
 #endif
-    constexpr bool PREF = R * NG <= ((FUSE && MSDP_PIPE_VARIANT == 0) ? 9 : 15);
+    constexpr bool PREF = !CSR && R * NG <= ((FUSE && MSDP_PIPE_VARIANT == 0) ? 9 : 15);
     // SPLIT: the four sums without H md under the gather, the other four behind the row stores (A/B builds: variant 1 = the gather
     // prefetched in the fused launch too, round 5's order; variant 2 = prefetched AND split)
     constexpr bool SPLIT = (MSDP_PIPE_VARIANT == 2 && FUSE) ? true : !PREF;
-    double2 X[R][NG];                                              // the gathered rows (in flight across the end of a trip)
+    double2 X[R][NG > 0 ? NG : 1];                                 // the gathered rows (in flight across the end of a trip)
     for (;;) {
         PTSTAMP(0);
         // ---- the products: C md of this trip (cmd) and C tangent(r) (ctr)
@@ -670,8 +709,9 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
                 (acc).x = fma(vv, xx.x, (acc).x); (acc).y = fma(vv, xx.y, (acc).y); } } while (0)
         // all EW columns through the buffer (the gradient / the refresh vectors are not in LDS): passes of NG columns
 #define PIPE_GATHER_ALL(rs, base, dst) do { \
+            if (CSR) { _Pragma("unroll 1") for (int r = 0; r < R; ++r) (dst)[r] = csr_gather(r, (rs), (base)); break; } \
             _Pragma("unroll") for (int r = 0; r < R; ++r) (dst)[r] = zz; \
-            _Pragma("unroll") for (int w0 = 0; w0 < EW; w0 += NG) { \
+            _Pragma("unroll") for (int w0 = 0; w0 < EW; w0 += (NG > 0 ? NG : 1)) { \
                 PIPE_ISSUE(rs, base, w0); \
                 _Pragma("unroll") for (int r = 0; r < R; ++r) PIPE_FOLDX(r, (dst)[r], w0); } \
             if (!colok) { _Pragma("unroll") for (int r = 0; r < R; ++r) (dst)[r] = zz; } } while (0)
@@ -708,13 +748,13 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
                 PIPE_GATHER_ALL(rs_md, 2u * half_bytes, cmd);
             }
             // the neighbours' rows of last trip's Hmd: requested inside that trip's reduction already (have_x), except behind a refresh
-            if (!have_x) PIPE_ISSUE(rs_md, (xq ^ 1u) * half_bytes, NL);
+            if (!CSR && !have_x) PIPE_ISSUE(rs_md, (xq ^ 1u) * half_bytes, NL);
             pre_sums();
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 double2 a = zz;
-                PIPE_FOLDL(r, a, HQs + (xq ^ 1u) * R * PB);
-                PIPE_FOLDX(r, a, NL);
+                if (CSR) a = csr_gather(r, rs_md, (xq ^ 1u) * half_bytes);
+                else { PIPE_FOLDL(r, a, HQs + (xq ^ 1u) * R * PB); PIPE_FOLDX(r, a, NL); }
                 if (!colok) a = zz;
                 ctr[r].x = fma(-alpha, a.x, ctr[r].x); ctr[r].y = fma(-alpha, a.y, ctr[r].y);      // C tangent(r') = C tangent(r) - alpha C Hmd
                 cmd[r].x = fma(beta, cmd[r].x, ctr[r].x); cmd[r].y = fma(beta, cmd[r].y, ctr[r].y);  // C md' = C tangent(r') + beta C md
@@ -949,14 +989,17 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         const double2 gpr = OK(r) ? make_double2(acc.x - ypr.x * dot, acc.y - ypr.y * dot) : zz;
         GPs[r * PB + threadIdx.x] = gpr;
         tv[1] += gpr.x * gpr.x + gpr.y * gpr.y;
-        if (sub == 0) {
+        if (sub == 0 && epi == 0) {
             EGPs[SLOT(r)] = ROK(r) ? dot : 0.0;
             if (ROK(r)) tv[0] += 0.5 * dot;
         }
         if (OK(r)) st2_sc1(rs_md, gx_base + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, gpr);
     };
-    if (R * EW <= 16) {                                            // all gathers in flight (wider rows: a row slot at a time, registers)
-        double2 XG[R][EW];
+    if (CSR) {
+#pragma unroll 1
+        for (int r = 0; r < R; ++r) prop_finish(r, csr_gather(r, rs_md, yx_base));
+    } else if (R * EW <= 16) {                                     // all gathers in flight (wider rows: a row slot at a time, registers)
+        double2 XG[R][EW > 0 ? EW : 1];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -971,7 +1014,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     } else {
 #pragma unroll 1
         for (int r = 0; r < R; ++r) {
-            double2 xw[EW];
+            double2 xw[EW > 0 ? EW : 1];
 #pragma unroll
             for (int w = 0; w < EW; ++w) xw[w] = ld2_sc1(rs_md, yx_base + ((unsigned)cs[w * ROWS + SLOT(r)] * gld + gcol) * 8u);
             double2 acc = zz;
@@ -1053,7 +1096,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
 #undef OK
 }
 
-template <int LPR, int EW, int R, bool TRACE = false, bool FUSE = false, int XRM = 0>
+template <int LPR, int EW, int R, bool TRACE = false, bool FUSE = false, int XRM = 0, int EP = 1>
 __global__ __launch_bounds__(PB) void k_tcg_pipe_obl(Dev d, unsigned long long* slots, int* err) {
-    tcg_pipe_body<LPR, EW, R, TRACE, FUSE, XRM>(d, slots, err, (int)blockIdx.x);
+    tcg_pipe_body<LPR, EW, R, TRACE, FUSE, XRM, EP>(d, slots, err, (int)blockIdx.x);
 }

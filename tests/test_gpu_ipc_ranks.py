@@ -17,6 +17,24 @@ _counter = [0]
 
 
 def _run_ranks(N, rows, cols, p, tmp_path, devices=None, two_level=False):
+    """Runs the group; more than four processes on ONE device get a second try when a member's launch met a synchronisation time-out.
+    Eight processes own eight sets of hardware queues on one GPU and the scheduler time-slices them when they are oversubscribed: a
+    member's launch can stay unmapped for seconds while the others spin for it (seen once in six to nine runs of the 8-process case,
+    never with up to four processes) -- a property of the stand-in, not of the N-GPU form, where every member owns its device."""
+    tries = 2 if (N > 4 and devices is None) else 1
+    for attempt in range(tries):
+        sub = tmp_path / ("try%d" % attempt)
+        sub.mkdir()
+        try:
+            return _run_ranks_once(N, rows, cols, p, sub, devices, two_level)
+        except AssertionError as e:
+            if attempt + 1 < tries and "a grid synchronisation timed out" in str(e):
+                print("8 processes on one device: a member's launch was not scheduled in time -- one more try")
+                continue
+            raise
+
+
+def _run_ranks_once(N, rows, cols, p, tmp_path, devices=None, two_level=False):
     _counter[0] += 1
     name = "/msdp_test_%d_%d" % (os.getpid(), _counter[0])
     procs, outs = [], []
