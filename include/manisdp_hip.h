@@ -405,7 +405,7 @@ int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, const int64_
  *                       sentinel until a row is stored, so the rows are their own flags (k - 1 = units of 64 cycles a wave sleeps
  *                       between posting the reduction and its first gather); 0 = at the top of the next trip, behind that
  *                       reduction (the round-4 trip).  Same arithmetic, same decisions; measured slower (default 0)
- *   "persist_pipe" 1/0  persistent tCG kernel (rows of <= 8 entries, p <= 32): ONE grid reduction per trip instead of two -- the
+ *   "persist_pipe" 1/0  persistent tCG kernel (rows of <= 8 entries, or CSR rows with "persist_ep"; p <= 32): ONE grid reduction per trip instead of two -- the
  *                       values of tCG.m:227-241 (model value, <r', r'>) follow from eight inner products formed BEFORE the step length
  *                       is known, the neighbours gather the rows of H*mdelta, and C*tangent(r), C*mdelta follow by linearity.
  *                       Same tests and decisions as tCG.m; <r', r'> and the model value that decide a trip carry a rounding error of
@@ -437,8 +437,9 @@ int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, const int64_
  *   "dense_pack"   1/0  dense C*U reads the MFMA-fragment-ordered copy of C (default 1; 0 = the row-major one;
  *                       bit-identical results, for A/B timing)
  *   "persist_ep"   1/0  persistent tCG kernel on CSR rows (rows of more than 8 entries): the 64 / lanes-per-row lane groups of a
- *                       wave share ONE row and split its entries where the grid leaves lanes free (G1: 12.5 -> 7.8 us per trip;
- *                       default 1; 0 = one lane group per row).  Same row arithmetic; the row's products are summed in another order
+ *                       wave share ONE row and split its entries where the grid leaves lanes free -- in that form the one-reduction trip
+ *                       ("persist_pipe") takes CSR rows too (G1: 12.5 -> 5.5 us per trip at p <= 16; default 1; 0 = one lane group per
+ *                       row, two reductions per trip).  Same row arithmetic; the row's products are summed in another order
  *   "dense_sym", "dense_sym_min", "dense_sym_rt", "dense_sym_db", "dense_sym_len", "dense_sym_res"  symmetric dense contraction
  *                       (msdp_densesym.hip): on from dense_sym_min rows (1, default) / always (2) / never (0); workgroup shape 1..4 =
  *                       8 x 16, 8 x 32, 16 x 16, 12 x 32 rows (0 = by p and n); one or two barriers per step; slice length; workgroups
@@ -455,7 +456,7 @@ int msdp_set_option(msdp_handle h, const char* name, int32_t value);
  * per trip.  Both follow tCG.m:95-292; the choice is a speed matter only. */
 int msdp_tcg_path(msdp_handle h, int32_t* path);
 /* (test / diagnostic) The trip form of the persistent kernel at the resident point: 2 = ONE grid reduction per trip (option
- * "persist_pipe", rows of <= 8 entries, p <= 32, every vector in registers), 1 = the "persist_early" form, 0 = two reductions per
+ * "persist_pipe", rows of <= 8 entries or shared CSR rows, p <= 32, every vector in registers), 1 = the "persist_early" form, 0 = two reductions per
  * trip (tCG.m:166 and :227-241 separately); -1 = the tCG is not persistent.  All forms follow tCG.m:95-292. */
 int msdp_debug_persist_form(msdp_handle h, int32_t* form);
 

@@ -880,7 +880,7 @@ static persist_fn persist_kernel_pipe(const PersistPlan& pl, bool fuse = false) 
     if (pl.ep > 1) {                                   // CSR rows, entry-parallel lanes (round 6)
         if (pl.ew != 0) return nullptr;
         if (pl.lpr == 8 && pl.r == 2) return fuse ? k_tcg_pipe_obl<8, 0, 2, false, true, 0, 8> : k_tcg_pipe_obl<8, 0, 2, false, false, 0, 8>;
-        if (pl.lpr == 16 && pl.r == 3) return fuse ? k_tcg_pipe_obl<16, 0, 3, false, true, 0, 4> : k_tcg_pipe_obl<16, 0, 3, false, false, 0, 4>;
+        if (pl.lpr == 16 && pl.r == 3) return fuse ? nullptr : k_tcg_pipe_obl<16, 0, 3, false, false, 0, 4>;   // (fused: 148 bytes of scratch -- the two-reduction instance runs fused)
         return nullptr;
     }
     // rows of 6..8 entries (3-D grids: six neighbours + the diagonal): every row through the buffer, per-iteration launches

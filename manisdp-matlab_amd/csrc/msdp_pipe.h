@@ -27,6 +27,7 @@
 // direct, then the step of the recurrences as on every trip.  (pipe_refresh >= 2, enforced by msdp_set_option / fill_ctl: with 1 every trip
 // would both gather regions 2 / 3 at its top and store into them before its reduction -- no reduction between one workgroup's store and a
 // slower one's gather; with >= 2 the reduction of the trip in between separates them.)
+// Round 6: CSR rows (EW = 0) run this trip too, in the entry-parallel form of msdp_persist.hip (EP lane groups per row: see tcg_pipe_body).
 // Per-row arithmetic of eta, r, md and Hmd: the statements of the two-reduction kernel (same reference lines).  What differs from
 // tCG.m in floating point: C md is assembled (as in the two-reduction kernel), and <r', r'> / the model value that decide the
 // stopping and model tests of a trip are the expanded forms above (relative error eps <r, r> / <r', r'>); the values that enter
@@ -627,14 +628,44 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
     unsigned g_base = 0u;
     const unsigned gld = (unsigned)d.ld, gcol = colok ? 2 * sub : 0;
     // CSR rows: C[row, :] * X[:, my columns] with X read through rs at byte offset base -- lane group epi takes the entries s0 + epi,
-    // s0 + epi + EP, ..., eight of them in flight per lane; the groups' partial products are added, the owner keeps the sum
+    // s0 + epi + EP, ..., eight of them in flight per lane; the groups' partial products are added, the owner keeps the sum.
+    // The lane's first eight (column, value) pairs of every row slot are static: they stay in registers for the whole launch where there
+    // are two row slots (eight lanes per row: 48 registers) -- a trip's gathers then wait for nothing but the rows themselves.
+    constexpr int CSR_CB = 8;
+    constexpr bool CSR_KEEP = CSR && R <= 2 && !FUSE;              // (the fused launch has no registers left for them: 244 bytes of scratch; kept
+                                                                   //  in LDS instead, one element per thread: 172 bytes, and G1's RTR time does not move)
+    int ckeep[CSR_KEEP ? R : 1][CSR_CB];
+    double vkeep[CSR_KEEP ? R : 1][CSR_CB];
+    if (CSR_KEEP) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool rok = ROK(r);
+            const int s0 = rok ? d.rowptr[ROW(r)] : 0, s1 = rok ? d.rowptr[ROW(r) + 1] : 0;
+#pragma unroll
+            for (int u = 0; u < CSR_CB; ++u) {
+                const int k = s0 + epi + u * EP;
+                const bool in = k < s1;
+                ckeep[r][u] = in ? d.colind[k] : (rok ? ROW(r) : lo);
+                vkeep[r][u] = in ? d.cval[k] : 0.0;
+            }
+        }
+    }
     auto csr_gather = [&](int r, __amdgpu_buffer_rsrc_t rs, unsigned base) -> double2 {
-        constexpr int CB = 8;
+        constexpr int CB = CSR_CB;
         double2 acc = make_double2(0.0, 0.0);
         const bool rok = ROK(r);
         const int s0 = (CSR && rok) ? d.rowptr[ROW(r)] : 0, s1 = (CSR && rok) ? d.rowptr[ROW(r) + 1] : 0;
         const unsigned gcg = colok_g ? 2 * sub : 0;
-        for (int k0 = s0 + epi; __builtin_amdgcn_ballot_w64(k0 < s1) != 0ULL; k0 += CB * EP) {
+        int kfirst = s0 + epi;
+        if (CSR_KEEP) {
+            double2 x[CB];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) x[u] = ld2_sc1(rs, base + ((unsigned)ckeep[CSR_KEEP ? r : 0][u] * gld + gcg) * 8u);
+#pragma unroll
+            for (int u = 0; u < CB; ++u) { const double cv = vkeep[CSR_KEEP ? r : 0][u]; acc.x = fma(cv, x[u].x, acc.x); acc.y = fma(cv, x[u].y, acc.y); }
+            kfirst += CB * EP;
+        }
+        for (int k0 = kfirst; __builtin_amdgcn_ballot_w64(k0 < s1) != 0ULL; k0 += CB * EP) {
             double2 x[CB];
             double cvk[CB];
 #pragma unroll
@@ -709,7 +740,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
                 (acc).x = fma(vv, xx.x, (acc).x); (acc).y = fma(vv, xx.y, (acc).y); } } while (0)
         // all EW columns through the buffer (the gradient / the refresh vectors are not in LDS): passes of NG columns
 #define PIPE_GATHER_ALL(rs, base, dst) do { \
-            if (CSR) { _Pragma("unroll 1") for (int r = 0; r < R; ++r) (dst)[r] = csr_gather(r, (rs), (base)); break; } \
+            if (CSR) { _Pragma("unroll") for (int r = 0; r < R; ++r) (dst)[r] = csr_gather(r, (rs), (base)); break; } \
             _Pragma("unroll") for (int r = 0; r < R; ++r) (dst)[r] = zz; \
             _Pragma("unroll") for (int w0 = 0; w0 < EW; w0 += (NG > 0 ? NG : 1)) { \
                 PIPE_ISSUE(rs, base, w0); \
@@ -996,7 +1027,7 @@ __device__ __forceinline__ void tcg_pipe_body(const Dev& d, unsigned long long* 
         if (OK(r)) st2_sc1(rs_md, gx_base + ((unsigned)ROW(r) * gld + 2 * sub) * 8u, gpr);
     };
     if (CSR) {
-#pragma unroll 1
+#pragma unroll
         for (int r = 0; r < R; ++r) prop_finish(r, csr_gather(r, rs_md, yx_base));
     } else if (R * EW <= 16) {                                     // all gathers in flight (wider rows: a row slot at a time, registers)
         double2 XG[R][EW > 0 ? EW : 1];

@@ -100,8 +100,9 @@ def test_rtr_matches_oracle_small(lib):
 @pytest.mark.parametrize("p", [4, 12, 20])
 def test_csr_rows_entry_parallel_lanes_match_the_row_per_lane_group_form(lib, p):
     """G1 (800 rows of ~48 entries: CSR rows in the persistent tCG).  Round 6: the lane groups of a wave share a row and split its
-    entries (option persist_ep, default on where the rows leave lanes free).  Same step as with one lane group per row (persist_ep = 0),
-    and as the oracle (tCG.m:160-289 inside trustregions.m:441-767): counts and stop code equal, cost to 1e-11."""
+    entries (option persist_ep, default on where the rows leave lanes free) -- in the two-reduction trip and, new, in the one-reduction
+    trip (persist_form() == 2 on G1).  Same step as with one lane group per row (persist_ep = 0), and as the oracle (tCG.m:160-289 inside
+    trustregions.m:441-767): counts and stop code equal, cost to 1e-11."""
     from manisdp_matlab_amd import problems
     from oracle import manisdp_ref as R, manopt_rtr
     C = problems.maxcut_cost_matrix(golden_path("G1.txt.gz"))
@@ -113,14 +114,17 @@ def test_csr_rows_entry_parallel_lanes_match_the_row_per_lane_group_form(lib, p)
     got = []
     for ep in (1, 0):
         h.set_option("persist_ep", ep)
-        for fused in (1, 0):
-            h.set_option("fused_rtr", fused)
-            h.set_point(Y)
-            assert h.tcg_path() == 1
-            st = h.rtr(lib.default_opts(maxiter=3, maxinner=20, tolgradnorm=1e-8))
-            assert (st.iters, st.hessvecs, st.last_stop_inner) == (info.iters, info.hessvecs, info.stop_inner[-1]), (ep, fused)
-            assert abs(st.cost - f_ref) < 1e-11 * max(1.0, abs(f_ref)), (ep, fused)
-            got.append(h.get_point())
+        for pipe in (1, 0):                                          # one / two grid reductions per trip (msdp_pipe.h needs the shared rows)
+            h.set_option("persist_pipe", pipe)
+            for fused in (1, 0):
+                h.set_option("fused_rtr", fused)
+                h.set_point(Y)
+                assert h.tcg_path() == 1
+                assert h.persist_form() == (2 if ep and pipe else 0), (ep, pipe)
+                st = h.rtr(lib.default_opts(maxiter=3, maxinner=20, tolgradnorm=1e-8))
+                assert (st.iters, st.hessvecs, st.last_stop_inner) == (info.iters, info.hessvecs, info.stop_inner[-1]), (ep, pipe, fused)
+                assert abs(st.cost - f_ref) < 1e-11 * max(1.0, abs(f_ref)), (ep, pipe, fused)
+                got.append(h.get_point())
     for Yg in got[1:]:
         assert np.abs(Yg - got[0]).max() < 1e-9
     h.close()
@@ -205,9 +209,9 @@ def test_persistent_tcg_matches_oracle(lib, shape, p, k):
     h.set_point(Y)
     assert h.tcg_path() == 1, "persistent kernel not selected"
     prob = R._OnlyUnitDiagProblem(C, n, p, q1="correct")
-    # both trip forms of the kernel (round 5): ONE grid reduction per trip (msdp_pipe.h: rows of <= 5 entries, p <= 32; the default
-    # there) and the two-reduction trip (everything else, and persist_pipe = 0)
-    one_reduction = p <= 32 and 2 * k + 1 <= 8               # (rows of <= 5 entries, and of 6..8 in the stored width 8; nine entries: CSR rows)
+    # both trip forms of the kernel (round 5): ONE grid reduction per trip (msdp_pipe.h: p <= 32; the default there) and the
+    # two-reduction trip (p > 32, and persist_pipe = 0)
+    one_reduction = p <= 32                                  # (rows of <= 5 entries, of 6..8 in the stored width 8, and -- round 6 -- CSR rows with entry-parallel lanes: nine entries at n = 700)
     refs = {}
     # ... each as per-iteration launches (tCG kernel + TR tail kernel) and, at p <= 32, with the whole trustregions() loop in one launch
     for pipe, fused in ((1, 1), (1, 0), (0, 1)):
