@@ -207,7 +207,9 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
     o = dict(options or {})
     for k, v in DEFAULTS["onlyunitdiag"].items():
         o.setdefault(k, v)
-    dense_max = int(o.get("dense_eig_max", 3000))
+    dense_max = int(o.get("dense_eig_max", 3000))          # the host eig(S) is allowed up to this order (options['eig'] = 'host') ...
+    dense_default = int(o.get("dense_eig_default", 600))   # ... and the default up to this one (round 6: G1, n = 800, 0.124 s with it, 0.047 s
+                                                           # with the device escape + its independent check; the affine kinds switch at 400 / 600)
     dense_X_max = int(o.get("dense_X_max", 4000))
     rng = rng or np.random.default_rng(0)
 
@@ -220,13 +222,13 @@ def _onlyunitdiag_impl(C, options=None, verbose=True, rng=None):
     if isinstance(C, SyntheticDenseC):
         # BASELINE config 5: every rank generates its rows of the dense C on the device; the matrix never exists on the host
         # (only the host eigen-solver of small test problems asks for it)
-        eig_mode = o.get("eig", "host" if (n <= dense_max and comm is None) else "device")
+        eig_mode = o.get("eig", "host" if (n <= dense_default and comm is None) else "device")
         Csp = C.toarray() if eig_mode == "host" else None
         nr, rk = (1, 0) if comm is None else ((int(comm[1]), int(comm[2])) if comm[0] == "local" else (int(comm[0]), int(comm[1])))
         h = _lib.Handle.dense_synthetic(n, C.seed, nranks=nr, rank=rk, pcap=pcap)
     else:
         Csp = C.tocsr() if sp.issparse(C) else np.asarray(C, dtype=np.float64)
-        eig_mode = o.get("eig", "host" if n <= dense_max else "device")
+        eig_mode = o.get("eig", "host" if n <= dense_default else "device")
         h = _lib.Handle.onlyunitdiag(Csp, pcap=pcap)
     # options['comm'] = (nranks, rank, unique_id): rows of the factor and of C sharded over the ranks (msdp_comm_init); this
     # host loop then runs replicated -- same start point (pass Y0 or seed rng identically), same data, same decisions on
