@@ -419,7 +419,7 @@ int msdp_block_eigs(msdp_handle h, int32_t nb, const int64_t* row0, const int64_
  *   "trip2"        0/1/2  chunked path, sparse C / oblique manifold / one rank: two launches per tCG trip (12 vector passes,
  *                       msdp_trip2.hip) instead of three (17 passes): 1 = where it pays, from 2^21 vector entries on (default);
  *                       2 = always (tests); 0 = never
- *   "escape_method" 0 = block eigen-solver where it applies (sparse C, n >= 2048), Lanczos otherwise (default); 1 = Lanczos
+ *   "escape_method" 0 = block eigen-solver where it applies (sparse C, n >= 512), Lanczos otherwise (default); 1 = Lanczos
  *                       always; 2 = block also for small n (tests)
  *   "be_width" 0/32/64/128, "be_degree", "be_grid", "be_lpr"  block eigen-solver: panel width, filter degree per round,
  *                       workgroups and lanes per row of the filter step (0 = automatic; measurement and tests)

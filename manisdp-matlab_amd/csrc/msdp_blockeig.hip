@@ -623,7 +623,7 @@ int msdp_blockeig_eligible(msdp_handle h, const double* Mdev, bool w_loc) {
     }
     if (h->d.p + 16 > 128 && h->tune.escape_method != 2) return 0;           // same, 128-wide panels
     if (h->lgroup) return 0;                                              // in-process ranks share one GPU and one set of tests: Lanczos path
-    if (h->d.n < 2048 && h->tune.escape_method != 2) return 0;           // small problems: a Lanczos run is a few hundred steps
+    if (h->d.n < 512 && h->tune.escape_method != 2) return 0;            // small problems: a Lanczos run is a few hundred steps (round 6: 2048 -> 512; G1, n = 800: escape 34 -> 19 ms per solve)
     if (h->d.n < 256) return 0;
     return 1;
 }
